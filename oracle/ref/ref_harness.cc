@@ -1,0 +1,360 @@
+/*
+ * ref_harness.cc -- TEST INFRASTRUCTURE ONLY.
+ *
+ * extern "C" entry points over the UNMODIFIED reference liblte_phy.cc, which the Makefile
+ * in this directory compiles in place from /root/reference (never copied into this repo).
+ * Output goes to oracle/_ref/libref_oracle.so.  Used by tests/ (parity checker), by
+ * tools/gen_golden.py (fixture generation) and by bench.py's cpu_baseline leg
+ * (kind "reference").  The product library (openlte_amd/csrc) never links or loads this.
+ *
+ * The reference keeps every helper at external linkage (no `static` in liblte_phy.cc), so
+ * the internals can be declared here and called directly.
+ */
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+
+#include "liblte_phy.h"
+
+// ---- internals of liblte_phy.cc (declared locally there at liblte_phy.cc:770-2197) ----
+void turbo_encode(LIBLTE_PHY_STRUCT *phy_struct, uint8 *c_bits, uint32 N_c_bits, uint32 N_fill_bits,
+                  uint8 *d_bits, uint32 *N_d_bits);
+void turbo_decode(LIBLTE_PHY_STRUCT *phy_struct, float *d_bits, uint32 N_d_bits, uint32 N_fill_bits,
+                  uint8 *c_bits, uint32 *N_c_bits);
+void viterbi_decode_siso(LIBLTE_PHY_STRUCT *phy_struct, int8 *d_bits, uint32 N_d_bits,
+                         uint32 constraint_len, uint32 rate, uint32 *g, int8 *c_bits, uint32 *N_c_bits);
+void conv_encode_soft(LIBLTE_PHY_STRUCT *phy_struct, int8 *c_bits, uint32 N_c_bits, uint32 constraint_len,
+                      uint32 rate, uint32 *g, bool tail_bit, int8 *d_bits, uint32 *N_d_bits);
+void modulation_demapper(float *d_re, float *d_im, uint32 M_symb, LIBLTE_PHY_MODULATION_TYPE_ENUM type,
+                         int8 *bits, uint32 *N_bits);
+void modulation_mapper(uint8 *bits, uint32 N_bits, LIBLTE_PHY_MODULATION_TYPE_ENUM type, float *d_re,
+                       float *d_im, uint32 *M_symb);
+void generate_prs_c(uint32 c_init, uint32 len, uint32 *c);
+void generate_crs(uint32 N_s, uint32 L, uint32 N_id_cell, uint32 N_sc_rb_dl, float *crs_re, float *crs_im);
+void calc_crc(uint8 *a_bits, uint32 N_a_bits, uint32 crc, uint8 *p_bits, uint32 N_p_bits);
+LIBLTE_ERROR_ENUM dlsch_channel_decode(LIBLTE_PHY_STRUCT *phy_struct, float *in_bits, uint32 N_in_bits,
+                                       uint32 tbs, uint32 tx_mode, uint32 rv_idx, uint32 M_dl_harq,
+                                       uint32 N_soft, uint8 *out_bits, uint32 *N_out_bits);
+void dlsch_channel_encode(LIBLTE_PHY_STRUCT *phy_struct, uint8 *in_bits, uint32 N_in_bits, uint32 tbs,
+                          uint32 tx_mode, uint32 rv_idx, uint32 G, uint32 N_l, uint32 Q_m, uint32 M_dl_harq,
+                          uint32 N_soft, uint8 *out_bits, uint32 *N_out_bits);
+void samples_to_symbols_dl(LIBLTE_PHY_STRUCT *phy_struct, float *samps_re, float *samps_im,
+                           uint32 slot_start_idx, uint32 symbol_offset, uint8 scale, float *symb_re,
+                           float *symb_im);
+void pre_decoder_and_matched_filter_dl(float *y_re, float *y_im, float *h_re, float *h_im, uint32 h_len,
+                                       uint32 M_ap_symb, uint8 N_ant, LIBLTE_PHY_PRE_CODER_TYPE_ENUM type,
+                                       float *x_re, float *x_im, uint32 *M_layer_symb);
+
+extern "C" {
+
+// Plain-C view of LIBLTE_PHY_ALLOCATION_STRUCT (liblte_phy.h:684-702) for ctypes callers.
+typedef struct {
+    uint32_t mod_type;       // LIBLTE_PHY_MODULATION_TYPE_ENUM
+    uint32_t tbs;
+    uint32_t rv_idx;
+    uint32_t N_prb;
+    uint32_t tx_mode;
+    uint32_t rnti;
+    uint32_t pre_coder_type; // LIBLTE_PHY_PRE_CODER_TYPE_ENUM
+    uint32_t N_codewords;
+    uint32_t prb[110];       // same PRB list used for both slots
+} ref_alloc_t;
+
+static void fill_alloc(LIBLTE_PHY_ALLOCATION_STRUCT *a, const ref_alloc_t *r, const uint8_t *msg_bits)
+{
+    memset(a, 0, sizeof(*a));
+    a->pre_coder_type = (LIBLTE_PHY_PRE_CODER_TYPE_ENUM)r->pre_coder_type;
+    a->mod_type       = (LIBLTE_PHY_MODULATION_TYPE_ENUM)r->mod_type;
+    a->chan_type      = LIBLTE_PHY_CHAN_TYPE_DLSCH;
+    a->tbs            = r->tbs;
+    a->rv_idx         = r->rv_idx;
+    a->N_prb          = r->N_prb;
+    for (uint32_t i = 0; i < r->N_prb && i < 110; i++) {
+        a->prb[0][i] = r->prb[i];
+        a->prb[1][i] = r->prb[i];
+    }
+    a->N_codewords = r->N_codewords;
+    a->N_layers    = 1;
+    a->tx_mode     = r->tx_mode;
+    a->rnti        = (uint16)r->rnti;
+    if (msg_bits) {
+        a->msg[0].N_bits = r->tbs;
+        memcpy(a->msg[0].msg, msg_bits, r->tbs);
+    }
+}
+
+size_t ref_sizeof_phy_struct(void) { return sizeof(LIBLTE_PHY_STRUCT); }
+size_t ref_sizeof_subframe_struct(void) { return sizeof(LIBLTE_PHY_SUBFRAME_STRUCT); }
+
+void *ref_phy_new(int fs_enum, int N_id_cell, int N_ant, int N_rb_dl)
+{
+    LIBLTE_PHY_STRUCT *phy = NULL;
+    if (LIBLTE_SUCCESS != liblte_phy_init(&phy, (LIBLTE_PHY_FS_ENUM)fs_enum, (uint16)N_id_cell, (uint8)N_ant,
+                                          (uint32)N_rb_dl, LIBLTE_PHY_N_SC_RB_DL_NORMAL_CP, 1.0f))
+        return NULL;
+    return phy;
+}
+void ref_phy_free(void *phy) { liblte_phy_cleanup((LIBLTE_PHY_STRUCT *)phy); }
+
+// The reference's de-interleaver leaves "holes" for the 20 uint32-overflow K: the
+// holes keep whatever the previous decode left in the scratch.  Zero the scratch so that the
+// reference's output is a function of its input only.
+void ref_zero_turbo_scratch(void *vphy)
+{
+    LIBLTE_PHY_STRUCT *p = (LIBLTE_PHY_STRUCT *)vphy;
+    memset(p->td_vitdec_in, 0, sizeof(p->td_vitdec_in));
+    memset(p->td_in_int, 0, sizeof(p->td_in_int));
+    memset(p->td_in_calc_1, 0, sizeof(p->td_in_calc_1));
+    memset(p->td_in_calc_2, 0, sizeof(p->td_in_calc_2));
+    memset(p->td_in_calc_3, 0, sizeof(p->td_in_calc_3));
+    memset(p->td_in_int_1, 0, sizeof(p->td_in_int_1));
+    memset(p->td_int_calc_1, 0, sizeof(p->td_int_calc_1));
+    memset(p->td_int_calc_2, 0, sizeof(p->td_int_calc_2));
+    memset(p->td_in_act_1, 0, sizeof(p->td_in_act_1));
+    memset(p->td_fb_1, 0, sizeof(p->td_fb_1));
+    memset(p->td_int_act_1, 0, sizeof(p->td_int_act_1));
+    memset(p->td_int_act_2, 0, sizeof(p->td_int_act_2));
+    memset(p->td_fb_int_1, 0, sizeof(p->td_fb_int_1));
+    memset(p->td_fb_int_2, 0, sizeof(p->td_fb_int_2));
+}
+
+// turbo_encode: K info bits (one per byte) -> PLANAR d (d0[D] d1[D] d2[D]), D = K+4.
+uint32_t ref_turbo_encode(void *phy, uint8_t *c_bits, uint32_t K, uint8_t *d_planar)
+{
+    uint32 N_d = 0;
+    turbo_encode((LIBLTE_PHY_STRUCT *)phy, c_bits, K, 0, d_planar, &N_d);
+    return N_d;
+}
+
+// turbo_decode: INTERLEAVED d[i*3+x] floats (modified in place by the reference's Step 0).
+void ref_turbo_decode(void *phy, float *d_interleaved, uint32_t N_d_bits, uint8_t *c_bits)
+{
+    uint32 N_c = 0;
+    ref_zero_turbo_scratch(phy);
+    turbo_decode((LIBLTE_PHY_STRUCT *)phy, d_interleaved, N_d_bits, 0, c_bits, &N_c);
+}
+
+// Batch form used for CPU-baseline timing: n_cb blocks back to back, returns seconds.
+double ref_turbo_decode_batch(void *phy, float *d_interleaved, uint32_t N_d_bits, uint32_t n_cb,
+                              uint8_t *c_bits, uint32_t K)
+{
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (uint32_t b = 0; b < n_cb; b++) {
+        uint32 N_c = 0;
+        ref_zero_turbo_scratch(phy);
+        turbo_decode((LIBLTE_PHY_STRUCT *)phy, d_interleaved + (size_t)b * N_d_bits, N_d_bits, 0,
+                     c_bits + (size_t)b * K, &N_c);
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+uint32_t ref_viterbi_siso(void *phy, int8_t *in, uint32_t N_in, int8_t *out)
+{
+    uint32 g[2] = {015, 013};
+    uint32 N    = 0;
+    viterbi_decode_siso((LIBLTE_PHY_STRUCT *)phy, (int8 *)in, N_in, 4, 2, g, (int8 *)out, &N);
+    return N;
+}
+
+uint32_t ref_conv_encode_soft_g03(void *phy, int8_t *in, uint32_t N_in, int8_t *out)
+{
+    uint32 g = 03;
+    uint32 N = 0;
+    conv_encode_soft((LIBLTE_PHY_STRUCT *)phy, (int8 *)in, N_in, 3, 1, &g, false, (int8 *)out, &N);
+    return N;
+}
+
+void ref_rate_match_turbo(void *phy, uint8_t *d_planar, uint32_t N_d_bits, uint32_t N_codeblocks,
+                          uint32_t tx_mode, uint32_t N_soft, uint32_t M_dl_harq, uint32_t chan_type,
+                          uint32_t rv_idx, uint32_t N_e_bits, uint8_t *e_bits)
+{
+    liblte_phy_rate_match_turbo((LIBLTE_PHY_STRUCT *)phy, d_planar, N_d_bits, N_codeblocks, tx_mode, N_soft,
+                                M_dl_harq, (LIBLTE_PHY_CHAN_TYPE_ENUM)chan_type, rv_idx, N_e_bits, e_bits);
+}
+
+// dummy block as dlsch_channel_decode builds it (liblte_phy.cc:12809-12821): turbo_encode(zeros).
+uint32_t ref_rate_unmatch_turbo(void *vphy, float *e_bits, uint32_t N_e_bits, uint32_t K,
+                                uint32_t N_codeblocks, uint32_t tx_mode, uint32_t N_soft, uint32_t M_dl_harq,
+                                uint32_t chan_type, uint32_t rv_idx, float *d_bits)
+{
+    LIBLTE_PHY_STRUCT *phy = (LIBLTE_PHY_STRUCT *)vphy;
+    uint32             N_d = 0;
+    uint8             *zeros = (uint8 *)calloc(K + 16, 1);
+    turbo_encode(phy, zeros, K, 0, phy->dlsch_tx_d_bits, &N_d);
+    free(zeros);
+    liblte_phy_rate_unmatch_turbo(phy, e_bits, N_e_bits, phy->dlsch_tx_d_bits, N_d / 3, N_codeblocks, tx_mode,
+                                  N_soft, M_dl_harq, (LIBLTE_PHY_CHAN_TYPE_ENUM)chan_type, rv_idx, d_bits,
+                                  &N_d);
+    return N_d;
+}
+
+uint32_t ref_modulation_demapper(float *d_re, float *d_im, uint32_t M_symb, uint32_t mod_type, int8_t *bits)
+{
+    uint32 N = 0;
+    modulation_demapper(d_re, d_im, M_symb, (LIBLTE_PHY_MODULATION_TYPE_ENUM)mod_type, (int8 *)bits, &N);
+    return N;
+}
+
+uint32_t ref_modulation_mapper(uint8_t *bits, uint32_t N_bits, uint32_t mod_type, float *d_re, float *d_im)
+{
+    uint32 M = 0;
+    modulation_mapper(bits, N_bits, (LIBLTE_PHY_MODULATION_TYPE_ENUM)mod_type, d_re, d_im, &M);
+    return M;
+}
+
+void ref_generate_prs_c(uint32_t c_init, uint32_t len, uint32_t *c) { generate_prs_c(c_init, len, c); }
+
+void ref_generate_crs(uint32_t N_s, uint32_t L, uint32_t N_id_cell, float *crs_re, float *crs_im)
+{
+    generate_crs(N_s, L, N_id_cell, LIBLTE_PHY_N_SC_RB_DL_NORMAL_CP, crs_re, crs_im);
+}
+
+void ref_calc_crc24a(uint8_t *a_bits, uint32_t N, uint8_t *p_bits) { calc_crc(a_bits, N, 0x01864CFB, p_bits, 24); }
+
+void ref_pre_decoder_dl(float *y_re, float *y_im, float *h_re, float *h_im, uint32_t h_len, uint32_t M_ap_symb,
+                        uint32_t N_ant, float *x_re, float *x_im, uint32_t *M_layer_symb)
+{
+    uint32 M = 0;
+    pre_decoder_and_matched_filter_dl(y_re, y_im, h_re, h_im, h_len, M_ap_symb, (uint8)N_ant,
+                                      LIBLTE_PHY_PRE_CODER_TYPE_TX_DIVERSITY, x_re, x_im, &M);
+    *M_layer_symb = M;
+}
+
+int ref_dlsch_channel_decode(void *phy, float *in_bits, uint32_t N_in_bits, uint32_t tbs, uint32_t tx_mode,
+                             uint32_t rv_idx, uint32_t M_dl_harq, uint32_t N_soft, uint8_t *out_bits,
+                             uint32_t *N_out_bits)
+{
+    uint32 N = 0;
+    ref_zero_turbo_scratch(phy);
+    int err = (int)dlsch_channel_decode((LIBLTE_PHY_STRUCT *)phy, in_bits, N_in_bits, tbs, tx_mode, rv_idx,
+                                        M_dl_harq, N_soft, out_bits, &N);
+    *N_out_bits = N;
+    return err;
+}
+
+// DL-SCH encode exactly as liblte_phy_pdsch_channel_encode calls it (liblte_phy.cc:3572-3584).
+uint32_t ref_dlsch_channel_encode(void *phy, uint8_t *in_bits, uint32_t tbs, uint32_t tx_mode, uint32_t rv_idx,
+                                  uint32_t G, uint32_t Q_m, uint8_t *out_bits)
+{
+    uint32 N = 0;
+    dlsch_channel_encode((LIBLTE_PHY_STRUCT *)phy, in_bits, tbs, tbs, tx_mode, rv_idx, G, 2, Q_m, 8, 250368,
+                         out_bits, &N);
+    return N;
+}
+
+// ---------------------------------------------------------------- subframe objects
+void *ref_subframe_new(void) { return calloc(1, sizeof(LIBLTE_PHY_SUBFRAME_STRUCT)); }
+void  ref_subframe_free(void *sf) { free(sf); }
+void  ref_subframe_clear_tx(void *vsf, uint32_t num)
+{
+    LIBLTE_PHY_SUBFRAME_STRUCT *sf = (LIBLTE_PHY_SUBFRAME_STRUCT *)vsf;
+    memset(sf->tx_symb_re, 0, sizeof(sf->tx_symb_re));
+    memset(sf->tx_symb_im, 0, sizeof(sf->tx_symb_im));
+    sf->num = num;
+}
+// which: 0 rx_symb_re, 1 rx_symb_im, 2 rx_ce_re, 3 rx_ce_im, 4 tx_symb_re, 5 tx_symb_im
+float *ref_subframe_ptr(void *vsf, int which)
+{
+    LIBLTE_PHY_SUBFRAME_STRUCT *sf = (LIBLTE_PHY_SUBFRAME_STRUCT *)vsf;
+    switch (which) {
+    case 0: return &sf->rx_symb_re[0][0];
+    case 1: return &sf->rx_symb_im[0][0];
+    case 2: return &sf->rx_ce_re[0][0][0];
+    case 3: return &sf->rx_ce_im[0][0][0];
+    case 4: return &sf->tx_symb_re[0][0][0];
+    case 5: return &sf->tx_symb_im[0][0][0];
+    }
+    return NULL;
+}
+void     ref_subframe_set_num(void *vsf, uint32_t num) { ((LIBLTE_PHY_SUBFRAME_STRUCT *)vsf)->num = num; }
+uint32_t ref_subframe_get_num(void *vsf) { return ((LIBLTE_PHY_SUBFRAME_STRUCT *)vsf)->num; }
+
+int ref_map_crs(void *phy, void *sf, uint32_t N_id_cell, uint32_t N_ant)
+{
+    return (int)liblte_phy_map_crs((LIBLTE_PHY_STRUCT *)phy, (LIBLTE_PHY_SUBFRAME_STRUCT *)sf, N_id_cell,
+                                   (uint8)N_ant);
+}
+
+// Encode n_alloc PDSCH allocations into sf->tx_symb (the reference caps a PDCCH struct at 6
+// allocations, liblte_phy.h:879, so larger sets are encoded in chunks on the same subframe).
+int ref_pdsch_channel_encode(void *phy, void *sf, const ref_alloc_t *allocs, uint32_t n_alloc,
+                             const uint8_t *msg_bits, uint32_t msg_stride, uint32_t N_pdcch_symbs,
+                             uint32_t N_id_cell, uint32_t N_ant)
+{
+    LIBLTE_PHY_PDCCH_STRUCT *pdcch = (LIBLTE_PHY_PDCCH_STRUCT *)calloc(1, sizeof(LIBLTE_PHY_PDCCH_STRUCT));
+    int                      err   = 0;
+    for (uint32_t base = 0; base < n_alloc && err == 0; base += LIBLTE_PHY_PDCCH_MAX_ALLOC) {
+        uint32_t n = n_alloc - base;
+        if (n > LIBLTE_PHY_PDCCH_MAX_ALLOC) n = LIBLTE_PHY_PDCCH_MAX_ALLOC;
+        pdcch->N_symbs = N_pdcch_symbs;
+        pdcch->N_alloc = n;
+        for (uint32_t a = 0; a < n; a++)
+            fill_alloc(&pdcch->alloc[a], &allocs[base + a], msg_bits + (size_t)(base + a) * msg_stride);
+        err = (int)liblte_phy_pdsch_channel_encode((LIBLTE_PHY_STRUCT *)phy, pdcch, N_id_cell, (uint8)N_ant,
+                                                   (LIBLTE_PHY_SUBFRAME_STRUCT *)sf);
+    }
+    free(pdcch);
+    return err;
+}
+
+int ref_create_dl_subframe(void *phy, void *sf, uint32_t ant, float *i_samps, float *q_samps)
+{
+    return (int)liblte_phy_create_dl_subframe((LIBLTE_PHY_STRUCT *)phy, (LIBLTE_PHY_SUBFRAME_STRUCT *)sf,
+                                              (uint8)ant, i_samps, q_samps);
+}
+
+int ref_get_dl_subframe_and_ce(void *phy, float *i_samps, float *q_samps, uint32_t frame_start_idx,
+                               uint32_t subfr_num, uint32_t N_id_cell, uint32_t N_ant, void *sf)
+{
+    return (int)liblte_phy_get_dl_subframe_and_ce((LIBLTE_PHY_STRUCT *)phy, i_samps, q_samps, frame_start_idx,
+                                                  (uint8)subfr_num, N_id_cell, (uint8)N_ant,
+                                                  (LIBLTE_PHY_SUBFRAME_STRUCT *)sf);
+}
+
+int ref_pdsch_channel_decode(void *phy, void *sf, const ref_alloc_t *alloc, uint32_t N_pdcch_symbs,
+                             uint32_t N_id_cell, uint32_t N_ant, uint8_t *out_bits, uint32_t *N_out_bits)
+{
+    LIBLTE_PHY_ALLOCATION_STRUCT *a = (LIBLTE_PHY_ALLOCATION_STRUCT *)calloc(1, sizeof(*a));
+    uint32                        N = 0;
+    fill_alloc(a, alloc, NULL);
+    ref_zero_turbo_scratch(phy);
+    int err = (int)liblte_phy_pdsch_channel_decode((LIBLTE_PHY_STRUCT *)phy, (LIBLTE_PHY_SUBFRAME_STRUCT *)sf, a,
+                                                   N_pdcch_symbs, N_id_cell, (uint8)N_ant, out_bits, &N);
+    *N_out_bits = N;
+    free(a);
+    return err;
+}
+
+// Intermediate PDSCH products the reference leaves in its scratch (for stage-by-stage parity).
+int8_t *ref_pdsch_soft_bits_ptr(void *phy) { return (int8_t *)((LIBLTE_PHY_STRUCT *)phy)->pdsch_soft_bits; }
+float  *ref_pdsch_descramb_bits_ptr(void *phy) { return ((LIBLTE_PHY_STRUCT *)phy)->pdsch_descramb_bits; }
+float  *ref_pdsch_d_re_ptr(void *phy) { return ((LIBLTE_PHY_STRUCT *)phy)->pdsch_d_re; }
+float  *ref_pdsch_d_im_ptr(void *phy) { return ((LIBLTE_PHY_STRUCT *)phy)->pdsch_d_im; }
+float  *ref_dlsch_rx_d_bits_ptr(void *phy) { return ((LIBLTE_PHY_STRUCT *)phy)->dlsch_rx_d_bits; }
+uint8_t *ref_dlsch_c_bits_ptr(void *phy) { return &((LIBLTE_PHY_STRUCT *)phy)->dlsch_c_bits[0][0]; }
+
+void ref_samples_to_symbols_dl(void *phy, float *re, float *im, uint32_t slot_start_idx, uint32_t symbol_offset,
+                               float *symb_re, float *symb_im)
+{
+    samples_to_symbols_dl((LIBLTE_PHY_STRUCT *)phy, re, im, slot_start_idx, symbol_offset, 0, symb_re, symb_im);
+}
+
+// CPU-baseline timing helpers ------------------------------------------------------------
+double ref_time_get_dl_subframe_and_ce(void *phy, float *i_samps, float *q_samps, uint32_t frame_start_idx,
+                                       uint32_t subfr_num, uint32_t N_id_cell, uint32_t N_ant, void *sf,
+                                       uint32_t reps)
+{
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (uint32_t r = 0; r < reps; r++)
+        liblte_phy_get_dl_subframe_and_ce((LIBLTE_PHY_STRUCT *)phy, i_samps, q_samps, frame_start_idx,
+                                          (uint8)subfr_num, N_id_cell, (uint8)N_ant,
+                                          (LIBLTE_PHY_SUBFRAME_STRUCT *)sf);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+} // extern "C"

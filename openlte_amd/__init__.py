@@ -1,0 +1,12 @@
+"""openlte_amd -- MI355X-native LTE downlink receive chain behind the liblte_phy hot-path API.
+
+The product is ``libmi_lte.so`` (hand-written HIP for gfx950 + a C-ABI, ``include/mi_lte.h``);
+this package is only its ctypes binding plus small host-side helpers.  There is no CPU fallback:
+importing works anywhere (so the C-ABI can be inspected), but creating a ``Context`` without the
+built library or without a gfx950 GPU raises.
+"""
+from .lib import (Context, DeviceBuffer, MiLteError, build_library, library_path, load_library,
+                  SOFT_F32, SOFT_I8, SOFT_I16, TURBO_REF, TURBO_BCJR)
+
+__all__ = ["Context", "DeviceBuffer", "MiLteError", "build_library", "library_path", "load_library",
+           "SOFT_F32", "SOFT_I8", "SOFT_I16", "TURBO_REF", "TURBO_BCJR"]

@@ -1,0 +1,176 @@
+// Context, memory and timing entry points of libmi_lte.so (see include/mi_lte.h).
+#include "ctx.hpp"
+
+#include <cstring>
+
+#include "lte_tables.h"
+
+extern "C" {
+
+int mi_lte_version(void) { return MI_LTE_VERSION; }
+
+int mi_lte_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mi_lte_ctx_create(int device, mi_lte_ctx **out)
+{
+    if (!out) return MI_LTE_ERR_INVALID_ARG;
+    *out  = nullptr;
+    int n = mi_lte_device_count();
+    if (n <= 0 || device < 0 || device >= n) {
+        fprintf(stderr, "mi_lte: no usable HIP device %d (found %d); this library has no CPU fallback\n", device, n);
+        return MI_LTE_ERR_NO_DEVICE;
+    }
+    mi_lte_ctx *ctx = new mi_lte_ctx();
+    ctx->device     = device;
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        delete ctx;
+        return MI_LTE_ERR_HIP;
+    }
+    ctx->dev_name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fprintf(stderr, "mi_lte: device %d is %s, but the kernels are built for gfx950 only\n", device, prop.gcnArchName);
+        delete ctx;
+        return MI_LTE_ERR_NO_DEVICE;
+    }
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
+        hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx;
+        return MI_LTE_ERR_HIP;
+    }
+    *out = ctx;
+    return MI_LTE_OK;
+}
+
+void mi_lte_ctx_destroy(mi_lte_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (void *p : ctx->owned) (void)hipFree(p);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *mi_lte_last_error(const mi_lte_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+const char *mi_lte_device_name(const mi_lte_ctx *ctx) { return ctx ? ctx->dev_name.c_str() : ""; }
+void       *mi_lte_stream(const mi_lte_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+const char *mi_lte_last_kernels(const mi_lte_ctx *ctx) { return ctx ? ctx->last_kernels.c_str() : ""; }
+
+int mi_lte_malloc(mi_lte_ctx *ctx, size_t bytes, void **d_ptr)
+{
+    if (!ctx || !d_ptr) return MI_LTE_ERR_INVALID_ARG;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    MI_HIP_CHECK(ctx, hipMalloc(d_ptr, bytes ? bytes : 1));
+    return MI_LTE_OK;
+}
+int mi_lte_free(mi_lte_ctx *ctx, void *d_ptr)
+{
+    if (!ctx) return MI_LTE_ERR_INVALID_ARG;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    MI_HIP_CHECK(ctx, hipFree(d_ptr));
+    return MI_LTE_OK;
+}
+int mi_lte_memset(mi_lte_ctx *ctx, void *d_ptr, int value, size_t bytes)
+{
+    if (!ctx) return MI_LTE_ERR_INVALID_ARG;
+    MI_HIP_CHECK(ctx, hipMemsetAsync(d_ptr, value, bytes, ctx->stream));
+    return MI_LTE_OK;
+}
+int mi_lte_memcpy_h2d(mi_lte_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
+{
+    if (!ctx) return MI_LTE_ERR_INVALID_ARG;
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return MI_LTE_OK;
+}
+int mi_lte_memcpy_d2h(mi_lte_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
+{
+    if (!ctx) return MI_LTE_ERR_INVALID_ARG;
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return MI_LTE_OK;
+}
+int mi_lte_sync(mi_lte_ctx *ctx)
+{
+    if (!ctx) return MI_LTE_ERR_INVALID_ARG;
+    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return MI_LTE_OK;
+}
+int mi_lte_timer_start(mi_lte_ctx *ctx)
+{
+    if (!ctx) return MI_LTE_ERR_INVALID_ARG;
+    MI_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return MI_LTE_OK;
+}
+int mi_lte_timer_stop(mi_lte_ctx *ctx, float *elapsed_ms)
+{
+    if (!ctx || !elapsed_ms) return MI_LTE_ERR_INVALID_ARG;
+    MI_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    MI_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
+    MI_HIP_CHECK(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    return MI_LTE_OK;
+}
+
+} // extern "C"
+
+int mi_ctx_reserve_scratch(mi_lte_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->scratch_bytes) return MI_LTE_OK;
+    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->scratch) MI_HIP_CHECK(ctx, hipFree(ctx->scratch));
+    ctx->scratch       = nullptr;
+    ctx->scratch_bytes = 0;
+    MI_HIP_CHECK(ctx, hipMalloc(&ctx->scratch, bytes));
+    ctx->scratch_bytes = bytes;
+    return MI_LTE_OK;
+}
+
+// QPP interleaver tables.  spec == 0 reproduces the reference's uint32 arithmetic
+// (liblte_phy.cc:10954-10958: idx = (f1*i + f2*i*i) % K, which wraps for 20 block sizes and is then
+// not a permutation); spec != 0 is the exact 3GPP TS 36.212 5.1.3.2.3 index.
+int mi_ctx_turbo_tables(mi_lte_ctx *ctx, uint32_t K, int spec, TurboTables *out)
+{
+    const uint64_t key = (uint64_t)K | ((uint64_t)(spec ? 1 : 0) << 32);
+    auto           it  = ctx->turbo_tables.find(key);
+    if (it != ctx->turbo_tables.end()) {
+        *out = it->second;
+        return MI_LTE_OK;
+    }
+    uint32_t f1 = 0, f2 = 0;
+    bool     found = false;
+    for (int r = 0; r < LTE_QPP_N_SIZES; r++)
+        if (LTE_QPP_ROWS[r].K == K) { f1 = LTE_QPP_ROWS[r].f1; f2 = LTE_QPP_ROWS[r].f2; found = true; }
+    if (!found) {
+        ctx->err = "K is not an LTE turbo block size";
+        return MI_LTE_ERR_INVALID_ARG;
+    }
+    std::vector<uint16_t> pi(K), inv(K, 0xFFFF);
+    for (uint32_t i = 0; i < K; i++) {
+        uint32_t idx;
+        if (spec) idx = (uint32_t)(((uint64_t)f1 * i + (uint64_t)f2 * i * i) % K);
+        else      idx = (f1 * i + f2 * i * i) % K; // wraps in uint32 exactly like the reference
+        pi[i]    = (uint16_t)idx;
+        inv[idx] = (uint16_t)i; // ascending i: the last (largest) writer wins, as in the reference's loop
+    }
+    TurboTables t;
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&t.d_pi, sizeof(uint16_t) * K));
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&t.d_inv, sizeof(uint16_t) * K));
+    ctx->owned.push_back(t.d_pi);
+    ctx->owned.push_back(t.d_inv);
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(t.d_pi, pi.data(), sizeof(uint16_t) * K, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(t.d_inv, inv.data(), sizeof(uint16_t) * K, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->turbo_tables[key] = t;
+    *out                   = t;
+    return MI_LTE_OK;
+}

@@ -1,0 +1,42 @@
+// Internal context of libmi_lte.so: one GPU, one stream, grow-only scratch, per-K table cache.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mi_lte.h"
+
+struct TurboTables {       // device-resident per-K tables
+    uint16_t *d_pi  = nullptr; // interleaver index pi[i]
+    uint16_t *d_inv = nullptr; // inv[j] = largest i with pi[i] == j, 0xFFFF if none ("hole")
+};
+
+struct mi_lte_ctx {
+    int                device = -1;
+    hipStream_t        stream = nullptr;
+    hipEvent_t         ev0 = nullptr, ev1 = nullptr;
+    std::string        err;
+    std::string        dev_name;
+    std::string        last_kernels;
+    void              *scratch       = nullptr;
+    size_t             scratch_bytes = 0;
+    std::map<uint64_t, TurboTables> turbo_tables; // key = K | (spec << 32)
+    std::vector<void *> owned;                    // allocations released at destroy
+};
+
+#define MI_HIP_CHECK(ctx, call)                                                                      \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                          \
+            return MI_LTE_ERR_HIP;                                                                   \
+        }                                                                                            \
+    } while (0)
+
+int   mi_ctx_reserve_scratch(mi_lte_ctx *ctx, size_t bytes);
+int   mi_ctx_turbo_tables(mi_lte_ctx *ctx, uint32_t K, int spec, TurboTables *out);

@@ -1,0 +1,463 @@
+// Turbo decoding on gfx950 (MI355X) -- hand-written HIP, no MFMA (nothing here is a dense contraction).
+//
+// REF mode restates the reference's turbo_decode() Steps 0-14 (liblte/src/liblte_phy.cc:10620-10845)
+// bit-exactly.  The algorithm is a strictly serial 8-state trellis walk per code block (the survivor
+// is chosen on a hard metric while a weighted metric is accumulated, so there is no associative
+// form to scan), therefore the parallel axes are: code blocks, and the elementwise / gather steps.
+//
+// Mapping ("lock-step tiles"):
+//   * 64 code blocks of equal K form a TILE; one wavefront walks the 64 trellises in lock-step,
+//     lane = code block, the 8 path metrics of a block live in that lane's VGPRs (no cross-lane
+//     traffic, every data-dependent branch of the reference becomes a select).
+//   * all per-step arrays of a tile are stored "line per block": element (lane, step t) sits at
+//     byte (t/64)*4096 + lane*64 + (t%64), so a lane streams its own 64-byte cache line per 64
+//     trellis steps (4 x global_load_dwordx4) and a wave-wide access is one contiguous 4 KiB burst.
+//   * traceback needs, per step, which of each predecessor pair had the larger stored metric:
+//     4 bits per step per block, packed 8 steps to a dword, streamed to HBM (3 KiB/pass at K=6144).
+//   * the steps that are parallel over the trellis index (quantise, interleave, soft re-encode,
+//     vote) run as one workgroup per code block with the block staged in LDS.
+//
+// Kernel sequence per batch:  prep -> siso(pass 1) -> perm -> siso(pass 2 | pass 3) -> vote
+#include "ctx.hpp"
+
+namespace {
+
+constexpr uint32_t RX_NULL_AS_INT = 10000; // RX_NULL_BIT, liblte_phy.cc:1620
+
+__host__ __device__ inline uint32_t kpad64(uint32_t K) { return (K + 63u) & ~63u; }
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+
+__device__ __forceinline__ int sbyte(uint32_t w, int k) { return (int)__builtin_amdgcn_sbfe(w, 8 * k, 8); }
+
+// sign * ((|a|+|b|) >> 1), sign negative iff exactly one operand is negative (0 counts as positive).
+// This one form covers the four branches of Step 3 (liblte_phy.cc:10688-10707) and the g=03 soft
+// re-encoder conv_encode_soft (liblte_phy.cc:10123-10147).
+__device__ __forceinline__ int soft_xor(int a, int b)
+{
+    int mag = (abs(a) + abs(b)) >> 1;
+    return ((a < 0) != (b < 0)) ? -mag : mag;
+}
+
+// fb[i] of Steps 2/8/9: fb[0] = 127, fb[i] = soft_xor(x[i-2], x[i-3]) with x[<0] = +127
+// (liblte_phy.cc:10676-10685 calling conv_encode_soft :10070-10151 with g = 03, register preset to 127).
+__device__ __forceinline__ int fb_at(const int8_t *x, int i)
+{
+    if (i == 0) return 127;
+    int a = (i >= 2) ? (int)x[i - 2] : 127;
+    int b = (i >= 3) ? (int)x[i - 3] : 127;
+    return soft_xor(a, b);
+}
+
+template <typename T> __device__ __forceinline__ float soft_to_float(T v) { return (float)v; }
+
+__device__ __forceinline__ float block_max_f(float v, float *red /* >= 4 floats */)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = red[0];
+    for (uint32_t w = 1; w < (blockDim.x >> 6); w++) r = fmaxf(r, red[w]);
+    return r;
+}
+__device__ __forceinline__ int block_max_i(int v, int *red)
+{
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int r = red[0];
+    for (uint32_t w = 1; w < (blockDim.x >> 6); w++) r = max(r, red[w]);
+    return r;
+}
+
+// copy n_arr LDS arrays of Kp bytes each into their tile arrays (16 B per thread per step)
+__device__ __forceinline__ void store_tile_lines(uint8_t *const *dst, const int8_t *lds, uint32_t n_arr, uint32_t Kp,
+                                                 size_t tile_off, uint32_t lane)
+{
+    const uint32_t units = Kp >> 4;
+    for (uint32_t idx = threadIdx.x; idx < n_arr * units; idx += blockDim.x) {
+        uint32_t a = idx / units, u = idx - a * units;
+        uint4    v = *reinterpret_cast<const uint4 *>(lds + (size_t)a * Kp + (size_t)u * 16);
+        *reinterpret_cast<uint4 *>(dst[a] + tile_off + (size_t)(u >> 2) * 4096 + lane * 64 + (u & 3) * 16) = v;
+    }
+}
+// load one tile array line-set of this block (lane) into LDS
+__device__ __forceinline__ void load_tile_lines(int8_t *lds, const uint8_t *src, uint32_t Kp, size_t tile_off, uint32_t lane)
+{
+    const uint32_t units = Kp >> 4;
+    for (uint32_t u = threadIdx.x; u < units; u += blockDim.x)
+        *reinterpret_cast<uint4 *>(lds + (size_t)u * 16) =
+            *reinterpret_cast<const uint4 *>(src + tile_off + (size_t)(u >> 2) * 4096 + lane * 64 + (u & 3) * 16);
+}
+
+struct PrepOut { uint8_t *arr[6]; }; // X0 X1 X2 I0 M1 M2
+
+// ------------------------------------------------------------------------------------------------
+// prep: Step 0 (NULL -> 0), Step 1 scaling to int8, Step 4 (interleave d0), SISO output magnitudes
+// for passes 1 and 2.  One workgroup per code block.
+//   q(x) = (int8)(x*127/max|x|)            liblte_phy.cc:10645-10664 (max over the K triples only)
+//   M[t] = (int8)(127*(w_t/W)), w_t = |in[2t]|+|in[2t+1]|, W = max_t w_t   liblte_phy.cc:10449,10498-10524
+//   (the branch weight is the same for every state, so the reference's path-dependent max_weight
+//    reduces to max_t w_t; the sign is applied by the traceback)
+template <typename T>
+__global__ __launch_bounds__(256) void k_turbo_prep(const T *__restrict__ soft, uint32_t K, uint32_t n_cb,
+                                                    const uint16_t *__restrict__ pi, PrepOut out)
+{
+    extern __shared__ __attribute__((aligned(16))) int8_t sm[];
+    __shared__ float red_f[4];
+    __shared__ int   red_i[4];
+    const uint32_t cb = blockIdx.x, tile = cb >> 6, lane = cb & 63, Kp = kpad64(K);
+    const size_t   tile_off = (size_t)tile * Kp * 64;
+    const T       *d = soft + (size_t)cb * 3 * (K + 4);
+    int8_t *q0 = sm, *q1 = q0 + Kp, *q2 = q1 + Kp, *i0 = q2 + Kp, *m1 = i0 + Kp, *m2 = m1 + Kp;
+
+    float mx = 0.0f;
+    for (uint32_t i = threadIdx.x; i < K; i += blockDim.x) {
+        for (int x = 0; x < 3; x++) {
+            float v = soft_to_float(d[i * 3 + x]);
+            if (v == (float)RX_NULL_AS_INT) v = 0.0f;
+            mx = fmaxf(mx, fabsf(v));
+        }
+    }
+    mx = block_max_f(mx, red_f);
+
+    for (uint32_t i = threadIdx.x; i < Kp; i += blockDim.x) {
+        int a = 0, b = 0, c = 0;
+        if (i < K) {
+            float v0 = soft_to_float(d[i * 3 + 0]), v1 = soft_to_float(d[i * 3 + 1]), v2 = soft_to_float(d[i * 3 + 2]);
+            if (v0 == (float)RX_NULL_AS_INT) v0 = 0.0f;
+            if (v1 == (float)RX_NULL_AS_INT) v1 = 0.0f;
+            if (v2 == (float)RX_NULL_AS_INT) v2 = 0.0f;
+            a = (int)(v0 * 127.0f / mx);
+            b = (int)(v1 * 127.0f / mx);
+            c = (int)(v2 * 127.0f / mx);
+        }
+        q0[i] = (int8_t)a;
+        q1[i] = (int8_t)b;
+        q2[i] = (int8_t)c;
+    }
+    __syncthreads();
+
+    int w1max = 0, w2max = 0;
+    for (uint32_t i = threadIdx.x; i < Kp; i += blockDim.x) {
+        int v = 0;
+        if (i < K) {
+            v     = q0[pi[i]];
+            w1max = max(w1max, abs((int)q1[i]) + abs((int)q0[i]));
+            w2max = max(w2max, abs((int)q2[i]) + abs(v));
+        }
+        i0[i] = (int8_t)v;
+    }
+    w1max = block_max_i(w1max, red_i);
+    w2max = block_max_i(w2max, red_i);
+    const float W1 = (float)w1max, W2 = (float)w2max;
+    for (uint32_t i = threadIdx.x; i < Kp; i += blockDim.x) {
+        int a = 0, b = 0;
+        if (i < K) {
+            float w1 = (float)(abs((int)q1[i]) + abs((int)q0[i]));
+            float w2 = (float)(abs((int)q2[i]) + abs((int)i0[i]));
+            a = (int)(127.0f * (w1 / W1));
+            b = (int)(127.0f * (w2 / W2));
+        }
+        m1[i] = (int8_t)a;
+        m2[i] = (int8_t)b;
+    }
+    __syncthreads();
+    store_tile_lines(out.arr, sm, 6, Kp, tile_off, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// siso: viterbi_decode_siso (liblte_phy.cc:10341-10529) for constraint length 4, g = {015,013},
+// 64 code blocks in lock-step.  blockIdx.y selects the pass (argument set).
+//
+// Trellis facts used (derived from liblte_phy.cc:10379-10408):
+//   predecessors of s are 2(s&3) and 2(s&3)+1; expected outputs for predecessor k=1 are the
+//   complement of those for k=0, so br(s,1) = -br(s,0) =: -beta_s with
+//   beta = {P, Q, -Q, -P, -P, -Q, Q, P}[s],  P = e0+e1, Q = e0-e1,  e = +1 if the hard input bit is 1.
+//   ACS (liblte_phy.cc:10454-10463): take k=1 iff beta + PM[p0] > -beta + PM[p1]
+//                                    <=>  PM[p1] - PM[p0] < 2*beta; new PM = PM[pk] +- w*beta.
+//   Traceback (liblte_phy.cc:10484-10497) re-compares the STORED metrics: bit_j = PM[2j] > PM[2j+1].
+struct SisoPass {
+    const uint8_t *in_a; // first soft value of each pair  (in[2t])
+    const uint8_t *in_b; // second soft value of each pair (in[2t+1])
+    const uint8_t *mag;  // |output| per step
+    uint8_t       *out;  // signed SISO output
+    uint32_t      *dec;  // traceback bits: [tile][blk][lane][8 words]
+};
+struct SisoArgs { SisoPass p[2]; };
+
+__device__ __forceinline__ void acs_step(int (&pm)[8], int x, int y, uint32_t &acc)
+{
+    const int e0 = (x < 0) ? 1 : -1, e1 = (y < 0) ? 1 : -1;
+    const int w  = abs(x) + abs(y);
+    const int P = e0 + e1, Q = e0 - e1;
+    const int wP = w * P, wQ = w * Q, P2 = 2 * P, Q2 = 2 * Q;
+    const int n0 = pm[1] - pm[0], n1 = pm[3] - pm[2], n2 = pm[5] - pm[4], n3 = pm[7] - pm[6];
+    // traceback bits for this time index (bit = PM[2j] > PM[2j+1] = sign bit of n_j), j = 0 first
+    acc = __builtin_amdgcn_alignbit(acc, (uint32_t)n0, 31);
+    acc = __builtin_amdgcn_alignbit(acc, (uint32_t)n1, 31);
+    acc = __builtin_amdgcn_alignbit(acc, (uint32_t)n2, 31);
+    acc = __builtin_amdgcn_alignbit(acc, (uint32_t)n3, 31);
+    int nw[8];
+    nw[0] = (n0 < P2) ? pm[1] - wP : pm[0] + wP;   // beta =  P
+    nw[4] = (n0 < -P2) ? pm[1] + wP : pm[0] - wP;  // beta = -P
+    nw[1] = (n1 < Q2) ? pm[3] - wQ : pm[2] + wQ;   // beta =  Q
+    nw[5] = (n1 < -Q2) ? pm[3] + wQ : pm[2] - wQ;  // beta = -Q
+    nw[2] = (n2 < -Q2) ? pm[5] + wQ : pm[4] - wQ;  // beta = -Q
+    nw[6] = (n2 < Q2) ? pm[5] - wQ : pm[4] + wQ;   // beta =  Q
+    nw[3] = (n3 < -P2) ? pm[7] + wP : pm[6] - wP;  // beta = -P
+    nw[7] = (n3 < P2) ? pm[7] - wP : pm[6] + wP;   // beta =  P
+#pragma unroll
+    for (int s = 0; s < 8; s++) pm[s] = nw[s];
+}
+
+__global__ __launch_bounds__(64) void k_turbo_siso(SisoArgs args, uint32_t K, uint32_t pass_base)
+{
+    const SisoPass &ps   = args.p[blockIdx.y];
+    const uint32_t  tile = blockIdx.x, lane = threadIdx.x, Kp = kpad64(K), nblk = Kp >> 6;
+    const size_t    tile_off = (size_t)tile * Kp * 64 + lane * 64;
+    const uint8_t  *pa = ps.in_a + tile_off, *pb = ps.in_b + tile_off;
+    uint32_t       *dec = ps.dec + ((size_t)tile * nblk * 64 + lane) * 8;
+    (void)pass_base;
+
+    int pm[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) pm[s] = 0; // all path metrics start at 0 (liblte_phy.cc:10411-10418)
+
+    // ---- forward add-compare-select
+    for (uint32_t blk = 0; blk < nblk; blk++) {
+        uint4 A[4], B[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            A[q] = reinterpret_cast<const uint4 *>(pa + (size_t)blk * 4096)[q];
+            B[q] = reinterpret_cast<const uint4 *>(pb + (size_t)blk * 4096)[q];
+        }
+        uint32_t dw[8];
+#pragma unroll
+        for (int g = 0; g < 8; g++) { // 8 groups of 8 steps = one decision word each
+            uint32_t acc = 0;
+            if (blk * 64 + g * 8 < K) { // uniform: K is a multiple of 8
+                const uint4    a4 = A[g >> 1], b4 = B[g >> 1];
+                const uint32_t a_lo = (g & 1) ? a4.z : a4.x, a_hi = (g & 1) ? a4.w : a4.y;
+                const uint32_t b_lo = (g & 1) ? b4.z : b4.x, b_hi = (g & 1) ? b4.w : b4.y;
+#pragma unroll
+                for (int r = 0; r < 4; r++) acs_step(pm, sbyte(a_lo, r), sbyte(b_lo, r), acc);
+#pragma unroll
+                for (int r = 0; r < 4; r++) acs_step(pm, sbyte(a_hi, r), sbyte(b_hi, r), acc);
+            }
+            dw[g] = acc;
+        }
+        uint4 *dp = reinterpret_cast<uint4 *>(dec + (size_t)blk * 64 * 8);
+        dp[0] = make_uint4(dw[0], dw[1], dw[2], dw[3]);
+        dp[1] = make_uint4(dw[4], dw[5], dw[6], dw[7]);
+    }
+
+    // ---- end state: first strict minimum (liblte_phy.cc:10467-10481)
+    int cur = 0, best = pm[0];
+#pragma unroll
+    for (int s = 1; s < 8; s++)
+        if (pm[s] < best) { best = pm[s]; cur = s; }
+
+    // ---- traceback + signed soft output (liblte_phy.cc:10483-10527)
+    const uint8_t *pmag = ps.mag + tile_off;
+    uint8_t       *pout = ps.out + tile_off;
+    for (int blk = (int)nblk - 1; blk >= 0; blk--) {
+        uint4        M[4];
+        const uint4 *dp = reinterpret_cast<const uint4 *>(dec + (size_t)blk * 64 * 8);
+        const uint4  d0 = dp[0], d1 = dp[1];
+        uint32_t     dw[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) M[q] = reinterpret_cast<const uint4 *>(pmag + (size_t)blk * 4096)[q];
+        uint32_t mw[16] = {M[0].x, M[0].y, M[0].z, M[0].w, M[1].x, M[1].y, M[1].z, M[1].w,
+                           M[2].x, M[2].y, M[2].z, M[2].w, M[3].x, M[3].y, M[3].z, M[3].w};
+        uint32_t ow[16];
+#pragma unroll
+        for (int g = 7; g >= 0; g--) {
+            uint32_t o_hi = 0, o_lo = 0;
+            if ((uint32_t)blk * 64 + g * 8 < K) {
+                const uint32_t word = dw[g];
+#pragma unroll
+                for (int r = 7; r >= 0; r--) {
+                    // bits of step r sit in nibble (7-r); pair j is bit (3-j) of the nibble
+                    const int j   = cur & 3;
+                    const int bit = (word >> (4 * (7 - r) + (3 - j))) & 1;
+                    const int st  = 2 * j + bit; // state at time t
+                    const int m   = sbyte(mw[g * 2 + (r >> 2)], r & 3);
+                    // output bit 0 ("+") when the step moved to a lower state, or stayed in state 0
+                    const bool pos = (cur < st) || (cur == st && cur == 0);
+                    const int  v   = pos ? m : -m;
+                    if (r >= 4) o_hi |= ((uint32_t)(v & 0xFF)) << (8 * (r - 4));
+                    else        o_lo |= ((uint32_t)(v & 0xFF)) << (8 * r);
+                    cur = st;
+                }
+            }
+            ow[g * 2]     = o_lo;
+            ow[g * 2 + 1] = o_hi;
+        }
+        uint4 *op = reinterpret_cast<uint4 *>(pout + (size_t)blk * 4096);
+#pragma unroll
+        for (int q = 0; q < 4; q++) op[q] = make_uint4(ow[4 * q], ow[4 * q + 1], ow[4 * q + 2], ow[4 * q + 3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// perm: Steps 2, 3, 5 and the pass-3 output magnitudes.  One workgroup per code block.
+//   C1 = soft_xor(A1, fb(A1)); I1[i] = C1[pi[i]]; M3 from pairs (q(d2), I1)
+struct PermArgs { const uint8_t *A1; const uint8_t *X2; uint8_t *out[2]; /* I1, M3 */ };
+
+__global__ __launch_bounds__(256) void k_turbo_perm(PermArgs a, uint32_t K, const uint16_t *__restrict__ pi)
+{
+    extern __shared__ __attribute__((aligned(16))) int8_t sm[];
+    __shared__ int red_i[4];
+    const uint32_t cb = blockIdx.x, tile = cb >> 6, lane = cb & 63, Kp = kpad64(K);
+    const size_t   tile_off = (size_t)tile * Kp * 64;
+    int8_t *i1 = sm, *m3 = i1 + Kp, *a1 = m3 + Kp, *c1 = a1 + Kp, *x2 = c1 + Kp;
+    load_tile_lines(a1, a.A1, Kp, tile_off, lane);
+    load_tile_lines(x2, a.X2, Kp, tile_off, lane);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < K; i += blockDim.x) c1[i] = (int8_t)soft_xor(a1[i], fb_at(a1, (int)i));
+    __syncthreads();
+    int wmax = 0;
+    for (uint32_t i = threadIdx.x; i < Kp; i += blockDim.x) {
+        int v = 0;
+        if (i < K) {
+            v    = c1[pi[i]];
+            wmax = max(wmax, abs((int)x2[i]) + abs(v));
+        }
+        i1[i] = (int8_t)v;
+    }
+    wmax          = block_max_i(wmax, red_i);
+    const float W = (float)wmax;
+    for (uint32_t i = threadIdx.x; i < Kp; i += blockDim.x) {
+        int m = 0;
+        if (i < K) m = (int)(127.0f * ((float)(abs((int)x2[i]) + abs((int)i1[i])) / W));
+        m3[i] = (int8_t)m;
+    }
+    __syncthreads();
+    store_tile_lines(a.out, sm, 2, Kp, tile_off, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// vote: Steps 2-3 (again, C1 is cheap to recompute), 8-14.  One workgroup per code block.
+struct VoteArgs { const uint8_t *X0, *A1, *B1, *B2; };
+
+__global__ __launch_bounds__(256) void k_turbo_vote(VoteArgs a, uint32_t K, const uint16_t *__restrict__ inv,
+                                                    uint8_t *__restrict__ c_bits)
+{
+    extern __shared__ __attribute__((aligned(16))) int8_t sm[];
+    const uint32_t cb = blockIdx.x, tile = cb >> 6, lane = cb & 63, Kp = kpad64(K);
+    const size_t   tile_off = (size_t)tile * Kp * 64;
+    int8_t *x0 = sm, *a1 = x0 + Kp, *b1 = a1 + Kp, *b2 = b1 + Kp, *d1 = b2 + Kp, *d2 = d1 + Kp;
+    load_tile_lines(x0, a.X0, Kp, tile_off, lane);
+    load_tile_lines(a1, a.A1, Kp, tile_off, lane);
+    load_tile_lines(b1, a.B1, Kp, tile_off, lane);
+    load_tile_lines(b2, a.B2, Kp, tile_off, lane);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < K; i += blockDim.x) {
+        const int A = a1[i], B = b1[i], G = fb_at(b1, (int)i), B_ = b2[i], G_ = fb_at(b2, (int)i);
+        int       v1, v2;
+        // Step 10 (liblte_phy.cc:10778-10797); the mixed-sign branches read in_act_1 (A), not int_act_1
+        if (B >= 0 && G >= 0)     v1 = (B + G) >> 1;
+        else if (B < 0 && G < 0)  v1 = (-B - G) >> 1;
+        else if (B >= 0 && G < 0) v1 = -((A - G) >> 1);
+        else                      v1 = -((-A + G) >> 1);
+        // Step 11 (liblte_phy.cc:10800-10819); last branch is -((-a - b) >> 1)
+        if (B_ >= 0 && G_ >= 0)     v2 = (B_ + G_) >> 1;
+        else if (B_ < 0 && G_ < 0)  v2 = (-B_ - G_) >> 1;
+        else if (B_ >= 0 && G_ < 0) v2 = -((B_ - G_) >> 1);
+        else                        v2 = -((-B_ - G_) >> 1);
+        d1[i] = (int8_t)v1;
+        d2[i] = (int8_t)v2;
+    }
+    __syncthreads();
+    uint8_t *o = c_bits + (size_t)cb * K;
+    for (uint32_t j = threadIdx.x; j < K; j += blockDim.x) {
+        const int      c1 = soft_xor(a1[j], fb_at(a1, (int)j));
+        const uint32_t i  = inv[j]; // Steps 12/13: de-interleave; a hole contributes 0
+        const int      c2 = (i != 0xFFFFu) ? (int)d1[i] : 0;
+        const int      c3 = (i != 0xFFFFu) ? (int)d2[i] : 0;
+        o[j] = ((int)x0[j] + c1 + c2 + c3 >= 0) ? 0 : 1; // Step 14
+    }
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host side
+
+namespace {
+constexpr int N_BYTE_ARRAYS = 11; // X0 X1 X2 I0 M1 M2 A1 I1 M3 B1 B2
+enum { AX0, AX1, AX2, AI0, AM1, AM2, AA1, AI1, AM3, AB1, AB2 };
+} // namespace
+
+extern "C" size_t mi_lte_turbo_scratch_bytes(uint32_t K, uint32_t n_cb)
+{
+    const size_t n_tiles = (n_cb + 63) / 64, Kp = kpad64(K);
+    return n_tiles * Kp * 64 * N_BYTE_ARRAYS + 3 * n_tiles * Kp * 32;
+}
+
+template <typename T>
+static int turbo_ref_batch(mi_lte_ctx *ctx, const T *d_soft, uint32_t K, uint32_t n_cb, uint8_t *d_c_bits)
+{
+    TurboTables tb;
+    int         rc = mi_ctx_turbo_tables(ctx, K, 0, &tb);
+    if (rc != MI_LTE_OK) return rc;
+    const size_t n_tiles = (n_cb + 63) / 64, Kp = kpad64(K), arr_bytes = n_tiles * Kp * 64, dec_bytes = n_tiles * Kp * 32;
+    rc = mi_ctx_reserve_scratch(ctx, mi_lte_turbo_scratch_bytes(K, n_cb));
+    if (rc != MI_LTE_OK) return rc;
+    uint8_t *base = (uint8_t *)ctx->scratch;
+    uint8_t *arr[N_BYTE_ARRAYS];
+    for (int a = 0; a < N_BYTE_ARRAYS; a++) arr[a] = base + a * arr_bytes;
+    uint32_t *dec[3];
+    for (int p = 0; p < 3; p++) dec[p] = (uint32_t *)(base + N_BYTE_ARRAYS * arr_bytes + p * dec_bytes);
+    if (n_cb % 64) // lanes past the batch end walk whatever the scratch holds; keep it defined
+        MI_HIP_CHECK(ctx, hipMemsetAsync(base, 0, N_BYTE_ARRAYS * arr_bytes, ctx->stream));
+
+    PrepOut po;
+    po.arr[0] = arr[AX0]; po.arr[1] = arr[AX1]; po.arr[2] = arr[AX2];
+    po.arr[3] = arr[AI0]; po.arr[4] = arr[AM1]; po.arr[5] = arr[AM2];
+    hipLaunchKernelGGL((k_turbo_prep<T>), dim3(n_cb), dim3(256), 6 * Kp, ctx->stream, d_soft, K, n_cb, tb.d_pi, po);
+
+    SisoArgs s1;
+    s1.p[0] = {arr[AX1], arr[AX0], arr[AM1], arr[AA1], dec[0]};
+    s1.p[1] = s1.p[0];
+    hipLaunchKernelGGL(k_turbo_siso, dim3(n_tiles, 1), dim3(64), 0, ctx->stream, s1, K, 0u);
+
+    PermArgs pa;
+    pa.A1 = arr[AA1]; pa.X2 = arr[AX2]; pa.out[0] = arr[AI1]; pa.out[1] = arr[AM3];
+    hipLaunchKernelGGL(k_turbo_perm, dim3(n_cb), dim3(256), 5 * Kp, ctx->stream, pa, K, tb.d_pi);
+
+    SisoArgs s23;
+    s23.p[0] = {arr[AX2], arr[AI0], arr[AM2], arr[AB1], dec[1]};
+    s23.p[1] = {arr[AX2], arr[AI1], arr[AM3], arr[AB2], dec[2]};
+    hipLaunchKernelGGL(k_turbo_siso, dim3(n_tiles, 2), dim3(64), 0, ctx->stream, s23, K, 1u);
+
+    VoteArgs va = {arr[AX0], arr[AA1], arr[AB1], arr[AB2]};
+    hipLaunchKernelGGL(k_turbo_vote, dim3(n_cb), dim3(256), 6 * Kp, ctx->stream, va, K, tb.d_inv, d_c_bits);
+    MI_HIP_CHECK(ctx, hipGetLastError());
+    ctx->last_kernels = "k_turbo_prep:1,k_turbo_siso:2,k_turbo_perm:1,k_turbo_vote:1";
+    return MI_LTE_OK;
+}
+
+extern "C" int mi_lte_turbo_decode_batch(mi_lte_ctx *ctx, const void *d_soft, mi_lte_soft_type soft_type, uint32_t K,
+                                         uint32_t n_cb, mi_lte_turbo_mode mode, uint32_t n_iter, int qpp_spec,
+                                         uint8_t *d_c_bits)
+{
+    if (!ctx || !d_soft || !d_c_bits || n_cb == 0 || K < 40 || K > 6144) return MI_LTE_ERR_INVALID_ARG;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (mode == MI_LTE_TURBO_REF) {
+        (void)n_iter;
+        (void)qpp_spec;
+        switch (soft_type) {
+        case MI_LTE_SOFT_F32: return turbo_ref_batch<float>(ctx, (const float *)d_soft, K, n_cb, d_c_bits);
+        case MI_LTE_SOFT_I8:  return turbo_ref_batch<int8_t>(ctx, (const int8_t *)d_soft, K, n_cb, d_c_bits);
+        case MI_LTE_SOFT_I16: return turbo_ref_batch<int16_t>(ctx, (const int16_t *)d_soft, K, n_cb, d_c_bits);
+        }
+        return MI_LTE_ERR_INVALID_ARG;
+    }
+    ctx->err = "BCJR mode not built yet";
+    return MI_LTE_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,172 @@
+"""ctypes binding of libmi_lte.so (include/mi_lte.h)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+SOFT_F32, SOFT_I8, SOFT_I16 = 0, 1, 2
+TURBO_REF, TURBO_BCJR = 0, 1
+_SOFT_OF_DTYPE = {np.dtype(np.float32): SOFT_F32, np.dtype(np.int8): SOFT_I8, np.dtype(np.int16): SOFT_I16}
+
+
+class MiLteError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, "libmi_lte.so")
+
+
+def build_library():
+    """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
+    return library_path()
+
+
+def load_library():
+    """Load libmi_lte.so; raises if it has not been built -- there is no fallback path."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise MiLteError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(the HIP extension is the only implementation; no CPU fallback exists)" % path)
+    L = C.CDLL(path)
+    vp, u32, sz = C.c_void_p, C.c_uint32, C.c_size_t
+    L.mi_lte_version.restype = C.c_int
+    L.mi_lte_device_count.restype = C.c_int
+    L.mi_lte_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.mi_lte_ctx_destroy.argtypes = [vp]
+    L.mi_lte_last_error.argtypes = [vp]
+    L.mi_lte_last_error.restype = C.c_char_p
+    L.mi_lte_device_name.argtypes = [vp]
+    L.mi_lte_device_name.restype = C.c_char_p
+    L.mi_lte_last_kernels.argtypes = [vp]
+    L.mi_lte_last_kernels.restype = C.c_char_p
+    L.mi_lte_stream.argtypes = [vp]
+    L.mi_lte_stream.restype = vp
+    L.mi_lte_malloc.argtypes = [vp, sz, C.POINTER(vp)]
+    L.mi_lte_free.argtypes = [vp, vp]
+    L.mi_lte_memset.argtypes = [vp, vp, C.c_int, sz]
+    L.mi_lte_memcpy_h2d.argtypes = [vp, vp, vp, sz]
+    L.mi_lte_memcpy_d2h.argtypes = [vp, vp, vp, sz]
+    L.mi_lte_sync.argtypes = [vp]
+    L.mi_lte_timer_start.argtypes = [vp]
+    L.mi_lte_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
+    L.mi_lte_turbo_decode_batch.argtypes = [vp, vp, C.c_int, u32, u32, C.c_int, u32, C.c_int, vp]
+    L.mi_lte_turbo_scratch_bytes.argtypes = [u32, u32]
+    L.mi_lte_turbo_scratch_bytes.restype = sz
+    _LIB = L
+    return L
+
+
+class DeviceBuffer:
+    """A block of HBM owned by a Context (hipMalloc through the C-ABI)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = C.c_void_p()
+        ctx._check(ctx.L.mi_lte_malloc(ctx.h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr, offset=0):
+        arr = np.ascontiguousarray(arr)
+        assert offset + arr.nbytes <= self.nbytes
+        self.ctx._check(self.ctx.L.mi_lte_memcpy_h2d(self.ctx.h, self.ptr + offset, arr.ctypes.data, arr.nbytes))
+        return self
+
+    def download(self, dtype, count=None, offset=0):
+        dtype = np.dtype(dtype)
+        if count is None:
+            count = (self.nbytes - offset) // dtype.itemsize
+        out = np.empty(count, dtype)
+        self.ctx._check(self.ctx.L.mi_lte_memcpy_d2h(self.ctx.h, out.ctypes.data, self.ptr + offset, out.nbytes))
+        return out
+
+    def zero(self):
+        self.ctx._check(self.ctx.L.mi_lte_memset(self.ctx.h, self.ptr, 0, self.nbytes))
+
+    def free(self):
+        if self.ptr:
+            self.ctx.L.mi_lte_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+
+class Context:
+    """One GPU + one stream.  Mirrors the role of LIBLTE_PHY_STRUCT: all scratch lives here."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        h = C.c_void_p()
+        rc = self.L.mi_lte_ctx_create(int(device), C.byref(h))
+        if rc != 0:
+            raise MiLteError("mi_lte_ctx_create(device=%d) failed with %d: no usable gfx950 GPU "
+                             "(the product path has no CPU fallback)" % (device, rc))
+        self.h = h
+        self.device = device
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MiLteError("libmi_lte error %d: %s" % (rc, self.L.mi_lte_last_error(self.h).decode()))
+
+    @property
+    def device_name(self):
+        return self.L.mi_lte_device_name(self.h).decode()
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return DeviceBuffer(self, arr.nbytes).upload(arr)
+
+    def sync(self):
+        self._check(self.L.mi_lte_sync(self.h))
+
+    def timer_start(self):
+        self._check(self.L.mi_lte_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._check(self.L.mi_lte_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def last_kernels(self):
+        return self.L.mi_lte_last_kernels(self.h).decode()
+
+    # ---- turbo -------------------------------------------------------------------------------
+    def turbo_decode_dev(self, d_soft, soft_type, K, n_cb, d_out, mode=TURBO_REF, n_iter=8, qpp_spec=False):
+        """Device-pointer form: everything already resident in HBM (what bench.py times)."""
+        self._check(self.L.mi_lte_turbo_decode_batch(self.h, d_soft.ptr, soft_type, K, n_cb, mode, n_iter,
+                                                     1 if qpp_spec else 0, d_out.ptr))
+
+    def turbo_decode(self, soft, K, mode=TURBO_REF, n_iter=8, qpp_spec=False):
+        """Host convenience: soft is [n_cb, 3*(K+4)] (float32 / int8 / int16), interleaved d[i*3+x]
+        exactly as the reference's turbo_decode takes it; returns [n_cb, K] uint8 hard bits."""
+        soft = np.ascontiguousarray(soft)
+        assert soft.ndim == 2 and soft.shape[1] == 3 * (K + 4), soft.shape
+        n_cb = soft.shape[0]
+        d_in = self.to_device(soft)
+        d_out = self.alloc(n_cb * K)
+        try:
+            self.turbo_decode_dev(d_in, _SOFT_OF_DTYPE[soft.dtype], K, n_cb, d_out, mode, n_iter, qpp_spec)
+            return d_out.download(np.uint8).reshape(n_cb, K)
+        finally:
+            d_in.free()
+            d_out.free()
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mi_lte_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -65,6 +65,13 @@ int mi_lte_sync(mi_lte_ctx *ctx);
 int mi_lte_timer_start(mi_lte_ctx *ctx);
 int mi_lte_timer_stop(mi_lte_ctx *ctx, float *elapsed_ms); /* records, synchronises, returns ms */
 
+/* Per-kernel timing: when enabled every kernel launch the library issues is bracketed by a pair
+ * of HIP events on the context's stream.  The report is "kernel:launches:total_ms;..." since the
+ * last reset (this is how bench.py measures the dominant kernel's average duration live). */
+int         mi_lte_profile_enable(mi_lte_ctx *ctx, int on);
+int         mi_lte_profile_reset(mi_lte_ctx *ctx);
+const char *mi_lte_profile_report(mi_lte_ctx *ctx);
+
 /* ---------------------------------------------------------------- turbo decode
  * Replaces turbo_decode() (liblte/src/liblte_phy.cc:10620-10845) for a batch of code blocks of one
  * size K.  Input layout is the reference's: per block 3*(K+4) soft values INTERLEAVED d[i*3+x]

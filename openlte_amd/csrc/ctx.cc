@@ -53,6 +53,7 @@ void mi_lte_ctx_destroy(mi_lte_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (void *p : ctx->owned) (void)hipFree(p);
+    for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -121,7 +122,61 @@ int mi_lte_timer_stop(mi_lte_ctx *ctx, float *elapsed_ms)
     return MI_LTE_OK;
 }
 
+int mi_lte_profile_enable(mi_lte_ctx *ctx, int on)
+{
+    if (!ctx) return MI_LTE_ERR_INVALID_ARG;
+    ctx->prof_on = on != 0;
+    return MI_LTE_OK;
+}
+int mi_lte_profile_reset(mi_lte_ctx *ctx)
+{
+    if (!ctx) return MI_LTE_ERR_INVALID_ARG;
+    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->prof_used = 0;
+    ctx->prof_recs.clear();
+    return MI_LTE_OK;
+}
+// "name:launches:total_ms;..." for every kernel bracketed since the last reset
+const char *mi_lte_profile_report(mi_lte_ctx *ctx)
+{
+    if (!ctx) return "";
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return "";
+    std::map<std::string, std::pair<int, double>> agg;
+    for (auto &r : ctx->prof_recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->prof_pool[r.second], ctx->prof_pool[r.second + 1]) != hipSuccess) continue;
+        auto &a = agg[r.first];
+        a.first += 1;
+        a.second += ms;
+    }
+    ctx->prof_report.clear();
+    char buf[256];
+    for (auto &kv : agg) {
+        snprintf(buf, sizeof(buf), "%s:%d:%.6f;", kv.first.c_str(), kv.second.first, kv.second.second);
+        ctx->prof_report += buf;
+    }
+    return ctx->prof_report.c_str();
+}
+
 } // extern "C"
+
+void mi_prof_begin(mi_lte_ctx *ctx, const char *name)
+{
+    if (!ctx->prof_on) return;
+    while (ctx->prof_pool.size() < ctx->prof_used + 2) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        ctx->prof_pool.push_back(e);
+    }
+    ctx->prof_recs.push_back({name, ctx->prof_used});
+    (void)hipEventRecord(ctx->prof_pool[ctx->prof_used], ctx->stream);
+}
+void mi_prof_end(mi_lte_ctx *ctx)
+{
+    if (!ctx->prof_on) return;
+    (void)hipEventRecord(ctx->prof_pool[ctx->prof_used + 1], ctx->stream);
+    ctx->prof_used += 2;
+}
 
 int mi_ctx_reserve_scratch(mi_lte_ctx *ctx, size_t bytes)
 {

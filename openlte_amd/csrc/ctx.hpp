@@ -27,7 +27,25 @@ struct mi_lte_ctx {
     size_t             scratch_bytes = 0;
     std::map<uint64_t, TurboTables> turbo_tables; // key = K | (spec << 32)
     std::vector<void *> owned;                    // allocations released at destroy
+
+    // optional per-launch HIP-event bracketing (mi_lte_profile_*): pairs are resolved at report time
+    bool                                   prof_on = false;
+    std::vector<hipEvent_t>                prof_pool;
+    size_t                                 prof_used = 0;
+    std::vector<std::pair<const char *, size_t>> prof_recs; // (kernel name, index of start event)
+    std::string                            prof_report;
 };
+
+void mi_prof_begin(mi_lte_ctx *ctx, const char *name);
+void mi_prof_end(mi_lte_ctx *ctx);
+
+// launch on the context's stream, bracketed by events when profiling is enabled
+#define MI_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                                         \
+    do {                                                                                             \
+        mi_prof_begin((ctx), (name));                                                                \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);                  \
+        mi_prof_end((ctx));                                                                          \
+    } while (0)
 
 #define MI_HIP_CHECK(ctx, call)                                                                      \
     do {                                                                                             \

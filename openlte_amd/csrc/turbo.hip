@@ -419,24 +419,24 @@ static int turbo_ref_batch(mi_lte_ctx *ctx, const T *d_soft, uint32_t K, uint32_
     PrepOut po;
     po.arr[0] = arr[AX0]; po.arr[1] = arr[AX1]; po.arr[2] = arr[AX2];
     po.arr[3] = arr[AI0]; po.arr[4] = arr[AM1]; po.arr[5] = arr[AM2];
-    hipLaunchKernelGGL((k_turbo_prep<T>), dim3(n_cb), dim3(256), 6 * Kp, ctx->stream, d_soft, K, n_cb, tb.d_pi, po);
+    MI_LAUNCH(ctx, "k_turbo_prep", (k_turbo_prep<T>), dim3(n_cb), dim3(256), 6 * Kp, d_soft, K, n_cb, tb.d_pi, po);
 
     SisoArgs s1;
     s1.p[0] = {arr[AX1], arr[AX0], arr[AM1], arr[AA1], dec[0]};
     s1.p[1] = s1.p[0];
-    hipLaunchKernelGGL(k_turbo_siso, dim3(n_tiles, 1), dim3(64), 0, ctx->stream, s1, K, 0u);
+    MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso, dim3(n_tiles, 1), dim3(64), 0, s1, K, 0u);
 
     PermArgs pa;
     pa.A1 = arr[AA1]; pa.X2 = arr[AX2]; pa.out[0] = arr[AI1]; pa.out[1] = arr[AM3];
-    hipLaunchKernelGGL(k_turbo_perm, dim3(n_cb), dim3(256), 5 * Kp, ctx->stream, pa, K, tb.d_pi);
+    MI_LAUNCH(ctx, "k_turbo_perm", k_turbo_perm, dim3(n_cb), dim3(256), 5 * Kp, pa, K, tb.d_pi);
 
     SisoArgs s23;
     s23.p[0] = {arr[AX2], arr[AI0], arr[AM2], arr[AB1], dec[1]};
     s23.p[1] = {arr[AX2], arr[AI1], arr[AM3], arr[AB2], dec[2]};
-    hipLaunchKernelGGL(k_turbo_siso, dim3(n_tiles, 2), dim3(64), 0, ctx->stream, s23, K, 1u);
+    MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso, dim3(n_tiles, 2), dim3(64), 0, s23, K, 1u);
 
     VoteArgs va = {arr[AX0], arr[AA1], arr[AB1], arr[AB2]};
-    hipLaunchKernelGGL(k_turbo_vote, dim3(n_cb), dim3(256), 6 * Kp, ctx->stream, va, K, tb.d_inv, d_c_bits);
+    MI_LAUNCH(ctx, "k_turbo_vote", k_turbo_vote, dim3(n_cb), dim3(256), 6 * Kp, va, K, tb.d_inv, d_c_bits);
     MI_HIP_CHECK(ctx, hipGetLastError());
     ctx->last_kernels = "k_turbo_prep:1,k_turbo_siso:2,k_turbo_perm:1,k_turbo_vote:1";
     return MI_LTE_OK;

@@ -58,6 +58,10 @@ def load_library():
     L.mi_lte_sync.argtypes = [vp]
     L.mi_lte_timer_start.argtypes = [vp]
     L.mi_lte_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
+    L.mi_lte_profile_enable.argtypes = [vp, C.c_int]
+    L.mi_lte_profile_reset.argtypes = [vp]
+    L.mi_lte_profile_report.argtypes = [vp]
+    L.mi_lte_profile_report.restype = C.c_char_p
     L.mi_lte_turbo_decode_batch.argtypes = [vp, vp, C.c_int, u32, u32, C.c_int, u32, C.c_int, vp]
     L.mi_lte_turbo_scratch_bytes.argtypes = [u32, u32]
     L.mi_lte_turbo_scratch_bytes.restype = sz
@@ -135,6 +139,19 @@ class Context:
         ms = C.c_float()
         self._check(self.L.mi_lte_timer_stop(self.h, C.byref(ms)))
         return ms.value
+
+    def profile(self, on=True):
+        self._check(self.L.mi_lte_profile_enable(self.h, 1 if on else 0))
+        self._check(self.L.mi_lte_profile_reset(self.h))
+
+    def profile_report(self):
+        """{kernel: (launches, total_ms)} for every launch bracketed since profile() / the last reset."""
+        out = {}
+        for item in self.L.mi_lte_profile_report(self.h).decode().split(";"):
+            if item:
+                name, n, ms = item.rsplit(":", 2)
+                out[name] = (int(n), float(ms))
+        return out
 
     def last_kernels(self):
         return self.L.mi_lte_last_kernels(self.h).decode()

@@ -1,0 +1,51 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/*.h declares (no compute
+calls here -- this container has no GPU), and refuses to create a context without a GPU."""
+import ctypes
+import glob
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    names = set()
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        txt = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names |= set(re.findall(r"\b(mi_lte_[a-z0-9_]+)\s*\(", txt))
+    return sorted(names)
+
+
+def test_library_exports_every_declared_symbol():
+    import openlte_amd
+    L = openlte_amd.load_library()
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    missing = [s for s in syms if not hasattr(L, s)]
+    assert not missing, "declared in include/*.h but not exported: %s" % missing
+
+
+def test_header_cites_reference_interfaces():
+    txt = open(os.path.join(ROOT, "include", "mi_lte.h")).read()
+    assert "liblte_phy.cc:" in txt and "liblte_phy.h" in txt
+
+
+def test_no_cpu_fallback_without_gpu():
+    import openlte_amd
+    L = openlte_amd.load_library()
+    if L.mi_lte_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(openlte_amd.MiLteError):
+        openlte_amd.Context(0)
+
+
+def test_product_never_touches_the_oracle():
+    """The product package and the library sources must not reference oracle/."""
+    bad = []
+    for path in glob.glob(os.path.join(ROOT, "openlte_amd", "**", "*"), recursive=True):
+        if os.path.isfile(path) and path.endswith((".py", ".cc", ".hip", ".hpp", ".h")):
+            if re.search(r"\boracle\b", open(path, errors="ignore").read()):
+                bad.append(os.path.relpath(path, ROOT))
+    assert not bad, bad

@@ -1,0 +1,155 @@
+"""CPU tests: the plain-C oracle against (a) the reference compiled in place (where available) and
+(b) the committed golden fixtures generated from that reference build."""
+import os
+
+import numpy as np
+import pytest
+
+import lte_testdata as td
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def golden_cases(name):
+    z = np.load(os.path.join(GOLD, name))
+    keys = sorted({k.rsplit("_", 1)[0] for k in z.files})
+    return z, keys
+
+
+def test_port_matches_golden_turbo_ref(port):
+    """Pins the restatement on machines without /root/reference."""
+    z, keys = golden_cases("turbo_ref.npz")
+    assert len(keys) >= 9
+    for key in keys:
+        K = int(key.split("_")[0][1:])
+        soft, want = z[key + "_soft"], z[key + "_bits"]
+        got = td.oracle_turbo_ref(port, soft, K)
+        assert (np.packbits(got, axis=-1) == want).all(), key
+
+
+@pytest.mark.parametrize("K", [40, 48, 200, 512, 1024, 3584, 4224, 6016, 6080, 6144])
+def test_port_turbo_ref_vs_reference(port, ref, ref_phy, K):
+    """Differential test against the compiled reference, incl. uint32-overflow sizes."""
+    for kind in ("clean", "awgn0.5", "awgn0.8", "int"):
+        tx, soft = td.turbo_blocks(port, K, 3, kind, seed=K)
+        for b in range(3):
+            d = np.ascontiguousarray(soft[b], dtype=np.float32)
+            a, c = np.zeros(K, np.uint8), np.zeros(K, np.uint8)
+            ref.ref_turbo_decode(ref_phy, d.copy(), 3 * (K + 4), a)
+            port.lo_turbo_decode_ref(d.copy(), K, c)
+            assert (a == c).all(), (K, kind, b)
+
+
+def test_port_all_188_block_sizes_vs_reference(port, ref, ref_phy):
+    from oracle.pyoracle import port as _p  # noqa: F401
+    rng = np.random.default_rng(5)
+    sizes = list(range(40, 513, 8)) + list(range(528, 1025, 16)) + list(range(1056, 2049, 32)) + list(range(2112, 6145, 64))
+    assert len(sizes) == 188
+    for K in sizes:
+        c = rng.integers(0, 2, K).astype(np.uint8)
+        d1, d2 = np.zeros(3 * (K + 4), np.uint8), np.zeros(3 * (K + 4), np.uint8)
+        ref.ref_turbo_encode(ref_phy, c, K, d1)
+        port.lo_turbo_encode(c, K, d2)
+        assert (d1 == d2).all(), K
+        x = (1 - 2 * d1.reshape(3, K + 4).astype(np.float32)) + 0.6 * rng.standard_normal((3, K + 4)).astype(np.float32)
+        d = np.ascontiguousarray(x.T.reshape(-1))
+        a, b = np.zeros(K, np.uint8), np.zeros(K, np.uint8)
+        ref.ref_turbo_decode(ref_phy, d.copy(), 3 * (K + 4), a)
+        port.lo_turbo_decode_ref(d.copy(), K, b)
+        assert (a == b).all(), K
+
+
+def test_port_siso_and_fb_vs_reference(port, ref, ref_phy):
+    rng = np.random.default_rng(11)
+    for K in (40, 1024, 6144):
+        x = rng.integers(-127, 128, 2 * K).astype(np.int8)
+        x[rng.random(2 * K) < 0.1] = 0
+        a, b = np.zeros(K + 16, np.int8), np.zeros(K + 16, np.int8)
+        ref.ref_viterbi_siso(ref_phy, x, 2 * K, a)
+        port.lo_viterbi_siso(x, K, b)
+        assert (a[:K] == b[:K]).all()
+        y = rng.integers(-127, 128, K).astype(np.int8)
+        fa, fb = np.zeros(K + 8, np.int8), np.zeros(K + 8, np.int8)
+        ref.ref_conv_encode_soft_g03(ref_phy, y, K, fa[1:])
+        fa[0] = 127
+        port.lo_fb_soft(y, K, fb)
+        assert (fa[:K] == fb[:K]).all()
+
+
+def test_port_prs_crc_crs_vs_reference(port, ref):
+    rng = np.random.default_rng(2)
+    for c_init in (0, 1, 0x1234567, (0x1234 << 14) | (3 << 9) | 17, 2**31 - 1):
+        a, b = np.zeros(3000, np.uint32), np.zeros(3000, np.uint8)
+        ref.ref_generate_prs_c(c_init, 3000, a)
+        port.lo_prs_c(c_init, 3000, b)
+        assert (a == b).all()
+    for n in (16, 40, 3240, 6120):
+        bits = rng.integers(0, 2, n).astype(np.uint8)
+        a, b = np.zeros(24, np.uint8), np.zeros(24, np.uint8)
+        ref.ref_calc_crc24a(bits, n, a)
+        port.lo_crc24a(bits, n, b)
+        assert (a == b).all()
+    for ns, l, cell in ((0, 0, 0), (7, 4, 17), (19, 1, 503)):
+        a = [np.zeros(220, np.float32) for _ in range(4)]
+        ref.ref_generate_crs(ns, l, cell, a[0], a[1])
+        port.lo_generate_crs(ns, l, cell, a[2], a[3])
+        assert (a[0] == a[2]).all() and (a[1] == a[3]).all()
+
+
+def test_port_rate_unmatch_vs_reference(port, ref, ref_phy):
+    """Restated ratematch round trip (liblte/manual_tests/ratematch_test.cc:58-251) + element-wise
+    comparison with the reference incl. puncturing, repetition (soft combining), rv, C, tx_mode."""
+    rng = np.random.default_rng(3)
+    for K in (40, 104, 512, 1088, 3264, 6016, 6144):
+        D = K + 4
+        for (rv, C_, M, txm, chan, ratio) in ((0, 1, 4, 2, 0, 3.0), (1, 1, 8, 1, 0, 2.1), (2, 2, 8, 3, 0, 4.7),
+                                             (3, 1, 8, 1, 0, 3.3), (0, 1, 1, 1, 2, 3.0)):
+            E = int(ratio * D) // 2 * 2
+            e = rng.integers(-127, 128, E).astype(np.float32)
+            a, b = np.full(3 * D, -7, np.float32), np.full(3 * D, -7, np.float32)
+            n_soft = 250368 if chan == 0 else 1
+            na = ref.ref_rate_unmatch_turbo(ref_phy, e.copy(), E, K, C_, txm, n_soft, M, chan, rv, a)
+            nb = port.lo_rate_unmatch_turbo(e.copy(), E, D, C_, txm, n_soft, M, chan, rv, b)
+            assert na == nb == 3 * D
+            assert (a == b).all(), (K, rv, C_, M, txm, chan, ratio)
+        # round trip with the TX side, error-free channel, G = 3D (ratematch_test.cc)
+        c = rng.integers(0, 2, K).astype(np.uint8)
+        d = np.zeros(3 * D, np.uint8)
+        port.lo_turbo_encode(c, K, d)
+        e8a, e8b = np.zeros(3 * D, np.uint8), np.zeros(3 * D, np.uint8)
+        ref.ref_rate_match_turbo(ref_phy, d.copy(), 3 * D, 1, 2, 250368, 4, 0, 0, 3 * D, e8a)
+        port.lo_rate_match_turbo(d, 3 * D, 1, 2, 250368, 4, 0, 0, 3 * D, e8b)
+        assert (e8a == e8b).all()
+        back = np.zeros(3 * D, np.float32)
+        port.lo_rate_unmatch_turbo((1.0 - 2.0 * e8b).astype(np.float32), 3 * D, D, 1, 2, 250368, 4, 0, 0, back)
+        rx = (back.reshape(D, 3).T < 0).astype(np.uint8).reshape(-1)
+        if 250368 // 4 >= 3 * (D + 28):  # the manual test skips K where N_cb != K_w
+            assert (rx == d).all()
+
+
+def test_port_demapper_vs_reference(port, ref):
+    rng = np.random.default_rng(4)
+    M = 4000
+    re = (rng.standard_normal(M) * 0.8).astype(np.float32)
+    im = (rng.standard_normal(M) * 0.8).astype(np.float32)
+    for mod, q in ((0, 1), (1, 2), (2, 4), (3, 6)):
+        a, b = np.zeros(q * M, np.int8), np.zeros(q * M, np.int8)
+        na = ref.ref_modulation_demapper(re, im, M, mod, a)
+        nb = port.lo_modulation_demapper(re, im, M, mod, b)
+        assert na == nb == q * M and (a == b).all(), mod
+
+
+def test_port_pre_decoder_vs_reference(port, ref):
+    rng = np.random.default_rng(6)
+    for n_ant, M_ap in ((1, 1000), (2, 1000), (4, 1000), (4, 998)):
+        cap = 5000
+        y = [rng.standard_normal(M_ap + 8).astype(np.float32) for _ in range(2)]
+        h = [rng.standard_normal(4 * cap).astype(np.float32) for _ in range(2)]
+        xa = [np.zeros(10000, np.float32) for _ in range(2)]
+        xb = [np.zeros(10000, np.float32) for _ in range(2)]
+        import ctypes as C
+        ml = C.c_uint32()
+        ref.ref_pre_decoder_dl(y[0], y[1], h[0], h[1], cap, M_ap, n_ant, xa[0], xa[1], C.byref(ml))
+        mb = port.lo_pre_decoder_dl(y[0], y[1], h[0], h[1], cap, M_ap, n_ant, xb[0], xb[1])
+        assert ml.value == mb
+        assert (xa[0] == xb[0]).all() and (xa[1] == xb[1]).all()

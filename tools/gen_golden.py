@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE ITSELF (oracle/_ref, built in place from
+/root/reference by oracle/ref/Makefile).  Run in the build container; the small .npz fixtures are
+committed so that the GPU box (which has no /root/reference) can check against them.
+
+    python tools/gen_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import pyoracle as po  # noqa: E402
+import lte_testdata as td  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def pack(bits):
+    return np.packbits(bits.astype(np.uint8), axis=-1)
+
+
+def turbo_ref_vectors(R, P, phy):
+    """REF turbo decode: seeded inputs + the reference's hard bits (packed)."""
+    rec = {}
+    cases = [(40, "awgn0.8", 8), (104, "int", 8), (1088, "awgn0.5", 6), (3264, "hard127", 4), (3584, "awgn0.5", 4),
+             (6016, "awgn0.8", 3), (6144, "awgn0.5", 3), (6144, "hard127", 3), (2048, "i16", 4)]
+    for K, kind, n in cases:
+        seed = 9000 + K + len(kind)
+        tx, soft = td.turbo_blocks(P, K, n, kind, seed)
+        out = np.zeros((n, K), np.uint8)
+        for b in range(n):
+            R.ref_turbo_decode(phy, np.ascontiguousarray(soft[b], dtype=np.float32), 3 * (K + 4), out[b])
+        key = "K%d_%s" % (K, kind)
+        rec[key + "_seed"] = np.array([seed, n])
+        rec[key + "_soft"] = soft  # inputs are stored too, so the fixture does not depend on numpy's RNG stream
+        rec[key + "_bits"] = pack(out)
+    np.savez_compressed(os.path.join(OUT, "turbo_ref.npz"), **rec)
+    print("turbo_ref.npz:", len(cases), "cases")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    R, P = po.ref(), po.port()
+    assert R is not None, "oracle/_ref is not built (needs /root/reference)"
+    phy = R.ref_phy_new(4, 17, 1, 100)
+    turbo_ref_vectors(R, P, phy)
+    R.ref_phy_free(phy)
+
+
+if __name__ == "__main__":
+    main()

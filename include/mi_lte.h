@@ -72,6 +72,51 @@ int         mi_lte_profile_enable(mi_lte_ctx *ctx, int on);
 int         mi_lte_profile_reset(mi_lte_ctx *ctx);
 const char *mi_lte_profile_report(mi_lte_ctx *ctx);
 
+/* ---------------------------------------------------------------- DL front end
+ * Replaces liblte_phy_get_dl_subframe_and_ce() (liblte/hdr/liblte_phy.h:1170-1177, implementation
+ * liblte/src/liblte_phy.cc:5905-6200) for a batch of independent subframe "units": 16 OFDM symbol
+ * FFTs (14 + the 2 look-ahead symbols the interpolation needs; the window starts one sample early,
+ * liblte_phy.cc:8621) and CRS channel estimation / interpolation for N_ant ports.
+ *
+ * Samples: either interleaved int8 I,Q (the capture file format the reference's callers convert
+ * from, LTE_fdd_dl_file_scan/src/LTE_fdd_dl_fs_samp_buf.cc:657-694) in d_samples_a, or planar fp32
+ * i_samps / q_samps (the reference API's own arguments) in d_samples_a / d_samples_b.
+ * d_unit_start[u] is the sample index of unit u's subframe start (the reference's
+ * frame_start_idx + subfr_num*N_samps_per_subfr); a unit reads up to start + 30720 + 4400 samples at
+ * 30.72 MHz (scaled for smaller FFT sizes).
+ *
+ * Output: one "device subframe" per unit, mi_lte_subframe_floats(N_ant) floats, laid out like the
+ * receive half of LIBLTE_PHY_SUBFRAME_STRUCT (liblte_phy.h:226-239) with row stride 1200:
+ *     rx_symb_re[16][1200] rx_symb_im[16][1200] rx_ce_re[N_ant][16][1200] rx_ce_im[N_ant][16][1200]
+ * (channel-estimate rows 14,15 are never written, as in the reference). */
+typedef enum { MI_LTE_IQ_I8 = 0, MI_LTE_IQ_F32_PLANAR = 1 } mi_lte_iq_format;
+typedef struct {
+    uint32_t fft_size;      /* 128, 256, 512, 1024, 2048 = N_samps_per_symb (liblte_phy.cc:2226-2274) */
+    uint32_t N_rb_dl;       /* 6..100 */
+    uint32_t N_ant;         /* 1, 2, 4 */
+    uint32_t sample_format; /* mi_lte_iq_format */
+} mi_lte_dl_cfg;
+
+size_t mi_lte_subframe_floats(uint32_t N_ant);
+int    mi_lte_dl_frontend_batch(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const void *d_samples_a,
+                                const void *d_samples_b, const uint64_t *d_unit_start, const uint32_t *d_subfr_num,
+                                const uint32_t *d_n_id_cell, uint32_t n_units, float *d_subframes);
+
+/* ---------------------------------------------------------------- PDSCH allocations
+ * Compact form of LIBLTE_PHY_ALLOCATION_STRUCT (liblte/hdr/liblte_phy.h:684-702): the fields
+ * liblte_phy_pdsch_channel_decode reads, plus the index of the subframe unit the allocation lives in. */
+typedef struct {
+    uint32_t unit;           /* index into the batch of device subframes                         */
+    uint32_t mod_type;       /* LIBLTE_PHY_MODULATION_TYPE_ENUM: 0 BPSK 1 QPSK 2 16QAM 3 64QAM     */
+    uint32_t tbs;            /* transport block size in bits                                     */
+    uint32_t rv_idx;
+    uint32_t tx_mode;
+    uint32_t rnti;
+    uint32_t N_prb;
+    uint32_t reserved;
+    uint8_t  prb[2][112];    /* PRB indices per slot (alloc->prb[L/7][...]), first N_prb valid    */
+} mi_lte_pdsch_alloc;
+
 /* ---------------------------------------------------------------- turbo decode
  * Replaces turbo_decode() (liblte/src/liblte_phy.cc:10620-10845) for a batch of code blocks of one
  * size K.  Input layout is the reference's: per block 3*(K+4) soft values INTERLEAVED d[i*3+x]
@@ -98,6 +143,34 @@ size_t mi_lte_turbo_scratch_bytes(uint32_t K, uint32_t n_cb);
 
 /* name and launch count of the kernels the last batch call issued (for bench.py / profiles) */
 const char *mi_lte_last_kernels(const mi_lte_ctx *ctx);
+
+/* ---------------------------------------------------------------- input synthesis (host side)
+ * A minimal LTE downlink transmitter for benchmark / test captures, the role LTE_fdd_dl_file_gen
+ * plays for the reference (LTE_fdd_dl_file_gen/src/LTE_fdd_dl_fg_samp_buf.cc:269-668).  Host code
+ * only; these functions never touch the GPU and nothing the library decodes runs on the CPU. */
+int mi_lte_synth_turbo_soft_i8(uint32_t K, uint32_t n, double flip, int amp, uint64_t seed, int ref_wrap,
+                               int8_t *h_soft, uint8_t *h_tx_bits);
+int mi_lte_synth_turbo_soft_f32(uint32_t K, uint32_t n, double sigma, uint64_t seed, int ref_wrap, float *h_soft,
+                                uint8_t *h_tx_bits);
+
+typedef struct {
+    double   gain_min, gain_max; /* |h| drawn uniformly per unit                                  */
+    double   max_delay;          /* integer timing offset drawn from 0..max_delay samples          */
+    double   snr_db;             /* AWGN relative to the mean signal power; >= 200 disables noise   */
+    double   peak;               /* int8 full-scale target for the signal peak (e.g. 100)           */
+    uint64_t seed;
+} mi_lte_synth_channel;
+
+/* n_units single-port (N_ant = 1) subframes, each with its own cell id / subframe number and
+ * n_alloc PDSCH allocations (allocs[u*n_alloc + a], .unit ignored), CFI = N_pdcch_symbs, random
+ * transport blocks.  Writes unit_len = 30720*s + 4400*s (s = fft_size/2048, rounded up to a
+ * multiple of 16) complex int8 samples per unit to h_iq, and the transport-block bits (one per byte,
+ * tbs_stride bytes per allocation) to h_tx_bits. */
+size_t mi_lte_synth_unit_len(uint32_t fft_size);
+int    mi_lte_synth_dl_units_i8(const mi_lte_dl_cfg *cfg, uint32_t n_units, const uint32_t *h_subfr_num,
+                                const uint32_t *h_n_id_cell, uint32_t N_pdcch_symbs, const mi_lte_pdsch_alloc *h_allocs,
+                                uint32_t n_alloc, const mi_lte_synth_channel *chan, int8_t *h_iq, uint8_t *h_tx_bits,
+                                uint32_t tbs_stride);
 
 #ifdef __cplusplus
 }

@@ -229,3 +229,44 @@ int mi_ctx_turbo_tables(mi_lte_ctx *ctx, uint32_t K, int spec, TurboTables *out)
     *out                   = t;
     return MI_LTE_OK;
 }
+
+// Gold sequence c(n) = x1(n+1600) ^ x2(n+1600) (3GPP TS 36.211 7.2; generate_prs_c,
+// liblte_phy.cc:9669-9704).  x1 does not depend on the seed; x2 is a linear function of the 31 seed
+// bits.  Table layout: x1[w] and x2b[j][w] hold output bits 32w..32w+31 (bit b of the word = c index
+// 32w+b) of the x1 sequence and of the x2 sequence seeded with 1<<j.  A kernel gets any word of any
+// sequence as x1[w] ^ XOR_{j in seed} x2b[j][w].
+int mi_ctx_gold_tables(mi_lte_ctx *ctx)
+{
+    if (ctx->d_gold_x1) return MI_LTE_OK;
+    const uint32_t W = 4096; // 131072 bits >= the largest PDSCH allocation (100 PRB x 64QAM ~ 86400 bits)
+    std::vector<uint32_t> x1w(W, 0), x2w((size_t)31 * W, 0);
+    {
+        uint32_t x1 = 0x54D21B24u; // x1 after the 1600-31 step warm-up (same constant as the reference)
+        for (uint32_t n = 0; n < 32 * W; n++) {
+            uint32_t nb = ((x1 >> 3) ^ x1) & 1u;
+            x1          = (x1 >> 1) | (nb << 30);
+            x1w[n >> 5] |= nb << (n & 31);
+        }
+    }
+    for (int j = 0; j < 31; j++) {
+        uint32_t x2 = 1u << j;
+        for (uint32_t n = 0; n < 1600 - 31; n++) {
+            uint32_t nb = ((x2 >> 3) ^ (x2 >> 2) ^ (x2 >> 1) ^ x2) & 1u;
+            x2          = (x2 >> 1) | (nb << 30);
+        }
+        for (uint32_t n = 0; n < 32 * W; n++) {
+            uint32_t nb = ((x2 >> 3) ^ (x2 >> 2) ^ (x2 >> 1) ^ x2) & 1u;
+            x2          = (x2 >> 1) | (nb << 30);
+            x2w[(size_t)j * W + (n >> 5)] |= nb << (n & 31);
+        }
+    }
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_gold_x1, sizeof(uint32_t) * W));
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_gold_x2b, sizeof(uint32_t) * 31 * W));
+    ctx->owned.push_back(ctx->d_gold_x1);
+    ctx->owned.push_back(ctx->d_gold_x2b);
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_gold_x1, x1w.data(), sizeof(uint32_t) * W, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_gold_x2b, x2w.data(), sizeof(uint32_t) * 31 * W, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->gold_words = W;
+    return MI_LTE_OK;
+}

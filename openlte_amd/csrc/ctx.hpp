@@ -28,6 +28,10 @@ struct mi_lte_ctx {
     std::map<uint64_t, TurboTables> turbo_tables; // key = K | (spec << 32)
     std::vector<void *> owned;                    // allocations released at destroy
 
+    // Gold-sequence tables (see mi_ctx_gold_tables)
+    uint32_t *d_gold_x1 = nullptr, *d_gold_x2b = nullptr;
+    uint32_t  gold_words = 0;
+
     // optional per-launch HIP-event bracketing (mi_lte_profile_*): pairs are resolved at report time
     bool                                   prof_on = false;
     std::vector<hipEvent_t>                prof_pool;
@@ -57,4 +61,5 @@ void mi_prof_end(mi_lte_ctx *ctx);
     } while (0)
 
 int   mi_ctx_reserve_scratch(mi_lte_ctx *ctx, size_t bytes);
+int   mi_ctx_gold_tables(mi_lte_ctx *ctx);
 int   mi_ctx_turbo_tables(mi_lte_ctx *ctx, uint32_t K, int spec, TurboTables *out);

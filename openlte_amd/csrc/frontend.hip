@@ -1,0 +1,380 @@
+// DL front end on gfx950: OFDM demodulation (16 FFTs per subframe) + CRS channel estimation.
+// Restates liblte_phy_get_dl_subframe_and_ce (liblte/src/liblte_phy.cc:5905-6200) for a batch of
+// independent subframe units.  HBM-bound by design: int8 IQ in, fp32 symbols + estimates out.
+//
+//   k_dl_fft  : one workgroup per (unit, OFDM symbol).  N-point Stockham FFT through LDS, radix-8
+//               passes in registers, int8->fp32 conversion fused into the first pass's loads and the
+//               guard-band drop / spectrum un-shift fused into the last pass's stores
+//               (samples_to_symbols_dl, liblte_phy.cc:8593-8644, scale = 0).
+//   k_dl_ce   : one workgroup per (unit, antenna port): pilot LS estimates, the reference's
+//               sequential phase unwrap, frequency interpolation, then time interpolation and
+//               mag/phase -> re/im for all 14 symbols (liblte_phy.cc:5959-6194).
+#include "ctx.hpp"
+
+namespace {
+
+constexpr int N_SC_MAX = 1200; // row stride of every subframe array (LIBLTE_PHY_N_RB_DL_20MHZ * 12)
+
+struct DlGeom {
+    uint32_t N;        // FFT size = samples per symbol
+    uint32_t cp0, cpe; // cyclic prefix of symbol 0 / other symbols
+    uint32_t n_slot;   // samples per slot
+    uint32_t half;     // used sub-carriers per side = 6 * N_rb_dl
+    uint32_t N_rb_dl;
+    uint32_t N_ant;
+    uint32_t sf_stride; // floats per device subframe
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); } // a * (-i)
+
+// forward DFTs of size 2/4/8 on registers, natural-order output
+__device__ __forceinline__ void dft2(float2 &a, float2 &b) { float2 t = a; a = cadd(t, b); b = csub(t, b); }
+__device__ __forceinline__ void dft4(float2 *v)
+{
+    float2 a = cadd(v[0], v[2]), b = csub(v[0], v[2]), c = cadd(v[1], v[3]), d = mul_mi(csub(v[1], v[3]));
+    v[0] = cadd(a, c); v[1] = cadd(b, d); v[2] = csub(a, c); v[3] = csub(b, d);
+}
+__device__ __forceinline__ void dft8(float2 *v)
+{
+    const float h = 0.70710678118654752440f;
+    float2 e[4] = {v[0], v[2], v[4], v[6]}, o[4] = {v[1], v[3], v[5], v[7]};
+    dft4(e);
+    dft4(o);
+    o[1] = cmul(o[1], make_float2(h, -h)); // W8^1
+    o[2] = mul_mi(o[2]);                   // W8^2
+    o[3] = cmul(o[3], make_float2(-h, -h)); // W8^3
+#pragma unroll
+    for (int k = 0; k < 4; k++) { v[k] = cadd(e[k], o[k]); v[k + 4] = csub(e[k], o[k]); }
+}
+template <int R> __device__ __forceinline__ void dftR(float2 *v)
+{
+    if (R == 8) dft8(v);
+    else if (R == 4) dft4(v);
+    else dft2(v[0], v[1]);
+}
+
+// LDS index padding: one extra float2 slot every 32 breaks the power-of-two strides of the passes
+__device__ __forceinline__ uint32_t pad(uint32_t i) { return i + (i >> 5); }
+
+// One Stockham pass of radix R over buf (N points, sub-transform length Ns so far).
+// SRC: 0 = LDS, 1 = gather from global int8/float samples.  DST: 0 = LDS, 1 = scatter to the symbol row.
+template <int R, typename LoadF, typename StoreF>
+__device__ __forceinline__ void fft_pass(uint32_t N, uint32_t Ns, LoadF load, StoreF store)
+{
+    const uint32_t nb = N / R;
+    for (uint32_t j = threadIdx.x; j < nb; j += blockDim.x) {
+        float2 v[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) v[r] = load(j + r * nb);
+        const uint32_t k = j & (Ns - 1);
+        if (Ns > 1) {
+            float s, c;
+            sincospif(-2.0f * (float)k / (float)(Ns * R), &s, &c); // exp(-2*pi*i*k/(Ns*R))
+            const float2 w1 = make_float2(c, s);
+            float2       w  = w1;
+#pragma unroll
+            for (int r = 1; r < R; r++) {
+                v[r] = cmul(v[r], w);
+                w    = cmul(w, w1);
+            }
+        }
+        dftR<R>(v);
+        const uint32_t j0 = (j - k) * R + k;
+#pragma unroll
+        for (int r = 0; r < R; r++) store(j0 + r * Ns, v[r]);
+    }
+}
+
+template <typename T> struct SampleSrc;
+template <> struct SampleSrc<int8_t> { // interleaved I,Q int8 (capture file format, LTE_fdd_dl_fs_samp_buf.cc:657-694)
+    const int8_t *p;
+    __device__ __forceinline__ float2 at(size_t n) const
+    {
+        const char2 v = *reinterpret_cast<const char2 *>(p + 2 * n);
+        return make_float2((float)v.x, (float)v.y);
+    }
+};
+template <> struct SampleSrc<float> { // planar i_samps / q_samps as the reference API takes them
+    const float *i, *q;
+    __device__ __forceinline__ float2 at(size_t n) const { return make_float2(i[n], q[n]); }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t *__restrict__ unit_start, DlGeom g,
+                                                float *__restrict__ subframes)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 buf[]; // pad(N) entries
+    const uint32_t sym = blockIdx.x, unit = blockIdx.y, N = g.N;
+    // window start: slot start + symbol offset + CP - 1  (one sample early: liblte_phy.cc:8621)
+    const uint32_t so   = sym % 7;
+    const size_t   first = unit_start[unit] + (size_t)(sym / 7) * g.n_slot + (size_t)(N + g.cpe) * so + (so ? g.cp0 - g.cpe : 0) +
+                         (so == 0 ? g.cp0 : g.cpe) - 1;
+    float *row_re = subframes + (size_t)unit * g.sf_stride + (size_t)sym * N_SC_MAX;
+    float *row_im = row_re + 16 * N_SC_MAX;
+    const uint32_t half = g.half;
+
+    auto ld_g = [&](uint32_t i) { return src.at(first + i); };
+    auto ld_s = [&](uint32_t i) { return buf[pad(i)]; };
+    auto st_s = [&](uint32_t i, float2 v) { buf[pad(i)] = v; };
+    auto st_g = [&](uint32_t o, float2 v) { // keep bins 1..half and N-half..N-1 (liblte_phy.cc:8625-8634)
+        if (o >= 1 && o <= half) { row_re[half + o - 1] = v.x; row_im[half + o - 1] = v.y; }
+        else if (o >= N - half)  { row_re[o - (N - half)] = v.x; row_im[o - (N - half)] = v.y; }
+    };
+
+    // radix plan: 8,8,8,4 (2048) | 8,8,8,2 (1024) | 8,8,8 (512) | 8,8,4 (256) | 8,8,2 (128)
+    uint32_t Ns = 1;
+    fft_pass<8>(N, Ns, ld_g, st_s); Ns *= 8;
+    __syncthreads();
+    {   // second radix-8 pass: read all, then write (in place)
+        const uint32_t nb = N / 8;
+        float2 v[8]; // one butterfly per thread when nb <= blockDim.x (N <= 2048)
+        const uint32_t j = threadIdx.x;
+        const bool act = j < nb;
+        if (act) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) v[r] = buf[pad(j + r * nb)];
+        }
+        __syncthreads();
+        if (act) {
+            const uint32_t k = j & (Ns - 1);
+            float s, c;
+            sincospif(-2.0f * (float)k / (float)(Ns * 8), &s, &c);
+            const float2 w1 = make_float2(c, s);
+            float2 w = w1;
+#pragma unroll
+            for (int r = 1; r < 8; r++) { v[r] = cmul(v[r], w); w = cmul(w, w1); }
+            dft8(v);
+            const uint32_t j0 = (j - k) * 8 + k;
+#pragma unroll
+            for (int r = 0; r < 8; r++) buf[pad(j0 + r * Ns)] = v[r];
+        }
+        Ns *= 8;
+    }
+    __syncthreads();
+    if (N == 128) { fft_pass<2>(N, Ns, ld_s, st_g); return; }
+    if (N == 256) { fft_pass<4>(N, Ns, ld_s, st_g); return; }
+    if (N == 512) { fft_pass<8>(N, Ns, ld_s, st_g); return; }
+    {   // third radix-8 pass in place
+        const uint32_t nb = N / 8;
+        float2 v[8];
+        const uint32_t j = threadIdx.x;
+        const bool act = j < nb;
+        if (act) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) v[r] = buf[pad(j + r * nb)];
+        }
+        __syncthreads();
+        if (act) {
+            const uint32_t k = j & (Ns - 1);
+            float s, c;
+            sincospif(-2.0f * (float)k / (float)(Ns * 8), &s, &c);
+            const float2 w1 = make_float2(c, s);
+            float2 w = w1;
+#pragma unroll
+            for (int r = 1; r < 8; r++) { v[r] = cmul(v[r], w); w = cmul(w, w1); }
+            dft8(v);
+            const uint32_t j0 = (j - k) * 8 + k;
+#pragma unroll
+            for (int r = 0; r < 8; r++) buf[pad(j0 + r * Ns)] = v[r];
+        }
+        Ns *= 8;
+    }
+    __syncthreads();
+    if (N == 1024) fft_pass<2>(N, Ns, ld_s, st_g);
+    else           fft_pass<4>(N, Ns, ld_s, st_g);
+}
+
+// ------------------------------------------------------------------------------------------------
+// channel estimation
+
+// wrap_phase (liblte_phy.cc:14105-14116): float difference compared against the double constant,
+// the +-2*pi correction is evaluated in double and rounded back to float.
+__device__ __forceinline__ float wrap_phase(float p1, float p2)
+{
+    while ((double)(p1 - p2) >= M_PI) p1 = (float)((double)p1 - 2 * M_PI);
+    while ((double)(p1 - p2) <= -M_PI) p1 = (float)((double)p1 + 2 * M_PI);
+    return p1;
+}
+
+struct GoldTables { const uint32_t *x1; const uint32_t *x2b; uint32_t words; }; // x2b[31][words]
+
+// 32 bits c[32w .. 32w+31] of the Gold sequence seeded with c_init (generate_prs_c,
+// liblte_phy.cc:9669-9704): the x2 register is linear in c_init, so the word is the XOR of the
+// per-seed-bit basis words; bit b of the result is c[32w + b].
+__device__ __forceinline__ uint32_t gold_word(const GoldTables &gt, uint32_t c_init, uint32_t w)
+{
+    uint32_t v = gt.x1[w];
+    for (uint32_t m = c_init; m; m &= m - 1) v ^= gt.x2b[(uint32_t)__builtin_ctz(m) * gt.words + w];
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_dl_ce(const uint32_t *__restrict__ subfr_num, const uint32_t *__restrict__ n_id_cell,
+                                               DlGeom g, GoldTables gt, float *__restrict__ subframes)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[]; // mag[5][N_sc] ang[5][N_sc]
+    __shared__ uint32_t crs_bits[5][14];
+    const uint32_t unit = blockIdx.x, p = blockIdx.y, N_sc = 12 * g.N_rb_dl, n_pil = 2 * g.N_rb_dl;
+    const uint32_t sf = subfr_num[unit], cell = n_id_cell[unit], v_shift = cell % 6;
+    float *mag = sm, *ang = sm + 5 * N_sc;
+    float *base   = subframes + (size_t)unit * g.sf_stride;
+    const float *sym_re = base, *sym_im = base + 16 * N_SC_MAX;
+    float *ce_re = base + 2 * 16 * N_SC_MAX + (size_t)p * 16 * N_SC_MAX;
+    float *ce_im = ce_re + (size_t)g.N_ant * 16 * N_SC_MAX;
+
+    // CRS symbols / frequency offsets of this port (liblte_phy.cc:5973-6014), as select chains so
+    // that nothing is indexed dynamically out of registers
+    const uint32_t N_sym = (p < 2) ? 5 : 3;
+    auto sym_of = [p](uint32_t i) -> uint32_t {
+        return (p < 2) ? (i == 0 ? 0u : i == 1 ? 4u : i == 2 ? 7u : i == 3 ? 11u : 14u) : (i == 0 ? 1u : i == 1 ? 8u : 15u);
+    };
+    auto voff_of = [p](uint32_t i) -> uint32_t {
+        return (p < 2) ? ((((i & 1) ^ (p & 1)) != 0) ? 3u : 0u) : (p == 2 ? ((i & 1) ? 3u : 0u) : ((i & 1) ? 6u : 3u));
+    };
+
+    // CRS bits (generate_crs, liblte_phy.cc:8300-8333; slots per :5960-5967)
+    if (threadIdx.x < N_sym * 14) {
+        const uint32_t i = threadIdx.x / 14, w = threadIdx.x % 14;
+        const uint32_t ns = (sf * 2 + sym_of(i) / 7) % 20, l = sym_of(i) % 7;
+        const uint32_t c_init = 1024 * (7 * (ns + 1) + l + 1) * (2 * cell + 1) + 2 * cell + 1;
+        crs_bits[i][w] = gold_word(gt, c_init, w);
+    }
+    __syncthreads();
+
+    // least-squares estimate at every pilot (liblte_phy.cc:6023-6030)
+    const float r2 = (float)(1.0 / sqrt(2.0));
+    for (uint32_t t = threadIdx.x; t < N_sym * n_pil; t += blockDim.x) {
+        const uint32_t i = t / n_pil, j = t % n_pil;
+        const uint32_t k = 6 * j + (voff_of(i) + v_shift) % 6, mp = j + 110 - g.N_rb_dl;
+        const uint32_t b0 = (crs_bits[i][(2 * mp) >> 5] >> ((2 * mp) & 31)) & 1u, b1 = (crs_bits[i][(2 * mp + 1) >> 5] >> ((2 * mp + 1) & 31)) & 1u;
+        const float rs_re = r2 * (1 - 2 * (float)b0), rs_im = r2 * (1 - 2 * (float)b1);
+        const float s_re = sym_re[sym_of(i) * N_SC_MAX + k], s_im = sym_im[sym_of(i) * N_SC_MAX + k];
+        const float t_re = s_re * rs_re + s_im * rs_im, t_im = s_im * rs_re - s_re * rs_im;
+        mag[i * N_sc + k] = sqrtf(t_re * t_re + t_im * t_im);
+        ang[i * N_sc + k] = atan2f(t_im, t_re);
+    }
+    __syncthreads();
+    // sequential unwrap along frequency, one lane per CRS symbol (liblte_phy.cc:6033-6035)
+    if (threadIdx.x < N_sym) {
+        const uint32_t i = threadIdx.x, off = (voff_of(i) + v_shift) % 6;
+        float prev = ang[i * N_sc + off];
+        for (uint32_t j = 1; j < n_pil; j++) {
+            const uint32_t k = 6 * j + off;
+            prev = wrap_phase(ang[i * N_sc + k], prev);
+            ang[i * N_sc + k] = prev;
+        }
+    }
+    __syncthreads();
+    // frequency interpolation between pilots, edges continue the first / last slope
+    // (liblte_phy.cc:6037-6063; repeated subtraction kept to reproduce the rounding)
+    for (uint32_t t = threadIdx.x; t < N_sym * n_pil; t += blockDim.x) {
+        const uint32_t i = t / n_pil, j = t % n_pil;
+        if (j == 0) continue;
+        const uint32_t off = (voff_of(i) + v_shift) % 6, k = 6 * j + off;
+        float *m = mag + i * N_sc, *a = ang + i * N_sc;
+        const float fm = (m[k] - m[k - 6]) / 6, fa = (a[k] - a[k - 6]) / 6;
+        float cm = m[k], ca = a[k];
+        for (uint32_t z = 1; z < 6; z++) { cm -= fm; ca -= fa; m[k - z] = cm; a[k - z] = ca; }
+        if (j == 1) {
+            cm = m[k - 6]; ca = a[k - 6];
+            for (uint32_t z = 1; z < off + 1; z++) { cm -= fm; ca -= fa; m[k - 6 - z] = cm; a[k - 6 - z] = ca; }
+        }
+        if (j == n_pil - 1) {
+            cm = m[k]; ca = a[k];
+            for (uint32_t z = 1; z < (5 - off) + 1; z++) { cm -= fm; ca -= fa; m[k + z] = cm; a[k + z] = ca; }
+        }
+    }
+    __syncthreads();
+
+    // time interpolation per sub-carrier (liblte_phy.cc:6066-6193)
+    for (uint32_t j = threadIdx.x; j < N_sc; j += blockDim.x) {
+        float M[5], A[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) { M[i] = mag[i * N_sc + j]; A[i] = ang[i * N_sc + j]; }
+        float fm, fa, cm, ca;
+#define EMIT(z, m, a) do { ce_re[(z) * N_SC_MAX + j] = (m) * cosf(a); ce_im[(z) * N_SC_MAX + j] = (m) * sinf(a); } while (0)
+#define SLOPE(hi, lo, dv) do { fm = (M[hi] - M[lo]) / (dv); A[hi] = wrap_phase(A[hi], A[lo]); fa = A[hi] - A[lo]; \
+                               fa = wrap_phase(fa, 0.0f); fa /= (dv); } while (0)
+        if (N_sym == 3) {
+            EMIT(1, M[0], A[0]);
+            EMIT(8, M[1], A[1]);
+            SLOPE(1, 0, 7);
+            cm = M[1]; ca = A[1];
+            for (int z = 7; z > 1; z--) { cm -= fm; ca -= fa; EMIT(z, cm, ca); }
+            cm = M[0] - fm; ca = A[0] - fa; // symbol 0 extrapolated with the 1->8 slope (:6093-6098)
+            EMIT(0, cm, ca);
+            SLOPE(2, 1, 7);
+            cm = M[2] - fm; ca = A[2] - fa;
+            for (int z = 13; z > 8; z--) { cm -= fm; ca -= fa; EMIT(z, cm, ca); }
+        } else {
+            EMIT(0, M[0], A[0]);
+            EMIT(4, M[1], A[1]);
+            EMIT(7, M[2], A[2]);
+            EMIT(11, M[3], A[3]);
+            SLOPE(1, 0, 4);
+            cm = M[1]; ca = A[1];
+            for (int z = 3; z > 0; z--) { cm -= fm; ca -= fa; EMIT(z, cm, ca); }
+            SLOPE(2, 1, 3);
+            cm = M[2]; ca = A[2];
+            for (int z = 6; z > 4; z--) { cm -= fm; ca -= fa; EMIT(z, cm, ca); }
+            SLOPE(3, 2, 4);
+            cm = M[3]; ca = A[3];
+            for (int z = 10; z > 7; z--) { cm -= fm; ca -= fa; EMIT(z, cm, ca); }
+            SLOPE(4, 3, 3);
+            cm = M[4]; ca = A[4];
+            for (int z = 13; z > 11; z--) { cm -= fm; ca -= fa; EMIT(z, cm, ca); }
+        }
+#undef EMIT
+#undef SLOPE
+    }
+}
+
+int make_geom(const mi_lte_dl_cfg *cfg, DlGeom *g)
+{
+    const uint32_t N = cfg->fft_size;
+    if (!(N == 128 || N == 256 || N == 512 || N == 1024 || N == 2048)) return MI_LTE_ERR_INVALID_ARG;
+    if (!(cfg->N_ant == 1 || cfg->N_ant == 2 || cfg->N_ant == 4)) return MI_LTE_ERR_INVALID_ARG;
+    if (cfg->N_rb_dl < 6 || cfg->N_rb_dl > 100 || cfg->N_rb_dl * 12 >= N) return MI_LTE_ERR_INVALID_ARG;
+    const uint32_t sc = 2048 / N;
+    g->N = N; g->cp0 = 160 / sc; g->cpe = 144 / sc; g->n_slot = 15360 / sc;
+    g->half = 6 * cfg->N_rb_dl; g->N_rb_dl = cfg->N_rb_dl; g->N_ant = cfg->N_ant;
+    g->sf_stride = (uint32_t)mi_lte_subframe_floats(cfg->N_ant);
+    return MI_LTE_OK;
+}
+
+} // namespace
+
+extern "C" size_t mi_lte_subframe_floats(uint32_t N_ant) { return (size_t)(2 + 2 * N_ant) * 16 * N_SC_MAX; }
+
+extern "C" int mi_lte_dl_frontend_batch(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const void *d_samples_a,
+                                        const void *d_samples_b, const uint64_t *d_unit_start,
+                                        const uint32_t *d_subfr_num, const uint32_t *d_n_id_cell, uint32_t n_units,
+                                        float *d_subframes)
+{
+    if (!ctx || !cfg || !d_samples_a || !d_unit_start || !d_subfr_num || !d_n_id_cell || !d_subframes || n_units == 0)
+        return MI_LTE_ERR_INVALID_ARG;
+    DlGeom g;
+    int    rc = make_geom(cfg, &g);
+    if (rc != MI_LTE_OK) return rc;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    rc = mi_ctx_gold_tables(ctx);
+    if (rc != MI_LTE_OK) return rc;
+    const size_t lds_fft = sizeof(float2) * (g.N + g.N / 32 + 1);
+    if (cfg->sample_format == MI_LTE_IQ_I8) {
+        SampleSrc<int8_t> s{(const int8_t *)d_samples_a};
+        MI_LAUNCH(ctx, "k_dl_fft", (k_dl_fft<int8_t>), dim3(16, n_units), dim3(256), lds_fft, s, d_unit_start, g, d_subframes);
+    } else if (cfg->sample_format == MI_LTE_IQ_F32_PLANAR) {
+        if (!d_samples_b) return MI_LTE_ERR_INVALID_ARG;
+        SampleSrc<float> s{(const float *)d_samples_a, (const float *)d_samples_b};
+        MI_LAUNCH(ctx, "k_dl_fft", (k_dl_fft<float>), dim3(16, n_units), dim3(256), lds_fft, s, d_unit_start, g, d_subframes);
+    } else
+        return MI_LTE_ERR_INVALID_ARG;
+    GoldTables gt{ctx->d_gold_x1, ctx->d_gold_x2b, ctx->gold_words};
+    const size_t lds_ce = sizeof(float) * 10 * 12 * g.N_rb_dl;
+    MI_LAUNCH(ctx, "k_dl_ce", k_dl_ce, dim3(n_units, g.N_ant), dim3(256), lds_ce, d_subfr_num, d_n_id_cell, g, gt, d_subframes);
+    MI_HIP_CHECK(ctx, hipGetLastError());
+    ctx->last_kernels = "k_dl_fft:1,k_dl_ce:1";
+    return MI_LTE_OK;
+}

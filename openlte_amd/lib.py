@@ -13,6 +13,29 @@ TURBO_REF, TURBO_BCJR = 0, 1
 _SOFT_OF_DTYPE = {np.dtype(np.float32): SOFT_F32, np.dtype(np.int8): SOFT_I8, np.dtype(np.int16): SOFT_I16}
 
 
+IQ_I8, IQ_F32_PLANAR = 0, 1
+
+
+class DlCfg(C.Structure):
+    """mi_lte_dl_cfg"""
+    _fields_ = [("fft_size", C.c_uint32), ("N_rb_dl", C.c_uint32), ("N_ant", C.c_uint32), ("sample_format", C.c_uint32)]
+
+
+class PdschAlloc(C.Structure):
+    """mi_lte_pdsch_alloc"""
+    _fields_ = [(n, C.c_uint32) for n in ("unit", "mod_type", "tbs", "rv_idx", "tx_mode", "rnti", "N_prb", "reserved")] + \
+               [("prb", (C.c_uint8 * 112) * 2)]
+
+
+def make_alloc(unit, mod_type, tbs, prbs, rnti, rv_idx=0, tx_mode=1, prbs_slot1=None):
+    a = PdschAlloc()
+    a.unit, a.mod_type, a.tbs, a.rv_idx, a.tx_mode, a.rnti, a.N_prb = unit, mod_type, tbs, rv_idx, tx_mode, rnti, len(prbs)
+    for i, p in enumerate(prbs):
+        a.prb[0][i] = p
+        a.prb[1][i] = (prbs_slot1 or prbs)[i]
+    return a
+
+
 class MiLteError(RuntimeError):
     pass
 
@@ -62,6 +85,9 @@ def load_library():
     L.mi_lte_profile_reset.argtypes = [vp]
     L.mi_lte_profile_report.argtypes = [vp]
     L.mi_lte_profile_report.restype = C.c_char_p
+    L.mi_lte_subframe_floats.argtypes = [u32]
+    L.mi_lte_subframe_floats.restype = sz
+    L.mi_lte_dl_frontend_batch.argtypes = [vp, C.POINTER(DlCfg), vp, vp, vp, vp, vp, u32, vp]
     L.mi_lte_turbo_decode_batch.argtypes = [vp, vp, C.c_int, u32, u32, C.c_int, u32, C.c_int, vp]
     L.mi_lte_turbo_scratch_bytes.argtypes = [u32, u32]
     L.mi_lte_turbo_scratch_bytes.restype = sz
@@ -155,6 +181,38 @@ class Context:
 
     def last_kernels(self):
         return self.L.mi_lte_last_kernels(self.h).decode()
+
+    # ---- front end --------------------------------------------------------------------------
+    def subframe_floats(self, n_ant):
+        return self.L.mi_lte_subframe_floats(n_ant)
+
+    def dl_frontend_dev(self, cfg, d_a, d_b, d_start, d_sf, d_cell, n_units, d_subframes):
+        self._check(self.L.mi_lte_dl_frontend_batch(self.h, C.byref(cfg), d_a.ptr, d_b.ptr if d_b is not None else None,
+                                                    d_start.ptr, d_sf.ptr, d_cell.ptr, n_units, d_subframes.ptr))
+
+    def dl_frontend(self, cfg, samples, unit_start, subfr_num, n_id_cell):
+        """Host convenience.  samples: int8 [..., 2] interleaved I,Q, or a (i, q) pair of float32 arrays.
+        Returns float32 [n_units, 2 + 2*N_ant, 16, 1200] = (symb_re, symb_im, ce_re[p].., ce_im[p]..)."""
+        n = len(unit_start)
+        if isinstance(samples, tuple):
+            d_a, d_b = self.to_device(samples[0].astype(np.float32)), self.to_device(samples[1].astype(np.float32))
+            cfg.sample_format = IQ_F32_PLANAR
+        else:
+            d_a, d_b = self.to_device(samples.astype(np.int8)), None
+            cfg.sample_format = IQ_I8
+        d_start = self.to_device(np.asarray(unit_start, np.uint64))
+        d_sf = self.to_device(np.asarray(subfr_num, np.uint32))
+        d_cell = self.to_device(np.asarray(n_id_cell, np.uint32))
+        nf = self.subframe_floats(cfg.N_ant)
+        d_out = self.alloc(n * nf * 4)
+        d_out.zero()
+        try:
+            self.dl_frontend_dev(cfg, d_a, d_b, d_start, d_sf, d_cell, n, d_out)
+            return d_out.download(np.float32).reshape(n, 2 + 2 * cfg.N_ant, 16, 1200)
+        finally:
+            for b in (d_a, d_b, d_start, d_sf, d_cell, d_out):
+                if b is not None:
+                    b.free()
 
     # ---- turbo -------------------------------------------------------------------------------
     def turbo_decode_dev(self, d_soft, soft_type, K, n_cb, d_out, mode=TURBO_REF, n_iter=8, qpp_spec=False):

@@ -4,11 +4,20 @@ import ctypes as C
 
 import numpy as np
 
-from .lib import load_library, MiLteError
+from .lib import load_library, MiLteError, DlCfg, PdschAlloc
 
 _i8p = np.ctypeslib.ndpointer(np.int8, flags="C_CONTIGUOUS")
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 _u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+
+
+_u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+
+
+class SynthChannel(C.Structure):
+    """mi_lte_synth_channel"""
+    _fields_ = [("gain_min", C.c_double), ("gain_max", C.c_double), ("max_delay", C.c_double), ("snr_db", C.c_double),
+                ("peak", C.c_double), ("seed", C.c_uint64)]
 
 
 def _lib():
@@ -16,6 +25,10 @@ def _lib():
     if not getattr(L, "_synth_bound", False):
         L.mi_lte_synth_turbo_soft_i8.argtypes = [C.c_uint32, C.c_uint32, C.c_double, C.c_int, C.c_uint64, C.c_int, _i8p, _u8p]
         L.mi_lte_synth_turbo_soft_f32.argtypes = [C.c_uint32, C.c_uint32, C.c_double, C.c_uint64, C.c_int, _f32p, _u8p]
+        L.mi_lte_synth_unit_len.argtypes = [C.c_uint32]
+        L.mi_lte_synth_unit_len.restype = C.c_size_t
+        L.mi_lte_synth_dl_units_i8.argtypes = [C.POINTER(DlCfg), C.c_uint32, _u32p, _u32p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                               C.POINTER(SynthChannel), _i8p, _u8p, C.c_uint32]
         L._synth_bound = True
     return L
 
@@ -37,3 +50,28 @@ def turbo_soft_blocks_awgn(K, n, sigma=0.5, seed=1, ref_wrap=True):
     if rc != 0:
         raise MiLteError("mi_lte_synth_turbo_soft_f32 failed: %d" % rc)
     return tx, soft
+
+
+def unit_len(fft_size=2048):
+    return int(_lib().mi_lte_synth_unit_len(fft_size))
+
+
+def dl_units(cfg, subfr_num, n_id_cell, allocs, n_alloc, n_pdcch_symbs=2, gain=(0.5, 1.5), max_delay=8, snr_db=30.0,
+             peak=100.0, seed=1):
+    """Synthesise len(subfr_num) single-port subframe units.
+
+    allocs: list of PdschAlloc, n_alloc per unit (unit-major).  Returns (iq int8 [n, unit_len, 2],
+    tx_bits uint8 [n, n_alloc, max_tbs])."""
+    n = len(subfr_num)
+    ul = unit_len(cfg.fft_size)
+    iq = np.zeros((n, ul, 2), np.int8)
+    max_tbs = max([a.tbs for a in allocs], default=8)
+    tx = np.zeros((n, max(n_alloc, 1), max_tbs), np.uint8)
+    arr = (PdschAlloc * max(len(allocs), 1))(*allocs)
+    ch = SynthChannel(gain[0], gain[1], float(max_delay), float(snr_db), float(peak), int(seed))
+    rc = _lib().mi_lte_synth_dl_units_i8(C.byref(cfg), n, np.ascontiguousarray(subfr_num, np.uint32),
+                                         np.ascontiguousarray(n_id_cell, np.uint32), n_pdcch_symbs,
+                                         C.cast(arr, C.c_void_p), n_alloc, C.byref(ch), iq, tx, max_tbs)
+    if rc != 0:
+        raise MiLteError("mi_lte_synth_dl_units_i8 failed: %d" % rc)
+    return iq, tx

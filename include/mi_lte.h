@@ -117,6 +117,35 @@ typedef struct {
     uint8_t  prb[2][112];    /* PRB indices per slot (alloc->prb[L/7][...]), first N_prb valid    */
 } mi_lte_pdsch_alloc;
 
+/* ---------------------------------------------------------------- PDSCH decode
+ * Replaces liblte_phy_pdsch_channel_decode() (liblte/hdr/liblte_phy.h:906-913, implementation
+ * liblte/src/liblte_phy.cc:3690-3853) and, under it, dlsch_channel_decode() (:12762-12872) for a
+ * batch of allocations over a batch of device subframes produced by mi_lte_dl_frontend_batch:
+ * RE extraction, pre-decoding (single port, or the reference's transmit-diversity combiner),
+ * layer de-mapping, modulation de-mapping, descrambling, turbo rate un-matching
+ * (liblte_phy_rate_unmatch_turbo, liblte_phy.h:1311-1323), REF-mode turbo decoding, filler removal
+ * and the CRC24A check.  M_dl_harq = 8 and N_soft = 250368 are fixed as in the reference (:3843-3844).
+ *
+ * Envelope: one code block per transport block (tbs + 24 <= 6144); larger ones make plan_create
+ * return MI_LTE_ERR_UNSUPPORTED (the reference's own multi-block path is broken).
+ *
+ * A plan holds the device copy of the allocation list and its grouping by code-block size, so a
+ * repeated schedule (the benchmark, or a semi-static grant pattern) pays for planning once.
+ * Outputs of run():  d_out_bits[a*out_stride + i], i < tbs: decoded transport block of allocation a,
+ * one bit per byte (the reference's out_bits), meaningful when d_status[a] == 0;
+ * d_status[a]: 0 = LIBLTE_SUCCESS, 3 = LIBLTE_ERROR_DECODE_FAIL (CRC mismatch). */
+typedef struct mi_lte_pdsch_plan mi_lte_pdsch_plan;
+int      mi_lte_pdsch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, uint32_t N_pdcch_symbs,
+                                  const mi_lte_pdsch_alloc *h_allocs, uint32_t n_alloc, mi_lte_pdsch_plan **out);
+void     mi_lte_pdsch_plan_destroy(mi_lte_ctx *ctx, mi_lte_pdsch_plan *plan);
+uint32_t mi_lte_pdsch_plan_out_stride(const mi_lte_pdsch_plan *plan);
+int      mi_lte_pdsch_decode_run(mi_lte_ctx *ctx, mi_lte_pdsch_plan *plan, const float *d_subframes,
+                                 const uint32_t *d_subfr_num, const uint32_t *d_n_id_cell, uint8_t *d_out_bits,
+                                 int32_t *d_status);
+/* stage tap: device pointers to the descrambled soft bits (int8) of one allocation and to their count */
+int      mi_lte_pdsch_plan_soft_bits(const mi_lte_pdsch_plan *plan, uint32_t alloc, const int8_t **d_e,
+                                     const uint32_t **d_len);
+
 /* ---------------------------------------------------------------- turbo decode
  * Replaces turbo_decode() (liblte/src/liblte_phy.cc:10620-10845) for a batch of code blocks of one
  * size K.  Input layout is the reference's: per block 3*(K+4) soft values INTERLEAVED d[i*3+x]

@@ -1,0 +1,365 @@
+// PDSCH receive chain on gfx950: RE extraction + pre-decoding + demapping + descrambling in one kernel,
+// then DL-SCH decoding (rate un-matching fused into the turbo decoder's prep kernel, CRC fused into
+// its vote kernel; see turbo.hip).  Restates liblte_phy_pdsch_channel_decode
+// (liblte/src/liblte_phy.cc:3690-3853) -> dlsch_channel_decode (:12762-12872) for a batch of
+// allocations, inside the envelope the reference itself can decode (one code block per allocation,
+// SURVEY F4).
+#include <algorithm>
+#include <map>
+
+#include "ctx.hpp"
+
+namespace {
+
+constexpr int N_SC_MAX = 1200;
+
+struct DemodGeom { uint32_t N_rb_dl, N_ant, cfi, sf_stride; };
+struct GoldTables { const uint32_t *x1; const uint32_t *x2b; uint32_t words; };
+
+__device__ __forceinline__ uint32_t gold_word(const GoldTables &gt, uint32_t c_init, uint32_t w)
+{
+    uint32_t v = gt.x1[w];
+    for (uint32_t m = c_init; m; m &= m - 1) v ^= gt.x2b[(uint32_t)__builtin_ctz(m) * gt.words + w];
+    return v;
+}
+
+// PBCH / PSS / SSS window (liblte_phy.cc:3722-3742)
+__device__ __forceinline__ void sync_window(uint32_t N_rb_dl, uint32_t &first_sc, uint32_t &last_sc)
+{
+    switch (N_rb_dl) {
+    case 6:  first_sc = 0;           last_sc = 71;          break;
+    case 15: first_sc = 4 * 12 + 6;  last_sc = 11 * 12 - 7; break;
+    case 25: first_sc = 9 * 12 + 6;  last_sc = 16 * 12 - 7; break;
+    case 50: first_sc = 22 * 12;     last_sc = 28 * 12 - 1; break;
+    case 75: first_sc = 34 * 12 + 6; last_sc = 41 * 12 - 7; break;
+    default: first_sc = 47 * 12;     last_sc = 53 * 12 - 1; break;
+    }
+}
+// 12-bit mask of the sub-carriers of (symbol L, PRB prb) that carry PDSCH (liblte_phy.cc:3753-3789)
+__device__ __forceinline__ uint32_t pdsch_mask(uint32_t N_ant, uint32_t cell, uint32_t sf, uint32_t L, uint32_t prb,
+                                               uint32_t first_sc, uint32_t last_sc)
+{
+    uint32_t m = 0;
+    for (uint32_t j = 0; j < 12; j++) {
+        const uint32_t sc = prb * 12 + j;
+        bool skip = false;
+        if (N_ant == 1 && (L % 7) == 0 && (cell % 6) == (j % 6)) skip = true;
+        else if (N_ant == 1 && (L % 7) == 4 && ((cell + 3) % 6) == (j % 6)) skip = true;
+        else if (N_ant >= 2 && ((L % 7) == 0 || (L % 7) == 4) && (cell % 3) == (j % 3)) skip = true;
+        else if (N_ant == 4 && (L % 7) == 1 && (cell % 3) == (j % 3)) skip = true;
+        else {
+            const bool in_win = sc >= first_sc && sc <= last_sc;
+            if (sf == 0 && in_win && L >= 7 && L <= 10) skip = true;
+            else if ((sf == 0 || sf == 5) && in_win && (L == 5 || L == 6)) skip = true;
+        }
+        if (!skip) m |= 1u << j;
+    }
+    return m;
+}
+
+// get_soft_decision (liblte_phy.cc:13880-13900) with max_dist = 1
+__device__ __forceinline__ float soft_decision(float rx_re, float rx_im, float exp_re, float exp_im)
+{
+    const float d_re = rx_re - exp_re, d_im = rx_im - exp_im;
+    float dist = sqrtf(d_re * d_re + d_im * d_im);
+    const float cap = 1.0f - (1.0f / 120);
+    if (dist >= cap) dist = cap;
+    return 1.0f - dist;
+}
+
+// modulation_demapper (liblte_phy.cc:9502-9660) for one symbol; writes Q_m int8 values
+__device__ __forceinline__ void demap_symbol(float re, float im, uint32_t mod, int8_t *b)
+{
+    const float r2 = (float)(1 / sqrt(2.0)), t10 = (float)(2 / sqrt(10.0)), t42 = (float)(2 / sqrt(42.0)),
+                f42 = (float)(4 / sqrt(42.0)), s42 = (float)(6 / sqrt(42.0));
+    if (mod == 3) {
+        const float ar = fabsf(re), ai = fabsf(im);
+        b[0] = (re > 0) ? 127 : -127;
+        b[1] = (im > 0) ? 127 : -127;
+        if (ar < f42) { b[2] = 127;  b[4] = (ar > t42) ? 127 : -127; }
+        else          { b[2] = -127; b[4] = (ar < s42) ? 127 : -127; }
+        if (ai < f42) { b[3] = 127;  b[5] = (ai > t42) ? 127 : -127; }
+        else          { b[3] = -127; b[5] = (ai < s42) ? 127 : -127; }
+    } else if (mod == 2) {
+        b[0] = (re > 0) ? 127 : -127;
+        b[1] = (im > 0) ? 127 : -127;
+        b[2] = (fabsf(re) < t10) ? 127 : -127;
+        b[3] = (fabsf(im) < t10) ? 127 : -127;
+    } else if (mod == 1) {
+        const float ang = atan2f(im, re);
+        float er, ei;
+        if (((double)ang >= 0) && ((double)ang < M_PI / 2))        { er = r2;  ei = r2; }
+        else if (((double)ang >= -M_PI / 2) && ((double)ang < 0))  { er = r2;  ei = -r2; }
+        else if (((double)ang >= M_PI / 2) && ((double)ang < M_PI)) { er = -r2; ei = r2; }
+        else                                                       { er = -r2; ei = -r2; }
+        const int m = (int)(127 * soft_decision(re, im, er, ei));
+        b[0] = (int8_t)((er > 0) ? m : -m);
+        b[1] = (int8_t)((ei > 0) ? m : -m);
+    } else {
+        const float ang = atan2f(im, re);
+        if (((double)ang > -M_PI / 4) && ((double)ang < 3 * M_PI / 4)) b[0] = (int8_t)(int)(127 * soft_decision(re, im, r2, r2));
+        else                                                          b[0] = (int8_t)(-(int)(127 * soft_decision(re, im, -r2, -r2)));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pdsch_demod(const float *__restrict__ subframes, DemodGeom g,
+                                                     const mi_lte_pdsch_alloc *__restrict__ allocs,
+                                                     const uint32_t *__restrict__ subfr_num, const uint32_t *__restrict__ n_id_cell,
+                                                     GoldTables gt, int8_t *__restrict__ e_base, const uint32_t *__restrict__ e_off,
+                                                     uint32_t *__restrict__ e_len, uint32_t max_pairs)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smu[]; // offs[max_pairs+1] | masks[max_pairs] | cw[...]
+    __shared__ uint32_t part[256];
+    const uint32_t a_idx = blockIdx.x;
+    const mi_lte_pdsch_alloc &al = allocs[a_idx];
+    const uint32_t unit = al.unit, sf = subfr_num[unit], cell = n_id_cell[unit], N_ant = g.N_ant, N_prb = al.N_prb;
+    const uint32_t Qm = al.mod_type == 3 ? 6 : al.mod_type == 2 ? 4 : al.mod_type == 1 ? 2 : 1;
+    uint32_t *offs = smu, *masks = smu + max_pairs + 1, *cw = masks + max_pairs;
+    uint32_t first_sc, last_sc;
+    sync_window(g.N_rb_dl, first_sc, last_sc);
+
+    // ---- phase 1: which REs, in the reference's loop order L -> PRB -> sub-carrier (liblte_phy.cc:3744-3802)
+    const uint32_t n_pairs = (14 - g.cfi) * N_prb, per = (n_pairs + 255) / 256;
+    uint32_t local = 0;
+    for (uint32_t q = threadIdx.x * per; q < min((threadIdx.x + 1) * per, n_pairs); q++) {
+        const uint32_t L = g.cfi + q / N_prb, prb = al.prb[L / 7][q % N_prb];
+        const uint32_t m = pdsch_mask(N_ant, cell, sf, L, prb, first_sc, last_sc);
+        masks[q] = m;
+        local += __popc(m);
+    }
+    part[threadIdx.x] = local;
+    __syncthreads();
+    if (threadIdx.x < 64) { // exclusive scan of the 256 partial counts by one wave
+        uint32_t v[4], s = 0;
+        for (int k = 0; k < 4; k++) { v[k] = part[threadIdx.x * 4 + k]; s += v[k]; }
+        uint32_t incl = s;
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t n = __shfl_up(incl, o);
+            if ((int)threadIdx.x >= o) incl += n;
+        }
+        uint32_t run = incl - s;
+        for (int k = 0; k < 4; k++) { part[threadIdx.x * 4 + k] = run; run += v[k]; }
+    }
+    __syncthreads();
+    {
+        uint32_t run = part[threadIdx.x];
+        for (uint32_t q = threadIdx.x * per; q < min((threadIdx.x + 1) * per, n_pairs); q++) {
+            offs[q] = run;
+            run += __popc(masks[q]);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { // total = offset past the last pair
+        uint32_t tot = 0;
+        if (n_pairs) tot = offs[n_pairs - 1] + __popc(masks[n_pairs - 1]);
+        offs[n_pairs] = tot;
+    }
+    __syncthreads();
+    const uint32_t M_ap = offs[n_pairs];
+    // pre-decoder / layer de-mapper symbol counts (liblte_phy.cc:7683, 7693, 7720, 7497)
+    const uint32_t n_grp = M_ap / N_ant, M_symb = n_grp * N_ant, N_bits = M_symb * Qm;
+    if (threadIdx.x == 0) e_len[a_idx] = N_bits;
+
+    // ---- phase 2: scrambling sequence words (c_init per liblte_phy.cc:3831)
+    const uint32_t c_init = (al.rnti << 14) | (0u << 13) | (sf << 9) | cell, n_words = (N_bits + 31) / 32;
+    for (uint32_t w = threadIdx.x; w < n_words; w += blockDim.x) cw[w] = gold_word(gt, c_init, w);
+    __syncthreads();
+
+    // ---- phase 3: per group of N_ant REs: gather, pre-decode, de-map, descramble
+    const float *base = subframes + (size_t)unit * g.sf_stride;
+    const float *y_re_p = base, *y_im_p = base + 16 * N_SC_MAX;
+    const float *h_re_p = base + 2 * 16 * N_SC_MAX, *h_im_p = h_re_p + (size_t)N_ant * 16 * N_SC_MAX;
+    int8_t *e = e_base + e_off[a_idx];
+    auto locate = [&](uint32_t idx) -> uint32_t { // RE index -> L * 1200 + sub-carrier
+        uint32_t lo = 0, hi = n_pairs; // offs[lo] <= idx < offs[hi]
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (offs[mid] <= idx) lo = mid; else hi = mid;
+        }
+        uint32_t r = idx - offs[lo], m = masks[lo];
+        for (; r; r--) m &= m - 1;
+        const uint32_t j = (uint32_t)__builtin_ctz(m), L = g.cfi + lo / N_prb, prb = al.prb[L / 7][lo % N_prb];
+        return L * N_SC_MAX + prb * 12 + j;
+    };
+    for (uint32_t i = threadIdx.x; i < n_grp; i += blockDim.x) {
+        float x_re[4], x_im[4];
+        if (N_ant == 1) { // liblte_phy.cc:7684-7690
+            const uint32_t p = locate(i);
+            const float yr = y_re_p[p], yi = y_im_p[p], hr = h_re_p[p], hi = h_im_p[p];
+            const float hn = hr * hr + hi * hi;
+            x_re[0] = (yr * hr + yi * hi) / hn;
+            x_im[0] = (yi * hr - yr * hi) / hn;
+        } else if (N_ant == 2) { // Alamouti combiner with the reference's normaliser (liblte_phy.cc:7694-7717)
+            const uint32_t p0 = locate(2 * i), p1 = locate(2 * i + 1);
+            const float y0r = y_re_p[p0], y0i = y_im_p[p0], y1r = y_re_p[p1], y1i = y_im_p[p1];
+            const float h0r = h_re_p[p0], h0i = h_im_p[p0], h1r = h_re_p[16 * N_SC_MAX + p0], h1i = h_im_p[16 * N_SC_MAX + p0];
+            const float a0 = h0r * h0r + h0i * h0i, a1 = h1r * h1r + h1i * h1i;
+            const float hn = sqrtf(a0 * a0 + a1 * a1);
+            x_re[0] = (h0r * y0r + h0i * y0i + h1r * y1r + h1i * y1i) / hn;
+            x_im[0] = (h0r * y0i - h0i * y0r - h1r * y1i + h1i * y1r) / hn;
+            x_re[1] = (-h1r * y0r - h1i * y0i + h0r * y1r + h0i * y1i) / hn;
+            x_im[1] = (h1r * y0i - h1i * y0r + h0r * y1i - h0i * y1r) / hn;
+        } else { // N_ant == 4 (liblte_phy.cc:7721-7765); the M_ap % 4 != 0 tail is outside the envelope
+            const uint32_t p0 = locate(4 * i), p1 = locate(4 * i + 1), p2 = locate(4 * i + 2), p3 = locate(4 * i + 3);
+            const size_t   ps = 16 * N_SC_MAX;
+            const float y0r = y_re_p[p0], y0i = y_im_p[p0], y1r = y_re_p[p1], y1i = y_im_p[p1];
+            const float y2r = y_re_p[p2], y2i = y_im_p[p2], y3r = y_re_p[p3], y3i = y_im_p[p3];
+            const float h0r = h_re_p[p0], h0i = h_im_p[p0], h2r = h_re_p[2 * ps + p0], h2i = h_im_p[2 * ps + p0];
+            const float h1r = h_re_p[ps + p2], h1i = h_im_p[ps + p2], h3r = h_re_p[3 * ps + p2], h3i = h_im_p[3 * ps + p2];
+            const float a0 = h0r * h0r + h0i * h0i, a1 = h1r * h1r + h1i * h1i, a2 = h2r * h2r + h2i * h2i, a3 = h3r * h3r + h3i * h3i;
+            const float n02 = sqrtf(a0 * a0 + a2 * a2), n13 = sqrtf(a1 * a1 + a3 * a3);
+            x_re[0] = (h0r * y0r + h0i * y0i + h2r * y1r + h2i * y1i) / n02;
+            x_im[0] = (h0r * y0i - h0i * y0r - h2r * y1i + h2i * y1r) / n02;
+            x_re[1] = (-h2r * y0r - h2i * y0i + h0r * y1r + h0i * y1i) / n02;
+            x_im[1] = -(-h2r * y0i + h2i * y0r - h0r * y1i + h0i * y1r) / n02;
+            x_re[2] = (h1r * y2r + h1i * y2i + h3r * y3r + h3i * y3i) / n13;
+            x_im[2] = (h1r * y2i - h1i * y2r - h3r * y3i + h3i * y3r) / n13;
+            x_re[3] = (-h3r * y2r - h3i * y2i + h1r * y3r + h1i * y3i) / n13;
+            x_im[3] = -(-h3r * y2i + h3i * y2r - h1r * y3i + h1i * y3r) / n13;
+        }
+        // layer de-mapping d[i*N_ant + p] = x_p[i] (liblte_phy.cc:7506-7513), de-map, descramble (:3833-3836)
+        for (uint32_t p = 0; p < N_ant; p++) {
+            int8_t b[6];
+            demap_symbol(x_re[p], x_im[p], al.mod_type, b);
+            const uint32_t n0 = (i * N_ant + p) * Qm;
+            for (uint32_t k = 0; k < Qm; k++) {
+                const uint32_t n = n0 + k, c = (cw[n >> 5] >> (n & 31)) & 1u;
+                e[n] = c ? (int8_t)-b[k] : b[k];
+            }
+        }
+    }
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host side: plans
+
+struct mi_lte_pdsch_plan {
+    mi_lte_dl_cfg cfg;
+    uint32_t      cfi = 0, n_alloc = 0, out_stride = 0, max_pairs = 0, max_words = 0;
+    size_t        e_bytes = 0;
+    mi_lte_pdsch_alloc *d_allocs = nullptr;
+    uint32_t *d_e_off = nullptr, *d_e_len = nullptr, *d_cb_alloc = nullptr;
+    int8_t   *d_e = nullptr;
+    struct Group { uint32_t K, n_cb, cb_base; };
+    std::vector<Group>    groups;
+    std::vector<uint32_t> h_e_off;
+};
+
+static uint32_t qpp_size_at_least(uint32_t B);
+#include "lte_tables.h"
+static uint32_t qpp_size_at_least(uint32_t B)
+{
+    for (int r = 0; r < LTE_QPP_N_SIZES; r++)
+        if (LTE_QPP_ROWS[r].K >= B) return LTE_QPP_ROWS[r].K;
+    return 0;
+}
+
+extern "C" {
+
+int mi_lte_pdsch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, uint32_t N_pdcch_symbs,
+                             const mi_lte_pdsch_alloc *h_allocs, uint32_t n_alloc, mi_lte_pdsch_plan **out)
+{
+    if (!ctx || !cfg || !h_allocs || !out || n_alloc == 0 || N_pdcch_symbs < 1 || N_pdcch_symbs > 4) return MI_LTE_ERR_INVALID_ARG;
+    if (!(cfg->N_ant == 1 || cfg->N_ant == 2 || cfg->N_ant == 4)) return MI_LTE_ERR_INVALID_ARG;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    auto *pl      = new mi_lte_pdsch_plan();
+    pl->cfg       = *cfg;
+    pl->cfi       = N_pdcch_symbs;
+    pl->n_alloc   = n_alloc;
+    std::map<uint32_t, std::vector<uint32_t>> byK;
+    uint32_t max_tbs = 0;
+    size_t   off = 0;
+    pl->h_e_off.resize(n_alloc);
+    for (uint32_t a = 0; a < n_alloc; a++) {
+        const mi_lte_pdsch_alloc &al = h_allocs[a];
+        const uint32_t B = al.tbs + 24, K = (B <= 6144) ? qpp_size_at_least(B) : 0;
+        if (K == 0 || al.N_prb == 0 || al.N_prb > cfg->N_rb_dl || al.mod_type > 3) {
+            // multi-code-block transport blocks: the reference's own C > 1 path is broken
+            ctx->err = "allocation outside the single-code-block envelope (tbs + 24 > 6144) or malformed";
+            delete pl;
+            return MI_LTE_ERR_UNSUPPORTED;
+        }
+        byK[K].push_back(a);
+        max_tbs = std::max(max_tbs, al.tbs);
+        const uint32_t Qm = al.mod_type == 3 ? 6 : al.mod_type == 2 ? 4 : al.mod_type == 1 ? 2 : 1;
+        const uint32_t pairs = (14 - N_pdcch_symbs) * al.N_prb, e_max = pairs * 12 * Qm;
+        pl->max_pairs = std::max(pl->max_pairs, pairs);
+        pl->max_words = std::max(pl->max_words, (e_max + 31) / 32);
+        pl->h_e_off[a] = (uint32_t)off;
+        off += (e_max + 63) & ~63u;
+    }
+    if (pl->max_words > 4096) {
+        ctx->err = "allocation larger than the scrambling table";
+        delete pl;
+        return MI_LTE_ERR_UNSUPPORTED;
+    }
+    pl->e_bytes    = off;
+    pl->out_stride = (max_tbs + 63) & ~63u;
+    std::vector<uint32_t> cb_alloc;
+    for (auto &kv : byK) {
+        pl->groups.push_back({kv.first, (uint32_t)kv.second.size(), (uint32_t)cb_alloc.size()});
+        cb_alloc.insert(cb_alloc.end(), kv.second.begin(), kv.second.end());
+    }
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_allocs, sizeof(mi_lte_pdsch_alloc) * n_alloc));
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_e_off, sizeof(uint32_t) * n_alloc));
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_e_len, sizeof(uint32_t) * n_alloc));
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_cb_alloc, sizeof(uint32_t) * n_alloc));
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_e, pl->e_bytes ? pl->e_bytes : 64));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_allocs, h_allocs, sizeof(mi_lte_pdsch_alloc) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_e_off, pl->h_e_off.data(), sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_cb_alloc, cb_alloc.data(), sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    *out = pl;
+    return MI_LTE_OK;
+}
+
+void mi_lte_pdsch_plan_destroy(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl)
+{
+    if (!pl) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    (void)hipFree(pl->d_allocs);
+    (void)hipFree(pl->d_e_off);
+    (void)hipFree(pl->d_e_len);
+    (void)hipFree(pl->d_cb_alloc);
+    (void)hipFree(pl->d_e);
+    delete pl;
+}
+
+uint32_t mi_lte_pdsch_plan_out_stride(const mi_lte_pdsch_plan *pl) { return pl ? pl->out_stride : 0; }
+
+int mi_lte_pdsch_plan_soft_bits(const mi_lte_pdsch_plan *pl, uint32_t alloc, const int8_t **d_e, const uint32_t **d_len)
+{
+    if (!pl || alloc >= pl->n_alloc || !d_e || !d_len) return MI_LTE_ERR_INVALID_ARG;
+    *d_e   = pl->d_e + pl->h_e_off[alloc];
+    *d_len = pl->d_e_len + alloc;
+    return MI_LTE_OK;
+}
+
+int mi_lte_pdsch_decode_run(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, const float *d_subframes, const uint32_t *d_subfr_num,
+                            const uint32_t *d_n_id_cell, uint8_t *d_out_bits, int32_t *d_status)
+{
+    if (!ctx || !pl || !d_subframes || !d_subfr_num || !d_n_id_cell || !d_out_bits || !d_status) return MI_LTE_ERR_INVALID_ARG;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    int rc = mi_ctx_gold_tables(ctx);
+    if (rc != MI_LTE_OK) return rc;
+    DemodGeom  g{pl->cfg.N_rb_dl, pl->cfg.N_ant, pl->cfi, (uint32_t)mi_lte_subframe_floats(pl->cfg.N_ant)};
+    GoldTables gt{ctx->d_gold_x1, ctx->d_gold_x2b, ctx->gold_words};
+    const size_t lds = sizeof(uint32_t) * (2 * (size_t)pl->max_pairs + 1 + pl->max_words);
+    MI_LAUNCH(ctx, "k_pdsch_demod", k_pdsch_demod, dim3(pl->n_alloc), dim3(256), lds, d_subframes, g, pl->d_allocs, d_subfr_num,
+              d_n_id_cell, gt, pl->d_e, pl->d_e_off, pl->d_e_len, pl->max_pairs);
+    MI_HIP_CHECK(ctx, hipGetLastError());
+    for (auto &gr : pl->groups) {
+        rc = mi_turbo_ref_group(ctx, gr.K, gr.n_cb, pl->d_allocs, pl->d_cb_alloc + gr.cb_base, pl->d_e, pl->d_e_off, pl->d_e_len,
+                                d_out_bits, pl->out_stride, d_status);
+        if (rc != MI_LTE_OK) return rc;
+    }
+    ctx->last_kernels = "k_pdsch_demod:1,k_turbo_prep,k_turbo_siso,k_turbo_perm,k_turbo_vote per block size";
+    return MI_LTE_OK;
+}
+
+} // extern "C"

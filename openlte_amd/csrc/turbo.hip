@@ -102,8 +102,110 @@ struct PrepOut { uint8_t *arr[6]; }; // X0 X1 X2 I0 M1 M2
 //   M[t] = (int8)(127*(w_t/W)), w_t = |in[2t]|+|in[2t+1]|, W = max_t w_t   liblte_phy.cc:10449,10498-10524
 //   (the branch weight is the same for every state, so the reference's path-dependent max_weight
 //    reduces to max_t w_t; the sign is applied by the traceback)
-template <typename T>
-__global__ __launch_bounds__(256) void k_turbo_prep(const T *__restrict__ soft, uint32_t K, uint32_t n_cb,
+// ---- where the soft values of a code block come from
+// (a) directly from the caller, in the reference's interleaved d[i*3+x] layout
+template <typename T> struct SrcDirect {
+    const T *soft;
+    const T *d;
+    __device__ __forceinline__ void init(uint32_t cb, uint32_t K) { d = soft + (size_t)cb * 3 * (K + 4); }
+    __device__ __forceinline__ float get(uint32_t i, int x) const
+    {
+        float v = (float)d[i * 3 + x];
+        return (v == (float)RX_NULL_AS_INT) ? 0.0f : v; // Step 0 (liblte_phy.cc:10636-10642)
+    }
+};
+
+// (b) from rate-matched, descrambled soft bits e[0..E) of a PDSCH allocation: turbo rate
+// un-matching (liblte_phy_rate_unmatch_turbo, liblte_phy.cc:11246-11490) fused in as a gather.
+// The circular buffer w[0..3*K_pi) holds, column-major, the sub-block-interleaved streams; the only
+// NULL positions the reference's receiver honours are the N_d = 32R - D head-padding slots of each
+// stream.  Walking w from k0 and consuming one e per non-NULL position means position p
+// receives e[rank(p) + t*Nnn], t = 0,1,.. (repeats are soft-combined by addition, :11402-11416), with
+// rank(p) = number of non-NULL positions between k0 and p in walk order.  Head padding sits in row 0,
+// so "NULLs below p" is a popcount over the 32 columns.
+struct RmGeom {
+    uint32_t R, K_pi, N_d, N_cb, k0m, Nnn, cnt_k0, mask0, mask2;
+    __device__ __forceinline__ static uint32_t lowmask(uint32_t n) { return n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u); }
+    __device__ __forceinline__ uint32_t nulls_below(uint32_t p) const
+    {
+        if (p <= K_pi) return __popc(mask0 & lowmask((p + R - 1) / R));
+        const uint32_t q = p - K_pi, a = (q + 1) >> 1, b = q >> 1;
+        return __popc(mask0) + __popc(mask0 & lowmask((a + R - 1) / R)) + __popc(mask2 & lowmask((b + R - 1) / R)) +
+               ((b > K_pi - 1) ? 1u : 0u);
+    }
+    __device__ __forceinline__ uint32_t cnt(uint32_t p) const { return p - nulls_below(p); }
+    // geometry per liblte_phy.cc:11283-11287 (R), :11371-11399 (K_w, N_ir, N_cb, k0) with the constants
+    // liblte_phy_pdsch_channel_decode passes (M_dl_harq = 8, N_soft = 250368, :3843-3844), C = 1
+    __device__ __forceinline__ void init(uint32_t D, uint32_t tx_mode, uint32_t rv)
+    {
+        R    = (D + 31) / 32;
+        K_pi = 32 * R;
+        N_d  = K_pi - D;
+        const uint32_t K_w = 3 * K_pi, K_mimo = (tx_mode == 3 || tx_mode == 4 || tx_mode == 8 || tx_mode == 9) ? 2 : 1;
+        const uint32_t N_ir = 250368 / (K_mimo * 8);
+        N_cb = N_ir < K_w ? N_ir : K_w;
+        const uint32_t k0 = R * (2 * ((N_cb + 8 * R - 1) / (8 * R)) * rv + 2);
+        k0m  = k0 % N_cb;
+        mask0 = mask2 = 0;
+        for (uint32_t c = 0; c < 32; c++) {
+            const uint32_t P = __brev(c) >> 27; // inter-column permutation = 5-bit reversal (36.212 table 5.1.4-1)
+            if (P < N_d) mask0 |= 1u << c;
+            if (P + 1 < N_d) mask2 |= 1u << c;
+        }
+        Nnn    = cnt(N_cb);
+        cnt_k0 = cnt(k0m);
+    }
+    // circular-buffer position of d[i*3+x]
+    __device__ __forceinline__ uint32_t pos(uint32_t i, int x) const
+    {
+        const uint32_t n = i + N_d;
+        if (x == 2) {
+            const uint32_t m = n - 1, ii = (__brev(m & 31) >> 27) * R + (m >> 5);
+            return K_pi + 2 * ii + 1;
+        }
+        const uint32_t ii = (__brev(n & 31) >> 27) * R + (n >> 5);
+        return x == 0 ? ii : K_pi + 2 * ii;
+    }
+};
+
+struct GroupDesc {                 // one launch = the code blocks of one size K out of a PDSCH batch
+    const mi_lte_pdsch_alloc *allocs;
+    const uint32_t *cb_alloc;      // [n_cb] allocation index of each code-block slot
+    const int8_t   *e_base;        // descrambled soft bits of all allocations
+    const uint32_t *e_off;         // [n_alloc] byte offset of an allocation's soft bits
+    const uint32_t *e_len;         // [n_alloc] E (written by the demodulation kernel)
+    uint8_t        *out_bits;      // [n_alloc][out_stride] decoded transport block, one bit per byte
+    uint32_t        out_stride;
+    int32_t        *status;        // [n_alloc] LIBLTE_ERROR_ENUM value
+    const uint32_t *crc_tab;       // x^(e+24) mod gCRC24A for e = 0..6143
+};
+
+struct SrcRateUnmatch {
+    GroupDesc     g;
+    RmGeom        rm;
+    const int8_t *e;
+    uint32_t      E;
+    __device__ __forceinline__ void init(uint32_t cb, uint32_t K)
+    {
+        const uint32_t a = g.cb_alloc[cb];
+        rm.init(K + 4, g.allocs[a].tx_mode, g.allocs[a].rv_idx);
+        e = g.e_base + g.e_off[a];
+        E = g.e_len[a];
+    }
+    __device__ __forceinline__ float get(uint32_t i, int x) const
+    {
+        const uint32_t p = rm.pos(i, x);
+        if (p >= rm.N_cb) return 0.0f; // never filled -> RX_NULL_BIT -> 0 in Step 0
+        const uint32_t c = rm.cnt(p);
+        uint32_t       k = (p >= rm.k0m) ? c - rm.cnt_k0 : rm.Nnn - rm.cnt_k0 + c;
+        float          v = 0.0f;
+        for (; k < E; k += rm.Nnn) v += (float)e[k];
+        return v;
+    }
+};
+
+template <typename Src>
+__global__ __launch_bounds__(256) void k_turbo_prep(Src src, uint32_t K, uint32_t n_cb,
                                                     const uint16_t *__restrict__ pi, PrepOut out)
 {
     extern __shared__ __attribute__((aligned(16))) int8_t sm[];
@@ -111,29 +213,20 @@ __global__ __launch_bounds__(256) void k_turbo_prep(const T *__restrict__ soft, 
     __shared__ int   red_i[4];
     const uint32_t cb = blockIdx.x, tile = cb >> 6, lane = cb & 63, Kp = kpad64(K);
     const size_t   tile_off = (size_t)tile * Kp * 64;
-    const T       *d = soft + (size_t)cb * 3 * (K + 4);
     int8_t *q0 = sm, *q1 = q0 + Kp, *q2 = q1 + Kp, *i0 = q2 + Kp, *m1 = i0 + Kp, *m2 = m1 + Kp;
+    src.init(cb, K);
 
     float mx = 0.0f;
-    for (uint32_t i = threadIdx.x; i < K; i += blockDim.x) {
-        for (int x = 0; x < 3; x++) {
-            float v = soft_to_float(d[i * 3 + x]);
-            if (v == (float)RX_NULL_AS_INT) v = 0.0f;
-            mx = fmaxf(mx, fabsf(v));
-        }
-    }
+    for (uint32_t i = threadIdx.x; i < K; i += blockDim.x)
+        for (int x = 0; x < 3; x++) mx = fmaxf(mx, fabsf(src.get(i, x)));
     mx = block_max_f(mx, red_f);
 
     for (uint32_t i = threadIdx.x; i < Kp; i += blockDim.x) {
         int a = 0, b = 0, c = 0;
         if (i < K) {
-            float v0 = soft_to_float(d[i * 3 + 0]), v1 = soft_to_float(d[i * 3 + 1]), v2 = soft_to_float(d[i * 3 + 2]);
-            if (v0 == (float)RX_NULL_AS_INT) v0 = 0.0f;
-            if (v1 == (float)RX_NULL_AS_INT) v1 = 0.0f;
-            if (v2 == (float)RX_NULL_AS_INT) v2 = 0.0f;
-            a = (int)(v0 * 127.0f / mx);
-            b = (int)(v1 * 127.0f / mx);
-            c = (int)(v2 * 127.0f / mx);
+            a = (int)(src.get(i, 0) * 127.0f / mx);
+            b = (int)(src.get(i, 1) * 127.0f / mx);
+            c = (int)(src.get(i, 2) * 127.0f / mx);
         }
         q0[i] = (int8_t)a;
         q1[i] = (int8_t)b;
@@ -344,10 +437,16 @@ __global__ __launch_bounds__(256) void k_turbo_perm(PermArgs a, uint32_t K, cons
 // vote: Steps 2-3 (again, C1 is cheap to recompute), 8-14.  One workgroup per code block.
 struct VoteArgs { const uint8_t *X0, *A1, *B1, *B2; };
 
+// GROUP = false: write the K hard bits of block cb to c_bits (turbo_decode's own output).
+// GROUP = true : finish dlsch_channel_decode (liblte_phy.cc:12840-12869): drop the F filler positions
+//                (liblte_phy_code_block_desegmentation, :9948-9986), check CRC24A (calc_crc :9713-9743)
+//                and report LIBLTE_SUCCESS / LIBLTE_ERROR_DECODE_FAIL like liblte_phy_pdsch_channel_decode.
+template <bool GROUP>
 __global__ __launch_bounds__(256) void k_turbo_vote(VoteArgs a, uint32_t K, const uint16_t *__restrict__ inv,
-                                                    uint8_t *__restrict__ c_bits)
+                                                    uint8_t *__restrict__ c_bits, GroupDesc g)
 {
     extern __shared__ __attribute__((aligned(16))) int8_t sm[];
+    __shared__ uint32_t red_u[4];
     const uint32_t cb = blockIdx.x, tile = cb >> 6, lane = cb & 63, Kp = kpad64(K);
     const size_t   tile_off = (size_t)tile * Kp * 64;
     int8_t *x0 = sm, *a1 = x0 + Kp, *b1 = a1 + Kp, *b2 = b1 + Kp, *d1 = b2 + Kp, *d2 = d1 + Kp;
@@ -373,13 +472,41 @@ __global__ __launch_bounds__(256) void k_turbo_vote(VoteArgs a, uint32_t K, cons
         d2[i] = (int8_t)v2;
     }
     __syncthreads();
+    uint32_t alloc = 0, tbs = 0, F = 0, crc = 0, par = 0;
     uint8_t *o = c_bits + (size_t)cb * K;
+    if (GROUP) {
+        alloc = g.cb_alloc[cb];
+        tbs   = g.allocs[alloc].tbs;
+        F     = K - tbs - 24;
+        o     = g.out_bits + (size_t)alloc * g.out_stride;
+    }
     for (uint32_t j = threadIdx.x; j < K; j += blockDim.x) {
         const int      c1 = soft_xor(a1[j], fb_at(a1, (int)j));
         const uint32_t i  = inv[j]; // Steps 12/13: de-interleave; a hole contributes 0
         const int      c2 = (i != 0xFFFFu) ? (int)d1[i] : 0;
         const int      c3 = (i != 0xFFFFu) ? (int)d2[i] : 0;
-        o[j] = ((int)x0[j] + c1 + c2 + c3 >= 0) ? 0 : 1; // Step 14
+        const uint32_t bit = ((int)x0[j] + c1 + c2 + c3 >= 0) ? 0u : 1u; // Step 14
+        if (!GROUP) o[j] = (uint8_t)bit;
+        else if (j >= F) {
+            const uint32_t m = j - F; // index into b = a (tbs bits) | p (24 bits)
+            if (m < tbs) {
+                o[m] = (uint8_t)bit;
+                if (bit) crc ^= g.crc_tab[tbs - 1 - m]; // CRC is linear: XOR of x^(e+24) mod g over the set bits
+            } else
+                par |= bit << (23 - (m - tbs));
+        }
+    }
+    if (GROUP) {
+        for (int s = 32; s > 0; s >>= 1) { crc ^= __shfl_xor(crc, s); par |= __shfl_xor(par, s); }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red_u[threadIdx.x >> 6] = crc;
+        __syncthreads();
+        crc = red_u[0] ^ red_u[1] ^ red_u[2] ^ red_u[3];
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red_u[threadIdx.x >> 6] = par;
+        __syncthreads();
+        par = red_u[0] | red_u[1] | red_u[2] | red_u[3];
+        if (threadIdx.x == 0) g.status[alloc] = (crc == par) ? 0 /* LIBLTE_SUCCESS */ : 3 /* LIBLTE_ERROR_DECODE_FAIL */;
     }
 }
 
@@ -399,8 +526,9 @@ extern "C" size_t mi_lte_turbo_scratch_bytes(uint32_t K, uint32_t n_cb)
     return n_tiles * Kp * 64 * N_BYTE_ARRAYS + 3 * n_tiles * Kp * 32;
 }
 
-template <typename T>
-static int turbo_ref_batch(mi_lte_ctx *ctx, const T *d_soft, uint32_t K, uint32_t n_cb, uint8_t *d_c_bits)
+// The five launches of one REF decode over n_cb code blocks of size K.
+template <typename Src, bool GROUP>
+static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, uint8_t *d_c_bits, GroupDesc gd)
 {
     TurboTables tb;
     int         rc = mi_ctx_turbo_tables(ctx, K, 0, &tb);
@@ -419,7 +547,7 @@ static int turbo_ref_batch(mi_lte_ctx *ctx, const T *d_soft, uint32_t K, uint32_
     PrepOut po;
     po.arr[0] = arr[AX0]; po.arr[1] = arr[AX1]; po.arr[2] = arr[AX2];
     po.arr[3] = arr[AI0]; po.arr[4] = arr[AM1]; po.arr[5] = arr[AM2];
-    MI_LAUNCH(ctx, "k_turbo_prep", (k_turbo_prep<T>), dim3(n_cb), dim3(256), 6 * Kp, d_soft, K, n_cb, tb.d_pi, po);
+    MI_LAUNCH(ctx, "k_turbo_prep", (k_turbo_prep<Src>), dim3(n_cb), dim3(256), 6 * Kp, src, K, n_cb, tb.d_pi, po);
 
     SisoArgs s1;
     s1.p[0] = {arr[AX1], arr[AX0], arr[AM1], arr[AA1], dec[0]};
@@ -436,10 +564,32 @@ static int turbo_ref_batch(mi_lte_ctx *ctx, const T *d_soft, uint32_t K, uint32_
     MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso, dim3(n_tiles, 2), dim3(64), 0, s23, K, 1u);
 
     VoteArgs va = {arr[AX0], arr[AA1], arr[AB1], arr[AB2]};
-    MI_LAUNCH(ctx, "k_turbo_vote", k_turbo_vote, dim3(n_cb), dim3(256), 6 * Kp, va, K, tb.d_inv, d_c_bits);
+    MI_LAUNCH(ctx, "k_turbo_vote", (k_turbo_vote<GROUP>), dim3(n_cb), dim3(256), 6 * Kp, va, K, tb.d_inv, d_c_bits, gd);
     MI_HIP_CHECK(ctx, hipGetLastError());
     ctx->last_kernels = "k_turbo_prep:1,k_turbo_siso:2,k_turbo_perm:1,k_turbo_vote:1";
     return MI_LTE_OK;
+}
+
+template <typename T>
+static int turbo_ref_batch(mi_lte_ctx *ctx, const T *d_soft, uint32_t K, uint32_t n_cb, uint8_t *d_c_bits)
+{
+    SrcDirect<T> src{d_soft, nullptr};
+    GroupDesc    none{};
+    return turbo_ref_run<SrcDirect<T>, false>(ctx, src, K, n_cb, d_c_bits, none);
+}
+
+// used by the PDSCH chain (chain.hip): decode the code blocks of one size K straight from the
+// demodulator's soft bits
+int mi_turbo_ref_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_pdsch_alloc *d_allocs,
+                       const uint32_t *d_cb_alloc, const int8_t *d_e, const uint32_t *d_e_off, const uint32_t *d_e_len,
+                       uint8_t *d_out_bits, uint32_t out_stride, int32_t *d_status)
+{
+    int rc = mi_ctx_crc_table(ctx);
+    if (rc != MI_LTE_OK) return rc;
+    GroupDesc gd{d_allocs, d_cb_alloc, d_e, d_e_off, d_e_len, d_out_bits, out_stride, d_status, ctx->d_crc_tab};
+    SrcRateUnmatch src;
+    src.g = gd;
+    return turbo_ref_run<SrcRateUnmatch, true>(ctx, src, K, n_cb, nullptr, gd);
 }
 
 extern "C" int mi_lte_turbo_decode_batch(mi_lte_ctx *ctx, const void *d_soft, mi_lte_soft_type soft_type, uint32_t K,

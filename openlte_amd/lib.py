@@ -88,6 +88,12 @@ def load_library():
     L.mi_lte_subframe_floats.argtypes = [u32]
     L.mi_lte_subframe_floats.restype = sz
     L.mi_lte_dl_frontend_batch.argtypes = [vp, C.POINTER(DlCfg), vp, vp, vp, vp, vp, u32, vp]
+    L.mi_lte_pdsch_plan_create.argtypes = [vp, C.POINTER(DlCfg), u32, vp, u32, C.POINTER(vp)]
+    L.mi_lte_pdsch_plan_destroy.argtypes = [vp, vp]
+    L.mi_lte_pdsch_plan_out_stride.argtypes = [vp]
+    L.mi_lte_pdsch_plan_out_stride.restype = u32
+    L.mi_lte_pdsch_decode_run.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.mi_lte_pdsch_plan_soft_bits.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(vp)]
     L.mi_lte_turbo_decode_batch.argtypes = [vp, vp, C.c_int, u32, u32, C.c_int, u32, C.c_int, vp]
     L.mi_lte_turbo_scratch_bytes.argtypes = [u32, u32]
     L.mi_lte_turbo_scratch_bytes.restype = sz
@@ -125,6 +131,54 @@ class DeviceBuffer:
         if self.ptr:
             self.ctx.L.mi_lte_free(self.ctx.h, self.ptr)
             self.ptr = None
+
+
+class PdschPlan:
+    """mi_lte_pdsch_plan: device copy of an allocation list, grouped by code-block size."""
+
+    def __init__(self, ctx, cfg, n_pdcch_symbs, allocs):
+        self.ctx, self.n_alloc = ctx, len(allocs)
+        arr = (PdschAlloc * len(allocs))(*allocs)
+        h = C.c_void_p()
+        ctx._check(ctx.L.mi_lte_pdsch_plan_create(ctx.h, C.byref(cfg), n_pdcch_symbs, C.cast(arr, C.c_void_p), len(allocs),
+                                                  C.byref(h)))
+        self.h = h
+        self.out_stride = ctx.L.mi_lte_pdsch_plan_out_stride(h)
+        self.tbs = [a.tbs for a in allocs]
+
+    def run_dev(self, d_subframes, d_sf, d_cell, d_out, d_status):
+        self.ctx._check(self.ctx.L.mi_lte_pdsch_decode_run(self.ctx.h, self.h, d_subframes.ptr, d_sf.ptr, d_cell.ptr,
+                                                           d_out.ptr, d_status.ptr))
+
+    def run(self, d_subframes, subfr_num, n_id_cell):
+        """Returns (status int32 [n_alloc], list of uint8 bit arrays)."""
+        ctx = self.ctx
+        d_sf, d_cell = ctx.to_device(np.asarray(subfr_num, np.uint32)), ctx.to_device(np.asarray(n_id_cell, np.uint32))
+        d_out, d_st = ctx.alloc(self.n_alloc * self.out_stride), ctx.alloc(4 * self.n_alloc)
+        d_out.zero()
+        try:
+            self.run_dev(d_subframes, d_sf, d_cell, d_out, d_st)
+            st = d_st.download(np.int32)
+            bits = d_out.download(np.uint8).reshape(self.n_alloc, self.out_stride)
+            return st, [bits[a, :self.tbs[a]] for a in range(self.n_alloc)]
+        finally:
+            for b in (d_sf, d_cell, d_out, d_st):
+                b.free()
+
+    def soft_bits(self, alloc):
+        """Descrambled int8 soft bits of one allocation (stage tap)."""
+        pe, pn = C.c_void_p(), C.c_void_p()
+        self.ctx._check(self.ctx.L.mi_lte_pdsch_plan_soft_bits(self.h, alloc, C.byref(pe), C.byref(pn)))
+        n = np.empty(1, np.uint32)
+        self.ctx._check(self.ctx.L.mi_lte_memcpy_d2h(self.ctx.h, n.ctypes.data, pn.value, 4))
+        out = np.empty(int(n[0]), np.int8)
+        self.ctx._check(self.ctx.L.mi_lte_memcpy_d2h(self.ctx.h, out.ctypes.data, pe.value, out.nbytes))
+        return out
+
+    def close(self):
+        if self.h:
+            self.ctx.L.mi_lte_pdsch_plan_destroy(self.ctx.h, self.h)
+            self.h = None
 
 
 class Context:
@@ -213,6 +267,10 @@ class Context:
             for b in (d_a, d_b, d_start, d_sf, d_cell, d_out):
                 if b is not None:
                     b.free()
+
+    # ---- PDSCH ------------------------------------------------------------------------------
+    def pdsch_plan(self, cfg, n_pdcch_symbs, allocs):
+        return PdschPlan(self, cfg, n_pdcch_symbs, allocs)
 
     # ---- turbo -------------------------------------------------------------------------------
     def turbo_decode_dev(self, d_soft, soft_type, K, n_cb, d_out, mode=TURBO_REF, n_iter=8, qpp_spec=False):

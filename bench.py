@@ -77,6 +77,9 @@ class TurboWorkload:
     def units_per_step(self):
         return self.n_cb
 
+    def roofline_bytes(self, kernel, n_launch_per_step):
+        return self.alg_bytes_per_unit * self.n_cb * n_launch_per_step
+
     def value_per_unit(self):
         return self.K / 1e6  # information Mbit per code block
 
@@ -107,15 +110,202 @@ class TurboWorkload:
                 "sample": "%d of the benchmark's K=%d code blocks, float soft values, 1 thread, %.1f s" % (n, K, t)}
 
 
-WORKLOADS = {"turbo": TurboWorkload}
+def _turbo_alg_bytes(K):
+    return 3 * (K + 4) + K // 8 + 4  # int8 soft in, packed bits + status out
+
+
+class ChainWorkload:
+    """BASELINE config 4 / SURVEY 8d W4 on one GPU per rank: 20 MHz, 100 RB, N_ant = 1, CFI = 2, every
+    subframe fully loaded with 9 x 64QAM allocations (8 x 12 PRB TBS 3240 + 1 x 4 PRB TBS 1064, one
+    code block each).  One step = FFT -> CE -> demap -> rate-unmatch -> turbo (REF) -> CRC over the
+    whole batch of subframes, int8 IQ resident in HBM, decoded bits + status left in HBM."""
+    name = "chain"
+    metric = "DL subframes/sec @20MHz 100RB 64QAM, full chain FFT->CE->demap->rate-unmatch->turbo(REF)->CRC (SURVEY 8d W4)"
+    unit = "subframes/s"
+    dtype = "i8 IQ in, f32 FFT/CE/equaliser, i8 soft bits, i32 path metrics"
+    alg_bytes_per_unit = 70240 + 26984 // 8  # fused accounting, SURVEY 8d: int8 IQ in + packed info bits out
+    dominant = "k_turbo_siso"
+    info_bits = 8 * 3240 + 1064
+
+    def __init__(self, ctx, n_units, rank):
+        import numpy as np
+        import openlte_amd as m
+        from openlte_amd import synth
+        import lte_testdata as td
+        self.ctx, self.m, self.np = ctx, m, np
+        self.n = n_units or 8192
+        self.cfg = m.DlCfg(2048, 100, 1, 0)
+        U = min(96, self.n)
+        sfs = np.array([[1, 2, 3, 4, 6, 7, 8, 9][i % 8] for i in range(U)], np.uint32)  # subframes 0/5 carry sync signals
+        cells = ((np.arange(U) * 37 + 11 * rank) % 504).astype(np.uint32)
+        allocs = []
+        for u in range(U):
+            allocs += td.w4_allocs(u)
+        iq, tx = synth.dl_units(self.cfg, sfs, cells, allocs, 9, snr_db=30.0, max_delay=8, seed=4242 + rank)
+        self.uniq = (iq, tx, sfs, cells, allocs)
+        idx = np.arange(self.n) % U
+        self.idx = idx
+        ul = iq.shape[1]
+        self.d_iq = ctx.to_device(iq[idx].reshape(-1, 2))
+        self.d_start = ctx.to_device((np.arange(self.n) * ul).astype(np.uint64))
+        self.d_sf = ctx.to_device(sfs[idx])
+        self.d_cell = ctx.to_device(cells[idx])
+        self.d_sub = ctx.alloc(self.n * ctx.subframe_floats(1) * 4)
+        all_allocs = []
+        for i in range(self.n):
+            all_allocs += td.w4_allocs(i)
+        self.plan = ctx.pdsch_plan(self.cfg, 2, all_allocs)
+        self.d_out = ctx.alloc(self.n * 9 * self.plan.out_stride)
+        self.d_status = ctx.alloc(self.n * 9 * 4)
+
+    def step(self):
+        self.ctx.dl_frontend_dev(self.cfg, self.d_iq, None, self.d_start, self.d_sf, self.d_cell, self.n, self.d_sub)
+        self.plan.run_dev(self.d_sub, self.d_sf, self.d_cell, self.d_out, self.d_status)
+
+    def units_per_step(self):
+        return self.n
+
+    def value_per_unit(self):
+        return 1.0
+
+    def extra(self, value):
+        np = self.np
+        st = self.d_status.download(np.int32)
+        bits = self.d_out.download(np.uint8).reshape(self.n * 9, self.plan.out_stride)
+        tx = self.uniq[1]
+        ok = int((st == 0).sum())
+        exact = all((bits[i * 9 + a, :(3240 if a < 8 else 1064)] == tx[self.idx[i], a, :(3240 if a < 8 else 1064)]).all()
+                    for i in range(0, self.n, max(1, self.n // 64)) for a in range(9))
+        return {"turbo_info_mbit_per_s": round(value * self.info_bits / 1e6, 2),
+                "crc_pass": "%d/%d allocations" % (ok, st.size), "sampled_blocks_equal_tx_bits": bool(exact)}
+
+    def roofline_bytes(self, kernel, n_launch_per_step):
+        """Algorithmic bytes the launches of `kernel` in ONE step account for (roofline table)."""
+        n = self.n
+        turbo = 8 * n * _turbo_alg_bytes(3264) + n * _turbo_alg_bytes(1088)
+        return {"k_dl_fft": n * (70240 + 16 * 1200 * 8), "k_dl_ce": n * (5 * 1200 * 8 + 14 * 1200 * 8),
+                "k_pdsch_demod": n * (8 * 1656 + 552) * (16 + 6),
+                "k_turbo_siso": 2 * turbo, "k_turbo_prep": turbo, "k_turbo_perm": turbo, "k_turbo_vote": turbo}.get(kernel)
+
+    def config(self, world):
+        return {"workload": "W4 full DL chain: 20 MHz/100 RB/64QAM, 9 allocations per subframe (8x12 PRB TBS 3240 + 1x4 PRB "
+                            "TBS 1064), %d subframes per GPU, int8 IQ in HBM" % self.n,
+                "subframes_per_gpu": self.n, "N_ant": 1, "CFI": 2, "decoder": "REF (reference-faithful, bit-exact)",
+                "unique_subframes": len(self.uniq[2]),
+                "sharding": "subframes block-cyclic over %d GPU(s), no collective" % world}
+
+    def cpu_baseline(self, budget_s=14.0):
+        """Reference CPU path on a bounded sample of the same subframes (1 thread)."""
+        import ctypes as C
+        np = self.np
+        from oracle import pyoracle as po
+        import lte_testdata as td
+        iq, tx, sfs, cells, allocs = self.uniq
+        R, P = po.ref(), po.port()
+        t_total, done, i = 0.0, 0, 0
+        phy = R.ref_phy_new(4, 0, 1, 100) if R is not None else None
+        sf_struct = R.ref_subframe_new() if R is not None else None
+        while t_total < budget_s and done < 4000:
+            u = i % len(sfs)
+            i += 1
+            sf, cell = int(sfs[u]), int(cells[u])
+            re = np.ascontiguousarray(np.concatenate([np.zeros(sf * 30720, np.float32), iq[u, :, 0].astype(np.float32)]))
+            im = np.ascontiguousarray(np.concatenate([np.zeros(sf * 30720, np.float32), iq[u, :, 1].astype(np.float32)]))
+            out, nb = np.zeros(6200, np.uint8), C.c_uint32()
+            t0 = time.perf_counter()
+            if R is not None:
+                R.ref_get_dl_subframe_and_ce(phy, re, im, 0, sf, cell, 1, sf_struct)
+                for a in range(9):
+                    la = td.to_lo_alloc(allocs[u * 9 + a])
+                    rc = R.ref_pdsch_channel_decode(phy, sf_struct, C.byref(la), 2, cell, 1, out, C.byref(nb))
+            else:
+                lc = po.LoCfg()
+                P.lo_cfg_init(C.byref(lc), 2048, 100)
+                s = po.LoSubframe()
+                P.lo_get_dl_subframe_and_ce(C.byref(lc), re, im, 0, sf, cell, 1, C.byref(s))
+                for a in range(9):
+                    la = td.to_lo_alloc(allocs[u * 9 + a])
+                    rc = P.lo_pdsch_channel_decode(C.byref(lc), C.byref(s), C.byref(la), 2, cell, 1, out, C.byref(nb), None, None)
+            t_total += time.perf_counter() - t0
+            done += 1
+        return {"value": round(done / t_total, 3), "unit": self.unit, "cores": 1,
+                "kind": "reference" if R is not None else "port",
+                "sample": "%d of the benchmark's subframes (get_dl_subframe_and_ce + 9 x pdsch_channel_decode each), 1 thread, "
+                          "%.1f s; FFT = float64 radix-2 stand-in for FFTW3f" % (done, t_total)}
+
+
+class FrontendWorkload:
+    """BASELINE config 2 / SURVEY 8d W2: 20 MHz OFDM demod + CRS channel estimate, 10k subframe units."""
+    name = "frontend"
+    metric = "DL subframes/sec @20MHz 100RB, OFDM demod + CRS channel estimate only (SURVEY 8d W2)"
+    unit = "subframes/s"
+    dtype = "i8 IQ in, f32 FFT/CE"
+    alg_bytes_per_unit = 339040
+    dominant = "k_dl_ce"
+
+    def __init__(self, ctx, n_units, rank):
+        import numpy as np
+        import openlte_amd as m
+        from openlte_amd import synth
+        import lte_testdata as td
+        self.ctx, self.np = ctx, np
+        self.n = n_units or 10000
+        self.cfg = m.DlCfg(2048, 100, 1, 0)
+        U = 64
+        sfs = (np.arange(U) % 10).astype(np.uint32)
+        cells = ((np.arange(U) * 37 + rank) % 504).astype(np.uint32)
+        allocs = []
+        for u in range(U):
+            allocs += td.w4_allocs(u)
+        iq, _ = synth.dl_units(self.cfg, sfs, cells, allocs, 9, snr_db=30.0, max_delay=8, seed=77 + rank)
+        self.uniq = (iq, sfs, cells)
+        idx = np.arange(self.n) % U
+        ul = iq.shape[1]
+        self.d_iq = ctx.to_device(iq[idx].reshape(-1, 2))
+        self.d_start = ctx.to_device((np.arange(self.n) * ul).astype(np.uint64))
+        self.d_sf, self.d_cell = ctx.to_device(sfs[idx]), ctx.to_device(cells[idx])
+        self.d_sub = ctx.alloc(self.n * ctx.subframe_floats(1) * 4)
+
+    def step(self):
+        self.ctx.dl_frontend_dev(self.cfg, self.d_iq, None, self.d_start, self.d_sf, self.d_cell, self.n, self.d_sub)
+
+    def units_per_step(self):
+        return self.n
+
+    def value_per_unit(self):
+        return 1.0
+
+    def roofline_bytes(self, kernel, n_launch_per_step):
+        return {"k_dl_fft": self.n * (70240 + 16 * 1200 * 8), "k_dl_ce": self.n * (5 * 1200 * 8 + 14 * 1200 * 8)}.get(kernel)
+
+    def config(self, world):
+        return {"workload": "W2 front end: 20 MHz/100 RB, %d subframe units per GPU, int8 IQ in HBM" % self.n,
+                "subframes_per_gpu": self.n, "N_ant": 1, "sharding": "subframes over %d GPU(s), no collective" % world}
+
+    def cpu_baseline(self, budget_s=10.0):
+        np = self.np
+        from oracle import pyoracle as po
+        R = po.ref()
+        iq, sfs, cells = self.uniq
+        if R is None:
+            return None
+        phy, sfp = R.ref_phy_new(4, 0, 1, 100), R.ref_subframe_new()
+        re = np.ascontiguousarray(iq[0, :, 0].astype(np.float32))
+        im = np.ascontiguousarray(iq[0, :, 1].astype(np.float32))
+        t = R.ref_time_get_dl_subframe_and_ce(phy, re, im, 0, 0, int(cells[0]), 1, sfp, 50)
+        reps = int(max(100, budget_s / (t / 50)))
+        t = R.ref_time_get_dl_subframe_and_ce(phy, re, im, 0, 0, int(cells[0]), 1, sfp, reps)
+        return {"value": round(reps / t, 2), "unit": self.unit, "cores": 1, "kind": "reference",
+                "sample": "%d calls of liblte_phy_get_dl_subframe_and_ce, 1 thread, %.1f s; FFT = float64 radix-2 stand-in" % (reps, t)}
+
+
+WORKLOADS = {"turbo": TurboWorkload, "frontend": FrontendWorkload, "chain": ChainWorkload}
 
 
 def pick_workload(name):
     if name != "auto":
         return WORKLOADS[name]
-    for k in ("chain", "frontend", "turbo"):
-        if k in WORKLOADS:
-            return WORKLOADS[k]
+    return WORKLOADS["chain"]
 
 
 def main():
@@ -153,26 +343,49 @@ def main():
     if rank == 0:
         units = wl.units_per_step() * world * args.steps
         value = units * wl.value_per_unit() / elapsed
-        dom = wl.dominant if wl.dominant in prof else max(prof, key=lambda k: prof[k][1])
+        dom = max(prof, key=lambda k: prof[k][1])  # the kernel with the largest share of the timed region
         n_launch, tot_ms = prof[dom]
         avg_ms = tot_ms / n_launch
-        alg_bytes = wl.alg_bytes_per_unit * wl.units_per_step()
+        per_kernel = {}
+        for k, (nl, ms) in prof.items():
+            b = wl.roofline_bytes(k, nl // args.steps) if hasattr(wl, "roofline_bytes") else None
+            if b is None:
+                b = wl.alg_bytes_per_unit * wl.units_per_step() * (nl // args.steps)
+            gbs = b * args.steps / (ms * 1e-3) / 1e9
+            per_kernel[k] = {"ms_per_step": round(ms / args.steps, 4), "launches_per_step": nl // args.steps,
+                             "alg_GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / HBM_PEAK_GBS, 4)}
+        alg_bytes = (wl.roofline_bytes(dom, n_launch // args.steps) if hasattr(wl, "roofline_bytes") else None) or \
+            wl.alg_bytes_per_unit * wl.units_per_step() * (n_launch // args.steps)
+        alg_bytes = alg_bytes / (n_launch // args.steps)  # per launch
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        try:  # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes of this command
+            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if tj.get("workload", wl.name) == wl.name:
+                traffic = tj["bytes_per_launch"].get(dom)
+        except Exception:
+            pass
         out = {
             "metric": wl.metric, "value": round(value, 3), "unit": wl.unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
             "config": wl.config(world),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" if traffic else None,
                          "avg_launch_ms": round(avg_ms, 4), "launches": n_launch,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "serial-trellis kernels are ALU/latency bound; see DESIGN.md"},
-            "kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items())},
+                         "note": "algorithmic bytes / measured launch time; trellis kernels are issue-bound, see DESIGN.md"},
+            "kernels": per_kernel,
+            "whole_chain_alg_GBps": round(wl.alg_bytes_per_unit * units / elapsed / 1e9, 2),
             "device": ctx.device_name,
         }
+        if hasattr(wl, "extra"):
+            out.update(wl.extra(value))
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = wl.cpu_baseline()
+            cb = wl.cpu_baseline()
+            if cb:
+                out["cpu_baseline"] = cb
         print(json.dumps(out))
     barrier()
     ctx.close()

@@ -167,11 +167,41 @@ int mi_lte_turbo_decode_batch(mi_lte_ctx *ctx, const void *d_soft, mi_lte_soft_t
                               uint32_t n_cb, mi_lte_turbo_mode mode, uint32_t n_iter, int qpp_spec,
                               uint8_t *d_c_bits);
 
+/* ---------------------------------------------------------------- turbo rate un-matching
+ * Replaces liblte_phy_rate_unmatch_turbo() (liblte/hdr/liblte_phy.h:1311-1323, implementation
+ * liblte/src/liblte_phy.cc:11246-11490) with its float interface, for n_cb code blocks that share
+ * one parameter set: e bits in (N_e_bits per block), interleaved d[i*3+x] out (3*D per block, D = the
+ * reference's N_dummy_bits = K+4), RX_NULL_BIT = 10000.0f where nothing was received.  chan_type uses
+ * LIBLTE_PHY_CHAN_TYPE_ENUM values (0 DLSCH, 1 PCH limit the soft buffer; 2 ULSCH, 3 ULCCH do not).
+ * (Inside mi_lte_pdsch_decode_run the same gather is fused into the decoder and never touches HBM.) */
+int mi_lte_rate_unmatch_turbo_batch(mi_lte_ctx *ctx, const float *d_e_bits, uint32_t N_e_bits, uint32_t D,
+                                    uint32_t N_codeblocks, uint32_t tx_mode, uint32_t N_soft, uint32_t M_dl_harq,
+                                    uint32_t chan_type, uint32_t rv_idx, uint32_t n_cb, float *d_d_bits);
+
 /* bytes of device scratch the decoder holds for (K, n_cb); grows on demand, reported for sizing */
 size_t mi_lte_turbo_scratch_bytes(uint32_t K, uint32_t n_cb);
 
 /* name and launch count of the kernels the last batch call issued (for bench.py / profiles) */
 const char *mi_lte_last_kernels(const mi_lte_ctx *ctx);
+
+/* ---------------------------------------------------------------- per-call host-pointer forms
+ * The bodies of the reference's three entry points on this path, for callers that hold host
+ * buffers exactly as the reference's callers do (LTE_fdd_dl_fs_samp_buf.cc:378-515,
+ * LTE_fdd_enb_phy.cc).  Each stages its arguments through HBM, runs the batch kernels with a batch
+ * of one, and copies the results back; shim/liblte_phy_shim.cc forwards the liblte_phy_* symbols
+ * here.  Return value: MI_LTE_* on infrastructure errors (< 0), else the LIBLTE_ERROR_ENUM value the
+ * reference would return (0 success, 1 invalid inputs, 3 decode fail). */
+int mi_lte_get_dl_subframe_and_ce_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_dl, const float *h_i_samps,
+                                       const float *h_q_samps, uint32_t frame_start_idx, uint32_t subfr_num,
+                                       uint32_t N_id_cell, uint32_t N_ant, float *h_rx_symb_re /*[16][1200]*/,
+                                       float *h_rx_symb_im, float *h_rx_ce_re /*[4][16][1200]*/, float *h_rx_ce_im);
+int mi_lte_pdsch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const float *h_rx_symb_re, const float *h_rx_symb_im,
+                                     const float *h_rx_ce_re, const float *h_rx_ce_im, uint32_t subfr_num,
+                                     const mi_lte_pdsch_alloc *alloc, uint32_t N_pdcch_symbs, uint32_t N_id_cell,
+                                     uint32_t N_ant, uint8_t *h_out_bits, uint32_t *N_out_bits);
+int mi_lte_rate_unmatch_turbo_host(mi_lte_ctx *ctx, const float *h_e_bits, uint32_t N_e_bits, uint32_t N_dummy_bits,
+                                   uint32_t N_codeblocks, uint32_t tx_mode, uint32_t N_soft, uint32_t M_dl_harq,
+                                   uint32_t chan_type, uint32_t rv_idx, float *h_d_bits, uint32_t *N_d_bits);
 
 /* ---------------------------------------------------------------- input synthesis (host side)
  * A minimal LTE downlink transmitter for benchmark / test captures, the role LTE_fdd_dl_file_gen

@@ -1,0 +1,114 @@
+// Per-call, host-pointer forms of the three reference entry points on the hot path (see
+// include/mi_lte.h).  They exist for drop-in use through shim/liblte_phy_shim.cc: stage through HBM,
+// run the same batch kernels with a batch of one, copy back.  No arithmetic happens on the host.
+#include <cstring>
+#include <vector>
+
+#include "ctx.hpp"
+
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) { return hipMalloc(&p, n ? n : 1) == hipSuccess ? 0 : -1; }
+};
+} // namespace
+
+extern "C" {
+
+// liblte_phy_get_dl_subframe_and_ce (liblte_phy.cc:5905-6200), argument checks as at :5937-5943
+int mi_lte_get_dl_subframe_and_ce_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_dl, const float *h_i, const float *h_q,
+                                       uint32_t frame_start_idx, uint32_t subfr_num, uint32_t N_id_cell, uint32_t N_ant,
+                                       float *h_symb_re, float *h_symb_im, float *h_ce_re, float *h_ce_im)
+{
+    if (!ctx) return MI_LTE_ERR_INVALID_ARG;
+    if (!h_i || !h_q || !(N_ant == 1 || N_ant == 2 || N_ant == 4) || !h_symb_re || !h_symb_im || !h_ce_re || !h_ce_im) return 1;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint32_t sc = 2048 / fft_size;
+    const size_t   per_sf = 30720 / sc, need = per_sf + 2 * fft_size + 160 / sc + 144 / sc - 1; // last sample symbol 15 reads, +1
+    const size_t   start = (size_t)frame_start_idx + (size_t)subfr_num * per_sf;
+    DevBuf d_i, d_q, d_par, d_sub;
+    const size_t nf = mi_lte_subframe_floats(N_ant);
+    if (d_i.alloc(need * 4) || d_q.alloc(need * 4) || d_par.alloc(32) || d_sub.alloc(nf * 4)) return MI_LTE_ERR_NOMEM;
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(d_i.p, h_i + start, need * 4, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(d_q.p, h_q + start, need * 4, hipMemcpyHostToDevice, ctx->stream));
+    struct { uint64_t start; uint32_t sf, cell; } par = {0, subfr_num, N_id_cell};
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(d_par.p, &par, sizeof(par), hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemsetAsync(d_sub.p, 0, nf * 4, ctx->stream));
+    mi_lte_dl_cfg cfg = {fft_size, N_rb_dl, N_ant, MI_LTE_IQ_F32_PLANAR};
+    int rc = mi_lte_dl_frontend_batch(ctx, &cfg, d_i.p, d_q.p, (const uint64_t *)d_par.p, (const uint32_t *)((char *)d_par.p + 8),
+                                      (const uint32_t *)((char *)d_par.p + 12), 1, (float *)d_sub.p);
+    if (rc != MI_LTE_OK) return rc;
+    const size_t row = 16 * 1200 * sizeof(float);
+    float       *s   = (float *)d_sub.p;
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(h_symb_re, s, row, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(h_symb_im, s + 16 * 1200, row, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(h_ce_re, s + 2 * 16 * 1200, row * N_ant, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(h_ce_im, s + (2 + N_ant) * 16 * 1200, row * N_ant, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// liblte_phy_pdsch_channel_decode (liblte_phy.cc:3690-3853)
+int mi_lte_pdsch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const float *h_symb_re, const float *h_symb_im,
+                                     const float *h_ce_re, const float *h_ce_im, uint32_t subfr_num, const mi_lte_pdsch_alloc *alloc,
+                                     uint32_t N_pdcch_symbs, uint32_t N_id_cell, uint32_t N_ant, uint8_t *h_out_bits,
+                                     uint32_t *N_out_bits)
+{
+    if (!ctx) return MI_LTE_ERR_INVALID_ARG;
+    if (!h_symb_re || !h_symb_im || !h_ce_re || !h_ce_im || !alloc || N_id_cell > 503 || !h_out_bits || !N_out_bits) return 1;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint32_t fft = N_rb_dl <= 6 ? 128 : N_rb_dl <= 15 ? 256 : N_rb_dl <= 25 ? 512 : N_rb_dl <= 50 ? 1024 : 2048;
+    mi_lte_dl_cfg       cfg = {fft, N_rb_dl, N_ant, MI_LTE_IQ_F32_PLANAR};
+    mi_lte_pdsch_alloc  a   = *alloc;
+    a.unit                  = 0;
+    mi_lte_pdsch_plan *plan = nullptr;
+    int                rc   = mi_lte_pdsch_plan_create(ctx, &cfg, N_pdcch_symbs, &a, 1, &plan);
+    if (rc == MI_LTE_ERR_UNSUPPORTED) return 3; // outside the envelope the reference itself decodes: report a decode failure
+    if (rc != MI_LTE_OK) return rc;
+    const size_t nf = mi_lte_subframe_floats(N_ant), row = 16 * 1200;
+    const uint32_t stride = mi_lte_pdsch_plan_out_stride(plan);
+    DevBuf d_sub, d_par, d_out, d_st;
+    if (d_sub.alloc(nf * 4) || d_par.alloc(16) || d_out.alloc(stride) || d_st.alloc(4)) { mi_lte_pdsch_plan_destroy(ctx, plan); return MI_LTE_ERR_NOMEM; }
+    float *s = (float *)d_sub.p;
+    uint32_t par[2] = {subfr_num, N_id_cell};
+    hipError_t e = hipMemcpyAsync(s, h_symb_re, row * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(s + row, h_symb_im, row * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(s + 2 * row, h_ce_re, row * 4 * N_ant, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(s + (2 + N_ant) * row, h_ce_im, row * 4 * N_ant, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_par.p, par, 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) { mi_lte_pdsch_plan_destroy(ctx, plan); ctx->err = hipGetErrorString(e); return MI_LTE_ERR_HIP; }
+    rc = mi_lte_pdsch_decode_run(ctx, plan, s, (const uint32_t *)d_par.p, (const uint32_t *)d_par.p + 1, (uint8_t *)d_out.p, (int32_t *)d_st.p);
+    int32_t st = 3;
+    if (rc == MI_LTE_OK) {
+        e = hipMemcpyAsync(&st, d_st.p, 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess && st == 0) { // the reference copies the bits out only when the CRC matched (:12861-12869)
+            e = hipMemcpy(h_out_bits, d_out.p, a.tbs, hipMemcpyDeviceToHost);
+            *N_out_bits = a.tbs;
+        }
+        if (e != hipSuccess) { rc = MI_LTE_ERR_HIP; ctx->err = hipGetErrorString(e); }
+    }
+    mi_lte_pdsch_plan_destroy(ctx, plan);
+    return rc != MI_LTE_OK ? rc : (int)st;
+}
+
+// liblte_phy_rate_unmatch_turbo (liblte_phy.cc:11246-11490)
+int mi_lte_rate_unmatch_turbo_host(mi_lte_ctx *ctx, const float *h_e, uint32_t N_e, uint32_t N_dummy_bits, uint32_t C, uint32_t tx_mode,
+                                   uint32_t N_soft, uint32_t M_dl_harq, uint32_t chan_type, uint32_t rv_idx, float *h_d, uint32_t *N_d)
+{
+    if (!ctx || !h_e || !h_d || !N_d) return MI_LTE_ERR_INVALID_ARG;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    DevBuf d_e, d_d;
+    if (d_e.alloc((size_t)N_e * 4) || d_d.alloc((size_t)3 * N_dummy_bits * 4)) return MI_LTE_ERR_NOMEM;
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(d_e.p, h_e, (size_t)N_e * 4, hipMemcpyHostToDevice, ctx->stream));
+    int rc = mi_lte_rate_unmatch_turbo_batch(ctx, (const float *)d_e.p, N_e, N_dummy_bits, C, tx_mode, N_soft, M_dl_harq, chan_type, rv_idx, 1,
+                                             (float *)d_d.p);
+    if (rc != MI_LTE_OK) return rc;
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(h_d, d_d.p, (size_t)3 * N_dummy_bits * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    *N_d = 3 * N_dummy_bits;
+    return 0;
+}
+
+} // extern "C"

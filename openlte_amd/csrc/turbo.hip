@@ -136,14 +136,15 @@ struct RmGeom {
     __device__ __forceinline__ uint32_t cnt(uint32_t p) const { return p - nulls_below(p); }
     // geometry per liblte_phy.cc:11283-11287 (R), :11371-11399 (K_w, N_ir, N_cb, k0) with the constants
     // liblte_phy_pdsch_channel_decode passes (M_dl_harq = 8, N_soft = 250368, :3843-3844), C = 1
-    __device__ __forceinline__ void init(uint32_t D, uint32_t tx_mode, uint32_t rv)
+    __device__ __forceinline__ void init(uint32_t D, uint32_t tx_mode, uint32_t rv, uint32_t N_soft = 250368,
+                                         uint32_t M_dl_harq = 8, uint32_t C = 1, bool limited = true)
     {
         R    = (D + 31) / 32;
         K_pi = 32 * R;
         N_d  = K_pi - D;
         const uint32_t K_w = 3 * K_pi, K_mimo = (tx_mode == 3 || tx_mode == 4 || tx_mode == 8 || tx_mode == 9) ? 2 : 1;
-        const uint32_t N_ir = 250368 / (K_mimo * 8);
-        N_cb = N_ir < K_w ? N_ir : K_w;
+        const uint32_t N_ir = N_soft / (K_mimo * (M_dl_harq < 8 ? M_dl_harq : 8));
+        N_cb = (limited && N_ir / C < K_w) ? N_ir / C : K_w; // DLSCH/PCH only (liblte_phy.cc:11387-11398)
         const uint32_t k0 = R * (2 * ((N_cb + 8 * R - 1) / (8 * R)) * rv + 2);
         k0m  = k0 % N_cb;
         mask0 = mask2 = 0;
@@ -510,6 +511,39 @@ __global__ __launch_bounds__(256) void k_turbo_vote(VoteArgs a, uint32_t K, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// stand-alone turbo rate un-matching with the reference's float interface
+// (liblte_phy_rate_unmatch_turbo, liblte_phy.cc:11246-11490): d[i*3+x] interleaved, positions no
+// e bit reaches read RX_NULL_BIT (10000.0f); repeats are added in transmission order, a repeat whose
+// value is RX_NULL_BIT is skipped (:11407-11412).
+struct RmParams { uint32_t D, E, C, tx_mode, N_soft, M_dl_harq, limited, rv; };
+
+__global__ __launch_bounds__(256) void k_rate_unmatch_f32(const float *__restrict__ e, RmParams pr, uint32_t n_cb,
+                                                          float *__restrict__ d)
+{
+    RmGeom rm;
+    rm.init(pr.D, pr.tx_mode, pr.rv, pr.N_soft, pr.M_dl_harq, pr.C, pr.limited != 0);
+    const uint32_t cb = blockIdx.y;
+    const float   *eb = e + (size_t)cb * pr.E;
+    float         *db = d + (size_t)cb * 3 * pr.D;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < 3 * pr.D; t += gridDim.x * blockDim.x) {
+        const uint32_t i = t / 3;
+        const int      x = (int)(t - 3 * i);
+        const uint32_t p = rm.pos(i, x);
+        float          v = (float)RX_NULL_AS_INT;
+        if (p < rm.N_cb) {
+            const uint32_t c = rm.cnt(p);
+            uint32_t       k = (p >= rm.k0m) ? c - rm.cnt_k0 : rm.Nnn - rm.cnt_k0 + c;
+            if (k < pr.E) {
+                v = eb[k];
+                for (k += rm.Nnn; k < pr.E; k += rm.Nnn)
+                    if (eb[k] != (float)RX_NULL_AS_INT) v += eb[k];
+            }
+        }
+        db[t] = v;
+    }
+}
+
 } // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -610,4 +644,18 @@ extern "C" int mi_lte_turbo_decode_batch(mi_lte_ctx *ctx, const void *d_soft, mi
     }
     ctx->err = "BCJR mode not built yet";
     return MI_LTE_ERR_UNSUPPORTED;
+}
+
+extern "C" int mi_lte_rate_unmatch_turbo_batch(mi_lte_ctx *ctx, const float *d_e_bits, uint32_t N_e_bits, uint32_t D,
+                                               uint32_t N_codeblocks, uint32_t tx_mode, uint32_t N_soft, uint32_t M_dl_harq,
+                                               uint32_t chan_type, uint32_t rv_idx, uint32_t n_cb, float *d_d_bits)
+{
+    if (!ctx || !d_e_bits || !d_d_bits || D < 44 || D > 6148 || N_codeblocks == 0 || M_dl_harq == 0 || n_cb == 0 || rv_idx > 3)
+        return MI_LTE_ERR_INVALID_ARG;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    RmParams pr{D, N_e_bits, N_codeblocks, tx_mode, N_soft, M_dl_harq, (chan_type == 0 || chan_type == 1) ? 1u : 0u, rv_idx};
+    MI_LAUNCH(ctx, "k_rate_unmatch_f32", k_rate_unmatch_f32, dim3((3 * D + 255) / 256, n_cb), dim3(256), 0, d_e_bits, pr, n_cb, d_d_bits);
+    MI_HIP_CHECK(ctx, hipGetLastError());
+    ctx->last_kernels = "k_rate_unmatch_f32:1";
+    return MI_LTE_OK;
 }

@@ -1,0 +1,83 @@
+"""GPU: the drop-in claim, end to end.
+
+shim/_build/dropin_gpu is a caller written purely against the reference's liblte_phy API, linked
+against the reference's own objects EXCEPT the three hot-path entry points, which come from
+shim/liblte_phy_shim.cc -> libmi_lte.so (built by shim/Makefile where /root/reference exists; the
+binary travels with the repo snapshot).  Its output must equal what the same caller prints when
+linked against the unmodified reference (tests/golden/dropin_demo_reference_cpu.txt)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import lte_testdata as td
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_dropin_demo_matches_reference_output():
+    exe = os.path.join(ROOT, "shim", "_build", "dropin_gpu")
+    if not os.path.exists(exe):
+        pytest.skip("shim/_build/dropin_gpu not built (needs the reference tree at build time)")
+    got = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    want = open(os.path.join(ROOT, "tests", "golden", "dropin_demo_reference_cpu.txt")).read().strip().splitlines()
+    lines = got.stdout.strip().splitlines()
+    assert got.returncode == 0, got.stdout + got.stderr
+    assert lines[1:] == want[1:], (lines, want)  # per-allocation verdicts: identical text
+    h_got, h_want = float(re.findall(r"[-0-9.]+$", lines[0])[0]), float(re.findall(r"[-0-9.]+$", want[0])[0])
+    assert abs(h_got - h_want) / h_want < 1e-4  # channel-estimate power: float tolerance
+
+
+def test_host_rate_unmatch_bit_exact(ctx, port):
+    """mi_lte_rate_unmatch_turbo_host == liblte_phy_rate_unmatch_turbo (oracle), incl. the 10000.0f sentinels."""
+    import ctypes as C
+    L = ctx.L
+    f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+    L.mi_lte_rate_unmatch_turbo_host.argtypes = [C.c_void_p, f32p] + [C.c_uint32] * 8 + [f32p, C.POINTER(C.c_uint32)]
+    rng = np.random.default_rng(8)
+    for K in (40, 104, 1088, 3264, 6144):
+        D = K + 4
+        for (rv, C_, M, txm, chan, ratio) in ((0, 1, 4, 2, 0, 3.0), (1, 1, 8, 1, 0, 2.1), (2, 2, 8, 3, 0, 4.7), (3, 1, 8, 1, 0, 1.6),
+                                             (0, 1, 1, 1, 2, 3.0)):
+            E = int(ratio * D) // 2 * 2
+            e = rng.integers(-127, 128, E).astype(np.float32)
+            n_soft = 250368 if chan == 0 else 1
+            want, got = np.zeros(3 * D, np.float32), np.zeros(3 * D, np.float32)
+            port.lo_rate_unmatch_turbo(e.copy(), E, D, C_, txm, n_soft, M, chan, rv, want)
+            n = C.c_uint32()
+            rc = L.mi_lte_rate_unmatch_turbo_host(ctx.h, e, E, D, C_, txm, n_soft, M, chan, rv, got, C.byref(n))
+            assert rc == 0 and n.value == 3 * D
+            assert (got == want).all(), (K, rv, C_, M, txm, chan, ratio)
+
+
+def test_host_front_end_and_pdsch(ctx, port):
+    """The two per-call host-pointer entry points against the oracle on one W4 subframe."""
+    import ctypes as C
+    import openlte_amd as m
+    from openlte_amd import synth
+    L = ctx.L
+    f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+    u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+    L.mi_lte_get_dl_subframe_and_ce_host.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, f32p, f32p] + [C.c_uint32] * 4 + [f32p] * 4
+    L.mi_lte_pdsch_channel_decode_host.argtypes = [C.c_void_p, C.c_uint32, f32p, f32p, f32p, f32p, C.c_uint32, C.c_void_p,
+                                                   C.c_uint32, C.c_uint32, C.c_uint32, u8p, C.POINTER(C.c_uint32)]
+    cfg = m.DlCfg(2048, 100, 1, 0)
+    sf, cell = 4, 211
+    allocs = td.w4_allocs(0)
+    iq, tx = synth.dl_units(cfg, [sf], [cell], allocs, 9, snr_db=28, seed=12)
+    i_s = np.concatenate([np.zeros(sf * 30720, np.float32), iq[0, :, 0].astype(np.float32)])
+    q_s = np.concatenate([np.zeros(sf * 30720, np.float32), iq[0, :, 1].astype(np.float32)])
+    sr, si = np.zeros((16, 1200), np.float32), np.zeros((16, 1200), np.float32)
+    cr, ci = np.zeros((4, 16, 1200), np.float32), np.zeros((4, 16, 1200), np.float32)
+    assert 0 == L.mi_lte_get_dl_subframe_and_ce_host(ctx.h, 2048, 100, i_s, q_s, 0, sf, cell, 1, sr, si, cr, ci)
+    _, s = td.oracle_frontend(port, 2048, 100, 1, iq[0], sf, cell)
+    assert np.linalg.norm(sr - s.arr("rx_symb_re")) / np.linalg.norm(s.arr("rx_symb_re")) < 1e-5
+    assert np.linalg.norm(cr[0, :14] - s.arr("rx_ce_re")[0, :14]) / np.linalg.norm(s.arr("rx_ce_re")[0, :14]) < 1e-4
+    for a in range(9):
+        out, n = np.zeros(6200, np.uint8), C.c_uint32()
+        rc = L.mi_lte_pdsch_channel_decode_host(ctx.h, 100, sr, si, cr, ci, sf, C.addressof(allocs[a]), 2, cell, 1, out, C.byref(n))
+        assert rc == 0 and n.value == allocs[a].tbs
+        assert (out[:n.value] == tx[0, a, :n.value]).all()

@@ -321,7 +321,8 @@ def main():
     rank, world, barrier, max_reduce = dist_setup(args.gpus)
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     import openlte_amd as m
-    ctx = m.Context(local_rank)
+    n_dev = max(1, m.load_library().mi_lte_device_count())
+    ctx = m.Context(local_rank % n_dev)  # one GPU per rank; the modulo only matters when ranks outnumber GPUs (testing)
     wl = pick_workload(args.workload)(ctx, args.units, rank)
 
     for _ in range(args.warmup):

@@ -106,7 +106,8 @@ __global__ __launch_bounds__(256) void k_pdsch_demod(const float *__restrict__ s
                                                      const mi_lte_pdsch_alloc *__restrict__ allocs,
                                                      const uint32_t *__restrict__ subfr_num, const uint32_t *__restrict__ n_id_cell,
                                                      GoldTables gt, int8_t *__restrict__ e_base, const uint32_t *__restrict__ e_off,
-                                                     uint32_t *__restrict__ e_len, uint32_t max_pairs)
+                                                     uint32_t *__restrict__ e_len, uint32_t max_pairs, uint32_t max_words,
+                                                     uint32_t e_lds_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smu[]; // offs[max_pairs+1] | masks[max_pairs] | cw[...]
     __shared__ uint32_t part[256];
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void k_pdsch_demod(const float *__restrict__ s
     const mi_lte_pdsch_alloc &al = allocs[a_idx];
     const uint32_t unit = al.unit, sf = subfr_num[unit], cell = n_id_cell[unit], N_ant = g.N_ant, N_prb = al.N_prb;
     const uint32_t Qm = al.mod_type == 3 ? 6 : al.mod_type == 2 ? 4 : al.mod_type == 1 ? 2 : 1;
-    uint32_t *offs = smu, *masks = smu + max_pairs + 1, *cw = masks + max_pairs;
+    uint32_t *offs = smu, *masks = smu + max_pairs + 1, *cw = smu + ((2 * max_pairs + 1 + 3u) & ~3u); // cw and e_lds stay 16-byte aligned
     uint32_t first_sc, last_sc;
     sync_window(g.N_rb_dl, first_sc, last_sc);
 
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void k_pdsch_demod(const float *__restrict__ s
     for (uint32_t q = threadIdx.x * per; q < min((threadIdx.x + 1) * per, n_pairs); q++) {
         const uint32_t L = g.cfi + q / N_prb, prb = al.prb[L / 7][q % N_prb];
         const uint32_t m = pdsch_mask(N_ant, cell, sf, L, prb, first_sc, last_sc);
-        masks[q] = m;
+        masks[q] = m | ((L * N_SC_MAX + prb * 12) << 12); // low 12 bits: RE mask, high 20 bits: L*1200 + first sub-carrier
         local += __popc(m);
     }
     part[threadIdx.x] = local;
@@ -145,13 +146,13 @@ __global__ __launch_bounds__(256) void k_pdsch_demod(const float *__restrict__ s
         uint32_t run = part[threadIdx.x];
         for (uint32_t q = threadIdx.x * per; q < min((threadIdx.x + 1) * per, n_pairs); q++) {
             offs[q] = run;
-            run += __popc(masks[q]);
+            run += __popc(masks[q] & 0xFFFu);
         }
     }
     __syncthreads();
     if (threadIdx.x == 0) { // total = offset past the last pair
         uint32_t tot = 0;
-        if (n_pairs) tot = offs[n_pairs - 1] + __popc(masks[n_pairs - 1]);
+        if (n_pairs) tot = offs[n_pairs - 1] + __popc(masks[n_pairs - 1] & 0xFFFu);
         offs[n_pairs] = tot;
     }
     __syncthreads();
@@ -176,20 +177,34 @@ __global__ __launch_bounds__(256) void k_pdsch_demod(const float *__restrict__ s
             const uint32_t mid = (lo + hi) >> 1;
             if (offs[mid] <= idx) lo = mid; else hi = mid;
         }
-        uint32_t r = idx - offs[lo], m = masks[lo];
+        uint32_t r = idx - offs[lo], m = masks[lo] & 0xFFFu;
         for (; r; r--) m &= m - 1;
-        const uint32_t j = (uint32_t)__builtin_ctz(m), L = g.cfi + lo / N_prb, prb = al.prb[L / 7][lo % N_prb];
-        return L * N_SC_MAX + prb * 12 + j;
+        return (masks[lo] >> 12) + (uint32_t)__builtin_ctz(m);
     };
-    for (uint32_t i = threadIdx.x; i < n_grp; i += blockDim.x) {
-        float x_re[4], x_im[4];
-        if (N_ant == 1) { // liblte_phy.cc:7684-7690
-            const uint32_t p = locate(i);
+    // soft bits are assembled in LDS when they fit and leave with 16-byte stores
+    int8_t    *e_lds  = reinterpret_cast<int8_t *>(cw + max_words);
+    const bool via_lds = N_bits <= e_lds_cap;
+    int8_t    *e_dst  = via_lds ? e_lds : e;
+    if (N_ant == 1) { // one RE = one symbol (liblte_phy.cc:7684-7690): thread per (PRB-symbol pair, sub-carrier), no search
+        for (uint32_t t = threadIdx.x; t < n_pairs * 12; t += blockDim.x) {
+            const uint32_t q = t / 12, j = t - q * 12, mk = masks[q];
+            if (!((mk >> j) & 1u)) continue;
+            const uint32_t idx = offs[q] + __popc(mk & ((1u << j) - 1u)), p = (mk >> 12) + j;
             const float yr = y_re_p[p], yi = y_im_p[p], hr = h_re_p[p], hi = h_im_p[p];
             const float hn = hr * hr + hi * hi;
-            x_re[0] = (yr * hr + yi * hi) / hn;
-            x_im[0] = (yi * hr - yr * hi) / hn;
-        } else if (N_ant == 2) { // Alamouti combiner with the reference's normaliser (liblte_phy.cc:7694-7717)
+            const float xr = (yr * hr + yi * hi) / hn, xi = (yi * hr - yr * hi) / hn;
+            int8_t b[6];
+            demap_symbol(xr, xi, al.mod_type, b);
+            const uint32_t n0 = idx * Qm;
+            for (uint32_t k = 0; k < Qm; k++) {
+                const uint32_t n = n0 + k, c = (cw[n >> 5] >> (n & 31)) & 1u;
+                e_dst[n] = c ? (int8_t)-b[k] : b[k];
+            }
+        }
+    } else
+    for (uint32_t i = threadIdx.x; i < n_grp; i += blockDim.x) {
+        float x_re[4], x_im[4];
+        if (N_ant == 2) { // Alamouti combiner with the reference's normaliser (liblte_phy.cc:7694-7717)
             const uint32_t p0 = locate(2 * i), p1 = locate(2 * i + 1);
             const float y0r = y_re_p[p0], y0i = y_im_p[p0], y1r = y_re_p[p1], y1i = y_im_p[p1];
             const float h0r = h_re_p[p0], h0i = h_im_p[p0], h1r = h_re_p[16 * N_SC_MAX + p0], h1i = h_im_p[16 * N_SC_MAX + p0];
@@ -224,9 +239,14 @@ __global__ __launch_bounds__(256) void k_pdsch_demod(const float *__restrict__ s
             const uint32_t n0 = (i * N_ant + p) * Qm;
             for (uint32_t k = 0; k < Qm; k++) {
                 const uint32_t n = n0 + k, c = (cw[n >> 5] >> (n & 31)) & 1u;
-                e[n] = c ? (int8_t)-b[k] : b[k];
+                e_dst[n] = c ? (int8_t)-b[k] : b[k];
             }
         }
+    }
+    if (via_lds) {
+        __syncthreads();
+        const uint32_t nq = (N_bits + 15) >> 4; // the allocation's slot in e_base is padded to 64 bytes
+        for (uint32_t w = threadIdx.x; w < nq; w += blockDim.x) reinterpret_cast<uint4 *>(e)[w] = reinterpret_cast<const uint4 *>(e_lds)[w];
     }
 }
 
@@ -242,7 +262,7 @@ struct mi_lte_pdsch_plan {
     mi_lte_pdsch_alloc *d_allocs = nullptr;
     uint32_t *d_e_off = nullptr, *d_e_len = nullptr, *d_cb_alloc = nullptr;
     int8_t   *d_e = nullptr;
-    struct Group { uint32_t K, n_cb, cb_base; };
+    struct Group { uint32_t K, n_cb, cb_base, e_max; };
     std::vector<Group>    groups;
     std::vector<uint32_t> h_e_off;
 };
@@ -269,6 +289,7 @@ int mi_lte_pdsch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, uint32_t
     pl->cfi       = N_pdcch_symbs;
     pl->n_alloc   = n_alloc;
     std::map<uint32_t, std::vector<uint32_t>> byK;
+    std::map<uint32_t, uint32_t>              emaxK;
     uint32_t max_tbs = 0;
     size_t   off = 0;
     pl->h_e_off.resize(n_alloc);
@@ -287,6 +308,7 @@ int mi_lte_pdsch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, uint32_t
         const uint32_t pairs = (14 - N_pdcch_symbs) * al.N_prb, e_max = pairs * 12 * Qm;
         pl->max_pairs = std::max(pl->max_pairs, pairs);
         pl->max_words = std::max(pl->max_words, (e_max + 31) / 32);
+        emaxK[K]       = std::max(emaxK[K], e_max);
         pl->h_e_off[a] = (uint32_t)off;
         off += (e_max + 63) & ~63u;
     }
@@ -299,7 +321,7 @@ int mi_lte_pdsch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, uint32_t
     pl->out_stride = (max_tbs + 63) & ~63u;
     std::vector<uint32_t> cb_alloc;
     for (auto &kv : byK) {
-        pl->groups.push_back({kv.first, (uint32_t)kv.second.size(), (uint32_t)cb_alloc.size()});
+        pl->groups.push_back({kv.first, (uint32_t)kv.second.size(), (uint32_t)cb_alloc.size(), emaxK[kv.first]});
         cb_alloc.insert(cb_alloc.end(), kv.second.begin(), kv.second.end());
     }
     MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_allocs, sizeof(mi_lte_pdsch_alloc) * n_alloc));
@@ -349,13 +371,17 @@ int mi_lte_pdsch_decode_run(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, const float 
     if (rc != MI_LTE_OK) return rc;
     DemodGeom  g{pl->cfg.N_rb_dl, pl->cfg.N_ant, pl->cfi, (uint32_t)mi_lte_subframe_floats(pl->cfg.N_ant)};
     GoldTables gt{ctx->d_gold_x1, ctx->d_gold_x2b, ctx->gold_words};
-    const size_t lds = sizeof(uint32_t) * (2 * (size_t)pl->max_pairs + 1 + pl->max_words);
+    // LDS: offs | masks | scrambling words | (when it fits in 32 KiB) the allocation's soft bits
+    const uint32_t words_al = (pl->max_words + 3u) & ~3u, e_bytes = (pl->max_words * 32 + 63u) & ~63u;
+    const uint32_t e_cap = (e_bytes <= 32 * 1024) ? e_bytes : 0;
+    const uint32_t pairs_al = ((2 * pl->max_pairs + 1 + 3u) & ~3u);
+    const size_t lds = sizeof(uint32_t) * ((size_t)pairs_al + words_al) + e_cap;
     MI_LAUNCH(ctx, "k_pdsch_demod", k_pdsch_demod, dim3(pl->n_alloc), dim3(256), lds, d_subframes, g, pl->d_allocs, d_subfr_num,
-              d_n_id_cell, gt, pl->d_e, pl->d_e_off, pl->d_e_len, pl->max_pairs);
+              d_n_id_cell, gt, pl->d_e, pl->d_e_off, pl->d_e_len, pl->max_pairs, words_al, e_cap);
     MI_HIP_CHECK(ctx, hipGetLastError());
     for (auto &gr : pl->groups) {
         rc = mi_turbo_ref_group(ctx, gr.K, gr.n_cb, pl->d_allocs, pl->d_cb_alloc + gr.cb_base, pl->d_e, pl->d_e_off, pl->d_e_len,
-                                d_out_bits, pl->out_stride, d_status);
+                                d_out_bits, pl->out_stride, d_status, gr.e_max);
         if (rc != MI_LTE_OK) return rc;
     }
     ctx->last_kernels = "k_pdsch_demod:1,k_turbo_prep,k_turbo_siso,k_turbo_perm,k_turbo_vote per block size";

@@ -16,6 +16,11 @@ struct TurboTables {       // device-resident per-K tables
     uint16_t *d_inv = nullptr; // inv[j] = largest i with pi[i] == j, 0xFFFF if none ("hole")
 };
 
+struct RmTables { // per-K rank tables of the fused turbo rate un-matching (see turbo.hip)
+    uint16_t *d_tabs = nullptr;
+    uint32_t *d_nnn  = nullptr;
+};
+
 struct mi_lte_ctx {
     int                device = -1;
     hipStream_t        stream = nullptr;
@@ -26,6 +31,7 @@ struct mi_lte_ctx {
     void              *scratch       = nullptr;
     size_t             scratch_bytes = 0;
     std::map<uint64_t, TurboTables> turbo_tables; // key = K | (spec << 32)
+    std::map<uint32_t, RmTables>    rm_tables;    // key = K
     std::vector<void *> owned;                    // allocations released at destroy
 
     // Gold-sequence tables (see mi_ctx_gold_tables)
@@ -67,5 +73,5 @@ int   mi_ctx_gold_tables(mi_lte_ctx *ctx);
 int   mi_ctx_crc_table(mi_lte_ctx *ctx);
 int   mi_turbo_ref_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_pdsch_alloc *d_allocs,
                          const uint32_t *d_cb_alloc, const int8_t *d_e, const uint32_t *d_e_off, const uint32_t *d_e_len,
-                         uint8_t *d_out_bits, uint32_t out_stride, int32_t *d_status);
+                         uint8_t *d_out_bits, uint32_t out_stride, int32_t *d_status, uint32_t e_max_bytes);
 int   mi_ctx_turbo_tables(mi_lte_ctx *ctx, uint32_t K, int spec, TurboTables *out);

@@ -88,6 +88,7 @@ __device__ __forceinline__ void store_tile_lines(uint8_t *const *dst, const int8
 __device__ __forceinline__ void load_tile_lines(int8_t *lds, const uint8_t *src, uint32_t Kp, size_t tile_off, uint32_t lane)
 {
     const uint32_t units = Kp >> 4;
+#pragma unroll 2
     for (uint32_t u = threadIdx.x; u < units; u += blockDim.x)
         *reinterpret_cast<uint4 *>(lds + (size_t)u * 16) =
             *reinterpret_cast<const uint4 *>(src + tile_off + (size_t)(u >> 2) * 4096 + lane * 64 + (u & 3) * 16);
@@ -105,9 +106,26 @@ struct PrepOut { uint8_t *arr[6]; }; // X0 X1 X2 I0 M1 M2
 // ---- where the soft values of a code block come from
 // (a) directly from the caller, in the reference's interleaved d[i*3+x] layout
 template <typename T> struct SrcDirect {
+    static constexpr bool kStage = false;
+    uint32_t e_cap;
+    __device__ __forceinline__ void stage_e(int8_t *) {}
+    static constexpr bool kRaw   = sizeof(T) == 1; // int8 blocks are first copied to LDS with dword loads
+    __device__ __forceinline__ int get_int(uint32_t, int) const { return 0; }
     const T *soft;
     const T *d;
     __device__ __forceinline__ void init(uint32_t cb, uint32_t K) { d = soft + (size_t)cb * 3 * (K + 4); }
+    __device__ __forceinline__ void stage_raw(int8_t *lds, uint32_t K)
+    {
+        if (sizeof(T) == 1) { // 3(K+4) bytes: a multiple of 4, and 4-byte aligned because K is a multiple of 8
+            const uint32_t nw = (3 * (K + 4)) >> 2;
+            const uint32_t *g = reinterpret_cast<const uint32_t *>(d);
+            uint32_t       *l = reinterpret_cast<uint32_t *>(lds);
+#pragma unroll 8
+            for (uint32_t w = threadIdx.x; w < nw; w += blockDim.x) l[w] = g[w];
+            __syncthreads();
+            d = reinterpret_cast<const T *>(lds);
+        }
+    }
     __device__ __forceinline__ float get(uint32_t i, int x) const
     {
         float v = (float)d[i * 3 + x];
@@ -167,6 +185,26 @@ struct RmGeom {
         const uint32_t ii = (__brev(n & 31) >> 27) * R + (n >> 5);
         return x == 0 ? ii : K_pi + 2 * ii;
     }
+    // the same position together with its non-NULL count below it, without integer division: the
+    // element sits in column c, row r of its stream's R x 32 matrix, and only row 0 holds NULLs, so
+    // "NULL slots below" is a popcount over the columns up to c (+1 if r > 0)
+    __device__ __forceinline__ void pos_cnt(uint32_t i, int x, uint32_t &p, uint32_t &cn) const
+    {
+        const uint32_t n = i + N_d - (x == 2 ? 1u : 0u), c = __brev(n & 31) >> 27, r = n >> 5, ii = c * R + r;
+        const uint32_t cc = c + (r > 0 ? 1u : 0u);
+        uint32_t nulls;
+        if (x == 0) {
+            p     = ii;
+            nulls = __popc(mask0 & lowmask(cc));
+        } else if (x == 1) {
+            p     = K_pi + 2 * ii;
+            nulls = __popc(mask0) + __popc(mask0 & lowmask(cc)) + __popc(mask2 & lowmask(cc));
+        } else {
+            p     = K_pi + 2 * ii + 1;
+            nulls = __popc(mask0) + __popc(mask0 & lowmask(c + 1)) + __popc(mask2 & lowmask(cc));
+        }
+        cn = p - nulls;
+    }
 };
 
 struct GroupDesc {                 // one launch = the code blocks of one size K out of a PDSCH batch
@@ -182,27 +220,49 @@ struct GroupDesc {                 // one launch = the code blocks of one size K
 };
 
 struct SrcRateUnmatch {
-    GroupDesc     g;
-    RmGeom        rm;
-    const int8_t *e;
-    uint32_t      E;
+    static constexpr bool kStage = true; // gather once into LDS (int16), then scale from there
+    static constexpr bool kRaw   = false;
+    uint32_t e_cap; // bytes of LDS available for staging e (0 = gather from global)
+    // copy the allocation's soft bits into LDS with wide loads: the gather below is otherwise a chain of
+    // dependent byte loads from L2 per element
+    __device__ __forceinline__ void stage_e(int8_t *lds)
+    {
+        if (E <= e_cap) {
+            const uint32_t nq = (E + 15) >> 4; // e_off is 64-byte aligned and padded
+            const uint4   *g  = reinterpret_cast<const uint4 *>(e);
+            uint4         *l  = reinterpret_cast<uint4 *>(lds);
+#pragma unroll 4
+            for (uint32_t w = threadIdx.x; w < nq; w += blockDim.x) l[w] = g[w];
+            __syncthreads();
+            e = lds;
+        }
+    }
+    __device__ __forceinline__ void stage_raw(int8_t *, uint32_t) {}
+    GroupDesc       g;
+    const uint16_t *tabs; // [8][3K] rank of every d element in the order e is consumed, per (rv, K_mimo)
+    const uint32_t *nnn;  // [8]     non-NULL slots per lap of the circular buffer
+    const uint16_t *tab;
+    const int8_t   *e;
+    uint32_t        E, Nnn, K_;
     __device__ __forceinline__ void init(uint32_t cb, uint32_t K)
     {
-        const uint32_t a = g.cb_alloc[cb];
-        rm.init(K + 4, g.allocs[a].tx_mode, g.allocs[a].rv_idx);
-        e = g.e_base + g.e_off[a];
-        E = g.e_len[a];
+        const uint32_t a = g.cb_alloc[cb], txm = g.allocs[a].tx_mode;
+        const uint32_t combo = ((g.allocs[a].rv_idx & 3u) << 1) | ((txm == 3 || txm == 4 || txm == 8 || txm == 9) ? 1u : 0u);
+        tab = tabs + (size_t)combo * 3 * K;
+        Nnn = nnn[combo];
+        K_  = K;
+        e   = g.e_base + g.e_off[a];
+        E   = g.e_len[a];
     }
-    __device__ __forceinline__ float get(uint32_t i, int x) const
+    __device__ __forceinline__ int get_int(uint32_t i, int x) const
     {
-        const uint32_t p = rm.pos(i, x);
-        if (p >= rm.N_cb) return 0.0f; // never filled -> RX_NULL_BIT -> 0 in Step 0
-        const uint32_t c = rm.cnt(p);
-        uint32_t       k = (p >= rm.k0m) ? c - rm.cnt_k0 : rm.Nnn - rm.cnt_k0 + c;
-        float          v = 0.0f;
-        for (; k < E; k += rm.Nnn) v += (float)e[k];
+        uint32_t k = tab[x * K_ + i];
+        if (k == 0xFFFFu) return 0; // never filled -> RX_NULL_BIT -> 0 in Step 0
+        int v = 0;
+        for (; k < E; k += Nnn) v += (int)e[k];
         return v;
     }
+    __device__ __forceinline__ float get(uint32_t i, int x) const { return (float)get_int(i, x); }
 };
 
 template <typename Src>
@@ -218,24 +278,48 @@ __global__ __launch_bounds__(256) void k_turbo_prep(Src src, uint32_t K, uint32_
     src.init(cb, K);
 
     float mx = 0.0f;
-    for (uint32_t i = threadIdx.x; i < K; i += blockDim.x)
-        for (int x = 0; x < 3; x++) mx = fmaxf(mx, fabsf(src.get(i, x)));
-    mx = block_max_f(mx, red_f);
+    bool  staged = false;
+    int16_t *sd = reinterpret_cast<int16_t *>(sm + 3 * Kp); // [3][Kp] int16, dead once q0..q2 exist (aliases i0/m1/m2)
+    if (Src::kRaw) src.stage_raw(sm + 3 * Kp, K);
+    if (Src::kStage) {
+        src.stage_e(sm + 9 * Kp + 64);
+        int amax = 0;
+        for (int x = 0; x < 3; x++)
+            for (uint32_t i = threadIdx.x; i < K; i += blockDim.x) {
+                const int v = src.get_int(i, x);
+                sd[x * Kp + i] = (int16_t)v;
+                amax = max(amax, abs(v));
+            }
+        amax   = block_max_i(amax, red_i);
+        staged = amax <= 32767; // otherwise (hundreds of repeats) fall back to gathering twice
+        mx     = (float)amax;
+    }
+    if (!staged) {
+        mx = 0.0f;
+        for (uint32_t i = threadIdx.x; i < K; i += blockDim.x)
+            for (int x = 0; x < 3; x++) mx = fmaxf(mx, fabsf(src.get(i, x)));
+        mx = block_max_f(mx, red_f);
+    }
 
+    // q0..q2 live below sd in LDS, so they can be written while sd is still being read; the arrays that
+    // alias sd (i0, m1, m2) are only written after the barrier that follows
     for (uint32_t i = threadIdx.x; i < Kp; i += blockDim.x) {
-        int a = 0, b = 0, c = 0;
+        int qa = 0, qb = 0, qc = 0;
         if (i < K) {
-            a = (int)(src.get(i, 0) * 127.0f / mx);
-            b = (int)(src.get(i, 1) * 127.0f / mx);
-            c = (int)(src.get(i, 2) * 127.0f / mx);
+            const float v0 = staged ? (float)sd[i] : src.get(i, 0), v1 = staged ? (float)sd[Kp + i] : src.get(i, 1),
+                        v2 = staged ? (float)sd[2 * Kp + i] : src.get(i, 2);
+            qa = (int)(v0 * 127.0f / mx);
+            qb = (int)(v1 * 127.0f / mx);
+            qc = (int)(v2 * 127.0f / mx);
         }
-        q0[i] = (int8_t)a;
-        q1[i] = (int8_t)b;
-        q2[i] = (int8_t)c;
+        q0[i] = (int8_t)qa;
+        q1[i] = (int8_t)qb;
+        q2[i] = (int8_t)qc;
     }
     __syncthreads();
 
     int w1max = 0, w2max = 0;
+#pragma unroll 4
     for (uint32_t i = threadIdx.x; i < Kp; i += blockDim.x) {
         int v = 0;
         if (i < K) {
@@ -285,10 +369,14 @@ struct SisoArgs { SisoPass p[2]; };
 
 __device__ __forceinline__ void acs_step(int (&pm)[8], int x, int y, uint32_t &acc)
 {
-    const int e0 = (x < 0) ? 1 : -1, e1 = (y < 0) ? 1 : -1;
-    const int w  = abs(x) + abs(y);
-    const int P = e0 + e1, Q = e0 - e1;
-    const int wP = w * P, wQ = w * Q, P2 = 2 * P, Q2 = 2 * Q;
+    // With w = |x|+|y| and e = +1 for a negative soft value:  w*P = -2(x+y) if the two signs agree, else 0;
+    // w*Q = -2(x-y) if they differ, else 0;  2P, 2Q = +-4 (sign of x) under the same conditions.
+    // Only adds, logic ops and selects remain (v_mad_i32_i24 runs at a quarter of the add rate on gfx950).
+    const int m0 = x >> 31, mx = m0 ^ (y >> 31), nmx = ~mx; // mx = -1 iff the signs differ
+    const int uP = ((x + y) << 1) & nmx;                    // -w*P
+    const int uQ = ((x - y) << 1) & mx;                     // -w*Q
+    const int c4 = (m0 & 8) - 4;                            // x < 0 ? 4 : -4
+    const int P2 = c4 & nmx, Q2 = c4 & mx, nP2 = -P2, nQ2 = -Q2;
     const int n0 = pm[1] - pm[0], n1 = pm[3] - pm[2], n2 = pm[5] - pm[4], n3 = pm[7] - pm[6];
     // traceback bits for this time index (bit = PM[2j] > PM[2j+1] = sign bit of n_j), j = 0 first
     acc = __builtin_amdgcn_alignbit(acc, (uint32_t)n0, 31);
@@ -296,14 +384,14 @@ __device__ __forceinline__ void acs_step(int (&pm)[8], int x, int y, uint32_t &a
     acc = __builtin_amdgcn_alignbit(acc, (uint32_t)n2, 31);
     acc = __builtin_amdgcn_alignbit(acc, (uint32_t)n3, 31);
     int nw[8];
-    nw[0] = (n0 < P2) ? pm[1] - wP : pm[0] + wP;   // beta =  P
-    nw[4] = (n0 < -P2) ? pm[1] + wP : pm[0] - wP;  // beta = -P
-    nw[1] = (n1 < Q2) ? pm[3] - wQ : pm[2] + wQ;   // beta =  Q
-    nw[5] = (n1 < -Q2) ? pm[3] + wQ : pm[2] - wQ;  // beta = -Q
-    nw[2] = (n2 < -Q2) ? pm[5] + wQ : pm[4] - wQ;  // beta = -Q
-    nw[6] = (n2 < Q2) ? pm[5] - wQ : pm[4] + wQ;   // beta =  Q
-    nw[3] = (n3 < -P2) ? pm[7] + wP : pm[6] - wP;  // beta = -P
-    nw[7] = (n3 < P2) ? pm[7] - wP : pm[6] + wP;   // beta =  P
+    nw[0] = (n0 < P2) ? pm[1] + uP : pm[0] - uP;  // beta =  P
+    nw[4] = (n0 < nP2) ? pm[1] - uP : pm[0] + uP; // beta = -P
+    nw[1] = (n1 < Q2) ? pm[3] + uQ : pm[2] - uQ;  // beta =  Q
+    nw[5] = (n1 < nQ2) ? pm[3] - uQ : pm[2] + uQ; // beta = -Q
+    nw[2] = (n2 < nQ2) ? pm[5] - uQ : pm[4] + uQ; // beta = -Q
+    nw[6] = (n2 < Q2) ? pm[5] + uQ : pm[4] - uQ;  // beta =  Q
+    nw[3] = (n3 < nP2) ? pm[7] - uP : pm[6] + uP; // beta = -P
+    nw[7] = (n3 < P2) ? pm[7] + uP : pm[6] - uP;  // beta =  P
 #pragma unroll
     for (int s = 0; s < 8; s++) pm[s] = nw[s];
 }
@@ -321,13 +409,20 @@ __global__ __launch_bounds__(64) void k_turbo_siso(SisoArgs args, uint32_t K, ui
 #pragma unroll
     for (int s = 0; s < 8; s++) pm[s] = 0; // all path metrics start at 0 (liblte_phy.cc:10411-10418)
 
-    // ---- forward add-compare-select
+    // ---- forward add-compare-select; the next block's 2 x 64 B are requested before this block's
+    // 64 trellis steps are walked, so the HBM latency hides under ~3k instructions
+    uint4 A[4], B[4], An[4], Bn[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        A[q] = reinterpret_cast<const uint4 *>(pa)[q];
+        B[q] = reinterpret_cast<const uint4 *>(pb)[q];
+    }
     for (uint32_t blk = 0; blk < nblk; blk++) {
-        uint4 A[4], B[4];
+        const uint32_t nxt = (blk + 1 < nblk) ? blk + 1 : blk;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            A[q] = reinterpret_cast<const uint4 *>(pa + (size_t)blk * 4096)[q];
-            B[q] = reinterpret_cast<const uint4 *>(pb + (size_t)blk * 4096)[q];
+            An[q] = reinterpret_cast<const uint4 *>(pa + (size_t)nxt * 4096)[q];
+            Bn[q] = reinterpret_cast<const uint4 *>(pb + (size_t)nxt * 4096)[q];
         }
         uint32_t dw[8];
 #pragma unroll
@@ -347,6 +442,8 @@ __global__ __launch_bounds__(64) void k_turbo_siso(SisoArgs args, uint32_t K, ui
         uint4 *dp = reinterpret_cast<uint4 *>(dec + (size_t)blk * 64 * 8);
         dp[0] = make_uint4(dw[0], dw[1], dw[2], dw[3]);
         dp[1] = make_uint4(dw[4], dw[5], dw[6], dw[7]);
+#pragma unroll
+        for (int q = 0; q < 4; q++) { A[q] = An[q]; B[q] = Bn[q]; }
     }
 
     // ---- end state: first strict minimum (liblte_phy.cc:10467-10481)
@@ -358,13 +455,22 @@ __global__ __launch_bounds__(64) void k_turbo_siso(SisoArgs args, uint32_t K, ui
     // ---- traceback + signed soft output (liblte_phy.cc:10483-10527)
     const uint8_t *pmag = ps.mag + tile_off;
     uint8_t       *pout = ps.out + tile_off;
-    for (int blk = (int)nblk - 1; blk >= 0; blk--) {
-        uint4        M[4];
-        const uint4 *dp = reinterpret_cast<const uint4 *>(dec + (size_t)blk * 64 * 8);
-        const uint4  d0 = dp[0], d1 = dp[1];
-        uint32_t     dw[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+    uint4 M[4], Mn[4], d0, d1, d0n, d1n;
+    {
+        const uint4 *dp = reinterpret_cast<const uint4 *>(dec + (size_t)(nblk - 1) * 64 * 8);
+        d0 = dp[0];
+        d1 = dp[1];
 #pragma unroll
-        for (int q = 0; q < 4; q++) M[q] = reinterpret_cast<const uint4 *>(pmag + (size_t)blk * 4096)[q];
+        for (int q = 0; q < 4; q++) M[q] = reinterpret_cast<const uint4 *>(pmag + (size_t)(nblk - 1) * 4096)[q];
+    }
+    for (int blk = (int)nblk - 1; blk >= 0; blk--) {
+        const int    prv = blk > 0 ? blk - 1 : 0; // prefetch the block below while this one is traced back
+        const uint4 *dpn = reinterpret_cast<const uint4 *>(dec + (size_t)prv * 64 * 8);
+        d0n = dpn[0];
+        d1n = dpn[1];
+#pragma unroll
+        for (int q = 0; q < 4; q++) Mn[q] = reinterpret_cast<const uint4 *>(pmag + (size_t)prv * 4096)[q];
+        uint32_t     dw[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
         uint32_t mw[16] = {M[0].x, M[0].y, M[0].z, M[0].w, M[1].x, M[1].y, M[1].z, M[1].w,
                            M[2].x, M[2].y, M[2].z, M[2].w, M[3].x, M[3].y, M[3].z, M[3].w};
         uint32_t ow[16];
@@ -394,6 +500,10 @@ __global__ __launch_bounds__(64) void k_turbo_siso(SisoArgs args, uint32_t K, ui
         uint4 *op = reinterpret_cast<uint4 *>(pout + (size_t)blk * 4096);
 #pragma unroll
         for (int q = 0; q < 4; q++) op[q] = make_uint4(ow[4 * q], ow[4 * q + 1], ow[4 * q + 2], ow[4 * q + 3]);
+        d0 = d0n;
+        d1 = d1n;
+#pragma unroll
+        for (int q = 0; q < 4; q++) M[q] = Mn[q];
     }
 }
 
@@ -511,6 +621,23 @@ __global__ __launch_bounds__(256) void k_turbo_vote(VoteArgs a, uint32_t K, cons
     }
 }
 
+// rank tables for the fused rate un-matching: one launch per block size, cached in the context.
+// combo = rv*2 + (K_mimo == 2); M_dl_harq = 8, N_soft = 250368, C = 1 as liblte_phy_pdsch_channel_decode passes them.
+__global__ __launch_bounds__(256) void k_rm_rank_table(uint32_t K, uint16_t *__restrict__ tabs, uint32_t *__restrict__ nnn)
+{
+    const uint32_t combo = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+    RmGeom rm;
+    rm.init(K + 4, (combo & 1) ? 3 : 1, combo >> 1);
+    if (t == 0) nnn[combo] = rm.Nnn;
+    if (t >= 3 * K) return;
+    const uint32_t x = t / K, i = t - x * K;
+    uint32_t p, c;
+    rm.pos_cnt(i, (int)x, p, c);
+    uint32_t k = 0xFFFFu;
+    if (p < rm.N_cb) k = (p >= rm.k0m) ? c - rm.cnt_k0 : rm.Nnn - rm.cnt_k0 + c;
+    tabs[(size_t)combo * 3 * K + t] = (uint16_t)k;
+}
+
 // ------------------------------------------------------------------------------------------------
 // stand-alone turbo rate un-matching with the reference's float interface
 // (liblte_phy_rate_unmatch_turbo, liblte_phy.cc:11246-11490): d[i*3+x] interleaved, positions no
@@ -562,7 +689,7 @@ extern "C" size_t mi_lte_turbo_scratch_bytes(uint32_t K, uint32_t n_cb)
 
 // The five launches of one REF decode over n_cb code blocks of size K.
 template <typename Src, bool GROUP>
-static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, uint8_t *d_c_bits, GroupDesc gd)
+static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, uint8_t *d_c_bits, GroupDesc gd, uint32_t e_cap = 0)
 {
     TurboTables tb;
     int         rc = mi_ctx_turbo_tables(ctx, K, 0, &tb);
@@ -581,7 +708,7 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
     PrepOut po;
     po.arr[0] = arr[AX0]; po.arr[1] = arr[AX1]; po.arr[2] = arr[AX2];
     po.arr[3] = arr[AI0]; po.arr[4] = arr[AM1]; po.arr[5] = arr[AM2];
-    MI_LAUNCH(ctx, "k_turbo_prep", (k_turbo_prep<Src>), dim3(n_cb), dim3(256), 6 * Kp, src, K, n_cb, tb.d_pi, po);
+    MI_LAUNCH(ctx, "k_turbo_prep", (k_turbo_prep<Src>), dim3(n_cb), dim3(256), ((Src::kStage || Src::kRaw) ? 9 : 6) * Kp + 64 + e_cap, src, K, n_cb, tb.d_pi, po);
 
     SisoArgs s1;
     s1.p[0] = {arr[AX1], arr[AX0], arr[AM1], arr[AA1], dec[0]};
@@ -607,7 +734,7 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
 template <typename T>
 static int turbo_ref_batch(mi_lte_ctx *ctx, const T *d_soft, uint32_t K, uint32_t n_cb, uint8_t *d_c_bits)
 {
-    SrcDirect<T> src{d_soft, nullptr};
+    SrcDirect<T> src{0, d_soft, nullptr};
     GroupDesc    none{};
     return turbo_ref_run<SrcDirect<T>, false>(ctx, src, K, n_cb, d_c_bits, none);
 }
@@ -616,14 +743,30 @@ static int turbo_ref_batch(mi_lte_ctx *ctx, const T *d_soft, uint32_t K, uint32_
 // demodulator's soft bits
 int mi_turbo_ref_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_pdsch_alloc *d_allocs,
                        const uint32_t *d_cb_alloc, const int8_t *d_e, const uint32_t *d_e_off, const uint32_t *d_e_len,
-                       uint8_t *d_out_bits, uint32_t out_stride, int32_t *d_status)
+                       uint8_t *d_out_bits, uint32_t out_stride, int32_t *d_status, uint32_t e_max_bytes)
 {
     int rc = mi_ctx_crc_table(ctx);
     if (rc != MI_LTE_OK) return rc;
     GroupDesc gd{d_allocs, d_cb_alloc, d_e, d_e_off, d_e_len, d_out_bits, out_stride, d_status, ctx->d_crc_tab};
+    auto it = ctx->rm_tables.find(K);
+    if (it == ctx->rm_tables.end()) {
+        RmTables t;
+        MI_HIP_CHECK(ctx, hipMalloc((void **)&t.d_tabs, sizeof(uint16_t) * 8 * 3 * K));
+        MI_HIP_CHECK(ctx, hipMalloc((void **)&t.d_nnn, sizeof(uint32_t) * 8));
+        ctx->owned.push_back(t.d_tabs);
+        ctx->owned.push_back(t.d_nnn);
+        MI_LAUNCH(ctx, "k_rm_rank_table", k_rm_rank_table, dim3((3 * K + 255) / 256, 8), dim3(256), 0, K, t.d_tabs, t.d_nnn);
+        MI_HIP_CHECK(ctx, hipGetLastError());
+        it = ctx->rm_tables.emplace(K, t).first;
+    }
     SrcRateUnmatch src;
-    src.g = gd;
-    return turbo_ref_run<SrcRateUnmatch, true>(ctx, src, K, n_cb, nullptr, gd);
+    src.g    = gd;
+    src.tabs = it->second.d_tabs;
+    src.nnn  = it->second.d_nnn;
+    // stage e in LDS when the largest allocation of the group fits next to the block's own arrays
+    const uint32_t cap = (e_max_bytes + 63u) & ~63u;
+    src.e_cap          = (9 * kpad64(K) + 64 + cap <= 64 * 1024) ? cap : 0;
+    return turbo_ref_run<SrcRateUnmatch, true>(ctx, src, K, n_cb, nullptr, gd, src.e_cap);
 }
 
 extern "C" int mi_lte_turbo_decode_batch(mi_lte_ctx *ctx, const void *d_soft, mi_lte_soft_type soft_type, uint32_t K,

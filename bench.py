@@ -299,6 +299,73 @@ class FrontendWorkload:
                 "sample": "%d calls of liblte_phy_get_dl_subframe_and_ce, 1 thread, %.1f s; FFT = float64 radix-2 stand-in" % (reps, t)}
 
 
+class MultiStream:
+    """Run S independent shards of a workload on S contexts (= S HIP streams) of the same GPU, launched
+    back to back and synchronised together.  Units are independent, so this is the same "shard by
+    unit, no exchange" split that is used across GPUs; on one GPU it lets the few-wave trellis kernels
+    of one shard overlap with the wide, LDS-bound kernels of another."""
+
+    def __init__(self, cls, ctxs, n_units, rank):
+        n_units = n_units or {"chain": 8192, "frontend": 10000, "turbo": 65536}[cls.name]
+        per = max(64, (n_units // len(ctxs) + 63) // 64 * 64)
+        self.parts = [cls(c, per, rank * 16 + k) for k, c in enumerate(ctxs)]
+        self.ctxs = ctxs
+        p0 = self.parts[0]
+        self.name, self.metric, self.unit, self.dtype = p0.name, p0.metric, p0.unit, p0.dtype
+        self.alg_bytes_per_unit, self.dominant = p0.alg_bytes_per_unit, p0.dominant
+
+    def step(self):
+        for p in self.parts:
+            p.step()
+
+    def sync(self):
+        for c in self.ctxs:
+            c.sync()
+
+    def profile(self, on):
+        for c in self.ctxs:
+            c.profile(on)
+
+    def profile_report(self):
+        out = {}
+        for c in self.ctxs:
+            for k, (n, ms) in c.profile_report().items():
+                a = out.get(k, (0, 0.0))
+                out[k] = (a[0] + n, a[1] + ms)
+        return out
+
+    def units_per_step(self):
+        return sum(p.units_per_step() for p in self.parts)
+
+    def value_per_unit(self):
+        return self.parts[0].value_per_unit()
+
+    def roofline_bytes(self, kernel, n_launch_per_step):
+        vals = [p.roofline_bytes(kernel, max(1, n_launch_per_step // len(self.parts))) for p in self.parts]
+        return None if any(v is None for v in vals) else sum(vals)
+
+    def config(self, world):
+        c = self.parts[0].config(world)
+        c["streams_per_gpu"] = len(self.parts)
+        c["units_per_gpu_per_step"] = self.units_per_step()
+        return c
+
+    def extra(self, value):
+        if not hasattr(self.parts[0], "extra"):
+            return {}
+        ex = [p.extra(value) for p in self.parts]
+        out = dict(ex[0])
+        if "crc_pass" in out:
+            ok = sum(int(e["crc_pass"].split("/")[0]) for e in ex)
+            tot = sum(int(e["crc_pass"].split("/")[1].split()[0]) for e in ex)
+            out["crc_pass"] = "%d/%d allocations" % (ok, tot)
+            out["sampled_blocks_equal_tx_bits"] = all(e["sampled_blocks_equal_tx_bits"] for e in ex)
+        return out
+
+    def cpu_baseline(self):
+        return self.parts[0].cpu_baseline()
+
+
 WORKLOADS = {"turbo": TurboWorkload, "frontend": FrontendWorkload, "chain": ChainWorkload}
 
 
@@ -315,6 +382,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="auto")
     ap.add_argument("--units", type=int, default=0, help="units (subframes / code blocks) per GPU per step")
+    ap.add_argument("--streams", type=int, default=2, help="independent shards (contexts/streams) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -322,24 +390,26 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     import openlte_amd as m
     n_dev = max(1, m.load_library().mi_lte_device_count())
-    ctx = m.Context(local_rank % n_dev)  # one GPU per rank; the modulo only matters when ranks outnumber GPUs (testing)
-    wl = pick_workload(args.workload)(ctx, args.units, rank)
+    # one GPU per rank; the modulo only matters when ranks outnumber GPUs (testing)
+    ctxs = [m.Context(local_rank % n_dev) for _ in range(max(1, args.streams))]
+    ctx = ctxs[0]
+    wl = MultiStream(pick_workload(args.workload), ctxs, args.units, rank)
 
     for _ in range(args.warmup):
         wl.step()
-    ctx.sync()
-    ctx.profile(True)  # HIP events around every kernel launch, on the launch stream
+    wl.sync()
+    wl.profile(True)  # HIP events around every kernel launch, on the launch stream
     barrier()
-    ctx.sync()
+    wl.sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         wl.step()
-    ctx.sync()
+    wl.sync()
     barrier()
     t1 = time.perf_counter()
     elapsed = max_reduce(t1 - t0)
-    prof = ctx.profile_report()
-    ctx.profile(False)
+    prof = wl.profile_report()
+    wl.profile(False)
 
     if rank == 0:
         units = wl.units_per_step() * world * args.steps
@@ -389,7 +459,8 @@ def main():
                 out["cpu_baseline"] = cb
         print(json.dumps(out))
     barrier()
-    ctx.close()
+    for c in ctxs:
+        c.close()
 
 
 if __name__ == "__main__":

@@ -40,19 +40,8 @@ __device__ __forceinline__ int soft_xor(int a, int b)
     return ((a < 0) != (b < 0)) ? -mag : mag;
 }
 
-// fb[i] of Steps 2/8/9: fb[0] = 127, fb[i] = soft_xor(x[i-2], x[i-3]) with x[<0] = +127
-// (liblte_phy.cc:10676-10685 calling conv_encode_soft :10070-10151 with g = 03, register preset to 127).
-__device__ __forceinline__ int fb_at(const int8_t *x, int i)
-{
-    if (i == 0) return 127;
-    int a = (i >= 2) ? (int)x[i - 2] : 127;
-    int b = (i >= 3) ? (int)x[i - 3] : 127;
-    return soft_xor(a, b);
-}
 
-template <typename T> __device__ __forceinline__ float soft_to_float(T v) { return (float)v; }
-
-__device__ __forceinline__ float block_max_f(float v, float *red /* >= 4 floats */)
+__device__ __forceinline__ float block_max_f(float v, float *red /* >= 8 floats */)
 {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     __syncthreads();
@@ -73,27 +62,6 @@ __device__ __forceinline__ int block_max_i(int v, int *red)
     return r;
 }
 
-// copy n_arr LDS arrays of Kp bytes each into their tile arrays (16 B per thread per step)
-__device__ __forceinline__ void store_tile_lines(uint8_t *const *dst, const int8_t *lds, uint32_t n_arr, uint32_t Kp,
-                                                 size_t tile_off, uint32_t lane)
-{
-    const uint32_t units = Kp >> 4;
-    for (uint32_t idx = threadIdx.x; idx < n_arr * units; idx += blockDim.x) {
-        uint32_t a = idx / units, u = idx - a * units;
-        uint4    v = *reinterpret_cast<const uint4 *>(lds + (size_t)a * Kp + (size_t)u * 16);
-        *reinterpret_cast<uint4 *>(dst[a] + tile_off + (size_t)(u >> 2) * 4096 + lane * 64 + (u & 3) * 16) = v;
-    }
-}
-// load one tile array line-set of this block (lane) into LDS
-__device__ __forceinline__ void load_tile_lines(int8_t *lds, const uint8_t *src, uint32_t Kp, size_t tile_off, uint32_t lane)
-{
-    const uint32_t units = Kp >> 4;
-#pragma unroll 2
-    for (uint32_t u = threadIdx.x; u < units; u += blockDim.x)
-        *reinterpret_cast<uint4 *>(lds + (size_t)u * 16) =
-            *reinterpret_cast<const uint4 *>(src + tile_off + (size_t)(u >> 2) * 4096 + lane * 64 + (u & 3) * 16);
-}
-
 struct PrepOut { uint8_t *arr[6]; }; // X0 X1 X2 I0 M1 M2
 
 // ------------------------------------------------------------------------------------------------
@@ -103,33 +71,80 @@ struct PrepOut { uint8_t *arr[6]; }; // X0 X1 X2 I0 M1 M2
 //   M[t] = (int8)(127*(w_t/W)), w_t = |in[2t]|+|in[2t+1]|, W = max_t w_t   liblte_phy.cc:10449,10498-10524
 //   (the branch weight is the same for every state, so the reference's path-dependent max_weight
 //    reduces to max_t w_t; the sign is applied by the traceback)
+// ---- "unit owner" mapping of the per-code-block kernels (prep, perm, vote):
+// a unit is 16 consecutive trellis indices = one 16-byte quarter of a tile line; thread t owns units
+// t, t+256 (NSLOT = 2 only for K > 4096), keeps them in registers across the phases and exchanges
+// only what is really permuted (q(d0), C1, D1/D2) through LDS.  Little LDS -> many resident waves.
+__device__ __forceinline__ uint4 pack16(const int (&q)[16])
+{
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        w[k] = (uint32_t)(q[4 * k] & 0xFF) | ((uint32_t)(q[4 * k + 1] & 0xFF) << 8) | ((uint32_t)(q[4 * k + 2] & 0xFF) << 16) |
+               ((uint32_t)(q[4 * k + 3] & 0xFF) << 24);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ void unpack16(uint4 v, int (&q)[16])
+{
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 16; k++) q[k] = sbyte(w[k >> 2], k & 3);
+}
+__device__ __forceinline__ size_t unit_off(size_t tile_off, uint32_t lane, uint32_t u)
+{
+    return tile_off + (size_t)(u >> 2) * 4096 + lane * 64 + (u & 3) * 16;
+}
+// 16 uint16 table entries starting at index 16u (nvalid = 16 or 8)
+__device__ __forceinline__ void load_idx16(const uint16_t *tab, uint32_t u, int nvalid, uint32_t (&idx)[16])
+{
+    const uint4 *p = reinterpret_cast<const uint4 *>(tab + 16 * (size_t)u);
+    const uint4  lo = p[0], hi = (nvalid > 8) ? p[1] : make_uint4(0, 0, 0, 0);
+    const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (int k = 0; k < 16; k++) idx[k] = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+}
+
 // ---- where the soft values of a code block come from
 // (a) directly from the caller, in the reference's interleaved d[i*3+x] layout
 template <typename T> struct SrcDirect {
-    static constexpr bool kStage = false;
     uint32_t e_cap;
-    __device__ __forceinline__ void stage_e(int8_t *) {}
-    static constexpr bool kRaw   = sizeof(T) == 1; // int8 blocks are first copied to LDS with dword loads
-    __device__ __forceinline__ int get_int(uint32_t, int) const { return 0; }
     const T *soft;
     const T *d;
     __device__ __forceinline__ void init(uint32_t cb, uint32_t K) { d = soft + (size_t)cb * 3 * (K + 4); }
-    __device__ __forceinline__ void stage_raw(int8_t *lds, uint32_t K)
+    __device__ __forceinline__ void stage_e(int8_t *) {}
+    // v[x][k] = d[(16u+k)*3 + x] for k < nvalid (16 or 8), with Step 0 (RX_NULL_BIT -> 0, liblte_phy.cc:10636-10642)
+    __device__ __forceinline__ void load16(uint32_t u, int nvalid, float (&v)[3][16]) const
     {
-        if (sizeof(T) == 1) { // 3(K+4) bytes: a multiple of 4, and 4-byte aligned because K is a multiple of 8
-            const uint32_t nw = (3 * (K + 4)) >> 2;
-            const uint32_t *g = reinterpret_cast<const uint32_t *>(d);
-            uint32_t       *l = reinterpret_cast<uint32_t *>(lds);
-#pragma unroll 8
-            for (uint32_t w = threadIdx.x; w < nw; w += blockDim.x) l[w] = g[w];
-            __syncthreads();
-            d = reinterpret_cast<const T *>(lds);
+        const T *p = d + (size_t)u * 48;
+        auto put = [&](int e, float t) { // element e = 3*k + x of the unit
+            const int k = e / 3, x = e - 3 * k;
+            v[x][k]     = (k < nvalid && t != (float)RX_NULL_AS_INT) ? t : 0.0f;
+        };
+        if (sizeof(T) == 1) { // 48 (24) bytes, 4-byte aligned
+            const uint32_t *g = reinterpret_cast<const uint32_t *>(p);
+#pragma unroll
+            for (int w = 0; w < 12; w++) {
+                const uint32_t x = (w < 6 || nvalid > 8) ? g[w] : 0u;
+#pragma unroll
+                for (int k = 0; k < 4; k++) put(4 * w + k, (float)sbyte(x, k));
+            }
+        } else if (sizeof(T) == 2) { // 96 (48) bytes, 16-byte aligned
+            const uint4 *g = reinterpret_cast<const uint4 *>(p);
+#pragma unroll
+            for (int w = 0; w < 6; w++) {
+                const uint4    x = (w < 3 || nvalid > 8) ? g[w] : make_uint4(0, 0, 0, 0);
+                const uint32_t c[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                for (int k = 0; k < 8; k++) put(8 * w + k, (float)(int)__builtin_amdgcn_sbfe(c[k >> 1], 16 * (k & 1), 16));
+            }
+        } else { // 192 (96) bytes, 16-byte aligned
+            const float4 *g = reinterpret_cast<const float4 *>(p);
+#pragma unroll
+            for (int w = 0; w < 12; w++) {
+                const float4 x = (w < 6 || nvalid > 8) ? g[w] : make_float4(0, 0, 0, 0);
+                put(4 * w, x.x); put(4 * w + 1, x.y); put(4 * w + 2, x.z); put(4 * w + 3, x.w);
+            }
         }
-    }
-    __device__ __forceinline__ float get(uint32_t i, int x) const
-    {
-        float v = (float)d[i * 3 + x];
-        return (v == (float)RX_NULL_AS_INT) ? 0.0f : v; // Step 0 (liblte_phy.cc:10636-10642)
     }
 };
 
@@ -220,24 +235,7 @@ struct GroupDesc {                 // one launch = the code blocks of one size K
 };
 
 struct SrcRateUnmatch {
-    static constexpr bool kStage = true; // gather once into LDS (int16), then scale from there
-    static constexpr bool kRaw   = false;
     uint32_t e_cap; // bytes of LDS available for staging e (0 = gather from global)
-    // copy the allocation's soft bits into LDS with wide loads: the gather below is otherwise a chain of
-    // dependent byte loads from L2 per element
-    __device__ __forceinline__ void stage_e(int8_t *lds)
-    {
-        if (E <= e_cap) {
-            const uint32_t nq = (E + 15) >> 4; // e_off is 64-byte aligned and padded
-            const uint4   *g  = reinterpret_cast<const uint4 *>(e);
-            uint4         *l  = reinterpret_cast<uint4 *>(lds);
-#pragma unroll 4
-            for (uint32_t w = threadIdx.x; w < nq; w += blockDim.x) l[w] = g[w];
-            __syncthreads();
-            e = lds;
-        }
-    }
-    __device__ __forceinline__ void stage_raw(int8_t *, uint32_t) {}
     GroupDesc       g;
     const uint16_t *tabs; // [8][3K] rank of every d element in the order e is consumed, per (rv, K_mimo)
     const uint32_t *nnn;  // [8]     non-NULL slots per lap of the circular buffer
@@ -254,97 +252,125 @@ struct SrcRateUnmatch {
         e   = g.e_base + g.e_off[a];
         E   = g.e_len[a];
     }
-    __device__ __forceinline__ int get_int(uint32_t i, int x) const
+    // copy the allocation's soft bits into LDS with wide loads (the gather is otherwise a chain of
+    // dependent byte loads from L2)
+    __device__ __forceinline__ void stage_e(int8_t *lds)
     {
-        uint32_t k = tab[x * K_ + i];
-        if (k == 0xFFFFu) return 0; // never filled -> RX_NULL_BIT -> 0 in Step 0
-        int v = 0;
-        for (; k < E; k += Nnn) v += (int)e[k];
-        return v;
+        if (E <= e_cap) {
+            const uint32_t nq = (E + 15) >> 4; // e_off is 64-byte aligned and padded
+            const uint4   *gp = reinterpret_cast<const uint4 *>(e);
+            uint4         *l  = reinterpret_cast<uint4 *>(lds);
+#pragma unroll 4
+            for (uint32_t w = threadIdx.x; w < nq; w += blockDim.x) l[w] = gp[w];
+            __syncthreads();
+            e = lds;
+        }
     }
-    __device__ __forceinline__ float get(uint32_t i, int x) const { return (float)get_int(i, x); }
+    __device__ __forceinline__ void load16(uint32_t u, int nvalid, float (&v)[3][16]) const
+    {
+#pragma unroll
+        for (int x = 0; x < 3; x++) {
+            uint32_t r[16];
+            load_idx16(tab + (size_t)x * K_, u, nvalid, r);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                int acc = 0;
+                if (k < nvalid && r[k] != 0xFFFFu) // 0xFFFF: never filled -> RX_NULL_BIT -> 0 in Step 0
+                    for (uint32_t q = r[k]; q < E; q += Nnn) acc += (int)e[q];
+                v[x][k] = (float)acc;
+            }
+        }
+    }
 };
 
-template <typename Src>
-__global__ __launch_bounds__(256) void k_turbo_prep(Src src, uint32_t K, uint32_t n_cb,
+template <typename Src, int NSLOT>
+__global__ __launch_bounds__(384) void k_turbo_prep(Src src, uint32_t K, uint32_t n_cb,
                                                     const uint16_t *__restrict__ pi, PrepOut out)
 {
-    extern __shared__ __attribute__((aligned(16))) int8_t sm[];
-    __shared__ float red_f[4];
-    __shared__ int   red_i[4];
-    const uint32_t cb = blockIdx.x, tile = cb >> 6, lane = cb & 63, Kp = kpad64(K);
+    extern __shared__ __attribute__((aligned(16))) int8_t sm[]; // q(d0)[Kp] | staged e
+    __shared__ float red_f[8];
+    __shared__ int   red_i[8];
+    const uint32_t cb = blockIdx.x, tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4;
     const size_t   tile_off = (size_t)tile * Kp * 64;
-    int8_t *q0 = sm, *q1 = q0 + Kp, *q2 = q1 + Kp, *i0 = q2 + Kp, *m1 = i0 + Kp, *m2 = m1 + Kp;
+    int8_t        *q0_lds = sm;
     src.init(cb, K);
+    src.stage_e(sm + Kp);
 
+    float v[NSLOT][3][16];
+    int   nval[NSLOT];
     float mx = 0.0f;
-    bool  staged = false;
-    int16_t *sd = reinterpret_cast<int16_t *>(sm + 3 * Kp); // [3][Kp] int16, dead once q0..q2 exist (aliases i0/m1/m2)
-    if (Src::kRaw) src.stage_raw(sm + 3 * Kp, K);
-    if (Src::kStage) {
-        src.stage_e(sm + 9 * Kp + 64);
-        int amax = 0;
-        for (int x = 0; x < 3; x++)
-            for (uint32_t i = threadIdx.x; i < K; i += blockDim.x) {
-                const int v = src.get_int(i, x);
-                sd[x * Kp + i] = (int16_t)v;
-                amax = max(amax, abs(v));
-            }
-        amax   = block_max_i(amax, red_i);
-        staged = amax <= 32767; // otherwise (hundreds of repeats) fall back to gathering twice
-        mx     = (float)amax;
-    }
-    if (!staged) {
-        mx = 0.0f;
-        for (uint32_t i = threadIdx.x; i < K; i += blockDim.x)
-            for (int x = 0; x < 3; x++) mx = fmaxf(mx, fabsf(src.get(i, x)));
-        mx = block_max_f(mx, red_f);
-    }
-
-    // q0..q2 live below sd in LDS, so they can be written while sd is still being read; the arrays that
-    // alias sd (i0, m1, m2) are only written after the barrier that follows
-    for (uint32_t i = threadIdx.x; i < Kp; i += blockDim.x) {
-        int qa = 0, qb = 0, qc = 0;
-        if (i < K) {
-            const float v0 = staged ? (float)sd[i] : src.get(i, 0), v1 = staged ? (float)sd[Kp + i] : src.get(i, 1),
-                        v2 = staged ? (float)sd[2 * Kp + i] : src.get(i, 2);
-            qa = (int)(v0 * 127.0f / mx);
-            qb = (int)(v1 * 127.0f / mx);
-            qc = (int)(v2 * 127.0f / mx);
+#pragma unroll
+    for (int s = 0; s < NSLOT; s++) {
+        const uint32_t u = threadIdx.x + s * blockDim.x;
+        nval[s] = (u < n_units) ? min(16, max(0, (int)K - 16 * (int)u)) : -1;
+        if (nval[s] > 0) src.load16(u, nval[s], v[s]);
+        else {
+#pragma unroll
+            for (int x = 0; x < 3; x++)
+#pragma unroll
+                for (int k = 0; k < 16; k++) v[s][x][k] = 0.0f;
         }
-        q0[i] = (int8_t)qa;
-        q1[i] = (int8_t)qb;
-        q2[i] = (int8_t)qc;
+#pragma unroll
+        for (int x = 0; x < 3; x++)
+#pragma unroll
+            for (int k = 0; k < 16; k++) mx = fmaxf(mx, fabsf(v[s][x][k]));
     }
+    mx = block_max_f(mx, red_f);
+
+    // quantise stream by stream and keep only the packed bytes (4 VGPRs per stream) across the barriers
+    const uint32_t u  = threadIdx.x;
+    const int      nv = nval[0];
+    uint4          Q[3] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+#pragma unroll
+    for (int x = 0; x < 3; x++) {
+        int q[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) q[k] = (k < nv) ? (int)(v[0][x][k] * 127.0f / mx) : 0;
+        Q[x] = pack16(q);
+        if (nv >= 0) *reinterpret_cast<uint4 *>(out.arr[x] + unit_off(tile_off, lane, u)) = Q[x];
+    }
+    if (nv >= 0) *reinterpret_cast<uint4 *>(q0_lds + 16 * u) = Q[0];
     __syncthreads();
 
-    int w1max = 0, w2max = 0;
-#pragma unroll 4
-    for (uint32_t i = threadIdx.x; i < Kp; i += blockDim.x) {
-        int v = 0;
-        if (i < K) {
-            v     = q0[pi[i]];
-            w1max = max(w1max, abs((int)q1[i]) + abs((int)q0[i]));
-            w2max = max(w2max, abs((int)q2[i]) + abs(v));
+    int   w1max = 0, w2max = 0;
+    uint4 I0 = make_uint4(0, 0, 0, 0);
+    {
+        int i0[16], q0[16], q1[16], q2[16];
+        unpack16(Q[0], q0);
+        unpack16(Q[1], q1);
+        unpack16(Q[2], q2);
+#pragma unroll
+        for (int k = 0; k < 16; k++) i0[k] = 0;
+        if (nv > 0) {
+            uint32_t idx[16];
+            load_idx16(pi, u, nv, idx);
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (k < nv) {
+                    i0[k] = q0_lds[idx[k]];
+                    w1max = max(w1max, abs(q1[k]) + abs(q0[k]));
+                    w2max = max(w2max, abs(q2[k]) + abs(i0[k]));
+                }
         }
-        i0[i] = (int8_t)v;
+        I0 = pack16(i0);
+        if (nv >= 0) *reinterpret_cast<uint4 *>(out.arr[3] + unit_off(tile_off, lane, u)) = I0;
     }
     w1max = block_max_i(w1max, red_i);
     w2max = block_max_i(w2max, red_i);
     const float W1 = (float)w1max, W2 = (float)w2max;
-    for (uint32_t i = threadIdx.x; i < Kp; i += blockDim.x) {
-        int a = 0, b = 0;
-        if (i < K) {
-            float w1 = (float)(abs((int)q1[i]) + abs((int)q0[i]));
-            float w2 = (float)(abs((int)q2[i]) + abs((int)i0[i]));
-            a = (int)(127.0f * (w1 / W1));
-            b = (int)(127.0f * (w2 / W2));
-        }
-        m1[i] = (int8_t)a;
-        m2[i] = (int8_t)b;
+    if (nv >= 0) {
+        int m[16], a[16], b[16];
+        unpack16(Q[1], a);
+        unpack16(Q[0], b);
+#pragma unroll
+        for (int k = 0; k < 16; k++) m[k] = (k < nv) ? (int)(127.0f * ((float)(abs(a[k]) + abs(b[k])) / W1)) : 0;
+        *reinterpret_cast<uint4 *>(out.arr[4] + unit_off(tile_off, lane, u)) = pack16(m);
+        unpack16(Q[2], a);
+        unpack16(I0, b);
+#pragma unroll
+        for (int k = 0; k < 16; k++) m[k] = (k < nv) ? (int)(127.0f * ((float)(abs(a[k]) + abs(b[k])) / W2)) : 0;
+        *reinterpret_cast<uint4 *>(out.arr[5] + unit_off(tile_off, lane, u)) = pack16(m);
     }
-    __syncthreads();
-    store_tile_lines(out.arr, sm, 6, Kp, tile_off, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -508,40 +534,74 @@ __global__ __launch_bounds__(64) void k_turbo_siso(SisoArgs args, uint32_t K, ui
 }
 
 // ------------------------------------------------------------------------------------------------
+// helpers for the soft re-encoder on a unit: x[-3..15] = three halo values + the unit's 16 values
+//   fb[i] = soft_xor(x[i-2], x[i-3]) with x[<0] = +127 (fb[0] = 127 falls out of the same formula)
+__device__ __forceinline__ void load_unit_halo(const uint8_t *arr, size_t tile_off, uint32_t lane, uint32_t u, int (&x)[19])
+{
+    const uint4 c = *reinterpret_cast<const uint4 *>(arr + unit_off(tile_off, lane, u));
+    uint32_t    prev = 0x7F7F7F7Fu; // x[-1], x[-2], x[-3] = +127 (conv_encode_soft register preset, liblte_phy.cc:10097-10100)
+    if (u > 0) prev = *reinterpret_cast<const uint32_t *>(arr + unit_off(tile_off, lane, u - 1) + 12);
+    x[0] = sbyte(prev, 1); x[1] = sbyte(prev, 2); x[2] = sbyte(prev, 3);
+    const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[3 + k] = sbyte(w[k >> 2], k & 3);
+}
+
+// ------------------------------------------------------------------------------------------------
 // perm: Steps 2, 3, 5 and the pass-3 output magnitudes.  One workgroup per code block.
 //   C1 = soft_xor(A1, fb(A1)); I1[i] = C1[pi[i]]; M3 from pairs (q(d2), I1)
 struct PermArgs { const uint8_t *A1; const uint8_t *X2; uint8_t *out[2]; /* I1, M3 */ };
 
-__global__ __launch_bounds__(256) void k_turbo_perm(PermArgs a, uint32_t K, const uint16_t *__restrict__ pi)
+template <int NSLOT>
+__global__ __launch_bounds__(384) void k_turbo_perm(PermArgs a, uint32_t K, const uint16_t *__restrict__ pi)
 {
-    extern __shared__ __attribute__((aligned(16))) int8_t sm[];
-    __shared__ int red_i[4];
-    const uint32_t cb = blockIdx.x, tile = cb >> 6, lane = cb & 63, Kp = kpad64(K);
+    extern __shared__ __attribute__((aligned(16))) int8_t sm[]; // C1[Kp]
+    __shared__ int red_i[8];
+    const uint32_t cb = blockIdx.x, tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4;
     const size_t   tile_off = (size_t)tile * Kp * 64;
-    int8_t *i1 = sm, *m3 = i1 + Kp, *a1 = m3 + Kp, *c1 = a1 + Kp, *x2 = c1 + Kp;
-    load_tile_lines(a1, a.A1, Kp, tile_off, lane);
-    load_tile_lines(x2, a.X2, Kp, tile_off, lane);
+    int nval[NSLOT], x2[NSLOT][16];
+#pragma unroll
+    for (int s = 0; s < NSLOT; s++) {
+        const uint32_t u = threadIdx.x + s * blockDim.x;
+        nval[s] = (u < n_units) ? min(16, max(0, (int)K - 16 * (int)u)) : -1;
+        if (nval[s] < 0) continue;
+        int xa[19], c1[16];
+        load_unit_halo(a.A1, tile_off, lane, u, xa);
+        unpack16(*reinterpret_cast<const uint4 *>(a.X2 + unit_off(tile_off, lane, u)), x2[s]);
+#pragma unroll
+        for (int k = 0; k < 16; k++) c1[k] = soft_xor(xa[3 + k], soft_xor(xa[k + 1], xa[k])); // Steps 2-3
+        *reinterpret_cast<uint4 *>(sm + 16 * u) = pack16(c1);
+    }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < K; i += blockDim.x) c1[i] = (int8_t)soft_xor(a1[i], fb_at(a1, (int)i));
-    __syncthreads();
-    int wmax = 0;
-    for (uint32_t i = threadIdx.x; i < Kp; i += blockDim.x) {
-        int v = 0;
-        if (i < K) {
-            v    = c1[pi[i]];
-            wmax = max(wmax, abs((int)x2[i]) + abs(v));
+    int i1[NSLOT][16], wmax = 0;
+#pragma unroll
+    for (int s = 0; s < NSLOT; s++) {
+        const uint32_t u = threadIdx.x + s * blockDim.x;
+#pragma unroll
+        for (int k = 0; k < 16; k++) i1[s][k] = 0;
+        if (nval[s] > 0) {
+            uint32_t idx[16];
+            load_idx16(pi, u, nval[s], idx);
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (k < nval[s]) {
+                    i1[s][k] = sm[idx[k]]; // Step 5
+                    wmax     = max(wmax, abs(x2[s][k]) + abs(i1[s][k]));
+                }
         }
-        i1[i] = (int8_t)v;
+        if (nval[s] >= 0) *reinterpret_cast<uint4 *>(a.out[0] + unit_off(tile_off, lane, u)) = pack16(i1[s]);
     }
     wmax          = block_max_i(wmax, red_i);
     const float W = (float)wmax;
-    for (uint32_t i = threadIdx.x; i < Kp; i += blockDim.x) {
-        int m = 0;
-        if (i < K) m = (int)(127.0f * ((float)(abs((int)x2[i]) + abs((int)i1[i])) / W));
-        m3[i] = (int8_t)m;
+#pragma unroll
+    for (int s = 0; s < NSLOT; s++) {
+        const uint32_t u = threadIdx.x + s * blockDim.x;
+        if (nval[s] < 0) continue;
+        int m3[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) m3[k] = (k < nval[s]) ? (int)(127.0f * ((float)(abs(x2[s][k]) + abs(i1[s][k])) / W)) : 0;
+        *reinterpret_cast<uint4 *>(a.out[1] + unit_off(tile_off, lane, u)) = pack16(m3);
     }
-    __syncthreads();
-    store_tile_lines(a.out, sm, 2, Kp, tile_off, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -552,72 +612,98 @@ struct VoteArgs { const uint8_t *X0, *A1, *B1, *B2; };
 // GROUP = true : finish dlsch_channel_decode (liblte_phy.cc:12840-12869): drop the F filler positions
 //                (liblte_phy_code_block_desegmentation, :9948-9986), check CRC24A (calc_crc :9713-9743)
 //                and report LIBLTE_SUCCESS / LIBLTE_ERROR_DECODE_FAIL like liblte_phy_pdsch_channel_decode.
-template <bool GROUP>
-__global__ __launch_bounds__(256) void k_turbo_vote(VoteArgs a, uint32_t K, const uint16_t *__restrict__ inv,
+template <bool GROUP, int NSLOT>
+__global__ __launch_bounds__(384) void k_turbo_vote(VoteArgs a, uint32_t K, const uint16_t *__restrict__ inv,
                                                     uint8_t *__restrict__ c_bits, GroupDesc g)
 {
-    extern __shared__ __attribute__((aligned(16))) int8_t sm[];
-    __shared__ uint32_t red_u[4];
-    const uint32_t cb = blockIdx.x, tile = cb >> 6, lane = cb & 63, Kp = kpad64(K);
+    extern __shared__ __attribute__((aligned(16))) int8_t sm[]; // D1[Kp] | D2[Kp] | (GROUP) bits[Kp]
+    __shared__ uint32_t red_u[8];
+    const uint32_t cb = blockIdx.x, tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4;
     const size_t   tile_off = (size_t)tile * Kp * 64;
-    int8_t *x0 = sm, *a1 = x0 + Kp, *b1 = a1 + Kp, *b2 = b1 + Kp, *d1 = b2 + Kp, *d2 = d1 + Kp;
-    load_tile_lines(x0, a.X0, Kp, tile_off, lane);
-    load_tile_lines(a1, a.A1, Kp, tile_off, lane);
-    load_tile_lines(b1, a.B1, Kp, tile_off, lane);
-    load_tile_lines(b2, a.B2, Kp, tile_off, lane);
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < K; i += blockDim.x) {
-        const int A = a1[i], B = b1[i], G = fb_at(b1, (int)i), B_ = b2[i], G_ = fb_at(b2, (int)i);
-        int       v1, v2;
-        // Step 10 (liblte_phy.cc:10778-10797); the mixed-sign branches read in_act_1 (A), not int_act_1
-        if (B >= 0 && G >= 0)     v1 = (B + G) >> 1;
-        else if (B < 0 && G < 0)  v1 = (-B - G) >> 1;
-        else if (B >= 0 && G < 0) v1 = -((A - G) >> 1);
-        else                      v1 = -((-A + G) >> 1);
-        // Step 11 (liblte_phy.cc:10800-10819); last branch is -((-a - b) >> 1)
-        if (B_ >= 0 && G_ >= 0)     v2 = (B_ + G_) >> 1;
-        else if (B_ < 0 && G_ < 0)  v2 = (-B_ - G_) >> 1;
-        else if (B_ >= 0 && G_ < 0) v2 = -((B_ - G_) >> 1);
-        else                        v2 = -((-B_ - G_) >> 1);
-        d1[i] = (int8_t)v1;
-        d2[i] = (int8_t)v2;
+    int8_t *d1 = sm, *d2 = sm + Kp, *bits = sm + 2 * Kp;
+    int nval[NSLOT], s0[NSLOT][16]; // s0 = q(d0) + C1, the part of the vote that is not de-interleaved
+#pragma unroll
+    for (int s = 0; s < NSLOT; s++) {
+        const uint32_t u = threadIdx.x + s * blockDim.x;
+        nval[s] = (u < n_units) ? min(16, max(0, (int)K - 16 * (int)u)) : -1;
+        if (nval[s] < 0) continue;
+        int xa[19], xb[19], xc[19], x0[16], v1[16], v2[16];
+        load_unit_halo(a.A1, tile_off, lane, u, xa);
+        load_unit_halo(a.B1, tile_off, lane, u, xb);
+        load_unit_halo(a.B2, tile_off, lane, u, xc);
+        unpack16(*reinterpret_cast<const uint4 *>(a.X0 + unit_off(tile_off, lane, u)), x0);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int A = xa[3 + k], B = xb[3 + k], G = soft_xor(xb[k + 1], xb[k]), B_ = xc[3 + k], G_ = soft_xor(xc[k + 1], xc[k]);
+            // Step 10 (liblte_phy.cc:10778-10797); the mixed-sign branches read in_act_1 (A), not int_act_1
+            if (B >= 0 && G >= 0)     v1[k] = (B + G) >> 1;
+            else if (B < 0 && G < 0)  v1[k] = (-B - G) >> 1;
+            else if (B >= 0 && G < 0) v1[k] = -((A - G) >> 1);
+            else                      v1[k] = -((-A + G) >> 1);
+            // Step 11 (liblte_phy.cc:10800-10819); last branch is -((-a - b) >> 1)
+            if (B_ >= 0 && G_ >= 0)     v2[k] = (B_ + G_) >> 1;
+            else if (B_ < 0 && G_ < 0)  v2[k] = (-B_ - G_) >> 1;
+            else if (B_ >= 0 && G_ < 0) v2[k] = -((B_ - G_) >> 1);
+            else                        v2[k] = -((-B_ - G_) >> 1);
+            s0[s][k] = x0[k] + soft_xor(A, soft_xor(xa[k + 1], xa[k])); // q(d0) + C1 (Steps 2-3)
+        }
+        *reinterpret_cast<uint4 *>(d1 + 16 * u) = pack16(v1);
+        *reinterpret_cast<uint4 *>(d2 + 16 * u) = pack16(v2);
     }
     __syncthreads();
     uint32_t alloc = 0, tbs = 0, F = 0, crc = 0, par = 0;
-    uint8_t *o = c_bits + (size_t)cb * K;
     if (GROUP) {
         alloc = g.cb_alloc[cb];
         tbs   = g.allocs[alloc].tbs;
         F     = K - tbs - 24;
-        o     = g.out_bits + (size_t)alloc * g.out_stride;
     }
-    for (uint32_t j = threadIdx.x; j < K; j += blockDim.x) {
-        const int      c1 = soft_xor(a1[j], fb_at(a1, (int)j));
-        const uint32_t i  = inv[j]; // Steps 12/13: de-interleave; a hole contributes 0
-        const int      c2 = (i != 0xFFFFu) ? (int)d1[i] : 0;
-        const int      c3 = (i != 0xFFFFu) ? (int)d2[i] : 0;
-        const uint32_t bit = ((int)x0[j] + c1 + c2 + c3 >= 0) ? 0u : 1u; // Step 14
-        if (!GROUP) o[j] = (uint8_t)bit;
-        else if (j >= F) {
-            const uint32_t m = j - F; // index into b = a (tbs bits) | p (24 bits)
-            if (m < tbs) {
-                o[m] = (uint8_t)bit;
-                if (bit) crc ^= g.crc_tab[tbs - 1 - m]; // CRC is linear: XOR of x^(e+24) mod g over the set bits
-            } else
-                par |= bit << (23 - (m - tbs));
+#pragma unroll
+    for (int s = 0; s < NSLOT; s++) {
+        const uint32_t u = threadIdx.x + s * blockDim.x;
+        if (nval[s] <= 0) continue;
+        uint32_t idx[16];
+        int      b[16];
+        load_idx16(inv, u, nval[s], idx);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            b[k] = 0;
+            if (k < nval[s]) {
+                const uint32_t i = idx[k]; // Steps 12/13: de-interleave; a hole contributes 0
+                const int c2 = (i != 0xFFFFu) ? (int)d1[i] : 0, c3 = (i != 0xFFFFu) ? (int)d2[i] : 0;
+                b[k] = (s0[s][k] + c2 + c3 >= 0) ? 0 : 1; // Step 14
+                if (GROUP) {
+                    const uint32_t j = 16 * u + k;
+                    if (j >= F) {
+                        const uint32_t m = j - F; // index into b = a (tbs bits) | p (24 bits)
+                        if (m < tbs) { if (b[k]) crc ^= g.crc_tab[tbs - 1 - m]; } // CRC is linear over GF(2)
+                        else par |= (uint32_t)b[k] << (23 - (m - tbs));
+                    }
+                }
+            }
+        }
+        const uint4 pk = pack16(b);
+        if (GROUP) *reinterpret_cast<uint4 *>(bits + 16 * u) = pk;
+        else {
+            uint2 *o = reinterpret_cast<uint2 *>(c_bits + (size_t)cb * K + 16 * u); // 8-byte aligned (K % 8 == 0)
+            o[0] = make_uint2(pk.x, pk.y);
+            if (nval[s] > 8) o[1] = make_uint2(pk.z, pk.w);
         }
     }
     if (GROUP) {
-        for (int s = 32; s > 0; s >>= 1) { crc ^= __shfl_xor(crc, s); par |= __shfl_xor(par, s); }
+        for (int sft = 32; sft > 0; sft >>= 1) { crc ^= __shfl_xor(crc, sft); par |= __shfl_xor(par, sft); }
         __syncthreads();
         if ((threadIdx.x & 63) == 0) red_u[threadIdx.x >> 6] = crc;
         __syncthreads();
-        crc = red_u[0] ^ red_u[1] ^ red_u[2] ^ red_u[3];
+        crc = 0;
+        for (uint32_t w = 0; w < (blockDim.x >> 6); w++) crc ^= red_u[w];
         __syncthreads();
         if ((threadIdx.x & 63) == 0) red_u[threadIdx.x >> 6] = par;
         __syncthreads();
-        par = red_u[0] | red_u[1] | red_u[2] | red_u[3];
+        par = 0;
+        for (uint32_t w = 0; w < (blockDim.x >> 6); w++) par |= red_u[w];
         if (threadIdx.x == 0) g.status[alloc] = (crc == par) ? 0 /* LIBLTE_SUCCESS */ : 3 /* LIBLTE_ERROR_DECODE_FAIL */;
+        uint8_t *o = g.out_bits + (size_t)alloc * g.out_stride;
+        for (uint32_t m = threadIdx.x; m < tbs; m += blockDim.x) o[m] = (uint8_t)bits[m + F];
     }
 }
 
@@ -708,7 +794,8 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
     PrepOut po;
     po.arr[0] = arr[AX0]; po.arr[1] = arr[AX1]; po.arr[2] = arr[AX2];
     po.arr[3] = arr[AI0]; po.arr[4] = arr[AM1]; po.arr[5] = arr[AM2];
-    MI_LAUNCH(ctx, "k_turbo_prep", (k_turbo_prep<Src>), dim3(n_cb), dim3(256), ((Src::kStage || Src::kRaw) ? 9 : 6) * Kp + 64 + e_cap, src, K, n_cb, tb.d_pi, po);
+    const uint32_t cb_threads = (uint32_t)(((Kp >> 4) + 63) & ~(size_t)63); // one thread per 16-step unit: 64..384
+    MI_LAUNCH(ctx, "k_turbo_prep", (k_turbo_prep<Src, 1>), dim3(n_cb), dim3(cb_threads), Kp + e_cap, src, K, n_cb, tb.d_pi, po);
 
     SisoArgs s1;
     s1.p[0] = {arr[AX1], arr[AX0], arr[AM1], arr[AA1], dec[0]};
@@ -717,7 +804,7 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
 
     PermArgs pa;
     pa.A1 = arr[AA1]; pa.X2 = arr[AX2]; pa.out[0] = arr[AI1]; pa.out[1] = arr[AM3];
-    MI_LAUNCH(ctx, "k_turbo_perm", k_turbo_perm, dim3(n_cb), dim3(256), 5 * Kp, pa, K, tb.d_pi);
+    MI_LAUNCH(ctx, "k_turbo_perm", k_turbo_perm<1>, dim3(n_cb), dim3(cb_threads), Kp, pa, K, tb.d_pi);
 
     SisoArgs s23;
     s23.p[0] = {arr[AX2], arr[AI0], arr[AM2], arr[AB1], dec[1]};
@@ -725,7 +812,7 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
     MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso, dim3(n_tiles, 2), dim3(64), 0, s23, K, 1u);
 
     VoteArgs va = {arr[AX0], arr[AA1], arr[AB1], arr[AB2]};
-    MI_LAUNCH(ctx, "k_turbo_vote", (k_turbo_vote<GROUP>), dim3(n_cb), dim3(256), 6 * Kp, va, K, tb.d_inv, d_c_bits, gd);
+    MI_LAUNCH(ctx, "k_turbo_vote", (k_turbo_vote<GROUP, 1>), dim3(n_cb), dim3(cb_threads), 3 * Kp, va, K, tb.d_inv, d_c_bits, gd);
     MI_HIP_CHECK(ctx, hipGetLastError());
     ctx->last_kernels = "k_turbo_prep:1,k_turbo_siso:2,k_turbo_perm:1,k_turbo_vote:1";
     return MI_LTE_OK;
@@ -765,7 +852,7 @@ int mi_turbo_ref_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_
     src.nnn  = it->second.d_nnn;
     // stage e in LDS when the largest allocation of the group fits next to the block's own arrays
     const uint32_t cap = (e_max_bytes + 63u) & ~63u;
-    src.e_cap          = (9 * kpad64(K) + 64 + cap <= 64 * 1024) ? cap : 0;
+    src.e_cap          = (kpad64(K) + cap <= 48 * 1024) ? cap : 0;
     return turbo_ref_run<SrcRateUnmatch, true>(ctx, src, K, n_cb, nullptr, gd, src.e_cap);
 }
 

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void k_pdsch_demod(const float *__restrict__ s
 
     // ---- phase 2: scrambling sequence words (c_init per liblte_phy.cc:3831)
     const uint32_t c_init = (al.rnti << 14) | (0u << 13) | (sf << 9) | cell, n_words = (N_bits + 31) / 32;
-    for (uint32_t w = threadIdx.x; w < n_words; w += blockDim.x) cw[w] = gold_word(gt, c_init, w);
+    for (uint32_t w = threadIdx.x; w <= n_words; w += blockDim.x) cw[w] = gold_word(gt, c_init, w); // one word of slack for the 2-word window in put_bits
     __syncthreads();
 
     // ---- phase 3: per group of N_ant REs: gather, pre-decode, de-map, descramble
@@ -184,23 +184,50 @@ __global__ __launch_bounds__(256) void k_pdsch_demod(const float *__restrict__ s
     // soft bits are assembled in LDS when they fit and leave with 16-byte stores
     int8_t    *e_lds  = reinterpret_cast<int8_t *>(cw + max_words);
     const bool via_lds = N_bits <= e_lds_cap;
-    int8_t    *e_dst  = via_lds ? e_lds : e;
-    if (N_ant == 1) { // one RE = one symbol (liblte_phy.cc:7684-7690): thread per (PRB-symbol pair, sub-carrier), no search
-        for (uint32_t t = threadIdx.x; t < n_pairs * 12; t += blockDim.x) {
-            const uint32_t q = t / 12, j = t - q * 12, mk = masks[q];
-            if (!((mk >> j) & 1u)) continue;
-            const uint32_t idx = offs[q] + __popc(mk & ((1u << j) - 1u)), p = (mk >> 12) + j;
-            const float yr = y_re_p[p], yi = y_im_p[p], hr = h_re_p[p], hi = h_im_p[p];
-            const float hn = hr * hr + hi * hi;
-            const float xr = (yr * hr + yi * hi) / hn, xi = (yi * hr - yr * hi) / hn;
-            int8_t b[6];
-            demap_symbol(xr, xi, al.mod_type, b);
-            const uint32_t n0 = idx * Qm;
-            for (uint32_t k = 0; k < Qm; k++) {
-                const uint32_t n = n0 + k, c = (cw[n >> 5] >> (n & 31)) & 1u;
-                e_dst[n] = c ? (int8_t)-b[k] : b[k];
-            }
+    // descramble + store the Q_m soft bits of symbol idx: c bit set -> negate (liblte_phy.cc:3833-3836).
+    // Q_m*idx is even for Q_m >= 2, so pairs of bytes leave as one 16-bit store.
+    auto put_bits = [&](auto *dst, uint32_t idx, const int8_t (&b)[6]) {
+        const uint32_t n0 = idx * Qm, w = n0 >> 5, sh = n0 & 31;
+        const uint32_t c = __builtin_amdgcn_alignbit(cw[w + 1], cw[w], sh); // bits n0.. of the scrambling sequence (cw is padded by one word)
+        if (Qm == 1) dst[n0] = (c & 1u) ? (int8_t)-b[0] : b[0];
+        else {
+#pragma unroll
+            for (uint32_t k = 0; k < 6; k += 2)
+                if (k < Qm) {
+                    const int lo = ((c >> k) & 1u) ? -b[k] : b[k], hi = ((c >> (k + 1)) & 1u) ? -b[k + 1] : b[k + 1];
+                    *reinterpret_cast<uint16_t *>(dst + n0 + k) = (uint16_t)((lo & 0xFF) | ((hi & 0xFF) << 8));
+                }
         }
+    };
+    if (N_ant == 1) { // one RE = one symbol (liblte_phy.cc:7684-7690): thread per (PRB-symbol pair, sub-carrier), no search
+        constexpr int UNR = 4; // loads of UNR independent REs in flight per thread (the kernel is latency-bound otherwise)
+        auto body = [&](auto *dst) {
+            const uint32_t total = n_pairs * 12;
+            for (uint32_t t0 = threadIdx.x; t0 < total; t0 += UNR * blockDim.x) {
+                float    yr[UNR], yi[UNR], hr[UNR], hi[UNR];
+                uint32_t idx[UNR];
+                bool     on[UNR];
+#pragma unroll
+                for (int r = 0; r < UNR; r++) {
+                    const uint32_t t = t0 + r * blockDim.x, tc = t < total ? t : 0u;
+                    const uint32_t q = tc / 12, j = tc - q * 12, mk = masks[q];
+                    on[r]  = t < total && ((mk >> j) & 1u);
+                    idx[r] = offs[q] + __popc(mk & ((1u << j) - 1u));
+                    const uint32_t p = on[r] ? (mk >> 12) + j : 0u;
+                    yr[r] = y_re_p[p]; yi[r] = y_im_p[p]; hr[r] = h_re_p[p]; hi[r] = h_im_p[p];
+                }
+#pragma unroll
+                for (int r = 0; r < UNR; r++) {
+                    if (!on[r]) continue;
+                    const float hn = hr[r] * hr[r] + hi[r] * hi[r];
+                    const float xr = (yr[r] * hr[r] + yi[r] * hi[r]) / hn, xi = (yi[r] * hr[r] - yr[r] * hi[r]) / hn;
+                    int8_t b[6] = {0, 0, 0, 0, 0, 0};
+                    demap_symbol(xr, xi, al.mod_type, b);
+                    put_bits(dst, idx[r], b);
+                }
+            }
+        };
+        if (via_lds) body(e_lds); else body(e);
     } else
     for (uint32_t i = threadIdx.x; i < n_grp; i += blockDim.x) {
         float x_re[4], x_im[4];
@@ -234,13 +261,9 @@ __global__ __launch_bounds__(256) void k_pdsch_demod(const float *__restrict__ s
         }
         // layer de-mapping d[i*N_ant + p] = x_p[i] (liblte_phy.cc:7506-7513), de-map, descramble (:3833-3836)
         for (uint32_t p = 0; p < N_ant; p++) {
-            int8_t b[6];
+            int8_t b[6] = {0, 0, 0, 0, 0, 0};
             demap_symbol(x_re[p], x_im[p], al.mod_type, b);
-            const uint32_t n0 = (i * N_ant + p) * Qm;
-            for (uint32_t k = 0; k < Qm; k++) {
-                const uint32_t n = n0 + k, c = (cw[n >> 5] >> (n & 31)) & 1u;
-                e_dst[n] = c ? (int8_t)-b[k] : b[k];
-            }
+            if (via_lds) put_bits(e_lds, i * N_ant + p, b); else put_bits(e, i * N_ant + p, b);
         }
     }
     if (via_lds) {
@@ -312,7 +335,7 @@ int mi_lte_pdsch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, uint32_t
         pl->h_e_off[a] = (uint32_t)off;
         off += (e_max + 63) & ~63u;
     }
-    if (pl->max_words > 4096) {
+    if (pl->max_words > 4095) { // the demodulator reads one word past the allocation's last scrambling word
         ctx->err = "allocation larger than the scrambling table";
         delete pl;
         return MI_LTE_ERR_UNSUPPORTED;
@@ -372,7 +395,7 @@ int mi_lte_pdsch_decode_run(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, const float 
     DemodGeom  g{pl->cfg.N_rb_dl, pl->cfg.N_ant, pl->cfi, (uint32_t)mi_lte_subframe_floats(pl->cfg.N_ant)};
     GoldTables gt{ctx->d_gold_x1, ctx->d_gold_x2b, ctx->gold_words};
     // LDS: offs | masks | scrambling words | (when it fits in 32 KiB) the allocation's soft bits
-    const uint32_t words_al = (pl->max_words + 3u) & ~3u, e_bytes = (pl->max_words * 32 + 63u) & ~63u;
+    const uint32_t words_al = (pl->max_words + 1u + 3u) & ~3u, e_bytes = (pl->max_words * 32 + 63u) & ~63u;
     const uint32_t e_cap = (e_bytes <= 32 * 1024) ? e_bytes : 0;
     const uint32_t pairs_al = ((2 * pl->max_pairs + 1 + 3u) & ~3u);
     const size_t lds = sizeof(uint32_t) * ((size_t)pairs_al + words_al) + e_cap;

@@ -272,15 +272,14 @@ int mi_ctx_gold_tables(mi_lte_ctx *ctx)
 }
 
 // CRC24A (36.212 5.1.1, g = 0x1864CFB; reference calc_crc, liblte_phy.cc:9713-9743) is linear over
-// GF(2): the remainder of a message is the XOR of x^(e+24) mod g over its set bits, e = distance of
-// the bit from the end of the message.  tab[e] = x^(e+24) mod g.
+// GF(2): a(x)*x^24 mod g == p(x) exactly when the XOR of x^e mod g over the set bits of the whole
+// block a|p (e = distance of the bit from the end of the block) is zero.  tab[e] = x^e mod g.
 int mi_ctx_crc_table(mi_lte_ctx *ctx)
 {
     if (ctx->d_crc_tab) return MI_LTE_OK;
     const uint32_t N = 6144;
     std::vector<uint32_t> tab(N);
     uint32_t r = 1; // x^0
-    for (uint32_t e = 0; e < 24; e++) { r <<= 1; if (r & 0x1000000u) r ^= 0x1864CFBu; } // x^24 mod g
     for (uint32_t e = 0; e < N; e++) {
         tab[e] = r;
         r <<= 1;

@@ -64,6 +64,13 @@ __device__ __forceinline__ int block_max_i(int v, int *red)
 
 struct PrepOut { uint8_t *arr[6]; }; // X0 X1 X2 I0 M1 M2
 
+// XCD-aware block -> code block mapping for the one-workgroup-per-code-block kernels.  Workgroup b runs
+// on XCD b % 8 (observed dispatch order; used for speed only), and a tile line is 64 bytes per code
+// block inside a 4 KiB burst shared by 64 code blocks: giving each XCD a contiguous range of tiles keeps
+// all writers (readers) of a burst behind one L2, so lines leave for HBM whole instead of in halves.
+__host__ __device__ inline uint32_t xcd_chunk(uint32_t n_cb) { return ((((n_cb + 63u) >> 6) + 7u) >> 3) << 6; } // code blocks per XCD
+__device__ __forceinline__ uint32_t xcd_cb(uint32_t b, uint32_t n_cb) { return (b & 7u) * xcd_chunk(n_cb) + (b >> 3); }
+
 // ------------------------------------------------------------------------------------------------
 // prep: Step 0 (NULL -> 0), Step 1 scaling to int8, Step 4 (interleave d0), SISO output magnitudes
 // for passes 1 and 2.  One workgroup per code block.
@@ -107,13 +114,14 @@ __device__ __forceinline__ void load_idx16(const uint16_t *tab, uint32_t u, int 
 // ---- where the soft values of a code block come from
 // (a) directly from the caller, in the reference's interleaved d[i*3+x] layout
 template <typename T> struct SrcDirect {
+    static constexpr bool kIntegerValued = sizeof(T) != 4; // int8 / int16 soft values
     uint32_t e_cap;
     const T *soft;
     const T *d;
     __device__ __forceinline__ void init(uint32_t cb, uint32_t K) { d = soft + (size_t)cb * 3 * (K + 4); }
-    __device__ __forceinline__ void stage_e(int8_t *) {}
+    __device__ __forceinline__ bool stage_e(int8_t *) { return false; }
     // v[x][k] = d[(16u+k)*3 + x] for k < nvalid (16 or 8), with Step 0 (RX_NULL_BIT -> 0, liblte_phy.cc:10636-10642)
-    __device__ __forceinline__ void load16(uint32_t u, int nvalid, float (&v)[3][16]) const
+    __device__ __forceinline__ void load16(uint32_t u, int nvalid, float (&v)[3][16], const int8_t *, bool) const
     {
         const T *p = d + (size_t)u * 48;
         auto put = [&](int e, float t) { // element e = 3*k + x of the unit
@@ -231,10 +239,11 @@ struct GroupDesc {                 // one launch = the code blocks of one size K
     uint8_t        *out_bits;      // [n_alloc][out_stride] decoded transport block, one bit per byte
     uint32_t        out_stride;
     int32_t        *status;        // [n_alloc] LIBLTE_ERROR_ENUM value
-    const uint32_t *crc_tab;       // x^(e+24) mod gCRC24A for e = 0..6143
+    const uint32_t *crc_tab;       // x^e mod gCRC24A for e = 0..6143
 };
 
 struct SrcRateUnmatch {
+    static constexpr bool kIntegerValued = true; // sums of int8 soft bits
     uint32_t e_cap; // bytes of LDS available for staging e (0 = gather from global)
     GroupDesc       g;
     const uint16_t *tabs; // [8][3K] rank of every d element in the order e is consumed, per (rv, K_mimo)
@@ -253,48 +262,74 @@ struct SrcRateUnmatch {
         E   = g.e_len[a];
     }
     // copy the allocation's soft bits into LDS with wide loads (the gather is otherwise a chain of
-    // dependent byte loads from L2)
-    __device__ __forceinline__ void stage_e(int8_t *lds)
+    // dependent byte loads from L2); returns whether the copy was made
+    __device__ __forceinline__ bool stage_e(int8_t *lds)
     {
-        if (E <= e_cap) {
-            const uint32_t nq = (E + 15) >> 4; // e_off is 64-byte aligned and padded
-            const uint4   *gp = reinterpret_cast<const uint4 *>(e);
-            uint4         *l  = reinterpret_cast<uint4 *>(lds);
+        if (E > e_cap) return false;
+        const uint32_t nq = (E + 15) >> 4; // e_off is 64-byte aligned and padded
+        const uint4   *gp = reinterpret_cast<const uint4 *>(e);
+        uint4         *l  = reinterpret_cast<uint4 *>(lds);
 #pragma unroll 4
-            for (uint32_t w = threadIdx.x; w < nq; w += blockDim.x) l[w] = gp[w];
-            __syncthreads();
-            e = lds;
-        }
+        for (uint32_t w = threadIdx.x; w < nq; w += blockDim.x) l[w] = gp[w];
+        __syncthreads();
+        return true;
     }
-    __device__ __forceinline__ void load16(uint32_t u, int nvalid, float (&v)[3][16]) const
+    // d[(16u+k)*3+x] = sum over laps t of e[rank + t*Nnn] (first visit stores, repeats add, :11402-11416).
+    // All first-lap loads of a unit are independent; later laps (uniform trip count) are masked.
+    template <typename P> __device__ __forceinline__ void gather16(P ep, uint32_t u, int nvalid, float (&v)[3][16]) const
     {
 #pragma unroll
         for (int x = 0; x < 3; x++) {
             uint32_t r[16];
+            int      acc[16];
             load_idx16(tab + (size_t)x * K_, u, nvalid, r);
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                int acc = 0;
-                if (k < nvalid && r[k] != 0xFFFFu) // 0xFFFF: never filled -> RX_NULL_BIT -> 0 in Step 0
-                    for (uint32_t q = r[k]; q < E; q += Nnn) acc += (int)e[q];
-                v[x][k] = (float)acc;
+            for (int k = 0; k < 16; k++) { // 0xFFFF: never filled -> RX_NULL_BIT -> 0 in Step 0
+                const bool ok = k < nvalid && r[k] != 0xFFFFu && r[k] < E;
+                const int  t  = (int)ep[ok ? r[k] : 0u]; // unconditional load, clamped index: no branch, loads stay in flight together
+                acc[k]        = ok ? t : 0;
+                if (!ok) r[k] = 0xFFFFFFFFu - 65536u * 4u; // keeps r + t*Nnn >= E without overflowing
             }
+            for (uint32_t base = Nnn; base < E; base += Nnn) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const uint32_t q = r[k] + base;
+                    const int      t = (int)ep[q < E ? q : 0u];
+                    acc[k] += (q < E) ? t : 0;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[x][k] = (float)acc[k];
         }
     }
+    __device__ __forceinline__ void load16(uint32_t u, int nvalid, float (&v)[3][16], const int8_t *e_lds, bool in_lds) const
+    {
+        if (in_lds) gather16(e_lds, u, nvalid, v); // ds_read path
+        else        gather16(e, u, nvalid, v);
+    }
 };
+
+// LDS tables that replace the per-element IEEE divisions: the quantiser and the SISO output magnitude
+// are functions of one small integer and a per-block constant, so each distinct value is divided once
+// (with exactly the reference's float expression) and every element looks its result up.
+constexpr uint32_t QTAB_N = 2048; // q(a) for |x| = a <= 2047; larger maxima fall back to dividing per element
+constexpr uint32_t MTAB_N = 256;  // w = |a|+|b| <= 254
+constexpr uint32_t PREP_TAB_BYTES = QTAB_N + 2 * MTAB_N;
 
 template <typename Src, int NSLOT>
 __global__ __launch_bounds__(384) void k_turbo_prep(Src src, uint32_t K, uint32_t n_cb,
                                                     const uint16_t *__restrict__ pi, PrepOut out)
 {
-    extern __shared__ __attribute__((aligned(16))) int8_t sm[]; // q(d0)[Kp] | staged e
+    extern __shared__ __attribute__((aligned(16))) int8_t sm[]; // qtab | mtab1 | mtab2 | q(d0)[Kp] | staged e
     __shared__ float red_f[8];
     __shared__ int   red_i[8];
-    const uint32_t cb = blockIdx.x, tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4;
+    const uint32_t cb = xcd_cb(blockIdx.x, n_cb), tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4;
+    if (cb >= n_cb) return; // uniform
     const size_t   tile_off = (size_t)tile * Kp * 64;
-    int8_t        *q0_lds = sm;
+    int8_t        *qtab = sm, *mtab1 = sm + QTAB_N, *mtab2 = mtab1 + MTAB_N, *q0_lds = sm + PREP_TAB_BYTES;
     src.init(cb, K);
-    src.stage_e(sm + Kp);
+    const int8_t *e_lds = q0_lds + Kp;
+    const bool    e_in_lds = src.stage_e(q0_lds + Kp);
 
     float v[NSLOT][3][16];
     int   nval[NSLOT];
@@ -303,7 +338,7 @@ __global__ __launch_bounds__(384) void k_turbo_prep(Src src, uint32_t K, uint32_
     for (int s = 0; s < NSLOT; s++) {
         const uint32_t u = threadIdx.x + s * blockDim.x;
         nval[s] = (u < n_units) ? min(16, max(0, (int)K - 16 * (int)u)) : -1;
-        if (nval[s] > 0) src.load16(u, nval[s], v[s]);
+        if (nval[s] > 0) src.load16(u, nval[s], v[s], e_lds, e_in_lds);
         else {
 #pragma unroll
             for (int x = 0; x < 3; x++)
@@ -316,6 +351,11 @@ __global__ __launch_bounds__(384) void k_turbo_prep(Src src, uint32_t K, uint32_
             for (int k = 0; k < 16; k++) mx = fmaxf(mx, fabsf(v[s][x][k]));
     }
     mx = block_max_f(mx, red_f);
+    const bool use_qtab = Src::kIntegerValued && mx < (float)QTAB_N; // uniform over the workgroup
+    if (use_qtab) {
+        for (uint32_t a = threadIdx.x; a <= (uint32_t)mx; a += blockDim.x) qtab[a] = (int8_t)(int)((float)a * 127.0f / mx);
+        __syncthreads();
+    }
 
     // quantise stream by stream and keep only the packed bytes (4 VGPRs per stream) across the barriers
     const uint32_t u  = threadIdx.x;
@@ -324,8 +364,17 @@ __global__ __launch_bounds__(384) void k_turbo_prep(Src src, uint32_t K, uint32_
 #pragma unroll
     for (int x = 0; x < 3; x++) {
         int q[16];
+        if (use_qtab) {
 #pragma unroll
-        for (int k = 0; k < 16; k++) q[k] = (k < nv) ? (int)(v[0][x][k] * 127.0f / mx) : 0;
+            for (int k = 0; k < 16; k++) {
+                const float f = v[0][x][k];
+                const int   t = qtab[(int)fabsf(f)]; // (int)(-a*127/mx) == -(int)(a*127/mx): IEEE division and truncation are odd
+                q[k]          = (k < nv) ? (f < 0.0f ? -t : t) : 0;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) q[k] = (k < nv) ? (int)(v[0][x][k] * 127.0f / mx) : 0;
+        }
         Q[x] = pack16(q);
         if (nv >= 0) *reinterpret_cast<uint4 *>(out.arr[x] + unit_off(tile_off, lane, u)) = Q[x];
     }
@@ -358,17 +407,23 @@ __global__ __launch_bounds__(384) void k_turbo_prep(Src src, uint32_t K, uint32_
     w1max = block_max_i(w1max, red_i);
     w2max = block_max_i(w2max, red_i);
     const float W1 = (float)w1max, W2 = (float)w2max;
+    for (uint32_t t = threadIdx.x; t < MTAB_N; t += blockDim.x) { // w <= 254 always; entries past W are never read
+        const float w = (float)t;
+        mtab1[t] = (int8_t)(int)(127.0f * (w / W1));
+        mtab2[t] = (int8_t)(int)(127.0f * (w / W2));
+    }
+    __syncthreads();
     if (nv >= 0) {
         int m[16], a[16], b[16];
         unpack16(Q[1], a);
         unpack16(Q[0], b);
 #pragma unroll
-        for (int k = 0; k < 16; k++) m[k] = (k < nv) ? (int)(127.0f * ((float)(abs(a[k]) + abs(b[k])) / W1)) : 0;
+        for (int k = 0; k < 16; k++) m[k] = (k < nv) ? (int)mtab1[abs(a[k]) + abs(b[k])] : 0;
         *reinterpret_cast<uint4 *>(out.arr[4] + unit_off(tile_off, lane, u)) = pack16(m);
         unpack16(Q[2], a);
         unpack16(I0, b);
 #pragma unroll
-        for (int k = 0; k < 16; k++) m[k] = (k < nv) ? (int)(127.0f * ((float)(abs(a[k]) + abs(b[k])) / W2)) : 0;
+        for (int k = 0; k < 16; k++) m[k] = (k < nv) ? (int)mtab2[abs(a[k]) + abs(b[k])] : 0;
         *reinterpret_cast<uint4 *>(out.arr[5] + unit_off(tile_off, lane, u)) = pack16(m);
     }
 }
@@ -553,11 +608,13 @@ __device__ __forceinline__ void load_unit_halo(const uint8_t *arr, size_t tile_o
 struct PermArgs { const uint8_t *A1; const uint8_t *X2; uint8_t *out[2]; /* I1, M3 */ };
 
 template <int NSLOT>
-__global__ __launch_bounds__(384) void k_turbo_perm(PermArgs a, uint32_t K, const uint16_t *__restrict__ pi)
+__global__ __launch_bounds__(384) void k_turbo_perm(PermArgs a, uint32_t K, uint32_t n_cb, const uint16_t *__restrict__ pi)
 {
     extern __shared__ __attribute__((aligned(16))) int8_t sm[]; // C1[Kp]
-    __shared__ int red_i[8];
-    const uint32_t cb = blockIdx.x, tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4;
+    __shared__ int    red_i[8];
+    __shared__ int8_t mtab[MTAB_N];
+    const uint32_t cb = xcd_cb(blockIdx.x, n_cb), tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4;
+    if (cb >= n_cb) return;
     const size_t   tile_off = (size_t)tile * Kp * 64;
     int nval[NSLOT], x2[NSLOT][16];
 #pragma unroll
@@ -593,13 +650,15 @@ __global__ __launch_bounds__(384) void k_turbo_perm(PermArgs a, uint32_t K, cons
     }
     wmax          = block_max_i(wmax, red_i);
     const float W = (float)wmax;
+    for (uint32_t t = threadIdx.x; t < MTAB_N; t += blockDim.x) mtab[t] = (int8_t)(int)(127.0f * ((float)t / W)); // one division per distinct w
+    __syncthreads();
 #pragma unroll
     for (int s = 0; s < NSLOT; s++) {
         const uint32_t u = threadIdx.x + s * blockDim.x;
         if (nval[s] < 0) continue;
         int m3[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) m3[k] = (k < nval[s]) ? (int)(127.0f * ((float)(abs(x2[s][k]) + abs(i1[s][k])) / W)) : 0;
+        for (int k = 0; k < 16; k++) m3[k] = (k < nval[s]) ? (int)mtab[abs(x2[s][k]) + abs(i1[s][k])] : 0;
         *reinterpret_cast<uint4 *>(a.out[1] + unit_off(tile_off, lane, u)) = pack16(m3);
     }
 }
@@ -613,12 +672,13 @@ struct VoteArgs { const uint8_t *X0, *A1, *B1, *B2; };
 //                (liblte_phy_code_block_desegmentation, :9948-9986), check CRC24A (calc_crc :9713-9743)
 //                and report LIBLTE_SUCCESS / LIBLTE_ERROR_DECODE_FAIL like liblte_phy_pdsch_channel_decode.
 template <bool GROUP, int NSLOT>
-__global__ __launch_bounds__(384) void k_turbo_vote(VoteArgs a, uint32_t K, const uint16_t *__restrict__ inv,
+__global__ __launch_bounds__(384) void k_turbo_vote(VoteArgs a, uint32_t K, uint32_t n_cb, const uint16_t *__restrict__ inv,
                                                     uint8_t *__restrict__ c_bits, GroupDesc g)
 {
     extern __shared__ __attribute__((aligned(16))) int8_t sm[]; // D1[Kp] | D2[Kp] | (GROUP) bits[Kp]
     __shared__ uint32_t red_u[8];
-    const uint32_t cb = blockIdx.x, tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4;
+    const uint32_t cb = xcd_cb(blockIdx.x, n_cb), tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4;
+    if (cb >= n_cb) return;
     const size_t   tile_off = (size_t)tile * Kp * 64;
     int8_t *d1 = sm, *d2 = sm + Kp, *bits = sm + 2 * Kp;
     int nval[NSLOT], s0[NSLOT][16]; // s0 = q(d0) + C1, the part of the vote that is not de-interleaved
@@ -651,7 +711,7 @@ __global__ __launch_bounds__(384) void k_turbo_vote(VoteArgs a, uint32_t K, cons
         *reinterpret_cast<uint4 *>(d2 + 16 * u) = pack16(v2);
     }
     __syncthreads();
-    uint32_t alloc = 0, tbs = 0, F = 0, crc = 0, par = 0;
+    uint32_t alloc = 0, tbs = 0, F = 0, crc = 0;
     if (GROUP) {
         alloc = g.cb_alloc[cb];
         tbs   = g.allocs[alloc].tbs;
@@ -671,15 +731,19 @@ __global__ __launch_bounds__(384) void k_turbo_vote(VoteArgs a, uint32_t K, cons
                 const uint32_t i = idx[k]; // Steps 12/13: de-interleave; a hole contributes 0
                 const int c2 = (i != 0xFFFFu) ? (int)d1[i] : 0, c3 = (i != 0xFFFFu) ? (int)d2[i] : 0;
                 b[k] = (s0[s][k] + c2 + c3 >= 0) ? 0 : 1; // Step 14
-                if (GROUP) {
-                    const uint32_t j = 16 * u + k;
-                    if (j >= F) {
-                        const uint32_t m = j - F; // index into b = a (tbs bits) | p (24 bits)
-                        if (m < tbs) { if (b[k]) crc ^= g.crc_tab[tbs - 1 - m]; } // CRC is linear over GF(2)
-                        else par |= (uint32_t)b[k] << (23 - (m - tbs));
-                    }
-                }
             }
+        }
+        if (GROUP) {
+            // CRC24A over the block without its F filler bits: bit j of the block weighs x^(K-1-j) mod g (the
+            // 24 parity bits weigh themselves), so the check "calc_crc(a) == p" is "XOR of the weights == 0".
+            // Weights of this unit = 16 (8) consecutive table entries, descending in j.
+            const int      nv = nval[s];
+            const uint4   *tp = reinterpret_cast<const uint4 *>(g.crc_tab + (K - 16 * u - nv)); // 32-byte aligned (K % 8 == 0)
+            const uint4    t0 = tp[0], t1 = tp[1], t2 = (nv > 8) ? tp[2] : t0, t3 = (nv > 8) ? tp[3] : t0;
+            const uint32_t tw[16] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w, t3.x, t3.y, t3.z, t3.w};
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (k < nv) crc ^= (b[k] && 16 * u + k >= F) ? tw[nv - 1 - k] : 0u;
         }
         const uint4 pk = pack16(b);
         if (GROUP) *reinterpret_cast<uint4 *>(bits + 16 * u) = pk;
@@ -690,20 +754,22 @@ __global__ __launch_bounds__(384) void k_turbo_vote(VoteArgs a, uint32_t K, cons
         }
     }
     if (GROUP) {
-        for (int sft = 32; sft > 0; sft >>= 1) { crc ^= __shfl_xor(crc, sft); par |= __shfl_xor(par, sft); }
+        for (int sft = 32; sft > 0; sft >>= 1) crc ^= __shfl_xor(crc, sft);
         __syncthreads();
         if ((threadIdx.x & 63) == 0) red_u[threadIdx.x >> 6] = crc;
         __syncthreads();
         crc = 0;
         for (uint32_t w = 0; w < (blockDim.x >> 6); w++) crc ^= red_u[w];
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) red_u[threadIdx.x >> 6] = par;
-        __syncthreads();
-        par = 0;
-        for (uint32_t w = 0; w < (blockDim.x >> 6); w++) par |= red_u[w];
-        if (threadIdx.x == 0) g.status[alloc] = (crc == par) ? 0 /* LIBLTE_SUCCESS */ : 3 /* LIBLTE_ERROR_DECODE_FAIL */;
+        if (threadIdx.x == 0) g.status[alloc] = (crc == 0) ? 0 /* LIBLTE_SUCCESS */ : 3 /* LIBLTE_ERROR_DECODE_FAIL */;
+        // transport block = bits F .. F+tbs-1 of the code block, one bit per byte, 16 bytes per store where aligned
         uint8_t *o = g.out_bits + (size_t)alloc * g.out_stride;
-        for (uint32_t m = threadIdx.x; m < tbs; m += blockDim.x) o[m] = (uint8_t)bits[m + F];
+        if ((F & 3u) == 0) {
+            const uint32_t nq = tbs >> 2;
+            const uint32_t *bw = reinterpret_cast<const uint32_t *>(bits + F);
+            for (uint32_t m = threadIdx.x; m < nq; m += blockDim.x) reinterpret_cast<uint32_t *>(o)[m] = bw[m];
+            for (uint32_t m = 4 * nq + threadIdx.x; m < tbs; m += blockDim.x) o[m] = (uint8_t)bits[m + F];
+        } else
+            for (uint32_t m = threadIdx.x; m < tbs; m += blockDim.x) o[m] = (uint8_t)bits[m + F];
     }
 }
 
@@ -795,7 +861,7 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
     po.arr[0] = arr[AX0]; po.arr[1] = arr[AX1]; po.arr[2] = arr[AX2];
     po.arr[3] = arr[AI0]; po.arr[4] = arr[AM1]; po.arr[5] = arr[AM2];
     const uint32_t cb_threads = (uint32_t)(((Kp >> 4) + 63) & ~(size_t)63); // one thread per 16-step unit: 64..384
-    MI_LAUNCH(ctx, "k_turbo_prep", (k_turbo_prep<Src, 1>), dim3(n_cb), dim3(cb_threads), Kp + e_cap, src, K, n_cb, tb.d_pi, po);
+    MI_LAUNCH(ctx, "k_turbo_prep", (k_turbo_prep<Src, 1>), dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), PREP_TAB_BYTES + Kp + e_cap, src, K, n_cb, tb.d_pi, po);
 
     SisoArgs s1;
     s1.p[0] = {arr[AX1], arr[AX0], arr[AM1], arr[AA1], dec[0]};
@@ -804,7 +870,7 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
 
     PermArgs pa;
     pa.A1 = arr[AA1]; pa.X2 = arr[AX2]; pa.out[0] = arr[AI1]; pa.out[1] = arr[AM3];
-    MI_LAUNCH(ctx, "k_turbo_perm", k_turbo_perm<1>, dim3(n_cb), dim3(cb_threads), Kp, pa, K, tb.d_pi);
+    MI_LAUNCH(ctx, "k_turbo_perm", k_turbo_perm<1>, dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), Kp, pa, K, n_cb, tb.d_pi);
 
     SisoArgs s23;
     s23.p[0] = {arr[AX2], arr[AI0], arr[AM2], arr[AB1], dec[1]};
@@ -812,7 +878,7 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
     MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso, dim3(n_tiles, 2), dim3(64), 0, s23, K, 1u);
 
     VoteArgs va = {arr[AX0], arr[AA1], arr[AB1], arr[AB2]};
-    MI_LAUNCH(ctx, "k_turbo_vote", (k_turbo_vote<GROUP, 1>), dim3(n_cb), dim3(cb_threads), 3 * Kp, va, K, tb.d_inv, d_c_bits, gd);
+    MI_LAUNCH(ctx, "k_turbo_vote", (k_turbo_vote<GROUP, 1>), dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), 3 * Kp, va, K, n_cb, tb.d_inv, d_c_bits, gd);
     MI_HIP_CHECK(ctx, hipGetLastError());
     ctx->last_kernels = "k_turbo_prep:1,k_turbo_siso:2,k_turbo_perm:1,k_turbo_vote:1";
     return MI_LTE_OK;
@@ -852,7 +918,7 @@ int mi_turbo_ref_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_
     src.nnn  = it->second.d_nnn;
     // stage e in LDS when the largest allocation of the group fits next to the block's own arrays
     const uint32_t cap = (e_max_bytes + 63u) & ~63u;
-    src.e_cap          = (kpad64(K) + cap <= 48 * 1024) ? cap : 0;
+    src.e_cap          = (PREP_TAB_BYTES + kpad64(K) + cap <= 48 * 1024) ? cap : 0;
     return turbo_ref_run<SrcRateUnmatch, true>(ctx, src, K, n_cb, nullptr, gd, src.e_cap);
 }
 

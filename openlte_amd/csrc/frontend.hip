@@ -256,14 +256,76 @@ __global__ __launch_bounds__(256) void k_dl_ce(const uint32_t *__restrict__ subf
         ang[i * N_sc + k] = atan2f(t_im, t_re);
     }
     __syncthreads();
-    // sequential unwrap along frequency, one lane per CRS symbol (liblte_phy.cc:6033-6035)
-    if (threadIdx.x < N_sym) {
-        const uint32_t i = threadIdx.x, off = (voff_of(i) + v_shift) % 6;
-        float prev = ang[i * N_sc + off];
-        for (uint32_t j = 1; j < n_pil; j++) {
-            const uint32_t k = 6 * j + off;
-            prev = wrap_phase(ang[i * N_sc + k], prev);
-            ang[i * N_sc + k] = prev;
+    // unwrap along frequency (liblte_phy.cc:6033-6035): u_0 = r_0, u_j = wrap_phase(r_j, u_{j-1}).  The chain is
+    // serial in the reference; here one wave per CRS symbol guesses the wrap count c_j of every pilot from
+    // the RAW neighbours (delta_j = steps wrap_phase(r_j, r_{j-1}) takes, c_j = prefix sum), applies the c_j
+    // rounded +-2*pi steps to r_j, and then VERIFIES every link with the reference's own test
+    // (wrap_phase(r_j, u_{j-1}) == u_j bit for bit).  If every link verifies, u is exactly the serial result
+    // (induction over j); otherwise (a phase step within rounding of +-pi) lane 0 redoes the symbol serially.
+    {
+        const uint32_t wave = threadIdx.x >> 6, ln = threadIdx.x & 63, n_wave = blockDim.x >> 6;
+        const uint32_t C = (n_pil + 63) / 64; // pilots per lane (<= 4 for 100 RB)
+        for (uint32_t i = wave; i < N_sym; i += n_wave) {
+            const uint32_t off = (voff_of(i) + v_shift) % 6;
+            float *a = ang + i * N_sc + off;
+            float  r[4], uu[4];
+            int    c[4], run = 0;
+            float  rprev = (ln > 0 && (ln * C - 1) < n_pil) ? a[6 * (ln * C - 1)] : 0.0f;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t j = ln * C + k;
+                r[k] = (k < C && j < n_pil) ? a[6 * j] : 0.0f;
+                int d = 0;
+                if (k < C && j < n_pil && j > 0) {
+                    float p1 = r[k];
+                    while ((double)(p1 - rprev) >= M_PI) { p1 = (float)((double)p1 - 2 * M_PI); d--; }
+                    while ((double)(p1 - rprev) <= -M_PI) { p1 = (float)((double)p1 + 2 * M_PI); d++; }
+                }
+                run += d;
+                c[k]  = run; // inclusive within the lane
+                rprev = r[k];
+            }
+            int incl = run; // wave-inclusive scan of the per-lane totals
+            for (int o = 1; o < 64; o <<= 1) {
+                const int n = __shfl_up(incl, o);
+                if ((int)ln >= o) incl += n;
+            }
+            const int base = incl - run;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                int   cc = c[k] + base;
+                float p1 = r[k];
+                for (; cc < 0; cc++) p1 = (float)((double)p1 - 2 * M_PI);
+                for (; cc > 0; cc--) p1 = (float)((double)p1 + 2 * M_PI);
+                uu[k] = p1;
+            }
+            // verify every link against the reference's own rule
+            const uint32_t last_k = C - 1;
+            float uprev = __shfl_up(last_k == 0 ? uu[0] : last_k == 1 ? uu[1] : last_k == 2 ? uu[2] : uu[3], 1);
+            bool  bad = false;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t j = ln * C + k;
+                if (k < C && j < n_pil) {
+                    if (j > 0) bad |= (__float_as_uint(wrap_phase(r[k], uprev)) != __float_as_uint(uu[k]));
+                    uprev = uu[k];
+                }
+            }
+            if (__any(bad)) {
+                if (ln == 0) {
+                    float prev = a[0];
+                    for (uint32_t j = 1; j < n_pil; j++) {
+                        prev     = wrap_phase(a[6 * j], prev);
+                        a[6 * j] = prev;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t j = ln * C + k;
+                    if (k < C && j < n_pil) a[6 * j] = uu[k];
+                }
+            }
         }
     }
     __syncthreads();
@@ -294,7 +356,7 @@ __global__ __launch_bounds__(256) void k_dl_ce(const uint32_t *__restrict__ subf
 #pragma unroll
         for (int i = 0; i < 5; i++) { M[i] = mag[i * N_sc + j]; A[i] = ang[i * N_sc + j]; }
         float fm, fa, cm, ca;
-#define EMIT(z, m, a) do { ce_re[(z) * N_SC_MAX + j] = (m) * cosf(a); ce_im[(z) * N_SC_MAX + j] = (m) * sinf(a); } while (0)
+#define EMIT(z, m, a) do { float sn_, cs_; sincosf((a), &sn_, &cs_); ce_re[(z) * N_SC_MAX + j] = (m) * cs_; ce_im[(z) * N_SC_MAX + j] = (m) * sn_; } while (0)
 #define SLOPE(hi, lo, dv) do { fm = (M[hi] - M[lo]) / (dv); A[hi] = wrap_phase(A[hi], A[lo]); fa = A[hi] - A[lo]; \
                                fa = wrap_phase(fa, 0.0f); fa /= (dv); } while (0)
         if (N_sym == 3) {

@@ -72,3 +72,23 @@ def test_frontend_float_planar_input(ctx, port):
     cfg2 = m.DlCfg(2048, 100, 1, 1)
     b = ctx.dl_frontend(cfg2, (iq[0, :, 0].astype(np.float32), iq[0, :, 1].astype(np.float32)), [0], [2], [9])
     assert (a == b).all()
+
+
+def test_frontend_many_phase_wraps(ctx, port):
+    """Large timing offsets -> steep phase ramps over frequency (dozens of 2*pi wraps across the band): exercises
+    the wave-parallel unwrap of k_dl_ce (wrap counts from a prefix sum, verified link by link against the
+    reference's own wrap_phase rule) far from the near-flat channels of the other cases."""
+    import openlte_amd as m
+    from openlte_amd import synth
+    cfg = m.DlCfg(2048, 100, 1, 0)
+    sfs, cells = [2, 4, 8, 9, 1, 3], [5, 100, 250, 333, 444, 501]
+    allocs = []
+    for u in range(6):
+        allocs += td.small_allocs(u, 100, 3, 2024, 8)
+    iq, _ = synth.dl_units(cfg, sfs, cells, allocs, 1, snr_db=30, max_delay=90, seed=99)
+    ul = iq.shape[1]
+    got = ctx.dl_frontend(cfg, iq.reshape(-1, 2), np.arange(6) * ul, sfs, cells)
+    for u in range(6):
+        _, s = td.oracle_frontend(port, 2048, 100, 1, iq[u], sfs[u], cells[u])
+        assert rel_l2(got[u, 2, :14, :1200], s.arr("rx_ce_re")[0, :14, :1200]) < TOL_CE, u
+        assert rel_l2(got[u, 3, :14, :1200], s.arr("rx_ce_im")[0, :14, :1200]) < TOL_CE, u

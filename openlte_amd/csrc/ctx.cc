@@ -1,4 +1,6 @@
 // Context, memory and timing entry points of libmi_lte.so (see include/mi_lte.h).
+#include <cmath>
+
 #include "ctx.hpp"
 
 #include <cstring>
@@ -268,6 +270,24 @@ int mi_ctx_gold_tables(mi_lte_ctx *ctx)
     MI_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_gold_x2b, x2w.data(), sizeof(uint32_t) * 31 * W, hipMemcpyHostToDevice, ctx->stream));
     MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->gold_words = W;
+    return MI_LTE_OK;
+}
+
+// Forward-DFT twiddles exp(-2*pi*i*k/2048), evaluated in double and rounded once; every smaller FFT
+// size and every Stockham pass reads this table with a stride.
+int mi_ctx_fft_twiddles(mi_lte_ctx *ctx)
+{
+    if (ctx->d_fft_tw) return MI_LTE_OK;
+    const uint32_t N = 2048;
+    std::vector<float2> tw(N);
+    for (uint32_t k = 0; k < N; k++) {
+        const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)N;
+        tw[k] = make_float2((float)cos(a), (float)sin(a));
+    }
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_fft_tw, sizeof(float2) * N));
+    ctx->owned.push_back(ctx->d_fft_tw);
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_fft_tw, tw.data(), sizeof(float2) * N, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return MI_LTE_OK;
 }
 

@@ -25,7 +25,12 @@ struct DlGeom {
     uint32_t sf_stride; // floats per device subframe
 };
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// The FFT has no bit-exact reference (FFTW's operation order is unspecified; parity is to tolerance), so its
+// complex multiplies may use fused multiply-adds; the rest of the library is built with -ffp-contract=off.
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+}
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); } // a * (-i)
@@ -56,13 +61,26 @@ template <int R> __device__ __forceinline__ void dftR(float2 *v)
     else dft2(v[0], v[1]);
 }
 
+// Twiddles w^1 .. w^(R-1) of one butterfly, w = exp(-2*pi*i*k/(Ns*R)), from the 2048-entry table:
+// w, w^2, w^4 are looked up (all below half a turn, so no index wrap), the rest are products.
+template <int R> __device__ __forceinline__ void twiddles(const float2 *__restrict__ tw, uint32_t k, uint32_t Ns, float2 (&w)[8])
+{
+    const uint32_t i1 = k * (2048u / (Ns * R));
+    w[1] = tw[i1];
+    if (R >= 4) { w[2] = tw[2 * i1]; w[3] = cmul(w[1], w[2]); }
+    if (R == 8) {
+        w[4] = tw[4 * i1];
+        w[5] = cmul(w[4], w[1]); w[6] = cmul(w[4], w[2]); w[7] = cmul(w[4], w[3]);
+    }
+}
+
 // LDS index padding: one extra float2 slot every 32 breaks the power-of-two strides of the passes
 __device__ __forceinline__ uint32_t pad(uint32_t i) { return i + (i >> 5); }
 
 // One Stockham pass of radix R over buf (N points, sub-transform length Ns so far).
 // SRC: 0 = LDS, 1 = gather from global int8/float samples.  DST: 0 = LDS, 1 = scatter to the symbol row.
 template <int R, typename LoadF, typename StoreF>
-__device__ __forceinline__ void fft_pass(uint32_t N, uint32_t Ns, LoadF load, StoreF store)
+__device__ __forceinline__ void fft_pass(const float2 *__restrict__ tw, uint32_t N, uint32_t Ns, LoadF load, StoreF store)
 {
     const uint32_t nb = N / R;
     for (uint32_t j = threadIdx.x; j < nb; j += blockDim.x) {
@@ -71,15 +89,10 @@ __device__ __forceinline__ void fft_pass(uint32_t N, uint32_t Ns, LoadF load, St
         for (int r = 0; r < R; r++) v[r] = load(j + r * nb);
         const uint32_t k = j & (Ns - 1);
         if (Ns > 1) {
-            float s, c;
-            sincospif(-2.0f * (float)k / (float)(Ns * R), &s, &c); // exp(-2*pi*i*k/(Ns*R))
-            const float2 w1 = make_float2(c, s);
-            float2       w  = w1;
+            float2 w[8];
+            twiddles<R>(tw, k, Ns, w);
 #pragma unroll
-            for (int r = 1; r < R; r++) {
-                v[r] = cmul(v[r], w);
-                w    = cmul(w, w1);
-            }
+            for (int r = 1; r < R; r++) v[r] = cmul(v[r], w[r]);
         }
         dftR<R>(v);
         const uint32_t j0 = (j - k) * R + k;
@@ -104,7 +117,7 @@ template <> struct SampleSrc<float> { // planar i_samps / q_samps as the referen
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t *__restrict__ unit_start, DlGeom g,
-                                                float *__restrict__ subframes)
+                                                const float2 *__restrict__ tw, float *__restrict__ subframes)
 {
     extern __shared__ __attribute__((aligned(16))) float2 buf[]; // pad(N) entries
     const uint32_t sym = blockIdx.x, unit = blockIdx.y, N = g.N;
@@ -126,7 +139,7 @@ __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t
 
     // radix plan: 8,8,8,4 (2048) | 8,8,8,2 (1024) | 8,8,8 (512) | 8,8,4 (256) | 8,8,2 (128)
     uint32_t Ns = 1;
-    fft_pass<8>(N, Ns, ld_g, st_s); Ns *= 8;
+    fft_pass<8>(tw, N, Ns, ld_g, st_s); Ns *= 8;
     __syncthreads();
     {   // second radix-8 pass: read all, then write (in place)
         const uint32_t nb = N / 8;
@@ -140,12 +153,10 @@ __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t
         __syncthreads();
         if (act) {
             const uint32_t k = j & (Ns - 1);
-            float s, c;
-            sincospif(-2.0f * (float)k / (float)(Ns * 8), &s, &c);
-            const float2 w1 = make_float2(c, s);
-            float2 w = w1;
+            float2 w[8];
+            twiddles<8>(tw, k, Ns, w);
 #pragma unroll
-            for (int r = 1; r < 8; r++) { v[r] = cmul(v[r], w); w = cmul(w, w1); }
+            for (int r = 1; r < 8; r++) v[r] = cmul(v[r], w[r]);
             dft8(v);
             const uint32_t j0 = (j - k) * 8 + k;
 #pragma unroll
@@ -154,9 +165,9 @@ __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t
         Ns *= 8;
     }
     __syncthreads();
-    if (N == 128) { fft_pass<2>(N, Ns, ld_s, st_g); return; }
-    if (N == 256) { fft_pass<4>(N, Ns, ld_s, st_g); return; }
-    if (N == 512) { fft_pass<8>(N, Ns, ld_s, st_g); return; }
+    if (N == 128) { fft_pass<2>(tw, N, Ns, ld_s, st_g); return; }
+    if (N == 256) { fft_pass<4>(tw, N, Ns, ld_s, st_g); return; }
+    if (N == 512) { fft_pass<8>(tw, N, Ns, ld_s, st_g); return; }
     {   // third radix-8 pass in place
         const uint32_t nb = N / 8;
         float2 v[8];
@@ -169,12 +180,10 @@ __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t
         __syncthreads();
         if (act) {
             const uint32_t k = j & (Ns - 1);
-            float s, c;
-            sincospif(-2.0f * (float)k / (float)(Ns * 8), &s, &c);
-            const float2 w1 = make_float2(c, s);
-            float2 w = w1;
+            float2 w[8];
+            twiddles<8>(tw, k, Ns, w);
 #pragma unroll
-            for (int r = 1; r < 8; r++) { v[r] = cmul(v[r], w); w = cmul(w, w1); }
+            for (int r = 1; r < 8; r++) v[r] = cmul(v[r], w[r]);
             dft8(v);
             const uint32_t j0 = (j - k) * 8 + k;
 #pragma unroll
@@ -183,8 +192,8 @@ __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t
         Ns *= 8;
     }
     __syncthreads();
-    if (N == 1024) fft_pass<2>(N, Ns, ld_s, st_g);
-    else           fft_pass<4>(N, Ns, ld_s, st_g);
+    if (N == 1024) fft_pass<2>(tw, N, Ns, ld_s, st_g);
+    else           fft_pass<4>(tw, N, Ns, ld_s, st_g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -423,14 +432,16 @@ extern "C" int mi_lte_dl_frontend_batch(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cf
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     rc = mi_ctx_gold_tables(ctx);
     if (rc != MI_LTE_OK) return rc;
+    rc = mi_ctx_fft_twiddles(ctx);
+    if (rc != MI_LTE_OK) return rc;
     const size_t lds_fft = sizeof(float2) * (g.N + g.N / 32 + 1);
     if (cfg->sample_format == MI_LTE_IQ_I8) {
         SampleSrc<int8_t> s{(const int8_t *)d_samples_a};
-        MI_LAUNCH(ctx, "k_dl_fft", (k_dl_fft<int8_t>), dim3(16, n_units), dim3(256), lds_fft, s, d_unit_start, g, d_subframes);
+        MI_LAUNCH(ctx, "k_dl_fft", (k_dl_fft<int8_t>), dim3(16, n_units), dim3(256), lds_fft, s, d_unit_start, g, ctx->d_fft_tw, d_subframes);
     } else if (cfg->sample_format == MI_LTE_IQ_F32_PLANAR) {
         if (!d_samples_b) return MI_LTE_ERR_INVALID_ARG;
         SampleSrc<float> s{(const float *)d_samples_a, (const float *)d_samples_b};
-        MI_LAUNCH(ctx, "k_dl_fft", (k_dl_fft<float>), dim3(16, n_units), dim3(256), lds_fft, s, d_unit_start, g, d_subframes);
+        MI_LAUNCH(ctx, "k_dl_fft", (k_dl_fft<float>), dim3(16, n_units), dim3(256), lds_fft, s, d_unit_start, g, ctx->d_fft_tw, d_subframes);
     } else
         return MI_LTE_ERR_INVALID_ARG;
     GoldTables gt{ctx->d_gold_x1, ctx->d_gold_x2b, ctx->gold_words};

@@ -101,11 +101,14 @@ __device__ __forceinline__ size_t unit_off(size_t tile_off, uint32_t lane, uint3
 {
     return tile_off + (size_t)(u >> 2) * 4096 + lane * 64 + (u & 3) * 16;
 }
-// 16 uint16 table entries starting at index 16u (nvalid = 16 or 8)
-__device__ __forceinline__ void load_idx16(const uint16_t *tab, uint32_t u, int nvalid, uint32_t (&idx)[16])
+// 16 uint16 table entries starting at index 16u (nvalid = 16 or 8); the entries past nvalid read `pad`
+// (callers pass the index of a slot that holds 0, so that nothing downstream needs a per-element predicate
+// -- predicated LDS reads compile to one branch + one waitcnt each)
+__device__ __forceinline__ void load_idx16(const uint16_t *tab, uint32_t u, int nvalid, uint32_t (&idx)[16], uint32_t pad = 0)
 {
     const uint4 *p = reinterpret_cast<const uint4 *>(tab + 16 * (size_t)u);
-    const uint4  lo = p[0], hi = (nvalid > 8) ? p[1] : make_uint4(0, 0, 0, 0);
+    const uint32_t pp = pad | (pad << 16);
+    const uint4  lo = p[0], hi = (nvalid > 8) ? p[1] : make_uint4(pp, pp, pp, pp);
     const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
     for (int k = 0; k < 16; k++) idx[k] = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
@@ -367,13 +370,13 @@ __global__ __launch_bounds__(384) void k_turbo_prep(Src src, uint32_t K, uint32_
         if (use_qtab) {
 #pragma unroll
             for (int k = 0; k < 16; k++) {
-                const float f = v[0][x][k];
+                const float f = v[0][x][k]; // 0 past the block end -> q = 0; the lookup is unconditional (no per-element branch)
                 const int   t = qtab[(int)fabsf(f)]; // (int)(-a*127/mx) == -(int)(a*127/mx): IEEE division and truncation are odd
-                q[k]          = (k < nv) ? (f < 0.0f ? -t : t) : 0;
+                q[k]          = f < 0.0f ? -t : t;
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 16; k++) q[k] = (k < nv) ? (int)(v[0][x][k] * 127.0f / mx) : 0;
+            for (int k = 0; k < 16; k++) q[k] = (int)(v[0][x][k] * 127.0f / mx); // v = 0 past the block end
         }
         Q[x] = pack16(q);
         if (nv >= 0) *reinterpret_cast<uint4 *>(out.arr[x] + unit_off(tile_off, lane, u)) = Q[x];
@@ -392,14 +395,13 @@ __global__ __launch_bounds__(384) void k_turbo_prep(Src src, uint32_t K, uint32_
         for (int k = 0; k < 16; k++) i0[k] = 0;
         if (nv > 0) {
             uint32_t idx[16];
-            load_idx16(pi, u, nv, idx);
+            load_idx16(pi, u, nv, idx, K); // past the block end: slot K, which holds q = 0 whenever K % 16 == 8
 #pragma unroll
-            for (int k = 0; k < 16; k++)
-                if (k < nv) {
-                    i0[k] = q0_lds[idx[k]];
-                    w1max = max(w1max, abs(q1[k]) + abs(q0[k]));
-                    w2max = max(w2max, abs(q2[k]) + abs(i0[k]));
-                }
+            for (int k = 0; k < 16; k++) { // unconditional LDS reads
+                i0[k] = q0_lds[idx[k]];
+                w1max = max(w1max, abs(q1[k]) + abs(q0[k]));
+                w2max = max(w2max, abs(q2[k]) + abs(i0[k]));
+            }
         }
         I0 = pack16(i0);
         if (nv >= 0) *reinterpret_cast<uint4 *>(out.arr[3] + unit_off(tile_off, lane, u)) = I0;
@@ -418,12 +420,12 @@ __global__ __launch_bounds__(384) void k_turbo_prep(Src src, uint32_t K, uint32_
         unpack16(Q[1], a);
         unpack16(Q[0], b);
 #pragma unroll
-        for (int k = 0; k < 16; k++) m[k] = (k < nv) ? (int)mtab1[abs(a[k]) + abs(b[k])] : 0;
+        for (int k = 0; k < 16; k++) m[k] = (int)mtab1[abs(a[k]) + abs(b[k])]; // past the end: |0|+|0| -> entry 0 = 0
         *reinterpret_cast<uint4 *>(out.arr[4] + unit_off(tile_off, lane, u)) = pack16(m);
         unpack16(Q[2], a);
         unpack16(I0, b);
 #pragma unroll
-        for (int k = 0; k < 16; k++) m[k] = (k < nv) ? (int)mtab2[abs(a[k]) + abs(b[k])] : 0;
+        for (int k = 0; k < 16; k++) m[k] = (int)mtab2[abs(a[k]) + abs(b[k])];
         *reinterpret_cast<uint4 *>(out.arr[5] + unit_off(tile_off, lane, u)) = pack16(m);
     }
 }
@@ -626,7 +628,7 @@ __global__ __launch_bounds__(384) void k_turbo_perm(PermArgs a, uint32_t K, uint
         load_unit_halo(a.A1, tile_off, lane, u, xa);
         unpack16(*reinterpret_cast<const uint4 *>(a.X2 + unit_off(tile_off, lane, u)), x2[s]);
 #pragma unroll
-        for (int k = 0; k < 16; k++) c1[k] = soft_xor(xa[3 + k], soft_xor(xa[k + 1], xa[k])); // Steps 2-3
+        for (int k = 0; k < 16; k++) c1[k] = soft_xor(xa[3 + k], soft_xor(xa[k + 1], xa[k])) & ((k - nval[s]) >> 31); // Steps 2-3; AND-mask: 0 past the end
         *reinterpret_cast<uint4 *>(sm + 16 * u) = pack16(c1);
     }
     __syncthreads();
@@ -638,13 +640,12 @@ __global__ __launch_bounds__(384) void k_turbo_perm(PermArgs a, uint32_t K, uint
         for (int k = 0; k < 16; k++) i1[s][k] = 0;
         if (nval[s] > 0) {
             uint32_t idx[16];
-            load_idx16(pi, u, nval[s], idx);
+            load_idx16(pi, u, nval[s], idx, K); // past the block end: slot K (C1 = 0 there)
 #pragma unroll
-            for (int k = 0; k < 16; k++)
-                if (k < nval[s]) {
-                    i1[s][k] = sm[idx[k]]; // Step 5
-                    wmax     = max(wmax, abs(x2[s][k]) + abs(i1[s][k]));
-                }
+            for (int k = 0; k < 16; k++) {
+                i1[s][k] = sm[idx[k]]; // Step 5
+                wmax     = max(wmax, abs(x2[s][k]) + abs(i1[s][k]));
+            }
         }
         if (nval[s] >= 0) *reinterpret_cast<uint4 *>(a.out[0] + unit_off(tile_off, lane, u)) = pack16(i1[s]);
     }
@@ -658,7 +659,7 @@ __global__ __launch_bounds__(384) void k_turbo_perm(PermArgs a, uint32_t K, uint
         if (nval[s] < 0) continue;
         int m3[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) m3[k] = (k < nval[s]) ? (int)mtab[abs(x2[s][k]) + abs(i1[s][k])] : 0;
+        for (int k = 0; k < 16; k++) m3[k] = (int)mtab[abs(x2[s][k]) + abs(i1[s][k])]; // x2 = i1 = 0 past the end -> 0
         *reinterpret_cast<uint4 *>(a.out[1] + unit_off(tile_off, lane, u)) = pack16(m3);
     }
 }
@@ -695,16 +696,17 @@ __global__ __launch_bounds__(384) void k_turbo_vote(VoteArgs a, uint32_t K, uint
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const int A = xa[3 + k], B = xb[3 + k], G = soft_xor(xb[k + 1], xb[k]), B_ = xc[3 + k], G_ = soft_xor(xc[k + 1], xc[k]);
-            // Step 10 (liblte_phy.cc:10778-10797); the mixed-sign branches read in_act_1 (A), not int_act_1
-            if (B >= 0 && G >= 0)     v1[k] = (B + G) >> 1;
-            else if (B < 0 && G < 0)  v1[k] = (-B - G) >> 1;
-            else if (B >= 0 && G < 0) v1[k] = -((A - G) >> 1);
-            else                      v1[k] = -((-A + G) >> 1);
-            // Step 11 (liblte_phy.cc:10800-10819); last branch is -((-a - b) >> 1)
-            if (B_ >= 0 && G_ >= 0)     v2[k] = (B_ + G_) >> 1;
-            else if (B_ < 0 && G_ < 0)  v2[k] = (-B_ - G_) >> 1;
-            else if (B_ >= 0 && G_ < 0) v2[k] = -((B_ - G_) >> 1);
-            else                        v2[k] = -((-B_ - G_) >> 1);
+            // Step 10 (liblte_phy.cc:10778-10797), as selects: equal signs -> (|B|+|G|)>>1; B >= 0 > G -> -((A - G) >> 1);
+            // B < 0 <= G -> -((-A + G) >> 1) -- the mixed-sign branches read in_act_1 (A), not int_act_1
+            {
+                const int same = (abs(B) + abs(G)) >> 1, t = (B >= 0) ? (A - G) : (G - A);
+                v1[k] = (((B ^ G) >= 0) ? same : -(t >> 1)) & ((k - nval[s]) >> 31); // AND-mask (0 past the block end), not a branch
+            }
+            // Step 11 (liblte_phy.cc:10800-10819): mixed signs -> -((B - G) >> 1) resp. -((-B - G) >> 1), i.e. -((|B| - G) >> 1)
+            {
+                const int same = (abs(B_) + abs(G_)) >> 1, t = abs(B_) - G_;
+                v2[k] = (((B_ ^ G_) >= 0) ? same : -(t >> 1)) & ((k - nval[s]) >> 31);
+            }
             s0[s][k] = x0[k] + soft_xor(A, soft_xor(xa[k + 1], xa[k])); // q(d0) + C1 (Steps 2-3)
         }
         *reinterpret_cast<uint4 *>(d1 + 16 * u) = pack16(v1);
@@ -723,15 +725,13 @@ __global__ __launch_bounds__(384) void k_turbo_vote(VoteArgs a, uint32_t K, uint
         if (nval[s] <= 0) continue;
         uint32_t idx[16];
         int      b[16];
-        load_idx16(inv, u, nval[s], idx);
+        load_idx16(inv, u, nval[s], idx, K); // past the block end: slot K (D1 = D2 = 0 there; those bits are never used)
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            b[k] = 0;
-            if (k < nval[s]) {
-                const uint32_t i = idx[k]; // Steps 12/13: de-interleave; a hole contributes 0
-                const int c2 = (i != 0xFFFFu) ? (int)d1[i] : 0, c3 = (i != 0xFFFFu) ? (int)d2[i] : 0;
-                b[k] = (s0[s][k] + c2 + c3 >= 0) ? 0 : 1; // Step 14
-            }
+            const uint32_t i = idx[k], ic = (i != 0xFFFFu) ? i : 0u; // Steps 12/13: de-interleave; a hole contributes 0
+            const int t2 = d1[ic], t3 = d2[ic];                        // unconditional reads, masked
+            const int c2 = (i != 0xFFFFu) ? t2 : 0, c3 = (i != 0xFFFFu) ? t3 : 0;
+            b[k] = (s0[s][k] + c2 + c3 < 0) ? 1 : 0; // Step 14
         }
         if (GROUP) {
             // CRC24A over the block without its F filler bits: bit j of the block weighs x^(K-1-j) mod g (the
@@ -742,8 +742,10 @@ __global__ __launch_bounds__(384) void k_turbo_vote(VoteArgs a, uint32_t K, uint
             const uint4    t0 = tp[0], t1 = tp[1], t2 = (nv > 8) ? tp[2] : t0, t3 = (nv > 8) ? tp[3] : t0;
             const uint32_t tw[16] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w, t3.x, t3.y, t3.z, t3.w};
 #pragma unroll
-            for (int k = 0; k < 16; k++)
-                if (k < nv) crc ^= (b[k] && 16 * u + k >= F) ? tw[nv - 1 - k] : 0u;
+            for (int k = 0; k < 16; k++) { // static register indices only: nv is 16, or 8 in the last unit of a K % 16 == 8 block
+                const uint32_t wgt = (nv > 8) ? tw[15 - k] : tw[(7 - k) & 15];
+                crc ^= (b[k] && 16 * u + k >= F && k < nv) ? wgt : 0u;
+            }
         }
         const uint4 pk = pack16(b);
         if (GROUP) *reinterpret_cast<uint4 *>(bits + 16 * u) = pk;

@@ -133,7 +133,7 @@ class ChainWorkload:
         from openlte_amd import synth
         import lte_testdata as td
         self.ctx, self.m, self.np = ctx, m, np
-        self.n = n_units or 8192
+        self.n = n_units or 32768
         self.cfg = m.DlCfg(2048, 100, 1, 0)
         U = min(96, self.n)
         sfs = np.array([[1, 2, 3, 4, 6, 7, 8, 9][i % 8] for i in range(U)], np.uint32)  # subframes 0/5 carry sync signals
@@ -302,11 +302,11 @@ class FrontendWorkload:
 class MultiStream:
     """Run S independent shards of a workload on S contexts (= S HIP streams) of the same GPU, launched
     back to back and synchronised together.  Units are independent, so this is the same "shard by
-    unit, no exchange" split that is used across GPUs; on one GPU it lets the few-wave trellis kernels
-    of one shard overlap with the wide, LDS-bound kernels of another."""
+    unit, no exchange" split that is used across GPUs.  Default S = 1: with a batch large enough to give
+    the lock-step trellis kernel 4+ waves per SIMD (32k subframes), one stream is the fastest."""
 
     def __init__(self, cls, ctxs, n_units, rank):
-        n_units = n_units or {"chain": 8192, "frontend": 10000, "turbo": 65536}[cls.name]
+        n_units = n_units or {"chain": 32768, "frontend": 10000, "turbo": 65536}[cls.name]
         per = max(64, (n_units // len(ctxs) + 63) // 64 * 64)
         self.parts = [cls(c, per, rank * 16 + k) for k, c in enumerate(ctxs)]
         self.ctxs = ctxs
@@ -382,7 +382,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="auto")
     ap.add_argument("--units", type=int, default=0, help="units (subframes / code blocks) per GPU per step")
-    ap.add_argument("--streams", type=int, default=2, help="independent shards (contexts/streams) per GPU")
+    ap.add_argument("--streams", type=int, default=1, help="independent shards (contexts/streams) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -320,7 +320,7 @@ constexpr uint32_t MTAB_N = 256;  // w = |a|+|b| <= 254
 constexpr uint32_t PREP_TAB_BYTES = QTAB_N + 2 * MTAB_N;
 
 template <typename Src, int NSLOT>
-__global__ __launch_bounds__(384) void k_turbo_prep(Src src, uint32_t K, uint32_t n_cb,
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_turbo_prep(Src src, uint32_t K, uint32_t n_cb,
                                                     const uint16_t *__restrict__ pi, PrepOut out)
 {
     extern __shared__ __attribute__((aligned(16))) int8_t sm[]; // qtab | mtab1 | mtab2 | q(d0)[Kp] | staged e
@@ -673,7 +673,7 @@ struct VoteArgs { const uint8_t *X0, *A1, *B1, *B2; };
 //                (liblte_phy_code_block_desegmentation, :9948-9986), check CRC24A (calc_crc :9713-9743)
 //                and report LIBLTE_SUCCESS / LIBLTE_ERROR_DECODE_FAIL like liblte_phy_pdsch_channel_decode.
 template <bool GROUP, int NSLOT>
-__global__ __launch_bounds__(384) void k_turbo_vote(VoteArgs a, uint32_t K, uint32_t n_cb, const uint16_t *__restrict__ inv,
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_turbo_vote(VoteArgs a, uint32_t K, uint32_t n_cb, const uint16_t *__restrict__ inv,
                                                     uint8_t *__restrict__ c_bits, GroupDesc g)
 {
     extern __shared__ __attribute__((aligned(16))) int8_t sm[]; // D1[Kp] | D2[Kp] | (GROUP) bits[Kp]

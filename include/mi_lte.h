@@ -184,6 +184,63 @@ size_t mi_lte_turbo_scratch_bytes(uint32_t K, uint32_t n_cb);
 /* name and launch count of the kernels the last batch call issued (for bench.py / profiles) */
 const char *mi_lte_last_kernels(const mi_lte_ctx *ctx);
 
+/* ---------------------------------------------------------------- uplink (eNodeB receive side)
+ * SURVEY 8f N1 / BASELINE config 5: the PUSCH receive chain of LTE_fdd_enodeb
+ * (LTE_fdd_enodeb/src/LTE_fdd_enb_phy.cc:832-917 calls liblte_phy_get_ul_subframe and
+ * liblte_phy_pusch_channel_decode once per scheduled UE).
+ *
+ * mi_lte_ul_frontend_batch replaces liblte_phy_get_ul_subframe() (liblte/hdr/liblte_phy.h:1190-1193,
+ * implementation liblte/src/liblte_phy.cc:6209-6236 over samples_to_symbols_ul :8654-8692): 14 SC-FDMA
+ * symbols per subframe unit; the reference's 2N-point FFT of the zero-padded N samples, of which it keeps
+ * the odd bins (the half-sub-carrier shift), is computed as an N-point FFT of the samples rotated by
+ * exp(-i*pi*n/N); the window starts one sample early (:8680) like the downlink one.
+ * Output per unit: mi_lte_ul_subframe_floats() floats, rx_symb_re[16][1200] rx_symb_im[16][1200]
+ * (rows 14, 15 unused), the receive half of LIBLTE_PHY_SUBFRAME_STRUCT. */
+size_t mi_lte_ul_subframe_floats(void);
+int    mi_lte_ul_frontend_batch(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg /* N_rb_dl = N_rb_ul, N_ant ignored */,
+                                const void *d_samples_a, const void *d_samples_b, const uint64_t *d_unit_start,
+                                uint32_t n_units, float *d_subframes);
+
+/* Cell-level uplink configuration: the arguments of liblte_phy_ul_init() (liblte_phy.h:613-625) that the
+ * PUSCH demodulation reference signals depend on (generate_dmrs_pusch, liblte_phy.cc:6868-6990); liblte_phy.h:613-625. */
+typedef struct {
+    uint32_t group_assignment_pusch;   /* delta_ss */
+    uint32_t group_hopping_enabled;
+    uint32_t sequence_hopping_enabled;
+    uint32_t cyclic_shift;             /* n1_DMRS index, 0..7 */
+    uint32_t cyclic_shift_dci;         /* n2_DMRS index, 0..7 */
+} mi_lte_ul_cfg;
+
+/* PUSCH demodulation reference signal of one (subframe, N_prb): 4 x 12*N_prb floats
+ * (dmrs_0_re, dmrs_0_im for symbol 3; dmrs_1_re, dmrs_1_im for symbol 10).  Host function; restates
+ * generate_dmrs_pusch / generate_ul_rs (liblte_phy.cc:6745-6990) with the reference's own arithmetic
+ * (double-precision libm calls on float-rounded arguments), layer 0. */
+int mi_lte_ul_dmrs_pusch(const mi_lte_ul_cfg *ul, uint32_t N_id_cell, uint32_t N_subfr, uint32_t N_prb, float *h_dmrs_0_re,
+                         float *h_dmrs_0_im, float *h_dmrs_1_re, float *h_dmrs_1_im);
+
+/* mi_lte_pusch_plan_* / mi_lte_pusch_decode_run replace liblte_phy_pusch_channel_decode()
+ * (liblte_phy.h:722-728, implementation liblte_phy.cc:2801-2935) and ulsch_channel_decode (:12363-12501)
+ * for a batch of allocations (one per scheduled UE) over a batch of uplink device subframes: RE extraction,
+ * DMRS least-squares estimate + magnitude/phase interpolation (get_ulsch_ce :13718-13790), one-tap
+ * equaliser (:6708-6736), transform pre-decoding (12 unnormalised backward DFTs of size 12*N_prb scaled by
+ * sqrt(12*N_prb), :6627-6660 -- the reference's scaling, reproduced), de-mapping, descrambling, channel
+ * de-interleaving (:12108-12225; with no RI/ACK/CQI bits it is a 12-column transpose), turbo rate
+ * un-matching with the UL-SCH soft-buffer rule (N_cb = K_w), REF turbo decoding, CRC24A.
+ * alloc.unit selects the subframe unit; the unit's subframe number and cell id are host arrays here because
+ * the reference signals are generated on the host per (cell, subframe, N_prb).  N_prb must be one the
+ * reference has an FFTW plan for: N_prb < N_rb_ul and divisible by 2, 3 or 5 (liblte_phy.cc:2360-2377);
+ * single antenna, one code block per transport block. */
+typedef struct mi_lte_pusch_plan mi_lte_pusch_plan;
+int      mi_lte_pusch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const mi_lte_ul_cfg *ul,
+                                  const uint32_t *h_unit_subfr_num, const uint32_t *h_unit_n_id_cell, uint32_t n_units,
+                                  const mi_lte_pdsch_alloc *h_allocs, uint32_t n_alloc, mi_lte_pusch_plan **out);
+void     mi_lte_pusch_plan_destroy(mi_lte_ctx *ctx, mi_lte_pusch_plan *plan);
+uint32_t mi_lte_pusch_plan_out_stride(const mi_lte_pusch_plan *plan);
+int      mi_lte_pusch_decode_run(mi_lte_ctx *ctx, mi_lte_pusch_plan *plan, const float *d_subframes, uint8_t *d_out_bits,
+                                 int32_t *d_status);
+/* stage tap: device pointer to the de-interleaved, descrambled soft bits (int8, 12*12*N_prb*Q_m of them) */
+int      mi_lte_pusch_plan_soft_bits(const mi_lte_pusch_plan *plan, uint32_t alloc, const int8_t **d_e, uint32_t *n_bits);
+
 /* ---------------------------------------------------------------- per-call host-pointer forms
  * The bodies of the reference's three entry points on this path, for callers that hold host
  * buffers exactly as the reference's callers do (LTE_fdd_dl_fs_samp_buf.cc:378-515,
@@ -228,6 +285,21 @@ typedef struct {
 size_t mi_lte_synth_unit_len(uint32_t fft_size);
 int    mi_lte_synth_dl_units_i8(const mi_lte_dl_cfg *cfg, uint32_t n_units, const uint32_t *h_subfr_num,
                                 const uint32_t *h_n_id_cell, uint32_t N_pdcch_symbs, const mi_lte_pdsch_alloc *h_allocs,
+                                uint32_t n_alloc, const mi_lte_synth_channel *chan, int8_t *h_iq, uint8_t *h_tx_bits,
+                                uint32_t tbs_stride);
+
+/* n_units uplink subframes for tests / benchmarks: every unit carries n_alloc PUSCH transmissions
+ * (allocs[u*n_alloc + a], .unit ignored) with random transport blocks, through one flat channel per unit.
+ * The transmit chain is the inverse of the reference's RECEIVER (36.212 5.2.2 / 36.211 5.3-5.6); the
+ * reference's own uplink transmit helpers are not usable as a model (its channel interleaver and SC-FDMA
+ * modulator index wrongly, liblte_phy.cc:12023-12042, :8565-8570 -- the eNodeB never transmits uplink).
+ * The transform precoder scales by 1/sqrt(12*N_prb) as a real UE does; the reference's receiver then sees
+ * 12*N_prb times the constellation point (its transform pre-decoding scaling, liblte_phy.cc:6644-6657), so QPSK
+ * decodes with every soft bit at +-1 while 16/64QAM fails -- in the reference and, identically, here.
+ * Writes mi_lte_synth_ul_unit_len(fft_size) complex int8 samples per unit. */
+size_t mi_lte_synth_ul_unit_len(uint32_t fft_size);
+int    mi_lte_synth_ul_units_i8(const mi_lte_dl_cfg *cfg, const mi_lte_ul_cfg *ul, uint32_t n_units,
+                                const uint32_t *h_subfr_num, const uint32_t *h_n_id_cell, const mi_lte_pdsch_alloc *h_allocs,
                                 uint32_t n_alloc, const mi_lte_synth_channel *chan, int8_t *h_iq, uint8_t *h_tx_bits,
                                 uint32_t tbs_stride);
 

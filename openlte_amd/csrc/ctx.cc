@@ -273,12 +273,12 @@ int mi_ctx_gold_tables(mi_lte_ctx *ctx)
     return MI_LTE_OK;
 }
 
-// Forward-DFT twiddles exp(-2*pi*i*k/2048), evaluated in double and rounded once; every smaller FFT
-// size and every Stockham pass reads this table with a stride.
+// Forward-DFT twiddles exp(-2*pi*i*k/4096), evaluated in double and rounded once; every FFT size and every
+// Stockham pass reads this table with a stride (the odd entries serve the uplink's half-sub-carrier rotation).
 int mi_ctx_fft_twiddles(mi_lte_ctx *ctx)
 {
     if (ctx->d_fft_tw) return MI_LTE_OK;
-    const uint32_t N = 2048;
+    const uint32_t N = 4096;
     std::vector<float2> tw(N);
     for (uint32_t k = 0; k < N; k++) {
         const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)N;

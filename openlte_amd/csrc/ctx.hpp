@@ -38,7 +38,7 @@ struct mi_lte_ctx {
     uint32_t *d_gold_x1 = nullptr, *d_gold_x2b = nullptr;
     uint32_t  gold_words = 0;
 
-    float2   *d_fft_tw  = nullptr; // exp(-2*pi*i*k/2048), k = 0..2047 (mi_ctx_fft_twiddles)
+    float2   *d_fft_tw  = nullptr; // exp(-2*pi*i*k/4096), k = 0..4095 (mi_ctx_fft_twiddles)
     uint32_t *d_crc_tab = nullptr; // x^e mod gCRC24A, e = 0..6143
 
     // optional per-launch HIP-event bracketing (mi_lte_profile_*): pairs are resolved at report time
@@ -75,5 +75,5 @@ int   mi_ctx_crc_table(mi_lte_ctx *ctx);
 int   mi_ctx_fft_twiddles(mi_lte_ctx *ctx);
 int   mi_turbo_ref_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_pdsch_alloc *d_allocs,
                          const uint32_t *d_cb_alloc, const int8_t *d_e, const uint32_t *d_e_off, const uint32_t *d_e_len,
-                         uint8_t *d_out_bits, uint32_t out_stride, int32_t *d_status, uint32_t e_max_bytes);
+                         uint8_t *d_out_bits, uint32_t out_stride, int32_t *d_status, uint32_t e_max_bytes, bool ul = false);
 int   mi_ctx_turbo_tables(mi_lte_ctx *ctx, uint32_t K, int spec, TurboTables *out);

@@ -23,6 +23,7 @@ struct DlGeom {
     uint32_t N_rb_dl;
     uint32_t N_ant;
     uint32_t sf_stride; // floats per device subframe
+    uint32_t ul;        // 1: uplink SC-FDMA demodulation (samples_to_symbols_ul, liblte_phy.cc:8654-8692)
 };
 
 // The FFT has no bit-exact reference (FFTW's operation order is unspecified; parity is to tolerance), so its
@@ -61,11 +62,11 @@ template <int R> __device__ __forceinline__ void dftR(float2 *v)
     else dft2(v[0], v[1]);
 }
 
-// Twiddles w^1 .. w^(R-1) of one butterfly, w = exp(-2*pi*i*k/(Ns*R)), from the 2048-entry table:
+// Twiddles w^1 .. w^(R-1) of one butterfly, w = exp(-2*pi*i*k/(Ns*R)), from the 4096-entry table:
 // w, w^2, w^4 are looked up (all below half a turn, so no index wrap), the rest are products.
 template <int R> __device__ __forceinline__ void twiddles(const float2 *__restrict__ tw, uint32_t k, uint32_t Ns, float2 (&w)[8])
 {
-    const uint32_t i1 = k * (2048u / (Ns * R));
+    const uint32_t i1 = k * (4096u / (Ns * R));
     w[1] = tw[i1];
     if (R >= 4) { w[2] = tw[2 * i1]; w[3] = cmul(w[1], w[2]); }
     if (R == 8) {
@@ -129,12 +130,18 @@ __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t
     float *row_im = row_re + 16 * N_SC_MAX;
     const uint32_t half = g.half;
 
-    auto ld_g = [&](uint32_t i) { return src.at(first + i); };
+    // uplink: the reference takes the ODD bins of a 2N-point FFT of the N samples zero-padded to 2N
+    // (liblte_phy.cc:8676-8690), i.e. the N-point FFT of x[n]*exp(-i*pi*n/N) -- the rotation is fused into the load
+    auto ld_g = [&](uint32_t i) {
+        const float2 v = src.at(first + i);
+        return g.ul ? cmul(v, tw[i * (2048u / N)]) : v;
+    };
     auto ld_s = [&](uint32_t i) { return buf[pad(i)]; };
     auto st_s = [&](uint32_t i, float2 v) { buf[pad(i)] = v; };
-    auto st_g = [&](uint32_t o, float2 v) { // keep bins 1..half and N-half..N-1 (liblte_phy.cc:8625-8634)
-        if (o >= 1 && o <= half) { row_re[half + o - 1] = v.x; row_im[half + o - 1] = v.y; }
-        else if (o >= N - half)  { row_re[o - (N - half)] = v.x; row_im[o - (N - half)] = v.y; }
+    const uint32_t dc = g.ul ? 0u : 1u; // downlink skips the DC bin, the half-shifted uplink grid has none
+    auto st_g = [&](uint32_t o, float2 v) { // keep bins dc..half-1+dc and N-half..N-1 (liblte_phy.cc:8625-8634, :8685-8690)
+        if (o >= dc && o < half + dc) { row_re[half + o - dc] = v.x; row_im[half + o - dc] = v.y; }
+        else if (o >= N - half)       { row_re[o - (N - half)] = v.x; row_im[o - (N - half)] = v.y; }
     };
 
     // radix plan: 8,8,8,4 (2048) | 8,8,8,2 (1024) | 8,8,8 (512) | 8,8,4 (256) | 8,8,2 (128)
@@ -412,6 +419,7 @@ int make_geom(const mi_lte_dl_cfg *cfg, DlGeom *g)
     g->N = N; g->cp0 = 160 / sc; g->cpe = 144 / sc; g->n_slot = 15360 / sc;
     g->half = 6 * cfg->N_rb_dl; g->N_rb_dl = cfg->N_rb_dl; g->N_ant = cfg->N_ant;
     g->sf_stride = (uint32_t)mi_lte_subframe_floats(cfg->N_ant);
+    g->ul = 0;
     return MI_LTE_OK;
 }
 
@@ -449,5 +457,39 @@ extern "C" int mi_lte_dl_frontend_batch(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cf
     MI_LAUNCH(ctx, "k_dl_ce", k_dl_ce, dim3(n_units, g.N_ant), dim3(256), lds_ce, d_subfr_num, d_n_id_cell, g, gt, d_subframes);
     MI_HIP_CHECK(ctx, hipGetLastError());
     ctx->last_kernels = "k_dl_fft:1,k_dl_ce:1";
+    return MI_LTE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// uplink front end: 14 SC-FDMA symbols per unit, no channel estimation here (the PUSCH estimate is per
+// allocation, see uplink.hip)
+extern "C" size_t mi_lte_ul_subframe_floats(void) { return (size_t)2 * 16 * N_SC_MAX; }
+
+extern "C" int mi_lte_ul_frontend_batch(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const void *d_samples_a, const void *d_samples_b,
+                                        const uint64_t *d_unit_start, uint32_t n_units, float *d_subframes)
+{
+    if (!ctx || !cfg || !d_samples_a || !d_unit_start || !d_subframes || n_units == 0) return MI_LTE_ERR_INVALID_ARG;
+    mi_lte_dl_cfg c1 = *cfg;
+    c1.N_ant         = 1;
+    DlGeom g;
+    int    rc = make_geom(&c1, &g);
+    if (rc != MI_LTE_OK) return rc;
+    g.ul        = 1;
+    g.sf_stride = (uint32_t)mi_lte_ul_subframe_floats();
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    rc = mi_ctx_fft_twiddles(ctx);
+    if (rc != MI_LTE_OK) return rc;
+    const size_t lds_fft = sizeof(float2) * (g.N + g.N / 32 + 1);
+    if (cfg->sample_format == MI_LTE_IQ_I8) {
+        SampleSrc<int8_t> s{(const int8_t *)d_samples_a};
+        MI_LAUNCH(ctx, "k_ul_fft", (k_dl_fft<int8_t>), dim3(14, n_units), dim3(256), lds_fft, s, d_unit_start, g, ctx->d_fft_tw, d_subframes);
+    } else if (cfg->sample_format == MI_LTE_IQ_F32_PLANAR) {
+        if (!d_samples_b) return MI_LTE_ERR_INVALID_ARG;
+        SampleSrc<float> s{(const float *)d_samples_a, (const float *)d_samples_b};
+        MI_LAUNCH(ctx, "k_ul_fft", (k_dl_fft<float>), dim3(14, n_units), dim3(256), lds_fft, s, d_unit_start, g, ctx->d_fft_tw, d_subframes);
+    } else
+        return MI_LTE_ERR_INVALID_ARG;
+    MI_HIP_CHECK(ctx, hipGetLastError());
+    ctx->last_kernels = "k_ul_fft:1";
     return MI_LTE_OK;
 }

@@ -1,0 +1,64 @@
+// Device helpers shared by the downlink (chain.hip) and uplink (uplink.hip) demodulators.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace {
+
+struct GoldTables { const uint32_t *x1; const uint32_t *x2b; uint32_t words; };
+
+__device__ __forceinline__ uint32_t gold_word(const GoldTables &gt, uint32_t c_init, uint32_t w)
+{
+    uint32_t v = gt.x1[w];
+    for (uint32_t m = c_init; m; m &= m - 1) v ^= gt.x2b[(uint32_t)__builtin_ctz(m) * gt.words + w];
+    return v;
+}
+
+// get_soft_decision (liblte_phy.cc:13880-13900) with max_dist = 1
+__device__ __forceinline__ float soft_decision(float rx_re, float rx_im, float exp_re, float exp_im)
+{
+    const float d_re = rx_re - exp_re, d_im = rx_im - exp_im;
+    float dist = sqrtf(d_re * d_re + d_im * d_im);
+    const float cap = 1.0f - (1.0f / 120);
+    if (dist >= cap) dist = cap;
+    return 1.0f - dist;
+}
+
+// modulation_demapper (liblte_phy.cc:9502-9660) for one symbol; writes Q_m int8 values
+__device__ __forceinline__ void demap_symbol(float re, float im, uint32_t mod, int8_t *b)
+{
+    const float r2 = (float)(1 / sqrt(2.0)), t10 = (float)(2 / sqrt(10.0)), t42 = (float)(2 / sqrt(42.0)),
+                f42 = (float)(4 / sqrt(42.0)), s42 = (float)(6 / sqrt(42.0));
+    if (mod == 3) {
+        const float ar = fabsf(re), ai = fabsf(im);
+        b[0] = (re > 0) ? 127 : -127;
+        b[1] = (im > 0) ? 127 : -127;
+        if (ar < f42) { b[2] = 127;  b[4] = (ar > t42) ? 127 : -127; }
+        else          { b[2] = -127; b[4] = (ar < s42) ? 127 : -127; }
+        if (ai < f42) { b[3] = 127;  b[5] = (ai > t42) ? 127 : -127; }
+        else          { b[3] = -127; b[5] = (ai < s42) ? 127 : -127; }
+    } else if (mod == 2) {
+        b[0] = (re > 0) ? 127 : -127;
+        b[1] = (im > 0) ? 127 : -127;
+        b[2] = (fabsf(re) < t10) ? 127 : -127;
+        b[3] = (fabsf(im) < t10) ? 127 : -127;
+    } else if (mod == 1) {
+        const float ang = atan2f(im, re);
+        float er, ei;
+        if (((double)ang >= 0) && ((double)ang < M_PI / 2))        { er = r2;  ei = r2; }
+        else if (((double)ang >= -M_PI / 2) && ((double)ang < 0))  { er = r2;  ei = -r2; }
+        else if (((double)ang >= M_PI / 2) && ((double)ang < M_PI)) { er = -r2; ei = r2; }
+        else                                                       { er = -r2; ei = -r2; }
+        const int m = (int)(127 * soft_decision(re, im, er, ei));
+        b[0] = (int8_t)((er > 0) ? m : -m);
+        b[1] = (int8_t)((ei > 0) ? m : -m);
+    } else {
+        const float ang = atan2f(im, re);
+        if (((double)ang > -M_PI / 4) && ((double)ang < 3 * M_PI / 4)) b[0] = (int8_t)(int)(127 * soft_decision(re, im, r2, r2));
+        else                                                          b[0] = (int8_t)(-(int)(127 * soft_decision(re, im, -r2, -r2)));
+    }
+}
+
+
+} // namespace

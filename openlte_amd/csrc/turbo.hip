@@ -243,21 +243,23 @@ struct GroupDesc {                 // one launch = the code blocks of one size K
     uint32_t        out_stride;
     int32_t        *status;        // [n_alloc] LIBLTE_ERROR_ENUM value
     const uint32_t *crc_tab;       // x^e mod gCRC24A for e = 0..6143
+    uint32_t        ul;            // 1: UL-SCH soft-buffer rule (N_cb = K_w: chan_type ULSCH, liblte_phy.cc:11387-11398, :12437-12449)
 };
 
 struct SrcRateUnmatch {
     static constexpr bool kIntegerValued = true; // sums of int8 soft bits
     uint32_t e_cap; // bytes of LDS available for staging e (0 = gather from global)
     GroupDesc       g;
-    const uint16_t *tabs; // [8][3K] rank of every d element in the order e is consumed, per (rv, K_mimo)
-    const uint32_t *nnn;  // [8]     non-NULL slots per lap of the circular buffer
+    const uint16_t *tabs; // [12][3K] rank of every d element in the order e is consumed: DL per (rv, K_mimo), then UL per rv
+    const uint32_t *nnn;  // [12]     non-NULL slots per lap of the circular buffer
     const uint16_t *tab;
     const int8_t   *e;
     uint32_t        E, Nnn, K_;
     __device__ __forceinline__ void init(uint32_t cb, uint32_t K)
     {
         const uint32_t a = g.cb_alloc[cb], txm = g.allocs[a].tx_mode;
-        const uint32_t combo = ((g.allocs[a].rv_idx & 3u) << 1) | ((txm == 3 || txm == 4 || txm == 8 || txm == 9) ? 1u : 0u);
+        const uint32_t combo = g.ul ? 8u + (g.allocs[a].rv_idx & 3u)
+                                    : ((g.allocs[a].rv_idx & 3u) << 1) | ((txm == 3 || txm == 4 || txm == 8 || txm == 9) ? 1u : 0u);
         tab = tabs + (size_t)combo * 3 * K;
         Nnn = nnn[combo];
         K_  = K;
@@ -776,12 +778,14 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 }
 
 // rank tables for the fused rate un-matching: one launch per block size, cached in the context.
-// combo = rv*2 + (K_mimo == 2); M_dl_harq = 8, N_soft = 250368, C = 1 as liblte_phy_pdsch_channel_decode passes them.
+// combo 0..7 = rv*2 + (K_mimo == 2) with M_dl_harq = 8, N_soft = 250368, C = 1 as liblte_phy_pdsch_channel_decode passes them;
+// combo 8..11 = UL-SCH, rv = combo - 8: ulsch_channel_decode passes chan_type ULSCH, so N_cb = K_w (liblte_phy.cc:12437-12449).
 __global__ __launch_bounds__(256) void k_rm_rank_table(uint32_t K, uint16_t *__restrict__ tabs, uint32_t *__restrict__ nnn)
 {
     const uint32_t combo = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
     RmGeom rm;
-    rm.init(K + 4, (combo & 1) ? 3 : 1, combo >> 1);
+    if (combo < 8) rm.init(K + 4, (combo & 1) ? 3 : 1, combo >> 1);
+    else           rm.init(K + 4, 1, combo - 8, 1, 1, 1, false);
     if (t == 0) nnn[combo] = rm.Nnn;
     if (t >= 3 * K) return;
     const uint32_t x = t / K, i = t - x * K;
@@ -898,19 +902,19 @@ static int turbo_ref_batch(mi_lte_ctx *ctx, const T *d_soft, uint32_t K, uint32_
 // demodulator's soft bits
 int mi_turbo_ref_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_pdsch_alloc *d_allocs,
                        const uint32_t *d_cb_alloc, const int8_t *d_e, const uint32_t *d_e_off, const uint32_t *d_e_len,
-                       uint8_t *d_out_bits, uint32_t out_stride, int32_t *d_status, uint32_t e_max_bytes)
+                       uint8_t *d_out_bits, uint32_t out_stride, int32_t *d_status, uint32_t e_max_bytes, bool ul)
 {
     int rc = mi_ctx_crc_table(ctx);
     if (rc != MI_LTE_OK) return rc;
-    GroupDesc gd{d_allocs, d_cb_alloc, d_e, d_e_off, d_e_len, d_out_bits, out_stride, d_status, ctx->d_crc_tab};
+    GroupDesc gd{d_allocs, d_cb_alloc, d_e, d_e_off, d_e_len, d_out_bits, out_stride, d_status, ctx->d_crc_tab, ul ? 1u : 0u};
     auto it = ctx->rm_tables.find(K);
     if (it == ctx->rm_tables.end()) {
         RmTables t;
-        MI_HIP_CHECK(ctx, hipMalloc((void **)&t.d_tabs, sizeof(uint16_t) * 8 * 3 * K));
-        MI_HIP_CHECK(ctx, hipMalloc((void **)&t.d_nnn, sizeof(uint32_t) * 8));
+        MI_HIP_CHECK(ctx, hipMalloc((void **)&t.d_tabs, sizeof(uint16_t) * 12 * 3 * K));
+        MI_HIP_CHECK(ctx, hipMalloc((void **)&t.d_nnn, sizeof(uint32_t) * 12));
         ctx->owned.push_back(t.d_tabs);
         ctx->owned.push_back(t.d_nnn);
-        MI_LAUNCH(ctx, "k_rm_rank_table", k_rm_rank_table, dim3((3 * K + 255) / 256, 8), dim3(256), 0, K, t.d_tabs, t.d_nnn);
+        MI_LAUNCH(ctx, "k_rm_rank_table", k_rm_rank_table, dim3((3 * K + 255) / 256, 12), dim3(256), 0, K, t.d_tabs, t.d_nnn);
         MI_HIP_CHECK(ctx, hipGetLastError());
         it = ctx->rm_tables.emplace(K, t).first;
     }

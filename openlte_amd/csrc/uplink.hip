@@ -1,0 +1,312 @@
+// PUSCH receive chain on gfx950 (BASELINE config 5): restates liblte_phy_pusch_channel_decode
+// (liblte/src/liblte_phy.cc:2801-2935) -> ulsch_channel_decode (:12363-12501) for a batch of allocations
+// (one per scheduled UE) inside the envelope the reference itself handles: single antenna, one codeword,
+// no RI/ACK/CQI multiplexing, one code block per transport block.
+//
+//   k_pusch_demod : one workgroup per allocation.
+//       DMRS least-squares estimate on symbols 3 and 10 and magnitude/phase interpolation over the 12
+//       data symbols (get_ulsch_ce :13718-13790), one-tap equaliser (pre_decoder_and_matched_filter_ul
+//       :6708-6736), transform pre-decoding = 12 unnormalised backward DFTs of size M = 12*N_prb times
+//       sqrt(M) (:6627-6660; the reference's scaling is reproduced as is), modulation de-mapping, descrambling
+//       (:2893-2898) and the channel de-interleaver, which without control bits is the transpose
+//       g[(k*12 + s)*Q_m + q] = h[(s*M + k)*Q_m + q] (:12108-12225).  M is any size FFTW would plan
+//       (N_prb divisible by 2, 3 or 5 -> radices 4, 2, 3, 5 and whatever prime is left), done as a
+//       mixed-radix Stockham transform through LDS.
+//   then the downlink's turbo stage (turbo.hip) with the UL-SCH rate-matching rule (N_cb = K_w).
+//
+// The DFT sizes are not powers of two and FFTW's operation order is unspecified, so like the downlink FFT
+// this stage is tolerance-checked; everything from the int8 soft bits on is integer-exact.
+#include <algorithm>
+#include <map>
+#include <tuple>
+
+#include "ctx.hpp"
+#include "phy_dev.hpp"
+#include "lte_tables.h"
+
+namespace {
+
+constexpr int N_SC_MAX = 1200;
+
+struct PuschDesc {
+    uint32_t subfr, cell;   // of the allocation's unit
+    uint32_t dmrs_off;      // float offset of dmrs_0_re | dmrs_0_im | dmrs_1_re | dmrs_1_im (M each) in the DMRS pool
+};
+
+// One Stockham pass of radix R (any R >= 2) over M points, sign +1 (backward transform):
+//   out[(j-k)*R + k + q*Ns] = sum_r in[j + r*M/R] * exp(+2*pi*i * r*(k + q*Ns)/(Ns*R)),  k = j mod Ns.
+// One thread per output; the angle is reduced as an integer before it reaches sincospif.
+__device__ __forceinline__ void dft_pass(const float2 *__restrict__ in, float2 *__restrict__ out, uint32_t M, uint32_t R, uint32_t Ns)
+{
+    const uint32_t nb = M / R, period = Ns * R;
+    for (uint32_t o = threadIdx.x; o < M; o += blockDim.x) {
+        const uint32_t q = o / nb, j = o - q * nb, k = j % Ns, step = k + q * Ns; // step < period
+        float    ar = 0.0f, ai = 0.0f;
+        uint32_t t  = 0; // r*step mod period
+        for (uint32_t r = 0; r < R; r++) {
+            float sn, cs;
+            sincospif(2.0f * (float)t / (float)period, &sn, &cs);
+            const float2 v = in[j + r * nb];
+            ar += v.x * cs - v.y * sn;
+            ai += v.x * sn + v.y * cs;
+            t += step;
+            if (t >= period) t -= period;
+        }
+        out[(j - k) * R + k + q * Ns] = make_float2(ar, ai);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pusch_demod(const float *__restrict__ subframes, uint32_t sf_stride,
+                                                     const mi_lte_pdsch_alloc *__restrict__ allocs, const PuschDesc *__restrict__ desc,
+                                                     const float *__restrict__ dmrs_pool, GoldTables gt, int8_t *__restrict__ e_base,
+                                                     const uint32_t *__restrict__ e_off, uint32_t *__restrict__ e_len, uint32_t M_max,
+                                                     uint32_t words_max)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    // LDS: est[6][M_max] (mag0 ang0 mag1 ang1 dmag dang) | buf A[M_max] | buf B[M_max] (float2) | scrambling words
+    float    *est  = sm;
+    float2   *bufA = reinterpret_cast<float2 *>(sm + 6 * (size_t)M_max), *bufB = bufA + M_max;
+    uint32_t *cw   = reinterpret_cast<uint32_t *>(bufB + M_max);
+    (void)words_max;
+
+    const uint32_t a_idx = blockIdx.x;
+    const mi_lte_pdsch_alloc &al = allocs[a_idx];
+    const PuschDesc           ds = desc[a_idx];
+    const uint32_t N_prb = al.N_prb, M = 12 * N_prb;
+    const uint32_t Qm = al.mod_type == 3 ? 6 : al.mod_type == 2 ? 4 : al.mod_type == 1 ? 2 : 1;
+    const uint32_t N_bits = 12 * M * Qm;
+    const float   *rx_re = subframes + (size_t)al.unit * sf_stride, *rx_im = rx_re + 16 * N_SC_MAX;
+    if (threadIdx.x == 0) e_len[a_idx] = N_bits;
+
+    // scrambling sequence (c_init per liblte_phy.cc:2893), one word of slack for the 2-word window below
+    const uint32_t c_init = (al.rnti << 14) | (0u << 13) | (ds.subfr << 9) | ds.cell, n_words = (N_bits + 31) / 32;
+    for (uint32_t w = threadIdx.x; w <= n_words; w += blockDim.x) cw[w] = gold_word(gt, c_init, w);
+
+    // ---- DMRS estimates and their interpolation slopes (get_ulsch_ce, liblte_phy.cc:13745-13768)
+    const float *d0_re = dmrs_pool + ds.dmrs_off, *d0_im = d0_re + M, *d1_re = d0_im + M, *d1_im = d1_re + M;
+    for (uint32_t i = threadIdx.x; i < M; i += blockDim.x) {
+        const uint32_t sc0 = al.prb[0][i / 12] * 12 + i % 12, sc1 = al.prb[1][i / 12] * 12 + i % 12;
+        const float c0r = rx_re[3 * N_SC_MAX + sc0], c0i = rx_im[3 * N_SC_MAX + sc0];
+        const float c1r = rx_re[10 * N_SC_MAX + sc1], c1i = rx_im[10 * N_SC_MAX + sc1];
+        float t_re = c0r * d0_re[i] + c0i * d0_im[i], t_im = c0i * d0_re[i] - c0r * d0_im[i];
+        const float mag_0 = sqrtf(t_re * t_re + t_im * t_im), ang_0 = atan2f(t_im, t_re);
+        t_re = c1r * d1_re[i] + c1i * d1_im[i];
+        t_im = c1i * d1_re[i] - c1r * d1_im[i];
+        const float mag_1 = sqrtf(t_re * t_re + t_im * t_im), ang_1 = atan2f(t_im, t_re);
+        const float f_mag = (mag_1 - mag_0) / 7;
+        float       f_ang = ang_1 - ang_0;
+        if ((double)f_ang >= M_PI) f_ang = (float)((double)f_ang - 2 * M_PI); // float compared / corrected in double (:13758-13764)
+        else if ((double)f_ang <= -M_PI) f_ang = (float)((double)f_ang + 2 * M_PI);
+        f_ang /= 7;
+        est[0 * M_max + i] = mag_0; est[1 * M_max + i] = ang_0; est[2 * M_max + i] = mag_1;
+        est[3 * M_max + i] = ang_1; est[4 * M_max + i] = f_mag; est[5 * M_max + i] = f_ang;
+    }
+    __syncthreads();
+
+    const float sqrt_M = (float)sqrt((double)M); // liblte_phy.cc:6644 (integer argument -> double sqrt, stored to float)
+    int8_t     *e      = e_base + e_off[a_idx];
+
+    for (uint32_t s = 0; s < 12; s++) {                       // data symbols in time order
+        const uint32_t L = s < 3 ? s : s < 9 ? s + 1 : s + 2; // skipping the DMRS symbols 3 and 10
+        // ---- channel estimate of this symbol and the one-tap equaliser
+        for (uint32_t i = threadIdx.x; i < M; i += blockDim.x) {
+            const float mag_0 = est[i], ang_0 = est[M_max + i], mag_1 = est[2 * M_max + i], ang_1 = est[3 * M_max + i];
+            const float f_mag = est[4 * M_max + i], f_ang = est[5 * M_max + i];
+            float cm, ca; // liblte_phy.cc:13770-13780
+            if (s < 3)      { cm = mag_0 - (float)(3 - s) * f_mag;       ca = ang_0 - (float)(3 - s) * f_ang; }
+            else if (s < 6) { cm = mag_0 + (float)(1 + (s - 3)) * f_mag; ca = ang_0 + (float)(1 + (s - 3)) * f_ang; }
+            else if (s < 9) { cm = mag_1 - (float)(3 - (s - 6)) * f_mag; ca = ang_1 - (float)(3 - (s - 6)) * f_ang; }
+            else            { cm = mag_1 + (float)(1 + (s - 9)) * f_mag; ca = ang_1 + (float)(1 + (s - 9)) * f_ang; }
+            float sn, cs;
+            sincosf(ca, &sn, &cs); // the compiled reference resolves cos(float) to cosf (C++ overload)
+            const float    h_re = cm * cs, h_im = cm * sn;
+            const uint32_t sc = al.prb[L / 7][i / 12] * 12 + i % 12;
+            const float    z_re = rx_re[L * N_SC_MAX + sc], z_im = rx_im[L * N_SC_MAX + sc];
+            const float    hn = h_re * h_re + h_im * h_im;
+            bufA[i] = make_float2((z_re * h_re + z_im * h_im) / hn, (z_im * h_re - z_re * h_im) / hn);
+        }
+        __syncthreads();
+        // ---- transform pre-decoding: M-point backward DFT, radices 4, 2, 3, 5, then the remaining prime
+        float2  *src = bufA, *dst = bufB;
+        uint32_t rem = M, Ns = 1;
+        while (rem > 1) { // uniform over the workgroup
+            uint32_t R;
+            if (rem % 4 == 0) R = 4;
+            else if (rem % 2 == 0) R = 2;
+            else if (rem % 3 == 0) R = 3;
+            else if (rem % 5 == 0) R = 5;
+            else {
+                R = 7;
+                while (rem % R) R += 2;
+            }
+            dft_pass(src, dst, M, R, Ns);
+            __syncthreads();
+            Ns *= R;
+            rem /= R;
+            float2 *t = src; src = dst; dst = t;
+        }
+        // ---- de-map, descramble, de-interleave (transpose): soft bit q of symbol k goes to (k*12 + s)*Q_m + q
+        for (uint32_t k = threadIdx.x; k < M; k += blockDim.x) {
+            const float2 x = src[k];
+            int8_t       b[6] = {0, 0, 0, 0, 0, 0};
+            demap_symbol(sqrt_M * x.x, sqrt_M * x.y, al.mod_type, b);
+            const uint32_t n0 = (s * M + k) * Qm, w = n0 >> 5, sh = n0 & 31;
+            const uint32_t c  = __builtin_amdgcn_alignbit(cw[w + 1], cw[w], sh);
+            int8_t        *o  = e + (size_t)(k * 12 + s) * Qm;
+            for (uint32_t q = 0; q < Qm; q++) o[q] = ((c >> q) & 1u) ? (int8_t)-b[q] : b[q];
+        }
+        __syncthreads();
+    }
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host side: plans
+
+struct mi_lte_pusch_plan {
+    mi_lte_dl_cfg cfg;
+    uint32_t      n_alloc = 0, out_stride = 0, M_max = 0, words_max = 0;
+    size_t        e_bytes = 0;
+    mi_lte_pdsch_alloc *d_allocs = nullptr;
+    PuschDesc          *d_desc   = nullptr;
+    float              *d_dmrs   = nullptr;
+    uint32_t *d_e_off = nullptr, *d_e_len = nullptr, *d_cb_alloc = nullptr;
+    int8_t   *d_e = nullptr;
+    struct Group { uint32_t K, n_cb, cb_base, e_max; };
+    std::vector<Group>    groups;
+    std::vector<uint32_t> h_e_off, h_e_len;
+};
+
+static uint32_t ul_qpp_size_at_least(uint32_t B)
+{
+    for (int r = 0; r < LTE_QPP_N_SIZES; r++)
+        if (LTE_QPP_ROWS[r].K >= B) return LTE_QPP_ROWS[r].K;
+    return 0;
+}
+
+extern "C" {
+
+int mi_lte_pusch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const mi_lte_ul_cfg *ul, const uint32_t *h_unit_subfr_num,
+                             const uint32_t *h_unit_n_id_cell, uint32_t n_units, const mi_lte_pdsch_alloc *h_allocs, uint32_t n_alloc,
+                             mi_lte_pusch_plan **out)
+{
+    if (!ctx || !cfg || !ul || !h_unit_subfr_num || !h_unit_n_id_cell || !h_allocs || !out || n_alloc == 0 || n_units == 0)
+        return MI_LTE_ERR_INVALID_ARG;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    auto *pl    = new mi_lte_pusch_plan();
+    pl->cfg     = *cfg;
+    pl->n_alloc = n_alloc;
+    std::map<uint32_t, std::vector<uint32_t>> byK;
+    std::map<uint32_t, uint32_t>              emaxK;
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> dmrs_at; // (cell, subframe, N_prb) -> float offset
+    std::vector<float>     dmrs;
+    std::vector<PuschDesc> desc(n_alloc);
+    uint32_t max_tbs = 0;
+    size_t   off = 0;
+    pl->h_e_off.resize(n_alloc);
+    pl->h_e_len.resize(n_alloc);
+    for (uint32_t a = 0; a < n_alloc; a++) {
+        const mi_lte_pdsch_alloc &al = h_allocs[a];
+        const uint32_t B = al.tbs + 24, K = (B <= 6144) ? ul_qpp_size_at_least(B) : 0;
+        // N_prb the reference has a transform pre-decoding plan for (liblte_phy.cc:2360-2377)
+        const bool planned = al.N_prb > 0 && al.N_prb < cfg->N_rb_dl && (al.N_prb % 2 == 0 || al.N_prb % 3 == 0 || al.N_prb % 5 == 0);
+        if (K == 0 || !planned || al.mod_type > 3 || al.unit >= n_units) {
+            ctx->err = "PUSCH allocation outside the envelope (one code block; N_prb < N_rb_ul and divisible by 2, 3 or 5) or malformed";
+            delete pl;
+            return MI_LTE_ERR_UNSUPPORTED;
+        }
+        const uint32_t sf = h_unit_subfr_num[al.unit] % 10, cell = h_unit_n_id_cell[al.unit], M = 12 * al.N_prb;
+        auto key = std::make_tuple(cell, sf, al.N_prb);
+        auto it  = dmrs_at.find(key);
+        if (it == dmrs_at.end()) {
+            const uint32_t at = (uint32_t)dmrs.size();
+            dmrs.resize(dmrs.size() + 4 * (size_t)M);
+            int rc = mi_lte_ul_dmrs_pusch(ul, cell, sf, al.N_prb, &dmrs[at], &dmrs[at + M], &dmrs[at + 2 * M], &dmrs[at + 3 * M]);
+            if (rc != MI_LTE_OK) { delete pl; return rc; }
+            it = dmrs_at.emplace(key, at).first;
+        }
+        desc[a] = {sf, cell, it->second};
+        byK[K].push_back(a);
+        max_tbs = std::max(max_tbs, al.tbs);
+        const uint32_t Qm = al.mod_type == 3 ? 6 : al.mod_type == 2 ? 4 : al.mod_type == 1 ? 2 : 1, E = 12 * M * Qm;
+        pl->M_max     = std::max(pl->M_max, M);
+        pl->words_max = std::max(pl->words_max, (E + 31) / 32 + 1);
+        emaxK[K]       = std::max(emaxK[K], E);
+        pl->h_e_off[a] = (uint32_t)off;
+        pl->h_e_len[a] = E;
+        off += (E + 63) & ~63u;
+    }
+    if (pl->words_max > 4096) { ctx->err = "allocation larger than the scrambling table"; delete pl; return MI_LTE_ERR_UNSUPPORTED; }
+    pl->e_bytes    = off;
+    pl->out_stride = (max_tbs + 63) & ~63u;
+    std::vector<uint32_t> cb_alloc;
+    for (auto &kv : byK) {
+        pl->groups.push_back({kv.first, (uint32_t)kv.second.size(), (uint32_t)cb_alloc.size(), emaxK[kv.first]});
+        cb_alloc.insert(cb_alloc.end(), kv.second.begin(), kv.second.end());
+    }
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_allocs, sizeof(mi_lte_pdsch_alloc) * n_alloc));
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_desc, sizeof(PuschDesc) * n_alloc));
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_dmrs, sizeof(float) * std::max<size_t>(dmrs.size(), 1)));
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_e_off, sizeof(uint32_t) * n_alloc));
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_e_len, sizeof(uint32_t) * n_alloc));
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_cb_alloc, sizeof(uint32_t) * n_alloc));
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_e, pl->e_bytes ? pl->e_bytes : 64));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_allocs, h_allocs, sizeof(mi_lte_pdsch_alloc) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_desc, desc.data(), sizeof(PuschDesc) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_dmrs, dmrs.data(), sizeof(float) * dmrs.size(), hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_e_off, pl->h_e_off.data(), sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_cb_alloc, cb_alloc.data(), sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    *out = pl;
+    return MI_LTE_OK;
+}
+
+void mi_lte_pusch_plan_destroy(mi_lte_ctx *ctx, mi_lte_pusch_plan *pl)
+{
+    if (!pl) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    (void)hipFree(pl->d_allocs);
+    (void)hipFree(pl->d_desc);
+    (void)hipFree(pl->d_dmrs);
+    (void)hipFree(pl->d_e_off);
+    (void)hipFree(pl->d_e_len);
+    (void)hipFree(pl->d_cb_alloc);
+    (void)hipFree(pl->d_e);
+    delete pl;
+}
+
+uint32_t mi_lte_pusch_plan_out_stride(const mi_lte_pusch_plan *pl) { return pl ? pl->out_stride : 0; }
+
+int mi_lte_pusch_plan_soft_bits(const mi_lte_pusch_plan *pl, uint32_t alloc, const int8_t **d_e, uint32_t *n_bits)
+{
+    if (!pl || alloc >= pl->n_alloc || !d_e || !n_bits) return MI_LTE_ERR_INVALID_ARG;
+    *d_e    = pl->d_e + pl->h_e_off[alloc];
+    *n_bits = pl->h_e_len[alloc];
+    return MI_LTE_OK;
+}
+
+int mi_lte_pusch_decode_run(mi_lte_ctx *ctx, mi_lte_pusch_plan *pl, const float *d_subframes, uint8_t *d_out_bits, int32_t *d_status)
+{
+    if (!ctx || !pl || !d_subframes || !d_out_bits || !d_status) return MI_LTE_ERR_INVALID_ARG;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    int rc = mi_ctx_gold_tables(ctx);
+    if (rc != MI_LTE_OK) return rc;
+    GoldTables   gt{ctx->d_gold_x1, ctx->d_gold_x2b, ctx->gold_words};
+    const size_t lds = sizeof(float) * 6 * (size_t)pl->M_max + sizeof(float2) * 2 * (size_t)pl->M_max + sizeof(uint32_t) * (pl->words_max + 1);
+    MI_LAUNCH(ctx, "k_pusch_demod", k_pusch_demod, dim3(pl->n_alloc), dim3(256), lds, d_subframes, (uint32_t)mi_lte_ul_subframe_floats(),
+              pl->d_allocs, pl->d_desc, pl->d_dmrs, gt, pl->d_e, pl->d_e_off, pl->d_e_len, pl->M_max, pl->words_max);
+    MI_HIP_CHECK(ctx, hipGetLastError());
+    for (auto &gr : pl->groups) {
+        rc = mi_turbo_ref_group(ctx, gr.K, gr.n_cb, pl->d_allocs, pl->d_cb_alloc + gr.cb_base, pl->d_e, pl->d_e_off, pl->d_e_len,
+                                d_out_bits, pl->out_stride, d_status, gr.e_max, /*ul=*/true);
+        if (rc != MI_LTE_OK) return rc;
+    }
+    ctx->last_kernels = "k_pusch_demod:1,k_turbo_prep,k_turbo_siso,k_turbo_perm,k_turbo_vote per block size";
+    return MI_LTE_OK;
+}
+
+} // extern "C"

@@ -21,6 +21,12 @@ class DlCfg(C.Structure):
     _fields_ = [("fft_size", C.c_uint32), ("N_rb_dl", C.c_uint32), ("N_ant", C.c_uint32), ("sample_format", C.c_uint32)]
 
 
+class UlCfg(C.Structure):
+    """mi_lte_ul_cfg: the liblte_phy_ul_init arguments the PUSCH DMRS depends on"""
+    _fields_ = [(n, C.c_uint32) for n in ("group_assignment_pusch", "group_hopping_enabled", "sequence_hopping_enabled",
+                                          "cyclic_shift", "cyclic_shift_dci")]
+
+
 class PdschAlloc(C.Structure):
     """mi_lte_pdsch_alloc"""
     _fields_ = [(n, C.c_uint32) for n in ("unit", "mod_type", "tbs", "rv_idx", "tx_mode", "rnti", "N_prb", "reserved")] + \
@@ -94,6 +100,17 @@ def load_library():
     L.mi_lte_pdsch_plan_out_stride.restype = u32
     L.mi_lte_pdsch_decode_run.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.mi_lte_pdsch_plan_soft_bits.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(vp)]
+    L.mi_lte_ul_subframe_floats.restype = sz
+    L.mi_lte_ul_frontend_batch.argtypes = [vp, C.POINTER(DlCfg), vp, vp, vp, u32, vp]
+    f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+    u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+    L.mi_lte_ul_dmrs_pusch.argtypes = [C.POINTER(UlCfg), u32, u32, u32, f32p, f32p, f32p, f32p]
+    L.mi_lte_pusch_plan_create.argtypes = [vp, C.POINTER(DlCfg), C.POINTER(UlCfg), u32p, u32p, u32, vp, u32, C.POINTER(vp)]
+    L.mi_lte_pusch_plan_destroy.argtypes = [vp, vp]
+    L.mi_lte_pusch_plan_out_stride.argtypes = [vp]
+    L.mi_lte_pusch_plan_out_stride.restype = u32
+    L.mi_lte_pusch_decode_run.argtypes = [vp, vp, vp, vp, vp]
+    L.mi_lte_pusch_plan_soft_bits.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u32)]
     L.mi_lte_turbo_decode_batch.argtypes = [vp, vp, C.c_int, u32, u32, C.c_int, u32, C.c_int, vp]
     L.mi_lte_turbo_scratch_bytes.argtypes = [u32, u32]
     L.mi_lte_turbo_scratch_bytes.restype = sz
@@ -179,6 +196,60 @@ class PdschPlan:
         if self.h:
             self.ctx.L.mi_lte_pdsch_plan_destroy(self.ctx.h, self.h)
             self.h = None
+
+
+class PuschPlan:
+    """mi_lte_pusch_plan: PUSCH allocations (one per scheduled UE) over a batch of uplink subframe units."""
+
+    def __init__(self, ctx, cfg, ulcfg, unit_subfr_num, unit_n_id_cell, allocs):
+        self.ctx, self.n_alloc = ctx, len(allocs)
+        arr = (PdschAlloc * len(allocs))(*allocs)
+        h = C.c_void_p()
+        sf, cell = np.ascontiguousarray(unit_subfr_num, np.uint32), np.ascontiguousarray(unit_n_id_cell, np.uint32)
+        ctx._check(ctx.L.mi_lte_pusch_plan_create(ctx.h, C.byref(cfg), C.byref(ulcfg), sf, cell, len(sf), C.cast(arr, C.c_void_p),
+                                                  len(allocs), C.byref(h)))
+        self.h = h
+        self.out_stride = ctx.L.mi_lte_pusch_plan_out_stride(h)
+        self.tbs = [a.tbs for a in allocs]
+
+    def run_dev(self, d_subframes, d_out, d_status):
+        self.ctx._check(self.ctx.L.mi_lte_pusch_decode_run(self.ctx.h, self.h, d_subframes.ptr, d_out.ptr, d_status.ptr))
+
+    def run(self, d_subframes):
+        """Returns (status int32 [n_alloc], list of uint8 bit arrays)."""
+        ctx = self.ctx
+        d_out, d_st = ctx.alloc(self.n_alloc * self.out_stride), ctx.alloc(4 * self.n_alloc)
+        d_out.zero()
+        try:
+            self.run_dev(d_subframes, d_out, d_st)
+            st = d_st.download(np.int32)
+            bits = d_out.download(np.uint8).reshape(self.n_alloc, self.out_stride)
+            return st, [bits[a, :self.tbs[a]] for a in range(self.n_alloc)]
+        finally:
+            d_out.free()
+            d_st.free()
+
+    def soft_bits(self, alloc):
+        """De-interleaved, descrambled int8 soft bits of one allocation (stage tap)."""
+        pe, n = C.c_void_p(), C.c_uint32()
+        self.ctx._check(self.ctx.L.mi_lte_pusch_plan_soft_bits(self.h, alloc, C.byref(pe), C.byref(n)))
+        out = np.empty(int(n.value), np.int8)
+        self.ctx._check(self.ctx.L.mi_lte_memcpy_d2h(self.ctx.h, out.ctypes.data, pe.value, out.nbytes))
+        return out
+
+    def close(self):
+        if self.h:
+            self.ctx.L.mi_lte_pusch_plan_destroy(self.ctx.h, self.h)
+            self.h = None
+
+
+def ul_dmrs_pusch(ulcfg, n_id_cell, n_subfr, n_prb):
+    """float32 [4, 12*n_prb]: dmrs_0_re, dmrs_0_im, dmrs_1_re, dmrs_1_im (host function of the library)."""
+    out = np.zeros((4, 12 * n_prb), np.float32)
+    rc = load_library().mi_lte_ul_dmrs_pusch(C.byref(ulcfg), n_id_cell, n_subfr, n_prb, out[0], out[1], out[2], out[3])
+    if rc != 0:
+        raise MiLteError("mi_lte_ul_dmrs_pusch failed: %d" % rc)
+    return out
 
 
 class Context:
@@ -267,6 +338,36 @@ class Context:
             for b in (d_a, d_b, d_start, d_sf, d_cell, d_out):
                 if b is not None:
                     b.free()
+
+    # ---- uplink ------------------------------------------------------------------------------
+    def ul_subframe_floats(self):
+        return self.L.mi_lte_ul_subframe_floats()
+
+    def ul_frontend_dev(self, cfg, d_a, d_b, d_start, n_units, d_subframes):
+        self._check(self.L.mi_lte_ul_frontend_batch(self.h, C.byref(cfg), d_a.ptr, d_b.ptr if d_b is not None else None,
+                                                    d_start.ptr, n_units, d_subframes.ptr))
+
+    def ul_frontend(self, cfg, samples, unit_start, keep=False):
+        """Host convenience: int8 [..., 2] samples -> float32 [n_units, 2, 16, 1200] (symb_re, symb_im); keep=True
+        also returns the device buffer (caller frees)."""
+        n = len(unit_start)
+        d_a = self.to_device(samples.astype(np.int8))
+        cfg.sample_format = IQ_I8
+        d_start = self.to_device(np.asarray(unit_start, np.uint64))
+        d_out = self.alloc(n * self.ul_subframe_floats() * 4)
+        d_out.zero()
+        try:
+            self.ul_frontend_dev(cfg, d_a, None, d_start, n, d_out)
+            host = d_out.download(np.float32).reshape(n, 2, 16, 1200)
+            return (host, d_out) if keep else host
+        finally:
+            d_a.free()
+            d_start.free()
+            if not keep:
+                d_out.free()
+
+    def pusch_plan(self, cfg, ulcfg, unit_subfr_num, unit_n_id_cell, allocs):
+        return PuschPlan(self, cfg, ulcfg, unit_subfr_num, unit_n_id_cell, allocs)
 
     # ---- PDSCH ------------------------------------------------------------------------------
     def pdsch_plan(self, cfg, n_pdcch_symbs, allocs):

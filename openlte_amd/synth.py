@@ -4,7 +4,7 @@ import ctypes as C
 
 import numpy as np
 
-from .lib import load_library, MiLteError, DlCfg, PdschAlloc
+from .lib import load_library, MiLteError, DlCfg, UlCfg, PdschAlloc
 
 _i8p = np.ctypeslib.ndpointer(np.int8, flags="C_CONTIGUOUS")
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
@@ -28,6 +28,10 @@ def _lib():
         L.mi_lte_synth_unit_len.argtypes = [C.c_uint32]
         L.mi_lte_synth_unit_len.restype = C.c_size_t
         L.mi_lte_synth_dl_units_i8.argtypes = [C.POINTER(DlCfg), C.c_uint32, _u32p, _u32p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                               C.POINTER(SynthChannel), _i8p, _u8p, C.c_uint32]
+        L.mi_lte_synth_ul_unit_len.argtypes = [C.c_uint32]
+        L.mi_lte_synth_ul_unit_len.restype = C.c_size_t
+        L.mi_lte_synth_ul_units_i8.argtypes = [C.POINTER(DlCfg), C.POINTER(UlCfg), C.c_uint32, _u32p, _u32p, C.c_void_p, C.c_uint32,
                                                C.POINTER(SynthChannel), _i8p, _u8p, C.c_uint32]
         L._synth_bound = True
     return L
@@ -74,4 +78,26 @@ def dl_units(cfg, subfr_num, n_id_cell, allocs, n_alloc, n_pdcch_symbs=2, gain=(
                                          C.cast(arr, C.c_void_p), n_alloc, C.byref(ch), iq, tx, max_tbs)
     if rc != 0:
         raise MiLteError("mi_lte_synth_dl_units_i8 failed: %d" % rc)
+    return iq, tx
+
+
+def ul_unit_len(fft_size=2048):
+    return int(_lib().mi_lte_synth_ul_unit_len(fft_size))
+
+
+def ul_units(cfg, ulcfg, subfr_num, n_id_cell, allocs, n_alloc, gain=(0.5, 1.5), max_delay=4, snr_db=30.0, peak=100.0, seed=1):
+    """Synthesise len(subfr_num) uplink subframe units, n_alloc PUSCH transmissions each (allocs unit-major).
+    Returns (iq int8 [n, ul_unit_len, 2], tx_bits uint8 [n, n_alloc, max_tbs])."""
+    n = len(subfr_num)
+    ul = ul_unit_len(cfg.fft_size)
+    iq = np.zeros((n, ul, 2), np.int8)
+    max_tbs = max([a.tbs for a in allocs], default=8)
+    tx = np.zeros((n, max(n_alloc, 1), max_tbs), np.uint8)
+    arr = (PdschAlloc * max(len(allocs), 1))(*allocs)
+    ch = SynthChannel(gain[0], gain[1], float(max_delay), float(snr_db), float(peak), int(seed))
+    rc = _lib().mi_lte_synth_ul_units_i8(C.byref(cfg), C.byref(ulcfg), n, np.ascontiguousarray(subfr_num, np.uint32),
+                                         np.ascontiguousarray(n_id_cell, np.uint32), C.cast(arr, C.c_void_p), n_alloc,
+                                         C.byref(ch), iq, tx, max_tbs)
+    if rc != 0:
+        raise MiLteError("mi_lte_synth_ul_units_i8 failed: %d" % rc)
     return iq, tx

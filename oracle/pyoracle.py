@@ -169,6 +169,21 @@ def ref():
     L.ref_samples_to_symbols_dl.argtypes = [vp, f32p, f32p, u32, u32, f32p, f32p]
     L.ref_time_get_dl_subframe_and_ce.argtypes = [vp, f32p, f32p, u32, u32, u32, u32, vp, u32]
     L.ref_time_get_dl_subframe_and_ce.restype = C.c_double
+    # uplink
+    L.ref_ul_init.argtypes = [vp, u32, u32, u32, u32, u32, u32]
+    L.ref_get_pusch_dmrs.argtypes = [vp, u32, u32, f32p]
+    L.ref_get_ul_subframe.argtypes = [vp, f32p, f32p, vp]
+    L.ref_pusch_channel_decode.argtypes = [vp, vp, C.POINTER(LoAlloc), u32, u32, u8p, C.POINTER(u32)]
+    L.ref_pusch_soft_bits_ptr.argtypes = [vp]
+    L.ref_pusch_soft_bits_ptr.restype = C.POINTER(C.c_int8)
+    L.ref_ulsch_rx_g_bits_ptr.argtypes = [vp]
+    L.ref_ulsch_rx_g_bits_ptr.restype = C.POINTER(C.c_float)
+    L.ref_pusch_d_re_ptr.argtypes = [vp]
+    L.ref_pusch_d_re_ptr.restype = C.POINTER(C.c_float)
+    L.ref_pusch_d_im_ptr.argtypes = [vp]
+    L.ref_pusch_d_im_ptr.restype = C.POINTER(C.c_float)
+    L.ref_time_pusch.argtypes = [vp, f32p, f32p, vp, C.POINTER(LoAlloc), u32, u32, u32]
+    L.ref_time_pusch.restype = C.c_double
     _REF = L
     return L
 

@@ -343,6 +343,62 @@ void ref_samples_to_symbols_dl(void *phy, float *re, float *im, uint32_t slot_st
 }
 
 // CPU-baseline timing helpers ------------------------------------------------------------
+// ---- uplink: liblte_phy_ul_init / get_ul_subframe / pusch_channel_decode, unmodified
+int ref_ul_init(void *phy, uint32_t N_id_cell, uint32_t group_assignment_pusch, uint32_t group_hopping_enabled,
+                uint32_t sequence_hopping_enabled, uint32_t cyclic_shift, uint32_t cyclic_shift_dci)
+{
+    // PRACH / PUCCH arguments are the eNodeB's defaults; nothing on the PUSCH path reads them
+    return (int)liblte_phy_ul_init((LIBLTE_PHY_STRUCT *)phy, (uint16)N_id_cell, 0, 0, 1, false, (uint8)group_assignment_pusch,
+                                   group_hopping_enabled != 0, sequence_hopping_enabled != 0, (uint8)cyclic_shift,
+                                   (uint8)cyclic_shift_dci, 0, 1);
+}
+// DMRS of (subframe, N_prb) as ul_init left it in the struct: out = dmrs_0_re | dmrs_0_im | dmrs_1_re | dmrs_1_im, M each
+void ref_get_pusch_dmrs(void *vphy, uint32_t N_subfr, uint32_t N_prb, float *out)
+{
+    LIBLTE_PHY_STRUCT *phy = (LIBLTE_PHY_STRUCT *)vphy;
+    const uint32_t     M   = N_prb * 12;
+    memcpy(out, phy->pusch_dmrs_0_re[N_subfr][N_prb], sizeof(float) * M);
+    memcpy(out + M, phy->pusch_dmrs_0_im[N_subfr][N_prb], sizeof(float) * M);
+    memcpy(out + 2 * M, phy->pusch_dmrs_1_re[N_subfr][N_prb], sizeof(float) * M);
+    memcpy(out + 3 * M, phy->pusch_dmrs_1_im[N_subfr][N_prb], sizeof(float) * M);
+}
+int ref_get_ul_subframe(void *phy, float *i_samps, float *q_samps, void *sf)
+{
+    return (int)liblte_phy_get_ul_subframe((LIBLTE_PHY_STRUCT *)phy, i_samps, q_samps, (LIBLTE_PHY_SUBFRAME_STRUCT *)sf);
+}
+int ref_pusch_channel_decode(void *phy, void *sf, const ref_alloc_t *alloc, uint32_t N_id_cell, uint32_t N_ant,
+                             uint8_t *out_bits, uint32_t *N_out_bits)
+{
+    LIBLTE_PHY_ALLOCATION_STRUCT *a = (LIBLTE_PHY_ALLOCATION_STRUCT *)calloc(1, sizeof(*a));
+    uint32                        N = 0;
+    fill_alloc(a, alloc, NULL);
+    a->chan_type = LIBLTE_PHY_CHAN_TYPE_ULSCH;
+    ref_zero_turbo_scratch(phy);
+    int err = (int)liblte_phy_pusch_channel_decode((LIBLTE_PHY_STRUCT *)phy, (LIBLTE_PHY_SUBFRAME_STRUCT *)sf, a, N_id_cell,
+                                                   (uint8)N_ant, out_bits, &N);
+    *N_out_bits = N;
+    free(a);
+    return err;
+}
+int8_t *ref_pusch_soft_bits_ptr(void *phy) { return (int8_t *)((LIBLTE_PHY_STRUCT *)phy)->pusch_soft_bits; }
+float  *ref_ulsch_rx_g_bits_ptr(void *phy) { return ((LIBLTE_PHY_STRUCT *)phy)->ulsch_rx_g_bits; }
+float  *ref_pusch_d_re_ptr(void *phy) { return ((LIBLTE_PHY_STRUCT *)phy)->pusch_d_re; }
+float  *ref_pusch_d_im_ptr(void *phy) { return ((LIBLTE_PHY_STRUCT *)phy)->pusch_d_im; }
+double ref_time_pusch(void *phy, float *i_samps, float *q_samps, void *sf, const ref_alloc_t *allocs, uint32_t n_alloc,
+                      uint32_t N_id_cell, uint32_t reps)
+{
+    uint8_t         out[6200];
+    uint32_t        n;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (uint32_t r = 0; r < reps; r++) {
+        ref_get_ul_subframe(phy, i_samps, q_samps, sf);
+        for (uint32_t a = 0; a < n_alloc; a++) ref_pusch_channel_decode(phy, sf, &allocs[a], N_id_cell, 1, out, &n);
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
 double ref_time_get_dl_subframe_and_ce(void *phy, float *i_samps, float *q_samps, uint32_t frame_start_idx,
                                        uint32_t subfr_num, uint32_t N_id_cell, uint32_t N_ant, void *sf,
                                        uint32_t reps)

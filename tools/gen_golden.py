@@ -42,6 +42,25 @@ def turbo_ref_vectors(R, P, phy):
     print("turbo_ref.npz:", len(cases), "cases")
 
 
+def uplink_vectors(R):
+    """Uplink receive chain: seeded int8 captures from the library's host transmitter + what the
+    reference's liblte_phy_get_ul_subframe / liblte_phy_pusch_channel_decode make of them."""
+    rec = {}
+    for name in ("1p4MHz_hop", "5MHz_seqhop_16qam", "10MHz_prime"):
+        case = td.ul_case(name)
+        symb, res = td.ref_ul_decode(R, case)
+        rec[name + "_iq"] = case["iq"]
+        n_sc = 12 * case["nrb"]
+        rec[name + "_symb"] = symb[:, :, :, :n_sc].astype(np.float32)
+        for i, (rc, bits, g) in enumerate(res):
+            rec["%s_a%d_rc" % (name, i)] = np.array([rc])
+            rec["%s_a%d_g" % (name, i)] = g
+            if bits is not None:
+                rec["%s_a%d_bits" % (name, i)] = pack(bits)
+    np.savez_compressed(os.path.join(OUT, "uplink_ref.npz"), **rec)
+    print("uplink_ref.npz:", sorted({k.split("_a")[0].rsplit("_", 1)[0] for k in rec}))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     R, P = po.ref(), po.port()
@@ -49,6 +68,7 @@ def main():
     phy = R.ref_phy_new(4, 17, 1, 100)
     turbo_ref_vectors(R, P, phy)
     R.ref_phy_free(phy)
+    uplink_vectors(R)
 
 
 if __name__ == "__main__":

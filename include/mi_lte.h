@@ -256,6 +256,16 @@ int mi_lte_pdsch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const fl
                                      const float *h_rx_ce_re, const float *h_rx_ce_im, uint32_t subfr_num,
                                      const mi_lte_pdsch_alloc *alloc, uint32_t N_pdcch_symbs, uint32_t N_id_cell,
                                      uint32_t N_ant, uint8_t *h_out_bits, uint32_t *N_out_bits);
+/* uplink: liblte_phy_get_ul_subframe (h_i / h_q point at the subframe's first sample; 14 rows of 1200 floats are
+ * written) and liblte_phy_pusch_channel_decode (the DMRS arrays are the caller's, i.e. what liblte_phy_ul_init
+ * stored in LIBLTE_PHY_STRUCT::pusch_dmrs_{0,1}_{re,im}[subframe][N_prb]; a CRC failure returns 1 =
+ * LIBLTE_ERROR_INVALID_INPUTS like the reference, liblte_phy.cc:2809, :2929) */
+int mi_lte_get_ul_subframe_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_ul, const float *h_i_samps, const float *h_q_samps,
+                                float *h_rx_symb_re /*[16][1200]*/, float *h_rx_symb_im);
+int mi_lte_pusch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_ul, const float *h_rx_symb_re, const float *h_rx_symb_im,
+                                     uint32_t subfr_num, const mi_lte_pdsch_alloc *alloc, uint32_t N_id_cell, uint32_t N_ant,
+                                     const float *h_dmrs_0_re, const float *h_dmrs_0_im, const float *h_dmrs_1_re,
+                                     const float *h_dmrs_1_im, uint8_t *h_out_bits, uint32_t *N_out_bits);
 int mi_lte_rate_unmatch_turbo_host(mi_lte_ctx *ctx, const float *h_e_bits, uint32_t N_e_bits, uint32_t N_dummy_bits,
                                    uint32_t N_codeblocks, uint32_t tx_mode, uint32_t N_soft, uint32_t M_dl_harq,
                                    uint32_t chan_type, uint32_t rv_idx, float *h_d_bits, uint32_t *N_d_bits);

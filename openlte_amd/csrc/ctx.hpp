@@ -77,3 +77,7 @@ int   mi_turbo_ref_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lt
                          const uint32_t *d_cb_alloc, const int8_t *d_e, const uint32_t *d_e_off, const uint32_t *d_e_len,
                          uint8_t *d_out_bits, uint32_t out_stride, int32_t *d_status, uint32_t e_max_bytes, bool ul = false);
 int   mi_ctx_turbo_tables(mi_lte_ctx *ctx, uint32_t K, int spec, TurboTables *out);
+struct mi_lte_pusch_plan;
+int   mi_pusch_plan_create_impl(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const mi_lte_ul_cfg *ul, const uint32_t *h_unit_subfr_num,
+                                const uint32_t *h_unit_n_id_cell, uint32_t n_units, const mi_lte_pdsch_alloc *h_allocs, uint32_t n_alloc,
+                                const float *h_dmrs, mi_lte_pusch_plan **out);

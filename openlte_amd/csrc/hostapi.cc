@@ -93,6 +93,79 @@ int mi_lte_pdsch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const fl
     return rc != MI_LTE_OK ? rc : (int)st;
 }
 
+// liblte_phy_get_ul_subframe (liblte_phy.cc:6209-6236)
+int mi_lte_get_ul_subframe_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_ul, const float *h_i, const float *h_q, float *h_symb_re,
+                                float *h_symb_im)
+{
+    if (!ctx) return MI_LTE_ERR_INVALID_ARG;
+    if (!h_i || !h_q || !h_symb_re || !h_symb_im) return 1;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint32_t sc = 2048 / fft_size;
+    const size_t   need = 30720 / sc; // the last symbol's window ends one sample before the subframe does
+    DevBuf d_i, d_q, d_par, d_sub;
+    const size_t nf = mi_lte_ul_subframe_floats();
+    if (d_i.alloc(need * 4) || d_q.alloc(need * 4) || d_par.alloc(8) || d_sub.alloc(nf * 4)) return MI_LTE_ERR_NOMEM;
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(d_i.p, h_i, need * 4, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(d_q.p, h_q, need * 4, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemsetAsync(d_par.p, 0, 8, ctx->stream));
+    mi_lte_dl_cfg cfg = {fft_size, N_rb_ul, 1, MI_LTE_IQ_F32_PLANAR};
+    int rc = mi_lte_ul_frontend_batch(ctx, &cfg, d_i.p, d_q.p, (const uint64_t *)d_par.p, 1, (float *)d_sub.p);
+    if (rc != MI_LTE_OK) return rc;
+    const size_t row = 14 * 1200 * sizeof(float); // rows 14, 15 of the caller's struct are left alone, as the reference leaves them
+    float       *s   = (float *)d_sub.p;
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(h_symb_re, s, row, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(h_symb_im, s + 16 * 1200, row, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// liblte_phy_pusch_channel_decode (liblte_phy.cc:2801-2935).  The reference signals are the caller's: the arrays
+// liblte_phy_ul_init stored in LIBLTE_PHY_STRUCT (pusch_dmrs_0/1_re/im[subframe][N_prb]).  A failed CRC is reported
+// as 1 = LIBLTE_ERROR_INVALID_INPUTS, which is what the reference returns in that case (:2809, :2929).
+int mi_lte_pusch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_ul, const float *h_symb_re, const float *h_symb_im, uint32_t subfr_num,
+                                     const mi_lte_pdsch_alloc *alloc, uint32_t N_id_cell, uint32_t N_ant, const float *h_dmrs_0_re,
+                                     const float *h_dmrs_0_im, const float *h_dmrs_1_re, const float *h_dmrs_1_im, uint8_t *h_out_bits,
+                                     uint32_t *N_out_bits)
+{
+    if (!ctx) return MI_LTE_ERR_INVALID_ARG;
+    if (!h_symb_re || !h_symb_im || !alloc || !h_out_bits || !N_out_bits || !h_dmrs_0_re || !h_dmrs_0_im || !h_dmrs_1_re || !h_dmrs_1_im) return 1;
+    (void)N_ant;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint32_t fft = N_rb_ul <= 6 ? 128 : N_rb_ul <= 15 ? 256 : N_rb_ul <= 25 ? 512 : N_rb_ul <= 50 ? 1024 : 2048;
+    mi_lte_dl_cfg      cfg = {fft, N_rb_ul, 1, MI_LTE_IQ_F32_PLANAR};
+    mi_lte_pdsch_alloc a   = *alloc;
+    a.unit                 = 0;
+    const size_t       M   = 12 * (size_t)a.N_prb;
+    std::vector<float> dm(4 * M);
+    memcpy(&dm[0], h_dmrs_0_re, M * 4); memcpy(&dm[M], h_dmrs_0_im, M * 4);
+    memcpy(&dm[2 * M], h_dmrs_1_re, M * 4); memcpy(&dm[3 * M], h_dmrs_1_im, M * 4);
+    mi_lte_pusch_plan *plan = nullptr;
+    int rc = mi_pusch_plan_create_impl(ctx, &cfg, nullptr, &subfr_num, &N_id_cell, 1, &a, 1, dm.data(), &plan);
+    if (rc == MI_LTE_ERR_UNSUPPORTED) return 1;
+    if (rc != MI_LTE_OK) return rc;
+    const size_t   nf = mi_lte_ul_subframe_floats(), row = 16 * 1200;
+    const uint32_t stride = mi_lte_pusch_plan_out_stride(plan);
+    DevBuf d_sub, d_out, d_st;
+    if (d_sub.alloc(nf * 4) || d_out.alloc(stride) || d_st.alloc(4)) { mi_lte_pusch_plan_destroy(ctx, plan); return MI_LTE_ERR_NOMEM; }
+    float     *s = (float *)d_sub.p;
+    hipError_t e = hipMemcpyAsync(s, h_symb_re, row * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(s + row, h_symb_im, row * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) { mi_lte_pusch_plan_destroy(ctx, plan); ctx->err = hipGetErrorString(e); return MI_LTE_ERR_HIP; }
+    rc = mi_lte_pusch_decode_run(ctx, plan, s, (uint8_t *)d_out.p, (int32_t *)d_st.p);
+    int32_t st = 3;
+    if (rc == MI_LTE_OK) {
+        e = hipMemcpyAsync(&st, d_st.p, 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess && st == 0) {
+            e = hipMemcpy(h_out_bits, d_out.p, a.tbs, hipMemcpyDeviceToHost);
+            *N_out_bits = a.tbs;
+        }
+        if (e != hipSuccess) { rc = MI_LTE_ERR_HIP; ctx->err = hipGetErrorString(e); }
+    }
+    mi_lte_pusch_plan_destroy(ctx, plan);
+    return rc != MI_LTE_OK ? rc : (st == 0 ? 0 : 1);
+}
+
 // liblte_phy_rate_unmatch_turbo (liblte_phy.cc:11246-11490)
 int mi_lte_rate_unmatch_turbo_host(mi_lte_ctx *ctx, const float *h_e, uint32_t N_e, uint32_t N_dummy_bits, uint32_t C, uint32_t tx_mode,
                                    uint32_t N_soft, uint32_t M_dl_harq, uint32_t chan_type, uint32_t rv_idx, float *h_d, uint32_t *N_d)

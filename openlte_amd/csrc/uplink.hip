@@ -185,13 +185,13 @@ static uint32_t ul_qpp_size_at_least(uint32_t B)
     return 0;
 }
 
-extern "C" {
-
-int mi_lte_pusch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const mi_lte_ul_cfg *ul, const uint32_t *h_unit_subfr_num,
-                             const uint32_t *h_unit_n_id_cell, uint32_t n_units, const mi_lte_pdsch_alloc *h_allocs, uint32_t n_alloc,
-                             mi_lte_pusch_plan **out)
+// h_dmrs (optional): caller-supplied reference signals, 4 x 12*N_prb floats per allocation back to back -- the
+// per-call host form passes the arrays liblte_phy_ul_init left in the caller's LIBLTE_PHY_STRUCT
+int mi_pusch_plan_create_impl(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const mi_lte_ul_cfg *ul, const uint32_t *h_unit_subfr_num,
+                              const uint32_t *h_unit_n_id_cell, uint32_t n_units, const mi_lte_pdsch_alloc *h_allocs, uint32_t n_alloc,
+                              const float *h_dmrs, mi_lte_pusch_plan **out)
 {
-    if (!ctx || !cfg || !ul || !h_unit_subfr_num || !h_unit_n_id_cell || !h_allocs || !out || n_alloc == 0 || n_units == 0)
+    if (!ctx || !cfg || (!ul && !h_dmrs) || !h_unit_subfr_num || !h_unit_n_id_cell || !h_allocs || !out || n_alloc == 0 || n_units == 0)
         return MI_LTE_ERR_INVALID_ARG;
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     auto *pl    = new mi_lte_pusch_plan();
@@ -217,16 +217,23 @@ int mi_lte_pusch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const mi
             return MI_LTE_ERR_UNSUPPORTED;
         }
         const uint32_t sf = h_unit_subfr_num[al.unit] % 10, cell = h_unit_n_id_cell[al.unit], M = 12 * al.N_prb;
-        auto key = std::make_tuple(cell, sf, al.N_prb);
-        auto it  = dmrs_at.find(key);
-        if (it == dmrs_at.end()) {
+        if (h_dmrs) {
             const uint32_t at = (uint32_t)dmrs.size();
-            dmrs.resize(dmrs.size() + 4 * (size_t)M);
-            int rc = mi_lte_ul_dmrs_pusch(ul, cell, sf, al.N_prb, &dmrs[at], &dmrs[at + M], &dmrs[at + 2 * M], &dmrs[at + 3 * M]);
-            if (rc != MI_LTE_OK) { delete pl; return rc; }
-            it = dmrs_at.emplace(key, at).first;
+            dmrs.insert(dmrs.end(), h_dmrs, h_dmrs + 4 * (size_t)M);
+            h_dmrs += 4 * (size_t)M;
+            desc[a] = {sf, cell, at};
+        } else {
+            auto key = std::make_tuple(cell, sf, al.N_prb);
+            auto it  = dmrs_at.find(key);
+            if (it == dmrs_at.end()) {
+                const uint32_t at = (uint32_t)dmrs.size();
+                dmrs.resize(dmrs.size() + 4 * (size_t)M);
+                int rc = mi_lte_ul_dmrs_pusch(ul, cell, sf, al.N_prb, &dmrs[at], &dmrs[at + M], &dmrs[at + 2 * M], &dmrs[at + 3 * M]);
+                if (rc != MI_LTE_OK) { delete pl; return rc; }
+                it = dmrs_at.emplace(key, at).first;
+            }
+            desc[a] = {sf, cell, it->second};
         }
-        desc[a] = {sf, cell, it->second};
         byK[K].push_back(a);
         max_tbs = std::max(max_tbs, al.tbs);
         const uint32_t Qm = al.mod_type == 3 ? 6 : al.mod_type == 2 ? 4 : al.mod_type == 1 ? 2 : 1, E = 12 * M * Qm;
@@ -260,6 +267,16 @@ int mi_lte_pusch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const mi
     MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     *out = pl;
     return MI_LTE_OK;
+}
+
+extern "C" {
+
+int mi_lte_pusch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const mi_lte_ul_cfg *ul, const uint32_t *h_unit_subfr_num,
+                             const uint32_t *h_unit_n_id_cell, uint32_t n_units, const mi_lte_pdsch_alloc *h_allocs, uint32_t n_alloc,
+                             mi_lte_pusch_plan **out)
+{
+    if (!ul) return MI_LTE_ERR_INVALID_ARG;
+    return mi_pusch_plan_create_impl(ctx, cfg, ul, h_unit_subfr_num, h_unit_n_id_cell, n_units, h_allocs, n_alloc, nullptr, out);
 }
 
 void mi_lte_pusch_plan_destroy(mi_lte_ctx *ctx, mi_lte_pusch_plan *pl)

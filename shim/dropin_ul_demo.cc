@@ -1,0 +1,59 @@
+// dropin_ul_demo.cc -- an uplink caller written purely against the reference's liblte_phy API, in the order
+// LTE_fdd_enodeb's radio thread uses it (LTE_fdd_enb_phy.cc:832-917): liblte_phy_init + liblte_phy_ul_init, then per
+// subframe liblte_phy_get_ul_subframe and one liblte_phy_pusch_channel_decode per scheduled UE.  The capture is an
+// int8 I,Q file of one subframe (tests write it with the library's host transmitter; the reference cannot transmit
+// uplink).  Linked twice by shim/Makefile, CPU-only and with the two entry points on the GPU; same lines expected.
+//
+//   dropin_ul_* <capture.bin> <N_rb_ul> <N_id_cell> <subframe> <delta_ss> <group_hop> <seq_hop> <cs> <cs_dci>
+//               then per UE: <mod> <tbs> <rnti> <first_prb> <N_prb>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "liblte_phy.h"
+
+int main(int argc, char **argv)
+{
+    if (argc < 15 || (argc - 10) % 5) { fprintf(stderr, "usage: see the file header\n"); return 2; }
+    const uint32 N_rb = atoi(argv[2]), cell = atoi(argv[3]), sf_num = atoi(argv[4]);
+    const LIBLTE_PHY_FS_ENUM fs = N_rb <= 6 ? LIBLTE_PHY_FS_1_92MHZ : N_rb <= 15 ? LIBLTE_PHY_FS_3_84MHZ : N_rb <= 25 ? LIBLTE_PHY_FS_7_68MHZ
+                                : N_rb <= 50 ? LIBLTE_PHY_FS_15_36MHZ : LIBLTE_PHY_FS_30_72MHZ;
+    LIBLTE_PHY_STRUCT *phy = NULL;
+    if (LIBLTE_SUCCESS != liblte_phy_init(&phy, fs, cell, 1, N_rb, 12, 1.0f)) return 3;
+    if (LIBLTE_SUCCESS != liblte_phy_ul_init(phy, cell, 0, 0, 1, false, atoi(argv[5]), atoi(argv[6]) != 0, atoi(argv[7]) != 0, atoi(argv[8]),
+                                             atoi(argv[9]), 0, 1))
+        return 3;
+    const uint32 n = phy->N_samps_per_subfr;
+    float *i_s = (float *)calloc(n + 64, sizeof(float)), *q_s = (float *)calloc(n + 64, sizeof(float));
+    FILE  *f   = fopen(argv[1], "rb");
+    if (!f) return 4;
+    for (uint32 k = 0; k < n; k++) {
+        signed char v[2];
+        if (fread(v, 1, 2, f) != 2) break;
+        i_s[k] = v[0];
+        q_s[k] = v[1];
+    }
+    fclose(f);
+    LIBLTE_PHY_SUBFRAME_STRUCT *rx = (LIBLTE_PHY_SUBFRAME_STRUCT *)calloc(1, sizeof(*rx));
+    rx->num = sf_num;
+    if (LIBLTE_SUCCESS != liblte_phy_get_ul_subframe(phy, i_s, q_s, rx)) { printf("get_ul_subframe failed\n"); return 5; }
+    double acc = 0;
+    for (int l = 0; l < 14; l++) for (uint32 k = 0; k < 12 * N_rb; k++) acc += rx->rx_symb_re[l][k] * rx->rx_symb_re[l][k] + rx->rx_symb_im[l][k] * rx->rx_symb_im[l][k];
+    printf("grid energy = %.4e\n", acc);
+    LIBLTE_PHY_ALLOCATION_STRUCT *al = (LIBLTE_PHY_ALLOCATION_STRUCT *)calloc(1, sizeof(*al));
+    for (int a = 10; a < argc; a += 5) {
+        memset(al, 0, sizeof(*al));
+        al->mod_type  = (LIBLTE_PHY_MODULATION_TYPE_ENUM)atoi(argv[a]);
+        al->chan_type = LIBLTE_PHY_CHAN_TYPE_ULSCH;
+        al->tbs = atoi(argv[a + 1]); al->rnti = atoi(argv[a + 2]); al->N_prb = atoi(argv[a + 4]);
+        for (uint32 i = 0; i < al->N_prb; i++) al->prb[0][i] = al->prb[1][i] = atoi(argv[a + 3]) + i;
+        al->N_codewords = 1; al->N_layers = 1; al->tx_mode = 1; al->rv_idx = 0;
+        uint8 out[LIBLTE_MAX_MSG_SIZE]; uint32 nb = 0;
+        LIBLTE_ERROR_ENUM e = liblte_phy_pusch_channel_decode(phy, rx, al, cell, 1, out, &nb);
+        uint32 h = 2166136261u; // FNV-1a over the decoded bits
+        for (uint32 i = 0; i < nb; i++) h = (h ^ out[i]) * 16777619u;
+        printf("rnti 0x%x: err=%d N_out_bits=%u hash=%08x\n", (unsigned)al->rnti, (int)e, nb, h);
+    }
+    liblte_phy_cleanup(phy);
+    return 0;
+}

@@ -1,14 +1,16 @@
 // liblte_phy_shim.cc -- the binding a maintainer of the reference adds to run the DL receive hot
-// path on an MI355X.  It is compiled AGAINST THE REFERENCE'S OWN HEADER (liblte/hdr/liblte_phy.h from
+// path -- and, since round 1, the uplink PUSCH receive path -- on an MI355X.  It is compiled AGAINST THE REFERENCE'S OWN HEADER (liblte/hdr/liblte_phy.h from
 // their tree; nothing from the reference is copied here) and defines, with the reference's exact
 // C++ signatures, the three public functions of the hot path:
 //
 //     liblte_phy_get_dl_subframe_and_ce   liblte_phy.h:1170-1177   (impl. liblte_phy.cc:5905-6200)
 //     liblte_phy_pdsch_channel_decode     liblte_phy.h:906-913     (impl. liblte_phy.cc:3690-3853)
 //     liblte_phy_rate_unmatch_turbo       liblte_phy.h:1311-1323   (impl. liblte_phy.cc:11246-11490)
+//     liblte_phy_get_ul_subframe          liblte_phy.h:1190-1193   (impl. liblte_phy.cc:6209-6236)
+//     liblte_phy_pusch_channel_decode     liblte_phy.h:722-728     (impl. liblte_phy.cc:2801-2935)
 //
 // by forwarding to libmi_lte.so's C-ABI (include/mi_lte.h).  The reference's own definitions of
-// these three symbols are kept out of the link by compiling liblte_phy.cc with
+// these symbols are kept out of the link by compiling liblte_phy.cc with
 //     -Dliblte_phy_get_dl_subframe_and_ce=liblte_phy_get_dl_subframe_and_ce_cpu   (etc.)
 // so every other liblte_phy_* function (sync, PBCH, PDCCH, TX side, UL) stays on the reference's CPU
 // code and keeps working unchanged -- see INTEGRATION.md and shim/Makefile.
@@ -92,4 +94,36 @@ void liblte_phy_rate_unmatch_turbo(LIBLTE_PHY_STRUCT *phy_struct, float *e_bits,
     if (c && 0 == mi_lte_rate_unmatch_turbo_host(c, e_bits, N_e_bits, N_dummy_bits, N_codeblocks, tx_mode, N_soft, M_dl_harq,
                                                  (uint32_t)chan_type, rv_idx, d_bits, &n))
         *N_d_bits = n;
+}
+
+// ---- uplink (LTE_fdd_enodeb's radio thread: LTE_fdd_enb_phy.cc:832-917)
+
+LIBLTE_ERROR_ENUM liblte_phy_get_ul_subframe(LIBLTE_PHY_STRUCT *phy_struct, float *i_samps, float *q_samps,
+                                             LIBLTE_PHY_SUBFRAME_STRUCT *subframe)
+{
+    if (phy_struct == NULL || i_samps == NULL || q_samps == NULL || subframe == NULL) return LIBLTE_ERROR_INVALID_INPUTS;
+    mi_lte_ctx *c = ctx_for(phy_struct);
+    if (!c) return LIBLTE_ERROR_INVALID_INPUTS;
+    int rc = mi_lte_get_ul_subframe_host(c, phy_struct->N_samps_per_symb, phy_struct->N_rb_ul, i_samps, q_samps,
+                                         &subframe->rx_symb_re[0][0], &subframe->rx_symb_im[0][0]);
+    return rc == 0 ? LIBLTE_SUCCESS : LIBLTE_ERROR_INVALID_INPUTS;
+}
+
+LIBLTE_ERROR_ENUM liblte_phy_pusch_channel_decode(LIBLTE_PHY_STRUCT *phy_struct, LIBLTE_PHY_SUBFRAME_STRUCT *subframe,
+                                                  LIBLTE_PHY_ALLOCATION_STRUCT *alloc, uint32 N_id_cell, uint8 N_ant, uint8 *out_bits,
+                                                  uint32 *N_out_bits)
+{
+    if (phy_struct == NULL || subframe == NULL || alloc == NULL || out_bits == NULL || N_out_bits == NULL || !phy_struct->ul_init ||
+        alloc->N_prb == 0 || alloc->N_prb >= LIBLTE_PHY_N_RB_UL_MAX || subframe->num > 9)
+        return LIBLTE_ERROR_INVALID_INPUTS;
+    mi_lte_ctx *c = ctx_for(phy_struct);
+    if (!c) return LIBLTE_ERROR_INVALID_INPUTS;
+    mi_lte_pdsch_alloc a;
+    to_mi_alloc(alloc, &a);
+    // the reference signals are the ones liblte_phy_ul_init (still the reference's own code) left in the struct
+    const uint32 sf = subframe->num, np = alloc->N_prb;
+    int rc = mi_lte_pusch_channel_decode_host(c, phy_struct->N_rb_ul, &subframe->rx_symb_re[0][0], &subframe->rx_symb_im[0][0], sf, &a,
+                                              N_id_cell, N_ant, phy_struct->pusch_dmrs_0_re[sf][np], phy_struct->pusch_dmrs_0_im[sf][np],
+                                              phy_struct->pusch_dmrs_1_re[sf][np], phy_struct->pusch_dmrs_1_im[sf][np], out_bits, N_out_bits);
+    return rc == 0 ? LIBLTE_SUCCESS : LIBLTE_ERROR_INVALID_INPUTS; // the reference's own failure code on this path (:2809, :2929)
 }

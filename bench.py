@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- one JSON line per run (driver contract).
 
-    python bench.py --gpus N --steps K --warmup W [--workload chain|frontend|turbo]
+    python bench.py --gpus N --steps K --warmup W [--workload chain|frontend|turbo|uplink]
 
 A "step" is one pass of the hot path over one batch of synthetic input that is already resident in
 HBM.  Work is sharded by unit (subframes / code blocks) over ranks with no data-path collective
@@ -299,6 +299,104 @@ class FrontendWorkload:
                 "sample": "%d calls of liblte_phy_get_dl_subframe_and_ce, 1 thread, %.1f s; FFT = float64 radix-2 stand-in" % (reps, t)}
 
 
+class UplinkWorkload:
+    """BASELINE config 5 / SURVEY 8d W5 (PUSCH part): eNodeB uplink, 20 MHz, 16 UEs per subframe, 6 PRB QPSK each
+    (TBS 504, inside the reference's own envelope: E >= 3(K+4), N_prb <= 10 as its scheduler caps it,
+    liblte_phy.cc:6426-6428).  One step = SC-FDMA demodulation -> per-UE DMRS estimate / equaliser / transform
+    pre-decoding / de-map / descramble / de-interleave -> rate un-match -> REF turbo -> CRC."""
+    name = "uplink"
+    metric = "UL subframes/sec @20MHz, 16 UEs x 6 PRB QPSK PUSCH: SC-FDMA demod + PUSCH demod + UL-SCH turbo decode (SURVEY 8d W5)"
+    unit = "subframes/s"
+    dtype = "i8 IQ in, f32 FFT/CE/equaliser/DFT, i8 soft bits, i32 path metrics"
+    N_UE, N_PRB, TBS = 16, 6, 504
+    alg_bytes_per_unit = 61440 + 16 * 504 // 8
+    dominant = "k_pusch_demod"
+
+    def __init__(self, ctx, n_units, rank):
+        import numpy as np
+        import openlte_amd as m
+        from openlte_amd import synth
+        self.ctx, self.m, self.np = ctx, m, np
+        self.n = n_units or 16384
+        self.cfg, self.ul = m.DlCfg(2048, 100, 1, 0), m.UlCfg(3, 0, 0, 2, 5)
+        U = min(20, self.n)
+        self.cell = 17 + rank
+        sfs = (np.arange(U) % 10).astype(np.uint32)
+        mk = lambda u: [m.make_alloc(u, 1, self.TBS, list(range(6 * a, 6 * a + 6)), 0x100 + a) for a in range(self.N_UE)]
+        allocs = []
+        for u in range(U):
+            allocs += mk(u)
+        iq, tx = synth.ul_units(self.cfg, self.ul, sfs, [self.cell] * U, allocs, self.N_UE, snr_db=20.0, max_delay=3, seed=777 + rank)
+        self.uniq = (iq, tx, sfs, allocs)
+        idx = np.arange(self.n) % U
+        self.idx = idx
+        ul_len = iq.shape[1]
+        self.d_iq = ctx.to_device(iq[idx].reshape(-1, 2))
+        self.d_start = ctx.to_device((np.arange(self.n) * ul_len).astype(np.uint64))
+        self.d_sub = ctx.alloc(self.n * ctx.ul_subframe_floats() * 4)
+        all_allocs = []
+        for i in range(self.n):
+            all_allocs += mk(i)
+        self.plan = ctx.pusch_plan(self.cfg, self.ul, sfs[idx], [self.cell] * self.n, all_allocs)
+        self.d_out = ctx.alloc(self.n * self.N_UE * self.plan.out_stride)
+        self.d_status = ctx.alloc(self.n * self.N_UE * 4)
+
+    def step(self):
+        self.ctx.ul_frontend_dev(self.cfg, self.d_iq, None, self.d_start, self.n, self.d_sub)
+        self.plan.run_dev(self.d_sub, self.d_out, self.d_status)
+
+    def units_per_step(self):
+        return self.n
+
+    def value_per_unit(self):
+        return 1.0
+
+    def extra(self, value):
+        np = self.np
+        st = self.d_status.download(np.int32)
+        bits = self.d_out.download(np.uint8).reshape(self.n * self.N_UE, self.plan.out_stride)
+        tx = self.uniq[1]
+        exact = all((bits[i * self.N_UE + a, :self.TBS] == tx[self.idx[i], a, :self.TBS]).all()
+                    for i in range(0, self.n, max(1, self.n // 64)) for a in range(self.N_UE))
+        return {"turbo_info_mbit_per_s": round(value * self.N_UE * self.TBS / 1e6, 2),
+                "crc_pass": "%d/%d allocations" % (int((st == 0).sum()), st.size), "sampled_blocks_equal_tx_bits": bool(exact)}
+
+    def roofline_bytes(self, kernel, n_launch_per_step):
+        n, M = self.n, 12 * self.N_PRB
+        turbo = n * self.N_UE * _turbo_alg_bytes(self.TBS + 24)
+        return {"k_ul_fft": n * (61440 + 14 * 1200 * 8), "k_pusch_demod": n * self.N_UE * (14 * M * 8 + 12 * M * 2),
+                "k_turbo_siso": 2 * turbo, "k_turbo_prep": turbo, "k_turbo_perm": turbo, "k_turbo_vote": turbo}.get(kernel)
+
+    def config(self, world):
+        return {"workload": "W5 uplink: 20 MHz, %d UEs x %d PRB QPSK PUSCH (TBS %d) per subframe, %d subframes per GPU, int8 IQ in HBM"
+                            % (self.N_UE, self.N_PRB, self.TBS, self.n),
+                "subframes_per_gpu": self.n, "decoder": "REF (reference-faithful, bit-exact)", "unique_subframes": len(self.uniq[2]),
+                "sharding": "subframes block-cyclic over %d GPU(s), no collective" % world}
+
+    def cpu_baseline(self, budget_s=12.0):
+        """The reference's liblte_phy_get_ul_subframe + 16 x liblte_phy_pusch_channel_decode on one core."""
+        import ctypes as C
+        np = self.np
+        from oracle import pyoracle as po
+        R = po.ref()
+        if R is None:
+            return None
+        iq, tx, sfs, allocs = self.uniq
+        phy = R.ref_phy_new(4, self.cell, 1, 100)
+        if R.ref_ul_init(phy, self.cell, 3, 0, 0, 2, 5) != 0:
+            return None
+        sfp = R.ref_subframe_new()
+        R.ref_subframe_set_num(sfp, int(sfs[0]))
+        la = (po.LoAlloc * self.N_UE)(*[po.make_alloc(1, self.TBS, list(range(6 * a, 6 * a + 6)), 0x100 + a) for a in range(self.N_UE)])
+        re, im = np.ascontiguousarray(iq[0, :, 0].astype(np.float32)), np.ascontiguousarray(iq[0, :, 1].astype(np.float32))
+        t = R.ref_time_pusch(phy, re, im, sfp, la, self.N_UE, self.cell, 3)
+        reps = int(max(5, min(4000, budget_s / (t / 3))))
+        t = R.ref_time_pusch(phy, re, im, sfp, la, self.N_UE, self.cell, reps)
+        return {"value": round(reps / t, 3), "unit": self.unit, "cores": 1, "kind": "reference",
+                "sample": "%d repetitions of one of the benchmark's subframes (get_ul_subframe + 16 x pusch_channel_decode), 1 thread, "
+                          "%.1f s; FFT/DFT = float64 stand-in for FFTW3f (O(n^2) for the 72-point DFTs)" % (reps, t)}
+
+
 class MultiStream:
     """Run S independent shards of a workload on S contexts (= S HIP streams) of the same GPU, launched
     back to back and synchronised together.  Units are independent, so this is the same "shard by
@@ -306,7 +404,7 @@ class MultiStream:
     the lock-step trellis kernel 4+ waves per SIMD (32k subframes), one stream is the fastest."""
 
     def __init__(self, cls, ctxs, n_units, rank):
-        n_units = n_units or {"chain": 32768, "frontend": 10000, "turbo": 65536}[cls.name]
+        n_units = n_units or {"chain": 32768, "frontend": 10000, "turbo": 65536, "uplink": 16384}[cls.name]
         per = max(64, (n_units // len(ctxs) + 63) // 64 * 64)
         self.parts = [cls(c, per, rank * 16 + k) for k, c in enumerate(ctxs)]
         self.ctxs = ctxs
@@ -366,7 +464,7 @@ class MultiStream:
         return self.parts[0].cpu_baseline()
 
 
-WORKLOADS = {"turbo": TurboWorkload, "frontend": FrontendWorkload, "chain": ChainWorkload}
+WORKLOADS = {"turbo": TurboWorkload, "frontend": FrontendWorkload, "chain": ChainWorkload, "uplink": UplinkWorkload}
 
 
 def pick_workload(name):

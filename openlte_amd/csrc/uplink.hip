@@ -33,26 +33,29 @@ struct PuschDesc {
     uint32_t dmrs_off;      // float offset of dmrs_0_re | dmrs_0_im | dmrs_1_re | dmrs_1_im (M each) in the DMRS pool
 };
 
-// One Stockham pass of radix R (any R >= 2) over M points, sign +1 (backward transform):
+// One Stockham pass of radix R (any R >= 2) over S symbols of M points each (symbol s at in + s*M_max), sign +1
+// (backward transform):
 //   out[(j-k)*R + k + q*Ns] = sum_r in[j + r*M/R] * exp(+2*pi*i * r*(k + q*Ns)/(Ns*R)),  k = j mod Ns.
-// One thread per output; the angle is reduced as an integer before it reaches sincospif.
-__device__ __forceinline__ void dft_pass(const float2 *__restrict__ in, float2 *__restrict__ out, uint32_t M, uint32_t R, uint32_t Ns)
+// One thread per output; Ns*R divides M, so the twiddle is entry (r*(k + q*Ns) mod Ns*R) * M/(Ns*R) of the
+// allocation's table tw[t] = exp(+2*pi*i*t/M).
+__device__ __forceinline__ void dft_pass(const float2 *__restrict__ in, float2 *__restrict__ out, const float2 *__restrict__ tw,
+                                         uint32_t S, uint32_t M, uint32_t M_max, uint32_t R, uint32_t Ns)
 {
-    const uint32_t nb = M / R, period = Ns * R;
-    for (uint32_t o = threadIdx.x; o < M; o += blockDim.x) {
-        const uint32_t q = o / nb, j = o - q * nb, k = j % Ns, step = k + q * Ns; // step < period
+    const uint32_t nb = M / R, period = Ns * R, tstride = M / period;
+    for (uint32_t o = threadIdx.x; o < S * M; o += blockDim.x) {
+        const uint32_t sy = o / M, oo = o - sy * M;
+        const uint32_t q = oo / nb, j = oo - q * nb, k = j % Ns, step = (k + q * Ns) * tstride; // step < M
+        const float2  *x = in + sy * M_max + j;
         float    ar = 0.0f, ai = 0.0f;
-        uint32_t t  = 0; // r*step mod period
+        uint32_t t  = 0; // r*step mod M
         for (uint32_t r = 0; r < R; r++) {
-            float sn, cs;
-            sincospif(2.0f * (float)t / (float)period, &sn, &cs);
-            const float2 v = in[j + r * nb];
-            ar += v.x * cs - v.y * sn;
-            ai += v.x * sn + v.y * cs;
+            const float2 w = tw[t], v = x[r * nb];
+            ar += v.x * w.x - v.y * w.y;
+            ai += v.x * w.y + v.y * w.x;
             t += step;
-            if (t >= period) t -= period;
+            if (t >= M) t -= M;
         }
-        out[(j - k) * R + k + q * Ns] = make_float2(ar, ai);
+        out[sy * M_max + (j - k) * R + k + q * Ns] = make_float2(ar, ai);
     }
 }
 
@@ -60,14 +63,14 @@ __global__ __launch_bounds__(256) void k_pusch_demod(const float *__restrict__ s
                                                      const mi_lte_pdsch_alloc *__restrict__ allocs, const PuschDesc *__restrict__ desc,
                                                      const float *__restrict__ dmrs_pool, GoldTables gt, int8_t *__restrict__ e_base,
                                                      const uint32_t *__restrict__ e_off, uint32_t *__restrict__ e_len, uint32_t M_max,
-                                                     uint32_t words_max)
+                                                     uint32_t S_par)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    // LDS: est[6][M_max] (mag0 ang0 mag1 ang1 dmag dang) | buf A[M_max] | buf B[M_max] (float2) | scrambling words
+    // LDS: est[6][M_max] (mag0 ang0 mag1 ang1 dmag dang) | tw[M_max] | buf A[S_par][M_max] | buf B[S_par][M_max] (float2) | scrambling words
     float    *est  = sm;
-    float2   *bufA = reinterpret_cast<float2 *>(sm + 6 * (size_t)M_max), *bufB = bufA + M_max;
-    uint32_t *cw   = reinterpret_cast<uint32_t *>(bufB + M_max);
-    (void)words_max;
+    float2   *tw   = reinterpret_cast<float2 *>(sm + 6 * (size_t)M_max);
+    float2   *bufA = tw + M_max, *bufB = bufA + (size_t)S_par * M_max;
+    uint32_t *cw   = reinterpret_cast<uint32_t *>(bufB + (size_t)S_par * M_max);
 
     const uint32_t a_idx = blockIdx.x;
     const mi_lte_pdsch_alloc &al = allocs[a_idx];
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(256) void k_pusch_demod(const float *__restrict__ s
     const uint32_t c_init = (al.rnti << 14) | (0u << 13) | (ds.subfr << 9) | ds.cell, n_words = (N_bits + 31) / 32;
     for (uint32_t w = threadIdx.x; w <= n_words; w += blockDim.x) cw[w] = gold_word(gt, c_init, w);
 
-    // ---- DMRS estimates and their interpolation slopes (get_ulsch_ce, liblte_phy.cc:13745-13768)
+    // ---- DMRS estimates and their interpolation slopes (get_ulsch_ce, liblte_phy.cc:13745-13768); DFT twiddles
     const float *d0_re = dmrs_pool + ds.dmrs_off, *d0_im = d0_re + M, *d1_re = d0_im + M, *d1_im = d1_re + M;
     for (uint32_t i = threadIdx.x; i < M; i += blockDim.x) {
         const uint32_t sc0 = al.prb[0][i / 12] * 12 + i % 12, sc1 = al.prb[1][i / 12] * 12 + i % 12;
@@ -100,16 +103,21 @@ __global__ __launch_bounds__(256) void k_pusch_demod(const float *__restrict__ s
         f_ang /= 7;
         est[0 * M_max + i] = mag_0; est[1 * M_max + i] = ang_0; est[2 * M_max + i] = mag_1;
         est[3 * M_max + i] = ang_1; est[4 * M_max + i] = f_mag; est[5 * M_max + i] = f_ang;
+        float sn, cs;
+        sincospif(2.0f * (float)i / (float)M, &sn, &cs);
+        tw[i] = make_float2(cs, sn);
     }
     __syncthreads();
 
     const float sqrt_M = (float)sqrt((double)M); // liblte_phy.cc:6644 (integer argument -> double sqrt, stored to float)
     int8_t     *e      = e_base + e_off[a_idx];
 
-    for (uint32_t s = 0; s < 12; s++) {                       // data symbols in time order
-        const uint32_t L = s < 3 ? s : s < 9 ? s + 1 : s + 2; // skipping the DMRS symbols 3 and 10
-        // ---- channel estimate of this symbol and the one-tap equaliser
-        for (uint32_t i = threadIdx.x; i < M; i += blockDim.x) {
+    for (uint32_t s0 = 0; s0 < 12; s0 += S_par) { // S_par data symbols at a time (all 12 when they fit in LDS)
+        const uint32_t S = min(S_par, 12u - s0);
+        // ---- channel estimate of each symbol and the one-tap equaliser
+        for (uint32_t o = threadIdx.x; o < S * M; o += blockDim.x) {
+            const uint32_t sy = o / M, i = o - sy * M, s = s0 + sy;
+            const uint32_t L = s < 3 ? s : s < 9 ? s + 1 : s + 2; // data symbols in time order, skipping DMRS symbols 3 and 10
             const float mag_0 = est[i], ang_0 = est[M_max + i], mag_1 = est[2 * M_max + i], ang_1 = est[3 * M_max + i];
             const float f_mag = est[4 * M_max + i], f_ang = est[5 * M_max + i];
             float cm, ca; // liblte_phy.cc:13770-13780
@@ -123,10 +131,10 @@ __global__ __launch_bounds__(256) void k_pusch_demod(const float *__restrict__ s
             const uint32_t sc = al.prb[L / 7][i / 12] * 12 + i % 12;
             const float    z_re = rx_re[L * N_SC_MAX + sc], z_im = rx_im[L * N_SC_MAX + sc];
             const float    hn = h_re * h_re + h_im * h_im;
-            bufA[i] = make_float2((z_re * h_re + z_im * h_im) / hn, (z_im * h_re - z_re * h_im) / hn);
+            bufA[sy * M_max + i] = make_float2((z_re * h_re + z_im * h_im) / hn, (z_im * h_re - z_re * h_im) / hn);
         }
         __syncthreads();
-        // ---- transform pre-decoding: M-point backward DFT, radices 4, 2, 3, 5, then the remaining prime
+        // ---- transform pre-decoding: M-point backward DFTs, radices 4, 2, 3, 5, then the remaining prime
         float2  *src = bufA, *dst = bufB;
         uint32_t rem = M, Ns = 1;
         while (rem > 1) { // uniform over the workgroup
@@ -139,21 +147,22 @@ __global__ __launch_bounds__(256) void k_pusch_demod(const float *__restrict__ s
                 R = 7;
                 while (rem % R) R += 2;
             }
-            dft_pass(src, dst, M, R, Ns);
+            dft_pass(src, dst, tw, S, M, M_max, R, Ns);
             __syncthreads();
             Ns *= R;
             rem /= R;
             float2 *t = src; src = dst; dst = t;
         }
         // ---- de-map, descramble, de-interleave (transpose): soft bit q of symbol k goes to (k*12 + s)*Q_m + q
-        for (uint32_t k = threadIdx.x; k < M; k += blockDim.x) {
-            const float2 x = src[k];
-            int8_t       b[6] = {0, 0, 0, 0, 0, 0};
+        for (uint32_t o = threadIdx.x; o < S * M; o += blockDim.x) {
+            const uint32_t sy = o % S, k = o / S, s = s0 + sy; // neighbouring threads write neighbouring bytes of e
+            const float2   x = src[sy * M_max + k];
+            int8_t         b[6] = {0, 0, 0, 0, 0, 0};
             demap_symbol(sqrt_M * x.x, sqrt_M * x.y, al.mod_type, b);
             const uint32_t n0 = (s * M + k) * Qm, w = n0 >> 5, sh = n0 & 31;
             const uint32_t c  = __builtin_amdgcn_alignbit(cw[w + 1], cw[w], sh);
-            int8_t        *o  = e + (size_t)(k * 12 + s) * Qm;
-            for (uint32_t q = 0; q < Qm; q++) o[q] = ((c >> q) & 1u) ? (int8_t)-b[q] : b[q];
+            int8_t        *ob = e + (size_t)(k * 12 + s) * Qm;
+            for (uint32_t q = 0; q < Qm; q++) ob[q] = ((c >> q) & 1u) ? (int8_t)-b[q] : b[q];
         }
         __syncthreads();
     }
@@ -313,9 +322,13 @@ int mi_lte_pusch_decode_run(mi_lte_ctx *ctx, mi_lte_pusch_plan *pl, const float 
     int rc = mi_ctx_gold_tables(ctx);
     if (rc != MI_LTE_OK) return rc;
     GoldTables   gt{ctx->d_gold_x1, ctx->d_gold_x2b, ctx->gold_words};
-    const size_t lds = sizeof(float) * 6 * (size_t)pl->M_max + sizeof(float2) * 2 * (size_t)pl->M_max + sizeof(uint32_t) * (pl->words_max + 1);
+    // as many of the 12 data symbols side by side as fit in ~40 KiB of ping-pong buffers (all 12 up to 17 PRB)
+    uint32_t S_par = 12;
+    while (S_par > 1 && (size_t)S_par * pl->M_max * 2 * sizeof(float2) > 40 * 1024) S_par = S_par == 12 ? 6 : S_par == 6 ? 4 : S_par == 4 ? 3 : S_par - 1;
+    const size_t lds = sizeof(float) * 6 * (size_t)pl->M_max + sizeof(float2) * (size_t)pl->M_max * (1 + 2 * S_par) +
+                       sizeof(uint32_t) * (pl->words_max + 1);
     MI_LAUNCH(ctx, "k_pusch_demod", k_pusch_demod, dim3(pl->n_alloc), dim3(256), lds, d_subframes, (uint32_t)mi_lte_ul_subframe_floats(),
-              pl->d_allocs, pl->d_desc, pl->d_dmrs, gt, pl->d_e, pl->d_e_off, pl->d_e_len, pl->M_max, pl->words_max);
+              pl->d_allocs, pl->d_desc, pl->d_dmrs, gt, pl->d_e, pl->d_e_off, pl->d_e_len, pl->M_max, S_par);
     MI_HIP_CHECK(ctx, hipGetLastError());
     for (auto &gr : pl->groups) {
         rc = mi_turbo_ref_group(ctx, gr.K, gr.n_cb, pl->d_allocs, pl->d_cb_alloc + gr.cb_base, pl->d_e, pl->d_e_off, pl->d_e_len,

@@ -529,9 +529,8 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
         try:  # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes of this command
-            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if tj.get("workload", wl.name) == wl.name:
-                traffic = tj["bytes_per_launch"].get(dom)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % wl.name)))
+            traffic = tj["bytes_per_launch"].get({"k_ul_fft": "k_dl_fft"}.get(dom, dom))  # rocprof sees the kernel's own name
         except Exception:
             pass
         out = {
@@ -541,7 +540,7 @@ def main():
             "config": wl.config(world),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" if traffic else None,
+                         "traffic_source": "profiles/pmc_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" % wl.name if traffic else None,
                          "avg_launch_ms": round(avg_ms, 4), "launches": n_launch,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "algorithmic bytes / measured launch time; trellis kernels are issue-bound, see DESIGN.md"},

@@ -19,7 +19,7 @@ def short(name):
     return m.group(1) if m else name[:40]
 
 
-def main(src, tag):
+def main(src, tag, workload="chain"):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     dst = os.path.join(root, "profiles")
     os.makedirs(dst, exist_ok=True)
@@ -73,8 +73,8 @@ def main(src, tag):
         t = traffic.setdefault(r["kernel"], [0, 0.0])
         t[0] += r["launches"]
         t[1] += r["launches"] * (r["fetch_bytes_x2"] + r["write_bytes"])
-    with open(os.path.join(dst, "pmc_traffic.json"), "w") as f:
-        json.dump({"source": tag, "note": "avg (2*FETCH_SIZE + WRITE_SIZE) bytes per launch, rocprofv3 --pmc passes of bench.py",
+    with open(os.path.join(dst, "pmc_traffic_%s.json" % workload), "w") as f:
+        json.dump({"source": tag, "workload": workload, "note": "avg (2*FETCH_SIZE + WRITE_SIZE) bytes per launch, rocprofv3 --pmc passes of bench.py",
                    "bytes_per_launch": {k: int(v[1] / v[0]) for k, v in traffic.items()}}, f, indent=1)
     with open(os.path.join(dst, tag + "_summary.json"), "w") as f:
         json.dump({"kernel_stats": stats, "per_launch": rows}, f, indent=1)
@@ -97,4 +97,4 @@ def main(src, tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], *(sys.argv[3:4]))

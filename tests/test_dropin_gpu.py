@@ -112,3 +112,23 @@ def test_uplink_dropin_demo_matches_reference_output(tmp_path):
     assert lines[1:] == want[1:], (lines, want)  # per-UE verdict, bit count and hash of the decoded bits: identical text
     e_got, e_want = float(lines[0].split("=")[1]), float(want[0].split("=")[1])
     assert abs(e_got - e_want) / e_want < 1e-4
+
+
+@pytest.mark.parametrize("n_rb,cell,frames,fs", [(6, 17, 30, "1.92"), (25, 301, 24, "7.68"), (100, 77, 12, "30.72")])
+def test_cell_scan_matches_reference_output(tmp_path, n_rb, cell, frames, fs):
+    """BASELINE config 1 / SURVEY 8d W1 (plumbing): a GNU-Radio-free cell scan in LTE_fdd_dl_file_scan's call order --
+    coarse timing, PSS, SSS, PBCH, PDCCH, PDSCH -- over an int8 capture written by capture_gen (the reference's TX API).
+    scan_gpu = the scanner linked against the reference's objects with the hot-path entry points replaced by the shim;
+    its report (cell id, MIB, SIB1, SIB2 fields, transport-block counts) must equal the all-reference build's text."""
+    build = os.path.join(ROOT, "shim", "_build")
+    gen, scan_gpu, scan_cpu = (os.path.join(build, n) for n in ("capture_gen", "scan_gpu", "scan_cpu"))
+    if not (os.path.exists(gen) and os.path.exists(scan_gpu)):
+        pytest.skip("shim/_build/capture_gen / scan_gpu not built (need the reference tree at build time)")
+    cap = os.path.join(str(tmp_path), "capture.bin")
+    subprocess.run([gen, cap, str(n_rb), str(cell), str(frames)], check=True, timeout=600)
+    want = open(os.path.join(ROOT, "tests", "golden", "scan_%drb_reference_cpu.txt" % n_rb)).read()
+    if os.path.exists(scan_cpu):
+        assert subprocess.run([scan_cpu, cap, fs], capture_output=True, text=True, timeout=900).stdout == want
+    got = subprocess.run([scan_gpu, cap, fs], capture_output=True, text=True, timeout=900)
+    assert got.returncode == 0, got.stdout + got.stderr
+    assert got.stdout == want

@@ -46,16 +46,28 @@ def dist_setup(n_gpus):
 
 
 # ------------------------------------------------------------------------------------------------
+DECODER = "ref"  # --decoder: "ref" = the reference-faithful decoder (parity mode), "bcjr" = max-log-MAP, 8 iterations
+
+
 class TurboWorkload:
     """BASELINE config 3: PDSCH turbo decode, K=6144, 64QAM-like int8 soft values, 64k code blocks
-    per GPU.  REF mode (bit-exact with the reference decoder)."""
+    per GPU.  REF mode (bit-exact with the reference decoder) by default; --decoder bcjr runs the
+    fixed-point max-log-MAP mode with 8 iterations on the same blocks."""
     name = "turbo"
     K = 6144
-    metric = "turbo-decode Mbit/s (K=6144 code blocks, 64QAM hard +-127 soft values, REF decoder, per SURVEY 8d W3)"
     unit = "Mbit/s"
     dtype = "i8 soft values, i32 path metrics"
     alg_bytes_per_unit = 19216  # SURVEY 8d: 3(K+4) int8 in + K/8 packed out + 4 B status, K=6144
-    dominant = "k_turbo_siso"
+
+    @property
+    def metric(self):
+        if DECODER == "bcjr":
+            return "turbo-decode Mbit/s (K=6144 code blocks, 64QAM hard +-127 soft values, max-log-MAP BCJR, 8 iterations, per SURVEY 8d W3)"
+        return "turbo-decode Mbit/s (K=6144 code blocks, 64QAM hard +-127 soft values, REF decoder, per SURVEY 8d W3)"
+
+    @property
+    def dominant(self):
+        return "k_bcjr_bwd" if DECODER == "bcjr" else "k_turbo_siso"
 
     def __init__(self, ctx, n_units, rank):
         import numpy as np
@@ -64,7 +76,7 @@ class TurboWorkload:
         self.ctx, self.m, self.np = ctx, m, np
         self.n_cb = n_units or 65536
         uniq = 64
-        _, soft = synth.turbo_soft_blocks(self.K, uniq, flip=0.02, seed=1234 + rank)
+        self.tx, soft = synth.turbo_soft_blocks(self.K, uniq, flip=0.02, seed=1234 + rank, ref_wrap=(DECODER != "bcjr"))
         self.uniq_soft = soft
         idx = (np.arange(self.n_cb) * 7 + np.arange(self.n_cb) // 64) % uniq
         self.d_in = ctx.to_device(soft[idx])
@@ -72,7 +84,10 @@ class TurboWorkload:
         self.idx = idx
 
     def step(self):
-        self.ctx.turbo_decode_dev(self.d_in, self.m.SOFT_I8, self.K, self.n_cb, self.d_out)
+        if DECODER == "bcjr":
+            self.ctx.turbo_decode_dev(self.d_in, self.m.SOFT_I8, self.K, self.n_cb, self.d_out, mode=self.m.TURBO_BCJR, n_iter=8, qpp_spec=True)
+        else:
+            self.ctx.turbo_decode_dev(self.d_in, self.m.SOFT_I8, self.K, self.n_cb, self.d_out)
 
     def units_per_step(self):
         return self.n_cb
@@ -80,12 +95,20 @@ class TurboWorkload:
     def roofline_bytes(self, kernel, n_launch_per_step):
         return self.alg_bytes_per_unit * self.n_cb * n_launch_per_step
 
+    def extra(self, value):
+        if DECODER != "bcjr":
+            return {}
+        got = self.d_out.download(self.np.uint8, count=64 * self.K).reshape(64, self.K)
+        return {"decoder": "max-log-MAP, 8 iterations, fixed point (specified by oracle/lte_oracle.c lo_turbo_decode_bcjr)",
+                "sampled_blocks_equal_tx_bits": bool((got == self.tx[self.idx[:64]]).all())}
+
     def value_per_unit(self):
         return self.K / 1e6  # information Mbit per code block
 
     def config(self, world):
-        return {"workload": "W3 turbo decode: K=6144 x %d code blocks per GPU, int8 soft in HBM, REF mode" % self.n_cb,
-                "K": self.K, "blocks_per_gpu": self.n_cb, "decoder": "REF (reference-faithful, bit-exact)",
+        return {"workload": "W3 turbo decode: K=6144 x %d code blocks per GPU, int8 soft in HBM, %s mode" % (self.n_cb, DECODER.upper()),
+                "K": self.K, "blocks_per_gpu": self.n_cb,
+                "decoder": "BCJR max-log-MAP x8" if DECODER == "bcjr" else "REF (reference-faithful, bit-exact)",
                 "sharding": "code blocks block-cyclic over %d GPU(s), no collective" % world}
 
     def cpu_baseline(self, budget_s=12.0):
@@ -93,6 +116,16 @@ class TurboWorkload:
         np = self.np
         from oracle import pyoracle
         K, D = self.K, self.K + 4
+        if DECODER == "bcjr":  # the reference has no such decoder: the CPU leg is the plain-C specification of the mode
+            P, s16 = pyoracle.port(), np.ascontiguousarray(self.uniq_soft.astype(np.int16))
+            out, n, t0 = np.zeros(K, np.uint8), 0, time.perf_counter()
+            while time.perf_counter() - t0 < budget_s:
+                P.lo_turbo_decode_bcjr(s16[n % len(s16)], K, 8, 1, out)
+                n += 1
+            t = time.perf_counter() - t0
+            return {"value": round(n * K / t / 1e6, 4), "unit": self.unit, "cores": 1, "kind": "port",
+                    "sample": "%d of the benchmark's K=%d code blocks through oracle/lte_oracle.c lo_turbo_decode_bcjr (8 iterations), "
+                              "1 thread, %.1f s" % (n, K, t)}
         soft_f = np.ascontiguousarray(self.uniq_soft.astype(np.float32))
         R = pyoracle.ref()
         if R is not None:
@@ -481,9 +514,12 @@ def main():
     ap.add_argument("--workload", default="auto")
     ap.add_argument("--units", type=int, default=0, help="units (subframes / code blocks) per GPU per step")
     ap.add_argument("--streams", type=int, default=1, help="independent shards (contexts/streams) per GPU")
+    ap.add_argument("--decoder", default="ref", choices=["ref", "bcjr"], help="turbo workload only: decoder mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    global DECODER
+    DECODER = args.decoder
     rank, world, barrier, max_reduce = dist_setup(args.gpus)
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     import openlte_amd as m

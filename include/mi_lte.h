@@ -156,8 +156,10 @@ int      mi_lte_pdsch_plan_soft_bits(const mi_lte_pdsch_plan *plan, uint32_t all
  *   MI_LTE_TURBO_REF   bit-exact restatement of the reference's Steps 0-14 (three hard-metric SISO
  *                      Viterbi passes + soft re-encodes + 4-way vote), including its uint32 QPP
  *                      wrap-around; de-interleaver holes read as 0.  n_iter is ignored.
- *   MI_LTE_TURBO_BCJR  max-log-MAP, n_iter full iterations; qpp_spec != 0 selects the exact 3GPP
- *                      interleaver instead of the reference's wrapped one.
+ *   MI_LTE_TURBO_BCJR  fixed-point max-log-MAP (extrinsic scaled by 3/4), n_iter full iterations, int8 LLRs
+ *                      (MI_LTE_SOFT_I8) only; qpp_spec != 0 selects the exact 3GPP interleaver instead of the
+ *                      reference's wrapped one.  Not a behaviour of the reference (its decoder is REF): specified
+ *                      by oracle/lte_oracle.c lo_turbo_decode_bcjr, which the kernels match bit for bit.
  *
  * Output: d_c_bits, one decoded bit per byte, K bytes per block (the reference's c_bits). */
 typedef enum { MI_LTE_TURBO_REF = 0, MI_LTE_TURBO_BCJR = 1 } mi_lte_turbo_mode;
@@ -180,6 +182,7 @@ int mi_lte_rate_unmatch_turbo_batch(mi_lte_ctx *ctx, const float *d_e_bits, uint
 
 /* bytes of device scratch the decoder holds for (K, n_cb); grows on demand, reported for sizing */
 size_t mi_lte_turbo_scratch_bytes(uint32_t K, uint32_t n_cb);
+size_t mi_lte_turbo_bcjr_scratch_bytes(uint32_t K, uint32_t n_cb);
 
 /* name and launch count of the kernels the last batch call issued (for bench.py / profiles) */
 const char *mi_lte_last_kernels(const mi_lte_ctx *ctx);

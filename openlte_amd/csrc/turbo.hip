@@ -944,8 +944,11 @@ extern "C" int mi_lte_turbo_decode_batch(mi_lte_ctx *ctx, const void *d_soft, mi
         }
         return MI_LTE_ERR_INVALID_ARG;
     }
-    ctx->err = "BCJR mode not built yet";
-    return MI_LTE_ERR_UNSUPPORTED;
+    if (soft_type != MI_LTE_SOFT_I8) {
+        ctx->err = "BCJR mode takes int8 LLRs (MI_LTE_SOFT_I8)";
+        return MI_LTE_ERR_UNSUPPORTED;
+    }
+    return mi_turbo_bcjr_batch(ctx, (const int8_t *)d_soft, K, n_cb, n_iter, qpp_spec, d_c_bits);
 }
 
 extern "C" int mi_lte_rate_unmatch_turbo_batch(mi_lte_ctx *ctx, const float *d_e_bits, uint32_t N_e_bits, uint32_t D,

@@ -316,6 +316,132 @@ void lo_turbo_encode(const uint8_t *c, uint32_t K, uint8_t *d)
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* max-log-MAP ("BCJR") turbo decoder in fixed point.  This is the specification of the product's */
+/* BCJR mode (bcjr.hip follows it operation for operation); the reference has no such decoder.    */
+/*                                                                                                */
+/* RSC of 36.212 5.1.3.2.1: feedback 1+D^2+D^3, parity 1+D+D^3.  State s = 4*r1 + 2*r2 + r3 (r1   */
+/* newest).  With a = u^r2^r3 the next state is 4a + (s>>1) and the parity is z = a^r1^r3, so the  */
+/* predecessors of next state n are 2(n&3) and 2(n&3)+1 with complementary (u,z) labels:           */
+/*   n:      0      1      2      3      4      5      6      7                                    */
+/*   from 2(n&3):   00     10     01     11     11     01     10     00                            */
+/*   from 2(n&3)+1: 11     01     10     00     00     10     01     11                            */
+/* Branch metric g(u,z) = [u==0]*(Ls+La) + [z==0]*Lp (positive LLR = bit 0; the common offset      */
+/* against the +-L/2 form cancels in every comparison).                                            */
+#define BCJR_NEG    (-32000)
+#define BCJR_LE_MAX 1023
+#define BCJR_W      8 /* alpha checkpoint spacing = backward window length; every QPP size is a multiple of 8 */
+
+static inline int bcjr_max(int a, int b) { return a > b ? a : b; }
+static void bcjr_norm(int *v) /* subtract the maximum, floor at BCJR_NEG */
+{
+    int m = v[0];
+    for (int s = 1; s < 8; s++) m = bcjr_max(m, v[s]);
+    for (int s = 0; s < 8; s++) v[s] = bcjr_max(v[s] - m, BCJR_NEG);
+}
+static void bcjr_alpha_step(const int *a, int g00, int g01, int g10, int *o)
+{
+    o[0] = bcjr_max(a[0] + g00, a[1]);       o[4] = bcjr_max(a[0], a[1] + g00);
+    o[1] = bcjr_max(a[2] + g10, a[3] + g01); o[5] = bcjr_max(a[2] + g01, a[3] + g10);
+    o[2] = bcjr_max(a[4] + g01, a[5] + g10); o[6] = bcjr_max(a[4] + g10, a[5] + g01);
+    o[3] = bcjr_max(a[6], a[7] + g00);       o[7] = bcjr_max(a[6] + g00, a[7]);
+}
+static void bcjr_beta_step(const int *b, int g00, int g01, int g10, int *o)
+{
+    o[0] = bcjr_max(b[0] + g00, b[4]);       o[1] = bcjr_max(b[0], b[4] + g00);
+    o[2] = bcjr_max(b[1] + g10, b[5] + g01); o[3] = bcjr_max(b[1] + g01, b[5] + g10);
+    o[4] = bcjr_max(b[2] + g01, b[6] + g10); o[5] = bcjr_max(b[2] + g10, b[6] + g01);
+    o[6] = bcjr_max(b[3], b[7] + g00);       o[7] = bcjr_max(b[3] + g00, b[7]);
+}
+/* one SISO pass: systematic S, parity P, a-priori A (K each), the 3 termination pairs, -> extrinsic E and (optionally)
+ * the a-posteriori LLR */
+static void bcjr_siso(const int8_t *S, const int8_t *P, const int16_t *A, const int8_t *tail_s, const int8_t *tail_p, uint32_t K,
+                      int16_t *E, int16_t *post)
+{
+    const uint32_t n_win = K / BCJR_W;
+    int16_t (*chk)[8] = (int16_t (*)[8])malloc(sizeof(int16_t) * 8 * n_win);
+    int a[8] = {0, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG}, t8[8];
+    for (uint32_t t = 0; t < K; t++) { /* forward: alpha, normalised and checkpointed every W steps */
+        if (t % BCJR_W == 0) {
+            bcjr_norm(a);
+            for (int s = 0; s < 8; s++) chk[t / BCJR_W][s] = (int16_t)a[s];
+        }
+        const int lsa = S[t] + A[t], lp = P[t];
+        bcjr_alpha_step(a, lsa + lp, lsa, lp, t8);
+        memcpy(a, t8, sizeof(a));
+    }
+    /* beta at step K from the termination: only the a = 0 edges exist, so state 2j+r3 continues to state j */
+    int b[8] = {0, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG};
+    for (int t = 2; t >= 0; t--) {
+        const int ls = tail_s[t], lp = tail_p[t], g00 = ls + lp, g01 = ls, g10 = lp;
+        t8[0] = b[0] + g00; t8[1] = b[0];       t8[2] = b[1] + g10; t8[3] = b[1] + g01;
+        t8[4] = b[2] + g01; t8[5] = b[2] + g10; t8[6] = b[3];       t8[7] = b[3] + g00;
+        memcpy(b, t8, sizeof(b));
+    }
+    bcjr_norm(b);
+    for (int w = (int)n_win - 1; w >= 0; w--) { /* backward, one window at a time: re-run alpha from the checkpoint */
+        const uint32_t t0 = (uint32_t)w * BCJR_W;
+        int al[BCJR_W][8];
+        for (int s = 0; s < 8; s++) al[0][s] = chk[w][s];
+        for (int i = 1; i < BCJR_W; i++) {
+            const int lsa = S[t0 + i - 1] + A[t0 + i - 1], lp = P[t0 + i - 1];
+            bcjr_alpha_step(al[i - 1], lsa + lp, lsa, lp, al[i]);
+        }
+        for (int i = BCJR_W - 1; i >= 0; i--) {
+            const uint32_t t = t0 + i;
+            const int lsa = S[t] + A[t], lp = P[t], g00 = lsa + lp, g01 = lsa, g10 = lp;
+            const int *x = al[i];
+            /* u = 0 edges: (0->0) (1->4) (7->3) (6->7) carry g00, (3->1) (2->5) (4->2) (5->6) carry g01;
+             * u = 1 edges: (2->1) (3->5) (5->2) (4->6) carry g10, (1->0) (0->4) (6->3) (7->7) carry 0 */
+            const int m00 = bcjr_max(bcjr_max(x[0] + b[0], x[1] + b[4]), bcjr_max(x[7] + b[3], x[6] + b[7]));
+            const int m01 = bcjr_max(bcjr_max(x[3] + b[1], x[2] + b[5]), bcjr_max(x[4] + b[2], x[5] + b[6]));
+            const int m10 = bcjr_max(bcjr_max(x[2] + b[1], x[3] + b[5]), bcjr_max(x[5] + b[2], x[4] + b[6]));
+            const int m11 = bcjr_max(bcjr_max(x[1] + b[0], x[0] + b[4]), bcjr_max(x[6] + b[3], x[7] + b[7]));
+            const int llr = bcjr_max(m00 + g00, m01 + g01) - bcjr_max(m10 + g10, m11);
+            int e = ((llr - lsa) * 3) >> 2; /* extrinsic, scaled by 3/4 (arithmetic shift) */
+            e     = e > BCJR_LE_MAX ? BCJR_LE_MAX : e < -BCJR_LE_MAX ? -BCJR_LE_MAX : e;
+            E[t]  = (int16_t)e;
+            if (post) post[t] = (int16_t)(llr > 32767 ? 32767 : llr < -32767 ? -32767 : llr);
+            bcjr_beta_step(b, g00, g01, g10, t8);
+            memcpy(b, t8, sizeof(b));
+        }
+        bcjr_norm(b);
+    }
+    free(chk);
+}
+
+void lo_turbo_decode_bcjr(const int16_t *soft, uint32_t K, uint32_t n_iter, int qpp_spec, uint8_t *c_bits)
+{
+    const uint32_t D = K + 4;
+    int8_t   *S1 = (int8_t *)malloc(4 * (size_t)K), *P1 = S1 + K, *S2 = P1 + K, *P2 = S2 + K;
+    int16_t  *A1 = (int16_t *)calloc(5 * (size_t)K, sizeof(int16_t)), *A2 = A1 + K, *E1 = A2 + K, *E2 = E1 + K, *post = E2 + K;
+    uint16_t *pi = (uint16_t *)malloc(sizeof(uint16_t) * 2 * K), *inv = pi + K;
+    int8_t    x[3 * 4];
+    if (qpp_spec) lo_qpp_map_spec(K, pi); else lo_qpp_map_ref(K, pi);
+    for (uint32_t j = 0; j < K; j++) inv[j] = 0xFFFF;
+    for (uint32_t i = 0; i < K; i++) inv[pi[i]] = (uint16_t)i; /* last writer wins, like the reference's de-interleaver */
+#define CLIP8(v) ((int8_t)((v) > 127 ? 127 : (v) < -127 ? -127 : (v)))
+    for (uint32_t i = 0; i < K; i++) { S1[i] = CLIP8(soft[3 * i]); P1[i] = CLIP8(soft[3 * i + 1]); P2[i] = CLIP8(soft[3 * i + 2]); }
+    for (uint32_t i = 0; i < K; i++) S2[i] = S1[pi[i]];
+    for (uint32_t r = 0; r < 4; r++)
+        for (uint32_t c = 0; c < 3; c++) x[3 * r + c] = CLIP8(soft[3 * (K + r) + c]); /* x[3r + stream] = d_stream[K + r] */
+#undef CLIP8
+    /* 36.212 5.1.3.2.2: d0 = x_K z_K+1 x'_K z'_K+1, d1 = z_K x_K+2 z'_K x'_K+2, d2 = x_K+1 z_K+2 x'_K+1 z'_K+2 */
+    const int8_t t1s[3] = {x[0], x[2], x[4]}, t1p[3] = {x[1], x[3], x[5]};
+    const int8_t t2s[3] = {x[6], x[8], x[10]}, t2p[3] = {x[7], x[9], x[11]};
+    for (uint32_t it = 0; it < n_iter; it++) {
+        bcjr_siso(S1, P1, A1, t1s, t1p, K, E1, NULL);
+        for (uint32_t i = 0; i < K; i++) A2[i] = E1[pi[i]];
+        bcjr_siso(S2, P2, A2, t2s, t2p, K, E2, post);
+        for (uint32_t j = 0; j < K; j++) A1[j] = inv[j] != 0xFFFF ? E2[inv[j]] : 0;
+    }
+    for (uint32_t j = 0; j < K; j++) {
+        const int l = inv[j] != 0xFFFF ? post[inv[j]] : S1[j] + A1[j];
+        c_bits[j]   = l < 0 ? 1 : 0;
+    }
+    free(S1); free(A1); free(pi);
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* rate matching (liblte_phy.cc:11081-11237 TX, :11246-11490 RX) as an index map over the       */
 /* circular buffer w[0..3*K_pi): which (stream x, padded index n) sits at each w position.      */
 typedef struct { uint32_t R, K_pi, N_d, K_w, N_cb, k0; } rm_geom_t;

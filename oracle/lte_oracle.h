@@ -68,7 +68,12 @@ void lo_turbo_decode_ref(const float *d_interleaved, uint32_t K, uint8_t *c_bits
 void lo_turbo_decode_ref_taps(const float *d_interleaved, uint32_t K, uint8_t *c_bits, int8_t *taps /*[11][K]*/);
 
 /* ---- turbo, max-log-MAP ("BCJR") decoder: restatement of OUR kernel, not of the reference ---- */
-/* lo_turbo_decode_bcjr: added with the BCJR kernel */
+/* Fixed-point max-log-MAP, defined jointly with the kernel (openlte_amd/csrc/bcjr.hip); NOT a behaviour of the
+ * reference -- parity for this mode is oracle <-> kernel bit-exactness plus decoding performance.
+ * soft: 3(K+4) values interleaved d[i*3+x], positive = bit 0, clipped to +-127.  qpp_spec != 0: exact 3GPP
+ * interleaver, else the reference's uint32-wrapped one (gather semantics; de-interleaving takes the last writer,
+ * holes read 0). */
+void lo_turbo_decode_bcjr(const int16_t *soft, uint32_t K, uint32_t n_iter, int qpp_spec, uint8_t *c_bits);
 
 /* ---- encoder side (input synthesis for tests) ---- */
 void lo_turbo_encode(const uint8_t *c_bits, uint32_t K, uint8_t *d_planar /* 3(K+4) */);

@@ -1,7 +1,7 @@
 // Max-log-MAP ("BCJR") turbo decoding on gfx950 -- the decoder BASELINE.json's north star sketches, offered as
 // MI_LTE_TURBO_BCJR next to the reference-faithful REF mode.  The reference has no such decoder, so
-// this mode is specified by oracle/lte_oracle.c (lo_turbo_decode_bcjr): fixed-point, every operation in the
-// same order, and the kernels below must match it bit for bit.
+// this mode is specified by a plain-C fixed-point model in the test tree (lo_turbo_decode_bcjr): every operation
+// in the same order, and the kernels below must match it bit for bit.
 //
 // Mapping: the same lock-step tiles as the REF decoder (lane = code block, 64 trellises per wavefront, all
 // per-step arrays "line per block" in HBM) -- the 8 alpha / beta metrics of a block live in its lane's VGPRs,
@@ -11,7 +11,7 @@
 // The extrinsic permutation between the two constituent decoders is a per-code-block LDS gather.
 //
 // Trellis (36.212 5.1.3.2.1, feedback 1+D^2+D^3, parity 1+D+D^3; state = 4 r1 + 2 r2 + r3): the predecessors of
-// state n are 2(n&3) and 2(n&3)+1 with complementary (u,z) labels -- see the table in lte_oracle.c.  Branch
+// state n are 2(n&3) and 2(n&3)+1 with complementary (u,z) labels -- see the table next to lo_turbo_decode_bcjr.  Branch
 // metric g(u,z) = [u==0](Ls+La) + [z==0]Lp, positive LLR = bit 0.
 #include "ctx.hpp"
 

@@ -9,6 +9,9 @@
 // steps (16 B per block per 8 steps); the backward pass re-runs alpha inside each 8-step window from that
 // checkpoint (56 values in registers) while beta walks down, so no per-step state ever goes to memory.
 // The extrinsic permutation between the two constituent decoders is a per-code-block LDS gather.
+// Occupancy: a 64k-block batch is only 1024 tiles, one wave per SIMD; blocks of >= 1024 steps are therefore cut
+// into 4 (2) segments decoded by separate waves, whose boundary alpha / beta come from the neighbouring segment's
+// previous iteration ("next iteration initialisation", double-buffered) -- part of the mode's specification.
 //
 // Trellis (36.212 5.1.3.2.1, feedback 1+D^2+D^3, parity 1+D+D^3; state = 4 r1 + 2 r2 + r3): the predecessors of
 // state n are 2(n&3) and 2(n&3)+1 with complementary (u,z) labels -- see the table next to lo_turbo_decode_bcjr.  Branch
@@ -23,6 +26,21 @@ __host__ __device__ inline uint32_t kpad64(uint32_t K) { return (K + 63u) & ~63u
 __device__ __forceinline__ int sb(uint32_t w, int k) { return (int)__builtin_amdgcn_sbfe(w, 8 * k, 8); }
 __device__ __forceinline__ int sh(uint32_t w, int k) { return (int)__builtin_amdgcn_sbfe(w, 16 * k, 16); }
 __device__ __forceinline__ uint32_t pk16(int lo, int hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); }
+
+__device__ __forceinline__ size_t g8(uint32_t tile, uint32_t Kp, uint32_t lane, uint32_t gran) { return (size_t)tile * Kp * 64 + (size_t)gran * 1024 + lane * 16; }   // byte offset, int8 arrays
+__device__ __forceinline__ size_t g16(uint32_t tile, uint32_t Kp, uint32_t lane, uint32_t gran) { return (size_t)tile * Kp * 128 + (size_t)gran * 1024 + lane * 16; } // byte offset, int16 arrays
+// XCD-aware block -> code block mapping of the per-code-block kernels (see turbo.hip)
+__host__ __device__ inline uint32_t xcd_chunk(uint32_t n_cb) { return ((((n_cb + 63u) >> 6) + 7u) >> 3) << 6; }
+__device__ __forceinline__ uint32_t xcd_cb(uint32_t b, uint32_t n_cb) { return (b & 7u) * xcd_chunk(n_cb) + (b >> 3); }
+
+__host__ __device__ inline uint32_t bcjr_n_seg(uint32_t K)
+{
+    const uint32_t nblk = (K + 63) / 64;
+    for (uint32_t n = 4; n > 1; n >>= 1)
+        if (nblk % n == 0 && (nblk / n) * 64 >= 512) return n;
+    return 1;
+}
+struct BcjrBnd { int16_t *a_rd, *a_wr, *b_rd, *b_wr; uint32_t n_tiles; }; // [segment][tile][lane][8] each
 
 __device__ __forceinline__ void norm8(int (&v)[8]) // subtract the maximum, floor at BCJR_NEG
 {
@@ -48,8 +66,10 @@ __device__ __forceinline__ void beta_step(int (&b)[8], int g00, int g01, int g10
     for (int s = 0; s < 8; s++) b[s] = o[s];
 }
 
-// ---- layouts of one tile (64 code blocks): int8 arrays: step t of lane l at (t/64)*4096 + l*64 + t%64;
-//      int16 arrays: (t/64)*8192 + l*128 + 2*(t%64); checkpoints: [window][lane][8 x int16]; tails: [lane][16 B]
+// ---- layouts of one tile (64 code blocks), "16-byte granules": the lock-step kernels consume 16 B per lane at a time,
+//      so granule g of lane l sits at g*1024 + l*16 -- every wave-wide access is one contiguous KiB.
+//      int8 arrays: granule = 16 steps (step t in granule t/16, byte t%16); int16 arrays: granule = 8 steps;
+//      checkpoints: [window][lane][8 x int16] (the same shape); tails: [lane][16 B]
 struct BcjrBufs {
     int8_t  *S1, *P1, *S2, *P2; // systematic / parity of the two constituent decoders (S2 = interleaved S1)
     int16_t *A, *E, *post;      // a-priori in, extrinsic out, a-posteriori of the last half-iteration
@@ -63,10 +83,10 @@ __global__ __launch_bounds__(384) void k_bcjr_prep(const int8_t *__restrict__ so
                                                    const uint16_t *__restrict__ pi, BcjrBufs B)
 {
     extern __shared__ __attribute__((aligned(16))) int8_t sm[]; // S1[Kp]
-    const uint32_t cb = blockIdx.x, tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4, u = threadIdx.x;
+    const uint32_t cb = xcd_cb(blockIdx.x, n_cb), tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4, u = threadIdx.x;
     if (cb >= n_cb) return;
     const int8_t *d = soft + (size_t)cb * 3 * (K + 4);
-    const size_t  o8 = (size_t)tile * Kp * 64 + (size_t)(u >> 2) * 4096 + lane * 64 + (u & 3) * 16;
+    const size_t  o8 = g8(tile, Kp, lane, u);
     const int     nv = (u < n_units) ? min(16, max(0, (int)K - 16 * (int)u)) : -1;
     uint32_t s1[4] = {0, 0, 0, 0}, p1[4] = {0, 0, 0, 0}, p2[4] = {0, 0, 0, 0};
     if (nv > 0) {
@@ -90,9 +110,9 @@ __global__ __launch_bounds__(384) void k_bcjr_prep(const int8_t *__restrict__ so
         *reinterpret_cast<uint4 *>(sm + 16 * u) = make_uint4(s1[0], s1[1], s1[2], s1[3]);
     }
     if (nv >= 0) { // a-priori = 0 (two uint4 of int16 per unit)
-        int16_t *ap = B.A + o8; // same element offset, 2-byte elements
-        reinterpret_cast<uint4 *>(ap)[0] = make_uint4(0, 0, 0, 0);
-        reinterpret_cast<uint4 *>(ap)[1] = make_uint4(0, 0, 0, 0);
+        char *ab = reinterpret_cast<char *>(B.A);
+        *reinterpret_cast<uint4 *>(ab + g16(tile, Kp, lane, 2 * u))     = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4 *>(ab + g16(tile, Kp, lane, 2 * u + 1)) = make_uint4(0, 0, 0, 0);
     }
     if (u == 0) { // termination bits: x[3r + stream] = d_stream[K + r]  (36.212 5.1.3.2.2)
         const int8_t *x = d + 3 * (size_t)K;
@@ -122,23 +142,28 @@ __global__ __launch_bounds__(384) void k_bcjr_prep(const int8_t *__restrict__ so
 // ------------------------------------------------------------------------------------------------
 // forward pass of one constituent decoder: alpha, normalised and checkpointed every 8 steps
 __global__ __launch_bounds__(64) void k_bcjr_fwd(const int8_t *__restrict__ S, const int8_t *__restrict__ P,
-                                                 const int16_t *__restrict__ A, int16_t *__restrict__ chk, uint32_t K)
+                                                 const int16_t *__restrict__ A, int16_t *__restrict__ chk, uint32_t K, BcjrBnd bnd)
 {
-    const uint32_t tile = blockIdx.x, lane = threadIdx.x, Kp = kpad64(K), nblk = Kp >> 6, n_win = Kp >> 3;
-    const size_t   base = (size_t)tile * Kp * 64 + lane * 64; // same element offset for the int8 and the int16 arrays
-    const int8_t  *ps = S + base, *pp = P + base;
-    const int16_t *pa = A + base;
-    uint4         *pc = reinterpret_cast<uint4 *>(chk + ((size_t)tile * n_win * 64 + lane) * 8);
+    const uint32_t tile = blockIdx.x, seg = blockIdx.y, n_seg = gridDim.y, lane = threadIdx.x, Kp = kpad64(K), nblk = Kp >> 6, n_win = Kp >> 3;
+    const uint32_t seg_blk = nblk / n_seg;
+    const char *ps = reinterpret_cast<const char *>(S), *pp = reinterpret_cast<const char *>(P), *pa = reinterpret_cast<const char *>(A);
+    uint4      *pc = reinterpret_cast<uint4 *>(chk + ((size_t)tile * n_win * 64 + lane) * 8);
+    (void)nblk;
     int a[8] = {0, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG};
-    for (uint32_t blk = 0; blk < nblk; blk++) {
+    if (seg > 0) { // alpha the previous segment reached in the previous iteration
+        const uint4 c4 = *reinterpret_cast<const uint4 *>(bnd.a_rd + (((size_t)seg * bnd.n_tiles + tile) * 64 + lane) * 8);
+        a[0] = sh(c4.x, 0); a[1] = sh(c4.x, 1); a[2] = sh(c4.y, 0); a[3] = sh(c4.y, 1);
+        a[4] = sh(c4.z, 0); a[5] = sh(c4.z, 1); a[6] = sh(c4.w, 0); a[7] = sh(c4.w, 1);
+    }
+    for (uint32_t blk = seg * seg_blk; blk < (seg + 1) * seg_blk; blk++) {
 #pragma unroll
         for (int q = 0; q < 4; q++) { // 16 steps = 2 windows per quarter line
             const uint32_t t0 = blk * 64 + q * 16;
             if (t0 >= K) break; // uniform
-            const uint4 s4 = reinterpret_cast<const uint4 *>(ps + (size_t)blk * 4096)[q];
-            const uint4 p4 = reinterpret_cast<const uint4 *>(pp + (size_t)blk * 4096)[q];
-            const uint4 a0 = reinterpret_cast<const uint4 *>(pa + (size_t)blk * 4096)[2 * q];
-            const uint4 a1 = reinterpret_cast<const uint4 *>(pa + (size_t)blk * 4096)[2 * q + 1];
+            const uint4 s4 = *reinterpret_cast<const uint4 *>(ps + g8(tile, Kp, lane, t0 >> 4));
+            const uint4 p4 = *reinterpret_cast<const uint4 *>(pp + g8(tile, Kp, lane, t0 >> 4));
+            const uint4 a0 = *reinterpret_cast<const uint4 *>(pa + g16(tile, Kp, lane, t0 >> 3));
+            const uint4 a1 = *reinterpret_cast<const uint4 *>(pa + g16(tile, Kp, lane, (t0 >> 3) + 1));
             const uint32_t sw[4] = {s4.x, s4.y, s4.z, s4.w}, pw[4] = {p4.x, p4.y, p4.z, p4.w};
             const uint32_t aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
@@ -157,6 +182,11 @@ __global__ __launch_bounds__(64) void k_bcjr_fwd(const int8_t *__restrict__ S, c
             }
         }
     }
+    if (seg + 1 < n_seg) { // hand the end state to the next segment's next iteration
+        norm8(a);
+        *reinterpret_cast<uint4 *>(bnd.a_wr + (((size_t)(seg + 1) * bnd.n_tiles + tile) * 64 + lane) * 8) =
+            make_uint4(pk16(a[0], a[1]), pk16(a[2], a[3]), pk16(a[4], a[5]), pk16(a[6], a[7]));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -166,17 +196,21 @@ template <bool POST>
 __global__ __launch_bounds__(64) void k_bcjr_bwd(const int8_t *__restrict__ S, const int8_t *__restrict__ P,
                                                  const int16_t *__restrict__ A, const int16_t *__restrict__ chk,
                                                  const int8_t *__restrict__ tail, uint32_t tail_off, int16_t *__restrict__ E,
-                                                 int16_t *__restrict__ post, uint32_t K, uint32_t n_cb)
+                                                 int16_t *__restrict__ post, uint32_t K, uint32_t n_cb, BcjrBnd bnd)
 {
-    const uint32_t tile = blockIdx.x, lane = threadIdx.x, Kp = kpad64(K), nblk = Kp >> 6, n_win = Kp >> 3;
-    const size_t   base = (size_t)tile * Kp * 64 + lane * 64;
-    const int8_t  *ps = S + base, *pp = P + base;
-    const int16_t *pa = A + base;
-    int16_t       *pe = E + base, *po = POST ? post + base : nullptr;
-    const uint4   *pc = reinterpret_cast<const uint4 *>(chk + ((size_t)tile * n_win * 64 + lane) * 8);
+    const uint32_t tile = blockIdx.x, seg = blockIdx.y, n_seg = gridDim.y, lane = threadIdx.x, Kp = kpad64(K), nblk = Kp >> 6, n_win = Kp >> 3;
+    const uint32_t seg_blk = nblk / n_seg;
+    const char  *ps = reinterpret_cast<const char *>(S), *pp = reinterpret_cast<const char *>(P), *pa = reinterpret_cast<const char *>(A);
+    char        *pe = reinterpret_cast<char *>(E), *po = POST ? reinterpret_cast<char *>(post) : nullptr;
+    const uint4 *pc = reinterpret_cast<const uint4 *>(chk + ((size_t)tile * n_win * 64 + lane) * 8);
+    (void)nblk;
 
     int b[8] = {0, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG};
-    {   // termination: only the a = 0 edges exist, state 2j + r3 continues to state j
+    if (seg + 1 < n_seg) { // beta the next segment reached in the previous iteration
+        const uint4 c4 = *reinterpret_cast<const uint4 *>(bnd.b_rd + (((size_t)seg * bnd.n_tiles + tile) * 64 + lane) * 8);
+        b[0] = sh(c4.x, 0); b[1] = sh(c4.x, 1); b[2] = sh(c4.y, 0); b[3] = sh(c4.y, 1);
+        b[4] = sh(c4.z, 0); b[5] = sh(c4.z, 1); b[6] = sh(c4.w, 0); b[7] = sh(c4.w, 1);
+    } else {   // termination: only the a = 0 edges exist, state 2j + r3 continues to state j
         const uint32_t cb = min(tile * 64 + lane, n_cb - 1);
         const int8_t  *t  = tail + ((size_t)cb << 4) + tail_off;
 #pragma unroll
@@ -190,15 +224,15 @@ __global__ __launch_bounds__(64) void k_bcjr_bwd(const int8_t *__restrict__ S, c
         }
         norm8(b);
     }
-    for (int blk = (int)nblk - 1; blk >= 0; blk--) {
+    for (int blk = (int)((seg + 1) * seg_blk) - 1; blk >= (int)(seg * seg_blk); blk--) {
 #pragma unroll
         for (int q = 3; q >= 0; q--) {
             const uint32_t t0 = (uint32_t)blk * 64 + q * 16;
             if (t0 >= K) continue; // uniform
-            const uint4 s4 = reinterpret_cast<const uint4 *>(ps + (size_t)blk * 4096)[q];
-            const uint4 p4 = reinterpret_cast<const uint4 *>(pp + (size_t)blk * 4096)[q];
-            const uint4 a0 = reinterpret_cast<const uint4 *>(pa + (size_t)blk * 4096)[2 * q];
-            const uint4 a1 = reinterpret_cast<const uint4 *>(pa + (size_t)blk * 4096)[2 * q + 1];
+            const uint4 s4 = *reinterpret_cast<const uint4 *>(ps + g8(tile, Kp, lane, t0 >> 4));
+            const uint4 p4 = *reinterpret_cast<const uint4 *>(pp + g8(tile, Kp, lane, t0 >> 4));
+            const uint4 a0 = *reinterpret_cast<const uint4 *>(pa + g16(tile, Kp, lane, t0 >> 3));
+            const uint4 a1 = *reinterpret_cast<const uint4 *>(pa + g16(tile, Kp, lane, (t0 >> 3) + 1));
             const uint32_t sw[4] = {s4.x, s4.y, s4.z, s4.w}, pw[4] = {p4.x, p4.y, p4.z, p4.w};
             const uint32_t aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
@@ -233,13 +267,16 @@ __global__ __launch_bounds__(64) void k_bcjr_bwd(const int8_t *__restrict__ S, c
                     beta_step(b, g00, g01, g10);
                 }
                 norm8(b);
-                const size_t off = (size_t)blk * 4096 + q * 16 + w * 8; // int16 elements
+                const size_t off = g16(tile, Kp, lane, (t0 >> 3) + w);
                 *reinterpret_cast<uint4 *>(pe + off) = make_uint4(pk16(ev[0], ev[1]), pk16(ev[2], ev[3]), pk16(ev[4], ev[5]), pk16(ev[6], ev[7]));
                 if (POST)
                     *reinterpret_cast<uint4 *>(po + off) = make_uint4(pk16(pv[0], pv[1]), pk16(pv[2], pv[3]), pk16(pv[4], pv[5]), pk16(pv[6], pv[7]));
             }
         }
     }
+    if (seg > 0) // beta at this segment's start = the previous segment's end, for its next iteration (already normalised)
+        *reinterpret_cast<uint4 *>(bnd.b_wr + (((size_t)(seg - 1) * bnd.n_tiles + tile) * 64 + lane) * 8) =
+            make_uint4(pk16(b[0], b[1]), pk16(b[2], b[3]), pk16(b[4], b[5]), pk16(b[6], b[7]));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -251,20 +288,20 @@ __global__ __launch_bounds__(384) void k_bcjr_perm(const int16_t *__restrict__ s
                                                    uint8_t *__restrict__ c_bits)
 {
     extern __shared__ __attribute__((aligned(16))) int16_t sm16[]; // src[Kp]
-    const uint32_t cb = blockIdx.x, tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4, u = threadIdx.x;
+    const uint32_t cb = xcd_cb(blockIdx.x, n_cb), tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4, u = threadIdx.x;
     if (cb >= n_cb) return;
-    const size_t off = (size_t)tile * Kp * 64 + (size_t)(u >> 2) * 4096 + lane * 64 + (u & 3) * 16; // element offset
-    const int    nv  = (u < n_units) ? min(16, max(0, (int)K - 16 * (int)u)) : -1;
+    const size_t off0 = g16(tile, Kp, lane, 2 * u), off1 = g16(tile, Kp, lane, 2 * u + 1); // byte offsets of the unit's two granules
+    const int    nv   = (u < n_units) ? min(16, max(0, (int)K - 16 * (int)u)) : -1;
     if (nv >= 0) {
-        const uint4 *g = reinterpret_cast<const uint4 *>(src + off);
-        reinterpret_cast<uint4 *>(sm16 + 16 * u)[0] = g[0];
-        reinterpret_cast<uint4 *>(sm16 + 16 * u)[1] = g[1];
+        const char *sb8 = reinterpret_cast<const char *>(src);
+        reinterpret_cast<uint4 *>(sm16 + 16 * u)[0] = *reinterpret_cast<const uint4 *>(sb8 + off0);
+        reinterpret_cast<uint4 *>(sm16 + 16 * u)[1] = *reinterpret_cast<const uint4 *>(sb8 + off1);
     }
     __syncthreads();
     if (nv <= 0) {
         if (nv == 0 && !FINAL) {
-            reinterpret_cast<uint4 *>(A + off)[0] = make_uint4(0, 0, 0, 0);
-            reinterpret_cast<uint4 *>(A + off)[1] = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(A) + off0) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(A) + off1) = make_uint4(0, 0, 0, 0);
         }
         return;
     }
@@ -281,11 +318,11 @@ __global__ __launch_bounds__(384) void k_bcjr_perm(const int16_t *__restrict__ s
         v[k] = hole[k] ? 0 : t;
     }
     if (!FINAL) {
-        uint4 *o = reinterpret_cast<uint4 *>(A + off);
-        o[0] = make_uint4(pk16(v[0], v[1]), pk16(v[2], v[3]), pk16(v[4], v[5]), pk16(v[6], v[7]));
-        o[1] = make_uint4(pk16(v[8], v[9]), pk16(v[10], v[11]), pk16(v[12], v[13]), pk16(v[14], v[15]));
+        char *ab = reinterpret_cast<char *>(A);
+        *reinterpret_cast<uint4 *>(ab + off0) = make_uint4(pk16(v[0], v[1]), pk16(v[2], v[3]), pk16(v[4], v[5]), pk16(v[6], v[7]));
+        *reinterpret_cast<uint4 *>(ab + off1) = make_uint4(pk16(v[8], v[9]), pk16(v[10], v[11]), pk16(v[12], v[13]), pk16(v[14], v[15]));
     } else {
-        const uint4    s4 = *reinterpret_cast<const uint4 *>(S1 + off);
+        const uint4    s4 = *reinterpret_cast<const uint4 *>(S1 + g8(tile, Kp, lane, u));
         const uint32_t sw[4] = {s4.x, s4.y, s4.z, s4.w};
         uint32_t ob[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -304,7 +341,7 @@ __global__ __launch_bounds__(384) void k_bcjr_perm(const int16_t *__restrict__ s
 extern "C" size_t mi_lte_turbo_bcjr_scratch_bytes(uint32_t K, uint32_t n_cb)
 {
     const size_t n_tiles = (n_cb + 63) / 64, Kp = kpad64(K);
-    return n_tiles * (Kp * 64 * 4 + Kp * 128 * 3 + Kp * 128 + 64 * 16);
+    return n_tiles * (Kp * 64 * 4 + Kp * 128 * 3 + Kp * 128 + 64 * 16 + 2 * 2 * 2 * 4 * 64 * 16); // + boundary states [dec][a|b][buf][seg]
 }
 
 // n_iter full iterations of max-log-MAP over n_cb code blocks of size K; int8 soft input in the reference's layout
@@ -323,21 +360,31 @@ int mi_turbo_bcjr_batch(mi_lte_ctx *ctx, const int8_t *d_soft, uint32_t K, uint3
     B.A  = (int16_t *)(base + 4 * a8); B.E = (int16_t *)(base + 4 * a8 + a16); B.post = (int16_t *)(base + 4 * a8 + 2 * a16);
     B.chk  = (int16_t *)(base + 4 * a8 + 3 * a16);
     B.tail = (int8_t *)(base + 4 * a8 + 4 * a16);
+    // segment boundary states: [decoder][alpha|beta][buffer][segment][tile][lane][8 x int16], uniform (0) before the first iteration
+    const uint32_t n_seg   = bcjr_n_seg(K);
+    const size_t   bnd_one = (size_t)4 * n_tiles * 64 * 8; // int16 elements of one [segment][tile][lane][8] array
+    int16_t       *bnd0    = (int16_t *)(base + 4 * a8 + 4 * a16 + n_tiles * 64 * 16);
+    MI_HIP_CHECK(ctx, hipMemsetAsync(bnd0, 0, 8 * bnd_one * sizeof(int16_t), ctx->stream));
+    auto bnd = [&](int dec, uint32_t it) {
+        const uint32_t rd = it & 1u, wr = rd ^ 1u;
+        int16_t *d = bnd0 + (size_t)dec * 4 * bnd_one;
+        return BcjrBnd{d + rd * bnd_one, d + wr * bnd_one, d + (2 + rd) * bnd_one, d + (2 + wr) * bnd_one, (uint32_t)n_tiles};
+    };
     if (n_cb % 64) MI_HIP_CHECK(ctx, hipMemsetAsync(base, 0, 4 * a8 + 3 * a16, ctx->stream)); // lanes past the batch end stay defined
     const uint32_t cb_threads = (uint32_t)(((Kp >> 4) + 63) & ~(size_t)63);
-    MI_LAUNCH(ctx, "k_bcjr_prep", k_bcjr_prep, dim3(n_cb), dim3(cb_threads), Kp, d_soft, K, n_cb, tb.d_pi, B);
+    MI_LAUNCH(ctx, "k_bcjr_prep", k_bcjr_prep, dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), Kp, d_soft, K, n_cb, tb.d_pi, B);
     for (uint32_t it = 0; it < n_iter; it++) {
         const bool last = it + 1 == n_iter;
-        MI_LAUNCH(ctx, "k_bcjr_fwd", k_bcjr_fwd, dim3(n_tiles), dim3(64), 0, B.S1, B.P1, B.A, B.chk, K);
-        MI_LAUNCH(ctx, "k_bcjr_bwd", k_bcjr_bwd<false>, dim3(n_tiles), dim3(64), 0, B.S1, B.P1, B.A, B.chk, B.tail, 0u, B.E, B.post, K, n_cb);
-        MI_LAUNCH(ctx, "k_bcjr_perm", k_bcjr_perm<false>, dim3(n_cb), dim3(cb_threads), 2 * Kp, B.E, tb.d_pi, K, n_cb, B.A, B.S1, d_c_bits);
-        MI_LAUNCH(ctx, "k_bcjr_fwd", k_bcjr_fwd, dim3(n_tiles), dim3(64), 0, B.S2, B.P2, B.A, B.chk, K);
+        MI_LAUNCH(ctx, "k_bcjr_fwd", k_bcjr_fwd, dim3(n_tiles, n_seg), dim3(64), 0, B.S1, B.P1, B.A, B.chk, K, bnd(0, it));
+        MI_LAUNCH(ctx, "k_bcjr_bwd", k_bcjr_bwd<false>, dim3(n_tiles, n_seg), dim3(64), 0, B.S1, B.P1, B.A, B.chk, B.tail, 0u, B.E, B.post, K, n_cb, bnd(0, it));
+        MI_LAUNCH(ctx, "k_bcjr_perm", k_bcjr_perm<false>, dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), 2 * Kp, B.E, tb.d_pi, K, n_cb, B.A, B.S1, d_c_bits);
+        MI_LAUNCH(ctx, "k_bcjr_fwd", k_bcjr_fwd, dim3(n_tiles, n_seg), dim3(64), 0, B.S2, B.P2, B.A, B.chk, K, bnd(1, it));
         if (!last) {
-            MI_LAUNCH(ctx, "k_bcjr_bwd", k_bcjr_bwd<false>, dim3(n_tiles), dim3(64), 0, B.S2, B.P2, B.A, B.chk, B.tail, 6u, B.E, B.post, K, n_cb);
-            MI_LAUNCH(ctx, "k_bcjr_perm", k_bcjr_perm<false>, dim3(n_cb), dim3(cb_threads), 2 * Kp, B.E, tb.d_inv, K, n_cb, B.A, B.S1, d_c_bits);
+            MI_LAUNCH(ctx, "k_bcjr_bwd", k_bcjr_bwd<false>, dim3(n_tiles, n_seg), dim3(64), 0, B.S2, B.P2, B.A, B.chk, B.tail, 6u, B.E, B.post, K, n_cb, bnd(1, it));
+            MI_LAUNCH(ctx, "k_bcjr_perm", k_bcjr_perm<false>, dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), 2 * Kp, B.E, tb.d_inv, K, n_cb, B.A, B.S1, d_c_bits);
         } else {
-            MI_LAUNCH(ctx, "k_bcjr_bwd", k_bcjr_bwd<true>, dim3(n_tiles), dim3(64), 0, B.S2, B.P2, B.A, B.chk, B.tail, 6u, B.E, B.post, K, n_cb);
-            MI_LAUNCH(ctx, "k_bcjr_perm", k_bcjr_perm<true>, dim3(n_cb), dim3(cb_threads), 2 * Kp, B.post, tb.d_inv, K, n_cb, B.A, B.S1, d_c_bits);
+            MI_LAUNCH(ctx, "k_bcjr_bwd", k_bcjr_bwd<true>, dim3(n_tiles, n_seg), dim3(64), 0, B.S2, B.P2, B.A, B.chk, B.tail, 6u, B.E, B.post, K, n_cb, bnd(1, it));
+            MI_LAUNCH(ctx, "k_bcjr_perm", k_bcjr_perm<true>, dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), 2 * Kp, B.post, tb.d_inv, K, n_cb, B.A, B.S1, d_c_bits);
         }
     }
     MI_HIP_CHECK(ctx, hipGetLastError());

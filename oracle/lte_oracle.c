@@ -352,66 +352,94 @@ static void bcjr_beta_step(const int *b, int g00, int g01, int g10, int *o)
     o[4] = bcjr_max(b[2] + g01, b[6] + g10); o[5] = bcjr_max(b[2] + g10, b[6] + g01);
     o[6] = bcjr_max(b[3], b[7] + g00);       o[7] = bcjr_max(b[3] + g00, b[7]);
 }
-/* one SISO pass: systematic S, parity P, a-priori A (K each), the 3 termination pairs, -> extrinsic E and (optionally)
- * the a-posteriori LLR */
-static void bcjr_siso(const int8_t *S, const int8_t *P, const int16_t *A, const int8_t *tail_s, const int8_t *tail_p, uint32_t K,
-                      int16_t *E, int16_t *post)
+/* Segments.  A block is cut into n_seg segments of equal length (a multiple of 64 steps) that are decoded
+ * independently within a half-iteration; alpha at the start of segment s > 0 and beta at the end of segment
+ * s < n_seg-1 are the (normalised) values the neighbouring segment reached in the PREVIOUS iteration of the same
+ * constituent decoder ("next iteration initialisation"), all-zero in the first iteration.  The kernel gets its
+ * occupancy from this; with segments of >= 512 steps the loss is immaterial.  n_seg = 4, 2 or 1. */
+uint32_t lo_bcjr_n_seg(uint32_t K)
 {
-    const uint32_t n_win = K / BCJR_W;
+    const uint32_t nblk = (K + 63) / 64;
+    for (uint32_t n = 4; n > 1; n >>= 1)
+        if (nblk % n == 0 && (nblk / n) * 64 >= 512) return n;
+    return 1;
+}
+typedef struct { int16_t a[2][4][8], b[2][4][8]; } bcjr_bnd_t; /* [buffer][segment][state] */
+
+/* one SISO pass: systematic S, parity P, a-priori A (K each), the 3 termination pairs, -> extrinsic E and (optionally)
+ * the a-posteriori LLR.  it = iteration number (selects the boundary buffers). */
+static void bcjr_siso(const int8_t *S, const int8_t *P, const int16_t *A, const int8_t *tail_s, const int8_t *tail_p, uint32_t K,
+                      int16_t *E, int16_t *post, bcjr_bnd_t *bnd, uint32_t it)
+{
+    const uint32_t n_win = K / BCJR_W, n_seg = lo_bcjr_n_seg(K), seg_len = ((K + 63) / 64 / n_seg) * 64, rd = it & 1, wr = rd ^ 1;
     int16_t (*chk)[8] = (int16_t (*)[8])malloc(sizeof(int16_t) * 8 * n_win);
-    int a[8] = {0, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG}, t8[8];
-    for (uint32_t t = 0; t < K; t++) { /* forward: alpha, normalised and checkpointed every W steps */
-        if (t % BCJR_W == 0) {
+    int t8[8];
+    for (uint32_t sg = 0; sg < n_seg; sg++) { /* forward: alpha, normalised and checkpointed every W steps */
+        const uint32_t t_lo = sg * seg_len, t_hi = (t_lo + seg_len < K) ? t_lo + seg_len : K;
+        int a[8] = {0, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG};
+        if (sg > 0) for (int s = 0; s < 8; s++) a[s] = bnd->a[rd][sg][s];
+        for (uint32_t t = t_lo; t < t_hi; t++) {
+            if (t % BCJR_W == 0) {
+                bcjr_norm(a);
+                for (int s = 0; s < 8; s++) chk[t / BCJR_W][s] = (int16_t)a[s];
+            }
+            const int lsa = S[t] + A[t], lp = P[t];
+            bcjr_alpha_step(a, lsa + lp, lsa, lp, t8);
+            memcpy(a, t8, sizeof(a));
+        }
+        if (sg + 1 < n_seg) {
             bcjr_norm(a);
-            for (int s = 0; s < 8; s++) chk[t / BCJR_W][s] = (int16_t)a[s];
+            for (int s = 0; s < 8; s++) bnd->a[wr][sg + 1][s] = (int16_t)a[s];
         }
-        const int lsa = S[t] + A[t], lp = P[t];
-        bcjr_alpha_step(a, lsa + lp, lsa, lp, t8);
-        memcpy(a, t8, sizeof(a));
     }
-    /* beta at step K from the termination: only the a = 0 edges exist, so state 2j+r3 continues to state j */
-    int b[8] = {0, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG};
-    for (int t = 2; t >= 0; t--) {
-        const int ls = tail_s[t], lp = tail_p[t], g00 = ls + lp, g01 = ls, g10 = lp;
-        t8[0] = b[0] + g00; t8[1] = b[0];       t8[2] = b[1] + g10; t8[3] = b[1] + g01;
-        t8[4] = b[2] + g01; t8[5] = b[2] + g10; t8[6] = b[3];       t8[7] = b[3] + g00;
-        memcpy(b, t8, sizeof(b));
-    }
-    bcjr_norm(b);
-    for (int w = (int)n_win - 1; w >= 0; w--) { /* backward, one window at a time: re-run alpha from the checkpoint */
-        const uint32_t t0 = (uint32_t)w * BCJR_W;
-        int al[BCJR_W][8];
-        for (int s = 0; s < 8; s++) al[0][s] = chk[w][s];
-        for (int i = 1; i < BCJR_W; i++) {
-            const int lsa = S[t0 + i - 1] + A[t0 + i - 1], lp = P[t0 + i - 1];
-            bcjr_alpha_step(al[i - 1], lsa + lp, lsa, lp, al[i]);
+    for (int sg = (int)n_seg - 1; sg >= 0; sg--) {
+        const uint32_t t_lo = (uint32_t)sg * seg_len, t_hi = (t_lo + seg_len < K) ? t_lo + seg_len : K;
+        int b[8] = {0, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG};
+        if (sg == (int)n_seg - 1) { /* beta at step K from the termination: only the a = 0 edges exist, so state 2j+r3 continues to state j */
+            for (int t = 2; t >= 0; t--) {
+                const int ls = tail_s[t], lp = tail_p[t], g00 = ls + lp, g01 = ls, g10 = lp;
+                t8[0] = b[0] + g00; t8[1] = b[0];       t8[2] = b[1] + g10; t8[3] = b[1] + g01;
+                t8[4] = b[2] + g01; t8[5] = b[2] + g10; t8[6] = b[3];       t8[7] = b[3] + g00;
+                memcpy(b, t8, sizeof(b));
+            }
+            bcjr_norm(b);
+        } else
+            for (int s = 0; s < 8; s++) b[s] = bnd->b[rd][sg][s];
+        for (int w = (int)(t_hi / BCJR_W) - 1; w >= (int)(t_lo / BCJR_W); w--) { /* backward, one window at a time: re-run alpha from the checkpoint */
+            const uint32_t t0 = (uint32_t)w * BCJR_W;
+            int al[BCJR_W][8];
+            for (int s = 0; s < 8; s++) al[0][s] = chk[w][s];
+            for (int i = 1; i < BCJR_W; i++) {
+                const int lsa = S[t0 + i - 1] + A[t0 + i - 1], lp = P[t0 + i - 1];
+                bcjr_alpha_step(al[i - 1], lsa + lp, lsa, lp, al[i]);
+            }
+            for (int i = BCJR_W - 1; i >= 0; i--) {
+                const uint32_t t = t0 + i;
+                const int lsa = S[t] + A[t], lp = P[t], g00 = lsa + lp, g01 = lsa, g10 = lp;
+                const int *x = al[i];
+                /* u = 0 edges: (0->0) (1->4) (7->3) (6->7) carry g00, (3->1) (2->5) (4->2) (5->6) carry g01;
+                 * u = 1 edges: (2->1) (3->5) (5->2) (4->6) carry g10, (1->0) (0->4) (6->3) (7->7) carry 0 */
+                const int m00 = bcjr_max(bcjr_max(x[0] + b[0], x[1] + b[4]), bcjr_max(x[7] + b[3], x[6] + b[7]));
+                const int m01 = bcjr_max(bcjr_max(x[3] + b[1], x[2] + b[5]), bcjr_max(x[4] + b[2], x[5] + b[6]));
+                const int m10 = bcjr_max(bcjr_max(x[2] + b[1], x[3] + b[5]), bcjr_max(x[5] + b[2], x[4] + b[6]));
+                const int m11 = bcjr_max(bcjr_max(x[1] + b[0], x[0] + b[4]), bcjr_max(x[6] + b[3], x[7] + b[7]));
+                const int llr = bcjr_max(m00 + g00, m01 + g01) - bcjr_max(m10 + g10, m11);
+                int e = ((llr - lsa) * 3) >> 2; /* extrinsic, scaled by 3/4 (arithmetic shift) */
+                e     = e > BCJR_LE_MAX ? BCJR_LE_MAX : e < -BCJR_LE_MAX ? -BCJR_LE_MAX : e;
+                E[t]  = (int16_t)e;
+                if (post) post[t] = (int16_t)(llr > 32767 ? 32767 : llr < -32767 ? -32767 : llr);
+                bcjr_beta_step(b, g00, g01, g10, t8);
+                memcpy(b, t8, sizeof(b));
+            }
+            bcjr_norm(b);
         }
-        for (int i = BCJR_W - 1; i >= 0; i--) {
-            const uint32_t t = t0 + i;
-            const int lsa = S[t] + A[t], lp = P[t], g00 = lsa + lp, g01 = lsa, g10 = lp;
-            const int *x = al[i];
-            /* u = 0 edges: (0->0) (1->4) (7->3) (6->7) carry g00, (3->1) (2->5) (4->2) (5->6) carry g01;
-             * u = 1 edges: (2->1) (3->5) (5->2) (4->6) carry g10, (1->0) (0->4) (6->3) (7->7) carry 0 */
-            const int m00 = bcjr_max(bcjr_max(x[0] + b[0], x[1] + b[4]), bcjr_max(x[7] + b[3], x[6] + b[7]));
-            const int m01 = bcjr_max(bcjr_max(x[3] + b[1], x[2] + b[5]), bcjr_max(x[4] + b[2], x[5] + b[6]));
-            const int m10 = bcjr_max(bcjr_max(x[2] + b[1], x[3] + b[5]), bcjr_max(x[5] + b[2], x[4] + b[6]));
-            const int m11 = bcjr_max(bcjr_max(x[1] + b[0], x[0] + b[4]), bcjr_max(x[6] + b[3], x[7] + b[7]));
-            const int llr = bcjr_max(m00 + g00, m01 + g01) - bcjr_max(m10 + g10, m11);
-            int e = ((llr - lsa) * 3) >> 2; /* extrinsic, scaled by 3/4 (arithmetic shift) */
-            e     = e > BCJR_LE_MAX ? BCJR_LE_MAX : e < -BCJR_LE_MAX ? -BCJR_LE_MAX : e;
-            E[t]  = (int16_t)e;
-            if (post) post[t] = (int16_t)(llr > 32767 ? 32767 : llr < -32767 ? -32767 : llr);
-            bcjr_beta_step(b, g00, g01, g10, t8);
-            memcpy(b, t8, sizeof(b));
-        }
-        bcjr_norm(b);
+        if (sg > 0) for (int s = 0; s < 8; s++) bnd->b[wr][sg - 1][s] = (int16_t)b[s];
     }
     free(chk);
 }
 
 void lo_turbo_decode_bcjr(const int16_t *soft, uint32_t K, uint32_t n_iter, int qpp_spec, uint8_t *c_bits)
 {
-    const uint32_t D = K + 4;
     int8_t   *S1 = (int8_t *)malloc(4 * (size_t)K), *P1 = S1 + K, *S2 = P1 + K, *P2 = S2 + K;
     int16_t  *A1 = (int16_t *)calloc(5 * (size_t)K, sizeof(int16_t)), *A2 = A1 + K, *E1 = A2 + K, *E2 = E1 + K, *post = E2 + K;
     uint16_t *pi = (uint16_t *)malloc(sizeof(uint16_t) * 2 * K), *inv = pi + K;
@@ -428,10 +456,13 @@ void lo_turbo_decode_bcjr(const int16_t *soft, uint32_t K, uint32_t n_iter, int 
     /* 36.212 5.1.3.2.2: d0 = x_K z_K+1 x'_K z'_K+1, d1 = z_K x_K+2 z'_K x'_K+2, d2 = x_K+1 z_K+2 x'_K+1 z'_K+2 */
     const int8_t t1s[3] = {x[0], x[2], x[4]}, t1p[3] = {x[1], x[3], x[5]};
     const int8_t t2s[3] = {x[6], x[8], x[10]}, t2p[3] = {x[7], x[9], x[11]};
+    bcjr_bnd_t bnd1, bnd2; /* segment boundaries of the two constituent decoders, all-zero (uniform) before the first iteration */
+    memset(&bnd1, 0, sizeof(bnd1));
+    memset(&bnd2, 0, sizeof(bnd2));
     for (uint32_t it = 0; it < n_iter; it++) {
-        bcjr_siso(S1, P1, A1, t1s, t1p, K, E1, NULL);
+        bcjr_siso(S1, P1, A1, t1s, t1p, K, E1, NULL, &bnd1, it);
         for (uint32_t i = 0; i < K; i++) A2[i] = E1[pi[i]];
-        bcjr_siso(S2, P2, A2, t2s, t2p, K, E2, post);
+        bcjr_siso(S2, P2, A2, t2s, t2p, K, E2, post, &bnd2, it);
         for (uint32_t j = 0; j < K; j++) A1[j] = inv[j] != 0xFFFF ? E2[inv[j]] : 0;
     }
     for (uint32_t j = 0; j < K; j++) {

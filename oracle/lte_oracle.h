@@ -73,6 +73,7 @@ void lo_turbo_decode_ref_taps(const float *d_interleaved, uint32_t K, uint8_t *c
  * soft: 3(K+4) values interleaved d[i*3+x], positive = bit 0, clipped to +-127.  qpp_spec != 0: exact 3GPP
  * interleaver, else the reference's uint32-wrapped one (gather semantics; de-interleaving takes the last writer,
  * holes read 0). */
+uint32_t lo_bcjr_n_seg(uint32_t K); /* 4, 2 or 1 independently decoded segments per block (see lte_oracle.c) */
 void lo_turbo_decode_bcjr(const int16_t *soft, uint32_t K, uint32_t n_iter, int qpp_spec, uint8_t *c_bits);
 
 /* ---- encoder side (input synthesis for tests) ---- */

@@ -244,6 +244,35 @@ int      mi_lte_pusch_decode_run(mi_lte_ctx *ctx, mi_lte_pusch_plan *plan, const
 /* stage tap: device pointer to the de-interleaved, descrambled soft bits (int8, 12*12*N_prb*Q_m of them) */
 int      mi_lte_pusch_plan_soft_bits(const mi_lte_pusch_plan *plan, uint32_t alloc, const int8_t **d_e, uint32_t *n_bits);
 
+/* PRACH detection: replaces liblte_phy_detect_prach() (liblte_phy.h:862-868, implementation liblte_phy.cc:3299-3479)
+ * for a batch of PRACH occasions (d_occ_start[o] = sample index of the occasion's first cyclic-prefix sample; an
+ * occasion spans mi_lte_prach_occasion_samples() samples), preamble formats 0-3.  The 839 PRACH sub-carriers are
+ * computed directly from the T_fft samples behind the prefix, correlated with every root sequence the cell's 64
+ * preambles use, and the reference's verdict -- one preamble if the peak reaches 50 x the averaged correlation
+ * power (:3460-3474) -- is evaluated on the host: h_N_det_pre[o] in {0,1}, h_det_pre[o] = preamble index,
+ * h_det_ta[o] = timing advance, exactly the reference's three outputs.  The plan generates the root sequences'
+ * spectra itself (prach_preamble_seq_gen :7130-7290 + the 839-point DFTs of liblte_phy_ul_init :2496-2508);
+ * mi_lte_prach_plan_create_roots takes them from the caller instead (LIBLTE_PHY_STRUCT::prach_x_u_fft_re/im). */
+typedef struct {
+    uint32_t root_seq_idx;     /* logical root sequence index, 0..837 */
+    uint32_t preamble_format;  /* 0..3 */
+    uint32_t zczc;             /* zeroCorrelationZoneConfig */
+    uint32_t hs_flag;          /* restricted set */
+    uint32_t freq_offset;      /* n_PRBoffset^RA */
+} mi_lte_prach_cfg;
+typedef struct mi_lte_prach_plan mi_lte_prach_plan;
+int      mi_lte_prach_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg /* N_rb_dl = N_rb_ul */, const mi_lte_prach_cfg *prach,
+                                  mi_lte_prach_plan **out);
+int      mi_lte_prach_plan_create_roots(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const mi_lte_prach_cfg *prach,
+                                        const float *h_x_u_fft_re /*[n_roots][839]*/, const float *h_x_u_fft_im, uint32_t n_roots,
+                                        mi_lte_prach_plan **out);
+void     mi_lte_prach_plan_destroy(mi_lte_ctx *ctx, mi_lte_prach_plan *plan);
+uint32_t mi_lte_prach_plan_n_roots(const mi_lte_prach_plan *plan);
+uint32_t mi_lte_prach_occasion_samples(const mi_lte_prach_plan *plan);
+int      mi_lte_prach_detect_run(mi_lte_ctx *ctx, mi_lte_prach_plan *plan, const void *d_samples_a, const void *d_samples_b,
+                                 const uint64_t *d_occ_start, uint32_t n_occ, uint32_t *h_N_det_pre, uint32_t *h_det_pre,
+                                 uint32_t *h_det_ta);
+
 /* ---------------------------------------------------------------- per-call host-pointer forms
  * The bodies of the reference's three entry points on this path, for callers that hold host
  * buffers exactly as the reference's callers do (LTE_fdd_dl_fs_samp_buf.cc:378-515,
@@ -269,6 +298,10 @@ int mi_lte_pusch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_ul, const fl
                                      uint32_t subfr_num, const mi_lte_pdsch_alloc *alloc, uint32_t N_id_cell, uint32_t N_ant,
                                      const float *h_dmrs_0_re, const float *h_dmrs_0_im, const float *h_dmrs_1_re,
                                      const float *h_dmrs_1_im, uint8_t *h_out_bits, uint32_t *N_out_bits);
+/* liblte_phy_detect_prach: h_re / h_im point at the occasion's first cyclic-prefix sample; root spectra from the caller's struct */
+int mi_lte_detect_prach_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_ul, const mi_lte_prach_cfg *prach,
+                             const float *h_x_u_fft_re /*[n_roots][839]*/, const float *h_x_u_fft_im, uint32_t n_roots, const float *h_re,
+                             const float *h_im, uint32_t *N_det_pre, uint32_t *det_pre, uint32_t *det_ta);
 int mi_lte_rate_unmatch_turbo_host(mi_lte_ctx *ctx, const float *h_e_bits, uint32_t N_e_bits, uint32_t N_dummy_bits,
                                    uint32_t N_codeblocks, uint32_t tx_mode, uint32_t N_soft, uint32_t M_dl_harq,
                                    uint32_t chan_type, uint32_t rv_idx, float *h_d_bits, uint32_t *N_d_bits);
@@ -315,6 +348,12 @@ int    mi_lte_synth_ul_units_i8(const mi_lte_dl_cfg *cfg, const mi_lte_ul_cfg *u
                                 const uint32_t *h_subfr_num, const uint32_t *h_n_id_cell, const mi_lte_pdsch_alloc *h_allocs,
                                 uint32_t n_alloc, const mi_lte_synth_channel *chan, int8_t *h_iq, uint8_t *h_tx_bits,
                                 uint32_t tbs_stride);
+
+/* n_occ PRACH occasions (format 0-3 preambles per 36.211 5.7.2-5.7.3): preamble h_preamble_idx[o] of the cell's 64,
+ * delayed by h_delay[o] samples, through a flat channel + AWGN; mi_lte_synth_prach_len() complex int8 samples each. */
+size_t mi_lte_synth_prach_len(uint32_t fft_size, uint32_t preamble_format);
+int    mi_lte_synth_prach_i8(const mi_lte_dl_cfg *cfg, const mi_lte_prach_cfg *prach, uint32_t n_occ, const uint32_t *h_preamble_idx,
+                             const uint32_t *h_delay, const mi_lte_synth_channel *chan, int8_t *h_iq);
 
 #ifdef __cplusplus
 }

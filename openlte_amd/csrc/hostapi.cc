@@ -166,6 +166,36 @@ int mi_lte_pusch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_ul, const fl
     return rc != MI_LTE_OK ? rc : (st == 0 ? 0 : 1);
 }
 
+// liblte_phy_detect_prach (liblte_phy.cc:3299-3479): h_re / h_im point at the occasion's first cyclic-prefix sample; the root
+// spectra are the caller's (LIBLTE_PHY_STRUCT::prach_x_u_fft_re/im, filled by liblte_phy_ul_init).  N_det_pre is always
+// written; det_pre / det_ta only when a preamble was found, like the reference.
+int mi_lte_detect_prach_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_ul, const mi_lte_prach_cfg *prach, const float *h_x_u_fft_re,
+                             const float *h_x_u_fft_im, uint32_t n_roots, const float *h_re, const float *h_im, uint32_t *N_det_pre,
+                             uint32_t *det_pre, uint32_t *det_ta)
+{
+    if (!ctx) return MI_LTE_ERR_INVALID_ARG;
+    if (!prach || !h_x_u_fft_re || !h_x_u_fft_im || !h_re || !h_im || !N_det_pre || !det_pre || !det_ta) return 1;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    mi_lte_dl_cfg      cfg = {fft_size, N_rb_ul, 1, MI_LTE_IQ_F32_PLANAR};
+    mi_lte_prach_plan *plan = nullptr;
+    int rc = mi_lte_prach_plan_create_roots(ctx, &cfg, prach, h_x_u_fft_re, h_x_u_fft_im, n_roots, &plan);
+    if (rc != MI_LTE_OK) return rc == MI_LTE_ERR_UNSUPPORTED ? 1 : rc;
+    const size_t need = mi_lte_prach_occasion_samples(plan);
+    DevBuf d_i, d_q, d_s;
+    if (d_i.alloc(need * 4) || d_q.alloc(need * 4) || d_s.alloc(8)) { mi_lte_prach_plan_destroy(ctx, plan); return MI_LTE_ERR_NOMEM; }
+    hipError_t e = hipMemcpyAsync(d_i.p, h_re, need * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_q.p, h_im, need * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_s.p, 0, 8, ctx->stream);
+    if (e != hipSuccess) { mi_lte_prach_plan_destroy(ctx, plan); ctx->err = hipGetErrorString(e); return MI_LTE_ERR_HIP; }
+    uint32_t n = 0, p = 0, ta = 0;
+    rc = mi_lte_prach_detect_run(ctx, plan, d_i.p, d_q.p, (const uint64_t *)d_s.p, 1, &n, &p, &ta);
+    mi_lte_prach_plan_destroy(ctx, plan);
+    if (rc != MI_LTE_OK) return rc;
+    *N_det_pre = n;
+    if (n) { *det_pre = p; *det_ta = ta; }
+    return 0;
+}
+
 // liblte_phy_rate_unmatch_turbo (liblte_phy.cc:11246-11490)
 int mi_lte_rate_unmatch_turbo_host(mi_lte_ctx *ctx, const float *h_e, uint32_t N_e, uint32_t N_dummy_bits, uint32_t C, uint32_t tx_mode,
                                    uint32_t N_soft, uint32_t M_dl_harq, uint32_t chan_type, uint32_t rv_idx, float *h_d, uint32_t *N_d)

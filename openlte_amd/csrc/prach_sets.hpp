@@ -1,0 +1,39 @@
+// Cyclic-shift sets of one PRACH root sequence (36.211 5.7.2), computed exactly as the reference derives them in
+// prach_preamble_seq_gen / liblte_phy_detect_prach (liblte/src/liblte_phy.cc:3336-3413, :7183-7252).  Host only.
+#pragma once
+#include <cstdint>
+
+#include "lte_tables.h"
+
+struct PrachSets { uint32_t N_cs, v_max, N_RA_shift, d_start; };
+
+inline PrachSets prach_sets(uint32_t u, uint32_t zczc, bool hs)
+{
+    constexpr uint32_t N_ZC = 839;
+    PrachSets s{hs ? (uint32_t)LTE_PRACH_NCS_RESTRICTED[zczc] : (uint32_t)LTE_PRACH_NCS_UNRESTRICTED[zczc], 0, 0, 0};
+    if (hs) {
+        uint32_t p;
+        for (p = 1; p <= N_ZC; p++)
+            if (((p * u) % N_ZC) == 1) break;
+        const uint32_t d_u = (p < N_ZC / 2) ? p : N_ZC - p;
+        uint32_t       N_RA_group;
+        int32_t        N_neg;
+        if (d_u >= s.N_cs && d_u < N_ZC / 3) {
+            s.N_RA_shift = d_u / s.N_cs;
+            s.d_start    = 2 * d_u + s.N_RA_shift * s.N_cs;
+            N_RA_group   = N_ZC / s.d_start;
+            N_neg        = (int32_t)((N_ZC - 2 * d_u - N_RA_group * s.d_start) / s.N_cs);
+            if (N_neg < 0) N_neg = 0;
+        } else {
+            s.N_RA_shift = (N_ZC - 2 * d_u) / s.N_cs;
+            s.d_start    = N_ZC - 2 * d_u + s.N_RA_shift * s.N_cs;
+            N_RA_group   = d_u / s.d_start;
+            N_neg        = (int32_t)((d_u - N_RA_group * s.d_start) / s.N_cs);
+            if (N_neg < 0) N_neg = 0;
+            if (N_neg > (int32_t)s.N_RA_shift) N_neg = (int32_t)s.N_RA_shift;
+        }
+        s.v_max = s.N_RA_shift * N_RA_group + (uint32_t)N_neg - 1;
+    } else
+        s.v_max = s.N_cs == 0 ? 0 : N_ZC / s.N_cs - 1;
+    return s;
+}

@@ -13,6 +13,7 @@
 
 #include "../../include/mi_lte.h"
 #include "lte_tables.h"
+#include "prach_sets.hpp"
 #include "synth.hpp"
 
 extern "C" {
@@ -139,6 +140,92 @@ int mi_lte_synth_ul_units_i8(const mi_lte_dl_cfg *cfg, const mi_lte_ul_cfg *ul, 
             const long qr = std::lround(yr * scale / std::max(1.0, chan->gain_max)), qi = std::lround(yi * scale / std::max(1.0, chan->gain_max));
             o[2 * i]     = (int8_t)std::max(-127L, std::min(127L, qr));
             o[2 * i + 1] = (int8_t)std::max(-127L, std::min(127L, qi));
+        }
+    }
+    return MI_LTE_OK;
+}
+
+
+// ---- PRACH (36.211 5.7.2-5.7.3): preamble v of root u is x_u((n + C_v) mod 839); its 839-point DFT sits on the PRACH
+// sub-carriers (1.25 kHz spacing) phi + K(k0 + 1/2) + k in natural order; cyclic prefix + sequence (twice for formats 2, 3)
+size_t mi_lte_synth_prach_len(uint32_t fft_size, uint32_t preamble_format)
+{
+    static const uint32_t cp_of_fmt[4] = {3168, 21024, 6240, 21024};
+    const uint32_t sc = 2048 / (fft_size ? fft_size : 2048), f = preamble_format & 3;
+    return ((cp_of_fmt[f] + 24576 * (f >= 2 ? 2 : 1) + 1024) / sc + 15) / 16 * 16;
+}
+
+int mi_lte_synth_prach_i8(const mi_lte_dl_cfg *cfg, const mi_lte_prach_cfg *pc, uint32_t n_occ, const uint32_t *h_preamble_idx,
+                          const uint32_t *h_delay, const mi_lte_synth_channel *chan, int8_t *h_iq)
+{
+    if (!cfg || !pc || !h_preamble_idx || !h_delay || !chan || !h_iq || pc->preamble_format > 3 || pc->root_seq_idx > 837) return MI_LTE_ERR_INVALID_ARG;
+    constexpr uint32_t N_ZC = 839;
+    static const uint32_t cp_of_fmt[4] = {3168, 21024, 6240, 21024};
+    const uint32_t N = cfg->fft_size, sc = 2048 / N, T = 24576 / sc, T_cp = cp_of_fmt[pc->preamble_format] / sc;
+    const uint32_t reps = pc->preamble_format >= 2 ? 2 : 1;
+    const size_t   len = mi_lte_synth_prach_len(N, pc->preamble_format);
+    const uint32_t k_0 = pc->freq_offset * 12 - cfg->N_rb_dl * 12 / 2 + N / 2, start = 7 + 12 * k_0 + 6;
+    synth::Rng rng(chan->seed);
+    std::vector<double> xr(N_ZC), xi(N_ZC), Xr(N_ZC), Xi(N_ZC), cz(N_ZC), sz(N_ZC), ct(T), st(T), sr(T), si(T), t_re(len), t_im(len);
+    for (uint32_t t = 0; t < N_ZC; t++) { cz[t] = std::cos(-2.0 * M_PI * t / N_ZC); sz[t] = std::sin(-2.0 * M_PI * t / N_ZC); }
+    for (uint32_t t = 0; t < T; t++) { ct[t] = std::cos(2.0 * M_PI * t / T); st[t] = std::sin(2.0 * M_PI * t / T); }
+    for (uint32_t o = 0; o < n_occ; o++) {
+        // which root and cyclic shift carry preamble index p (prach_preamble_seq_gen's enumeration, liblte_phy.cc:7155-7290)
+        uint32_t p = h_preamble_idx[o] % 64, r = 0, u = 0, C_v = 0;
+        for (;; r++) {
+            if (pc->root_seq_idx + r > 837) return MI_LTE_ERR_INVALID_ARG;
+            u = LTE_PRACH_ROOT_ORDER[pc->root_seq_idx + r];
+            const PrachSets ps = prach_sets(u, pc->zczc, pc->hs_flag != 0);
+            if (p <= ps.v_max) {
+                C_v = pc->hs_flag ? ps.d_start * (p / ps.N_RA_shift) + (p % ps.N_RA_shift) * ps.N_cs : p * ps.N_cs;
+                break;
+            }
+            p -= ps.v_max + 1;
+        }
+        for (uint32_t n = 0; n < N_ZC; n++) {
+            const uint32_t m = (n + C_v) % N_ZC;
+            const double   ph = -M_PI * u * m * (m + 1) / N_ZC;
+            xr[n] = std::cos(ph); xi[n] = std::sin(ph);
+        }
+        for (uint32_t k = 0; k < N_ZC; k++) {
+            double ar = 0, ai = 0;
+            uint32_t t = 0;
+            for (uint32_t n = 0; n < N_ZC; n++) {
+                ar += xr[n] * cz[t] - xi[n] * sz[t];
+                ai += xr[n] * sz[t] + xi[n] * cz[t];
+                t += k; if (t >= N_ZC) t -= N_ZC;
+            }
+            Xr[k] = ar; Xi[k] = ai;
+        }
+        for (uint32_t n = 0; n < T; n++) { // s(n) = sum_k X(k) exp(+2*pi*i*idx_k*n/T)
+            double ar = 0, ai = 0;
+            for (uint32_t k = 0; k < N_ZC; k++) {
+                const uint32_t idx = (k + start + T / 2) % T, t = (uint32_t)(((uint64_t)idx * n) % T);
+                ar += Xr[k] * ct[t] - Xi[k] * st[t];
+                ai += Xr[k] * st[t] + Xi[k] * ct[t];
+            }
+            sr[n] = ar; si[n] = ai;
+        }
+        std::fill(t_re.begin(), t_re.end(), 0.0);
+        std::fill(t_im.begin(), t_im.end(), 0.0);
+        const uint32_t dly = h_delay[o];
+        for (uint32_t i = 0; i < T_cp + reps * T; i++) {
+            const uint32_t n = (i + T - (T_cp % T)) % T; // cyclic prefix = tail of the sequence
+            if (dly + i < len) { t_re[dly + i] = sr[n]; t_im[dly + i] = si[n]; }
+        }
+        const double gain = chan->gain_min + (chan->gain_max - chan->gain_min) * rng.uniform(), ph = 2.0 * M_PI * rng.uniform() - M_PI;
+        double p_sig = 0, peak = 0;
+        for (size_t i = 0; i < len; i++) { p_sig += t_re[i] * t_re[i] + t_im[i] * t_im[i]; peak = std::max(peak, std::max(std::fabs(t_re[i]), std::fabs(t_im[i]))); }
+        p_sig /= (double)len;
+        const double scale = peak > 0 ? chan->peak / peak : 1.0;
+        const double sigma = chan->snr_db >= 200 ? 0.0 : std::sqrt(p_sig / std::pow(10.0, chan->snr_db / 10.0) / 2.0);
+        const double hr = gain * std::cos(ph), hi = gain * std::sin(ph);
+        int8_t *ob = h_iq + (size_t)o * len * 2;
+        for (size_t i = 0; i < len; i++) {
+            const double yr = hr * t_re[i] - hi * t_im[i] + sigma * rng.normal(), yi = hr * t_im[i] + hi * t_re[i] + sigma * rng.normal();
+            const long qr = std::lround(yr * scale / std::max(1.0, chan->gain_max)), qi = std::lround(yi * scale / std::max(1.0, chan->gain_max));
+            ob[2 * i]     = (int8_t)std::max(-127L, std::min(127L, qr));
+            ob[2 * i + 1] = (int8_t)std::max(-127L, std::min(127L, qi));
         }
     }
     return MI_LTE_OK;

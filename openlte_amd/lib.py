@@ -27,6 +27,11 @@ class UlCfg(C.Structure):
                                           "cyclic_shift", "cyclic_shift_dci")]
 
 
+class PrachCfg(C.Structure):
+    """mi_lte_prach_cfg"""
+    _fields_ = [(n, C.c_uint32) for n in ("root_seq_idx", "preamble_format", "zczc", "hs_flag", "freq_offset")]
+
+
 class PdschAlloc(C.Structure):
     """mi_lte_pdsch_alloc"""
     _fields_ = [(n, C.c_uint32) for n in ("unit", "mod_type", "tbs", "rv_idx", "tx_mode", "rnti", "N_prb", "reserved")] + \
@@ -111,6 +116,14 @@ def load_library():
     L.mi_lte_pusch_plan_out_stride.restype = u32
     L.mi_lte_pusch_decode_run.argtypes = [vp, vp, vp, vp, vp]
     L.mi_lte_pusch_plan_soft_bits.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u32)]
+    L.mi_lte_prach_plan_create.argtypes = [vp, C.POINTER(DlCfg), C.POINTER(PrachCfg), C.POINTER(vp)]
+    L.mi_lte_prach_plan_create_roots.argtypes = [vp, C.POINTER(DlCfg), C.POINTER(PrachCfg), f32p, f32p, u32, C.POINTER(vp)]
+    L.mi_lte_prach_plan_destroy.argtypes = [vp, vp]
+    L.mi_lte_prach_plan_n_roots.argtypes = [vp]
+    L.mi_lte_prach_plan_n_roots.restype = u32
+    L.mi_lte_prach_occasion_samples.argtypes = [vp]
+    L.mi_lte_prach_occasion_samples.restype = u32
+    L.mi_lte_prach_detect_run.argtypes = [vp, vp, vp, vp, vp, u32, u32p, u32p, u32p]
     L.mi_lte_turbo_decode_batch.argtypes = [vp, vp, C.c_int, u32, u32, C.c_int, u32, C.c_int, vp]
     L.mi_lte_turbo_scratch_bytes.argtypes = [u32, u32]
     L.mi_lte_turbo_scratch_bytes.restype = sz
@@ -243,6 +256,42 @@ class PuschPlan:
             self.h = None
 
 
+class PrachPlan:
+    """mi_lte_prach_plan: root-sequence spectra of one cell's PRACH configuration."""
+
+    def __init__(self, ctx, cfg, prach_cfg, roots_fft=None):
+        self.ctx = ctx
+        h = C.c_void_p()
+        if roots_fft is None:
+            ctx._check(ctx.L.mi_lte_prach_plan_create(ctx.h, C.byref(cfg), C.byref(prach_cfg), C.byref(h)))
+        else:
+            re, im = np.ascontiguousarray(roots_fft[0], np.float32), np.ascontiguousarray(roots_fft[1], np.float32)
+            ctx._check(ctx.L.mi_lte_prach_plan_create_roots(ctx.h, C.byref(cfg), C.byref(prach_cfg), re, im, re.shape[0], C.byref(h)))
+        self.h = h
+        self.n_roots = ctx.L.mi_lte_prach_plan_n_roots(h)
+        self.occasion_samples = ctx.L.mi_lte_prach_occasion_samples(h)
+
+    def detect_dev(self, d_a, d_b, d_start, n_occ):
+        """(N_det_pre, det_pre, det_ta) uint32 arrays, one entry per occasion."""
+        out = [np.zeros(n_occ, np.uint32) for _ in range(3)]
+        self.ctx._check(self.ctx.L.mi_lte_prach_detect_run(self.ctx.h, self.h, d_a.ptr, d_b.ptr if d_b is not None else None, d_start.ptr,
+                                                            n_occ, out[0], out[1], out[2]))
+        return out
+
+    def detect(self, iq, occ_start):
+        d_a, d_s = self.ctx.to_device(iq.astype(np.int8)), self.ctx.to_device(np.asarray(occ_start, np.uint64))
+        try:
+            return self.detect_dev(d_a, None, d_s, len(occ_start))
+        finally:
+            d_a.free()
+            d_s.free()
+
+    def close(self):
+        if self.h:
+            self.ctx.L.mi_lte_prach_plan_destroy(self.ctx.h, self.h)
+            self.h = None
+
+
 def ul_dmrs_pusch(ulcfg, n_id_cell, n_subfr, n_prb):
     """float32 [4, 12*n_prb]: dmrs_0_re, dmrs_0_im, dmrs_1_re, dmrs_1_im (host function of the library)."""
     out = np.zeros((4, 12 * n_prb), np.float32)
@@ -365,6 +414,9 @@ class Context:
             d_start.free()
             if not keep:
                 d_out.free()
+
+    def prach_plan(self, cfg, prach_cfg, roots_fft=None):
+        return PrachPlan(self, cfg, prach_cfg, roots_fft)
 
     def pusch_plan(self, cfg, ulcfg, unit_subfr_num, unit_n_id_cell, allocs):
         return PuschPlan(self, cfg, ulcfg, unit_subfr_num, unit_n_id_cell, allocs)

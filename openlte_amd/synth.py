@@ -4,7 +4,7 @@ import ctypes as C
 
 import numpy as np
 
-from .lib import load_library, MiLteError, DlCfg, UlCfg, PdschAlloc
+from .lib import load_library, MiLteError, DlCfg, UlCfg, PrachCfg, PdschAlloc
 
 _i8p = np.ctypeslib.ndpointer(np.int8, flags="C_CONTIGUOUS")
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
@@ -33,6 +33,9 @@ def _lib():
         L.mi_lte_synth_ul_unit_len.restype = C.c_size_t
         L.mi_lte_synth_ul_units_i8.argtypes = [C.POINTER(DlCfg), C.POINTER(UlCfg), C.c_uint32, _u32p, _u32p, C.c_void_p, C.c_uint32,
                                                C.POINTER(SynthChannel), _i8p, _u8p, C.c_uint32]
+        L.mi_lte_synth_prach_len.argtypes = [C.c_uint32, C.c_uint32]
+        L.mi_lte_synth_prach_len.restype = C.c_size_t
+        L.mi_lte_synth_prach_i8.argtypes = [C.POINTER(DlCfg), C.POINTER(PrachCfg), C.c_uint32, _u32p, _u32p, C.POINTER(SynthChannel), _i8p]
         L._synth_bound = True
     return L
 
@@ -101,3 +104,16 @@ def ul_units(cfg, ulcfg, subfr_num, n_id_cell, allocs, n_alloc, gain=(0.5, 1.5),
     if rc != 0:
         raise MiLteError("mi_lte_synth_ul_units_i8 failed: %d" % rc)
     return iq, tx
+
+
+def prach_occasions(cfg, prach_cfg, preamble_idx, delay, gain=(0.5, 1.5), snr_db=20.0, peak=100.0, seed=1):
+    """int8 [n_occ, prach_len, 2]: one PRACH preamble per occasion (index preamble_idx[o] of the cell's 64, delayed by delay[o] samples)."""
+    n = len(preamble_idx)
+    ln = int(_lib().mi_lte_synth_prach_len(cfg.fft_size, prach_cfg.preamble_format))
+    iq = np.zeros((n, ln, 2), np.int8)
+    ch = SynthChannel(gain[0], gain[1], 0.0, float(snr_db), float(peak), int(seed))
+    rc = _lib().mi_lte_synth_prach_i8(C.byref(cfg), C.byref(prach_cfg), n, np.ascontiguousarray(preamble_idx, np.uint32),
+                                      np.ascontiguousarray(delay, np.uint32), C.byref(ch), iq)
+    if rc != 0:
+        raise MiLteError("mi_lte_synth_prach_i8 failed: %d" % rc)
+    return iq

@@ -182,6 +182,11 @@ def ref():
     L.ref_pusch_d_re_ptr.restype = C.POINTER(C.c_float)
     L.ref_pusch_d_im_ptr.argtypes = [vp]
     L.ref_pusch_d_im_ptr.restype = C.POINTER(C.c_float)
+    L.ref_ul_init_prach.argtypes = [vp, u32, u32, u32, u32, u32]
+    L.ref_detect_prach.argtypes = [vp, f32p, f32p, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    L.ref_prach_n_roots.argtypes = [vp]
+    L.ref_prach_n_roots.restype = u32
+    L.ref_get_prach_root_fft.argtypes = [vp, u32, f32p, f32p]
     L.ref_time_pusch.argtypes = [vp, f32p, f32p, vp, C.POINTER(LoAlloc), u32, u32, u32]
     L.ref_time_pusch.restype = C.c_double
     _REF = L

@@ -352,6 +352,22 @@ int ref_ul_init(void *phy, uint32_t N_id_cell, uint32_t group_assignment_pusch, 
                                    group_hopping_enabled != 0, sequence_hopping_enabled != 0, (uint8)cyclic_shift,
                                    (uint8)cyclic_shift_dci, 0, 1);
 }
+int ref_ul_init_prach(void *phy, uint32_t N_id_cell, uint32_t root_seq_idx, uint32_t preamble_format, uint32_t zczc, uint32_t hs_flag)
+{
+    return (int)liblte_phy_ul_init((LIBLTE_PHY_STRUCT *)phy, (uint16)N_id_cell, root_seq_idx, preamble_format, zczc, hs_flag != 0, 0, false,
+                                   false, 0, 0, 0, 1);
+}
+int ref_detect_prach(void *phy, float *re, float *im, uint32_t freq_offset, uint32_t *N_det_pre, uint32_t *det_pre, uint32_t *det_ta)
+{
+    return (int)liblte_phy_detect_prach((LIBLTE_PHY_STRUCT *)phy, re, im, freq_offset, N_det_pre, det_pre, det_ta);
+}
+uint32_t ref_prach_n_roots(void *phy) { return ((LIBLTE_PHY_STRUCT *)phy)->prach_N_x_u; }
+void ref_get_prach_root_fft(void *vphy, uint32_t root, float *re, float *im)
+{
+    LIBLTE_PHY_STRUCT *phy = (LIBLTE_PHY_STRUCT *)vphy;
+    memcpy(re, phy->prach_x_u_fft_re[root], sizeof(float) * 839);
+    memcpy(im, phy->prach_x_u_fft_im[root], sizeof(float) * 839);
+}
 // DMRS of (subframe, N_prb) as ul_init left it in the struct: out = dmrs_0_re | dmrs_0_im | dmrs_1_re | dmrs_1_im, M each
 void ref_get_pusch_dmrs(void *vphy, uint32_t N_subfr, uint32_t N_prb, float *out)
 {

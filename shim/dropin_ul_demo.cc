@@ -6,6 +6,8 @@
 //
 //   dropin_ul_* <capture.bin> <N_rb_ul> <N_id_cell> <subframe> <delta_ss> <group_hop> <seq_hop> <cs> <cs_dci>
 //               then per UE: <mod> <tbs> <rnti> <first_prb> <N_prb>
+//   with PRACH_CAPTURE=<file> PRACH_CFG="root,fmt,zczc,hs,freq_offset" in the environment it also runs liblte_phy_detect_prach
+//   over that capture (one occasion starting at the file's first sample)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -20,7 +22,9 @@ int main(int argc, char **argv)
                                 : N_rb <= 50 ? LIBLTE_PHY_FS_15_36MHZ : LIBLTE_PHY_FS_30_72MHZ;
     LIBLTE_PHY_STRUCT *phy = NULL;
     if (LIBLTE_SUCCESS != liblte_phy_init(&phy, fs, cell, 1, N_rb, 12, 1.0f)) return 3;
-    if (LIBLTE_SUCCESS != liblte_phy_ul_init(phy, cell, 0, 0, 1, false, atoi(argv[5]), atoi(argv[6]) != 0, atoi(argv[7]) != 0, atoi(argv[8]),
+    uint32 pr[5] = {0, 0, 1, 0, 0};
+    if (getenv("PRACH_CFG")) sscanf(getenv("PRACH_CFG"), "%u,%u,%u,%u,%u", &pr[0], &pr[1], &pr[2], &pr[3], &pr[4]);
+    if (LIBLTE_SUCCESS != liblte_phy_ul_init(phy, cell, pr[0], pr[1], pr[2], pr[3] != 0, atoi(argv[5]), atoi(argv[6]) != 0, atoi(argv[7]) != 0, atoi(argv[8]),
                                              atoi(argv[9]), 0, 1))
         return 3;
     const uint32 n = phy->N_samps_per_subfr;
@@ -53,6 +57,22 @@ int main(int argc, char **argv)
         uint32 h = 2166136261u; // FNV-1a over the decoded bits
         for (uint32 i = 0; i < nb; i++) h = (h ^ out[i]) * 16777619u;
         printf("rnti 0x%x: err=%d N_out_bits=%u hash=%08x\n", (unsigned)al->rnti, (int)e, nb, h);
+    }
+    if (getenv("PRACH_CAPTURE")) {
+        FILE *pf = fopen(getenv("PRACH_CAPTURE"), "rb");
+        if (!pf) return 6;
+        const uint32 np = phy->prach_T_cp + 2 * phy->prach_T_fft;
+        float *pi_s = (float *)calloc(np + 64, sizeof(float)), *pq_s = (float *)calloc(np + 64, sizeof(float));
+        for (uint32 k = 0; k < np; k++) {
+            signed char v[2];
+            if (fread(v, 1, 2, pf) != 2) break;
+            pi_s[k] = v[0];
+            pq_s[k] = v[1];
+        }
+        fclose(pf);
+        uint32 nd = 0, dp = 0, ta = 0;
+        LIBLTE_ERROR_ENUM e = liblte_phy_detect_prach(phy, pi_s, pq_s, pr[4], &nd, &dp, &ta);
+        printf("prach: err=%d N_det_pre=%u det_pre=%u det_ta=%u\n", (int)e, nd, nd ? dp : 0, nd ? ta : 0);
     }
     liblte_phy_cleanup(phy);
     return 0;

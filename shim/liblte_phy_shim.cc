@@ -8,6 +8,7 @@
 //     liblte_phy_rate_unmatch_turbo       liblte_phy.h:1311-1323   (impl. liblte_phy.cc:11246-11490)
 //     liblte_phy_get_ul_subframe          liblte_phy.h:1190-1193   (impl. liblte_phy.cc:6209-6236)
 //     liblte_phy_pusch_channel_decode     liblte_phy.h:722-728     (impl. liblte_phy.cc:2801-2935)
+//     liblte_phy_detect_prach             liblte_phy.h:862-868     (impl. liblte_phy.cc:3299-3479)
 //
 // by forwarding to libmi_lte.so's C-ABI (include/mi_lte.h).  The reference's own definitions of
 // these symbols are kept out of the link by compiling liblte_phy.cc with
@@ -126,4 +127,20 @@ LIBLTE_ERROR_ENUM liblte_phy_pusch_channel_decode(LIBLTE_PHY_STRUCT *phy_struct,
                                               N_id_cell, N_ant, phy_struct->pusch_dmrs_0_re[sf][np], phy_struct->pusch_dmrs_0_im[sf][np],
                                               phy_struct->pusch_dmrs_1_re[sf][np], phy_struct->pusch_dmrs_1_im[sf][np], out_bits, N_out_bits);
     return rc == 0 ? LIBLTE_SUCCESS : LIBLTE_ERROR_INVALID_INPUTS; // the reference's own failure code on this path (:2809, :2929)
+}
+
+LIBLTE_ERROR_ENUM liblte_phy_detect_prach(LIBLTE_PHY_STRUCT *phy_struct, float *samps_re, float *samps_im, uint32 freq_offset,
+                                          uint32 *N_det_pre, uint32 *det_pre, uint32 *det_ta)
+{
+    if (phy_struct == NULL || samps_re == NULL || samps_im == NULL || N_det_pre == NULL || det_pre == NULL || det_ta == NULL ||
+        !phy_struct->ul_init || phy_struct->prach_preamble_format > 3)
+        return LIBLTE_ERROR_INVALID_INPUTS; // (format 4 is TDD-only; this shim covers the FDD formats)
+    mi_lte_ctx *c = ctx_for(phy_struct);
+    if (!c) return LIBLTE_ERROR_INVALID_INPUTS;
+    mi_lte_prach_cfg pc = {phy_struct->prach_root_seq_idx, phy_struct->prach_preamble_format, phy_struct->prach_zczc,
+                           phy_struct->prach_hs_flag ? 1u : 0u, freq_offset};
+    // the root sequences' spectra are the ones liblte_phy_ul_init (still the reference's code) left in the struct
+    int rc = mi_lte_detect_prach_host(c, phy_struct->N_samps_per_symb, phy_struct->N_rb_ul, &pc, &phy_struct->prach_x_u_fft_re[0][0],
+                                      &phy_struct->prach_x_u_fft_im[0][0], phy_struct->prach_N_x_u, samps_re, samps_im, N_det_pre, det_pre, det_ta);
+    return rc == 0 ? LIBLTE_SUCCESS : LIBLTE_ERROR_INVALID_INPUTS;
 }

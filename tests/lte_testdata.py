@@ -133,3 +133,46 @@ def ref_ul_decode(R, case):
     R.ref_subframe_free(sfp)
     R.ref_phy_free(phy)
     return np.stack(symb), res
+
+
+# ---------------------------------------------------------------------------------------------------
+# PRACH occasions (rest of SURVEY 8f N1)
+
+PRACH_CASES = {
+    # name: (fft, N_rb_ul, root_seq_idx, preamble_format, zczc, hs_flag, freq_offset, preamble indices, delays, snr_db)
+    "1p4MHz_8roots": (128, 6, 22, 0, 11, 0, 0, [0, 5, 63, 17, 33], [0, 3, 10, 0, 7], 10.0),
+    "5MHz_1root": (512, 25, 100, 0, 1, 0, 2, [0, 40, 63], [0, 20, 5], 5.0),
+    "3MHz_restricted": (256, 15, 300, 0, 6, 1, 1, [2, 9, 30], [1, 4, 0], 10.0),
+    "1p4MHz_noise_only": (128, 6, 22, 0, 11, 0, 0, [0], [0], -30.0),
+}
+
+
+def prach_case(name, seed=3):
+    import openlte_amd as m
+    from openlte_amd import synth
+    fft, nrb, root, fmt, zczc, hs, fo, pre, dly, snr = PRACH_CASES[name]
+    cfg, pc = m.DlCfg(fft, nrb, 1, 0), m.PrachCfg(root, fmt, zczc, hs, fo)
+    iq = synth.prach_occasions(cfg, pc, pre, dly, snr_db=snr, seed=seed)
+    return dict(cfg=cfg, pc=pc, iq=iq, fft=fft, nrb=nrb, args=(root, fmt, zczc, hs), fo=fo)
+
+
+def ref_prach_detect(R, case):
+    """The compiled reference's liblte_phy_detect_prach over a case -> uint32 [n_occ, 3] (N_det_pre, det_pre, det_ta); the last two
+    are reported as 0 when nothing was detected (the reference leaves them untouched)."""
+    import ctypes as C
+    from oracle import pyoracle as po
+    phy = R.ref_phy_new(po.FS_ENUM[case["fft"]], 1, 1, case["nrb"])
+    assert R.ref_ul_init_prach(phy, 1, *case["args"]) == 0
+    out = []
+    for o in range(case["iq"].shape[0]):
+        re = np.ascontiguousarray(case["iq"][o, :, 0].astype(np.float32))
+        im = np.ascontiguousarray(case["iq"][o, :, 1].astype(np.float32))
+        n, p, ta = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        assert R.ref_detect_prach(phy, re, im, case["fo"], C.byref(n), C.byref(p), C.byref(ta)) == 0
+        out.append((n.value, p.value if n.value else 0, ta.value if n.value else 0))
+    n_roots = R.ref_prach_n_roots(phy)
+    re, im = np.zeros((n_roots, 839), np.float32), np.zeros((n_roots, 839), np.float32)
+    for r in range(n_roots):
+        R.ref_get_prach_root_fft(phy, r, re[r], im[r])
+    R.ref_phy_free(phy)
+    return np.array(out, np.uint32), (re, im)

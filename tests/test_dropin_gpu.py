@@ -95,19 +95,31 @@ def _ul_demo_args(tmp_path):
     return args
 
 
+def _ul_demo_env(tmp_path):
+    """One 20 MHz PRACH occasion (preamble 37 of root index 5, 80 samples late) for the demo's liblte_phy_detect_prach call."""
+    import openlte_amd as m
+    from openlte_amd import synth
+    cfg, pc = m.DlCfg(2048, 100, 1, 0), m.PrachCfg(5, 0, 12, 0, 3)
+    iq = synth.prach_occasions(cfg, pc, [37], [80], snr_db=5.0, seed=8)
+    path = os.path.join(str(tmp_path), "prach.bin")
+    iq[0].tofile(path)
+    return dict(os.environ, PRACH_CAPTURE=path, PRACH_CFG="5,0,12,0,3")
+
+
 def test_uplink_dropin_demo_matches_reference_output(tmp_path):
-    """liblte_phy_get_ul_subframe + liblte_phy_pusch_channel_decode through the shim == the unmodified reference."""
+    """liblte_phy_get_ul_subframe + liblte_phy_pusch_channel_decode + liblte_phy_detect_prach through the shim == the
+    unmodified reference."""
     exe = os.path.join(ROOT, "shim", "_build", "dropin_ul_gpu")
     if not os.path.exists(exe):
         pytest.skip("shim/_build/dropin_ul_gpu not built (needs the reference tree at build time)")
-    args = _ul_demo_args(tmp_path)
-    got = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+    args, env = _ul_demo_args(tmp_path), _ul_demo_env(tmp_path)
+    got = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300, env=env)
     assert got.returncode == 0, got.stdout + got.stderr
     lines = got.stdout.strip().splitlines()
     want = open(os.path.join(ROOT, "tests", "golden", "dropin_ul_demo_reference_cpu.txt")).read().strip().splitlines()
     cpu = os.path.join(ROOT, "shim", "_build", "dropin_ul_cpu")
     if os.path.exists(cpu):  # the reference-only build travelled too: it must still print the committed text
-        ref_now = subprocess.run([cpu] + args, capture_output=True, text=True, timeout=600).stdout.strip().splitlines()
+        ref_now = subprocess.run([cpu] + args, capture_output=True, text=True, timeout=600, env=env).stdout.strip().splitlines()
         assert ref_now == want
     assert lines[1:] == want[1:], (lines, want)  # per-UE verdict, bit count and hash of the decoded bits: identical text
     e_got, e_want = float(lines[0].split("=")[1]), float(want[0].split("=")[1])

@@ -61,6 +61,18 @@ def uplink_vectors(R):
     print("uplink_ref.npz:", sorted({k.split("_a")[0].rsplit("_", 1)[0] for k in rec}))
 
 
+def prach_vectors(R):
+    """PRACH detection: seeded occasions from the library's host transmitter + the reference's three outputs per occasion."""
+    rec = {}
+    for name in td.PRACH_CASES:
+        case = td.prach_case(name)
+        want, _ = td.ref_prach_detect(R, case)
+        rec[name + "_iq"] = case["iq"]
+        rec[name + "_det"] = want
+    np.savez_compressed(os.path.join(OUT, "prach_ref.npz"), **rec)
+    print("prach_ref.npz:", {k: rec[k + "_det"].tolist() for k in td.PRACH_CASES})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     R, P = po.ref(), po.port()
@@ -69,6 +81,7 @@ def main():
     turbo_ref_vectors(R, P, phy)
     R.ref_phy_free(phy)
     uplink_vectors(R)
+    prach_vectors(R)
 
 
 if __name__ == "__main__":

@@ -273,6 +273,59 @@ int      mi_lte_prach_detect_run(mi_lte_ctx *ctx, mi_lte_prach_plan *plan, const
                                  const uint64_t *d_occ_start, uint32_t n_occ, uint32_t *h_N_det_pre, uint32_t *h_det_pre,
                                  uint32_t *h_det_ta);
 
+/* ---------------------------------------------------------------- PCFICH + PDCCH (common search space)
+ * mi_lte_pdcch_plan_* / mi_lte_pdcch_decode_run replace liblte_phy_pdcch_channel_decode()
+ * (liblte/hdr/liblte_phy.h:1012-1020, implementation liblte/src/liblte_phy.cc:4519-5135) for a batch of device
+ * subframes -- the call that sits between liblte_phy_get_dl_subframe_and_ce and liblte_phy_pdsch_channel_decode in the
+ * reference's receiver (LTE_fdd_dl_fs_samp_buf.cc:445-470).  Per subframe: the control-format indicator from the
+ * PCFICH, N_symbs = cfi (+1 for N_rb_dl <= 10), and the DCIs found for SI-, P- and RA-RNTI in the reference's six
+ * common-search-space candidates (four at aggregation level 4, two at level 8; formats 1A and 1C each), in the
+ * reference's order and capped at LIBLTE_PHY_PDCCH_MAX_ALLOC = 6.  Each DCI comes raw (payload bits) and unpacked into
+ * the allocation liblte_phy_pdsch_channel_decode needs (dci_1a_unpack :13273-13378, dci_1c_unpack :13400-13611);
+ * a DCI that does not unpack is dropped like the reference does.  h_rc[u] is the reference's return value for the
+ * subframe: 3 (LIBLTE_ERROR_INVALID_CRC, h_cfi[u] = 0) when the PCFICH did not decode, else what its last DCI unpacker
+ * call returned (0 or 4), or 1 (LIBLTE_ERROR_INVALID_INPUTS, its initial value) when no DCI was found.
+ * Candidates reaching past the subframe's last CCE are decoded with the missing CCEs as erasures -- the reference reads
+ * stale scratch there, zeros on a fresh LIBLTE_PHY_STRUCT.
+ *
+ * The plan holds the resource-element index tables of the listed cells (a cell the plan was not built for decodes
+ * as cfi = 0).  PHICH: only the positions are needed (its REGs are excluded from the PDCCH), normal duration only --
+ * the reference does not handle the extended duration either (:8280-8283).
+ *
+ * Transmit diversity: the reference passes its per-port estimate array [4][288] to the combiner with a port stride of
+ * 576 (:4881, :7935), so with two ports the second port's estimate is read as zero and with four ports the rows are
+ * scrambled and nothing decodes.  By default the plan reproduces exactly that arithmetic (parity with the reference,
+ * rows it never writes taken as the zeros of a fresh LIBLTE_PHY_STRUCT); MI_LTE_PDCCH_PER_PORT_ESTIMATES gives every
+ * port its own estimate instead -- the decoder the reference meant, which does decode 4-port cells. */
+#define MI_LTE_PDCCH_MAX_DCI 6
+#define MI_LTE_PDCCH_PER_PORT_ESTIMATES 1u
+typedef struct {
+    uint32_t rnti;         /* 0xFFFF SI, 0xFFFE P, 0x0001..0x003C RA                               */
+    uint32_t format;       /* 0 = DCI 1A, 1 = DCI 1C                                              */
+    uint32_t candidate;    /* 0..3 aggregation level 4 (CCE 4*c), 4..5 aggregation level 8        */
+    uint32_t n_bits;       /* DCI size for this bandwidth (:4835-4857)                            */
+    uint32_t payload;      /* the DCI, first bit in bit n_bits-1                                  */
+    uint32_t mcs;
+    uint32_t alloc_valid;  /* the DCI unpacked into alloc                                         */
+    uint32_t reserved;
+    mi_lte_pdsch_alloc alloc; /* unit, mod_type, tbs, rv_idx, tx_mode, rnti, N_prb, prb[2][N_prb]   */
+} mi_lte_pdcch_dci;
+typedef struct mi_lte_pdcch_plan mi_lte_pdcch_plan;
+int  mi_lte_pdcch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, float phich_res /* N_g: 1/6, 1/2, 1, 2 */,
+                              uint32_t phich_dur_extended, uint32_t flags, const uint32_t *h_cells, uint32_t n_cells,
+                              mi_lte_pdcch_plan **out);
+void mi_lte_pdcch_plan_destroy(mi_lte_ctx *ctx, mi_lte_pdcch_plan *plan);
+int  mi_lte_pdcch_decode_run(mi_lte_ctx *ctx, mi_lte_pdcch_plan *plan, const float *d_subframes, const uint32_t *d_subfr_num,
+                             const uint32_t *d_n_id_cell, uint32_t n_units, uint32_t *h_rc, uint32_t *h_cfi, uint32_t *h_n_symbs,
+                             uint32_t *h_n_dci, mi_lte_pdcch_dci *h_dci /* [n_units][MI_LTE_PDCCH_MAX_DCI] */);
+/* the plan's index tables on their own (host arithmetic): grid index l*1200 + k of the 16 PCFICH resource elements and of
+ * the six candidates' resource elements in decoding order (0xFFFFFFFF: CCE past the subframe's last one) */
+int  mi_lte_pdcch_re_tables(uint32_t N_rb_dl, uint32_t N_ant, uint32_t N_id_cell, float phich_res, uint32_t N_symbs,
+                            uint32_t *pcfich /* [16] */, uint32_t *cand /* [6][288] */);
+/* the two DCI unpackers on their own (host arithmetic; what the shim and tests compare with the reference's) */
+int  mi_lte_dci_1a_unpack(uint32_t payload, uint32_t n_bits, uint32_t rnti, uint32_t N_rb_dl, uint32_t N_ant, mi_lte_pdcch_dci *out);
+int  mi_lte_dci_1c_unpack(uint32_t payload, uint32_t n_bits, uint32_t rnti, uint32_t N_rb_dl, uint32_t N_ant, mi_lte_pdcch_dci *out);
+
 /* ---------------------------------------------------------------- per-call host-pointer forms
  * The bodies of the reference's three entry points on this path, for callers that hold host
  * buffers exactly as the reference's callers do (LTE_fdd_dl_fs_samp_buf.cc:378-515,

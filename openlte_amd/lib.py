@@ -47,6 +47,11 @@ def make_alloc(unit, mod_type, tbs, prbs, rnti, rv_idx=0, tx_mode=1, prbs_slot1=
     return a
 
 
+class PdcchDci(C.Structure):
+    """mi_lte_pdcch_dci"""
+    _fields_ = [(n, C.c_uint32) for n in ("rnti", "format", "candidate", "n_bits", "payload", "mcs", "alloc_valid", "reserved")] + [("alloc", PdschAlloc)]
+
+
 class MiLteError(RuntimeError):
     pass
 
@@ -124,6 +129,12 @@ def load_library():
     L.mi_lte_prach_occasion_samples.argtypes = [vp]
     L.mi_lte_prach_occasion_samples.restype = u32
     L.mi_lte_prach_detect_run.argtypes = [vp, vp, vp, vp, vp, u32, u32p, u32p, u32p]
+    L.mi_lte_pdcch_plan_create.argtypes = [vp, C.POINTER(DlCfg), C.c_float, u32, u32, u32p, u32, C.POINTER(vp)]
+    L.mi_lte_pdcch_plan_destroy.argtypes = [vp, vp]
+    L.mi_lte_pdcch_decode_run.argtypes = [vp, vp, vp, vp, vp, u32, u32p, u32p, u32p, u32p, C.POINTER(PdcchDci)]
+    L.mi_lte_pdcch_re_tables.argtypes = [u32, u32, u32, C.c_float, u32, u32p, u32p]
+    L.mi_lte_dci_1a_unpack.argtypes = [u32, u32, u32, u32, u32, C.POINTER(PdcchDci)]
+    L.mi_lte_dci_1c_unpack.argtypes = [u32, u32, u32, u32, u32, C.POINTER(PdcchDci)]
     L.mi_lte_turbo_decode_batch.argtypes = [vp, vp, C.c_int, u32, u32, C.c_int, u32, C.c_int, vp]
     L.mi_lte_turbo_scratch_bytes.argtypes = [u32, u32]
     L.mi_lte_turbo_scratch_bytes.restype = sz
@@ -292,6 +303,47 @@ class PrachPlan:
             self.h = None
 
 
+class PdcchPlan:
+    """mi_lte_pdcch_plan: PCFICH / PDCCH resource-element tables of the listed cells."""
+
+    def __init__(self, ctx, cfg, cells, phich_res=1.0, phich_dur_extended=0, per_port_estimates=False):
+        self.ctx = ctx
+        h = C.c_void_p()
+        cells = np.ascontiguousarray(cells, np.uint32)
+        ctx._check(ctx.L.mi_lte_pdcch_plan_create(ctx.h, C.byref(cfg), float(phich_res), int(phich_dur_extended), 1 if per_port_estimates else 0, cells,
+                                                  len(cells), C.byref(h)))
+        self.h = h
+
+    def decode_dev(self, d_subframes, d_sf, d_cell, n_units):
+        """(rc[n], cfi[n], n_symbs[n], list of per-unit lists of PdcchDci)"""
+        rc, cfi, nsym, ndci = (np.zeros(n_units, np.uint32) for _ in range(4))
+        dci = (PdcchDci * (6 * n_units))()
+        self.ctx._check(self.ctx.L.mi_lte_pdcch_decode_run(self.ctx.h, self.h, d_subframes.ptr, d_sf.ptr, d_cell.ptr, n_units, rc, cfi, nsym, ndci, dci))
+        return rc, cfi, nsym, [[dci[6 * u + k] for k in range(int(ndci[u]))] for u in range(n_units)]
+
+    def close(self):
+        if self.h:
+            self.ctx.L.mi_lte_pdcch_plan_destroy(self.ctx.h, self.h)
+            self.h = None
+
+
+def pdcch_re_tables(n_rb_dl, n_ant, cell, phich_res, n_symbs):
+    """(pcfich[16], cand[6, 288]) uint32 grid indices l*1200 + k (host function of the library)."""
+    pc, cand = np.zeros(16, np.uint32), np.zeros((6, 288), np.uint32)
+    rc = load_library().mi_lte_pdcch_re_tables(n_rb_dl, n_ant, cell, float(phich_res), n_symbs, pc, cand)
+    if rc != 0:
+        raise MiLteError("mi_lte_pdcch_re_tables failed: %d" % rc)
+    return pc, cand
+
+
+def dci_unpack(fmt, payload, n_bits, rnti, n_rb_dl, n_ant):
+    """(rc, PdcchDci): the library's DCI 1A (fmt 0) / 1C (fmt 1) unpacker (host arithmetic)."""
+    d = PdcchDci()
+    L = load_library()
+    f = L.mi_lte_dci_1a_unpack if fmt == 0 else L.mi_lte_dci_1c_unpack
+    return f(int(payload), int(n_bits), int(rnti), int(n_rb_dl), int(n_ant), C.byref(d)), d
+
+
 def ul_dmrs_pusch(ulcfg, n_id_cell, n_subfr, n_prb):
     """float32 [4, 12*n_prb]: dmrs_0_re, dmrs_0_im, dmrs_1_re, dmrs_1_im (host function of the library)."""
     out = np.zeros((4, 12 * n_prb), np.float32)
@@ -417,6 +469,9 @@ class Context:
 
     def prach_plan(self, cfg, prach_cfg, roots_fft=None):
         return PrachPlan(self, cfg, prach_cfg, roots_fft)
+
+    def pdcch_plan(self, cfg, cells, phich_res=1.0, per_port_estimates=False):
+        return PdcchPlan(self, cfg, cells, phich_res, 0, per_port_estimates)
 
     def pusch_plan(self, cfg, ulcfg, unit_subfr_num, unit_n_id_cell, allocs):
         return PuschPlan(self, cfg, ulcfg, unit_subfr_num, unit_n_id_cell, allocs)

@@ -123,6 +123,8 @@ def ref():
     vp = C.c_void_p
     L.ref_phy_new.restype = vp
     L.ref_phy_new.argtypes = [C.c_int] * 4
+    L.ref_phy_new_phich.restype = vp
+    L.ref_phy_new_phich.argtypes = [C.c_int] * 4 + [C.c_float]
     L.ref_phy_free.argtypes = [vp]
     L.ref_sizeof_phy_struct.restype = C.c_size_t
     L.ref_sizeof_subframe_struct.restype = C.c_size_t
@@ -189,6 +191,12 @@ def ref():
     L.ref_get_prach_root_fft.argtypes = [vp, u32, f32p, f32p]
     L.ref_time_pusch.argtypes = [vp, f32p, f32p, vp, C.POINTER(LoAlloc), u32, u32, u32]
     L.ref_time_pusch.restype = C.c_double
+    # control channels
+    L.ref_pdcch_channel_encode.argtypes = [vp, vp, u32, C.POINTER(LoAlloc), u32p, u32, u32, u32, C.c_float]
+    L.ref_pdcch_channel_decode.argtypes = [vp, vp, u32, u32, C.c_float, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(LoAlloc), u32p, u32p]
+    L.ref_time_pdcch.argtypes = [vp, vp, u32, u32, C.c_float, u32]
+    L.ref_time_pdcch.restype = C.c_double
+    L.ref_dci_unpack.argtypes = [u32, u8p, u32, u32, u32, u32, C.POINTER(LoAlloc), C.POINTER(u32), u32p]
     _REF = L
     return L
 

@@ -46,6 +46,11 @@ void pre_decoder_and_matched_filter_dl(float *y_re, float *y_im, float *h_re, fl
                                        uint32 M_ap_symb, uint8 N_ant, LIBLTE_PHY_PRE_CODER_TYPE_ENUM type,
                                        float *x_re, float *x_im, uint32 *M_layer_symb);
 
+LIBLTE_ERROR_ENUM dci_1a_unpack(uint8 *in_bits, uint32 N_in_bits, LIBLTE_PHY_DCI_CA_PRESENCE_ENUM ca_presence, uint16 rnti,
+                                uint32 N_rb_dl, uint8 N_ant, LIBLTE_PHY_ALLOCATION_STRUCT *alloc);
+LIBLTE_ERROR_ENUM dci_1c_unpack(uint8 *in_bits, uint32 N_in_bits, uint16 rnti, uint32 N_rb_dl, uint8 N_ant,
+                                LIBLTE_PHY_ALLOCATION_STRUCT *alloc);
+
 extern "C" {
 
 // Plain-C view of LIBLTE_PHY_ALLOCATION_STRUCT (liblte_phy.h:684-702) for ctypes callers.
@@ -92,6 +97,15 @@ void *ref_phy_new(int fs_enum, int N_id_cell, int N_ant, int N_rb_dl)
     LIBLTE_PHY_STRUCT *phy = NULL;
     if (LIBLTE_SUCCESS != liblte_phy_init(&phy, (LIBLTE_PHY_FS_ENUM)fs_enum, (uint16)N_id_cell, (uint8)N_ant,
                                           (uint32)N_rb_dl, LIBLTE_PHY_N_SC_RB_DL_NORMAL_CP, 1.0f))
+        return NULL;
+    return phy;
+}
+// liblte_phy_init pre-computes the transmitter's PDCCH REG permutations for one PHICH resource (liblte_phy.cc:2292)
+void *ref_phy_new_phich(int fs_enum, int N_id_cell, int N_ant, int N_rb_dl, float phich_res)
+{
+    LIBLTE_PHY_STRUCT *phy = NULL;
+    if (LIBLTE_SUCCESS != liblte_phy_init(&phy, (LIBLTE_PHY_FS_ENUM)fs_enum, (uint16)N_id_cell, (uint8)N_ant,
+                                          (uint32)N_rb_dl, LIBLTE_PHY_N_SC_RB_DL_NORMAL_CP, phich_res))
         return NULL;
     return phy;
 }
@@ -341,6 +355,81 @@ void ref_samples_to_symbols_dl(void *phy, float *re, float *im, uint32_t slot_st
 {
     samples_to_symbols_dl((LIBLTE_PHY_STRUCT *)phy, re, im, slot_start_idx, symbol_offset, 0, symb_re, symb_im);
 }
+
+// ---- control channels: PCFICH / PHICH / PDCCH encode and decode, the DCI unpackers ----
+static void read_alloc(const LIBLTE_PHY_ALLOCATION_STRUCT *a, ref_alloc_t *r, uint32_t *mcs, uint32_t *prb_slot1)
+{
+    memset(r, 0, sizeof(*r));
+    r->mod_type = a->mod_type; r->tbs = a->tbs; r->rv_idx = a->rv_idx; r->N_prb = a->N_prb; r->tx_mode = a->tx_mode;
+    r->rnti = a->rnti; r->pre_coder_type = a->pre_coder_type; r->N_codewords = a->N_codewords;
+    for (uint32_t i = 0; i < a->N_prb && i < 110; i++) { r->prb[i] = a->prb[0][i]; prb_slot1[i] = a->prb[1][i]; }
+    *mcs = a->mcs;
+}
+
+int ref_pdcch_channel_encode(void *phy, void *sf, uint32_t cfi, const ref_alloc_t *allocs, const uint32_t *mcs, uint32_t n_alloc,
+                             uint32_t N_id_cell, uint32_t N_ant, float phich_res)
+{
+    LIBLTE_PHY_PCFICH_STRUCT pcfich;
+    LIBLTE_PHY_PHICH_STRUCT  phich;
+    LIBLTE_PHY_PDCCH_STRUCT *pdcch = (LIBLTE_PHY_PDCCH_STRUCT *)calloc(1, sizeof(LIBLTE_PHY_PDCCH_STRUCT));
+    memset(&pcfich, 0, sizeof(pcfich));
+    memset(&phich, 0, sizeof(phich));
+    pcfich.cfi     = cfi;
+    pdcch->N_alloc = n_alloc;
+    for (uint32_t a = 0; a < n_alloc && a < LIBLTE_PHY_PDCCH_MAX_ALLOC; a++) {
+        fill_alloc(&pdcch->alloc[a], &allocs[a], NULL);
+        pdcch->alloc[a].mcs = (uint8)mcs[a];
+    }
+    int err = (int)liblte_phy_pdcch_channel_encode((LIBLTE_PHY_STRUCT *)phy, &pcfich, &phich, pdcch, N_id_cell, (uint8)N_ant, phich_res,
+                                                   LIBLTE_RRC_PHICH_DURATION_NORMAL, (LIBLTE_PHY_SUBFRAME_STRUCT *)sf);
+    free(pdcch);
+    return err;
+}
+
+int ref_pdcch_channel_decode(void *phy, void *sf, uint32_t N_id_cell, uint32_t N_ant, float phich_res, uint32_t *cfi, uint32_t *N_symbs,
+                             uint32_t *N_alloc, ref_alloc_t *allocs /*[6]*/, uint32_t *mcs /*[6]*/, uint32_t *prb_slot1 /*[6][110]*/)
+{
+    LIBLTE_PHY_PCFICH_STRUCT pcfich;
+    LIBLTE_PHY_PHICH_STRUCT  phich;
+    LIBLTE_PHY_PDCCH_STRUCT *pdcch = (LIBLTE_PHY_PDCCH_STRUCT *)calloc(1, sizeof(LIBLTE_PHY_PDCCH_STRUCT));
+    memset(&pcfich, 0, sizeof(pcfich));
+    memset(&phich, 0, sizeof(phich));
+    int err = (int)liblte_phy_pdcch_channel_decode((LIBLTE_PHY_STRUCT *)phy, (LIBLTE_PHY_SUBFRAME_STRUCT *)sf, N_id_cell, (uint8)N_ant, phich_res,
+                                                   LIBLTE_RRC_PHICH_DURATION_NORMAL, &pcfich, &phich, pdcch);
+    *cfi = pcfich.cfi; *N_symbs = pdcch->N_symbs; *N_alloc = pdcch->N_alloc;
+    for (uint32_t a = 0; a < pdcch->N_alloc && a < LIBLTE_PHY_PDCCH_MAX_ALLOC; a++)
+        read_alloc(&pdcch->alloc[a], &allocs[a], &mcs[a], prb_slot1 + 110 * a);
+    free(pdcch);
+    return err;
+}
+
+double ref_time_pdcch(void *phy, void *sf, uint32_t N_id_cell, uint32_t N_ant, float phich_res, uint32_t reps)
+{
+    LIBLTE_PHY_PCFICH_STRUCT pcfich;
+    LIBLTE_PHY_PHICH_STRUCT  phich;
+    LIBLTE_PHY_PDCCH_STRUCT *pdcch = (LIBLTE_PHY_PDCCH_STRUCT *)calloc(1, sizeof(LIBLTE_PHY_PDCCH_STRUCT));
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (uint32_t r = 0; r < reps; r++)
+        liblte_phy_pdcch_channel_decode((LIBLTE_PHY_STRUCT *)phy, (LIBLTE_PHY_SUBFRAME_STRUCT *)sf, N_id_cell, (uint8)N_ant, phich_res,
+                                        LIBLTE_RRC_PHICH_DURATION_NORMAL, &pcfich, &phich, pdcch);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    free(pdcch);
+    return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+}
+
+// format 0 = 1A, 1 = 1C; the allocation starts zeroed
+int ref_dci_unpack(uint32_t format, uint8_t *bits, uint32_t n_bits, uint32_t rnti, uint32_t N_rb_dl, uint32_t N_ant, ref_alloc_t *out,
+                   uint32_t *mcs, uint32_t *prb_slot1 /*[110]*/)
+{
+    LIBLTE_PHY_ALLOCATION_STRUCT *a = (LIBLTE_PHY_ALLOCATION_STRUCT *)calloc(1, sizeof(*a));
+    int err = format == 0 ? (int)dci_1a_unpack(bits, n_bits, LIBLTE_PHY_DCI_CA_NOT_PRESENT, (uint16)rnti, N_rb_dl, (uint8)N_ant, a)
+                          : (int)dci_1c_unpack(bits, n_bits, (uint16)rnti, N_rb_dl, (uint8)N_ant, a);
+    read_alloc(a, out, mcs, prb_slot1);
+    free(a);
+    return err;
+}
+
 
 // CPU-baseline timing helpers ------------------------------------------------------------
 // ---- uplink: liblte_phy_ul_init / get_ul_subframe / pusch_channel_decode, unmodified

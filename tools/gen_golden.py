@@ -73,6 +73,31 @@ def prach_vectors(R):
     print("prach_ref.npz:", {k: rec[k + "_det"].tolist() for k in td.PRACH_CASES})
 
 
+def pdcch_vectors(R):
+    """PCFICH/PDCCH: received control-region grids (symbols 0-3 only) built by tests/lte_testdata.pdcch_case with the reference's
+    transmitter, and what liblte_phy_pdcch_channel_decode returned for them."""
+    rec, names = {}, []
+    for name in td.PDCCH_CASES:
+        case = td.pdcch_case(R, name)
+        keep = min(len(case["sfs"]), 3)
+        case["sfs"], case["grids"] = case["sfs"][:keep], case["grids"][:keep]
+        want = td.ref_pdcch_decode(R, case)
+        names.append(name)
+        rec[name + "_cfg"] = np.array([case["fft"], case["nrb"], case["n_ant"], case["cell"]], np.uint32)
+        rec[name + "_phich_res"] = np.float32(case["phich_res"])
+        rec[name + "_sfs"] = np.array(case["sfs"], np.uint32)
+        rec[name + "_grids"] = case["grids"][:, :, :4, :].astype(np.float32)
+        rec[name + "_rc"] = np.array([w[0] for w in want], np.uint32)
+        rec[name + "_cfi"] = np.array([w[1] for w in want], np.uint32)
+        rec[name + "_nsym"] = np.array([w[2] for w in want], np.uint32)
+        # per DCI: unit, rnti, mcs, tbs, rv, N_prb, tx_mode, mod_type, first PRB of slot 0, last PRB of slot 1
+        rows = [[u] + list(r[:7]) + [r[7][0] if r[7] else 0, r[8][-1] if r[8] else 0] for u, w in enumerate(want) for r in w[3]]
+        rec[name + "_dci"] = np.array(rows, np.int64).reshape(len(rows), 10)
+    rec["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "pdcch_ref.npz"), **rec)
+    print("pdcch_ref.npz:", {n: rec[n + "_dci"].shape[0] for n in names})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     R, P = po.ref(), po.port()
@@ -82,6 +107,7 @@ def main():
     R.ref_phy_free(phy)
     uplink_vectors(R)
     prach_vectors(R)
+    pdcch_vectors(R)
 
 
 if __name__ == "__main__":

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- one JSON line per run (driver contract).
 
-    python bench.py --gpus N --steps K --warmup W [--workload chain|frontend|turbo|uplink]
+    python bench.py --gpus N --steps K --warmup W [--workload chain|frontend|turbo|uplink|control]
 
 A "step" is one pass of the hot path over one batch of synthetic input that is already resident in
 HBM.  Work is sharded by unit (subframes / code blocks) over ranks with no data-path collective
@@ -430,6 +430,90 @@ class UplinkWorkload:
                           "%.1f s; FFT/DFT = float64 stand-in for FFTW3f (O(n^2) for the 72-point DFTs)" % (reps, t)}
 
 
+class ControlWorkload:
+    """the control region of every downlink subframe -- PCFICH + the PDCCH common search space (six candidates x
+    DCI formats 1A / 1C: rate un-matching, K = 7 Viterbi, CRC16, RNTI test, DCI unpacking) at 20 MHz, 1 port, CFI 2, with an
+    SI-RNTI and an RA-RNTI format-1A DCI per subframe.  One step = mi_lte_pdcch_decode_run over the batch of device
+    subframes (what the front end leaves in HBM), results on the host."""
+    name = "control"
+    metric = "DL subframes/sec @20MHz, PCFICH + PDCCH common-search-space decode (6 candidates x DCI 1A/1C), liblte_phy_pdcch_channel_decode (SURVEY 8f N3)"
+    unit = "subframes/s"
+    dtype = "f32 combiner / de-mapper, i32 soft bits and path metrics"
+    N_RE = 16 + 4 * 144  # distinct resource elements one subframe's decode reads (the two level-8 candidates re-read level-4 ones)
+    alg_bytes_per_unit = N_RE * 16 + 112
+    dominant = "k_pdcch_decode"
+
+    def __init__(self, ctx, n_units, rank):
+        import numpy as np
+        import openlte_amd as m
+        from openlte_amd import synth
+        self.ctx, self.m, self.np = ctx, m, np
+        self.n = n_units or 8192
+        self.cfg = m.DlCfg(2048, 100, 1, 0)
+        U = min(128, self.n)
+        self.cell = 17 + rank
+        rng = np.random.default_rng(99 + rank)
+        sfs = (np.arange(U) % 10).astype(np.uint32)
+        self.dcis = [[(0xFFFF, int(rng.integers(0, 27)), int(rng.integers(1, 9)), int(rng.integers(0, 90)), int(rng.integers(0, 4))),
+                      (int(rng.integers(1, 0x3D)), int(rng.integers(0, 27)), int(rng.integers(1, 9)), int(rng.integers(0, 90)), 0)] for _ in range(U)]
+        g = synth.ctrl_grids(self.cfg, sfs, [self.cell] * U, [2] * U, self.dcis, snr_db=15.0, seed=4242 + rank)
+        self.uniq = (g, sfs)
+        self.idx = np.arange(self.n) % U
+        self.d_sub = ctx.to_device(g[self.idx])
+        self.d_sf, self.d_cell = ctx.to_device(sfs[self.idx]), ctx.to_device(np.full(self.n, self.cell, np.uint32))
+        self.plan = ctx.pdcch_plan(self.cfg, [self.cell], 1.0)
+        self.last = None
+
+    def step(self):
+        self.last = self.plan.decode_raw(self.d_sub, self.d_sf, self.d_cell, self.n)
+
+    def units_per_step(self):
+        return self.n
+
+    def value_per_unit(self):
+        return 1.0
+
+    def extra(self, value):
+        rc, cfi, nsym, ndci, dci = self.last
+        ok = sum(1 for i in range(self.n)
+                 if {t[:4] for t in self.dcis[self.idx[i]]} <= {(dci[6 * i + k].alloc.rnti, dci[6 * i + k].mcs, dci[6 * i + k].alloc.N_prb,
+                                                                 dci[6 * i + k].alloc.prb[0][0]) for k in range(int(ndci[i]))})
+        return {"cfi_ok": "%d/%d" % (int((cfi == 2).sum()), self.n), "subframes_with_every_sent_dci_found": "%d/%d" % (ok, self.n),
+                "dci_per_s": round(value * 2, 1)}
+
+    def roofline_bytes(self, kernel, n_launch_per_step):
+        return {"k_pdcch_decode": self.n * self.alg_bytes_per_unit}.get(kernel)
+
+    def config(self, world):
+        return {"workload": "N3 control region: 20 MHz, 1 port, CFI 2, SI-RNTI + RA-RNTI DCI 1A per subframe, %d device subframes per GPU "
+                            "resident in HBM, results (CFI, DCIs, allocations) to the host" % self.n,
+                "subframes_per_gpu": self.n, "unique_subframes": len(self.uniq[1]), "mode": "reference arithmetic (parity mode)",
+                "sharding": "subframes block-cyclic over %d GPU(s), no collective" % world}
+
+    def cpu_baseline(self, budget_s=10.0):
+        """The reference's liblte_phy_pdcch_channel_decode on one core over one of the benchmark's subframes."""
+        np = self.np
+        from oracle import pyoracle as po
+        R = po.ref()
+        if R is None:
+            return None
+        g, sfs = self.uniq
+        phy = R.ref_phy_new(4, self.cell, 1, 100)
+        sfp = R.ref_subframe_new()
+        R.ref_subframe_set_num(sfp, int(sfs[0]))
+        po.ref_subframe_view(R, sfp, 0)[:] = g[0, 0]
+        po.ref_subframe_view(R, sfp, 1)[:] = g[0, 1]
+        po.ref_subframe_view(R, sfp, 2, True)[0] = g[0, 2]
+        po.ref_subframe_view(R, sfp, 3, True)[0] = g[0, 3]
+        t = R.ref_time_pdcch(phy, sfp, self.cell, 1, 1.0, 20)
+        reps = int(max(20, min(200000, budget_s / (t / 20))))
+        t = R.ref_time_pdcch(phy, sfp, self.cell, 1, 1.0, reps)
+        R.ref_subframe_free(sfp)
+        R.ref_phy_free(phy)
+        return {"value": round(reps / t, 3), "unit": self.unit, "cores": 1, "kind": "reference",
+                "sample": "%d repetitions of liblte_phy_pdcch_channel_decode on one of the benchmark's subframes, 1 thread, %.1f s" % (reps, t)}
+
+
 class MultiStream:
     """Run S independent shards of a workload on S contexts (= S HIP streams) of the same GPU, launched
     back to back and synchronised together.  Units are independent, so this is the same "shard by
@@ -437,7 +521,7 @@ class MultiStream:
     the lock-step trellis kernel 4+ waves per SIMD (32k subframes), one stream is the fastest."""
 
     def __init__(self, cls, ctxs, n_units, rank):
-        n_units = n_units or {"chain": 32768, "frontend": 10000, "turbo": 65536, "uplink": 16384}[cls.name]
+        n_units = n_units or {"chain": 32768, "frontend": 10000, "turbo": 65536, "uplink": 16384, "control": 8192}[cls.name]
         per = max(64, (n_units // len(ctxs) + 63) // 64 * 64)
         self.parts = [cls(c, per, rank * 16 + k) for k, c in enumerate(ctxs)]
         self.ctxs = ctxs
@@ -497,7 +581,7 @@ class MultiStream:
         return self.parts[0].cpu_baseline()
 
 
-WORKLOADS = {"turbo": TurboWorkload, "frontend": FrontendWorkload, "chain": ChainWorkload, "uplink": UplinkWorkload}
+WORKLOADS = {"turbo": TurboWorkload, "frontend": FrontendWorkload, "chain": ChainWorkload, "uplink": UplinkWorkload, "control": ControlWorkload}
 
 
 def pick_workload(name):

@@ -322,6 +322,9 @@ int  mi_lte_pdcch_decode_run(mi_lte_ctx *ctx, mi_lte_pdcch_plan *plan, const flo
  * the six candidates' resource elements in decoding order (0xFFFFFFFF: CCE past the subframe's last one) */
 int  mi_lte_pdcch_re_tables(uint32_t N_rb_dl, uint32_t N_ant, uint32_t N_id_cell, float phich_res, uint32_t N_symbs,
                             uint32_t *pcfich /* [16] */, uint32_t *cand /* [6][288] */);
+/* what the reference leaves in LIBLTE_PHY_PCFICH_STRUCT::k, n and LIBLTE_PHY_PHICH_STRUCT::N_reg, k (:7903-7910, :8243-8278) */
+int  mi_lte_ctrl_reg_positions(uint32_t N_rb_dl, uint32_t N_id_cell, float phich_res, uint32_t *pcfich_k /* [4] */,
+                               float *pcfich_n /* [4] */, uint32_t *phich_N_reg, uint32_t *phich_k /* [75] */);
 /* the two DCI unpackers on their own (host arithmetic; what the shim and tests compare with the reference's) */
 int  mi_lte_dci_1a_unpack(uint32_t payload, uint32_t n_bits, uint32_t rnti, uint32_t N_rb_dl, uint32_t N_ant, mi_lte_pdcch_dci *out);
 int  mi_lte_dci_1c_unpack(uint32_t payload, uint32_t n_bits, uint32_t rnti, uint32_t N_rb_dl, uint32_t N_ant, mi_lte_pdcch_dci *out);
@@ -341,6 +344,12 @@ int mi_lte_pdsch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const fl
                                      const float *h_rx_ce_re, const float *h_rx_ce_im, uint32_t subfr_num,
                                      const mi_lte_pdsch_alloc *alloc, uint32_t N_pdcch_symbs, uint32_t N_id_cell,
                                      uint32_t N_ant, uint8_t *h_out_bits, uint32_t *N_out_bits);
+/* liblte_phy_pdcch_channel_decode: returns the reference's value (0; 1 no DCI found; 3 PCFICH failed; 4 last DCI did
+ * not unpack) with *cfi, *N_symbs, *N_dci and dci[] as mi_lte_pdcch_decode_run writes them for one subframe */
+int mi_lte_pdcch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const float *h_rx_symb_re, const float *h_rx_symb_im,
+                                     const float *h_rx_ce_re, const float *h_rx_ce_im, uint32_t subfr_num, uint32_t N_id_cell,
+                                     uint32_t N_ant, float phich_res, uint32_t phich_dur_extended, uint32_t flags, uint32_t *cfi,
+                                     uint32_t *N_symbs, uint32_t *N_dci, mi_lte_pdcch_dci *dci /* [MI_LTE_PDCCH_MAX_DCI] */);
 /* uplink: liblte_phy_get_ul_subframe (h_i / h_q point at the subframe's first sample; 14 rows of 1200 floats are
  * written) and liblte_phy_pusch_channel_decode (the DMRS arrays are the caller's, i.e. what liblte_phy_ul_init
  * stored in LIBLTE_PHY_STRUCT::pusch_dmrs_{0,1}_{re,im}[subframe][N_prb]; a CRC failure returns 1 =
@@ -386,6 +395,17 @@ int    mi_lte_synth_dl_units_i8(const mi_lte_dl_cfg *cfg, uint32_t n_units, cons
                                 const uint32_t *h_n_id_cell, uint32_t N_pdcch_symbs, const mi_lte_pdsch_alloc *h_allocs,
                                 uint32_t n_alloc, const mi_lte_synth_channel *chan, int8_t *h_iq, uint8_t *h_tx_bits,
                                 uint32_t tbs_stride);
+
+/* control regions: PCFICH + n_dci format-1A DCIs (rnti = 0: slot unused) at aggregation level 4 in candidates 0..n_dci-1,
+ * standard transmit diversity on cfg->N_ant ports, through a smooth random channel per port (gain_min..gain_max) and
+ * AWGN (snr_db), written directly as device-subframe grids (mi_lte_subframe_floats(N_ant) floats per unit, symbols 0-3
+ * filled) with noisy channel estimates.  Input of mi_lte_pdcch_decode_run for the benchmark and the tests. */
+typedef struct {
+    uint32_t rnti, mcs, N_prb, rb_start, rv_idx;
+} mi_lte_synth_dci;
+int mi_lte_synth_ctrl_grids(const mi_lte_dl_cfg *cfg, float phich_res, uint32_t n_units, const uint32_t *h_subfr_num,
+                            const uint32_t *h_n_id_cell, const uint32_t *h_cfi, const mi_lte_synth_dci *h_dci, uint32_t n_dci,
+                            const mi_lte_synth_channel *chan, float *h_grids);
 
 /* n_units uplink subframes for tests / benchmarks: every unit carries n_alloc PUSCH transmissions
  * (allocs[u*n_alloc + a], .unit ignored) with random transport blocks, through one flat channel per unit.

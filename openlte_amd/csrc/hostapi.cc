@@ -93,6 +93,40 @@ int mi_lte_pdsch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const fl
     return rc != MI_LTE_OK ? rc : (int)st;
 }
 
+// liblte_phy_pdcch_channel_decode (liblte_phy.cc:4519-5135): PCFICH + common-search-space DCIs of one subframe
+int mi_lte_pdcch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const float *h_symb_re, const float *h_symb_im, const float *h_ce_re,
+                                     const float *h_ce_im, uint32_t subfr_num, uint32_t N_id_cell, uint32_t N_ant, float phich_res,
+                                     uint32_t phich_dur_extended, uint32_t flags, uint32_t *cfi, uint32_t *N_symbs, uint32_t *N_dci,
+                                     mi_lte_pdcch_dci *dci /*[MI_LTE_PDCCH_MAX_DCI]*/)
+{
+    if (!ctx) return MI_LTE_ERR_INVALID_ARG;
+    if (!h_symb_re || !h_symb_im || !h_ce_re || !h_ce_im || N_id_cell > 503 || !cfi || !N_symbs || !N_dci || !dci) return 1;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint32_t fft = N_rb_dl <= 6 ? 128 : N_rb_dl <= 15 ? 256 : N_rb_dl <= 25 ? 512 : N_rb_dl <= 50 ? 1024 : 2048;
+    mi_lte_dl_cfg      cfg  = {fft, N_rb_dl, N_ant, MI_LTE_IQ_F32_PLANAR};
+    mi_lte_pdcch_plan *plan = nullptr;
+    int rc = mi_lte_pdcch_plan_create(ctx, &cfg, phich_res, phich_dur_extended, flags, &N_id_cell, 1, &plan);
+    if (rc != MI_LTE_OK) return rc;
+    const size_t nf = mi_lte_subframe_floats(N_ant), row = 16 * 1200;
+    DevBuf d_sub, d_par;
+    if (d_sub.alloc(nf * 4) || d_par.alloc(16)) { mi_lte_pdcch_plan_destroy(ctx, plan); return MI_LTE_ERR_NOMEM; }
+    float   *s      = (float *)d_sub.p;
+    uint32_t par[2] = {subfr_num, N_id_cell}, h_rc = 1;
+    // only the control region is read: symbols 0..3
+    const size_t ctl = 4 * 1200 * sizeof(float);
+    hipError_t   e   = hipMemcpyAsync(s, h_symb_re, ctl, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(s + row, h_symb_im, ctl, hipMemcpyHostToDevice, ctx->stream);
+    for (uint32_t p = 0; p < N_ant && e == hipSuccess; p++) {
+        e = hipMemcpyAsync(s + (2 + p) * row, h_ce_re + p * row, ctl, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(s + (2 + N_ant + p) * row, h_ce_im + p * row, ctl, hipMemcpyHostToDevice, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(d_par.p, par, 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) { mi_lte_pdcch_plan_destroy(ctx, plan); ctx->err = hipGetErrorString(e); return MI_LTE_ERR_HIP; }
+    rc = mi_lte_pdcch_decode_run(ctx, plan, s, (const uint32_t *)d_par.p, (const uint32_t *)d_par.p + 1, 1, &h_rc, cfi, N_symbs, N_dci, dci);
+    mi_lte_pdcch_plan_destroy(ctx, plan);
+    return rc != MI_LTE_OK ? rc : (int)h_rc;
+}
+
 // liblte_phy_get_ul_subframe (liblte_phy.cc:6209-6236)
 int mi_lte_get_ul_subframe_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_ul, const float *h_i, const float *h_q, float *h_symb_re,
                                 float *h_symb_im)

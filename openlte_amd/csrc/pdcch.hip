@@ -29,6 +29,7 @@
 #include "ctx.hpp"
 #include "phy_dev.hpp"
 #include "lte_tables.h"
+#include "synth.hpp"
 
 namespace {
 
@@ -442,6 +443,20 @@ int mi_lte_pdcch_re_tables(uint32_t N_rb_dl, uint32_t N_ant, uint32_t N_id_cell,
     return MI_LTE_OK;
 }
 
+// PCFICH / PHICH resource-element-group positions as the reference reports them in LIBLTE_PHY_PCFICH_STRUCT::k, n and
+// LIBLTE_PHY_PHICH_STRUCT::k, N_reg (pcfich_channel_demap :7903-7910, phich_channel_demap :8243-8278)
+int mi_lte_ctrl_reg_positions(uint32_t N_rb_dl, uint32_t N_id_cell, float phich_res, uint32_t *pcfich_k /*[4]*/, float *pcfich_n /*[4]*/,
+                              uint32_t *phich_N_reg, uint32_t *phich_k /*[75]*/)
+{
+    if (!pcfich_k || !pcfich_n || !phich_N_reg || !phich_k || N_rb_dl < 6 || N_rb_dl > 100 || N_id_cell > 503) return MI_LTE_ERR_INVALID_ARG;
+    const CtrlRegs cr = ctrl_regs(N_rb_dl, N_id_cell, phich_res);
+    if (cr.phich_k.size() > 75) return MI_LTE_ERR_INVALID_ARG;
+    for (uint32_t i = 0; i < 4; i++) { pcfich_k[i] = cr.pcfich_k[i]; pcfich_n[i] = cr.pcfich_n[i]; }
+    *phich_N_reg = (uint32_t)cr.phich_k.size();
+    std::copy(cr.phich_k.begin(), cr.phich_k.end(), phich_k);
+    return MI_LTE_OK;
+}
+
 void mi_lte_pdcch_plan_destroy(mi_lte_ctx *ctx, mi_lte_pdcch_plan *pl)
 {
     if (!pl) return;
@@ -576,6 +591,123 @@ int mi_lte_pdcch_decode_run(mi_lte_ctx *ctx, mi_lte_pdcch_plan *pl, const float 
         h_rc[u]    = rc;
     }
     ctx->last_kernels = "k_pdcch_decode:1";
+    return MI_LTE_OK;
+}
+
+
+// ---- input synthesis (benchmark and tests): control regions as 36.211 / 36.212 transmit them --------------------------
+// PCFICH + up to four format-1A DCIs at aggregation level 4 in the common search space (what the reference's own
+// transmitter sends, liblte_phy.cc:4113-4330), through a smooth random channel per port + AWGN, directly as device-subframe
+// grids with noisy channel estimates.  Transmit diversity follows 36.211 6.3.4.3 on all ports.
+int mi_lte_synth_ctrl_grids(const mi_lte_dl_cfg *cfg, float phich_res, uint32_t n_units, const uint32_t *h_subfr_num, const uint32_t *h_n_id_cell,
+                            const uint32_t *h_cfi, const mi_lte_synth_dci *h_dci /*[n_units][n_dci]*/, uint32_t n_dci,
+                            const mi_lte_synth_channel *chan, float *h_grids)
+{
+    if (!cfg || !h_subfr_num || !h_n_id_cell || !h_cfi || (n_dci && !h_dci) || n_dci > 4 || !chan || !h_grids) return MI_LTE_ERR_INVALID_ARG;
+    const uint32_t nrb = cfg->N_rb_dl, n_ant = cfg->N_ant;
+    if (!(n_ant == 1 || n_ant == 2 || n_ant == 4)) return MI_LTE_ERR_INVALID_ARG;
+    uint32_t sz[2];
+    dci_sizes(nrb, &sz[0], &sz[1]);
+    const uint32_t K = sz[0] + 16;
+    std::vector<uint16_t> map(576);
+    conv_rm_map(K, 288, map.data());
+    const size_t plane = 16 * (size_t)N_SC_MAX, nf = (2 + 2 * (size_t)n_ant) * plane;
+    const double r2 = 1.0 / std::sqrt(2.0);
+    synth::Rng   rng(chan->seed);
+    std::vector<double> tr(n_ant * plane), ti(n_ant * plane);
+    std::vector<uint32_t> cand(N_CAND * RE_MAX);
+    uint32_t pcf[16];
+    for (uint32_t u = 0; u < n_units; u++) {
+        const uint32_t sf = h_subfr_num[u], cell = h_n_id_cell[u], cfi = h_cfi[u], n_symbs = cfi + (nrb <= 10 ? 1 : 0);
+        if (cfi < 1 || cfi > 4 || n_symbs > 4 || cell > 503 || sf > 9) return MI_LTE_ERR_INVALID_ARG;
+        int rc = mi_lte_pdcch_re_tables(nrb, n_ant, cell, phich_res, n_symbs, pcf, cand.data());
+        if (rc != MI_LTE_OK) return rc;
+        std::fill(tr.begin(), tr.end(), 0.0);
+        std::fill(ti.begin(), ti.end(), 0.0);
+        // d[0..n): QPSK symbols of scrambled bits b -> transmit-diversity pre-coding onto the elements pos[]
+        auto place = [&](const uint32_t *pos, const uint8_t *b, uint32_t n) {
+            std::vector<double> dr(n), di(n);
+            for (uint32_t i = 0; i < n; i++) { dr[i] = (1 - 2 * (int)b[2 * i]) * r2; di[i] = (1 - 2 * (int)b[2 * i + 1]) * r2; }
+            auto put = [&](uint32_t port, uint32_t p, double re, double im) { tr[port * plane + p] = re; ti[port * plane + p] = im; };
+            if (n_ant == 1) {
+                for (uint32_t i = 0; i < n; i++) put(0, pos[i], dr[i], di[i]);
+            } else {
+                for (uint32_t i = 0; i + 1 < n; i += 2) { // pairs (x0, x1): port a sends x0, x1; port b sends -x1*, x0*
+                    const uint32_t a = n_ant == 2 ? 0 : ((i & 2) ? 1 : 0), bb = n_ant == 2 ? 1 : ((i & 2) ? 3 : 2);
+                    put(a, pos[i], r2 * dr[i], r2 * di[i]);
+                    put(a, pos[i + 1], r2 * dr[i + 1], r2 * di[i + 1]);
+                    put(bb, pos[i], -r2 * dr[i + 1], r2 * di[i + 1]);
+                    put(bb, pos[i + 1], r2 * dr[i], -r2 * di[i]);
+                }
+            }
+        };
+        { // PCFICH (36.212 5.3.4, 36.211 6.7)
+            uint8_t b[32], c[32];
+            synth::gold((((sf + 1) * (2 * cell + 1)) << 9) + cell, 32, c);
+            for (uint32_t i = 0; i < 32; i++) b[i] = (uint8_t)((cfi == 4 ? 0u : ((i % 3) == cfi - 1 ? 0u : 1u)) ^ c[i]);
+            place(pcf, b, 16);
+        }
+        std::vector<uint8_t> c(4 * 288);
+        synth::gold((sf << 9) + cell, 4 * 288, c.data());
+        for (uint32_t a = 0; a < n_dci; a++) {
+            const mi_lte_synth_dci &d = h_dci[(size_t)u * n_dci + a];
+            if (d.rnti == 0) continue; // unused slot
+            if (cand[a * RE_MAX + 143] == NO_RE) continue; // this candidate's CCEs do not all exist: nothing is sent (as the reference)
+            // DCI format 1A for SI-/P-/RA-RNTI (36.212 5.3.3.1.3; the reference's dci_1a_pack :13138-13215)
+            std::vector<uint8_t> bits(K, 0);
+            uint32_t             pos = 0;
+            auto push = [&](uint32_t v, uint32_t n) { for (uint32_t i = 0; i < n; i++) bits[pos++] = (uint8_t)((v >> (n - 1 - i)) & 1u); };
+            const uint32_t riv_len = (uint32_t)ceilf(logf(nrb * (nrb + 1) / 2) / logf(2));
+            if (d.N_prb == 0 || d.N_prb - 1 > nrb / 2 || d.rb_start + d.N_prb > nrb || d.mcs > 26) return MI_LTE_ERR_INVALID_ARG;
+            push(1, 1); push(0, 1); push(nrb * (d.N_prb - 1) + d.rb_start, riv_len); push(d.mcs, 5); push(0, 3); push(0, 1); push(d.rv_idx, 2); push(1, 2);
+            // CRC16 masked with the RNTI (36.212 5.3.3.2)
+            uint32_t rem = 0;
+            for (uint32_t t = 0; t < sz[0] + 16; t++) {
+                rem = (rem << 1) | (t < sz[0] ? bits[t] : 0u);
+                if (rem & 0x10000u) rem ^= 0x11021u;
+            }
+            rem ^= d.rnti & 0xFFFFu;
+            for (uint32_t i = 0; i < 16; i++) bits[sz[0] + i] = (uint8_t)((rem >> (15 - i)) & 1u);
+            // tail-biting convolutional code, K = 7, rate 1/3 (36.212 5.1.3.1)
+            std::vector<uint8_t> dd(3 * K);
+            uint32_t             state = 0;
+            for (uint32_t i = 0; i < 6; i++) state |= (uint32_t)bits[K - 1 - i] << (5 - i); // most recent input in bit 5
+            const uint32_t G[3] = {0133, 0171, 0165};
+            for (uint32_t t = 0; t < K; t++) {
+                const uint32_t reg = ((uint32_t)bits[t] << 6) | state;
+                for (uint32_t o = 0; o < 3; o++) dd[3 * t + o] = (uint8_t)(__builtin_popcount(reg & G[o]) & 1);
+                state = reg >> 1;
+            }
+            // rate matching to E = 288 (aggregation level 4) and scrambling at the candidate's offset
+            uint8_t e[288];
+            for (uint32_t k = 0; k < 288; k++) e[k] = dd[map[k]] ^ c[a * 288 + k];
+            place(&cand[a * RE_MAX], e, 144);
+        }
+        // channel + noise -> rx grid and estimates (symbols 0..3 only: the control region)
+        float *g = h_grids + (size_t)u * nf;
+        std::fill(g, g + nf, 0.0f);
+        const double sig = chan->snr_db >= 200 ? 0.0 : std::pow(10.0, -chan->snr_db / 20.0) * r2;
+        std::vector<double> rr(4 * N_SC_MAX, 0.0), ri(4 * N_SC_MAX, 0.0);
+        for (uint32_t p = 0; p < n_ant; p++) {
+            const double amp = chan->gain_min + (chan->gain_max - chan->gain_min) * rng.uniform();
+            const double tau = (2 * rng.uniform() - 1) * 2e-3, ph = (2 * rng.uniform() - 1) * M_PI;
+            for (uint32_t l = 0; l < 4; l++)
+                for (uint32_t k = 0; k < 12 * nrb; k++) {
+                    const double hr = amp * std::cos(ph + 2 * M_PI * tau * k), hi = amp * std::sin(ph + 2 * M_PI * tau * k);
+                    const size_t q = l * N_SC_MAX + k;
+                    rr[q] += hr * tr[p * plane + q] - hi * ti[p * plane + q];
+                    ri[q] += hr * ti[p * plane + q] + hi * tr[p * plane + q];
+                    g[(2 + p) * plane + q]         = (float)(hr + 0.2 * sig * rng.normal());
+                    g[(2 + n_ant + p) * plane + q] = (float)(hi + 0.2 * sig * rng.normal());
+                }
+        }
+        for (uint32_t l = 0; l < 4; l++)
+            for (uint32_t k = 0; k < 12 * nrb; k++) {
+                const size_t q = l * N_SC_MAX + k;
+                g[q]         = (float)(rr[q] + sig * rng.normal());
+                g[plane + q] = (float)(ri[q] + sig * rng.normal());
+            }
+    }
     return MI_LTE_OK;
 }
 

@@ -314,12 +314,21 @@ class PdcchPlan:
                                                   len(cells), C.byref(h)))
         self.h = h
 
+    def decode_raw(self, d_subframes, d_sf, d_cell, n_units):
+        """(rc[n], cfi[n], n_symbs[n], n_dci[n], ctypes array PdcchDci[n * 6]); the buffers are the plan's and are reused by the next call."""
+        if getattr(self, "_n", None) != n_units:
+            self._n = n_units
+            self._out = [np.zeros(n_units, np.uint32) for _ in range(4)]
+            self._dci = (PdcchDci * (6 * n_units))()
+        rc, cfi, nsym, ndci = self._out
+        self.ctx._check(self.ctx.L.mi_lte_pdcch_decode_run(self.ctx.h, self.h, d_subframes.ptr, d_sf.ptr, d_cell.ptr, n_units, rc, cfi, nsym, ndci,
+                                                            self._dci))
+        return rc, cfi, nsym, ndci, self._dci
+
     def decode_dev(self, d_subframes, d_sf, d_cell, n_units):
         """(rc[n], cfi[n], n_symbs[n], list of per-unit lists of PdcchDci)"""
-        rc, cfi, nsym, ndci = (np.zeros(n_units, np.uint32) for _ in range(4))
-        dci = (PdcchDci * (6 * n_units))()
-        self.ctx._check(self.ctx.L.mi_lte_pdcch_decode_run(self.ctx.h, self.h, d_subframes.ptr, d_sf.ptr, d_cell.ptr, n_units, rc, cfi, nsym, ndci, dci))
-        return rc, cfi, nsym, [[dci[6 * u + k] for k in range(int(ndci[u]))] for u in range(n_units)]
+        rc, cfi, nsym, ndci, dci = self.decode_raw(d_subframes, d_sf, d_cell, n_units)
+        return rc.copy(), cfi.copy(), nsym.copy(), [[dci[6 * u + k] for k in range(int(ndci[u]))] for u in range(n_units)]
 
     def close(self):
         if self.h:

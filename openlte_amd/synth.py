@@ -36,6 +36,8 @@ def _lib():
         L.mi_lte_synth_prach_len.argtypes = [C.c_uint32, C.c_uint32]
         L.mi_lte_synth_prach_len.restype = C.c_size_t
         L.mi_lte_synth_prach_i8.argtypes = [C.POINTER(DlCfg), C.POINTER(PrachCfg), C.c_uint32, _u32p, _u32p, C.POINTER(SynthChannel), _i8p]
+        L.mi_lte_synth_ctrl_grids.argtypes = [C.POINTER(DlCfg), C.c_float, C.c_uint32, _u32p, _u32p, _u32p, _u32p, C.c_uint32,
+                                              C.POINTER(SynthChannel), _f32p]
         L._synth_bound = True
     return L
 
@@ -117,3 +119,23 @@ def prach_occasions(cfg, prach_cfg, preamble_idx, delay, gain=(0.5, 1.5), snr_db
     if rc != 0:
         raise MiLteError("mi_lte_synth_prach_i8 failed: %d" % rc)
     return iq
+
+
+def ctrl_grids(cfg, subfr_num, n_id_cell, cfi, dcis, phich_res=1.0, gain=(0.6, 1.4), snr_db=10.0, seed=1):
+    """Control regions as device-subframe grids, float32 [n, 2 + 2*N_ant, 16, 1200] (symbols 0-3 filled): PCFICH + the format-1A
+    DCIs dcis[u] = [(rnti, mcs, N_prb, rb_start, rv_idx), ...] (at most 4, candidate = list position) with standard transmit
+    diversity on cfg.N_ant ports."""
+    n = len(subfr_num)
+    n_dci = max([len(d) for d in dcis] + [1])
+    tab = np.zeros((n, n_dci, 5), np.uint32)
+    for u, lst in enumerate(dcis):
+        for a, t in enumerate(lst):
+            tab[u, a] = t
+    g = np.zeros((n, 2 + 2 * cfg.N_ant, 16, 1200), np.float32)
+    ch = SynthChannel(gain[0], gain[1], 0.0, float(snr_db), 0.0, int(seed))
+    rc = _lib().mi_lte_synth_ctrl_grids(C.byref(cfg), float(phich_res), n, np.ascontiguousarray(subfr_num, np.uint32),
+                                        np.ascontiguousarray(n_id_cell, np.uint32), np.ascontiguousarray(cfi, np.uint32), tab.reshape(-1), n_dci,
+                                        C.byref(ch), g.reshape(-1))
+    if rc != 0:
+        raise MiLteError("mi_lte_synth_ctrl_grids failed: %d" % rc)
+    return g

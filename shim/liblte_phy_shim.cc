@@ -9,6 +9,7 @@
 //     liblte_phy_get_ul_subframe          liblte_phy.h:1190-1193   (impl. liblte_phy.cc:6209-6236)
 //     liblte_phy_pusch_channel_decode     liblte_phy.h:722-728     (impl. liblte_phy.cc:2801-2935)
 //     liblte_phy_detect_prach             liblte_phy.h:862-868     (impl. liblte_phy.cc:3299-3479)
+//     liblte_phy_pdcch_channel_decode     liblte_phy.h:1012-1020   (impl. liblte_phy.cc:4519-5135)
 //
 // by forwarding to libmi_lte.so's C-ABI (include/mi_lte.h).  The reference's own definitions of
 // these symbols are kept out of the link by compiling liblte_phy.cc with
@@ -143,4 +144,49 @@ LIBLTE_ERROR_ENUM liblte_phy_detect_prach(LIBLTE_PHY_STRUCT *phy_struct, float *
     int rc = mi_lte_detect_prach_host(c, phy_struct->N_samps_per_symb, phy_struct->N_rb_ul, &pc, &phy_struct->prach_x_u_fft_re[0][0],
                                       &phy_struct->prach_x_u_fft_im[0][0], phy_struct->prach_N_x_u, samps_re, samps_im, N_det_pre, det_pre, det_ta);
     return rc == 0 ? LIBLTE_SUCCESS : LIBLTE_ERROR_INVALID_INPUTS;
+}
+
+// ---- control region: PCFICH + PDCCH common search space (LTE_fdd_dl_fs_samp_buf.cc:445-470)
+
+LIBLTE_ERROR_ENUM liblte_phy_pdcch_channel_decode(LIBLTE_PHY_STRUCT *phy_struct, LIBLTE_PHY_SUBFRAME_STRUCT *subframe, uint32 N_id_cell,
+                                                  uint8 N_ant, float phich_res, LIBLTE_RRC_PHICH_DURATION_ENUM phich_dur,
+                                                  LIBLTE_PHY_PCFICH_STRUCT *pcfich, LIBLTE_PHY_PHICH_STRUCT *phich, LIBLTE_PHY_PDCCH_STRUCT *pdcch)
+{
+    if (phy_struct == NULL || subframe == NULL || pcfich == NULL || phich == NULL || pdcch == NULL) return LIBLTE_ERROR_INVALID_INPUTS;
+    mi_lte_ctx *c = ctx_for(phy_struct);
+    if (!c) return LIBLTE_ERROR_INVALID_INPUTS;
+    // MI_LTE_PDCCH_PER_PORT=1 selects the standard transmit-diversity combiner instead of the reference's arithmetic (mi_lte.h)
+    const char      *pp    = getenv("MI_LTE_PDCCH_PER_PORT");
+    const uint32_t   flags = (pp && atoi(pp)) ? MI_LTE_PDCCH_PER_PORT_ESTIMATES : 0u;
+    uint32_t         cfi = 0, n_symbs = 0, n_dci = 0, n_reg = 0, k[75];
+    mi_lte_pdcch_dci dci[MI_LTE_PDCCH_MAX_DCI];
+    pcfich->N_reg = 4;
+    if (mi_lte_ctrl_reg_positions(phy_struct->N_rb_dl, N_id_cell, phich_res, pcfich->k, pcfich->n, &n_reg, k) != MI_LTE_OK)
+        return LIBLTE_ERROR_INVALID_INPUTS;
+    int rc = mi_lte_pdcch_channel_decode_host(c, phy_struct->N_rb_dl, &subframe->rx_symb_re[0][0], &subframe->rx_symb_im[0][0],
+                                              &subframe->rx_ce_re[0][0][0], &subframe->rx_ce_im[0][0][0], subframe->num, N_id_cell, N_ant, phich_res,
+                                              phich_dur == LIBLTE_RRC_PHICH_DURATION_NORMAL ? 0u : 1u, flags, &cfi, &n_symbs, &n_dci, dci);
+    if (rc < 0) return LIBLTE_ERROR_INVALID_INPUTS;
+    if (rc == 3) return LIBLTE_ERROR_INVALID_CRC; // PCFICH: nothing else is written, as in the reference (:4563-4570)
+    pcfich->cfi               = cfi;
+    phy_struct->N_group_phich = n_reg / 3;
+    phich->N_reg              = n_reg;
+    for (uint32 i = 0; i < n_reg; i++) phich->k[i] = k[i];
+    pdcch->N_symbs = n_symbs;
+    pdcch->N_alloc = n_dci;
+    for (uint32 a = 0; a < n_dci; a++) { // the fields dci_1a_unpack / dci_1c_unpack write (:13273-13378, :13400-13611)
+        LIBLTE_PHY_ALLOCATION_STRUCT *o = &pdcch->alloc[a];
+        const mi_lte_pdsch_alloc     &m = dci[a].alloc;
+        o->N_prb  = m.N_prb;
+        o->mcs    = (uint8)dci[a].mcs;
+        if (dci[a].format == 0) o->rv_idx = m.rv_idx;
+        for (uint32 i = 0; i < m.N_prb && i < LIBLTE_PHY_N_RB_DL_MAX; i++) { o->prb[0][i] = m.prb[0][i]; o->prb[1][i] = m.prb[1][i]; }
+        o->mod_type       = LIBLTE_PHY_MODULATION_TYPE_QPSK;
+        o->pre_coder_type = LIBLTE_PHY_PRE_CODER_TYPE_TX_DIVERSITY;
+        o->tx_mode        = m.tx_mode;
+        o->N_codewords    = 1;
+        o->tbs            = m.tbs;
+        o->rnti           = (uint16)m.rnti;
+    }
+    return rc == 0 ? LIBLTE_SUCCESS : rc == 4 ? LIBLTE_ERROR_INVALID_CONTENTS : LIBLTE_ERROR_INVALID_INPUTS;
 }

@@ -116,3 +116,55 @@ def test_pdcch_per_port_estimates_decode_standard_transmit_diversity(ctx, ref, n
         n_ref_mode += len({(d.alloc.rnti, d.mcs) for d in res[False][3][u]} & {(t[0], t[1]) for t in tx})
     if n_ant == 4:
         assert n_ref_mode == 0
+
+
+@pytest.mark.parametrize("n_ant,fft,nrb", [(1, 2048, 100), (2, 2048, 100), (4, 2048, 100), (1, 128, 6), (2, 512, 25), (1, 1024, 50), (2, 2048, 75), (1, 256, 15)])
+def test_pdcch_batch_finds_every_dci_sent(ctx, ref, n_ant, fft, nrb):
+    """Size-independent property on a batch of synthetic control regions (the library's own standard-conformant transmitter,
+    random cells / subframes / CFIs / DCIs): every DCI sent is found with the fields it was sent with, nothing else is, and --
+    with one port, where the reference's arithmetic is the standard's -- the compiled reference agrees on a sample."""
+    import openlte_amd as m
+    from openlte_amd import synth
+    rng = np.random.default_rng(fft + n_ant)
+    n, cells = 96, [int(c) for c in rng.choice(504, 5, replace=False)]
+    cfg = m.DlCfg(fft, nrb, n_ant, 0)
+    sfs, cell = rng.integers(0, 10, n), rng.choice(cells, n)
+    cfis = rng.integers(2 if nrb > 10 else 1, 4, n)
+    rntis = [0xFFFF, 0xFFFE] + list(range(1, 0x3D))
+    dcis = []
+    for u in range(n):
+        k = int(rng.integers(0, 4 if nrb > 6 else 2))
+        lst = []
+        for r in rng.choice(rntis, k, replace=False):
+            npb = int(rng.integers(1, min(nrb // 2, 8) + 1))
+            lst.append((int(r), int(rng.integers(0, 27)), npb, int(rng.integers(0, nrb - npb + 1)), int(rng.integers(0, 4))))
+        dcis.append(lst)
+    g = synth.ctrl_grids(cfg, sfs, cell, cfis, dcis, snr_db=12.0, seed=nrb + n_ant)
+    plan = ctx.pdcch_plan(cfg, cells, 1.0, per_port_estimates=True)
+    d_g, d_sf, d_cell = ctx.to_device(g), ctx.to_device(sfs.astype(np.uint32)), ctx.to_device(cell.astype(np.uint32))
+    rc, cfi, nsym, got = plan.decode_dev(d_g, d_sf, d_cell, n)
+    for d in (d_g, d_sf, d_cell):
+        d.free()
+    plan.close()
+    assert cfi.tolist() == cfis.tolist()
+    n_extra = 0
+    for u in range(n):
+        _, cand = m.pdcch_re_tables(nrb, n_ant, int(cell[u]), 1.0, int(nsym[u]))
+        sent = {t for a, t in enumerate(dcis[u]) if cand[a, 143] != 0xFFFFFFFF}  # a candidate without all its CCEs is not transmitted
+        found = {(d.alloc.rnti, d.mcs, d.alloc.N_prb, d.alloc.prb[0][0], d.alloc.rv_idx) for d in got[u] if d.format == 0}
+        assert sent <= found, (u, dcis[u])
+        # the reference's Viterbi decoder is not tail-biting aware, so the last bits it puts out -- the low bits of the RNTI-masked
+        # CRC -- are its least reliable: a random-access DCI can come back a second time (aggregation level 8) under a neighbouring
+        # RA-RNTI; and with 60 RA-RNTIs accepted, noise passes the 16-bit CRC once in about a thousand decodes.  Anything found
+        # beyond what was sent must be an RA-RNTI, and there must be few of them.
+        for f in found - sent:
+            assert f[0] <= 0x3C, (u, f, dcis[u])
+        n_extra += len(found - sent)
+    assert n_extra <= n // 8
+    if n_ant == 1:
+        case = dict(fft=fft, nrb=nrb, n_ant=1, cell=None, phich_res=1.0)
+        for u in range(0, n, 8):
+            c1 = dict(case, cell=int(cell[u]), sfs=[int(sfs[u])], grids=g[u:u + 1])
+            w_rc, w_cfi, w_nsym, recs = td.ref_pdcch_decode(ref, c1)[0]
+            assert (w_rc, w_cfi, w_nsym) == (int(rc[u]), int(cfi[u]), int(nsym[u]))
+            assert recs == td.dci_records(got[u]), u

@@ -41,7 +41,8 @@ typedef enum {
 } mi_lte_status;
 
 /* per-block verdicts, numerically identical to LIBLTE_ERROR_ENUM (liblte_common.h:59-65) */
-enum { MI_LTE_DECODE_SUCCESS = 0, MI_LTE_DECODE_INVALID_INPUTS = 1, MI_LTE_DECODE_FAIL = 3, MI_LTE_DECODE_INVALID_CRC = 4 };
+enum { MI_LTE_DECODE_SUCCESS = 0, MI_LTE_DECODE_INVALID_INPUTS = 1, MI_LTE_DECODE_FAIL = 2, MI_LTE_DECODE_INVALID_CRC = 3,
+       MI_LTE_DECODE_INVALID_CONTENTS = 4 };
 
 typedef struct mi_lte_ctx mi_lte_ctx; /* opaque */
 
@@ -133,7 +134,7 @@ typedef struct {
  * repeated schedule (the benchmark, or a semi-static grant pattern) pays for planning once.
  * Outputs of run():  d_out_bits[a*out_stride + i], i < tbs: decoded transport block of allocation a,
  * one bit per byte (the reference's out_bits), meaningful when d_status[a] == 0;
- * d_status[a]: 0 = LIBLTE_SUCCESS, 3 = LIBLTE_ERROR_DECODE_FAIL (CRC mismatch). */
+ * d_status[a]: 0 = LIBLTE_SUCCESS, 2 = LIBLTE_ERROR_DECODE_FAIL (CRC mismatch). */
 typedef struct mi_lte_pdsch_plan mi_lte_pdsch_plan;
 int      mi_lte_pdsch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, uint32_t N_pdcch_symbs,
                                   const mi_lte_pdsch_alloc *h_allocs, uint32_t n_alloc, mi_lte_pdsch_plan **out);
@@ -329,13 +330,23 @@ int  mi_lte_ctrl_reg_positions(uint32_t N_rb_dl, uint32_t N_id_cell, float phich
 int  mi_lte_dci_1a_unpack(uint32_t payload, uint32_t n_bits, uint32_t rnti, uint32_t N_rb_dl, uint32_t N_ant, mi_lte_pdcch_dci *out);
 int  mi_lte_dci_1c_unpack(uint32_t payload, uint32_t n_bits, uint32_t rnti, uint32_t N_rb_dl, uint32_t N_ant, mi_lte_pdcch_dci *out);
 
+/* ---------------------------------------------------------------- PBCH
+ * mi_lte_pbch_decode_run replaces liblte_phy_bch_channel_decode() (liblte/hdr/liblte_phy.h:947-953, implementation
+ * liblte/src/liblte_phy.cc:3968-4105 with bch_channel_decode :12581-12650) for a batch of device subframes holding subframe 0
+ * of a frame with channel estimates for all four ports (cfg->N_ant = 4: the reference tries 1, 2 and 4 ports against the
+ * same struct, LTE_fdd_dl_fs_samp_buf.cc:395-410).  Twelve hypotheses per subframe -- {1, 2, 4} ports x {0..3} position
+ * in the 40 ms BCH period -- in the reference's order, first success wins: h_N_ant[u] (0 = LIBLTE_ERROR_DECODE_FAIL),
+ * h_offset[u] (the reference's *offset: SFN mod 4), h_mib[u] = the 24 BCH bits, first bit in bit 23. */
+int mi_lte_pbch_decode_run(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const float *d_subframes, const uint32_t *d_n_id_cell,
+                           uint32_t n_units, uint32_t *h_N_ant, uint32_t *h_offset, uint32_t *h_mib);
+
 /* ---------------------------------------------------------------- per-call host-pointer forms
  * The bodies of the reference's three entry points on this path, for callers that hold host
  * buffers exactly as the reference's callers do (LTE_fdd_dl_fs_samp_buf.cc:378-515,
  * LTE_fdd_enb_phy.cc).  Each stages its arguments through HBM, runs the batch kernels with a batch
  * of one, and copies the results back; shim/liblte_phy_shim.cc forwards the liblte_phy_* symbols
  * here.  Return value: MI_LTE_* on infrastructure errors (< 0), else the LIBLTE_ERROR_ENUM value the
- * reference would return (0 success, 1 invalid inputs, 3 decode fail). */
+ * reference would return (0 success, 1 invalid inputs, 2 decode fail). */
 int mi_lte_get_dl_subframe_and_ce_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_dl, const float *h_i_samps,
                                        const float *h_q_samps, uint32_t frame_start_idx, uint32_t subfr_num,
                                        uint32_t N_id_cell, uint32_t N_ant, float *h_rx_symb_re /*[16][1200]*/,
@@ -350,6 +361,11 @@ int mi_lte_pdcch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const fl
                                      const float *h_rx_ce_re, const float *h_rx_ce_im, uint32_t subfr_num, uint32_t N_id_cell,
                                      uint32_t N_ant, float phich_res, uint32_t phich_dur_extended, uint32_t flags, uint32_t *cfi,
                                      uint32_t *N_symbs, uint32_t *N_dci, mi_lte_pdcch_dci *dci /* [MI_LTE_PDCCH_MAX_DCI] */);
+/* liblte_phy_bch_channel_decode: 0 with *N_ant, h_out_bits[24], *N_out_bits = 24 and *offset written, or 2
+ * (LIBLTE_ERROR_DECODE_FAIL) with *N_ant = 0 and the rest untouched; h_rx_ce_* hold all four ports */
+int mi_lte_bch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const float *h_rx_symb_re, const float *h_rx_symb_im,
+                                   const float *h_rx_ce_re /*[4][16][1200]*/, const float *h_rx_ce_im, uint32_t N_id_cell, uint8_t *N_ant,
+                                   uint8_t *h_out_bits, uint32_t *N_out_bits, uint8_t *offset);
 /* uplink: liblte_phy_get_ul_subframe (h_i / h_q point at the subframe's first sample; 14 rows of 1200 floats are
  * written) and liblte_phy_pusch_channel_decode (the DMRS arrays are the caller's, i.e. what liblte_phy_ul_init
  * stored in LIBLTE_PHY_STRUCT::pusch_dmrs_{0,1}_{re,im}[subframe][N_prb]; a CRC failure returns 1 =

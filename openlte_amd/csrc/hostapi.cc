@@ -64,7 +64,7 @@ int mi_lte_pdsch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const fl
     a.unit                  = 0;
     mi_lte_pdsch_plan *plan = nullptr;
     int                rc   = mi_lte_pdsch_plan_create(ctx, &cfg, N_pdcch_symbs, &a, 1, &plan);
-    if (rc == MI_LTE_ERR_UNSUPPORTED) return 3; // outside the envelope the reference itself decodes: report a decode failure
+    if (rc == MI_LTE_ERR_UNSUPPORTED) return 2; // outside the envelope the reference itself decodes: report a decode failure
     if (rc != MI_LTE_OK) return rc;
     const size_t nf = mi_lte_subframe_floats(N_ant), row = 16 * 1200;
     const uint32_t stride = mi_lte_pdsch_plan_out_stride(plan);
@@ -79,7 +79,7 @@ int mi_lte_pdsch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const fl
     if (e == hipSuccess) e = hipMemcpyAsync(d_par.p, par, 8, hipMemcpyHostToDevice, ctx->stream);
     if (e != hipSuccess) { mi_lte_pdsch_plan_destroy(ctx, plan); ctx->err = hipGetErrorString(e); return MI_LTE_ERR_HIP; }
     rc = mi_lte_pdsch_decode_run(ctx, plan, s, (const uint32_t *)d_par.p, (const uint32_t *)d_par.p + 1, (uint8_t *)d_out.p, (int32_t *)d_st.p);
-    int32_t st = 3;
+    int32_t st = 2;
     if (rc == MI_LTE_OK) {
         e = hipMemcpyAsync(&st, d_st.p, 4, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -125,6 +125,40 @@ int mi_lte_pdcch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const fl
     rc = mi_lte_pdcch_decode_run(ctx, plan, s, (const uint32_t *)d_par.p, (const uint32_t *)d_par.p + 1, 1, &h_rc, cfi, N_symbs, N_dci, dci);
     mi_lte_pdcch_plan_destroy(ctx, plan);
     return rc != MI_LTE_OK ? rc : (int)h_rc;
+}
+
+// liblte_phy_bch_channel_decode (liblte_phy.cc:3968-4105)
+int mi_lte_bch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const float *h_symb_re, const float *h_symb_im, const float *h_ce_re,
+                                   const float *h_ce_im, uint32_t N_id_cell, uint8_t *N_ant, uint8_t *h_out_bits, uint32_t *N_out_bits, uint8_t *offset)
+{
+    if (!ctx) return MI_LTE_ERR_INVALID_ARG;
+    if (!h_symb_re || !h_symb_im || !h_ce_re || !h_ce_im || N_id_cell > 503 || !N_ant || !h_out_bits || !N_out_bits || !offset) return 1;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint32_t fft = N_rb_dl <= 6 ? 128 : N_rb_dl <= 15 ? 256 : N_rb_dl <= 25 ? 512 : N_rb_dl <= 50 ? 1024 : 2048;
+    mi_lte_dl_cfg cfg = {fft, N_rb_dl, 4, MI_LTE_IQ_F32_PLANAR};
+    const size_t  nf = mi_lte_subframe_floats(4), row = 16 * 1200;
+    DevBuf d_sub, d_par;
+    if (d_sub.alloc(nf * 4) || d_par.alloc(16)) return MI_LTE_ERR_NOMEM;
+    float *s = (float *)d_sub.p;
+    // only symbols 7..10 are read
+    const size_t o = 7 * 1200, len = 4 * 1200 * sizeof(float);
+    hipError_t   e = hipMemcpyAsync(s + o, h_symb_re + o, len, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(s + row + o, h_symb_im + o, len, hipMemcpyHostToDevice, ctx->stream);
+    for (uint32_t p = 0; p < 4 && e == hipSuccess; p++) {
+        e = hipMemcpyAsync(s + (2 + p) * row + o, h_ce_re + p * row + o, len, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(s + (6 + p) * row + o, h_ce_im + p * row + o, len, hipMemcpyHostToDevice, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(d_par.p, &N_id_cell, 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return MI_LTE_ERR_HIP; }
+    uint32_t n_ant = 0, off = 0, mib = 0;
+    int rc = mi_lte_pbch_decode_run(ctx, &cfg, s, (const uint32_t *)d_par.p, 1, &n_ant, &off, &mib);
+    if (rc != MI_LTE_OK) return rc;
+    *N_ant = (uint8_t)n_ant; // the reference zeroes it before trying (:4029)
+    if (n_ant == 0) return 2;
+    for (uint32_t i = 0; i < 24; i++) h_out_bits[i] = (uint8_t)((mib >> (23 - i)) & 1u);
+    *N_out_bits = 24;
+    *offset     = (uint8_t)off;
+    return 0;
 }
 
 // liblte_phy_get_ul_subframe (liblte_phy.cc:6209-6236)
@@ -186,7 +220,7 @@ int mi_lte_pusch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_ul, const fl
     if (e == hipSuccess) e = hipMemcpyAsync(s + row, h_symb_im, row * 4, hipMemcpyHostToDevice, ctx->stream);
     if (e != hipSuccess) { mi_lte_pusch_plan_destroy(ctx, plan); ctx->err = hipGetErrorString(e); return MI_LTE_ERR_HIP; }
     rc = mi_lte_pusch_decode_run(ctx, plan, s, (uint8_t *)d_out.p, (int32_t *)d_st.p);
-    int32_t st = 3;
+    int32_t st = 2;
     if (rc == MI_LTE_OK) {
         e = hipMemcpyAsync(&st, d_st.p, 4, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

@@ -92,11 +92,13 @@ __device__ __forceinline__ void combine(uint32_t N_ant, const float (&yr)[4], co
 // receiver).  With two ports row 2 is never written: port 1's estimate is 0 and the second antenna goes unsuppressed; with
 // four ports nothing decodes.  per_port = 0 reproduces exactly that (rows never written read as the zeros a fresh
 // LIBLTE_PHY_STRUCT holds); per_port = 1 is the decoder the reference meant.
-__device__ __forceinline__ void demod_res(const float *__restrict__ base, uint32_t N_ant, uint32_t per_port, const uint32_t *__restrict__ re, uint32_t n_re,
-                                          const GoldTables &gt, uint32_t c_init, uint32_t c_off, int *soft, uint32_t ln)
+// (n_planes = number of channel-estimate planes the device subframe was laid out with; N_ant = ports the combiner assumes)
+__device__ __forceinline__ void demod_res(const float *__restrict__ base, uint32_t n_planes, uint32_t N_ant, uint32_t per_port,
+                                          const uint32_t *__restrict__ re, uint32_t n_re, const GoldTables &gt, uint32_t c_init, uint32_t c_off,
+                                          int *soft, uint32_t ln)
 {
     const float *y_re_p = base, *y_im_p = base + 16 * N_SC_MAX, *h_re_p = base + 2 * 16 * N_SC_MAX;
-    const float *h_im_p = h_re_p + (size_t)N_ant * 16 * N_SC_MAX;
+    const float *h_im_p = h_re_p + (size_t)n_planes * 16 * N_SC_MAX;
     for (uint32_t g = ln; g < n_re / N_ant; g += 64) {
         float yr[4], yi[4], hr[4][4], hi[4][4], xr[4], xi[4];
         const bool absent = re[g * N_ant] == NO_RE;
@@ -126,6 +128,71 @@ __device__ __forceinline__ void demod_res(const float *__restrict__ base, uint32
             soft[n + 1] = absent ? 0 : ((w2 >> ((cn + 1) & 31)) & 1u) ? -(int)b[1] : (int)b[1];
         }
     }
+}
+
+// The reference's K = 7, rate-1/3 Viterbi decoder (viterbi_decode, liblte_phy.cc:10161-10332) over N trellis steps, one state per
+// lane: all states start at 0 (it is not tail-biting aware), the survivor is chosen on the Hamming branch metric while the
+// weighted metric p + w*br is what is stored, the end state is the first strict minimum, and the traceback re-compares the
+// stored metrics of each predecessor pair (one ballot per step, kept in dec[]).  d: 3N integer soft bits in LDS.  The decoded
+// bits come back on lane 0, bit t at position t of (lo, hi).
+__device__ __forceinline__ void viterbi_k7(const int *d, uint32_t N, uint64_t *dec, uint32_t ln, uint32_t &bits_lo, uint32_t &bits_hi)
+{
+    // trellis labels of this lane's state (:10197-10222): register = input bit | predecessor state
+    const uint32_t G[3] = {0133, 0171, 0165};
+    uint32_t lab[2] = {0, 0};
+    for (uint32_t k = 0; k < 2; k++) {
+        const uint32_t prev = (2 * ln + k) & 63u, reg = ((ln >> 5) << 6) | prev;
+        for (uint32_t o = 0; o < 3; o++) lab[k] |= ((uint32_t)__popc(reg & G[o]) & 1u) << o;
+    }
+    int pm = 0;
+    for (uint32_t i = 0; i < N; i++) {
+        // which of each predecessor pair has the larger stored metric (what the traceback re-compares, :10300-10308)
+        const int      up = __shfl_down(pm, 1);
+        const uint64_t gt_mask = __ballot(pm > up); // bit 2m: pm[2m] > pm[2m+1]
+        if (ln == 0) dec[i] = gt_mask;
+        const int d0 = d[3 * i], d1 = d[3 * i + 1], d2 = d[3 * i + 2];
+        const uint32_t in = (d0 < 0 ? 1u : 0u) | (d1 < 0 ? 2u : 0u) | (d2 < 0 ? 4u : 0u);
+        const int      w  = abs(d0) + abs(d1) + abs(d2);
+        const int      p0 = __shfl(pm, (2 * ln) & 63), p1 = __shfl(pm, (2 * ln + 1) & 63);
+        const int      b0 = __popc(lab[0] ^ in), b1 = __popc(lab[1] ^ in);
+        pm = (b0 + p0 > b1 + p1) ? p1 + w * b1 : p0 + w * b0; // select on the Hamming metric, accumulate the weighted one
+    }
+    // end state: first strict minimum (:10281-10292)
+    int      best = pm;
+    uint32_t st   = ln;
+    for (int o = 32; o > 0; o >>= 1) {
+        const int      ob = __shfl_xor(best, o);
+        const uint32_t os = __shfl_xor(st, o);
+        if (ob < best || (ob == best && os < st)) { best = ob; st = os; }
+    }
+    bits_lo = bits_hi = 0;
+    if (ln == 0) {
+        // traceback (:10294-10309) and bit read-out (:10313-10331): states s_N .. s_0, bit t from (s_{t+1}, s_t)
+        uint32_t cur = st;
+        for (int i = (int)N - 1; i >= 0; i--) {
+            const uint32_t p0 = (2 * cur) & 63u;
+            const uint32_t prev = ((dec[i] >> p0) & 1ull) ? p0 + 1 : p0;
+            const uint32_t bit  = (cur < prev) ? 0u : (cur > prev) ? 1u : (cur == 0 ? 0u : 1u);
+            if (i < 32) bits_lo |= bit << i; else bits_hi |= bit << (i - 32);
+            cur = prev;
+        }
+    }
+}
+
+// CRC16 (polynomial 0x11021, calc_crc :9713-9743) of bits 0..n_info-1 XOR the 16 parity bits that follow them; bit t of the block at
+// position t of (lo, hi).  Also returns the information bits, first bit in the MSB of an n_info-bit field.
+__device__ __forceinline__ uint32_t crc16_syndrome(uint32_t bits_lo, uint32_t bits_hi, uint32_t n_info, uint32_t &payload)
+{
+    auto bit_at = [&](uint32_t t) { return t < 32 ? (bits_lo >> t) & 1u : (bits_hi >> (t - 32)) & 1u; };
+    uint32_t rem = 0, par = 0;
+    payload = 0;
+    for (uint32_t t = 0; t < n_info + 16; t++) {
+        rem = (rem << 1) | (t < n_info ? bit_at(t) : 0u);
+        if (rem & 0x10000u) rem ^= 0x11021u;
+    }
+    for (uint32_t t = 0; t < n_info; t++) payload = (payload << 1) | bit_at(t);
+    for (uint32_t t = 0; t < 16; t++) par = (par << 1) | bit_at(n_info + t);
+    return (par ^ rem) & 0xFFFFu;
 }
 
 __global__ __launch_bounds__(384) void k_pdcch_decode(const float *__restrict__ subframes, uint32_t sf_stride,
@@ -158,7 +225,7 @@ __global__ __launch_bounds__(384) void k_pdcch_decode(const float *__restrict__ 
     }
     // ---- PCFICH (pcfich_channel_demap + cfi_channel_decode)
     if (wave == 0) {
-        demod_res(base, P.N_ant, P.per_port, P.pcfich + (size_t)ci * 16, 16, gt, (((sf + 1) * (2 * cell + 1)) << 9) + cell, 0, pc_soft, ln);
+        demod_res(base, P.N_ant, P.N_ant, P.per_port, P.pcfich + (size_t)ci * 16, 16, gt, (((sf + 1) * (2 * cell + 1)) << 9) + cell, 0, pc_soft, ln);
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
         uint32_t bit = 0, m[4] = {0, 0, 0, 0};
@@ -186,17 +253,10 @@ __global__ __launch_bounds__(384) void k_pdcch_decode(const float *__restrict__ 
     const uint32_t *re = P.cand + (((size_t)ci * 4 + (n_symbs - 1)) * N_CAND + c) * RE_MAX;
     if (re[0] == NO_RE) return; // the candidate reaches past the last CCE
     const uint32_t c_off = c < 4 ? c * 288u : (c - 4) * 576u; // offset into the subframe's scrambling sequence (:4908, :5035)
-    demod_res(base, P.N_ant, P.per_port, re, n_re, gt, (sf << 9) + cell, c_off, soft[c], ln);
+    demod_res(base, P.N_ant, P.N_ant, P.per_port, re, n_re, gt, (sf << 9) + cell, c_off, soft[c], ln);
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
 
-    // trellis labels of this lane's state (viterbi_decode :10197-10222): register = input bit | predecessor state
-    const uint32_t G[3] = {0133, 0171, 0165};
-    uint32_t lab[2] = {0, 0};
-    for (uint32_t k = 0; k < 2; k++) {
-        const uint32_t prev = (2 * ln + k) & 63u, reg = ((ln >> 5) << 6) | prev;
-        for (uint32_t o = 0; o < 3; o++) lab[k] |= ((uint32_t)__popc(reg & G[o]) & 1u) << o;
-    }
     for (uint32_t f = 0; f < 2; f++) {
         const uint32_t n_out = P.dci_size[f], N = n_out + 16; // information + CRC bits = trellis steps
         // rate un-matching with soft combining (rate_unmatch_conv): every received bit adds onto its d position
@@ -206,54 +266,76 @@ __global__ __launch_bounds__(384) void k_pdcch_decode(const float *__restrict__ 
         for (uint32_t k = ln; k < E; k += 64) atomicAdd(&dbits[c][map[k]], soft[c][k]);
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
-        // forward pass, lane = state
-        int pm = 0;
-        for (uint32_t i = 0; i < N; i++) {
-            // which of each predecessor pair has the larger stored metric (what the traceback re-compares, :10300-10308)
-            const int      up = __shfl_down(pm, 1);
-            const uint64_t gt_mask = __ballot(pm > up); // bit 2m: pm[2m] > pm[2m+1]
-            if (ln == 0) dec[c][i] = gt_mask;
-            const int d0 = dbits[c][3 * i], d1 = dbits[c][3 * i + 1], d2 = dbits[c][3 * i + 2];
-            const uint32_t in = (d0 < 0 ? 1u : 0u) | (d1 < 0 ? 2u : 0u) | (d2 < 0 ? 4u : 0u);
-            const int      w  = abs(d0) + abs(d1) + abs(d2);
-            const int      p0 = __shfl(pm, (2 * ln) & 63), p1 = __shfl(pm, (2 * ln + 1) & 63);
-            const int      b0 = __popc(lab[0] ^ in), b1 = __popc(lab[1] ^ in);
-            pm = (b0 + p0 > b1 + p1) ? p1 + w * b1 : p0 + w * b0; // select on the Hamming metric, accumulate the weighted one
-        }
-        // end state: first strict minimum (:10281-10292)
-        int      best = pm;
-        uint32_t st   = ln;
-        for (int o = 32; o > 0; o >>= 1) {
-            const int      ob = __shfl_xor(best, o);
-            const uint32_t os = __shfl_xor(st, o);
-            if (ob < best || (ob == best && os < st)) { best = ob; st = os; }
-        }
+        uint32_t bits_lo, bits_hi;
+        viterbi_k7(dbits[c], N, dec[c], ln, bits_lo, bits_hi);
         if (ln == 0) {
-            // traceback (:10294-10309) and bit read-out (:10313-10331): states s_N .. s_0, bit t from (s_{t+1}, s_t)
-            uint32_t bits_hi = 0, bits_lo = 0, cur = st; // bit t stored at position t (t < 64)
-            for (int i = (int)N - 1; i >= 0; i--) {
-                const uint32_t p0 = (2 * cur) & 63u;
-                const uint32_t prev = ((dec[c][i] >> p0) & 1ull) ? p0 + 1 : p0;
-                const uint32_t bit  = (cur < prev) ? 0u : (cur > prev) ? 1u : (cur == 0 ? 0u : 1u);
-                if (i < 32) bits_lo |= bit << i; else bits_hi |= bit << (i - 32);
-                cur = prev;
-            }
-            auto bit_at = [&](uint32_t t) { return t < 32 ? (bits_lo >> t) & 1u : (bits_hi >> (t - 32)) & 1u; };
-            // CRC16 of the information bits (calc_crc :9713-9743, polynomial 0x11021) against the received parity
-            uint32_t rem = 0, payload = 0, par = 0;
-            for (uint32_t t = 0; t < n_out + 16; t++) {
-                rem = (rem << 1) | (t < n_out ? bit_at(t) : 0u);
-                if (rem & 0x10000u) rem ^= 0x11021u;
-            }
-            for (uint32_t t = 0; t < n_out; t++) payload = (payload << 1) | bit_at(t);
-            for (uint32_t t = 0; t < 16; t++) par = (par << 1) | bit_at(n_out + t);
-            const uint32_t x = (par ^ rem) & 0xFFFFu; // = RNTI when the CRC matches (UE antenna mask 0)
+            uint32_t       payload;
+            const uint32_t x = crc16_syndrome(bits_lo, bits_hi, n_out, payload); // = RNTI when the CRC matches (UE antenna mask 0)
             if (x == 0xFFFFu || x == 0xFFFEu || (x >= 1 && x <= 0x3Cu)) { // SI-, P-, RA-RNTI (:4915-4947)
                 res->rnti[c * 2 + f]    = x;
                 res->payload[c * 2 + f] = payload;
             }
         }
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- PBCH (liblte_phy_bch_channel_decode, liblte_phy.cc:3968-4105; bch_channel_decode :12581-12650) ----------------------
+// One workgroup per subframe 0, twelve wavefronts = {1, 2, 4 antenna ports} x {4 positions in the 40 ms BCH period}: each gathers
+// the 240 PBCH resource elements (symbols 7-10, centre 72 sub-carriers, CRS positions of symbols 7, 8 left out) with the
+// estimates of the ports its hypothesis needs, combines / de-maps / descrambles with the quarter of the 1920-bit sequence its
+// position selects, rate-un-matches (every d position gets 4 of the 480 bits), runs the same Viterbi decoder over 40 steps and
+// checks CRC16 against its port-count mask.  The reference tries the hypotheses in this order and stops at the first success:
+// the lowest successful wave index wins.
+struct PbchLap { uint8_t pos[120]; }; // d position (3i + x) of the k-th bit of one lap of the circular buffer (40 bits per stream)
+struct PbchResult { uint32_t N_ant, offset, mib; };
+
+__global__ __launch_bounds__(768) void k_pbch_decode(const float *__restrict__ subframes, uint32_t sf_stride, uint32_t N_rb_dl,
+                                                     const uint32_t *__restrict__ n_id_cell, PbchLap lap, GoldTables gt,
+                                                     PbchResult *__restrict__ out)
+{
+    __shared__ uint32_t re[240];
+    __shared__ int      soft[12][480];
+    __shared__ int      dbits[12][120];
+    __shared__ uint64_t dec[12][40];
+    __shared__ uint32_t s_mib[12], s_win;
+    const uint32_t unit = blockIdx.x, wave = threadIdx.x >> 6, ln = threadIdx.x & 63, cell = n_id_cell[unit];
+    const float   *base = subframes + (size_t)unit * sf_stride;
+    if (threadIdx.x < 240) {
+        const uint32_t t = threadIdx.x, k0 = 6 * N_rb_dl - 36, r = cell % 3;
+        uint32_t sym, i;
+        if (t < 96) { // symbols 7, 8: the two non-CRS residues of every group of three sub-carriers
+            const uint32_t j = t % 48, lo = r == 0 ? 1u : 0u, hi = r == 2 ? 1u : 2u;
+            sym = 7 + t / 48;
+            i   = 3 * (j / 2) + ((j & 1) ? hi : lo);
+        } else {
+            sym = 9 + (t - 96) / 72;
+            i   = (t - 96) % 72;
+        }
+        re[t] = sym * N_SC_MAX + k0 + i;
+    }
+    if (threadIdx.x == 0) s_win = 0xFFFFFFFFu;
+    __syncthreads();
+    const uint32_t p = wave < 4 ? 1u : wave < 8 ? 2u : 4u, off = wave & 3u;
+    demod_res(base, 4, p, 1, re, 240, gt, cell, off * 480, soft[wave], ln); // the PBCH estimates are strided correctly (:4030)
+    for (uint32_t k = ln; k < 120; k += 64) dbits[wave][k] = 0;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t k = ln; k < 480; k += 64) atomicAdd(&dbits[wave][lap.pos[k % 120]], soft[wave][k]);
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    uint32_t bits_lo, bits_hi;
+    viterbi_k7(dbits[wave], 40, dec[wave], ln, bits_lo, bits_hi);
+    if (ln == 0) {
+        uint32_t       mib;
+        const uint32_t x = crc16_syndrome(bits_lo, bits_hi, 24, mib), mask = p == 1 ? 0u : p == 2 ? 0xFFFFu : 0x5555u; // 36.212 table 5.3.1.1-1
+        s_mib[wave] = mib;
+        if (x == mask) atomicMin(&s_win, wave);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t w = s_win;
+        out[unit] = w == 0xFFFFFFFFu ? PbchResult{0, 0, 0} : PbchResult{w < 4 ? 1u : w < 8 ? 2u : 4u, w & 3u, s_mib[w]};
     }
 }
 
@@ -594,6 +676,38 @@ int mi_lte_pdcch_decode_run(mi_lte_ctx *ctx, mi_lte_pdcch_plan *pl, const float 
     return MI_LTE_OK;
 }
 
+
+// liblte_phy_bch_channel_decode for a batch of device subframes (subframe 0 of a frame, estimated for 4 ports as the reference's
+// callers do, LTE_fdd_dl_fs_samp_buf.cc:395-410): h_N_ant[u] = 0 is LIBLTE_ERROR_DECODE_FAIL
+int mi_lte_pbch_decode_run(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const float *d_subframes, const uint32_t *d_n_id_cell, uint32_t n_units,
+                           uint32_t *h_N_ant, uint32_t *h_offset, uint32_t *h_mib)
+{
+    if (!ctx || !cfg || !d_subframes || !d_n_id_cell || n_units == 0 || !h_N_ant || !h_offset || !h_mib) return MI_LTE_ERR_INVALID_ARG;
+    if (cfg->N_ant != 4 || cfg->N_rb_dl < 6 || cfg->N_rb_dl > 100) {
+        ctx->err = "PBCH decode reads the estimates of all four ports: the device subframes must be laid out with N_ant = 4";
+        return MI_LTE_ERR_UNSUPPORTED;
+    }
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    int rc = mi_ctx_gold_tables(ctx);
+    if (rc != MI_LTE_OK) return rc;
+    rc = mi_ctx_reserve_scratch(ctx, sizeof(PbchResult) * (size_t)n_units);
+    if (rc != MI_LTE_OK) return rc;
+    PbchLap  lap;
+    uint16_t map[120];
+    conv_rm_map(40, 120, map);
+    for (uint32_t k = 0; k < 120; k++) lap.pos[k] = (uint8_t)map[k];
+    PbchResult *d_res = (PbchResult *)ctx->scratch;
+    GoldTables  gt{ctx->d_gold_x1, ctx->d_gold_x2b, ctx->gold_words};
+    MI_LAUNCH(ctx, "k_pbch_decode", k_pbch_decode, dim3(n_units), dim3(768), 0, d_subframes, (uint32_t)mi_lte_subframe_floats(4), cfg->N_rb_dl, d_n_id_cell,
+              lap, gt, d_res);
+    MI_HIP_CHECK(ctx, hipGetLastError());
+    std::vector<PbchResult> res(n_units);
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(res.data(), d_res, sizeof(PbchResult) * (size_t)n_units, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t u = 0; u < n_units; u++) { h_N_ant[u] = res[u].N_ant; h_offset[u] = res[u].offset; h_mib[u] = res[u].mib; }
+    ctx->last_kernels = "k_pbch_decode:1";
+    return MI_LTE_OK;
+}
 
 // ---- input synthesis (benchmark and tests): control regions as 36.211 / 36.212 transmit them --------------------------
 // PCFICH + up to four format-1A DCIs at aggregation level 4 in the common search space (what the reference's own

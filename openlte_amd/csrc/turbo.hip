@@ -764,7 +764,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         __syncthreads();
         crc = 0;
         for (uint32_t w = 0; w < (blockDim.x >> 6); w++) crc ^= red_u[w];
-        if (threadIdx.x == 0) g.status[alloc] = (crc == 0) ? 0 /* LIBLTE_SUCCESS */ : 3 /* LIBLTE_ERROR_DECODE_FAIL */;
+        if (threadIdx.x == 0) g.status[alloc] = (crc == 0) ? 0 /* LIBLTE_SUCCESS */ : 2 /* LIBLTE_ERROR_DECODE_FAIL */;
         // transport block = bits F .. F+tbs-1 of the code block, one bit per byte, 16 bytes per store where aligned
         uint8_t *o = g.out_bits + (size_t)alloc * g.out_stride;
         if ((F & 3u) == 0) {

@@ -132,6 +132,7 @@ def load_library():
     L.mi_lte_pdcch_plan_create.argtypes = [vp, C.POINTER(DlCfg), C.c_float, u32, u32, u32p, u32, C.POINTER(vp)]
     L.mi_lte_pdcch_plan_destroy.argtypes = [vp, vp]
     L.mi_lte_pdcch_decode_run.argtypes = [vp, vp, vp, vp, vp, u32, u32p, u32p, u32p, u32p, C.POINTER(PdcchDci)]
+    L.mi_lte_pbch_decode_run.argtypes = [vp, C.POINTER(DlCfg), vp, vp, u32, u32p, u32p, u32p]
     L.mi_lte_pdcch_re_tables.argtypes = [u32, u32, u32, C.c_float, u32, u32p, u32p]
     L.mi_lte_dci_1a_unpack.argtypes = [u32, u32, u32, u32, u32, C.POINTER(PdcchDci)]
     L.mi_lte_dci_1c_unpack.argtypes = [u32, u32, u32, u32, u32, C.POINTER(PdcchDci)]
@@ -478,6 +479,12 @@ class Context:
 
     def prach_plan(self, cfg, prach_cfg, roots_fft=None):
         return PrachPlan(self, cfg, prach_cfg, roots_fft)
+
+    def pbch_decode_dev(self, cfg, d_subframes, d_cell, n_units):
+        """(N_ant[n] (0 = not decoded), offset[n], mib[n] = the 24 BCH bits, first bit in bit 23); cfg.N_ant must be 4."""
+        out = [np.zeros(n_units, np.uint32) for _ in range(3)]
+        self._check(self.L.mi_lte_pbch_decode_run(self.h, C.byref(cfg), d_subframes.ptr, d_cell.ptr, n_units, out[0], out[1], out[2]))
+        return out
 
     def pdcch_plan(self, cfg, cells, phich_res=1.0, per_port_estimates=False):
         return PdcchPlan(self, cfg, cells, phich_res, 0, per_port_estimates)

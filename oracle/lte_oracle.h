@@ -25,8 +25,8 @@ extern "C" {
 
 enum { LO_MOD_BPSK = 0, LO_MOD_QPSK = 1, LO_MOD_16QAM = 2, LO_MOD_64QAM = 3 }; /* liblte_phy.h:212-217 */
 enum { LO_CHAN_DLSCH = 0, LO_CHAN_PCH = 1, LO_CHAN_ULSCH = 2, LO_CHAN_ULCCH = 3 }; /* liblte_phy.h:219-224 */
-enum { LO_SUCCESS = 0, LO_ERR_INVALID_INPUTS = 1, LO_ERR_ENCODE_FAIL = 2, LO_ERR_DECODE_FAIL = 3,
-       LO_ERR_INVALID_CRC = 4, LO_ERR_INVALID_CONTENTS = 5 }; /* liblte_common.h:59-65 */
+enum { LO_SUCCESS = 0, LO_ERR_INVALID_INPUTS = 1, LO_ERR_DECODE_FAIL = 2, LO_ERR_INVALID_CRC = 3,
+       LO_ERR_INVALID_CONTENTS = 4 }; /* liblte_common.h:59-65 */
 
 /* Receive half of LIBLTE_PHY_SUBFRAME_STRUCT (liblte_phy.h:226-239). */
 typedef struct {

@@ -197,6 +197,10 @@ def ref():
     L.ref_time_pdcch.argtypes = [vp, vp, u32, u32, C.c_float, u32]
     L.ref_time_pdcch.restype = C.c_double
     L.ref_dci_unpack.argtypes = [u32, u8p, u32, u32, u32, u32, C.POINTER(LoAlloc), C.POINTER(u32), u32p]
+    L.ref_bch_channel_encode.argtypes = [vp, vp, u8p, u32, u32, u32]
+    L.ref_bch_channel_decode.argtypes = [vp, vp, u32, C.POINTER(u32), u8p, C.POINTER(u32)]
+    L.ref_time_bch.argtypes = [vp, vp, u32, u32]
+    L.ref_time_bch.restype = C.c_double
     _REF = L
     return L
 

@@ -418,6 +418,31 @@ double ref_time_pdcch(void *phy, void *sf, uint32_t N_id_cell, uint32_t N_ant, f
     return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
 }
 
+// PBCH: the MIB of system frame sfn goes into subframe 0 of that frame; decode tries {1,2,4} ports x 4 positions
+int ref_bch_channel_encode(void *phy, void *sf, uint8_t *mib_bits /*[24]*/, uint32_t N_id_cell, uint32_t N_ant, uint32_t sfn)
+{
+    return (int)liblte_phy_bch_channel_encode((LIBLTE_PHY_STRUCT *)phy, mib_bits, 24, N_id_cell, (uint8)N_ant, (LIBLTE_PHY_SUBFRAME_STRUCT *)sf, sfn);
+}
+int ref_bch_channel_decode(void *phy, void *sf, uint32_t N_id_cell, uint32_t *N_ant, uint8_t *out_bits /*[24]*/, uint32_t *offset)
+{
+    uint8  na = 0, off = 0;
+    uint32 n = 0;
+    int    err = (int)liblte_phy_bch_channel_decode((LIBLTE_PHY_STRUCT *)phy, (LIBLTE_PHY_SUBFRAME_STRUCT *)sf, N_id_cell, &na, out_bits, &n, &off);
+    *N_ant = na; *offset = off;
+    return err;
+}
+double ref_time_bch(void *phy, void *sf, uint32_t N_id_cell, uint32_t reps)
+{
+    uint8  na = 0, off = 0, bits[32];
+    uint32 n = 0;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (uint32_t r = 0; r < reps; r++)
+        liblte_phy_bch_channel_decode((LIBLTE_PHY_STRUCT *)phy, (LIBLTE_PHY_SUBFRAME_STRUCT *)sf, N_id_cell, &na, bits, &n, &off);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+}
+
 // format 0 = 1A, 1 = 1C; the allocation starts zeroed
 int ref_dci_unpack(uint32_t format, uint8_t *bits, uint32_t n_bits, uint32_t rnti, uint32_t N_rb_dl, uint32_t N_ant, ref_alloc_t *out,
                    uint32_t *mcs, uint32_t *prb_slot1 /*[110]*/)

@@ -10,6 +10,7 @@
 //     liblte_phy_pusch_channel_decode     liblte_phy.h:722-728     (impl. liblte_phy.cc:2801-2935)
 //     liblte_phy_detect_prach             liblte_phy.h:862-868     (impl. liblte_phy.cc:3299-3479)
 //     liblte_phy_pdcch_channel_decode     liblte_phy.h:1012-1020   (impl. liblte_phy.cc:4519-5135)
+//     liblte_phy_bch_channel_decode       liblte_phy.h:947-953     (impl. liblte_phy.cc:3968-4105)
 //
 // by forwarding to libmi_lte.so's C-ABI (include/mi_lte.h).  The reference's own definitions of
 // these symbols are kept out of the link by compiling liblte_phy.cc with
@@ -189,4 +190,16 @@ LIBLTE_ERROR_ENUM liblte_phy_pdcch_channel_decode(LIBLTE_PHY_STRUCT *phy_struct,
         o->rnti           = (uint16)m.rnti;
     }
     return rc == 0 ? LIBLTE_SUCCESS : rc == 4 ? LIBLTE_ERROR_INVALID_CONTENTS : LIBLTE_ERROR_INVALID_INPUTS;
+}
+
+LIBLTE_ERROR_ENUM liblte_phy_bch_channel_decode(LIBLTE_PHY_STRUCT *phy_struct, LIBLTE_PHY_SUBFRAME_STRUCT *subframe, uint32 N_id_cell, uint8 *N_ant,
+                                                uint8 *out_bits, uint32 *N_out_bits, uint8 *offset)
+{
+    if (phy_struct == NULL || subframe == NULL || N_id_cell > 503 || N_ant == NULL || out_bits == NULL || N_out_bits == NULL || offset == NULL)
+        return LIBLTE_ERROR_INVALID_INPUTS;
+    mi_lte_ctx *c = ctx_for(phy_struct);
+    if (!c) return LIBLTE_ERROR_INVALID_INPUTS;
+    int rc = mi_lte_bch_channel_decode_host(c, phy_struct->N_rb_dl, &subframe->rx_symb_re[0][0], &subframe->rx_symb_im[0][0], &subframe->rx_ce_re[0][0][0],
+                                            &subframe->rx_ce_im[0][0][0], N_id_cell, N_ant, out_bits, N_out_bits, offset);
+    return rc == 0 ? LIBLTE_SUCCESS : rc == 2 ? LIBLTE_ERROR_DECODE_FAIL : LIBLTE_ERROR_INVALID_INPUTS;
 }

@@ -337,3 +337,76 @@ def pdcch_per_port_case(ref, fft, nrb, n_ant, cell, phich_res, units, snr_db, se
         rx += (sig * (rng.standard_normal(rx.shape) + 1j * rng.standard_normal(rx.shape))).astype(np.complex64)
         grids[u, 0], grids[u, 1] = rx.real.reshape(16, 1200), rx.imag.reshape(16, 1200)
     return dict(fft=fft, nrb=nrb, n_ant=n_ant, cell=cell, phich_res=phich_res, sfs=[x[0] for x in units], units=units, grids=grids)
+
+
+# ---------------------------------------------------------------------------------------------------
+# PBCH (rest of SURVEY 8f N3): subframe 0 with the MIB of frame sfn, built with the reference's transmitter
+
+PBCH_CASES = {
+    # name: (fft, N_rb_dl, N_ant (transmitted), [(cell, sfn) per unit], snr_db)
+    "20MHz_1ant": (2048, 100, 1, [(17, 0), (17, 1), (17, 2), (17, 3), (301, 6), (0, 1023)], 6.0),
+    "1p4MHz_1ant": (128, 6, 1, [(301, 5), (150, 2), (503, 3)], 8.0),
+    "5MHz_2ant": (512, 25, 2, [(44, 0), (45, 1), (46, 7)], 8.0),
+    "10MHz_4ant": (1024, 50, 4, [(100, 0), (101, 2)], 10.0),
+    "15MHz_noisy": (2048, 75, 1, [(7, s) for s in range(8)], -2.0),
+}
+
+
+def pbch_case(R, name, seed=31):
+    """Units for one case: grids in the device-subframe layout with FOUR estimate planes (float32 [n, 10, 16, 1200]), rx = sum over the
+    transmitted ports of h_p * tx_p + noise; ports that do not transmit get a noise-only estimate (what a CRS estimator sees)."""
+    from oracle import pyoracle as po
+    fft, nrb, n_ant, units, snr_db = PBCH_CASES[name]
+    rng = np.random.default_rng(seed)
+    grids = np.zeros((len(units), 10, 16, 1200), np.float32)
+    k = np.arange(1200)
+    mibs = []
+    sig = 10 ** (-snr_db / 20) / np.sqrt(2)
+    for u, (cell, sfn) in enumerate(units):
+        phy = R.ref_phy_new(po.FS_ENUM[fft], cell, n_ant, nrb)
+        sfp = R.ref_subframe_new()
+        R.ref_subframe_clear_tx(sfp, 0)
+        mib = rng.integers(0, 2, 24).astype(np.uint8)
+        mibs.append(mib)
+        assert R.ref_bch_channel_encode(phy, sfp, mib, cell, n_ant, sfn) == 0
+        tx_re = np.ctypeslib.as_array(R.ref_subframe_ptr(sfp, 4), shape=(4, 16, 1200))
+        tx_im = np.ctypeslib.as_array(R.ref_subframe_ptr(sfp, 5), shape=(4, 16, 1200))
+        rx = np.zeros((16, 1200), np.complex64)
+        for p in range(4):
+            if p < n_ant:
+                a, tau, ph = rng.uniform(0.6, 1.4), rng.uniform(-2e-3, 2e-3), rng.uniform(-np.pi, np.pi)
+                h = (a * np.exp(1j * (ph + 2 * np.pi * tau * k)))[None, :] * np.ones((16, 1))
+                rx += (h * (tx_re[p] + 1j * tx_im[p])).astype(np.complex64)
+            else:
+                h = np.zeros((16, 1200), np.complex64)
+            est = h + 0.2 * sig * (rng.standard_normal(h.shape) + 1j * rng.standard_normal(h.shape))
+            grids[u, 2 + p], grids[u, 6 + p] = est.real, est.imag
+        rx += (sig * (rng.standard_normal(rx.shape) + 1j * rng.standard_normal(rx.shape))).astype(np.complex64)
+        grids[u, 0], grids[u, 1] = rx.real, rx.imag
+        R.ref_subframe_free(sfp)
+        R.ref_phy_free(phy)
+    return dict(fft=fft, nrb=nrb, n_ant=n_ant, units=units, grids=grids, mibs=mibs)
+
+
+def ref_pbch_decode(R, case):
+    """liblte_phy_bch_channel_decode of the compiled reference over a case's grids -> uint32 [n, 4]: rc, N_ant, offset, mib (24 bits, MSB first;
+    N_ant, offset, mib = 0 when rc != 0)."""
+    import ctypes as C
+    from oracle import pyoracle as po
+    out = []
+    sfp = R.ref_subframe_new()
+    for u, (cell, sfn) in enumerate(case["units"]):
+        phy = R.ref_phy_new(po.FS_ENUM[case["fft"]], cell, 4, case["nrb"])
+        R.ref_subframe_set_num(sfp, 0)
+        g = case["grids"][u]
+        po.ref_subframe_view(R, sfp, 0)[:] = g[0]
+        po.ref_subframe_view(R, sfp, 1)[:] = g[1]
+        po.ref_subframe_view(R, sfp, 2, True)[:] = g[2:6]
+        po.ref_subframe_view(R, sfp, 3, True)[:] = g[6:10]
+        na, off, bits = C.c_uint32(), C.c_uint32(), np.zeros(32, np.uint8)
+        rc = R.ref_bch_channel_decode(phy, sfp, cell, C.byref(na), bits, C.byref(off))
+        mib = int("".join(str(int(b)) for b in bits[:24]), 2) if rc == 0 else 0
+        out.append((rc, na.value if rc == 0 else 0, off.value if rc == 0 else 0, mib))
+        R.ref_phy_free(phy)
+    R.ref_subframe_free(sfp)
+    return np.array(out, np.uint32)

@@ -98,6 +98,24 @@ def pdcch_vectors(R):
     print("pdcch_ref.npz:", {n: rec[n + "_dci"].shape[0] for n in names})
 
 
+def pbch_vectors(R):
+    """PBCH: received grids (symbols 7-10 only, four estimate planes) built by tests/lte_testdata.pbch_case with the reference's
+    transmitter, and what liblte_phy_bch_channel_decode returned for them (rc, N_ant, offset, MIB)."""
+    rec, names = {}, []
+    for name in td.PBCH_CASES:
+        case = td.pbch_case(R, name)
+        keep = min(len(case["units"]), 4)
+        case["units"], case["grids"] = case["units"][:keep], case["grids"][:keep]
+        names.append(name)
+        rec[name + "_cfg"] = np.array([case["fft"], case["nrb"]], np.uint32)
+        rec[name + "_cells"] = np.array([c for c, _ in case["units"]], np.uint32)
+        rec[name + "_grids"] = case["grids"][:, :, 7:11, :].astype(np.float32)
+        rec[name + "_want"] = td.ref_pbch_decode(R, case)
+    rec["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "pbch_ref.npz"), **rec)
+    print("pbch_ref.npz:", {n: rec[n + "_want"].tolist() for n in names})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     R, P = po.ref(), po.port()
@@ -108,6 +126,7 @@ def main():
     uplink_vectors(R)
     prach_vectors(R)
     pdcch_vectors(R)
+    pbch_vectors(R)
 
 
 if __name__ == "__main__":

@@ -54,8 +54,9 @@ struct PdcchResult { // per unit
 
 // transmit-diversity combiner of one group of N_ant resource elements (pre_decoder_and_matched_filter_dl,
 // liblte_phy.cc:7645-7796); h[p][e]: estimate of port p at element e of the group
-__device__ __forceinline__ void combine(uint32_t N_ant, const float (&yr)[4], const float (&yi)[4], const float (&hr)[4][4],
-                                        const float (&hi)[4][4], float (&xr)[4], float (&xi)[4])
+template <uint32_t N_ant>
+__device__ __forceinline__ void combine(const float (&yr)[4], const float (&yi)[4], const float (&hr)[4][4], const float (&hi)[4][4], float (&xr)[4],
+                                        float (&xi)[4])
 {
     if (N_ant == 1) {
         const float hn = hr[0][0] * hr[0][0] + hi[0][0] * hi[0][0];
@@ -93,9 +94,9 @@ __device__ __forceinline__ void combine(uint32_t N_ant, const float (&yr)[4], co
 // four ports nothing decodes.  per_port = 0 reproduces exactly that (rows never written read as the zeros a fresh
 // LIBLTE_PHY_STRUCT holds); per_port = 1 is the decoder the reference meant.
 // (n_planes = number of channel-estimate planes the device subframe was laid out with; N_ant = ports the combiner assumes)
-__device__ __forceinline__ void demod_res(const float *__restrict__ base, uint32_t n_planes, uint32_t N_ant, uint32_t per_port,
-                                          const uint32_t *__restrict__ re, uint32_t n_re, const GoldTables &gt, uint32_t c_init, uint32_t c_off,
-                                          int *soft, uint32_t ln)
+template <uint32_t N_ant>
+__device__ __forceinline__ void demod_res_n(const float *__restrict__ base, uint32_t n_planes, uint32_t per_port, const uint32_t *__restrict__ re,
+                                            uint32_t n_re, const GoldTables &gt, uint32_t c_init, uint32_t c_off, int *soft, uint32_t ln)
 {
     const float *y_re_p = base, *y_im_p = base + 16 * N_SC_MAX, *h_re_p = base + 2 * 16 * N_SC_MAX;
     const float *h_im_p = h_re_p + (size_t)n_planes * 16 * N_SC_MAX;
@@ -118,7 +119,7 @@ __device__ __forceinline__ void demod_res(const float *__restrict__ base, uint32
                 hr[3][e] = im2; hi[3][e] = 0.0f;
             }
         }
-        combine(N_ant, yr, yi, hr, hi, xr, xi);
+        combine<N_ant>(yr, yi, hr, hi, xr, xi);
         for (uint32_t e = 0; e < N_ant; e++) { // layer de-mapping d[g*N_ant + e] = x_e[g] (layer_demapper_dl, :7473-7514)
             int8_t b[6] = {0, 0, 0, 0, 0, 0};
             demap_symbol(xr[e], xi[e], 1 /* QPSK */, b);
@@ -128,6 +129,16 @@ __device__ __forceinline__ void demod_res(const float *__restrict__ base, uint32
             soft[n + 1] = absent ? 0 : ((w2 >> ((cn + 1) & 31)) & 1u) ? -(int)b[1] : (int)b[1];
         }
     }
+}
+
+__device__ __forceinline__ void demod_res(const float *__restrict__ base, uint32_t n_planes, uint32_t N_ant, uint32_t per_port,
+                                          const uint32_t *__restrict__ re, uint32_t n_re, const GoldTables &gt, uint32_t c_init, uint32_t c_off,
+                                          int *soft, uint32_t ln)
+{
+    // the port count is a template parameter so that the small per-group arrays stay in registers
+    if (N_ant == 1) demod_res_n<1>(base, n_planes, per_port, re, n_re, gt, c_init, c_off, soft, ln);
+    else if (N_ant == 2) demod_res_n<2>(base, n_planes, per_port, re, n_re, gt, c_init, c_off, soft, ln);
+    else demod_res_n<4>(base, n_planes, per_port, re, n_re, gt, c_init, c_off, soft, ln);
 }
 
 // The reference's K = 7, rate-1/3 Viterbi decoder (viterbi_decode, liblte_phy.cc:10161-10332) over N trellis steps, one state per

@@ -340,6 +340,34 @@ int  mi_lte_dci_1c_unpack(uint32_t payload, uint32_t n_bits, uint32_t rnti, uint
 int mi_lte_pbch_decode_run(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const float *d_subframes, const uint32_t *d_n_id_cell,
                            uint32_t n_units, uint32_t *h_N_ant, uint32_t *h_offset, uint32_t *h_mib);
 
+/* ---------------------------------------------------------------- initial synchronisation
+ * The three searches that precede the first subframe (LTE_fdd_dl_fs_samp_buf.cc:277-395), over samples resident in HBM
+ * (format as for mi_lte_dl_frontend_batch; `start` = index of the capture's first sample in the buffer):
+ *   mi_lte_coarse_timing_run  replaces liblte_phy_dl_find_coarse_timing_and_freq_offset (liblte_phy.h:1134-1138, impl.
+ *       liblte_phy.cc:5697-5852); reads mi_lte_coarse_timing_samples(fft_size, N_slots) samples.  mi_lte_coarse_timing is
+ *       LIBLTE_PHY_COARSE_TIMING_STRUCT (liblte_phy.h:1128-1132).
+ *   mi_lte_find_pss_run       replaces liblte_phy_find_pss_and_fine_timing (liblte_phy.h:1068-1075, impl. :5306-5510);
+ *       symb_starts[7] is read and rewritten like the reference's; reads up to symb_starts[6] + 12 slots + one symbol + 40.
+ *   mi_lte_find_sss_run       replaces liblte_phy_find_sss (liblte_phy.h:1106-1113, impl. :5578-5687); *found = 0 is the
+ *       reference's LIBLTE_ERROR_INVALID_INPUTS return (no SSS above 0.9 x pss_thresh).
+ * The device computes every correlation sum in the reference's summation order; the decisions on them are evaluated on the
+ * host with the reference's expressions.  Coarse timing is bit-identical for integer-valued samples (all sums are exact);
+ * the PSS / SSS stages sit behind an FFT and agree to its tolerance (decisions identical unless two candidates tie). */
+typedef struct {
+    float    freq_offset[5];
+    uint32_t symb_starts[5][7];
+    uint32_t n_corr_peaks;
+} mi_lte_coarse_timing;
+size_t mi_lte_coarse_timing_samples(uint32_t fft_size, uint32_t N_slots);
+int    mi_lte_coarse_timing_run(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const void *d_samples_a, const void *d_samples_b,
+                                uint64_t start, uint32_t N_slots, mi_lte_coarse_timing *out);
+int    mi_lte_find_pss_run(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const void *d_samples_a, const void *d_samples_b, uint64_t start,
+                           uint32_t *symb_starts /* [7] in/out */, uint32_t *N_id_2, uint32_t *pss_symb, float *pss_thresh,
+                           float *freq_offset);
+int    mi_lte_find_sss_run(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const void *d_samples_a, const void *d_samples_b, uint64_t start,
+                           uint32_t N_id_2, uint32_t *symb_starts /* [7] in/out */, float pss_thresh, uint32_t *N_id_1,
+                           uint32_t *frame_start_idx, uint32_t *found);
+
 /* ---------------------------------------------------------------- per-call host-pointer forms
  * The bodies of the reference's three entry points on this path, for callers that hold host
  * buffers exactly as the reference's callers do (LTE_fdd_dl_fs_samp_buf.cc:378-515,
@@ -366,6 +394,14 @@ int mi_lte_pdcch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const fl
 int mi_lte_bch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const float *h_rx_symb_re, const float *h_rx_symb_im,
                                    const float *h_rx_ce_re /*[4][16][1200]*/, const float *h_rx_ce_im, uint32_t N_id_cell, uint8_t *N_ant,
                                    uint8_t *h_out_bits, uint32_t *N_out_bits, uint8_t *offset);
+/* the three synchronisation searches on host sample arrays (they read exactly as far as the reference does); find_sss
+ * returns 1 (LIBLTE_ERROR_INVALID_INPUTS, the reference's value) when no SSS clears the threshold */
+int mi_lte_dl_find_coarse_timing_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_dl, const float *h_i_samps, const float *h_q_samps,
+                                      uint32_t N_slots, mi_lte_coarse_timing *out);
+int mi_lte_find_pss_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_dl, const float *h_i_samps, const float *h_q_samps,
+                         uint32_t *symb_starts, uint32_t *N_id_2, uint32_t *pss_symb, float *pss_thresh, float *freq_offset);
+int mi_lte_find_sss_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_dl, const float *h_i_samps, const float *h_q_samps, uint32_t N_id_2,
+                         uint32_t *symb_starts, float pss_thresh, uint32_t *N_id_1, uint32_t *frame_start_idx);
 /* uplink: liblte_phy_get_ul_subframe (h_i / h_q point at the subframe's first sample; 14 rows of 1200 floats are
  * written) and liblte_phy_pusch_channel_decode (the DMRS arrays are the caller's, i.e. what liblte_phy_ul_init
  * stored in LIBLTE_PHY_STRUCT::pusch_dmrs_{0,1}_{re,im}[subframe][N_prb]; a CRC failure returns 1 =

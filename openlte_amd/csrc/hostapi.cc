@@ -161,6 +161,63 @@ int mi_lte_bch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const floa
     return 0;
 }
 
+// ---- initial synchronisation (liblte_phy.cc:5697-5852, :5306-5510, :5578-5687): stage n samples of each array, run the device search
+namespace {
+int stage_iq(mi_lte_ctx *ctx, const float *h_i, const float *h_q, size_t n, DevBuf &d_i, DevBuf &d_q)
+{
+    if (d_i.alloc(n * 4) || d_q.alloc(n * 4)) return MI_LTE_ERR_NOMEM;
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(d_i.p, h_i, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(d_q.p, h_q, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    return MI_LTE_OK;
+}
+} // namespace
+
+int mi_lte_dl_find_coarse_timing_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_dl, const float *h_i, const float *h_q, uint32_t N_slots,
+                                      mi_lte_coarse_timing *out)
+{
+    if (!ctx) return MI_LTE_ERR_INVALID_ARG;
+    if (!h_i || !h_q || !out) return 1;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    mi_lte_dl_cfg cfg = {fft_size, N_rb_dl, 1, MI_LTE_IQ_F32_PLANAR};
+    DevBuf d_i, d_q;
+    int    rc = stage_iq(ctx, h_i, h_q, mi_lte_coarse_timing_samples(fft_size, N_slots), d_i, d_q);
+    if (rc != MI_LTE_OK) return rc;
+    return mi_lte_coarse_timing_run(ctx, &cfg, d_i.p, d_q.p, 0, N_slots, out);
+}
+
+int mi_lte_find_pss_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_dl, const float *h_i, const float *h_q, uint32_t *symb_starts,
+                         uint32_t *N_id_2, uint32_t *pss_symb, float *pss_thresh, float *freq_offset)
+{
+    if (!ctx) return MI_LTE_ERR_INVALID_ARG;
+    if (!h_i || !h_q || !symb_starts || !N_id_2 || !pss_symb || !pss_thresh || !freq_offset) return 1;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    mi_lte_dl_cfg  cfg = {fft_size, N_rb_dl, 1, MI_LTE_IQ_F32_PLANAR};
+    const uint32_t sc = 2048 / (fft_size ? fft_size : 2048);
+    uint32_t       last = 0;
+    for (int j = 0; j < 7; j++) last = symb_starts[j] > last ? symb_starts[j] : last;
+    const size_t n = (size_t)last + 11 * (15360 / sc) + 160 / sc + fft_size + 38; // last window of the 84, or of the +39 fine-timing trial
+    DevBuf d_i, d_q;
+    int    rc = stage_iq(ctx, h_i, h_q, n, d_i, d_q);
+    if (rc != MI_LTE_OK) return rc;
+    return mi_lte_find_pss_run(ctx, &cfg, d_i.p, d_q.p, 0, symb_starts, N_id_2, pss_symb, pss_thresh, freq_offset);
+}
+
+int mi_lte_find_sss_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_dl, const float *h_i, const float *h_q, uint32_t N_id_2, uint32_t *symb_starts,
+                         float pss_thresh, uint32_t *N_id_1, uint32_t *frame_start_idx)
+{
+    if (!ctx) return MI_LTE_ERR_INVALID_ARG;
+    if (!h_i || !h_q || !symb_starts || !N_id_1 || !frame_start_idx) return 1;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    mi_lte_dl_cfg  cfg = {fft_size, N_rb_dl, 1, MI_LTE_IQ_F32_PLANAR};
+    const uint32_t sc = 2048 / (fft_size ? fft_size : 2048);
+    DevBuf d_i, d_q;
+    int    rc = stage_iq(ctx, h_i, h_q, (size_t)symb_starts[5] + 160 / sc - 1 + fft_size, d_i, d_q);
+    if (rc != MI_LTE_OK) return rc;
+    uint32_t found = 0;
+    rc = mi_lte_find_sss_run(ctx, &cfg, d_i.p, d_q.p, 0, N_id_2, symb_starts, pss_thresh, N_id_1, frame_start_idx, &found);
+    return rc != MI_LTE_OK ? rc : (found ? 0 : 1);
+}
+
 // liblte_phy_get_ul_subframe (liblte_phy.cc:6209-6236)
 int mi_lte_get_ul_subframe_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_ul, const float *h_i, const float *h_q, float *h_symb_re,
                                 float *h_symb_im)

@@ -52,6 +52,11 @@ class PdcchDci(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("rnti", "format", "candidate", "n_bits", "payload", "mcs", "alloc_valid", "reserved")] + [("alloc", PdschAlloc)]
 
 
+class CoarseTiming(C.Structure):
+    """mi_lte_coarse_timing = LIBLTE_PHY_COARSE_TIMING_STRUCT"""
+    _fields_ = [("freq_offset", C.c_float * 5), ("symb_starts", (C.c_uint32 * 7) * 5), ("n_corr_peaks", C.c_uint32)]
+
+
 class MiLteError(RuntimeError):
     pass
 
@@ -132,6 +137,11 @@ def load_library():
     L.mi_lte_pdcch_plan_create.argtypes = [vp, C.POINTER(DlCfg), C.c_float, u32, u32, u32p, u32, C.POINTER(vp)]
     L.mi_lte_pdcch_plan_destroy.argtypes = [vp, vp]
     L.mi_lte_pdcch_decode_run.argtypes = [vp, vp, vp, vp, vp, u32, u32p, u32p, u32p, u32p, C.POINTER(PdcchDci)]
+    L.mi_lte_coarse_timing_samples.argtypes = [u32, u32]
+    L.mi_lte_coarse_timing_samples.restype = C.c_size_t
+    L.mi_lte_coarse_timing_run.argtypes = [vp, C.POINTER(DlCfg), vp, vp, C.c_uint64, u32, C.POINTER(CoarseTiming)]
+    L.mi_lte_find_pss_run.argtypes = [vp, C.POINTER(DlCfg), vp, vp, C.c_uint64, u32p, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.mi_lte_find_sss_run.argtypes = [vp, C.POINTER(DlCfg), vp, vp, C.c_uint64, u32, u32p, C.c_float, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
     L.mi_lte_pbch_decode_run.argtypes = [vp, C.POINTER(DlCfg), vp, vp, u32, u32p, u32p, u32p]
     L.mi_lte_pdcch_re_tables.argtypes = [u32, u32, u32, C.c_float, u32, u32p, u32p]
     L.mi_lte_dci_1a_unpack.argtypes = [u32, u32, u32, u32, u32, C.POINTER(PdcchDci)]
@@ -479,6 +489,28 @@ class Context:
 
     def prach_plan(self, cfg, prach_cfg, roots_fft=None):
         return PrachPlan(self, cfg, prach_cfg, roots_fft)
+
+    def coarse_timing_dev(self, cfg, d_a, d_b, n_slots, start=0):
+        """CoarseTiming for samples resident in HBM (d_b None for int8 interleaved)."""
+        out = CoarseTiming()
+        self._check(self.L.mi_lte_coarse_timing_run(self.h, C.byref(cfg), d_a.ptr, d_b.ptr if d_b is not None else None, start, n_slots, C.byref(out)))
+        return out
+
+    def find_pss_dev(self, cfg, d_a, d_b, symb_starts, start=0):
+        """(symb_starts[7] rewritten, N_id_2, pss_symb, pss_thresh, freq_offset)"""
+        ss = np.ascontiguousarray(symb_starts, np.uint32).copy()
+        n2, ps, th, fo = C.c_uint32(), C.c_uint32(), C.c_float(), C.c_float()
+        self._check(self.L.mi_lte_find_pss_run(self.h, C.byref(cfg), d_a.ptr, d_b.ptr if d_b is not None else None, start, ss, C.byref(n2), C.byref(ps),
+                                               C.byref(th), C.byref(fo)))
+        return ss, n2.value, ps.value, th.value, fo.value
+
+    def find_sss_dev(self, cfg, d_a, d_b, n_id_2, symb_starts, pss_thresh, start=0):
+        """(found, N_id_1, frame_start_idx, symb_starts[7])"""
+        ss = np.ascontiguousarray(symb_starts, np.uint32).copy()
+        n1, fs, found = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._check(self.L.mi_lte_find_sss_run(self.h, C.byref(cfg), d_a.ptr, d_b.ptr if d_b is not None else None, start, n_id_2, ss, pss_thresh,
+                                               C.byref(n1), C.byref(fs), C.byref(found)))
+        return bool(found.value), n1.value, fs.value, ss
 
     def pbch_decode_dev(self, cfg, d_subframes, d_cell, n_units):
         """(N_ant[n] (0 = not decoded), offset[n], mib[n] = the 24 BCH bits, first bit in bit 23); cfg.N_ant must be 4."""

@@ -201,6 +201,11 @@ def ref():
     L.ref_bch_channel_decode.argtypes = [vp, vp, u32, C.POINTER(u32), u8p, C.POINTER(u32)]
     L.ref_time_bch.argtypes = [vp, vp, u32, u32]
     L.ref_time_bch.restype = C.c_double
+    L.ref_find_coarse_timing.argtypes = [vp, f32p, f32p, u32, C.POINTER(u32), f32p, u32p]
+    L.ref_find_pss.argtypes = [vp, f32p, f32p, u32p, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.ref_find_sss.argtypes = [vp, f32p, f32p, u32, u32p, C.c_float, C.POINTER(u32), C.POINTER(u32)]
+    L.ref_time_coarse_timing.argtypes = [vp, f32p, f32p, u32, u32]
+    L.ref_time_coarse_timing.restype = C.c_double
     _REF = L
     return L
 

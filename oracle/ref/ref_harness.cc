@@ -443,6 +443,40 @@ double ref_time_bch(void *phy, void *sf, uint32_t N_id_cell, uint32_t reps)
     return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
 }
 
+// ---- initial synchronisation
+int ref_find_coarse_timing(void *phy, float *i_samps, float *q_samps, uint32_t N_slots, uint32_t *n_peaks, float *freq_offset /*[5]*/,
+                           uint32_t *symb_starts /*[5][7]*/)
+{
+    LIBLTE_PHY_COARSE_TIMING_STRUCT t;
+    memset(&t, 0, sizeof(t));
+    int err = (int)liblte_phy_dl_find_coarse_timing_and_freq_offset((LIBLTE_PHY_STRUCT *)phy, i_samps, q_samps, N_slots, &t);
+    *n_peaks = t.n_corr_peaks;
+    for (uint32_t i = 0; i < 5; i++) {
+        freq_offset[i] = t.freq_offset[i];
+        for (uint32_t j = 0; j < 7; j++) symb_starts[i * 7 + j] = t.symb_starts[i][j];
+    }
+    return err;
+}
+int ref_find_pss(void *phy, float *i_samps, float *q_samps, uint32_t *symb_starts /*[7] in/out*/, uint32_t *N_id_2, uint32_t *pss_symb, float *pss_thresh,
+                 float *freq_offset)
+{
+    return (int)liblte_phy_find_pss_and_fine_timing((LIBLTE_PHY_STRUCT *)phy, i_samps, q_samps, symb_starts, N_id_2, pss_symb, pss_thresh, freq_offset);
+}
+int ref_find_sss(void *phy, float *i_samps, float *q_samps, uint32_t N_id_2, uint32_t *symb_starts, float pss_thresh, uint32_t *N_id_1,
+                 uint32_t *frame_start_idx)
+{
+    return (int)liblte_phy_find_sss((LIBLTE_PHY_STRUCT *)phy, i_samps, q_samps, N_id_2, symb_starts, pss_thresh, N_id_1, frame_start_idx);
+}
+double ref_time_coarse_timing(void *phy, float *i_samps, float *q_samps, uint32_t N_slots, uint32_t reps)
+{
+    LIBLTE_PHY_COARSE_TIMING_STRUCT t;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (uint32_t r = 0; r < reps; r++) liblte_phy_dl_find_coarse_timing_and_freq_offset((LIBLTE_PHY_STRUCT *)phy, i_samps, q_samps, N_slots, &t);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+}
+
 // format 0 = 1A, 1 = 1C; the allocation starts zeroed
 int ref_dci_unpack(uint32_t format, uint8_t *bits, uint32_t n_bits, uint32_t rnti, uint32_t N_rb_dl, uint32_t N_ant, ref_alloc_t *out,
                    uint32_t *mcs, uint32_t *prb_slot1 /*[110]*/)

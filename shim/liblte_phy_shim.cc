@@ -11,6 +11,9 @@
 //     liblte_phy_detect_prach             liblte_phy.h:862-868     (impl. liblte_phy.cc:3299-3479)
 //     liblte_phy_pdcch_channel_decode     liblte_phy.h:1012-1020   (impl. liblte_phy.cc:4519-5135)
 //     liblte_phy_bch_channel_decode       liblte_phy.h:947-953     (impl. liblte_phy.cc:3968-4105)
+//     liblte_phy_dl_find_coarse_timing_and_freq_offset  liblte_phy.h:1134-1138 (impl. liblte_phy.cc:5697-5852)
+//     liblte_phy_find_pss_and_fine_timing liblte_phy.h:1068-1075   (impl. liblte_phy.cc:5306-5510)
+//     liblte_phy_find_sss                 liblte_phy.h:1106-1113   (impl. liblte_phy.cc:5578-5687)
 //
 // by forwarding to libmi_lte.so's C-ABI (include/mi_lte.h).  The reference's own definitions of
 // these symbols are kept out of the link by compiling liblte_phy.cc with
@@ -202,4 +205,47 @@ LIBLTE_ERROR_ENUM liblte_phy_bch_channel_decode(LIBLTE_PHY_STRUCT *phy_struct, L
     int rc = mi_lte_bch_channel_decode_host(c, phy_struct->N_rb_dl, &subframe->rx_symb_re[0][0], &subframe->rx_symb_im[0][0], &subframe->rx_ce_re[0][0][0],
                                             &subframe->rx_ce_im[0][0][0], N_id_cell, N_ant, out_bits, N_out_bits, offset);
     return rc == 0 ? LIBLTE_SUCCESS : rc == 2 ? LIBLTE_ERROR_DECODE_FAIL : LIBLTE_ERROR_INVALID_INPUTS;
+}
+
+// ---- initial synchronisation (LTE_fdd_dl_fs_samp_buf.cc:277-395)
+
+LIBLTE_ERROR_ENUM liblte_phy_dl_find_coarse_timing_and_freq_offset(LIBLTE_PHY_STRUCT *phy_struct, float *i_samps, float *q_samps, uint32 N_slots,
+                                                                   LIBLTE_PHY_COARSE_TIMING_STRUCT *timing_struct)
+{
+    if (phy_struct == NULL || i_samps == NULL || q_samps == NULL || timing_struct == NULL) return LIBLTE_ERROR_INVALID_INPUTS;
+    mi_lte_ctx *c = ctx_for(phy_struct);
+    if (!c) return LIBLTE_ERROR_INVALID_INPUTS;
+    mi_lte_coarse_timing t;
+    if (mi_lte_dl_find_coarse_timing_host(c, phy_struct->N_samps_per_symb, phy_struct->N_rb_dl, i_samps, q_samps, N_slots, &t) != 0)
+        return LIBLTE_ERROR_INVALID_INPUTS;
+    timing_struct->n_corr_peaks = t.n_corr_peaks;
+    for (uint32 i = 0; i < t.n_corr_peaks && i < LIBLTE_PHY_N_MAX_ROUGH_CORR_SEARCH_PEAKS; i++) { // the reference writes the found peaks only
+        timing_struct->freq_offset[i] = t.freq_offset[i];
+        for (uint32 j = 0; j < 7; j++) timing_struct->symb_starts[i][j] = t.symb_starts[i][j];
+    }
+    return LIBLTE_SUCCESS;
+}
+
+LIBLTE_ERROR_ENUM liblte_phy_find_pss_and_fine_timing(LIBLTE_PHY_STRUCT *phy_struct, float *i_samps, float *q_samps, uint32 *symb_starts,
+                                                      uint32 *N_id_2, uint32 *pss_symb, float *pss_thresh, float *freq_offset)
+{
+    if (phy_struct == NULL || i_samps == NULL || q_samps == NULL || symb_starts == NULL || N_id_2 == NULL || pss_symb == NULL || pss_thresh == NULL)
+        return LIBLTE_ERROR_INVALID_INPUTS;
+    mi_lte_ctx *c = ctx_for(phy_struct);
+    if (!c) return LIBLTE_ERROR_INVALID_INPUTS;
+    float f = 0;
+    int   rc = mi_lte_find_pss_host(c, phy_struct->N_samps_per_symb, phy_struct->N_rb_dl, i_samps, q_samps, symb_starts, N_id_2, pss_symb, pss_thresh, &f);
+    if (rc == 0 && freq_offset) *freq_offset = f;
+    return rc == 0 ? LIBLTE_SUCCESS : LIBLTE_ERROR_INVALID_INPUTS;
+}
+
+LIBLTE_ERROR_ENUM liblte_phy_find_sss(LIBLTE_PHY_STRUCT *phy_struct, float *i_samps, float *q_samps, uint32 N_id_2, uint32 *symb_starts, float pss_thresh,
+                                      uint32 *N_id_1, uint32 *frame_start_idx)
+{
+    if (phy_struct == NULL || i_samps == NULL || q_samps == NULL || symb_starts == NULL || N_id_1 == NULL || frame_start_idx == NULL)
+        return LIBLTE_ERROR_INVALID_INPUTS;
+    mi_lte_ctx *c = ctx_for(phy_struct);
+    if (!c) return LIBLTE_ERROR_INVALID_INPUTS;
+    int rc = mi_lte_find_sss_host(c, phy_struct->N_samps_per_symb, phy_struct->N_rb_dl, i_samps, q_samps, N_id_2, symb_starts, pss_thresh, N_id_1, frame_start_idx);
+    return rc == 0 ? LIBLTE_SUCCESS : LIBLTE_ERROR_INVALID_INPUTS;
 }

@@ -410,3 +410,67 @@ def ref_pbch_decode(R, case):
         R.ref_phy_free(phy)
     R.ref_subframe_free(sfp)
     return np.array(out, np.uint32)
+
+
+# ---------------------------------------------------------------------------------------------------
+# initial synchronisation: int8 captures written by shim/_build/capture_gen (the reference's TX API), impaired in numpy
+
+SYNC_CASES = {
+    # name: (fft, N_rb_dl, cell, frames, delay samples prepended, frequency offset Hz, snr_db)
+    "1p4MHz_clean": (128, 6, 17, 18, 0, 0.0, 300.0),
+    "1p4MHz_offset": (128, 6, 301, 18, 1234, 700.0, 12.0),
+    "5MHz_noisy": (512, 25, 150, 18, 40000, -300.0, 6.0),
+    "20MHz": (2048, 100, 77, 10, 100001, 150.0, 15.0),
+}
+
+
+def capture_gen_path():
+    import os
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "shim", "_build", "capture_gen")
+    return p if os.path.exists(p) else None
+
+
+def sync_case(name, tmp_dir, seed=41):
+    """int8 interleaved I,Q capture for one case (numpy int8 [n, 2])."""
+    import os
+    import subprocess
+    fft, nrb, cell, frames, delay, f_off, snr_db = SYNC_CASES[name]
+    path = os.path.join(str(tmp_dir), "cap_%s.bin" % name)
+    subprocess.run([capture_gen_path(), path, str(nrb), str(cell), str(frames)], check=True, timeout=600, stdout=subprocess.DEVNULL)
+    x = np.fromfile(path, np.int8).reshape(-1, 2).astype(np.float32)
+    os.remove(path)
+    rng = np.random.default_rng(seed)
+    z = x[:, 0] + 1j * x[:, 1]
+    rms = float(np.sqrt(np.mean(np.abs(z) ** 2)))
+    z = np.concatenate([np.zeros(delay, np.complex64), z])
+    fs = 30.72e6 * fft / 2048
+    z = z * np.exp(2j * np.pi * f_off * np.arange(len(z)) / fs)
+    if snr_db < 200:
+        sig = rms * 10 ** (-snr_db / 20) / np.sqrt(2)
+        z = z + sig * (rng.standard_normal(len(z)) + 1j * rng.standard_normal(len(z)))
+    iq = np.stack([np.clip(np.round(z.real), -127, 127), np.clip(np.round(z.imag), -127, 127)], axis=1).astype(np.int8)
+    return dict(fft=fft, nrb=nrb, cell=cell, iq=iq, delay=delay, f_off=f_off)
+
+
+def ref_sync(R, case, n_slots=160):
+    """The compiled reference's three searches over a capture (the scanner's sequence, first coarse peak that yields a cell):
+    dict(coarse=(n_peaks, freq_offset[5], symb_starts[5,7]), per_peak=[(pss tuple, sss tuple or None) ...])."""
+    import ctypes as C
+    from oracle import pyoracle as po
+    phy = R.ref_phy_new(po.FS_ENUM[case["fft"]], 0, 1, case["nrb"])
+    i = np.ascontiguousarray(case["iq"][:, 0].astype(np.float32))
+    q = np.ascontiguousarray(case["iq"][:, 1].astype(np.float32))
+    n, fo, ss = C.c_uint32(), np.zeros(5, np.float32), np.zeros(35, np.uint32)
+    assert R.ref_find_coarse_timing(phy, i, q, n_slots, C.byref(n), fo, ss) == 0
+    ss = ss.reshape(5, 7)
+    peaks = []
+    for p in range(n.value):
+        s = ss[p].copy()
+        n2, ps, th, f = C.c_uint32(), C.c_uint32(), C.c_float(), C.c_float()
+        assert R.ref_find_pss(phy, i, q, s, C.byref(n2), C.byref(ps), C.byref(th), C.byref(f)) == 0
+        pss = (s.copy(), n2.value, ps.value, th.value, f.value)
+        n1, fs = C.c_uint32(), C.c_uint32()
+        rc = R.ref_find_sss(phy, i, q, n2.value, s, th.value, C.byref(n1), C.byref(fs))
+        peaks.append((pss, (n1.value, fs.value, s.copy()) if rc == 0 else None))
+    R.ref_phy_free(phy)
+    return dict(coarse=(n.value, fo, ss), per_peak=peaks)

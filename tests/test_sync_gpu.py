@@ -1,0 +1,72 @@
+"""GPU parity: initial synchronisation (HIP) vs the compiled reference.
+
+Coarse timing: exact.  The samples are integer-valued (the int8 capture format), every correlation sum is an exact integer in
+float32, and the decisions on them are the reference's expressions evaluated on the host -- peak count, symbol starts and the
+float frequency offsets must be equal bit for bit.  PSS / SSS: the correlations sit behind the FFT (parity to 1e-5), so
+the integer results (N_id_2, PSS symbol, symbol starts, N_id_1, frame start) must be equal and pss_thresh within 1e-4 relative."""
+import os
+
+import numpy as np
+import pytest
+
+import lte_testdata as td
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_sync(ctx, case, n_slots=160):
+    import openlte_amd as m
+    cfg = m.DlCfg(case["fft"], case["nrb"], 1, m.IQ_I8)
+    d = ctx.to_device(np.ascontiguousarray(case["iq"]))
+    try:
+        t = ctx.coarse_timing_dev(cfg, d, None, n_slots)
+        ss = np.array([list(t.symb_starts[i]) for i in range(5)], np.uint32)
+        peaks = []
+        for p in range(t.n_corr_peaks):
+            s, n2, ps, th, f = ctx.find_pss_dev(cfg, d, None, ss[p])
+            found, n1, fs, s2 = ctx.find_sss_dev(cfg, d, None, n2, s, th)
+            peaks.append(((s, n2, ps, th, f), (n1, fs, s2) if found else None))
+        return dict(coarse=(t.n_corr_peaks, np.array(list(t.freq_offset), np.float32), ss), per_peak=peaks)
+    finally:
+        d.free()
+
+
+def compare(got, want):
+    n = want["coarse"][0]
+    assert got["coarse"][0] == n
+    assert got["coarse"][2][:n].tolist() == want["coarse"][2][:n].tolist()
+    assert got["coarse"][1][:n].tobytes() == want["coarse"][1][:n].tobytes(), (got["coarse"][1], want["coarse"][1])
+    for (gp, gs), (wp, ws) in zip(got["per_peak"], want["per_peak"]):
+        assert gp[0].tolist() == wp[0].tolist() and gp[1:3] == wp[1:3] and gp[4] == wp[4], (gp, wp)
+        assert abs(gp[3] - wp[3]) <= 1e-4 * abs(wp[3])
+        assert (gs is None) == (ws is None)
+        if ws is not None:
+            assert gs[:2] == ws[:2] and gs[2].tolist() == ws[2].tolist()
+
+
+@pytest.mark.parametrize("name", list(td.SYNC_CASES))
+def test_sync_matches_reference(ctx, ref, tmp_path, name):
+    if td.capture_gen_path() is None:
+        pytest.skip("shim/_build/capture_gen not built (needs the reference tree at build time)")
+    case = td.sync_case(name, tmp_path)
+    want = td.ref_sync(ref, case)
+    got = gpu_sync(ctx, case)
+    compare(got, want)
+    # and the cell comes out where it was put (the fine timing lands a few samples inside the cyclic prefix at the wider bandwidths)
+    hits = [(3 * s[0] + p[1], s[1]) for p, s in got["per_peak"] if s is not None]
+    n_frame, slack = 307200 * case["fft"] // 2048, 20 * case["fft"] // 2048 + 1
+    assert any(c == case["cell"] and min((fs - case["delay"]) % n_frame, (case["delay"] - fs) % n_frame) <= slack for c, fs in hits), hits
+
+
+def test_sync_golden_fixture(ctx):
+    """A 1.4 MHz capture and what the reference's three searches returned for it, recorded by tools/gen_golden.py."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sync_ref.npz"), allow_pickle=False)
+    case = dict(fft=int(g["cfg"][0]), nrb=int(g["cfg"][1]), iq=g["iq"])
+    got = gpu_sync(ctx, case)
+    n = int(g["n_peaks"])
+    assert got["coarse"][0] == n and got["coarse"][2][:n].tolist() == g["symb_starts"][:n].tolist()
+    assert got["coarse"][1][:n].tobytes() == g["freq_offset"][:n].tobytes()
+    for p, (gp, gs) in enumerate(got["per_peak"]):
+        assert [gp[1], gp[2]] + gp[0].tolist() == g["pss"][p].tolist()
+        assert abs(gp[3] - g["pss_thresh"][p]) <= 1e-4 * g["pss_thresh"][p]
+        assert ([1, gs[0], gs[1]] if gs is not None else [0, 0, 0]) == g["sss"][p].tolist()

@@ -116,6 +116,24 @@ def pbch_vectors(R):
     print("pbch_ref.npz:", {n: rec[n + "_want"].tolist() for n in names})
 
 
+def sync_vectors(R):
+    """Initial synchronisation: one impaired 1.4 MHz capture (int8) and the outputs of the reference's coarse-timing, PSS and SSS
+    searches over it, per coarse peak."""
+    import tempfile
+    if td.capture_gen_path() is None:
+        print("sync_ref.npz: skipped (shim/_build/capture_gen not built)")
+        return
+    with tempfile.TemporaryDirectory() as tmp:
+        case = td.sync_case("1p4MHz_offset", tmp)
+    want = td.ref_sync(R, case)
+    n, fo, ss = want["coarse"]
+    pss = np.array([[p[1], p[2]] + p[0].tolist() for p, _ in want["per_peak"]], np.uint32)
+    np.savez_compressed(os.path.join(OUT, "sync_ref.npz"), cfg=np.array([case["fft"], case["nrb"]], np.uint32), iq=case["iq"], n_peaks=np.uint32(n),
+                        freq_offset=fo, symb_starts=ss, pss=pss, pss_thresh=np.array([p[3] for p, _ in want["per_peak"]], np.float32),
+                        sss=np.array([[1, s[0], s[1]] if s is not None else [0, 0, 0] for _, s in want["per_peak"]], np.uint32))
+    print("sync_ref.npz:", n, "peaks;", [(3 * s[0] + p[1], s[1]) for p, s in want["per_peak"] if s is not None])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     R, P = po.ref(), po.port()
@@ -127,6 +145,7 @@ def main():
     prach_vectors(R)
     pdcch_vectors(R)
     pbch_vectors(R)
+    sync_vectors(R)
 
 
 if __name__ == "__main__":

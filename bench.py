@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- one JSON line per run (driver contract).
 
-    python bench.py --gpus N --steps K --warmup W [--workload chain|frontend|turbo|uplink|control]
+    python bench.py --gpus N --steps K --warmup W [--workload chain|frontend|turbo|uplink|control|sync]
 
 A "step" is one pass of the hot path over one batch of synthetic input that is already resident in
 HBM.  Work is sharded by unit (subframes / code blocks) over ranks with no data-path collective
@@ -514,6 +514,85 @@ class ControlWorkload:
                 "sample": "%d repetitions of liblte_phy_pdcch_channel_decode on one of the benchmark's subframes, 1 thread, %.1f s" % (reps, t)}
 
 
+class SyncWorkload:
+    """initial synchronisation of a 20 MHz capture -- the CP-autocorrelation coarse timing search over 160 slots
+    (the dominant cost of scanning, 354 M complex MACs), the PSS search with fine timing (164 FFTs) and the SSS search.  One unit =
+    one capture position searched (the three calls the scanner makes before it can read a subframe); captures are int8 in HBM."""
+    name = "sync"
+    metric = "cell searches/sec @20MHz: coarse timing over 160 slots + PSS/fine timing + SSS (liblte_phy_dl_find_coarse_timing_and_freq_offset, _find_pss_and_fine_timing, _find_sss; SURVEY 8f N4)"
+    unit = "searches/s"
+    dtype = "i8 IQ in, f32 correlations (reference summation order), f32 FFT"
+    N_SLOTS = 160
+    alg_bytes_per_unit = 161 * 15360 * 2 + 2208 + 15360 * 4
+    dominant = "k_cp_corr"
+
+    def __init__(self, ctx, n_units, rank):
+        import numpy as np
+        import openlte_amd as m
+        from openlte_amd import synth
+        self.ctx, self.m, self.np = ctx, m, np
+        self.n = n_units or 32
+        self.cfg = m.DlCfg(2048, 100, 1, m.IQ_I8)
+        # a synthetic 20 MHz capture: the library's downlink subframes back to back (CRS + PDSCH give the cyclic-prefix structure
+        # the coarse search looks for; PSS/SSS are not needed to time the searches)
+        n_sf = 100
+        cfg1 = m.DlCfg(2048, 100, 1, 0)
+        allocs = []
+        for u in range(n_sf):
+            allocs += [m.make_alloc(u, 2, 1384, list(range(8 * a, 8 * a + 8)), 0x100 + a) for a in range(4)]
+        iq, _ = synth.dl_units(cfg1, np.arange(n_sf) % 10, [17 + rank] * n_sf, allocs, 4, snr_db=20.0, max_delay=0, seed=5 + rank)
+        cap = iq[:, :30720, :].reshape(-1, 2)
+        self.cap = np.ascontiguousarray(cap)
+        self.d_cap = ctx.to_device(self.cap)
+        need = int(ctx.L.mi_lte_coarse_timing_samples(2048, self.N_SLOTS))
+        self.starts = [int(x) for x in (np.arange(self.n) * 3001) % (len(cap) - need - 13 * 15360)]
+        self.last = None
+
+    def step(self):
+        for st in self.starts:
+            t = self.ctx.coarse_timing_dev(self.cfg, self.d_cap, None, self.N_SLOTS, start=st)
+            ss, n2, ps, th, fo = self.ctx.find_pss_dev(self.cfg, self.d_cap, None, list(t.symb_starts[0]), start=st)
+            self.last = (t.n_corr_peaks, n2, self.ctx.find_sss_dev(self.cfg, self.d_cap, None, n2, ss, th, start=st))
+
+    def units_per_step(self):
+        return self.n
+
+    def value_per_unit(self):
+        return 1.0
+
+    def extra(self, value):
+        return {"slots_searched_per_s": round(value * self.N_SLOTS, 1), "capture_seconds_per_second": round(value * self.N_SLOTS * 0.0005, 2),
+                "last_search": "peaks=%d N_id_2=%d sss_found=%s" % (self.last[0], self.last[1], self.last[2][0])}
+
+    def roofline_bytes(self, kernel, n_launch_per_step):
+        n = self.n
+        return {"k_cp_corr": n * (161 * 15360 * 2 + 160 * 15360 * 8), "k_cp_accum": n * (160 * 15360 * 8 + 15360 * 4), "k_cp_gather": n * 160 * 5 * 16,
+                "k_sync_fft": n * 165 * (2048 * 2 + 1200 * 8), "k_seq_corr": n * (164 * 1200 * 8 + 1200 * 8)}.get(kernel)
+
+    def config(self, world):
+        return {"workload": "N4 initial sync: 20 MHz int8 capture resident in HBM, %d search positions per GPU per step, each = coarse timing over "
+                            "160 slots + PSS search (84 + 80 FFTs) + SSS search" % self.n,
+                "searches_per_gpu": self.n, "sharding": "search positions / captures over %d GPU(s), no collective" % world}
+
+    def cpu_baseline(self, budget_s=12.0):
+        """The reference's liblte_phy_dl_find_coarse_timing_and_freq_offset (the dominant call) on one core."""
+        np = self.np
+        from oracle import pyoracle as po
+        R = po.ref()
+        if R is None:
+            return None
+        phy = R.ref_phy_new(4, 17, 1, 100)
+        st = self.starts[0]
+        i = np.ascontiguousarray(self.cap[st:, 0].astype(np.float32))
+        q = np.ascontiguousarray(self.cap[st:, 1].astype(np.float32))
+        t1 = R.ref_time_coarse_timing(phy, i, q, self.N_SLOTS, 1)
+        reps = int(max(2, min(200, budget_s / t1)))
+        t = R.ref_time_coarse_timing(phy, i, q, self.N_SLOTS, reps)
+        R.ref_phy_free(phy)
+        return {"value": round(reps / t, 3), "unit": self.unit, "cores": 1, "kind": "reference",
+                "sample": "%d repetitions of the coarse-timing call alone (the PSS/SSS calls add ~10%% on the CPU), 1 thread, %.1f s" % (reps, t)}
+
+
 class MultiStream:
     """Run S independent shards of a workload on S contexts (= S HIP streams) of the same GPU, launched
     back to back and synchronised together.  Units are independent, so this is the same "shard by
@@ -521,7 +600,7 @@ class MultiStream:
     the lock-step trellis kernel 4+ waves per SIMD (32k subframes), one stream is the fastest."""
 
     def __init__(self, cls, ctxs, n_units, rank):
-        n_units = n_units or {"chain": 32768, "frontend": 10000, "turbo": 65536, "uplink": 16384, "control": 8192}[cls.name]
+        n_units = n_units or {"chain": 32768, "frontend": 10000, "turbo": 65536, "uplink": 16384, "control": 8192, "sync": 32}[cls.name]
         per = max(64, (n_units // len(ctxs) + 63) // 64 * 64)
         self.parts = [cls(c, per, rank * 16 + k) for k, c in enumerate(ctxs)]
         self.ctxs = ctxs
@@ -581,7 +660,7 @@ class MultiStream:
         return self.parts[0].cpu_baseline()
 
 
-WORKLOADS = {"turbo": TurboWorkload, "frontend": FrontendWorkload, "chain": ChainWorkload, "uplink": UplinkWorkload, "control": ControlWorkload}
+WORKLOADS = {"turbo": TurboWorkload, "frontend": FrontendWorkload, "chain": ChainWorkload, "uplink": UplinkWorkload, "control": ControlWorkload, "sync": SyncWorkload}
 
 
 def pick_workload(name):

@@ -42,18 +42,26 @@ template <> struct Samples<float> {
 template <typename S>
 __global__ __launch_bounds__(256) void k_cp_corr(S src, uint64_t start, uint32_t n_slot, uint32_t N, uint32_t cp, float2 *__restrict__ corr)
 {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x, slot = blockIdx.y;
-    if (i >= n_slot) return;
-    const size_t b = start + (size_t)slot * n_slot + i;
-    float re = 0, im = 0;
-    for (uint32_t j = 0; j < cp; j++) {
-        float ar, ai, br, bi;
-        src.at(b + j, ar, ai);
-        src.at(b + j + N, br, bi);
-        re += ar * br + ai * bi;
-        im += ar * bi - ai * br;
+    // the 256 windows of a block overlap: stage the 256 + cp samples at both ends of the symbol once (cp <= 144)
+    __shared__ float2 xa[256 + 144], xb[256 + 144];
+    const uint32_t i0 = blockIdx.x * 256, slot = blockIdx.y, t = threadIdx.x;
+    const size_t   b0 = start + (size_t)slot * n_slot + i0;
+    for (uint32_t k = t; k < 256 + cp; k += 256) {
+        float re, im;
+        src.at(b0 + k, re, im);
+        xa[k] = make_float2(re, im);
+        src.at(b0 + k + N, re, im);
+        xb[k] = make_float2(re, im);
     }
-    corr[(size_t)slot * n_slot + i] = make_float2(re, im);
+    __syncthreads();
+    if (i0 + t >= n_slot) return;
+    float re = 0, im = 0;
+    for (uint32_t j = 0; j < cp; j++) { // serial, in the reference's order
+        const float2 a = xa[t + j], b = xb[t + j];
+        re += a.x * b.x + a.y * b.y;
+        im += a.x * b.y - a.y * b.x;
+    }
+    corr[(size_t)slot * n_slot + i0 + t] = make_float2(re, im);
 }
 
 // acc[i] = sum over slots, in slot order, of |corr|^2 (:5743)
@@ -153,10 +161,15 @@ int fft_and_corr(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const void *a, const
                  const std::vector<uint32_t> &z0, std::vector<float2> &h_out)
 {
     const uint32_t n_rows = (uint32_t)win.size(), n_seq = (uint32_t)z0.size();
-    Dev d_win, d_rows, d_seq, d_z0, d_out;
-    if (d_win.get(8 * n_rows) || d_rows.get((size_t)n_rows * 2 * N_SC_MAX * 4) || d_seq.get(seq.size() * 8) || d_z0.get(4 * n_seq) ||
-        d_out.get((size_t)n_rows * n_seq * 8))
-        return MI_LTE_ERR_NOMEM;
+    // carve the per-call tables out of the context's scratch (no allocation on the search path)
+    struct Ptr { void *p; } d_win, d_rows, d_seq, d_z0, d_out;
+    const size_t sz[5] = {8 * (size_t)n_rows, (size_t)n_rows * 2 * N_SC_MAX * 4, seq.size() * 8, 4 * (size_t)n_seq, (size_t)n_rows * n_seq * 8};
+    size_t       off[5], tot = 0;
+    for (int i = 0; i < 5; i++) { off[i] = tot; tot += (sz[i] + 255) & ~(size_t)255; }
+    int rc0 = mi_ctx_reserve_scratch(ctx, tot);
+    if (rc0 != MI_LTE_OK) return rc0;
+    char *base = (char *)ctx->scratch;
+    d_win.p = base + off[0]; d_rows.p = base + off[1]; d_seq.p = base + off[2]; d_z0.p = base + off[3]; d_out.p = base + off[4];
     MI_HIP_CHECK(ctx, hipMemcpyAsync(d_win.p, win.data(), 8 * n_rows, hipMemcpyHostToDevice, ctx->stream));
     MI_HIP_CHECK(ctx, hipMemcpyAsync(d_seq.p, seq.data(), seq.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     MI_HIP_CHECK(ctx, hipMemcpyAsync(d_z0.p, z0.data(), 4 * n_seq, hipMemcpyHostToDevice, ctx->stream));

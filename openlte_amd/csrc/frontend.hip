@@ -24,8 +24,6 @@ struct DlGeom {
     uint32_t N_ant;
     uint32_t sf_stride; // floats per device subframe
     uint32_t ul;        // 1: uplink SC-FDMA demodulation (samples_to_symbols_ul, liblte_phy.cc:8654-8692)
-    uint32_t raw;       // 1: one symbol per unit, unit_start[] is the FFT window's first sample (the sync searches, sync.hip)
-    uint32_t im_off;    // floats from a row of real parts to the row of imaginary parts
 };
 
 // The FFT has no bit-exact reference (FFTW's operation order is unspecified; parity is to tolerance), so its
@@ -118,7 +116,7 @@ template <> struct SampleSrc<float> { // planar i_samps / q_samps as the referen
     __device__ __forceinline__ float2 at(size_t n) const { return make_float2(i[n], q[n]); }
 };
 
-template <typename T>
+template <typename T, bool RAW = false>
 __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t *__restrict__ unit_start, DlGeom g,
                                                 const float2 *__restrict__ tw, float *__restrict__ subframes)
 {
@@ -126,11 +124,11 @@ __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t
     const uint32_t sym = blockIdx.x, unit = blockIdx.y, N = g.N;
     // window start: slot start + symbol offset + CP - 1  (one sample early: liblte_phy.cc:8621)
     const uint32_t so   = sym % 7;
-    const size_t   first = g.raw ? (size_t)unit_start[unit]
-                                 : unit_start[unit] + (size_t)(sym / 7) * g.n_slot + (size_t)(N + g.cpe) * so + (so ? g.cp0 - g.cpe : 0) +
-                                       (so == 0 ? g.cp0 : g.cpe) - 1;
+    const size_t   first = RAW ? (size_t)unit_start[unit] // (one symbol per unit, the window start given directly: sync.hip)
+                               : unit_start[unit] + (size_t)(sym / 7) * g.n_slot + (size_t)(N + g.cpe) * so + (so ? g.cp0 - g.cpe : 0) +
+                                     (so == 0 ? g.cp0 : g.cpe) - 1;
     float *row_re = subframes + (size_t)unit * g.sf_stride + (size_t)sym * N_SC_MAX;
-    float *row_im = row_re + g.im_off;
+    float *row_im = row_re + (RAW ? N_SC_MAX : 16 * N_SC_MAX);
     const uint32_t half = g.half;
 
     // uplink: the reference takes the ODD bins of a 2N-point FFT of the N samples zero-padded to 2N
@@ -422,7 +420,7 @@ int make_geom(const mi_lte_dl_cfg *cfg, DlGeom *g)
     g->N = N; g->cp0 = 160 / sc; g->cpe = 144 / sc; g->n_slot = 15360 / sc;
     g->half = 6 * cfg->N_rb_dl; g->N_rb_dl = cfg->N_rb_dl; g->N_ant = cfg->N_ant;
     g->sf_stride = (uint32_t)mi_lte_subframe_floats(cfg->N_ant);
-    g->ul = 0; g->raw = 0; g->im_off = 16 * N_SC_MAX;
+    g->ul = 0;
     return MI_LTE_OK;
 }
 
@@ -473,17 +471,17 @@ int mi_fft_rows(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const void *d_samples
     DlGeom g;
     int    rc = make_geom(&c1, &g);
     if (rc != MI_LTE_OK) return rc;
-    g.raw = 1; g.sf_stride = 2 * N_SC_MAX; g.im_off = N_SC_MAX;
+    g.sf_stride = 2 * N_SC_MAX; // one row of real parts, one of imaginary parts per window
     rc = mi_ctx_fft_twiddles(ctx);
     if (rc != MI_LTE_OK) return rc;
     const size_t lds_fft = sizeof(float2) * (g.N + g.N / 32 + 1);
     if (cfg->sample_format == MI_LTE_IQ_I8) {
         SampleSrc<int8_t> s{(const int8_t *)d_samples_a};
-        MI_LAUNCH(ctx, "k_sync_fft", (k_dl_fft<int8_t>), dim3(1, n_rows), dim3(256), lds_fft, s, d_win_start, g, ctx->d_fft_tw, d_rows);
+        MI_LAUNCH(ctx, "k_sync_fft", (k_dl_fft<int8_t, true>), dim3(1, n_rows), dim3(256), lds_fft, s, d_win_start, g, ctx->d_fft_tw, d_rows);
     } else {
         if (!d_samples_b) return MI_LTE_ERR_INVALID_ARG;
         SampleSrc<float> s{(const float *)d_samples_a, (const float *)d_samples_b};
-        MI_LAUNCH(ctx, "k_sync_fft", (k_dl_fft<float>), dim3(1, n_rows), dim3(256), lds_fft, s, d_win_start, g, ctx->d_fft_tw, d_rows);
+        MI_LAUNCH(ctx, "k_sync_fft", (k_dl_fft<float, true>), dim3(1, n_rows), dim3(256), lds_fft, s, d_win_start, g, ctx->d_fft_tw, d_rows);
     }
     MI_HIP_CHECK(ctx, hipGetLastError());
     return MI_LTE_OK;

@@ -166,7 +166,7 @@ class ChainWorkload:
         from openlte_amd import synth
         import lte_testdata as td
         self.ctx, self.m, self.np = ctx, m, np
-        self.n = n_units or 32768
+        self.n = n_units or 65536
         self.cfg = m.DlCfg(2048, 100, 1, 0)
         U = min(96, self.n)
         sfs = np.array([[1, 2, 3, 4, 6, 7, 8, 9][i % 8] for i in range(U)], np.uint32)  # subframes 0/5 carry sync signals
@@ -600,7 +600,7 @@ class MultiStream:
     the lock-step trellis kernel 4+ waves per SIMD (32k subframes), one stream is the fastest."""
 
     def __init__(self, cls, ctxs, n_units, rank):
-        n_units = n_units or {"chain": 32768, "frontend": 10000, "turbo": 65536, "uplink": 16384, "control": 8192, "sync": 32}[cls.name]
+        n_units = n_units or {"chain": 65536, "frontend": 10000, "turbo": 65536, "uplink": 16384, "control": 8192, "sync": 32}[cls.name]
         per = max(64, (n_units // len(ctxs) + 63) // 64 * 64)
         self.parts = [cls(c, per, rank * 16 + k) for k, c in enumerate(ctxs)]
         self.ctxs = ctxs

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void k_pdsch_demod(const float *__restrict__ s
     const float *base = subframes + (size_t)unit * g.sf_stride;
     const float *y_re_p = base, *y_im_p = base + 16 * N_SC_MAX;
     const float *h_re_p = base + 2 * 16 * N_SC_MAX, *h_im_p = h_re_p + (size_t)N_ant * 16 * N_SC_MAX;
-    int8_t *e = e_base + e_off[a_idx];
+    int8_t *e = e_base + (size_t)e_off[a_idx] * 64; // offsets are kept in 64-byte units: a batch may hold more than 4 GiB of soft bits
     auto locate = [&](uint32_t idx) -> uint32_t { // RE index -> L * 1200 + sub-carrier
         uint32_t lo = 0, hi = n_pairs; // offs[lo] <= idx < offs[hi]
         while (hi - lo > 1) {
@@ -279,7 +279,7 @@ int mi_lte_pdsch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, uint32_t
         pl->max_pairs = std::max(pl->max_pairs, pairs);
         pl->max_words = std::max(pl->max_words, (e_max + 31) / 32);
         emaxK[K]       = std::max(emaxK[K], e_max);
-        pl->h_e_off[a] = (uint32_t)off;
+        pl->h_e_off[a] = (uint32_t)(off >> 6); // in 64-byte units
         off += (e_max + 63) & ~63u;
     }
     if (pl->max_words > 4095) { // the demodulator reads one word past the allocation's last scrambling word
@@ -327,7 +327,7 @@ uint32_t mi_lte_pdsch_plan_out_stride(const mi_lte_pdsch_plan *pl) { return pl ?
 int mi_lte_pdsch_plan_soft_bits(const mi_lte_pdsch_plan *pl, uint32_t alloc, const int8_t **d_e, const uint32_t **d_len)
 {
     if (!pl || alloc >= pl->n_alloc || !d_e || !d_len) return MI_LTE_ERR_INVALID_ARG;
-    *d_e   = pl->d_e + pl->h_e_off[alloc];
+    *d_e   = pl->d_e + (size_t)pl->h_e_off[alloc] * 64;
     *d_len = pl->d_e_len + alloc;
     return MI_LTE_OK;
 }

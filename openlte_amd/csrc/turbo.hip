@@ -237,7 +237,7 @@ struct GroupDesc {                 // one launch = the code blocks of one size K
     const mi_lte_pdsch_alloc *allocs;
     const uint32_t *cb_alloc;      // [n_cb] allocation index of each code-block slot
     const int8_t   *e_base;        // descrambled soft bits of all allocations
-    const uint32_t *e_off;         // [n_alloc] byte offset of an allocation's soft bits
+    const uint32_t *e_off;         // [n_alloc] offset of an allocation's soft bits in 64-byte units
     const uint32_t *e_len;         // [n_alloc] E (written by the demodulation kernel)
     uint8_t        *out_bits;      // [n_alloc][out_stride] decoded transport block, one bit per byte
     uint32_t        out_stride;
@@ -263,7 +263,7 @@ struct SrcRateUnmatch {
         tab = tabs + (size_t)combo * 3 * K;
         Nnn = nnn[combo];
         K_  = K;
-        e   = g.e_base + g.e_off[a];
+        e   = g.e_base + (size_t)g.e_off[a] * 64;
         E   = g.e_len[a];
     }
     // copy the allocation's soft bits into LDS with wide loads (the gather is otherwise a chain of

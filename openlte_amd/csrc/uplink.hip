@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_pusch_demod(const float *__restrict__ s
     __syncthreads();
 
     const float sqrt_M = (float)sqrt((double)M); // liblte_phy.cc:6644 (integer argument -> double sqrt, stored to float)
-    int8_t     *e      = e_base + e_off[a_idx];
+    int8_t     *e      = e_base + (size_t)e_off[a_idx] * 64; // 64-byte units
 
     for (uint32_t s0 = 0; s0 < 12; s0 += S_par) { // S_par data symbols at a time (all 12 when they fit in LDS)
         const uint32_t S = min(S_par, 12u - s0);
@@ -249,7 +249,7 @@ int mi_pusch_plan_create_impl(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const m
         pl->M_max     = std::max(pl->M_max, M);
         pl->words_max = std::max(pl->words_max, (E + 31) / 32 + 1);
         emaxK[K]       = std::max(emaxK[K], E);
-        pl->h_e_off[a] = (uint32_t)off;
+        pl->h_e_off[a] = (uint32_t)(off >> 6); // in 64-byte units
         pl->h_e_len[a] = E;
         off += (E + 63) & ~63u;
     }
@@ -310,7 +310,7 @@ uint32_t mi_lte_pusch_plan_out_stride(const mi_lte_pusch_plan *pl) { return pl ?
 int mi_lte_pusch_plan_soft_bits(const mi_lte_pusch_plan *pl, uint32_t alloc, const int8_t **d_e, uint32_t *n_bits)
 {
     if (!pl || alloc >= pl->n_alloc || !d_e || !n_bits) return MI_LTE_ERR_INVALID_ARG;
-    *d_e    = pl->d_e + pl->h_e_off[alloc];
+    *d_e    = pl->d_e + (size_t)pl->h_e_off[alloc] * 64;
     *n_bits = pl->h_e_len[alloc];
     return MI_LTE_OK;
 }

@@ -960,17 +960,20 @@ int lo_get_dl_subframe_and_ce(const lo_cfg_t *cfg, const float *i_samps, const f
 
 /* liblte_phy_pdsch_channel_decode (liblte_phy.cc:3690-3853).  The reference's static buffers cap
  * one allocation at 5000 REs / 10000 soft bits (liblte_phy.h:349-363); larger allocations are
- * outside the envelope and rejected here. */
+ * outside the envelope the unmodified reference can run. */
 int lo_pdsch_channel_decode(const lo_cfg_t *cfg, const lo_subframe_t *sf, const lo_alloc_t *alloc, uint32_t N_pdcch_symbs,
                             uint32_t N_id_cell, uint32_t N_ant, uint8_t *out_bits, uint32_t *N_out_bits,
                             int8_t *soft_tap, uint32_t *N_soft_tap)
 {
-    enum { CAP = 5000 };
-    float   *buf = (float *)malloc(sizeof(float) * (2 * CAP + 2 * 4 * CAP + 4 * 10000 + 10000));
+    /* the reference's scratch arrays hold 5000 resource elements (liblte_phy.h: LIBLTE_PHY_PDSCH... sizes); larger allocations
+     * overrun them there.  The restatement sizes its scratch from the allocation so that it can also check the "big" variant
+     * of SURVEY 8d W4 (one 100-PRB allocation), which the unmodified reference cannot run. */
+    const uint32_t CAP = alloc->N_prb * 168u + 8u > 5000u ? alloc->N_prb * 168u + 8u : 5000u, NS = 2 * CAP, NB = 6 * CAP + 64;
+    float   *buf = (float *)malloc(sizeof(float) * ((size_t)2 * CAP + 2 * 4 * CAP + 4 * NS + NB));
     float   *y_re = buf, *y_im = y_re + CAP, *c_re = y_im + CAP, *c_im = c_re + 4 * CAP, *x_re = c_im + 4 * CAP,
-            *x_im = x_re + 10000, *d_re = x_im + 10000, *d_im = d_re + 10000, *desc = d_im + 10000;
-    int8_t  *soft = (int8_t *)malloc(10000 + 64);
-    uint8_t *c    = (uint8_t *)malloc(10000 + 64);
+            *x_im = x_re + NS, *d_re = x_im + NS, *d_im = d_re + NS, *desc = d_im + NS;
+    int8_t  *soft = (int8_t *)malloc(NB);
+    uint8_t *c    = (uint8_t *)malloc(NB);
     uint32_t idx, M_layer, M_symb, N_bits, c_init;
     int      err = LO_ERR_DECODE_FAIL;
 

@@ -24,7 +24,7 @@ def upload_oracle_subframe(ctx, s, n_ant):
 def oracle_pdsch(port, lc, s, alloc, cfi, cell, n_ant):
     from oracle import pyoracle as po
     out, n = np.zeros(6200, np.uint8), C.c_uint32()
-    soft, ns = np.zeros(20000, np.int8), C.c_uint32()
+    soft, ns = np.zeros(max(20000, 6 * 168 * alloc.N_prb + 64), np.int8), C.c_uint32()
     la = td.to_lo_alloc(alloc)
     err = port.lo_pdsch_channel_decode(C.byref(lc), C.byref(s), C.byref(la), cfi, cell, n_ant, out, C.byref(n),
                                        soft.ctypes.data_as(C.c_void_p), C.byref(ns))
@@ -101,6 +101,34 @@ def test_w4_full_chain_end_to_end(ctx, port):
     plan.close()
     for b in (d_iq, d_start, d_sf, d_cell, d_sub):
         b.free()
+
+
+def test_big_allocation_soft_combining(ctx, port):
+    """SURVEY 8d W4, "big" variant: one 100-PRB 64QAM allocation, E = 82 800 soft bits for K = 6016 -- 4.6 laps of the circular
+    buffer, i.e. heavy soft combining.  The unmodified reference cannot run it (its scratch arrays hold 10 000 soft bits), so the
+    checker is the plain-C restatement with scratch sized from the allocation; the product has no such cap."""
+    import openlte_amd as m
+    from openlte_amd import synth
+    cfg = m.DlCfg(2048, 100, 1, 0)
+    sfs, cells = [1, 8], [17, 404]
+    allocs = [m.make_alloc(u, 3, 5992, list(range(100)), 0x100 + u) for u in range(2)]
+    for snr in (30, 14, 4):  # parity at every SNR (at 4 dB both sides fail the CRC); clean decode where the channel allows
+        iq, tx = synth.dl_units(cfg, sfs, cells, allocs, 1, snr_db=snr, max_delay=4, seed=1234 + snr)
+        for u in range(2):
+            lc, s = td.oracle_frontend(port, 2048, 100, 1, iq[u], sfs[u], cells[u])
+            sub = upload_oracle_subframe(ctx, s, 1)
+            al = [m.make_alloc(0, 3, 5992, list(range(100)), 0x100 + u)]
+            plan = ctx.pdsch_plan(cfg, 2, al)
+            d_sub = ctx.to_device(sub)
+            st, bits = plan.run(d_sub, [sfs[u]], [cells[u]])
+            err, out, desc = oracle_pdsch(port, lc, s, al[0], 2, cells[u], 1)
+            assert len(desc) == 82800
+            assert (plan.soft_bits(0)[:len(desc)] == desc).all()
+            assert st[0] == err and (err != 0 or (bits[0] == out).all())
+            if snr >= 14:
+                assert err == 0 and (bits[0] == tx[u, 0, :5992]).all(), (snr, u)
+            plan.close()
+            d_sub.free()
 
 
 def test_two_port_stage_parity(ctx, port):

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <malloc.h>
 
 #include "liblte_phy.h"
 
@@ -92,8 +93,19 @@ static void fill_alloc(LIBLTE_PHY_ALLOCATION_STRUCT *a, const ref_alloc_t *r, co
 size_t ref_sizeof_phy_struct(void) { return sizeof(LIBLTE_PHY_STRUCT); }
 size_t ref_sizeof_subframe_struct(void) { return sizeof(LIBLTE_PHY_SUBFRAME_STRUCT); }
 
+// liblte_phy_init malloc()s its 46 MB struct and never clears it; several receive paths read members nothing has written yet
+// (pss_mod_*_n1/_p1 outside the 62 PSS positions, the PDCCH estimate rows of absent ports, CCE scratch past the last CCE ...).
+// In the reference's applications the struct is allocated once at start-up, i.e. from fresh zero pages.  A long-lived test
+// process must not hand it recycled heap instead: keep big blocks on mmap and give the heap top back before every init.
+static void fresh_pages_for_init(void)
+{
+    mallopt(M_MMAP_THRESHOLD, 1 << 20);
+    malloc_trim(0);
+}
+
 void *ref_phy_new(int fs_enum, int N_id_cell, int N_ant, int N_rb_dl)
 {
+    fresh_pages_for_init();
     LIBLTE_PHY_STRUCT *phy = NULL;
     if (LIBLTE_SUCCESS != liblte_phy_init(&phy, (LIBLTE_PHY_FS_ENUM)fs_enum, (uint16)N_id_cell, (uint8)N_ant,
                                           (uint32)N_rb_dl, LIBLTE_PHY_N_SC_RB_DL_NORMAL_CP, 1.0f))
@@ -103,6 +115,7 @@ void *ref_phy_new(int fs_enum, int N_id_cell, int N_ant, int N_rb_dl)
 // liblte_phy_init pre-computes the transmitter's PDCCH REG permutations for one PHICH resource (liblte_phy.cc:2292)
 void *ref_phy_new_phich(int fs_enum, int N_id_cell, int N_ant, int N_rb_dl, float phich_res)
 {
+    fresh_pages_for_init();
     LIBLTE_PHY_STRUCT *phy = NULL;
     if (LIBLTE_SUCCESS != liblte_phy_init(&phy, (LIBLTE_PHY_FS_ENUM)fs_enum, (uint16)N_id_cell, (uint8)N_ant,
                                           (uint32)N_rb_dl, LIBLTE_PHY_N_SC_RB_DL_NORMAL_CP, phich_res))

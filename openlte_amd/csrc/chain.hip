@@ -27,29 +27,33 @@ __device__ __forceinline__ void sync_window(uint32_t N_rb_dl, uint32_t &first_sc
     default: first_sc = 47 * 12;     last_sc = 53 * 12 - 1; break;
     }
 }
-// 12-bit mask of the sub-carriers of (symbol L, PRB prb) that carry PDSCH (liblte_phy.cc:3753-3789)
+// 12-bit mask of the sub-carriers of (symbol L, PRB prb) that carry PDSCH (liblte_phy.cc:3753-3789): per sub-carrier the
+// reference first tests the CRS positions of the port count, and only where none matches the PBCH / PSS / SSS window of
+// subframes 0 and 5 -- i.e. the union of two masks, both of which are closed forms of (cell, L, prb).
 __device__ __forceinline__ uint32_t pdsch_mask(uint32_t N_ant, uint32_t cell, uint32_t sf, uint32_t L, uint32_t prb,
                                                uint32_t first_sc, uint32_t last_sc)
 {
-    uint32_t m = 0;
-    for (uint32_t j = 0; j < 12; j++) {
-        const uint32_t sc = prb * 12 + j;
-        bool skip = false;
-        if (N_ant == 1 && (L % 7) == 0 && (cell % 6) == (j % 6)) skip = true;
-        else if (N_ant == 1 && (L % 7) == 4 && ((cell + 3) % 6) == (j % 6)) skip = true;
-        else if (N_ant >= 2 && ((L % 7) == 0 || (L % 7) == 4) && (cell % 3) == (j % 3)) skip = true;
-        else if (N_ant == 4 && (L % 7) == 1 && (cell % 3) == (j % 3)) skip = true;
-        else {
-            const bool in_win = sc >= first_sc && sc <= last_sc;
-            if (sf == 0 && in_win && L >= 7 && L <= 10) skip = true;
-            else if ((sf == 0 || sf == 5) && in_win && (L == 5 || L == 6)) skip = true;
-        }
-        if (!skip) m |= 1u << j;
+    const uint32_t l7 = L >= 7 ? L - 7 : L, c6 = cell % 6, c3 = cell % 3;
+    uint32_t skip = 0;
+    if (N_ant == 1) {
+        if (l7 == 0) skip = 0x041u << c6;                     // j % 6 == cell % 6
+        else if (l7 == 4) skip = 0x041u << ((c6 + 3) % 6);    // j % 6 == (cell + 3) % 6
+    } else if (l7 == 0 || l7 == 4 || (N_ant == 4 && l7 == 1))
+        skip = (0x249u << c3) & 0xFFFu;                       // j % 3 == cell % 3
+    const bool win = (sf == 0 && L >= 7 && L <= 10) || ((sf == 0 || sf == 5) && (L == 5 || L == 6));
+    const uint32_t s0 = prb * 12;
+    if (win && last_sc >= s0 && first_sc <= s0 + 11) {
+        const uint32_t lo = first_sc > s0 ? first_sc - s0 : 0u, hi = last_sc - s0 < 11u ? last_sc - s0 : 11u;
+        skip |= ((2u << hi) - 1u) & ~((1u << lo) - 1u);
     }
-    return m;
+    return ~skip & 0xFFFu;
 }
 
-__global__ __launch_bounds__(256) void k_pdsch_demod(const float *__restrict__ subframes, DemodGeom g,
+// The kernel is latency-bound (a chain of dependent table reads, then scattered plane reads per resource element), so it lives on
+// occupancy: 8 waves per SIMD with a few spilled registers beat 4 without (2.80 -> 2.18 ms per 32k subframes); the single-port
+// case is its own instantiation so that the 2/4-port combiners do not set its register count.
+template <bool ONE_PORT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_pdsch_demod(const float *__restrict__ subframes, DemodGeom g,
                                                      const mi_lte_pdsch_alloc *__restrict__ allocs,
                                                      const uint32_t *__restrict__ subfr_num, const uint32_t *__restrict__ n_id_cell,
                                                      GoldTables gt, int8_t *__restrict__ e_base, const uint32_t *__restrict__ e_off,
@@ -57,61 +61,50 @@ __global__ __launch_bounds__(256) void k_pdsch_demod(const float *__restrict__ s
                                                      uint32_t e_lds_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smu[]; // offs[max_pairs+1] | masks[max_pairs] | cw[...]
-    __shared__ uint32_t part[256];
     const uint32_t a_idx = blockIdx.x;
     const mi_lte_pdsch_alloc &al = allocs[a_idx];
-    const uint32_t unit = al.unit, sf = subfr_num[unit], cell = n_id_cell[unit], N_ant = g.N_ant, N_prb = al.N_prb;
+    const uint32_t unit = al.unit, sf = subfr_num[unit], cell = n_id_cell[unit], N_ant = ONE_PORT ? 1u : g.N_ant, N_prb = al.N_prb;
     const uint32_t Qm = al.mod_type == 3 ? 6 : al.mod_type == 2 ? 4 : al.mod_type == 1 ? 2 : 1;
     uint32_t *offs = smu, *masks = smu + max_pairs + 1, *cw = smu + ((2 * max_pairs + 1 + 3u) & ~3u); // cw and e_lds stay 16-byte aligned
     uint32_t first_sc, last_sc;
     sync_window(g.N_rb_dl, first_sc, last_sc);
 
-    // ---- phase 1: which REs, in the reference's loop order L -> PRB -> sub-carrier (liblte_phy.cc:3744-3802)
-    const uint32_t n_pairs = (14 - g.cfi) * N_prb, per = (n_pairs + 255) / 256;
-    uint32_t local = 0;
-    for (uint32_t q = threadIdx.x * per; q < min((threadIdx.x + 1) * per, n_pairs); q++) {
-        const uint32_t L = g.cfi + q / N_prb, prb = al.prb[L / 7][q % N_prb];
-        const uint32_t m = pdsch_mask(N_ant, cell, sf, L, prb, first_sc, last_sc);
-        masks[q] = m | ((L * N_SC_MAX + prb * 12) << 12); // low 12 bits: RE mask, high 20 bits: L*1200 + first sub-carrier
-        local += __popc(m);
-    }
-    part[threadIdx.x] = local;
-    __syncthreads();
-    if (threadIdx.x < 64) { // exclusive scan of the 256 partial counts by one wave
-        uint32_t v[4], s = 0;
-        for (int k = 0; k < 4; k++) { v[k] = part[threadIdx.x * 4 + k]; s += v[k]; }
-        uint32_t incl = s;
-        for (int o = 1; o < 64; o <<= 1) {
-            uint32_t n = __shfl_up(incl, o);
-            if ((int)threadIdx.x >= o) incl += n;
+    // ---- phases 1 and 2 side by side.  Wave 0: which REs, in the reference's loop order L -> PRB -> sub-carrier
+    // (liblte_phy.cc:3744-3802) -- a 12-bit mask per (symbol, PRB) pair and, by a scan inside the wave, the running count of REs
+    // before each pair.  Waves 1-3: the scrambling sequence words (c_init per :3831) for the upper bound of the bit count, which
+    // does not wait for the scan.  One barrier for both.
+    const uint32_t n_pairs = (14 - g.cfi) * N_prb;
+    const uint32_t c_init = (al.rnti << 14) | (0u << 13) | (sf << 9) | cell;
+    if (threadIdx.x < 64) {
+        const uint32_t ln = threadIdx.x, per = (n_pairs + 63) / 64, q0 = ln * per, q1 = min(q0 + per, n_pairs);
+        const uint32_t magic = 0xFFFFFFFFu / N_prb + 1u; // q / N_prb = mulhi(q, magic), exact for q < 2^32 / N_prb^2
+        uint32_t local = 0;
+        for (uint32_t q = q0; q < q1; q++) {
+            const uint32_t row = __umulhi(q, magic), L = g.cfi + row, prb = al.prb[L / 7][q - row * N_prb];
+            const uint32_t m = pdsch_mask(N_ant, cell, sf, L, prb, first_sc, last_sc);
+            masks[q] = m | ((L * N_SC_MAX + prb * 12) << 12); // low 12 bits: RE mask, high 20 bits: L*1200 + first sub-carrier
+            local += __popc(m);
         }
-        uint32_t run = incl - s;
-        for (int k = 0; k < 4; k++) { part[threadIdx.x * 4 + k] = run; run += v[k]; }
-    }
-    __syncthreads();
-    {
-        uint32_t run = part[threadIdx.x];
-        for (uint32_t q = threadIdx.x * per; q < min((threadIdx.x + 1) * per, n_pairs); q++) {
+        uint32_t incl = local;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t n = __shfl_up(incl, o);
+            if ((int)ln >= o) incl += n;
+        }
+        uint32_t run = incl - local;
+        for (uint32_t q = q0; q < q1; q++) {
             offs[q] = run;
             run += __popc(masks[q] & 0xFFFu);
         }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) { // total = offset past the last pair
-        uint32_t tot = 0;
-        if (n_pairs) tot = offs[n_pairs - 1] + __popc(masks[n_pairs - 1] & 0xFFFu);
-        offs[n_pairs] = tot;
+        if (ln == 63) offs[n_pairs] = incl; // total
+    } else {
+        const uint32_t n_words_ub = (n_pairs * 12 * Qm + 31) / 32; // <= max_words; one word of slack for the 2-word window in put_bits
+        for (uint32_t w = threadIdx.x - 64; w <= n_words_ub; w += blockDim.x - 64) cw[w] = gold_word(gt, c_init, w);
     }
     __syncthreads();
     const uint32_t M_ap = offs[n_pairs];
     // pre-decoder / layer de-mapper symbol counts (liblte_phy.cc:7683, 7693, 7720, 7497)
     const uint32_t n_grp = M_ap / N_ant, M_symb = n_grp * N_ant, N_bits = M_symb * Qm;
     if (threadIdx.x == 0) e_len[a_idx] = N_bits;
-
-    // ---- phase 2: scrambling sequence words (c_init per liblte_phy.cc:3831)
-    const uint32_t c_init = (al.rnti << 14) | (0u << 13) | (sf << 9) | cell, n_words = (N_bits + 31) / 32;
-    for (uint32_t w = threadIdx.x; w <= n_words; w += blockDim.x) cw[w] = gold_word(gt, c_init, w); // one word of slack for the 2-word window in put_bits
-    __syncthreads();
 
     // ---- phase 3: per group of N_ant REs: gather, pre-decode, de-map, descramble
     const float *base = subframes + (size_t)unit * g.sf_stride;
@@ -146,7 +139,7 @@ __global__ __launch_bounds__(256) void k_pdsch_demod(const float *__restrict__ s
                 }
         }
     };
-    if (N_ant == 1) { // one RE = one symbol (liblte_phy.cc:7684-7690): thread per (PRB-symbol pair, sub-carrier), no search
+    if (ONE_PORT) { // one RE = one symbol (liblte_phy.cc:7684-7690): thread per (PRB-symbol pair, sub-carrier), no search
         constexpr int UNR = 4; // loads of UNR independent REs in flight per thread (the kernel is latency-bound otherwise)
         auto body = [&](auto *dst) {
             const uint32_t total = n_pairs * 12;
@@ -346,8 +339,12 @@ int mi_lte_pdsch_decode_run(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, const float 
     const uint32_t e_cap = (e_bytes <= 32 * 1024) ? e_bytes : 0;
     const uint32_t pairs_al = ((2 * pl->max_pairs + 1 + 3u) & ~3u);
     const size_t lds = sizeof(uint32_t) * ((size_t)pairs_al + words_al) + e_cap;
-    MI_LAUNCH(ctx, "k_pdsch_demod", k_pdsch_demod, dim3(pl->n_alloc), dim3(256), lds, d_subframes, g, pl->d_allocs, d_subfr_num,
-              d_n_id_cell, gt, pl->d_e, pl->d_e_off, pl->d_e_len, pl->max_pairs, words_al, e_cap);
+    if (g.N_ant == 1)
+        MI_LAUNCH(ctx, "k_pdsch_demod", k_pdsch_demod<true>, dim3(pl->n_alloc), dim3(256), lds, d_subframes, g, pl->d_allocs, d_subfr_num,
+                  d_n_id_cell, gt, pl->d_e, pl->d_e_off, pl->d_e_len, pl->max_pairs, words_al, e_cap);
+    else
+        MI_LAUNCH(ctx, "k_pdsch_demod", k_pdsch_demod<false>, dim3(pl->n_alloc), dim3(256), lds, d_subframes, g, pl->d_allocs, d_subfr_num,
+                  d_n_id_cell, gt, pl->d_e, pl->d_e_off, pl->d_e_len, pl->max_pairs, words_al, e_cap);
     MI_HIP_CHECK(ctx, hipGetLastError());
     for (auto &gr : pl->groups) {
         rc = mi_turbo_ref_group(ctx, gr.K, gr.n_cb, pl->d_allocs, pl->d_cb_alloc + gr.cb_base, pl->d_e, pl->d_e_off, pl->d_e_len,

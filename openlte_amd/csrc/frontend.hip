@@ -223,8 +223,19 @@ struct GoldTables { const uint32_t *x1; const uint32_t *x2b; uint32_t words; }; 
 // per-seed-bit basis words; bit b of the result is c[32w + b].
 __device__ __forceinline__ uint32_t gold_word(const GoldTables &gt, uint32_t c_init, uint32_t w)
 {
-    uint32_t v = gt.x1[w];
-    for (uint32_t m = c_init; m; m &= m - 1) v ^= gt.x2b[(uint32_t)__builtin_ctz(m) * gt.words + w];
+    uint32_t v = gt.x1[w], m = c_init; // table reads eight at a time, in flight together (see phy_dev.hpp)
+    while (m) {
+        uint32_t t[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const bool     on = m != 0;
+            const uint32_t b  = on ? (uint32_t)__builtin_ctz(m) : 0u;
+            t[k] = gt.x2b[b * gt.words + w];
+            t[k] = on ? t[k] : 0u;
+            m &= m - 1;
+        }
+        v ^= (t[0] ^ t[1]) ^ (t[2] ^ t[3]) ^ (t[4] ^ t[5]) ^ (t[6] ^ t[7]);
+    }
     return v;
 }
 

@@ -8,10 +8,24 @@ namespace {
 
 struct GoldTables { const uint32_t *x1; const uint32_t *x2b; uint32_t words; };
 
+// word w of the Gold sequence for c_init: x1's word XOR the basis words of x2 for every set bit of c_init (the sequence is linear in
+// c_init).  The table reads are issued eight at a time so that they are in flight together -- a plain loop over the set bits
+// makes every L2 round trip wait for the previous one, which dominated the prologue of the per-allocation kernels.
 __device__ __forceinline__ uint32_t gold_word(const GoldTables &gt, uint32_t c_init, uint32_t w)
 {
-    uint32_t v = gt.x1[w];
-    for (uint32_t m = c_init; m; m &= m - 1) v ^= gt.x2b[(uint32_t)__builtin_ctz(m) * gt.words + w];
+    uint32_t v = gt.x1[w], m = c_init;
+    while (m) {
+        uint32_t t[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const bool     on = m != 0;
+            const uint32_t b  = on ? (uint32_t)__builtin_ctz(m) : 0u;
+            t[k] = gt.x2b[b * gt.words + w]; // unconditional (row 0 when the bits are used up): no branch between the loads
+            t[k] = on ? t[k] : 0u;
+            m &= m - 1; // 0 stays 0
+        }
+        v ^= (t[0] ^ t[1]) ^ (t[2] ^ t[3]) ^ (t[4] ^ t[5]) ^ (t[6] ^ t[7]);
+    }
     return v;
 }
 

@@ -481,7 +481,7 @@ __device__ __forceinline__ void acs_step(int (&pm)[8], int x, int y, uint32_t &a
     for (int s = 0; s < 8; s++) pm[s] = nw[s];
 }
 
-__global__ __launch_bounds__(64) void k_turbo_siso(SisoArgs args, uint32_t K, uint32_t pass_base)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_turbo_siso(SisoArgs args, uint32_t K, uint32_t pass_base)
 {
     const SisoPass &ps   = args.p[blockIdx.y];
     const uint32_t  tile = blockIdx.x, lane = threadIdx.x, Kp = kpad64(K), nblk = Kp >> 6;

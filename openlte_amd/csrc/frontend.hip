@@ -105,6 +105,9 @@ __device__ __forceinline__ void fft_pass(const float2 *__restrict__ tw, uint32_t
 template <typename T> struct SampleSrc;
 template <> struct SampleSrc<int8_t> { // interleaved I,Q int8 (capture file format, LTE_fdd_dl_fs_samp_buf.cc:657-694)
     const int8_t *p;
+    typedef char2 raw_t; // a fetched sample as it is held until its transform starts
+    __device__ __forceinline__ raw_t raw(size_t n) const { return *reinterpret_cast<const char2 *>(p + 2 * n); }
+    static __device__ __forceinline__ float2 cvt(raw_t v) { return make_float2((float)v.x, (float)v.y); }
     __device__ __forceinline__ float2 at(size_t n) const
     {
         const char2 v = *reinterpret_cast<const char2 *>(p + 2 * n);
@@ -113,6 +116,9 @@ template <> struct SampleSrc<int8_t> { // interleaved I,Q int8 (capture file for
 };
 template <> struct SampleSrc<float> { // planar i_samps / q_samps as the reference API takes them
     const float *i, *q;
+    typedef float2 raw_t;
+    __device__ __forceinline__ raw_t raw(size_t n) const { return make_float2(i[n], q[n]); }
+    static __device__ __forceinline__ float2 cvt(raw_t v) { return v; }
     __device__ __forceinline__ float2 at(size_t n) const { return make_float2(i[n], q[n]); }
 };
 
@@ -133,11 +139,12 @@ __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t
         return RAW ? ustart // (one symbol per unit, the window start given directly: sync.hip)
                    : ustart + (size_t)(sym / 7) * g.n_slot + (size_t)(N + g.cpe) * so + (so ? g.cp0 - g.cpe : 0) + (so == 0 ? g.cp0 : g.cpe) - 1;
     };
-    auto fetch = [&](uint32_t sym, float2 (&v)[8]) {
+    typedef typename SampleSrc<T>::raw_t raw_t;
+    auto fetch = [&](uint32_t sym, raw_t (&v)[8]) {
         const size_t f = win(sym);
         if (act) {
 #pragma unroll
-            for (int r = 0; r < 8; r++) v[r] = src.at(f + j + r * nb);
+            for (int r = 0; r < 8; r++) v[r] = src.raw(f + j + r * nb);
         }
     };
     auto ld_s = [&](uint32_t i) { return buf[pad(i)]; };
@@ -145,8 +152,9 @@ __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t
 
     uint32_t       sym = PERSIST ? 0u : blockIdx.x;
     const uint32_t sym_end = PERSIST ? n_sym : sym + 1;
-    float2 cur[8], nxt[8];
+    raw_t cur[8], nxt[8];
     fetch(sym, cur);
+#pragma nounroll
     for (; sym < sym_end; sym++) {
         if (PERSIST && sym + 1 < sym_end) fetch(sym + 1, nxt);
         float *row_re = subframes + (size_t)unit * g.sf_stride + (size_t)sym * N_SC_MAX;
@@ -162,7 +170,10 @@ __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t
         if (act) {
             float2 v[8];
 #pragma unroll
-            for (int r = 0; r < 8; r++) v[r] = g.ul ? cmul(cur[r], tw[(j + r * nb) * (2048u / N)]) : cur[r];
+            for (int r = 0; r < 8; r++) {
+                const float2 x = SampleSrc<T>::cvt(cur[r]);
+                v[r] = g.ul ? cmul(x, tw[(j + r * nb) * (2048u / N)]) : x;
+            }
             dft8(v);
 #pragma unroll
             for (int r = 0; r < 8; r++) buf[pad(j * 8 + r)] = v[r];

@@ -18,6 +18,8 @@
 //     vote) run as one workgroup per code block with the block staged in LDS.
 //
 // Kernel sequence per batch:  prep -> siso(pass 1) -> perm -> siso(pass 2 | pass 3) -> vote
+#include <type_traits>
+
 #include "ctx.hpp"
 
 namespace {
@@ -60,6 +62,17 @@ __device__ __forceinline__ int block_max_i(int v, int *red)
     int r = red[0];
     for (uint32_t w = 1; w < (blockDim.x >> 6); w++) r = max(r, red[w]);
     return r;
+}
+
+// two maxima in one round (red: >= 16 ints)
+__device__ __forceinline__ void block_max_i2(int &a, int &b, int *red)
+{
+    for (int o = 32; o > 0; o >>= 1) { a = max(a, __shfl_xor(a, o)); b = max(b, __shfl_xor(b, o)); }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[8 + (threadIdx.x >> 6)] = b; }
+    __syncthreads();
+    a = red[0]; b = red[8];
+    for (uint32_t w = 1; w < (blockDim.x >> 6); w++) { a = max(a, red[w]); b = max(b, red[8 + w]); }
 }
 
 struct PrepOut { uint8_t *arr[6]; }; // X0 X1 X2 I0 M1 M2
@@ -118,6 +131,7 @@ __device__ __forceinline__ void load_idx16(const uint16_t *tab, uint32_t u, int 
 // (a) directly from the caller, in the reference's interleaved d[i*3+x] layout
 template <typename T> struct SrcDirect {
     static constexpr bool kIntegerValued = sizeof(T) != 4; // int8 / int16 soft values
+    static constexpr bool kIntPath = false;
     uint32_t e_cap;
     const T *soft;
     const T *d;
@@ -281,7 +295,7 @@ struct SrcRateUnmatch {
     }
     // d[(16u+k)*3+x] = sum over laps t of e[rank + t*Nnn] (first visit stores, repeats add, :11402-11416).
     // All first-lap loads of a unit are independent; later laps (uniform trip count) are masked.
-    template <typename P> __device__ __forceinline__ void gather16(P ep, uint32_t u, int nvalid, float (&v)[3][16]) const
+    template <typename P, typename V> __device__ __forceinline__ void gather16(P ep, uint32_t u, int nvalid, V (&v)[3][16]) const
     {
 #pragma unroll
         for (int x = 0; x < 3; x++) {
@@ -304,10 +318,11 @@ struct SrcRateUnmatch {
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 16; k++) v[x][k] = (float)acc[k];
+            for (int k = 0; k < 16; k++) v[x][k] = (V)acc[k];
         }
     }
-    __device__ __forceinline__ void load16(uint32_t u, int nvalid, float (&v)[3][16], const int8_t *e_lds, bool in_lds) const
+    static constexpr bool kIntPath = true; // the sums are small integers: the quantiser below never leaves integer arithmetic
+    template <typename V> __device__ __forceinline__ void load16(uint32_t u, int nvalid, V (&v)[3][16], const int8_t *e_lds, bool in_lds) const
     {
         if (in_lds) gather16(e_lds, u, nvalid, v); // ds_read path
         else        gather16(e, u, nvalid, v);
@@ -317,7 +332,8 @@ struct SrcRateUnmatch {
 // LDS tables that replace the per-element IEEE divisions: the quantiser and the SISO output magnitude
 // are functions of one small integer and a per-block constant, so each distinct value is divided once
 // (with exactly the reference's float expression) and every element looks its result up.
-constexpr uint32_t QTAB_N = 2048; // q(a) for |x| = a <= 2047; larger maxima fall back to dividing per element
+constexpr uint32_t QTAB_N = 4096; // q(x) for |x| <= 2047 (signed index x + max on the integer path); larger maxima divide per element
+constexpr uint32_t QTAB_HALF = 2048;
 constexpr uint32_t MTAB_N = 256;  // w = |a|+|b| <= 254
 constexpr uint32_t PREP_TAB_BYTES = QTAB_N + 2 * MTAB_N;
 
@@ -327,7 +343,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 {
     extern __shared__ __attribute__((aligned(16))) int8_t sm[]; // qtab | mtab1 | mtab2 | q(d0)[Kp] | staged e
     __shared__ float red_f[8];
-    __shared__ int   red_i[8];
+    __shared__ int   red_i[16];
     const uint32_t cb = xcd_cb(blockIdx.x, n_cb), tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4;
     if (cb >= n_cb) return; // uniform
     const size_t   tile_off = (size_t)tile * Kp * 64;
@@ -336,9 +352,10 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     const int8_t *e_lds = q0_lds + Kp;
     const bool    e_in_lds = src.stage_e(q0_lds + Kp);
 
-    float v[NSLOT][3][16];
+    typedef typename std::conditional<Src::kIntPath, int, float>::type val_t;
+    val_t v[NSLOT][3][16];
     int   nval[NSLOT];
-    float mx = 0.0f;
+    val_t mxv = 0;
 #pragma unroll
     for (int s = 0; s < NSLOT; s++) {
         const uint32_t u = threadIdx.x + s * blockDim.x;
@@ -348,17 +365,27 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 #pragma unroll
             for (int x = 0; x < 3; x++)
 #pragma unroll
-                for (int k = 0; k < 16; k++) v[s][x][k] = 0.0f;
+                for (int k = 0; k < 16; k++) v[s][x][k] = 0;
         }
 #pragma unroll
         for (int x = 0; x < 3; x++)
 #pragma unroll
-            for (int k = 0; k < 16; k++) mx = fmaxf(mx, fabsf(v[s][x][k]));
+            for (int k = 0; k < 16; k++) {
+                if constexpr (Src::kIntPath) mxv = max(mxv, abs(v[s][x][k]));
+                else mxv = fmaxf(mxv, fabsf(v[s][x][k]));
+            }
     }
-    mx = block_max_f(mx, red_f);
-    const bool use_qtab = Src::kIntegerValued && mx < (float)QTAB_N; // uniform over the workgroup
+    float mx;
+    int   mxi = 0;
+    if constexpr (Src::kIntPath) { mxi = block_max_i(mxv, red_i); mx = (float)mxi; }
+    else mx = block_max_f(mxv, red_f);
+    const bool use_qtab = Src::kIntegerValued && mx < (float)QTAB_HALF; // uniform over the workgroup
     if (use_qtab) {
-        for (uint32_t a = threadIdx.x; a <= (uint32_t)mx; a += blockDim.x) qtab[a] = (int8_t)(int)((float)a * 127.0f / mx);
+        if constexpr (Src::kIntPath) { // signed table: entry d + max holds q(d) -- one add and one read per element
+            for (uint32_t a = threadIdx.x; a <= 2u * (uint32_t)mxi; a += blockDim.x) qtab[a] = (int8_t)(int)((float)((int)a - mxi) * 127.0f / mx);
+        } else {
+            for (uint32_t a = threadIdx.x; a <= (uint32_t)mx; a += blockDim.x) qtab[a] = (int8_t)(int)((float)a * 127.0f / mx);
+        }
         __syncthreads();
     }
 
@@ -372,13 +399,16 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         if (use_qtab) {
 #pragma unroll
             for (int k = 0; k < 16; k++) {
-                const float f = v[0][x][k]; // 0 past the block end -> q = 0; the lookup is unconditional (no per-element branch)
-                const int   t = qtab[(int)fabsf(f)]; // (int)(-a*127/mx) == -(int)(a*127/mx): IEEE division and truncation are odd
-                q[k]          = f < 0.0f ? -t : t;
+                if constexpr (Src::kIntPath) q[k] = qtab[v[0][x][k] + mxi]; // 0 past the block end -> q(0) = 0
+                else {
+                    const float f = v[0][x][k]; // 0 past the block end -> q = 0; the lookup is unconditional (no per-element branch)
+                    const int   t = qtab[(int)fabsf(f)]; // (int)(-a*127/mx) == -(int)(a*127/mx): IEEE division and truncation are odd
+                    q[k]          = f < 0.0f ? -t : t;
+                }
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 16; k++) q[k] = (int)(v[0][x][k] * 127.0f / mx); // v = 0 past the block end
+            for (int k = 0; k < 16; k++) q[k] = (int)((float)v[0][x][k] * 127.0f / mx); // v = 0 past the block end
         }
         Q[x] = pack16(q);
         if (nv >= 0) *reinterpret_cast<uint4 *>(out.arr[x] + unit_off(tile_off, lane, u)) = Q[x];
@@ -408,8 +438,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         I0 = pack16(i0);
         if (nv >= 0) *reinterpret_cast<uint4 *>(out.arr[3] + unit_off(tile_off, lane, u)) = I0;
     }
-    w1max = block_max_i(w1max, red_i);
-    w2max = block_max_i(w2max, red_i);
+    block_max_i2(w1max, w2max, red_i);
     const float W1 = (float)w1max, W2 = (float)w2max;
     for (uint32_t t = threadIdx.x; t < MTAB_N; t += blockDim.x) { // w <= 254 always; entries past W are never read
         const float w = (float)t;

@@ -67,7 +67,7 @@ def library_path():
 
 def build_library():
     """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
-    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(_HERE, "csrc")])
     return library_path()
 
 

@@ -1,5 +1,7 @@
 /*
- * mi_lte.h -- C-ABI of the MI355X-native LTE downlink receive chain (libmi_lte.so).
+ * mi_lte.h -- C-ABI of the MI355X-native LTE receive chains (libmi_lte.so): the downlink hot path (front end, PDSCH,
+ * turbo), and -- widened one row at a time -- the eNodeB uplink (SC-FDMA front end, PUSCH, PRACH), the downlink control
+ * region (PCFICH, PDCCH, PBCH) and initial synchronisation (coarse timing, PSS, SSS).
  *
  * Drop-in boundary for the hot path of mgp25/OpenLTE's liblte_phy (reference paths are relative to
  * the reference root).  The reference has no plugin/FFI mechanism: its apps link liblte statically
@@ -12,9 +14,10 @@
  *  - plain pointers and sizes only; no C++/torch types.  Pointers named d_* are DEVICE pointers
  *    (HIP memory on the context's GPU, from mi_lte_malloc or any other HIP allocator);
  *    pointers named h_* are HOST pointers.
- *  - every function returns MI_LTE_OK (0) or a negative mi_lte_status; decode verdicts
+ *  - every batch function returns MI_LTE_OK (0) or a negative mi_lte_status; decode verdicts
  *    (LIBLTE_ERROR_ENUM values, liblte/hdr/liblte_common.h:59-65) are reported per block in
- *    output arrays, never through the return code.
+ *    output arrays, never through the return code.  The per-call *_host forms at the end mirror the
+ *    reference's own functions instead: negative on infrastructure errors, else the LIBLTE_ERROR_ENUM value.
  *  - one mi_lte_ctx per GPU and per host thread (the reference's LIBLTE_PHY_STRUCT is likewise not
  *    re-entrant: all its scratch lives in the struct).  All work is issued on the context's stream.
  *  - there is NO CPU fallback: if no gfx950 device is usable every entry point fails loudly.

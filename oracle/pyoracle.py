@@ -164,6 +164,8 @@ def ref():
     L.ref_pdsch_channel_decode.argtypes = [vp, vp, C.POINTER(LoAlloc), u32, u32, u32, u8p, C.POINTER(u32)]
     L.ref_pdsch_soft_bits_ptr.argtypes = [vp]
     L.ref_pdsch_soft_bits_ptr.restype = C.POINTER(C.c_int8)
+    L.ref_pdsch_descramb_bits_ptr.argtypes = [vp]
+    L.ref_pdsch_descramb_bits_ptr.restype = C.POINTER(C.c_float)
     L.ref_dlsch_rx_d_bits_ptr.argtypes = [vp]
     L.ref_dlsch_rx_d_bits_ptr.restype = C.POINTER(C.c_float)
     L.ref_dlsch_c_bits_ptr.argtypes = [vp]

@@ -213,7 +213,7 @@ def pdcch_case(R, name, seed=11):
         al = (po.LoAlloc * 6)()
         mcs = np.zeros(6, np.uint32)
         for i, (rnti, m_, nprb, rb0, rv) in enumerate(dcis):
-            al[i] = po.make_alloc(1, 0, list(range(rb0, rb0 + nprb)), rnti, rv, 1 if n_ant == 1 else 2, 0 if n_ant == 1 else 1)
+            al[i] = po.make_alloc(1, 0, list(range(rb0, rb0 + nprb)), rnti, rv, 1 if n_ant == 1 else 2, 0)
             mcs[i] = m_
         assert R.ref_pdcch_channel_encode(phy, sfp, cfi, al, mcs, len(dcis), cell, n_ant, phich_res) == 0
         tx_re = np.ctypeslib.as_array(R.ref_subframe_ptr(sfp, 4), shape=(4, 16, 1200))
@@ -284,7 +284,7 @@ def pdcch_tx_grid(ref, fft, nrb, n_ant, cell, phich_res, sf, cfi, dcis):
     ref.ref_subframe_clear_tx(sfp, sf)
     al, mcs = (po.LoAlloc * 6)(), np.zeros(6, np.uint32)
     for i, (rnti, m_, nprb, rb0, rv) in enumerate(dcis):
-        al[i] = po.make_alloc(1, 0, list(range(rb0, rb0 + nprb)), rnti, rv, 1 if n_ant == 1 else 2, 0 if n_ant == 1 else 1)
+        al[i] = po.make_alloc(1, 0, list(range(rb0, rb0 + nprb)), rnti, rv, 1 if n_ant == 1 else 2, 0)
         mcs[i] = m_
     assert ref.ref_pdcch_channel_encode(phy, sfp, cfi, al, mcs, len(dcis), cell, n_ant, phich_res) == 0
     g = np.ctypeslib.as_array(ref.ref_subframe_ptr(sfp, 4), shape=(4, 16, 1200)) + 1j * np.ctypeslib.as_array(ref.ref_subframe_ptr(sfp, 5), shape=(4, 16, 1200))

@@ -196,3 +196,68 @@ def test_w4_chain_batch_property(ctx):
     plan.close()
     for b in (d_iq, d_start, d_sf, d_cell, d_sub, d_out, d_st):
         b.free()
+
+
+@pytest.mark.parametrize("n_ant", [2, 4])
+def test_multi_port_transmit_diversity_end_to_end(ctx, ref, n_ant):
+    """A real 2- / 4-port cell: CRS on every port and a transmit-diversity PDSCH from the reference's own transmitter, each
+    antenna through its own channel, summed and quantised to int8.  (a) stage parity: fed the reference's received grid and
+    estimates, the combiner / de-mapper / descrambler / decoder give the reference's soft bits and transport block exactly;
+    (b) end to end through the library's own front end the transport block is the transmitted one."""
+    import ctypes as C
+    import openlte_amd as m
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(70 + n_ant)
+    fft, nrb, cell, sf, cfi = 2048, 100, 101, 4, 2
+    tbs, prbs = 2024, list(range(10, 22))  # 16QAM, 12 PRB: E well above 3(K + 4) also with the extra CRS
+    phy = ref.ref_phy_new(po.FS_ENUM[fft], cell, n_ant, nrb)
+    sfp = ref.ref_subframe_new()
+    la = po.make_alloc(2, tbs, prbs, 0x2345, 0, 2, 0)  # tx_mode 2, LIBLTE_PHY_PRE_CODER_TYPE_TX_DIVERSITY
+    msg = rng.integers(0, 2, tbs).astype(np.uint8)
+    n_samp = 30720
+    z = np.zeros(2 * n_samp, np.complex64)  # the subframe and the next one (its first CRS symbols feed the interpolation)
+    gains = [rng.uniform(0.6, 1.2) * np.exp(1j * rng.uniform(-np.pi, np.pi)) for _ in range(n_ant)]
+    for k in range(2):
+        ref.ref_subframe_clear_tx(sfp, sf + k)
+        assert ref.ref_map_crs(phy, sfp, cell, n_ant) == 0
+        if k == 0:
+            arr = (po.LoAlloc * 1)(la)
+            assert ref.ref_pdsch_channel_encode(phy, sfp, arr, 1, msg, tbs, cfi, cell, n_ant) == 0
+        for p in range(n_ant):
+            i_s, q_s = np.zeros(n_samp, np.float32), np.zeros(n_samp, np.float32)
+            assert ref.ref_create_dl_subframe(phy, sfp, p, i_s, q_s) == 0
+            z[k * n_samp:(k + 1) * n_samp] += gains[p] * (i_s + 1j * q_s)
+    z *= 90.0 / np.abs(np.concatenate([z.real, z.imag])).max()
+    z += 0.5 * (rng.standard_normal(len(z)) + 1j * rng.standard_normal(len(z)))
+    iq = np.stack([np.round(z.real), np.round(z.imag)], axis=1).astype(np.int8)
+    # the reference's receiver on the same int8-valued samples
+    i_f = np.ascontiguousarray(np.concatenate([np.zeros(sf * n_samp, np.float32), iq[:, 0].astype(np.float32)]))
+    q_f = np.ascontiguousarray(np.concatenate([np.zeros(sf * n_samp, np.float32), iq[:, 1].astype(np.float32)]))
+    rx = ref.ref_subframe_new()
+    assert ref.ref_get_dl_subframe_and_ce(phy, i_f, q_f, 0, sf, cell, n_ant, rx) == 0
+    out, n = np.zeros(6200, np.uint8), C.c_uint32()
+    rc = ref.ref_pdsch_channel_decode(phy, rx, C.byref(la), cfi, cell, n_ant, out, C.byref(n))
+    assert rc == 0 and (out[:tbs] == msg).all(), "the reference does not decode its own %d-port transmission" % n_ant
+    want_soft = np.ctypeslib.as_array(ref.ref_pdsch_descramb_bits_ptr(phy), shape=(12 * 12 * 12 * 4,)).copy()
+    cfg = m.DlCfg(fft, nrb, n_ant, 0)
+    alloc = [m.make_alloc(0, 2, tbs, prbs, 0x2345, 0, 2)]
+    # (a) stage parity on the reference's grid
+    grid = np.concatenate([po.ref_subframe_view(ref, rx, 0).ravel(), po.ref_subframe_view(ref, rx, 1).ravel(),
+                           po.ref_subframe_view(ref, rx, 2, True)[:n_ant].ravel(), po.ref_subframe_view(ref, rx, 3, True)[:n_ant].ravel()]).astype(np.float32)
+    d_sub = ctx.to_device(grid)
+    plan = ctx.pdsch_plan(cfg, cfi, alloc)
+    st, bits = plan.run(d_sub, [sf], [cell])
+    e = plan.soft_bits(0)
+    assert st[0] == 0 and (bits[0] == out[:tbs]).all()
+    assert (e == want_soft[:len(e)].astype(np.int8)).all(), "soft bits differ from the reference's"
+    d_sub.free()
+    # (b) end to end through the library's front end
+    got = ctx.dl_frontend(cfg, iq, [0], [sf], [cell])
+    d_sub = ctx.to_device(np.ascontiguousarray(got[0], np.float32))
+    st, bits = plan.run(d_sub, [sf], [cell])
+    assert st[0] == 0 and (bits[0] == msg).all()
+    plan.close()
+    d_sub.free()
+    ref.ref_subframe_free(sfp)
+    ref.ref_subframe_free(rx)
+    ref.ref_phy_free(phy)

@@ -474,3 +474,34 @@ def ref_sync(R, case, n_slots=160):
         peaks.append((pss, (n1.value, fs.value, s.copy()) if rc == 0 else None))
     R.ref_phy_free(phy)
     return dict(coarse=(n.value, fo, ss), per_peak=peaks)
+
+
+def multi_port_capture(R, n_ant, seed=70, fft=2048, nrb=100, cell=101, sf=4, cfi=2, mod=2, tbs=2024, prbs=None, noise=0.5):
+    """One subframe (+ the next one's CRS, which the estimator's interpolation reads) of a real n_ant-port cell from the reference's
+    own transmitter: CRS on every port, one transmit-diversity PDSCH allocation, each antenna through its own complex gain, summed,
+    scaled to int8.  Returns dict with iq int8 [2*30720*fft/2048, 2], the message bits, the reference allocation and its phy."""
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(seed + n_ant)
+    prbs = prbs or list(range(10, 22))
+    phy = R.ref_phy_new(po.FS_ENUM[fft], cell, n_ant, nrb)
+    sfp = R.ref_subframe_new()
+    la = po.make_alloc(mod, tbs, prbs, 0x2345, 0, 1 if n_ant == 1 else 2, 0)  # LIBLTE_PHY_PRE_CODER_TYPE_TX_DIVERSITY
+    msg = rng.integers(0, 2, tbs).astype(np.uint8)
+    n_samp = 30720 * fft // 2048
+    z = np.zeros(2 * n_samp, np.complex64)
+    gains = [rng.uniform(0.6, 1.2) * np.exp(1j * rng.uniform(-np.pi, np.pi)) for _ in range(n_ant)]
+    for k in range(2):
+        R.ref_subframe_clear_tx(sfp, sf + k)
+        assert R.ref_map_crs(phy, sfp, cell, n_ant) == 0
+        if k == 0:
+            arr = (po.LoAlloc * 1)(la)
+            assert R.ref_pdsch_channel_encode(phy, sfp, arr, 1, msg, tbs, cfi, cell, n_ant) == 0
+        for p in range(n_ant):
+            i_s, q_s = np.zeros(n_samp, np.float32), np.zeros(n_samp, np.float32)
+            assert R.ref_create_dl_subframe(phy, sfp, p, i_s, q_s) == 0
+            z[k * n_samp:(k + 1) * n_samp] += gains[p] * (i_s + 1j * q_s)
+    z *= 90.0 / np.abs(np.concatenate([z.real, z.imag])).max()
+    z += noise * (rng.standard_normal(len(z)) + 1j * rng.standard_normal(len(z)))
+    iq = np.stack([np.round(z.real), np.round(z.imag)], axis=1).astype(np.int8)
+    R.ref_subframe_free(sfp)
+    return dict(fft=fft, nrb=nrb, cell=cell, sf=sf, cfi=cfi, tbs=tbs, prbs=prbs, msg=msg, iq=iq, la=la, phy=phy)

@@ -207,29 +207,9 @@ def test_multi_port_transmit_diversity_end_to_end(ctx, ref, n_ant):
     import ctypes as C
     import openlte_amd as m
     from oracle import pyoracle as po
-    rng = np.random.default_rng(70 + n_ant)
-    fft, nrb, cell, sf, cfi = 2048, 100, 101, 4, 2
-    tbs, prbs = 2024, list(range(10, 22))  # 16QAM, 12 PRB: E well above 3(K + 4) also with the extra CRS
-    phy = ref.ref_phy_new(po.FS_ENUM[fft], cell, n_ant, nrb)
-    sfp = ref.ref_subframe_new()
-    la = po.make_alloc(2, tbs, prbs, 0x2345, 0, 2, 0)  # tx_mode 2, LIBLTE_PHY_PRE_CODER_TYPE_TX_DIVERSITY
-    msg = rng.integers(0, 2, tbs).astype(np.uint8)
+    cap = td.multi_port_capture(ref, n_ant)
+    fft, nrb, cell, sf, cfi, tbs, prbs, msg, iq, la, phy = (cap[k] for k in ("fft", "nrb", "cell", "sf", "cfi", "tbs", "prbs", "msg", "iq", "la", "phy"))
     n_samp = 30720
-    z = np.zeros(2 * n_samp, np.complex64)  # the subframe and the next one (its first CRS symbols feed the interpolation)
-    gains = [rng.uniform(0.6, 1.2) * np.exp(1j * rng.uniform(-np.pi, np.pi)) for _ in range(n_ant)]
-    for k in range(2):
-        ref.ref_subframe_clear_tx(sfp, sf + k)
-        assert ref.ref_map_crs(phy, sfp, cell, n_ant) == 0
-        if k == 0:
-            arr = (po.LoAlloc * 1)(la)
-            assert ref.ref_pdsch_channel_encode(phy, sfp, arr, 1, msg, tbs, cfi, cell, n_ant) == 0
-        for p in range(n_ant):
-            i_s, q_s = np.zeros(n_samp, np.float32), np.zeros(n_samp, np.float32)
-            assert ref.ref_create_dl_subframe(phy, sfp, p, i_s, q_s) == 0
-            z[k * n_samp:(k + 1) * n_samp] += gains[p] * (i_s + 1j * q_s)
-    z *= 90.0 / np.abs(np.concatenate([z.real, z.imag])).max()
-    z += 0.5 * (rng.standard_normal(len(z)) + 1j * rng.standard_normal(len(z)))
-    iq = np.stack([np.round(z.real), np.round(z.imag)], axis=1).astype(np.int8)
     # the reference's receiver on the same int8-valued samples
     i_f = np.ascontiguousarray(np.concatenate([np.zeros(sf * n_samp, np.float32), iq[:, 0].astype(np.float32)]))
     q_f = np.ascontiguousarray(np.concatenate([np.zeros(sf * n_samp, np.float32), iq[:, 1].astype(np.float32)]))
@@ -258,6 +238,5 @@ def test_multi_port_transmit_diversity_end_to_end(ctx, ref, n_ant):
     assert st[0] == 0 and (bits[0] == msg).all()
     plan.close()
     d_sub.free()
-    ref.ref_subframe_free(sfp)
     ref.ref_subframe_free(rx)
     ref.ref_phy_free(phy)

@@ -92,3 +92,29 @@ def test_frontend_many_phase_wraps(ctx, port):
         _, s = td.oracle_frontend(port, 2048, 100, 1, iq[u], sfs[u], cells[u])
         assert rel_l2(got[u, 2, :14, :1200], s.arr("rx_ce_re")[0, :14, :1200]) < TOL_CE, u
         assert rel_l2(got[u, 3, :14, :1200], s.arr("rx_ce_im")[0, :14, :1200]) < TOL_CE, u
+
+
+@pytest.mark.parametrize("n_ant", [2, 4])
+def test_frontend_real_multi_port_cell(ctx, ref, n_ant):
+    """Channel estimates of every port of a real 2- / 4-port cell (CRS on all ports, per-antenna gains; the reference's transmitter)
+    against the compiled reference's estimator: ports 2, 3 have two CRS symbols per slot instead of four and their own interpolation."""
+    import ctypes as C
+    import openlte_amd as m
+    from oracle import pyoracle as po
+    cap = td.multi_port_capture(ref, n_ant)
+    n_samp, sf, cell = 30720, cap["sf"], cap["cell"]
+    iq = cap["iq"]
+    i_f = np.ascontiguousarray(np.concatenate([np.zeros(sf * n_samp, np.float32), iq[:, 0].astype(np.float32)]))
+    q_f = np.ascontiguousarray(np.concatenate([np.zeros(sf * n_samp, np.float32), iq[:, 1].astype(np.float32)]))
+    rx = ref.ref_subframe_new()
+    assert ref.ref_get_dl_subframe_and_ce(cap["phy"], i_f, q_f, 0, sf, cell, n_ant, rx) == 0
+    got = ctx.dl_frontend(m.DlCfg(2048, 100, n_ant, 0), iq, [0], [sf], [cell])[0]
+    assert rel_l2(got[0, :14], po.ref_subframe_view(ref, rx, 0)[:14]) < TOL_SYMB
+    assert rel_l2(got[1, :14], po.ref_subframe_view(ref, rx, 1)[:14]) < TOL_SYMB
+    for p in range(n_ant):
+        w_re, w_im = po.ref_subframe_view(ref, rx, 2, True)[p, :14], po.ref_subframe_view(ref, rx, 3, True)[p, :14]
+        assert rel_l2(got[2 + p, :14], w_re) < TOL_CE and rel_l2(got[2 + n_ant + p, :14], w_im) < TOL_CE, p
+        h = np.hypot(w_re, w_im)
+        assert (np.hypot(got[2 + p, :14] - w_re, got[2 + n_ant + p, :14] - w_im) / h).max() < 10 * TOL_CE, p
+    ref.ref_subframe_free(rx)
+    ref.ref_phy_free(cap["phy"])

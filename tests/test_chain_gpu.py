@@ -240,3 +240,42 @@ def test_multi_port_transmit_diversity_end_to_end(ctx, ref, n_ant):
     d_sub.free()
     ref.ref_subframe_free(rx)
     ref.ref_phy_free(phy)
+
+
+@pytest.mark.parametrize("fft,nrb,n_ant", [(128, 6, 1), (256, 15, 2), (512, 25, 1), (1024, 50, 4), (2048, 75, 2)])
+def test_every_bandwidth_end_to_end(ctx, ref, fft, nrb, n_ant):
+    """The other five LTE bandwidths (FFT 128 ... 2048, 6 ... 75 resource blocks; 1, 2 or 4 ports): a 64QAM allocation from the reference's
+    transmitter through the library's front end and PDSCH chain decodes to the transmitted block, and -- on the reference's own
+    received grid -- to the reference's soft bits exactly."""
+    import ctypes as C
+    import openlte_amd as m
+    from oracle import pyoracle as po
+    n_sym = 3 if nrb <= 10 else 2  # PDCCH symbols (the helper's "cfi" argument is that count)
+    cap = td.multi_port_capture(ref, n_ant, seed=fft, fft=fft, nrb=nrb, cell=(7 * nrb) % 504, sf=7, cfi=n_sym, mod=3, tbs=1064,
+                                prbs=list(range(1, 6)))  # 5 PRB x 64QAM: E >= 3(K + 4) in every configuration
+    n_samp, sf, cell, cfi, tbs, iq, la, phy = 30720 * fft // 2048, cap["sf"], cap["cell"], cap["cfi"], cap["tbs"], cap["iq"], cap["la"], cap["phy"]
+    i_f = np.ascontiguousarray(np.concatenate([np.zeros(sf * n_samp, np.float32), iq[:, 0].astype(np.float32)]))
+    q_f = np.ascontiguousarray(np.concatenate([np.zeros(sf * n_samp, np.float32), iq[:, 1].astype(np.float32)]))
+    rx = ref.ref_subframe_new()
+    assert ref.ref_get_dl_subframe_and_ce(phy, i_f, q_f, 0, sf, cell, n_ant, rx) == 0
+    out, n = np.zeros(6200, np.uint8), C.c_uint32()
+    assert ref.ref_pdsch_channel_decode(phy, rx, C.byref(la), n_sym, cell, n_ant, out, C.byref(n)) == 0 and (out[:tbs] == cap["msg"]).all()
+    cfg = m.DlCfg(fft, nrb, n_ant, 0)
+    alloc = [m.make_alloc(0, 3, tbs, cap["prbs"], 0x2345, 0, 1 if n_ant == 1 else 2)]
+    plan = ctx.pdsch_plan(cfg, n_sym, alloc)
+    grid = np.concatenate([po.ref_subframe_view(ref, rx, 0).ravel(), po.ref_subframe_view(ref, rx, 1).ravel(),
+                           po.ref_subframe_view(ref, rx, 2, True)[:n_ant].ravel(), po.ref_subframe_view(ref, rx, 3, True)[:n_ant].ravel()]).astype(np.float32)
+    d_sub = ctx.to_device(grid)
+    st, bits = plan.run(d_sub, [sf], [cell])
+    e = plan.soft_bits(0)
+    want = np.ctypeslib.as_array(ref.ref_pdsch_descramb_bits_ptr(phy), shape=(len(e),)).astype(np.int8)
+    assert (e == want).all() and st[0] == 0 and (bits[0] == out[:tbs]).all()
+    d_sub.free()
+    got = ctx.dl_frontend(cfg, iq, [0], [sf], [cell])
+    d_sub = ctx.to_device(np.ascontiguousarray(got[0], np.float32))
+    st, bits = plan.run(d_sub, [sf], [cell])
+    assert st[0] == 0 and (bits[0] == cap["msg"]).all()
+    plan.close()
+    d_sub.free()
+    ref.ref_subframe_free(rx)
+    ref.ref_phy_free(phy)

@@ -476,7 +476,7 @@ def ref_sync(R, case, n_slots=160):
     return dict(coarse=(n.value, fo, ss), per_peak=peaks)
 
 
-def multi_port_capture(R, n_ant, seed=70, fft=2048, nrb=100, cell=101, sf=4, cfi=2, mod=2, tbs=2024, prbs=None, noise=0.5):
+def multi_port_capture(R, n_ant, seed=70, fft=2048, nrb=100, cell=101, sf=4, cfi=2, mod=2, tbs=2024, prbs=None, noise=0.5, rv=0):
     """One subframe (+ the next one's CRS, which the estimator's interpolation reads) of a real n_ant-port cell from the reference's
     own transmitter: CRS on every port, one transmit-diversity PDSCH allocation, each antenna through its own complex gain, summed,
     scaled to int8.  Returns dict with iq int8 [2*30720*fft/2048, 2], the message bits, the reference allocation and its phy."""
@@ -485,7 +485,7 @@ def multi_port_capture(R, n_ant, seed=70, fft=2048, nrb=100, cell=101, sf=4, cfi
     prbs = prbs or list(range(10, 22))
     phy = R.ref_phy_new(po.FS_ENUM[fft], cell, n_ant, nrb)
     sfp = R.ref_subframe_new()
-    la = po.make_alloc(mod, tbs, prbs, 0x2345, 0, 1 if n_ant == 1 else 2, 0)  # LIBLTE_PHY_PRE_CODER_TYPE_TX_DIVERSITY
+    la = po.make_alloc(mod, tbs, prbs, 0x2345, rv, 1 if n_ant == 1 else 2, 0)  # LIBLTE_PHY_PRE_CODER_TYPE_TX_DIVERSITY
     msg = rng.integers(0, 2, tbs).astype(np.uint8)
     n_samp = 30720 * fft // 2048
     z = np.zeros(2 * n_samp, np.complex64)

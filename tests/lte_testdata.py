@@ -144,6 +144,10 @@ PRACH_CASES = {
     "5MHz_1root": (512, 25, 100, 0, 1, 0, 2, [0, 40, 63], [0, 20, 5], 5.0),
     "3MHz_restricted": (256, 15, 300, 0, 6, 1, 1, [2, 9, 30], [1, 4, 0], 10.0),
     "1p4MHz_noise_only": (128, 6, 22, 0, 11, 0, 0, [0], [0], -30.0),
+    # the longer preamble formats: 1 (long prefix), 2 and 3 (the sequence sent twice)
+    "1p4MHz_format1": (128, 6, 50, 1, 11, 0, 0, [3, 44], [0, 9], 10.0),
+    "5MHz_format2": (512, 25, 700, 2, 4, 0, 3, [0, 21, 63], [0, 30, 11], 5.0),
+    "3MHz_format3": (256, 15, 123, 3, 8, 0, 1, [7, 50], [2, 15], 8.0),
 }
 
 

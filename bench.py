@@ -355,7 +355,7 @@ class UplinkWorkload:
     liblte_phy.cc:6426-6428).  One step = SC-FDMA demodulation -> per-UE DMRS estimate / equaliser / transform
     pre-decoding / de-map / descramble / de-interleave -> rate un-match -> REF turbo -> CRC."""
     name = "uplink"
-    metric = "UL subframes/sec @20MHz, 16 UEs x 6 PRB QPSK PUSCH: SC-FDMA demod + PUSCH demod + UL-SCH turbo decode (SURVEY 8d W5)"
+    metric = "UL subframes/sec @20MHz, 16 UEs x 6 PRB QPSK PUSCH + 1 PRACH occasion per 10 subframes: SC-FDMA demod + PUSCH demod + UL-SCH turbo decode + PRACH correlation (SURVEY 8d W5)"
     unit = "subframes/s"
     dtype = "i8 IQ in, f32 FFT/CE/equaliser/DFT, i8 soft bits, i32 path metrics"
     N_UE, N_PRB, TBS = 16, 6, 504
@@ -390,10 +390,22 @@ class UplinkWorkload:
         self.plan = ctx.pusch_plan(self.cfg, self.ul, sfs[idx], [self.cell] * self.n, all_allocs)
         self.d_out = ctx.alloc(self.n * self.N_UE * self.plan.out_stride)
         self.d_status = ctx.alloc(self.n * self.N_UE * 4)
+        # one PRACH occasion (format 0) per 10 subframes, a preamble in each (BASELINE config 5: "PRACH correlate + ...")
+        self.pc = m.PrachCfg(22, 0, 11, 0, 4)
+        self.n_occ = max(1, self.n // 10)
+        PU = min(8, self.n_occ)
+        self.pre = [(7 * k + 3) % 64 for k in range(PU)]
+        piq = synth.prach_occasions(self.cfg, self.pc, self.pre, [16 * (k + 1) for k in range(PU)], snr_db=5.0, seed=31 + rank)
+        self.pidx = np.arange(self.n_occ) % PU
+        self.d_prach = ctx.to_device(piq[self.pidx].reshape(-1, 2))
+        self.d_pstart = ctx.to_device((np.arange(self.n_occ) * piq.shape[1]).astype(np.uint64))
+        self.pplan = ctx.prach_plan(self.cfg, self.pc)
+        self.prach_last = None
 
     def step(self):
         self.ctx.ul_frontend_dev(self.cfg, self.d_iq, None, self.d_start, self.n, self.d_sub)
         self.plan.run_dev(self.d_sub, self.d_out, self.d_status)
+        self.prach_last = self.pplan.detect_dev(self.d_prach, None, self.d_pstart, self.n_occ)
 
     def units_per_step(self):
         return self.n
@@ -408,18 +420,21 @@ class UplinkWorkload:
         tx = self.uniq[1]
         exact = all((bits[i * self.N_UE + a, :self.TBS] == tx[self.idx[i], a, :self.TBS]).all()
                     for i in range(0, self.n, max(1, self.n // 64)) for a in range(self.N_UE))
+        nd, pr, _ = self.prach_last
         return {"turbo_info_mbit_per_s": round(value * self.N_UE * self.TBS / 1e6, 2),
-                "crc_pass": "%d/%d allocations" % (int((st == 0).sum()), st.size), "sampled_blocks_equal_tx_bits": bool(exact)}
+                "crc_pass": "%d/%d allocations" % (int((st == 0).sum()), st.size), "sampled_blocks_equal_tx_bits": bool(exact),
+                "prach": "%d/%d occasions: the transmitted preamble detected" % (int(((nd == 1) & (pr == np.array(self.pre)[self.pidx])).sum()), self.n_occ)}
 
     def roofline_bytes(self, kernel, n_launch_per_step):
         n, M = self.n, 12 * self.N_PRB
         turbo = n * self.N_UE * _turbo_alg_bytes(self.TBS + 24)
-        return {"k_ul_fft": n * (61440 + 14 * 1200 * 8), "k_pusch_demod": n * self.N_UE * (14 * M * 8 + 12 * M * 2),
+        return {"k_prach_bins": self.n_occ * (24576 * 2 + 839 * 8), "k_prach_corr": self.n_occ * (839 * 8 + 64 * 12),
+                "k_ul_fft": n * (61440 + 14 * 1200 * 8), "k_pusch_demod": n * self.N_UE * (14 * M * 8 + 12 * M * 2),
                 "k_turbo_siso": 2 * turbo, "k_turbo_prep": turbo, "k_turbo_perm": turbo, "k_turbo_vote": turbo}.get(kernel)
 
     def config(self, world):
-        return {"workload": "W5 uplink: 20 MHz, %d UEs x %d PRB QPSK PUSCH (TBS %d) per subframe, %d subframes per GPU, int8 IQ in HBM"
-                            % (self.N_UE, self.N_PRB, self.TBS, self.n),
+        return {"workload": "W5 uplink: 20 MHz, %d UEs x %d PRB QPSK PUSCH (TBS %d) per subframe, %d subframes per GPU + %d PRACH occasions "
+                            "(format 0, one per 10 subframes), int8 IQ in HBM" % (self.N_UE, self.N_PRB, self.TBS, self.n, self.n_occ),
                 "subframes_per_gpu": self.n, "decoder": "REF (reference-faithful, bit-exact)", "unique_subframes": len(self.uniq[2]),
                 "sharding": "subframes block-cyclic over %d GPU(s), no collective" % world}
 

@@ -40,6 +40,7 @@ struct mi_lte_ctx {
 
     float2   *d_fft_tw  = nullptr; // exp(-2*pi*i*k/4096), k = 0..4095 (mi_ctx_fft_twiddles)
     uint32_t *d_crc_tab = nullptr; // x^e mod gCRC24A, e = 0..6143
+    float2   *d_prach_tab = nullptr; // chirp | filter spectrum | twiddles of the 839-point chirp-z transform (prach.hip)
 
     // optional per-launch HIP-event bracketing (mi_lte_profile_*): pairs are resolved at report time
     bool                                   prof_on = false;

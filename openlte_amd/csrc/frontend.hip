@@ -122,12 +122,12 @@ template <> struct SampleSrc<float> { // planar i_samps / q_samps as the referen
     __device__ __forceinline__ float2 at(size_t n) const { return make_float2(i[n], q[n]); }
 };
 
-// PERSIST: one workgroup walks all n_sym symbols of its unit and requests the next symbol's samples before it transforms the
-// current one.  Measured SLOWER than one workgroup per symbol on the MI355X (9.5 vs 6.5 ms per 64k subframes: the sixteen-fold
-// drop in independent workgroups costs more than the hidden load latency buys), so the launches below do not use it.
-template <typename T, bool RAW = false, bool PERSIST = false>
+// One workgroup per (symbol, unit).  (A persistent variant -- one workgroup walking all symbols of its unit with the next symbol's
+// samples prefetched -- was measured slower on the MI355X, 9.5 vs 6.5 ms per 64k subframes: the compiler hoists the twiddles
+// out of the symbol loop and the register count collapses the occupancy; it is not kept.)
+template <typename T, bool RAW = false>
 __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t *__restrict__ unit_start, DlGeom g,
-                                                const float2 *__restrict__ tw, float *__restrict__ subframes, uint32_t n_sym)
+                                                const float2 *__restrict__ tw, float *__restrict__ subframes)
 {
     extern __shared__ __attribute__((aligned(16))) float2 buf[]; // pad(N) entries
     const uint32_t unit = blockIdx.y, N = g.N, nb = N / 8, j = threadIdx.x, half = g.half;
@@ -150,13 +150,10 @@ __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t
     auto ld_s = [&](uint32_t i) { return buf[pad(i)]; };
     const uint32_t dc = g.ul ? 0u : 1u; // downlink skips the DC bin, the half-shifted uplink grid has none
 
-    uint32_t       sym = PERSIST ? 0u : blockIdx.x;
-    const uint32_t sym_end = PERSIST ? n_sym : sym + 1;
-    raw_t cur[8], nxt[8];
+    const uint32_t sym = blockIdx.x;
+    raw_t cur[8];
     fetch(sym, cur);
-#pragma nounroll
-    for (; sym < sym_end; sym++) {
-        if (PERSIST && sym + 1 < sym_end) fetch(sym + 1, nxt);
+    {
         float *row_re = subframes + (size_t)unit * g.sf_stride + (size_t)sym * N_SC_MAX;
         float *row_im = row_re + (RAW ? N_SC_MAX : 16 * N_SC_MAX);
         auto st_g = [&](uint32_t o, float2 v) { // keep bins dc..half-1+dc and N-half..N-1 (liblte_phy.cc:8625-8634, :8685-8690)
@@ -228,11 +225,6 @@ __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t
             __syncthreads();
             if (N == 1024) fft_pass<2>(tw, N, Ns, ld_s, st_g);
             else           fft_pass<4>(tw, N, Ns, ld_s, st_g);
-        }
-        if (PERSIST) {
-            __syncthreads(); // the last pass still reads buf
-#pragma unroll
-            for (int r = 0; r < 8; r++) cur[r] = nxt[r];
         }
     }
 }
@@ -490,11 +482,11 @@ extern "C" int mi_lte_dl_frontend_batch(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cf
     const size_t lds_fft = sizeof(float2) * (g.N + g.N / 32 + 1);
     if (cfg->sample_format == MI_LTE_IQ_I8) {
         SampleSrc<int8_t> s{(const int8_t *)d_samples_a};
-        MI_LAUNCH(ctx, "k_dl_fft", (k_dl_fft<int8_t>), dim3(16, n_units), dim3(256), lds_fft, s, d_unit_start, g, ctx->d_fft_tw, d_subframes, 16u);
+        MI_LAUNCH(ctx, "k_dl_fft", (k_dl_fft<int8_t>), dim3(16, n_units), dim3(256), lds_fft, s, d_unit_start, g, ctx->d_fft_tw, d_subframes);
     } else if (cfg->sample_format == MI_LTE_IQ_F32_PLANAR) {
         if (!d_samples_b) return MI_LTE_ERR_INVALID_ARG;
         SampleSrc<float> s{(const float *)d_samples_a, (const float *)d_samples_b};
-        MI_LAUNCH(ctx, "k_dl_fft", (k_dl_fft<float>), dim3(16, n_units), dim3(256), lds_fft, s, d_unit_start, g, ctx->d_fft_tw, d_subframes, 16u);
+        MI_LAUNCH(ctx, "k_dl_fft", (k_dl_fft<float>), dim3(16, n_units), dim3(256), lds_fft, s, d_unit_start, g, ctx->d_fft_tw, d_subframes);
     } else
         return MI_LTE_ERR_INVALID_ARG;
     GoldTables gt{ctx->d_gold_x1, ctx->d_gold_x2b, ctx->gold_words};
@@ -521,11 +513,11 @@ int mi_fft_rows(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const void *d_samples
     const size_t lds_fft = sizeof(float2) * (g.N + g.N / 32 + 1);
     if (cfg->sample_format == MI_LTE_IQ_I8) {
         SampleSrc<int8_t> s{(const int8_t *)d_samples_a};
-        MI_LAUNCH(ctx, "k_sync_fft", (k_dl_fft<int8_t, true>), dim3(1, n_rows), dim3(256), lds_fft, s, d_win_start, g, ctx->d_fft_tw, d_rows, 1u);
+        MI_LAUNCH(ctx, "k_sync_fft", (k_dl_fft<int8_t, true>), dim3(1, n_rows), dim3(256), lds_fft, s, d_win_start, g, ctx->d_fft_tw, d_rows);
     } else {
         if (!d_samples_b) return MI_LTE_ERR_INVALID_ARG;
         SampleSrc<float> s{(const float *)d_samples_a, (const float *)d_samples_b};
-        MI_LAUNCH(ctx, "k_sync_fft", (k_dl_fft<float, true>), dim3(1, n_rows), dim3(256), lds_fft, s, d_win_start, g, ctx->d_fft_tw, d_rows, 1u);
+        MI_LAUNCH(ctx, "k_sync_fft", (k_dl_fft<float, true>), dim3(1, n_rows), dim3(256), lds_fft, s, d_win_start, g, ctx->d_fft_tw, d_rows);
     }
     MI_HIP_CHECK(ctx, hipGetLastError());
     return MI_LTE_OK;
@@ -553,11 +545,11 @@ extern "C" int mi_lte_ul_frontend_batch(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cf
     const size_t lds_fft = sizeof(float2) * (g.N + g.N / 32 + 1);
     if (cfg->sample_format == MI_LTE_IQ_I8) {
         SampleSrc<int8_t> s{(const int8_t *)d_samples_a};
-        MI_LAUNCH(ctx, "k_ul_fft", (k_dl_fft<int8_t>), dim3(14, n_units), dim3(256), lds_fft, s, d_unit_start, g, ctx->d_fft_tw, d_subframes, 14u);
+        MI_LAUNCH(ctx, "k_ul_fft", (k_dl_fft<int8_t>), dim3(14, n_units), dim3(256), lds_fft, s, d_unit_start, g, ctx->d_fft_tw, d_subframes);
     } else if (cfg->sample_format == MI_LTE_IQ_F32_PLANAR) {
         if (!d_samples_b) return MI_LTE_ERR_INVALID_ARG;
         SampleSrc<float> s{(const float *)d_samples_a, (const float *)d_samples_b};
-        MI_LAUNCH(ctx, "k_ul_fft", (k_dl_fft<float>), dim3(14, n_units), dim3(256), lds_fft, s, d_unit_start, g, ctx->d_fft_tw, d_subframes, 14u);
+        MI_LAUNCH(ctx, "k_ul_fft", (k_dl_fft<float>), dim3(14, n_units), dim3(256), lds_fft, s, d_unit_start, g, ctx->d_fft_tw, d_subframes);
     } else
         return MI_LTE_ERR_INVALID_ARG;
     MI_HIP_CHECK(ctx, hipGetLastError());

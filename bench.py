@@ -188,6 +188,8 @@ class ChainWorkload:
         for i in range(self.n):
             all_allocs += td.w4_allocs(i)
         self.plan = ctx.pdsch_plan(self.cfg, 2, all_allocs)
+        if DECODER == "bcjr":  # the max-log-MAP decoder instead of the reference's (8 iterations; the reference transmitter's interleaver)
+            self.plan.set_decoder(m.TURBO_BCJR, 8, 0)
         self.d_out = ctx.alloc(self.n * 9 * self.plan.out_stride)
         self.d_status = ctx.alloc(self.n * 9 * 4)
 
@@ -235,12 +237,15 @@ class ChainWorkload:
         turbo = 8 * n * _turbo_alg_bytes(3264) + n * _turbo_alg_bytes(1088)
         return {"k_dl_fft": n * (70240 + 16 * 1200 * 8), "k_dl_ce": n * (5 * 1200 * 8 + 14 * 1200 * 8),
                 "k_pdsch_demod": n * (8 * 1656 + 552) * (16 + 6),
-                "k_turbo_siso": 2 * turbo, "k_turbo_prep": turbo, "k_turbo_perm": turbo, "k_turbo_vote": turbo}.get(kernel)
+                "k_turbo_siso": 2 * turbo, "k_turbo_prep": turbo, "k_turbo_perm": turbo, "k_turbo_vote": turbo,
+                "k_rm_to_i8": turbo, "k_crc_finish": turbo, "k_bcjr_prep": turbo, "k_bcjr_fwd": 16 * turbo, "k_bcjr_bwd": 16 * turbo,
+                "k_bcjr_perm": 16 * turbo}.get(kernel)
 
     def config(self, world):
         return {"workload": "W4 full DL chain: 20 MHz/100 RB/64QAM, 9 allocations per subframe (8x12 PRB TBS 3240 + 1x4 PRB "
                             "TBS 1064), %d subframes per GPU, int8 IQ in HBM" % self.n,
-                "subframes_per_gpu": self.n, "N_ant": 1, "CFI": 2, "decoder": "REF (reference-faithful, bit-exact)",
+                "subframes_per_gpu": self.n, "N_ant": 1, "CFI": 2,
+                "decoder": "BCJR (max-log-MAP, 8 iterations; specified by the plain-C model, not by the reference)" if DECODER == "bcjr" else "REF (reference-faithful, bit-exact)",
                 "unique_subframes": len(self.uniq[2]),
                 "sharding": "subframes block-cyclic over %d GPU(s), no collective" % world}
 

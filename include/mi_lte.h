@@ -142,6 +142,12 @@ typedef struct mi_lte_pdsch_plan mi_lte_pdsch_plan;
 int      mi_lte_pdsch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, uint32_t N_pdcch_symbs,
                                   const mi_lte_pdsch_alloc *h_allocs, uint32_t n_alloc, mi_lte_pdsch_plan **out);
 void     mi_lte_pdsch_plan_destroy(mi_lte_ctx *ctx, mi_lte_pdsch_plan *plan);
+/* Decoder of the plan's transport blocks: MI_LTE_TURBO_REF (default; the reference's decoder, bit-exact) or MI_LTE_TURBO_BCJR with
+ * n_iter iterations (the max-log-MAP decoder of mi_lte_turbo_decode_batch; the reference has no such mode).  In BCJR mode the soft
+ * bits are rate-un-matched to int8 channel values (sums of repeats saturated to +-127) and the decoded block is finished like
+ * dlsch_channel_decode does (filler removed, CRC24A, one bit per byte).  qpp_spec != 0: the exact 3GPP interleaver (what a
+ * standard eNodeB transmits); 0: the reference transmitter's uint32-wrapped one (they differ for 20 block sizes). */
+int      mi_lte_pdsch_plan_set_decoder(mi_lte_pdsch_plan *plan, uint32_t mode /* mi_lte_turbo_mode */, uint32_t n_iter, int qpp_spec);
 uint32_t mi_lte_pdsch_plan_out_stride(const mi_lte_pdsch_plan *plan);
 int      mi_lte_pdsch_decode_run(mi_lte_ctx *ctx, mi_lte_pdsch_plan *plan, const float *d_subframes,
                                  const uint32_t *d_subfr_num, const uint32_t *d_n_id_cell, uint8_t *d_out_bits,

@@ -220,6 +220,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 
 struct mi_lte_pdsch_plan {
     mi_lte_dl_cfg cfg;
+    uint32_t      decoder = MI_LTE_TURBO_REF, n_iter = 8; // MI_LTE_TURBO_BCJR: mi_lte_pdsch_plan_set_decoder
+    int           qpp_spec = 0;
+    int8_t       *d_bcjr_soft = nullptr;                  // [max n_cb][3(K+4)] int8 channel values of the group being decoded
+    uint8_t      *d_bcjr_bits = nullptr;                  // [max n_cb][K] its hard decisions
     uint32_t      cfi = 0, n_alloc = 0, out_stride = 0, max_pairs = 0, max_words = 0;
     size_t        e_bytes = 0;
     mi_lte_pdsch_alloc *d_allocs = nullptr;
@@ -312,6 +316,8 @@ void mi_lte_pdsch_plan_destroy(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl)
     (void)hipFree(pl->d_e_len);
     (void)hipFree(pl->d_cb_alloc);
     (void)hipFree(pl->d_e);
+    if (pl->d_bcjr_soft) (void)hipFree(pl->d_bcjr_soft);
+    if (pl->d_bcjr_bits) (void)hipFree(pl->d_bcjr_bits);
     delete pl;
 }
 
@@ -322,6 +328,13 @@ int mi_lte_pdsch_plan_soft_bits(const mi_lte_pdsch_plan *pl, uint32_t alloc, con
     if (!pl || alloc >= pl->n_alloc || !d_e || !d_len) return MI_LTE_ERR_INVALID_ARG;
     *d_e   = pl->d_e + (size_t)pl->h_e_off[alloc] * 64;
     *d_len = pl->d_e_len + alloc;
+    return MI_LTE_OK;
+}
+
+int mi_lte_pdsch_plan_set_decoder(mi_lte_pdsch_plan *pl, uint32_t mode, uint32_t n_iter, int qpp_spec)
+{
+    if (!pl || !(mode == MI_LTE_TURBO_REF || mode == MI_LTE_TURBO_BCJR) || (mode == MI_LTE_TURBO_BCJR && (n_iter == 0 || n_iter > 64))) return MI_LTE_ERR_INVALID_ARG;
+    pl->decoder = mode; pl->n_iter = n_iter; pl->qpp_spec = qpp_spec;
     return MI_LTE_OK;
 }
 
@@ -346,12 +359,23 @@ int mi_lte_pdsch_decode_run(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, const float 
         MI_LAUNCH(ctx, "k_pdsch_demod", k_pdsch_demod<false>, dim3(pl->n_alloc), dim3(256), lds, d_subframes, g, pl->d_allocs, d_subfr_num,
                   d_n_id_cell, gt, pl->d_e, pl->d_e_off, pl->d_e_len, pl->max_pairs, words_al, e_cap);
     MI_HIP_CHECK(ctx, hipGetLastError());
+    if (pl->decoder == MI_LTE_TURBO_BCJR && !pl->d_bcjr_soft) {
+        size_t soft = 0, bits = 0;
+        for (auto &gr : pl->groups) { soft = std::max(soft, (size_t)gr.n_cb * 3 * (gr.K + 4)); bits = std::max(bits, (size_t)gr.n_cb * gr.K); }
+        MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_bcjr_soft, soft));
+        MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_bcjr_bits, bits));
+    }
     for (auto &gr : pl->groups) {
-        rc = mi_turbo_ref_group(ctx, gr.K, gr.n_cb, pl->d_allocs, pl->d_cb_alloc + gr.cb_base, pl->d_e, pl->d_e_off, pl->d_e_len,
-                                d_out_bits, pl->out_stride, d_status, gr.e_max);
+        if (pl->decoder == MI_LTE_TURBO_BCJR)
+            rc = mi_turbo_bcjr_group(ctx, gr.K, gr.n_cb, pl->d_allocs, pl->d_cb_alloc + gr.cb_base, pl->d_e, pl->d_e_off, pl->d_e_len, d_out_bits,
+                                     pl->out_stride, d_status, false, pl->d_bcjr_soft, pl->d_bcjr_bits, pl->n_iter, pl->qpp_spec);
+        else
+            rc = mi_turbo_ref_group(ctx, gr.K, gr.n_cb, pl->d_allocs, pl->d_cb_alloc + gr.cb_base, pl->d_e, pl->d_e_off, pl->d_e_len,
+                                    d_out_bits, pl->out_stride, d_status, gr.e_max);
         if (rc != MI_LTE_OK) return rc;
     }
-    ctx->last_kernels = "k_pdsch_demod:1,k_turbo_prep,k_turbo_siso,k_turbo_perm,k_turbo_vote per block size";
+    ctx->last_kernels = pl->decoder == MI_LTE_TURBO_BCJR ? "k_pdsch_demod:1,k_rm_to_i8,k_bcjr_*,k_crc_finish per block size"
+                                                         : "k_pdsch_demod:1,k_turbo_prep,k_turbo_siso,k_turbo_perm,k_turbo_vote per block size";
     return MI_LTE_OK;
 }
 

@@ -858,6 +858,60 @@ __global__ __launch_bounds__(256) void k_rate_unmatch_f32(const float *__restric
     }
 }
 
+// ---- BCJR mode of the PDSCH / PUSCH chains (MI_LTE_TURBO_BCJR): the max-log-MAP decoder (bcjr.hip) takes int8 channel values
+// d[i*3+x], tail included, so the soft bits are rate-un-matched into that layout first (same walk as above, sums of repeats
+// saturated to +-127, positions no bit reaches = 0), and the decoded block is finished the way dlsch_channel_decode does
+// (liblte_phy.cc:12840-12869): filler removed, CRC24A checked, transport block written one bit per byte.
+__global__ __launch_bounds__(256) void k_rm_to_i8(GroupDesc g, uint32_t K, uint32_t n_cb, const uint16_t *__restrict__ tabs, const uint32_t *__restrict__ nnn,
+                                                  int8_t *__restrict__ d_soft)
+{
+    __shared__ RmGeom rm_s;
+    const uint32_t cb = blockIdx.x, D = K + 4, a = g.cb_alloc[cb], txm = g.allocs[a].tx_mode, rv = g.allocs[a].rv_idx & 3u;
+    if (threadIdx.x == 0) { // the geometry is the same for the whole code block; only the 12 tail values need it (the tables stop at K)
+        if (g.ul) rm_s.init(D, 1, rv, 1, 1, 1, false);
+        else      rm_s.init(D, txm, rv);
+    }
+    __syncthreads();
+    const uint32_t combo = g.ul ? 8u + rv : (rv << 1) | ((txm == 3 || txm == 4 || txm == 8 || txm == 9) ? 1u : 0u);
+    const uint16_t *tab = tabs + (size_t)combo * 3 * K;
+    const uint32_t Nnn = nnn[combo], E = g.e_len[a];
+    const int8_t  *e = g.e_base + (size_t)g.e_off[a] * 64;
+    int8_t        *db = d_soft + (size_t)cb * 3 * D;
+    for (uint32_t t = threadIdx.x; t < 3 * D; t += blockDim.x) {
+        const uint32_t i = t / 3;
+        const int      x = (int)(t - 3 * i);
+        uint32_t k = 0xFFFFu; // rank of d[i*3+x] in the order e is consumed; 0xFFFF: never filled
+        if (i < K) k = tab[(size_t)x * K + i];
+        else {
+            const RmGeom  &rm = rm_s;
+            const uint32_t p = rm.pos(i, x);
+            if (p < rm.N_cb) { const uint32_t c = rm.cnt(p); k = (p >= rm.k0m) ? c - rm.cnt_k0 : rm.Nnn - rm.cnt_k0 + c; }
+        }
+        int v = 0;
+        if (k != 0xFFFFu)
+            for (; k < E; k += Nnn) v += e[k];
+        db[t] = (int8_t)max(-127, min(127, v));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_crc_finish(const uint8_t *__restrict__ c_bits, uint32_t K, uint32_t n_cb, GroupDesc g)
+{
+    __shared__ uint32_t red[4];
+    const uint32_t cb = blockIdx.x, alloc = g.cb_alloc[cb], tbs = g.allocs[alloc].tbs, F = K - tbs - 24;
+    const uint8_t *c = c_bits + (size_t)cb * K;
+    uint8_t       *o = g.out_bits + (size_t)alloc * g.out_stride;
+    uint32_t crc = 0;
+    for (uint32_t j = F + threadIdx.x; j < K; j += blockDim.x) {
+        const uint32_t b = c[j] & 1u;
+        crc ^= b ? g.crc_tab[K - 1 - j] : 0u; // bit j weighs x^(K-1-j) mod gCRC24A; the check is "XOR of the weights == 0"
+        if (j < F + tbs) o[j - F] = (uint8_t)b;
+    }
+    for (int sft = 32; sft > 0; sft >>= 1) crc ^= __shfl_xor(crc, sft);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = crc;
+    __syncthreads();
+    if (threadIdx.x == 0) g.status[alloc] = ((red[0] ^ red[1] ^ red[2] ^ red[3]) == 0) ? 0 : 2;
+}
+
 } // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -927,15 +981,9 @@ static int turbo_ref_batch(mi_lte_ctx *ctx, const T *d_soft, uint32_t K, uint32_
     return turbo_ref_run<SrcDirect<T>, false>(ctx, src, K, n_cb, d_c_bits, none);
 }
 
-// used by the PDSCH chain (chain.hip): decode the code blocks of one size K straight from the
-// demodulator's soft bits
-int mi_turbo_ref_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_pdsch_alloc *d_allocs,
-                       const uint32_t *d_cb_alloc, const int8_t *d_e, const uint32_t *d_e_off, const uint32_t *d_e_len,
-                       uint8_t *d_out_bits, uint32_t out_stride, int32_t *d_status, uint32_t e_max_bytes, bool ul)
+// per-K rank tables of the fused rate un-matching, built on first use and cached in the context
+static int rm_rank_tables(mi_lte_ctx *ctx, uint32_t K, RmTables *out)
 {
-    int rc = mi_ctx_crc_table(ctx);
-    if (rc != MI_LTE_OK) return rc;
-    GroupDesc gd{d_allocs, d_cb_alloc, d_e, d_e_off, d_e_len, d_out_bits, out_stride, d_status, ctx->d_crc_tab, ul ? 1u : 0u};
     auto it = ctx->rm_tables.find(K);
     if (it == ctx->rm_tables.end()) {
         RmTables t;
@@ -947,14 +995,49 @@ int mi_turbo_ref_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_
         MI_HIP_CHECK(ctx, hipGetLastError());
         it = ctx->rm_tables.emplace(K, t).first;
     }
+    *out = it->second;
+    return MI_LTE_OK;
+}
+
+// used by the PDSCH chain (chain.hip): decode the code blocks of one size K straight from the
+// demodulator's soft bits
+int mi_turbo_ref_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_pdsch_alloc *d_allocs,
+                       const uint32_t *d_cb_alloc, const int8_t *d_e, const uint32_t *d_e_off, const uint32_t *d_e_len,
+                       uint8_t *d_out_bits, uint32_t out_stride, int32_t *d_status, uint32_t e_max_bytes, bool ul)
+{
+    int rc = mi_ctx_crc_table(ctx);
+    if (rc != MI_LTE_OK) return rc;
+    GroupDesc gd{d_allocs, d_cb_alloc, d_e, d_e_off, d_e_len, d_out_bits, out_stride, d_status, ctx->d_crc_tab, ul ? 1u : 0u};
+    RmTables rt;
+    rc = rm_rank_tables(ctx, K, &rt);
+    if (rc != MI_LTE_OK) return rc;
     SrcRateUnmatch src;
     src.g    = gd;
-    src.tabs = it->second.d_tabs;
-    src.nnn  = it->second.d_nnn;
+    src.tabs = rt.d_tabs;
+    src.nnn  = rt.d_nnn;
     // stage e in LDS when the largest allocation of the group fits next to the block's own arrays
     const uint32_t cap = (e_max_bytes + 63u) & ~63u;
     src.e_cap          = (PREP_TAB_BYTES + kpad64(K) + cap <= 48 * 1024) ? cap : 0;
     return turbo_ref_run<SrcRateUnmatch, true>(ctx, src, K, n_cb, nullptr, gd, src.e_cap);
+}
+
+int mi_turbo_bcjr_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_pdsch_alloc *d_allocs, const uint32_t *d_cb_alloc, const int8_t *d_e,
+                        const uint32_t *d_e_off, const uint32_t *d_e_len, uint8_t *d_out_bits, uint32_t out_stride, int32_t *d_status, bool ul,
+                        int8_t *d_soft, uint8_t *d_c_bits, uint32_t n_iter, int qpp_spec)
+{
+    int rc = mi_ctx_crc_table(ctx);
+    if (rc != MI_LTE_OK) return rc;
+    GroupDesc gd{d_allocs, d_cb_alloc, d_e, d_e_off, d_e_len, d_out_bits, out_stride, d_status, ctx->d_crc_tab, ul ? 1u : 0u};
+    RmTables  t;
+    rc = rm_rank_tables(ctx, K, &t);
+    if (rc != MI_LTE_OK) return rc;
+    MI_LAUNCH(ctx, "k_rm_to_i8", k_rm_to_i8, dim3(n_cb), dim3(256), 0, gd, K, n_cb, (const uint16_t *)t.d_tabs, (const uint32_t *)t.d_nnn, d_soft);
+    MI_HIP_CHECK(ctx, hipGetLastError());
+    rc = mi_turbo_bcjr_batch(ctx, d_soft, K, n_cb, n_iter, qpp_spec, d_c_bits);
+    if (rc != MI_LTE_OK) return rc;
+    MI_LAUNCH(ctx, "k_crc_finish", k_crc_finish, dim3(n_cb), dim3(256), 0, (const uint8_t *)d_c_bits, K, n_cb, gd);
+    MI_HIP_CHECK(ctx, hipGetLastError());
+    return MI_LTE_OK;
 }
 
 extern "C" int mi_lte_turbo_decode_batch(mi_lte_ctx *ctx, const void *d_soft, mi_lte_soft_type soft_type, uint32_t K,

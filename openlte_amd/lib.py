@@ -111,6 +111,7 @@ def load_library():
     L.mi_lte_dl_frontend_batch.argtypes = [vp, C.POINTER(DlCfg), vp, vp, vp, vp, vp, u32, vp]
     L.mi_lte_pdsch_plan_create.argtypes = [vp, C.POINTER(DlCfg), u32, vp, u32, C.POINTER(vp)]
     L.mi_lte_pdsch_plan_destroy.argtypes = [vp, vp]
+    L.mi_lte_pdsch_plan_set_decoder.argtypes = [vp, u32, u32, C.c_int]
     L.mi_lte_pdsch_plan_out_stride.argtypes = [vp]
     L.mi_lte_pdsch_plan_out_stride.restype = u32
     L.mi_lte_pdsch_decode_run.argtypes = [vp, vp, vp, vp, vp, vp, vp]
@@ -197,6 +198,10 @@ class PdschPlan:
         self.h = h
         self.out_stride = ctx.L.mi_lte_pdsch_plan_out_stride(h)
         self.tbs = [a.tbs for a in allocs]
+
+    def set_decoder(self, mode, n_iter=8, qpp_spec=0):
+        """TURBO_REF (default, the reference's decoder) or TURBO_BCJR (max-log-MAP, n_iter iterations)."""
+        self.ctx._check(self.ctx.L.mi_lte_pdsch_plan_set_decoder(self.h, mode, n_iter, qpp_spec))
 
     def run_dev(self, d_subframes, d_sf, d_cell, d_out, d_status):
         self.ctx._check(self.ctx.L.mi_lte_pdsch_decode_run(self.ctx.h, self.h, d_subframes.ptr, d_sf.ptr, d_cell.ptr,

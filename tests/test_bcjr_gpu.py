@@ -80,3 +80,45 @@ def test_bcjr_rejects_float_input(ctx):
     import openlte_amd as m
     with pytest.raises(m.MiLteError):
         ctx.turbo_decode(np.zeros((1, 3 * 44), np.float32), 40, mode=m.TURBO_BCJR)
+
+
+@pytest.mark.parametrize("snr", [30.0, 9.0])
+def test_pdsch_chain_in_bcjr_mode(ctx, port, snr):
+    """mi_lte_pdsch_plan_set_decoder(BCJR): the full chain with the max-log-MAP decoder.  Checker = the pieces composed on the CPU:
+    the allocation's soft bits (already pinned to the oracle by the REF-mode tests) -> the restated rate un-matching -> saturation
+    to int8, NULL -> 0 -> the plain-C model of the decoder -> filler removal + CRC24A.  Bits and verdicts must be equal."""
+    import ctypes as C
+    import openlte_amd as m
+    from openlte_amd import synth
+    cfg = m.DlCfg(2048, 100, 1, 0)
+    sfs, cells = [1, 6], [17, 404]
+    allocs = []
+    for u in range(2):
+        allocs += td.w4_allocs(u)
+    iq, tx = synth.dl_units(cfg, sfs, cells, allocs, 9, snr_db=snr, max_delay=4, seed=321)
+    got = ctx.dl_frontend(cfg, iq.reshape(-1, 2), np.arange(2) * iq.shape[1], sfs, cells)
+    d_sub = ctx.to_device(np.ascontiguousarray(got, np.float32))
+    plan = ctx.pdsch_plan(cfg, 2, allocs)
+    plan.set_decoder(m.TURBO_BCJR, 6, 0)
+    st, bits = plan.run(d_sub, sfs, cells)
+    n_ok = 0
+    for a, al in enumerate(allocs):
+        e = plan.soft_bits(a).astype(np.float32)
+        K = al.tbs + 24
+        d = np.zeros(3 * (K + 4), np.float32)
+        n = port.lo_rate_unmatch_turbo(np.ascontiguousarray(e), len(e), K + 4, 1, al.tx_mode, 250368, 8, 0, al.rv_idx, d)
+        assert n == 3 * (K + 4)
+        soft = np.where(d == 10000.0, 0.0, np.clip(d, -127, 127)).astype(np.int16)
+        c = np.zeros(K, np.uint8)
+        port.lo_turbo_decode_bcjr(soft, K, 6, 0, c)
+        p = np.zeros(24, np.uint8)
+        port.lo_crc24a(np.ascontiguousarray(c[:al.tbs]), al.tbs, p)
+        ok = bool((p == c[al.tbs:]).all())
+        assert (st[a] == 0) == ok, a
+        assert (bits[a] == c[:al.tbs]).all(), a
+        if ok:
+            n_ok += 1
+            assert (bits[a] == tx[al.unit, a % 9, :al.tbs]).all()
+    assert n_ok == len(allocs) if snr >= 30 else n_ok > 0
+    plan.close()
+    d_sub.free()

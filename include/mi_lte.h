@@ -283,6 +283,26 @@ int      mi_lte_prach_detect_run(mi_lte_ctx *ctx, mi_lte_prach_plan *plan, const
                                  const uint64_t *d_occ_start, uint32_t n_occ, uint32_t *h_N_det_pre, uint32_t *h_det_pre,
                                  uint32_t *h_det_ta);
 
+/* ---------------------------------------------------------------- PUCCH formats 1 / 1a / 1b
+ * mi_lte_pucch_decode_run replaces liblte_phy_pucch_format_1_1a_1b_channel_decode() (liblte/hdr/liblte_phy.h:775-782,
+ * implementation liblte/src/liblte_phy.cc:2961-3146 with get_ulcch_ce :13799-13868) for a batch of PUCCH resources over UL device
+ * subframes (mi_lte_ul_frontend_batch) -- the fourth receive call of the eNodeB's radio thread (LTE_fdd_enb_phy.cc:867).
+ * The sequences are the caller's, i.e. what liblte_phy_ul_init left in LIBLTE_PHY_STRUCT for (subframe N, resource n = N_1_p_pucch);
+ * per resource h_tables holds MI_LTE_PUCCH_TAB_FLOATS floats:
+ *     pucch_dmrs_0_re[N][n][36] pucch_dmrs_0_im[..][36] pucch_dmrs_1_re[..][36] pucch_dmrs_1_im[..][36]
+ *     r_re[2][4][12] r_im[2][4][12]   = pucch_r_u_v_alpha_p_re/_im[N][n][m'][symbol 0, 1, 5, 6][12]
+ *     sw_re[2][4]    sw_im[2][4]      = s_ns(m') * W_5_4_1_2[pucch_n_oc_p[N][n][m']][i]   (s_ns = 1 or (cos(pi/2), sin(pi/2)), :3058-3068)
+ * Outputs per resource: h_bits[2r], h_bits[2r+1], h_n_bits (1 for formats 1 / 1a, 2 for 1b), h_rc = 0 (LIBLTE_SUCCESS) or 1
+ * (LIBLTE_ERROR_INVALID_INPUTS: soft decision <= 0.5, the reference's failure value).  N_ant = 1 like the reference. */
+#define MI_LTE_PUCCH_TAB_FLOATS 352
+typedef struct {
+    uint32_t unit;         /* index into the batch of UL device subframes */
+    uint32_t format;       /* 0 = format 1, 1 = 1a, 2 = 1b (LIBLTE_PHY_PUCCH_FORMAT_ENUM) */
+    uint32_t N_1_p_pucch;
+} mi_lte_pucch_res;
+int mi_lte_pucch_decode_run(mi_lte_ctx *ctx, uint32_t N_rb_ul, uint32_t N_ant, const float *d_subframes, const mi_lte_pucch_res *h_res,
+                            const float *h_tables, uint32_t n_res, uint8_t *h_bits, uint32_t *h_n_bits, uint32_t *h_rc);
+
 /* ---------------------------------------------------------------- PCFICH + PDCCH (common search space)
  * mi_lte_pdcch_plan_* / mi_lte_pdcch_decode_run replace liblte_phy_pdcch_channel_decode()
  * (liblte/hdr/liblte_phy.h:1012-1020, implementation liblte/src/liblte_phy.cc:4519-5135) for a batch of device
@@ -403,6 +423,10 @@ int mi_lte_pdcch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const fl
 int mi_lte_bch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const float *h_rx_symb_re, const float *h_rx_symb_im,
                                    const float *h_rx_ce_re /*[4][16][1200]*/, const float *h_rx_ce_im, uint32_t N_id_cell, uint8_t *N_ant,
                                    uint8_t *h_out_bits, uint32_t *N_out_bits, uint8_t *offset);
+/* liblte_phy_pucch_format_1_1a_1b_channel_decode: 0 or 1 (the reference's failure value) with the bit(s) and their count written
+ * in both cases, as the reference does; h_tables as for mi_lte_pucch_decode_run */
+int mi_lte_pucch_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_ul, const float *h_rx_symb_re, const float *h_rx_symb_im, uint32_t format,
+                             uint32_t N_ant, uint32_t N_1_p_pucch, const float *h_tables, uint8_t *h_out_bits, uint32_t *N_out_bits);
 /* the three synchronisation searches on host sample arrays (they read exactly as far as the reference does); find_sss
  * returns 1 (LIBLTE_ERROR_INVALID_INPUTS, the reference's value) when no SSS clears the threshold */
 int mi_lte_dl_find_coarse_timing_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_dl, const float *h_i_samps, const float *h_q_samps,

@@ -161,6 +161,30 @@ int mi_lte_bch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const floa
     return 0;
 }
 
+// liblte_phy_pucch_format_1_1a_1b_channel_decode (liblte_phy.cc:2961-3146); the sequences are the caller's (mi_lte.h)
+int mi_lte_pucch_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_ul, const float *h_symb_re, const float *h_symb_im, uint32_t format, uint32_t N_ant,
+                             uint32_t N_1_p_pucch, const float *h_tables, uint8_t *h_out_bits, uint32_t *N_out_bits)
+{
+    if (!ctx) return MI_LTE_ERR_INVALID_ARG;
+    if (!h_symb_re || !h_symb_im || format > 2 || !h_tables || !h_out_bits || !N_out_bits) return 1;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    DevBuf d_sub;
+    const size_t row = 16 * 1200;
+    if (d_sub.alloc(mi_lte_ul_subframe_floats() * 4)) return MI_LTE_ERR_NOMEM;
+    float *s = (float *)d_sub.p;
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(s, h_symb_re, 14 * 1200 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(s + row, h_symb_im, 14 * 1200 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    mi_lte_pucch_res r = {0, format, N_1_p_pucch};
+    uint8_t  bits[2] = {0, 0};
+    uint32_t nb = 0, rc2 = 1;
+    int rc = mi_lte_pucch_decode_run(ctx, N_rb_ul, N_ant, s, &r, h_tables, 1, bits, &nb, &rc2);
+    if (rc != MI_LTE_OK) return rc == MI_LTE_ERR_INVALID_ARG ? 1 : rc;
+    h_out_bits[0] = bits[0];
+    if (nb == 2) h_out_bits[1] = bits[1];
+    *N_out_bits = nb;
+    return (int)rc2;
+}
+
 // ---- initial synchronisation (liblte_phy.cc:5697-5852, :5306-5510, :5578-5687): stage n samples of each array, run the device search
 namespace {
 int stage_iq(mi_lte_ctx *ctx, const float *h_i, const float *h_q, size_t n, DevBuf &d_i, DevBuf &d_q)

@@ -168,6 +168,87 @@ __global__ __launch_bounds__(256) void k_pusch_demod(const float *__restrict__ s
     }
 }
 
+// ---- PUCCH formats 1 / 1a / 1b (liblte_phy_pucch_format_1_1a_1b_channel_decode, liblte_phy.cc:2961-3146) -----------------------
+// One wavefront per PUCCH resource: the resource's PRB pair (N_1_p in slot 0, N_rb_ul - N_1_p - 1 in slot 1), a channel estimate
+// per slot from its three reference symbols (get_ulcch_ce :13799-13868: mean magnitude, the FIRST symbol's phase), one-tap
+// equalisation, and the coherent sum over 2 x 4 x 12 elements of z / (s_ns w(i) r_u,v(n)) -- summed in the reference's order by one
+// lane, divided by 95 as the reference does (its loop index after the last element, not the count) -- then the reference's decision.
+// The sequences are the caller's (what liblte_phy_ul_init left in LIBLTE_PHY_STRUCT): per resource 352 floats, see mi_lte.h.
+struct PucchRes { uint32_t unit, format, N_1_p; };
+constexpr uint32_t PUCCH_TAB_FLOATS = 4 * 36 + 2 * 96 + 16;
+
+__device__ __forceinline__ float pucch_soft(float rx_re, float rx_im, float exp_re, float exp_im)
+{
+    const float d_re = rx_re - exp_re, d_im = rx_im - exp_im;
+    float dist = sqrtf(d_re * d_re + d_im * d_im); // (C++ overload resolution in the reference: sqrt(float) is the float function)
+    const float cap = 1.0f - (1.0f / 120);
+    if (dist >= cap) dist = cap;
+    return 1.0f - dist;
+}
+
+__global__ __launch_bounds__(64) void k_pucch_decode(const float *__restrict__ subframes, uint32_t sf_stride, uint32_t N_rb_ul, uint32_t N_ant,
+                                                     const PucchRes *__restrict__ res, const float *__restrict__ tabs, uint8_t *__restrict__ out /*[n][4]*/)
+{
+    __shared__ float c_re[2][12], c_im[2][12], t_re[96], t_im[96];
+    const uint32_t r = blockIdx.x, ln = threadIdx.x;
+    const PucchRes pr = res[r];
+    const float *base = subframes + (size_t)pr.unit * sf_stride, *y_re = base, *y_im = base + 16 * N_SC_MAX;
+    const float *tb = tabs + (size_t)r * PUCCH_TAB_FLOATS;
+    const float *dm_re[2] = {tb, tb + 72}, *dm_im[2] = {tb + 36, tb + 108};
+    const float *ruv_re = tb + 144, *ruv_im = tb + 240, *sw_re = tb + 336, *sw_im = tb + 344;
+    const uint32_t prb[2] = {pr.N_1_p, N_rb_ul - pr.N_1_p - 1};
+    if (ln < 24) { // (slot, sub-carrier): channel estimate from the three reference symbols 2, 3, 4 (9, 10, 11)
+        const uint32_t s = ln / 12, j = ln % 12;
+        float ave_mag = 0, ang0 = 0;
+        for (uint32_t i = 0; i < 3; i++) {
+            const uint32_t L = 7 * s + 2 + i, k = prb[s] * 12 + j, idx = i * 12 + j;
+            const float cr = y_re[L * N_SC_MAX + k], ci = y_im[L * N_SC_MAX + k], dr = dm_re[s][idx], di = dm_im[s][idx];
+            const float denom = dr * dr + di * di;
+            const float tr = (1 / denom) * (cr * dr + ci * di), ti = (1 / denom) * (ci * dr - cr * di);
+            ave_mag += sqrtf(tr * tr + ti * ti) / 3; // (:13842; float sqrt / int)
+            if (i == 0) ang0 = atan2f(ti, tr);
+        }
+        c_re[s][j] = ave_mag * cosf(ang0);
+        c_im[s][j] = ave_mag * sinf(ang0);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t idx = ln; idx < 96; idx += 64) { // element (slot m', data symbol i, sub-carrier j)
+        const uint32_t mp = idx / 48, i = (idx % 48) / 12, j = idx % 12, L = 7 * mp + (i < 2 ? i : i + 3), k = prb[mp] * 12 + j;
+        const float zr = y_re[L * N_SC_MAX + k], zi = y_im[L * N_SC_MAX + k], hr = c_re[mp][j], hi = c_im[mp][j];
+        const float hn = hr * hr + hi * hi;
+        const float xr = (zr * hr + zi * hi) / hn, xi = (zi * hr - zr * hi) / hn; // pre_decoder_and_matched_filter_ul (:6727-6732)
+        const float swr = sw_re[mp * 4 + i], swi = sw_im[mp * 4 + i], rr = ruv_re[idx], ri = ruv_im[idx];
+        const float pr_ = swr * rr - swi * ri, pi_ = swr * ri + swi * rr, denom = pr_ * pr_ + pi_ * pi_;
+        t_re[idx] = (1 / denom) * (xr * pr_ + xi * pi_);
+        t_im[idx] = (1 / denom) * (-xr * pi_ + xi * pr_);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (ln == 0) {
+        float d_re = 0, d_im = 0;
+        for (uint32_t idx = 0; idx < 96; idx++) { d_re += t_re[idx]; d_im += t_im[idx]; }
+        d_re /= 95u; // the reference divides by its last index (:3097-3098)
+        d_im /= 95u;
+        d_re *= sqrt((double)N_ant);
+        d_im *= sqrt((double)N_ant);
+        uint8_t b0 = 0, b1 = 0, nb = 1;
+        float   sd;
+        if (pr.format <= 1) {
+            if (d_re < 0) { sd = pucch_soft(d_re, d_im, -1, 0); b0 = 1; }
+            else          { sd = pucch_soft(d_re, d_im, 1, 0); b0 = 0; }
+        } else {
+            const float ang = atan2f(d_im, d_re);
+            nb = 2;
+            if (ang >= M_PI / 4 && ang < 3 * M_PI / 4)        { sd = pucch_soft(d_re, d_im, 0, 1); b0 = 1; b1 = 0; }
+            else if (ang >= -M_PI / 4 && ang < M_PI / 4)      { sd = pucch_soft(d_re, d_im, 1, 0); b0 = 0; b1 = 0; }
+            else if (ang >= -3 * M_PI / 4 && ang < -M_PI / 4) { sd = pucch_soft(d_re, d_im, 0, -1); b0 = 0; b1 = 1; }
+            else                                              { sd = pucch_soft(d_re, d_im, -1, 0); b0 = 1; b1 = 1; }
+        }
+        out[4 * r] = b0; out[4 * r + 1] = b1; out[4 * r + 2] = nb; out[4 * r + 3] = sd > 0.5f ? 0 : 1; // LIBLTE_SUCCESS / LIBLTE_ERROR_INVALID_INPUTS
+    }
+}
+
 } // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -336,6 +417,35 @@ int mi_lte_pusch_decode_run(mi_lte_ctx *ctx, mi_lte_pusch_plan *pl, const float 
         if (rc != MI_LTE_OK) return rc;
     }
     ctx->last_kernels = "k_pusch_demod:1,k_turbo_prep,k_turbo_siso,k_turbo_perm,k_turbo_vote per block size";
+    return MI_LTE_OK;
+}
+
+// liblte_phy_pucch_format_1_1a_1b_channel_decode for a batch of PUCCH resources over UL device subframes
+int mi_lte_pucch_decode_run(mi_lte_ctx *ctx, uint32_t N_rb_ul, uint32_t N_ant, const float *d_subframes, const mi_lte_pucch_res *h_res,
+                            const float *h_tables, uint32_t n_res, uint8_t *h_bits /*[n_res][2]*/, uint32_t *h_n_bits, uint32_t *h_rc)
+{
+    if (!ctx || !d_subframes || !h_res || !h_tables || n_res == 0 || !h_bits || !h_n_bits || !h_rc || N_rb_ul < 6 || N_rb_ul > 100 || N_ant != 1)
+        return MI_LTE_ERR_INVALID_ARG;
+    for (uint32_t r = 0; r < n_res; r++)
+        if (h_res[r].format > 2 || h_res[r].N_1_p_pucch >= N_rb_ul) return MI_LTE_ERR_INVALID_ARG;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t b_res = sizeof(PucchRes) * (size_t)n_res, b_tab = sizeof(float) * PUCCH_TAB_FLOATS * (size_t)n_res, b_out = 4 * (size_t)n_res;
+    const size_t o_tab = (b_res + 255) & ~(size_t)255, o_out = (o_tab + b_tab + 255) & ~(size_t)255;
+    int rc = mi_ctx_reserve_scratch(ctx, o_out + b_out);
+    if (rc != MI_LTE_OK) return rc;
+    char *base = (char *)ctx->scratch;
+    std::vector<PucchRes> res(n_res);
+    for (uint32_t r = 0; r < n_res; r++) res[r] = PucchRes{h_res[r].unit, h_res[r].format, h_res[r].N_1_p_pucch};
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(base, res.data(), b_res, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(base + o_tab, h_tables, b_tab, hipMemcpyHostToDevice, ctx->stream));
+    MI_LAUNCH(ctx, "k_pucch_decode", k_pucch_decode, dim3(n_res), dim3(64), 0, d_subframes, (uint32_t)mi_lte_ul_subframe_floats(), N_rb_ul, N_ant,
+              (const PucchRes *)base, (const float *)(base + o_tab), (uint8_t *)(base + o_out));
+    MI_HIP_CHECK(ctx, hipGetLastError());
+    std::vector<uint8_t> o(b_out);
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(o.data(), base + o_out, b_out, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t r = 0; r < n_res; r++) { h_bits[2 * r] = o[4 * r]; h_bits[2 * r + 1] = o[4 * r + 1]; h_n_bits[r] = o[4 * r + 2]; h_rc[r] = o[4 * r + 3]; }
+    ctx->last_kernels = "k_pucch_decode:1";
     return MI_LTE_OK;
 }
 

@@ -47,6 +47,11 @@ def make_alloc(unit, mod_type, tbs, prbs, rnti, rv_idx=0, tx_mode=1, prbs_slot1=
     return a
 
 
+class PucchRes(C.Structure):
+    """mi_lte_pucch_res"""
+    _fields_ = [("unit", C.c_uint32), ("format", C.c_uint32), ("N_1_p_pucch", C.c_uint32)]
+
+
 class PdcchDci(C.Structure):
     """mi_lte_pdcch_dci"""
     _fields_ = [(n, C.c_uint32) for n in ("rnti", "format", "candidate", "n_bits", "payload", "mcs", "alloc_valid", "reserved")] + [("alloc", PdschAlloc)]
@@ -120,6 +125,7 @@ def load_library():
     L.mi_lte_ul_frontend_batch.argtypes = [vp, C.POINTER(DlCfg), vp, vp, vp, u32, vp]
     f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
     u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+    u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
     L.mi_lte_ul_dmrs_pusch.argtypes = [C.POINTER(UlCfg), u32, u32, u32, f32p, f32p, f32p, f32p]
     L.mi_lte_pusch_plan_create.argtypes = [vp, C.POINTER(DlCfg), C.POINTER(UlCfg), u32p, u32p, u32, vp, u32, C.POINTER(vp)]
     L.mi_lte_pusch_plan_destroy.argtypes = [vp, vp]
@@ -138,6 +144,7 @@ def load_library():
     L.mi_lte_pdcch_plan_create.argtypes = [vp, C.POINTER(DlCfg), C.c_float, u32, u32, u32p, u32, C.POINTER(vp)]
     L.mi_lte_pdcch_plan_destroy.argtypes = [vp, vp]
     L.mi_lte_pdcch_decode_run.argtypes = [vp, vp, vp, vp, vp, u32, u32p, u32p, u32p, u32p, C.POINTER(PdcchDci)]
+    L.mi_lte_pucch_decode_run.argtypes = [vp, u32, u32, vp, C.POINTER(PucchRes), f32p, u32, u8p, u32p, u32p]
     L.mi_lte_coarse_timing_samples.argtypes = [u32, u32]
     L.mi_lte_coarse_timing_samples.restype = C.c_size_t
     L.mi_lte_coarse_timing_run.argtypes = [vp, C.POINTER(DlCfg), vp, vp, C.c_uint64, u32, C.POINTER(CoarseTiming)]
@@ -494,6 +501,15 @@ class Context:
 
     def prach_plan(self, cfg, prach_cfg, roots_fft=None):
         return PrachPlan(self, cfg, prach_cfg, roots_fft)
+
+    def pucch_decode_dev(self, n_rb_ul, d_subframes, res, tables):
+        """res: list of (unit, format 0/1/2, N_1_p_pucch); tables float32 [n, 352] (mi_lte.h).  Returns (bits uint8 [n, 2], n_bits, rc)."""
+        n = len(res)
+        arr = (PucchRes * n)(*[PucchRes(*r) for r in res])
+        bits, nb, rc = np.zeros((n, 2), np.uint8), np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        self._check(self.L.mi_lte_pucch_decode_run(self.h, n_rb_ul, 1, d_subframes.ptr, arr, np.ascontiguousarray(tables, np.float32).reshape(-1), n,
+                                                   bits.reshape(-1), nb, rc))
+        return bits, nb, rc
 
     def coarse_timing_dev(self, cfg, d_a, d_b, n_slots, start=0):
         """CoarseTiming for samples resident in HBM (d_b None for int8 interleaved)."""

@@ -208,6 +208,11 @@ def ref():
     L.ref_find_sss.argtypes = [vp, f32p, f32p, u32, u32p, C.c_float, C.POINTER(u32), C.POINTER(u32)]
     L.ref_time_coarse_timing.argtypes = [vp, f32p, f32p, u32, u32]
     L.ref_time_coarse_timing.restype = C.c_double
+    L.ref_ul_init_pucch.argtypes = [vp, u32, u32, u32, u32, u32]
+    L.ref_pucch_decode.argtypes = [vp, vp, u32, u32, u32, u32, u8p, C.POINTER(u32)]
+    L.ref_get_pucch_tables.argtypes = [vp, u32, u32, f32p]
+    L.ref_get_n_rb_ul.argtypes = [vp]
+    L.ref_get_n_rb_ul.restype = u32
     _REF = L
     return L
 

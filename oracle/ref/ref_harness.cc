@@ -15,6 +15,7 @@
 #include <cstring>
 #include <ctime>
 #include <malloc.h>
+#include <math.h>
 
 #include "liblte_phy.h"
 
@@ -51,6 +52,8 @@ LIBLTE_ERROR_ENUM dci_1a_unpack(uint8 *in_bits, uint32 N_in_bits, LIBLTE_PHY_DCI
                                 uint32 N_rb_dl, uint8 N_ant, LIBLTE_PHY_ALLOCATION_STRUCT *alloc);
 LIBLTE_ERROR_ENUM dci_1c_unpack(uint8 *in_bits, uint32 N_in_bits, uint16 rnti, uint32 N_rb_dl, uint8 N_ant,
                                 LIBLTE_PHY_ALLOCATION_STRUCT *alloc);
+
+extern int32 W_5_4_1_2[3][4]; // liblte_phy.cc:161 (36.211 table 5.4.1-2)
 
 extern "C" {
 
@@ -490,6 +493,37 @@ double ref_time_coarse_timing(void *phy, float *i_samps, float *q_samps, uint32_
     return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
 }
 
+// ---- PUCCH formats 1 / 1a / 1b: decode, and the sequences liblte_phy_ul_init left in the struct for (subframe, resource)
+int ref_pucch_decode(void *phy, void *sf, uint32_t format, uint32_t N_id_cell, uint32_t N_ant, uint32_t N_1_p_pucch, uint8_t *out_bits, uint32_t *N_out_bits)
+{
+    uint32 n = 0;
+    int err = (int)liblte_phy_pucch_format_1_1a_1b_channel_decode((LIBLTE_PHY_STRUCT *)phy, (LIBLTE_PHY_SUBFRAME_STRUCT *)sf, (LIBLTE_PHY_PUCCH_FORMAT_ENUM)format,
+                                                                 N_id_cell, (uint8)N_ant, N_1_p_pucch, out_bits, &n);
+    *N_out_bits = n;
+    return err;
+}
+void ref_get_pucch_tables(void *vphy, uint32_t N_subfr, uint32_t n, float *t /*[352]*/)
+{
+    LIBLTE_PHY_STRUCT *p = (LIBLTE_PHY_STRUCT *)vphy;
+    memcpy(t, p->pucch_dmrs_0_re[N_subfr][n], 36 * sizeof(float));
+    memcpy(t + 36, p->pucch_dmrs_0_im[N_subfr][n], 36 * sizeof(float));
+    memcpy(t + 72, p->pucch_dmrs_1_re[N_subfr][n], 36 * sizeof(float));
+    memcpy(t + 108, p->pucch_dmrs_1_im[N_subfr][n], 36 * sizeof(float));
+    static const uint32_t symb[4] = {0, 1, 5, 6};
+    for (uint32_t m = 0; m < 2; m++) {
+        float s_re, s_im; // s_ns as the decoder computes it (liblte_phy.cc:3058-3068)
+        if ((p->pucch_n_prime_p[N_subfr][n][m] % 2) == 0) { s_re = 1; s_im = 0; }
+        else { s_re = cos(M_PI / 2); s_im = sin(M_PI / 2); }
+        for (uint32_t i = 0; i < 4; i++) {
+            memcpy(t + 144 + (m * 4 + i) * 12, p->pucch_r_u_v_alpha_p_re[N_subfr][n][m][symb[i]], 12 * sizeof(float));
+            memcpy(t + 240 + (m * 4 + i) * 12, p->pucch_r_u_v_alpha_p_im[N_subfr][n][m][symb[i]], 12 * sizeof(float));
+            t[336 + m * 4 + i] = s_re * W_5_4_1_2[p->pucch_n_oc_p[N_subfr][n][m]][i];
+            t[344 + m * 4 + i] = s_im * W_5_4_1_2[p->pucch_n_oc_p[N_subfr][n][m]][i];
+        }
+    }
+}
+uint32_t ref_get_n_rb_ul(void *phy) { return ((LIBLTE_PHY_STRUCT *)phy)->N_rb_ul; }
+
 // format 0 = 1A, 1 = 1C; the allocation starts zeroed
 int ref_dci_unpack(uint32_t format, uint8_t *bits, uint32_t n_bits, uint32_t rnti, uint32_t N_rb_dl, uint32_t N_ant, ref_alloc_t *out,
                    uint32_t *mcs, uint32_t *prb_slot1 /*[110]*/)
@@ -512,6 +546,12 @@ int ref_ul_init(void *phy, uint32_t N_id_cell, uint32_t group_assignment_pusch, 
     return (int)liblte_phy_ul_init((LIBLTE_PHY_STRUCT *)phy, (uint16)N_id_cell, 0, 0, 1, false, (uint8)group_assignment_pusch,
                                    group_hopping_enabled != 0, sequence_hopping_enabled != 0, (uint8)cyclic_shift,
                                    (uint8)cyclic_shift_dci, 0, 1);
+}
+int ref_ul_init_pucch(void *phy, uint32_t N_id_cell, uint32_t group_assignment_pusch, uint32_t group_hopping_enabled, uint32_t N_cs_an,
+                      uint32_t delta_pucch_shift)
+{
+    return (int)liblte_phy_ul_init((LIBLTE_PHY_STRUCT *)phy, (uint16)N_id_cell, 0, 0, 1, false, (uint8)group_assignment_pusch, group_hopping_enabled != 0,
+                                   false, 0, 0, (uint8)N_cs_an, (uint8)delta_pucch_shift);
 }
 int ref_ul_init_prach(void *phy, uint32_t N_id_cell, uint32_t root_seq_idx, uint32_t preamble_format, uint32_t zczc, uint32_t hs_flag)
 {

@@ -7,7 +7,8 @@
 //   dropin_ul_* <capture.bin> <N_rb_ul> <N_id_cell> <subframe> <delta_ss> <group_hop> <seq_hop> <cs> <cs_dci>
 //               then per UE: <mod> <tbs> <rnti> <first_prb> <N_prb>
 //   with PRACH_CAPTURE=<file> PRACH_CFG="root,fmt,zczc,hs,freq_offset" in the environment it also runs liblte_phy_detect_prach
-//   over that capture (one occasion starting at the file's first sample)
+//   over that capture (one occasion starting at the file's first sample); with PUCCH_DEMO=1 it also decodes four PUCCH format 1/1a/1b
+//   resources it builds itself from the sequences in the struct (liblte_phy_pucch_format_1_1a_1b_channel_decode)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -73,6 +74,45 @@ int main(int argc, char **argv)
         uint32 nd = 0, dp = 0, ta = 0;
         LIBLTE_ERROR_ENUM e = liblte_phy_detect_prach(phy, pi_s, pq_s, pr[4], &nd, &dp, &ta);
         printf("prach: err=%d N_det_pre=%u det_pre=%u det_ta=%u\n", (int)e, nd, nd ? dp : 0, nd ? ta : 0);
+    }
+    if (getenv("PUCCH_DEMO")) {
+        // PUCCH formats 1 / 1a / 1b: the reference cannot transmit them either, so a resource is built here from the sequences
+        // liblte_phy_ul_init left in the struct (36.211 5.4.1), through a fixed complex gain, and handed to the decoder
+        static LIBLTE_PHY_SUBFRAME_STRUCT ps;
+        extern int32 W_5_4_1_2[3][4];
+        const struct { LIBLTE_PHY_PUCCH_FORMAT_ENUM fmt; uint32 n1; float d_re, d_im; } tc[4] = {
+            {LIBLTE_PHY_PUCCH_FORMAT_1, 0, 1, 0}, {LIBLTE_PHY_PUCCH_FORMAT_1A, 1, -1, 0}, {LIBLTE_PHY_PUCCH_FORMAT_1B, 2, 0, 1}, {LIBLTE_PHY_PUCCH_FORMAT_1B, 1, -1, 0}};
+        for (int t = 0; t < 4; t++) {
+            memset(&ps, 0, sizeof(ps));
+            ps.num = sf_num;
+            const uint32 symb[4] = {0, 1, 5, 6}, n1 = tc[t].n1;
+            for (uint32 m = 0; m < 2; m++) {
+                const uint32 prb = m == 0 ? n1 : phy->N_rb_ul - n1 - 1;
+                const float  hr = m == 0 ? 0.8f : -0.3f, hi = m == 0 ? 0.5f : 1.1f; // per-slot channel
+                const float  s_re = (phy->pucch_n_prime_p[sf_num][n1][m] % 2) == 0 ? 1.0f : 0.0f, s_im = (phy->pucch_n_prime_p[sf_num][n1][m] % 2) == 0 ? 0.0f : 1.0f;
+                for (uint32 j = 0; j < 12; j++) {
+                    for (uint32 i = 0; i < 4; i++) {
+                        const float w = (float)W_5_4_1_2[phy->pucch_n_oc_p[sf_num][n1][m]][i];
+                        const float rr = phy->pucch_r_u_v_alpha_p_re[sf_num][n1][m][symb[i]][j], ri = phy->pucch_r_u_v_alpha_p_im[sf_num][n1][m][symb[i]][j];
+                        // x = d * s * w * r ;  y = h * x
+                        const float ar = tc[t].d_re * s_re - tc[t].d_im * s_im, ai = tc[t].d_re * s_im + tc[t].d_im * s_re;
+                        const float xr = w * (ar * rr - ai * ri), xi = w * (ar * ri + ai * rr);
+                        ps.rx_symb_re[7 * m + symb[i]][prb * 12 + j] = hr * xr - hi * xi;
+                        ps.rx_symb_im[7 * m + symb[i]][prb * 12 + j] = hr * xi + hi * xr;
+                    }
+                    for (uint32 i = 0; i < 3; i++) {
+                        const float dr = m == 0 ? phy->pucch_dmrs_0_re[sf_num][n1][i * 12 + j] : phy->pucch_dmrs_1_re[sf_num][n1][i * 12 + j];
+                        const float di = m == 0 ? phy->pucch_dmrs_0_im[sf_num][n1][i * 12 + j] : phy->pucch_dmrs_1_im[sf_num][n1][i * 12 + j];
+                        ps.rx_symb_re[7 * m + 2 + i][prb * 12 + j] = hr * dr - hi * di;
+                        ps.rx_symb_im[7 * m + 2 + i][prb * 12 + j] = hr * di + hi * dr;
+                    }
+                }
+            }
+            uint8  b[4] = {0, 0, 0, 0};
+            uint32 nb = 0;
+            LIBLTE_ERROR_ENUM e = liblte_phy_pucch_format_1_1a_1b_channel_decode(phy, &ps, tc[t].fmt, cell, 1, n1, b, &nb);
+            printf("pucch format %s resource %u: err=%d N_out_bits=%u bits=%u%u\n", liblte_phy_pucch_format_text[tc[t].fmt], n1, (int)e, nb, b[0], nb == 2 ? b[1] : 0);
+        }
     }
     liblte_phy_cleanup(phy);
     return 0;

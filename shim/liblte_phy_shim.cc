@@ -11,6 +11,7 @@
 //     liblte_phy_detect_prach             liblte_phy.h:862-868     (impl. liblte_phy.cc:3299-3479)
 //     liblte_phy_pdcch_channel_decode     liblte_phy.h:1012-1020   (impl. liblte_phy.cc:4519-5135)
 //     liblte_phy_bch_channel_decode       liblte_phy.h:947-953     (impl. liblte_phy.cc:3968-4105)
+//     liblte_phy_pucch_format_1_1a_1b_channel_decode   liblte_phy.h:775-782 (impl. liblte_phy.cc:2961-3146)
 //     liblte_phy_dl_find_coarse_timing_and_freq_offset  liblte_phy.h:1134-1138 (impl. liblte_phy.cc:5697-5852)
 //     liblte_phy_find_pss_and_fine_timing liblte_phy.h:1068-1075   (impl. liblte_phy.cc:5306-5510)
 //     liblte_phy_find_sss                 liblte_phy.h:1106-1113   (impl. liblte_phy.cc:5578-5687)
@@ -23,6 +24,7 @@
 //
 // LIBLTE_PHY_STRUCT stays byte-identical (callers read its fields directly); the GPU
 // context lives in a side table keyed by the struct pointer.
+#include <cmath>
 #include <map>
 #include <mutex>
 
@@ -247,5 +249,45 @@ LIBLTE_ERROR_ENUM liblte_phy_find_sss(LIBLTE_PHY_STRUCT *phy_struct, float *i_sa
     mi_lte_ctx *c = ctx_for(phy_struct);
     if (!c) return LIBLTE_ERROR_INVALID_INPUTS;
     int rc = mi_lte_find_sss_host(c, phy_struct->N_samps_per_symb, phy_struct->N_rb_dl, i_samps, q_samps, N_id_2, symb_starts, pss_thresh, N_id_1, frame_start_idx);
+    return rc == 0 ? LIBLTE_SUCCESS : LIBLTE_ERROR_INVALID_INPUTS;
+}
+
+// ---- PUCCH formats 1 / 1a / 1b (LTE_fdd_enb_phy.cc:867)
+
+extern int32 W_5_4_1_2[3][4]; // the reference's orthogonal-sequence table (liblte_phy.cc:161), still its own object
+
+LIBLTE_ERROR_ENUM liblte_phy_pucch_format_1_1a_1b_channel_decode(LIBLTE_PHY_STRUCT *phy_struct, LIBLTE_PHY_SUBFRAME_STRUCT *subframe,
+                                                                 LIBLTE_PHY_PUCCH_FORMAT_ENUM format, uint32 N_id_cell, uint8 N_ant, uint32 N_1_p_pucch,
+                                                                 uint8 *out_bits, uint32 *N_out_bits)
+{
+    (void)N_id_cell;
+    if (phy_struct == NULL || subframe == NULL || !(format == LIBLTE_PHY_PUCCH_FORMAT_1 || format == LIBLTE_PHY_PUCCH_FORMAT_1A || format == LIBLTE_PHY_PUCCH_FORMAT_1B) ||
+        out_bits == NULL || N_out_bits == NULL || subframe->num > 9 || N_1_p_pucch >= LIBLTE_PHY_N_RB_UL_MAX / 2 || N_ant != 1)
+        return LIBLTE_ERROR_INVALID_INPUTS;
+    mi_lte_ctx *c = ctx_for(phy_struct);
+    if (!c) return LIBLTE_ERROR_INVALID_INPUTS;
+    // the sequences liblte_phy_ul_init (still the reference's code) left in the struct for this (subframe, resource)
+    static const uint32 symb[4] = {0, 1, 5, 6};
+    const uint32 N = subframe->num, n = N_1_p_pucch;
+    float        t[MI_LTE_PUCCH_TAB_FLOATS];
+    memcpy(t, phy_struct->pucch_dmrs_0_re[N][n], 36 * sizeof(float));
+    memcpy(t + 36, phy_struct->pucch_dmrs_0_im[N][n], 36 * sizeof(float));
+    memcpy(t + 72, phy_struct->pucch_dmrs_1_re[N][n], 36 * sizeof(float));
+    memcpy(t + 108, phy_struct->pucch_dmrs_1_im[N][n], 36 * sizeof(float));
+    for (uint32 m = 0; m < 2; m++) {
+        float s_re, s_im; // s(n_s), liblte_phy.cc:3058-3068
+        if ((phy_struct->pucch_n_prime_p[N][n][m] % 2) == 0) { s_re = 1; s_im = 0; }
+        else { s_re = cos(M_PI / 2); s_im = sin(M_PI / 2); }
+        for (uint32 i = 0; i < 4; i++) {
+            memcpy(t + 144 + (m * 4 + i) * 12, phy_struct->pucch_r_u_v_alpha_p_re[N][n][m][symb[i]], 12 * sizeof(float));
+            memcpy(t + 240 + (m * 4 + i) * 12, phy_struct->pucch_r_u_v_alpha_p_im[N][n][m][symb[i]], 12 * sizeof(float));
+            t[336 + m * 4 + i] = s_re * W_5_4_1_2[phy_struct->pucch_n_oc_p[N][n][m]][i];
+            t[344 + m * 4 + i] = s_im * W_5_4_1_2[phy_struct->pucch_n_oc_p[N][n][m]][i];
+        }
+    }
+    uint32_t nb = 0;
+    int rc = mi_lte_pucch_decode_host(c, phy_struct->N_rb_ul, &subframe->rx_symb_re[0][0], &subframe->rx_symb_im[0][0], (uint32_t)format, N_ant, N_1_p_pucch, t,
+                                      out_bits, &nb);
+    if (rc == 0 || rc == 1) *N_out_bits = nb;
     return rc == 0 ? LIBLTE_SUCCESS : LIBLTE_ERROR_INVALID_INPUTS;
 }

@@ -103,11 +103,11 @@ def _ul_demo_env(tmp_path):
     iq = synth.prach_occasions(cfg, pc, [37], [80], snr_db=5.0, seed=8)
     path = os.path.join(str(tmp_path), "prach.bin")
     iq[0].tofile(path)
-    return dict(os.environ, PRACH_CAPTURE=path, PRACH_CFG="5,0,12,0,3")
+    return dict(os.environ, PRACH_CAPTURE=path, PRACH_CFG="5,0,12,0,3", PUCCH_DEMO="1")
 
 
 def test_uplink_dropin_demo_matches_reference_output(tmp_path):
-    """liblte_phy_get_ul_subframe + liblte_phy_pusch_channel_decode + liblte_phy_detect_prach through the shim == the
+    """liblte_phy_get_ul_subframe + liblte_phy_pusch_channel_decode + liblte_phy_detect_prach + PUCCH 1/1a/1b through the shim == the
     unmodified reference."""
     exe = os.path.join(ROOT, "shim", "_build", "dropin_ul_gpu")
     if not os.path.exists(exe):

@@ -297,11 +297,23 @@ struct SrcRateUnmatch {
     // All first-lap loads of a unit are independent; later laps (uniform trip count) are masked.
     template <typename P, typename V> __device__ __forceinline__ void gather16(P ep, uint32_t u, int nvalid, V (&v)[3][16]) const
     {
+        // the rank words of all three streams are requested before the first is used: one L2 round trip instead of three
+        uint4 raw[3][2];
+#pragma unroll
+        for (int x = 0; x < 3; x++) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(tab + (size_t)x * K_ + 16 * (size_t)u);
+            raw[x][0] = p[0];
+            raw[x][1] = (nvalid > 8) ? p[1] : make_uint4(0, 0, 0, 0);
+        }
 #pragma unroll
         for (int x = 0; x < 3; x++) {
             uint32_t r[16];
             int      acc[16];
-            load_idx16(tab + (size_t)x * K_, u, nvalid, r);
+            {
+                const uint32_t w[8] = {raw[x][0].x, raw[x][0].y, raw[x][0].z, raw[x][0].w, raw[x][1].x, raw[x][1].y, raw[x][1].z, raw[x][1].w};
+#pragma unroll
+                for (int k = 0; k < 16; k++) r[k] = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+            }
 #pragma unroll
             for (int k = 0; k < 16; k++) { // 0xFFFF: never filled -> RX_NULL_BIT -> 0 in Step 0
                 const bool ok = k < nvalid && r[k] != 0xFFFFu && r[k] < E;

@@ -127,6 +127,25 @@ __device__ __forceinline__ void load_idx16(const uint16_t *tab, uint32_t u, int 
     for (int k = 0; k < 16; k++) idx[k] = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
 }
 
+// the same in two halves, so that the table words can be requested long before they are needed (the kernels below wait on L2
+// round trips far more than they compute)
+struct IdxRaw { uint4 lo, hi; };
+__device__ __forceinline__ IdxRaw load_idx_raw(const uint16_t *tab, uint32_t u, int nvalid, uint32_t pad = 0)
+{
+    const uint4   *p = reinterpret_cast<const uint4 *>(tab + 16 * (size_t)u);
+    const uint32_t pp = pad | (pad << 16);
+    IdxRaw r;
+    r.lo = (nvalid > 0) ? p[0] : make_uint4(pp, pp, pp, pp);
+    r.hi = (nvalid > 8) ? p[1] : make_uint4(pp, pp, pp, pp);
+    return r;
+}
+__device__ __forceinline__ void unpack_idx(const IdxRaw &r, uint32_t (&idx)[16])
+{
+    const uint32_t w[8] = {r.lo.x, r.lo.y, r.lo.z, r.lo.w, r.hi.x, r.hi.y, r.hi.z, r.hi.w};
+#pragma unroll
+    for (int k = 0; k < 16; k++) idx[k] = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+}
+
 // ---- where the soft values of a code block come from
 // (a) directly from the caller, in the reference's interleaved d[i*3+x] layout
 template <typename T> struct SrcDirect {
@@ -726,10 +745,12 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     const size_t   tile_off = (size_t)tile * Kp * 64;
     int8_t *d1 = sm, *d2 = sm + Kp, *bits = sm + 2 * Kp;
     int nval[NSLOT], s0[NSLOT][16]; // s0 = q(d0) + C1, the part of the vote that is not de-interleaved
+    IdxRaw vraw[NSLOT];
 #pragma unroll
     for (int s = 0; s < NSLOT; s++) {
         const uint32_t u = threadIdx.x + s * blockDim.x;
         nval[s] = (u < n_units) ? min(16, max(0, (int)K - 16 * (int)u)) : -1;
+        vraw[s] = load_idx_raw(inv, u < n_units ? u : 0, nval[s], K); // needed after the barrier; requested now
         if (nval[s] < 0) continue;
         int xa[19], xb[19], xc[19], x0[16], v1[16], v2[16];
         load_unit_halo(a.A1, tile_off, lane, u, xa);
@@ -768,7 +789,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         if (nval[s] <= 0) continue;
         uint32_t idx[16];
         int      b[16];
-        load_idx16(inv, u, nval[s], idx, K); // past the block end: slot K (D1 = D2 = 0 there; those bits are never used)
+        unpack_idx(vraw[s], idx); // past the block end: slot K (D1 = D2 = 0 there; those bits are never used)
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const uint32_t i = idx[k], ic = (i != 0xFFFFu) ? i : 0u; // Steps 12/13: de-interleave; a hole contributes 0

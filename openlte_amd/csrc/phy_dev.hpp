@@ -58,12 +58,21 @@ __device__ __forceinline__ void demap_symbol(float re, float im, uint32_t mod, i
         b[2] = (fabsf(re) < t10) ? 127 : -127;
         b[3] = (fabsf(im) < t10) ? 127 : -127;
     } else if (mod == 1) {
-        const float ang = atan2f(im, re);
         float er, ei;
-        if (((double)ang >= 0) && ((double)ang < M_PI / 2))        { er = r2;  ei = r2; }
-        else if (((double)ang >= -M_PI / 2) && ((double)ang < 0))  { er = r2;  ei = -r2; }
-        else if (((double)ang >= M_PI / 2) && ((double)ang < M_PI)) { er = -r2; ei = r2; }
-        else                                                       { er = -r2; ei = -r2; }
+        // The reference picks the quadrant from atan2f(im, re) compared with 0, +-pi/2 and pi in double.  Away from the axes that
+        // is the pair of signs (atan2f is good to a few ulp, the margin below is five orders wider); on or next to an axis --
+        // zeros, signed zeros, angles that round to float(pi/2) or float(pi), NaN -- the comparisons themselves are evaluated.
+        const float ar = fabsf(re), ai = fabsf(im);
+        if (ar > 1e-5f * ai && ai > 1e-5f * ar) { // false for NaN, zeros and infinities as well
+            er = re > 0 ? r2 : -r2;
+            ei = im > 0 ? r2 : -r2;
+        } else {
+            const float ang = atan2f(im, re);
+            if (((double)ang >= 0) && ((double)ang < M_PI / 2))         { er = r2;  ei = r2; }
+            else if (((double)ang >= -M_PI / 2) && ((double)ang < 0))   { er = r2;  ei = -r2; }
+            else if (((double)ang >= M_PI / 2) && ((double)ang < M_PI)) { er = -r2; ei = r2; }
+            else                                                        { er = -r2; ei = -r2; }
+        }
         const int m = (int)(127 * soft_decision(re, im, er, ei));
         b[0] = (int8_t)((er > 0) ? m : -m);
         b[1] = (int8_t)((ei > 0) ? m : -m);

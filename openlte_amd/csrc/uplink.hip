@@ -28,23 +28,136 @@ namespace {
 
 constexpr int N_SC_MAX = 1200;
 
+constexpr uint32_t EST_ROWS = 9; // k_pusch_demod: LDS floats kept per subcarrier of the allocation
+
 struct PuschDesc {
     uint32_t subfr, cell;   // of the allocation's unit
     uint32_t dmrs_off;      // float offset of dmrs_0_re | dmrs_0_im | dmrs_1_re | dmrs_1_im (M each) in the DMRS pool
 };
 
-// One Stockham pass of radix R (any R >= 2) over S symbols of M points each (symbol s at in + s*M_max), sign +1
-// (backward transform):
-//   out[(j-k)*R + k + q*Ns] = sum_r in[j + r*M/R] * exp(+2*pi*i * r*(k + q*Ns)/(Ns*R)),  k = j mod Ns.
-// One thread per output; Ns*R divides M, so the twiddle is entry (r*(k + q*Ns) mod Ns*R) * M/(Ns*R) of the
-// allocation's table tw[t] = exp(+2*pi*i*t/M).
+// floor(n / d) for n < 2^16, d < 2^16 as the high word of n * inv, inv = floor((2^32 - 1) / d) + 1 (exact in that range; d = 1
+// wraps to inv = 0, which div_by reads as "no division"): the index arithmetic of the passes below divides by sizes known only
+// per allocation, and a 32-bit division without a hardware divider costs more than the butterfly it addresses.
+__device__ __forceinline__ uint32_t inv_of(uint32_t d) { return 0xFFFFFFFFu / d + 1u; }
+__device__ __forceinline__ uint32_t div_by(uint32_t n, uint32_t inv) { return inv ? __umulhi(n, inv) : n; }
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmuli(float2 a) { return make_float2(-a.y, a.x); } // a * i
+
+// R-point backward DFTs in registers: v[q] <- sum_r v[r] exp(+2*pi*i * r*q/R).
+__device__ __forceinline__ void dft3(float2 &a, float2 &b, float2 &c)
+{
+    const float  h3 = 0.86602540378443864676f; // sin(2 pi / 3)
+    const float2 s = cadd(b, c), d = csub(b, c);
+    const float2 m = make_float2(a.x - 0.5f * s.x, a.y - 0.5f * s.y), n = make_float2(-h3 * d.y, h3 * d.x);
+    a = cadd(a, s);
+    b = cadd(m, n);
+    c = csub(m, n);
+}
+__device__ __forceinline__ void dft4(float2 &a, float2 &b, float2 &c, float2 &d)
+{
+    const float2 s02 = cadd(a, c), d02 = csub(a, c), s13 = cadd(b, d), d13 = cmuli(csub(b, d));
+    a = cadd(s02, s13);
+    b = cadd(d02, d13);
+    c = csub(s02, s13);
+    d = csub(d02, d13);
+}
+template <uint32_t R> __device__ __forceinline__ void butterfly(float2 (&v)[R]);
+template <> __device__ __forceinline__ void butterfly<2>(float2 (&v)[2])
+{
+    const float2 a = v[0];
+    v[0] = cadd(a, v[1]);
+    v[1] = csub(a, v[1]);
+}
+template <> __device__ __forceinline__ void butterfly<3>(float2 (&v)[3]) { dft3(v[0], v[1], v[2]); }
+template <> __device__ __forceinline__ void butterfly<4>(float2 (&v)[4]) { dft4(v[0], v[1], v[2], v[3]); }
+template <> __device__ __forceinline__ void butterfly<5>(float2 (&v)[5])
+{
+    const float  c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f; // cos(2 pi / 5), cos(4 pi / 5)
+    const float  s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;  // sin(2 pi / 5), sin(4 pi / 5)
+    const float2 a1 = cadd(v[1], v[4]), d1 = csub(v[1], v[4]), a2 = cadd(v[2], v[3]), d2 = csub(v[2], v[3]);
+    const float2 m1 = make_float2(v[0].x + c1 * a1.x + c2 * a2.x, v[0].y + c1 * a1.y + c2 * a2.y);
+    const float2 m2 = make_float2(v[0].x + c2 * a1.x + c1 * a2.x, v[0].y + c2 * a1.y + c1 * a2.y);
+    const float2 n1 = cmuli(make_float2(s1 * d1.x + s2 * d2.x, s1 * d1.y + s2 * d2.y));
+    const float2 n2 = cmuli(make_float2(s2 * d1.x - s1 * d2.x, s2 * d1.y - s1 * d2.y));
+    v[0] = cadd(v[0], cadd(a1, a2));
+    v[1] = cadd(m1, n1);
+    v[2] = cadd(m2, n2);
+    v[3] = csub(m2, n2);
+    v[4] = csub(m1, n1);
+}
+template <> __device__ __forceinline__ void butterfly<8>(float2 (&v)[8])
+{
+    // even outputs from v[r] + v[r+4], odd ones from (v[r] - v[r+4]) * exp(+2*pi*i * r/8), a 4-point transform of each
+    const float r2 = 0.70710678118654752440f;
+    float2      a[4], b[4];
+#pragma unroll
+    for (uint32_t r = 0; r < 4; r++) { a[r] = cadd(v[r], v[r + 4]); b[r] = csub(v[r], v[r + 4]); }
+    b[1] = make_float2(r2 * (b[1].x - b[1].y), r2 * (b[1].x + b[1].y));
+    b[2] = cmuli(b[2]);
+    b[3] = make_float2(-r2 * (b[3].x + b[3].y), r2 * (b[3].x - b[3].y));
+    dft4(a[0], a[1], a[2], a[3]);
+    dft4(b[0], b[1], b[2], b[3]);
+#pragma unroll
+    for (uint32_t p = 0; p < 4; p++) { v[2 * p] = a[p]; v[2 * p + 1] = b[p]; }
+}
+template <> __device__ __forceinline__ void butterfly<9>(float2 (&v)[9])
+{
+    // r = r1 + 3 r2, q = 3 q1 + q2: 3-point transforms over r2, the twiddles exp(+2*pi*i * r1*q2/9), 3-point transforms over r1
+    const float2 w1 = make_float2(0.76604444311897803520f, 0.64278760968653932632f);  // exp(2 pi i / 9)
+    const float2 w2 = make_float2(0.17364817766693034885f, 0.98480775301220805937f);  // exp(4 pi i / 9)
+    const float2 w4 = make_float2(-0.93969262078590838405f, 0.34202014332566873304f); // exp(8 pi i / 9)
+    dft3(v[0], v[3], v[6]); // r1 = 0: results indexed by q2 in v[0], v[3], v[6]
+    dft3(v[1], v[4], v[7]); // r1 = 1
+    dft3(v[2], v[5], v[8]); // r1 = 2
+    v[4] = cmul(v[4], w1); v[7] = cmul(v[7], w2); // r1 = 1: q2 = 1, 2
+    v[5] = cmul(v[5], w2); v[8] = cmul(v[8], w4); // r1 = 2: q2 = 1, 2
+    dft3(v[0], v[1], v[2]); // q2 = 0: outputs q = 0, 3, 6
+    dft3(v[3], v[4], v[5]); // q2 = 1: outputs q = 1, 4, 7
+    dft3(v[6], v[7], v[8]); // q2 = 2: outputs q = 2, 5, 8
+    const float2 t1 = v[1], t2 = v[2], t3 = v[3], t5 = v[5], t6 = v[6], t7 = v[7];
+    v[1] = t3; v[2] = t6; v[3] = t1; v[5] = t7; v[6] = t2; v[7] = t5; // v[3*q2 + q1] -> v[3*q1 + q2]
+}
+
+// One Stockham pass of radix R in {2, 3, 4, 5, 8, 9} over S symbols of M points each (symbol s at in + s*M_max), sign +1 (backward
+// transform), one thread per butterfly:
+//   out[(j-k)*R + k + q*Ns] = sum_r in[j + r*M/R] * w^(r*k) * exp(+2*pi*i * r*q/R),  k = j mod Ns,  w = exp(+2*pi*i / (Ns*R)),
+// the twiddle w^(r*k) being entry r*k*M/(Ns*R) (< M) of the allocation's table tw[t] = exp(+2*pi*i*t/M).
+template <uint32_t R>
+__device__ __forceinline__ void dft_pass_r(const float2 *__restrict__ in, float2 *__restrict__ out, const float2 *__restrict__ tw,
+                                           uint32_t S, uint32_t M, uint32_t M_max, uint32_t Ns)
+{
+    const uint32_t nb = M / R, tstride = nb / Ns, inv_nb = inv_of(nb), inv_ns = inv_of(Ns);
+    for (uint32_t o = threadIdx.x; o < S * nb; o += blockDim.x) {
+        const uint32_t sy = div_by(o, inv_nb), j = o - sy * nb, k = j - div_by(j, inv_ns) * Ns;
+        const float2  *x = in + sy * M_max + j;
+        float2         v[R];
+#pragma unroll
+        for (uint32_t r = 0; r < R; r++) v[r] = x[r * nb];
+        if (Ns > 1) { // uniform; the first pass has k = 0 throughout
+            const uint32_t t = k * tstride;
+#pragma unroll
+            for (uint32_t r = 1; r < R; r++) v[r] = cmul(v[r], tw[r * t]);
+        }
+        butterfly<R>(v);
+        float2 *y = out + sy * M_max + (j - k) * R + k;
+#pragma unroll
+        for (uint32_t q = 0; q < R; q++) y[q * Ns] = v[q];
+    }
+}
+
+// The same pass for any other radix (the prime FFTW would be left with when N_prb has a factor >= 7), one thread per output:
+// step = (k + q*Ns) * M/(Ns*R) < M, twiddle index r*step mod M.
 __device__ __forceinline__ void dft_pass(const float2 *__restrict__ in, float2 *__restrict__ out, const float2 *__restrict__ tw,
                                          uint32_t S, uint32_t M, uint32_t M_max, uint32_t R, uint32_t Ns)
 {
     const uint32_t nb = M / R, period = Ns * R, tstride = M / period;
+    const uint32_t inv_m = inv_of(M), inv_nb = inv_of(nb), inv_ns = inv_of(Ns);
     for (uint32_t o = threadIdx.x; o < S * M; o += blockDim.x) {
-        const uint32_t sy = o / M, oo = o - sy * M;
-        const uint32_t q = oo / nb, j = oo - q * nb, k = j % Ns, step = (k + q * Ns) * tstride; // step < M
+        const uint32_t sy = div_by(o, inv_m), oo = o - sy * M;
+        const uint32_t q = div_by(oo, inv_nb), j = oo - q * nb, k = j - div_by(j, inv_ns) * Ns, step = (k + q * Ns) * tstride;
         const float2  *x = in + sy * M_max + j;
         float    ar = 0.0f, ai = 0.0f;
         uint32_t t  = 0; // r*step mod M
@@ -59,16 +172,23 @@ __device__ __forceinline__ void dft_pass(const float2 *__restrict__ in, float2 *
     }
 }
 
-__global__ __launch_bounds__(256) void k_pusch_demod(const float *__restrict__ subframes, uint32_t sf_stride,
+#ifndef PUSCH_THREADS
+#define PUSCH_THREADS 256
+#endif
+#ifndef WPE
+#define WPE 6
+#endif
+__attribute__((amdgpu_waves_per_eu(WPE, 8)))
+__global__ __launch_bounds__(PUSCH_THREADS) void k_pusch_demod(const float *__restrict__ subframes, uint32_t sf_stride,
                                                      const mi_lte_pdsch_alloc *__restrict__ allocs, const PuschDesc *__restrict__ desc,
                                                      const float *__restrict__ dmrs_pool, GoldTables gt, int8_t *__restrict__ e_base,
                                                      const uint32_t *__restrict__ e_off, uint32_t *__restrict__ e_len, uint32_t M_max,
                                                      uint32_t S_par)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    // LDS: est[6][M_max] (mag0 ang0 mag1 ang1 dmag dang) | tw[M_max] | buf A[S_par][M_max] | buf B[S_par][M_max] (float2) | scrambling words
+    // LDS: est[9][M_max] (mag0 mag1 dmag | unit vectors of ang0, ang1, dang) | tw[M_max] | buf A[S_par][M_max] | buf B[S_par][M_max] (float2) | scrambling words
     float    *est  = sm;
-    float2   *tw   = reinterpret_cast<float2 *>(sm + 6 * (size_t)M_max);
+    float2   *tw   = reinterpret_cast<float2 *>(sm + EST_ROWS * (size_t)M_max);
     float2   *bufA = tw + M_max, *bufB = bufA + (size_t)S_par * M_max;
     uint32_t *cw   = reinterpret_cast<uint32_t *>(bufB + (size_t)S_par * M_max);
 
@@ -85,27 +205,40 @@ __global__ __launch_bounds__(256) void k_pusch_demod(const float *__restrict__ s
     const uint32_t c_init = (al.rnti << 14) | (0u << 13) | (ds.subfr << 9) | ds.cell, n_words = (N_bits + 31) / 32;
     for (uint32_t w = threadIdx.x; w <= n_words; w += blockDim.x) cw[w] = gold_word(gt, c_init, w);
 
-    // ---- DMRS estimates and their interpolation slopes (get_ulsch_ce, liblte_phy.cc:13745-13768); DFT twiddles
-    const float *d0_re = dmrs_pool + ds.dmrs_off, *d0_im = d0_re + M, *d1_re = d0_im + M, *d1_im = d1_re + M;
+    // ---- DMRS estimates and their interpolation slopes (get_ulsch_ce, liblte_phy.cc:13745-13768); DFT twiddles.
+    // The reference interpolates in polar form, h(s) = (mag_b + n f_mag) exp(i (ang_b + n f_ang)), n = -3..3 around DMRS symbol b:
+    // what is kept per subcarrier is exp(i ang_b) = t_b / |t_b| and exp(i f_ang), so the 12 data symbols cost complex products,
+    // not 12 sin/cos pairs.  Work is spread as (subcarrier, task): task 0/1 = DMRS symbol 0/1, task 2 = the twiddle.
+    const float *d_pool = dmrs_pool + ds.dmrs_off; // dmrs_0_re | dmrs_0_im | dmrs_1_re | dmrs_1_im (M each)
+    for (uint32_t o = threadIdx.x; o < 3 * M; o += blockDim.x) {
+        const uint32_t task = o >= 2 * M ? 2 : o >= M ? 1 : 0, i = o - task * M;
+        if (task == 2) {
+            float sn, cs;
+            sincospif(2.0f * (float)i / (float)M, &sn, &cs);
+            tw[i] = make_float2(cs, sn);
+        } else {
+            const uint32_t sc = al.prb[task][i / 12] * 12 + i % 12, L = task ? 10 : 3;
+            const float    cr = rx_re[L * N_SC_MAX + sc], ci = rx_im[L * N_SC_MAX + sc];
+            const float    dr = d_pool[2 * task * M + i], di = d_pool[(2 * task + 1) * M + i];
+            const float    t_re = cr * dr + ci * di, t_im = ci * dr - cr * di;
+            const float    mag = sqrtf(t_re * t_re + t_im * t_im);
+            est[task * M_max + i] = mag;
+            est[(3 + 2 * task) * M_max + i] = mag > 0.0f ? t_re / mag : 1.0f; // atan2f(0, 0) = 0
+            est[(4 + 2 * task) * M_max + i] = mag > 0.0f ? t_im / mag : 0.0f;
+            if (task == 0) est[8 * M_max + i] = atan2f(t_im, t_re);
+            else           est[2 * M_max + i] = atan2f(t_im, t_re); // parked in the rows the second step overwrites
+        }
+    }
+    __syncthreads();
     for (uint32_t i = threadIdx.x; i < M; i += blockDim.x) {
-        const uint32_t sc0 = al.prb[0][i / 12] * 12 + i % 12, sc1 = al.prb[1][i / 12] * 12 + i % 12;
-        const float c0r = rx_re[3 * N_SC_MAX + sc0], c0i = rx_im[3 * N_SC_MAX + sc0];
-        const float c1r = rx_re[10 * N_SC_MAX + sc1], c1i = rx_im[10 * N_SC_MAX + sc1];
-        float t_re = c0r * d0_re[i] + c0i * d0_im[i], t_im = c0i * d0_re[i] - c0r * d0_im[i];
-        const float mag_0 = sqrtf(t_re * t_re + t_im * t_im), ang_0 = atan2f(t_im, t_re);
-        t_re = c1r * d1_re[i] + c1i * d1_im[i];
-        t_im = c1i * d1_re[i] - c1r * d1_im[i];
-        const float mag_1 = sqrtf(t_re * t_re + t_im * t_im), ang_1 = atan2f(t_im, t_re);
-        const float f_mag = (mag_1 - mag_0) / 7;
-        float       f_ang = ang_1 - ang_0;
+        const float f_mag = (est[M_max + i] - est[i]) / 7;
+        float       f_ang = est[2 * M_max + i] - est[8 * M_max + i];
         if ((double)f_ang >= M_PI) f_ang = (float)((double)f_ang - 2 * M_PI); // float compared / corrected in double (:13758-13764)
         else if ((double)f_ang <= -M_PI) f_ang = (float)((double)f_ang + 2 * M_PI);
         f_ang /= 7;
-        est[0 * M_max + i] = mag_0; est[1 * M_max + i] = ang_0; est[2 * M_max + i] = mag_1;
-        est[3 * M_max + i] = ang_1; est[4 * M_max + i] = f_mag; est[5 * M_max + i] = f_ang;
         float sn, cs;
-        sincospif(2.0f * (float)i / (float)M, &sn, &cs);
-        tw[i] = make_float2(cs, sn);
+        sincosf(f_ang, &sn, &cs);
+        est[2 * M_max + i] = f_mag; est[7 * M_max + i] = cs; est[8 * M_max + i] = sn;
     }
     __syncthreads();
 
@@ -113,41 +246,54 @@ __global__ __launch_bounds__(256) void k_pusch_demod(const float *__restrict__ s
     int8_t     *e      = e_base + (size_t)e_off[a_idx] * 64; // 64-byte units
 
     for (uint32_t s0 = 0; s0 < 12; s0 += S_par) { // S_par data symbols at a time (all 12 when they fit in LDS)
-        const uint32_t S = min(S_par, 12u - s0);
-        // ---- channel estimate of each symbol and the one-tap equaliser
-        for (uint32_t o = threadIdx.x; o < S * M; o += blockDim.x) {
-            const uint32_t sy = o / M, i = o - sy * M, s = s0 + sy;
-            const uint32_t L = s < 3 ? s : s < 9 ? s + 1 : s + 2; // data symbols in time order, skipping DMRS symbols 3 and 10
-            const float mag_0 = est[i], ang_0 = est[M_max + i], mag_1 = est[2 * M_max + i], ang_1 = est[3 * M_max + i];
-            const float f_mag = est[4 * M_max + i], f_ang = est[5 * M_max + i];
-            float cm, ca; // liblte_phy.cc:13770-13780
-            if (s < 3)      { cm = mag_0 - (float)(3 - s) * f_mag;       ca = ang_0 - (float)(3 - s) * f_ang; }
-            else if (s < 6) { cm = mag_0 + (float)(1 + (s - 3)) * f_mag; ca = ang_0 + (float)(1 + (s - 3)) * f_ang; }
-            else if (s < 9) { cm = mag_1 - (float)(3 - (s - 6)) * f_mag; ca = ang_1 - (float)(3 - (s - 6)) * f_ang; }
-            else            { cm = mag_1 + (float)(1 + (s - 9)) * f_mag; ca = ang_1 + (float)(1 + (s - 9)) * f_ang; }
-            float sn, cs;
-            sincosf(ca, &sn, &cs); // the compiled reference resolves cos(float) to cosf (C++ overload)
-            const float    h_re = cm * cs, h_im = cm * sn;
-            const uint32_t sc = al.prb[L / 7][i / 12] * 12 + i % 12;
-            const float    z_re = rx_re[L * N_SC_MAX + sc], z_im = rx_im[L * N_SC_MAX + sc];
-            const float    hn = h_re * h_re + h_im * h_im;
-            bufA[sy * M_max + i] = make_float2((z_re * h_re + z_im * h_im) / hn, (z_im * h_re - z_re * h_im) / hn);
+        const uint32_t S = min(S_par, 12u - s0), inv_s = inv_of(S);
+        // ---- channel estimate of each symbol and the one-tap equaliser.  One item per (subcarrier, slot): the slot's DMRS
+        // estimate, its unit vector and the powers of exp(i f_ang) are fetched / formed once and serve the slot's (up to) six data
+        // symbols; S is 12 (both slots) or divides 6 (part of one slot).
+        const uint32_t slot0 = s0 >= 6, n_slots = S == 12 ? 2 : 1, sp0 = s0 - 6 * slot0, sp1 = sp0 + (S == 12 ? 6 : S);
+        for (uint32_t o = threadIdx.x; o < n_slots * M; o += blockDim.x) {
+            const uint32_t b = slot0 + (o >= M), i = o - (o >= M ? M : 0);
+            const float    mag = est[b * M_max + i], f_mag = est[2 * M_max + i];
+            const float2   u = make_float2(est[(3 + 2 * b) * M_max + i], est[(4 + 2 * b) * M_max + i]);
+            const float2   f1 = make_float2(est[7 * M_max + i], est[8 * M_max + i]), f2 = cmul(f1, f1), f3 = cmul(f2, f1);
+            const uint32_t sc = al.prb[b][i / 12] * 12 + i % 12;
+            const float   *z_re = rx_re + 7 * b * N_SC_MAX + sc, *z_im = rx_im + 7 * b * N_SC_MAX + sc;
+            float2        *dst = bufA + ((int)(6 * b) - (int)s0) * (int)M_max + (int)i; // symbol s = 6 b + sp goes to row s - s0
+#pragma unroll
+            for (uint32_t sp = 0; sp < 6; sp++) {
+                if (sp < sp0 || sp >= sp1) continue; // uniform
+                // liblte_phy.cc:13770-13780: symbols 0-2 / 3-5 of a slot lie -3..-1 / +1..+3 steps from its DMRS symbol (symbol 3 of 7)
+                const int    n = sp < 3 ? (int)sp - 3 : (int)sp - 2;
+                const uint32_t l = sp < 3 ? sp : sp + 1; // position in the slot, skipping the DMRS symbol
+                const float2 fa = n == 1 || n == -1 ? f1 : n == 2 || n == -2 ? f2 : f3;
+                const float2 f = make_float2(fa.x, n < 0 ? -fa.y : fa.y);
+                const float  cm = mag + (float)n * f_mag;
+                const float2 ph = cmul(u, f);
+                const float  h_re = cm * ph.x, h_im = cm * ph.y;
+                const float  zr = z_re[l * N_SC_MAX], zi = z_im[l * N_SC_MAX];
+                const float  hn = 1.0f / (h_re * h_re + h_im * h_im);
+                dst[sp * M_max] = make_float2((zr * h_re + zi * h_im) * hn, (zi * h_re - zr * h_im) * hn);
+            }
         }
         __syncthreads();
-        // ---- transform pre-decoding: M-point backward DFTs, radices 4, 2, 3, 5, then the remaining prime
+        // ---- transform pre-decoding: M-point backward DFTs, radices 9, 3, 5, 8, 4, 2, then the remaining prime.  Odd radices go
+        // first: the first pass writes its R outputs R float2 apart across lanes, which is conflict-free in LDS only for odd R
+        // (M = 12 N_prb always has a factor 3 to start with).
         float2  *src = bufA, *dst = bufB;
         uint32_t rem = M, Ns = 1;
         while (rem > 1) { // uniform over the workgroup
             uint32_t R;
-            if (rem % 4 == 0) R = 4;
-            else if (rem % 2 == 0) R = 2;
-            else if (rem % 3 == 0) R = 3;
-            else if (rem % 5 == 0) R = 5;
+            if (rem % 9 == 0)      { R = 9; dft_pass_r<9>(src, dst, tw, S, M, M_max, Ns); }
+            else if (rem % 3 == 0) { R = 3; dft_pass_r<3>(src, dst, tw, S, M, M_max, Ns); }
+            else if (rem % 5 == 0) { R = 5; dft_pass_r<5>(src, dst, tw, S, M, M_max, Ns); }
+            else if (rem % 8 == 0) { R = 8; dft_pass_r<8>(src, dst, tw, S, M, M_max, Ns); }
+            else if (rem % 4 == 0) { R = 4; dft_pass_r<4>(src, dst, tw, S, M, M_max, Ns); }
+            else if (rem % 2 == 0) { R = 2; dft_pass_r<2>(src, dst, tw, S, M, M_max, Ns); }
             else {
                 R = 7;
                 while (rem % R) R += 2;
+                dft_pass(src, dst, tw, S, M, M_max, R, Ns);
             }
-            dft_pass(src, dst, tw, S, M, M_max, R, Ns);
             __syncthreads();
             Ns *= R;
             rem /= R;
@@ -155,14 +301,25 @@ __global__ __launch_bounds__(256) void k_pusch_demod(const float *__restrict__ s
         }
         // ---- de-map, descramble, de-interleave (transpose): soft bit q of symbol k goes to (k*12 + s)*Q_m + q
         for (uint32_t o = threadIdx.x; o < S * M; o += blockDim.x) {
-            const uint32_t sy = o % S, k = o / S, s = s0 + sy; // neighbouring threads write neighbouring bytes of e
+            const uint32_t k = div_by(o, inv_s), sy = o - k * S, s = s0 + sy; // neighbouring threads write neighbouring bytes of e
             const float2   x = src[sy * M_max + k];
             int8_t         b[6] = {0, 0, 0, 0, 0, 0};
             demap_symbol(sqrt_M * x.x, sqrt_M * x.y, al.mod_type, b);
             const uint32_t n0 = (s * M + k) * Qm, w = n0 >> 5, sh = n0 & 31;
             const uint32_t c  = __builtin_amdgcn_alignbit(cw[w + 1], cw[w], sh);
             int8_t        *ob = e + (size_t)(k * 12 + s) * Qm;
-            for (uint32_t q = 0; q < Qm; q++) ob[q] = ((c >> q) & 1u) ? (int8_t)-b[q] : b[q];
+            // descrambled soft bits q, q + 1 as one 16-bit word (the Q_m bytes of a symbol start on an even address)
+            auto pair = [&](uint32_t q) -> uint32_t {
+                const int lo = ((c >> q) & 1u) ? -b[q] : b[q], hi = ((c >> (q + 1)) & 1u) ? -b[q + 1] : b[q + 1];
+                return (uint32_t)(uint8_t)lo | (uint32_t)(uint8_t)hi << 8;
+            };
+            if (Qm == 2) *reinterpret_cast<uint16_t *>(ob) = (uint16_t)pair(0);
+            else if (Qm == 4) *reinterpret_cast<uint32_t *>(ob) = pair(0) | pair(2) << 16;
+            else if (Qm == 6) {
+                *reinterpret_cast<uint16_t *>(ob)     = (uint16_t)pair(0);
+                *reinterpret_cast<uint16_t *>(ob + 2) = (uint16_t)pair(2);
+                *reinterpret_cast<uint16_t *>(ob + 4) = (uint16_t)pair(4);
+            } else ob[0] = (c & 1u) ? (int8_t)-b[0] : b[0];
         }
         __syncthreads();
     }
@@ -405,10 +562,10 @@ int mi_lte_pusch_decode_run(mi_lte_ctx *ctx, mi_lte_pusch_plan *pl, const float 
     GoldTables   gt{ctx->d_gold_x1, ctx->d_gold_x2b, ctx->gold_words};
     // as many of the 12 data symbols side by side as fit in ~40 KiB of ping-pong buffers (all 12 up to 17 PRB)
     uint32_t S_par = 12;
-    while (S_par > 1 && (size_t)S_par * pl->M_max * 2 * sizeof(float2) > 40 * 1024) S_par = S_par == 12 ? 6 : S_par == 6 ? 4 : S_par == 4 ? 3 : S_par - 1;
-    const size_t lds = sizeof(float) * 6 * (size_t)pl->M_max + sizeof(float2) * (size_t)pl->M_max * (1 + 2 * S_par) +
+    while (S_par > 1 && (size_t)S_par * pl->M_max * 2 * sizeof(float2) > 40 * 1024) S_par = S_par == 12 ? 6 : S_par == 6 ? 3 : S_par - 1; // 12, or a divisor of 6
+    const size_t lds = sizeof(float) * EST_ROWS * (size_t)pl->M_max + sizeof(float2) * (size_t)pl->M_max * (1 + 2 * S_par) +
                        sizeof(uint32_t) * (pl->words_max + 1);
-    MI_LAUNCH(ctx, "k_pusch_demod", k_pusch_demod, dim3(pl->n_alloc), dim3(256), lds, d_subframes, (uint32_t)mi_lte_ul_subframe_floats(),
+    MI_LAUNCH(ctx, "k_pusch_demod", k_pusch_demod, dim3(pl->n_alloc), dim3(PUSCH_THREADS), lds, d_subframes, (uint32_t)mi_lte_ul_subframe_floats(),
               pl->d_allocs, pl->d_desc, pl->d_dmrs, gt, pl->d_e, pl->d_e_off, pl->d_e_len, pl->M_max, S_par);
     MI_HIP_CHECK(ctx, hipGetLastError());
     for (auto &gr : pl->groups) {

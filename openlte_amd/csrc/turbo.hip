@@ -300,17 +300,59 @@ struct SrcRateUnmatch {
         E   = g.e_len[a];
     }
     // copy the allocation's soft bits into LDS with wide loads (the gather is otherwise a chain of
-    // dependent byte loads from L2); returns whether the copy was made
+    // dependent byte loads from L2), followed by zeros up to the next 16-byte boundary and at least at index E: the
+    // gather below reads "nothing" (a NULL slot, a rank the allocation does not reach) as e[min(rank, E)] = 0.
+    // Returns whether the copy was made.
     __device__ __forceinline__ bool stage_e(int8_t *lds)
     {
-        if (E > e_cap) return false;
-        const uint32_t nq = (E + 15) >> 4; // e_off is 64-byte aligned and padded
+        if (E + 16 > e_cap || E >= 0xFFFFu) return false;
+        const uint32_t nq = E >> 4, tail = E & 15u; // e_off is 64-byte aligned and padded
         const uint4   *gp = reinterpret_cast<const uint4 *>(e);
         uint4         *l  = reinterpret_cast<uint4 *>(lds);
 #pragma unroll 4
         for (uint32_t w = threadIdx.x; w < nq; w += blockDim.x) l[w] = gp[w];
+        if (threadIdx.x == (nq & 63u)) { // the quarter line that holds index E
+            uint4 t = make_uint4(0, 0, 0, 0);
+            if (tail) {
+                t = gp[nq];
+                uint32_t c[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const int keep = (int)tail - 4 * (int)k; // bytes of word k below index E
+                    c[k] = keep >= 4 ? c[k] : keep <= 0 ? 0u : (c[k] & ((1u << (8 * keep)) - 1u));
+                }
+                t = make_uint4(c[0], c[1], c[2], c[3]);
+            }
+            l[nq] = t;
+        }
         __syncthreads();
         return true;
+    }
+    // the gather from the staged copy: v[x][k] = sum over laps t of e[min(rank + t*Nnn, E)], ranks 0xFFFF (NULL, or past the
+    // block end) included -- three operations per element and lap, no predicate
+    __device__ __forceinline__ void gather16_staged(const int8_t *el, uint32_t u, int nvalid, int (&v)[3][16]) const
+    {
+        uint4 raw[3][2];
+#pragma unroll
+        for (int x = 0; x < 3; x++) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(tab + (size_t)x * K_ + 16 * (size_t)u);
+            raw[x][0] = p[0];
+            raw[x][1] = (nvalid > 8) ? p[1] : make_uint4(~0u, ~0u, ~0u, ~0u);
+        }
+#pragma unroll
+        for (int x = 0; x < 3; x++) {
+            const uint32_t w[8] = {raw[x][0].x, raw[x][0].y, raw[x][0].z, raw[x][0].w, raw[x][1].x, raw[x][1].y, raw[x][1].z, raw[x][1].w};
+            uint32_t       r[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                r[k]    = (k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xFFFFu);
+                v[x][k] = (int)el[min(r[k], E)];
+            }
+            for (uint32_t base = Nnn; base < E; base += Nnn) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) v[x][k] += (int)el[min(r[k] + base, E)];
+            }
+        }
     }
     // d[(16u+k)*3+x] = sum over laps t of e[rank + t*Nnn] (first visit stores, repeats add, :11402-11416).
     // All first-lap loads of a unit are independent; later laps (uniform trip count) are masked.
@@ -353,9 +395,9 @@ struct SrcRateUnmatch {
         }
     }
     static constexpr bool kIntPath = true; // the sums are small integers: the quantiser below never leaves integer arithmetic
-    template <typename V> __device__ __forceinline__ void load16(uint32_t u, int nvalid, V (&v)[3][16], const int8_t *e_lds, bool in_lds) const
+    __device__ __forceinline__ void load16(uint32_t u, int nvalid, int (&v)[3][16], const int8_t *e_lds, bool in_lds) const
     {
-        if (in_lds) gather16(e_lds, u, nvalid, v); // ds_read path
+        if (in_lds) gather16_staged(e_lds, u, nvalid, v);
         else        gather16(e, u, nvalid, v);
     }
 };
@@ -368,52 +410,99 @@ constexpr uint32_t QTAB_HALF = 2048;
 constexpr uint32_t MTAB_N = 256;  // w = |a|+|b| <= 254
 constexpr uint32_t PREP_TAB_BYTES = QTAB_N + 2 * MTAB_N;
 
+// byte-parallel helpers for the per-code-block kernels.  Soft values travel as four int8 per register; |a| of one of them is
+// the masked byte SAD of the biased word (x + 128 per byte, i.e. word ^ 0x80808080) against 0x80 in that byte alone
+// (v_msad_u8 skips the bytes whose reference byte is 0), so |a_k| + |b_k| is two instructions on the packed words.
+__device__ __forceinline__ uint32_t pack4u(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3) { return b0 | (b1 << 8) | (b2 << 16) | (b3 << 24); } // bytes < 256
+__device__ __forceinline__ uint32_t bias4(uint32_t w) { return w ^ 0x80808080u; }
+template <int K4> __device__ __forceinline__ uint32_t abs_sum2(uint32_t wa_biased, uint32_t wb_biased) // |a[K4]| + |b[K4]|
+{
+    return __builtin_amdgcn_msad_u8(wb_biased, 0x80u << (8 * K4), __builtin_amdgcn_msad_u8(wa_biased, 0x80u << (8 * K4), 0u));
+}
+// w[k] = |a[k]| + |b[k]| for the 16 values of a unit, and their maximum folded into wmax
+__device__ __forceinline__ void abs_sum16(const uint4 &A, const uint4 &B, uint32_t (&w)[16], uint32_t &wmax)
+{
+    const uint32_t a[4] = {bias4(A.x), bias4(A.y), bias4(A.z), bias4(A.w)}, b[4] = {bias4(B.x), bias4(B.y), bias4(B.z), bias4(B.w)};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        w[4 * j]     = abs_sum2<0>(a[j], b[j]);
+        w[4 * j + 1] = abs_sum2<1>(a[j], b[j]);
+        w[4 * j + 2] = abs_sum2<2>(a[j], b[j]);
+        w[4 * j + 3] = abs_sum2<3>(a[j], b[j]);
+        wmax = max(max(wmax, w[4 * j]), max(w[4 * j + 1], max(w[4 * j + 2], w[4 * j + 3])));
+    }
+}
+// m[k] = mtab[w[k]] as sixteen packed bytes (mtab entries are 0..127)
+__device__ __forceinline__ uint4 lookup16(const int8_t *mtab, const uint32_t (&w)[16])
+{
+    const uint8_t *t = reinterpret_cast<const uint8_t *>(mtab);
+    uint32_t       o[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) o[j] = pack4u(t[w[4 * j]], t[w[4 * j + 1]], t[w[4 * j + 2]], t[w[4 * j + 3]]);
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+// g[k] = arr[idx[k]] as sixteen packed bytes
+__device__ __forceinline__ uint4 gather16_bytes(const int8_t *arr, const uint32_t (&idx)[16])
+{
+    const uint8_t *t = reinterpret_cast<const uint8_t *>(arr);
+    uint32_t       o[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) o[j] = pack4u(t[idx[4 * j]], t[idx[4 * j + 1]], t[idx[4 * j + 2]], t[idx[4 * j + 3]]);
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 template <typename Src, int NSLOT>
-__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_turbo_prep(Src src, uint32_t K, uint32_t n_cb,
+#ifndef PREP_WPE
+#define PREP_WPE 6
+#endif
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(PREP_WPE, 8))) void k_turbo_prep(Src src, uint32_t K, uint32_t n_cb,
                                                     const uint16_t *__restrict__ pi, PrepOut out)
 {
-    extern __shared__ __attribute__((aligned(16))) int8_t sm[]; // qtab | mtab1 | mtab2 | q(d0)[Kp] | staged e
+    static_assert(NSLOT == 1, "one unit per thread (K <= 6144 -> at most 384 units)");
+    extern __shared__ __attribute__((aligned(16))) int8_t sm[]; // qtab | mtab1 | mtab2 | staged e [e_cap] | q(d0)[Kp]
     __shared__ float red_f[8];
     __shared__ int   red_i[16];
     const uint32_t cb = xcd_cb(blockIdx.x, n_cb), tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4;
     if (cb >= n_cb) return; // uniform
     const size_t   tile_off = (size_t)tile * Kp * 64;
-    int8_t        *qtab = sm, *mtab1 = sm + QTAB_N, *mtab2 = mtab1 + MTAB_N, *q0_lds = sm + PREP_TAB_BYTES;
+    int8_t        *qtab = sm, *qc = sm + QTAB_HALF, *mtab1 = sm + QTAB_N, *mtab2 = mtab1 + MTAB_N, *e_lds = sm + PREP_TAB_BYTES;
+    int8_t        *q0_lds = e_lds + src.e_cap;
     src.init(cb, K);
-    const int8_t *e_lds = q0_lds + Kp;
-    const bool    e_in_lds = src.stage_e(q0_lds + Kp);
+    const bool     e_in_lds = src.stage_e(e_lds);
+    const uint32_t u  = threadIdx.x;
+    const int      nv = (u < n_units) ? min(16, max(0, (int)K - 16 * (int)u)) : -1; // 16, 8 (last unit of a K % 16 == 8 block), 0 (padding), -1
 
     typedef typename std::conditional<Src::kIntPath, int, float>::type val_t;
-    val_t v[NSLOT][3][16];
-    int   nval[NSLOT];
-    val_t mxv = 0;
-#pragma unroll
-    for (int s = 0; s < NSLOT; s++) {
-        const uint32_t u = threadIdx.x + s * blockDim.x;
-        nval[s] = (u < n_units) ? min(16, max(0, (int)K - 16 * (int)u)) : -1;
-        if (nval[s] > 0) src.load16(u, nval[s], v[s], e_lds, e_in_lds);
-        else {
-#pragma unroll
-            for (int x = 0; x < 3; x++)
-#pragma unroll
-                for (int k = 0; k < 16; k++) v[s][x][k] = 0;
-        }
+    val_t v[3][16];
+    if (nv > 0) src.load16(u, nv, v, e_lds, e_in_lds);
+    else {
 #pragma unroll
         for (int x = 0; x < 3; x++)
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                if constexpr (Src::kIntPath) mxv = max(mxv, abs(v[s][x][k]));
-                else mxv = fmaxf(mxv, fabsf(v[s][x][k]));
-            }
+            for (int k = 0; k < 16; k++) v[x][k] = 0;
     }
     float mx;
     int   mxi = 0;
-    if constexpr (Src::kIntPath) { mxi = block_max_i(mxv, red_i); mx = (float)mxi; }
-    else mx = block_max_f(mxv, red_f);
+    if constexpr (Src::kIntPath) {
+        int hi = 0, lo = 0;
+#pragma unroll
+        for (int x = 0; x < 3; x++)
+#pragma unroll
+            for (int k = 0; k < 16; k += 2) { hi = max(max(hi, v[x][k]), v[x][k + 1]); lo = min(min(lo, v[x][k]), v[x][k + 1]); }
+        mxi = block_max_i(max(hi, -lo), red_i);
+        mx  = (float)mxi;
+    } else {
+        float mxv = 0;
+#pragma unroll
+        for (int x = 0; x < 3; x++)
+#pragma unroll
+            for (int k = 0; k < 16; k++) mxv = fmaxf(mxv, fabsf(v[x][k]));
+        mx = block_max_f(mxv, red_f);
+    }
     const bool use_qtab = Src::kIntegerValued && mx < (float)QTAB_HALF; // uniform over the workgroup
     if (use_qtab) {
-        if constexpr (Src::kIntPath) { // signed table: entry d + max holds q(d) -- one add and one read per element
-            for (uint32_t a = threadIdx.x; a <= 2u * (uint32_t)mxi; a += blockDim.x) qtab[a] = (int8_t)(int)((float)((int)a - mxi) * 127.0f / mx);
+        if constexpr (Src::kIntPath) { // signed table centred on a fixed slot: entry QTAB_HALF + d holds q(d) -- one read per element
+            for (int d = (int)threadIdx.x - mxi; d <= mxi; d += (int)blockDim.x) qc[d] = (int8_t)(int)((float)d * 127.0f / mx);
         } else {
             for (uint32_t a = threadIdx.x; a <= (uint32_t)mx; a += blockDim.x) qtab[a] = (int8_t)(int)((float)a * 127.0f / mx);
         }
@@ -421,54 +510,47 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     }
 
     // quantise stream by stream and keep only the packed bytes (4 VGPRs per stream) across the barriers
-    const uint32_t u  = threadIdx.x;
-    const int      nv = nval[0];
-    uint4          Q[3] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+    uint4 Q[3];
 #pragma unroll
     for (int x = 0; x < 3; x++) {
-        int q[16];
-        if (use_qtab) {
+        if (Src::kIntPath && use_qtab) {
+            const uint8_t *t = reinterpret_cast<const uint8_t *>(qc);
+            uint32_t       o[4];
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                if constexpr (Src::kIntPath) q[k] = qtab[v[0][x][k] + mxi]; // 0 past the block end -> q(0) = 0
-                else {
-                    const float f = v[0][x][k]; // 0 past the block end -> q = 0; the lookup is unconditional (no per-element branch)
+            for (int j = 0; j < 4; j++) // 0 past the block end -> q(0) = 0
+                o[j] = pack4u(t[(int)v[x][4 * j]], t[(int)v[x][4 * j + 1]], t[(int)v[x][4 * j + 2]], t[(int)v[x][4 * j + 3]]);
+            Q[x] = make_uint4(o[0], o[1], o[2], o[3]);
+        } else {
+            int q[16];
+            if (use_qtab) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const float f = v[x][k]; // 0 past the block end -> q = 0; the lookup is unconditional (no per-element branch)
                     const int   t = qtab[(int)fabsf(f)]; // (int)(-a*127/mx) == -(int)(a*127/mx): IEEE division and truncation are odd
                     q[k]          = f < 0.0f ? -t : t;
                 }
-            }
-        } else {
+            } else {
 #pragma unroll
-            for (int k = 0; k < 16; k++) q[k] = (int)((float)v[0][x][k] * 127.0f / mx); // v = 0 past the block end
+                for (int k = 0; k < 16; k++) q[k] = (int)((float)v[x][k] * 127.0f / mx); // v = 0 past the block end
+            }
+            Q[x] = pack16(q);
         }
-        Q[x] = pack16(q);
         if (nv >= 0) *reinterpret_cast<uint4 *>(out.arr[x] + unit_off(tile_off, lane, u)) = Q[x];
     }
     if (nv >= 0) *reinterpret_cast<uint4 *>(q0_lds + 16 * u) = Q[0];
     __syncthreads();
 
-    int   w1max = 0, w2max = 0;
     uint4 I0 = make_uint4(0, 0, 0, 0);
-    {
-        int i0[16], q0[16], q1[16], q2[16];
-        unpack16(Q[0], q0);
-        unpack16(Q[1], q1);
-        unpack16(Q[2], q2);
-#pragma unroll
-        for (int k = 0; k < 16; k++) i0[k] = 0;
-        if (nv > 0) {
-            uint32_t idx[16];
-            load_idx16(pi, u, nv, idx, K); // past the block end: slot K, which holds q = 0 whenever K % 16 == 8
-#pragma unroll
-            for (int k = 0; k < 16; k++) { // unconditional LDS reads
-                i0[k] = q0_lds[idx[k]];
-                w1max = max(w1max, abs(q1[k]) + abs(q0[k]));
-                w2max = max(w2max, abs(q2[k]) + abs(i0[k]));
-            }
-        }
-        I0 = pack16(i0);
-        if (nv >= 0) *reinterpret_cast<uint4 *>(out.arr[3] + unit_off(tile_off, lane, u)) = I0;
+    if (nv > 0) {
+        uint32_t idx[16];
+        load_idx16(pi, u, nv, idx, K); // past the block end: slot K, which holds q = 0 whenever K % 16 == 8
+        I0 = gather16_bytes(q0_lds, idx);
     }
+    if (nv >= 0) *reinterpret_cast<uint4 *>(out.arr[3] + unit_off(tile_off, lane, u)) = I0;
+    uint32_t w1[16], w2[16], w1m = 0, w2m = 0; // pass-1 / pass-2 branch weights |q(d1)| + |q(d0)|, |q(d2)| + |I0|: 0 past the block end
+    abs_sum16(Q[1], Q[0], w1, w1m);
+    abs_sum16(Q[2], I0, w2, w2m);
+    int w1max = (int)w1m, w2max = (int)w2m;
     block_max_i2(w1max, w2max, red_i);
     const float W1 = (float)w1max, W2 = (float)w2max;
     for (uint32_t t = threadIdx.x; t < MTAB_N; t += blockDim.x) { // w <= 254 always; entries past W are never read
@@ -478,17 +560,8 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     }
     __syncthreads();
     if (nv >= 0) {
-        int m[16], a[16], b[16];
-        unpack16(Q[1], a);
-        unpack16(Q[0], b);
-#pragma unroll
-        for (int k = 0; k < 16; k++) m[k] = (int)mtab1[abs(a[k]) + abs(b[k])]; // past the end: |0|+|0| -> entry 0 = 0
-        *reinterpret_cast<uint4 *>(out.arr[4] + unit_off(tile_off, lane, u)) = pack16(m);
-        unpack16(Q[2], a);
-        unpack16(I0, b);
-#pragma unroll
-        for (int k = 0; k < 16; k++) m[k] = (int)mtab2[abs(a[k]) + abs(b[k])];
-        *reinterpret_cast<uint4 *>(out.arr[5] + unit_off(tile_off, lane, u)) = pack16(m);
+        *reinterpret_cast<uint4 *>(out.arr[4] + unit_off(tile_off, lane, u)) = lookup16(mtab1, w1); // past the end: entry 0 = 0
+        *reinterpret_cast<uint4 *>(out.arr[5] + unit_off(tile_off, lane, u)) = lookup16(mtab2, w2);
     }
 }
 
@@ -1049,7 +1122,7 @@ int mi_turbo_ref_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_
     src.tabs = rt.d_tabs;
     src.nnn  = rt.d_nnn;
     // stage e in LDS when the largest allocation of the group fits next to the block's own arrays
-    const uint32_t cap = (e_max_bytes + 63u) & ~63u;
+    const uint32_t cap = (e_max_bytes + 16u + 63u) & ~63u; // room for the zero slot behind the longest allocation
     src.e_cap          = (PREP_TAB_BYTES + kpad64(K) + cap <= 48 * 1024) ? cap : 0;
     return turbo_ref_run<SrcRateUnmatch, true>(ctx, src, K, n_cb, nullptr, gd, src.e_cap);
 }

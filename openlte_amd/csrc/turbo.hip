@@ -726,17 +726,45 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 }
 
 // ------------------------------------------------------------------------------------------------
-// helpers for the soft re-encoder on a unit: x[-3..15] = three halo values + the unit's 16 values
-//   fb[i] = soft_xor(x[i-2], x[i-3]) with x[<0] = +127 (fb[0] = 127 falls out of the same formula)
-__device__ __forceinline__ void load_unit_halo(const uint8_t *arr, size_t tile_off, uint32_t lane, uint32_t u, int (&x)[19])
+// Two-at-a-time int16 arithmetic for the soft re-encoder and the vote (v_pk_*_i16): a register of four int8 values b0..b3 is
+// split into its even pair (b0, b2) and its odd pair (b1, b3), sign-extended to 16 bits; all element-wise work is done on pairs.
+typedef short v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2s      as_v2s(uint32_t w) { return __builtin_bit_cast(v2s, w); }
+__device__ __forceinline__ uint32_t as_u32(v2s v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ v2s      even2(uint32_t w) { return (as_v2s(w) << 8) >> 8; }
+__device__ __forceinline__ v2s      odd2(uint32_t w) { return as_v2s(w) >> 8; }
+__device__ __forceinline__ uint32_t merge_bytes(v2s e, v2s o) { return __builtin_amdgcn_perm(as_u32(o), as_u32(e), 0x06020400u); } // low bytes of (e.lo, o.lo, e.hi, o.hi)
+__device__ __forceinline__ v2s      abs2(v2s a) { return __builtin_elementwise_max(a, (v2s)(0) - a); }
+// soft_xor on pairs: sign * ((|a|+|b|) >> 1), sign negative iff exactly one operand is negative
+__device__ __forceinline__ v2s sxor2(v2s a, v2s b)
 {
-    const uint4 c = *reinterpret_cast<const uint4 *>(arr + unit_off(tile_off, lane, u));
-    uint32_t    prev = 0x7F7F7F7Fu; // x[-1], x[-2], x[-3] = +127 (conv_encode_soft register preset, liblte_phy.cc:10097-10100)
+    const v2s mag = (abs2(a) + abs2(b)) >> 1, s = (a ^ b) >> 15;
+    return (mag ^ s) - s;
+}
+// A unit of 16 values x[0..15] plus its three-value halo x[-3..-1], as pairs: E[j] = (x[4j-4], x[4j-2]), O[j] = (x[4j-3], x[4j-1]),
+// j = 0 (halo word) .. 4.  The delayed sequences the soft re-encoder needs are then
+//   x[k-2]: even pairs (E[j].hi, E[j+1].lo), odd pairs (O[j].hi, O[j+1].lo)  -- one v_alignbit each
+//   x[k-3]: even pairs O[j], odd pairs = the even pairs of x[k-2]              -- free
+// with x[<0] = +127 in the first unit (conv_encode_soft register preset, liblte_phy.cc:10097-10100).
+struct UnitPairs { v2s E[5], O[5]; };
+__device__ __forceinline__ UnitPairs load_unit_pairs(const uint8_t *arr, size_t tile_off, uint32_t lane, uint32_t u)
+{
+    const uint4 c    = *reinterpret_cast<const uint4 *>(arr + unit_off(tile_off, lane, u));
+    uint32_t    prev = 0x7F7F7F7Fu;
     if (u > 0) prev = *reinterpret_cast<const uint32_t *>(arr + unit_off(tile_off, lane, u - 1) + 12);
-    x[0] = sbyte(prev, 1); x[1] = sbyte(prev, 2); x[2] = sbyte(prev, 3);
-    const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+    const uint32_t w[5] = {prev, c.x, c.y, c.z, c.w};
+    UnitPairs      p;
 #pragma unroll
-    for (int k = 0; k < 16; k++) x[3 + k] = sbyte(w[k >> 2], k & 3);
+    for (int j = 0; j < 5; j++) { p.E[j] = even2(w[j]); p.O[j] = odd2(w[j]); }
+    return p;
+}
+__device__ __forceinline__ v2s delay2(v2s cur, v2s prev) { return as_v2s(__builtin_amdgcn_alignbit(as_u32(cur), as_u32(prev), 16)); } // (prev.hi, cur.lo)
+// fb = soft_xor(x[k-2], x[k-3]) for word j (0..3) of the unit: even and odd pairs
+__device__ __forceinline__ void feedback2(const UnitPairs &p, int j, v2s &fe, v2s &fo)
+{
+    const v2s d2e = delay2(p.E[j + 1], p.E[j]), d2o = delay2(p.O[j + 1], p.O[j]);
+    fe = sxor2(d2e, p.O[j]);
+    fo = sxor2(d2o, d2e);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -747,56 +775,44 @@ struct PermArgs { const uint8_t *A1; const uint8_t *X2; uint8_t *out[2]; /* I1, 
 template <int NSLOT>
 __global__ __launch_bounds__(384) void k_turbo_perm(PermArgs a, uint32_t K, uint32_t n_cb, const uint16_t *__restrict__ pi)
 {
+    static_assert(NSLOT == 1, "one unit per thread");
     extern __shared__ __attribute__((aligned(16))) int8_t sm[]; // C1[Kp]
     __shared__ int    red_i[8];
     __shared__ int8_t mtab[MTAB_N];
     const uint32_t cb = xcd_cb(blockIdx.x, n_cb), tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4;
     if (cb >= n_cb) return;
     const size_t   tile_off = (size_t)tile * Kp * 64;
-    int nval[NSLOT], x2[NSLOT][16];
+    const uint32_t u  = threadIdx.x;
+    const int      nv = (u < n_units) ? min(16, max(0, (int)K - 16 * (int)u)) : -1;
+    uint4          X2 = make_uint4(0, 0, 0, 0);
+    if (nv >= 0) {
+        const UnitPairs pa = load_unit_pairs(a.A1, tile_off, lane, u);
+        X2 = *reinterpret_cast<const uint4 *>(a.X2 + unit_off(tile_off, lane, u));
+        uint32_t c1[4];
 #pragma unroll
-    for (int s = 0; s < NSLOT; s++) {
-        const uint32_t u = threadIdx.x + s * blockDim.x;
-        nval[s] = (u < n_units) ? min(16, max(0, (int)K - 16 * (int)u)) : -1;
-        if (nval[s] < 0) continue;
-        int xa[19], c1[16];
-        load_unit_halo(a.A1, tile_off, lane, u, xa);
-        unpack16(*reinterpret_cast<const uint4 *>(a.X2 + unit_off(tile_off, lane, u)), x2[s]);
-#pragma unroll
-        for (int k = 0; k < 16; k++) c1[k] = soft_xor(xa[3 + k], soft_xor(xa[k + 1], xa[k])) & ((k - nval[s]) >> 31); // Steps 2-3; AND-mask: 0 past the end
-        *reinterpret_cast<uint4 *>(sm + 16 * u) = pack16(c1);
+        for (int j = 0; j < 4; j++) { // Steps 2-3; 0 past the block end
+            v2s fe, fo;
+            feedback2(pa, j, fe, fo);
+            c1[j] = (4 * j < nv) ? merge_bytes(sxor2(pa.E[j + 1], fe), sxor2(pa.O[j + 1], fo)) : 0u;
+        }
+        *reinterpret_cast<uint4 *>(sm + 16 * u) = make_uint4(c1[0], c1[1], c1[2], c1[3]);
     }
     __syncthreads();
-    int i1[NSLOT][16], wmax = 0;
-#pragma unroll
-    for (int s = 0; s < NSLOT; s++) {
-        const uint32_t u = threadIdx.x + s * blockDim.x;
-#pragma unroll
-        for (int k = 0; k < 16; k++) i1[s][k] = 0;
-        if (nval[s] > 0) {
-            uint32_t idx[16];
-            load_idx16(pi, u, nval[s], idx, K); // past the block end: slot K (C1 = 0 there)
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                i1[s][k] = sm[idx[k]]; // Step 5
-                wmax     = max(wmax, abs(x2[s][k]) + abs(i1[s][k]));
-            }
-        }
-        if (nval[s] >= 0) *reinterpret_cast<uint4 *>(a.out[0] + unit_off(tile_off, lane, u)) = pack16(i1[s]);
+    uint4 I1 = make_uint4(0, 0, 0, 0);
+    if (nv > 0) {
+        uint32_t idx[16];
+        load_idx16(pi, u, nv, idx, K); // past the block end: slot K (C1 = 0 there)
+        I1 = gather16_bytes(sm, idx);  // Step 5
     }
-    wmax          = block_max_i(wmax, red_i);
+    if (nv >= 0) *reinterpret_cast<uint4 *>(a.out[0] + unit_off(tile_off, lane, u)) = I1;
+    uint32_t w[16], wm = 0; // |q(d2)| + |I1|; both are 0 past the block end
+    if (nv <= 0) X2 = make_uint4(0, 0, 0, 0);
+    abs_sum16(X2, I1, w, wm);
+    const int   wmax = block_max_i((int)wm, red_i);
     const float W = (float)wmax;
     for (uint32_t t = threadIdx.x; t < MTAB_N; t += blockDim.x) mtab[t] = (int8_t)(int)(127.0f * ((float)t / W)); // one division per distinct w
     __syncthreads();
-#pragma unroll
-    for (int s = 0; s < NSLOT; s++) {
-        const uint32_t u = threadIdx.x + s * blockDim.x;
-        if (nval[s] < 0) continue;
-        int m3[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) m3[k] = (int)mtab[abs(x2[s][k]) + abs(i1[s][k])]; // x2 = i1 = 0 past the end -> 0
-        *reinterpret_cast<uint4 *>(a.out[1] + unit_off(tile_off, lane, u)) = pack16(m3);
-    }
+    if (nv >= 0) *reinterpret_cast<uint4 *>(a.out[1] + unit_off(tile_off, lane, u)) = lookup16(mtab, w);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -811,43 +827,57 @@ template <bool GROUP, int NSLOT>
 __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_turbo_vote(VoteArgs a, uint32_t K, uint32_t n_cb, const uint16_t *__restrict__ inv,
                                                     uint8_t *__restrict__ c_bits, GroupDesc g)
 {
-    extern __shared__ __attribute__((aligned(16))) int8_t sm[]; // D1[Kp] | D2[Kp] | (GROUP) bits[Kp]
+    static_assert(NSLOT == 1, "one unit per thread");
+    extern __shared__ __attribute__((aligned(16))) int8_t sm[]; // D12[Kp + 16] (int16: D1 + D2, a zero slot at Kp) | (GROUP) bits[Kp]
     __shared__ uint32_t red_u[8];
     const uint32_t cb = xcd_cb(blockIdx.x, n_cb), tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4;
     if (cb >= n_cb) return;
     const size_t   tile_off = (size_t)tile * Kp * 64;
-    int8_t *d1 = sm, *d2 = sm + Kp, *bits = sm + 2 * Kp;
-    int nval[NSLOT], s0[NSLOT][16]; // s0 = q(d0) + C1, the part of the vote that is not de-interleaved
-    IdxRaw vraw[NSLOT];
+    int8_t        *d12 = sm, *bits = sm + 2 * Kp + 32;
+    const uint32_t u  = threadIdx.x;
+    const int      nv = (u < n_units) ? min(16, max(0, (int)K - 16 * (int)u)) : -1;
+    const IdxRaw   vraw = load_idx_raw(inv, u < n_units ? u : 0, nv, K); // needed after the barrier; requested now
+    v2s            s0e[4], s0o[4]; // s0 = q(d0) + C1, the part of the vote that is not de-interleaved
+    if (threadIdx.x == 0) *reinterpret_cast<uint32_t *>(d12 + 2 * Kp) = 0u; // what a hole of the de-interleaver reads
+    if (nv >= 0) {
+        const UnitPairs pa = load_unit_pairs(a.A1, tile_off, lane, u), pb = load_unit_pairs(a.B1, tile_off, lane, u),
+                        pc = load_unit_pairs(a.B2, tile_off, lane, u);
+        const uint4    x0 = *reinterpret_cast<const uint4 *>(a.X0 + unit_off(tile_off, lane, u));
+        const uint32_t x0w[4] = {x0.x, x0.y, x0.z, x0.w};
+        uint32_t       dn[8]; // D1 + D2 of the unit in natural order, two int16 per word
 #pragma unroll
-    for (int s = 0; s < NSLOT; s++) {
-        const uint32_t u = threadIdx.x + s * blockDim.x;
-        nval[s] = (u < n_units) ? min(16, max(0, (int)K - 16 * (int)u)) : -1;
-        vraw[s] = load_idx_raw(inv, u < n_units ? u : 0, nval[s], K); // needed after the barrier; requested now
-        if (nval[s] < 0) continue;
-        int xa[19], xb[19], xc[19], x0[16], v1[16], v2[16];
-        load_unit_halo(a.A1, tile_off, lane, u, xa);
-        load_unit_halo(a.B1, tile_off, lane, u, xb);
-        load_unit_halo(a.B2, tile_off, lane, u, xc);
-        unpack16(*reinterpret_cast<const uint4 *>(a.X0 + unit_off(tile_off, lane, u)), x0);
+        for (int j = 0; j < 4; j++) {
+            v2s fe, fo, ge, go, he, ho;
+            feedback2(pa, j, fe, fo);
+            feedback2(pb, j, ge, go); // G  = soft_xor(B1[k-2], B1[k-3])
+            feedback2(pc, j, he, ho); // G' = soft_xor(B2[k-2], B2[k-3])
+            v2s d[2];
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int A = xa[3 + k], B = xb[3 + k], G = soft_xor(xb[k + 1], xb[k]), B_ = xc[3 + k], G_ = soft_xor(xc[k + 1], xc[k]);
-            // Step 10 (liblte_phy.cc:10778-10797), as selects: equal signs -> (|B|+|G|)>>1; B >= 0 > G -> -((A - G) >> 1);
-            // B < 0 <= G -> -((-A + G) >> 1) -- the mixed-sign branches read in_act_1 (A), not int_act_1
-            {
-                const int same = (abs(B) + abs(G)) >> 1, t = (B >= 0) ? (A - G) : (G - A);
-                v1[k] = (((B ^ G) >= 0) ? same : -(t >> 1)) & ((k - nval[s]) >> 31); // AND-mask (0 past the block end), not a branch
+            for (int h = 0; h < 2; h++) {
+                const v2s A = h ? pa.O[j + 1] : pa.E[j + 1], B = h ? pb.O[j + 1] : pb.E[j + 1], B_ = h ? pc.O[j + 1] : pc.E[j + 1];
+                const v2s G = h ? go : ge, G_ = h ? ho : he;
+                // Step 10 (liblte_phy.cc:10778-10797), as selects: equal signs -> (|B|+|G|)>>1; B >= 0 > G -> -((A - G) >> 1);
+                // B < 0 <= G -> -((-A + G) >> 1) -- the mixed-sign branches read in_act_1 (A), not int_act_1
+                const v2s sb = B >> 15, dAG = A - G, t = (dAG ^ sb) - sb; // (B >= 0) ? A - G : G - A
+                const v2s same = (abs2(B) + abs2(G)) >> 1, mix = (v2s)(0) - (t >> 1), m = (B ^ G) >> 15;
+                const v2s v1 = (same & ~m) | (mix & m);
+                // Step 11 (liblte_phy.cc:10800-10819): mixed signs -> -((B - G) >> 1) resp. -((-B - G) >> 1), i.e. -((|B| - G) >> 1)
+                const v2s ab = abs2(B_), same_ = (ab + abs2(G_)) >> 1, mix_ = (v2s)(0) - ((ab - G_) >> 1), m_ = (B_ ^ G_) >> 15;
+                const v2s v2 = (same_ & ~m_) | (mix_ & m_);
+                d[h] = v1 + v2;
+                const v2s c1 = sxor2(A, h ? fo : fe); // Steps 2-3
+                (h ? s0o[j] : s0e[j]) = (h ? odd2(x0w[j]) : even2(x0w[j])) + c1;
             }
-            // Step 11 (liblte_phy.cc:10800-10819): mixed signs -> -((B - G) >> 1) resp. -((-B - G) >> 1), i.e. -((|B| - G) >> 1)
-            {
-                const int same = (abs(B_) + abs(G_)) >> 1, t = abs(B_) - G_;
-                v2[k] = (((B_ ^ G_) >= 0) ? same : -(t >> 1)) & ((k - nval[s]) >> 31);
-            }
-            s0[s][k] = x0[k] + soft_xor(A, soft_xor(xa[k + 1], xa[k])); // q(d0) + C1 (Steps 2-3)
+            const bool in = 4 * j < nv; // 0 past the block end (nv is 16, 8 or 0)
+            dn[2 * j]     = in ? __builtin_amdgcn_perm(as_u32(d[1]), as_u32(d[0]), 0x05040100u) : 0u; // (e.lo, o.lo)
+            dn[2 * j + 1] = in ? __builtin_amdgcn_perm(as_u32(d[1]), as_u32(d[0]), 0x07060302u) : 0u; // (e.hi, o.hi)
         }
-        *reinterpret_cast<uint4 *>(d1 + 16 * u) = pack16(v1);
-        *reinterpret_cast<uint4 *>(d2 + 16 * u) = pack16(v2);
+        uint4 *dst = reinterpret_cast<uint4 *>(d12 + 32 * u);
+        dst[0] = make_uint4(dn[0], dn[1], dn[2], dn[3]);
+        dst[1] = make_uint4(dn[4], dn[5], dn[6], dn[7]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) s0e[j] = s0o[j] = (v2s)(0);
     }
     __syncthreads();
     uint32_t alloc = 0, tbs = 0, F = 0, crc = 0;
@@ -856,40 +886,49 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         tbs   = g.allocs[alloc].tbs;
         F     = K - tbs - 24;
     }
+    if (nv > 0) {
+        // Steps 12-14: de-interleave D1 + D2 (a hole contributes 0; past the block end: slot K, where D1 = D2 = 0), add, take the sign
+        const uint32_t  iw[8] = {vraw.lo.x, vraw.lo.y, vraw.lo.z, vraw.lo.w, vraw.hi.x, vraw.hi.y, vraw.hi.z, vraw.hi.w};
+        const uint16_t *dt = reinterpret_cast<const uint16_t *>(d12);
+        uint32_t        me[4], mo[4], bw[4]; // sign masks of the even / odd pairs (0xFFFF per negative sum), the bits one per byte
 #pragma unroll
-    for (int s = 0; s < NSLOT; s++) {
-        const uint32_t u = threadIdx.x + s * blockDim.x;
-        if (nval[s] <= 0) continue;
-        uint32_t idx[16];
-        int      b[16];
-        unpack_idx(vraw[s], idx); // past the block end: slot K (D1 = D2 = 0 there; those bits are never used)
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const uint32_t i = idx[k], ic = (i != 0xFFFFu) ? i : 0u; // Steps 12/13: de-interleave; a hole contributes 0
-            const int t2 = d1[ic], t3 = d2[ic];                        // unconditional reads, masked
-            const int c2 = (i != 0xFFFFu) ? t2 : 0, c3 = (i != 0xFFFFu) ? t3 : 0;
-            b[k] = (s0[s][k] + c2 + c3 < 0) ? 1 : 0; // Step 14
+        for (int j = 0; j < 4; j++) {
+            const uint32_t i0 = min(iw[2 * j] & 0xFFFFu, Kp), i1 = min(iw[2 * j] >> 16, Kp), i2 = min(iw[2 * j + 1] & 0xFFFFu, Kp), i3 = min(iw[2 * j + 1] >> 16, Kp);
+            const uint32_t ge = (uint32_t)dt[i0] | (uint32_t)dt[i2] << 16, go = (uint32_t)dt[i1] | (uint32_t)dt[i3] << 16;
+            me[j] = as_u32((s0e[j] + as_v2s(ge)) >> 15);
+            mo[j] = as_u32((s0o[j] + as_v2s(go)) >> 15);
+            bw[j] = (me[j] & 0x00010001u) | (mo[j] & 0x00010001u) << 8; // Step 14
         }
         if (GROUP) {
             // CRC24A over the block without its F filler bits: bit j of the block weighs x^(K-1-j) mod g (the
             // 24 parity bits weigh themselves), so the check "calc_crc(a) == p" is "XOR of the weights == 0".
             // Weights of this unit = 16 (8) consecutive table entries, descending in j.
-            const int      nv = nval[s];
             const uint4   *tp = reinterpret_cast<const uint4 *>(g.crc_tab + (K - 16 * u - nv)); // 32-byte aligned (K % 8 == 0)
             const uint4    t0 = tp[0], t1 = tp[1], t2 = (nv > 8) ? tp[2] : t0, t3 = (nv > 8) ? tp[3] : t0;
             const uint32_t tw[16] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w, t3.x, t3.y, t3.z, t3.w};
+            if (nv == 16 && 16 * u >= F) { // a whole unit of payload: no per-bit predicate
 #pragma unroll
-            for (int k = 0; k < 16; k++) { // static register indices only: nv is 16, or 8 in the last unit of a K % 16 == 8 block
-                const uint32_t wgt = (nv > 8) ? tw[15 - k] : tw[(7 - k) & 15];
-                crc ^= (b[k] && 16 * u + k >= F && k < nv) ? wgt : 0u;
+                for (int j = 0; j < 4; j++) {
+                    crc ^= tw[15 - 4 * j] & (uint32_t)__builtin_amdgcn_sbfe(me[j], 0, 1);
+                    crc ^= tw[14 - 4 * j] & (uint32_t)__builtin_amdgcn_sbfe(mo[j], 0, 1);
+                    crc ^= tw[13 - 4 * j] & (uint32_t)((int)me[j] >> 31);
+                    crc ^= tw[12 - 4 * j] & (uint32_t)((int)mo[j] >> 31);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k++) { // static register indices only: nv is 16, or 8 in the last unit of a K % 16 == 8 block
+                    const uint32_t wgt = (nv > 8) ? tw[15 - k] : tw[(7 - k) & 15];
+                    const bool     b   = (bw[k >> 2] >> (8 * (k & 3))) & 1u;
+                    crc ^= (b && 16 * u + k >= F && k < nv) ? wgt : 0u;
+                }
             }
         }
-        const uint4 pk = pack16(b);
+        const uint4 pk = make_uint4(bw[0], bw[1], bw[2], bw[3]);
         if (GROUP) *reinterpret_cast<uint4 *>(bits + 16 * u) = pk;
         else {
             uint2 *o = reinterpret_cast<uint2 *>(c_bits + (size_t)cb * K + 16 * u); // 8-byte aligned (K % 8 == 0)
             o[0] = make_uint2(pk.x, pk.y);
-            if (nval[s] > 8) o[1] = make_uint2(pk.z, pk.w);
+            if (nv > 8) o[1] = make_uint2(pk.z, pk.w);
         }
     }
     if (GROUP) {
@@ -1073,7 +1112,7 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
     MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso, dim3(n_tiles, 2), dim3(64), 0, s23, K, 1u);
 
     VoteArgs va = {arr[AX0], arr[AA1], arr[AB1], arr[AB2]};
-    MI_LAUNCH(ctx, "k_turbo_vote", (k_turbo_vote<GROUP, 1>), dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), 3 * Kp, va, K, n_cb, tb.d_inv, d_c_bits, gd);
+    MI_LAUNCH(ctx, "k_turbo_vote", (k_turbo_vote<GROUP, 1>), dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), 3 * Kp + 32, va, K, n_cb, tb.d_inv, d_c_bits, gd);
     MI_HIP_CHECK(ctx, hipGetLastError());
     ctx->last_kernels = "k_turbo_prep:1,k_turbo_siso:2,k_turbo_perm:1,k_turbo_vote:1";
     return MI_LTE_OK;

@@ -87,7 +87,7 @@ __device__ __forceinline__ void fft_pass(const float2 *__restrict__ tw, uint32_t
     for (uint32_t j = threadIdx.x; j < nb; j += blockDim.x) {
         float2 v[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) v[r] = load(j + r * nb);
+        for (int r = 0; r < R; r++) v[r] = load(j, r, nb);
         const uint32_t k = j & (Ns - 1);
         if (Ns > 1) {
             float2 w[8];
@@ -125,12 +125,15 @@ template <> struct SampleSrc<float> { // planar i_samps / q_samps as the referen
 // One workgroup per (symbol, unit).  (A persistent variant -- one workgroup walking all symbols of its unit with the next symbol's
 // samples prefetched -- was measured slower on the MI355X, 9.5 vs 6.5 ms per 64k subframes: the compiler hoists the twiddles
 // out of the symbol loop and the register count collapses the occupancy; it is not kept.)
-template <typename T, bool RAW = false>
+// The transform length is a template parameter: with N fixed every LDS address of the passes is one per-thread base plus an
+// immediate offset (pad() of a sum splits into constants), which takes a fifth of the kernel's vector instructions away.
+template <typename T, bool RAW, uint32_t NT>
 __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t *__restrict__ unit_start, DlGeom g,
                                                 const float2 *__restrict__ tw, float *__restrict__ subframes)
 {
     extern __shared__ __attribute__((aligned(16))) float2 buf[]; // pad(N) entries
-    const uint32_t unit = blockIdx.y, N = g.N, nb = N / 8, j = threadIdx.x, half = g.half;
+    constexpr uint32_t N = NT, nb = N / 8;
+    const uint32_t unit = blockIdx.y, j = threadIdx.x, half = g.half;
     const bool     act = j < nb; // one radix-8 butterfly per thread (N <= 2048)
     const size_t   ustart = unit_start[unit];
     // window start: slot start + symbol offset + CP - 1  (one sample early: liblte_phy.cc:8621)
@@ -147,7 +150,12 @@ __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t
             for (int r = 0; r < 8; r++) v[r] = src.raw(f + j + r * nb);
         }
     };
-    auto ld_s = [&](uint32_t i) { return buf[pad(i)]; };
+    // element base + r * stride of the padded buffer: when the stride is a multiple of the padding period the pad of the sum splits,
+    // so the R accesses of a butterfly are one address and R immediate offsets
+    auto at = [&](uint32_t base, uint32_t r, uint32_t stride) -> float2 & {
+        return (stride % 32 == 0) ? buf[pad(base) + r * (stride + stride / 32)] : buf[pad(base + r * stride)];
+    };
+    auto ld_s = [&](uint32_t base, uint32_t r, uint32_t stride) { return at(base, r, stride); };
     const uint32_t dc = g.ul ? 0u : 1u; // downlink skips the DC bin, the half-shifted uplink grid has none
 
     const uint32_t sym = blockIdx.x;
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t
             float2 v[8];
             if (act) {
 #pragma unroll
-                for (int r = 0; r < 8; r++) v[r] = buf[pad(j + r * nb)];
+                for (int r = 0; r < 8; r++) v[r] = at(j, r, nb);
             }
             __syncthreads();
             if (act) {
@@ -191,9 +199,10 @@ __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t
 #pragma unroll
                 for (int r = 1; r < 8; r++) v[r] = cmul(v[r], w[r]);
                 dft8(v);
-                const uint32_t j0 = (j - k) * 8 + k;
+                // j0 = 8 (j - k) + k with k < 8 and j - k a multiple of 8: (j0 + 8 r) >> 5 = (j - k) / 4 + (r >> 2)
+                const uint32_t j0 = (j - k) * 8 + k, pj0 = j0 + ((j - k) >> 2);
 #pragma unroll
-                for (int r = 0; r < 8; r++) buf[pad(j0 + r * Ns)] = v[r];
+                for (int r = 0; r < 8; r++) buf[pj0 + 8 * r + (r >> 2)] = v[r];
             }
             Ns *= 8;
         }
@@ -206,7 +215,7 @@ __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t
                 float2 v[8];
                 if (act) {
 #pragma unroll
-                    for (int r = 0; r < 8; r++) v[r] = buf[pad(j + r * nb)];
+                    for (int r = 0; r < 8; r++) v[r] = at(j, r, nb);
                 }
                 __syncthreads();
                 if (act) {
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t
                     dft8(v);
                     const uint32_t j0 = (j - k) * 8 + k;
 #pragma unroll
-                    for (int r = 0; r < 8; r++) buf[pad(j0 + r * Ns)] = v[r];
+                    for (int r = 0; r < 8; r++) at(j0, r, 64) = v[r]; // Ns = 64 here
                 }
                 Ns *= 8;
             }
@@ -228,6 +237,17 @@ __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t
         }
     }
 }
+
+// one instantiation per LTE transform length
+#define FFT_LAUNCH(name, T, RAW, grid, ...)                                                                                        \
+    switch (g.N) {                                                                                                                 \
+    case 2048: MI_LAUNCH(ctx, name, (k_dl_fft<T, RAW, 2048>), grid, dim3(256), lds_fft, __VA_ARGS__); break;                       \
+    case 1024: MI_LAUNCH(ctx, name, (k_dl_fft<T, RAW, 1024>), grid, dim3(256), lds_fft, __VA_ARGS__); break;                       \
+    case 512:  MI_LAUNCH(ctx, name, (k_dl_fft<T, RAW, 512>), grid, dim3(256), lds_fft, __VA_ARGS__); break;                        \
+    case 256:  MI_LAUNCH(ctx, name, (k_dl_fft<T, RAW, 256>), grid, dim3(256), lds_fft, __VA_ARGS__); break;                        \
+    case 128:  MI_LAUNCH(ctx, name, (k_dl_fft<T, RAW, 128>), grid, dim3(256), lds_fft, __VA_ARGS__); break;                        \
+    default: return MI_LTE_ERR_INVALID_ARG;                                                                                        \
+    }
 
 // ------------------------------------------------------------------------------------------------
 // channel estimation
@@ -482,11 +502,11 @@ extern "C" int mi_lte_dl_frontend_batch(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cf
     const size_t lds_fft = sizeof(float2) * (g.N + g.N / 32 + 1);
     if (cfg->sample_format == MI_LTE_IQ_I8) {
         SampleSrc<int8_t> s{(const int8_t *)d_samples_a};
-        MI_LAUNCH(ctx, "k_dl_fft", (k_dl_fft<int8_t>), dim3(16, n_units), dim3(256), lds_fft, s, d_unit_start, g, ctx->d_fft_tw, d_subframes);
+        FFT_LAUNCH("k_dl_fft", int8_t, false, dim3(16, n_units), s, d_unit_start, g, ctx->d_fft_tw, d_subframes);
     } else if (cfg->sample_format == MI_LTE_IQ_F32_PLANAR) {
         if (!d_samples_b) return MI_LTE_ERR_INVALID_ARG;
         SampleSrc<float> s{(const float *)d_samples_a, (const float *)d_samples_b};
-        MI_LAUNCH(ctx, "k_dl_fft", (k_dl_fft<float>), dim3(16, n_units), dim3(256), lds_fft, s, d_unit_start, g, ctx->d_fft_tw, d_subframes);
+        FFT_LAUNCH("k_dl_fft", float, false, dim3(16, n_units), s, d_unit_start, g, ctx->d_fft_tw, d_subframes);
     } else
         return MI_LTE_ERR_INVALID_ARG;
     GoldTables gt{ctx->d_gold_x1, ctx->d_gold_x2b, ctx->gold_words};
@@ -513,11 +533,11 @@ int mi_fft_rows(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const void *d_samples
     const size_t lds_fft = sizeof(float2) * (g.N + g.N / 32 + 1);
     if (cfg->sample_format == MI_LTE_IQ_I8) {
         SampleSrc<int8_t> s{(const int8_t *)d_samples_a};
-        MI_LAUNCH(ctx, "k_sync_fft", (k_dl_fft<int8_t, true>), dim3(1, n_rows), dim3(256), lds_fft, s, d_win_start, g, ctx->d_fft_tw, d_rows);
+        FFT_LAUNCH("k_sync_fft", int8_t, true, dim3(1, n_rows), s, d_win_start, g, ctx->d_fft_tw, d_rows);
     } else {
         if (!d_samples_b) return MI_LTE_ERR_INVALID_ARG;
         SampleSrc<float> s{(const float *)d_samples_a, (const float *)d_samples_b};
-        MI_LAUNCH(ctx, "k_sync_fft", (k_dl_fft<float, true>), dim3(1, n_rows), dim3(256), lds_fft, s, d_win_start, g, ctx->d_fft_tw, d_rows);
+        FFT_LAUNCH("k_sync_fft", float, true, dim3(1, n_rows), s, d_win_start, g, ctx->d_fft_tw, d_rows);
     }
     MI_HIP_CHECK(ctx, hipGetLastError());
     return MI_LTE_OK;
@@ -545,11 +565,11 @@ extern "C" int mi_lte_ul_frontend_batch(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cf
     const size_t lds_fft = sizeof(float2) * (g.N + g.N / 32 + 1);
     if (cfg->sample_format == MI_LTE_IQ_I8) {
         SampleSrc<int8_t> s{(const int8_t *)d_samples_a};
-        MI_LAUNCH(ctx, "k_ul_fft", (k_dl_fft<int8_t>), dim3(14, n_units), dim3(256), lds_fft, s, d_unit_start, g, ctx->d_fft_tw, d_subframes);
+        FFT_LAUNCH("k_ul_fft", int8_t, false, dim3(14, n_units), s, d_unit_start, g, ctx->d_fft_tw, d_subframes);
     } else if (cfg->sample_format == MI_LTE_IQ_F32_PLANAR) {
         if (!d_samples_b) return MI_LTE_ERR_INVALID_ARG;
         SampleSrc<float> s{(const float *)d_samples_a, (const float *)d_samples_b};
-        MI_LAUNCH(ctx, "k_ul_fft", (k_dl_fft<float>), dim3(14, n_units), dim3(256), lds_fft, s, d_unit_start, g, ctx->d_fft_tw, d_subframes);
+        FFT_LAUNCH("k_ul_fft", float, false, dim3(14, n_units), s, d_unit_start, g, ctx->d_fft_tw, d_subframes);
     } else
         return MI_LTE_ERR_INVALID_ARG;
     MI_HIP_CHECK(ctx, hipGetLastError());

@@ -576,6 +576,22 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(PREP_WPE, 8
 //   ACS (liblte_phy.cc:10454-10463): take k=1 iff beta + PM[p0] > -beta + PM[p1]
 //                                    <=>  PM[p1] - PM[p0] < 2*beta; new PM = PM[pk] +- w*beta.
 //   Traceback (liblte_phy.cc:10484-10497) re-compares the STORED metrics: bit_j = PM[2j] > PM[2j+1].
+//
+// Two trellises per lane.  The comparisons of the reference -- PM[p1] - PM[p0] against 2*beta in the ACS, PM[2j] > PM[2j+1] in the
+// traceback, the minimum over the end states -- only ever look at DIFFERENCES of path metrics, and those stay small: the ACS takes
+// the predecessor with the lower stored metric up to a slack of |2*beta| <= 4 and moves it by |w*beta| <= 508, and every state is
+// reached from every state in three steps, so at any time max PM - min PM <= 3*512 + 3*508 < 2^15.  The metrics themselves grow
+// without bound in the reference's ints, but kept modulo 2^16 every difference of two of them is still exact.  That lets one lane
+// walk two independent trellises in the halves of its registers (v_pk_*_i16): two tiles of the first pass, or passes 2 and 3 of the
+// same tile (which share their first input, q(d2)).
+typedef short v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2s      as_v2s(uint32_t w) { return __builtin_bit_cast(v2s, w); }
+__device__ __forceinline__ uint32_t as_u32(v2s v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ v2s      even2(uint32_t w) { return (as_v2s(w) << 8) >> 8; }
+__device__ __forceinline__ v2s      odd2(uint32_t w) { return as_v2s(w) >> 8; }
+__device__ __forceinline__ uint32_t merge_bytes(v2s e, v2s o) { return __builtin_amdgcn_perm(as_u32(o), as_u32(e), 0x06020400u); } // low bytes of (e.lo, o.lo, e.hi, o.hi)
+__device__ __forceinline__ v2s      abs2(v2s a) { return __builtin_elementwise_max(a, (v2s)(0) - a); }
+
 struct SisoPass {
     const uint8_t *in_a; // first soft value of each pair  (in[2t])
     const uint8_t *in_b; // second soft value of each pair (in[2t+1])
@@ -585,156 +601,212 @@ struct SisoPass {
 };
 struct SisoArgs { SisoPass p[2]; };
 
-__device__ __forceinline__ void acs_step(int (&pm)[8], int x, int y, uint32_t &acc)
+typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t sign_bits(v2s n) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(v2u, n) >> 15); } // 1 per negative half
+
+// one trellis step of both halves.  x, y: the step's two soft inputs as int16 pairs; acc: the traceback bits of the current four
+// steps, 16 bits per half (bit = PM[2j] > PM[2j+1] = sign of n_j, j = 0 first)
+__device__ __forceinline__ void acs_step2(v2s (&pm)[8], v2s x, v2s y, uint32_t &acc)
 {
     // With w = |x|+|y| and e = +1 for a negative soft value:  w*P = -2(x+y) if the two signs agree, else 0;
     // w*Q = -2(x-y) if they differ, else 0;  2P, 2Q = +-4 (sign of x) under the same conditions.
-    // Only adds, logic ops and selects remain (v_mad_i32_i24 runs at a quarter of the add rate on gfx950).
-    const int m0 = x >> 31, mx = m0 ^ (y >> 31), nmx = ~mx; // mx = -1 iff the signs differ
-    const int uP = ((x + y) << 1) & nmx;                    // -w*P
-    const int uQ = ((x - y) << 1) & mx;                     // -w*Q
-    const int c4 = (m0 & 8) - 4;                            // x < 0 ? 4 : -4
-    const int P2 = c4 & nmx, Q2 = c4 & mx, nP2 = -P2, nQ2 = -Q2;
-    const int n0 = pm[1] - pm[0], n1 = pm[3] - pm[2], n2 = pm[5] - pm[4], n3 = pm[7] - pm[6];
-    // traceback bits for this time index (bit = PM[2j] > PM[2j+1] = sign bit of n_j), j = 0 first
-    acc = __builtin_amdgcn_alignbit(acc, (uint32_t)n0, 31);
-    acc = __builtin_amdgcn_alignbit(acc, (uint32_t)n1, 31);
-    acc = __builtin_amdgcn_alignbit(acc, (uint32_t)n2, 31);
-    acc = __builtin_amdgcn_alignbit(acc, (uint32_t)n3, 31);
-    int nw[8];
-    nw[0] = (n0 < P2) ? pm[1] + uP : pm[0] - uP;  // beta =  P
-    nw[4] = (n0 < nP2) ? pm[1] - uP : pm[0] + uP; // beta = -P
-    nw[1] = (n1 < Q2) ? pm[3] + uQ : pm[2] - uQ;  // beta =  Q
-    nw[5] = (n1 < nQ2) ? pm[3] - uQ : pm[2] + uQ; // beta = -Q
-    nw[2] = (n2 < nQ2) ? pm[5] - uQ : pm[4] + uQ; // beta = -Q
-    nw[6] = (n2 < Q2) ? pm[5] + uQ : pm[4] - uQ;  // beta =  Q
-    nw[3] = (n3 < nP2) ? pm[7] - uP : pm[6] + uP; // beta = -P
-    nw[7] = (n3 < P2) ? pm[7] + uP : pm[6] - uP;  // beta =  P
+    const v2s m0 = x >> 15, mx = m0 ^ (y >> 15), nmx = ~mx; // mx = -1 iff the signs differ
+    const v2s uP = ((x + y) << 1) & nmx;                    // -w*P
+    const v2s uQ = ((x - y) << 1) & mx;                     // -w*Q
+    const v2s c4 = (m0 & (v2s)(8)) - (v2s)(4);              // x < 0 ? 4 : -4
+    const v2s P2 = c4 & nmx, Q2 = c4 & mx;
+    const v2s n0 = pm[1] - pm[0], n1 = pm[3] - pm[2], n2 = pm[5] - pm[4], n3 = pm[7] - pm[6];
+    // (acc << 1) | sign, both halves in one 32-bit operation: a half never holds more than its 16 bits
+    acc = (acc << 1) | sign_bits(n0);
+    acc = (acc << 1) | sign_bits(n1);
+    acc = (acc << 1) | sign_bits(n2);
+    acc = (acc << 1) | sign_bits(n3);
+    // d < 0 ? yes : no per half, as sign mask + bit select; the mask is made opaque because the compiler otherwise turns the
+    // pattern back into per-half compares and selects, which costs twice the instructions
+    auto sel = [](v2s d, v2s yes, v2s no) {
+        uint32_t m;
+        asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(m) : "v"(as_u32(d))); // the inline constant has no upper half
+        return as_v2s((as_u32(yes) & m) | (as_u32(no) & ~m));
+    };
+    v2s nw[8];
+    nw[0] = sel(n0 - P2, pm[1] + uP, pm[0] - uP); // beta =  P: (n0 <  P2) ? ..
+    nw[4] = sel(n0 + P2, pm[1] - uP, pm[0] + uP); // beta = -P: (n0 < -P2) ? ..
+    nw[1] = sel(n1 - Q2, pm[3] + uQ, pm[2] - uQ); // beta =  Q
+    nw[5] = sel(n1 + Q2, pm[3] - uQ, pm[2] + uQ); // beta = -Q
+    nw[2] = sel(n2 + Q2, pm[5] - uQ, pm[4] + uQ); // beta = -Q
+    nw[6] = sel(n2 - Q2, pm[5] + uQ, pm[4] - uQ); // beta =  Q
+    nw[3] = sel(n3 + P2, pm[7] - uP, pm[6] + uP); // beta = -P
+    nw[7] = sel(n3 - P2, pm[7] + uP, pm[6] - uP); // beta =  P
 #pragma unroll
     for (int s = 0; s < 8; s++) pm[s] = nw[s];
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_turbo_siso(SisoArgs args, uint32_t K, uint32_t pass_base)
+// byte r of the two words, sign-extended, as the pair (lo: word0, hi: word1)
+template <int R> __device__ __forceinline__ v2s byte_pair(uint32_t w0, uint32_t w1)
 {
-    const SisoPass &ps   = args.p[blockIdx.y];
-    const uint32_t  tile = blockIdx.x, lane = threadIdx.x, Kp = kpad64(K), nblk = Kp >> 6;
-    const size_t    tile_off = (size_t)tile * Kp * 64 + lane * 64;
-    const uint8_t  *pa = ps.in_a + tile_off, *pb = ps.in_b + tile_off;
-    uint32_t       *dec = ps.dec + ((size_t)tile * nblk * 64 + lane) * 8;
-    (void)pass_base;
+    return as_v2s(__builtin_amdgcn_perm(w1, w0, (uint32_t)(4 + R) << 24 | 0x0C0000u | (uint32_t)R << 8 | 0x0Cu)) >> 8;
+}
 
-    int pm[8];
+// grid.x = workgroups of one wavefront; mode 0: trellis h of workgroup b is tile 2b + h of pass p[0] (first pass, two tiles per
+// lane); mode 1: trellis h is tile b of pass p[h] (passes 2 and 3 of one tile)
+__global__ __launch_bounds__(64) void k_turbo_siso(SisoArgs args, uint32_t K, uint32_t n_tiles, uint32_t mode)
+{
+    const uint32_t lane = threadIdx.x, Kp = kpad64(K), nblk = Kp >> 6;
+    const uint8_t *pa[2], *pb[2], *pmag[2];
+    uint8_t       *pout[2];
+    uint32_t      *dec[2];
 #pragma unroll
-    for (int s = 0; s < 8; s++) pm[s] = 0; // all path metrics start at 0 (liblte_phy.cc:10411-10418)
-
-    // ---- forward add-compare-select; the next block's 2 x 64 B are requested before this block's
-    // 64 trellis steps are walked, so the HBM latency hides under ~3k instructions
-    uint4 A[4], B[4], An[4], Bn[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        A[q] = reinterpret_cast<const uint4 *>(pa)[q];
-        B[q] = reinterpret_cast<const uint4 *>(pb)[q];
+    for (int h = 0; h < 2; h++) {
+        const SisoPass &ps   = args.p[mode ? h : 0];
+        const uint32_t  tile = mode ? blockIdx.x : min(2 * blockIdx.x + h, n_tiles - 1); // an odd tile count: the last one twice
+        const size_t    off  = (size_t)tile * Kp * 64 + lane * 64;
+        pa[h] = ps.in_a + off; pb[h] = ps.in_b + off; pmag[h] = ps.mag + off; pout[h] = ps.out + off;
+        dec[h] = ps.dec + ((size_t)tile * nblk * 64 + lane) * 8;
     }
-    for (uint32_t blk = 0; blk < nblk; blk++) {
-        const uint32_t nxt = (blk + 1 < nblk) ? blk + 1 : blk;
+
+    v2s pm[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) pm[s] = (v2s)(0); // all path metrics start at 0 (liblte_phy.cc:10411-10418)
+
+    // ---- forward add-compare-select.  A block is 64 steps = one 64-byte line per input and trellis, held as four quarters; a
+    // quarter's registers are refilled with the next block's data as soon as its 16 steps are done, so the loads run
+    // three quarters of a block ahead
+    uint4 A[2][4], B[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; h++)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            An[q] = reinterpret_cast<const uint4 *>(pa + (size_t)nxt * 4096)[q];
-            Bn[q] = reinterpret_cast<const uint4 *>(pb + (size_t)nxt * 4096)[q];
+            A[h][q] = reinterpret_cast<const uint4 *>(pa[h])[q];
+            B[h][q] = reinterpret_cast<const uint4 *>(pb[h])[q];
         }
-        uint32_t dw[8];
+    for (uint32_t blk = 0; blk < nblk; blk++) {
+        const uint32_t nxt = (blk + 1 < nblk) ? blk + 1 : blk;
+        uint32_t       dw[2][8];
 #pragma unroll
-        for (int g = 0; g < 8; g++) { // 8 groups of 8 steps = one decision word each
-            uint32_t acc = 0;
-            if (blk * 64 + g * 8 < K) { // uniform: K is a multiple of 8
-                const uint4    a4 = A[g >> 1], b4 = B[g >> 1];
-                const uint32_t a_lo = (g & 1) ? a4.z : a4.x, a_hi = (g & 1) ? a4.w : a4.y;
-                const uint32_t b_lo = (g & 1) ? b4.z : b4.x, b_hi = (g & 1) ? b4.w : b4.y;
+        for (int q = 0; q < 4; q++) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) acs_step(pm, sbyte(a_lo, r), sbyte(b_lo, r), acc);
-#pragma unroll
-                for (int r = 0; r < 4; r++) acs_step(pm, sbyte(a_hi, r), sbyte(b_hi, r), acc);
+            for (int g2 = 0; g2 < 2; g2++) { // 2 groups of 8 steps = one decision word per trellis each
+                const int g = 2 * q + g2;
+                uint32_t  acc_lo = 0, acc_hi = 0; // steps 0-3 / 4-7 of the group, 16 bits per trellis
+                if (blk * 64 + g * 8 < K) {       // uniform: K is a multiple of 8
+                    const uint32_t a0l = g2 ? A[0][q].z : A[0][q].x, a0h = g2 ? A[0][q].w : A[0][q].y;
+                    const uint32_t a1l = g2 ? A[1][q].z : A[1][q].x, a1h = g2 ? A[1][q].w : A[1][q].y;
+                    const uint32_t b0l = g2 ? B[0][q].z : B[0][q].x, b0h = g2 ? B[0][q].w : B[0][q].y;
+                    const uint32_t b1l = g2 ? B[1][q].z : B[1][q].x, b1h = g2 ? B[1][q].w : B[1][q].y;
+                    acs_step2(pm, byte_pair<0>(a0l, a1l), byte_pair<0>(b0l, b1l), acc_lo);
+                    acs_step2(pm, byte_pair<1>(a0l, a1l), byte_pair<1>(b0l, b1l), acc_lo);
+                    acs_step2(pm, byte_pair<2>(a0l, a1l), byte_pair<2>(b0l, b1l), acc_lo);
+                    acs_step2(pm, byte_pair<3>(a0l, a1l), byte_pair<3>(b0l, b1l), acc_lo);
+                    acs_step2(pm, byte_pair<0>(a0h, a1h), byte_pair<0>(b0h, b1h), acc_hi);
+                    acs_step2(pm, byte_pair<1>(a0h, a1h), byte_pair<1>(b0h, b1h), acc_hi);
+                    acs_step2(pm, byte_pair<2>(a0h, a1h), byte_pair<2>(b0h, b1h), acc_hi);
+                    acs_step2(pm, byte_pair<3>(a0h, a1h), byte_pair<3>(b0h, b1h), acc_hi);
+                }
+                dw[0][g] = __builtin_amdgcn_perm(acc_lo, acc_hi, 0x05040100u); // steps 0-3 in the upper half, 4-7 in the lower
+                dw[1][g] = __builtin_amdgcn_perm(acc_lo, acc_hi, 0x07060302u);
             }
-            dw[g] = acc;
-        }
-        uint4 *dp = reinterpret_cast<uint4 *>(dec + (size_t)blk * 64 * 8);
-        dp[0] = make_uint4(dw[0], dw[1], dw[2], dw[3]);
-        dp[1] = make_uint4(dw[4], dw[5], dw[6], dw[7]);
 #pragma unroll
-        for (int q = 0; q < 4; q++) { A[q] = An[q]; B[q] = Bn[q]; }
+            for (int h = 0; h < 2; h++) {
+                A[h][q] = reinterpret_cast<const uint4 *>(pa[h] + (size_t)nxt * 4096)[q];
+                B[h][q] = reinterpret_cast<const uint4 *>(pb[h] + (size_t)nxt * 4096)[q];
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            uint4 *dp = reinterpret_cast<uint4 *>(dec[h] + (size_t)blk * 64 * 8);
+            dp[0] = make_uint4(dw[h][0], dw[h][1], dw[h][2], dw[h][3]);
+            dp[1] = make_uint4(dw[h][4], dw[h][5], dw[h][6], dw[h][7]);
+        }
     }
 
-    // ---- end state: first strict minimum (liblte_phy.cc:10467-10481)
-    int cur = 0, best = pm[0];
-#pragma unroll
-    for (int s = 1; s < 8; s++)
-        if (pm[s] < best) { best = pm[s]; cur = s; }
-
-    // ---- traceback + signed soft output (liblte_phy.cc:10483-10527)
-    const uint8_t *pmag = ps.mag + tile_off;
-    uint8_t       *pout = ps.out + tile_off;
-    uint4 M[4], Mn[4], d0, d1, d0n, d1n;
+    // ---- end state: first strict minimum (liblte_phy.cc:10467-10481), on the metrics relative to state 0
+    int cur[2] = {0, 0};
     {
-        const uint4 *dp = reinterpret_cast<const uint4 *>(dec + (size_t)(nblk - 1) * 64 * 8);
-        d0 = dp[0];
-        d1 = dp[1];
+        int best[2] = {0, 0};
 #pragma unroll
-        for (int q = 0; q < 4; q++) M[q] = reinterpret_cast<const uint4 *>(pmag + (size_t)(nblk - 1) * 4096)[q];
+        for (int s = 1; s < 8; s++) {
+            const uint32_t d  = as_u32(pm[s] - pm[0]);
+            const int      dh[2] = {(int)__builtin_amdgcn_sbfe(d, 0, 16), (int)d >> 16};
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+                if (dh[h] < best[h]) { best[h] = dh[h]; cur[h] = s; }
+        }
+    }
+
+    // ---- traceback + signed soft output (liblte_phy.cc:10483-10527), the two trellises interleaved
+    uint4 M[2][4], Mn[2][4], D[2][2], Dn[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint4 *dp = reinterpret_cast<const uint4 *>(dec[h] + (size_t)(nblk - 1) * 64 * 8);
+        D[h][0] = dp[0];
+        D[h][1] = dp[1];
+#pragma unroll
+        for (int q = 0; q < 4; q++) M[h][q] = reinterpret_cast<const uint4 *>(pmag[h] + (size_t)(nblk - 1) * 4096)[q];
     }
     for (int blk = (int)nblk - 1; blk >= 0; blk--) {
-        const int    prv = blk > 0 ? blk - 1 : 0; // prefetch the block below while this one is traced back
-        const uint4 *dpn = reinterpret_cast<const uint4 *>(dec + (size_t)prv * 64 * 8);
-        d0n = dpn[0];
-        d1n = dpn[1];
+        const int prv = blk > 0 ? blk - 1 : 0; // prefetch the block below while this one is traced back
 #pragma unroll
-        for (int q = 0; q < 4; q++) Mn[q] = reinterpret_cast<const uint4 *>(pmag + (size_t)prv * 4096)[q];
-        uint32_t     dw[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-        uint32_t mw[16] = {M[0].x, M[0].y, M[0].z, M[0].w, M[1].x, M[1].y, M[1].z, M[1].w,
-                           M[2].x, M[2].y, M[2].z, M[2].w, M[3].x, M[3].y, M[3].z, M[3].w};
-        uint32_t ow[16];
+        for (int h = 0; h < 2; h++) {
+            const uint4 *dpn = reinterpret_cast<const uint4 *>(dec[h] + (size_t)prv * 64 * 8);
+            Dn[h][0] = dpn[0];
+            Dn[h][1] = dpn[1];
 #pragma unroll
-        for (int g = 7; g >= 0; g--) {
-            uint32_t o_hi = 0, o_lo = 0;
-            if ((uint32_t)blk * 64 + g * 8 < K) {
-                const uint32_t word = dw[g];
-#pragma unroll
-                for (int r = 7; r >= 0; r--) {
-                    // bits of step r sit in nibble (7-r); pair j is bit (3-j) of the nibble
-                    const int j   = cur & 3;
-                    const int bit = (word >> (4 * (7 - r) + (3 - j))) & 1;
-                    const int st  = 2 * j + bit; // state at time t
-                    const int m   = sbyte(mw[g * 2 + (r >> 2)], r & 3);
-                    // output bit 0 ("+") when the step moved to a lower state, or stayed in state 0
-                    const bool pos = (cur < st) || (cur == st && cur == 0);
-                    const int  v   = pos ? m : -m;
-                    if (r >= 4) o_hi |= ((uint32_t)(v & 0xFF)) << (8 * (r - 4));
-                    else        o_lo |= ((uint32_t)(v & 0xFF)) << (8 * r);
-                    cur = st;
-                }
-            }
-            ow[g * 2]     = o_lo;
-            ow[g * 2 + 1] = o_hi;
+            for (int q = 0; q < 4; q++) Mn[h][q] = reinterpret_cast<const uint4 *>(pmag[h] + (size_t)prv * 4096)[q];
         }
-        uint4 *op = reinterpret_cast<uint4 *>(pout + (size_t)blk * 4096);
 #pragma unroll
-        for (int q = 0; q < 4; q++) op[q] = make_uint4(ow[4 * q], ow[4 * q + 1], ow[4 * q + 2], ow[4 * q + 3]);
-        d0 = d0n;
-        d1 = d1n;
+        for (int q = 3; q >= 0; q--) {
+            uint32_t ow[2][4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) M[q] = Mn[q];
+            for (int g2 = 1; g2 >= 0; g2--) {
+                const int g = 2 * q + g2;
+                uint32_t  o_hi[2] = {0, 0}, o_lo[2] = {0, 0};
+                if ((uint32_t)blk * 64 + g * 8 < K) {
+                    uint32_t word[2], mlo[2], mhi[2];
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const uint4 dq = D[h][g >> 2];
+                        word[h] = (g & 3) == 0 ? dq.x : (g & 3) == 1 ? dq.y : (g & 3) == 2 ? dq.z : dq.w;
+                        mlo[h]  = g2 ? M[h][q].z : M[h][q].x;
+                        mhi[h]  = g2 ? M[h][q].w : M[h][q].y;
+                    }
+#pragma unroll
+                    for (int r = 7; r >= 0; r--) {
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            // bits of step r sit in nibble (7-r); pair j is bit (3-j) of the nibble
+                            const int j   = cur[h] & 3;
+                            const int bit = (word[h] >> (4 * (7 - r) + (3 - j))) & 1;
+                            const int st  = 2 * j + bit; // state at time t
+                            const int m   = sbyte(r >= 4 ? mhi[h] : mlo[h], r & 3);
+                            // output bit 0 ("+") when the step moved to a lower state, or stayed in state 0
+                            const bool pos = (cur[h] < st) || (cur[h] == st && cur[h] == 0);
+                            const int  v   = pos ? m : -m;
+                            if (r >= 4) o_hi[h] |= ((uint32_t)(v & 0xFF)) << (8 * (r - 4));
+                            else        o_lo[h] |= ((uint32_t)(v & 0xFF)) << (8 * r);
+                            cur[h] = st;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; h++) { ow[h][2 * g2] = o_lo[h]; ow[h][2 * g2 + 1] = o_hi[h]; }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+                reinterpret_cast<uint4 *>(pout[h] + (size_t)blk * 4096)[q] = make_uint4(ow[h][0], ow[h][1], ow[h][2], ow[h][3]);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            D[h][0] = Dn[h][0];
+            D[h][1] = Dn[h][1];
+#pragma unroll
+            for (int q = 0; q < 4; q++) M[h][q] = Mn[h][q];
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // Two-at-a-time int16 arithmetic for the soft re-encoder and the vote (v_pk_*_i16): a register of four int8 values b0..b3 is
 // split into its even pair (b0, b2) and its odd pair (b1, b3), sign-extended to 16 bits; all element-wise work is done on pairs.
-typedef short v2s __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2s      as_v2s(uint32_t w) { return __builtin_bit_cast(v2s, w); }
-__device__ __forceinline__ uint32_t as_u32(v2s v) { return __builtin_bit_cast(uint32_t, v); }
-__device__ __forceinline__ v2s      even2(uint32_t w) { return (as_v2s(w) << 8) >> 8; }
-__device__ __forceinline__ v2s      odd2(uint32_t w) { return as_v2s(w) >> 8; }
-__device__ __forceinline__ uint32_t merge_bytes(v2s e, v2s o) { return __builtin_amdgcn_perm(as_u32(o), as_u32(e), 0x06020400u); } // low bytes of (e.lo, o.lo, e.hi, o.hi)
-__device__ __forceinline__ v2s      abs2(v2s a) { return __builtin_elementwise_max(a, (v2s)(0) - a); }
 // soft_xor on pairs: sign * ((|a|+|b|) >> 1), sign negative iff exactly one operand is negative
 __device__ __forceinline__ v2s sxor2(v2s a, v2s b)
 {
@@ -1100,7 +1172,7 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
     SisoArgs s1;
     s1.p[0] = {arr[AX1], arr[AX0], arr[AM1], arr[AA1], dec[0]};
     s1.p[1] = s1.p[0];
-    MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso, dim3(n_tiles, 1), dim3(64), 0, s1, K, 0u);
+    MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso, dim3((n_tiles + 1) / 2), dim3(64), 0, s1, K, (uint32_t)n_tiles, 0u); // two tiles per lane
 
     PermArgs pa;
     pa.A1 = arr[AA1]; pa.X2 = arr[AX2]; pa.out[0] = arr[AI1]; pa.out[1] = arr[AM3];
@@ -1109,7 +1181,7 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
     SisoArgs s23;
     s23.p[0] = {arr[AX2], arr[AI0], arr[AM2], arr[AB1], dec[1]};
     s23.p[1] = {arr[AX2], arr[AI1], arr[AM3], arr[AB2], dec[2]};
-    MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso, dim3(n_tiles, 2), dim3(64), 0, s23, K, 1u);
+    MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso, dim3(n_tiles), dim3(64), 0, s23, K, (uint32_t)n_tiles, 1u); // passes 2 and 3 of a tile per lane
 
     VoteArgs va = {arr[AX0], arr[AA1], arr[AB1], arr[AB2]};
     MI_LAUNCH(ctx, "k_turbo_vote", (k_turbo_vote<GROUP, 1>), dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), 3 * Kp + 32, va, K, n_cb, tb.d_inv, d_c_bits, gd);

@@ -56,7 +56,7 @@ class TurboWorkload:
     name = "turbo"
     K = 6144
     unit = "Mbit/s"
-    dtype = "i8 soft values, i32 path metrics"
+    dtype = "i8 soft values, i16 path metrics (differences exact modulo 2^16)"
     alg_bytes_per_unit = 19216  # 3(K+4) int8 in + K/8 packed out + 4 B status, K=6144
 
     @property
@@ -155,7 +155,7 @@ class ChainWorkload:
     name = "chain"
     metric = "DL subframes/sec @20MHz 100RB 64QAM, full chain FFT->CE->demap->rate-unmatch->turbo(REF)->CRC (SURVEY 8d W4)"
     unit = "subframes/s"
-    dtype = "i8 IQ in, f32 FFT/CE/equaliser, i8 soft bits, i32 path metrics"
+    dtype = "i8 IQ in, f32 FFT/CE/equaliser, i8 soft bits, i16 path metrics (differences exact modulo 2^16)"
     alg_bytes_per_unit = 70240 + 26984 // 8  # fused accounting, SURVEY 8d: int8 IQ in + packed info bits out
     dominant = "k_turbo_siso"
     info_bits = 8 * 3240 + 1064
@@ -362,7 +362,7 @@ class UplinkWorkload:
     name = "uplink"
     metric = "UL subframes/sec @20MHz, 16 UEs x 6 PRB QPSK PUSCH + 1 PRACH occasion per 10 subframes: SC-FDMA demod + PUSCH demod + UL-SCH turbo decode + PRACH correlation (SURVEY 8d W5)"
     unit = "subframes/s"
-    dtype = "i8 IQ in, f32 FFT/CE/equaliser/DFT, i8 soft bits, i32 path metrics"
+    dtype = "i8 IQ in, f32 FFT/CE/equaliser/DFT, i8 soft bits, i16 path metrics (differences exact modulo 2^16)"
     N_UE, N_PRB, TBS = 16, 6, 504
     alg_bytes_per_unit = 61440 + 16 * 504 // 8
     dominant = "k_pusch_demod"

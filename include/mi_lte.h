@@ -78,9 +78,10 @@ const char *mi_lte_profile_report(mi_lte_ctx *ctx);
 
 /* ---------------------------------------------------------------- DL front end
  * Replaces liblte_phy_get_dl_subframe_and_ce() (liblte/hdr/liblte_phy.h:1170-1177, implementation
- * liblte/src/liblte_phy.cc:5905-6200) for a batch of independent subframe "units": 16 OFDM symbol
- * FFTs (14 + the 2 look-ahead symbols the interpolation needs; the window starts one sample early,
- * liblte_phy.cc:8621) and CRS channel estimation / interpolation for N_ant ports.
+ * liblte/src/liblte_phy.cc:5905-6200) for a batch of independent subframe "units": 14 OFDM symbol
+ * FFTs + the look-ahead symbols the interpolation needs (symbol 14 = the next subframe's first symbol;
+ * with N_ant = 4 also symbol 15, which only ports 2 and 3 read -- row 15 is not produced for N_ant <= 2;
+ * the window starts one sample early, liblte_phy.cc:8621) and CRS channel estimation / interpolation for N_ant ports.
  *
  * Samples: either interleaved int8 I,Q (the capture file format the reference's callers convert
  * from, LTE_fdd_dl_file_scan/src/LTE_fdd_dl_fs_samp_buf.cc:657-694) in d_samples_a, or planar fp32

@@ -1,4 +1,4 @@
-// DL front end on gfx950: OFDM demodulation (16 FFTs per subframe) + CRS channel estimation.
+// DL front end on gfx950: OFDM demodulation (15 or 16 FFTs per subframe) + CRS channel estimation.
 // Restates liblte_phy_get_dl_subframe_and_ce (liblte/src/liblte_phy.cc:5905-6200) for a batch of
 // independent subframe units.  HBM-bound by design: int8 IQ in, fp32 symbols + estimates out.
 //
@@ -500,13 +500,16 @@ extern "C" int mi_lte_dl_frontend_batch(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cf
     rc = mi_ctx_fft_twiddles(ctx);
     if (rc != MI_LTE_OK) return rc;
     const size_t lds_fft = sizeof(float2) * (g.N + g.N / 32 + 1);
+    // 14 symbols + the look-ahead symbols of the next subframe that the CRS interpolation reads: symbol 14 (ports 0 and 1) and, only
+    // with four ports, symbol 15 (ports 2 and 3 carry their CRS in the second symbol of a slot)
+    const uint32_t n_sym = cfg->N_ant > 2 ? 16 : 15;
     if (cfg->sample_format == MI_LTE_IQ_I8) {
         SampleSrc<int8_t> s{(const int8_t *)d_samples_a};
-        FFT_LAUNCH("k_dl_fft", int8_t, false, dim3(16, n_units), s, d_unit_start, g, ctx->d_fft_tw, d_subframes);
+        FFT_LAUNCH("k_dl_fft", int8_t, false, dim3(n_sym, n_units), s, d_unit_start, g, ctx->d_fft_tw, d_subframes);
     } else if (cfg->sample_format == MI_LTE_IQ_F32_PLANAR) {
         if (!d_samples_b) return MI_LTE_ERR_INVALID_ARG;
         SampleSrc<float> s{(const float *)d_samples_a, (const float *)d_samples_b};
-        FFT_LAUNCH("k_dl_fft", float, false, dim3(16, n_units), s, d_unit_start, g, ctx->d_fft_tw, d_subframes);
+        FFT_LAUNCH("k_dl_fft", float, false, dim3(n_sym, n_units), s, d_unit_start, g, ctx->d_fft_tw, d_subframes);
     } else
         return MI_LTE_ERR_INVALID_ARG;
     GoldTables gt{ctx->d_gold_x1, ctx->d_gold_x2b, ctx->gold_words};

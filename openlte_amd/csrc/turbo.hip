@@ -33,6 +33,17 @@ __host__ __device__ inline uint32_t kpad64(uint32_t K) { return (K + 63u) & ~63u
 
 __device__ __forceinline__ int sbyte(uint32_t w, int k) { return (int)__builtin_amdgcn_sbfe(w, 8 * k, 8); }
 
+// Reads at absolute LDS byte addresses.  The compiler adds the start of the dynamic LDS block to every access as a late-resolved
+// constant (a v_add per gathered byte); the per-code-block kernels declare no static LDS, so their dynamic block starts at address 0
+// (checked on the host before the first launch, no_static_lds) and "block + constant + index" is the index register plus an
+// immediate offset.
+typedef __attribute__((address_space(3))) const uint8_t  lds_u8_t;
+typedef __attribute__((address_space(3))) const int8_t   lds_i8_t;
+typedef __attribute__((address_space(3))) const uint16_t lds_u16_t;
+__device__ __forceinline__ uint32_t lds_u8(uint32_t addr) { return *(lds_u8_t *)(uintptr_t)addr; }
+__device__ __forceinline__ int      lds_i8(uint32_t addr) { return *(lds_i8_t *)(uintptr_t)addr; }
+__device__ __forceinline__ uint32_t lds_u16(uint32_t addr) { return *(lds_u16_t *)(uintptr_t)addr; }
+
 // sign * ((|a|+|b|) >> 1), sign negative iff exactly one operand is negative (0 counts as positive).
 // This one form covers the four branches of Step 3 (liblte_phy.cc:10688-10707) and the g=03 soft
 // re-encoder conv_encode_soft (liblte_phy.cc:10123-10147).
@@ -157,7 +168,7 @@ template <typename T> struct SrcDirect {
     __device__ __forceinline__ void init(uint32_t cb, uint32_t K) { d = soft + (size_t)cb * 3 * (K + 4); }
     __device__ __forceinline__ bool stage_e(int8_t *) { return false; }
     // v[x][k] = d[(16u+k)*3 + x] for k < nvalid (16 or 8), with Step 0 (RX_NULL_BIT -> 0, liblte_phy.cc:10636-10642)
-    __device__ __forceinline__ void load16(uint32_t u, int nvalid, float (&v)[3][16], const int8_t *, bool) const
+    __device__ __forceinline__ void load16(uint32_t u, int nvalid, float (&v)[3][16], uint32_t, bool) const
     {
         const T *p = d + (size_t)u * 48;
         auto put = [&](int e, float t) { // element e = 3*k + x of the unit
@@ -330,7 +341,7 @@ struct SrcRateUnmatch {
     }
     // the gather from the staged copy: v[x][k] = sum over laps t of e[min(rank + t*Nnn, E)], ranks 0xFFFF (NULL, or past the
     // block end) included -- three operations per element and lap, no predicate
-    __device__ __forceinline__ void gather16_staged(const int8_t *el, uint32_t u, int nvalid, int (&v)[3][16]) const
+    __device__ __forceinline__ void gather16_staged(uint32_t el /* LDS address of the staged copy */, uint32_t u, int nvalid, int (&v)[3][16]) const
     {
         uint4 raw[3][2];
 #pragma unroll
@@ -346,11 +357,11 @@ struct SrcRateUnmatch {
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 r[k]    = (k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xFFFFu);
-                v[x][k] = (int)el[min(r[k], E)];
+                v[x][k] = lds_i8(el + min(r[k], E));
             }
             for (uint32_t base = Nnn; base < E; base += Nnn) {
 #pragma unroll
-                for (int k = 0; k < 16; k++) v[x][k] += (int)el[min(r[k] + base, E)];
+                for (int k = 0; k < 16; k++) v[x][k] += lds_i8(el + min(r[k] + base, E));
             }
         }
     }
@@ -395,7 +406,7 @@ struct SrcRateUnmatch {
         }
     }
     static constexpr bool kIntPath = true; // the sums are small integers: the quantiser below never leaves integer arithmetic
-    __device__ __forceinline__ void load16(uint32_t u, int nvalid, int (&v)[3][16], const int8_t *e_lds, bool in_lds) const
+    __device__ __forceinline__ void load16(uint32_t u, int nvalid, int (&v)[3][16], uint32_t e_lds, bool in_lds) const
     {
         if (in_lds) gather16_staged(e_lds, u, nvalid, v);
         else        gather16(e, u, nvalid, v);
@@ -432,24 +443,16 @@ __device__ __forceinline__ void abs_sum16(const uint4 &A, const uint4 &B, uint32
         wmax = max(max(wmax, w[4 * j]), max(w[4 * j + 1], max(w[4 * j + 2], w[4 * j + 3])));
     }
 }
-// m[k] = mtab[w[k]] as sixteen packed bytes (mtab entries are 0..127)
-__device__ __forceinline__ uint4 lookup16(const int8_t *mtab, const uint32_t (&w)[16])
+// m[k] = byte at LDS address base + w[k], as sixteen packed bytes (table entries are 0..127)
+__device__ __forceinline__ uint4 lookup16(uint32_t base, const uint32_t (&w)[16])
 {
-    const uint8_t *t = reinterpret_cast<const uint8_t *>(mtab);
-    uint32_t       o[4];
+    uint32_t o[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) o[j] = pack4u(t[w[4 * j]], t[w[4 * j + 1]], t[w[4 * j + 2]], t[w[4 * j + 3]]);
+    for (int j = 0; j < 4; j++) o[j] = pack4u(lds_u8(base + w[4 * j]), lds_u8(base + w[4 * j + 1]), lds_u8(base + w[4 * j + 2]), lds_u8(base + w[4 * j + 3]));
     return make_uint4(o[0], o[1], o[2], o[3]);
 }
-// g[k] = arr[idx[k]] as sixteen packed bytes
-__device__ __forceinline__ uint4 gather16_bytes(const int8_t *arr, const uint32_t (&idx)[16])
-{
-    const uint8_t *t = reinterpret_cast<const uint8_t *>(arr);
-    uint32_t       o[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) o[j] = pack4u(t[idx[4 * j]], t[idx[4 * j + 1]], t[idx[4 * j + 2]], t[idx[4 * j + 3]]);
-    return make_uint4(o[0], o[1], o[2], o[3]);
-}
+// g[k] = byte at LDS address base + idx[k], as sixteen packed bytes
+__device__ __forceinline__ uint4 gather16_bytes(uint32_t base, const uint32_t (&idx)[16]) { return lookup16(base, idx); }
 
 template <typename Src, int NSLOT>
 #ifndef PREP_WPE
@@ -459,14 +462,16 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(PREP_WPE, 8
                                                     const uint16_t *__restrict__ pi, PrepOut out)
 {
     static_assert(NSLOT == 1, "one unit per thread (K <= 6144 -> at most 384 units)");
-    extern __shared__ __attribute__((aligned(16))) int8_t sm[]; // qtab | mtab1 | mtab2 | staged e [e_cap] | q(d0)[Kp]
-    __shared__ float red_f[8];
-    __shared__ int   red_i[16];
+    // qtab | mtab1 | mtab2 | staged e [e_cap] | q(d0)[Kp] | reduction scratch (64 B).  No static LDS next to it: the dynamic block then
+    // starts at LDS address 0 and the table / gather reads below are "index register + immediate offset", with no base to add
+    extern __shared__ __attribute__((aligned(16))) int8_t sm[];
     const uint32_t cb = xcd_cb(blockIdx.x, n_cb), tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4;
     if (cb >= n_cb) return; // uniform
     const size_t   tile_off = (size_t)tile * Kp * 64;
     int8_t        *qtab = sm, *qc = sm + QTAB_HALF, *mtab1 = sm + QTAB_N, *mtab2 = mtab1 + MTAB_N, *e_lds = sm + PREP_TAB_BYTES;
     int8_t        *q0_lds = e_lds + src.e_cap;
+    float         *red_f  = reinterpret_cast<float *>(q0_lds + Kp);
+    int           *red_i  = reinterpret_cast<int *>(q0_lds + Kp);
     src.init(cb, K);
     const bool     e_in_lds = src.stage_e(e_lds);
     const uint32_t u  = threadIdx.x;
@@ -474,7 +479,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(PREP_WPE, 8
 
     typedef typename std::conditional<Src::kIntPath, int, float>::type val_t;
     val_t v[3][16];
-    if (nv > 0) src.load16(u, nv, v, e_lds, e_in_lds);
+    if (nv > 0) src.load16(u, nv, v, PREP_TAB_BYTES, e_in_lds);
     else {
 #pragma unroll
         for (int x = 0; x < 3; x++)
@@ -514,11 +519,10 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(PREP_WPE, 8
 #pragma unroll
     for (int x = 0; x < 3; x++) {
         if (Src::kIntPath && use_qtab) {
-            const uint8_t *t = reinterpret_cast<const uint8_t *>(qc);
-            uint32_t       o[4];
+            uint32_t o[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) // 0 past the block end -> q(0) = 0
-                o[j] = pack4u(t[(int)v[x][4 * j]], t[(int)v[x][4 * j + 1]], t[(int)v[x][4 * j + 2]], t[(int)v[x][4 * j + 3]]);
+                o[j] = pack4u(lds_u8(QTAB_HALF + v[x][4 * j]), lds_u8(QTAB_HALF + v[x][4 * j + 1]), lds_u8(QTAB_HALF + v[x][4 * j + 2]), lds_u8(QTAB_HALF + v[x][4 * j + 3]));
             Q[x] = make_uint4(o[0], o[1], o[2], o[3]);
         } else {
             int q[16];
@@ -544,7 +548,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(PREP_WPE, 8
     if (nv > 0) {
         uint32_t idx[16];
         load_idx16(pi, u, nv, idx, K); // past the block end: slot K, which holds q = 0 whenever K % 16 == 8
-        I0 = gather16_bytes(q0_lds, idx);
+        I0 = gather16_bytes(PREP_TAB_BYTES + src.e_cap, idx);
     }
     if (nv >= 0) *reinterpret_cast<uint4 *>(out.arr[3] + unit_off(tile_off, lane, u)) = I0;
     uint32_t w1[16], w2[16], w1m = 0, w2m = 0; // pass-1 / pass-2 branch weights |q(d1)| + |q(d0)|, |q(d2)| + |I0|: 0 past the block end
@@ -560,8 +564,8 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(PREP_WPE, 8
     }
     __syncthreads();
     if (nv >= 0) {
-        *reinterpret_cast<uint4 *>(out.arr[4] + unit_off(tile_off, lane, u)) = lookup16(mtab1, w1); // past the end: entry 0 = 0
-        *reinterpret_cast<uint4 *>(out.arr[5] + unit_off(tile_off, lane, u)) = lookup16(mtab2, w2);
+        *reinterpret_cast<uint4 *>(out.arr[4] + unit_off(tile_off, lane, u)) = lookup16(QTAB_N, w1); // past the end: entry 0 = 0
+        *reinterpret_cast<uint4 *>(out.arr[5] + unit_off(tile_off, lane, u)) = lookup16(QTAB_N + MTAB_N, w2);
     }
 }
 
@@ -848,12 +852,12 @@ template <int NSLOT>
 __global__ __launch_bounds__(384) void k_turbo_perm(PermArgs a, uint32_t K, uint32_t n_cb, const uint16_t *__restrict__ pi)
 {
     static_assert(NSLOT == 1, "one unit per thread");
-    extern __shared__ __attribute__((aligned(16))) int8_t sm[]; // C1[Kp]
-    __shared__ int    red_i[8];
-    __shared__ int8_t mtab[MTAB_N];
+    extern __shared__ __attribute__((aligned(16))) int8_t smp[]; // mtab[256] | C1[Kp] | reduction scratch (32 B); no static LDS (see k_turbo_prep)
+    int8_t *mtab = smp, *sm = smp + MTAB_N;
     const uint32_t cb = xcd_cb(blockIdx.x, n_cb), tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4;
     if (cb >= n_cb) return;
     const size_t   tile_off = (size_t)tile * Kp * 64;
+    int           *red_i = reinterpret_cast<int *>(sm + Kp);
     const uint32_t u  = threadIdx.x;
     const int      nv = (u < n_units) ? min(16, max(0, (int)K - 16 * (int)u)) : -1;
     uint4          X2 = make_uint4(0, 0, 0, 0);
@@ -874,7 +878,7 @@ __global__ __launch_bounds__(384) void k_turbo_perm(PermArgs a, uint32_t K, uint
     if (nv > 0) {
         uint32_t idx[16];
         load_idx16(pi, u, nv, idx, K); // past the block end: slot K (C1 = 0 there)
-        I1 = gather16_bytes(sm, idx);  // Step 5
+        I1 = gather16_bytes(MTAB_N, idx); // Step 5
     }
     if (nv >= 0) *reinterpret_cast<uint4 *>(a.out[0] + unit_off(tile_off, lane, u)) = I1;
     uint32_t w[16], wm = 0; // |q(d2)| + |I1|; both are 0 past the block end
@@ -884,7 +888,7 @@ __global__ __launch_bounds__(384) void k_turbo_perm(PermArgs a, uint32_t K, uint
     const float W = (float)wmax;
     for (uint32_t t = threadIdx.x; t < MTAB_N; t += blockDim.x) mtab[t] = (int8_t)(int)(127.0f * ((float)t / W)); // one division per distinct w
     __syncthreads();
-    if (nv >= 0) *reinterpret_cast<uint4 *>(a.out[1] + unit_off(tile_off, lane, u)) = lookup16(mtab, w);
+    if (nv >= 0) *reinterpret_cast<uint4 *>(a.out[1] + unit_off(tile_off, lane, u)) = lookup16(0, w);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -900,12 +904,12 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                                                     uint8_t *__restrict__ c_bits, GroupDesc g)
 {
     static_assert(NSLOT == 1, "one unit per thread");
-    extern __shared__ __attribute__((aligned(16))) int8_t sm[]; // D12[Kp + 16] (int16: D1 + D2, a zero slot at Kp) | (GROUP) bits[Kp]
-    __shared__ uint32_t red_u[8];
+    extern __shared__ __attribute__((aligned(16))) int8_t sm[]; // D12[Kp + 16] (int16: D1 + D2, a zero slot at Kp) | bits[Kp] | reduction scratch (32 B); no static LDS
     const uint32_t cb = xcd_cb(blockIdx.x, n_cb), tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4;
     if (cb >= n_cb) return;
     const size_t   tile_off = (size_t)tile * Kp * 64;
     int8_t        *d12 = sm, *bits = sm + 2 * Kp + 32;
+    uint32_t      *red_u = reinterpret_cast<uint32_t *>(bits + Kp);
     const uint32_t u  = threadIdx.x;
     const int      nv = (u < n_units) ? min(16, max(0, (int)K - 16 * (int)u)) : -1;
     const IdxRaw   vraw = load_idx_raw(inv, u < n_units ? u : 0, nv, K); // needed after the barrier; requested now
@@ -961,12 +965,11 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     if (nv > 0) {
         // Steps 12-14: de-interleave D1 + D2 (a hole contributes 0; past the block end: slot K, where D1 = D2 = 0), add, take the sign
         const uint32_t  iw[8] = {vraw.lo.x, vraw.lo.y, vraw.lo.z, vraw.lo.w, vraw.hi.x, vraw.hi.y, vraw.hi.z, vraw.hi.w};
-        const uint16_t *dt = reinterpret_cast<const uint16_t *>(d12);
         uint32_t        me[4], mo[4], bw[4]; // sign masks of the even / odd pairs (0xFFFF per negative sum), the bits one per byte
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const uint32_t i0 = min(iw[2 * j] & 0xFFFFu, Kp), i1 = min(iw[2 * j] >> 16, Kp), i2 = min(iw[2 * j + 1] & 0xFFFFu, Kp), i3 = min(iw[2 * j + 1] >> 16, Kp);
-            const uint32_t ge = (uint32_t)dt[i0] | (uint32_t)dt[i2] << 16, go = (uint32_t)dt[i1] | (uint32_t)dt[i3] << 16;
+            const uint32_t ge = lds_u16(2 * i0) | lds_u16(2 * i2) << 16, go = lds_u16(2 * i1) | lds_u16(2 * i3) << 16; // D12 sits at LDS address 0
             me[j] = as_u32((s0e[j] + as_v2s(ge)) >> 15);
             mo[j] = as_u32((s0o[j] + as_v2s(go)) >> 15);
             bw[j] = (me[j] & 0x00010001u) | (mo[j] & 0x00010001u) << 8; // Step 14
@@ -1145,6 +1148,12 @@ extern "C" size_t mi_lte_turbo_scratch_bytes(uint32_t K, uint32_t n_cb)
     return n_tiles * Kp * 64 * N_BYTE_ARRAYS + 3 * n_tiles * Kp * 32;
 }
 
+static bool no_static_lds(const void *kernel)
+{
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, kernel) == hipSuccess && a.sharedSizeBytes == 0;
+}
+
 // The five launches of one REF decode over n_cb code blocks of size K.
 template <typename Src, bool GROUP>
 static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, uint8_t *d_c_bits, GroupDesc gd, uint32_t e_cap = 0)
@@ -1152,6 +1161,13 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
     TurboTables tb;
     int         rc = mi_ctx_turbo_tables(ctx, K, 0, &tb);
     if (rc != MI_LTE_OK) return rc;
+    // the per-code-block kernels address their dynamic LDS block from 0 (lds_u8 and friends): that holds while they own no static LDS
+    static const bool lds_ok = no_static_lds((const void *)k_turbo_prep<Src, 1>) && no_static_lds((const void *)k_turbo_perm<1>) &&
+                               no_static_lds((const void *)k_turbo_vote<GROUP, 1>);
+    if (!lds_ok) {
+        ctx->err = "turbo kernels were built with static LDS: absolute LDS addressing is invalid";
+        return MI_LTE_ERR_HIP;
+    }
     const size_t n_tiles = (n_cb + 63) / 64, Kp = kpad64(K), arr_bytes = n_tiles * Kp * 64, dec_bytes = n_tiles * Kp * 32;
     rc = mi_ctx_reserve_scratch(ctx, mi_lte_turbo_scratch_bytes(K, n_cb));
     if (rc != MI_LTE_OK) return rc;
@@ -1167,7 +1183,7 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
     po.arr[0] = arr[AX0]; po.arr[1] = arr[AX1]; po.arr[2] = arr[AX2];
     po.arr[3] = arr[AI0]; po.arr[4] = arr[AM1]; po.arr[5] = arr[AM2];
     const uint32_t cb_threads = (uint32_t)(((Kp >> 4) + 63) & ~(size_t)63); // one thread per 16-step unit: 64..384
-    MI_LAUNCH(ctx, "k_turbo_prep", (k_turbo_prep<Src, 1>), dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), PREP_TAB_BYTES + Kp + e_cap, src, K, n_cb, tb.d_pi, po);
+    MI_LAUNCH(ctx, "k_turbo_prep", (k_turbo_prep<Src, 1>), dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), PREP_TAB_BYTES + Kp + e_cap + 64, src, K, n_cb, tb.d_pi, po);
 
     SisoArgs s1;
     s1.p[0] = {arr[AX1], arr[AX0], arr[AM1], arr[AA1], dec[0]};
@@ -1176,7 +1192,7 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
 
     PermArgs pa;
     pa.A1 = arr[AA1]; pa.X2 = arr[AX2]; pa.out[0] = arr[AI1]; pa.out[1] = arr[AM3];
-    MI_LAUNCH(ctx, "k_turbo_perm", k_turbo_perm<1>, dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), Kp, pa, K, n_cb, tb.d_pi);
+    MI_LAUNCH(ctx, "k_turbo_perm", k_turbo_perm<1>, dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), MTAB_N + Kp + 32, pa, K, n_cb, tb.d_pi);
 
     SisoArgs s23;
     s23.p[0] = {arr[AX2], arr[AI0], arr[AM2], arr[AB1], dec[1]};
@@ -1184,7 +1200,7 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
     MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso, dim3(n_tiles), dim3(64), 0, s23, K, (uint32_t)n_tiles, 1u); // passes 2 and 3 of a tile per lane
 
     VoteArgs va = {arr[AX0], arr[AA1], arr[AB1], arr[AB2]};
-    MI_LAUNCH(ctx, "k_turbo_vote", (k_turbo_vote<GROUP, 1>), dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), 3 * Kp + 32, va, K, n_cb, tb.d_inv, d_c_bits, gd);
+    MI_LAUNCH(ctx, "k_turbo_vote", (k_turbo_vote<GROUP, 1>), dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), 3 * Kp + 64, va, K, n_cb, tb.d_inv, d_c_bits, gd);
     MI_HIP_CHECK(ctx, hipGetLastError());
     ctx->last_kernels = "k_turbo_prep:1,k_turbo_siso:2,k_turbo_perm:1,k_turbo_vote:1";
     return MI_LTE_OK;
@@ -1234,7 +1250,7 @@ int mi_turbo_ref_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_
     src.nnn  = rt.d_nnn;
     // stage e in LDS when the largest allocation of the group fits next to the block's own arrays
     const uint32_t cap = (e_max_bytes + 16u + 63u) & ~63u; // room for the zero slot behind the longest allocation
-    src.e_cap          = (PREP_TAB_BYTES + kpad64(K) + cap <= 48 * 1024) ? cap : 0;
+    src.e_cap          = (PREP_TAB_BYTES + kpad64(K) + cap + 64 <= 48 * 1024) ? cap : 0;
     return turbo_ref_run<SrcRateUnmatch, true>(ctx, src, K, n_cb, nullptr, gd, src.e_cap);
 }
 

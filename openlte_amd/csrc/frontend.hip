@@ -284,6 +284,20 @@ __device__ __forceinline__ uint32_t gold_word(const GoldTables &gt, uint32_t c_i
     return v;
 }
 
+// sin / cos of an unwrapped phase for the time interpolation: two-constant reduction to [-pi, pi] (the phases are a few turns at
+// most), then the hardware's v_sin_f32 / v_cos_f32, which take revolutions.  The estimate is a float-tolerance stage
+// (TOL_CE = 1e-4 in tests/test_frontend_gpu.py; measured against the oracle the estimate's relative L2 error is 2.4e-7 this way and
+// 2.2e-7 with libm's sincosf, which spent two thirds of this kernel's instructions here).
+__device__ __forceinline__ void ce_sincos(float x, float &sn, float &cs)
+{
+    const float k = rintf(x * 0.15915494309189533577f);
+    float       r = fmaf(-k, 6.28318548202514648438f, x); // 2 pi rounded to float ...
+    r             = fmaf(-k, -1.74845553146951715e-07f, r); // ... and the rest of it
+    r *= 0.15915494309189533577f;
+    sn = __builtin_amdgcn_sinf(r);
+    cs = __builtin_amdgcn_cosf(r);
+}
+
 __global__ __launch_bounds__(256) void k_dl_ce(const uint32_t *__restrict__ subfr_num, const uint32_t *__restrict__ n_id_cell,
                                                DlGeom g, GoldTables gt, float *__restrict__ subframes)
 {
@@ -429,7 +443,7 @@ __global__ __launch_bounds__(256) void k_dl_ce(const uint32_t *__restrict__ subf
 #pragma unroll
         for (int i = 0; i < 5; i++) { M[i] = mag[i * N_sc + j]; A[i] = ang[i * N_sc + j]; }
         float fm, fa, cm, ca;
-#define EMIT(z, m, a) do { float sn_, cs_; sincosf((a), &sn_, &cs_); ce_re[(z) * N_SC_MAX + j] = (m) * cs_; ce_im[(z) * N_SC_MAX + j] = (m) * sn_; } while (0)
+#define EMIT(z, m, a) do { float sn_, cs_; ce_sincos((a), sn_, cs_); ce_re[(z) * N_SC_MAX + j] = (m) * cs_; ce_im[(z) * N_SC_MAX + j] = (m) * sn_; } while (0)
 #define SLOPE(hi, lo, dv) do { fm = (M[hi] - M[lo]) / (dv); A[hi] = wrap_phase(A[hi], A[lo]); fa = A[hi] - A[lo]; \
                                fa = wrap_phase(fa, 0.0f); fa /= (dv); } while (0)
         if (N_sym == 3) {

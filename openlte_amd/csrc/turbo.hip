@@ -595,6 +595,15 @@ __device__ __forceinline__ v2s      even2(uint32_t w) { return (as_v2s(w) << 8) 
 __device__ __forceinline__ v2s      odd2(uint32_t w) { return as_v2s(w) >> 8; }
 __device__ __forceinline__ uint32_t merge_bytes(v2s e, v2s o) { return __builtin_amdgcn_perm(as_u32(o), as_u32(e), 0x06020400u); } // low bytes of (e.lo, o.lo, e.hi, o.hi)
 __device__ __forceinline__ v2s      abs2(v2s a) { return __builtin_elementwise_max(a, (v2s)(0) - a); }
+// 0xFFFF per negative half.  Opaque on purpose: from a visible "x >> 15" feeding an and/or select the compiler rebuilds per-half
+// compares and selects, which costs twice the instructions of the mask + one bit-select it replaces.
+__device__ __forceinline__ uint32_t neg_mask(v2s d)
+{
+    uint32_t m;
+    asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(m) : "v"(as_u32(d))); // the inline constant has no upper half
+    return m;
+}
+__device__ __forceinline__ v2s bit_select(uint32_t m, v2s yes, v2s no) { return as_v2s((as_u32(yes) & m) | (as_u32(no) & ~m)); }
 
 struct SisoPass {
     const uint8_t *in_a; // first soft value of each pair  (in[2t])
@@ -625,13 +634,7 @@ __device__ __forceinline__ void acs_step2(v2s (&pm)[8], v2s x, v2s y, uint32_t &
     acc = (acc << 1) | sign_bits(n1);
     acc = (acc << 1) | sign_bits(n2);
     acc = (acc << 1) | sign_bits(n3);
-    // d < 0 ? yes : no per half, as sign mask + bit select; the mask is made opaque because the compiler otherwise turns the
-    // pattern back into per-half compares and selects, which costs twice the instructions
-    auto sel = [](v2s d, v2s yes, v2s no) {
-        uint32_t m;
-        asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(m) : "v"(as_u32(d))); // the inline constant has no upper half
-        return as_v2s((as_u32(yes) & m) | (as_u32(no) & ~m));
-    };
+    auto sel = [](v2s d, v2s yes, v2s no) { return bit_select(neg_mask(d), yes, no); }; // d < 0 ? yes : no per half
     v2s nw[8];
     nw[0] = sel(n0 - P2, pm[1] + uP, pm[0] - uP); // beta =  P: (n0 <  P2) ? ..
     nw[4] = sel(n0 + P2, pm[1] - uP, pm[0] + uP); // beta = -P: (n0 < -P2) ? ..
@@ -818,30 +821,53 @@ __device__ __forceinline__ v2s sxor2(v2s a, v2s b)
     return (mag ^ s) - s;
 }
 // A unit of 16 values x[0..15] plus its three-value halo x[-3..-1], as pairs: E[j] = (x[4j-4], x[4j-2]), O[j] = (x[4j-3], x[4j-1]),
-// j = 0 (halo word) .. 4.  The delayed sequences the soft re-encoder needs are then
-//   x[k-2]: even pairs (E[j].hi, E[j+1].lo), odd pairs (O[j].hi, O[j+1].lo)  -- one v_alignbit each
+// j = 0 (halo word) .. 4, each pair split into magnitudes and sign masks (0 / 0xFFFF): soft_xor of two such values is
+// ((m_a + m_b) >> 1, s_a ^ s_b), three instructions per pair.  The delayed sequences the soft re-encoder needs are
+//   x[k-2]: even pairs (E[j].hi, E[j+1].lo), odd pairs (O[j].hi, O[j+1].lo)  -- one v_alignbit per component
 //   x[k-3]: even pairs O[j], odd pairs = the even pairs of x[k-2]              -- free
 // with x[<0] = +127 in the first unit (conv_encode_soft register preset, liblte_phy.cc:10097-10100).
-struct UnitPairs { v2s E[5], O[5]; };
-__device__ __forceinline__ UnitPairs load_unit_pairs(const uint8_t *arr, size_t tile_off, uint32_t lane, uint32_t u)
+struct SM { v2s m; uint32_t s; }; // |x| and the sign mask of a pair
+__device__ __forceinline__ SM   to_sm(v2s x) { return SM{abs2(x), neg_mask(x)}; }
+__device__ __forceinline__ v2s  to_tc(const SM &a) { return as_v2s(as_u32(a.m) ^ a.s) - as_v2s(a.s); } // back to two's complement
+__device__ __forceinline__ SM   sxor_sm(const SM &a, const SM &b) { return SM{(a.m + b.m) >> 1, a.s ^ b.s}; }
+struct UnitWords { uint32_t w[5]; }; // halo word, then the unit's four words
+__device__ __forceinline__ UnitWords load_unit_words(const uint8_t *arr, size_t tile_off, uint32_t lane, uint32_t u)
 {
     const uint4 c    = *reinterpret_cast<const uint4 *>(arr + unit_off(tile_off, lane, u));
     uint32_t    prev = 0x7F7F7F7Fu;
     if (u > 0) prev = *reinterpret_cast<const uint32_t *>(arr + unit_off(tile_off, lane, u - 1) + 12);
-    const uint32_t w[5] = {prev, c.x, c.y, c.z, c.w};
-    UnitPairs      p;
-#pragma unroll
-    for (int j = 0; j < 5; j++) { p.E[j] = even2(w[j]); p.O[j] = odd2(w[j]); }
-    return p;
+    return UnitWords{{prev, c.x, c.y, c.z, c.w}};
 }
-__device__ __forceinline__ v2s delay2(v2s cur, v2s prev) { return as_v2s(__builtin_amdgcn_alignbit(as_u32(cur), as_u32(prev), 16)); } // (prev.hi, cur.lo)
-// fb = soft_xor(x[k-2], x[k-3]) for word j (0..3) of the unit: even and odd pairs
-__device__ __forceinline__ void feedback2(const UnitPairs &p, int j, v2s &fe, v2s &fo)
+// the pairs of one word, and of the word before it: converted as the walk over the unit reaches them, so that only two words of
+// an array are live in sign-magnitude form at a time
+struct WordPairs { v2s et, ot; SM e, o; }; // two's complement and sign-magnitude
+__device__ __forceinline__ WordPairs word_pairs(uint32_t w)
 {
-    const v2s d2e = delay2(p.E[j + 1], p.E[j]), d2o = delay2(p.O[j + 1], p.O[j]);
-    fe = sxor2(d2e, p.O[j]);
-    fo = sxor2(d2o, d2e);
+    const v2s e = even2(w), o = odd2(w);
+    return WordPairs{e, o, to_sm(e), to_sm(o)};
 }
+__device__ __forceinline__ SM delay_sm(const SM &cur, const SM &prev) // (prev.hi, cur.lo)
+{
+    return SM{as_v2s(__builtin_amdgcn_alignbit(as_u32(cur.m), as_u32(prev.m), 16)), __builtin_amdgcn_alignbit(cur.s, prev.s, 16)};
+}
+// a soft_xor result in all three forms its consumers want: two's complement, magnitude, and the sign mask OF THE VALUE -- a result
+// of magnitude 0 is +0 to whatever reads it next (soft_xor counts 0 as positive), whatever the signs of its operands were
+struct SX { v2s tc, m; uint32_t s; };
+__device__ __forceinline__ SX sxor_full(const SM &a, const SM &b)
+{
+    const SM  r  = sxor_sm(a, b);
+    const v2s tc = to_tc(r);
+    return SX{tc, r.m, neg_mask(tc)};
+}
+// fb = soft_xor(x[k-2], x[k-3]) for the values of word `cur`, `prev` being the word before it: even and odd pairs
+__device__ __forceinline__ void feedback_sm(const WordPairs &cur, const WordPairs &prev, SX &fe, SX &fo)
+{
+    const SM d2e = delay_sm(cur.e, prev.e), d2o = delay_sm(cur.o, prev.o);
+    fe = sxor_full(d2e, prev.o);
+    fo = sxor_full(d2o, d2e);
+}
+// soft_xor(a, f) in two's complement
+__device__ __forceinline__ v2s sxor_tc(const SM &a, const SX &f) { return to_tc(SM{(a.m + f.m) >> 1, a.s ^ f.s}); }
 
 // ------------------------------------------------------------------------------------------------
 // perm: Steps 2, 3, 5 and the pass-3 output magnitudes.  One workgroup per code block.
@@ -862,14 +888,17 @@ __global__ __launch_bounds__(384) void k_turbo_perm(PermArgs a, uint32_t K, uint
     const int      nv = (u < n_units) ? min(16, max(0, (int)K - 16 * (int)u)) : -1;
     uint4          X2 = make_uint4(0, 0, 0, 0);
     if (nv >= 0) {
-        const UnitPairs pa = load_unit_pairs(a.A1, tile_off, lane, u);
+        const UnitWords wa = load_unit_words(a.A1, tile_off, lane, u);
+        WordPairs       pa = word_pairs(wa.w[0]);
         X2 = *reinterpret_cast<const uint4 *>(a.X2 + unit_off(tile_off, lane, u));
         uint32_t c1[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) { // Steps 2-3; 0 past the block end
-            v2s fe, fo;
-            feedback2(pa, j, fe, fo);
-            c1[j] = (4 * j < nv) ? merge_bytes(sxor2(pa.E[j + 1], fe), sxor2(pa.O[j + 1], fo)) : 0u;
+            const WordPairs ca = word_pairs(wa.w[j + 1]);
+            SX              fe, fo;
+            feedback_sm(ca, pa, fe, fo);
+            c1[j] = (4 * j < nv) ? merge_bytes(sxor_tc(ca.e, fe), sxor_tc(ca.o, fo)) : 0u;
+            pa    = ca;
         }
         *reinterpret_cast<uint4 *>(sm + 16 * u) = make_uint4(c1[0], c1[1], c1[2], c1[3]);
     }
@@ -916,34 +945,36 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     v2s            s0e[4], s0o[4]; // s0 = q(d0) + C1, the part of the vote that is not de-interleaved
     if (threadIdx.x == 0) *reinterpret_cast<uint32_t *>(d12 + 2 * Kp) = 0u; // what a hole of the de-interleaver reads
     if (nv >= 0) {
-        const UnitPairs pa = load_unit_pairs(a.A1, tile_off, lane, u), pb = load_unit_pairs(a.B1, tile_off, lane, u),
-                        pc = load_unit_pairs(a.B2, tile_off, lane, u);
+        const UnitWords wa = load_unit_words(a.A1, tile_off, lane, u), wb = load_unit_words(a.B1, tile_off, lane, u),
+                        wc = load_unit_words(a.B2, tile_off, lane, u);
+        WordPairs       pa = word_pairs(wa.w[0]), pb = word_pairs(wb.w[0]), pc = word_pairs(wc.w[0]);
         const uint4    x0 = *reinterpret_cast<const uint4 *>(a.X0 + unit_off(tile_off, lane, u));
         const uint32_t x0w[4] = {x0.x, x0.y, x0.z, x0.w};
         uint32_t       dn[8]; // D1 + D2 of the unit in natural order, two int16 per word
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            v2s fe, fo, ge, go, he, ho;
-            feedback2(pa, j, fe, fo);
-            feedback2(pb, j, ge, go); // G  = soft_xor(B1[k-2], B1[k-3])
-            feedback2(pc, j, he, ho); // G' = soft_xor(B2[k-2], B2[k-3])
+            const WordPairs ca = word_pairs(wa.w[j + 1]), cb1 = word_pairs(wb.w[j + 1]), cb2 = word_pairs(wc.w[j + 1]);
+            SX              fe, fo, ge, go, he, ho;
+            feedback_sm(ca, pa, fe, fo);
+            feedback_sm(cb1, pb, ge, go); // G  = soft_xor(B1[k-2], B1[k-3])
+            feedback_sm(cb2, pc, he, ho); // G' = soft_xor(B2[k-2], B2[k-3])
             v2s d[2];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                const v2s A = h ? pa.O[j + 1] : pa.E[j + 1], B = h ? pb.O[j + 1] : pb.E[j + 1], B_ = h ? pc.O[j + 1] : pc.E[j + 1];
-                const v2s G = h ? go : ge, G_ = h ? ho : he;
+                const SM  &A = h ? ca.o : ca.e, &B = h ? cb1.o : cb1.e, &B_ = h ? cb2.o : cb2.e;
+                const SX  &G = h ? go : ge, &G_ = h ? ho : he;
+                const v2s  At = h ? ca.ot : ca.et;
                 // Step 10 (liblte_phy.cc:10778-10797), as selects: equal signs -> (|B|+|G|)>>1; B >= 0 > G -> -((A - G) >> 1);
                 // B < 0 <= G -> -((-A + G) >> 1) -- the mixed-sign branches read in_act_1 (A), not int_act_1
-                const v2s sb = B >> 15, dAG = A - G, t = (dAG ^ sb) - sb; // (B >= 0) ? A - G : G - A
-                const v2s same = (abs2(B) + abs2(G)) >> 1, mix = (v2s)(0) - (t >> 1), m = (B ^ G) >> 15;
-                const v2s v1 = (same & ~m) | (mix & m);
+                const v2s dAG = At - G.tc, t = as_v2s(as_u32(dAG) ^ B.s) - as_v2s(B.s); // (B >= 0) ? A - G : G - A
+                const v2s v1  = bit_select(B.s ^ G.s, (v2s)(0) - (t >> 1), (B.m + G.m) >> 1);
                 // Step 11 (liblte_phy.cc:10800-10819): mixed signs -> -((B - G) >> 1) resp. -((-B - G) >> 1), i.e. -((|B| - G) >> 1)
-                const v2s ab = abs2(B_), same_ = (ab + abs2(G_)) >> 1, mix_ = (v2s)(0) - ((ab - G_) >> 1), m_ = (B_ ^ G_) >> 15;
-                const v2s v2 = (same_ & ~m_) | (mix_ & m_);
+                const v2s v2  = bit_select(B_.s ^ G_.s, (v2s)(0) - ((B_.m - G_.tc) >> 1), (B_.m + G_.m) >> 1);
                 d[h] = v1 + v2;
-                const v2s c1 = sxor2(A, h ? fo : fe); // Steps 2-3
+                const v2s c1 = sxor_tc(A, h ? fo : fe); // Steps 2-3
                 (h ? s0o[j] : s0e[j]) = (h ? odd2(x0w[j]) : even2(x0w[j])) + c1;
             }
+            pa = ca; pb = cb1; pc = cb2;
             const bool in = 4 * j < nv; // 0 past the block end (nv is 16, 8 or 0)
             dn[2 * j]     = in ? __builtin_amdgcn_perm(as_u32(d[1]), as_u32(d[0]), 0x05040100u) : 0u; // (e.lo, o.lo)
             dn[2 * j + 1] = in ? __builtin_amdgcn_perm(as_u32(d[1]), as_u32(d[0]), 0x07060302u) : 0u; // (e.hi, o.hi)

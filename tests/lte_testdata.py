@@ -6,7 +6,10 @@ def turbo_blocks(port, K, n, kind, seed):
     """Return (tx_bits [n,K] uint8, soft [n,3(K+4)] in the reference's interleaved layout).
 
     kind: 'clean' +-1 floats, 'awgn0.5'/'awgn0.8' BPSK+noise floats, 'hard127' int8 +-127 with 2 % flips,
-          'int' integer-valued floats with exact zeros, 'i16' repetition-combined int16 values.
+          'int' integer-valued floats with exact zeros, 'i16' repetition-combined int16 values,
+          'rand127' +-127 with random signs and 'noise' uniform int8 -- no code word underneath: every step moves the path
+          metrics by the most it can, in directions the trellis does not agree with (the stress case for the kernel's
+          modulo-2^16 path metrics).
     """
     rng = np.random.default_rng(seed)
     D = K + 4
@@ -25,6 +28,10 @@ def turbo_blocks(port, K, n, kind, seed):
             y = (127 * x * np.where(flip, -1, 1)).astype(np.int8)
         elif kind == "int":
             y = np.round((x + 0.7 * rng.standard_normal((3, D))) * 9).astype(np.float32)
+        elif kind == "rand127":
+            y = (127 * (1 - 2 * rng.integers(0, 2, (3, D)))).astype(np.int8)
+        elif kind == "noise":
+            y = rng.integers(-127, 128, (3, D)).astype(np.int8)
         elif kind == "i16":
             reps = rng.integers(1, 5, (3, D))
             y = (127 * x * reps).astype(np.int16)

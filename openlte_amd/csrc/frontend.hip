@@ -286,7 +286,7 @@ __device__ __forceinline__ uint32_t gold_word(const GoldTables &gt, uint32_t c_i
 
 // sin / cos of an unwrapped phase for the time interpolation: two-constant reduction to [-pi, pi] (the phases are a few turns at
 // most), then the hardware's v_sin_f32 / v_cos_f32, which take revolutions.  The estimate is a float-tolerance stage
-// (TOL_CE = 1e-4 in tests/test_frontend_gpu.py; measured against the oracle the estimate's relative L2 error is 2.4e-7 this way and
+// (TOL_CE = 1e-4 in tests/test_frontend_gpu.py; measured against the CPU restatement of the reference the estimate's relative L2 error is 2.4e-7 this way and
 // 2.2e-7 with libm's sincosf, which spent two thirds of this kernel's instructions here).
 __device__ __forceinline__ void ce_sincos(float x, float &sn, float &cs)
 {

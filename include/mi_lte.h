@@ -94,7 +94,11 @@ const char *mi_lte_profile_report(mi_lte_ctx *ctx);
  * receive half of LIBLTE_PHY_SUBFRAME_STRUCT (liblte_phy.h:226-239) with row stride 1200:
  *     rx_symb_re[16][1200] rx_symb_im[16][1200] rx_ce_re[N_ant][16][1200] rx_ce_im[N_ant][16][1200]
  * (channel-estimate rows 14,15 are never written, as in the reference). */
-typedef enum { MI_LTE_IQ_I8 = 0, MI_LTE_IQ_F32_PLANAR = 1 } mi_lte_iq_format;
+typedef enum {
+    MI_LTE_IQ_I8 = 0, MI_LTE_IQ_F32_PLANAR = 1,
+    MI_LTE_IQ_ALL_ROWS = 0x100 /* OR into sample_format for mi_lte_dl_frontend_batch: produce symbol row 15 for N_ant <= 2 as well, as the
+                                  reference's struct holds it (the per-call host form and the shim set it) */
+} mi_lte_iq_format;
 typedef struct {
     uint32_t fft_size;      /* 128, 256, 512, 1024, 2048 = N_samps_per_symb (liblte_phy.cc:2226-2274) */
     uint32_t N_rb_dl;       /* 6..100 */

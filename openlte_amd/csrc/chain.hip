@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                      uint32_t e_lds_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smu[]; // offs[max_pairs+1] | masks[max_pairs] | cw[...]
+    __shared__ uint2 qam_lut[64]; // hard-decision mask -> six soft bits (16QAM / 64QAM)
     const uint32_t a_idx = blockIdx.x;
     const mi_lte_pdsch_alloc &al = allocs[a_idx];
     const uint32_t unit = al.unit, sf = subfr_num[unit], cell = n_id_cell[unit], N_ant = ONE_PORT ? 1u : g.N_ant, N_prb = al.N_prb;
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         if (ln == 63) offs[n_pairs] = incl; // total
     } else {
         const uint32_t n_words_ub = (n_pairs * 12 * Qm + 31) / 32; // <= max_words; one word of slack for the 2-word window in put_bits
+        if (threadIdx.x < 128) qam_lut[threadIdx.x - 64] = qam_lut_entry(threadIdx.x - 64);
         for (uint32_t w = threadIdx.x - 64; w <= n_words_ub; w += blockDim.x - 64) cw[w] = gold_word(gt, c_init, w);
     }
     __syncthreads();
@@ -139,31 +141,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 }
         }
     };
+    // 16QAM / 64QAM: every soft bit is +-127, so a symbol is its mask of negative bits; XOR with the scrambling bits and one table
+    // read give the Q_m bytes (4: one store; 6: three 16-bit stores, the symbol starts on an even address)
+    auto put_qam = [&](auto *dst, uint32_t idx, uint32_t neg) {
+        const uint32_t n0 = Qm == 4 ? idx << 2 : (idx << 2) + (idx << 1), w = n0 >> 5, sh = n0 & 31;
+        const uint32_t c  = __builtin_amdgcn_alignbit(cw[w + 1], cw[w], sh);
+        const uint2    v  = qam_lut[(neg ^ c) & (Qm == 4 ? 15u : 63u)];
+        if (Qm == 4) *reinterpret_cast<uint32_t *>(dst + n0) = v.x;
+        else {
+            *reinterpret_cast<uint16_t *>(dst + n0)     = (uint16_t)v.x;
+            *reinterpret_cast<uint16_t *>(dst + n0 + 2) = (uint16_t)(v.x >> 16);
+            *reinterpret_cast<uint16_t *>(dst + n0 + 4) = (uint16_t)v.y;
+        }
+    };
+    const bool qam = al.mod_type >= 2; // uniform
     if (ONE_PORT) { // one RE = one symbol (liblte_phy.cc:7684-7690): thread per (PRB-symbol pair, sub-carrier), no search
         constexpr int UNR = 4; // loads of UNR independent REs in flight per thread (the kernel is latency-bound otherwise)
+        // 21 pairs x 12 sub-carriers per sweep of the workgroup: a thread keeps its sub-carrier, so nothing is divided in the loop
+        const uint32_t q_thr = threadIdx.x / 12, j = threadIdx.x - 12 * q_thr, below = (1u << j) - 1u;
+        const bool     lane_on = threadIdx.x < 252;
         auto body = [&](auto *dst) {
-            const uint32_t total = n_pairs * 12;
-            for (uint32_t t0 = threadIdx.x; t0 < total; t0 += UNR * blockDim.x) {
+            for (uint32_t qb = 0; qb < n_pairs; qb += 21 * UNR) {
                 float    yr[UNR], yi[UNR], hr[UNR], hi[UNR];
                 uint32_t idx[UNR];
                 bool     on[UNR];
 #pragma unroll
                 for (int r = 0; r < UNR; r++) {
-                    const uint32_t t = t0 + r * blockDim.x, tc = t < total ? t : 0u;
-                    const uint32_t q = tc / 12, j = tc - q * 12, mk = masks[q];
-                    on[r]  = t < total && ((mk >> j) & 1u);
-                    idx[r] = offs[q] + __popc(mk & ((1u << j) - 1u));
-                    const uint32_t p = on[r] ? (mk >> 12) + j : 0u;
-                    yr[r] = y_re_p[p]; yi[r] = y_im_p[p]; hr[r] = h_re_p[p]; hi[r] = h_im_p[p];
+                    const uint32_t q = qb + 21 * r + q_thr;
+                    const bool     in = lane_on && q < n_pairs;
+                    const uint32_t qc = in ? q : 0u, mk = masks[qc];
+                    on[r]  = in && ((mk >> j) & 1u);
+                    idx[r] = offs[qc] + __popc(mk & below);
+                    const uint32_t ob = on[r] ? ((mk >> 12) + j) << 2 : 0u; // byte offset in 32 bits: one register serves the four planes
+                    yr[r] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(y_re_p) + ob);
+                    yi[r] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(y_im_p) + ob);
+                    hr[r] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(h_re_p) + ob);
+                    hi[r] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(h_im_p) + ob);
                 }
 #pragma unroll
                 for (int r = 0; r < UNR; r++) {
                     if (!on[r]) continue;
                     const float hn = hr[r] * hr[r] + hi[r] * hi[r];
                     const float xr = (yr[r] * hr[r] + yi[r] * hi[r]) / hn, xi = (yi[r] * hr[r] - yr[r] * hi[r]) / hn;
-                    int8_t b[6] = {0, 0, 0, 0, 0, 0};
-                    demap_symbol(xr, xi, al.mod_type, b);
-                    put_bits(dst, idx[r], b);
+                    if (qam) put_qam(dst, idx[r], qam_neg_bits(xr, xi, al.mod_type));
+                    else {
+                        int8_t b[6] = {0, 0, 0, 0, 0, 0};
+                        demap_symbol(xr, xi, al.mod_type, b);
+                        put_bits(dst, idx[r], b);
+                    }
                 }
             }
         };
@@ -201,6 +226,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         }
         // layer de-mapping d[i*N_ant + p] = x_p[i] (liblte_phy.cc:7506-7513), de-map, descramble (:3833-3836)
         for (uint32_t p = 0; p < N_ant; p++) {
+            if (qam) {
+                const uint32_t neg = qam_neg_bits(x_re[p], x_im[p], al.mod_type);
+                if (via_lds) put_qam(e_lds, i * N_ant + p, neg); else put_qam(e, i * N_ant + p, neg);
+                continue;
+            }
             int8_t b[6] = {0, 0, 0, 0, 0, 0};
             demap_symbol(x_re[p], x_im[p], al.mod_type, b);
             if (via_lds) put_bits(e_lds, i * N_ant + p, b); else put_bits(e, i * N_ant + p, b);

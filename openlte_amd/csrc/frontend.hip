@@ -516,11 +516,12 @@ extern "C" int mi_lte_dl_frontend_batch(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cf
     const size_t lds_fft = sizeof(float2) * (g.N + g.N / 32 + 1);
     // 14 symbols + the look-ahead symbols of the next subframe that the CRS interpolation reads: symbol 14 (ports 0 and 1) and, only
     // with four ports, symbol 15 (ports 2 and 3 carry their CRS in the second symbol of a slot)
-    const uint32_t n_sym = cfg->N_ant > 2 ? 16 : 15;
-    if (cfg->sample_format == MI_LTE_IQ_I8) {
+    const uint32_t fmt = cfg->sample_format & ~(uint32_t)MI_LTE_IQ_ALL_ROWS;
+    const uint32_t n_sym = (cfg->N_ant > 2 || (cfg->sample_format & MI_LTE_IQ_ALL_ROWS)) ? 16 : 15;
+    if (fmt == MI_LTE_IQ_I8) {
         SampleSrc<int8_t> s{(const int8_t *)d_samples_a};
         FFT_LAUNCH("k_dl_fft", int8_t, false, dim3(n_sym, n_units), s, d_unit_start, g, ctx->d_fft_tw, d_subframes);
-    } else if (cfg->sample_format == MI_LTE_IQ_F32_PLANAR) {
+    } else if (fmt == MI_LTE_IQ_F32_PLANAR) {
         if (!d_samples_b) return MI_LTE_ERR_INVALID_ARG;
         SampleSrc<float> s{(const float *)d_samples_a, (const float *)d_samples_b};
         FFT_LAUNCH("k_dl_fft", float, false, dim3(n_sym, n_units), s, d_unit_start, g, ctx->d_fft_tw, d_subframes);

@@ -35,7 +35,7 @@ int mi_lte_get_dl_subframe_and_ce_host(mi_lte_ctx *ctx, uint32_t fft_size, uint3
     struct { uint64_t start; uint32_t sf, cell; } par = {0, subfr_num, N_id_cell};
     MI_HIP_CHECK(ctx, hipMemcpyAsync(d_par.p, &par, sizeof(par), hipMemcpyHostToDevice, ctx->stream));
     MI_HIP_CHECK(ctx, hipMemsetAsync(d_sub.p, 0, nf * 4, ctx->stream));
-    mi_lte_dl_cfg cfg = {fft_size, N_rb_dl, N_ant, MI_LTE_IQ_F32_PLANAR};
+    mi_lte_dl_cfg cfg = {fft_size, N_rb_dl, N_ant, MI_LTE_IQ_F32_PLANAR | MI_LTE_IQ_ALL_ROWS}; // every row the reference's struct holds
     int rc = mi_lte_dl_frontend_batch(ctx, &cfg, d_i.p, d_q.p, (const uint64_t *)d_par.p, (const uint32_t *)((char *)d_par.p + 8),
                                       (const uint32_t *)((char *)d_par.p + 12), 1, (float *)d_sub.p);
     if (rc != MI_LTE_OK) return rc;

@@ -84,4 +84,29 @@ __device__ __forceinline__ void demap_symbol(float re, float im, uint32_t mod, i
 }
 
 
+// The hard decisions of modulation_demapper for 16QAM / 64QAM (liblte_phy.cc:9560-9660) as a bit mask: bit k set <=> soft bit k is
+// -127 (all of them are +-127 for these two modulations).  Same comparisons as demap_symbol above, negated where the reference's
+// branch yields -127, so NaNs fall the same way.
+__device__ __forceinline__ uint32_t qam_neg_bits(float re, float im, uint32_t mod)
+{
+    const float t10 = (float)(2 / sqrt(10.0)), t42 = (float)(2 / sqrt(42.0)), f42 = (float)(4 / sqrt(42.0)), s42 = (float)(6 / sqrt(42.0));
+    const float ar = fabsf(re), ai = fabsf(im);
+    uint32_t    t = (!(re > 0) ? 1u : 0u) | (!(im > 0) ? 2u : 0u);
+    if (mod == 3) {
+        const bool in_r = ar < f42, in_i = ai < f42;
+        t |= (!in_r ? 4u : 0u) | (!in_i ? 8u : 0u);
+        t |= ((in_r ? !(ar > t42) : !(ar < s42)) ? 16u : 0u) | ((in_i ? !(ai > t42) : !(ai < s42)) ? 32u : 0u);
+    } else {
+        t |= (!(ar < t10) ? 4u : 0u) | (!(ai < t10) ? 8u : 0u);
+    }
+    return t;
+}
+// entry t of the table that turns such a mask into soft bits: byte k = (t >> k) & 1 ? -127 : 127, k = 0..5
+__device__ __forceinline__ uint2 qam_lut_entry(uint32_t t)
+{
+    uint32_t w[2] = {0, 0};
+    for (uint32_t k = 0; k < 6; k++) w[k >> 2] |= (((t >> k) & 1u) ? 0x81u : 0x7Fu) << (8 * (k & 3));
+    return make_uint2(w[0], w[1]);
+}
+
 } // namespace

@@ -53,7 +53,10 @@ __device__ __forceinline__ uint32_t pdsch_mask(uint32_t N_ant, uint32_t cell, ui
 // occupancy: 8 waves per SIMD with a few spilled registers beat 4 without (2.80 -> 2.18 ms per 32k subframes); the single-port
 // case is its own instantiation so that the 2/4-port combiners do not set its register count.
 template <bool ONE_PORT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_pdsch_demod(const float *__restrict__ subframes, DemodGeom g,
+#ifndef DEMOD_WPE
+#define DEMOD_WPE 8
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEMOD_WPE, 8))) void k_pdsch_demod(const float *__restrict__ subframes, DemodGeom g,
                                                      const mi_lte_pdsch_alloc *__restrict__ allocs,
                                                      const uint32_t *__restrict__ subfr_num, const uint32_t *__restrict__ n_id_cell,
                                                      GoldTables gt, int8_t *__restrict__ e_base, const uint32_t *__restrict__ e_off,

@@ -654,18 +654,48 @@ template <int R> __device__ __forceinline__ v2s byte_pair(uint32_t w0, uint32_t 
     return as_v2s(__builtin_amdgcn_perm(w1, w0, (uint32_t)(4 + R) << 24 | 0x0C0000u | (uint32_t)R << 8 | 0x0Cu)) >> 8;
 }
 
-// grid.x = workgroups of one wavefront; mode 0: trellis h of workgroup b is tile 2b + h of pass p[0] (first pass, two tiles per
-// lane); mode 1: trellis h is tile b of pass p[h] (passes 2 and 3 of one tile)
-__global__ __launch_bounds__(64) void k_turbo_siso(SisoArgs args, uint32_t K, uint32_t n_tiles, uint32_t mode)
+// Traceback two steps at a time.  One step of the reference's traceback (liblte_phy.cc:10483-10527) maps (state at t+1, the four stored
+// compare bits of time t) to (state at t, sign of the output); two of them are a function of 3 + 8 bits, kept as a 2048-entry LDS
+// table per workgroup: entry = state after both steps | byte masks (0xFF = negative) of the two outputs in bits 8-23, the first
+// step's in the upper byte.  The outputs are then the magnitude words with the masked bytes negated (carry-free byte arithmetic).
+__device__ __forceinline__ uint32_t traceback_entry(uint32_t byte, uint32_t cur)
 {
-    const uint32_t lane = threadIdx.x, Kp = kpad64(K), nblk = Kp >> 6;
+    uint32_t mask = 0;
+    for (int k = 0; k < 2; k++) {
+        const uint32_t nib = k ? byte >> 4 : byte & 15u; // the step processed first sits in the low nibble
+        const uint32_t j = cur & 3u, bit = (nib >> (3 - j)) & 1u, st = 2 * j + bit; // pair j is bit (3-j) of the nibble
+        const bool     pos = (cur < st) || (cur == st && cur == 0); // "+" when the step moved to a lower state, or stayed in state 0
+        if (!pos) mask |= k ? 0x00FFu : 0xFF00u;
+        cur = st;
+    }
+    return cur | mask << 8;
+}
+__device__ __forceinline__ uint32_t negate_bytes(uint32_t w, uint32_t m) // -b in the bytes where m is 0xFF, b elsewhere
+{
+    const uint32_t x = w ^ m, y = m & 0x01010101u;
+    return ((x & 0x7F7F7F7Fu) + y) ^ (x & 0x80808080u);
+}
+
+// Workgroups of four independent wavefronts (they only share the traceback table).  mode 0: trellis h of wavefront b is tile 2b + h of
+// pass p[0] (first pass, two tiles per lane); mode 1: trellis h is tile b of pass p[h] (passes 2 and 3 of one tile)
+#ifndef SISO_WPE
+#define SISO_WPE 4
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SISO_WPE, 8))) void k_turbo_siso(SisoArgs args, uint32_t K, uint32_t n_tiles, uint32_t mode)
+{
+    __shared__ uint32_t tb_lut[2048];
+    for (uint32_t i = threadIdx.x; i < 2048; i += blockDim.x) tb_lut[i] = traceback_entry(i >> 3, i & 7u);
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wv = blockIdx.x * 4 + (threadIdx.x >> 6), n_wv = mode ? n_tiles : (n_tiles + 1) / 2;
+    const uint32_t Kp = kpad64(K), nblk = Kp >> 6;
+    if (wv >= n_wv) return; // wavefront-uniform
     const uint8_t *pa[2], *pb[2], *pmag[2];
     uint8_t       *pout[2];
     uint32_t      *dec[2];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const SisoPass &ps   = args.p[mode ? h : 0];
-        const uint32_t  tile = mode ? blockIdx.x : min(2 * blockIdx.x + h, n_tiles - 1); // an odd tile count: the last one twice
+        const uint32_t  tile = mode ? wv : min(2 * wv + h, n_tiles - 1); // an odd tile count: the last one twice
         const size_t    off  = (size_t)tile * Kp * 64 + lane * 64;
         pa[h] = ps.in_a + off; pb[h] = ps.in_b + off; pmag[h] = ps.mag + off; pout[h] = ps.out + off;
         dec[h] = ps.dec + ((size_t)tile * nblk * 64 + lane) * 8;
@@ -768,7 +798,7 @@ __global__ __launch_bounds__(64) void k_turbo_siso(SisoArgs args, uint32_t K, ui
                 const int g = 2 * q + g2;
                 uint32_t  o_hi[2] = {0, 0}, o_lo[2] = {0, 0};
                 if ((uint32_t)blk * 64 + g * 8 < K) {
-                    uint32_t word[2], mlo[2], mhi[2];
+                    uint32_t word[2], mlo[2], mhi[2], msk[2][4];
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
                         const uint4 dq = D[h][g >> 2];
@@ -776,22 +806,20 @@ __global__ __launch_bounds__(64) void k_turbo_siso(SisoArgs args, uint32_t K, ui
                         mlo[h]  = g2 ? M[h][q].z : M[h][q].x;
                         mhi[h]  = g2 ? M[h][q].w : M[h][q].y;
                     }
+                    // the compare bits of step r sit in nibble (7-r) of the word: byte b holds steps 7-2b (low nibble, traced first) and 6-2b
 #pragma unroll
-                    for (int r = 7; r >= 0; r--) {
+                    for (int b = 0; b < 4; b++) {
 #pragma unroll
                         for (int h = 0; h < 2; h++) {
-                            // bits of step r sit in nibble (7-r); pair j is bit (3-j) of the nibble
-                            const int j   = cur[h] & 3;
-                            const int bit = (word[h] >> (4 * (7 - r) + (3 - j))) & 1;
-                            const int st  = 2 * j + bit; // state at time t
-                            const int m   = sbyte(r >= 4 ? mhi[h] : mlo[h], r & 3);
-                            // output bit 0 ("+") when the step moved to a lower state, or stayed in state 0
-                            const bool pos = (cur[h] < st) || (cur[h] == st && cur[h] == 0);
-                            const int  v   = pos ? m : -m;
-                            if (r >= 4) o_hi[h] |= ((uint32_t)(v & 0xFF)) << (8 * (r - 4));
-                            else        o_lo[h] |= ((uint32_t)(v & 0xFF)) << (8 * r);
-                            cur[h] = st;
+                            const uint32_t e = tb_lut[((word[h] >> (8 * b)) & 0xFFu) << 3 | (uint32_t)cur[h]];
+                            cur[h]    = (int)(e & 7u);
+                            msk[h][b] = e >> 8;
                         }
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; h++) { // steps 7..4 -> bytes 3..0 of o_hi, steps 3..0 -> o_lo
+                        o_hi[h] = negate_bytes(mhi[h], msk[h][0] << 16 | msk[h][1]);
+                        o_lo[h] = negate_bytes(mlo[h], msk[h][2] << 16 | msk[h][3]);
                     }
                 }
 #pragma unroll
@@ -1219,7 +1247,7 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
     SisoArgs s1;
     s1.p[0] = {arr[AX1], arr[AX0], arr[AM1], arr[AA1], dec[0]};
     s1.p[1] = s1.p[0];
-    MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso, dim3((n_tiles + 1) / 2), dim3(64), 0, s1, K, (uint32_t)n_tiles, 0u); // two tiles per lane
+    MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso, dim3(((n_tiles + 1) / 2 + 3) / 4), dim3(256), 0, s1, K, (uint32_t)n_tiles, 0u); // two tiles per lane
 
     PermArgs pa;
     pa.A1 = arr[AA1]; pa.X2 = arr[AX2]; pa.out[0] = arr[AI1]; pa.out[1] = arr[AM3];
@@ -1228,7 +1256,7 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
     SisoArgs s23;
     s23.p[0] = {arr[AX2], arr[AI0], arr[AM2], arr[AB1], dec[1]};
     s23.p[1] = {arr[AX2], arr[AI1], arr[AM3], arr[AB2], dec[2]};
-    MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso, dim3(n_tiles), dim3(64), 0, s23, K, (uint32_t)n_tiles, 1u); // passes 2 and 3 of a tile per lane
+    MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso, dim3((n_tiles + 3) / 4), dim3(256), 0, s23, K, (uint32_t)n_tiles, 1u); // passes 2 and 3 of a tile per lane
 
     VoteArgs va = {arr[AX0], arr[AA1], arr[AB1], arr[AB2]};
     MI_LAUNCH(ctx, "k_turbo_vote", (k_turbo_vote<GROUP, 1>), dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), 3 * Kp + 64, va, K, n_cb, tb.d_inv, d_c_bits, gd);

@@ -505,7 +505,10 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(PREP_WPE, 8
         mx = block_max_f(mxv, red_f);
     }
     const bool use_qtab = Src::kIntegerValued && mx < (float)QTAB_HALF; // uniform over the workgroup
-    if (use_qtab) {
+    // max = 127 (any saturated soft bit and no repetition: every 16QAM / 64QAM allocation): q(d) = (int)(d * 127.0f / 127.0f) = d,
+    // the product and the quotient being exact -- no table, the bytes are the values themselves
+    const bool identity = Src::kIntPath && mxi == 127;
+    if (use_qtab && !identity) {
         if constexpr (Src::kIntPath) { // signed table centred on a fixed slot: entry QTAB_HALF + d holds q(d) -- one read per element
             for (int d = (int)threadIdx.x - mxi; d <= mxi; d += (int)blockDim.x) qc[d] = (int8_t)(int)((float)d * 127.0f / mx);
         } else {
@@ -518,7 +521,12 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(PREP_WPE, 8
     uint4 Q[3];
 #pragma unroll
     for (int x = 0; x < 3; x++) {
-        if (Src::kIntPath && use_qtab) {
+        if (Src::kIntPath && identity) {
+            int q[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) q[k] = (int)v[x][k];
+            Q[x] = pack16(q);
+        } else if (Src::kIntPath && use_qtab) {
             uint32_t o[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) // 0 past the block end -> q(0) = 0

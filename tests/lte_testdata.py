@@ -98,6 +98,12 @@ UL_CASES = {
                                                              (1, 904, list(range(20, 30)), 0x42)]),
     "1p4MHz_hop": (128, 6, 301, (0, 1, 0, 0, 0), [0, 9], [(1, 120, [1, 2], 0x55), (1, 256, [3, 4, 5], 0x56)]),
     "5MHz_seqhop_16qam": (512, 25, 44, (7, 0, 1, 3, 1), [3], [(1, 904, list(range(2, 12)), 0x77), (2, 1000, list(range(12, 18)), 0x78)]),
+    # the PUSCH widths up to 10 PRB the reference has DFT plans for (N_prb divisible by 2, 3 or 5, liblte_phy.cc:2360-2377):
+    # transform sizes 24 .. 120, i.e. every radix of the pre-decoding DFT (9, 3, 5, 8, 4, 2) in first and later passes
+    "20MHz_radices": (2048, 100, 23, (5, 0, 0, 1, 2), [2], [(1, 144, [1, 2], 0x62), (1, 256, [3, 4, 5], 0x63),
+                                                            (1, 328, list(range(6, 10)), 0x64), (1, 408, list(range(10, 15)), 0x65),
+                                                            (1, 504, list(range(15, 21)), 0x66), (1, 712, list(range(21, 29)), 0x67),
+                                                            (1, 776, list(range(29, 38)), 0x68), (1, 904, list(range(38, 48)), 0x69)]),
     "10MHz_prime": (1024, 50, 100, (11, 0, 0, 7, 3), [7, 8], [(1, 1256, list(range(4, 18)), 0x99), (1, 2024, list(range(20, 42)), 0x9A)]),
 }
 

@@ -44,6 +44,24 @@ __device__ __forceinline__ uint32_t lds_u8(uint32_t addr) { return *(lds_u8_t *)
 __device__ __forceinline__ int      lds_i8(uint32_t addr) { return *(lds_i8_t *)(uintptr_t)addr; }
 __device__ __forceinline__ uint32_t lds_u16(uint32_t addr) { return *(lds_u16_t *)(uintptr_t)addr; }
 
+// pairs of int16 in one register (v_pk_*_i16), used by the per-code-block kernels and the SISO kernel below
+typedef short v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2s      as_v2s(uint32_t w) { return __builtin_bit_cast(v2s, w); }
+__device__ __forceinline__ uint32_t as_u32(v2s v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ v2s      even2(uint32_t w) { return (as_v2s(w) << 8) >> 8; }
+__device__ __forceinline__ v2s      odd2(uint32_t w) { return as_v2s(w) >> 8; }
+__device__ __forceinline__ uint32_t merge_bytes(v2s e, v2s o) { return __builtin_amdgcn_perm(as_u32(o), as_u32(e), 0x06020400u); } // low bytes of (e.lo, o.lo, e.hi, o.hi)
+__device__ __forceinline__ v2s      abs2(v2s a) { return __builtin_elementwise_max(a, (v2s)(0) - a); }
+// 0xFFFF per negative half.  Opaque on purpose: from a visible "x >> 15" feeding an and/or select the compiler rebuilds per-half
+// compares and selects, which costs twice the instructions of the mask + one bit-select it replaces.
+__device__ __forceinline__ uint32_t neg_mask(v2s d)
+{
+    uint32_t m;
+    asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(m) : "v"(as_u32(d))); // the inline constant has no upper half
+    return m;
+}
+__device__ __forceinline__ v2s bit_select(uint32_t m, v2s yes, v2s no) { return as_v2s((as_u32(yes) & m) | (as_u32(no) & ~m)); }
+
 // sign * ((|a|+|b|) >> 1), sign negative iff exactly one operand is negative (0 counts as positive).
 // This one form covers the four branches of Step 3 (liblte_phy.cc:10688-10707) and the g=03 soft
 // re-encoder conv_encode_soft (liblte_phy.cc:10123-10147).
@@ -162,12 +180,13 @@ __device__ __forceinline__ void unpack_idx(const IdxRaw &r, uint32_t (&idx)[16])
 template <typename T> struct SrcDirect {
     static constexpr bool kIntegerValued = sizeof(T) != 4; // int8 / int16 soft values
     static constexpr bool kIntPath = false;
+    static constexpr bool kPacked = false;
     uint32_t e_cap;
     const T *soft;
     const T *d;
     __device__ __forceinline__ void init(uint32_t cb, uint32_t K) { d = soft + (size_t)cb * 3 * (K + 4); }
     __device__ __forceinline__ bool stage_e(int8_t *) { return false; }
-    // v[x][k] = d[(16u+k)*3 + x] for k < nvalid (16 or 8), with Step 0 (RX_NULL_BIT -> 0, liblte_phy.cc:10636-10642)
+    // v[Src::kPacked ? 0 : x][k] = d[(16u+k)*3 + x] for k < nvalid (16 or 8), with Step 0 (RX_NULL_BIT -> 0, liblte_phy.cc:10636-10642)
     __device__ __forceinline__ void load16(uint32_t u, int nvalid, float (&v)[3][16], uint32_t, bool) const
     {
         const T *p = d + (size_t)u * 48;
@@ -339,9 +358,11 @@ struct SrcRateUnmatch {
         __syncthreads();
         return true;
     }
-    // the gather from the staged copy: v[x][k] = sum over laps t of e[min(rank + t*Nnn, E)], ranks 0xFFFF (NULL, or past the
+    // the gather from the staged copy: v[Src::kPacked ? 0 : x][k] = sum over laps t of e[min(rank + t*Nnn, E)], ranks 0xFFFF (NULL, or past the
     // block end) included -- three operations per element and lap, no predicate
-    __device__ __forceinline__ void gather16_staged(uint32_t el /* LDS address of the staged copy */, uint32_t u, int nvalid, int (&v)[3][16]) const
+    // (emit(x, acc) receives the 16 sums of stream x; it is called stream by stream so that a caller that packs them keeps only one
+    // stream unpacked at a time)
+    template <typename Emit> __device__ __forceinline__ void gather16_staged(uint32_t el /* LDS address of the staged copy */, uint32_t u, int nvalid, Emit emit) const
     {
         uint4 raw[3][2];
 #pragma unroll
@@ -354,20 +375,22 @@ struct SrcRateUnmatch {
         for (int x = 0; x < 3; x++) {
             const uint32_t w[8] = {raw[x][0].x, raw[x][0].y, raw[x][0].z, raw[x][0].w, raw[x][1].x, raw[x][1].y, raw[x][1].z, raw[x][1].w};
             uint32_t       r[16];
+            int            acc[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) {
-                r[k]    = (k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xFFFFu);
-                v[x][k] = lds_i8(el + min(r[k], E));
+                r[k]   = (k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xFFFFu);
+                acc[k] = lds_i8(el + min(r[k], E));
             }
             for (uint32_t base = Nnn; base < E; base += Nnn) {
 #pragma unroll
-                for (int k = 0; k < 16; k++) v[x][k] += lds_i8(el + min(r[k] + base, E));
+                for (int k = 0; k < 16; k++) acc[k] += lds_i8(el + min(r[k] + base, E));
             }
+            emit(x, acc);
         }
     }
     // d[(16u+k)*3+x] = sum over laps t of e[rank + t*Nnn] (first visit stores, repeats add, :11402-11416).
     // All first-lap loads of a unit are independent; later laps (uniform trip count) are masked.
-    template <typename P, typename V> __device__ __forceinline__ void gather16(P ep, uint32_t u, int nvalid, V (&v)[3][16]) const
+    template <typename P, typename Emit> __device__ __forceinline__ void gather16(P ep, uint32_t u, int nvalid, Emit emit) const
     {
         // the rank words of all three streams are requested before the first is used: one L2 round trip instead of three
         uint4 raw[3][2];
@@ -401,17 +424,34 @@ struct SrcRateUnmatch {
                     acc[k] += (q < E) ? t : 0;
                 }
             }
-#pragma unroll
-            for (int k = 0; k < 16; k++) v[x][k] = (V)acc[k];
+            emit(x, acc);
         }
     }
+    static constexpr bool kPacked = false;
     static constexpr bool kIntPath = true; // the sums are small integers: the quantiser below never leaves integer arithmetic
     __device__ __forceinline__ void load16(uint32_t u, int nvalid, int (&v)[3][16], uint32_t e_lds, bool in_lds) const
     {
-        if (in_lds) gather16_staged(e_lds, u, nvalid, v);
-        else        gather16(e, u, nvalid, v);
+        auto emit = [&](int x, const int (&acc)[16]) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[x][k] = acc[k];
+        };
+        if (in_lds) gather16_staged(e_lds, u, nvalid, emit);
+        else        gather16(e, u, nvalid, emit);
+    }
+    // the same with the sums kept two per register as int16 (vp[x][j] = values 2j, 2j+1 of stream x): 24 registers instead of 48 across
+    // the block-wide maximum, which is what lets the kernel run 8 waves per SIMD.  Valid while the sums fit (SrcRateUnmatchPk below).
+    __device__ __forceinline__ void load16_pk(uint32_t u, int nvalid, uint32_t (&vp)[3][8], uint32_t e_lds, bool in_lds) const
+    {
+        auto emit = [&](int x, const int (&acc)[16]) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) vp[x][j] = __builtin_amdgcn_perm((uint32_t)acc[2 * j + 1], (uint32_t)acc[2 * j], 0x05040100u);
+        };
+        if (in_lds) gather16_staged(e_lds, u, nvalid, emit);
+        else        gather16(e, u, nvalid, emit);
     }
 };
+// chosen by the host when no sum can leave int16: ceil(E / Nnn) laps of |e| <= 127 each
+struct SrcRateUnmatchPk : SrcRateUnmatch { static constexpr bool kPacked = true; };
 
 // LDS tables that replace the per-element IEEE divisions: the quantiser and the SISO output magnitude
 // are functions of one small integer and a per-block constant, so each distinct value is divided once
@@ -458,7 +498,10 @@ template <typename Src, int NSLOT>
 #ifndef PREP_WPE
 #define PREP_WPE 6
 #endif
-__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(PREP_WPE, 8))) void k_turbo_prep(Src src, uint32_t K, uint32_t n_cb,
+#ifndef PREP_WPE_PK
+#define PREP_WPE_PK 6 // the int16-pair variant needs 79 VGPRs unspilled (7 waves: 5.3 ms, 8 waves: 8.9 ms, 6: 4.65 ms per 64k subframes)
+#endif
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Src::kPacked ? PREP_WPE_PK : PREP_WPE, 8))) void k_turbo_prep(Src src, uint32_t K, uint32_t n_cb,
                                                     const uint16_t *__restrict__ pi, PrepOut out)
 {
     static_assert(NSLOT == 1, "one unit per thread (K <= 6144 -> at most 384 units)");
@@ -478,31 +521,47 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(PREP_WPE, 8
     const int      nv = (u < n_units) ? min(16, max(0, (int)K - 16 * (int)u)) : -1; // 16, 8 (last unit of a K % 16 == 8 block), 0 (padding), -1
 
     typedef typename std::conditional<Src::kIntPath, int, float>::type val_t;
-    val_t v[3][16];
-    if (nv > 0) src.load16(u, nv, v, PREP_TAB_BYTES, e_in_lds);
-    else {
+    val_t    v[Src::kPacked ? 1 : 3][16]; // the sums of the three streams ...
+    uint32_t vp[3][8];                    // ... or, two per register as int16, when the source says they fit
+    float    mx;
+    int      mxi = 0;
+    if constexpr (Src::kPacked) {
 #pragma unroll
         for (int x = 0; x < 3; x++)
 #pragma unroll
-            for (int k = 0; k < 16; k++) v[x][k] = 0;
-    }
-    float mx;
-    int   mxi = 0;
-    if constexpr (Src::kIntPath) {
-        int hi = 0, lo = 0;
+            for (int j = 0; j < 8; j++) vp[x][j] = 0;
+        if (nv > 0) src.load16_pk(u, nv, vp, PREP_TAB_BYTES, e_in_lds);
+        v2s hi = (v2s)(0), lo = (v2s)(0);
 #pragma unroll
         for (int x = 0; x < 3; x++)
 #pragma unroll
-            for (int k = 0; k < 16; k += 2) { hi = max(max(hi, v[x][k]), v[x][k + 1]); lo = min(min(lo, v[x][k]), v[x][k + 1]); }
-        mxi = block_max_i(max(hi, -lo), red_i);
+            for (int j = 0; j < 8; j++) { hi = __builtin_elementwise_max(hi, as_v2s(vp[x][j])); lo = __builtin_elementwise_min(lo, as_v2s(vp[x][j])); }
+        mxi = block_max_i(max(max((int)hi.x, (int)hi.y), -min((int)lo.x, (int)lo.y)), red_i);
         mx  = (float)mxi;
     } else {
-        float mxv = 0;
+        if (nv > 0) src.load16(u, nv, v, PREP_TAB_BYTES, e_in_lds);
+        else {
 #pragma unroll
-        for (int x = 0; x < 3; x++)
+            for (int x = 0; x < 3; x++)
 #pragma unroll
-            for (int k = 0; k < 16; k++) mxv = fmaxf(mxv, fabsf(v[x][k]));
-        mx = block_max_f(mxv, red_f);
+                for (int k = 0; k < 16; k++) v[Src::kPacked ? 0 : x][k] = 0;
+        }
+        if constexpr (Src::kIntPath) {
+            int hi = 0, lo = 0;
+#pragma unroll
+            for (int x = 0; x < 3; x++)
+#pragma unroll
+                for (int k = 0; k < 16; k += 2) { hi = max(max(hi, v[Src::kPacked ? 0 : x][k]), v[x][k + 1]); lo = min(min(lo, v[Src::kPacked ? 0 : x][k]), v[x][k + 1]); }
+            mxi = block_max_i(max(hi, -lo), red_i);
+            mx  = (float)mxi;
+        } else {
+            float mxv = 0;
+#pragma unroll
+            for (int x = 0; x < 3; x++)
+#pragma unroll
+                for (int k = 0; k < 16; k++) mxv = fmaxf(mxv, fabsf(v[Src::kPacked ? 0 : x][k]));
+            mx = block_max_f(mxv, red_f);
+        }
     }
     const bool use_qtab = Src::kIntegerValued && mx < (float)QTAB_HALF; // uniform over the workgroup
     // max = 127 (any saturated soft bit and no repetition: every 16QAM / 64QAM allocation): q(d) = (int)(d * 127.0f / 127.0f) = d,
@@ -521,29 +580,51 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(PREP_WPE, 8
     uint4 Q[3];
 #pragma unroll
     for (int x = 0; x < 3; x++) {
-        if (Src::kIntPath && identity) {
+        if constexpr (Src::kPacked) {
+            uint32_t o[4];
+            if (identity) { // the low bytes of the four int16 values of two registers
+#pragma unroll
+                for (int j = 0; j < 4; j++) o[j] = __builtin_amdgcn_perm(vp[x][2 * j + 1], vp[x][2 * j], 0x06040200u);
+            } else {
+                int d[16];
+#pragma unroll
+                for (int j = 0; j < 8; j++) { d[2 * j] = (int)__builtin_amdgcn_sbfe(vp[x][j], 0, 16); d[2 * j + 1] = (int)vp[x][j] >> 16; }
+                if (use_qtab) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) // 0 past the block end -> q(0) = 0
+                        o[j] = pack4u(lds_u8(QTAB_HALF + d[4 * j]), lds_u8(QTAB_HALF + d[4 * j + 1]), lds_u8(QTAB_HALF + d[4 * j + 2]), lds_u8(QTAB_HALF + d[4 * j + 3]));
+                } else {
+                    int q[16];
+#pragma unroll
+                    for (int k = 0; k < 16; k++) q[k] = (int)((float)d[k] * 127.0f / mx);
+                    const uint4 t = pack16(q);
+                    o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+                }
+            }
+            Q[x] = make_uint4(o[0], o[1], o[2], o[3]);
+        } else if (Src::kIntPath && identity) {
             int q[16];
 #pragma unroll
-            for (int k = 0; k < 16; k++) q[k] = (int)v[x][k];
+            for (int k = 0; k < 16; k++) q[k] = (int)v[Src::kPacked ? 0 : x][k];
             Q[x] = pack16(q);
         } else if (Src::kIntPath && use_qtab) {
             uint32_t o[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) // 0 past the block end -> q(0) = 0
-                o[j] = pack4u(lds_u8(QTAB_HALF + v[x][4 * j]), lds_u8(QTAB_HALF + v[x][4 * j + 1]), lds_u8(QTAB_HALF + v[x][4 * j + 2]), lds_u8(QTAB_HALF + v[x][4 * j + 3]));
+                o[j] = pack4u(lds_u8(QTAB_HALF + v[Src::kPacked ? 0 : x][4 * j]), lds_u8(QTAB_HALF + v[Src::kPacked ? 0 : x][4 * j + 1]), lds_u8(QTAB_HALF + v[Src::kPacked ? 0 : x][4 * j + 2]), lds_u8(QTAB_HALF + v[Src::kPacked ? 0 : x][4 * j + 3]));
             Q[x] = make_uint4(o[0], o[1], o[2], o[3]);
         } else {
             int q[16];
             if (use_qtab) {
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
-                    const float f = v[x][k]; // 0 past the block end -> q = 0; the lookup is unconditional (no per-element branch)
+                    const float f = v[Src::kPacked ? 0 : x][k]; // 0 past the block end -> q = 0; the lookup is unconditional (no per-element branch)
                     const int   t = qtab[(int)fabsf(f)]; // (int)(-a*127/mx) == -(int)(a*127/mx): IEEE division and truncation are odd
                     q[k]          = f < 0.0f ? -t : t;
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < 16; k++) q[k] = (int)((float)v[x][k] * 127.0f / mx); // v = 0 past the block end
+                for (int k = 0; k < 16; k++) q[k] = (int)((float)v[Src::kPacked ? 0 : x][k] * 127.0f / mx); // v = 0 past the block end
             }
             Q[x] = pack16(q);
         }
@@ -596,22 +677,6 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(PREP_WPE, 8
 // without bound in the reference's ints, but kept modulo 2^16 every difference of two of them is still exact.  That lets one lane
 // walk two independent trellises in the halves of its registers (v_pk_*_i16): two tiles of the first pass, or passes 2 and 3 of the
 // same tile (which share their first input, q(d2)).
-typedef short v2s __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2s      as_v2s(uint32_t w) { return __builtin_bit_cast(v2s, w); }
-__device__ __forceinline__ uint32_t as_u32(v2s v) { return __builtin_bit_cast(uint32_t, v); }
-__device__ __forceinline__ v2s      even2(uint32_t w) { return (as_v2s(w) << 8) >> 8; }
-__device__ __forceinline__ v2s      odd2(uint32_t w) { return as_v2s(w) >> 8; }
-__device__ __forceinline__ uint32_t merge_bytes(v2s e, v2s o) { return __builtin_amdgcn_perm(as_u32(o), as_u32(e), 0x06020400u); } // low bytes of (e.lo, o.lo, e.hi, o.hi)
-__device__ __forceinline__ v2s      abs2(v2s a) { return __builtin_elementwise_max(a, (v2s)(0) - a); }
-// 0xFFFF per negative half.  Opaque on purpose: from a visible "x >> 15" feeding an and/or select the compiler rebuilds per-half
-// compares and selects, which costs twice the instructions of the mask + one bit-select it replaces.
-__device__ __forceinline__ uint32_t neg_mask(v2s d)
-{
-    uint32_t m;
-    asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(m) : "v"(as_u32(d))); // the inline constant has no upper half
-    return m;
-}
-__device__ __forceinline__ v2s bit_select(uint32_t m, v2s yes, v2s no) { return as_v2s((as_u32(yes) & m) | (as_u32(no) & ~m)); }
 
 struct SisoPass {
     const uint8_t *in_a; // first soft value of each pair  (in[2t])
@@ -1318,6 +1383,14 @@ int mi_turbo_ref_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_
     // stage e in LDS when the largest allocation of the group fits next to the block's own arrays
     const uint32_t cap = (e_max_bytes + 16u + 63u) & ~63u; // room for the zero slot behind the longest allocation
     src.e_cap          = (PREP_TAB_BYTES + kpad64(K) + cap + 64 <= 48 * 1024) ? cap : 0;
+    // every stream has at most 31 NULL slots, so a lap of the circular buffer consumes at least 3K - 81 soft bits: while the longest
+    // allocation makes no more than 258 laps no sum of int8 values leaves int16, and the kernel may keep them in pairs
+    const uint32_t laps = (e_max_bytes + (3 * K - 81) - 1) / (3 * K - 81);
+    if (laps <= 258) {
+        SrcRateUnmatchPk pk;
+        static_cast<SrcRateUnmatch &>(pk) = src;
+        return turbo_ref_run<SrcRateUnmatchPk, true>(ctx, pk, K, n_cb, nullptr, gd, src.e_cap);
+    }
     return turbo_ref_run<SrcRateUnmatch, true>(ctx, src, K, n_cb, nullptr, gd, src.e_cap);
 }
 

@@ -219,11 +219,18 @@ int mi_ctx_turbo_tables(mi_lte_ctx *ctx, uint32_t K, int spec, TurboTables *out)
         pi[i]    = (uint16_t)idx;
         inv[idx] = (uint16_t)i; // ascending i: the last (largest) writer wins, as in the reference's loop
     }
+    const uint32_t K16 = (K + 15u) & ~15u, zero_slot = 2u * ((K + 63u) & ~63u);
+    std::vector<uint16_t> inv2(K16, (uint16_t)zero_slot);
+    for (uint32_t j = 0; j < K; j++)
+        if (inv[j] != 0xFFFF) inv2[j] = (uint16_t)(2u * inv[j]);
     TurboTables t;
     MI_HIP_CHECK(ctx, hipMalloc((void **)&t.d_pi, sizeof(uint16_t) * K));
     MI_HIP_CHECK(ctx, hipMalloc((void **)&t.d_inv, sizeof(uint16_t) * K));
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&t.d_inv2, sizeof(uint16_t) * K16));
     ctx->owned.push_back(t.d_pi);
     ctx->owned.push_back(t.d_inv);
+    ctx->owned.push_back(t.d_inv2);
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(t.d_inv2, inv2.data(), sizeof(uint16_t) * K16, hipMemcpyHostToDevice, ctx->stream));
     MI_HIP_CHECK(ctx, hipMemcpyAsync(t.d_pi, pi.data(), sizeof(uint16_t) * K, hipMemcpyHostToDevice, ctx->stream));
     MI_HIP_CHECK(ctx, hipMemcpyAsync(t.d_inv, inv.data(), sizeof(uint16_t) * K, hipMemcpyHostToDevice, ctx->stream));
     MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

@@ -14,6 +14,8 @@
 struct TurboTables {       // device-resident per-K tables
     uint16_t *d_pi  = nullptr; // interleaver index pi[i]
     uint16_t *d_inv = nullptr; // inv[j] = largest i with pi[i] == j, 0xFFFF if none ("hole")
+    uint16_t *d_inv2 = nullptr; // k_turbo_vote's form: 2 * inv[j] (a byte offset into its int16 array), holes and the entries from K up to the
+                                // next multiple of 16 = 2 * kpad64(K), the offset of the array's zero slot
 };
 
 struct RmTables { // per-K rank tables of the fused turbo rate un-matching (see turbo.hip)

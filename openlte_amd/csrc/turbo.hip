@@ -1042,7 +1042,14 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     uint32_t      *red_u = reinterpret_cast<uint32_t *>(bits + Kp);
     const uint32_t u  = threadIdx.x;
     const int      nv = (u < n_units) ? min(16, max(0, (int)K - 16 * (int)u)) : -1;
-    const IdxRaw   vraw = load_idx_raw(inv, u < n_units ? u : 0, nv, K); // needed after the barrier; requested now
+    // the de-interleaver's byte offsets into D12 (ctx.hpp, d_inv2: holes and the positions past the block end point at the zero slot), 16 per
+    // unit; needed after the barrier, requested now
+    IdxRaw vraw;
+    {
+        const uint4 *ip = reinterpret_cast<const uint4 *>(inv + 16 * (size_t)(nv > 0 ? u : 0));
+        vraw.lo = ip[0];
+        vraw.hi = ip[1];
+    }
     v2s            s0e[4], s0o[4]; // s0 = q(d0) + C1, the part of the vote that is not de-interleaved
     if (threadIdx.x == 0) *reinterpret_cast<uint32_t *>(d12 + 2 * Kp) = 0u; // what a hole of the de-interleaver reads
     if (nv >= 0) {
@@ -1095,13 +1102,13 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         F     = K - tbs - 24;
     }
     if (nv > 0) {
-        // Steps 12-14: de-interleave D1 + D2 (a hole contributes 0; past the block end: slot K, where D1 = D2 = 0), add, take the sign
+        // Steps 12-14: de-interleave D1 + D2 (a hole, or a position past the block end, reads the zero slot), add, take the sign
         const uint32_t  iw[8] = {vraw.lo.x, vraw.lo.y, vraw.lo.z, vraw.lo.w, vraw.hi.x, vraw.hi.y, vraw.hi.z, vraw.hi.w};
         uint32_t        me[4], mo[4], bw[4]; // sign masks of the even / odd pairs (0xFFFF per negative sum), the bits one per byte
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const uint32_t i0 = min(iw[2 * j] & 0xFFFFu, Kp), i1 = min(iw[2 * j] >> 16, Kp), i2 = min(iw[2 * j + 1] & 0xFFFFu, Kp), i3 = min(iw[2 * j + 1] >> 16, Kp);
-            const uint32_t ge = lds_u16(2 * i0) | lds_u16(2 * i2) << 16, go = lds_u16(2 * i1) | lds_u16(2 * i3) << 16; // D12 sits at LDS address 0
+            const uint32_t i0 = iw[2 * j] & 0xFFFFu, i1 = iw[2 * j] >> 16, i2 = iw[2 * j + 1] & 0xFFFFu, i3 = iw[2 * j + 1] >> 16;
+            const uint32_t ge = lds_u16(i0) | lds_u16(i2) << 16, go = lds_u16(i1) | lds_u16(i3) << 16; // D12 sits at LDS address 0
             me[j] = as_u32((s0e[j] + as_v2s(ge)) >> 15);
             mo[j] = as_u32((s0o[j] + as_v2s(go)) >> 15);
             bw[j] = (me[j] & 0x00010001u) | (mo[j] & 0x00010001u) << 8; // Step 14
@@ -1332,7 +1339,7 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
     MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso, dim3((n_tiles + 3) / 4), dim3(256), 0, s23, K, (uint32_t)n_tiles, 1u); // passes 2 and 3 of a tile per lane
 
     VoteArgs va = {arr[AX0], arr[AA1], arr[AB1], arr[AB2]};
-    MI_LAUNCH(ctx, "k_turbo_vote", (k_turbo_vote<GROUP, 1>), dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), 3 * Kp + 64, va, K, n_cb, tb.d_inv, d_c_bits, gd);
+    MI_LAUNCH(ctx, "k_turbo_vote", (k_turbo_vote<GROUP, 1>), dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), 3 * Kp + 64, va, K, n_cb, tb.d_inv2, d_c_bits, gd);
     MI_HIP_CHECK(ctx, hipGetLastError());
     ctx->last_kernels = "k_turbo_prep:1,k_turbo_siso:2,k_turbo_perm:1,k_turbo_vote:1";
     return MI_LTE_OK;

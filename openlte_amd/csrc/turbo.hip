@@ -133,12 +133,6 @@ __device__ __forceinline__ uint4 pack16(const int (&q)[16])
                ((uint32_t)(q[4 * k + 3] & 0xFF) << 24);
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
-__device__ __forceinline__ void unpack16(uint4 v, int (&q)[16])
-{
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int k = 0; k < 16; k++) q[k] = sbyte(w[k >> 2], k & 3);
-}
 __device__ __forceinline__ size_t unit_off(size_t tile_off, uint32_t lane, uint32_t u)
 {
     return tile_off + (size_t)(u >> 2) * 4096 + lane * 64 + (u & 3) * 16;
@@ -159,21 +153,6 @@ __device__ __forceinline__ void load_idx16(const uint16_t *tab, uint32_t u, int 
 // the same in two halves, so that the table words can be requested long before they are needed (the kernels below wait on L2
 // round trips far more than they compute)
 struct IdxRaw { uint4 lo, hi; };
-__device__ __forceinline__ IdxRaw load_idx_raw(const uint16_t *tab, uint32_t u, int nvalid, uint32_t pad = 0)
-{
-    const uint4   *p = reinterpret_cast<const uint4 *>(tab + 16 * (size_t)u);
-    const uint32_t pp = pad | (pad << 16);
-    IdxRaw r;
-    r.lo = (nvalid > 0) ? p[0] : make_uint4(pp, pp, pp, pp);
-    r.hi = (nvalid > 8) ? p[1] : make_uint4(pp, pp, pp, pp);
-    return r;
-}
-__device__ __forceinline__ void unpack_idx(const IdxRaw &r, uint32_t (&idx)[16])
-{
-    const uint32_t w[8] = {r.lo.x, r.lo.y, r.lo.z, r.lo.w, r.hi.x, r.hi.y, r.hi.z, r.hi.w};
-#pragma unroll
-    for (int k = 0; k < 16; k++) idx[k] = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
-}
 
 // ---- where the soft values of a code block come from
 // (a) directly from the caller, in the reference's interleaved d[i*3+x] layout
@@ -912,15 +891,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SISO_WPE, 8
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Two-at-a-time int16 arithmetic for the soft re-encoder and the vote (v_pk_*_i16): a register of four int8 values b0..b3 is
-// split into its even pair (b0, b2) and its odd pair (b1, b3), sign-extended to 16 bits; all element-wise work is done on pairs.
-// soft_xor on pairs: sign * ((|a|+|b|) >> 1), sign negative iff exactly one operand is negative
-__device__ __forceinline__ v2s sxor2(v2s a, v2s b)
-{
-    const v2s mag = (abs2(a) + abs2(b)) >> 1, s = (a ^ b) >> 15;
-    return (mag ^ s) - s;
-}
 // A unit of 16 values x[0..15] plus its three-value halo x[-3..-1], as pairs: E[j] = (x[4j-4], x[4j-2]), O[j] = (x[4j-3], x[4j-1]),
 // j = 0 (halo word) .. 4, each pair split into magnitudes and sign masks (0 / 0xFFFF): soft_xor of two such values is
 // ((m_a + m_b) >> 1, s_a ^ s_b), three instructions per pair.  The delayed sequences the soft re-encoder needs are

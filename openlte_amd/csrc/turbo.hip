@@ -150,8 +150,7 @@ __device__ __forceinline__ void load_idx16(const uint16_t *tab, uint32_t u, int 
     for (int k = 0; k < 16; k++) idx[k] = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
 }
 
-// the same in two halves, so that the table words can be requested long before they are needed (the kernels below wait on L2
-// round trips far more than they compute)
+// sixteen table entries as fetched, for kernels that request them long before they unpack them
 struct IdxRaw { uint4 lo, hi; };
 
 // ---- where the soft values of a code block come from

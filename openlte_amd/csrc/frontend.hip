@@ -28,9 +28,14 @@ struct DlGeom {
 
 // The FFT has no bit-exact reference (FFTW's operation order is unspecified; parity is to tolerance), so its
 // complex multiplies may use fused multiply-adds; the rest of the library is built with -ffp-contract=off.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f    to_v(float2 a) { return __builtin_bit_cast(v2f, a); }
+__device__ __forceinline__ float2 to_f2(v2f a) { return __builtin_bit_cast(float2, a); }
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
-    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+    // (a.x b.x - a.y b.y, a.x b.y + a.y b.x) as one packed multiply and one packed fused multiply-add
+    const v2f av = to_v(a), bv = to_v(b), sw = {-bv.y, bv.x};
+    return to_f2(__builtin_elementwise_fma(av.yy, sw, av.xx * bv));
 }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }

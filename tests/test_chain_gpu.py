@@ -130,6 +130,31 @@ def test_big_allocation_soft_combining(ctx, port):
             plan.close()
             d_sub.free()
 
+@pytest.mark.parametrize("mod,tbs,nprb", [(1, 1000, 50), (2, 2024, 60), (1, 256, 40)])
+def test_staged_soft_combining(ctx, port, mod, tbs, nprb):
+    """Several laps of the circular buffer with the allocation's soft bits staged in LDS (E well below the staging limit): QPSK sums of
+    soft values (the quantiser table path), 16QAM sums of +-127 (block maxima of 254, 381, ...)."""
+    import openlte_amd as m
+    from openlte_amd import synth
+    cfg = m.DlCfg(2048, 100, 1, 0)
+    sf, cell = 6, 77
+    allocs = [m.make_alloc(0, mod, tbs, list(range(20, 20 + nprb)), 0x222)]
+    for snr in (20, 2):
+        iq, tx = synth.dl_units(cfg, [sf], [cell], allocs, 1, snr_db=snr, max_delay=4, seed=99 + snr)
+        lc, s = td.oracle_frontend(port, 2048, 100, 1, iq[0], sf, cell)
+        d_sub = ctx.to_device(upload_oracle_subframe(ctx, s, 1))
+        plan = ctx.pdsch_plan(cfg, 2, allocs)
+        st, bits = plan.run(d_sub, [sf], [cell])
+        err, out, desc = oracle_pdsch(port, lc, s, allocs[0], 2, cell, 1)
+        assert len(desc) < 40000 and len(desc) > 3 * (tbs + 28) * 2  # at least two laps, staged
+        assert (plan.soft_bits(0)[:len(desc)] == desc).all()
+        assert st[0] == err and (err != 0 or (bits[0] == out).all())
+        if snr >= 20:
+            assert err == 0 and (bits[0] == tx[0, 0, :tbs]).all()
+        plan.close()
+        d_sub.free()
+
+
 
 def test_two_port_stage_parity(ctx, port):
     """Transmit-diversity combiner path (N_ant = 2) on a single-port capture: garbage in, but the

@@ -5,8 +5,18 @@
 
 A "step" is one pass of the hot path over one batch of synthetic input that is already resident in
 HBM.  Work is sharded by unit (subframes / code blocks) over ranks with no data-path collective
-(weak scaling: the per-GPU batch is fixed); torch.distributed is used only for the barrier and the
-max-over-ranks of the elapsed time.
+(weak scaling: the per-GPU batch is fixed); torch.distributed (gloo, CPU tensors) is used only for the
+barrier and the max-over-ranks of the elapsed time.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes this script under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`, one rank per GPU; under an
+external launcher (the driver's torchrun line) WORLD_SIZE must equal N.  Every rank must own a distinct gfx950 device.
+
+Roofline accounting, stated once:
+  * a STAGE's algorithmic bytes are SURVEY 8d's figure for it, charged ONCE per step against the summed time of the stage's kernels;
+  * a KERNEL's "own_io" is the minimal bytes that kernel has to read and write at its own interface as the data is laid out;
+  * the headline `roofline` is the kernel with the largest share of the timed region, priced at its STAGE's bytes (charged once)
+    over that kernel's time per step -- never a multiple of the stage bytes.
 """
 import argparse
 import json
@@ -21,11 +31,31 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def maybe_relaunch(n_gpus, argv):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: become N ranks.  Returns only in the single-process case or inside a rank."""
+    if n_gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 def dist_setup(n_gpus):
     """Returns (rank, world, barrier, max_reduce).  torch is imported only for multi-rank runs and
-    BEFORE libmi_lte.so so that both share one HIP runtime."""
+    BEFORE libmi_lte.so so that both share one HIP runtime.  Fails loudly when the launcher's world size is not --gpus."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world != max(1, n_gpus):
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; refusing to report a wrong n_gpus" % (n_gpus, world))
     if world == 1:
         return 0, 1, (lambda: None), (lambda x: x)
     import torch
@@ -45,8 +75,71 @@ def dist_setup(n_gpus):
     return rank, world, barrier, max_reduce
 
 
+def cpu_info():
+    """(model string, logical CPUs this process may run on)."""
+    model = "unknown CPU"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return model, n
+
+
+def run_threads(workers):
+    """Run the callables concurrently, one thread each, released together; every callable spends its time inside a C timing loop
+    (the GIL is released).  Returns (results, wall seconds from the common start to the last finisher)."""
+    import threading
+    n = len(workers)
+    gate, res, t_end = threading.Barrier(n + 1), [None] * n, [0.0] * n
+
+    def body(k):
+        gate.wait()
+        res[k] = workers[k]()
+        t_end[k] = time.perf_counter()
+
+    th = [threading.Thread(target=body, args=(k,)) for k in range(n)]
+    for t in th:
+        t.start()
+    gate.wait()
+    t0 = time.perf_counter()
+    for t in th:
+        t.join()
+    return res, max(t_end) - t0
+
+
 # ------------------------------------------------------------------------------------------------
 DECODER = "ref"  # --decoder: "ref" = the reference-faithful decoder (parity mode), "bcjr" = max-log-MAP, 8 iterations
+
+
+def _turbo_alg_bytes(K):
+    return 3 * (K + 4) + K // 8 + 4  # SURVEY 8d: int8 soft in, packed bits + status out
+
+
+def _kp(K):
+    return (K + 63) // 64 * 64
+
+
+def turbo_own_io(K, n_cb, in_bytes, out_bytes, bcjr_iters=0):
+    """Minimal bytes each turbo kernel reads + writes per step for n_cb code blocks of size K, as the tile arrays are laid out
+    (DESIGN.md 3 / 6.0).  in_bytes: what the first kernel reads per block (3(K+4) int8 soft values, or E soft bits);
+    out_bytes: what the last kernel writes per block."""
+    k = _kp(K)
+    if bcjr_iters:
+        h = 2 * bcjr_iters  # half-iterations
+        return {"k_bcjr_prep": n_cb * (in_bytes + 6 * k), "k_bcjr_fwd": n_cb * h * 6 * k, "k_bcjr_bwd": n_cb * (h * 8 * k + 2 * k),
+                "k_bcjr_perm": n_cb * ((h - 1) * 4 * k + 3 * k + out_bytes), "k_rm_to_i8": n_cb * (in_bytes + 3 * (K + 4)),
+                "k_crc_finish": n_cb * (K + out_bytes)}
+    return {"k_turbo_prep": n_cb * (in_bytes + 6 * k),          # X0 X1 X2 I0 M1 M2
+            "k_turbo_siso": n_cb * 3 * 5 * k,                   # per pass: two inputs, magnitudes, output, traceback bits out and back in
+            "k_turbo_perm": n_cb * 4 * k,                       # A1 X2 in, I1 M3 out
+            "k_turbo_vote": n_cb * (4 * k + out_bytes)}         # X0 A1 B1 B2 in, bits out
 
 
 class TurboWorkload:
@@ -92,8 +185,10 @@ class TurboWorkload:
     def units_per_step(self):
         return self.n_cb
 
-    def roofline_bytes(self, kernel, n_launch_per_step):
-        return self.alg_bytes_per_unit * self.n_cb * n_launch_per_step
+    def accounting(self):
+        ks = ["k_bcjr_prep", "k_bcjr_fwd", "k_bcjr_bwd", "k_bcjr_perm"] if DECODER == "bcjr" else ["k_turbo_prep", "k_turbo_siso", "k_turbo_perm", "k_turbo_vote"]
+        return {"stages": {"turbo": (self.alg_bytes_per_unit * self.n_cb, ks)},
+                "own_io": turbo_own_io(self.K, self.n_cb, 3 * (self.K + 4), self.K, 8 if DECODER == "bcjr" else 0)}
 
     def extra(self, value):
         if DECODER != "bcjr":
@@ -139,12 +234,18 @@ class TurboWorkload:
         t = run(32)
         n = int(max(64, min(20000, budget_s / (t / 32))))
         t = run(n)
-        return {"value": round(n * K / t / 1e6, 4), "unit": self.unit, "cores": 1, "kind": kind,
-                "sample": "%d of the benchmark's K=%d code blocks, float soft values, 1 thread, %.1f s" % (n, K, t)}
-
-
-def _turbo_alg_bytes(K):
-    return 3 * (K + 4) + K // 8 + 4  # int8 soft in, packed bits + status out
+        model, n_cpu = cpu_info()
+        out = {"value": round(n * K / t / 1e6, 4), "unit": self.unit, "cores": 1, "kind": kind, "cpu": model,
+               "sample": "%d of the benchmark's K=%d code blocks, float soft values, 1 thread, %.1f s" % (n, K, t)}
+        if R is not None and n_cpu > 1:
+            def worker():
+                phy_k = R.ref_phy_new(4, 17, 1, 100)
+                x, o = np.ascontiguousarray(np.tile(soft_f, ((n + 63) // 64, 1))[:n]), np.zeros(n * K, np.uint8)
+                return lambda: R.ref_turbo_decode_batch(phy_k, x, 3 * D, n, o, K)
+            res, wall = run_threads([worker() for _ in range(n_cpu)])
+            out["all_cores"] = {"value": round(n_cpu * n * K / wall / 1e6, 3), "unit": self.unit, "cores": n_cpu, "kind": kind, "cpu": model,
+                                "sample": "%d threads, one private LIBLTE_PHY_STRUCT each, %d code blocks per thread, wall %.1f s" % (n_cpu, n, wall)}
+        return out
 
 
 class ChainWorkload:
@@ -153,8 +254,13 @@ class ChainWorkload:
     code block each).  One step = FFT -> CE -> demap -> rate-unmatch -> turbo (REF) -> CRC over the
     whole batch of subframes, int8 IQ resident in HBM, decoded bits + status left in HBM."""
     name = "chain"
-    metric = "DL subframes/sec @20MHz 100RB 64QAM, full chain FFT->CE->demap->rate-unmatch->turbo(REF)->CRC (SURVEY 8d W4)"
     unit = "subframes/s"
+
+    @property
+    def metric(self):
+        return "DL subframes/sec @20MHz 100RB 64QAM, full chain FFT->CE->demap->rate-unmatch->turbo(%s)->CRC (SURVEY 8d W4)" % \
+               ("max-log-MAP BCJR x8" if DECODER == "bcjr" else "REF")
+
     dtype = "i8 IQ in, f32 FFT/CE/equaliser, i8 soft bits, i16 path metrics (differences exact modulo 2^16)"
     alg_bytes_per_unit = 70240 + 26984 // 8  # fused accounting, SURVEY 8d: int8 IQ in + packed info bits out
     dominant = "k_turbo_siso"
@@ -174,7 +280,14 @@ class ChainWorkload:
         allocs = []
         for u in range(U):
             allocs += td.w4_allocs(u)
-        iq, tx = synth.dl_units(self.cfg, sfs, cells, allocs, 9, snr_db=30.0, max_delay=8, seed=4242 + rank)
+        # three thirds of the unique subframes at 30 / 26 / 23 dB: the demapper's hard 64QAM decisions carry a growing share of wrong
+        # +-127 soft bits into the decoder (the kernels are branch-free, so this changes the data, not the timing)
+        parts = [synth.dl_units(self.cfg, sfs[k::3], cells[k::3], [a for u in range(k, U, 3) for a in td.w4_allocs(u // 3)], 9,
+                                snr_db=snr, max_delay=8, seed=4242 + rank + k) for k, snr in enumerate((30.0, 26.0, 23.0)) if len(sfs[k::3])]
+        iq = np.zeros((U,) + parts[0][0].shape[1:], parts[0][0].dtype)
+        tx = np.zeros((U,) + parts[0][1].shape[1:], parts[0][1].dtype)
+        for k, (q, t) in enumerate(parts):
+            iq[k::3], tx[k::3] = q, t
         self.uniq = (iq, tx, sfs, cells, allocs)
         idx = np.arange(self.n) % U
         self.idx = idx
@@ -231,15 +344,23 @@ class ChainWorkload:
                                               "outputs downloaded (%.1f GB), serial on one stream; PCIe-inclusive, not the headline value"
                                               % (h2d / 1e9, d2h / 1e9)}}
 
-    def roofline_bytes(self, kernel, n_launch_per_step):
-        """Algorithmic bytes the launches of `kernel` in ONE step account for (roofline table)."""
+    def accounting(self):
+        """SURVEY 8d per-stage bytes (charged once per step) and each kernel's own minimal I/O."""
         n = self.n
-        turbo = 8 * n * _turbo_alg_bytes(3264) + n * _turbo_alg_bytes(1088)
-        return {"k_dl_fft": n * (70240 + 16 * 1200 * 8), "k_dl_ce": n * (5 * 1200 * 8 + 14 * 1200 * 8),
-                "k_pdsch_demod": n * (8 * 1656 + 552) * (16 + 6),
-                "k_turbo_siso": 2 * turbo, "k_turbo_prep": turbo, "k_turbo_perm": turbo, "k_turbo_vote": turbo,
-                "k_rm_to_i8": turbo, "k_crc_finish": turbo, "k_bcjr_prep": turbo, "k_bcjr_fwd": 16 * turbo, "k_bcjr_bwd": 16 * turbo,
-                "k_bcjr_perm": 16 * turbo}.get(kernel)
+        res = 8 * 1656 + 552  # PDSCH resource elements per subframe
+        bc = 8 if DECODER == "bcjr" else 0
+        own = {"k_dl_fft": n * (15 * 2048 * 2 + 15 * 1200 * 8),       # the 15 symbol windows in, 15 rows of symbols out
+               "k_dl_ce": n * (5 * 200 * 8 + 14 * 1200 * 8),           # pilots in, 14 estimate rows out
+               "k_pdsch_demod": n * res * (16 + 6)}                    # y and h per element in, six soft bits out
+        for K, cnt, E, tbs in ((3264, 8, 9936, 3240), (1088, 1, 3312, 1064)):
+            for k, v in turbo_own_io(K, n * cnt, E, tbs, bc).items():
+                own[k] = own.get(k, 0) + v
+        tk = ["k_rm_to_i8", "k_bcjr_prep", "k_bcjr_fwd", "k_bcjr_bwd", "k_bcjr_perm", "k_crc_finish"] if bc else \
+             ["k_turbo_prep", "k_turbo_siso", "k_turbo_perm", "k_turbo_vote"]
+        return {"stages": {"frontend": (n * 339040, ["k_dl_fft", "k_dl_ce"]),
+                           "demod": (n * res * (16 + 6), ["k_pdsch_demod"]),
+                           "turbo": (n * (8 * _turbo_alg_bytes(3264) + _turbo_alg_bytes(1088)), tk)},
+                "own_io": own}
 
     def config(self, world):
         return {"workload": "W4 full DL chain: 20 MHz/100 RB/64QAM, 9 allocations per subframe (8x12 PRB TBS 3240 + 1x4 PRB "
@@ -247,46 +368,74 @@ class ChainWorkload:
                 "subframes_per_gpu": self.n, "N_ant": 1, "CFI": 2,
                 "decoder": "BCJR (max-log-MAP, 8 iterations; specified by the plain-C model, not by the reference)" if DECODER == "bcjr" else "REF (reference-faithful, bit-exact)",
                 "unique_subframes": len(self.uniq[2]),
+                "batch_note": "the %d subframes of a step are %d unique synthetic subframes (30 / 26 / 23 dB) repeated; every kernel on the path is "
+                              "branch-free, so the repetition does not shorten the timed work" % (self.n, len(self.uniq[2])),
                 "sharding": "subframes block-cyclic over %d GPU(s), no collective" % world}
 
-    def cpu_baseline(self, budget_s=14.0):
-        """Reference CPU path on a bounded sample of the same subframes (1 thread)."""
+    def cpu_baseline(self, budget_s=10.0):
+        """The reference's own CPU path on a bounded sample of the benchmark's subframes: (a) one thread, as the reference ships
+        (it is single-threaded), (b) one private LIBLTE_PHY_STRUCT per thread on every CPU this process may use."""
         import ctypes as C
         np = self.np
         from oracle import pyoracle as po
         import lte_testdata as td
         iq, tx, sfs, cells, allocs = self.uniq
-        R, P = po.ref(), po.port()
-        t_total, done, i = 0.0, 0, 0
-        phy = R.ref_phy_new(4, 0, 1, 100) if R is not None else None
-        sf_struct = R.ref_subframe_new() if R is not None else None
-        while t_total < budget_s and done < 4000:
-            u = i % len(sfs)
-            i += 1
-            sf, cell = int(sfs[u]), int(cells[u])
-            re = np.ascontiguousarray(np.concatenate([np.zeros(sf * 30720, np.float32), iq[u, :, 0].astype(np.float32)]))
-            im = np.ascontiguousarray(np.concatenate([np.zeros(sf * 30720, np.float32), iq[u, :, 1].astype(np.float32)]))
-            out, nb = np.zeros(6200, np.uint8), C.c_uint32()
-            t0 = time.perf_counter()
-            if R is not None:
-                R.ref_get_dl_subframe_and_ce(phy, re, im, 0, sf, cell, 1, sf_struct)
-                for a in range(9):
-                    la = td.to_lo_alloc(allocs[u * 9 + a])
-                    rc = R.ref_pdsch_channel_decode(phy, sf_struct, C.byref(la), 2, cell, 1, out, C.byref(nb))
-            else:
-                lc = po.LoCfg()
+        R = po.ref()
+        model, n_cpu = cpu_info()
+        if R is None:  # no compiled reference on this machine: the plain-C restatement, one thread
+            P = po.port()
+            t_total, done = 0.0, 0
+            while t_total < budget_s and done < 4000:
+                u = done % len(sfs)
+                sf, cell = int(sfs[u]), int(cells[u])
+                re = np.ascontiguousarray(np.concatenate([np.zeros(sf * 30720, np.float32), iq[u, :, 0].astype(np.float32)]))
+                im = np.ascontiguousarray(np.concatenate([np.zeros(sf * 30720, np.float32), iq[u, :, 1].astype(np.float32)]))
+                out, nb = np.zeros(6200, np.uint8), C.c_uint32()
+                t0 = time.perf_counter()
+                lc, s = po.LoCfg(), po.LoSubframe()
                 P.lo_cfg_init(C.byref(lc), 2048, 100)
-                s = po.LoSubframe()
                 P.lo_get_dl_subframe_and_ce(C.byref(lc), re, im, 0, sf, cell, 1, C.byref(s))
                 for a in range(9):
                     la = td.to_lo_alloc(allocs[u * 9 + a])
-                    rc = P.lo_pdsch_channel_decode(C.byref(lc), C.byref(s), C.byref(la), 2, cell, 1, out, C.byref(nb), None, None)
-            t_total += time.perf_counter() - t0
-            done += 1
-        return {"value": round(done / t_total, 3), "unit": self.unit, "cores": 1,
-                "kind": "reference" if R is not None else "port",
-                "sample": "%d of the benchmark's subframes (get_dl_subframe_and_ce + 9 x pdsch_channel_decode each), 1 thread, "
-                          "%.1f s; FFT = float64 radix-2 stand-in for FFTW3f" % (done, t_total)}
+                    P.lo_pdsch_channel_decode(C.byref(lc), C.byref(s), C.byref(la), 2, cell, 1, out, C.byref(nb), None, None)
+                t_total += time.perf_counter() - t0
+                done += 1
+            return {"value": round(done / t_total, 3), "unit": self.unit, "cores": 1, "kind": "port", "cpu": model,
+                    "sample": "%d of the benchmark's subframes through oracle/lte_oracle.c, 1 thread, %.1f s" % (done, t_total)}
+
+        def unit_inputs(u):
+            sf, cell = int(sfs[u]), int(cells[u])
+            re = np.ascontiguousarray(np.concatenate([np.zeros(sf * 30720, np.float32), iq[u, :, 0].astype(np.float32)]))
+            im = np.ascontiguousarray(np.concatenate([np.zeros(sf * 30720, np.float32), iq[u, :, 1].astype(np.float32)]))
+            la = (po.LoAlloc * 9)(*[td.to_lo_alloc(allocs[u * 9 + a]) for a in range(9)])
+            return sf, cell, re, im, la
+
+        def worker(u, reps):
+            sf, cell, re, im, la = unit_inputs(u % len(sfs))
+            phy, sfp = R.ref_phy_new(4, 0, 1, 100), R.ref_subframe_new()
+
+            def run():
+                ok = C.c_uint32()
+                t = R.ref_time_dl_chain(phy, re, im, sf, cell, sfp, la, 9, 2, reps, C.byref(ok))
+                R.ref_subframe_free(sfp)
+                R.ref_phy_free(phy)
+                return reps, t, ok.value
+            return run
+
+        _, t3, _ = worker(0, 3)()
+        reps1 = int(max(8, min(4000, budget_s / (t3 / 3))))
+        n1, t1, ok1 = worker(1, reps1)()
+        out = {"value": round(n1 / t1, 3), "unit": self.unit, "cores": 1, "kind": "reference", "cpu": model,
+               "sample": "%d repetitions of one of the benchmark's subframes (liblte_phy_get_dl_subframe_and_ce + 9 x liblte_phy_pdsch_channel_decode, "
+                         "%d/%d CRC pass), 1 thread, %.1f s; FFT = float64 radix-2 stand-in for FFTW3f (pessimistic for the front-end share)"
+                         % (n1, ok1, 9 * n1, t1)}
+        if n_cpu > 1:
+            res, wall = run_threads([worker(k, reps1) for k in range(n_cpu)])
+            tot = sum(r[0] for r in res)
+            out["all_cores"] = {"value": round(tot / wall, 2), "unit": self.unit, "cores": n_cpu, "kind": "reference", "cpu": model,
+                                "sample": "%d threads (every CPU this process may run on), one private LIBLTE_PHY_STRUCT each, %d repetitions per "
+                                          "thread of a benchmark subframe, wall %.1f s" % (n_cpu, reps1, wall)}
+        return out
 
 
 class FrontendWorkload:
@@ -330,8 +479,10 @@ class FrontendWorkload:
     def value_per_unit(self):
         return 1.0
 
-    def roofline_bytes(self, kernel, n_launch_per_step):
-        return {"k_dl_fft": self.n * (70240 + 16 * 1200 * 8), "k_dl_ce": self.n * (5 * 1200 * 8 + 14 * 1200 * 8)}.get(kernel)
+    def accounting(self):
+        n = self.n
+        return {"stages": {"frontend": (n * 339040, ["k_dl_fft", "k_dl_ce"])},
+                "own_io": {"k_dl_fft": n * (15 * 2048 * 2 + 15 * 1200 * 8), "k_dl_ce": n * (5 * 200 * 8 + 14 * 1200 * 8)}}
 
     def config(self, world):
         return {"workload": "W2 front end: 20 MHz/100 RB, %d subframe units per GPU, int8 IQ in HBM" % self.n,
@@ -430,12 +581,18 @@ class UplinkWorkload:
                 "crc_pass": "%d/%d allocations" % (int((st == 0).sum()), st.size), "sampled_blocks_equal_tx_bits": bool(exact),
                 "prach": "%d/%d occasions: the transmitted preamble detected" % (int(((nd == 1) & (pr == np.array(self.pre)[self.pidx])).sum()), self.n_occ)}
 
-    def roofline_bytes(self, kernel, n_launch_per_step):
-        n, M = self.n, 12 * self.N_PRB
-        turbo = n * self.N_UE * _turbo_alg_bytes(self.TBS + 24)
-        return {"k_prach_bins": self.n_occ * (24576 * 2 + 839 * 8), "k_prach_corr": self.n_occ * (839 * 8 + 64 * 12),
-                "k_ul_fft": n * (61440 + 14 * 1200 * 8), "k_pusch_demod": n * self.N_UE * (14 * M * 8 + 12 * M * 2),
-                "k_turbo_siso": 2 * turbo, "k_turbo_prep": turbo, "k_turbo_perm": turbo, "k_turbo_vote": turbo}.get(kernel)
+    def accounting(self):
+        n, M, K = self.n, 12 * self.N_PRB, self.TBS + 24
+        E = 12 * M * 2  # QPSK soft bits per allocation
+        own = {"k_prach_fft": self.n_occ * (24576 * 2 + 24576 * 8), "k_prach_bins": self.n_occ * (24576 * 8 + 839 * 8),
+               "k_prach_corr": self.n_occ * (839 * 8 + 64 * 12),
+               "k_ul_fft": n * (14 * 2048 * 2 + 14 * 1200 * 8), "k_pusch_demod": n * self.N_UE * (14 * M * 8 + E)}
+        own.update(turbo_own_io(K, n * self.N_UE, E, self.TBS))
+        return {"stages": {"frontend": (n * (61440 + 14 * 1200 * 8), ["k_ul_fft"]),
+                           "demod": (n * self.N_UE * (14 * M * 8 + E), ["k_pusch_demod"]),
+                           "turbo": (n * self.N_UE * _turbo_alg_bytes(K), ["k_turbo_prep", "k_turbo_siso", "k_turbo_perm", "k_turbo_vote"]),
+                           "prach": (self.n_occ * (24576 * 2 + 64 * 12), ["k_prach_fft", "k_prach_bins", "k_prach_corr"])},
+                "own_io": own}
 
     def config(self, world):
         return {"workload": "W5 uplink: 20 MHz, %d UEs x %d PRB QPSK PUSCH (TBS %d) per subframe, %d subframes per GPU + %d PRACH occasions "
@@ -518,8 +675,9 @@ class ControlWorkload:
         return {"cfi_ok": "%d/%d" % (int((cfi == 2).sum()), self.n), "subframes_with_every_sent_dci_found": "%d/%d" % (ok, self.n),
                 "dci_per_s": round(value * 2, 1)}
 
-    def roofline_bytes(self, kernel, n_launch_per_step):
-        return {"k_pdcch_decode": self.n * self.alg_bytes_per_unit}.get(kernel)
+    def accounting(self):
+        b = self.n * self.alg_bytes_per_unit
+        return {"stages": {"control": (b, ["k_pdcch_decode"])}, "own_io": {"k_pdcch_decode": b}}
 
     def config(self, world):
         return {"workload": "N3 control region: 20 MHz, 1 port, CFI 2, SI-RNTI + RA-RNTI DCI 1A per subframe, %d device subframes per GPU "
@@ -601,10 +759,11 @@ class SyncWorkload:
         return {"slots_searched_per_s": round(value * self.N_SLOTS, 1), "capture_seconds_per_second": round(value * self.N_SLOTS * 0.0005, 2),
                 "last_search": "peaks=%d N_id_2=%d sss_found=%s" % (self.last[0], self.last[1], self.last[2][0])}
 
-    def roofline_bytes(self, kernel, n_launch_per_step):
+    def accounting(self):
         n = self.n
-        return {"k_cp_corr": n * (161 * 15360 * 2 + 160 * 15360 * 8), "k_cp_accum": n * (160 * 15360 * 8 + 15360 * 4), "k_cp_gather": n * 160 * 5 * 16,
-                "k_sync_fft": n * 165 * (2048 * 2 + 1200 * 8), "k_seq_corr": n * (164 * 1200 * 8 + 1200 * 8)}.get(kernel)
+        own = {"k_cp_corr": n * (161 * 15360 * 2 + 160 * 15360 * 8), "k_cp_accum": n * (160 * 15360 * 8 + 15360 * 4), "k_cp_gather": n * 160 * 5 * 16,
+               "k_sync_fft": n * 165 * (2048 * 2 + 1200 * 8), "k_seq_corr": n * (164 * 1200 * 8 + 1200 * 8)}
+        return {"stages": {"sync": (n * self.alg_bytes_per_unit, list(own))}, "own_io": own}
 
     def config(self, world):
         return {"workload": "N4 initial sync: 20 MHz int8 capture resident in HBM, %d search positions per GPU per step, each = coarse timing over "
@@ -671,9 +830,11 @@ class MultiStream:
     def value_per_unit(self):
         return self.parts[0].value_per_unit()
 
-    def roofline_bytes(self, kernel, n_launch_per_step):
-        vals = [p.roofline_bytes(kernel, max(1, n_launch_per_step // len(self.parts))) for p in self.parts]
-        return None if any(v is None for v in vals) else sum(vals)
+    def accounting(self):
+        accs = [p.accounting() for p in self.parts]
+        st = {k: (sum(a["stages"][k][0] for a in accs), v[1]) for k, v in accs[0]["stages"].items()}
+        own = {k: sum(a["own_io"].get(k, 0) for a in accs) for k in accs[0]["own_io"]}
+        return {"stages": st, "own_io": own}
 
     def config(self, world):
         c = self.parts[0].config(world)
@@ -706,6 +867,61 @@ def pick_workload(name):
     return WORKLOADS["chain"]
 
 
+def turbo_leg(ctx, decoder, n_cb, steps):
+    """The second half of BASELINE.json's metric inside the default line: W3 (K = 6144 code blocks, int8 soft values resident in HBM)
+    decoded `steps` times, timed with HIP events on the launch stream.  Returns information Mbit/s."""
+    import numpy as np
+    import openlte_amd as m
+    from openlte_amd import synth
+    K = 6144
+    tx, soft = synth.turbo_soft_blocks(K, 64, flip=0.02, seed=4321, ref_wrap=(decoder != "bcjr"))
+    idx = (np.arange(n_cb) * 7 + np.arange(n_cb) // 64) % 64
+    d_in, d_out = ctx.to_device(soft[idx]), ctx.alloc(n_cb * K)
+
+    def step():
+        if decoder == "bcjr":
+            ctx.turbo_decode_dev(d_in, m.SOFT_I8, K, n_cb, d_out, mode=m.TURBO_BCJR, n_iter=8, qpp_spec=True)
+        else:
+            ctx.turbo_decode_dev(d_in, m.SOFT_I8, K, n_cb, d_out)
+    step()
+    ctx.sync()
+    ctx.timer_start()
+    for _ in range(steps):
+        step()
+    ms = ctx.timer_stop()
+    got = d_out.download(np.uint8, count=64 * K).reshape(64, K)
+    ok = bool((got == tx[idx[:64]]).all())
+    d_in.free()
+    d_out.free()
+    return {"mbit_per_s": round(n_cb * K * steps / (ms * 1e-3) / 1e6, 1), "ms_per_decode": round(ms / steps, 3), "code_blocks": n_cb, "K": K,
+            "steps": steps, "sampled_blocks_equal_tx_bits": ok}
+
+
+def selftest(args, rank, world, barrier, max_reduce):
+    """--workload selftest: the launch / sharding / timing control plane with no GPU work (what tests/test_dist_cpu.py runs through
+    `--gpus 2` on CPU).  A step is a host-side walk over this rank's shard of a 1000-unit batch."""
+    from openlte_amd.sharding import shard_units, shard_counts
+    mine = list(shard_units(1000, rank, world))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        acc = sum(mine)
+    barrier()
+    elapsed = max_reduce(time.perf_counter() - t0 + 1e-6)
+    import torch.distributed as dist
+    ranks = [None] * world
+    if world > 1:
+        dist.all_gather_object(ranks, (rank, int(os.environ.get("LOCAL_RANK", rank)), len(mine), mine[:3]))
+    else:
+        ranks = [(0, 0, len(mine), mine[:3])]
+    if rank == 0:
+        print(json.dumps({"metric": "selftest (control plane only, no GPU work)", "value": round(1000 * args.steps / elapsed, 1), "unit": "units/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "synthetic",
+                          "config": {"workload": "selftest"}, "ranks": ranks, "shard_counts": shard_counts(1000, world), "checksum": acc}))
+    barrier()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -716,23 +932,29 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="independent shards (contexts/streams) per GPU")
     ap.add_argument("--decoder", default="ref", choices=["ref", "bcjr"], help="turbo workload only: decoder mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-turbo-leg", action="store_true", help="chain workload: skip the short W3 turbo-decode legs after the timed region")
     args = ap.parse_args()
 
     global DECODER
     DECODER = args.decoder
+    maybe_relaunch(args.gpus, sys.argv[1:])
     rank, world, barrier, max_reduce = dist_setup(args.gpus)
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if args.workload == "selftest":
+        return selftest(args, rank, world, barrier, max_reduce)
     import openlte_amd as m
-    n_dev = max(1, m.load_library().mi_lte_device_count())
-    # one GPU per rank; the modulo only matters when ranks outnumber GPUs (testing)
-    ctxs = [m.Context(local_rank % n_dev) for _ in range(max(1, args.streams))]
+    n_dev = m.load_library().mi_lte_device_count()
+    if local_rank >= n_dev:  # one GPU per rank, no sharing: n_gpus in the line means N contexts on N distinct devices
+        raise SystemExit("bench.py: rank %d needs GPU %d but only %d HIP device(s) are visible; --gpus %d cannot be honoured here"
+                         % (rank, local_rank, n_dev, args.gpus))
+    ctxs = [m.Context(local_rank) for _ in range(max(1, args.streams))]
     ctx = ctxs[0]
     wl = MultiStream(pick_workload(args.workload), ctxs, args.units, rank)
 
     for _ in range(args.warmup):
         wl.step()
     wl.sync()
-    wl.profile(True)  # HIP events around every kernel launch, on the launch stream
+    wl.profile(True)  # HIP events around every kernel launch, on the launch stream (two event records per launch: < 0.1 % of a step)
     barrier()
     wl.sync()
     t0 = time.perf_counter()
@@ -744,52 +966,93 @@ def main():
     elapsed = max_reduce(t1 - t0)
     prof = wl.profile_report()
     wl.profile(False)
+    devices = [local_rank]
+    if world > 1:
+        import torch.distributed as dist
+        got = [None] * world
+        dist.all_gather_object(got, (int(os.environ.get("GROUP_RANK", "0")), local_rank))
+        if len(set(got)) != world:
+            raise SystemExit("bench.py: ranks share a device: %s" % (got,))
+        devices = [g[1] for g in got]
 
     if rank == 0:
-        units = wl.units_per_step() * world * args.steps
+        steps = args.steps
+        units = wl.units_per_step() * world * steps
         value = units * wl.value_per_unit() / elapsed
-        dom = max(prof, key=lambda k: prof[k][1])  # the kernel with the largest share of the timed region
-        n_launch, tot_ms = prof[dom]
-        avg_ms = tot_ms / n_launch
-        per_kernel = {}
-        for k, (nl, ms) in prof.items():
-            b = wl.roofline_bytes(k, nl // args.steps) if hasattr(wl, "roofline_bytes") else None
-            if b is None:
-                b = wl.alg_bytes_per_unit * wl.units_per_step() * (nl // args.steps)
-            gbs = b * args.steps / (ms * 1e-3) / 1e9
-            per_kernel[k] = {"ms_per_step": round(ms / args.steps, 4), "launches_per_step": nl // args.steps,
-                             "alg_GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / HBM_PEAK_GBS, 4)}
-        alg_bytes = (wl.roofline_bytes(dom, n_launch // args.steps) if hasattr(wl, "roofline_bytes") else None) or \
-            wl.alg_bytes_per_unit * wl.units_per_step() * (n_launch // args.steps)
-        alg_bytes = alg_bytes / (n_launch // args.steps)  # per launch
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        try:  # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes of this command
-            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % wl.name)))
-            traffic = tj["bytes_per_launch"].get({"k_ul_fft": "k_dl_fft"}.get(dom, dom))  # rocprof sees the kernel's own name
+        acc = wl.accounting()
+        ms_step = {k: ms / steps for k, (nl, ms) in prof.items()}
+        stage_of = {k: st for st, (_, ks) in acc["stages"].items() for k in ks}
+        traffic_tab = {}
+        try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command (tools/profile_bench.sh)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s%s.json" % (wl.name, "_bcjr" if DECODER == "bcjr" else ""))))
+            traffic_tab = tj["bytes_per_launch"]
         except Exception:
             pass
+        per_kernel = {}
+        for k, (nl, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+            own = acc["own_io"].get(k)
+            ent = {"ms_per_step": round(ms / steps, 4), "launches_per_step": nl // steps, "stage": stage_of.get(k)}
+            if own:
+                ent["own_io_bytes_per_step"] = own
+                ent["own_io_GBps"] = round(own / (ms / steps * 1e-3) / 1e9, 1)
+                ent["own_io_frac_of_peak"] = round(own / (ms / steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            tr = traffic_tab.get({"k_ul_fft": "k_dl_fft"}.get(k, k))  # rocprof sees the kernel's own name
+            if tr:
+                ent["hbm_traffic_bytes_per_step"] = int(tr * (nl // steps))
+                ent["hbm_traffic_GBps"] = round(tr * (nl // steps) / (ms / steps * 1e-3) / 1e9, 1)
+                if own:
+                    ent["traffic_over_own_io"] = round(tr * (nl // steps) / own, 2)
+            per_kernel[k] = ent
+        stages = {}
+        for st, (b, ks) in acc["stages"].items():
+            ms = sum(ms_step.get(k, 0.0) for k in ks)
+            if ms > 0:
+                tr = sum(per_kernel[k].get("hbm_traffic_bytes_per_step", 0) for k in ks if k in per_kernel)
+                stages[st] = {"algorithmic_bytes_per_step": b, "ms_per_step": round(ms, 4), "alg_GBps": round(b / (ms * 1e-3) / 1e9, 1),
+                              "frac_of_peak": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kernels": [k for k in ks if k in ms_step]}
+                if tr:
+                    stages[st]["hbm_traffic_over_algorithmic"] = round(tr / b, 2)
+        dom = max(prof, key=lambda k: prof[k][1])  # the kernel with the largest share of the timed region
+        n_launch, tot_ms = prof[dom]
+        lps = max(1, n_launch // steps)
+        st_bytes = acc["stages"][stage_of[dom]][0] if dom in stage_of else wl.alg_bytes_per_unit * wl.units_per_step()
+        alg_per_launch = st_bytes / lps                       # the stage's bytes, charged once per step, spread over this kernel's launches
+        avg_ms = tot_ms / n_launch
+        achieved = alg_per_launch / (avg_ms * 1e-3) / 1e9
+        tr = traffic_tab.get({"k_ul_fft": "k_dl_fft"}.get(dom, dom))
+        whole = wl.alg_bytes_per_unit * units / elapsed / 1e9
         out = {
-            "metric": wl.metric, "value": round(value, 3), "unit": wl.unit, "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "metric": wl.metric, "value": round(value, 3), "unit": wl.unit, "n_gpus": world, "steps": steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
             "config": wl.config(world),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "traffic_source": "profiles/pmc_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" % wl.name if traffic else None,
-                         "avg_launch_ms": round(avg_ms, 4), "launches": n_launch,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "algorithmic bytes / measured launch time; trellis kernels are issue-bound, see DESIGN.md"},
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": tr,
+                         "traffic_source": ("profiles/pmc_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" % wl.name) if tr else None,
+                         "avg_launch_ms": round(avg_ms, 4), "launches": n_launch, "launches_per_step": lps,
+                         "algorithmic_bytes_per_launch": alg_per_launch,
+                         "accounting": "stage '%s' algorithmic bytes (SURVEY 8d, %d B per step) charged ONCE per step and spread over this kernel's %d "
+                                       "launches, divided by its measured average launch time (HIP events on the launch stream)"
+                                       % (stage_of.get(dom, "whole path"), st_bytes, lps)},
+            "stages": stages,
             "kernels": per_kernel,
-            "whole_chain_alg_GBps": round(wl.alg_bytes_per_unit * units / elapsed / 1e9, 2),
-            "device": ctx.device_name,
+            "whole_chain_alg_GBps": round(whole, 2), "whole_chain_frac_of_peak": round(whole / HBM_PEAK_GBS, 5),
+            "device": ctx.device_name, "devices": devices,
         }
         if hasattr(wl, "extra"):
             out.update(wl.extra(value))
+        if wl.name == "chain" and DECODER == "ref" and not args.no_turbo_leg and world == 1:
+            out["turbo_decode"] = {"note": "BASELINE.json's second metric, measured in this run after the timed region: W3, K = 6144 x 65536 code blocks, "
+                                           "int8 soft values resident in HBM, information Mbit/s",
+                                   "bcjr_max_log_map_8_iterations": turbo_leg(ctx, "bcjr", 65536, 3),
+                                   "ref_decoder": turbo_leg(ctx, "ref", 65536, 3)}
         if world == 1 and not args.no_cpu_baseline:
             cb = wl.cpu_baseline()
             if cb:
+                allc = cb.pop("all_cores", None)
                 out["cpu_baseline"] = cb
+                if allc:
+                    out["cpu_baseline_all_cores"] = allc
         print(json.dumps(out))
     barrier()
     for c in ctxs:

@@ -278,6 +278,8 @@ static uint32_t qpp_size_at_least(uint32_t B)
 
 extern "C" {
 
+void mi_lte_pdsch_plan_destroy(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl);
+
 int mi_lte_pdsch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, uint32_t N_pdcch_symbs,
                              const mi_lte_pdsch_alloc *h_allocs, uint32_t n_alloc, mi_lte_pdsch_plan **out)
 {
@@ -285,6 +287,7 @@ int mi_lte_pdsch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, uint32_t
     if (!(cfg->N_ant == 1 || cfg->N_ant == 2 || cfg->N_ant == 4)) return MI_LTE_ERR_INVALID_ARG;
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     auto *pl      = new mi_lte_pdsch_plan();
+    auto  guard   = on_fail([&] { (void)hipStreamSynchronize(ctx->stream); mi_lte_pdsch_plan_destroy(nullptr, pl); });
     pl->cfg       = *cfg;
     pl->cfi       = N_pdcch_symbs;
     pl->n_alloc   = n_alloc;
@@ -299,7 +302,6 @@ int mi_lte_pdsch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, uint32_t
         if (K == 0 || al.N_prb == 0 || al.N_prb > cfg->N_rb_dl || al.mod_type > 3) {
             // multi-code-block transport blocks: the reference's own C > 1 path is broken
             ctx->err = "allocation outside the single-code-block envelope (tbs + 24 > 6144) or malformed";
-            delete pl;
             return MI_LTE_ERR_UNSUPPORTED;
         }
         byK[K].push_back(a);
@@ -314,7 +316,6 @@ int mi_lte_pdsch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, uint32_t
     }
     if (pl->max_words > 4095) { // the demodulator reads one word past the allocation's last scrambling word
         ctx->err = "allocation larger than the scrambling table";
-        delete pl;
         return MI_LTE_ERR_UNSUPPORTED;
     }
     pl->e_bytes    = off;
@@ -333,6 +334,7 @@ int mi_lte_pdsch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, uint32_t
     MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_e_off, pl->h_e_off.data(), sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
     MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_cb_alloc, cb_alloc.data(), sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
     MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    guard.armed = false;
     *out = pl;
     return MI_LTE_OK;
 }

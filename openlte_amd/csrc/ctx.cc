@@ -164,18 +164,21 @@ const char *mi_lte_profile_report(mi_lte_ctx *ctx)
 
 void mi_prof_begin(mi_lte_ctx *ctx, const char *name)
 {
+    ctx->prof_armed = false;
     if (!ctx->prof_on) return;
     while (ctx->prof_pool.size() < ctx->prof_used + 2) {
         hipEvent_t e;
-        if (hipEventCreate(&e) != hipSuccess) return;
+        if (hipEventCreate(&e) != hipSuccess) return; // this launch goes unbracketed
         ctx->prof_pool.push_back(e);
     }
     ctx->prof_recs.push_back({name, ctx->prof_used});
     (void)hipEventRecord(ctx->prof_pool[ctx->prof_used], ctx->stream);
+    ctx->prof_armed = true;
 }
 void mi_prof_end(mi_lte_ctx *ctx)
 {
-    if (!ctx->prof_on) return;
+    if (!ctx->prof_armed) return; // profiling off, or the begin side could not get its pair of events
+    ctx->prof_armed = false;
     (void)hipEventRecord(ctx->prof_pool[ctx->prof_used + 1], ctx->stream);
     ctx->prof_used += 2;
 }

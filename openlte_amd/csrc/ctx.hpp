@@ -45,7 +45,7 @@ struct mi_lte_ctx {
     float2   *d_prach_tab = nullptr; // chirp | filter spectrum | twiddles of the 839-point chirp-z transform (prach.hip)
 
     // optional per-launch HIP-event bracketing (mi_lte_profile_*): pairs are resolved at report time
-    bool                                   prof_on = false;
+    bool                                   prof_on = false, prof_armed = false;
     std::vector<hipEvent_t>                prof_pool;
     size_t                                 prof_used = 0;
     std::vector<std::pair<const char *, size_t>> prof_recs; // (kernel name, index of start event)
@@ -71,6 +71,16 @@ void mi_prof_end(mi_lte_ctx *ctx);
             return MI_LTE_ERR_HIP;                                                                   \
         }                                                                                            \
     } while (0)
+
+// runs f when the enclosing function leaves without having disarmed it: the error paths of the plan constructors (every MI_HIP_CHECK
+// is a return) wait for the stream -- copies from host vectors that are about to go out of scope may still be queued -- and release
+// what was built so far
+template <typename F> struct OnFail {
+    F    f;
+    bool armed = true;
+    ~OnFail() { if (armed) f(); }
+};
+template <typename F> OnFail<F> on_fail(F f) { return OnFail<F>{f}; }
 
 int   mi_ctx_reserve_scratch(mi_lte_ctx *ctx, size_t bytes);
 int   mi_ctx_gold_tables(mi_lte_ctx *ctx);

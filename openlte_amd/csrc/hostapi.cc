@@ -12,6 +12,11 @@ struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
     int alloc(size_t n) { return hipMalloc(&p, n ? n : 1) == hipSuccess ? 0 : -1; }
 };
+// the LTE transform lengths and a grid that fits inside them: checked before any size arithmetic is done with fft_size
+bool valid_fft(uint32_t fft_size, uint32_t N_rb)
+{
+    return (fft_size == 128 || fft_size == 256 || fft_size == 512 || fft_size == 1024 || fft_size == 2048) && N_rb >= 6 && N_rb * 12 < fft_size;
+}
 } // namespace
 
 extern "C" {
@@ -22,7 +27,8 @@ int mi_lte_get_dl_subframe_and_ce_host(mi_lte_ctx *ctx, uint32_t fft_size, uint3
                                        float *h_symb_re, float *h_symb_im, float *h_ce_re, float *h_ce_im)
 {
     if (!ctx) return MI_LTE_ERR_INVALID_ARG;
-    if (!h_i || !h_q || !(N_ant == 1 || N_ant == 2 || N_ant == 4) || !h_symb_re || !h_symb_im || !h_ce_re || !h_ce_im) return 1;
+    if (!h_i || !h_q || !(N_ant == 1 || N_ant == 2 || N_ant == 4) || !h_symb_re || !h_symb_im || !h_ce_re || !h_ce_im || !valid_fft(fft_size, N_rb_dl))
+        return 1;
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const uint32_t sc = 2048 / fft_size;
     const size_t   per_sf = 30720 / sc, need = per_sf + 2 * fft_size + 160 / sc + 144 / sc - 1; // last sample symbol 15 reads, +1
@@ -200,7 +206,7 @@ int mi_lte_dl_find_coarse_timing_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32
                                       mi_lte_coarse_timing *out)
 {
     if (!ctx) return MI_LTE_ERR_INVALID_ARG;
-    if (!h_i || !h_q || !out) return 1;
+    if (!h_i || !h_q || !out || !valid_fft(fft_size, N_rb_dl)) return 1;
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     mi_lte_dl_cfg cfg = {fft_size, N_rb_dl, 1, MI_LTE_IQ_F32_PLANAR};
     DevBuf d_i, d_q;
@@ -213,10 +219,10 @@ int mi_lte_find_pss_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_dl, c
                          uint32_t *N_id_2, uint32_t *pss_symb, float *pss_thresh, float *freq_offset)
 {
     if (!ctx) return MI_LTE_ERR_INVALID_ARG;
-    if (!h_i || !h_q || !symb_starts || !N_id_2 || !pss_symb || !pss_thresh || !freq_offset) return 1;
+    if (!h_i || !h_q || !symb_starts || !N_id_2 || !pss_symb || !pss_thresh || !freq_offset || !valid_fft(fft_size, N_rb_dl)) return 1;
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     mi_lte_dl_cfg  cfg = {fft_size, N_rb_dl, 1, MI_LTE_IQ_F32_PLANAR};
-    const uint32_t sc = 2048 / (fft_size ? fft_size : 2048);
+    const uint32_t sc = 2048 / fft_size;
     uint32_t       last = 0;
     for (int j = 0; j < 7; j++) last = symb_starts[j] > last ? symb_starts[j] : last;
     const size_t n = (size_t)last + 11 * (15360 / sc) + 160 / sc + fft_size + 38; // last window of the 84, or of the +39 fine-timing trial
@@ -230,10 +236,10 @@ int mi_lte_find_sss_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_dl, c
                          float pss_thresh, uint32_t *N_id_1, uint32_t *frame_start_idx)
 {
     if (!ctx) return MI_LTE_ERR_INVALID_ARG;
-    if (!h_i || !h_q || !symb_starts || !N_id_1 || !frame_start_idx) return 1;
+    if (!h_i || !h_q || !symb_starts || !N_id_1 || !frame_start_idx || !valid_fft(fft_size, N_rb_dl)) return 1;
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     mi_lte_dl_cfg  cfg = {fft_size, N_rb_dl, 1, MI_LTE_IQ_F32_PLANAR};
-    const uint32_t sc = 2048 / (fft_size ? fft_size : 2048);
+    const uint32_t sc = 2048 / fft_size;
     DevBuf d_i, d_q;
     int    rc = stage_iq(ctx, h_i, h_q, (size_t)symb_starts[5] + 160 / sc - 1 + fft_size, d_i, d_q);
     if (rc != MI_LTE_OK) return rc;
@@ -247,7 +253,7 @@ int mi_lte_get_ul_subframe_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_r
                                 float *h_symb_im)
 {
     if (!ctx) return MI_LTE_ERR_INVALID_ARG;
-    if (!h_i || !h_q || !h_symb_re || !h_symb_im) return 1;
+    if (!h_i || !h_q || !h_symb_re || !h_symb_im || !valid_fft(fft_size, N_rb_ul)) return 1;
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const uint32_t sc = 2048 / fft_size;
     const size_t   need = 30720 / sc; // the last symbol's window ends one sample before the subframe does
@@ -323,7 +329,7 @@ int mi_lte_detect_prach_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_u
                              uint32_t *det_pre, uint32_t *det_ta)
 {
     if (!ctx) return MI_LTE_ERR_INVALID_ARG;
-    if (!prach || !h_x_u_fft_re || !h_x_u_fft_im || !h_re || !h_im || !N_det_pre || !det_pre || !det_ta) return 1;
+    if (!prach || !h_x_u_fft_re || !h_x_u_fft_im || !h_re || !h_im || !N_det_pre || !det_pre || !det_ta || !valid_fft(fft_size, N_rb_ul)) return 1;
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     mi_lte_dl_cfg      cfg = {fft_size, N_rb_ul, 1, MI_LTE_IQ_F32_PLANAR};
     mi_lte_prach_plan *plan = nullptr;

@@ -488,10 +488,11 @@ int mi_lte_pdcch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, float ph
     }
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     auto *pl = new mi_lte_pdcch_plan();
+    auto  guard = on_fail([&] { (void)hipStreamSynchronize(ctx->stream); mi_lte_pdcch_plan_destroy(nullptr, pl); });
     pl->cfg  = *cfg;
     std::vector<uint32_t> cells(h_cells, h_cells + n_cells), pcf((size_t)n_cells * 16), cand((size_t)n_cells * 4 * N_CAND * RE_MAX);
     for (uint32_t c = 0; c < n_cells; c++) {
-        if (cells[c] > 503) { delete pl; return MI_LTE_ERR_INVALID_ARG; }
+        if (cells[c] > 503) return MI_LTE_ERR_INVALID_ARG;
         for (uint32_t ns = 1; ns <= 4; ns++)
             mi_lte_pdcch_re_tables(nrb, cfg->N_ant, cells[c], phich_res, ns, &pcf[(size_t)c * 16], &cand[((size_t)c * 4 + ns - 1) * N_CAND * RE_MAX]);
     }
@@ -508,14 +509,13 @@ int mi_lte_pdcch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, float ph
     void *d_cells, *d_pcf, *d_cand, *d_rm;
     if (up(cells.data(), cells.size() * 4, &d_cells) || up(pcf.data(), pcf.size() * 4, &d_pcf) || up(cand.data(), cand.size() * 4, &d_cand) ||
         up(rm.data(), rm.size() * 2, &d_rm)) {
-        for (void *p : pl->owned) (void)hipFree(p);
-        delete pl;
         ctx->err = "PDCCH plan: device allocation failed";
         return MI_LTE_ERR_NOMEM;
     }
     MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     pl->dev = PdcchDev{nrb, cfg->N_ant, n_cells, {sz[0], sz[1]}, (flags & MI_LTE_PDCCH_PER_PORT_ESTIMATES) ? 1u : 0u, (const uint32_t *)d_cells, (const uint32_t *)d_pcf, (const uint32_t *)d_cand,
                        (const uint16_t *)d_rm};
+    guard.armed = false;
     *out = pl;
     return MI_LTE_OK;
 }

@@ -227,6 +227,7 @@ static int prach_bluestein_tables(mi_lte_ctx *ctx, float2 **d_chirp, float2 **d_
     return MI_LTE_OK;
 }
 
+extern "C" void mi_lte_prach_plan_destroy(mi_lte_ctx *ctx, mi_lte_prach_plan *pl);
 static int prach_plan_common(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const mi_lte_prach_cfg *pc, const float *h_xu_fft_re,
                              const float *h_xu_fft_im, uint32_t n_roots_given, mi_lte_prach_plan **out)
 {
@@ -239,6 +240,7 @@ static int prach_plan_common(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const mi
     }
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     auto *pl = new mi_lte_prach_plan();
+    auto  guard = on_fail([&] { (void)hipStreamSynchronize(ctx->stream); mi_lte_prach_plan_destroy(nullptr, pl); });
     pl->cfg  = *cfg;
     const uint32_t sc = 2048 / N; // 30.72 MHz / fs
     static const uint32_t cp_of_fmt[4] = {3168, 21024, 6240, 21024};
@@ -289,6 +291,7 @@ static int prach_plan_common(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const mi
     int rcb = prach_bluestein_tables(ctx, &pl->d_chirp, &pl->d_bspec, &pl->d_tw);
     if (rcb != MI_LTE_OK) return rcb;
     MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    guard.armed = false;
     *out = pl;
     return MI_LTE_OK;
 }

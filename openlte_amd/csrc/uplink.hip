@@ -434,6 +434,7 @@ static uint32_t ul_qpp_size_at_least(uint32_t B)
 
 // h_dmrs (optional): caller-supplied reference signals, 4 x 12*N_prb floats per allocation back to back -- the
 // per-call host form passes the arrays liblte_phy_ul_init left in the caller's LIBLTE_PHY_STRUCT
+extern "C" void mi_lte_pusch_plan_destroy(mi_lte_ctx *ctx, mi_lte_pusch_plan *pl);
 int mi_pusch_plan_create_impl(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const mi_lte_ul_cfg *ul, const uint32_t *h_unit_subfr_num,
                               const uint32_t *h_unit_n_id_cell, uint32_t n_units, const mi_lte_pdsch_alloc *h_allocs, uint32_t n_alloc,
                               const float *h_dmrs, mi_lte_pusch_plan **out)
@@ -442,6 +443,7 @@ int mi_pusch_plan_create_impl(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const m
         return MI_LTE_ERR_INVALID_ARG;
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     auto *pl    = new mi_lte_pusch_plan();
+    auto  guard = on_fail([&] { (void)hipStreamSynchronize(ctx->stream); mi_lte_pusch_plan_destroy(nullptr, pl); });
     pl->cfg     = *cfg;
     pl->n_alloc = n_alloc;
     std::map<uint32_t, std::vector<uint32_t>> byK;
@@ -460,7 +462,6 @@ int mi_pusch_plan_create_impl(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const m
         const bool planned = al.N_prb > 0 && al.N_prb < cfg->N_rb_dl && (al.N_prb % 2 == 0 || al.N_prb % 3 == 0 || al.N_prb % 5 == 0);
         if (K == 0 || !planned || al.mod_type > 3 || al.unit >= n_units) {
             ctx->err = "PUSCH allocation outside the envelope (one code block; N_prb < N_rb_ul and divisible by 2, 3 or 5) or malformed";
-            delete pl;
             return MI_LTE_ERR_UNSUPPORTED;
         }
         const uint32_t sf = h_unit_subfr_num[al.unit] % 10, cell = h_unit_n_id_cell[al.unit], M = 12 * al.N_prb;
@@ -476,7 +477,7 @@ int mi_pusch_plan_create_impl(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const m
                 const uint32_t at = (uint32_t)dmrs.size();
                 dmrs.resize(dmrs.size() + 4 * (size_t)M);
                 int rc = mi_lte_ul_dmrs_pusch(ul, cell, sf, al.N_prb, &dmrs[at], &dmrs[at + M], &dmrs[at + 2 * M], &dmrs[at + 3 * M]);
-                if (rc != MI_LTE_OK) { delete pl; return rc; }
+                if (rc != MI_LTE_OK) return rc;
                 it = dmrs_at.emplace(key, at).first;
             }
             desc[a] = {sf, cell, it->second};
@@ -491,7 +492,7 @@ int mi_pusch_plan_create_impl(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const m
         pl->h_e_len[a] = E;
         off += (E + 63) & ~63u;
     }
-    if (pl->words_max > 4096) { ctx->err = "allocation larger than the scrambling table"; delete pl; return MI_LTE_ERR_UNSUPPORTED; }
+    if (pl->words_max > 4096) { ctx->err = "allocation larger than the scrambling table"; return MI_LTE_ERR_UNSUPPORTED; }
     pl->e_bytes    = off;
     pl->out_stride = (max_tbs + 63) & ~63u;
     std::vector<uint32_t> cb_alloc;
@@ -512,6 +513,7 @@ int mi_pusch_plan_create_impl(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const m
     MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_e_off, pl->h_e_off.data(), sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
     MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_cb_alloc, cb_alloc.data(), sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
     MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    guard.armed = false;
     *out = pl;
     return MI_LTE_OK;
 }

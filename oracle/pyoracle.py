@@ -173,6 +173,9 @@ def ref():
     L.ref_samples_to_symbols_dl.argtypes = [vp, f32p, f32p, u32, u32, f32p, f32p]
     L.ref_time_get_dl_subframe_and_ce.argtypes = [vp, f32p, f32p, u32, u32, u32, u32, vp, u32]
     L.ref_time_get_dl_subframe_and_ce.restype = C.c_double
+    if hasattr(L, "ref_time_dl_chain"):  # absent from a libref_oracle.so built before round 2
+        L.ref_time_dl_chain.argtypes = [vp, f32p, f32p, u32, u32, vp, C.POINTER(LoAlloc), u32, u32, u32, C.POINTER(u32)]
+        L.ref_time_dl_chain.restype = C.c_double
     # uplink
     L.ref_ul_init.argtypes = [vp, u32, u32, u32, u32, u32, u32]
     L.ref_get_pusch_dmrs.argtypes = [vp, u32, u32, f32p]

@@ -630,4 +630,24 @@ double ref_time_get_dl_subframe_and_ce(void *phy, float *i_samps, float *q_samps
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
 
+// One core's worth of the reference's downlink receive chain: reps x (liblte_phy_get_dl_subframe_and_ce + n_alloc x
+// liblte_phy_pdsch_channel_decode) on one LIBLTE_PHY_STRUCT, timed in here so that a caller running one of these per thread
+// (the all-core baseline) never holds an interpreter lock.  Returns seconds; *n_ok counts LIBLTE_SUCCESS verdicts.
+double ref_time_dl_chain(void *phy, float *i_samps, float *q_samps, uint32_t subfr_num, uint32_t N_id_cell, void *sf,
+                         const ref_alloc_t *allocs, uint32_t n_alloc, uint32_t N_pdcch_symbs, uint32_t reps, uint32_t *n_ok)
+{
+    uint8_t         out[6200];
+    uint32_t        n, ok = 0;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (uint32_t r = 0; r < reps; r++) {
+        ref_get_dl_subframe_and_ce(phy, i_samps, q_samps, 0, subfr_num, N_id_cell, 1, sf);
+        for (uint32_t a = 0; a < n_alloc; a++)
+            ok += ref_pdsch_channel_decode(phy, sf, &allocs[a], N_pdcch_symbs, N_id_cell, 1, out, &n) == 0;
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (n_ok) *n_ok = ok;
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
 } // extern "C"

@@ -49,6 +49,19 @@ def oracle_turbo_ref(port, soft, K):
     return out
 
 
+ALL_K = list(range(40, 513, 8)) + list(range(528, 1025, 16)) + list(range(1056, 2049, 32)) + list(range(2112, 6145, 64))  # the 188 LTE turbo block sizes
+OVERFLOW_K = [3584, 4224, 4352, 4480, 4608, 4736, 4928, 4992, 5248, 5312, 5376, 5440, 5568, 5632, 5696, 5824, 5888, 5952, 6080, 6144]
+
+
+def parallel_map(fn, items, threads=None):
+    """The oracle's C functions release the interpreter lock (ctypes) and hold no static state: run them on every host core."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    threads = threads or max(1, min(32, len(os.sched_getaffinity(0))))
+    with ThreadPoolExecutor(threads) as ex:
+        return list(ex.map(fn, items))
+
+
 # ---------------------------------------------------------------------------------------------------
 # subframe units (uses the library's host-side transmitter, openlte_amd.synth)
 
@@ -104,6 +117,8 @@ UL_CASES = {
                                                             (1, 328, list(range(6, 10)), 0x64), (1, 408, list(range(10, 15)), 0x65),
                                                             (1, 504, list(range(15, 21)), 0x66), (1, 712, list(range(21, 29)), 0x67),
                                                             (1, 776, list(range(29, 38)), 0x68), (1, 904, list(range(38, 48)), 0x69)]),
+    # BASELINE config 5's shape: 16 UEs in one 20 MHz subframe, 6 PRB QPSK each (what bench.py --workload uplink batches)
+    "20MHz_16ue": (2048, 100, 17, (3, 0, 0, 2, 5), [2, 7], [(1, 504, list(range(6 * a, 6 * a + 6)), 0x100 + a) for a in range(16)]),
     "10MHz_prime": (1024, 50, 100, (11, 0, 0, 7, 3), [7, 8], [(1, 1256, list(range(4, 18)), 0x99), (1, 2024, list(range(20, 42)), 0x9A)]),
 }
 

@@ -338,3 +338,38 @@ def test_redundancy_versions(ctx, ref, rv, mod, tbs, nprb):
     d_sub.free()
     ref.ref_subframe_free(rx)
     ref.ref_phy_free(phy)
+
+
+@pytest.mark.parametrize("tbs,mod,nprb", [(672, 1, 8), (1376, 2, 8), (2000, 3, 8), (680, 1, 8), (3200, 3, 12)])
+def test_filler_bit_transport_blocks_same_verdict_as_reference(ctx, ref, tbs, mod, nprb):
+    """F > 0 (tbs + 24 is not a turbo block size): the reference fails its own noise-free transmission with LIBLTE_ERROR_DECODE_FAIL
+    because its receiver does not treat the filler positions as NULL (liblte_phy.cc:9826-9829, :11404).  Drop-in means
+    the same verdict, and the same soft bits on the way there; tbs = 680 (F = 0) is the control that decodes."""
+    import ctypes as C
+    import openlte_amd as m
+    from oracle import pyoracle as po
+    cap = td.multi_port_capture(ref, 1, seed=tbs, mod=mod, tbs=tbs, prbs=list(range(30, 30 + nprb)), noise=0.0)
+    sf, cell, iq, la, phy = cap["sf"], cap["cell"], cap["iq"], cap["la"], cap["phy"]
+    i_f = np.ascontiguousarray(np.concatenate([np.zeros(sf * 30720, np.float32), iq[:, 0].astype(np.float32)]))
+    q_f = np.ascontiguousarray(np.concatenate([np.zeros(sf * 30720, np.float32), iq[:, 1].astype(np.float32)]))
+    rx = ref.ref_subframe_new()
+    assert ref.ref_get_dl_subframe_and_ce(phy, i_f, q_f, 0, sf, cell, 1, rx) == 0
+    out, n = np.zeros(6200, np.uint8), C.c_uint32()
+    rc = ref.ref_pdsch_channel_decode(phy, rx, C.byref(la), 2, cell, 1, out, C.byref(n))
+    assert (rc == 0) == (tbs == 680) and rc in (0, 2)
+    cfg = m.DlCfg(2048, 100, 1, 0)
+    plan = ctx.pdsch_plan(cfg, 2, [m.make_alloc(0, mod, tbs, cap["prbs"], 0x2345, 0, 1)])
+    grid = np.concatenate([po.ref_subframe_view(ref, rx, 0).ravel(), po.ref_subframe_view(ref, rx, 1).ravel(),
+                           po.ref_subframe_view(ref, rx, 2, True)[:1].ravel(), po.ref_subframe_view(ref, rx, 3, True)[:1].ravel()]).astype(np.float32)
+    d_sub = ctx.to_device(grid)
+    st, bits = plan.run(d_sub, [sf], [cell])
+    e = plan.soft_bits(0)
+    want = np.ctypeslib.as_array(ref.ref_pdsch_descramb_bits_ptr(phy), shape=(len(e),)).astype(np.int8)
+    assert (e == want).all()
+    assert st[0] == rc, (st[0], rc)
+    if rc == 0:
+        assert (bits[0] == out[:tbs]).all() and (bits[0] == cap["msg"]).all()
+    plan.close()
+    d_sub.free()
+    ref.ref_subframe_free(rx)
+    ref.ref_phy_free(phy)

@@ -26,3 +26,25 @@ def test_sharding_covers_every_unit_once():
         seen = sorted(u for r in range(w) for u in shard_units(n, r, w))
         assert seen == list(range(n))
         assert sum(shard_counts(n, w)) == n
+
+
+def test_bench_gpus_2_starts_two_ranks_by_itself():
+    """`python bench.py --gpus 2` with no launcher around it must become two ranks (torch.distributed.run, 127.0.0.1) and report
+    n_gpus = 2 only because two ranks really ran: the selftest workload exercises launch, sharding, barrier and the max-over-ranks
+    timing on CPU (gloo)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "selftest", "--steps", "3", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout  # rank 0 prints the one JSON line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["shard_counts"] == [500, 500]
+    assert sorted(x[0] for x in out["ranks"]) == [0, 1] and sorted(x[1] for x in out["ranks"]) == [0, 1]
+    assert {tuple(x[3]) for x in out["ranks"]} == {(0, 2, 4), (1, 3, 5)}
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--workload", "selftest"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "refusing" in (r.stdout + r.stderr)

@@ -179,3 +179,85 @@ def test_bcjr_model_decodes_and_segments(port):
         out = np.zeros(K, np.uint8)
         port.lo_turbo_decode_bcjr(np.ascontiguousarray(llr), K, 8, spec, out)
         assert (out == tx).all(), (K, spec)
+
+
+def _ref_vs_port_subframe(port, ref, iq_unit, sf, cell, n_ant):
+    """Both CPU front ends on one int8 unit -> (ref phy, ref subframe, port cfg, port subframe)."""
+    import ctypes as C
+    from oracle import pyoracle as po
+    i_f = np.ascontiguousarray(np.concatenate([np.zeros(sf * 30720, np.float32), iq_unit[:, 0].astype(np.float32)]))
+    q_f = np.ascontiguousarray(np.concatenate([np.zeros(sf * 30720, np.float32), iq_unit[:, 1].astype(np.float32)]))
+    phy, rx = ref.ref_phy_new(4, cell, n_ant, 100), ref.ref_subframe_new()
+    assert ref.ref_get_dl_subframe_and_ce(phy, i_f, q_f, 0, sf, cell, n_ant, rx) == 0
+    lc, s = td.oracle_frontend(port, 2048, 100, n_ant, iq_unit, sf, cell)
+    return phy, rx, lc, s
+
+
+def test_port_w4_subframe_front_end_and_pdsch_decode_vs_reference(port, ref):
+    """The two composite functions of the restatement that the GPU stage-parity and smoke tests check against, pinned directly on
+    the headline configuration (20 MHz, 1 port, CFI 2, 8 x 12 PRB TBS 3240 + 1 x 4 PRB TBS 1064, 64QAM):
+    lo_get_dl_subframe_and_ce vs liblte_phy_get_dl_subframe_and_ce (liblte_phy.cc:5905; float stage: both sit on a float64 DFT,
+    so they agree to rounding) and lo_pdsch_channel_decode vs liblte_phy_pdsch_channel_decode (:3690) fed the SAME received grid:
+    soft bits, decoded bits, bit count and return code identical for every allocation."""
+    import ctypes as C
+    import openlte_amd as m
+    from openlte_amd import synth
+    from oracle import pyoracle as po
+    cfg = m.DlCfg(2048, 100, 1, 0)
+    sfs, cells = [3, 8], [42, 301]
+    allocs = td.w4_allocs(0) + td.w4_allocs(1)
+    for snr in (30.0, 21.0):
+        iq, tx = synth.dl_units(cfg, sfs, cells, allocs, 9, snr_db=snr, max_delay=6, seed=int(snr))
+        for u in range(2):
+            phy, rx, lc, s = _ref_vs_port_subframe(port, ref, iq[u], sfs[u], cells[u], 1)
+            for which, name in ((0, "rx_symb_re"), (1, "rx_symb_im")):
+                a, b = po.ref_subframe_view(ref, rx, which)[:15], s.arr(name)[:15]
+                assert np.linalg.norm(a - b) <= 1e-6 * np.linalg.norm(a), name
+            for which, name in ((2, "rx_ce_re"), (3, "rx_ce_im")):
+                a, b = po.ref_subframe_view(ref, rx, which, True)[0, :14], s.arr(name)[0, :14]
+                assert np.linalg.norm(a - b) <= 1e-5 * np.linalg.norm(a) and np.abs(a - b).max() <= 1e-4 * np.abs(a).max(), name
+            # the same grid into both decoders: copy the reference's received symbols and estimates into the restatement's struct
+            s.arr("rx_symb_re")[:] = po.ref_subframe_view(ref, rx, 0)
+            s.arr("rx_symb_im")[:] = po.ref_subframe_view(ref, rx, 1)
+            s.arr("rx_ce_re")[:] = po.ref_subframe_view(ref, rx, 2, True)
+            s.arr("rx_ce_im")[:] = po.ref_subframe_view(ref, rx, 3, True)
+            n_ok = 0
+            for a in range(9):
+                al = allocs[u * 9 + a]
+                la = td.to_lo_alloc(al)
+                o1, n1, o2, n2 = np.zeros(6200, np.uint8), C.c_uint32(), np.zeros(6200, np.uint8), C.c_uint32()
+                soft, ns = np.zeros(20000, np.int8), C.c_uint32()
+                rc1 = ref.ref_pdsch_channel_decode(phy, rx, C.byref(la), 2, cells[u], 1, o1, C.byref(n1))
+                rc2 = port.lo_pdsch_channel_decode(C.byref(lc), C.byref(s), C.byref(la), 2, cells[u], 1, o2, C.byref(n2), soft.ctypes.data_as(C.c_void_p), C.byref(ns))
+                want_soft = np.ctypeslib.as_array(ref.ref_pdsch_soft_bits_ptr(phy), shape=(ns.value,))
+                assert ns.value == (9936 if a < 8 else 3312) and (soft[:ns.value] == want_soft).all(), (snr, u, a)
+                assert rc1 == rc2 and n1.value == n2.value and (o1[:n1.value] == o2[:n2.value]).all(), (snr, u, a, rc1, rc2)
+                n_ok += rc1 == 0 and bool((o1[:al.tbs] == tx[u, a, :al.tbs]).all())
+            assert n_ok == 9 or snr < 25
+            ref.ref_subframe_free(rx)
+            ref.ref_phy_free(phy)
+
+
+@pytest.mark.parametrize("tbs,mod,nprb", [(672, 1, 8), (1376, 2, 8), (2000, 3, 8), (680, 1, 8)])
+def test_port_filler_bit_transport_blocks_vs_reference(port, ref, tbs, mod, nprb):
+    """Transport blocks whose size + 24 is not a turbo block size (F > 0 filler bits).  The reference's transmitter skips the fillers
+    when rate matching but its receiver does not treat them as NULL (uint8 filler markers never equal RX_NULL_BIT,
+    liblte_phy.cc:9826-9829, :11404), so it fails its own noise-free loopback with LIBLTE_ERROR_DECODE_FAIL; tbs = 680 (F = 0) is the
+    control.  The restatement must give the reference's verdict, bit count and soft bits."""
+    import ctypes as C
+    cap = td.multi_port_capture(ref, 1, seed=tbs, mod=mod, tbs=tbs, prbs=list(range(30, 30 + nprb)), noise=0.0)
+    sf, cell, iq, la, phy = cap["sf"], cap["cell"], cap["iq"], cap["la"], cap["phy"]
+    phy2, rx, lc, s = _ref_vs_port_subframe(port, ref, iq, sf, cell, 1)
+    o1, n1, o2, n2 = np.zeros(6200, np.uint8), C.c_uint32(), np.zeros(6200, np.uint8), C.c_uint32()
+    rc1 = ref.ref_pdsch_channel_decode(phy, rx, C.byref(la), 2, cell, 1, o1, C.byref(n1))
+    s.arr("rx_symb_re")[:], s.arr("rx_symb_im")[:] = np.ctypeslib.as_array(ref.ref_subframe_ptr(rx, 0), shape=(16, 1200)), np.ctypeslib.as_array(ref.ref_subframe_ptr(rx, 1), shape=(16, 1200))
+    s.arr("rx_ce_re")[:], s.arr("rx_ce_im")[:] = np.ctypeslib.as_array(ref.ref_subframe_ptr(rx, 2), shape=(4, 16, 1200)), np.ctypeslib.as_array(ref.ref_subframe_ptr(rx, 3), shape=(4, 16, 1200))
+    rc2 = port.lo_pdsch_channel_decode(C.byref(lc), C.byref(s), C.byref(la), 2, cell, 1, o2, C.byref(n2), None, None)
+    assert rc1 == rc2, (rc1, rc2)
+    if tbs == 680:
+        assert rc1 == 0 and (o1[:tbs] == cap["msg"]).all() and (o2[:tbs] == cap["msg"]).all()
+    else:
+        assert rc1 == 2  # LIBLTE_ERROR_DECODE_FAIL, noise-free
+    ref.ref_subframe_free(rx)
+    ref.ref_phy_free(phy)
+    ref.ref_phy_free(phy2)

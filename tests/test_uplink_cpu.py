@@ -21,7 +21,7 @@ def test_dmrs_bit_exact_vs_reference(ref, cell, ulc):
     ref.ref_phy_free(phy)
 
 
-@pytest.mark.parametrize("name", ["1p4MHz_hop", "5MHz_seqhop_16qam"])
+@pytest.mark.parametrize("name", ["1p4MHz_hop", "5MHz_seqhop_16qam", "20MHz_16ue"])
 def test_reference_receiver_decodes_the_host_transmitter(ref, name):
     case = td.ul_case(name)
     _, res = td.ref_ul_decode(ref, case)

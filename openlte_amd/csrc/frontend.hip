@@ -10,6 +10,7 @@
 //               sequential phase unwrap, frequency interpolation, then time interpolation and
 //               mag/phase -> re/im for all 14 symbols (liblte_phy.cc:5959-6194).
 #include "ctx.hpp"
+#include "phy_dev.hpp"
 
 namespace {
 
@@ -24,6 +25,7 @@ struct DlGeom {
     uint32_t N_ant;
     uint32_t sf_stride; // floats per device subframe
     uint32_t ul;        // 1: uplink SC-FDMA demodulation (samples_to_symbols_ul, liblte_phy.cc:8654-8692)
+    uint32_t ce_compact; // 1: the estimator stops after the frequency direction and writes magnitude / phase rows (MI_LTE_CE_COMPACT)
 };
 
 // The FFT has no bit-exact reference (FFTW's operation order is unspecified; parity is to tolerance), so its
@@ -257,52 +259,6 @@ __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t
 // ------------------------------------------------------------------------------------------------
 // channel estimation
 
-// wrap_phase (liblte_phy.cc:14105-14116): float difference compared against the double constant,
-// the +-2*pi correction is evaluated in double and rounded back to float.
-__device__ __forceinline__ float wrap_phase(float p1, float p2)
-{
-    while ((double)(p1 - p2) >= M_PI) p1 = (float)((double)p1 - 2 * M_PI);
-    while ((double)(p1 - p2) <= -M_PI) p1 = (float)((double)p1 + 2 * M_PI);
-    return p1;
-}
-
-struct GoldTables { const uint32_t *x1; const uint32_t *x2b; uint32_t words; }; // x2b[31][words]
-
-// 32 bits c[32w .. 32w+31] of the Gold sequence seeded with c_init (generate_prs_c,
-// liblte_phy.cc:9669-9704): the x2 register is linear in c_init, so the word is the XOR of the
-// per-seed-bit basis words; bit b of the result is c[32w + b].
-__device__ __forceinline__ uint32_t gold_word(const GoldTables &gt, uint32_t c_init, uint32_t w)
-{
-    uint32_t v = gt.x1[w], m = c_init; // table reads eight at a time, in flight together (see phy_dev.hpp)
-    while (m) {
-        uint32_t t[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const bool     on = m != 0;
-            const uint32_t b  = on ? (uint32_t)__builtin_ctz(m) : 0u;
-            t[k] = gt.x2b[b * gt.words + w];
-            t[k] = on ? t[k] : 0u;
-            m &= m - 1;
-        }
-        v ^= (t[0] ^ t[1]) ^ (t[2] ^ t[3]) ^ (t[4] ^ t[5]) ^ (t[6] ^ t[7]);
-    }
-    return v;
-}
-
-// sin / cos of an unwrapped phase for the time interpolation: two-constant reduction to [-pi, pi] (the phases are a few turns at
-// most), then the hardware's v_sin_f32 / v_cos_f32, which take revolutions.  The estimate is a float-tolerance stage
-// (TOL_CE = 1e-4 in tests/test_frontend_gpu.py; measured against the CPU restatement of the reference the estimate's relative L2 error is 2.4e-7 this way and
-// 2.2e-7 with libm's sincosf, which spent two thirds of this kernel's instructions here).
-__device__ __forceinline__ void ce_sincos(float x, float &sn, float &cs)
-{
-    const float k = rintf(x * 0.15915494309189533577f);
-    float       r = fmaf(-k, 6.28318548202514648438f, x); // 2 pi rounded to float ...
-    r             = fmaf(-k, -1.74845553146951715e-07f, r); // ... and the rest of it
-    r *= 0.15915494309189533577f;
-    sn = __builtin_amdgcn_sinf(r);
-    cs = __builtin_amdgcn_cosf(r);
-}
-
 __global__ __launch_bounds__(256) void k_dl_ce(const uint32_t *__restrict__ subfr_num, const uint32_t *__restrict__ n_id_cell,
                                                DlGeom g, GoldTables gt, float *__restrict__ subframes)
 {
@@ -442,16 +398,28 @@ __global__ __launch_bounds__(256) void k_dl_ce(const uint32_t *__restrict__ subf
     }
     __syncthreads();
 
+    if (g.ce_compact) {
+        // compact form for the PDSCH chain (MI_LTE_CE_COMPACT): the demodulator interpolates along time itself (ce_time_interp5, the same
+        // code as below), so what leaves this kernel is the magnitude / phase rows at the CRS symbols -- rows 0..N_sym-1 of the port's
+        // real-part plane hold mag, the same rows of its imaginary-part plane hold ang
+        const uint32_t nq = N_sc >> 2; // N_sc is a multiple of 12
+        for (uint32_t t = threadIdx.x; t < N_sym * nq; t += blockDim.x) {
+            const uint32_t i = t / nq, c = t - i * nq;
+            reinterpret_cast<float4 *>(ce_re + i * N_SC_MAX)[c] = reinterpret_cast<const float4 *>(mag + i * N_sc)[c];
+            reinterpret_cast<float4 *>(ce_im + i * N_SC_MAX)[c] = reinterpret_cast<const float4 *>(ang + i * N_sc)[c];
+        }
+        return;
+    }
     // time interpolation per sub-carrier (liblte_phy.cc:6066-6193)
     for (uint32_t j = threadIdx.x; j < N_sc; j += blockDim.x) {
         float M[5], A[5];
 #pragma unroll
         for (int i = 0; i < 5; i++) { M[i] = mag[i * N_sc + j]; A[i] = ang[i * N_sc + j]; }
-        float fm, fa, cm, ca;
 #define EMIT(z, m, a) do { float sn_, cs_; ce_sincos((a), sn_, cs_); ce_re[(z) * N_SC_MAX + j] = (m) * cs_; ce_im[(z) * N_SC_MAX + j] = (m) * sn_; } while (0)
+        if (N_sym == 3) {
+            float fm, fa, cm, ca;
 #define SLOPE(hi, lo, dv) do { fm = (M[hi] - M[lo]) / (dv); A[hi] = wrap_phase(A[hi], A[lo]); fa = A[hi] - A[lo]; \
                                fa = wrap_phase(fa, 0.0f); fa /= (dv); } while (0)
-        if (N_sym == 3) {
             EMIT(1, M[0], A[0]);
             EMIT(8, M[1], A[1]);
             SLOPE(1, 0, 7);
@@ -462,26 +430,14 @@ __global__ __launch_bounds__(256) void k_dl_ce(const uint32_t *__restrict__ subf
             SLOPE(2, 1, 7);
             cm = M[2] - fm; ca = A[2] - fa;
             for (int z = 13; z > 8; z--) { cm -= fm; ca -= fa; EMIT(z, cm, ca); }
+#undef SLOPE
         } else {
-            EMIT(0, M[0], A[0]);
-            EMIT(4, M[1], A[1]);
-            EMIT(7, M[2], A[2]);
-            EMIT(11, M[3], A[3]);
-            SLOPE(1, 0, 4);
-            cm = M[1]; ca = A[1];
-            for (int z = 3; z > 0; z--) { cm -= fm; ca -= fa; EMIT(z, cm, ca); }
-            SLOPE(2, 1, 3);
-            cm = M[2]; ca = A[2];
-            for (int z = 6; z > 4; z--) { cm -= fm; ca -= fa; EMIT(z, cm, ca); }
-            SLOPE(3, 2, 4);
-            cm = M[3]; ca = A[3];
-            for (int z = 10; z > 7; z--) { cm -= fm; ca -= fa; EMIT(z, cm, ca); }
-            SLOPE(4, 3, 3);
-            cm = M[4]; ca = A[4];
-            for (int z = 13; z > 11; z--) { cm -= fm; ca -= fa; EMIT(z, cm, ca); }
+            float m[14], a[14];
+            ce_time_interp5(M, A, m, a);
+#pragma unroll
+            for (int z = 0; z < 14; z++) EMIT(z, m[z], a[z]);
         }
 #undef EMIT
-#undef SLOPE
     }
 }
 
@@ -496,6 +452,7 @@ int make_geom(const mi_lte_dl_cfg *cfg, DlGeom *g)
     g->half = 6 * cfg->N_rb_dl; g->N_rb_dl = cfg->N_rb_dl; g->N_ant = cfg->N_ant;
     g->sf_stride = (uint32_t)mi_lte_subframe_floats(cfg->N_ant);
     g->ul = 0;
+    g->ce_compact = 0;
     return MI_LTE_OK;
 }
 
@@ -521,7 +478,11 @@ extern "C" int mi_lte_dl_frontend_batch(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cf
     const size_t lds_fft = sizeof(float2) * (g.N + g.N / 32 + 1);
     // 14 symbols + the look-ahead symbols of the next subframe that the CRS interpolation reads: symbol 14 (ports 0 and 1) and, only
     // with four ports, symbol 15 (ports 2 and 3 carry their CRS in the second symbol of a slot)
-    const uint32_t fmt = cfg->sample_format & ~(uint32_t)MI_LTE_IQ_ALL_ROWS;
+    const uint32_t fmt = cfg->sample_format & ~(uint32_t)(MI_LTE_IQ_ALL_ROWS | MI_LTE_CE_COMPACT);
+    if (cfg->sample_format & MI_LTE_CE_COMPACT) {
+        if (cfg->N_ant != 1) { ctx->err = "MI_LTE_CE_COMPACT: single-port cells only"; return MI_LTE_ERR_UNSUPPORTED; }
+        g.ce_compact = 1;
+    }
     const uint32_t n_sym = (cfg->N_ant > 2 || (cfg->sample_format & MI_LTE_IQ_ALL_ROWS)) ? 16 : 15;
     if (fmt == MI_LTE_IQ_I8) {
         SampleSrc<int8_t> s{(const int8_t *)d_samples_a};

@@ -29,6 +29,55 @@ __device__ __forceinline__ uint32_t gold_word(const GoldTables &gt, uint32_t c_i
     return v;
 }
 
+// wrap_phase (liblte_phy.cc:14105-14116): float difference compared against the double constant,
+// the +-2*pi correction is evaluated in double and rounded back to float.
+__device__ __forceinline__ float wrap_phase(float p1, float p2)
+{
+    while ((double)(p1 - p2) >= M_PI) p1 = (float)((double)p1 - 2 * M_PI);
+    while ((double)(p1 - p2) <= -M_PI) p1 = (float)((double)p1 + 2 * M_PI);
+    return p1;
+}
+
+// sin / cos of an unwrapped phase for the time interpolation: two-constant reduction to [-pi, pi] (the phases are a few turns at
+// most), then the hardware's v_sin_f32 / v_cos_f32, which take revolutions.  The estimate is a float-tolerance stage
+// (TOL_CE = 1e-4 in tests/test_frontend_gpu.py; measured against the CPU restatement of the reference the estimate's relative L2 error is 2.4e-7 this way and
+// 2.2e-7 with libm's sincosf, which spent two thirds of the estimator's instructions here).
+__device__ __forceinline__ void ce_sincos(float x, float &sn, float &cs)
+{
+    const float k = rintf(x * 0.15915494309189533577f);
+    float       r = fmaf(-k, 6.28318548202514648438f, x); // 2 pi rounded to float ...
+    r             = fmaf(-k, -1.74845553146951715e-07f, r); // ... and the rest of it
+    r *= 0.15915494309189533577f;
+    sn = __builtin_amdgcn_sinf(r);
+    cs = __builtin_amdgcn_cosf(r);
+}
+
+// Time interpolation of the channel estimate for antenna ports 0 and 1 (liblte_phy.cc:6119-6190): magnitude m[z] and phase a[z] at the
+// 14 symbols of a subframe from the values M[i], A[i] at the CRS symbols 0, 4, 7, 11 and 14 (the next subframe's first).  The
+// reference's order is kept: symbols 0, 4, 7, 11 take the CRS-symbol values as they are; then segment by segment the later phase is
+// wrapped against the (already wrapped) earlier one, the slope is (hi - lo) / d with the phase difference wrapped against 0, and the
+// symbols in between are reached by repeated subtraction from the later end.  The estimate itself is m * (cos a, sin a).
+__device__ __forceinline__ void ce_time_interp5(const float (&M)[5], float (&A)[5], float (&m)[14], float (&a)[14])
+{
+    m[0] = M[0]; a[0] = A[0]; m[4] = M[1]; a[4] = A[1]; m[7] = M[2]; a[7] = A[2]; m[11] = M[3]; a[11] = A[3];
+    float fm, fa, cm, ca;
+#define MI_CE_SLOPE(hi, lo, dv) do { fm = (M[hi] - M[lo]) / (dv); A[hi] = wrap_phase(A[hi], A[lo]); fa = A[hi] - A[lo]; \
+                                     fa = wrap_phase(fa, 0.0f); fa /= (dv); cm = M[hi]; ca = A[hi]; } while (0)
+    MI_CE_SLOPE(1, 0, 4);
+#pragma unroll
+    for (int z = 3; z > 0; z--) { cm -= fm; ca -= fa; m[z] = cm; a[z] = ca; }
+    MI_CE_SLOPE(2, 1, 3);
+#pragma unroll
+    for (int z = 6; z > 4; z--) { cm -= fm; ca -= fa; m[z] = cm; a[z] = ca; }
+    MI_CE_SLOPE(3, 2, 4);
+#pragma unroll
+    for (int z = 10; z > 7; z--) { cm -= fm; ca -= fa; m[z] = cm; a[z] = ca; }
+    MI_CE_SLOPE(4, 3, 3);
+#pragma unroll
+    for (int z = 13; z > 11; z--) { cm -= fm; ca -= fa; m[z] = cm; a[z] = ca; }
+#undef MI_CE_SLOPE
+}
+
 // get_soft_decision (liblte_phy.cc:13880-13900) with max_dist = 1
 __device__ __forceinline__ float soft_decision(float rx_re, float rx_im, float exp_re, float exp_im)
 {

@@ -56,10 +56,10 @@ def test_pdsch_stage_parity_exact(ctx, port, mod, tbs, nprb, snr):
     for u in range(4):
         err, out, desc = want[u]
         e = plan.soft_bits(u)
-        if mod != 1:
-            assert e.shape == desc.shape and (e == desc).all(), "soft bits differ (unit %d)" % u
-        else:  # QPSK is graded through atan2f/sqrtf: allow the libm boundary cases
-            assert e.shape == desc.shape and np.mean(e != desc) < 1e-3 and np.abs(e.astype(int) - desc).max() <= 254
+        # every modulation, QPSK's graded soft values included: the equaliser is IEEE arithmetic in the reference's order, the quadrant
+        # is the reference's (signs away from the axes, its atan2f comparisons next to them) and sqrtf is correctly rounded, so the
+        # bytes are identical -- measured on 441 240 QPSK soft bits from 300 dB down to 0 dB SNR: none differ (tools/diag_qpsk.py)
+        assert e.shape == desc.shape and (e == desc).all(), "soft bits differ (unit %d): %d" % (u, int((e != desc).sum()))
         assert st[u] == err, (u, st[u], err)
         if err == 0:
             assert (bits[u] == out).all()
@@ -329,8 +329,7 @@ def test_redundancy_versions(ctx, ref, rv, mod, tbs, nprb):
     st, bits = plan.run(d_sub, [sf], [cell])
     e = plan.soft_bits(0)
     want = np.ctypeslib.as_array(ref.ref_pdsch_descramb_bits_ptr(phy), shape=(len(e),)).astype(np.int8)
-    if mod != 1:
-        assert (e == want).all()
+    assert (e == want).all()
     assert (st[0] == 0) == (rc == 0)
     if rc == 0:
         assert (bits[0] == out[:tbs]).all()

@@ -129,6 +129,7 @@ def all_cores_rate(make_worker, n_cpu, budget_s):
 
 
 # ------------------------------------------------------------------------------------------------
+CE_MODE = "compact"  # --ce: form of the channel estimate between the front end and the PDSCH demodulator (chain workload)
 DECODER = "ref"  # --decoder: "ref" = the reference-faithful decoder (parity mode), "bcjr" = max-log-MAP, 8 iterations
 
 
@@ -294,7 +295,9 @@ class ChainWorkload:
         import lte_testdata as td
         self.ctx, self.m, self.np = ctx, m, np
         self.n = n_units or 65536
-        self.cfg = m.DlCfg(2048, 100, 1, 0)
+        # MI_LTE_CE_COMPACT: the estimator hands the demodulator magnitude / phase rows at the CRS symbols instead of 14 estimate rows
+        # (identical results, 172 KB less HBM traffic per subframe); --ce full runs the reference's stage boundary as it is
+        self.cfg = m.DlCfg(2048, 100, 1, m.IQ_I8 | (m.CE_COMPACT if CE_MODE == "compact" else 0))
         U = min(96, self.n)
         sfs = np.array([[1, 2, 3, 4, 6, 7, 8, 9][i % 8] for i in range(U)], np.uint32)  # subframes 0/5 carry sync signals
         cells = ((np.arange(U) * 37 + 11 * rank) % 504).astype(np.uint32)
@@ -401,7 +404,7 @@ class ChainWorkload:
     def config(self, world):
         return {"workload": "W4 full DL chain: 20 MHz/100 RB/64QAM, 9 allocations per subframe (8x12 PRB TBS 3240 + 1x4 PRB "
                             "TBS 1064), %d subframes per GPU, int8 IQ in HBM" % self.n,
-                "subframes_per_gpu": self.n, "N_ant": 1, "CFI": 2,
+                "subframes_per_gpu": self.n, "N_ant": 1, "CFI": 2, "channel_estimate_form": CE_MODE,
                 "decoder": "BCJR (max-log-MAP, 8 iterations; specified by the plain-C model, not by the reference)" if DECODER == "bcjr" else "REF (reference-faithful, bit-exact)",
                 "unique_subframes": len(self.uniq[2]),
                 "batch_note": "the %d subframes of a step are %d unique synthetic subframes (30 / 27 / 25 dB) repeated; every kernel on the path is "
@@ -978,12 +981,13 @@ def main():
     ap.add_argument("--units", type=int, default=0, help="units (subframes / code blocks) per GPU per step")
     ap.add_argument("--streams", type=int, default=1, help="independent shards (contexts/streams) per GPU")
     ap.add_argument("--decoder", default="ref", choices=["ref", "bcjr"], help="turbo workload only: decoder mode")
+    ap.add_argument("--ce", default="compact", choices=["compact", "full"], help="chain workload: channel-estimate form handed to the demodulator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-turbo-leg", action="store_true", help="chain workload: skip the short W3 turbo-decode legs after the timed region")
     args = ap.parse_args()
 
-    global DECODER
-    DECODER = args.decoder
+    global DECODER, CE_MODE
+    DECODER, CE_MODE = args.decoder, args.ce
     maybe_relaunch(args.gpus, sys.argv[1:])
     rank, world, barrier, max_reduce = dist_setup(args.gpus)
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))

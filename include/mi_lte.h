@@ -96,8 +96,15 @@ const char *mi_lte_profile_report(mi_lte_ctx *ctx);
  * (channel-estimate rows 14,15 are never written, as in the reference). */
 typedef enum {
     MI_LTE_IQ_I8 = 0, MI_LTE_IQ_F32_PLANAR = 1,
-    MI_LTE_IQ_ALL_ROWS = 0x100 /* OR into sample_format for mi_lte_dl_frontend_batch: produce symbol row 15 for N_ant <= 2 as well, as the
+    MI_LTE_IQ_ALL_ROWS = 0x100, /* OR into sample_format for mi_lte_dl_frontend_batch: produce symbol row 15 for N_ant <= 2 as well, as the
                                   reference's struct holds it (the per-call host form and the shim set it) */
+    MI_LTE_CE_COMPACT = 0x200  /* OR into sample_format of BOTH mi_lte_dl_frontend_batch and mi_lte_pdsch_plan_create (single-port cells): the
+                                  estimator stops after the frequency direction and leaves, instead of the 14 estimate rows, the magnitude and
+                                  phase rows at the five CRS symbols (rows 0-4 of rx_ce_re = magnitude, rows 0-4 of rx_ce_im = phase); the PDSCH
+                                  demodulator then runs the reference's time interpolation (liblte_phy.cc:6119-6190) itself, for its own
+                                  resource elements only.  Same arithmetic in the same order, so soft bits and decoded blocks are identical
+                                  to the full form; 172 KB per subframe less HBM traffic.  Device subframes in this form are for the PDSCH
+                                  chain only (the control-channel decoders and the host forms want the estimate rows). */
 } mi_lte_iq_format;
 typedef struct {
     uint32_t fft_size;      /* 128, 256, 512, 1024, 2048 = N_samps_per_symb (liblte_phy.cc:2226-2274) */

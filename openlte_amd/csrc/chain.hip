@@ -52,11 +52,14 @@ __device__ __forceinline__ uint32_t pdsch_mask(uint32_t N_ant, uint32_t cell, ui
 // The kernel is latency-bound (a chain of dependent table reads, then scattered plane reads per resource element), so it lives on
 // occupancy: 8 waves per SIMD with a few spilled registers beat 4 without (2.80 -> 2.18 ms per 32k subframes); the single-port
 // case is its own instantiation so that the 2/4-port combiners do not set its register count.
-template <bool ONE_PORT>
+template <bool ONE_PORT, bool COMPACT = false>
 #ifndef DEMOD_WPE
 #define DEMOD_WPE 8
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEMOD_WPE, 8))) void k_pdsch_demod(const float *__restrict__ subframes, DemodGeom g,
+#ifndef DEMOD_WPE_C
+#define DEMOD_WPE_C 8
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? DEMOD_WPE_C : DEMOD_WPE, 8))) void k_pdsch_demod(const float *__restrict__ subframes, DemodGeom g,
                                                      const mi_lte_pdsch_alloc *__restrict__ allocs,
                                                      const uint32_t *__restrict__ subfr_num, const uint32_t *__restrict__ n_id_cell,
                                                      GoldTables gt, int8_t *__restrict__ e_base, const uint32_t *__restrict__ e_off,
@@ -158,7 +161,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEMOD_WPE, 
         }
     };
     const bool qam = al.mod_type >= 2; // uniform
-    if (ONE_PORT) { // one RE = one symbol (liblte_phy.cc:7684-7690): thread per (PRB-symbol pair, sub-carrier), no search
+    if (ONE_PORT && COMPACT) {
+        // MI_LTE_CE_COMPACT: the estimate arrives as magnitude / phase rows at the five CRS symbols (mag in the real-part plane, phase in
+        // the imaginary-part plane, rows 0-4).  One thread per (slot, PRB, sub-carrier): it loads the ten values of its sub-carrier, runs the
+        // reference's time interpolation for the whole subframe (the later segments depend on the phases wrapped in the earlier ones), and
+        // equalises its slot's resource elements with m * (cos a, sin a) -- the values k_dl_ce would have written, bit for bit.
+        const uint32_t per_slot = N_prb * 12, n_items = 2 * per_slot;
+        const uint32_t magic12 = 0xFFFFFFFFu / 12u + 1u;
+        auto body = [&](auto *dst) {
+            for (uint32_t item = threadIdx.x; item < n_items; item += blockDim.x) {
+                const uint32_t s = item >= per_slot ? 1u : 0u, r = item - s * per_slot, i = __umulhi(r, magic12), j = r - 12 * i;
+                const uint32_t k = (uint32_t)al.prb[s][i] * 12 + j, below = (1u << j) - 1u;
+                float M[5], A[5], m[14], a[14];
+#pragma unroll
+                for (int c = 0; c < 5; c++) { M[c] = h_re_p[c * N_SC_MAX + k]; A[c] = h_im_p[c * N_SC_MAX + k]; }
+                // the slot's symbols: requested before the interpolation needs its inputs
+                float yr[7], yi[7];
+#pragma unroll
+                for (int t = 0; t < 7; t++) { yr[t] = y_re_p[(7 * s + t) * N_SC_MAX + k]; yi[t] = y_im_p[(7 * s + t) * N_SC_MAX + k]; }
+                ce_time_interp5(M, A, m, a);
+#pragma unroll
+                for (int t = 0; t < 7; t++) {
+                    const uint32_t L = 7 * s + t;
+                    if (L < g.cfi) continue;
+                    const uint32_t q = (L - g.cfi) * N_prb + i, mk = masks[q];
+                    if (!((mk >> j) & 1u)) continue;
+                    const uint32_t idx = offs[q] + __popc(mk & below);
+                    float sn, cs;
+                    ce_sincos(s ? a[7 + t] : a[t], sn, cs);
+                    const float mm = s ? m[7 + t] : m[t], hr = mm * cs, hi = mm * sn;
+                    const float hn = hr * hr + hi * hi;
+                    const float xr = (yr[t] * hr + yi[t] * hi) / hn, xi = (yi[t] * hr - yr[t] * hi) / hn;
+                    if (qam) put_qam(dst, idx, qam_neg_bits(xr, xi, al.mod_type));
+                    else {
+                        int8_t b[6] = {0, 0, 0, 0, 0, 0};
+                        demap_symbol(xr, xi, al.mod_type, b);
+                        put_bits(dst, idx, b);
+                    }
+                }
+            }
+        };
+        if (via_lds) body(e_lds); else body(e);
+    } else if (ONE_PORT) { // one RE = one symbol (liblte_phy.cc:7684-7690): thread per (PRB-symbol pair, sub-carrier), no search
         constexpr int UNR = 4; // loads of UNR independent REs in flight per thread (the kernel is latency-bound otherwise)
         // 21 pairs x 12 sub-carriers per sweep of the workgroup: a thread keeps its sub-carrier, so nothing is divided in the loop
         const uint32_t q_thr = threadIdx.x / 12, j = threadIdx.x - 12 * q_thr, below = (1u << j) - 1u;
@@ -285,6 +329,7 @@ int mi_lte_pdsch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, uint32_t
 {
     if (!ctx || !cfg || !h_allocs || !out || n_alloc == 0 || N_pdcch_symbs < 1 || N_pdcch_symbs > 4) return MI_LTE_ERR_INVALID_ARG;
     if (!(cfg->N_ant == 1 || cfg->N_ant == 2 || cfg->N_ant == 4)) return MI_LTE_ERR_INVALID_ARG;
+    if ((cfg->sample_format & MI_LTE_CE_COMPACT) && cfg->N_ant != 1) { ctx->err = "MI_LTE_CE_COMPACT: single-port cells only"; return MI_LTE_ERR_UNSUPPORTED; }
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     auto *pl      = new mi_lte_pdsch_plan();
     auto  guard   = on_fail([&] { (void)hipStreamSynchronize(ctx->stream); mi_lte_pdsch_plan_destroy(nullptr, pl); });
@@ -387,7 +432,10 @@ int mi_lte_pdsch_decode_run(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, const float 
     const uint32_t e_cap = (e_bytes <= 32 * 1024) ? e_bytes : 0;
     const uint32_t pairs_al = ((2 * pl->max_pairs + 1 + 3u) & ~3u);
     const size_t lds = sizeof(uint32_t) * ((size_t)pairs_al + words_al) + e_cap;
-    if (g.N_ant == 1)
+    if (g.N_ant == 1 && (pl->cfg.sample_format & MI_LTE_CE_COMPACT))
+        MI_LAUNCH(ctx, "k_pdsch_demod", (k_pdsch_demod<true, true>), dim3(pl->n_alloc), dim3(256), lds, d_subframes, g, pl->d_allocs, d_subfr_num,
+                  d_n_id_cell, gt, pl->d_e, pl->d_e_off, pl->d_e_len, pl->max_pairs, words_al, e_cap);
+    else if (g.N_ant == 1)
         MI_LAUNCH(ctx, "k_pdsch_demod", k_pdsch_demod<true>, dim3(pl->n_alloc), dim3(256), lds, d_subframes, g, pl->d_allocs, d_subfr_num,
                   d_n_id_cell, gt, pl->d_e, pl->d_e_off, pl->d_e_len, pl->max_pairs, words_al, e_cap);
     else

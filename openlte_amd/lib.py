@@ -15,6 +15,7 @@ _SOFT_OF_DTYPE = {np.dtype(np.float32): SOFT_F32, np.dtype(np.int8): SOFT_I8, np
 
 IQ_I8, IQ_F32_PLANAR = 0, 1
 IQ_ALL_ROWS = 0x100  # OR into DlCfg.sample_format: symbol row 15 also for one or two ports (MI_LTE_IQ_ALL_ROWS)
+CE_COMPACT = 0x200   # OR into DlCfg.sample_format of the front end AND the PDSCH plan: magnitude / phase rows instead of estimate rows (MI_LTE_CE_COMPACT)
 
 
 class DlCfg(C.Structure):

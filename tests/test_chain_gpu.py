@@ -372,3 +372,61 @@ def test_filler_bit_transport_blocks_same_verdict_as_reference(ctx, ref, tbs, mo
     d_sub.free()
     ref.ref_subframe_free(rx)
     ref.ref_phy_free(phy)
+
+
+def test_compact_estimate_form_is_bit_identical(ctx, port):
+    """MI_LTE_CE_COMPACT (the form bench.py's chain runs in): the estimator stops after the frequency direction and the demodulator runs
+    the reference's time interpolation (liblte_phy.cc:6119-6190) for its own resource elements.  Same arithmetic in the same order, so
+    every soft bit, verdict and decoded bit must equal the full form's -- on W4 subframes, on subframes 0 and 5 (PBCH / PSS / SSS
+    windows), with QPSK / 16QAM / 64QAM, with different PRBs in the two slots and at an SNR where blocks fail -- and the oracle's."""
+    import openlte_amd as m
+    from openlte_amd import synth
+    cfg_f, cfg_c = m.DlCfg(2048, 100, 1, m.IQ_I8), m.DlCfg(2048, 100, 1, m.IQ_I8 | m.CE_COMPACT)
+    sfs, cells = [0, 5, 3, 9, 6, 1], [0, 17, 100, 301, 404, 503]
+    for case, snr in (("w4", 30.0), ("w4", 21.0), ("mixed", 25.0)):
+        allocs = []
+        for u in range(len(sfs)):
+            if case == "w4":
+                allocs += td.w4_allocs(u)
+            else:
+                allocs += [m.make_alloc(u, 1, 680, list(range(0, 8)), 0x200), m.make_alloc(u, 2, 1384, list(range(40, 48)), 0x201),
+                           m.make_alloc(u, 3, 2024, list(range(50, 58)), 0x202, prbs_slot1=list(range(70, 78))),
+                           m.make_alloc(u, 1, 1000, list(range(10, 40)), 0x203), m.make_alloc(u, 3, 1064, [99, 98, 97, 96], 0x204)]
+        n_al = len(allocs) // len(sfs)
+        iq, tx = synth.dl_units(cfg_f, sfs, cells, allocs, n_al, snr_db=snr, max_delay=5, seed=int(snr) + n_al)
+        n, ul = len(sfs), iq.shape[1]
+        d_iq = ctx.to_device(iq.reshape(-1, 2))
+        d_start = ctx.to_device((np.arange(n) * ul).astype(np.uint64))
+        d_sf, d_cell = ctx.to_device(np.asarray(sfs, np.uint32)), ctx.to_device(np.asarray(cells, np.uint32))
+        res = []
+        for cfg in (cfg_f, cfg_c):
+            d_sub = ctx.alloc(n * ctx.subframe_floats(1) * 4)
+            d_sub.zero()
+            ctx.dl_frontend_dev(cfg, d_iq, None, d_start, d_sf, d_cell, n, d_sub)
+            plan = ctx.pdsch_plan(cfg, 2, allocs)
+            st, bits = plan.run(d_sub, sfs, cells)
+            res.append((st.copy(), [b.copy() for b in bits], [plan.soft_bits(a).copy() for a in range(len(allocs))]))
+            plan.close()
+            d_sub.free()
+        (st_f, bits_f, e_f), (st_c, bits_c, e_c) = res
+        assert (st_f == st_c).all(), (case, snr)
+        for a in range(len(allocs)):
+            assert e_f[a].shape == e_c[a].shape and (e_f[a] == e_c[a]).all(), (case, snr, a, int((e_f[a] != e_c[a]).sum()))
+            assert (bits_f[a] == bits_c[a]).all(), (case, snr, a)
+        if case == "w4":  # and the oracle's verdicts / bits (the oracle's allocation has one PRB list for both slots)
+            if snr >= 30:  # everything decodes except where the PBCH / PSS / SSS window of subframes 0 and 5 punctures an allocation below rate 1/3
+                assert (st_c[18:] == 0).all()
+            for u in (0, 3):
+                lc, s = td.oracle_frontend(port, 2048, 100, 1, iq[u], sfs[u], cells[u])
+                for a in range(9):
+                    k = u * 9 + a
+                    err, out, _ = oracle_pdsch(port, lc, s, allocs[k], 2, cells[u], 1)
+                    assert err == st_c[k] and (err != 0 or (out == bits_c[k]).all()), (snr, u, a)
+        for b in (d_iq, d_start, d_sf, d_cell):
+            b.free()
+
+
+def test_compact_estimate_form_is_single_port_only(ctx):
+    import openlte_amd as m
+    with pytest.raises(m.MiLteError):
+        ctx.pdsch_plan(m.DlCfg(2048, 100, 2, m.IQ_I8 | m.CE_COMPACT), 2, td.small_allocs(0, 100, 3, 2024, 8))

@@ -54,6 +54,7 @@ void mi_lte_ctx_destroy(mi_lte_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->host_cache_free) ctx->host_cache_free(ctx);
     for (void *p : ctx->owned) (void)hipFree(p);
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     if (ctx->scratch) (void)hipFree(ctx->scratch);

@@ -50,6 +50,10 @@ struct mi_lte_ctx {
     size_t                                 prof_used = 0;
     std::vector<std::pair<const char *, size_t>> prof_recs; // (kernel name, index of start event)
     std::string                            prof_report;
+
+    // persistent state of the per-call host forms (hostapi.cc): staging buffers, the device subframe, plan caches
+    void *host_cache = nullptr;
+    void (*host_cache_free)(mi_lte_ctx *) = nullptr;
 };
 
 void mi_prof_begin(mi_lte_ctx *ctx, const char *name);

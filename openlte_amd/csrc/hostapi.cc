@@ -1,25 +1,209 @@
-// Per-call, host-pointer forms of the three reference entry points on the hot path (see
-// include/mi_lte.h).  They exist for drop-in use through shim/liblte_phy_shim.cc: stage through HBM,
-// run the same batch kernels with a batch of one, copy back.  No arithmetic happens on the host.
+// Per-call, host-pointer forms of the reference's entry points on the hot path (see include/mi_lte.h).  They exist for drop-in use
+// through shim/liblte_phy_shim.cc: stage through HBM, run the same batch kernels with a batch of one, copy back.  No arithmetic
+// happens on the host.
+//
+// A caller of the reference API makes several calls per subframe on the same LIBLTE_PHY_SUBFRAME_STRUCT (get_dl_subframe_and_ce ->
+// pdcch_channel_decode -> pdsch_channel_decode per allocation; LTE_fdd_dl_fs_samp_buf.cc:445-515) and has 1 ms per subframe in the
+// eNodeB's radio thread (LTE_fdd_enb_phy.cc:429-446).  So nothing here allocates per call: every context owns
+//   * pinned host staging and device buffers that grow to the largest call seen and stay,
+//   * ONE device subframe, tagged with the host arrays it mirrors and a fingerprint of their contents: the copy
+//     get_dl_subframe_and_ce leaves in HBM is what the decoders called next read -- the 300-770 KB upload of the caller's struct only
+//     happens when the caller hands in a subframe this context has not produced (or has changed since),
+//   * plans (PDSCH, PDCCH, PUSCH, PRACH) cached by everything they were built from, least recently used evicted.
 #include <cstring>
+#include <list>
+#include <string>
 #include <vector>
 
 #include "ctx.hpp"
 
 namespace {
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t n) { return hipMalloc(&p, n ? n : 1) == hipSuccess ? 0 : -1; }
-};
+constexpr size_t ROW = 16 * 1200; // floats per plane of a subframe struct (LIBLTE_PHY_SUBFRAME_STRUCT rows, liblte_phy.h:226-239)
+
 // the LTE transform lengths and a grid that fits inside them: checked before any size arithmetic is done with fft_size
 bool valid_fft(uint32_t fft_size, uint32_t N_rb)
 {
     return (fft_size == 128 || fft_size == 256 || fft_size == 512 || fft_size == 1024 || fft_size == 2048) && N_rb >= 6 && N_rb * 12 < fft_size;
 }
+uint32_t fft_of(uint32_t N_rb) { return N_rb <= 6 ? 128 : N_rb <= 15 ? 256 : N_rb <= 25 ? 512 : N_rb <= 50 ? 1024 : 2048; }
+
+template <typename Plan> struct PlanCache { // key -> plan, most recently used first
+    typedef void (*Destroy)(mi_lte_ctx *, Plan *);
+    std::list<std::pair<std::string, Plan *>> items;
+    Destroy destroy;
+    size_t  cap;
+    PlanCache(Destroy d, size_t c) : destroy(d), cap(c) {}
+    Plan *find(const std::string &k)
+    {
+        for (auto it = items.begin(); it != items.end(); ++it)
+            if (it->first == k) { items.splice(items.begin(), items, it); return items.front().second; }
+        return nullptr;
+    }
+    void put(mi_lte_ctx *ctx, const std::string &k, Plan *p)
+    {
+        items.emplace_front(k, p);
+        while (items.size() > cap) { destroy(ctx, items.back().second); items.pop_back(); }
+    }
+    void clear(mi_lte_ctx *ctx)
+    {
+        for (auto &kv : items) destroy(ctx, kv.second);
+        items.clear();
+    }
+};
+template <typename T> void key_add(std::string &k, const T &v) { k.append(reinterpret_cast<const char *>(&v), sizeof(T)); }
+uint64_t fnv(const void *p, size_t n, uint64_t h = 1469598103934665603ull)
+{
+    const uint8_t *b = (const uint8_t *)p;
+    for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+struct HostCache {
+    uint8_t *h_pin = nullptr; size_t h_pin_bytes = 0; // pinned staging
+    uint8_t *d_in = nullptr;  size_t d_in_bytes = 0;  // sample staging on the device
+    float    *d_sub = nullptr;                        // the device subframe: (2 + 2*4) planes of 16 x 1200 floats
+    uint32_t *d_par = nullptr;                        // 16 words of per-call parameters
+    uint8_t  *d_out = nullptr;                        // decoded bits of one transport block (6144 + 64 bytes)
+    int32_t  *d_st  = nullptr;
+    // what d_sub mirrors: the caller's rx_symb_re array, the port count its layout was written for, and a fingerprint of the contents
+    const float *sub_host = nullptr;
+    uint32_t     sub_n_ant = 0;
+    bool         sub_ul = false;
+    uint64_t     sub_fp = 0;
+    uint64_t     n_reuse = 0, n_upload = 0; // statistics (mi_lte_host_cache_stats)
+    PlanCache<mi_lte_pdsch_plan> pdsch{mi_lte_pdsch_plan_destroy, 64};
+    PlanCache<mi_lte_pdcch_plan> pdcch{mi_lte_pdcch_plan_destroy, 8};
+    PlanCache<mi_lte_pusch_plan> pusch{mi_lte_pusch_plan_destroy, 64};
+    PlanCache<mi_lte_prach_plan> prach{mi_lte_prach_plan_destroy, 4};
+};
+
+void host_cache_free(mi_lte_ctx *ctx)
+{
+    HostCache *hc = (HostCache *)ctx->host_cache;
+    if (!hc) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    hc->pdsch.clear(ctx); hc->pdcch.clear(ctx); hc->pusch.clear(ctx); hc->prach.clear(ctx);
+    if (hc->h_pin) (void)hipHostFree(hc->h_pin);
+    (void)hipFree(hc->d_in); (void)hipFree(hc->d_sub); (void)hipFree(hc->d_par); (void)hipFree(hc->d_out); (void)hipFree(hc->d_st);
+    delete hc;
+    ctx->host_cache = nullptr;
+}
+
+int host_cache(mi_lte_ctx *ctx, HostCache **out)
+{
+    if (!ctx->host_cache) {
+        HostCache *hc = new HostCache();
+        ctx->host_cache      = hc;
+        ctx->host_cache_free = host_cache_free;
+        MI_HIP_CHECK(ctx, hipMalloc((void **)&hc->d_sub, 10 * ROW * sizeof(float)));
+        MI_HIP_CHECK(ctx, hipMemsetAsync(hc->d_sub, 0, 10 * ROW * sizeof(float), ctx->stream));
+        MI_HIP_CHECK(ctx, hipMalloc((void **)&hc->d_par, 64));
+        MI_HIP_CHECK(ctx, hipMalloc((void **)&hc->d_out, 6144 + 64));
+        MI_HIP_CHECK(ctx, hipMalloc((void **)&hc->d_st, 64));
+    }
+    *out = (HostCache *)ctx->host_cache;
+    return MI_LTE_OK;
+}
+int need_pin(mi_lte_ctx *ctx, HostCache *hc, size_t bytes)
+{
+    if (bytes <= hc->h_pin_bytes) return MI_LTE_OK;
+    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (hc->h_pin) (void)hipHostFree(hc->h_pin);
+    hc->h_pin = nullptr; hc->h_pin_bytes = 0;
+    bytes = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+    MI_HIP_CHECK(ctx, hipHostMalloc((void **)&hc->h_pin, bytes, hipHostMallocDefault));
+    hc->h_pin_bytes = bytes;
+    return MI_LTE_OK;
+}
+int need_dev_in(mi_lte_ctx *ctx, HostCache *hc, size_t bytes)
+{
+    if (bytes <= hc->d_in_bytes) return MI_LTE_OK;
+    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(hc->d_in);
+    hc->d_in = nullptr; hc->d_in_bytes = 0;
+    bytes = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&hc->d_in, bytes));
+    hc->d_in_bytes = bytes;
+    return MI_LTE_OK;
+}
+// n floats of each of two host arrays -> d_in (a | b), through the pinned staging buffer: one copy on the PCIe link
+int stage_pair(mi_lte_ctx *ctx, HostCache *hc, const float *h_a, const float *h_b, size_t n, float **d_a, float **d_b)
+{
+    int rc = need_pin(ctx, hc, 2 * n * 4);
+    if (rc == MI_LTE_OK) rc = need_dev_in(ctx, hc, 2 * n * 4);
+    if (rc != MI_LTE_OK) return rc;
+    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); // the staging buffer may still be the source of the previous call's copy
+    memcpy(hc->h_pin, h_a, n * 4);
+    memcpy(hc->h_pin + n * 4, h_b, n * 4);
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->d_in, hc->h_pin, 2 * n * 4, hipMemcpyHostToDevice, ctx->stream));
+    *d_a = (float *)hc->d_in;
+    *d_b = (float *)hc->d_in + n;
+    return MI_LTE_OK;
+}
+
+// Fingerprint of a host subframe: 8 samples of every row of every plane that carries data.  It answers "is this still what the
+// device copy was made from" for a caller that does not edit the arrays behind the library's back element by element (the
+// reference's callers never write them); a caller that does calls mi_lte_host_cache_invalidate.
+uint64_t subframe_fp(const float *re, const float *im, const float *ce_re, const float *ce_im, uint32_t n_ant, uint32_t n_sc, uint32_t rows)
+{
+    uint64_t     h = 1469598103934665603ull ^ ((uint64_t)n_ant << 32 | n_sc);
+    const float *pl[10];
+    uint32_t     np = 0;
+    pl[np++] = re; pl[np++] = im;
+    for (uint32_t p = 0; p < n_ant && ce_re; p++) { pl[np++] = ce_re + p * ROW; pl[np++] = ce_im + p * ROW; }
+    for (uint32_t q = 0; q < np; q++)
+        for (uint32_t r = 0; r < rows; r++) {
+            const float *row = pl[q] + r * 1200;
+            uint32_t     w[8];
+            for (uint32_t k = 0; k < 8; k++) memcpy(&w[k], row + (k * n_sc) / 8 + (r + k) % 5, 4);
+            h = fnv(w, sizeof(w), h);
+        }
+    return h;
+}
+
+// make d_sub hold the caller's subframe (downlink layout for n_ant ports, or the two uplink planes): nothing to do when it is the
+// copy this context produced (or uploaded) last and the arrays have not changed since
+int bind_subframe(mi_lte_ctx *ctx, HostCache *hc, const float *re, const float *im, const float *ce_re, const float *ce_im, uint32_t n_ant, uint32_t n_sc, bool ul)
+{
+    const uint32_t rows = ul ? 14 : 16;
+    const uint64_t fp = subframe_fp(re, im, ce_re, ce_im, ul ? 0 : n_ant, n_sc, ul ? 14 : 14);
+    if (hc->sub_host == re && hc->sub_n_ant == n_ant && hc->sub_ul == ul && hc->sub_fp == fp) { hc->n_reuse++; return MI_LTE_OK; }
+    const size_t planes = ul ? 2 : 2 + 2 * (size_t)n_ant, bytes = planes * ROW * 4;
+    int rc = need_pin(ctx, hc, bytes);
+    if (rc != MI_LTE_OK) return rc;
+    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    float *st = (float *)hc->h_pin;
+    memcpy(st, re, ROW * 4);
+    memcpy(st + ROW, im, ROW * 4);
+    if (!ul) {
+        memcpy(st + 2 * ROW, ce_re, n_ant * ROW * 4);
+        memcpy(st + (2 + n_ant) * ROW, ce_im, n_ant * ROW * 4);
+    }
+    (void)rows;
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->d_sub, st, bytes, hipMemcpyHostToDevice, ctx->stream));
+    hc->sub_host = re; hc->sub_n_ant = n_ant; hc->sub_ul = ul; hc->sub_fp = fp;
+    hc->n_upload++;
+    return MI_LTE_OK;
+}
 } // namespace
 
 extern "C" {
+
+int mi_lte_host_cache_stats(mi_lte_ctx *ctx, uint64_t *n_subframe_reuse, uint64_t *n_subframe_upload, uint32_t *n_plans)
+{
+    if (!ctx) return MI_LTE_ERR_INVALID_ARG;
+    HostCache *hc = (HostCache *)ctx->host_cache;
+    if (n_subframe_reuse) *n_subframe_reuse = hc ? hc->n_reuse : 0;
+    if (n_subframe_upload) *n_subframe_upload = hc ? hc->n_upload : 0;
+    if (n_plans) *n_plans = hc ? (uint32_t)(hc->pdsch.items.size() + hc->pdcch.items.size() + hc->pusch.items.size() + hc->prach.items.size()) : 0;
+    return MI_LTE_OK;
+}
+int mi_lte_host_cache_invalidate(mi_lte_ctx *ctx)
+{
+    if (!ctx) return MI_LTE_ERR_INVALID_ARG;
+    if (ctx->host_cache) ((HostCache *)ctx->host_cache)->sub_host = nullptr;
+    return MI_LTE_OK;
+}
 
 // liblte_phy_get_dl_subframe_and_ce (liblte_phy.cc:5905-6200), argument checks as at :5937-5943
 int mi_lte_get_dl_subframe_and_ce_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_dl, const float *h_i, const float *h_q,
@@ -30,28 +214,36 @@ int mi_lte_get_dl_subframe_and_ce_host(mi_lte_ctx *ctx, uint32_t fft_size, uint3
     if (!h_i || !h_q || !(N_ant == 1 || N_ant == 2 || N_ant == 4) || !h_symb_re || !h_symb_im || !h_ce_re || !h_ce_im || !valid_fft(fft_size, N_rb_dl))
         return 1;
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    HostCache *hc;
+    int        rc = host_cache(ctx, &hc);
+    if (rc != MI_LTE_OK) return rc;
     const uint32_t sc = 2048 / fft_size;
     const size_t   per_sf = 30720 / sc, need = per_sf + 2 * fft_size + 160 / sc + 144 / sc - 1; // last sample symbol 15 reads, +1
     const size_t   start = (size_t)frame_start_idx + (size_t)subfr_num * per_sf;
-    DevBuf d_i, d_q, d_par, d_sub;
-    const size_t nf = mi_lte_subframe_floats(N_ant);
-    if (d_i.alloc(need * 4) || d_q.alloc(need * 4) || d_par.alloc(32) || d_sub.alloc(nf * 4)) return MI_LTE_ERR_NOMEM;
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(d_i.p, h_i + start, need * 4, hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(d_q.p, h_q + start, need * 4, hipMemcpyHostToDevice, ctx->stream));
-    struct { uint64_t start; uint32_t sf, cell; } par = {0, subfr_num, N_id_cell};
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(d_par.p, &par, sizeof(par), hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP_CHECK(ctx, hipMemsetAsync(d_sub.p, 0, nf * 4, ctx->stream));
-    mi_lte_dl_cfg cfg = {fft_size, N_rb_dl, N_ant, MI_LTE_IQ_F32_PLANAR | MI_LTE_IQ_ALL_ROWS}; // every row the reference's struct holds
-    int rc = mi_lte_dl_frontend_batch(ctx, &cfg, d_i.p, d_q.p, (const uint64_t *)d_par.p, (const uint32_t *)((char *)d_par.p + 8),
-                                      (const uint32_t *)((char *)d_par.p + 12), 1, (float *)d_sub.p);
+    float *d_i, *d_q;
+    rc = stage_pair(ctx, hc, h_i + start, h_q + start, need, &d_i, &d_q);
     if (rc != MI_LTE_OK) return rc;
-    const size_t row = 16 * 1200 * sizeof(float);
-    float       *s   = (float *)d_sub.p;
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(h_symb_re, s, row, hipMemcpyDeviceToHost, ctx->stream));
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(h_symb_im, s + 16 * 1200, row, hipMemcpyDeviceToHost, ctx->stream));
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(h_ce_re, s + 2 * 16 * 1200, row * N_ant, hipMemcpyDeviceToHost, ctx->stream));
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(h_ce_im, s + (2 + N_ant) * 16 * 1200, row * N_ant, hipMemcpyDeviceToHost, ctx->stream));
+    struct { uint64_t start; uint32_t sf, cell; } par = {0, subfr_num, N_id_cell};
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->d_par, &par, sizeof(par), hipMemcpyHostToDevice, ctx->stream));
+    hc->sub_host = nullptr; // d_sub is being rewritten
+    mi_lte_dl_cfg cfg = {fft_size, N_rb_dl, N_ant, MI_LTE_IQ_F32_PLANAR | MI_LTE_IQ_ALL_ROWS}; // every row the reference's struct holds
+    rc = mi_lte_dl_frontend_batch(ctx, &cfg, d_i, d_q, (const uint64_t *)hc->d_par, hc->d_par + 2, hc->d_par + 3, 1, hc->d_sub);
+    if (rc != MI_LTE_OK) return rc;
+    const size_t planes = 2 + 2 * (size_t)N_ant, bytes = planes * ROW * 4;
+    rc = need_pin(ctx, hc, bytes);
+    if (rc != MI_LTE_OK) return rc;
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->h_pin, hc->d_sub, bytes, hipMemcpyDeviceToHost, ctx->stream));
     MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const float *st = (const float *)hc->h_pin;
+    memcpy(h_symb_re, st, ROW * 4);
+    memcpy(h_symb_im, st + ROW, ROW * 4);
+    for (uint32_t p = 0; p < N_ant; p++) { // estimate rows 14 and 15 are never written, as in the reference
+        memcpy(h_ce_re + p * ROW, st + (2 + p) * ROW, 14 * 1200 * 4);
+        memcpy(h_ce_im + p * ROW, st + (2 + N_ant + p) * ROW, 14 * 1200 * 4);
+    }
+    // the device copy stays: the decoders the caller runs next on this struct read it (bind_subframe)
+    hc->sub_host = h_symb_re; hc->sub_n_ant = N_ant; hc->sub_ul = false;
+    hc->sub_fp = subframe_fp(h_symb_re, h_symb_im, h_ce_re, h_ce_im, N_ant, 12 * N_rb_dl, 14);
     return 0;
 }
 
@@ -62,41 +254,44 @@ int mi_lte_pdsch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const fl
                                      uint32_t *N_out_bits)
 {
     if (!ctx) return MI_LTE_ERR_INVALID_ARG;
-    if (!h_symb_re || !h_symb_im || !h_ce_re || !h_ce_im || !alloc || N_id_cell > 503 || !h_out_bits || !N_out_bits) return 1;
+    if (!h_symb_re || !h_symb_im || !h_ce_re || !h_ce_im || !alloc || N_id_cell > 503 || !h_out_bits || !N_out_bits || N_rb_dl < 6 || N_rb_dl > 100 ||
+        !(N_ant == 1 || N_ant == 2 || N_ant == 4))
+        return 1;
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    const uint32_t fft = N_rb_dl <= 6 ? 128 : N_rb_dl <= 15 ? 256 : N_rb_dl <= 25 ? 512 : N_rb_dl <= 50 ? 1024 : 2048;
-    mi_lte_dl_cfg       cfg = {fft, N_rb_dl, N_ant, MI_LTE_IQ_F32_PLANAR};
-    mi_lte_pdsch_alloc  a   = *alloc;
-    a.unit                  = 0;
-    mi_lte_pdsch_plan *plan = nullptr;
-    int                rc   = mi_lte_pdsch_plan_create(ctx, &cfg, N_pdcch_symbs, &a, 1, &plan);
-    if (rc == MI_LTE_ERR_UNSUPPORTED) return 2; // outside the envelope the reference itself decodes: report a decode failure
+    HostCache *hc;
+    int        rc = host_cache(ctx, &hc);
     if (rc != MI_LTE_OK) return rc;
-    const size_t nf = mi_lte_subframe_floats(N_ant), row = 16 * 1200;
-    const uint32_t stride = mi_lte_pdsch_plan_out_stride(plan);
-    DevBuf d_sub, d_par, d_out, d_st;
-    if (d_sub.alloc(nf * 4) || d_par.alloc(16) || d_out.alloc(stride) || d_st.alloc(4)) { mi_lte_pdsch_plan_destroy(ctx, plan); return MI_LTE_ERR_NOMEM; }
-    float *s = (float *)d_sub.p;
-    uint32_t par[2] = {subfr_num, N_id_cell};
-    hipError_t e = hipMemcpyAsync(s, h_symb_re, row * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(s + row, h_symb_im, row * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(s + 2 * row, h_ce_re, row * 4 * N_ant, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(s + (2 + N_ant) * row, h_ce_im, row * 4 * N_ant, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_par.p, par, 8, hipMemcpyHostToDevice, ctx->stream);
-    if (e != hipSuccess) { mi_lte_pdsch_plan_destroy(ctx, plan); ctx->err = hipGetErrorString(e); return MI_LTE_ERR_HIP; }
-    rc = mi_lte_pdsch_decode_run(ctx, plan, s, (const uint32_t *)d_par.p, (const uint32_t *)d_par.p + 1, (uint8_t *)d_out.p, (int32_t *)d_st.p);
-    int32_t st = 2;
-    if (rc == MI_LTE_OK) {
-        e = hipMemcpyAsync(&st, d_st.p, 4, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e == hipSuccess && st == 0) { // the reference copies the bits out only when the CRC matched (:12861-12869)
-            e = hipMemcpy(h_out_bits, d_out.p, a.tbs, hipMemcpyDeviceToHost);
-            *N_out_bits = a.tbs;
-        }
-        if (e != hipSuccess) { rc = MI_LTE_ERR_HIP; ctx->err = hipGetErrorString(e); }
+    mi_lte_dl_cfg       cfg = {fft_of(N_rb_dl), N_rb_dl, N_ant, MI_LTE_IQ_F32_PLANAR};
+    mi_lte_pdsch_alloc  a   = *alloc;
+    a.unit = 0; a.reserved = 0;
+    std::string key;
+    key_add(key, cfg); key_add(key, N_pdcch_symbs); key_add(key, a);
+    mi_lte_pdsch_plan *plan = hc->pdsch.find(key);
+    if (!plan) {
+        rc = mi_lte_pdsch_plan_create(ctx, &cfg, N_pdcch_symbs, &a, 1, &plan);
+        if (rc == MI_LTE_ERR_UNSUPPORTED) return 2; // outside the envelope the reference itself decodes: report a decode failure
+        if (rc != MI_LTE_OK) return rc;
+        hc->pdsch.put(ctx, key, plan);
     }
-    mi_lte_pdsch_plan_destroy(ctx, plan);
-    return rc != MI_LTE_OK ? rc : (int)st;
+    rc = bind_subframe(ctx, hc, h_symb_re, h_symb_im, h_ce_re, h_ce_im, N_ant, 12 * N_rb_dl, false);
+    if (rc != MI_LTE_OK) return rc;
+    const uint32_t par[2] = {subfr_num, N_id_cell};
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->d_par + 4, par, 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = mi_lte_pdsch_decode_run(ctx, plan, hc->d_sub, hc->d_par + 4, hc->d_par + 5, hc->d_out, hc->d_st);
+    if (rc != MI_LTE_OK) return rc;
+    rc = need_pin(ctx, hc, 8192);
+    if (rc != MI_LTE_OK) return rc;
+    // verdict and bits in one go (the bits are only handed over when the CRC matched, like the reference, :12861-12869)
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->h_pin, hc->d_st, 4, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->h_pin + 64, hc->d_out, a.tbs, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    int32_t st;
+    memcpy(&st, hc->h_pin, 4);
+    if (st == 0) {
+        memcpy(h_out_bits, hc->h_pin + 64, a.tbs);
+        *N_out_bits = a.tbs;
+    }
+    return (int)st;
 }
 
 // liblte_phy_pdcch_channel_decode (liblte_phy.cc:4519-5135): PCFICH + common-search-space DCIs of one subframe
@@ -106,30 +301,26 @@ int mi_lte_pdcch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const fl
                                      mi_lte_pdcch_dci *dci /*[MI_LTE_PDCCH_MAX_DCI]*/)
 {
     if (!ctx) return MI_LTE_ERR_INVALID_ARG;
-    if (!h_symb_re || !h_symb_im || !h_ce_re || !h_ce_im || N_id_cell > 503 || !cfi || !N_symbs || !N_dci || !dci) return 1;
+    if (!h_symb_re || !h_symb_im || !h_ce_re || !h_ce_im || N_id_cell > 503 || !cfi || !N_symbs || !N_dci || !dci || !(N_ant == 1 || N_ant == 2 || N_ant == 4)) return 1;
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    const uint32_t fft = N_rb_dl <= 6 ? 128 : N_rb_dl <= 15 ? 256 : N_rb_dl <= 25 ? 512 : N_rb_dl <= 50 ? 1024 : 2048;
-    mi_lte_dl_cfg      cfg  = {fft, N_rb_dl, N_ant, MI_LTE_IQ_F32_PLANAR};
-    mi_lte_pdcch_plan *plan = nullptr;
-    int rc = mi_lte_pdcch_plan_create(ctx, &cfg, phich_res, phich_dur_extended, flags, &N_id_cell, 1, &plan);
+    HostCache *hc;
+    int        rc = host_cache(ctx, &hc);
     if (rc != MI_LTE_OK) return rc;
-    const size_t nf = mi_lte_subframe_floats(N_ant), row = 16 * 1200;
-    DevBuf d_sub, d_par;
-    if (d_sub.alloc(nf * 4) || d_par.alloc(16)) { mi_lte_pdcch_plan_destroy(ctx, plan); return MI_LTE_ERR_NOMEM; }
-    float   *s      = (float *)d_sub.p;
-    uint32_t par[2] = {subfr_num, N_id_cell}, h_rc = 1;
-    // only the control region is read: symbols 0..3
-    const size_t ctl = 4 * 1200 * sizeof(float);
-    hipError_t   e   = hipMemcpyAsync(s, h_symb_re, ctl, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(s + row, h_symb_im, ctl, hipMemcpyHostToDevice, ctx->stream);
-    for (uint32_t p = 0; p < N_ant && e == hipSuccess; p++) {
-        e = hipMemcpyAsync(s + (2 + p) * row, h_ce_re + p * row, ctl, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(s + (2 + N_ant + p) * row, h_ce_im + p * row, ctl, hipMemcpyHostToDevice, ctx->stream);
+    mi_lte_dl_cfg cfg = {fft_of(N_rb_dl), N_rb_dl, N_ant, MI_LTE_IQ_F32_PLANAR};
+    std::string   key;
+    key_add(key, cfg); key_add(key, phich_res); key_add(key, phich_dur_extended); key_add(key, flags); key_add(key, N_id_cell);
+    mi_lte_pdcch_plan *plan = hc->pdcch.find(key);
+    if (!plan) {
+        rc = mi_lte_pdcch_plan_create(ctx, &cfg, phich_res, phich_dur_extended, flags, &N_id_cell, 1, &plan);
+        if (rc != MI_LTE_OK) return rc;
+        hc->pdcch.put(ctx, key, plan);
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(d_par.p, par, 8, hipMemcpyHostToDevice, ctx->stream);
-    if (e != hipSuccess) { mi_lte_pdcch_plan_destroy(ctx, plan); ctx->err = hipGetErrorString(e); return MI_LTE_ERR_HIP; }
-    rc = mi_lte_pdcch_decode_run(ctx, plan, s, (const uint32_t *)d_par.p, (const uint32_t *)d_par.p + 1, 1, &h_rc, cfi, N_symbs, N_dci, dci);
-    mi_lte_pdcch_plan_destroy(ctx, plan);
+    rc = bind_subframe(ctx, hc, h_symb_re, h_symb_im, h_ce_re, h_ce_im, N_ant, 12 * N_rb_dl, false);
+    if (rc != MI_LTE_OK) return rc;
+    const uint32_t par[2] = {subfr_num, N_id_cell};
+    uint32_t       h_rc = 1;
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->d_par + 4, par, 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = mi_lte_pdcch_decode_run(ctx, plan, hc->d_sub, hc->d_par + 4, hc->d_par + 5, 1, &h_rc, cfi, N_symbs, N_dci, dci);
     return rc != MI_LTE_OK ? rc : (int)h_rc;
 }
 
@@ -140,24 +331,15 @@ int mi_lte_bch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const floa
     if (!ctx) return MI_LTE_ERR_INVALID_ARG;
     if (!h_symb_re || !h_symb_im || !h_ce_re || !h_ce_im || N_id_cell > 503 || !N_ant || !h_out_bits || !N_out_bits || !offset) return 1;
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    const uint32_t fft = N_rb_dl <= 6 ? 128 : N_rb_dl <= 15 ? 256 : N_rb_dl <= 25 ? 512 : N_rb_dl <= 50 ? 1024 : 2048;
-    mi_lte_dl_cfg cfg = {fft, N_rb_dl, 4, MI_LTE_IQ_F32_PLANAR};
-    const size_t  nf = mi_lte_subframe_floats(4), row = 16 * 1200;
-    DevBuf d_sub, d_par;
-    if (d_sub.alloc(nf * 4) || d_par.alloc(16)) return MI_LTE_ERR_NOMEM;
-    float *s = (float *)d_sub.p;
-    // only symbols 7..10 are read
-    const size_t o = 7 * 1200, len = 4 * 1200 * sizeof(float);
-    hipError_t   e = hipMemcpyAsync(s + o, h_symb_re + o, len, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(s + row + o, h_symb_im + o, len, hipMemcpyHostToDevice, ctx->stream);
-    for (uint32_t p = 0; p < 4 && e == hipSuccess; p++) {
-        e = hipMemcpyAsync(s + (2 + p) * row + o, h_ce_re + p * row + o, len, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(s + (6 + p) * row + o, h_ce_im + p * row + o, len, hipMemcpyHostToDevice, ctx->stream);
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(d_par.p, &N_id_cell, 4, hipMemcpyHostToDevice, ctx->stream);
-    if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return MI_LTE_ERR_HIP; }
+    HostCache *hc;
+    int        rc = host_cache(ctx, &hc);
+    if (rc != MI_LTE_OK) return rc;
+    mi_lte_dl_cfg cfg = {fft_of(N_rb_dl), N_rb_dl, 4, MI_LTE_IQ_F32_PLANAR};
+    rc = bind_subframe(ctx, hc, h_symb_re, h_symb_im, h_ce_re, h_ce_im, 4, 12 * N_rb_dl, false); // all four ports' estimates are tried
+    if (rc != MI_LTE_OK) return rc;
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->d_par + 4, &N_id_cell, 4, hipMemcpyHostToDevice, ctx->stream));
     uint32_t n_ant = 0, off = 0, mib = 0;
-    int rc = mi_lte_pbch_decode_run(ctx, &cfg, s, (const uint32_t *)d_par.p, 1, &n_ant, &off, &mib);
+    rc = mi_lte_pbch_decode_run(ctx, &cfg, hc->d_sub, hc->d_par + 4, 1, &n_ant, &off, &mib);
     if (rc != MI_LTE_OK) return rc;
     *N_ant = (uint8_t)n_ant; // the reference zeroes it before trying (:4029)
     if (n_ant == 0) return 2;
@@ -174,16 +356,15 @@ int mi_lte_pucch_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_ul, const float *h_s
     if (!ctx) return MI_LTE_ERR_INVALID_ARG;
     if (!h_symb_re || !h_symb_im || format > 2 || !h_tables || !h_out_bits || !N_out_bits) return 1;
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    DevBuf d_sub;
-    const size_t row = 16 * 1200;
-    if (d_sub.alloc(mi_lte_ul_subframe_floats() * 4)) return MI_LTE_ERR_NOMEM;
-    float *s = (float *)d_sub.p;
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(s, h_symb_re, 14 * 1200 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(s + row, h_symb_im, 14 * 1200 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HostCache *hc;
+    int        rc = host_cache(ctx, &hc);
+    if (rc != MI_LTE_OK) return rc;
+    rc = bind_subframe(ctx, hc, h_symb_re, h_symb_im, nullptr, nullptr, 1, 12 * N_rb_ul, true);
+    if (rc != MI_LTE_OK) return rc;
     mi_lte_pucch_res r = {0, format, N_1_p_pucch};
     uint8_t  bits[2] = {0, 0};
     uint32_t nb = 0, rc2 = 1;
-    int rc = mi_lte_pucch_decode_run(ctx, N_rb_ul, N_ant, s, &r, h_tables, 1, bits, &nb, &rc2);
+    rc = mi_lte_pucch_decode_run(ctx, N_rb_ul, N_ant, hc->d_sub, &r, h_tables, 1, bits, &nb, &rc2);
     if (rc != MI_LTE_OK) return rc == MI_LTE_ERR_INVALID_ARG ? 1 : rc;
     h_out_bits[0] = bits[0];
     if (nb == 2) h_out_bits[1] = bits[1];
@@ -192,27 +373,20 @@ int mi_lte_pucch_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_ul, const float *h_s
 }
 
 // ---- initial synchronisation (liblte_phy.cc:5697-5852, :5306-5510, :5578-5687): stage n samples of each array, run the device search
-namespace {
-int stage_iq(mi_lte_ctx *ctx, const float *h_i, const float *h_q, size_t n, DevBuf &d_i, DevBuf &d_q)
-{
-    if (d_i.alloc(n * 4) || d_q.alloc(n * 4)) return MI_LTE_ERR_NOMEM;
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(d_i.p, h_i, n * 4, hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(d_q.p, h_q, n * 4, hipMemcpyHostToDevice, ctx->stream));
-    return MI_LTE_OK;
-}
-} // namespace
-
 int mi_lte_dl_find_coarse_timing_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_dl, const float *h_i, const float *h_q, uint32_t N_slots,
                                       mi_lte_coarse_timing *out)
 {
     if (!ctx) return MI_LTE_ERR_INVALID_ARG;
     if (!h_i || !h_q || !out || !valid_fft(fft_size, N_rb_dl)) return 1;
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    mi_lte_dl_cfg cfg = {fft_size, N_rb_dl, 1, MI_LTE_IQ_F32_PLANAR};
-    DevBuf d_i, d_q;
-    int    rc = stage_iq(ctx, h_i, h_q, mi_lte_coarse_timing_samples(fft_size, N_slots), d_i, d_q);
+    HostCache *hc;
+    int        rc = host_cache(ctx, &hc);
     if (rc != MI_LTE_OK) return rc;
-    return mi_lte_coarse_timing_run(ctx, &cfg, d_i.p, d_q.p, 0, N_slots, out);
+    mi_lte_dl_cfg cfg = {fft_size, N_rb_dl, 1, MI_LTE_IQ_F32_PLANAR};
+    float *d_i, *d_q;
+    rc = stage_pair(ctx, hc, h_i, h_q, mi_lte_coarse_timing_samples(fft_size, N_slots), &d_i, &d_q);
+    if (rc != MI_LTE_OK) return rc;
+    return mi_lte_coarse_timing_run(ctx, &cfg, d_i, d_q, 0, N_slots, out);
 }
 
 int mi_lte_find_pss_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_dl, const float *h_i, const float *h_q, uint32_t *symb_starts,
@@ -221,15 +395,18 @@ int mi_lte_find_pss_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_dl, c
     if (!ctx) return MI_LTE_ERR_INVALID_ARG;
     if (!h_i || !h_q || !symb_starts || !N_id_2 || !pss_symb || !pss_thresh || !freq_offset || !valid_fft(fft_size, N_rb_dl)) return 1;
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    HostCache *hc;
+    int        rc = host_cache(ctx, &hc);
+    if (rc != MI_LTE_OK) return rc;
     mi_lte_dl_cfg  cfg = {fft_size, N_rb_dl, 1, MI_LTE_IQ_F32_PLANAR};
     const uint32_t sc = 2048 / fft_size;
     uint32_t       last = 0;
     for (int j = 0; j < 7; j++) last = symb_starts[j] > last ? symb_starts[j] : last;
     const size_t n = (size_t)last + 11 * (15360 / sc) + 160 / sc + fft_size + 38; // last window of the 84, or of the +39 fine-timing trial
-    DevBuf d_i, d_q;
-    int    rc = stage_iq(ctx, h_i, h_q, n, d_i, d_q);
+    float *d_i, *d_q;
+    rc = stage_pair(ctx, hc, h_i, h_q, n, &d_i, &d_q);
     if (rc != MI_LTE_OK) return rc;
-    return mi_lte_find_pss_run(ctx, &cfg, d_i.p, d_q.p, 0, symb_starts, N_id_2, pss_symb, pss_thresh, freq_offset);
+    return mi_lte_find_pss_run(ctx, &cfg, d_i, d_q, 0, symb_starts, N_id_2, pss_symb, pss_thresh, freq_offset);
 }
 
 int mi_lte_find_sss_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_dl, const float *h_i, const float *h_q, uint32_t N_id_2, uint32_t *symb_starts,
@@ -238,13 +415,16 @@ int mi_lte_find_sss_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_dl, c
     if (!ctx) return MI_LTE_ERR_INVALID_ARG;
     if (!h_i || !h_q || !symb_starts || !N_id_1 || !frame_start_idx || !valid_fft(fft_size, N_rb_dl)) return 1;
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    HostCache *hc;
+    int        rc = host_cache(ctx, &hc);
+    if (rc != MI_LTE_OK) return rc;
     mi_lte_dl_cfg  cfg = {fft_size, N_rb_dl, 1, MI_LTE_IQ_F32_PLANAR};
     const uint32_t sc = 2048 / fft_size;
-    DevBuf d_i, d_q;
-    int    rc = stage_iq(ctx, h_i, h_q, (size_t)symb_starts[5] + 160 / sc - 1 + fft_size, d_i, d_q);
+    float *d_i, *d_q;
+    rc = stage_pair(ctx, hc, h_i, h_q, (size_t)symb_starts[5] + 160 / sc - 1 + fft_size, &d_i, &d_q);
     if (rc != MI_LTE_OK) return rc;
     uint32_t found = 0;
-    rc = mi_lte_find_sss_run(ctx, &cfg, d_i.p, d_q.p, 0, N_id_2, symb_starts, pss_thresh, N_id_1, frame_start_idx, &found);
+    rc = mi_lte_find_sss_run(ctx, &cfg, d_i, d_q, 0, N_id_2, symb_starts, pss_thresh, N_id_1, frame_start_idx, &found);
     return rc != MI_LTE_OK ? rc : (found ? 0 : 1);
 }
 
@@ -255,22 +435,28 @@ int mi_lte_get_ul_subframe_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_r
     if (!ctx) return MI_LTE_ERR_INVALID_ARG;
     if (!h_i || !h_q || !h_symb_re || !h_symb_im || !valid_fft(fft_size, N_rb_ul)) return 1;
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    HostCache *hc;
+    int        rc = host_cache(ctx, &hc);
+    if (rc != MI_LTE_OK) return rc;
     const uint32_t sc = 2048 / fft_size;
     const size_t   need = 30720 / sc; // the last symbol's window ends one sample before the subframe does
-    DevBuf d_i, d_q, d_par, d_sub;
-    const size_t nf = mi_lte_ul_subframe_floats();
-    if (d_i.alloc(need * 4) || d_q.alloc(need * 4) || d_par.alloc(8) || d_sub.alloc(nf * 4)) return MI_LTE_ERR_NOMEM;
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(d_i.p, h_i, need * 4, hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(d_q.p, h_q, need * 4, hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP_CHECK(ctx, hipMemsetAsync(d_par.p, 0, 8, ctx->stream));
-    mi_lte_dl_cfg cfg = {fft_size, N_rb_ul, 1, MI_LTE_IQ_F32_PLANAR};
-    int rc = mi_lte_ul_frontend_batch(ctx, &cfg, d_i.p, d_q.p, (const uint64_t *)d_par.p, 1, (float *)d_sub.p);
+    float *d_i, *d_q;
+    rc = stage_pair(ctx, hc, h_i, h_q, need, &d_i, &d_q);
     if (rc != MI_LTE_OK) return rc;
-    const size_t row = 14 * 1200 * sizeof(float); // rows 14, 15 of the caller's struct are left alone, as the reference leaves them
-    float       *s   = (float *)d_sub.p;
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(h_symb_re, s, row, hipMemcpyDeviceToHost, ctx->stream));
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(h_symb_im, s + 16 * 1200, row, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemsetAsync(hc->d_par, 0, 8, ctx->stream));
+    hc->sub_host = nullptr;
+    mi_lte_dl_cfg cfg = {fft_size, N_rb_ul, 1, MI_LTE_IQ_F32_PLANAR};
+    rc = mi_lte_ul_frontend_batch(ctx, &cfg, d_i, d_q, (const uint64_t *)hc->d_par, 1, hc->d_sub);
+    if (rc != MI_LTE_OK) return rc;
+    rc = need_pin(ctx, hc, 2 * ROW * 4);
+    if (rc != MI_LTE_OK) return rc;
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->h_pin, hc->d_sub, 2 * ROW * 4, hipMemcpyDeviceToHost, ctx->stream));
     MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t row = 14 * 1200 * sizeof(float); // rows 14, 15 of the caller's struct are left alone, as the reference leaves them
+    memcpy(h_symb_re, hc->h_pin, row);
+    memcpy(h_symb_im, hc->h_pin + ROW * 4, row);
+    hc->sub_host = h_symb_re; hc->sub_n_ant = 1; hc->sub_ul = true;
+    hc->sub_fp = subframe_fp(h_symb_re, h_symb_im, nullptr, nullptr, 0, 12 * N_rb_ul, 14);
     return 0;
 }
 
@@ -283,42 +469,48 @@ int mi_lte_pusch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_ul, const fl
                                      uint32_t *N_out_bits)
 {
     if (!ctx) return MI_LTE_ERR_INVALID_ARG;
-    if (!h_symb_re || !h_symb_im || !alloc || !h_out_bits || !N_out_bits || !h_dmrs_0_re || !h_dmrs_0_im || !h_dmrs_1_re || !h_dmrs_1_im) return 1;
+    if (!h_symb_re || !h_symb_im || !alloc || !h_out_bits || !N_out_bits || !h_dmrs_0_re || !h_dmrs_0_im || !h_dmrs_1_re || !h_dmrs_1_im || N_rb_ul < 6 || N_rb_ul > 100 ||
+        alloc->N_prb == 0 || alloc->N_prb > 110)
+        return 1;
     (void)N_ant;
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    const uint32_t fft = N_rb_ul <= 6 ? 128 : N_rb_ul <= 15 ? 256 : N_rb_ul <= 25 ? 512 : N_rb_ul <= 50 ? 1024 : 2048;
-    mi_lte_dl_cfg      cfg = {fft, N_rb_ul, 1, MI_LTE_IQ_F32_PLANAR};
+    HostCache *hc;
+    int        rc = host_cache(ctx, &hc);
+    if (rc != MI_LTE_OK) return rc;
+    mi_lte_dl_cfg      cfg = {fft_of(N_rb_ul), N_rb_ul, 1, MI_LTE_IQ_F32_PLANAR};
     mi_lte_pdsch_alloc a   = *alloc;
-    a.unit                 = 0;
+    a.unit = 0; a.reserved = 0;
     const size_t       M   = 12 * (size_t)a.N_prb;
     std::vector<float> dm(4 * M);
     memcpy(&dm[0], h_dmrs_0_re, M * 4); memcpy(&dm[M], h_dmrs_0_im, M * 4);
     memcpy(&dm[2 * M], h_dmrs_1_re, M * 4); memcpy(&dm[3 * M], h_dmrs_1_im, M * 4);
-    mi_lte_pusch_plan *plan = nullptr;
-    int rc = mi_pusch_plan_create_impl(ctx, &cfg, nullptr, &subfr_num, &N_id_cell, 1, &a, 1, dm.data(), &plan);
-    if (rc == MI_LTE_ERR_UNSUPPORTED) return 1;
-    if (rc != MI_LTE_OK) return rc;
-    const size_t   nf = mi_lte_ul_subframe_floats(), row = 16 * 1200;
-    const uint32_t stride = mi_lte_pusch_plan_out_stride(plan);
-    DevBuf d_sub, d_out, d_st;
-    if (d_sub.alloc(nf * 4) || d_out.alloc(stride) || d_st.alloc(4)) { mi_lte_pusch_plan_destroy(ctx, plan); return MI_LTE_ERR_NOMEM; }
-    float     *s = (float *)d_sub.p;
-    hipError_t e = hipMemcpyAsync(s, h_symb_re, row * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(s + row, h_symb_im, row * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (e != hipSuccess) { mi_lte_pusch_plan_destroy(ctx, plan); ctx->err = hipGetErrorString(e); return MI_LTE_ERR_HIP; }
-    rc = mi_lte_pusch_decode_run(ctx, plan, s, (uint8_t *)d_out.p, (int32_t *)d_st.p);
-    int32_t st = 2;
-    if (rc == MI_LTE_OK) {
-        e = hipMemcpyAsync(&st, d_st.p, 4, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e == hipSuccess && st == 0) {
-            e = hipMemcpy(h_out_bits, d_out.p, a.tbs, hipMemcpyDeviceToHost);
-            *N_out_bits = a.tbs;
-        }
-        if (e != hipSuccess) { rc = MI_LTE_ERR_HIP; ctx->err = hipGetErrorString(e); }
+    // the plan carries the subframe number, the cell and the reference signals: all of them are part of its key
+    std::string key;
+    key_add(key, cfg); key_add(key, subfr_num); key_add(key, N_id_cell); key_add(key, a);
+    key_add(key, fnv(dm.data(), dm.size() * 4));
+    mi_lte_pusch_plan *plan = hc->pusch.find(key);
+    if (!plan) {
+        rc = mi_pusch_plan_create_impl(ctx, &cfg, nullptr, &subfr_num, &N_id_cell, 1, &a, 1, dm.data(), &plan);
+        if (rc == MI_LTE_ERR_UNSUPPORTED) return 1;
+        if (rc != MI_LTE_OK) return rc;
+        hc->pusch.put(ctx, key, plan);
     }
-    mi_lte_pusch_plan_destroy(ctx, plan);
-    return rc != MI_LTE_OK ? rc : (st == 0 ? 0 : 1);
+    rc = bind_subframe(ctx, hc, h_symb_re, h_symb_im, nullptr, nullptr, 1, 12 * N_rb_ul, true);
+    if (rc != MI_LTE_OK) return rc;
+    rc = mi_lte_pusch_decode_run(ctx, plan, hc->d_sub, hc->d_out, hc->d_st);
+    if (rc != MI_LTE_OK) return rc;
+    rc = need_pin(ctx, hc, 8192);
+    if (rc != MI_LTE_OK) return rc;
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->h_pin, hc->d_st, 4, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->h_pin + 64, hc->d_out, a.tbs, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    int32_t st;
+    memcpy(&st, hc->h_pin, 4);
+    if (st == 0) {
+        memcpy(h_out_bits, hc->h_pin + 64, a.tbs);
+        *N_out_bits = a.tbs;
+    }
+    return st == 0 ? 0 : 1;
 }
 
 // liblte_phy_detect_prach (liblte_phy.cc:3299-3479): h_re / h_im point at the occasion's first cyclic-prefix sample; the root
@@ -329,22 +521,28 @@ int mi_lte_detect_prach_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_u
                              uint32_t *det_pre, uint32_t *det_ta)
 {
     if (!ctx) return MI_LTE_ERR_INVALID_ARG;
-    if (!prach || !h_x_u_fft_re || !h_x_u_fft_im || !h_re || !h_im || !N_det_pre || !det_pre || !det_ta || !valid_fft(fft_size, N_rb_ul)) return 1;
+    if (!prach || !h_x_u_fft_re || !h_x_u_fft_im || !h_re || !h_im || !N_det_pre || !det_pre || !det_ta || !valid_fft(fft_size, N_rb_ul) || n_roots == 0 || n_roots > 64) return 1;
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    mi_lte_dl_cfg      cfg = {fft_size, N_rb_ul, 1, MI_LTE_IQ_F32_PLANAR};
-    mi_lte_prach_plan *plan = nullptr;
-    int rc = mi_lte_prach_plan_create_roots(ctx, &cfg, prach, h_x_u_fft_re, h_x_u_fft_im, n_roots, &plan);
-    if (rc != MI_LTE_OK) return rc == MI_LTE_ERR_UNSUPPORTED ? 1 : rc;
+    HostCache *hc;
+    int        rc = host_cache(ctx, &hc);
+    if (rc != MI_LTE_OK) return rc;
+    mi_lte_dl_cfg cfg = {fft_size, N_rb_ul, 1, MI_LTE_IQ_F32_PLANAR};
+    std::string   key;
+    key_add(key, cfg); key_add(key, *prach); key_add(key, n_roots);
+    key_add(key, fnv(h_x_u_fft_re, (size_t)n_roots * 839 * 4, fnv(h_x_u_fft_im, (size_t)n_roots * 839 * 4)));
+    mi_lte_prach_plan *plan = hc->prach.find(key);
+    if (!plan) {
+        rc = mi_lte_prach_plan_create_roots(ctx, &cfg, prach, h_x_u_fft_re, h_x_u_fft_im, n_roots, &plan);
+        if (rc != MI_LTE_OK) return rc == MI_LTE_ERR_UNSUPPORTED ? 1 : rc;
+        hc->prach.put(ctx, key, plan);
+    }
     const size_t need = mi_lte_prach_occasion_samples(plan);
-    DevBuf d_i, d_q, d_s;
-    if (d_i.alloc(need * 4) || d_q.alloc(need * 4) || d_s.alloc(8)) { mi_lte_prach_plan_destroy(ctx, plan); return MI_LTE_ERR_NOMEM; }
-    hipError_t e = hipMemcpyAsync(d_i.p, h_re, need * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_q.p, h_im, need * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_s.p, 0, 8, ctx->stream);
-    if (e != hipSuccess) { mi_lte_prach_plan_destroy(ctx, plan); ctx->err = hipGetErrorString(e); return MI_LTE_ERR_HIP; }
+    float *d_i, *d_q;
+    rc = stage_pair(ctx, hc, h_re, h_im, need, &d_i, &d_q);
+    if (rc != MI_LTE_OK) return rc;
+    MI_HIP_CHECK(ctx, hipMemsetAsync(hc->d_par, 0, 8, ctx->stream));
     uint32_t n = 0, p = 0, ta = 0;
-    rc = mi_lte_prach_detect_run(ctx, plan, d_i.p, d_q.p, (const uint64_t *)d_s.p, 1, &n, &p, &ta);
-    mi_lte_prach_plan_destroy(ctx, plan);
+    rc = mi_lte_prach_detect_run(ctx, plan, d_i, d_q, (const uint64_t *)hc->d_par, 1, &n, &p, &ta);
     if (rc != MI_LTE_OK) return rc;
     *N_det_pre = n;
     if (n) { *det_pre = p; *det_ta = ta; }
@@ -357,14 +555,23 @@ int mi_lte_rate_unmatch_turbo_host(mi_lte_ctx *ctx, const float *h_e, uint32_t N
 {
     if (!ctx || !h_e || !h_d || !N_d) return MI_LTE_ERR_INVALID_ARG;
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    DevBuf d_e, d_d;
-    if (d_e.alloc((size_t)N_e * 4) || d_d.alloc((size_t)3 * N_dummy_bits * 4)) return MI_LTE_ERR_NOMEM;
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(d_e.p, h_e, (size_t)N_e * 4, hipMemcpyHostToDevice, ctx->stream));
-    int rc = mi_lte_rate_unmatch_turbo_batch(ctx, (const float *)d_e.p, N_e, N_dummy_bits, C, tx_mode, N_soft, M_dl_harq, chan_type, rv_idx, 1,
-                                             (float *)d_d.p);
+    if (N_dummy_bits < 44 || N_dummy_bits > 6148 || N_e == 0) return MI_LTE_ERR_INVALID_ARG;
+    HostCache *hc;
+    int        rc = host_cache(ctx, &hc);
     if (rc != MI_LTE_OK) return rc;
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(h_d, d_d.p, (size_t)3 * N_dummy_bits * 4, hipMemcpyDeviceToHost, ctx->stream));
+    const size_t e_bytes = (((size_t)N_e * 4) + 255) & ~(size_t)255, d_bytes = (size_t)3 * N_dummy_bits * 4;
+    rc = need_pin(ctx, hc, e_bytes > d_bytes ? e_bytes : d_bytes);
+    if (rc == MI_LTE_OK) rc = need_dev_in(ctx, hc, e_bytes + d_bytes);
+    if (rc != MI_LTE_OK) return rc;
     MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(hc->h_pin, h_e, (size_t)N_e * 4);
+    float *d_e = (float *)hc->d_in, *d_d = (float *)(hc->d_in + e_bytes);
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(d_e, hc->h_pin, (size_t)N_e * 4, hipMemcpyHostToDevice, ctx->stream));
+    rc = mi_lte_rate_unmatch_turbo_batch(ctx, d_e, N_e, N_dummy_bits, C, tx_mode, N_soft, M_dl_harq, chan_type, rv_idx, 1, d_d);
+    if (rc != MI_LTE_OK) return rc;
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->h_pin, d_d, d_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(h_d, hc->h_pin, d_bytes);
     *N_d = 3 * N_dummy_bits;
     return 0;
 }

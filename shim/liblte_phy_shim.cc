@@ -1,7 +1,7 @@
 // liblte_phy_shim.cc -- the binding a maintainer of the reference adds to run the DL receive hot
 // path -- and, since round 1, the uplink PUSCH receive path -- on an MI355X.  It is compiled AGAINST THE REFERENCE'S OWN HEADER (liblte/hdr/liblte_phy.h from
 // their tree; nothing from the reference is copied here) and defines, with the reference's exact
-// C++ signatures, the three public functions of the hot path:
+// C++ signatures, the public functions of the receive paths (and liblte_phy_cleanup, which owns the GPU context's lifetime):
 //
 //     liblte_phy_get_dl_subframe_and_ce   liblte_phy.h:1170-1177   (impl. liblte_phy.cc:5905-6200)
 //     liblte_phy_pdsch_channel_decode     liblte_phy.h:906-913     (impl. liblte_phy.cc:3690-3853)
@@ -32,20 +32,34 @@
 #include "mi_lte.h"
 
 namespace {
-std::mutex                               g_mu;
-std::map<LIBLTE_PHY_STRUCT *, mi_lte_ctx *> g_ctx;
+// One GPU context per LIBLTE_PHY_STRUCT, created on first use and destroyed with the struct (liblte_phy_cleanup below).  The
+// reference's contract is one call at a time per struct (all of its mutable state lives there); the context has the same
+// contract -- one stream, one scratch, one staged subframe -- and the entry's mutex enforces it for callers that share a struct
+// between threads anyway.
+struct Entry {
+    mi_lte_ctx *ctx = nullptr;
+    std::mutex  mu;
+};
+std::mutex                         g_mu;
+std::map<LIBLTE_PHY_STRUCT *, Entry *> g_ctx;
 
-mi_lte_ctx *ctx_for(LIBLTE_PHY_STRUCT *phy)
+Entry *entry_for(LIBLTE_PHY_STRUCT *phy)
 {
     std::lock_guard<std::mutex> lk(g_mu);
     auto                        it = g_ctx.find(phy);
     if (it != g_ctx.end()) return it->second;
-    mi_lte_ctx *c  = nullptr;
+    Entry      *e  = new Entry();
     const char *dv = getenv("MI_LTE_DEVICE");
-    if (mi_lte_ctx_create(dv ? atoi(dv) : 0, &c) != MI_LTE_OK) c = nullptr; // no GPU: every call below fails loudly
-    g_ctx[phy] = c;
-    return c;
+    if (mi_lte_ctx_create(dv ? atoi(dv) : 0, &e->ctx) != MI_LTE_OK) e->ctx = nullptr; // no GPU: every call below fails loudly
+    g_ctx[phy] = e;
+    return e;
 }
+// the context of a struct, locked for the duration of the enclosing call
+#define MI_LOCKED_CTX(phy, fail)                                                                                                   \
+    Entry *entry_ = entry_for(phy);                                                                                                \
+    if (!entry_->ctx) return fail;                                                                                                 \
+    std::lock_guard<std::mutex> call_lock_(entry_->mu);                                                                            \
+    mi_lte_ctx *c = entry_->ctx
 
 void to_mi_alloc(const LIBLTE_PHY_ALLOCATION_STRUCT *a, mi_lte_pdsch_alloc *o)
 {
@@ -61,14 +75,32 @@ void to_mi_alloc(const LIBLTE_PHY_ALLOCATION_STRUCT *a, mi_lte_pdsch_alloc *o)
 }
 } // namespace
 
+// liblte_phy_cleanup (liblte_phy.h:636, impl. liblte_phy.cc:2524-2543): the struct's GPU context goes first -- stream, scratch, staging buffers
+// and cached plans are released, and a later struct that malloc places at the same address starts with a fresh context -- then the
+// reference's own cleanup (compiled under the name liblte_phy_cleanup_cpu, shim/Makefile) frees the struct.
+LIBLTE_ERROR_ENUM liblte_phy_cleanup_cpu(LIBLTE_PHY_STRUCT *phy_struct);
+LIBLTE_ERROR_ENUM liblte_phy_cleanup(LIBLTE_PHY_STRUCT *phy_struct)
+{
+    Entry *e = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto                        it = g_ctx.find(phy_struct);
+        if (it != g_ctx.end()) { e = it->second; g_ctx.erase(it); }
+    }
+    if (e) {
+        { std::lock_guard<std::mutex> call(e->mu); if (e->ctx) mi_lte_ctx_destroy(e->ctx); } // waits for a call that is still running on it
+        delete e;
+    }
+    return liblte_phy_cleanup_cpu(phy_struct);
+}
+
 LIBLTE_ERROR_ENUM liblte_phy_get_dl_subframe_and_ce(LIBLTE_PHY_STRUCT *phy_struct, float *i_samps, float *q_samps,
                                                     uint32 frame_start_idx, uint8 subfr_num, uint32 N_id_cell, uint8 N_ant,
                                                     LIBLTE_PHY_SUBFRAME_STRUCT *subframe)
 {
     if (phy_struct == NULL || i_samps == NULL || q_samps == NULL || !(N_ant == 1 || N_ant == 2 || N_ant == 4) || subframe == NULL)
         return LIBLTE_ERROR_INVALID_INPUTS;
-    mi_lte_ctx *c = ctx_for(phy_struct);
-    if (!c) return LIBLTE_ERROR_INVALID_INPUTS;
+    MI_LOCKED_CTX(phy_struct, LIBLTE_ERROR_INVALID_INPUTS);
     subframe->num = subfr_num;
     int rc = mi_lte_get_dl_subframe_and_ce_host(c, phy_struct->N_samps_per_symb, phy_struct->N_rb_dl, i_samps, q_samps, frame_start_idx,
                                                 subfr_num, N_id_cell, N_ant, &subframe->rx_symb_re[0][0], &subframe->rx_symb_im[0][0],
@@ -80,10 +112,9 @@ LIBLTE_ERROR_ENUM liblte_phy_pdsch_channel_decode(LIBLTE_PHY_STRUCT *phy_struct,
                                                   LIBLTE_PHY_ALLOCATION_STRUCT *alloc, uint32 N_pdcch_symbs, uint32 N_id_cell,
                                                   uint8 N_ant, uint8 *out_bits, uint32 *N_out_bits)
 {
-    if (phy_struct == NULL || subframe == NULL || N_id_cell > 503 || out_bits == NULL || N_out_bits == NULL)
+    if (phy_struct == NULL || subframe == NULL || alloc == NULL || N_id_cell > 503 || out_bits == NULL || N_out_bits == NULL)
         return LIBLTE_ERROR_INVALID_INPUTS;
-    mi_lte_ctx *c = ctx_for(phy_struct);
-    if (!c) return LIBLTE_ERROR_INVALID_INPUTS;
+    MI_LOCKED_CTX(phy_struct, LIBLTE_ERROR_INVALID_INPUTS);
     mi_lte_pdsch_alloc a;
     to_mi_alloc(alloc, &a);
     int rc = mi_lte_pdsch_channel_decode_host(c, phy_struct->N_rb_dl, &subframe->rx_symb_re[0][0], &subframe->rx_symb_im[0][0],
@@ -97,9 +128,10 @@ void liblte_phy_rate_unmatch_turbo(LIBLTE_PHY_STRUCT *phy_struct, float *e_bits,
                                    LIBLTE_PHY_CHAN_TYPE_ENUM chan_type, uint32 rv_idx, float *d_bits, uint32 *N_d_bits)
 {
     (void)dummy_bits; // only its length matters: a uint8 can never equal RX_NULL_BIT
-    mi_lte_ctx *c = ctx_for(phy_struct);
-    uint32_t    n = 0;
-    if (c && 0 == mi_lte_rate_unmatch_turbo_host(c, e_bits, N_e_bits, N_dummy_bits, N_codeblocks, tx_mode, N_soft, M_dl_harq,
+    if (phy_struct == NULL || e_bits == NULL || d_bits == NULL || N_d_bits == NULL) return;
+    MI_LOCKED_CTX(phy_struct, (void)0);
+    uint32_t n = 0;
+    if (0 == mi_lte_rate_unmatch_turbo_host(c, e_bits, N_e_bits, N_dummy_bits, N_codeblocks, tx_mode, N_soft, M_dl_harq,
                                                  (uint32_t)chan_type, rv_idx, d_bits, &n))
         *N_d_bits = n;
 }
@@ -110,8 +142,7 @@ LIBLTE_ERROR_ENUM liblte_phy_get_ul_subframe(LIBLTE_PHY_STRUCT *phy_struct, floa
                                              LIBLTE_PHY_SUBFRAME_STRUCT *subframe)
 {
     if (phy_struct == NULL || i_samps == NULL || q_samps == NULL || subframe == NULL) return LIBLTE_ERROR_INVALID_INPUTS;
-    mi_lte_ctx *c = ctx_for(phy_struct);
-    if (!c) return LIBLTE_ERROR_INVALID_INPUTS;
+    MI_LOCKED_CTX(phy_struct, LIBLTE_ERROR_INVALID_INPUTS);
     int rc = mi_lte_get_ul_subframe_host(c, phy_struct->N_samps_per_symb, phy_struct->N_rb_ul, i_samps, q_samps,
                                          &subframe->rx_symb_re[0][0], &subframe->rx_symb_im[0][0]);
     return rc == 0 ? LIBLTE_SUCCESS : LIBLTE_ERROR_INVALID_INPUTS;
@@ -124,8 +155,7 @@ LIBLTE_ERROR_ENUM liblte_phy_pusch_channel_decode(LIBLTE_PHY_STRUCT *phy_struct,
     if (phy_struct == NULL || subframe == NULL || alloc == NULL || out_bits == NULL || N_out_bits == NULL || !phy_struct->ul_init ||
         alloc->N_prb == 0 || alloc->N_prb >= LIBLTE_PHY_N_RB_UL_MAX || subframe->num > 9)
         return LIBLTE_ERROR_INVALID_INPUTS;
-    mi_lte_ctx *c = ctx_for(phy_struct);
-    if (!c) return LIBLTE_ERROR_INVALID_INPUTS;
+    MI_LOCKED_CTX(phy_struct, LIBLTE_ERROR_INVALID_INPUTS);
     mi_lte_pdsch_alloc a;
     to_mi_alloc(alloc, &a);
     // the reference signals are the ones liblte_phy_ul_init (still the reference's own code) left in the struct
@@ -142,8 +172,7 @@ LIBLTE_ERROR_ENUM liblte_phy_detect_prach(LIBLTE_PHY_STRUCT *phy_struct, float *
     if (phy_struct == NULL || samps_re == NULL || samps_im == NULL || N_det_pre == NULL || det_pre == NULL || det_ta == NULL ||
         !phy_struct->ul_init || phy_struct->prach_preamble_format > 3)
         return LIBLTE_ERROR_INVALID_INPUTS; // (format 4 is TDD-only; this shim covers the FDD formats)
-    mi_lte_ctx *c = ctx_for(phy_struct);
-    if (!c) return LIBLTE_ERROR_INVALID_INPUTS;
+    MI_LOCKED_CTX(phy_struct, LIBLTE_ERROR_INVALID_INPUTS);
     mi_lte_prach_cfg pc = {phy_struct->prach_root_seq_idx, phy_struct->prach_preamble_format, phy_struct->prach_zczc,
                            phy_struct->prach_hs_flag ? 1u : 0u, freq_offset};
     // the root sequences' spectra are the ones liblte_phy_ul_init (still the reference's code) left in the struct
@@ -159,8 +188,7 @@ LIBLTE_ERROR_ENUM liblte_phy_pdcch_channel_decode(LIBLTE_PHY_STRUCT *phy_struct,
                                                   LIBLTE_PHY_PCFICH_STRUCT *pcfich, LIBLTE_PHY_PHICH_STRUCT *phich, LIBLTE_PHY_PDCCH_STRUCT *pdcch)
 {
     if (phy_struct == NULL || subframe == NULL || pcfich == NULL || phich == NULL || pdcch == NULL) return LIBLTE_ERROR_INVALID_INPUTS;
-    mi_lte_ctx *c = ctx_for(phy_struct);
-    if (!c) return LIBLTE_ERROR_INVALID_INPUTS;
+    MI_LOCKED_CTX(phy_struct, LIBLTE_ERROR_INVALID_INPUTS);
     // MI_LTE_PDCCH_PER_PORT=1 selects the standard transmit-diversity combiner instead of the reference's arithmetic (mi_lte.h)
     const char      *pp    = getenv("MI_LTE_PDCCH_PER_PORT");
     const uint32_t   flags = (pp && atoi(pp)) ? MI_LTE_PDCCH_PER_PORT_ESTIMATES : 0u;
@@ -202,8 +230,7 @@ LIBLTE_ERROR_ENUM liblte_phy_bch_channel_decode(LIBLTE_PHY_STRUCT *phy_struct, L
 {
     if (phy_struct == NULL || subframe == NULL || N_id_cell > 503 || N_ant == NULL || out_bits == NULL || N_out_bits == NULL || offset == NULL)
         return LIBLTE_ERROR_INVALID_INPUTS;
-    mi_lte_ctx *c = ctx_for(phy_struct);
-    if (!c) return LIBLTE_ERROR_INVALID_INPUTS;
+    MI_LOCKED_CTX(phy_struct, LIBLTE_ERROR_INVALID_INPUTS);
     int rc = mi_lte_bch_channel_decode_host(c, phy_struct->N_rb_dl, &subframe->rx_symb_re[0][0], &subframe->rx_symb_im[0][0], &subframe->rx_ce_re[0][0][0],
                                             &subframe->rx_ce_im[0][0][0], N_id_cell, N_ant, out_bits, N_out_bits, offset);
     return rc == 0 ? LIBLTE_SUCCESS : rc == 2 ? LIBLTE_ERROR_DECODE_FAIL : LIBLTE_ERROR_INVALID_INPUTS;
@@ -215,8 +242,7 @@ LIBLTE_ERROR_ENUM liblte_phy_dl_find_coarse_timing_and_freq_offset(LIBLTE_PHY_ST
                                                                    LIBLTE_PHY_COARSE_TIMING_STRUCT *timing_struct)
 {
     if (phy_struct == NULL || i_samps == NULL || q_samps == NULL || timing_struct == NULL) return LIBLTE_ERROR_INVALID_INPUTS;
-    mi_lte_ctx *c = ctx_for(phy_struct);
-    if (!c) return LIBLTE_ERROR_INVALID_INPUTS;
+    MI_LOCKED_CTX(phy_struct, LIBLTE_ERROR_INVALID_INPUTS);
     mi_lte_coarse_timing t;
     if (mi_lte_dl_find_coarse_timing_host(c, phy_struct->N_samps_per_symb, phy_struct->N_rb_dl, i_samps, q_samps, N_slots, &t) != 0)
         return LIBLTE_ERROR_INVALID_INPUTS;
@@ -233,8 +259,7 @@ LIBLTE_ERROR_ENUM liblte_phy_find_pss_and_fine_timing(LIBLTE_PHY_STRUCT *phy_str
 {
     if (phy_struct == NULL || i_samps == NULL || q_samps == NULL || symb_starts == NULL || N_id_2 == NULL || pss_symb == NULL || pss_thresh == NULL)
         return LIBLTE_ERROR_INVALID_INPUTS;
-    mi_lte_ctx *c = ctx_for(phy_struct);
-    if (!c) return LIBLTE_ERROR_INVALID_INPUTS;
+    MI_LOCKED_CTX(phy_struct, LIBLTE_ERROR_INVALID_INPUTS);
     float f = 0;
     int   rc = mi_lte_find_pss_host(c, phy_struct->N_samps_per_symb, phy_struct->N_rb_dl, i_samps, q_samps, symb_starts, N_id_2, pss_symb, pss_thresh, &f);
     if (rc == 0 && freq_offset) *freq_offset = f;
@@ -246,8 +271,7 @@ LIBLTE_ERROR_ENUM liblte_phy_find_sss(LIBLTE_PHY_STRUCT *phy_struct, float *i_sa
 {
     if (phy_struct == NULL || i_samps == NULL || q_samps == NULL || symb_starts == NULL || N_id_1 == NULL || frame_start_idx == NULL)
         return LIBLTE_ERROR_INVALID_INPUTS;
-    mi_lte_ctx *c = ctx_for(phy_struct);
-    if (!c) return LIBLTE_ERROR_INVALID_INPUTS;
+    MI_LOCKED_CTX(phy_struct, LIBLTE_ERROR_INVALID_INPUTS);
     int rc = mi_lte_find_sss_host(c, phy_struct->N_samps_per_symb, phy_struct->N_rb_dl, i_samps, q_samps, N_id_2, symb_starts, pss_thresh, N_id_1, frame_start_idx);
     return rc == 0 ? LIBLTE_SUCCESS : LIBLTE_ERROR_INVALID_INPUTS;
 }
@@ -264,8 +288,7 @@ LIBLTE_ERROR_ENUM liblte_phy_pucch_format_1_1a_1b_channel_decode(LIBLTE_PHY_STRU
     if (phy_struct == NULL || subframe == NULL || !(format == LIBLTE_PHY_PUCCH_FORMAT_1 || format == LIBLTE_PHY_PUCCH_FORMAT_1A || format == LIBLTE_PHY_PUCCH_FORMAT_1B) ||
         out_bits == NULL || N_out_bits == NULL || subframe->num > 9 || N_1_p_pucch >= LIBLTE_PHY_N_RB_UL_MAX / 2 || N_ant != 1)
         return LIBLTE_ERROR_INVALID_INPUTS;
-    mi_lte_ctx *c = ctx_for(phy_struct);
-    if (!c) return LIBLTE_ERROR_INVALID_INPUTS;
+    MI_LOCKED_CTX(phy_struct, LIBLTE_ERROR_INVALID_INPUTS);
     // the sequences liblte_phy_ul_init (still the reference's code) left in the struct for this (subframe, resource)
     static const uint32 symb[4] = {0, 1, 5, 6};
     const uint32 N = subframe->num, n = N_1_p_pucch;

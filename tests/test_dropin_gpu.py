@@ -83,6 +83,63 @@ def test_host_front_end_and_pdsch(ctx, port):
         assert (out[:n.value] == tx[0, a, :n.value]).all()
 
 
+def test_host_forms_keep_the_subframe_on_the_device(port):
+    """The per-call forms allocate nothing per call and reuse the device copy of a subframe this context produced: after
+    get_dl_subframe_and_ce the PDCCH-less decode calls of the same host arrays upload nothing; a subframe the context has not seen (or
+    one whose arrays changed) is uploaded once; plans are cached by allocation.  Results stay the oracle's throughout."""
+    import ctypes as C
+    import openlte_amd as m
+    from openlte_amd import synth
+    ctx = m.Context(0)  # a context of its own: the counters start at zero
+    L = ctx.L
+    f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+    u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+    L.mi_lte_get_dl_subframe_and_ce_host.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, f32p, f32p] + [C.c_uint32] * 4 + [f32p] * 4
+    L.mi_lte_pdsch_channel_decode_host.argtypes = [C.c_void_p, C.c_uint32, f32p, f32p, f32p, f32p, C.c_uint32, C.c_void_p,
+                                                   C.c_uint32, C.c_uint32, C.c_uint32, u8p, C.POINTER(C.c_uint32)]
+    L.mi_lte_host_cache_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+
+    def stats():
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        assert L.mi_lte_host_cache_stats(ctx.h, C.byref(a), C.byref(b), C.byref(c)) == 0
+        return a.value, b.value, c.value
+
+    cfg = m.DlCfg(2048, 100, 1, 0)
+    sfs, cells = [4, 7], [211, 38]
+    allocs = td.w4_allocs(0) + td.w4_allocs(1)
+    iq, tx = synth.dl_units(cfg, sfs, cells, allocs, 9, snr_db=28, seed=12)
+    subs = []
+    for u in range(2):
+        i_s = np.concatenate([np.zeros(sfs[u] * 30720, np.float32), iq[u, :, 0].astype(np.float32)])
+        q_s = np.concatenate([np.zeros(sfs[u] * 30720, np.float32), iq[u, :, 1].astype(np.float32)])
+        sr, si = np.zeros((16, 1200), np.float32), np.zeros((16, 1200), np.float32)
+        cr, ci = np.full((4, 16, 1200), 7.0, np.float32), np.full((4, 16, 1200), 7.0, np.float32)
+        assert 0 == L.mi_lte_get_dl_subframe_and_ce_host(ctx.h, 2048, 100, i_s, q_s, 0, sfs[u], cells[u], 1, sr, si, cr, ci)
+        assert (cr[0, 14:] == 7.0).all() and (cr[1:] == 7.0).all()  # estimate rows 14, 15 and the other ports: never written, as in the reference
+        subs.append((sr, si, cr, ci))
+
+    def decode(u, a):
+        out, n = np.zeros(6200, np.uint8), C.c_uint32()
+        sr, si, cr, ci = subs[u]
+        rc = L.mi_lte_pdsch_channel_decode_host(ctx.h, 100, sr, si, cr, ci, sfs[u], C.addressof(allocs[9 * u + a]), 2, cells[u], 1, out, C.byref(n))
+        assert rc == 0 and n.value == allocs[9 * u + a].tbs and (out[:n.value] == tx[u, a, :n.value]).all(), (u, a, rc)
+
+    assert stats()[:2] == (0, 0)
+    for a in range(9):  # the subframe produced last is still on the device
+        decode(1, a)
+    assert stats() == (9, 0, 9)  # nine reuses, no upload, nine plans
+    decode(0, 0)  # the other subframe: one upload ...
+    for a in range(1, 9):
+        decode(0, a)  # ... then reuse; the plans are the cached ones (same allocations)
+    assert stats() == (17, 1, 9)
+    subs[0][0][3, 100:110] += 1.0  # the caller edits a row the fingerprint may or may not sample: it says so
+    assert L.mi_lte_host_cache_invalidate(ctx.h) == 0
+    out, n = np.zeros(6200, np.uint8), C.c_uint32()
+    L.mi_lte_pdsch_channel_decode_host(ctx.h, 100, *subs[0], sfs[0], C.addressof(allocs[0]), 2, cells[0], 1, out, C.byref(n))
+    assert stats()[1] == 2
+    ctx.close()
+
+
 def _ul_demo_args(tmp_path):
     """One 20 MHz uplink subframe with three UEs, written as an int8 capture + the demo's command line."""
     case = td.ul_case("20MHz_3ue")
@@ -144,3 +201,10 @@ def test_cell_scan_matches_reference_output(tmp_path, n_rb, cell, frames, fs):
     got = subprocess.run([scan_gpu, cap, fs], capture_output=True, text=True, timeout=900)
     assert got.returncode == 0, got.stdout + got.stderr
     assert got.stdout == want
+    # wall-clock of the two builds' phases (stderr of the scanner), kept next to the test run for INTEGRATION.md
+    if os.path.exists(scan_cpu):
+        cpu = subprocess.run([scan_cpu, cap, fs], capture_output=True, text=True, timeout=900)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "scan_timing_%drb.txt" % n_rb), "w") as f:
+            f.write("scan_gpu %s" % got.stderr)
+            f.write("scan_cpu %s" % cpu.stderr)

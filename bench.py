@@ -362,26 +362,46 @@ class ChainWorkload:
                 la = td.to_lo_alloc(allocs_u[u * 9 + a])
                 rc = P.lo_pdsch_channel_decode(C.byref(lc), C.byref(sfr), C.byref(la), 2, int(cells_u[u]), 1, o, C.byref(nb), None, None)
                 same &= int(st[u * 9 + a]) == rc and (rc != 0 or bool((bits[u * 9 + a, :nb.value] == o[:nb.value]).all()))
-        # the same step with the samples coming from host memory and every verdict and bit going back (pageable buffers, one
-        # stream, no overlap): what a caller holding host buffers sees -- reported next to the device-resident rate, never as `value`
+        # the same work for a caller that holds HOST buffers: mi_lte_dl_pipeline -- pinned int8 units in, chunks of 4096 subframes
+        # overlapped on three lanes (H2D / kernels / D2H), packed transport blocks + verdicts out.  PCIe-inclusive: reported next to the
+        # device-resident rate, never as `value`
+        res = {"turbo_info_mbit_per_s": round(value * self.info_bits / 1e6, 2),
+               "crc_pass": "%d/%d allocations" % (ok, st.size), "sampled_blocks_equal_tx_bits": bool(exact),
+               "sampled_subframes_equal_cpu_restatement": bool(same)}
+        if DECODER != "ref":
+            return res
         import time
-        m = min(self.n, 4096)
-        h_iq = np.ascontiguousarray(self.uniq[0][self.idx[:m]].reshape(-1, 2))  # the batch repeats every 96 subframes: one chunk serves
+        m_ = self.m
+        n_h = min(self.n, 32768)
+        pipe = m_.DlPipeline(self.ctx.device, self.cfg, 2, td.w4_allocs(0), 4096, 3)
+        ul = self.uniq[0].shape[1]
+        h_iq, h_sf, h_cell = m_.HostBuffer((n_h, ul, 2), np.int8), m_.HostBuffer((n_h,), np.uint32), m_.HostBuffer((n_h,), np.uint32)
+        h_out, h_st = m_.HostBuffer((n_h * 9, pipe.out_stride), np.uint8), m_.HostBuffer((n_h * 9,), np.int32)
+        U = len(self.uniq[2])
+        for c0 in range(0, n_h, U):
+            k = min(U, n_h - c0)
+            h_iq.arr[c0:c0 + k] = self.uniq[0][:k]
+        h_sf.arr[:], h_cell.arr[:] = self.uniq[2][np.arange(n_h) % U], self.uniq[3][np.arange(n_h) % U]
+        pipe.run(h_iq.arr, h_sf.arr, h_cell.arr, n_h, h_out.arr, h_st.arr)  # warm-up: tables, scratch
         t0 = time.perf_counter()
-        for c in range(self.n // m):
-            self.d_iq.upload(h_iq, offset=c * h_iq.nbytes)
-        self.step()
-        st2 = self.d_status.download(np.int32)
-        bits2 = self.d_out.download(np.uint8)
-        dt = time.perf_counter() - t0
-        h2d, d2h = (self.n // m) * h_iq.nbytes, st2.nbytes + bits2.nbytes
-        return {"turbo_info_mbit_per_s": round(value * self.info_bits / 1e6, 2),
-                "crc_pass": "%d/%d allocations" % (ok, st.size), "sampled_blocks_equal_tx_bits": bool(exact),
-                "sampled_subframes_equal_cpu_restatement": bool(same),
-                "from_host_buffers": {"subframes_per_s": round((self.n // m) * m / dt, 1),
-                                      "note": "int8 IQ uploaded from pageable host memory (%.1f GB), one step, all verdicts and one-byte-per-bit "
-                                              "outputs downloaded (%.1f GB), serial on one stream; PCIe-inclusive, not the headline value"
-                                              % (h2d / 1e9, d2h / 1e9)}}
+        reps = 3
+        for _ in range(reps):
+            pipe.run(h_iq.arr, h_sf.arr, h_cell.arr, n_h, h_out.arr, h_st.arr)
+        dt = (time.perf_counter() - t0) / reps
+        host_ok = bool((h_st.arr == st[:n_h * 9]).all()) and all(
+            (np.unpackbits(h_out.arr[i * 9 + a, :(3240 if a < 8 else 1064) // 8]) == bits[i * 9 + a, :(3240 if a < 8 else 1064)]).all()
+            for i in range(0, n_h, max(1, n_h // 32)) for a in range(9))
+        h2d, d2h = n_h * ul * 2, h_out.arr.nbytes + h_st.arr.nbytes
+        pipe.close()
+        for b in (h_iq, h_sf, h_cell, h_out, h_st):
+            b.free()
+        res.update({
+                "from_host_buffers": {"subframes_per_s": round(n_h / dt, 1), "equal_to_device_resident_results": host_ok,
+                                      "h2d_GBps": round(h2d / dt / 1e9, 1), "d2h_GBps": round(d2h / dt / 1e9, 2),
+                                      "note": "mi_lte_dl_pipeline: %d subframes of int8 IQ from pinned host memory (%.1f GB) in chunks of 4096 on 3 lanes, "
+                                              "copies overlapped with the kernels, packed transport blocks + verdicts back (%.2f GB); PCIe-inclusive, "
+                                              "not the headline value" % (n_h, h2d / 1e9, d2h / 1e9)}})
+        return res
 
     def accounting(self):
         """SURVEY 8d per-stage bytes (charged once per step) and each kernel's own minimal I/O."""

@@ -160,6 +160,10 @@ void     mi_lte_pdsch_plan_destroy(mi_lte_ctx *ctx, mi_lte_pdsch_plan *plan);
  * dlsch_channel_decode does (filler removed, CRC24A, one bit per byte).  qpp_spec != 0: the exact 3GPP interleaver (what a
  * standard eNodeB transmits); 0: the reference transmitter's uint32-wrapped one (they differ for 20 block sizes). */
 int      mi_lte_pdsch_plan_set_decoder(mi_lte_pdsch_plan *plan, uint32_t mode /* mi_lte_turbo_mode */, uint32_t n_iter, int qpp_spec);
+/* Output form: packed = 0 (default) one bit per byte, the reference's out_bits (liblte_common.h:53); packed != 0 eight bits per byte, the
+ * first bit of the transport block in the most significant position of byte 0 (what liblte_bits_2_value would assemble, and SURVEY 8d's
+ * K/8-byte accounting): 8x less to bring back over PCIe.  Changes mi_lte_pdsch_plan_out_stride. */
+int      mi_lte_pdsch_plan_set_output(mi_lte_pdsch_plan *plan, uint32_t packed);
 uint32_t mi_lte_pdsch_plan_out_stride(const mi_lte_pdsch_plan *plan);
 int      mi_lte_pdsch_decode_run(mi_lte_ctx *ctx, mi_lte_pdsch_plan *plan, const float *d_subframes,
                                  const uint32_t *d_subfr_num, const uint32_t *d_n_id_cell, uint8_t *d_out_bits,
@@ -472,6 +476,28 @@ int mi_lte_detect_prach_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_u
 int mi_lte_rate_unmatch_turbo_host(mi_lte_ctx *ctx, const float *h_e_bits, uint32_t N_e_bits, uint32_t N_dummy_bits,
                                    uint32_t N_codeblocks, uint32_t tx_mode, uint32_t N_soft, uint32_t M_dl_harq,
                                    uint32_t chan_type, uint32_t rv_idx, float *h_d_bits, uint32_t *N_d_bits);
+
+/* ---------------------------------------------------------------- whole-chain batches from host buffers
+ * Captures live in host memory, so the batch form for callers that hold host buffers: n_units units of int8 I,Q (each
+ * mi_lte_dl_pipeline_unit_samples() pairs: one subframe + the two look-ahead symbols, as for mi_lte_dl_frontend_batch with d_unit_start[u] =
+ * u * that) go in, transport blocks come back packed eight bits per byte ([unit][allocation][mi_lte_dl_pipeline_out_stride()]) with one
+ * verdict per allocation.  Every unit carries the same n_alloc_per_unit allocations (h_unit_allocs; a semi-static grant pattern -- the
+ * `unit` field is ignored).  The batch is cut into chunks of chunk_units that flow H2D -> front end -> PDSCH chain -> D2H on n_lanes
+ * independent lanes (a context, a stream, a plan and device buffers each), so that one lane's copies run under another lane's kernels;
+ * nothing is allocated per run.  Host arrays should come from mi_lte_host_alloc (pinned): with pageable memory the copies are staged by the
+ * driver and do not overlap.  cfg->sample_format: MI_LTE_IQ_I8, optionally | MI_LTE_CE_COMPACT.  The link is the limit by design: 70 KB
+ * of samples per 20 MHz subframe. */
+typedef struct mi_lte_dl_pipeline mi_lte_dl_pipeline;
+void       *mi_lte_host_alloc(size_t bytes);
+void        mi_lte_host_free(void *p);
+int         mi_lte_dl_pipeline_create(int device, const mi_lte_dl_cfg *cfg, uint32_t N_pdcch_symbs, const mi_lte_pdsch_alloc *h_unit_allocs,
+                                      uint32_t n_alloc_per_unit, uint32_t chunk_units, uint32_t n_lanes, mi_lte_dl_pipeline **out);
+void        mi_lte_dl_pipeline_destroy(mi_lte_dl_pipeline *p);
+uint32_t    mi_lte_dl_pipeline_out_stride(const mi_lte_dl_pipeline *p);
+size_t      mi_lte_dl_pipeline_unit_samples(const mi_lte_dl_pipeline *p);
+const char *mi_lte_dl_pipeline_last_error(const mi_lte_dl_pipeline *p);
+int         mi_lte_dl_pipeline_run(mi_lte_dl_pipeline *p, const int8_t *h_iq, const uint32_t *h_subfr_num, const uint32_t *h_n_id_cell, uint32_t n_units,
+                                   uint8_t *h_out_packed, int32_t *h_status);
 
 /* ---------------------------------------------------------------- input synthesis (host side)
  * A minimal LTE downlink transmitter for benchmark / test captures, the role LTE_fdd_dl_file_gen

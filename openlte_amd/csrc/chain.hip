@@ -301,7 +301,7 @@ struct mi_lte_pdsch_plan {
     int           qpp_spec = 0;
     int8_t       *d_bcjr_soft = nullptr;                  // [max n_cb][3(K+4)] int8 channel values of the group being decoded
     uint8_t      *d_bcjr_bits = nullptr;                  // [max n_cb][K] its hard decisions
-    uint32_t      cfi = 0, n_alloc = 0, out_stride = 0, max_pairs = 0, max_words = 0;
+    uint32_t      cfi = 0, n_alloc = 0, out_stride = 0, max_pairs = 0, max_words = 0, max_tbs = 0, packed = 0;
     size_t        e_bytes = 0;
     mi_lte_pdsch_alloc *d_allocs = nullptr;
     uint32_t *d_e_off = nullptr, *d_e_len = nullptr, *d_cb_alloc = nullptr;
@@ -365,6 +365,7 @@ int mi_lte_pdsch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, uint32_t
     }
     pl->e_bytes    = off;
     pl->out_stride = (max_tbs + 63) & ~63u;
+    pl->max_tbs    = max_tbs;
     std::vector<uint32_t> cb_alloc;
     for (auto &kv : byK) {
         pl->groups.push_back({kv.first, (uint32_t)kv.second.size(), (uint32_t)cb_alloc.size(), emaxK[kv.first]});
@@ -418,6 +419,14 @@ int mi_lte_pdsch_plan_set_decoder(mi_lte_pdsch_plan *pl, uint32_t mode, uint32_t
     return MI_LTE_OK;
 }
 
+int mi_lte_pdsch_plan_set_output(mi_lte_pdsch_plan *pl, uint32_t packed)
+{
+    if (!pl) return MI_LTE_ERR_INVALID_ARG;
+    pl->packed     = packed ? 1u : 0u;
+    pl->out_stride = packed ? (((pl->max_tbs + 7) / 8 + 63) & ~63u) : ((pl->max_tbs + 63) & ~63u);
+    return MI_LTE_OK;
+}
+
 int mi_lte_pdsch_decode_run(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, const float *d_subframes, const uint32_t *d_subfr_num,
                             const uint32_t *d_n_id_cell, uint8_t *d_out_bits, int32_t *d_status)
 {
@@ -451,10 +460,10 @@ int mi_lte_pdsch_decode_run(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, const float 
     for (auto &gr : pl->groups) {
         if (pl->decoder == MI_LTE_TURBO_BCJR)
             rc = mi_turbo_bcjr_group(ctx, gr.K, gr.n_cb, pl->d_allocs, pl->d_cb_alloc + gr.cb_base, pl->d_e, pl->d_e_off, pl->d_e_len, d_out_bits,
-                                     pl->out_stride, d_status, false, pl->d_bcjr_soft, pl->d_bcjr_bits, pl->n_iter, pl->qpp_spec);
+                                     pl->out_stride, d_status, false, pl->d_bcjr_soft, pl->d_bcjr_bits, pl->n_iter, pl->qpp_spec, pl->packed != 0);
         else
             rc = mi_turbo_ref_group(ctx, gr.K, gr.n_cb, pl->d_allocs, pl->d_cb_alloc + gr.cb_base, pl->d_e, pl->d_e_off, pl->d_e_len,
-                                    d_out_bits, pl->out_stride, d_status, gr.e_max);
+                                    d_out_bits, pl->out_stride, d_status, gr.e_max, false, pl->packed != 0);
         if (rc != MI_LTE_OK) return rc;
     }
     ctx->last_kernels = pl->decoder == MI_LTE_TURBO_BCJR ? "k_pdsch_demod:1,k_rm_to_i8,k_bcjr_*,k_crc_finish per block size"

@@ -285,6 +285,7 @@ struct GroupDesc {                 // one launch = the code blocks of one size K
     int32_t        *status;        // [n_alloc] LIBLTE_ERROR_ENUM value
     const uint32_t *crc_tab;       // x^e mod gCRC24A for e = 0..6143
     uint32_t        ul;            // 1: UL-SCH soft-buffer rule (N_cb = K_w: chan_type ULSCH, liblte_phy.cc:11387-11398, :12437-12449)
+    uint32_t        packed;        // 1: out_bits holds eight bits per byte, first bit in the most significant position (liblte_value_2_bits order)
 };
 
 struct SrcRateUnmatch {
@@ -1124,7 +1125,24 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         if (threadIdx.x == 0) g.status[alloc] = (crc == 0) ? 0 /* LIBLTE_SUCCESS */ : 2 /* LIBLTE_ERROR_DECODE_FAIL */;
         // transport block = bits F .. F+tbs-1 of the code block, one bit per byte, 16 bytes per store where aligned
         uint8_t *o = g.out_bits + (size_t)alloc * g.out_stride;
-        if ((F & 3u) == 0) {
+        if (g.packed && ((F | tbs) & 7u) == 0) {
+            // eight bits per byte (SURVEY 8d's K/8-byte output): the bytes in LDS are 0 / 1, so four of them become a nibble by one
+            // multiplication (b0 b1 b2 b3 -> b0<<3 | b1<<2 | b2<<1 | b3 in the product's top byte); 32 bits per thread and store
+            const uint32_t nby = tbs >> 3, nw = nby >> 2;
+            auto byte_at = [&](uint32_t m) -> uint32_t { // output byte m = bits F + 8m .. F + 8m + 7
+                const uint2 w = *reinterpret_cast<const uint2 *>(bits + F + 8 * m);
+                return (((w.x * 0x08040201u) >> 24) & 0xFu) << 4 | (((w.y * 0x08040201u) >> 24) & 0xFu);
+            };
+            for (uint32_t m = threadIdx.x; m < nw; m += blockDim.x)
+                reinterpret_cast<uint32_t *>(o)[m] = byte_at(4 * m) | byte_at(4 * m + 1) << 8 | byte_at(4 * m + 2) << 16 | byte_at(4 * m + 3) << 24;
+            for (uint32_t m = 4 * nw + threadIdx.x; m < nby; m += blockDim.x) o[m] = (uint8_t)byte_at(m);
+        } else if (g.packed) { // a transport block size that is not a multiple of 8 (none of TS 36.213's is): bit by bit, last byte zero-padded
+            for (uint32_t m = threadIdx.x; m < (tbs + 7) >> 3; m += blockDim.x) {
+                uint32_t v = 0;
+                for (uint32_t b = 0; b < 8; b++) v = v << 1 | ((8 * m + b < tbs) ? ((uint32_t)bits[F + 8 * m + b] & 1u) : 0u);
+                o[m] = (uint8_t)v;
+            }
+        } else if ((F & 3u) == 0) {
             const uint32_t nq = tbs >> 2;
             const uint32_t *bw = reinterpret_cast<const uint32_t *>(bits + F);
             for (uint32_t m = threadIdx.x; m < nq; m += blockDim.x) reinterpret_cast<uint32_t *>(o)[m] = bw[m];
@@ -1232,8 +1250,14 @@ __global__ __launch_bounds__(256) void k_crc_finish(const uint8_t *__restrict__ 
     for (uint32_t j = F + threadIdx.x; j < K; j += blockDim.x) {
         const uint32_t b = c[j] & 1u;
         crc ^= b ? g.crc_tab[K - 1 - j] : 0u; // bit j weighs x^(K-1-j) mod gCRC24A; the check is "XOR of the weights == 0"
-        if (j < F + tbs) o[j - F] = (uint8_t)b;
+        if (j < F + tbs && !g.packed) o[j - F] = (uint8_t)b;
     }
+    if (g.packed)
+        for (uint32_t m = threadIdx.x; m < (tbs + 7) >> 3; m += blockDim.x) {
+            uint32_t v = 0;
+            for (uint32_t b = 0; b < 8; b++) v = v << 1 | ((8 * m + b < tbs) ? (c[F + 8 * m + b] & 1u) : 0u);
+            o[m] = (uint8_t)v;
+        }
     for (int sft = 32; sft > 0; sft >>= 1) crc ^= __shfl_xor(crc, sft);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = crc;
     __syncthreads();
@@ -1344,11 +1368,11 @@ static int rm_rank_tables(mi_lte_ctx *ctx, uint32_t K, RmTables *out)
 // demodulator's soft bits
 int mi_turbo_ref_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_pdsch_alloc *d_allocs,
                        const uint32_t *d_cb_alloc, const int8_t *d_e, const uint32_t *d_e_off, const uint32_t *d_e_len,
-                       uint8_t *d_out_bits, uint32_t out_stride, int32_t *d_status, uint32_t e_max_bytes, bool ul)
+                       uint8_t *d_out_bits, uint32_t out_stride, int32_t *d_status, uint32_t e_max_bytes, bool ul, bool packed)
 {
     int rc = mi_ctx_crc_table(ctx);
     if (rc != MI_LTE_OK) return rc;
-    GroupDesc gd{d_allocs, d_cb_alloc, d_e, d_e_off, d_e_len, d_out_bits, out_stride, d_status, ctx->d_crc_tab, ul ? 1u : 0u};
+    GroupDesc gd{d_allocs, d_cb_alloc, d_e, d_e_off, d_e_len, d_out_bits, out_stride, d_status, ctx->d_crc_tab, ul ? 1u : 0u, packed ? 1u : 0u};
     RmTables rt;
     rc = rm_rank_tables(ctx, K, &rt);
     if (rc != MI_LTE_OK) return rc;
@@ -1372,11 +1396,11 @@ int mi_turbo_ref_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_
 
 int mi_turbo_bcjr_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_pdsch_alloc *d_allocs, const uint32_t *d_cb_alloc, const int8_t *d_e,
                         const uint32_t *d_e_off, const uint32_t *d_e_len, uint8_t *d_out_bits, uint32_t out_stride, int32_t *d_status, bool ul,
-                        int8_t *d_soft, uint8_t *d_c_bits, uint32_t n_iter, int qpp_spec)
+                        int8_t *d_soft, uint8_t *d_c_bits, uint32_t n_iter, int qpp_spec, bool packed)
 {
     int rc = mi_ctx_crc_table(ctx);
     if (rc != MI_LTE_OK) return rc;
-    GroupDesc gd{d_allocs, d_cb_alloc, d_e, d_e_off, d_e_len, d_out_bits, out_stride, d_status, ctx->d_crc_tab, ul ? 1u : 0u};
+    GroupDesc gd{d_allocs, d_cb_alloc, d_e, d_e_off, d_e_len, d_out_bits, out_stride, d_status, ctx->d_crc_tab, ul ? 1u : 0u, packed ? 1u : 0u};
     RmTables  t;
     rc = rm_rank_tables(ctx, K, &t);
     if (rc != MI_LTE_OK) return rc;

@@ -119,6 +119,19 @@ def load_library():
     L.mi_lte_pdsch_plan_create.argtypes = [vp, C.POINTER(DlCfg), u32, vp, u32, C.POINTER(vp)]
     L.mi_lte_pdsch_plan_destroy.argtypes = [vp, vp]
     L.mi_lte_pdsch_plan_set_decoder.argtypes = [vp, u32, u32, C.c_int]
+    L.mi_lte_pdsch_plan_set_output.argtypes = [vp, u32]
+    L.mi_lte_host_alloc.argtypes = [sz]
+    L.mi_lte_host_alloc.restype = vp
+    L.mi_lte_host_free.argtypes = [vp]
+    L.mi_lte_dl_pipeline_create.argtypes = [C.c_int, C.POINTER(DlCfg), u32, vp, u32, u32, u32, C.POINTER(vp)]
+    L.mi_lte_dl_pipeline_destroy.argtypes = [vp]
+    L.mi_lte_dl_pipeline_out_stride.argtypes = [vp]
+    L.mi_lte_dl_pipeline_out_stride.restype = u32
+    L.mi_lte_dl_pipeline_unit_samples.argtypes = [vp]
+    L.mi_lte_dl_pipeline_unit_samples.restype = sz
+    L.mi_lte_dl_pipeline_last_error.argtypes = [vp]
+    L.mi_lte_dl_pipeline_last_error.restype = C.c_char_p
+    L.mi_lte_dl_pipeline_run.argtypes = [vp, vp, vp, vp, u32, vp, vp]
     L.mi_lte_pdsch_plan_out_stride.argtypes = [vp]
     L.mi_lte_pdsch_plan_out_stride.restype = u32
     L.mi_lte_pdsch_decode_run.argtypes = [vp, vp, vp, vp, vp, vp, vp]
@@ -212,6 +225,12 @@ class PdschPlan:
         """TURBO_REF (default, the reference's decoder) or TURBO_BCJR (max-log-MAP, n_iter iterations)."""
         self.ctx._check(self.ctx.L.mi_lte_pdsch_plan_set_decoder(self.h, mode, n_iter, qpp_spec))
 
+    def set_packed(self, packed=True):
+        """Eight bits per byte (first bit in the most significant position) instead of the reference's one bit per byte; changes out_stride."""
+        self.ctx._check(self.ctx.L.mi_lte_pdsch_plan_set_output(self.h, 1 if packed else 0))
+        self.packed = bool(packed)
+        self.out_stride = self.ctx.L.mi_lte_pdsch_plan_out_stride(self.h)
+
     def run_dev(self, d_subframes, d_sf, d_cell, d_out, d_status):
         self.ctx._check(self.ctx.L.mi_lte_pdsch_decode_run(self.ctx.h, self.h, d_subframes.ptr, d_sf.ptr, d_cell.ptr,
                                                            d_out.ptr, d_status.ptr))
@@ -226,6 +245,8 @@ class PdschPlan:
             self.run_dev(d_subframes, d_sf, d_cell, d_out, d_st)
             st = d_st.download(np.int32)
             bits = d_out.download(np.uint8).reshape(self.n_alloc, self.out_stride)
+            if getattr(self, "packed", False):  # back to one bit per byte for the caller
+                return st, [np.unpackbits(bits[a, :(self.tbs[a] + 7) // 8])[:self.tbs[a]] for a in range(self.n_alloc)]
             return st, [bits[a, :self.tbs[a]] for a in range(self.n_alloc)]
         finally:
             for b in (d_sf, d_cell, d_out, d_st):
@@ -244,6 +265,53 @@ class PdschPlan:
     def close(self):
         if self.h:
             self.ctx.L.mi_lte_pdsch_plan_destroy(self.ctx.h, self.h)
+            self.h = None
+
+
+class HostBuffer:
+    """Pinned host memory (mi_lte_host_alloc) viewed as a numpy array: what the host-batch pipeline wants its arrays in."""
+
+    def __init__(self, shape, dtype):
+        self.L = load_library()
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) * dt.itemsize
+        self.ptr = self.L.mi_lte_host_alloc(max(n, 1))
+        if not self.ptr:
+            raise MiLteError("mi_lte_host_alloc(%d) failed" % n)
+        self.arr = np.frombuffer((C.c_uint8 * max(n, 1)).from_address(self.ptr), dtype=dt, count=int(np.prod(shape))).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            self.arr = None
+            self.L.mi_lte_host_free(self.ptr)
+            self.ptr = None
+
+
+class DlPipeline:
+    """mi_lte_dl_pipeline: whole-chain batches from host buffers, chunks overlapped on several lanes."""
+
+    def __init__(self, device, cfg, n_pdcch_symbs, unit_allocs, chunk_units, n_lanes=3):
+        self.L = load_library()
+        arr = (PdschAlloc * len(unit_allocs))(*unit_allocs)
+        h = C.c_void_p()
+        rc = self.L.mi_lte_dl_pipeline_create(device, C.byref(cfg), n_pdcch_symbs, C.cast(arr, C.c_void_p), len(unit_allocs), chunk_units, n_lanes, C.byref(h))
+        if rc != 0:
+            raise MiLteError("mi_lte_dl_pipeline_create failed: %d" % rc)
+        self.h, self.n_alloc = h, len(unit_allocs)
+        self.out_stride = self.L.mi_lte_dl_pipeline_out_stride(h)
+        self.unit_samples = self.L.mi_lte_dl_pipeline_unit_samples(h)
+        self.tbs = [a.tbs for a in unit_allocs]
+
+    def run(self, h_iq, h_sf, h_cell, n_units, h_out, h_status):
+        """h_iq int8 [n_units, unit_samples, 2], h_sf / h_cell uint32 [n_units], h_out uint8 [n_units * n_alloc, out_stride], h_status int32:
+        numpy arrays, ideally views of HostBuffer (pinned)."""
+        rc = self.L.mi_lte_dl_pipeline_run(self.h, h_iq.ctypes.data, h_sf.ctypes.data, h_cell.ctypes.data, n_units, h_out.ctypes.data, h_status.ctypes.data)
+        if rc != 0:
+            raise MiLteError("mi_lte_dl_pipeline_run failed: %d (%s)" % (rc, self.L.mi_lte_dl_pipeline_last_error(self.h).decode()))
+
+    def close(self):
+        if self.h:
+            self.L.mi_lte_dl_pipeline_destroy(self.h)
             self.h = None
 
 

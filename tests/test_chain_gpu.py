@@ -430,3 +430,94 @@ def test_compact_estimate_form_is_single_port_only(ctx):
     import openlte_amd as m
     with pytest.raises(m.MiLteError):
         ctx.pdsch_plan(m.DlCfg(2048, 100, 2, m.IQ_I8 | m.CE_COMPACT), 2, td.small_allocs(0, 100, 3, 2024, 8))
+
+
+def test_packed_output_equals_the_unpacked_bits(ctx):
+    """mi_lte_pdsch_plan_set_output(packed): eight bits per byte, first bit most significant -- np.packbits of the one-bit-per-byte output,
+    for block sizes with and without filler bits, in both decoder modes."""
+    import openlte_amd as m
+    from openlte_amd import synth
+    cfg = m.DlCfg(2048, 100, 1, m.IQ_I8 | m.CE_COMPACT)
+    sfs, cells = [2, 8], [10, 499]
+    allocs = []
+    for u in range(2):
+        allocs += [m.make_alloc(u, 3, 3240, list(range(0, 12)), 0x300), m.make_alloc(u, 3, 3200, list(range(12, 24)), 0x301),
+                   m.make_alloc(u, 2, 1384, list(range(30, 38)), 0x302), m.make_alloc(u, 1, 680, list(range(40, 48)), 0x303),
+                   m.make_alloc(u, 3, 1064, list(range(96, 100)), 0x304)]
+    iq, tx = synth.dl_units(cfg, sfs, cells, allocs, 5, snr_db=28, max_delay=4, seed=3)
+    d_iq = ctx.to_device(iq.reshape(-1, 2))
+    d_start = ctx.to_device((np.arange(2) * iq.shape[1]).astype(np.uint64))
+    d_sf, d_cell = ctx.to_device(np.asarray(sfs, np.uint32)), ctx.to_device(np.asarray(cells, np.uint32))
+    d_sub = ctx.alloc(2 * ctx.subframe_floats(1) * 4)
+    ctx.dl_frontend_dev(cfg, d_iq, None, d_start, d_sf, d_cell, 2, d_sub)
+    for mode in (m.TURBO_REF, m.TURBO_BCJR):
+        plan = ctx.pdsch_plan(cfg, 2, allocs)
+        if mode == m.TURBO_BCJR:
+            plan.set_decoder(m.TURBO_BCJR, 6, 0)
+        st, bits = plan.run(d_sub, sfs, cells)
+        stride_bytes = plan.out_stride
+        plan.set_packed(True)
+        assert plan.out_stride == ((3240 // 8 + 63) // 64) * 64 and stride_bytes == ((3240 + 63) // 64) * 64
+        d_out, d_st = ctx.alloc(len(allocs) * plan.out_stride), ctx.alloc(4 * len(allocs))
+        d_out.zero()
+        plan.run_dev(d_sub, d_sf, d_cell, d_out, d_st)
+        st_p = d_st.download(np.int32)
+        raw = d_out.download(np.uint8).reshape(len(allocs), plan.out_stride)
+        assert (st_p == st).all()
+        for a, al in enumerate(allocs):
+            assert (raw[a, :al.tbs // 8] == np.packbits(bits[a])).all(), (mode, a)
+            if st[a] == 0:
+                assert (np.unpackbits(raw[a, :al.tbs // 8]) == tx[a // 5, a % 5, :al.tbs]).all()
+        assert (st == 0).sum() >= 8  # the F > 0 block (tbs 3200) fails its CRC, as in the reference
+        plan.close()
+        d_out.free(); d_st.free()
+    for b in (d_iq, d_start, d_sf, d_cell, d_sub):
+        b.free()
+
+
+@pytest.mark.parametrize("n_units,chunk,lanes", [(40, 16, 3), (64, 32, 2), (7, 8, 1)])
+def test_host_batch_pipeline_equals_the_device_resident_chain(ctx, n_units, chunk, lanes):
+    """mi_lte_dl_pipeline: int8 units from pinned host memory, chunks overlapped on several lanes, packed transport blocks and
+    verdicts back in host memory -- identical to what the device-resident batch path produces for the same units, including a ragged
+    last chunk."""
+    import openlte_amd as m
+    from openlte_amd import synth
+    cfg = m.DlCfg(2048, 100, 1, m.IQ_I8 | m.CE_COMPACT)
+    U = 8
+    sfs_u = np.array([1, 2, 3, 4, 6, 7, 8, 9], np.uint32)
+    cells_u = ((np.arange(U) * 61 + 5) % 504).astype(np.uint32)
+    allocs_u = []
+    for u in range(U):
+        allocs_u += td.w4_allocs(u)
+    iq_u, tx = synth.dl_units(cfg, sfs_u, cells_u, allocs_u, 9, snr_db=30, max_delay=6, seed=n_units)
+    idx = (np.arange(n_units) * 3) % U
+    pipe = m.DlPipeline(0, cfg, 2, td.w4_allocs(0), chunk, lanes)
+    assert pipe.unit_samples == iq_u.shape[1]
+    h_iq, h_sf, h_cell = m.HostBuffer((n_units, iq_u.shape[1], 2), np.int8), m.HostBuffer((n_units,), np.uint32), m.HostBuffer((n_units,), np.uint32)
+    h_out, h_st = m.HostBuffer((n_units * 9, pipe.out_stride), np.uint8), m.HostBuffer((n_units * 9,), np.int32)
+    h_iq.arr[:], h_sf.arr[:], h_cell.arr[:] = iq_u[idx], sfs_u[idx], cells_u[idx]
+    h_out.arr[:], h_st.arr[:] = 0xEE, -7
+    for _ in range(2):  # a second run over the same lanes: nothing is left over from the first
+        pipe.run(h_iq.arr, h_sf.arr, h_cell.arr, n_units, h_out.arr, h_st.arr)
+    # the device-resident path on the same units
+    d_iq = ctx.to_device(iq_u[idx].reshape(-1, 2))
+    d_start = ctx.to_device((np.arange(n_units) * iq_u.shape[1]).astype(np.uint64))
+    d_sf, d_cell = ctx.to_device(sfs_u[idx]), ctx.to_device(cells_u[idx])
+    d_sub = ctx.alloc(n_units * ctx.subframe_floats(1) * 4)
+    ctx.dl_frontend_dev(cfg, d_iq, None, d_start, d_sf, d_cell, n_units, d_sub)
+    all_allocs = []
+    for i in range(n_units):
+        all_allocs += td.w4_allocs(i)
+    plan = ctx.pdsch_plan(cfg, 2, all_allocs)
+    st, bits = plan.run(d_sub, sfs_u[idx], cells_u[idx])
+    assert (h_st.arr == st).all() and (st == 0).all()
+    for k in range(n_units * 9):
+        t = all_allocs[k].tbs
+        assert (np.unpackbits(h_out.arr[k, :t // 8]) == bits[k]).all(), k
+        assert (bits[k] == tx[idx[k // 9], k % 9, :t]).all()
+    plan.close()
+    pipe.close()
+    for b in (d_iq, d_start, d_sf, d_cell, d_sub):
+        b.free()
+    for b in (h_iq, h_sf, h_cell, h_out, h_st):
+        b.free()

@@ -147,10 +147,9 @@ def turbo_own_io(K, n_cb, in_bytes, out_bytes, bcjr_iters=0):
     out_bytes: what the last kernel writes per block."""
     k = _kp(K)
     if bcjr_iters:
-        h = 2 * bcjr_iters  # half-iterations
-        return {"k_bcjr_prep": n_cb * (in_bytes + 6 * k), "k_bcjr_fwd": n_cb * h * 6 * k, "k_bcjr_bwd": n_cb * (h * 8 * k + 2 * k),
-                "k_bcjr_perm": n_cb * ((h - 1) * 4 * k + 3 * k + out_bytes), "k_rm_to_i8": n_cb * (in_bytes + 3 * (K + 4)),
-                "k_crc_finish": n_cb * (K + out_bytes)}
+        h = 2 * bcjr_iters  # half-iterations: systematic, parity, a-priori in, extrinsic out, one byte of boundary state per step
+        return {"k_bcjr_prep": n_cb * (in_bytes + 4 * k), "k_bcjr_half": n_cb * h * 5 * K, "k_bcjr_final": n_cb * 2 * K,
+                "k_rm_to_i8": n_cb * (in_bytes + 3 * (K + 4)), "k_crc_finish": n_cb * (K + out_bytes)}
     return {"k_turbo_prep": n_cb * (in_bytes + 6 * k),          # X0 X1 X2 I0 M1 M2
             "k_turbo_siso": n_cb * 3 * 5 * k,                   # per pass: two inputs, magnitudes, output, traceback bits out and back in
             "k_turbo_perm": n_cb * 4 * k,                       # A1 X2 in, I1 M3 out
@@ -175,7 +174,7 @@ class TurboWorkload:
 
     @property
     def dominant(self):
-        return "k_bcjr_bwd" if DECODER == "bcjr" else "k_turbo_siso"
+        return "k_bcjr_half" if DECODER == "bcjr" else "k_turbo_siso"
 
     def __init__(self, ctx, n_units, rank):
         import numpy as np
@@ -201,7 +200,7 @@ class TurboWorkload:
         return self.n_cb
 
     def accounting(self):
-        ks = ["k_bcjr_prep", "k_bcjr_fwd", "k_bcjr_bwd", "k_bcjr_perm"] if DECODER == "bcjr" else ["k_turbo_prep", "k_turbo_siso", "k_turbo_perm", "k_turbo_vote"]
+        ks = ["k_bcjr_prep", "k_bcjr_half", "k_bcjr_final"] if DECODER == "bcjr" else ["k_turbo_prep", "k_turbo_siso", "k_turbo_perm", "k_turbo_vote"]
         return {"stages": {"turbo": (self.alg_bytes_per_unit * self.n_cb, ks)},
                 "own_io": turbo_own_io(self.K, self.n_cb, 3 * (self.K + 4), self.K, 8 if DECODER == "bcjr" else 0)}
 
@@ -414,7 +413,7 @@ class ChainWorkload:
         for K, cnt, E, tbs in ((3264, 8, 9936, 3240), (1088, 1, 3312, 1064)):
             for k, v in turbo_own_io(K, n * cnt, E, tbs, bc).items():
                 own[k] = own.get(k, 0) + v
-        tk = ["k_rm_to_i8", "k_bcjr_prep", "k_bcjr_fwd", "k_bcjr_bwd", "k_bcjr_perm", "k_crc_finish"] if bc else \
+        tk = ["k_rm_to_i8", "k_bcjr_prep", "k_bcjr_half", "k_bcjr_final", "k_crc_finish"] if bc else \
              ["k_turbo_prep", "k_turbo_siso", "k_turbo_perm", "k_turbo_vote"]
         return {"stages": {"frontend": (n * 339040, ["k_dl_fft", "k_dl_ce"]),
                            "demod": (n * res * (16 + 6), ["k_pdsch_demod"]),

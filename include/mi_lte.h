@@ -421,10 +421,10 @@ int    mi_lte_find_sss_run(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const void
  * here.  Return value: MI_LTE_* on infrastructure errors (< 0), else the LIBLTE_ERROR_ENUM value the
  * reference would return (0 success, 1 invalid inputs, 2 decode fail). */
 /* Nothing in these forms allocates per call: a context keeps pinned staging, device buffers and ONE device subframe tagged with the host
- * arrays it mirrors (rx_symb_re's address + a fingerprint of the contents), plus plans cached by everything they were built from.  The
- * decoders called on a subframe this context produced with mi_lte_get_dl_subframe_and_ce_host / _get_ul_subframe_host read the copy
- * that is already in HBM; any other subframe is uploaded once.  A caller that edits a subframe's arrays in place between calls
- * (the reference's callers do not) calls mi_lte_host_cache_invalidate first.  One call at a time per context, like the reference's
+ * arrays it mirrors (rx_symb_re's address + a 64-bit hash of the whole contents, rows 0-13 of every plane), plus plans cached by
+ * everything they were built from.  The decoders called on a subframe this context produced with mi_lte_get_dl_subframe_and_ce_host /
+ * _get_ul_subframe_host -- or uploaded for an earlier call -- read the copy that is already in HBM; a subframe whose arrays changed in
+ * any element hashes differently and is uploaded again (mi_lte_host_cache_invalidate forces that).  One call at a time per context, like the reference's
  * "one call at a time per LIBLTE_PHY_STRUCT" (SURVEY 8b). */
 int mi_lte_host_cache_stats(mi_lte_ctx *ctx, uint64_t *n_subframe_reuse, uint64_t *n_subframe_upload, uint32_t *n_plans);
 int mi_lte_host_cache_invalidate(mi_lte_ctx *ctx);

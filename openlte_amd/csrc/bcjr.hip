@@ -3,15 +3,22 @@
 // this mode is specified by a plain-C fixed-point model in the test tree (lo_turbo_decode_bcjr): every operation
 // in the same order, and the kernels below must match it bit for bit.
 //
-// Mapping: the same lock-step tiles as the REF decoder (lane = code block, 64 trellises per wavefront, all
-// per-step arrays "line per block" in HBM) -- the 8 alpha / beta metrics of a block live in its lane's VGPRs,
-// max* is a plain v_max, nothing crosses lanes.  A forward pass stores the normalised alpha vector every 8
-// steps (16 B per block per 8 steps); the backward pass re-runs alpha inside each 8-step window from that
-// checkpoint (56 values in registers) while beta walks down, so no per-step state ever goes to memory.
-// The extrinsic permutation between the two constituent decoders is a per-code-block LDS gather.
-// Occupancy: a 64k-block batch is only 1024 tiles, one wave per SIMD; blocks of >= 1024 steps are therefore cut
-// into 4 (2) segments decoded by separate waves, whose boundary alpha / beta come from the neighbouring segment's
-// previous iteration ("next iteration initialisation", double-buffered) -- part of the mode's specification.
+// Mapping: lock-step tiles like the REF decoder, TWO code blocks per lane: lane l of a wavefront walks the trellises of
+// code block l of tile 2p and of tile 2p+1 in the two halves of its registers (v_pk_add_i16 / v_pk_max_i16; the model's number
+// ranges keep every intermediate inside int16, so nothing saturates).  The 8 alpha / beta metrics of a trellis live in 8 VGPRs,
+// max* is a plain packed max, nothing crosses lanes.
+//
+// One launch per half-iteration (k_bcjr_half): a wavefront takes a segment of its tile pair and works through it in blocks of 32
+// steps -- forward (alpha, normalised and kept every 8 steps), then backward over the same 32 steps (alpha re-run inside each 8-step
+// window from its checkpoint, LLR, extrinsic, beta), beta starting from what the following block reached in the previous iteration
+// ("next iteration initialisation", part of the specification).  Nothing per trellis step is stored: per step and code block the
+// kernel reads 3 bytes (systematic, parity, a-priori) and writes 1 (extrinsic), plus 2 bytes of boundary state -- against 18 bytes
+// for the forward / backward / permute kernels this replaces.
+//
+// The exchange between the two constituent decoders needs no kernel of its own: extrinsics are stored one ROW per trellis step
+// (128 bytes: the 64 lanes of both tiles of a pair), so "A[t] = E[pi[t]]" is a row index taken from a table that is the same for
+// every lane -- a scalar load and a fully coalesced 128-byte access per step.  Row Kp of every pair is zero: holes of the
+// de-interleaver and the padding past K point there.
 //
 // Trellis (36.212 5.1.3.2.1, feedback 1+D^2+D^3, parity 1+D+D^3; state = 4 r1 + 2 r2 + r3): the predecessors of
 // state n are 2(n&3) and 2(n&3)+1 with complementary (u,z) labels -- see the table next to lo_turbo_decode_bcjr.  Branch
@@ -20,15 +27,12 @@
 
 namespace {
 
-constexpr int BCJR_NEG = -32000, BCJR_LE_MAX = 1023;
+constexpr int BCJR_NEG = -6000, BCJR_X_MAX = 340, BCJR_LE_MAX = 254;
 
 __host__ __device__ inline uint32_t kpad64(uint32_t K) { return (K + 63u) & ~63u; }
 __device__ __forceinline__ int sb(uint32_t w, int k) { return (int)__builtin_amdgcn_sbfe(w, 8 * k, 8); }
-__device__ __forceinline__ int sh(uint32_t w, int k) { return (int)__builtin_amdgcn_sbfe(w, 16 * k, 16); }
-__device__ __forceinline__ uint32_t pk16(int lo, int hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); }
 
-__device__ __forceinline__ size_t g8(uint32_t tile, uint32_t Kp, uint32_t lane, uint32_t gran) { return (size_t)tile * Kp * 64 + (size_t)gran * 1024 + lane * 16; }   // byte offset, int8 arrays
-__device__ __forceinline__ size_t g16(uint32_t tile, uint32_t Kp, uint32_t lane, uint32_t gran) { return (size_t)tile * Kp * 128 + (size_t)gran * 1024 + lane * 16; } // byte offset, int16 arrays
+__device__ __forceinline__ size_t g8(uint32_t tile, uint32_t Kp, uint32_t lane, uint32_t gran) { return (size_t)tile * Kp * 64 + (size_t)gran * 1024 + lane * 16; }   // byte offset, int8 granule arrays
 // XCD-aware block -> code block mapping of the per-code-block kernels (see turbo.hip)
 __host__ __device__ inline uint32_t xcd_chunk(uint32_t n_cb) { return ((((n_cb + 63u) >> 6) + 7u) >> 3) << 6; }
 __device__ __forceinline__ uint32_t xcd_cb(uint32_t b, uint32_t n_cb) { return (b & 7u) * xcd_chunk(n_cb) + (b >> 3); }
@@ -36,49 +40,68 @@ __device__ __forceinline__ uint32_t xcd_cb(uint32_t b, uint32_t n_cb) { return (
 __host__ __device__ inline uint32_t bcjr_n_seg(uint32_t K)
 {
     const uint32_t nblk = (K + 63) / 64;
-    for (uint32_t n = 4; n > 1; n >>= 1)
+    for (uint32_t n = 8; n > 1; n >>= 1)
         if (nblk % n == 0 && (nblk / n) * 64 >= 512) return n;
     return 1;
 }
-struct BcjrBnd { int16_t *a_rd, *a_wr, *b_rd, *b_wr; uint32_t n_tiles; }; // [segment][tile][lane][8] each
 
-__device__ __forceinline__ void norm8(int (&v)[8]) // subtract the maximum, floor at BCJR_NEG
+// pairs of int16 in one register: low half = the code block of tile 2p, high half = tile 2p+1
+typedef short v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2s      as_v2s(uint32_t w) { return __builtin_bit_cast(v2s, w); }
+__device__ __forceinline__ uint32_t as_u32(v2s v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ v2s      vmax(v2s a, v2s b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ v2s      vmin(v2s a, v2s b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ v2s      splat(int v) { return (v2s)((short)v); }
+// byte R of the two words, sign-extended, as the pair (lo: w0, hi: w1)
+template <int R> __device__ __forceinline__ v2s byte_pair(uint32_t w0, uint32_t w1)
 {
-    const int m = max(max(max(v[0], v[1]), max(v[2], v[3])), max(max(v[4], v[5]), max(v[6], v[7])));
+    return as_v2s(__builtin_amdgcn_perm(w1, w0, (uint32_t)(4 + R) << 24 | 0x0C0000u | (uint32_t)R << 8 | 0x0Cu)) >> 8;
+}
+__device__ __forceinline__ v2s byte_pair_rt(uint32_t w0, uint32_t w1, int r) // r = 0..3, resolved at compile time after unrolling
+{
+    return r == 0 ? byte_pair<0>(w0, w1) : r == 1 ? byte_pair<1>(w0, w1) : r == 2 ? byte_pair<2>(w0, w1) : byte_pair<3>(w0, w1);
+}
+__device__ __forceinline__ uint32_t word_of(const uint4 &q, int k) { return k == 0 ? q.x : k == 1 ? q.y : k == 2 ? q.z : q.w; }
+
+__device__ __forceinline__ void norm8(v2s (&v)[8]) // subtract the maximum, floor at BCJR_NEG (per half)
+{
+    const v2s m = vmax(vmax(vmax(v[0], v[1]), vmax(v[2], v[3])), vmax(vmax(v[4], v[5]), vmax(v[6], v[7])));
 #pragma unroll
-    for (int s = 0; s < 8; s++) v[s] = max(v[s] - m, BCJR_NEG);
+    for (int s = 0; s < 8; s++) v[s] = vmax(v[s] - m, splat(BCJR_NEG));
 }
-__device__ __forceinline__ void alpha_step(const int (&a)[8], int g00, int g01, int g10, int (&o)[8])
+__device__ __forceinline__ void alpha_step(const v2s (&a)[8], v2s g00, v2s g01, v2s g10, v2s (&o)[8])
 {
-    o[0] = max(a[0] + g00, a[1]);       o[4] = max(a[0], a[1] + g00);
-    o[1] = max(a[2] + g10, a[3] + g01); o[5] = max(a[2] + g01, a[3] + g10);
-    o[2] = max(a[4] + g01, a[5] + g10); o[6] = max(a[4] + g10, a[5] + g01);
-    o[3] = max(a[6], a[7] + g00);       o[7] = max(a[6] + g00, a[7]);
+    o[0] = vmax(a[0] + g00, a[1]);       o[4] = vmax(a[0], a[1] + g00);
+    o[1] = vmax(a[2] + g10, a[3] + g01); o[5] = vmax(a[2] + g01, a[3] + g10);
+    o[2] = vmax(a[4] + g01, a[5] + g10); o[6] = vmax(a[4] + g10, a[5] + g01);
+    o[3] = vmax(a[6], a[7] + g00);       o[7] = vmax(a[6] + g00, a[7]);
 }
-__device__ __forceinline__ void beta_step(int (&b)[8], int g00, int g01, int g10)
+__device__ __forceinline__ void beta_step(v2s (&b)[8], v2s g00, v2s g01, v2s g10)
 {
-    int o[8];
-    o[0] = max(b[0] + g00, b[4]);       o[1] = max(b[0], b[4] + g00);
-    o[2] = max(b[1] + g10, b[5] + g01); o[3] = max(b[1] + g01, b[5] + g10);
-    o[4] = max(b[2] + g01, b[6] + g10); o[5] = max(b[2] + g10, b[6] + g01);
-    o[6] = max(b[3], b[7] + g00);       o[7] = max(b[3] + g00, b[7]);
+    v2s o[8];
+    o[0] = vmax(b[0] + g00, b[4]);       o[1] = vmax(b[0], b[4] + g00);
+    o[2] = vmax(b[1] + g10, b[5] + g01); o[3] = vmax(b[1] + g01, b[5] + g10);
+    o[4] = vmax(b[2] + g01, b[6] + g10); o[5] = vmax(b[2] + g10, b[6] + g01);
+    o[6] = vmax(b[3], b[7] + g00);       o[7] = vmax(b[3] + g00, b[7]);
 #pragma unroll
     for (int s = 0; s < 8; s++) b[s] = o[s];
 }
 
-// ---- layouts of one tile (64 code blocks), "16-byte granules": the lock-step kernels consume 16 B per lane at a time,
-//      so granule g of lane l sits at g*1024 + l*16 -- every wave-wide access is one contiguous KiB.
-//      int8 arrays: granule = 16 steps (step t in granule t/16, byte t%16); int16 arrays: granule = 8 steps;
-//      checkpoints: [window][lane][8 x int16] (the same shape); tails: [lane][16 B]
+// ---- layouts
+//   S1 P1 S2 P2   int8, per tile, "16-byte granules": granule g (16 steps) of lane l at g*1024 + l*16 -- a wave-wide access is one KiB
+//   E1 E2 HD      int8, per tile PAIR, one 128-byte row per step: byte (t, lane, h) at (pair*(Kp+1) + t)*128 + lane*2 + h, h = tile & 1;
+//                 E1 = extrinsic halves of decoder 1 in natural order, E2 = those of decoder 2 in ITS (interleaved) order, HD = hard
+//                 decisions of the last half-iteration in decoder 2's order; row Kp is zero
+//   tail          per block: t1s[3] t1p[3] t2s[3] t2p[3] pad[4]
+//   boundaries    alpha: [seg][pair][lane][8 x v2s]; beta: [blk32][pair][lane][8 x v2s]; two buffers each (read: previous iteration)
 struct BcjrBufs {
-    int8_t  *S1, *P1, *S2, *P2; // systematic / parity of the two constituent decoders (S2 = interleaved S1)
-    int16_t *A, *E, *post;      // a-priori in, extrinsic out, a-posteriori of the last half-iteration
-    int16_t *chk;
-    int8_t  *tail;              // per block: t1s[3] t1p[3] t2s[3] t2p[3] pad[4]
+    int8_t *S1, *P1, *S2, *P2;
+    int8_t *tail;
 };
+__device__ __forceinline__ size_t ex_row(uint32_t pair, uint32_t Kp, uint32_t t) { return ((size_t)pair * (Kp + 1) + t) * 128; }
 
 // ------------------------------------------------------------------------------------------------
-// prep: split the interleaved d[i*3+x] input into tile lines, interleave the systematic stream, clear the a-priori
+// prep: split the interleaved d[i*3+x] input into tile granules, interleave the systematic stream
 __global__ __launch_bounds__(384) void k_bcjr_prep(const int8_t *__restrict__ soft, uint32_t K, uint32_t n_cb,
                                                    const uint16_t *__restrict__ pi, BcjrBufs B)
 {
@@ -109,11 +132,6 @@ __global__ __launch_bounds__(384) void k_bcjr_prep(const int8_t *__restrict__ so
         *reinterpret_cast<uint4 *>(B.P2 + o8) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
         *reinterpret_cast<uint4 *>(sm + 16 * u) = make_uint4(s1[0], s1[1], s1[2], s1[3]);
     }
-    if (nv >= 0) { // a-priori = 0 (two uint4 of int16 per unit)
-        char *ab = reinterpret_cast<char *>(B.A);
-        *reinterpret_cast<uint4 *>(ab + g16(tile, Kp, lane, 2 * u))     = make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4 *>(ab + g16(tile, Kp, lane, 2 * u + 1)) = make_uint4(0, 0, 0, 0);
-    }
     if (u == 0) { // termination bits: x[3r + stream] = d_stream[K + r]  (36.212 5.1.3.2.2)
         const int8_t *x = d + 3 * (size_t)K;
         int8_t       *t = B.tail + ((size_t)cb << 4);
@@ -140,199 +158,188 @@ __global__ __launch_bounds__(384) void k_bcjr_prep(const int8_t *__restrict__ so
 }
 
 // ------------------------------------------------------------------------------------------------
-// forward pass of one constituent decoder: alpha, normalised and checkpointed every 8 steps
-__global__ __launch_bounds__(64) void k_bcjr_fwd(const int8_t *__restrict__ S, const int8_t *__restrict__ P,
-                                                 const int16_t *__restrict__ A, int16_t *__restrict__ chk, uint32_t K, BcjrBnd bnd)
+// one half-iteration of one constituent decoder over a segment of a tile pair
+struct HalfArgs {
+    const int8_t   *S, *P;      // this decoder's systematic / parity granules
+    const int8_t   *A;          // a-priori halves: the other decoder's extrinsic rows ...
+    const uint32_t *row;        // ... through this table: A[t] = row A_rows[row[t]] (pi towards decoder 2, the inverse map back; Kp = the zero row)
+    int8_t         *E;          // extrinsic halves out, row t
+    uint8_t        *HD;         // LAST: hard decisions out, row t
+    const int8_t   *tail;
+    uint32_t        tail_off;   // 0 / 6: the decoder's three termination pairs inside a block's tail record
+    const uint4    *a_rd, *b_rd;
+    uint4          *a_wr, *b_wr;
+    uint32_t        K, n_cb, n_tiles, n_pairs;
+};
+
+#ifndef BCJR_WPE
+#define BCJR_WPE 4
+#endif
+template <bool LAST>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BCJR_WPE, 8))) void k_bcjr_half(HalfArgs g)
 {
-    const uint32_t tile = blockIdx.x, seg = blockIdx.y, n_seg = gridDim.y, lane = threadIdx.x, Kp = kpad64(K), nblk = Kp >> 6, n_win = Kp >> 3;
-    const uint32_t seg_blk = nblk / n_seg;
-    const char *ps = reinterpret_cast<const char *>(S), *pp = reinterpret_cast<const char *>(P), *pa = reinterpret_cast<const char *>(A);
-    uint4      *pc = reinterpret_cast<uint4 *>(chk + ((size_t)tile * n_win * 64 + lane) * 8);
-    (void)nblk;
-    int a[8] = {0, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG};
+    // alpha checkpoints of the current 32-step block: [window][first | second four states][lane].  The windows are walked by real
+    // loops (a fully unrolled block is 67 KB of code, more than the instruction cache holds), so what is indexed by the window number
+    // lives here rather than in registers
+    __shared__ uint4 chk[4][2][64];
+    const uint32_t pair = blockIdx.x, seg = blockIdx.y, n_seg = gridDim.y, lane = threadIdx.x, K = g.K, Kp = kpad64(K);
+    const uint32_t seg_len = ((Kp >> 6) / n_seg) * 64, t_lo = seg * seg_len, t_hi = min(t_lo + seg_len, K), n_blk = (K + 31) >> 5;
+    const uint32_t tile0 = 2 * pair, tile1 = min(2 * pair + 1, g.n_tiles - 1); // an odd tile count: the last tile twice (its results land in the spare half)
+    const char *s0 = reinterpret_cast<const char *>(g.S) + g8(tile0, Kp, lane, 0), *s1 = reinterpret_cast<const char *>(g.S) + g8(tile1, Kp, lane, 0);
+    const char *p0 = reinterpret_cast<const char *>(g.P) + g8(tile0, Kp, lane, 0), *p1 = reinterpret_cast<const char *>(g.P) + g8(tile1, Kp, lane, 0);
+    const char *arow = reinterpret_cast<const char *>(g.A) + ex_row(pair, Kp, 0) + lane * 2;
+    char       *erow = reinterpret_cast<char *>(g.E) + ex_row(pair, Kp, 0) + lane * 2;
+    char       *hrow = LAST ? reinterpret_cast<char *>(g.HD) + ex_row(pair, Kp, 0) + lane * 2 : nullptr;
+    const size_t bnd_lane = ((size_t)pair * 64 + lane) * 2, bnd_stride = (size_t)g.n_pairs * 64 * 2; // in uint4 units: 8 x v2s = two uint4
+
+    // the eight steps of the window that starts at t0 (a multiple of 8): Ls + La and Lp of both trellises
+    auto load_window = [&](uint32_t t0, v2s (&lsa)[8], v2s (&lp)[8]) {
+        const size_t go = (size_t)(t0 >> 4) * 1024 + (t0 & 8u);
+        const uint2  S0 = *reinterpret_cast<const uint2 *>(s0 + go), S1 = *reinterpret_cast<const uint2 *>(s1 + go);
+        const uint2  P0 = *reinterpret_cast<const uint2 *>(p0 + go), P1 = *reinterpret_cast<const uint2 *>(p1 + go);
+        const uint4  r0 = *reinterpret_cast<const uint4 *>(g.row + t0), r1 = *reinterpret_cast<const uint4 *>(g.row + t0 + 4); // uniform: scalar loads
+        const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        uint32_t aq[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) aq[r] = *reinterpret_cast<const uint16_t *>(arow + (size_t)rw[r] * 128); // (q of tile 2p) | (q of tile 2p+1) << 8
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const v2s la = as_v2s(__builtin_amdgcn_perm(0u, aq[r], 0x010C000Cu)) >> 7; // 2q per half: the byte in the half's upper byte, arithmetic shift by 7
+            lsa[r] = byte_pair_rt(r < 4 ? S0.x : S0.y, r < 4 ? S1.x : S1.y, r & 3) + la;
+            lp[r]  = byte_pair_rt(r < 4 ? P0.x : P0.y, r < 4 ? P1.x : P1.y, r & 3);
+        }
+    };
+
+    v2s a[8];
+    a[0] = splat(0);
+#pragma unroll
+    for (int s = 1; s < 8; s++) a[s] = splat(BCJR_NEG);
     if (seg > 0) { // alpha the previous segment reached in the previous iteration
-        const uint4 c4 = *reinterpret_cast<const uint4 *>(bnd.a_rd + (((size_t)seg * bnd.n_tiles + tile) * 64 + lane) * 8);
-        a[0] = sh(c4.x, 0); a[1] = sh(c4.x, 1); a[2] = sh(c4.y, 0); a[3] = sh(c4.y, 1);
-        a[4] = sh(c4.z, 0); a[5] = sh(c4.z, 1); a[6] = sh(c4.w, 0); a[7] = sh(c4.w, 1);
+        const uint4 c0 = g.a_rd[seg * bnd_stride + bnd_lane], c1 = g.a_rd[seg * bnd_stride + bnd_lane + 1];
+        a[0] = as_v2s(c0.x); a[1] = as_v2s(c0.y); a[2] = as_v2s(c0.z); a[3] = as_v2s(c0.w);
+        a[4] = as_v2s(c1.x); a[5] = as_v2s(c1.y); a[6] = as_v2s(c1.z); a[7] = as_v2s(c1.w);
     }
-    for (uint32_t blk = seg * seg_blk; blk < (seg + 1) * seg_blk; blk++) {
+    for (uint32_t b0 = t_lo; b0 < t_hi; b0 += 32) {
+        const uint32_t blk = b0 >> 5, n_w = min(32u, t_hi - b0) >> 3; // 1..4 windows of 8 steps (uniform)
+        // ---- forward: alpha, normalised and kept every 8 steps
+#pragma unroll 1
+        for (uint32_t w = 0; w < n_w; w++) {
+            v2s lsa[8], lp[8];
+            load_window(b0 + 8 * w, lsa, lp);
+            norm8(a);
+            chk[w][0][lane] = make_uint4(as_u32(a[0]), as_u32(a[1]), as_u32(a[2]), as_u32(a[3]));
+            chk[w][1][lane] = make_uint4(as_u32(a[4]), as_u32(a[5]), as_u32(a[6]), as_u32(a[7]));
 #pragma unroll
-        for (int q = 0; q < 4; q++) { // 16 steps = 2 windows per quarter line
-            const uint32_t t0 = blk * 64 + q * 16;
-            if (t0 >= K) break; // uniform
-            const uint4 s4 = *reinterpret_cast<const uint4 *>(ps + g8(tile, Kp, lane, t0 >> 4));
-            const uint4 p4 = *reinterpret_cast<const uint4 *>(pp + g8(tile, Kp, lane, t0 >> 4));
-            const uint4 a0 = *reinterpret_cast<const uint4 *>(pa + g16(tile, Kp, lane, t0 >> 3));
-            const uint4 a1 = *reinterpret_cast<const uint4 *>(pa + g16(tile, Kp, lane, (t0 >> 3) + 1));
-            const uint32_t sw[4] = {s4.x, s4.y, s4.z, s4.w}, pw[4] = {p4.x, p4.y, p4.z, p4.w};
-            const uint32_t aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            for (int r = 0; r < 8; r++) {
+                v2s o[8];
+                alpha_step(a, lsa[r] + lp[r], lsa[r], lp[r], o);
 #pragma unroll
-            for (int w = 0; w < 2; w++) {
-                if (t0 + 8 * w >= K) break; // uniform (K % 8 == 0)
-                norm8(a);
-                pc[(size_t)((t0 >> 3) + w) * 64] = make_uint4(pk16(a[0], a[1]), pk16(a[2], a[3]), pk16(a[4], a[5]), pk16(a[6], a[7]));
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    const int i = 8 * w + r, lsa = sb(sw[i >> 2], i & 3) + sh(aw[i >> 1], i & 1), lp = sb(pw[i >> 2], i & 3);
-                    int o[8];
-                    alpha_step(a, lsa + lp, lsa, lp, o);
-#pragma unroll
-                    for (int s = 0; s < 8; s++) a[s] = o[s];
-                }
+                for (int s = 0; s < 8; s++) a[s] = o[s];
             }
+        }
+
+        // ---- beta at the block's end
+        v2s b[8];
+        if (blk + 1 == n_blk) { // termination: only the a = 0 edges exist, state 2j + r3 continues to state j
+            const uint32_t cb0 = min(tile0 * 64 + lane, g.n_cb - 1), cb1 = min(tile1 * 64 + lane, g.n_cb - 1);
+            const int8_t  *ta = g.tail + ((size_t)cb0 << 4) + g.tail_off, *tb = g.tail + ((size_t)cb1 << 4) + g.tail_off;
+            b[0] = splat(0);
+#pragma unroll
+            for (int s = 1; s < 8; s++) b[s] = splat(BCJR_NEG);
+#pragma unroll
+            for (int k = 2; k >= 0; k--) {
+                v2s ls, lp;
+                ls.x = ta[k]; ls.y = tb[k]; lp.x = ta[3 + k]; lp.y = tb[3 + k];
+                const v2s g00 = ls + lp, g01 = ls, g10 = lp;
+                v2s       o[8];
+                o[0] = b[0] + g00; o[1] = b[0];       o[2] = b[1] + g10; o[3] = b[1] + g01;
+                o[4] = b[2] + g01; o[5] = b[2] + g10; o[6] = b[3];       o[7] = b[3] + g00;
+#pragma unroll
+                for (int s = 0; s < 8; s++) b[s] = o[s];
+            }
+            norm8(b);
+        } else { // what block blk + 1 reached at its start in the previous iteration
+            const uint4 c0 = g.b_rd[blk * bnd_stride + bnd_lane], c1 = g.b_rd[blk * bnd_stride + bnd_lane + 1];
+            b[0] = as_v2s(c0.x); b[1] = as_v2s(c0.y); b[2] = as_v2s(c0.z); b[3] = as_v2s(c0.w);
+            b[4] = as_v2s(c1.x); b[5] = as_v2s(c1.y); b[6] = as_v2s(c1.z); b[7] = as_v2s(c1.w);
+        }
+
+        // ---- backward, window by window: alpha re-run from the checkpoint, LLR / extrinsic per step, beta step
+#pragma unroll 1
+        for (int w = (int)n_w - 1; w >= 0; w--) {
+            v2s lsa[8], lp[8];
+            load_window(b0 + 8 * w, lsa, lp); // the same 8 steps again (they are one L2 hit away): cheaper than holding 32 steps in registers
+            v2s al[8][8];
+            {
+                const uint4 c0 = chk[w][0][lane], c1 = chk[w][1][lane];
+                al[0][0] = as_v2s(c0.x); al[0][1] = as_v2s(c0.y); al[0][2] = as_v2s(c0.z); al[0][3] = as_v2s(c0.w);
+                al[0][4] = as_v2s(c1.x); al[0][5] = as_v2s(c1.y); al[0][6] = as_v2s(c1.z); al[0][7] = as_v2s(c1.w);
+            }
+#pragma unroll
+            for (int r = 1; r < 8; r++) alpha_step(al[r - 1], lsa[r - 1] + lp[r - 1], lsa[r - 1], lp[r - 1], al[r]);
+#pragma unroll
+            for (int r = 7; r >= 0; r--) {
+                const v2s g00 = lsa[r] + lp[r], g01 = lsa[r], g10 = lp[r];
+                const v2s(&x)[8] = al[r];
+                const v2s m00 = vmax(vmax(x[0] + b[0], x[1] + b[4]), vmax(x[7] + b[3], x[6] + b[7]));
+                const v2s m01 = vmax(vmax(x[3] + b[1], x[2] + b[5]), vmax(x[4] + b[2], x[5] + b[6]));
+                const v2s m10 = vmax(vmax(x[2] + b[1], x[3] + b[5]), vmax(x[5] + b[2], x[4] + b[6]));
+                const v2s m11 = vmax(vmax(x[1] + b[0], x[0] + b[4]), vmax(x[6] + b[3], x[7] + b[7]));
+                const v2s llr = vmax(m00 + g00, m01 + g01) - vmax(m10 + g10, m11);
+                v2s       e   = vmin(vmax(llr - lsa[r], splat(-BCJR_X_MAX)), splat(BCJR_X_MAX));
+                e             = (e * (v2s)(3)) >> 2; // the 3/4 scaling (arithmetic shift)
+                e             = vmin(vmax(e, splat(-BCJR_LE_MAX)), splat(BCJR_LE_MAX)) >> 1; // the stored half
+                const size_t ro = (size_t)(b0 + 8 * w + r) * 128;
+                *reinterpret_cast<uint16_t *>(erow + ro) = (uint16_t)__builtin_amdgcn_perm(0u, as_u32(e), 0x0C0C0200u); // the two low bytes
+                if (LAST) {
+                    const uint32_t neg = as_u32(llr) >> 15; // bit 0: low half negative, bit 16: high half negative
+                    *reinterpret_cast<uint16_t *>(hrow + ro) = (uint16_t)((neg & 1u) | ((neg >> 8) & 0x100u));
+                }
+                beta_step(b, g00, g01, g10);
+            }
+            norm8(b);
+        }
+        if (blk > 0) { // beta at this block's start = the end of block blk - 1, for its next iteration (already normalised)
+            g.b_wr[(blk - 1) * bnd_stride + bnd_lane]     = make_uint4(as_u32(b[0]), as_u32(b[1]), as_u32(b[2]), as_u32(b[3]));
+            g.b_wr[(blk - 1) * bnd_stride + bnd_lane + 1] = make_uint4(as_u32(b[4]), as_u32(b[5]), as_u32(b[6]), as_u32(b[7]));
         }
     }
     if (seg + 1 < n_seg) { // hand the end state to the next segment's next iteration
         norm8(a);
-        *reinterpret_cast<uint4 *>(bnd.a_wr + (((size_t)(seg + 1) * bnd.n_tiles + tile) * 64 + lane) * 8) =
-            make_uint4(pk16(a[0], a[1]), pk16(a[2], a[3]), pk16(a[4], a[5]), pk16(a[6], a[7]));
+        g.a_wr[(seg + 1) * bnd_stride + bnd_lane]     = make_uint4(as_u32(a[0]), as_u32(a[1]), as_u32(a[2]), as_u32(a[3]));
+        g.a_wr[(seg + 1) * bnd_stride + bnd_lane + 1] = make_uint4(as_u32(a[4]), as_u32(a[5]), as_u32(a[6]), as_u32(a[7]));
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward pass: beta from the termination, then window by window: alpha re-run from the checkpoint,
-// LLR / extrinsic per step, beta step; beta normalised after every window
-template <bool POST>
-__global__ __launch_bounds__(64) void k_bcjr_bwd(const int8_t *__restrict__ S, const int8_t *__restrict__ P,
-                                                 const int16_t *__restrict__ A, const int16_t *__restrict__ chk,
-                                                 const int8_t *__restrict__ tail, uint32_t tail_off, int16_t *__restrict__ E,
-                                                 int16_t *__restrict__ post, uint32_t K, uint32_t n_cb, BcjrBnd bnd)
+// hard decisions in natural order: c[j] = HD[inv[j]] (decoder 2's last a-posteriori sign), a hole of the de-interleaver falls back on
+// the sign of S1[j] (its a-priori value is the zero a hole reads).  One workgroup per (tile pair, 64 bit positions): 64 rows of 128
+// bytes come in coalesced, go through LDS, and leave as 64 contiguous bytes per code block.
+__global__ __launch_bounds__(128) void k_bcjr_final(const uint8_t *__restrict__ HD, const uint32_t *__restrict__ inv_row, const int8_t *__restrict__ S1,
+                                                    uint32_t K, uint32_t n_cb, uint32_t n_tiles, uint8_t *__restrict__ c_bits)
 {
-    const uint32_t tile = blockIdx.x, seg = blockIdx.y, n_seg = gridDim.y, lane = threadIdx.x, Kp = kpad64(K), nblk = Kp >> 6, n_win = Kp >> 3;
-    const uint32_t seg_blk = nblk / n_seg;
-    const char  *ps = reinterpret_cast<const char *>(S), *pp = reinterpret_cast<const char *>(P), *pa = reinterpret_cast<const char *>(A);
-    char        *pe = reinterpret_cast<char *>(E), *po = POST ? reinterpret_cast<char *>(post) : nullptr;
-    const uint4 *pc = reinterpret_cast<const uint4 *>(chk + ((size_t)tile * n_win * 64 + lane) * 8);
-    (void)nblk;
-
-    int b[8] = {0, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG};
-    if (seg + 1 < n_seg) { // beta the next segment reached in the previous iteration
-        const uint4 c4 = *reinterpret_cast<const uint4 *>(bnd.b_rd + (((size_t)seg * bnd.n_tiles + tile) * 64 + lane) * 8);
-        b[0] = sh(c4.x, 0); b[1] = sh(c4.x, 1); b[2] = sh(c4.y, 0); b[3] = sh(c4.y, 1);
-        b[4] = sh(c4.z, 0); b[5] = sh(c4.z, 1); b[6] = sh(c4.w, 0); b[7] = sh(c4.w, 1);
-    } else {   // termination: only the a = 0 edges exist, state 2j + r3 continues to state j
-        const uint32_t cb = min(tile * 64 + lane, n_cb - 1);
-        const int8_t  *t  = tail + ((size_t)cb << 4) + tail_off;
-#pragma unroll
-        for (int k = 2; k >= 0; k--) {
-            const int ls = t[k], lp = t[3 + k], g00 = ls + lp, g01 = ls, g10 = lp;
-            int o[8];
-            o[0] = b[0] + g00; o[1] = b[0];       o[2] = b[1] + g10; o[3] = b[1] + g01;
-            o[4] = b[2] + g01; o[5] = b[2] + g10; o[6] = b[3];       o[7] = b[3] + g00;
-#pragma unroll
-            for (int s = 0; s < 8; s++) b[s] = o[s];
+    __shared__ uint8_t sm[64][132];
+    const uint32_t pair = blockIdx.x, j0 = blockIdx.y * 64, Kp = kpad64(K), th = threadIdx.x;
+    const uint8_t *base = HD + ex_row(pair, Kp, 0);
+    for (uint32_t jj = 0; jj < 64; jj++) {
+        const uint32_t j = j0 + jj, r = j < K ? inv_row[j] : Kp;
+        uint8_t        v = base[(size_t)r * 128 + th]; // byte th = lane * 2 + h
+        if (r == Kp && j < K) { // a hole: the sign of the systematic value of that code block at position j
+            const uint32_t tile = min(2 * pair + (th & 1u), n_tiles - 1), lane = th >> 1;
+            v = (uint8_t)(S1[g8(tile, Kp, lane, j >> 4) + (j & 15u)] < 0 ? 1 : 0);
         }
-        norm8(b);
-    }
-    for (int blk = (int)((seg + 1) * seg_blk) - 1; blk >= (int)(seg * seg_blk); blk--) {
-#pragma unroll
-        for (int q = 3; q >= 0; q--) {
-            const uint32_t t0 = (uint32_t)blk * 64 + q * 16;
-            if (t0 >= K) continue; // uniform
-            const uint4 s4 = *reinterpret_cast<const uint4 *>(ps + g8(tile, Kp, lane, t0 >> 4));
-            const uint4 p4 = *reinterpret_cast<const uint4 *>(pp + g8(tile, Kp, lane, t0 >> 4));
-            const uint4 a0 = *reinterpret_cast<const uint4 *>(pa + g16(tile, Kp, lane, t0 >> 3));
-            const uint4 a1 = *reinterpret_cast<const uint4 *>(pa + g16(tile, Kp, lane, (t0 >> 3) + 1));
-            const uint32_t sw[4] = {s4.x, s4.y, s4.z, s4.w}, pw[4] = {p4.x, p4.y, p4.z, p4.w};
-            const uint32_t aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-            for (int w = 1; w >= 0; w--) {
-                if (t0 + 8 * w >= K) continue; // uniform
-                const uint4 c4 = pc[(size_t)((t0 >> 3) + w) * 64];
-                int al[8][8];
-                al[0][0] = sh(c4.x, 0); al[0][1] = sh(c4.x, 1); al[0][2] = sh(c4.y, 0); al[0][3] = sh(c4.y, 1);
-                al[0][4] = sh(c4.z, 0); al[0][5] = sh(c4.z, 1); al[0][6] = sh(c4.w, 0); al[0][7] = sh(c4.w, 1);
-                int lsa[8], lp[8];
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    const int i = 8 * w + r;
-                    lsa[r] = sb(sw[i >> 2], i & 3) + sh(aw[i >> 1], i & 1);
-                    lp[r]  = sb(pw[i >> 2], i & 3);
-                }
-#pragma unroll
-                for (int r = 1; r < 8; r++) alpha_step(al[r - 1], lsa[r - 1] + lp[r - 1], lsa[r - 1], lp[r - 1], al[r]);
-                int ev[8], pv[8];
-#pragma unroll
-                for (int r = 7; r >= 0; r--) {
-                    const int g00 = lsa[r] + lp[r], g01 = lsa[r], g10 = lp[r];
-                    const int(&x)[8] = al[r];
-                    const int m00 = max(max(x[0] + b[0], x[1] + b[4]), max(x[7] + b[3], x[6] + b[7]));
-                    const int m01 = max(max(x[3] + b[1], x[2] + b[5]), max(x[4] + b[2], x[5] + b[6]));
-                    const int m10 = max(max(x[2] + b[1], x[3] + b[5]), max(x[5] + b[2], x[4] + b[6]));
-                    const int m11 = max(max(x[1] + b[0], x[0] + b[4]), max(x[6] + b[3], x[7] + b[7]));
-                    const int llr = max(m00 + g00, m01 + g01) - max(m10 + g10, m11);
-                    const int e   = ((llr - lsa[r]) * 3) >> 2;
-                    ev[r] = min(max(e, -BCJR_LE_MAX), BCJR_LE_MAX);
-                    pv[r] = min(max(llr, -32767), 32767);
-                    beta_step(b, g00, g01, g10);
-                }
-                norm8(b);
-                const size_t off = g16(tile, Kp, lane, (t0 >> 3) + w);
-                *reinterpret_cast<uint4 *>(pe + off) = make_uint4(pk16(ev[0], ev[1]), pk16(ev[2], ev[3]), pk16(ev[4], ev[5]), pk16(ev[6], ev[7]));
-                if (POST)
-                    *reinterpret_cast<uint4 *>(po + off) = make_uint4(pk16(pv[0], pv[1]), pk16(pv[2], pv[3]), pk16(pv[4], pv[5]), pk16(pv[6], pv[7]));
-            }
-        }
-    }
-    if (seg > 0) // beta at this segment's start = the previous segment's end, for its next iteration (already normalised)
-        *reinterpret_cast<uint4 *>(bnd.b_wr + (((size_t)(seg - 1) * bnd.n_tiles + tile) * 64 + lane) * 8) =
-            make_uint4(pk16(b[0], b[1]), pk16(b[2], b[3]), pk16(b[4], b[5]), pk16(b[6], b[7]));
-}
-
-// ------------------------------------------------------------------------------------------------
-// extrinsic exchange: A[i] = E[tab[i]] (tab = pi towards decoder 2, inv -- with 0xFFFF holes reading 0 -- back
-// towards decoder 1).  FINAL: instead of A, the hard decisions c[j] = post[inv[j]] < 0 (a hole falls back on S1[j]).
-template <bool FINAL>
-__global__ __launch_bounds__(384) void k_bcjr_perm(const int16_t *__restrict__ src, const uint16_t *__restrict__ tab, uint32_t K,
-                                                   uint32_t n_cb, int16_t *__restrict__ A, const int8_t *__restrict__ S1,
-                                                   uint8_t *__restrict__ c_bits)
-{
-    extern __shared__ __attribute__((aligned(16))) int16_t sm16[]; // src[Kp]
-    const uint32_t cb = xcd_cb(blockIdx.x, n_cb), tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4, u = threadIdx.x;
-    if (cb >= n_cb) return;
-    const size_t off0 = g16(tile, Kp, lane, 2 * u), off1 = g16(tile, Kp, lane, 2 * u + 1); // byte offsets of the unit's two granules
-    const int    nv   = (u < n_units) ? min(16, max(0, (int)K - 16 * (int)u)) : -1;
-    if (nv >= 0) {
-        const char *sb8 = reinterpret_cast<const char *>(src);
-        reinterpret_cast<uint4 *>(sm16 + 16 * u)[0] = *reinterpret_cast<const uint4 *>(sb8 + off0);
-        reinterpret_cast<uint4 *>(sm16 + 16 * u)[1] = *reinterpret_cast<const uint4 *>(sb8 + off1);
+        sm[jj][th] = v;
     }
     __syncthreads();
-    if (nv <= 0) {
-        if (nv == 0 && !FINAL) {
-            *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(A) + off0) = make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(A) + off1) = make_uint4(0, 0, 0, 0);
-        }
-        return;
-    }
-    const uint4 *p = reinterpret_cast<const uint4 *>(tab + 16 * (size_t)u);
-    const uint4  lo = p[0], hi = (nv > 8) ? p[1] : make_uint4(~0u, ~0u, ~0u, ~0u);
-    const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    int v[16];
-    bool hole[16];
+    const uint32_t h = th >> 6, lane = th & 63u, tile = 2 * pair + h, cb = tile * 64 + lane; // thread -> code block
+    if (tile >= n_tiles || cb >= n_cb) return;
+    uint8_t *o = c_bits + (size_t)cb * K + j0;
+    const uint32_t n = min(64u, K > j0 ? K - j0 : 0u); // a multiple of 8
+    for (uint32_t q = 0; q < n; q += 8) {
+        uint32_t w0 = 0, w1 = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const uint32_t idx = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
-        hole[k] = idx == 0xFFFFu;
-        const int t = sm16[hole[k] ? 0u : idx]; // unconditional read, masked
-        v[k] = hole[k] ? 0 : t;
-    }
-    if (!FINAL) {
-        char *ab = reinterpret_cast<char *>(A);
-        *reinterpret_cast<uint4 *>(ab + off0) = make_uint4(pk16(v[0], v[1]), pk16(v[2], v[3]), pk16(v[4], v[5]), pk16(v[6], v[7]));
-        *reinterpret_cast<uint4 *>(ab + off1) = make_uint4(pk16(v[8], v[9]), pk16(v[10], v[11]), pk16(v[12], v[13]), pk16(v[14], v[15]));
-    } else {
-        const uint4    s4 = *reinterpret_cast<const uint4 *>(S1 + g8(tile, Kp, lane, u));
-        const uint32_t sw[4] = {s4.x, s4.y, s4.z, s4.w};
-        uint32_t ob[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int l = hole[k] ? sb(sw[k >> 2], k & 3) : v[k];
-            ob[k >> 2] |= (l < 0 ? 1u : 0u) << (8 * (k & 3));
-        }
-        uint2 *o = reinterpret_cast<uint2 *>(c_bits + (size_t)cb * K + 16 * u); // 8-byte aligned (K % 8 == 0)
-        o[0] = make_uint2(ob[0], ob[1]);
-        if (nv > 8) o[1] = make_uint2(ob[2], ob[3]);
+        for (uint32_t k = 0; k < 4; k++) { w0 |= (uint32_t)sm[q + k][lane * 2 + h] << (8 * k); w1 |= (uint32_t)sm[q + 4 + k][lane * 2 + h] << (8 * k); }
+        *reinterpret_cast<uint2 *>(o + q) = make_uint2(w0, w1); // 8-byte aligned: K and j0 are multiples of 8
     }
 }
 
@@ -340,8 +347,11 @@ __global__ __launch_bounds__(384) void k_bcjr_perm(const int16_t *__restrict__ s
 
 extern "C" size_t mi_lte_turbo_bcjr_scratch_bytes(uint32_t K, uint32_t n_cb)
 {
-    const size_t n_tiles = (n_cb + 63) / 64, Kp = kpad64(K);
-    return n_tiles * (Kp * 64 * 4 + Kp * 128 * 3 + Kp * 128 + 64 * 16 + 2 * 2 * 2 * 4 * 64 * 16); // + boundary states [dec][a|b][buf][seg]
+    const size_t n_tiles = (n_cb + 63) / 64, n_pairs = (n_tiles + 1) / 2, Kp = kpad64(K), n_blk = (Kp + 31) / 32;
+    return n_tiles * (Kp * 64 * 4 + 64 * 16)                 // S1 P1 S2 P2, tails
+           + n_pairs * ((Kp + 1) * 128 * 3)                  // E1 E2 HD rows
+           + n_pairs * 64 * 32 * (2 * 2 * 8 + 2 * 2 * n_blk) // boundary states [decoder][buffer][segment | block]
+           + 4096;
 }
 
 // n_iter full iterations of max-log-MAP over n_cb code blocks of size K; int8 soft input in the reference's layout
@@ -351,43 +361,48 @@ int mi_turbo_bcjr_batch(mi_lte_ctx *ctx, const int8_t *d_soft, uint32_t K, uint3
     TurboTables tb;
     int         rc = mi_ctx_turbo_tables(ctx, K, qpp_spec ? 1 : 0, &tb);
     if (rc != MI_LTE_OK) return rc;
-    const size_t n_tiles = (n_cb + 63) / 64, Kp = kpad64(K), a8 = n_tiles * Kp * 64, a16 = n_tiles * Kp * 128;
+    const size_t n_tiles = (n_cb + 63) / 64, n_pairs = (n_tiles + 1) / 2, Kp = kpad64(K), a8 = n_tiles * Kp * 64, ex = n_pairs * (Kp + 1) * 128;
+    const size_t n_blk = (Kp + 31) / 32;
     rc = mi_ctx_reserve_scratch(ctx, mi_lte_turbo_bcjr_scratch_bytes(K, n_cb));
     if (rc != MI_LTE_OK) return rc;
     uint8_t *base = (uint8_t *)ctx->scratch;
     BcjrBufs B;
     B.S1 = (int8_t *)base; B.P1 = B.S1 + a8; B.S2 = B.P1 + a8; B.P2 = B.S2 + a8;
-    B.A  = (int16_t *)(base + 4 * a8); B.E = (int16_t *)(base + 4 * a8 + a16); B.post = (int16_t *)(base + 4 * a8 + 2 * a16);
-    B.chk  = (int16_t *)(base + 4 * a8 + 3 * a16);
-    B.tail = (int8_t *)(base + 4 * a8 + 4 * a16);
-    // segment boundary states: [decoder][alpha|beta][buffer][segment][tile][lane][8 x int16], uniform (0) before the first iteration
-    const uint32_t n_seg   = bcjr_n_seg(K);
-    const size_t   bnd_one = (size_t)4 * n_tiles * 64 * 8; // int16 elements of one [segment][tile][lane][8] array
-    int16_t       *bnd0    = (int16_t *)(base + 4 * a8 + 4 * a16 + n_tiles * 64 * 16);
-    MI_HIP_CHECK(ctx, hipMemsetAsync(bnd0, 0, 8 * bnd_one * sizeof(int16_t), ctx->stream));
-    auto bnd = [&](int dec, uint32_t it) {
-        const uint32_t rd = it & 1u, wr = rd ^ 1u;
-        int16_t *d = bnd0 + (size_t)dec * 4 * bnd_one;
-        return BcjrBnd{d + rd * bnd_one, d + wr * bnd_one, d + (2 + rd) * bnd_one, d + (2 + wr) * bnd_one, (uint32_t)n_tiles};
-    };
-    if (n_cb % 64) MI_HIP_CHECK(ctx, hipMemsetAsync(base, 0, 4 * a8 + 3 * a16, ctx->stream)); // lanes past the batch end stay defined
+    B.tail = (int8_t *)(base + 4 * a8);
+    int8_t  *E1 = (int8_t *)(base + 4 * a8 + n_tiles * 64 * 16), *E2 = E1 + ex;
+    uint8_t *HD = (uint8_t *)(E2 + ex);
+    // boundary states: per decoder and buffer, alpha [8 segments] then beta [n_blk blocks], each [pair][lane][8 x v2s = 2 x uint4];
+    // uniform (0) before the first iteration
+    const size_t one = n_pairs * 64 * 2; // uint4 per [segment | block]
+    uint4       *bnd0 = (uint4 *)(((uintptr_t)(HD + ex) + 255) & ~(uintptr_t)255);
+    const size_t per_buf = (8 + n_blk) * one;
+    MI_HIP_CHECK(ctx, hipMemsetAsync(bnd0, 0, 4 * per_buf * sizeof(uint4), ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemsetAsync(E2, 0, ex, ctx->stream)); // the a-priori values of the first half-iteration (and E2's zero rows)
+    MI_HIP_CHECK(ctx, hipMemset2DAsync(E1 + Kp * 128, (Kp + 1) * 128, 0, 128, n_pairs, ctx->stream)); // E1's zero row of every pair
+    if (n_cb % 64 || (n_tiles & 1)) MI_HIP_CHECK(ctx, hipMemsetAsync(base, 0, 4 * a8 + n_tiles * 64 * 16, ctx->stream)); // lanes past the batch end stay defined
     const uint32_t cb_threads = (uint32_t)(((Kp >> 4) + 63) & ~(size_t)63);
     MI_LAUNCH(ctx, "k_bcjr_prep", k_bcjr_prep, dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), Kp, d_soft, K, n_cb, tb.d_pi, B);
+    const uint32_t n_seg = bcjr_n_seg(K);
     for (uint32_t it = 0; it < n_iter; it++) {
         const bool last = it + 1 == n_iter;
-        MI_LAUNCH(ctx, "k_bcjr_fwd", k_bcjr_fwd, dim3(n_tiles, n_seg), dim3(64), 0, B.S1, B.P1, B.A, B.chk, K, bnd(0, it));
-        MI_LAUNCH(ctx, "k_bcjr_bwd", k_bcjr_bwd<false>, dim3(n_tiles, n_seg), dim3(64), 0, B.S1, B.P1, B.A, B.chk, B.tail, 0u, B.E, B.post, K, n_cb, bnd(0, it));
-        MI_LAUNCH(ctx, "k_bcjr_perm", k_bcjr_perm<false>, dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), 2 * Kp, B.E, tb.d_pi, K, n_cb, B.A, B.S1, d_c_bits);
-        MI_LAUNCH(ctx, "k_bcjr_fwd", k_bcjr_fwd, dim3(n_tiles, n_seg), dim3(64), 0, B.S2, B.P2, B.A, B.chk, K, bnd(1, it));
-        if (!last) {
-            MI_LAUNCH(ctx, "k_bcjr_bwd", k_bcjr_bwd<false>, dim3(n_tiles, n_seg), dim3(64), 0, B.S2, B.P2, B.A, B.chk, B.tail, 6u, B.E, B.post, K, n_cb, bnd(1, it));
-            MI_LAUNCH(ctx, "k_bcjr_perm", k_bcjr_perm<false>, dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), 2 * Kp, B.E, tb.d_inv, K, n_cb, B.A, B.S1, d_c_bits);
-        } else {
-            MI_LAUNCH(ctx, "k_bcjr_bwd", k_bcjr_bwd<true>, dim3(n_tiles, n_seg), dim3(64), 0, B.S2, B.P2, B.A, B.chk, B.tail, 6u, B.E, B.post, K, n_cb, bnd(1, it));
-            MI_LAUNCH(ctx, "k_bcjr_perm", k_bcjr_perm<true>, dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), 2 * Kp, B.post, tb.d_inv, K, n_cb, B.A, B.S1, d_c_bits);
-        }
+        const uint32_t rd = it & 1u, wr = rd ^ 1u;
+        auto args = [&](int dec) {
+            uint4 *d = bnd0 + (size_t)dec * 2 * per_buf;
+            HalfArgs h;
+            h.S = dec ? B.S2 : B.S1; h.P = dec ? B.P2 : B.P1;
+            h.A = dec ? E1 : E2; h.row = dec ? tb.d_pi_row : tb.d_inv_row; h.E = dec ? E2 : E1; h.HD = HD;
+            h.tail = B.tail; h.tail_off = dec ? 6u : 0u;
+            h.a_rd = d + rd * per_buf; h.b_rd = d + rd * per_buf + 8 * one; h.a_wr = d + wr * per_buf; h.b_wr = d + wr * per_buf + 8 * one;
+            h.K = K; h.n_cb = n_cb; h.n_tiles = (uint32_t)n_tiles; h.n_pairs = (uint32_t)n_pairs;
+            return h;
+        };
+        MI_LAUNCH(ctx, "k_bcjr_half", k_bcjr_half<false>, dim3(n_pairs, n_seg), dim3(64), 0, args(0));
+        if (!last) MI_LAUNCH(ctx, "k_bcjr_half", k_bcjr_half<false>, dim3(n_pairs, n_seg), dim3(64), 0, args(1));
+        else       MI_LAUNCH(ctx, "k_bcjr_half", k_bcjr_half<true>, dim3(n_pairs, n_seg), dim3(64), 0, args(1));
     }
+    MI_LAUNCH(ctx, "k_bcjr_final", k_bcjr_final, dim3(n_pairs, Kp / 64), dim3(128), 0, (const uint8_t *)HD, (const uint32_t *)tb.d_inv_row, (const int8_t *)B.S1, K, n_cb,
+              (uint32_t)n_tiles, d_c_bits);
     MI_HIP_CHECK(ctx, hipGetLastError());
-    ctx->last_kernels = "k_bcjr_prep:1,k_bcjr_fwd,k_bcjr_bwd,k_bcjr_perm: 2 each per iteration";
+    ctx->last_kernels = "k_bcjr_prep:1,k_bcjr_half: 2 per iteration,k_bcjr_final:1";
     return MI_LTE_OK;
 }

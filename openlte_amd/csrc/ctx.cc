@@ -227,7 +227,19 @@ int mi_ctx_turbo_tables(mi_lte_ctx *ctx, uint32_t K, int spec, TurboTables *out)
     std::vector<uint16_t> inv2(K16, (uint16_t)zero_slot);
     for (uint32_t j = 0; j < K; j++)
         if (inv[j] != 0xFFFF) inv2[j] = (uint16_t)(2u * inv[j]);
+    const uint32_t Kp64 = (K + 63u) & ~63u;
+    std::vector<uint32_t> pi_row(Kp64, Kp64), inv_row(Kp64, Kp64);
+    for (uint32_t j = 0; j < K; j++) {
+        pi_row[j] = pi[j];
+        if (inv[j] != 0xFFFF) inv_row[j] = inv[j];
+    }
     TurboTables t;
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&t.d_pi_row, sizeof(uint32_t) * Kp64));
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&t.d_inv_row, sizeof(uint32_t) * Kp64));
+    ctx->owned.push_back(t.d_pi_row);
+    ctx->owned.push_back(t.d_inv_row);
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(t.d_pi_row, pi_row.data(), sizeof(uint32_t) * Kp64, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(t.d_inv_row, inv_row.data(), sizeof(uint32_t) * Kp64, hipMemcpyHostToDevice, ctx->stream));
     MI_HIP_CHECK(ctx, hipMalloc((void **)&t.d_pi, sizeof(uint16_t) * K));
     MI_HIP_CHECK(ctx, hipMalloc((void **)&t.d_inv, sizeof(uint16_t) * K));
     MI_HIP_CHECK(ctx, hipMalloc((void **)&t.d_inv2, sizeof(uint16_t) * K16));

@@ -16,6 +16,8 @@ struct TurboTables {       // device-resident per-K tables
     uint16_t *d_inv = nullptr; // inv[j] = largest i with pi[i] == j, 0xFFFF if none ("hole")
     uint16_t *d_inv2 = nullptr; // k_turbo_vote's form: 2 * inv[j] (a byte offset into its int16 array), holes and the entries from K up to the
                                 // next multiple of 16 = 2 * kpad64(K), the offset of the array's zero slot
+    uint32_t *d_pi_row = nullptr, *d_inv_row = nullptr; // the BCJR kernels' form (32-bit entries: read with scalar loads), kpad64(K) entries each: pi[i] resp. inv[j] as a row index, with
+                                                        // holes and the entries from K on = kpad64(K), the index of the all-zero row
 };
 
 struct RmTables { // per-K rank tables of the fused turbo rate un-matching (see turbo.hip)

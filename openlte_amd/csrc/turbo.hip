@@ -163,6 +163,7 @@ template <typename T> struct SrcDirect {
     const T *soft;
     const T *d;
     __device__ __forceinline__ void init(uint32_t cb, uint32_t K) { d = soft + (size_t)cb * 3 * (K + 4); }
+    __device__ __forceinline__ bool hard_inputs() const { return false; }
     __device__ __forceinline__ bool stage_e(int8_t *) { return false; }
     // v[Src::kPacked ? 0 : x][k] = d[(16u+k)*3 + x] for k < nvalid (16 or 8), with Step 0 (RX_NULL_BIT -> 0, liblte_phy.cc:10636-10642)
     __device__ __forceinline__ void load16(uint32_t u, int nvalid, float (&v)[3][16], uint32_t, bool) const
@@ -307,7 +308,10 @@ struct SrcRateUnmatch {
         K_  = K;
         e   = g.e_base + (size_t)g.e_off[a] * 64;
         E   = g.e_len[a];
+        hard = g.allocs[a].mod_type >= 2 && E <= Nnn; // the de-mapper's 16QAM / 64QAM soft bits are all +-127 (liblte_phy.cc:9573-9659), and no position is summed
     }
+    bool hard;
+    __device__ __forceinline__ bool hard_inputs() const { return hard; }
     // copy the allocation's soft bits into LDS with wide loads (the gather is otherwise a chain of
     // dependent byte loads from L2), followed by zeros up to the next 16-byte boundary and at least at index E: the
     // gather below reads "nothing" (a NULL slot, a rank the allocation does not reach) as e[min(rank, E)] = 0.
@@ -619,6 +623,26 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Src::kPacke
         I0 = gather16_bytes(PREP_TAB_BYTES + src.e_cap, idx);
     }
     if (nv >= 0) *reinterpret_cast<uint4 *>(out.arr[3] + unit_off(tile_off, lane, u)) = I0;
+    if (identity && src.hard_inputs()) {
+        // Every soft value of the block is 0 or +-127 (hard-decision 16QAM / 64QAM soft bits, one lap of the circular buffer, identity
+        // quantiser): a branch weight w = |a| + |b| is 127 x (how many of the two are non-zero), and that count is the sum of the
+        // values' lowest bits (0x7F and 0x81 are odd, 0 is even).  The SISO output magnitude (int8)(127 * (w / W)) is then 127 where
+        // w == W, 63 where w is half of W = 254, 0 where w == 0 -- four elements per instruction, no table, no second barrier.
+        auto cnt4 = [](uint32_t a, uint32_t b) { return (a & 0x01010101u) + (b & 0x01010101u); };
+        const uint32_t c1[4] = {cnt4(Q[1].x, Q[0].x), cnt4(Q[1].y, Q[0].y), cnt4(Q[1].z, Q[0].z), cnt4(Q[1].w, Q[0].w)};
+        const uint32_t c2[4] = {cnt4(Q[2].x, I0.x), cnt4(Q[2].y, I0.y), cnt4(Q[2].z, I0.z), cnt4(Q[2].w, I0.w)};
+        const uint32_t o1 = c1[0] | c1[1] | c1[2] | c1[3], o2 = c2[0] | c2[1] | c2[2] | c2[3];
+        int w1max = (o1 & 0x02020202u) ? 254 : (o1 ? 127 : 0), w2max = (o2 & 0x02020202u) ? 254 : (o2 ? 127 : 0);
+        block_max_i2(w1max, w2max, red_i);
+        if (w1max != 0 && w2max != 0) { // (an all-zero stream pair divides by zero in the reference: the table path below reproduces what it stores)
+            auto mag4 = [](uint32_t cnt, int W) { return W == 254 ? (cnt << 6) - ((cnt | (cnt >> 1)) & 0x01010101u) : (cnt << 7) - cnt; };
+            if (nv >= 0) {
+                *reinterpret_cast<uint4 *>(out.arr[4] + unit_off(tile_off, lane, u)) = make_uint4(mag4(c1[0], w1max), mag4(c1[1], w1max), mag4(c1[2], w1max), mag4(c1[3], w1max));
+                *reinterpret_cast<uint4 *>(out.arr[5] + unit_off(tile_off, lane, u)) = make_uint4(mag4(c2[0], w2max), mag4(c2[1], w2max), mag4(c2[2], w2max), mag4(c2[3], w2max));
+            }
+            return;
+        }
+    }
     uint32_t w1[16], w2[16], w1m = 0, w2m = 0; // pass-1 / pass-2 branch weights |q(d1)| + |q(d0)|, |q(d2)| + |I0|: 0 past the block end
     abs_sum16(Q[1], Q[0], w1, w1m);
     abs_sum16(Q[2], I0, w2, w2m);

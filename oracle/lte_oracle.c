@@ -316,8 +316,9 @@ void lo_turbo_encode(const uint8_t *c, uint32_t K, uint8_t *d)
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* max-log-MAP ("BCJR") turbo decoder in fixed point.  This is the specification of the product's */
-/* BCJR mode (bcjr.hip follows it operation for operation); the reference has no such decoder.    */
+/* max-log-MAP ("BCJR") turbo decoder in 16-bit fixed point.  This is the specification of the    */
+/* product's BCJR mode (bcjr.hip follows it operation for operation); the reference has no such   */
+/* decoder, so parity for this mode is "the kernels equal this model bit for bit".    */
 /*                                                                                                */
 /* RSC of 36.212 5.1.3.2.1: feedback 1+D^2+D^3, parity 1+D+D^3.  State s = 4*r1 + 2*r2 + r3 (r1   */
 /* newest).  With a = u^r2^r3 the next state is 4a + (s>>1) and the parity is z = a^r1^r3, so the  */
@@ -327,9 +328,27 @@ void lo_turbo_encode(const uint8_t *c, uint32_t K, uint8_t *d)
 /*   from 2(n&3)+1: 11     01     10     00     00     10     01     11                            */
 /* Branch metric g(u,z) = [u==0]*(Ls+La) + [z==0]*Lp (positive LLR = bit 0; the common offset      */
 /* against the +-L/2 form cancels in every comparison).                                            */
-#define BCJR_NEG    (-32000)
-#define BCJR_LE_MAX 1023
-#define BCJR_W      8 /* alpha checkpoint spacing = backward window length; every QPP size is a multiple of 8 */
+/*                                                                                                */
+/* Number ranges (every intermediate fits int16, so the kernels run two code blocks per lane on    */
+/* packed 16-bit arithmetic with no saturation anywhere):                                          */
+/*   channel values Ls, Lp: int8, clipped to +-127;                                                */
+/*   extrinsic: e = ((x*3)>>2) with x = clamp(llr - (Ls+La), +-340), clamped to +-254, STORED as   */
+/*     q = e>>1 in int8 (the a-priori value the other decoder adds is La = 2q, |La| <= 254);       */
+/*   alpha, beta: normalised (maximum 0, floor BCJR_NEG = -6000) every 8 steps; in between they    */
+/*     move by at most 8*(127+254+127): [-10064, 4064]; alpha+beta+g >= -20636, llr within         */
+/*     +-29272, llr - (Ls+La) within +-29653.                                                      */
+/* Schedule: alpha runs continuously through a SEGMENT (n_seg = 8, 4, 2 or 1 per code block:       */
+/* occupancy), starting from the value the previous segment reached in the previous iteration;     */
+/* beta is initialised at the end of every 32-step BLOCK from the value the following block        */
+/* reached at its start in the previous iteration of the same constituent decoder ("next           */
+/* iteration initialisation"; all-zero = uniform before the first iteration; the block that ends   */
+/* the code block starts from the termination bits).  That makes a block's forward and backward    */
+/* pass one unit of work that needs nothing stored per trellis step.                               */
+#define BCJR_NEG    (-6000)
+#define BCJR_X_MAX  340 /* clamp of llr - (Ls+La) before the 3/4 scaling */
+#define BCJR_LE_MAX 254
+#define BCJR_W      8   /* alpha checkpoint spacing = backward window length; every QPP size is a multiple of 8 */
+#define BCJR_BLK    32  /* beta block: next-iteration initialisation at every multiple of 32 steps */
 
 static inline int bcjr_max(int a, int b) { return a > b ? a : b; }
 static void bcjr_norm(int *v) /* subtract the maximum, floor at BCJR_NEG */
@@ -352,96 +371,101 @@ static void bcjr_beta_step(const int *b, int g00, int g01, int g10, int *o)
     o[4] = bcjr_max(b[2] + g01, b[6] + g10); o[5] = bcjr_max(b[2] + g10, b[6] + g01);
     o[6] = bcjr_max(b[3], b[7] + g00);       o[7] = bcjr_max(b[3] + g00, b[7]);
 }
-/* Segments.  A block is cut into n_seg segments of equal length (a multiple of 64 steps) that are decoded
- * independently within a half-iteration; alpha at the start of segment s > 0 and beta at the end of segment
- * s < n_seg-1 are the (normalised) values the neighbouring segment reached in the PREVIOUS iteration of the same
- * constituent decoder ("next iteration initialisation"), all-zero in the first iteration.  The kernel gets its
- * occupancy from this; with segments of >= 512 steps the loss is immaterial.  n_seg = 4, 2 or 1. */
+/* Segments: n_seg = 8, 4, 2 or 1 pieces of equal length (a multiple of 64 steps, at least 512) decoded by separate wavefronts */
 uint32_t lo_bcjr_n_seg(uint32_t K)
 {
     const uint32_t nblk = (K + 63) / 64;
-    for (uint32_t n = 4; n > 1; n >>= 1)
+    for (uint32_t n = 8; n > 1; n >>= 1)
         if (nblk % n == 0 && (nblk / n) * 64 >= 512) return n;
     return 1;
 }
-typedef struct { int16_t a[2][4][8], b[2][4][8]; } bcjr_bnd_t; /* [buffer][segment][state] */
+#define BCJR_MAX_BLKS 192 /* 6144 / 32 */
+typedef struct { int16_t a[2][8][8], b[2][BCJR_MAX_BLKS][8]; } bcjr_bnd_t; /* [buffer][segment | block][state] */
+static int bcjr_range_ok = 1; /* cleared if any intermediate leaves int16 (checked by the tests through lo_bcjr_range_ok) */
+int lo_bcjr_range_ok(void) { return bcjr_range_ok; }
+#define BCJR_CHK(v) do { if ((v) > 32767 || (v) < -32768) bcjr_range_ok = 0; } while (0)
 
-/* one SISO pass: systematic S, parity P, a-priori A (K each), the 3 termination pairs, -> extrinsic E and (optionally)
- * the a-posteriori LLR.  it = iteration number (selects the boundary buffers). */
-static void bcjr_siso(const int8_t *S, const int8_t *P, const int16_t *A, const int8_t *tail_s, const int8_t *tail_p, uint32_t K,
-                      int16_t *E, int16_t *post, bcjr_bnd_t *bnd, uint32_t it)
+/* one SISO pass: systematic S, parity P (int8), stored a-priori halves Aq (int8; La = 2*Aq), the 3 termination pairs -> stored
+ * extrinsic halves Eq and (optionally) the sign of the a-posteriori LLR (1 = negative = bit 1).  it = iteration number. */
+static void bcjr_siso(const int8_t *S, const int8_t *P, const int8_t *Aq, const int8_t *tail_s, const int8_t *tail_p, uint32_t K,
+                      int8_t *Eq, uint8_t *hard, bcjr_bnd_t *bnd, uint32_t it)
 {
-    const uint32_t n_win = K / BCJR_W, n_seg = lo_bcjr_n_seg(K), seg_len = ((K + 63) / 64 / n_seg) * 64, rd = it & 1, wr = rd ^ 1;
-    int16_t (*chk)[8] = (int16_t (*)[8])malloc(sizeof(int16_t) * 8 * n_win);
+    const uint32_t n_seg = lo_bcjr_n_seg(K), seg_len = ((K + 63) / 64 / n_seg) * 64, rd = it & 1, wr = rd ^ 1, n_blk = (K + BCJR_BLK - 1) / BCJR_BLK;
     int t8[8];
-    for (uint32_t sg = 0; sg < n_seg; sg++) { /* forward: alpha, normalised and checkpointed every W steps */
+    for (uint32_t sg = 0; sg < n_seg; sg++) {
         const uint32_t t_lo = sg * seg_len, t_hi = (t_lo + seg_len < K) ? t_lo + seg_len : K;
         int a[8] = {0, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG};
         if (sg > 0) for (int s = 0; s < 8; s++) a[s] = bnd->a[rd][sg][s];
-        for (uint32_t t = t_lo; t < t_hi; t++) {
-            if (t % BCJR_W == 0) {
-                bcjr_norm(a);
-                for (int s = 0; s < 8; s++) chk[t / BCJR_W][s] = (int16_t)a[s];
+        for (uint32_t b0 = t_lo; b0 < t_hi; b0 += BCJR_BLK) { /* one 32-step block: forward, then backward */
+            const uint32_t b1 = (b0 + BCJR_BLK < t_hi) ? b0 + BCJR_BLK : t_hi, blk = b0 / BCJR_BLK, n_w = (b1 - b0) / BCJR_W;
+            int chk[BCJR_BLK / BCJR_W][8];
+            for (uint32_t t = b0; t < b1; t++) { /* alpha, normalised and checkpointed every W steps */
+                if (t % BCJR_W == 0) {
+                    bcjr_norm(a);
+                    memcpy(chk[(t - b0) / BCJR_W], a, sizeof(a));
+                }
+                const int lsa = S[t] + 2 * Aq[t], lp = P[t];
+                bcjr_alpha_step(a, lsa + lp, lsa, lp, t8);
+                memcpy(a, t8, sizeof(a));
+                for (int s = 0; s < 8; s++) BCJR_CHK(a[s]);
             }
-            const int lsa = S[t] + A[t], lp = P[t];
-            bcjr_alpha_step(a, lsa + lp, lsa, lp, t8);
-            memcpy(a, t8, sizeof(a));
+            int b[8] = {0, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG};
+            if (blk + 1 == n_blk) { /* beta at step K from the termination: only the a = 0 edges exist, so state 2j+r3 continues to state j */
+                for (int t = 2; t >= 0; t--) {
+                    const int ls = tail_s[t], lp = tail_p[t], g00 = ls + lp, g01 = ls, g10 = lp;
+                    t8[0] = b[0] + g00; t8[1] = b[0];       t8[2] = b[1] + g10; t8[3] = b[1] + g01;
+                    t8[4] = b[2] + g01; t8[5] = b[2] + g10; t8[6] = b[3];       t8[7] = b[3] + g00;
+                    memcpy(b, t8, sizeof(b));
+                }
+                bcjr_norm(b);
+            } else
+                for (int s = 0; s < 8; s++) b[s] = bnd->b[rd][blk][s]; /* what block blk+1 reached at its start in the previous iteration */
+            for (int w = (int)n_w - 1; w >= 0; w--) { /* backward, one window at a time: re-run alpha from the checkpoint */
+                const uint32_t t0 = b0 + (uint32_t)w * BCJR_W;
+                int al[BCJR_W][8];
+                memcpy(al[0], chk[w], sizeof(al[0]));
+                for (int i = 1; i < BCJR_W; i++) {
+                    const int lsa = S[t0 + i - 1] + 2 * Aq[t0 + i - 1], lp = P[t0 + i - 1];
+                    bcjr_alpha_step(al[i - 1], lsa + lp, lsa, lp, al[i]);
+                }
+                for (int i = BCJR_W - 1; i >= 0; i--) {
+                    const uint32_t t = t0 + i;
+                    const int lsa = S[t] + 2 * Aq[t], lp = P[t], g00 = lsa + lp, g01 = lsa, g10 = lp;
+                    const int *x = al[i];
+                    /* u = 0 edges: (0->0) (1->4) (7->3) (6->7) carry g00, (3->1) (2->5) (4->2) (5->6) carry g01;
+                     * u = 1 edges: (2->1) (3->5) (5->2) (4->6) carry g10, (1->0) (0->4) (6->3) (7->7) carry 0 */
+                    const int m00 = bcjr_max(bcjr_max(x[0] + b[0], x[1] + b[4]), bcjr_max(x[7] + b[3], x[6] + b[7]));
+                    const int m01 = bcjr_max(bcjr_max(x[3] + b[1], x[2] + b[5]), bcjr_max(x[4] + b[2], x[5] + b[6]));
+                    const int m10 = bcjr_max(bcjr_max(x[2] + b[1], x[3] + b[5]), bcjr_max(x[5] + b[2], x[4] + b[6]));
+                    const int m11 = bcjr_max(bcjr_max(x[1] + b[0], x[0] + b[4]), bcjr_max(x[6] + b[3], x[7] + b[7]));
+                    const int llr = bcjr_max(m00 + g00, m01 + g01) - bcjr_max(m10 + g10, m11);
+                    BCJR_CHK(m00 + g00); BCJR_CHK(m01 + g01); BCJR_CHK(m10 + g10); BCJR_CHK(m11); BCJR_CHK(llr); BCJR_CHK(llr - lsa);
+                    int xx = llr - lsa;
+                    xx     = xx > BCJR_X_MAX ? BCJR_X_MAX : xx < -BCJR_X_MAX ? -BCJR_X_MAX : xx;
+                    int e  = (xx * 3) >> 2; /* extrinsic, scaled by 3/4 (arithmetic shift) */
+                    e      = e > BCJR_LE_MAX ? BCJR_LE_MAX : e < -BCJR_LE_MAX ? -BCJR_LE_MAX : e;
+                    Eq[t]  = (int8_t)(e >> 1);
+                    if (hard) hard[t] = llr < 0 ? 1 : 0;
+                    bcjr_beta_step(b, g00, g01, g10, t8);
+                    memcpy(b, t8, sizeof(b));
+                    for (int s = 0; s < 8; s++) BCJR_CHK(b[s]);
+                }
+                bcjr_norm(b);
+            }
+            if (blk > 0) for (int s = 0; s < 8; s++) bnd->b[wr][blk - 1][s] = (int16_t)b[s]; /* beta at this block's start, for block blk-1's next iteration */
         }
         if (sg + 1 < n_seg) {
             bcjr_norm(a);
             for (int s = 0; s < 8; s++) bnd->a[wr][sg + 1][s] = (int16_t)a[s];
         }
     }
-    for (int sg = (int)n_seg - 1; sg >= 0; sg--) {
-        const uint32_t t_lo = (uint32_t)sg * seg_len, t_hi = (t_lo + seg_len < K) ? t_lo + seg_len : K;
-        int b[8] = {0, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG};
-        if (sg == (int)n_seg - 1) { /* beta at step K from the termination: only the a = 0 edges exist, so state 2j+r3 continues to state j */
-            for (int t = 2; t >= 0; t--) {
-                const int ls = tail_s[t], lp = tail_p[t], g00 = ls + lp, g01 = ls, g10 = lp;
-                t8[0] = b[0] + g00; t8[1] = b[0];       t8[2] = b[1] + g10; t8[3] = b[1] + g01;
-                t8[4] = b[2] + g01; t8[5] = b[2] + g10; t8[6] = b[3];       t8[7] = b[3] + g00;
-                memcpy(b, t8, sizeof(b));
-            }
-            bcjr_norm(b);
-        } else
-            for (int s = 0; s < 8; s++) b[s] = bnd->b[rd][sg][s];
-        for (int w = (int)(t_hi / BCJR_W) - 1; w >= (int)(t_lo / BCJR_W); w--) { /* backward, one window at a time: re-run alpha from the checkpoint */
-            const uint32_t t0 = (uint32_t)w * BCJR_W;
-            int al[BCJR_W][8];
-            for (int s = 0; s < 8; s++) al[0][s] = chk[w][s];
-            for (int i = 1; i < BCJR_W; i++) {
-                const int lsa = S[t0 + i - 1] + A[t0 + i - 1], lp = P[t0 + i - 1];
-                bcjr_alpha_step(al[i - 1], lsa + lp, lsa, lp, al[i]);
-            }
-            for (int i = BCJR_W - 1; i >= 0; i--) {
-                const uint32_t t = t0 + i;
-                const int lsa = S[t] + A[t], lp = P[t], g00 = lsa + lp, g01 = lsa, g10 = lp;
-                const int *x = al[i];
-                /* u = 0 edges: (0->0) (1->4) (7->3) (6->7) carry g00, (3->1) (2->5) (4->2) (5->6) carry g01;
-                 * u = 1 edges: (2->1) (3->5) (5->2) (4->6) carry g10, (1->0) (0->4) (6->3) (7->7) carry 0 */
-                const int m00 = bcjr_max(bcjr_max(x[0] + b[0], x[1] + b[4]), bcjr_max(x[7] + b[3], x[6] + b[7]));
-                const int m01 = bcjr_max(bcjr_max(x[3] + b[1], x[2] + b[5]), bcjr_max(x[4] + b[2], x[5] + b[6]));
-                const int m10 = bcjr_max(bcjr_max(x[2] + b[1], x[3] + b[5]), bcjr_max(x[5] + b[2], x[4] + b[6]));
-                const int m11 = bcjr_max(bcjr_max(x[1] + b[0], x[0] + b[4]), bcjr_max(x[6] + b[3], x[7] + b[7]));
-                const int llr = bcjr_max(m00 + g00, m01 + g01) - bcjr_max(m10 + g10, m11);
-                int e = ((llr - lsa) * 3) >> 2; /* extrinsic, scaled by 3/4 (arithmetic shift) */
-                e     = e > BCJR_LE_MAX ? BCJR_LE_MAX : e < -BCJR_LE_MAX ? -BCJR_LE_MAX : e;
-                E[t]  = (int16_t)e;
-                if (post) post[t] = (int16_t)(llr > 32767 ? 32767 : llr < -32767 ? -32767 : llr);
-                bcjr_beta_step(b, g00, g01, g10, t8);
-                memcpy(b, t8, sizeof(b));
-            }
-            bcjr_norm(b);
-        }
-        if (sg > 0) for (int s = 0; s < 8; s++) bnd->b[wr][sg - 1][s] = (int16_t)b[s];
-    }
-    free(chk);
 }
 
 void lo_turbo_decode_bcjr(const int16_t *soft, uint32_t K, uint32_t n_iter, int qpp_spec, uint8_t *c_bits)
 {
     int8_t   *S1 = (int8_t *)malloc(4 * (size_t)K), *P1 = S1 + K, *S2 = P1 + K, *P2 = S2 + K;
-    int16_t  *A1 = (int16_t *)calloc(5 * (size_t)K, sizeof(int16_t)), *A2 = A1 + K, *E1 = A2 + K, *E2 = E1 + K, *post = E2 + K;
+    int8_t   *A1 = (int8_t *)calloc(4 * (size_t)K, 1), *A2 = A1 + K, *E1 = A2 + K, *E2 = E1 + K;
+    uint8_t  *hard = (uint8_t *)calloc(K, 1);
     uint16_t *pi = (uint16_t *)malloc(sizeof(uint16_t) * 2 * K), *inv = pi + K;
     int8_t    x[3 * 4];
     if (qpp_spec) lo_qpp_map_spec(K, pi); else lo_qpp_map_ref(K, pi);
@@ -456,20 +480,16 @@ void lo_turbo_decode_bcjr(const int16_t *soft, uint32_t K, uint32_t n_iter, int 
     /* 36.212 5.1.3.2.2: d0 = x_K z_K+1 x'_K z'_K+1, d1 = z_K x_K+2 z'_K x'_K+2, d2 = x_K+1 z_K+2 x'_K+1 z'_K+2 */
     const int8_t t1s[3] = {x[0], x[2], x[4]}, t1p[3] = {x[1], x[3], x[5]};
     const int8_t t2s[3] = {x[6], x[8], x[10]}, t2p[3] = {x[7], x[9], x[11]};
-    bcjr_bnd_t bnd1, bnd2; /* segment boundaries of the two constituent decoders, all-zero (uniform) before the first iteration */
-    memset(&bnd1, 0, sizeof(bnd1));
-    memset(&bnd2, 0, sizeof(bnd2));
+    bcjr_bnd_t *bnd1 = (bcjr_bnd_t *)calloc(2, sizeof(bcjr_bnd_t)), *bnd2 = bnd1 + 1; /* all-zero (uniform) before the first iteration */
     for (uint32_t it = 0; it < n_iter; it++) {
-        bcjr_siso(S1, P1, A1, t1s, t1p, K, E1, NULL, &bnd1, it);
+        bcjr_siso(S1, P1, A1, t1s, t1p, K, E1, NULL, bnd1, it);
         for (uint32_t i = 0; i < K; i++) A2[i] = E1[pi[i]];
-        bcjr_siso(S2, P2, A2, t2s, t2p, K, E2, post, &bnd2, it);
+        bcjr_siso(S2, P2, A2, t2s, t2p, K, E2, it + 1 == n_iter ? hard : NULL, bnd2, it);
         for (uint32_t j = 0; j < K; j++) A1[j] = inv[j] != 0xFFFF ? E2[inv[j]] : 0;
     }
-    for (uint32_t j = 0; j < K; j++) {
-        const int l = inv[j] != 0xFFFF ? post[inv[j]] : S1[j] + A1[j];
-        c_bits[j]   = l < 0 ? 1 : 0;
-    }
-    free(S1); free(A1); free(pi);
+    for (uint32_t j = 0; j < K; j++) /* a hole of the (wrapped) de-interleaver falls back on the first decoder's view of that bit */
+        c_bits[j] = inv[j] != 0xFFFF ? hard[inv[j]] : (uint8_t)(S1[j] + 2 * A1[j] < 0 ? 1 : 0);
+    free(S1); free(A1); free(hard); free(pi); free(bnd1);
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -60,6 +60,24 @@ def test_bcjr_outperforms_ref_mode(ctx, port):
     assert (ref != tx).any(axis=1).mean() > 0.5
 
 
+@pytest.mark.parametrize("K", [3264, 6016])
+def test_bcjr_agrees_with_the_reference_decoder_wherever_that_one_decodes(ctx, port, K):
+    """SURVEY 8d W3's gate for the mode the reference does not have: on every code block where the reference's own decoder recovers
+    the transmitted bits (REF mode here is that decoder bit for bit, tests/test_turbo_gpu.py), the max-log-MAP decoder's output
+    equals it -- over a noise range that runs from where the reference decodes everything to where it decodes almost nothing."""
+    import openlte_amd as m
+    n_gate = 0
+    for sigma in (0.0, 0.5, 0.7, 0.8, 0.9):
+        tx, soft = llr_blocks(port, K, 128, sigma, seed=K + int(100 * sigma))
+        ref = ctx.turbo_decode(soft, K, mode=m.TURBO_REF)
+        bcjr = ctx.turbo_decode(soft, K, mode=m.TURBO_BCJR, n_iter=8)
+        ok_ref = (ref == tx).all(axis=1)
+        n_gate += int(ok_ref.sum())
+        assert (bcjr[ok_ref] == ref[ok_ref]).all(), (K, sigma, int((bcjr[ok_ref] != ref[ok_ref]).any(axis=1).sum()))
+        assert (bcjr == tx).all(), (K, sigma)  # and it decodes the blocks the reference's decoder loses as well
+    assert n_gate >= 128  # the gate was exercised
+
+
 def test_bcjr_full_batch_property(ctx, port):
     """BASELINE config 3 shape (K = 6144, 65536 blocks, 8 iterations): oracle-check 8 unique blocks and require every
     replica, wherever it sits in a tile, to decode to the same bits."""

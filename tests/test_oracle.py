@@ -261,3 +261,16 @@ def test_port_filler_bit_transport_blocks_vs_reference(port, ref, tbs, mod, nprb
     ref.ref_subframe_free(rx)
     ref.ref_phy_free(phy)
     ref.ref_phy_free(phy2)
+
+
+def test_bcjr_model_stays_inside_int16(port):
+    """The kernels run two code blocks per lane on packed 16-bit arithmetic; the model flags any intermediate that would leave int16."""
+    import ctypes as C
+    port.lo_bcjr_range_ok.restype = C.c_int
+    rng = np.random.default_rng(1)
+    for K in (40, 512, 6144):
+        for kind in ("sat", "noise"):
+            soft = (127 * (1 - 2 * rng.integers(0, 2, 3 * (K + 4)))).astype(np.int16) if kind == "sat" else rng.integers(-127, 128, 3 * (K + 4)).astype(np.int16)
+            out = np.zeros(K, np.uint8)
+            port.lo_turbo_decode_bcjr(np.ascontiguousarray(soft), K, 8, 0, out)
+    assert port.lo_bcjr_range_ok() == 1

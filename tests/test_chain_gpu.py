@@ -434,14 +434,14 @@ def test_compact_estimate_form_is_single_port_only(ctx):
 
 def test_packed_output_equals_the_unpacked_bits(ctx):
     """mi_lte_pdsch_plan_set_output(packed): eight bits per byte, first bit most significant -- np.packbits of the one-bit-per-byte output,
-    for block sizes with and without filler bits, in both decoder modes."""
+    for several block sizes and modulations, in both decoder modes."""
     import openlte_amd as m
     from openlte_amd import synth
     cfg = m.DlCfg(2048, 100, 1, m.IQ_I8 | m.CE_COMPACT)
     sfs, cells = [2, 8], [10, 499]
     allocs = []
     for u in range(2):
-        allocs += [m.make_alloc(u, 3, 3240, list(range(0, 12)), 0x300), m.make_alloc(u, 3, 3200, list(range(12, 24)), 0x301),
+        allocs += [m.make_alloc(u, 3, 3240, list(range(0, 12)), 0x300), m.make_alloc(u, 3, 2024, list(range(12, 20)), 0x301),
                    m.make_alloc(u, 2, 1384, list(range(30, 38)), 0x302), m.make_alloc(u, 1, 680, list(range(40, 48)), 0x303),
                    m.make_alloc(u, 3, 1064, list(range(96, 100)), 0x304)]
     iq, tx = synth.dl_units(cfg, sfs, cells, allocs, 5, snr_db=28, max_delay=4, seed=3)
@@ -468,7 +468,7 @@ def test_packed_output_equals_the_unpacked_bits(ctx):
             assert (raw[a, :al.tbs // 8] == np.packbits(bits[a])).all(), (mode, a)
             if st[a] == 0:
                 assert (np.unpackbits(raw[a, :al.tbs // 8]) == tx[a // 5, a % 5, :al.tbs]).all()
-        assert (st == 0).sum() >= 8  # the F > 0 block (tbs 3200) fails its CRC, as in the reference
+        assert (st == 0).all()
         plan.close()
         d_out.free(); d_st.free()
     for b in (d_iq, d_start, d_sf, d_cell, d_sub):

@@ -157,10 +157,10 @@ def test_port_pre_decoder_vs_reference(port, ref):
 
 def test_bcjr_model_decodes_and_segments(port):
     """The plain-C model of the BCJR mode (the mode's specification): decodes BPSK/AWGN at Eb/N0 ~ 2.7 dB error free,
-    with the exact 3GPP interleaver on a uint32-overflow size too, and cuts long blocks into 4 segments."""
+    with the exact 3GPP interleaver on a uint32-overflow size too, and cuts long blocks into up to 8 segments."""
     import ctypes as C
     port.lo_bcjr_n_seg.restype = C.c_uint32
-    assert [port.lo_bcjr_n_seg(K) for K in (40, 512, 1024, 2048, 3264, 6144)] == [1, 1, 2, 4, 1, 4]
+    assert [port.lo_bcjr_n_seg(K) for K in (40, 512, 1024, 2048, 3264, 6144)] == [1, 1, 2, 4, 1, 8]
     rng = np.random.default_rng(4)
     for K, spec in ((512, 0), (2048, 0), (6144, 1)):
         tx = rng.integers(0, 2, K).astype(np.uint8)

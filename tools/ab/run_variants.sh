@@ -1,8 +1,8 @@
 #!/bin/bash
-# On the GPU box: tools/ab/run_variants.sh <workload>  -- per-kernel ms of every _ko/lib_*.so variant, the current library first and last
+# On the GPU box: tools/ab/run_variants.sh <workload> [bench args]  -- per-kernel ms of every _ko/lib_*.so variant, the current library first and last
 cp openlte_amd/libmi_lte.so _ko/lib_BASE.so
 for v in BASE $(ls _ko | sed 's/lib_//;s/.so//' | grep -v BASE) BASE; do
   cp _ko/lib_$v.so openlte_amd/libmi_lte.so; echo "== $v"
-  python tools/ab/bench_kernels.py $1 --no-cpu-baseline 2>&1 | tail -1
+  python tools/ab/bench_kernels.py "$@" --no-cpu-baseline 2>&1 | tail -1
 done
 cp _ko/lib_BASE.so openlte_amd/libmi_lte.so

@@ -129,6 +129,7 @@ def all_cores_rate(make_worker, n_cpu, budget_s):
 
 
 # ------------------------------------------------------------------------------------------------
+NO_HOST_LEG = False  # --no-host-leg: skip the host-buffer pipeline measurement after the timed region (profiling runs)
 CE_MODE = "compact"  # --ce: form of the channel estimate between the front end and the PDSCH demodulator (chain workload)
 DECODER = "ref"  # --decoder: "ref" = the reference-faithful decoder (parity mode), "bcjr" = max-log-MAP, 8 iterations
 
@@ -367,7 +368,7 @@ class ChainWorkload:
         res = {"turbo_info_mbit_per_s": round(value * self.info_bits / 1e6, 2),
                "crc_pass": "%d/%d allocations" % (ok, st.size), "sampled_blocks_equal_tx_bits": bool(exact),
                "sampled_subframes_equal_cpu_restatement": bool(same)}
-        if DECODER != "ref":
+        if DECODER != "ref" or NO_HOST_LEG:
             return res
         import time
         m_ = self.m
@@ -1002,11 +1003,12 @@ def main():
     ap.add_argument("--decoder", default="ref", choices=["ref", "bcjr"], help="turbo workload only: decoder mode")
     ap.add_argument("--ce", default="compact", choices=["compact", "full"], help="chain workload: channel-estimate form handed to the demodulator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-leg", action="store_true", help="chain workload: skip the host-buffer pipeline measurement after the timed region")
     ap.add_argument("--no-turbo-leg", action="store_true", help="chain workload: skip the short W3 turbo-decode legs after the timed region")
     args = ap.parse_args()
 
-    global DECODER, CE_MODE
-    DECODER, CE_MODE = args.decoder, args.ce
+    global DECODER, CE_MODE, NO_HOST_LEG
+    DECODER, CE_MODE, NO_HOST_LEG = args.decoder, args.ce, args.no_host_leg
     maybe_relaunch(args.gpus, sys.argv[1:])
     rank, world, barrier, max_reduce = dist_setup(args.gpus)
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))

@@ -460,7 +460,7 @@ int mi_lte_pdsch_decode_run(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, const float 
     for (auto &gr : pl->groups) {
         if (pl->decoder == MI_LTE_TURBO_BCJR)
             rc = mi_turbo_bcjr_group(ctx, gr.K, gr.n_cb, pl->d_allocs, pl->d_cb_alloc + gr.cb_base, pl->d_e, pl->d_e_off, pl->d_e_len, d_out_bits,
-                                     pl->out_stride, d_status, false, pl->d_bcjr_soft, pl->d_bcjr_bits, pl->n_iter, pl->qpp_spec, pl->packed != 0);
+                                     pl->out_stride, d_status, false, pl->d_bcjr_soft, pl->d_bcjr_bits, pl->n_iter, pl->qpp_spec, pl->packed != 0, gr.e_max);
         else
             rc = mi_turbo_ref_group(ctx, gr.K, gr.n_cb, pl->d_allocs, pl->d_cb_alloc + gr.cb_base, pl->d_e, pl->d_e_off, pl->d_e_len,
                                     d_out_bits, pl->out_stride, d_status, gr.e_max, false, pl->packed != 0);

@@ -1233,30 +1233,65 @@ __global__ __launch_bounds__(256) void k_rate_unmatch_f32(const float *__restric
 // saturated to +-127, positions no bit reaches = 0), and the decoded block is finished the way dlsch_channel_decode does
 // (liblte_phy.cc:12840-12869): filler removed, CRC24A checked, transport block written one bit per byte.
 __global__ __launch_bounds__(256) void k_rm_to_i8(GroupDesc g, uint32_t K, uint32_t n_cb, const uint16_t *__restrict__ tabs, const uint32_t *__restrict__ nnn,
-                                                  int8_t *__restrict__ d_soft)
+                                                  int8_t *__restrict__ d_soft, uint32_t e_cap)
 {
+    // the allocation's soft bits staged in LDS (16-byte loads; a zero behind index E, so that "rank the allocation does not reach" and
+    // "never filled" both read 0 without a predicate), then four trellis positions per thread: their three rank words come in as
+    // 8-byte loads, the twelve values leave as three dwords
+    extern __shared__ __attribute__((aligned(16))) int8_t e_lds[];
     __shared__ RmGeom rm_s;
     const uint32_t cb = blockIdx.x, D = K + 4, a = g.cb_alloc[cb], txm = g.allocs[a].tx_mode, rv = g.allocs[a].rv_idx & 3u;
     if (threadIdx.x == 0) { // the geometry is the same for the whole code block; only the 12 tail values need it (the tables stop at K)
         if (g.ul) rm_s.init(D, 1, rv, 1, 1, 1, false);
         else      rm_s.init(D, txm, rv);
     }
-    __syncthreads();
     const uint32_t combo = g.ul ? 8u + rv : (rv << 1) | ((txm == 3 || txm == 4 || txm == 8 || txm == 9) ? 1u : 0u);
     const uint16_t *tab = tabs + (size_t)combo * 3 * K;
     const uint32_t Nnn = nnn[combo], E = g.e_len[a];
     const int8_t  *e = g.e_base + (size_t)g.e_off[a] * 64;
     int8_t        *db = d_soft + (size_t)cb * 3 * D;
-    for (uint32_t t = threadIdx.x; t < 3 * D; t += blockDim.x) {
-        const uint32_t i = t / 3;
-        const int      x = (int)(t - 3 * i);
-        uint32_t k = 0xFFFFu; // rank of d[i*3+x] in the order e is consumed; 0xFFFF: never filled
-        if (i < K) k = tab[(size_t)x * K + i];
-        else {
-            const RmGeom  &rm = rm_s;
-            const uint32_t p = rm.pos(i, x);
-            if (p < rm.N_cb) { const uint32_t c = rm.cnt(p); k = (p >= rm.k0m) ? c - rm.cnt_k0 : rm.Nnn - rm.cnt_k0 + c; }
+    const bool     staged = E + 16 <= e_cap && E < 0xFFFFu;
+    if (staged) {
+        const uint32_t nq = (E + 15) >> 4; // the allocation's slot is padded to 64 bytes
+        for (uint32_t w = threadIdx.x; w < nq; w += blockDim.x) reinterpret_cast<uint4 *>(e_lds)[w] = reinterpret_cast<const uint4 *>(e)[w];
+        __syncthreads();
+        for (uint32_t k = E + threadIdx.x; k < ((E + 16) & ~15u); k += blockDim.x) e_lds[k] = 0; // the zero behind the last soft bit
+    }
+    __syncthreads();
+    auto sum_at = [&](uint32_t k) -> int { // sum over the laps of the circular buffer, saturated to int8 (first visit stores, repeats add: :11402-11416)
+        int v = 0;
+        if (staged) {
+            v = e_lds[min(k, E)];
+            for (uint32_t q = k + Nnn; q < E; q += Nnn) v += e_lds[q];
+        } else if (k != 0xFFFFu) {
+            for (; k < E; k += Nnn) v += e[k];
         }
+        return max(-127, min(127, v));
+    };
+    // K is a multiple of 8: groups of four positions, 12 output bytes at byte offset 12 * (i / 4), 4-byte aligned (3 D is a multiple of 4)
+    for (uint32_t i0 = 4 * threadIdx.x; i0 < K; i0 += 4 * blockDim.x) {
+        uint32_t r[3][4];
+#pragma unroll
+        for (int x = 0; x < 3; x++) {
+            const uint2 w = *reinterpret_cast<const uint2 *>(tab + (size_t)x * K + i0);
+            r[x][0] = w.x & 0xFFFFu; r[x][1] = w.x >> 16; r[x][2] = w.y & 0xFFFFu; r[x][3] = w.y >> 16;
+        }
+        uint32_t o[3] = {0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 12; j++) { // output byte j of the group = d[(i0 + j / 3) * 3 + j % 3]
+            const int v = sum_at(r[j % 3][j / 3]);
+            o[j >> 2] |= ((uint32_t)v & 0xFFu) << (8 * (j & 3));
+        }
+        uint32_t *dst = reinterpret_cast<uint32_t *>(db + 3 * (size_t)i0);
+        dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+    }
+    if (threadIdx.x < 12) { // the termination values d[K..K+3][x]
+        const uint32_t t = 3 * K + threadIdx.x, i = t / 3;
+        const int      x = (int)(t - 3 * i);
+        const RmGeom  &rm = rm_s;
+        const uint32_t p = rm.pos(i, x);
+        uint32_t       k = 0xFFFFu;
+        if (p < rm.N_cb) { const uint32_t c = rm.cnt(p); k = (p >= rm.k0m) ? c - rm.cnt_k0 : rm.Nnn - rm.cnt_k0 + c; }
         int v = 0;
         if (k != 0xFFFFu)
             for (; k < E; k += Nnn) v += e[k];
@@ -1420,7 +1455,7 @@ int mi_turbo_ref_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_
 
 int mi_turbo_bcjr_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_pdsch_alloc *d_allocs, const uint32_t *d_cb_alloc, const int8_t *d_e,
                         const uint32_t *d_e_off, const uint32_t *d_e_len, uint8_t *d_out_bits, uint32_t out_stride, int32_t *d_status, bool ul,
-                        int8_t *d_soft, uint8_t *d_c_bits, uint32_t n_iter, int qpp_spec, bool packed)
+                        int8_t *d_soft, uint8_t *d_c_bits, uint32_t n_iter, int qpp_spec, bool packed, uint32_t e_max_bytes)
 {
     int rc = mi_ctx_crc_table(ctx);
     if (rc != MI_LTE_OK) return rc;
@@ -1428,7 +1463,8 @@ int mi_turbo_bcjr_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte
     RmTables  t;
     rc = rm_rank_tables(ctx, K, &t);
     if (rc != MI_LTE_OK) return rc;
-    MI_LAUNCH(ctx, "k_rm_to_i8", k_rm_to_i8, dim3(n_cb), dim3(256), 0, gd, K, n_cb, (const uint16_t *)t.d_tabs, (const uint32_t *)t.d_nnn, d_soft);
+    const uint32_t cap = (e_max_bytes + 16u + 63u) & ~63u, e_cap = cap <= 60 * 1024 ? cap : 0; // stage the allocation in LDS when it fits
+    MI_LAUNCH(ctx, "k_rm_to_i8", k_rm_to_i8, dim3(n_cb), dim3(256), e_cap, gd, K, n_cb, (const uint16_t *)t.d_tabs, (const uint32_t *)t.d_nnn, d_soft, e_cap);
     MI_HIP_CHECK(ctx, hipGetLastError());
     rc = mi_turbo_bcjr_batch(ctx, d_soft, K, n_cb, n_iter, qpp_spec, d_c_bits);
     if (rc != MI_LTE_OK) return rc;

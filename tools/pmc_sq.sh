@@ -3,7 +3,7 @@
 TAG=${1:-sq}; shift || true
 OUT=gpurun_out/pmc_${TAG}; mkdir -p $OUT; export TMPDIR=/tmp
 CTRS=${SQ_COUNTERS:-SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY}
-rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT -o k -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $OUT/bench.json 2> $OUT/log.txt
+rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT -o k -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-turbo-leg --no-host-leg "$@" > $OUT/bench.json 2> $OUT/log.txt
 python - <<PY
 import csv, collections
 acc=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter()

@@ -1003,6 +1003,7 @@ def main():
     ap.add_argument("--decoder", default="ref", choices=["ref", "bcjr"], help="turbo workload only: decoder mode")
     ap.add_argument("--ce", default="compact", choices=["compact", "full"], help="chain workload: channel-estimate form handed to the demodulator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="time the steps without the per-launch HIP events (no roofline in the line): measures what the events cost")
     ap.add_argument("--no-host-leg", action="store_true", help="chain workload: skip the host-buffer pipeline measurement after the timed region")
     ap.add_argument("--no-turbo-leg", action="store_true", help="chain workload: skip the short W3 turbo-decode legs after the timed region")
     args = ap.parse_args()
@@ -1026,7 +1027,7 @@ def main():
     for _ in range(args.warmup):
         wl.step()
     wl.sync()
-    wl.profile(True)  # HIP events around every kernel launch, on the launch stream (two event records per launch: < 0.1 % of a step)
+    wl.profile(not args.no_kernel_events)  # HIP events around every kernel launch, on the launch stream (two event records per launch)
     barrier()
     wl.sync()
     t0 = time.perf_counter()
@@ -1047,7 +1048,12 @@ def main():
             raise SystemExit("bench.py: ranks share a device: %s" % (got,))
         devices = [g[1] for g in got]
 
-    if rank == 0:
+    if rank == 0 and args.no_kernel_events:
+        units = wl.units_per_step() * world * args.steps
+        print(json.dumps({"metric": wl.metric, "value": round(units * wl.value_per_unit() / elapsed, 3), "unit": wl.unit, "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic", "config": wl.config(world), "kernel_events": False}))
+    elif rank == 0:
         steps = args.steps
         units = wl.units_per_step() * world * steps
         value = units * wl.value_per_unit() / elapsed

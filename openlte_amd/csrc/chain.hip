@@ -172,14 +172,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
             for (uint32_t item = threadIdx.x; item < n_items; item += blockDim.x) {
                 const uint32_t s = item >= per_slot ? 1u : 0u, r = item - s * per_slot, i = __umulhi(r, magic12), j = r - 12 * i;
                 const uint32_t k = (uint32_t)al.prb[s][i] * 12 + j, below = (1u << j) - 1u;
-                float M[5], A[5], m[14], a[14];
+                float M[5], A[5], m[7], a[7];
 #pragma unroll
                 for (int c = 0; c < 5; c++) { M[c] = h_re_p[c * N_SC_MAX + k]; A[c] = h_im_p[c * N_SC_MAX + k]; }
                 // the slot's symbols: requested before the interpolation needs its inputs
                 float yr[7], yi[7];
 #pragma unroll
                 for (int t = 0; t < 7; t++) { yr[t] = y_re_p[(7 * s + t) * N_SC_MAX + k]; yi[t] = y_im_p[(7 * s + t) * N_SC_MAX + k]; }
-                ce_time_interp5(M, A, m, a);
+                ce_time_interp5_slot(M, A, s, m, a);
 #pragma unroll
                 for (int t = 0; t < 7; t++) {
                     const uint32_t L = 7 * s + t;
@@ -188,8 +188,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
                     if (!((mk >> j) & 1u)) continue;
                     const uint32_t idx = offs[q] + __popc(mk & below);
                     float sn, cs;
-                    ce_sincos(s ? a[7 + t] : a[t], sn, cs);
-                    const float mm = s ? m[7 + t] : m[t], hr = mm * cs, hi = mm * sn;
+                    ce_sincos(a[t], sn, cs);
+                    const float mm = m[t], hr = mm * cs, hi = mm * sn;
                     const float hn = hr * hr + hi * hi;
                     const float xr = (yr[t] * hr + yi[t] * hi) / hn, xi = (yi[t] * hr - yr[t] * hi) / hn;
                     if (qam) put_qam(dst, idx, qam_neg_bits(xr, xi, al.mod_type));

@@ -31,10 +31,13 @@ __device__ __forceinline__ uint32_t gold_word(const GoldTables &gt, uint32_t c_i
 
 // wrap_phase (liblte_phy.cc:14105-14116): float difference compared against the double constant,
 // the +-2*pi correction is evaluated in double and rounded back to float.
+// The comparison needs no double: (float)M_PI = 3.14159274... is the smallest float that is >= the double constant (its predecessor
+// 3.14159250... is below it), so for a float d, (double)d >= M_PI exactly when d >= (float)M_PI, and likewise on the negative side.
 __device__ __forceinline__ float wrap_phase(float p1, float p2)
 {
-    while ((double)(p1 - p2) >= M_PI) p1 = (float)((double)p1 - 2 * M_PI);
-    while ((double)(p1 - p2) <= -M_PI) p1 = (float)((double)p1 + 2 * M_PI);
+    const float pi_up = 3.14159274101257324f;
+    while (p1 - p2 >= pi_up) p1 = (float)((double)p1 - 2 * M_PI);
+    while (p1 - p2 <= -pi_up) p1 = (float)((double)p1 + 2 * M_PI);
     return p1;
 }
 
@@ -75,6 +78,35 @@ __device__ __forceinline__ void ce_time_interp5(const float (&M)[5], float (&A)[
     MI_CE_SLOPE(4, 3, 3);
 #pragma unroll
     for (int z = 13; z > 11; z--) { cm -= fm; ca -= fa; m[z] = cm; a[z] = ca; }
+#undef MI_CE_SLOPE
+}
+// The same interpolation for ONE slot (symbols 7*slot .. 7*slot + 6 -> m[0..6], a[0..6]): what the PDSCH demodulator's threads need, each
+// working on one slot of one sub-carrier.  The second slot's segments still depend on the phases wrapped in the first slot's (A1 against A0,
+// A2 against the wrapped A1), so those two wraps are made, but not the first slot's slopes and chains.
+__device__ __forceinline__ void ce_time_interp5_slot(const float (&M)[5], float (&A)[5], uint32_t slot, float (&m)[7], float (&a)[7])
+{
+    float fm, fa, cm, ca;
+#define MI_CE_SLOPE(hi, lo, dv) do { fm = (M[hi] - M[lo]) / (dv); A[hi] = wrap_phase(A[hi], A[lo]); fa = A[hi] - A[lo]; \
+                                     fa = wrap_phase(fa, 0.0f); fa /= (dv); cm = M[hi]; ca = A[hi]; } while (0)
+    if (slot == 0) {
+        m[0] = M[0]; a[0] = A[0]; m[4] = M[1]; a[4] = A[1]; // symbols 0 and 4 as estimated (before A1 is wrapped)
+        MI_CE_SLOPE(1, 0, 4);
+#pragma unroll
+        for (int z = 3; z > 0; z--) { cm -= fm; ca -= fa; m[z] = cm; a[z] = ca; }
+        MI_CE_SLOPE(2, 1, 3);
+#pragma unroll
+        for (int z = 6; z > 4; z--) { cm -= fm; ca -= fa; m[z] = cm; a[z] = ca; }
+    } else {
+        m[0] = M[2]; a[0] = A[2]; m[4] = M[3]; a[4] = A[3]; // symbols 7 and 11 as estimated
+        A[1] = wrap_phase(A[1], A[0]);
+        A[2] = wrap_phase(A[2], A[1]);
+        MI_CE_SLOPE(3, 2, 4);
+#pragma unroll
+        for (int z = 3; z > 0; z--) { cm -= fm; ca -= fa; m[z] = cm; a[z] = ca; } // symbols 10, 9, 8
+        MI_CE_SLOPE(4, 3, 3);
+#pragma unroll
+        for (int z = 6; z > 4; z--) { cm -= fm; ca -= fa; m[z] = cm; a[z] = ca; } // symbols 13, 12
+    }
 #undef MI_CE_SLOPE
 }
 

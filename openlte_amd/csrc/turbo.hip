@@ -364,9 +364,18 @@ struct SrcRateUnmatch {
                 r[k]   = (k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xFFFFu);
                 acc[k] = lds_i8(el + min(r[k], E));
             }
-            for (uint32_t base = Nnn; base < E; base += Nnn) {
+            if (Nnn < E) { // more than one lap of the circular buffer: repeats are added (soft combining)
+                // A lap past the first only reaches the ranks below E - base -- with E just above one lap (the W4 allocations: 9936 soft
+                // bits for 9804 positions) that is 1 % of the positions, all in one stream -- so a stream none of whose ranks in this
+                // wavefront is reached skips its sixteen reads of the zero slot (wave-uniform test on the smallest rank)
+                uint32_t rmin = r[0];
 #pragma unroll
-                for (int k = 0; k < 16; k++) acc[k] += lds_i8(el + min(r[k] + base, E));
+                for (int k = 1; k < 16; k++) rmin = min(rmin, r[k]);
+                for (uint32_t base = Nnn; base < E; base += Nnn) {
+                    if (!__any(rmin + base < E)) break; // the ranks only grow with the lap
+#pragma unroll
+                    for (int k = 0; k < 16; k++) acc[k] += lds_i8(el + min(r[k] + base, E));
+                }
             }
             emit(x, acc);
         }
@@ -550,7 +559,10 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Src::kPacke
     // max = 127 (any saturated soft bit and no repetition: every 16QAM / 64QAM allocation): q(d) = (int)(d * 127.0f / 127.0f) = d,
     // the product and the quotient being exact -- no table, the bytes are the values themselves
     const bool identity = Src::kIntPath && mxi == 127;
-    if (use_qtab && !identity) {
+    // max = 254 (two laps of saturated soft bits, the W4 allocations): q(d) = (int)(d * 127.0f / 254.0f) is d / 2 truncated towards zero for
+    // every integer |d| <= 254 (checked exhaustively in float arithmetic, tests/test_oracle.py) -- two packed instructions instead of a table read
+    const bool halving = Src::kPacked && mxi == 254;
+    if (use_qtab && !identity && !halving) {
         if constexpr (Src::kIntPath) { // signed table centred on a fixed slot: entry QTAB_HALF + d holds q(d) -- one read per element
             for (int d = (int)threadIdx.x - mxi; d <= mxi; d += (int)blockDim.x) qc[d] = (int8_t)(int)((float)d * 127.0f / mx);
         } else {
@@ -568,6 +580,12 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Src::kPacke
             if (identity) { // the low bytes of the four int16 values of two registers
 #pragma unroll
                 for (int j = 0; j < 4; j++) o[j] = __builtin_amdgcn_perm(vp[x][2 * j + 1], vp[x][2 * j], 0x06040200u);
+            } else if (halving) { // (d - (d >> 15)) >> 1 = d / 2 towards zero, per int16 half
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const v2s a = as_v2s(vp[x][2 * j]), b = as_v2s(vp[x][2 * j + 1]);
+                    o[j] = __builtin_amdgcn_perm(as_u32((b - (b >> 15)) >> 1), as_u32((a - (a >> 15)) >> 1), 0x06040200u);
+                }
             } else {
                 int d[16];
 #pragma unroll
@@ -648,16 +666,30 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Src::kPacke
     abs_sum16(Q[2], I0, w2, w2m);
     int w1max = (int)w1m, w2max = (int)w2m;
     block_max_i2(w1max, w2max, red_i);
-    const float W1 = (float)w1max, W2 = (float)w2max;
-    for (uint32_t t = threadIdx.x; t < MTAB_N; t += blockDim.x) { // w <= 254 always; entries past W are never read
-        const float w = (float)t;
-        mtab1[t] = (int8_t)(int)(127.0f * (w / W1));
-        mtab2[t] = (int8_t)(int)(127.0f * (w / W2));
+    // (int8)(127 * (w / W)) has closed forms for the two maxima that saturated soft values produce: W = 254 -> w >> 1, W = 127 -> w, for
+    // every w <= W (checked exhaustively in float arithmetic, tests/test_oracle.py); any other maximum goes through the per-block table
+    auto closed = [](int W) { return W == 254 || W == 127; };
+    auto closed16 = [](const uint32_t (&w)[16], int W) {
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t p = pack4u(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+            o[j] = W == 254 ? (p >> 1) & 0x7F7F7F7Fu : p;
+        }
+        return make_uint4(o[0], o[1], o[2], o[3]);
+    };
+    if (!(closed(w1max) && closed(w2max))) {
+        const float W1 = (float)w1max, W2 = (float)w2max;
+        for (uint32_t t = threadIdx.x; t < MTAB_N; t += blockDim.x) { // w <= 254 always; entries past W are never read
+            const float w = (float)t;
+            mtab1[t] = (int8_t)(int)(127.0f * (w / W1));
+            mtab2[t] = (int8_t)(int)(127.0f * (w / W2));
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (nv >= 0) {
-        *reinterpret_cast<uint4 *>(out.arr[4] + unit_off(tile_off, lane, u)) = lookup16(QTAB_N, w1); // past the end: entry 0 = 0
-        *reinterpret_cast<uint4 *>(out.arr[5] + unit_off(tile_off, lane, u)) = lookup16(QTAB_N + MTAB_N, w2);
+        *reinterpret_cast<uint4 *>(out.arr[4] + unit_off(tile_off, lane, u)) = closed(w1max) ? closed16(w1, w1max) : lookup16(QTAB_N, w1); // past the end: entry 0 = 0
+        *reinterpret_cast<uint4 *>(out.arr[5] + unit_off(tile_off, lane, u)) = closed(w2max) ? closed16(w2, w2max) : lookup16(QTAB_N + MTAB_N, w2);
     }
 }
 
@@ -1009,6 +1041,16 @@ __global__ __launch_bounds__(384) void k_turbo_perm(PermArgs a, uint32_t K, uint
     if (nv <= 0) X2 = make_uint4(0, 0, 0, 0);
     abs_sum16(X2, I1, w, wm);
     const int   wmax = block_max_i((int)wm, red_i);
+    if (wmax == 254 || wmax == 127) { // closed forms of (int8)(127 * (w / W)), as in k_turbo_prep
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t p = pack4u(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+            o[j] = wmax == 254 ? (p >> 1) & 0x7F7F7F7Fu : p;
+        }
+        if (nv >= 0) *reinterpret_cast<uint4 *>(a.out[1] + unit_off(tile_off, lane, u)) = make_uint4(o[0], o[1], o[2], o[3]);
+        return;
+    }
     const float W = (float)wmax;
     for (uint32_t t = threadIdx.x; t < MTAB_N; t += blockDim.x) mtab[t] = (int8_t)(int)(127.0f * ((float)t / W)); // one division per distinct w
     __syncthreads();

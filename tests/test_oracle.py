@@ -274,3 +274,17 @@ def test_bcjr_model_stays_inside_int16(port):
             out = np.zeros(K, np.uint8)
             port.lo_turbo_decode_bcjr(np.ascontiguousarray(soft), K, 8, 0, out)
     assert port.lo_bcjr_range_ok() == 1
+
+
+def test_closed_forms_of_the_two_float_sites_the_kernels_shortcut():
+    """k_turbo_prep / k_turbo_perm replace two of the reference's float expressions by integer closed forms when the block maximum is the
+    one saturated soft values produce: q(d) = (int8)(d * 127 / max) with max = 254 is d / 2 towards zero (liblte_phy.cc:10645-10664), and
+    (int8)(127 * (w / W)) is w >> 1 for W = 254 and w for W = 127 (:10498-10524).  Exhaustive check in IEEE float32 (numpy rounds like the
+    reference's SSE code and like the un-contracted device code)."""
+    f = np.float32
+    d = np.arange(-254, 255)
+    assert ((d.astype(f) * f(127.0) / f(254.0)).astype(np.int32) == np.trunc(d / 2).astype(np.int32)).all()
+    w = np.arange(0, 255)
+    assert ((f(127.0) * (w.astype(f) / f(254.0))).astype(np.int32) == (w >> 1)).all()
+    w = np.arange(0, 128)
+    assert ((f(127.0) * (w.astype(f) / f(127.0))).astype(np.int32) == w).all()

@@ -121,8 +121,8 @@ def run_threads(workers):
 def all_cores_rate(make_worker, n_cpu, budget_s):
     """Units per second with one worker per CPU: a short calibration round sizes the timed round to about budget_s (per-thread speed
     under full load is far below the single-thread speed: the reference's 46 MB scratch struct per thread is memory-bound)."""
-    res, wall = run_threads([make_worker(k, 2) for k in range(n_cpu)])
-    per_rep = wall / 2
+    res, wall = run_threads([make_worker(k, 4) for k in range(n_cpu)])
+    per_rep = wall / 4
     reps = int(max(2, min(100000, budget_s / per_rep)))
     res, wall = run_threads([make_worker(k, reps) for k in range(n_cpu)])
     return sum(r[0] for r in res), wall, reps

@@ -281,21 +281,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BCJR_WPE, 8)
             for (int r = 7; r >= 0; r--) {
                 const v2s g00 = lsa[r] + lp[r], g01 = lsa[r], g10 = lp[r];
                 const v2s(&x)[8] = al[r];
-                const v2s m00 = vmax(vmax(x[0] + b[0], x[1] + b[4]), vmax(x[7] + b[3], x[6] + b[7]));
-                const v2s m01 = vmax(vmax(x[3] + b[1], x[2] + b[5]), vmax(x[4] + b[2], x[5] + b[6]));
-                const v2s m10 = vmax(vmax(x[2] + b[1], x[3] + b[5]), vmax(x[5] + b[2], x[4] + b[6]));
-                const v2s m11 = vmax(vmax(x[1] + b[0], x[0] + b[4]), vmax(x[6] + b[3], x[7] + b[7]));
-                const v2s llr = vmax(m00 + g00, m01 + g01) - vmax(m10 + g10, m11);
+                // The twelve sums "branch metric + beta of the edge's end state" serve twice: their pairwise maxima are the beta step, and
+                // added to alpha of the edge's start state they are the LLR's candidates (integer + and max: the model's grouping
+                // max(m00 + g00, ..) gives the same values).  u0[s] / u1[s]: the edge that leaves state s with u = 0 / u = 1.
+                const v2s u0[8] = {b[0] + g00, b[4] + g00, b[5] + g01, b[1] + g01, b[2] + g01, b[6] + g01, b[7] + g00, b[3] + g00};
+                const v2s u1[8] = {b[4], b[0], b[1] + g10, b[5] + g10, b[6] + g10, b[2] + g10, b[3], b[7]};
+                v2s l0 = x[0] + u0[0], l1 = x[0] + u1[0];
+#pragma unroll
+                for (int s = 1; s < 8; s++) { l0 = vmax(l0, x[s] + u0[s]); l1 = vmax(l1, x[s] + u1[s]); }
+                const v2s llr = l0 - l1;
                 v2s       e   = vmin(vmax(llr - lsa[r], splat(-BCJR_X_MAX)), splat(BCJR_X_MAX));
-                e             = (e * (v2s)(3)) >> 2; // the 3/4 scaling (arithmetic shift)
-                e             = vmin(vmax(e, splat(-BCJR_LE_MAX)), splat(BCJR_LE_MAX)) >> 1; // the stored half
+                e             = (e * (v2s)(3)) >> 2;              // the 3/4 scaling (arithmetic shift): within +-255
+                e             = vmax(e, splat(-BCJR_LE_MAX)) >> 1; // the stored half (the upper clamp would not change it: 255 >> 1 = 254 >> 1)
                 const size_t ro = (size_t)(b0 + 8 * w + r) * 128;
                 *reinterpret_cast<uint16_t *>(erow + ro) = (uint16_t)__builtin_amdgcn_perm(0u, as_u32(e), 0x0C0C0200u); // the two low bytes
                 if (LAST) {
                     const uint32_t neg = as_u32(llr) >> 15; // bit 0: low half negative, bit 16: high half negative
                     *reinterpret_cast<uint16_t *>(hrow + ro) = (uint16_t)((neg & 1u) | ((neg >> 8) & 0x100u));
                 }
-                beta_step(b, g00, g01, g10);
+#pragma unroll
+                for (int s = 0; s < 8; s++) b[s] = vmax(u0[s], u1[s]); // the beta step
             }
             norm8(b);
         }

@@ -411,6 +411,9 @@ class ChainWorkload:
         own = {"k_dl_fft": n * (15 * 2048 * 2 + 15 * 1200 * 8),       # the 15 symbol windows in, 15 rows of symbols out
                "k_dl_ce": n * (5 * 200 * 8 + 14 * 1200 * 8),           # pilots in, 14 estimate rows out
                "k_pdsch_demod": n * res * (16 + 6)}                    # y and h per element in, six soft bits out
+        if CE_MODE == "compact":  # five magnitude + five phase rows out; y per element + ten values per (slot, sub-carrier) in
+            own["k_dl_ce"] = n * (5 * 200 * 8 + 10 * 1200 * 4)
+            own["k_pdsch_demod"] = n * (res * (8 + 6) + 2 * 1200 * 40)
         for K, cnt, E, tbs in ((3264, 8, 9936, 3240), (1088, 1, 3312, 1064)):
             for k, v in turbo_own_io(K, n * cnt, E, tbs, bc).items():
                 own[k] = own.get(k, 0) + v

@@ -97,12 +97,14 @@ int host_cache(mi_lte_ctx *ctx, HostCache **out)
         HostCache *hc = new HostCache();
         ctx->host_cache      = hc;
         ctx->host_cache_free = host_cache_free;
+        auto guard = on_fail([&] { host_cache_free(ctx); }); // a half-built cache is not left behind: the next call starts over
         MI_HIP_CHECK(ctx, hipMalloc((void **)&hc->d_sub, 10 * ROW * sizeof(float)));
         MI_HIP_CHECK(ctx, hipMemsetAsync(hc->d_sub, 0, 10 * ROW * sizeof(float), ctx->stream));
         MI_HIP_CHECK(ctx, hipMalloc((void **)&hc->d_par, 64));
         MI_HIP_CHECK(ctx, hipMalloc((void **)&hc->d_res, 64 + 6144 + 64));
         hc->d_st  = (int32_t *)hc->d_res;
         hc->d_out = hc->d_res + 64;
+        guard.armed = false;
     }
     *out = (HostCache *)ctx->host_cache;
     return MI_LTE_OK;

@@ -84,10 +84,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
     const uint32_t c_init = (al.rnti << 14) | (0u << 13) | (sf << 9) | cell;
     if (threadIdx.x < 64) {
         const uint32_t ln = threadIdx.x, per = (n_pairs + 63) / 64, q0 = ln * per, q1 = min(q0 + per, n_pairs);
-        const uint32_t magic = 0xFFFFFFFFu / N_prb + 1u; // q / N_prb = mulhi(q, magic), exact for q < 2^32 / N_prb^2
+        const uint32_t magic = 0xFFFFFFFFu / N_prb + 1u; // q / N_prb = mulhi(q, magic), exact for q < 2^32 / N_prb^2; a single PRB wraps it to 0 = "no division"
         uint32_t local = 0;
         for (uint32_t q = q0; q < q1; q++) {
-            const uint32_t row = __umulhi(q, magic), L = g.cfi + row, prb = al.prb[L / 7][q - row * N_prb];
+            const uint32_t row = magic ? __umulhi(q, magic) : q, L = g.cfi + row, prb = al.prb[L / 7][q - row * N_prb];
             const uint32_t m = pdsch_mask(N_ant, cell, sf, L, prb, first_sc, last_sc);
             masks[q] = m | ((L * N_SC_MAX + prb * 12) << 12); // low 12 bits: RE mask, high 20 bits: L*1200 + first sub-carrier
             local += __popc(m);

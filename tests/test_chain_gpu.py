@@ -578,3 +578,43 @@ def test_random_allocations_stage_parity(ctx, port):
         for b in (d_iq, d_start, d_sf, d_cell):
             b.free()
     assert n_ok >= 10  # most cases decode; the punctured and the low-SNR ones fail on both sides alike
+
+
+@pytest.mark.parametrize("fft,nrb,n_ant", [(128, 6, 1), (256, 15, 2), (512, 25, 4), (1024, 50, 2), (2048, 75, 1), (2048, 100, 4)])
+def test_random_allocations_other_bandwidths_and_ports(ctx, port, fft, nrb, n_ant):
+    """The same seeded random geometries on the other bandwidths and with the 2- / 4-port transmit-diversity combiner (on a single-port
+    capture: garbage in, but the oracle's garbage out -- the reference's |h|^4 normaliser, quirk Q4, and the layer de-mapper are what is
+    exercised): soft bits, verdict and bits equal the oracle's on the oracle's grid."""
+    import openlte_amd as m
+    from openlte_amd import synth
+    rng = np.random.default_rng(fft * 7 + n_ant)
+    sizes = [k - 24 for k in td.ALL_K if k - 24 >= 16]
+    cfg1, cfg = m.DlCfg(fft, nrb, 1, m.IQ_I8), m.DlCfg(fft, nrb, n_ant, m.IQ_I8)
+    done = 0
+    for case in range(14):
+        cell, cfi, mod = int(rng.integers(0, 504)), int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        sf = int(rng.integers(0, 10)) if n_ant < 4 else int(rng.choice([1, 2, 3, 4, 6, 7, 8, 9]))  # 4 ports: the M_ap % 4 != 0 tail is outside the envelope
+        n_sym = cfi + (1 if nrb <= 10 else 0)
+        n_prb = int(rng.integers(1, min(nrb, 16) + 1))
+        first = int(rng.integers(0, nrb - n_prb + 1))
+        e_ub = n_prb * 12 * (14 - n_sym) * (2, 4, 6)[mod - 1]
+        fit = [t for t in sizes if 3 * (t + 28) <= e_ub * 0.85]
+        if not fit:
+            continue
+        tbs = int(fit[int(rng.integers(max(0, len(fit) - 5), len(fit)))])
+        alloc = [m.make_alloc(0, mod, tbs, list(range(first, first + n_prb)), int(rng.integers(1, 0xFFF0)), 0, 1 if n_ant == 1 else 2)]
+        iq, tx = synth.dl_units(cfg1, [sf], [cell], alloc, 1, n_pdcch_symbs=n_sym, snr_db=25.0, max_delay=2, seed=case)
+        lc, s = td.oracle_frontend(port, fft, nrb, n_ant, iq[0], sf, cell)
+        err, out, desc = oracle_pdsch(port, lc, s, alloc[0], n_sym, cell, n_ant)
+        d_sub = ctx.to_device(upload_oracle_subframe(ctx, s, n_ant))
+        plan = ctx.pdsch_plan(cfg, n_sym, alloc)
+        st, bits = plan.run(d_sub, [sf], [cell])
+        e = plan.soft_bits(0)
+        assert e.shape == desc.shape and (e == desc).all(), (case, cell, sf, cfi, mod, n_prb, first, tbs, int((e[:min(len(e), len(desc))] != desc[:min(len(e), len(desc))]).sum()))
+        assert st[0] == err and (err != 0 or (bits[0] == out).all()), (case, st[0], err)
+        if n_ant == 1 and err == 0:
+            assert (bits[0] == tx[0, 0, :tbs]).all()
+        plan.close()
+        d_sub.free()
+        done += 1
+    assert done >= 8

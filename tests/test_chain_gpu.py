@@ -618,3 +618,29 @@ def test_random_allocations_other_bandwidths_and_ports(ctx, port, fft, nrb, n_an
         d_sub.free()
         done += 1
     assert done >= 8
+
+
+@pytest.mark.parametrize("tx_mode,tbs,nprb,mod,rv", [(3, 5992, 100, 3, 0), (4, 5352, 70, 2, 2), (3, 6120, 100, 3, 1), (1, 6120, 100, 3, 3), (8, 4584, 40, 3, 0)])
+def test_limited_soft_buffer_and_redundancy_versions_on_large_blocks(ctx, port, tx_mode, tbs, nprb, mod, rv):
+    """Transmission modes 3 / 4 / 8 halve the soft buffer (K_MIMO = 2, liblte_phy.cc:11381-11386): for the largest code blocks N_cb drops
+    below K_w and the circular buffer wraps early -- the rank tables' odd combinations -- here with every redundancy version and heavy
+    repetition (one 40-100 PRB allocation for one code block).  Checker: the restatement, whose scratch is sized from the allocation
+    (the unmodified reference caps an allocation at 10 000 soft bits)."""
+    import openlte_amd as m
+    from openlte_amd import synth
+    cfg = m.DlCfg(2048, 100, 1, 0)
+    sf, cell = 7, 250
+    rx_alloc = [m.make_alloc(0, mod, tbs, list(range(nprb)), 0x321, rv, tx_mode)]  # the host transmitter maps on one port whatever the mode and
+    for snr in (30, 6):                                                           # takes its soft-buffer size from it, like the receiver
+        iq, tx = synth.dl_units(cfg, [sf], [cell], rx_alloc, 1, snr_db=snr, max_delay=4, seed=tbs + rv)
+        lc, s = td.oracle_frontend(port, 2048, 100, 1, iq[0], sf, cell)
+        err, out, desc = oracle_pdsch(port, lc, s, rx_alloc[0], 2, cell, 1)
+        d_sub = ctx.to_device(upload_oracle_subframe(ctx, s, 1))
+        plan = ctx.pdsch_plan(cfg, 2, rx_alloc)
+        st, bits = plan.run(d_sub, [sf], [cell])
+        assert (plan.soft_bits(0)[:len(desc)] == desc).all()
+        assert st[0] == err and (err != 0 or (bits[0] == out).all()), (snr, st[0], err)
+        if err == 0:  # (the K = 6144 block with half a soft buffer fails in the reference's decoder even at 30 dB: punctured, and its interleaver wraps)
+            assert (bits[0] == tx[0, 0, :tbs]).all(), (tx_mode, tbs)
+        plan.close()
+        d_sub.free()

@@ -296,20 +296,38 @@ int mi_ctx_gold_tables(mi_lte_ctx *ctx)
     return MI_LTE_OK;
 }
 
-// Forward-DFT twiddles exp(-2*pi*i*k/4096), evaluated in double and rounded once; every FFT size and every
-// Stockham pass reads this table with a stride (the odd entries serve the uplink's half-sub-carrier rotation).
+// Forward-DFT twiddles exp(-2*pi*i*k/4096), evaluated in double and rounded once (the odd entries serve the uplink's half-sub-carrier
+// rotation), followed by the per-pass tables the Stockham passes read (MI_FFT_TWC_* in ctx.hpp): for butterfly k of a radix-R pass over
+// sub-transforms of length Ns the entries w, w^2 (R >= 4), w^4 (R = 8) with w = exp(-2*pi*i*k/(Ns*R)), side by side -- the same values the
+// strided reads of the big table gave, but one or two 16-byte loads per butterfly out of a few cache lines per wavefront instead of three
+// 8-byte loads that touched up to 64 lines each (the front end's FFT spent a third of its time on those).
 int mi_ctx_fft_twiddles(mi_lte_ctx *ctx)
 {
     if (ctx->d_fft_tw) return MI_LTE_OK;
     const uint32_t N = 4096;
-    std::vector<float2> tw(N);
+    std::vector<float2> tw(N + MI_FFT_TWC_TOTAL, make_float2(0.0f, 0.0f));
     for (uint32_t k = 0; k < N; k++) {
         const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)N;
         tw[k] = make_float2((float)cos(a), (float)sin(a));
     }
-    MI_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_fft_tw, sizeof(float2) * N));
+    auto fill = [&](uint32_t off, uint32_t Ns, uint32_t R) { // entry k: tw[k * 4096 / (Ns * R)] and its 2nd / 4th power, R / 2 (at least 1) slots wide
+        const uint32_t st = N / (Ns * R), wd = R == 8 ? 4 : R == 4 ? 2 : 1;
+        for (uint32_t k = 0; k < Ns; k++) {
+            float2 *e = &tw[N + off + (size_t)k * wd];
+            e[0] = tw[k * st];
+            if (R >= 4) e[1] = tw[2 * k * st];
+            if (R == 8) e[2] = tw[4 * k * st];
+        }
+    };
+    fill(MI_FFT_TWC_P2, 8, 8);
+    fill(MI_FFT_TWC_P3, 64, 8);
+    fill(MI_FFT_TWC_L2048, 512, 4);
+    fill(MI_FFT_TWC_L1024, 512, 2);
+    fill(MI_FFT_TWC_L256, 64, 4);
+    fill(MI_FFT_TWC_L128, 64, 2);
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_fft_tw, sizeof(float2) * tw.size()));
     ctx->owned.push_back(ctx->d_fft_tw);
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_fft_tw, tw.data(), sizeof(float2) * N, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_fft_tw, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice, ctx->stream));
     MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return MI_LTE_OK;
 }

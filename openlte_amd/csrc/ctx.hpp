@@ -25,6 +25,12 @@ struct RmTables { // per-K rank tables of the fused turbo rate un-matching (see 
     uint32_t *d_nnn  = nullptr;
 };
 
+// Per-pass twiddle tables behind the 4096-entry table (offsets in float2 from d_fft_tw + 4096; see mi_ctx_fft_twiddles): second pass
+// (sub-transform length 8, radix 8: 4 slots per butterfly), third pass (64, radix 8; also the last pass of the 512-point transform),
+// and the last pass of the 2048 / 1024 / 256 / 128-point transforms (radix 4: 2 slots, radix 2: 1 slot)
+enum : uint32_t { MI_FFT_TWC_P2 = 0, MI_FFT_TWC_P3 = 32, MI_FFT_TWC_L2048 = 288, MI_FFT_TWC_L1024 = 1312, MI_FFT_TWC_L256 = 1824, MI_FFT_TWC_L128 = 1952,
+                  MI_FFT_TWC_TOTAL = 2016 };
+
 struct mi_lte_ctx {
     int                device = -1;
     hipStream_t        stream = nullptr;
@@ -42,7 +48,7 @@ struct mi_lte_ctx {
     uint32_t *d_gold_x1 = nullptr, *d_gold_x2b = nullptr;
     uint32_t  gold_words = 0;
 
-    float2   *d_fft_tw  = nullptr; // exp(-2*pi*i*k/4096), k = 0..4095 (mi_ctx_fft_twiddles)
+    float2   *d_fft_tw  = nullptr; // exp(-2*pi*i*k/4096), k = 0..4095, then the per-pass tables at 4096 + MI_FFT_TWC_* (mi_ctx_fft_twiddles)
     uint32_t *d_crc_tab = nullptr; // x^e mod gCRC24A, e = 0..6143
     float2   *d_prach_tab = nullptr; // chirp | filter spectrum | twiddles of the 839-point chirp-z transform (prach.hip)
 

@@ -69,16 +69,20 @@ template <int R> __device__ __forceinline__ void dftR(float2 *v)
     else dft2(v[0], v[1]);
 }
 
-// Twiddles w^1 .. w^(R-1) of one butterfly, w = exp(-2*pi*i*k/(Ns*R)), from the 4096-entry table:
-// w, w^2, w^4 are looked up (all below half a turn, so no index wrap), the rest are products.
-template <int R> __device__ __forceinline__ void twiddles(const float2 *__restrict__ tw, uint32_t k, uint32_t Ns, float2 (&w)[8])
+// Twiddles w^1 .. w^(R-1) of butterfly k of a radix-R pass, w = exp(-2*pi*i*k/(Ns*R)): w, w^2, w^4 come from the pass's own table
+// (ctx.hpp MI_FFT_TWC_*: R / 2 float2 slots per butterfly, side by side), the rest are products.
+template <int R> __device__ __forceinline__ void twiddles(const float2 *__restrict__ tc, uint32_t k, float2 (&w)[8])
 {
-    const uint32_t i1 = k * (4096u / (Ns * R));
-    w[1] = tw[i1];
-    if (R >= 4) { w[2] = tw[2 * i1]; w[3] = cmul(w[1], w[2]); }
-    if (R == 8) {
-        w[4] = tw[4 * i1];
-        w[5] = cmul(w[4], w[1]); w[6] = cmul(w[4], w[2]); w[7] = cmul(w[4], w[3]);
+    if (R == 2) w[1] = tc[k];
+    else {
+        const float4 a = *reinterpret_cast<const float4 *>(tc + (size_t)k * (R / 2));
+        w[1] = make_float2(a.x, a.y);
+        w[2] = make_float2(a.z, a.w);
+        w[3] = cmul(w[1], w[2]);
+        if (R == 8) {
+            w[4] = tc[(size_t)k * 4 + 2];
+            w[5] = cmul(w[4], w[1]); w[6] = cmul(w[4], w[2]); w[7] = cmul(w[4], w[3]);
+        }
     }
 }
 
@@ -87,8 +91,9 @@ __device__ __forceinline__ uint32_t pad(uint32_t i) { return i + (i >> 5); }
 
 // One Stockham pass of radix R over buf (N points, sub-transform length Ns so far).
 // SRC: 0 = LDS, 1 = gather from global int8/float samples.  DST: 0 = LDS, 1 = scatter to the symbol row.
+// tc: the pass's twiddle table (unused when Ns = 1)
 template <int R, typename LoadF, typename StoreF>
-__device__ __forceinline__ void fft_pass(const float2 *__restrict__ tw, uint32_t N, uint32_t Ns, LoadF load, StoreF store)
+__device__ __forceinline__ void fft_pass(const float2 *__restrict__ tc, uint32_t N, uint32_t Ns, LoadF load, StoreF store)
 {
     const uint32_t nb = N / R;
     for (uint32_t j = threadIdx.x; j < nb; j += blockDim.x) {
@@ -98,7 +103,7 @@ __device__ __forceinline__ void fft_pass(const float2 *__restrict__ tw, uint32_t
         const uint32_t k = j & (Ns - 1);
         if (Ns > 1) {
             float2 w[8];
-            twiddles<R>(tw, k, Ns, w);
+            twiddles<R>(tc, k, w);
 #pragma unroll
             for (int r = 1; r < R; r++) v[r] = cmul(v[r], w[r]);
         }
@@ -165,6 +170,7 @@ __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t
     auto ld_s = [&](uint32_t base, uint32_t r, uint32_t stride) { return at(base, r, stride); };
     const uint32_t dc = g.ul ? 0u : 1u; // downlink skips the DC bin, the half-shifted uplink grid has none
 
+    const float2 *__restrict__ twc = tw + 4096; // the per-pass tables
     const uint32_t sym = blockIdx.x;
     raw_t cur[8];
     fetch(sym, cur);
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t
             if (act) {
                 const uint32_t k = j & (Ns - 1);
                 float2 w[8];
-                twiddles<8>(tw, k, Ns, w);
+                twiddles<8>(twc + MI_FFT_TWC_P2, k, w);
 #pragma unroll
                 for (int r = 1; r < 8; r++) v[r] = cmul(v[r], w[r]);
                 dft8(v);
@@ -214,9 +220,9 @@ __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t
             Ns *= 8;
         }
         __syncthreads();
-        if (N == 128) fft_pass<2>(tw, N, Ns, ld_s, st_g);
-        else if (N == 256) fft_pass<4>(tw, N, Ns, ld_s, st_g);
-        else if (N == 512) fft_pass<8>(tw, N, Ns, ld_s, st_g);
+        if (N == 128) fft_pass<2>(twc + MI_FFT_TWC_L128, N, Ns, ld_s, st_g);
+        else if (N == 256) fft_pass<4>(twc + MI_FFT_TWC_L256, N, Ns, ld_s, st_g);
+        else if (N == 512) fft_pass<8>(twc + MI_FFT_TWC_P3, N, Ns, ld_s, st_g);
         else {
             {   // third radix-8 pass in place
                 float2 v[8];
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t
                 if (act) {
                     const uint32_t k = j & (Ns - 1);
                     float2 w[8];
-                    twiddles<8>(tw, k, Ns, w);
+                    twiddles<8>(twc + MI_FFT_TWC_P3, k, w);
 #pragma unroll
                     for (int r = 1; r < 8; r++) v[r] = cmul(v[r], w[r]);
                     dft8(v);
@@ -239,8 +245,8 @@ __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t
                 Ns *= 8;
             }
             __syncthreads();
-            if (N == 1024) fft_pass<2>(tw, N, Ns, ld_s, st_g);
-            else           fft_pass<4>(tw, N, Ns, ld_s, st_g);
+            if (N == 1024) fft_pass<2>(twc + MI_FFT_TWC_L1024, N, Ns, ld_s, st_g);
+            else           fft_pass<4>(twc + MI_FFT_TWC_L2048, N, Ns, ld_s, st_g);
         }
     }
 }

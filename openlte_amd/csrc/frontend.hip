@@ -268,11 +268,10 @@ __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t
 __global__ __launch_bounds__(256) void k_dl_ce(const uint32_t *__restrict__ subfr_num, const uint32_t *__restrict__ n_id_cell,
                                                DlGeom g, GoldTables gt, float *__restrict__ subframes)
 {
-    extern __shared__ __attribute__((aligned(16))) float sm[]; // mag[5][N_sc] ang[5][N_sc]
+    extern __shared__ __attribute__((aligned(16))) float sm[]; // mag[n_i][N_sc] ang[n_i][N_sc]
     __shared__ uint32_t crs_bits[5][14];
     const uint32_t unit = blockIdx.x, p = blockIdx.y, N_sc = 12 * g.N_rb_dl, n_pil = 2 * g.N_rb_dl;
     const uint32_t sf = subfr_num[unit], cell = n_id_cell[unit], v_shift = cell % 6;
-    float *mag = sm, *ang = sm + 5 * N_sc;
     float *base   = subframes + (size_t)unit * g.sf_stride;
     const float *sym_re = base, *sym_im = base + 16 * N_SC_MAX;
     float *ce_re = base + 2 * 16 * N_SC_MAX + (size_t)p * 16 * N_SC_MAX;
@@ -281,6 +280,11 @@ __global__ __launch_bounds__(256) void k_dl_ce(const uint32_t *__restrict__ subf
     // CRS symbols / frequency offsets of this port (liblte_phy.cc:5973-6014), as select chains so
     // that nothing is indexed dynamically out of registers
     const uint32_t N_sym = (p < 2) ? 5 : 3;
+    // The CRS symbols are independent until the time interpolation.  The compact form stops before it, so there a workgroup is ONE
+    // wavefront working on ONE CRS symbol (blockIdx.z): a fifth of the LDS (five times the resident workgroups), no wavefront waiting
+    // at a barrier while another walks the unwrap, and the serial part of a subframe's estimate spread over five workgroups.
+    const uint32_t i_lo = g.ce_compact ? blockIdx.z : 0u, i_hi = g.ce_compact ? i_lo + 1 : N_sym, n_i = i_hi - i_lo;
+    float *mag = sm, *ang = sm + n_i * N_sc; // row r = CRS symbol i_lo + r
     auto sym_of = [p](uint32_t i) -> uint32_t {
         return (p < 2) ? (i == 0 ? 0u : i == 1 ? 4u : i == 2 ? 7u : i == 3 ? 11u : 14u) : (i == 0 ? 1u : i == 1 ? 8u : 15u);
     };
@@ -289,25 +293,25 @@ __global__ __launch_bounds__(256) void k_dl_ce(const uint32_t *__restrict__ subf
     };
 
     // CRS bits (generate_crs, liblte_phy.cc:8300-8333; slots per :5960-5967)
-    if (threadIdx.x < N_sym * 14) {
-        const uint32_t i = threadIdx.x / 14, w = threadIdx.x % 14;
+    if (threadIdx.x < n_i * 14) {
+        const uint32_t i = i_lo + threadIdx.x / 14, w = threadIdx.x % 14;
         const uint32_t ns = (sf * 2 + sym_of(i) / 7) % 20, l = sym_of(i) % 7;
         const uint32_t c_init = 1024 * (7 * (ns + 1) + l + 1) * (2 * cell + 1) + 2 * cell + 1;
-        crs_bits[i][w] = gold_word(gt, c_init, w);
+        crs_bits[i - i_lo][w] = gold_word(gt, c_init, w);
     }
     __syncthreads();
 
     // least-squares estimate at every pilot (liblte_phy.cc:6023-6030)
     const float r2 = (float)(1.0 / sqrt(2.0));
-    for (uint32_t t = threadIdx.x; t < N_sym * n_pil; t += blockDim.x) {
-        const uint32_t i = t / n_pil, j = t % n_pil;
+    for (uint32_t t = threadIdx.x; t < n_i * n_pil; t += blockDim.x) {
+        const uint32_t ri = t / n_pil, i = i_lo + ri, j = t % n_pil;
         const uint32_t k = 6 * j + (voff_of(i) + v_shift) % 6, mp = j + 110 - g.N_rb_dl;
-        const uint32_t b0 = (crs_bits[i][(2 * mp) >> 5] >> ((2 * mp) & 31)) & 1u, b1 = (crs_bits[i][(2 * mp + 1) >> 5] >> ((2 * mp + 1) & 31)) & 1u;
+        const uint32_t b0 = (crs_bits[ri][(2 * mp) >> 5] >> ((2 * mp) & 31)) & 1u, b1 = (crs_bits[ri][(2 * mp + 1) >> 5] >> ((2 * mp + 1) & 31)) & 1u;
         const float rs_re = r2 * (1 - 2 * (float)b0), rs_im = r2 * (1 - 2 * (float)b1);
         const float s_re = sym_re[sym_of(i) * N_SC_MAX + k], s_im = sym_im[sym_of(i) * N_SC_MAX + k];
         const float t_re = s_re * rs_re + s_im * rs_im, t_im = s_im * rs_re - s_re * rs_im;
-        mag[i * N_sc + k] = sqrtf(t_re * t_re + t_im * t_im);
-        ang[i * N_sc + k] = atan2f(t_im, t_re);
+        mag[ri * N_sc + k] = sqrtf(t_re * t_re + t_im * t_im);
+        ang[ri * N_sc + k] = atan2f(t_im, t_re);
     }
     __syncthreads();
     // unwrap along frequency (liblte_phy.cc:6033-6035): u_0 = r_0, u_j = wrap_phase(r_j, u_{j-1}).  The chain is
@@ -319,9 +323,9 @@ __global__ __launch_bounds__(256) void k_dl_ce(const uint32_t *__restrict__ subf
     {
         const uint32_t wave = threadIdx.x >> 6, ln = threadIdx.x & 63, n_wave = blockDim.x >> 6;
         const uint32_t C = (n_pil + 63) / 64; // pilots per lane (<= 4 for 100 RB)
-        for (uint32_t i = wave; i < N_sym; i += n_wave) {
+        for (uint32_t i = i_lo + wave; i < i_hi; i += n_wave) {
             const uint32_t off = (voff_of(i) + v_shift) % 6;
-            float *a = ang + i * N_sc + off;
+            float *a = ang + (i - i_lo) * N_sc + off;
             float  r[4], uu[4];
             int    c[4], run = 0;
             float  rprev = (ln > 0 && (ln * C - 1) < n_pil) ? a[6 * (ln * C - 1)] : 0.0f;
@@ -385,11 +389,11 @@ __global__ __launch_bounds__(256) void k_dl_ce(const uint32_t *__restrict__ subf
     __syncthreads();
     // frequency interpolation between pilots, edges continue the first / last slope
     // (liblte_phy.cc:6037-6063; repeated subtraction kept to reproduce the rounding)
-    for (uint32_t t = threadIdx.x; t < N_sym * n_pil; t += blockDim.x) {
-        const uint32_t i = t / n_pil, j = t % n_pil;
+    for (uint32_t t = threadIdx.x; t < n_i * n_pil; t += blockDim.x) {
+        const uint32_t ri = t / n_pil, i = i_lo + ri, j = t % n_pil;
         if (j == 0) continue;
         const uint32_t off = (voff_of(i) + v_shift) % 6, k = 6 * j + off;
-        float *m = mag + i * N_sc, *a = ang + i * N_sc;
+        float *m = mag + ri * N_sc, *a = ang + ri * N_sc;
         const float fm = (m[k] - m[k - 6]) / 6, fa = (a[k] - a[k - 6]) / 6;
         float cm = m[k], ca = a[k];
         for (uint32_t z = 1; z < 6; z++) { cm -= fm; ca -= fa; m[k - z] = cm; a[k - z] = ca; }
@@ -409,10 +413,10 @@ __global__ __launch_bounds__(256) void k_dl_ce(const uint32_t *__restrict__ subf
         // code as below), so what leaves this kernel is the magnitude / phase rows at the CRS symbols -- rows 0..N_sym-1 of the port's
         // real-part plane hold mag, the same rows of its imaginary-part plane hold ang
         const uint32_t nq = N_sc >> 2; // N_sc is a multiple of 12
-        for (uint32_t t = threadIdx.x; t < N_sym * nq; t += blockDim.x) {
-            const uint32_t i = t / nq, c = t - i * nq;
-            reinterpret_cast<float4 *>(ce_re + i * N_SC_MAX)[c] = reinterpret_cast<const float4 *>(mag + i * N_sc)[c];
-            reinterpret_cast<float4 *>(ce_im + i * N_SC_MAX)[c] = reinterpret_cast<const float4 *>(ang + i * N_sc)[c];
+        for (uint32_t t = threadIdx.x; t < n_i * nq; t += blockDim.x) {
+            const uint32_t ri = t / nq, i = i_lo + ri, c = t - ri * nq;
+            reinterpret_cast<float4 *>(ce_re + i * N_SC_MAX)[c] = reinterpret_cast<const float4 *>(mag + ri * N_sc)[c];
+            reinterpret_cast<float4 *>(ce_im + i * N_SC_MAX)[c] = reinterpret_cast<const float4 *>(ang + ri * N_sc)[c];
         }
         return;
     }
@@ -500,8 +504,13 @@ extern "C" int mi_lte_dl_frontend_batch(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cf
     } else
         return MI_LTE_ERR_INVALID_ARG;
     GoldTables gt{ctx->d_gold_x1, ctx->d_gold_x2b, ctx->gold_words};
-    const size_t lds_ce = sizeof(float) * 10 * 12 * g.N_rb_dl;
-    MI_LAUNCH(ctx, "k_dl_ce", k_dl_ce, dim3(n_units, g.N_ant), dim3(256), lds_ce, d_subfr_num, d_n_id_cell, g, gt, d_subframes);
+    if (g.ce_compact) { // one wavefront per (unit, CRS symbol); single-port cells only, so five symbols
+        const size_t lds_ce = sizeof(float) * 2 * 12 * g.N_rb_dl;
+        MI_LAUNCH(ctx, "k_dl_ce", k_dl_ce, dim3(n_units, g.N_ant, 5), dim3(64), lds_ce, d_subfr_num, d_n_id_cell, g, gt, d_subframes);
+    } else {
+        const size_t lds_ce = sizeof(float) * 10 * 12 * g.N_rb_dl;
+        MI_LAUNCH(ctx, "k_dl_ce", k_dl_ce, dim3(n_units, g.N_ant), dim3(256), lds_ce, d_subfr_num, d_n_id_cell, g, gt, d_subframes);
+    }
     MI_HIP_CHECK(ctx, hipGetLastError());
     ctx->last_kernels = "k_dl_fft:1,k_dl_ce:1";
     return MI_LTE_OK;

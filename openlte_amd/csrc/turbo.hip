@@ -61,6 +61,15 @@ __device__ __forceinline__ uint32_t neg_mask(v2s d)
     return m;
 }
 __device__ __forceinline__ v2s bit_select(uint32_t m, v2s yes, v2s no) { return as_v2s((as_u32(yes) & m) | (as_u32(no) & ~m)); }
+// (a + b) >> 1 per half, for sums that fit their 16 bits (magnitudes <= 127 here).  The sum is made opaque: the compiler otherwise
+// recognises the "average" idiom and, having no such instruction, expands it into the overflow-safe (a & b) + ((a ^ b) >> 1) -- four
+// instructions (some of them split per half) where these two do.
+__device__ __forceinline__ v2s half_sum(v2s a, v2s b)
+{
+    uint32_t t = as_u32(a + b);
+    asm("" : "+v"(t));
+    return as_v2s(t) >> 1;
+}
 
 // sign * ((|a|+|b|) >> 1), sign negative iff exactly one operand is negative (0 counts as positive).
 // This one form covers the four branches of Step 3 (liblte_phy.cc:10688-10707) and the g=03 soft
@@ -956,7 +965,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SISO_WPE, 8
 struct SM { v2s m; uint32_t s; }; // |x| and the sign mask of a pair
 __device__ __forceinline__ SM   to_sm(v2s x) { return SM{abs2(x), neg_mask(x)}; }
 __device__ __forceinline__ v2s  to_tc(const SM &a) { return as_v2s(as_u32(a.m) ^ a.s) - as_v2s(a.s); } // back to two's complement
-__device__ __forceinline__ SM   sxor_sm(const SM &a, const SM &b) { return SM{(a.m + b.m) >> 1, a.s ^ b.s}; }
+__device__ __forceinline__ SM   sxor_sm(const SM &a, const SM &b) { return SM{half_sum(a.m, b.m), a.s ^ b.s}; }
 struct UnitWords { uint32_t w[5]; }; // halo word, then the unit's four words
 __device__ __forceinline__ UnitWords load_unit_words(const uint8_t *arr, size_t tile_off, uint32_t lane, uint32_t u)
 {
@@ -994,7 +1003,7 @@ __device__ __forceinline__ void feedback_sm(const WordPairs &cur, const WordPair
     fo = sxor_full(d2o, d2e);
 }
 // soft_xor(a, f) in two's complement
-__device__ __forceinline__ v2s sxor_tc(const SM &a, const SX &f) { return to_tc(SM{(a.m + f.m) >> 1, a.s ^ f.s}); }
+__device__ __forceinline__ v2s sxor_tc(const SM &a, const SX &f) { return to_tc(SM{half_sum(a.m, f.m), a.s ^ f.s}); }
 
 // ------------------------------------------------------------------------------------------------
 // perm: Steps 2, 3, 5 and the pass-3 output magnitudes.  One workgroup per code block.
@@ -1111,9 +1120,9 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                 // Step 10 (liblte_phy.cc:10778-10797), as selects: equal signs -> (|B|+|G|)>>1; B >= 0 > G -> -((A - G) >> 1);
                 // B < 0 <= G -> -((-A + G) >> 1) -- the mixed-sign branches read in_act_1 (A), not int_act_1
                 const v2s dAG = At - G.tc, t = as_v2s(as_u32(dAG) ^ B.s) - as_v2s(B.s); // (B >= 0) ? A - G : G - A
-                const v2s v1  = bit_select(B.s ^ G.s, (v2s)(0) - (t >> 1), (B.m + G.m) >> 1);
+                const v2s v1  = bit_select(B.s ^ G.s, (v2s)(0) - (t >> 1), half_sum(B.m, G.m));
                 // Step 11 (liblte_phy.cc:10800-10819): mixed signs -> -((B - G) >> 1) resp. -((-B - G) >> 1), i.e. -((|B| - G) >> 1)
-                const v2s v2  = bit_select(B_.s ^ G_.s, (v2s)(0) - ((B_.m - G_.tc) >> 1), (B_.m + G_.m) >> 1);
+                const v2s v2  = bit_select(B_.s ^ G_.s, (v2s)(0) - ((B_.m - G_.tc) >> 1), half_sum(B_.m, G_.m));
                 d[h] = v1 + v2;
                 const v2s c1 = sxor_tc(A, h ? fo : fe); // Steps 2-3
                 (h ? s0o[j] : s0e[j]) = (h ? odd2(x0w[j]) : even2(x0w[j])) + c1;

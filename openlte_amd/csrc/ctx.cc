@@ -334,17 +334,26 @@ int mi_ctx_fft_twiddles(mi_lte_ctx *ctx)
 
 // CRC24A (36.212 5.1.1, g = 0x1864CFB; reference calc_crc, liblte_phy.cc:9713-9743) is linear over
 // GF(2): a(x)*x^24 mod g == p(x) exactly when the XOR of x^e mod g over the set bits of the whole
-// block a|p (e = distance of the bit from the end of the block) is zero.  tab[e] = x^e mod g.
+// block a|p (e = distance of the bit from the end of the block) is zero.
+// tab[MI_CRC_TAB_BIAS + e] = (x^e mod g) << 8 for e = -8 .. 6143: the remainder sits in the upper 24 bits, so that "times x" is a shift,
+// the sign bit and one conditional XOR (k_turbo_vote derives a unit's sixteen weights from one entry that way); the eight negative
+// exponents let the short last unit of a K % 16 == 8 block start from the same relative position as a full one.
 int mi_ctx_crc_table(mi_lte_ctx *ctx)
 {
     if (ctx->d_crc_tab) return MI_LTE_OK;
-    const uint32_t N = 6144;
+    const uint32_t N = 6144 + MI_CRC_TAB_BIAS;
     std::vector<uint32_t> tab(N);
     uint32_t r = 1; // x^0
-    for (uint32_t e = 0; e < N; e++) {
-        tab[e] = r;
+    for (uint32_t e = 0; e < 6144; e++) {
+        tab[MI_CRC_TAB_BIAS + e] = r << 8;
         r <<= 1;
         if (r & 0x1000000u) r ^= 0x1864CFBu;
+    }
+    r = 1;
+    for (uint32_t e = 1; e <= MI_CRC_TAB_BIAS; e++) { // x^-e: divide by x (g's constant term is 1, so x is invertible)
+        if (r & 1u) r ^= 0x1864CFBu;
+        r >>= 1;
+        tab[MI_CRC_TAB_BIAS - e] = r << 8;
     }
     MI_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_crc_tab, sizeof(uint32_t) * N));
     ctx->owned.push_back(ctx->d_crc_tab);

@@ -31,6 +31,8 @@ struct RmTables { // per-K rank tables of the fused turbo rate un-matching (see 
 enum : uint32_t { MI_FFT_TWC_P2 = 0, MI_FFT_TWC_P3 = 32, MI_FFT_TWC_L2048 = 288, MI_FFT_TWC_L1024 = 1312, MI_FFT_TWC_L256 = 1824, MI_FFT_TWC_L128 = 1952,
                   MI_FFT_TWC_TOTAL = 2016 };
 
+constexpr uint32_t MI_CRC_TAB_BIAS = 8;
+
 struct mi_lte_ctx {
     int                device = -1;
     hipStream_t        stream = nullptr;
@@ -49,7 +51,7 @@ struct mi_lte_ctx {
     uint32_t  gold_words = 0;
 
     float2   *d_fft_tw  = nullptr; // exp(-2*pi*i*k/4096), k = 0..4095, then the per-pass tables at 4096 + MI_FFT_TWC_* (mi_ctx_fft_twiddles)
-    uint32_t *d_crc_tab = nullptr; // x^e mod gCRC24A, e = 0..6143
+    uint32_t *d_crc_tab = nullptr; // (x^e mod gCRC24A) << 8 at index MI_CRC_TAB_BIAS + e, e = -8..6143 (mi_ctx_crc_table)
     float2   *d_prach_tab = nullptr; // chirp | filter spectrum | twiddles of the 839-point chirp-z transform (prach.hip)
 
     // optional per-launch HIP-event bracketing (mi_lte_profile_*): pairs are resolved at report time

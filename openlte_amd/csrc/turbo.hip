@@ -293,7 +293,7 @@ struct GroupDesc {                 // one launch = the code blocks of one size K
     uint8_t        *out_bits;      // [n_alloc][out_stride] decoded transport block, one bit per byte
     uint32_t        out_stride;
     int32_t        *status;        // [n_alloc] LIBLTE_ERROR_ENUM value
-    const uint32_t *crc_tab;       // x^e mod gCRC24A for e = 0..6143
+    const uint32_t *crc_tab;       // (x^e mod gCRC24A) << 8 at index MI_CRC_TAB_BIAS + e (ctx.cc)
     uint32_t        ul;            // 1: UL-SCH soft-buffer rule (N_cb = K_w: chan_type ULSCH, liblte_phy.cc:11387-11398, :12437-12449)
     uint32_t        packed;        // 1: out_bits holds eight bits per byte, first bit in the most significant position (liblte_value_2_bits order)
 };
@@ -1095,6 +1095,9 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         vraw.lo = ip[0];
         vraw.hi = ip[1];
     }
+    // ... and so is the CRC weight of the unit's LAST position (GROUP): bit j of the block weighs x^(K-1-j) mod g, so position 16u + 15
+    // weighs entry K - 16u - 16 (a short last unit of eight bits: the same expression, a negative exponent, its upper eight positions masked)
+    const uint32_t crc_w0 = (GROUP && nv > 0) ? g.crc_tab[MI_CRC_TAB_BIAS + K - 16 * u - 16] : 0u;
     v2s            s0e[4], s0o[4]; // s0 = q(d0) + C1, the part of the vote that is not de-interleaved
     if (threadIdx.x == 0) *reinterpret_cast<uint32_t *>(d12 + 2 * Kp) = 0u; // what a hole of the de-interleaver reads
     if (nv >= 0) {
@@ -1159,27 +1162,28 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
             bw[j] = (me[j] & 0x00010001u) | (mo[j] & 0x00010001u) << 8; // Step 14
         }
         if (GROUP) {
-            // CRC24A over the block without its F filler bits: bit j of the block weighs x^(K-1-j) mod g (the
-            // 24 parity bits weigh themselves), so the check "calc_crc(a) == p" is "XOR of the weights == 0".
-            // Weights of this unit = 16 (8) consecutive table entries, descending in j.
-            const uint4   *tp = reinterpret_cast<const uint4 *>(g.crc_tab + (K - 16 * u - nv)); // 32-byte aligned (K % 8 == 0)
-            const uint4    t0 = tp[0], t1 = tp[1], t2 = (nv > 8) ? tp[2] : t0, t3 = (nv > 8) ? tp[3] : t0;
-            const uint32_t tw[16] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w, t3.x, t3.y, t3.z, t3.w};
-            if (nv == 16 && 16 * u >= F) { // a whole unit of payload: no per-bit predicate
+            // CRC24A over the block without its F filler bits: bit j of the block weighs x^(K-1-j) mod g (the 24 parity bits weigh
+            // themselves), so the check "calc_crc(a) == p" is "XOR of the weights of the set bits == 0".  The sixteen weights of a unit are
+            // x^0 .. x^15 times the weight of its last position: one table entry, then fifteen "times x" steps (shift, sign, conditional XOR
+            // of g) -- the table itself, read sixteen entries per thread by every workgroup of the launch, cost the kernel a quarter of
+            // its time in cache traffic.
+            if (!(nv == 16 && 16 * u >= F)) { // a unit with filler or past the block end: clear the decisions that do not count
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    crc ^= tw[15 - 4 * j] & (uint32_t)__builtin_amdgcn_sbfe(me[j], 0, 1);
-                    crc ^= tw[14 - 4 * j] & (uint32_t)__builtin_amdgcn_sbfe(mo[j], 0, 1);
-                    crc ^= tw[13 - 4 * j] & (uint32_t)((int)me[j] >> 31);
-                    crc ^= tw[12 - 4 * j] & (uint32_t)((int)mo[j] >> 31);
+                    auto ok = [&](int k) { return (k < nv && 16 * u + k >= F) ? 0xFFFFu : 0u; };
+                    me[j] &= ok(4 * j) | ok(4 * j + 2) << 16;
+                    mo[j] &= ok(4 * j + 1) | ok(4 * j + 3) << 16;
                 }
-            } else {
+            }
+            const uint32_t GS = 0x864CFBu << 8; // g without its x^24 term, in the table's left-aligned form
+            uint32_t       w = crc_w0;
 #pragma unroll
-                for (int k = 0; k < 16; k++) { // static register indices only: nv is 16, or 8 in the last unit of a K % 16 == 8 block
-                    const uint32_t wgt = (nv > 8) ? tw[15 - k] : tw[(7 - k) & 15];
-                    const bool     b   = (bw[k >> 2] >> (8 * (k & 3))) & 1u;
-                    crc ^= (b && 16 * u + k >= F && k < nv) ? wgt : 0u;
-                }
+            for (int k = 15; k >= 0; k--) {
+                const int      j = k >> 2;
+                const uint32_t m = (k & 3) == 0 ? (uint32_t)__builtin_amdgcn_sbfe(me[j], 0, 1) : (k & 3) == 1 ? (uint32_t)__builtin_amdgcn_sbfe(mo[j], 0, 1)
+                                 : (k & 3) == 2 ? (uint32_t)((int)me[j] >> 31) : (uint32_t)((int)mo[j] >> 31);
+                crc ^= w & m;
+                if (k > 0) w = (w << 1) ^ ((uint32_t)((int)w >> 31) & GS);
             }
         }
         const uint4 pk = make_uint4(bw[0], bw[1], bw[2], bw[3]);
@@ -1359,7 +1363,7 @@ __global__ __launch_bounds__(256) void k_crc_finish(const uint8_t *__restrict__ 
     uint32_t crc = 0;
     for (uint32_t j = F + threadIdx.x; j < K; j += blockDim.x) {
         const uint32_t b = c[j] & 1u;
-        crc ^= b ? g.crc_tab[K - 1 - j] : 0u; // bit j weighs x^(K-1-j) mod gCRC24A; the check is "XOR of the weights == 0"
+        crc ^= b ? g.crc_tab[MI_CRC_TAB_BIAS + K - 1 - j] : 0u; // bit j weighs x^(K-1-j) mod gCRC24A; the check is "XOR of the weights == 0"
         if (j < F + tbs && !g.packed) o[j - F] = (uint8_t)b;
     }
     if (g.packed)

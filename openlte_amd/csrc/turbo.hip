@@ -822,9 +822,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SISO_WPE, 8
 #pragma unroll
     for (int s = 0; s < 8; s++) pm[s] = (v2s)(0); // all path metrics start at 0 (liblte_phy.cc:10411-10418)
 
-    // ---- forward add-compare-select.  A block is 64 steps = one 64-byte line per input and trellis, held as four quarters; a
-    // quarter's registers are refilled with the next block's data as soon as its 16 steps are done, so the loads run
-    // three quarters of a block ahead
+    // ---- forward add-compare-select.  A block is 64 steps = one 64-byte line per input and trellis, held as four quarters whose
+    // registers are refilled with the next block's data while the current block's last quarter(s) are walked
     uint4 A[2][4], B[2][4];
 #pragma unroll
     for (int h = 0; h < 2; h++)
@@ -859,10 +858,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SISO_WPE, 8
                 dw[0][g] = __builtin_amdgcn_perm(acc_lo, acc_hi, 0x05040100u); // steps 0-3 in the upper half, 4-7 in the lower
                 dw[1][g] = __builtin_amdgcn_perm(acc_lo, acc_hi, 0x07060302u);
             }
+            // refill for the next block: quarters 0-2 together once the third quarter is done, the last quarter after itself.  The three
+            // loads of a lane hit the same 64-byte line back to back (one L2 request, two L1 hits); refilling each quarter as soon as it
+            // was free spread the four loads of a line over a block's worth of steps, and each of them went to the L2 on its own
+            if (q >= 2) {
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                A[h][q] = reinterpret_cast<const uint4 *>(pa[h] + (size_t)nxt * 4096)[q];
-                B[h][q] = reinterpret_cast<const uint4 *>(pb[h] + (size_t)nxt * 4096)[q];
+                for (int qq = (q == 2 ? 0 : 3); qq <= (q == 2 ? 2 : 3); qq++)
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        A[h][qq] = reinterpret_cast<const uint4 *>(pa[h] + (size_t)nxt * 4096)[qq];
+                        B[h][qq] = reinterpret_cast<const uint4 *>(pb[h] + (size_t)nxt * 4096)[qq];
+                    }
             }
         }
 #pragma unroll

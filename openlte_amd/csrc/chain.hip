@@ -6,6 +6,7 @@
 // SURVEY F4).
 #include <algorithm>
 #include <map>
+#include <type_traits>
 
 #include "ctx.hpp"
 #include "phy_dev.hpp"
@@ -114,7 +115,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
     const uint32_t n_grp = M_ap / N_ant, M_symb = n_grp * N_ant, N_bits = M_symb * Qm;
     if (threadIdx.x == 0) e_len[a_idx] = N_bits;
 
-    // ---- phase 3: per group of N_ant REs: gather, pre-decode, de-map, descramble
+    // ---- phase 3: per group of N_ant REs: gather, pre-decode, de-map, descramble.  The modulation is uniform over the workgroup: the whole
+    // phase is instantiated per modulation (`run` below), so that the per-element code holds no modulation branch, no re-read of the
+    // allocation descriptor and compile-time bit counts -- as one generic routine it was a dozen scalar branches and a scalar load per element
     const float *base = subframes + (size_t)unit * g.sf_stride;
     const float *y_re_p = base, *y_im_p = base + 16 * N_SC_MAX;
     const float *h_re_p = base + 2 * 16 * N_SC_MAX, *h_im_p = h_re_p + (size_t)N_ant * 16 * N_SC_MAX;
@@ -132,16 +135,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
     // soft bits are assembled in LDS when they fit and leave with 16-byte stores
     int8_t    *e_lds  = reinterpret_cast<int8_t *>(cw + max_words);
     const bool via_lds = N_bits <= e_lds_cap;
+    auto run = [&](auto modc) {
+    constexpr uint32_t MOD = decltype(modc)::value, QM = MOD == 3 ? 6 : MOD == 2 ? 4 : MOD == 1 ? 2 : 1;
+    constexpr bool     QAM = MOD >= 2;
     // descramble + store the Q_m soft bits of symbol idx: c bit set -> negate (liblte_phy.cc:3833-3836).
     // Q_m*idx is even for Q_m >= 2, so pairs of bytes leave as one 16-bit store.
     auto put_bits = [&](auto *dst, uint32_t idx, const int8_t (&b)[6]) {
-        const uint32_t n0 = idx * Qm, w = n0 >> 5, sh = n0 & 31;
+        const uint32_t n0 = idx * QM, w = n0 >> 5, sh = n0 & 31;
         const uint32_t c = __builtin_amdgcn_alignbit(cw[w + 1], cw[w], sh); // bits n0.. of the scrambling sequence (cw is padded by one word)
-        if (Qm == 1) dst[n0] = (c & 1u) ? (int8_t)-b[0] : b[0];
+        if (QM == 1) dst[n0] = (c & 1u) ? (int8_t)-b[0] : b[0];
         else {
 #pragma unroll
             for (uint32_t k = 0; k < 6; k += 2)
-                if (k < Qm) {
+                if (k < QM) {
                     const int lo = ((c >> k) & 1u) ? -b[k] : b[k], hi = ((c >> (k + 1)) & 1u) ? -b[k + 1] : b[k + 1];
                     *reinterpret_cast<uint16_t *>(dst + n0 + k) = (uint16_t)((lo & 0xFF) | ((hi & 0xFF) << 8));
                 }
@@ -150,17 +156,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
     // 16QAM / 64QAM: every soft bit is +-127, so a symbol is its mask of negative bits; XOR with the scrambling bits and one table
     // read give the Q_m bytes (4: one store; 6: three 16-bit stores, the symbol starts on an even address)
     auto put_qam = [&](auto *dst, uint32_t idx, uint32_t neg) {
-        const uint32_t n0 = Qm == 4 ? idx << 2 : (idx << 2) + (idx << 1), w = n0 >> 5, sh = n0 & 31;
+        const uint32_t n0 = QM == 4 ? idx << 2 : (idx << 2) + (idx << 1), w = n0 >> 5, sh = n0 & 31;
         const uint32_t c  = __builtin_amdgcn_alignbit(cw[w + 1], cw[w], sh);
-        const uint2    v  = qam_lut[(neg ^ c) & (Qm == 4 ? 15u : 63u)];
-        if (Qm == 4) *reinterpret_cast<uint32_t *>(dst + n0) = v.x;
+        const uint2    v  = qam_lut[(neg ^ c) & (QM == 4 ? 15u : 63u)];
+        if (QM == 4) *reinterpret_cast<uint32_t *>(dst + n0) = v.x;
         else {
             *reinterpret_cast<uint16_t *>(dst + n0)     = (uint16_t)v.x;
             *reinterpret_cast<uint16_t *>(dst + n0 + 2) = (uint16_t)(v.x >> 16);
             *reinterpret_cast<uint16_t *>(dst + n0 + 4) = (uint16_t)v.y;
         }
     };
-    const bool qam = al.mod_type >= 2; // uniform
     if (ONE_PORT && COMPACT) {
         // MI_LTE_CE_COMPACT: the estimate arrives as magnitude / phase rows at the five CRS symbols (mag in the real-part plane, phase in
         // the imaginary-part plane, rows 0-4).  One thread per (slot, PRB, sub-carrier): it loads the ten values of its sub-carrier, runs the
@@ -192,10 +197,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
                     const float mm = m[t], hr = mm * cs, hi = mm * sn;
                     const float hn = hr * hr + hi * hi;
                     const float xr = (yr[t] * hr + yi[t] * hi) / hn, xi = (yi[t] * hr - yr[t] * hi) / hn;
-                    if (qam) put_qam(dst, idx, qam_neg_bits(xr, xi, al.mod_type));
+                    if (QAM) put_qam(dst, idx, qam_neg_bits(xr, xi, MOD));
                     else {
                         int8_t b[6] = {0, 0, 0, 0, 0, 0};
-                        demap_symbol(xr, xi, al.mod_type, b);
+                        demap_symbol(xr, xi, MOD, b);
                         put_bits(dst, idx, b);
                     }
                 }
@@ -230,10 +235,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
                     if (!on[r]) continue;
                     const float hn = hr[r] * hr[r] + hi[r] * hi[r];
                     const float xr = (yr[r] * hr[r] + yi[r] * hi[r]) / hn, xi = (yi[r] * hr[r] - yr[r] * hi[r]) / hn;
-                    if (qam) put_qam(dst, idx[r], qam_neg_bits(xr, xi, al.mod_type));
+                    if (QAM) put_qam(dst, idx[r], qam_neg_bits(xr, xi, MOD));
                     else {
                         int8_t b[6] = {0, 0, 0, 0, 0, 0};
-                        demap_symbol(xr, xi, al.mod_type, b);
+                        demap_symbol(xr, xi, MOD, b);
                         put_bits(dst, idx[r], b);
                     }
                 }
@@ -273,15 +278,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
         }
         // layer de-mapping d[i*N_ant + p] = x_p[i] (liblte_phy.cc:7506-7513), de-map, descramble (:3833-3836)
         for (uint32_t p = 0; p < N_ant; p++) {
-            if (qam) {
-                const uint32_t neg = qam_neg_bits(x_re[p], x_im[p], al.mod_type);
+            if (QAM) {
+                const uint32_t neg = qam_neg_bits(x_re[p], x_im[p], MOD);
                 if (via_lds) put_qam(e_lds, i * N_ant + p, neg); else put_qam(e, i * N_ant + p, neg);
                 continue;
             }
             int8_t b[6] = {0, 0, 0, 0, 0, 0};
-            demap_symbol(x_re[p], x_im[p], al.mod_type, b);
+            demap_symbol(x_re[p], x_im[p], MOD, b);
             if (via_lds) put_bits(e_lds, i * N_ant + p, b); else put_bits(e, i * N_ant + p, b);
         }
+    }
+    };
+    switch (al.mod_type) {
+    case 0:  run(std::integral_constant<uint32_t, 0>{}); break;
+    case 1:  run(std::integral_constant<uint32_t, 1>{}); break;
+    case 2:  run(std::integral_constant<uint32_t, 2>{}); break;
+    default: run(std::integral_constant<uint32_t, 3>{}); break;
     }
     if (via_lds) {
         __syncthreads();

@@ -284,6 +284,11 @@ struct RmGeom {
     }
 };
 
+// Everything the per-code-block kernels need to know about their block, gathered once per decode by k_cb_desc: read through the
+// allocation tables it is a chain of three dependent L2 round trips at the start of every workgroup (slot -> allocation -> its fields ->
+// its soft bits), which was a third of a k_turbo_prep workgroup's lifetime
+struct CbDesc { uint32_t alloc, e_off, E, combo, Nnn, hard, tbs, pad; }; // 32 bytes
+
 struct GroupDesc {                 // one launch = the code blocks of one size K out of a PDSCH batch
     const mi_lte_pdsch_alloc *allocs;
     const uint32_t *cb_alloc;      // [n_cb] allocation index of each code-block slot
@@ -296,6 +301,7 @@ struct GroupDesc {                 // one launch = the code blocks of one size K
     const uint32_t *crc_tab;       // (x^e mod gCRC24A) << 8 at index MI_CRC_TAB_BIAS + e (ctx.cc)
     uint32_t        ul;            // 1: UL-SCH soft-buffer rule (N_cb = K_w: chan_type ULSCH, liblte_phy.cc:11387-11398, :12437-12449)
     uint32_t        packed;        // 1: out_bits holds eight bits per byte, first bit in the most significant position (liblte_value_2_bits order)
+    const CbDesc   *desc;          // [n_cb] filled by k_cb_desc before the first kernel of the group (REF decoder)
 };
 
 struct SrcRateUnmatch {
@@ -309,15 +315,14 @@ struct SrcRateUnmatch {
     uint32_t        E, Nnn, K_;
     __device__ __forceinline__ void init(uint32_t cb, uint32_t K)
     {
-        const uint32_t a = g.cb_alloc[cb], txm = g.allocs[a].tx_mode;
-        const uint32_t combo = g.ul ? 8u + (g.allocs[a].rv_idx & 3u)
-                                    : ((g.allocs[a].rv_idx & 3u) << 1) | ((txm == 3 || txm == 4 || txm == 8 || txm == 9) ? 1u : 0u);
-        tab = tabs + (size_t)combo * 3 * K;
-        Nnn = nnn[combo];
+        const uint4 *dp = reinterpret_cast<const uint4 *>(g.desc + cb);
+        const uint4  d0 = dp[0], d1 = dp[1]; // alloc e_off E combo | Nnn hard tbs -
+        tab = tabs + (size_t)d0.w * 3 * K;
+        Nnn = d1.x;
         K_  = K;
-        e   = g.e_base + (size_t)g.e_off[a] * 64;
-        E   = g.e_len[a];
-        hard = g.allocs[a].mod_type >= 2 && E <= Nnn; // the de-mapper's 16QAM / 64QAM soft bits are all +-127 (liblte_phy.cc:9573-9659), and no position is summed
+        e   = g.e_base + (size_t)d0.y * 64;
+        E   = d0.z;
+        hard = d1.y != 0;
     }
     bool hard;
     __device__ __forceinline__ bool hard_inputs() const { return hard; }
@@ -1151,8 +1156,8 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     __syncthreads();
     uint32_t alloc = 0, tbs = 0, F = 0, crc = 0;
     if (GROUP) {
-        alloc = g.cb_alloc[cb];
-        tbs   = g.allocs[alloc].tbs;
+        alloc = g.desc[cb].alloc;
+        tbs   = g.desc[cb].tbs;
         F     = K - tbs - 24;
     }
     if (nv > 0) {
@@ -1235,6 +1240,21 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         } else
             for (uint32_t m = threadIdx.x; m < tbs; m += blockDim.x) o[m] = (uint8_t)bits[m + F];
     }
+}
+
+// one thread per code block of the group: the descriptor the per-code-block kernels read (CbDesc)
+__global__ __launch_bounds__(256) void k_cb_desc(GroupDesc g, uint32_t n_cb, const uint32_t *__restrict__ nnn, CbDesc *__restrict__ out)
+{
+    const uint32_t cb = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cb >= n_cb) return;
+    const uint32_t a = g.cb_alloc[cb], txm = g.allocs[a].tx_mode;
+    const uint32_t combo = g.ul ? 8u + (g.allocs[a].rv_idx & 3u)
+                                : ((g.allocs[a].rv_idx & 3u) << 1) | ((txm == 3 || txm == 4 || txm == 8 || txm == 9) ? 1u : 0u);
+    CbDesc d;
+    d.alloc = a; d.e_off = g.e_off[a]; d.E = g.e_len[a]; d.combo = combo; d.Nnn = nnn[combo];
+    d.hard  = (g.allocs[a].mod_type >= 2 && d.E <= d.Nnn) ? 1u : 0u; // the de-mapper's 16QAM / 64QAM soft bits are all +-127 (liblte_phy.cc:9573-9659), and no position is summed
+    d.tbs   = g.allocs[a].tbs; d.pad = 0;
+    out[cb] = d;
 }
 
 // rank tables for the fused rate un-matching: one launch per block size, cached in the context.
@@ -1397,7 +1417,7 @@ enum { AX0, AX1, AX2, AI0, AM1, AM2, AA1, AI1, AM3, AB1, AB2 };
 extern "C" size_t mi_lte_turbo_scratch_bytes(uint32_t K, uint32_t n_cb)
 {
     const size_t n_tiles = (n_cb + 63) / 64, Kp = kpad64(K);
-    return n_tiles * Kp * 64 * N_BYTE_ARRAYS + 3 * n_tiles * Kp * 32;
+    return n_tiles * Kp * 64 * N_BYTE_ARRAYS + 3 * n_tiles * Kp * 32 + n_tiles * 64 * sizeof(CbDesc);
 }
 
 static bool no_static_lds(const void *kernel)
@@ -1431,6 +1451,11 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
     if (n_cb % 64) // lanes past the batch end walk whatever the scratch holds; keep it defined
         MI_HIP_CHECK(ctx, hipMemsetAsync(base, 0, N_BYTE_ARRAYS * arr_bytes, ctx->stream));
 
+    if constexpr (GROUP) { // the per-block descriptors behind the tile arrays and the traceback words
+        CbDesc *d_desc = (CbDesc *)(base + N_BYTE_ARRAYS * arr_bytes + 3 * dec_bytes);
+        gd.desc = src.g.desc = d_desc;
+        MI_LAUNCH(ctx, "k_cb_desc", k_cb_desc, dim3((n_cb + 255) / 256), dim3(256), 0, gd, n_cb, (const uint32_t *)src.nnn, d_desc);
+    }
     PrepOut po;
     po.arr[0] = arr[AX0]; po.arr[1] = arr[AX1]; po.arr[2] = arr[AX2];
     po.arr[3] = arr[AI0]; po.arr[4] = arr[AM1]; po.arr[5] = arr[AM2];

@@ -418,7 +418,9 @@ class ChainWorkload:
             for k, v in turbo_own_io(K, n * cnt, E, tbs, bc).items():
                 own[k] = own.get(k, 0) + v
         tk = ["k_rm_to_i8", "k_bcjr_prep", "k_bcjr_half", "k_bcjr_final", "k_crc_finish"] if bc else \
-             ["k_turbo_prep", "k_turbo_siso", "k_turbo_perm", "k_turbo_vote"]
+             ["k_cb_desc", "k_turbo_prep", "k_turbo_siso", "k_turbo_perm", "k_turbo_vote"]
+        if not bc:
+            own["k_cb_desc"] = n * 9 * 80  # per code block: its allocation's fields in, a 32-byte descriptor out
         return {"stages": {"frontend": (n * 339040, ["k_dl_fft", "k_dl_ce"]),
                            "demod": (n * res * (16 + 6), ["k_pdsch_demod"]),
                            "turbo": (n * (8 * _turbo_alg_bytes(3264) + _turbo_alg_bytes(1088)), tk)},
@@ -651,9 +653,10 @@ class UplinkWorkload:
                "k_prach_corr": self.n_occ * (839 * 8 + 64 * 12),
                "k_ul_fft": n * (14 * 2048 * 2 + 14 * 1200 * 8), "k_pusch_demod": n * self.N_UE * (14 * M * 8 + E)}
         own.update(turbo_own_io(K, n * self.N_UE, E, self.TBS))
+        own["k_cb_desc"] = n * self.N_UE * 80
         return {"stages": {"frontend": (n * (61440 + 14 * 1200 * 8), ["k_ul_fft"]),
                            "demod": (n * self.N_UE * (14 * M * 8 + E), ["k_pusch_demod"]),
-                           "turbo": (n * self.N_UE * _turbo_alg_bytes(K), ["k_turbo_prep", "k_turbo_siso", "k_turbo_perm", "k_turbo_vote"]),
+                           "turbo": (n * self.N_UE * _turbo_alg_bytes(K), ["k_cb_desc", "k_turbo_prep", "k_turbo_siso", "k_turbo_perm", "k_turbo_vote"]),
                            "prach": (self.n_occ * (24576 * 2 + 64 * 12), ["k_prach_fft", "k_prach_bins", "k_prach_corr"])},
                 "own_io": own}
 

@@ -2,7 +2,7 @@
 # On the GPU box: the profile set DESIGN.md 6 cites, under gpurun_out/ (tag = $1): kernel trace + HBM counters for chain / uplink / turbo (REF and
 # BCJR), SQ instruction counters for chain / turbo-BCJR, and one bench line per workload.
 set -u
-TAG=${1:-r02g}
+TAG=${1:-r02h}
 bash tools/profile_bench.sh ${TAG}_chain --workload chain > /dev/null 2>&1
 bash tools/profile_bench.sh ${TAG}_uplink --workload uplink > /dev/null 2>&1
 bash tools/profile_bench.sh ${TAG}_turbo --workload turbo > /dev/null 2>&1

@@ -20,6 +20,8 @@
 #include <map>
 #include <tuple>
 
+#include <type_traits>
+
 #include "ctx.hpp"
 #include "phy_dev.hpp"
 #include "lte_tables.h"
@@ -299,27 +301,37 @@ __global__ __launch_bounds__(PUSCH_THREADS) void k_pusch_demod(const float *__re
             rem /= R;
             float2 *t = src; src = dst; dst = t;
         }
-        // ---- de-map, descramble, de-interleave (transpose): soft bit q of symbol k goes to (k*12 + s)*Q_m + q
+        // ---- de-map, descramble, de-interleave (transpose): soft bit q of symbol k goes to (k*12 + s)*Q_m + q.  Instantiated per modulation
+        // (uniform over the workgroup): no modulation branches and no re-read of the allocation descriptor per element
+        auto demap_all = [&](auto modc) {
+        constexpr uint32_t MOD = decltype(modc)::value, QM = MOD == 3 ? 6 : MOD == 2 ? 4 : MOD == 1 ? 2 : 1;
         for (uint32_t o = threadIdx.x; o < S * M; o += blockDim.x) {
             const uint32_t k = div_by(o, inv_s), sy = o - k * S, s = s0 + sy; // neighbouring threads write neighbouring bytes of e
             const float2   x = src[sy * M_max + k];
             int8_t         b[6] = {0, 0, 0, 0, 0, 0};
-            demap_symbol(sqrt_M * x.x, sqrt_M * x.y, al.mod_type, b);
-            const uint32_t n0 = (s * M + k) * Qm, w = n0 >> 5, sh = n0 & 31;
+            demap_symbol(sqrt_M * x.x, sqrt_M * x.y, MOD, b);
+            const uint32_t n0 = (s * M + k) * QM, w = n0 >> 5, sh = n0 & 31;
             const uint32_t c  = __builtin_amdgcn_alignbit(cw[w + 1], cw[w], sh);
-            int8_t        *ob = e + (size_t)(k * 12 + s) * Qm;
+            int8_t        *ob = e + (size_t)(k * 12 + s) * QM;
             // descrambled soft bits q, q + 1 as one 16-bit word (the Q_m bytes of a symbol start on an even address)
             auto pair = [&](uint32_t q) -> uint32_t {
                 const int lo = ((c >> q) & 1u) ? -b[q] : b[q], hi = ((c >> (q + 1)) & 1u) ? -b[q + 1] : b[q + 1];
                 return (uint32_t)(uint8_t)lo | (uint32_t)(uint8_t)hi << 8;
             };
-            if (Qm == 2) *reinterpret_cast<uint16_t *>(ob) = (uint16_t)pair(0);
-            else if (Qm == 4) *reinterpret_cast<uint32_t *>(ob) = pair(0) | pair(2) << 16;
-            else if (Qm == 6) {
+            if (QM == 2) *reinterpret_cast<uint16_t *>(ob) = (uint16_t)pair(0);
+            else if (QM == 4) *reinterpret_cast<uint32_t *>(ob) = pair(0) | pair(2) << 16;
+            else if (QM == 6) {
                 *reinterpret_cast<uint16_t *>(ob)     = (uint16_t)pair(0);
                 *reinterpret_cast<uint16_t *>(ob + 2) = (uint16_t)pair(2);
                 *reinterpret_cast<uint16_t *>(ob + 4) = (uint16_t)pair(4);
             } else ob[0] = (c & 1u) ? (int8_t)-b[0] : b[0];
+        }
+        };
+        switch (al.mod_type) {
+        case 0:  demap_all(std::integral_constant<uint32_t, 0>{}); break;
+        case 1:  demap_all(std::integral_constant<uint32_t, 1>{}); break;
+        case 2:  demap_all(std::integral_constant<uint32_t, 2>{}); break;
+        default: demap_all(std::integral_constant<uint32_t, 3>{}); break;
         }
         __syncthreads();
     }

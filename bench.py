@@ -956,12 +956,23 @@ def turbo_leg(ctx, decoder, n_cb, steps):
         step()
     ms = ctx.timer_stop()
     got = d_out.download(np.uint8, count=64 * K).reshape(64, K)
-    d_in.free()
-    d_out.free()
     out = {"mbit_per_s": round(n_cb * K * steps / (ms * 1e-3) / 1e6, 1), "ms_per_decode": round(ms / steps, 3), "code_blocks": n_cb, "K": K, "steps": steps}
     if decoder == "bcjr":
         out["sampled_blocks_equal_tx_bits"] = bool((got == tx[idx[:64]]).all())
-    else:  # K = 6144 is one of the sizes whose interleaver the reference computes with uint32 overflow: it never decodes to the transmitted
+        # the same decoder for a per-call caller's handful of blocks: MI_LTE_TURBO_BCJR_BLOCK, one code block per wavefront, one launch
+        lat = {}
+        for nb in (1, 9):
+            for name, mode in (("batch_kernels", m.TURBO_BCJR), ("one_block_per_wavefront", m.TURBO_BCJR_BLOCK)):
+                ctx.turbo_decode_dev(d_in, m.SOFT_I8, K, nb, d_out, mode=mode, n_iter=8, qpp_spec=True)
+                ctx.sync()
+                ctx.timer_start()
+                for _ in range(5):
+                    ctx.turbo_decode_dev(d_in, m.SOFT_I8, K, nb, d_out, mode=mode, n_iter=8, qpp_spec=True)
+                lat["%s_%d_block%s_ms" % (name, nb, "" if nb == 1 else "s")] = round(ctx.timer_stop() / 5, 3)
+        out["latency_8_iterations"] = lat
+    d_in.free()
+    d_out.free()
+    if decoder != "bcjr":  # K = 6144 is one of the sizes whose interleaver the reference computes with uint32 overflow: it never decodes to the transmitted
         # bits there; the check is bit-equality with the CPU restatement of the reference's decoder
         from oracle import pyoracle
         P, want = pyoracle.port(), np.zeros(K, np.uint8)

@@ -183,12 +183,17 @@ int      mi_lte_pdsch_plan_soft_bits(const mi_lte_pdsch_plan *plan, uint32_t all
  *                      Viterbi passes + soft re-encodes + 4-way vote), including its uint32 QPP
  *                      wrap-around; de-interleaver holes read as 0.  n_iter is ignored.
  *   MI_LTE_TURBO_BCJR  fixed-point max-log-MAP (extrinsic scaled by 3/4), n_iter full iterations, int8 LLRs
+ *   MI_LTE_TURBO_BCJR_BLOCK  the same decoder laid out for a HANDFUL of blocks (the per-call forms): one code block per wavefront, the
+ *                      64 lanes walk 64 segments of the block, every array of the decode in LDS, one launch for all iterations.  Its
+ *                      alpha recursion restarts (from the previous iteration's value) every 32-96 steps instead of every K/8, so its
+ *                      output is specified by its own model (lo_turbo_decode_bcjr_block) and can differ from MI_LTE_TURBO_BCJR's on
+ *                      blocks near the decoding threshold; ~4x lower latency for a single K = 6144 block.
  *                      (MI_LTE_SOFT_I8) only; qpp_spec != 0 selects the exact 3GPP interleaver instead of the
  *                      reference's wrapped one.  Not a behaviour of the reference (its decoder is REF): specified
  *                      by oracle/lte_oracle.c lo_turbo_decode_bcjr, which the kernels match bit for bit.
  *
  * Output: d_c_bits, one decoded bit per byte, K bytes per block (the reference's c_bits). */
-typedef enum { MI_LTE_TURBO_REF = 0, MI_LTE_TURBO_BCJR = 1 } mi_lte_turbo_mode;
+typedef enum { MI_LTE_TURBO_REF = 0, MI_LTE_TURBO_BCJR = 1, MI_LTE_TURBO_BCJR_BLOCK = 2 } mi_lte_turbo_mode;
 typedef enum { MI_LTE_SOFT_F32 = 0, MI_LTE_SOFT_I8 = 1, MI_LTE_SOFT_I16 = 2 } mi_lte_soft_type;
 
 int mi_lte_turbo_decode_batch(mi_lte_ctx *ctx, const void *d_soft, mi_lte_soft_type soft_type, uint32_t K,

@@ -348,6 +348,209 @@ __global__ __launch_bounds__(128) void k_bcjr_final(const uint8_t *__restrict__ 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// MI_LTE_TURBO_BCJR_BLOCK: ONE code block per wavefront, the whole decode in one launch (the form BASELINE.json's north star sketches; meant
+// for the handful of blocks a per-call caller has, where the batch kernels above would leave 63 of 64 lanes idle).  The 64 lanes are 64
+// alpha SEGMENTS of the block (lo_bcjr_block_seg_len: every lane a whole number of the 32-step beta blocks, 96 steps at K = 6144), each lane
+// with its trellis' eight metrics in its own registers -- the same arithmetic as k_bcjr_half, one trellis per lane, plain 32-bit integers.
+// Everything the iterations touch lives in LDS: the four channel-value arrays, both extrinsic arrays, the interleaver tables (as LDS slots), the
+// boundary states of both constituent decoders, the alpha checkpoints.  The exchange between the decoders is a byte gather out of LDS.
+// Segment g's steps sit at g * (L + 8) + t: the 8 bytes of padding put the 64 lanes' 8-byte window reads on 64 different banks.
+// Specification: lo_turbo_decode_bcjr_block (the batch model with alpha restarting every L steps instead of every K / n_seg).
+constexpr uint32_t BLK_PAD = 8;
+__host__ __device__ inline uint32_t bcjr_block_seg_len(uint32_t K) { return 32u * ((((K + 31u) >> 5) + 63u) >> 6); }
+__host__ __device__ inline uint32_t bcjr_block_arr_bytes(uint32_t K) // one int8 array in the padded layout + a zero slot, rounded to 16
+{
+    const uint32_t L = bcjr_block_seg_len(K), n_seg = (K + L - 1) / L;
+    return (n_seg * (L + BLK_PAD) + 16u + 15u) & ~15u;
+}
+struct BlockLds { uint32_t arr, S1, P1, S2, P2, E1, E2, HD, tabP, tabI, aB, bB, chk, total; };
+__host__ __device__ inline BlockLds bcjr_block_lds(uint32_t K)
+{
+    BlockLds l;
+    l.arr = bcjr_block_arr_bytes(K);
+    const uint32_t n_blk = (K + 31) >> 5;
+    l.S1 = 0; l.P1 = l.arr; l.S2 = 2 * l.arr; l.P2 = 3 * l.arr; l.E1 = 4 * l.arr; l.E2 = 5 * l.arr; l.HD = 6 * l.arr;
+    l.tabP = 7 * l.arr;                 // uint16 [arr]: LDS slot of E1 that decoder 2 reads at its step t (slot layout as the arrays)
+    l.tabI = l.tabP + 2 * l.arr;        // uint16 [arr]: LDS slot of E2 that decoder 1 reads at its step t (a hole: the zero slot)
+    l.aB   = l.tabI + 2 * l.arr;        // int16 [2 decoders][2 buffers][64 segments][8]
+    l.bB   = l.aB + 2 * 2 * 64 * 8 * 2; // int16 [2][2][n_blk][8]
+    l.chk  = l.bB + 2 * 2 * n_blk * 8 * 2; // int32 [4 windows][8 states][64 lanes]
+    l.total = l.chk + 4 * 8 * 64 * 4;
+    return l;
+}
+
+__device__ __forceinline__ void norm8i(int (&v)[8])
+{
+    const int m = max(max(max(v[0], v[1]), max(v[2], v[3])), max(max(v[4], v[5]), max(v[6], v[7])));
+#pragma unroll
+    for (int s = 0; s < 8; s++) v[s] = max(v[s] - m, BCJR_NEG);
+}
+__device__ __forceinline__ void alpha_step_i(const int (&a)[8], int g00, int g01, int g10, int (&o)[8])
+{
+    o[0] = max(a[0] + g00, a[1]);       o[4] = max(a[0], a[1] + g00);
+    o[1] = max(a[2] + g10, a[3] + g01); o[5] = max(a[2] + g01, a[3] + g10);
+    o[2] = max(a[4] + g01, a[5] + g10); o[6] = max(a[4] + g10, a[5] + g01);
+    o[3] = max(a[6], a[7] + g00);       o[7] = max(a[6] + g00, a[7]);
+}
+
+__global__ __launch_bounds__(64) void k_bcjr_block(const int8_t *__restrict__ soft, uint32_t K, uint32_t n_cb, uint32_t n_iter,
+                                                   const uint32_t *__restrict__ pi_row, const uint32_t *__restrict__ inv_row, uint8_t *__restrict__ c_bits)
+{
+    extern __shared__ __attribute__((aligned(16))) int8_t sm[];
+    const uint32_t cb = blockIdx.x, g = threadIdx.x, Kp = kpad64(K), L = bcjr_block_seg_len(K), n_seg = (K + L - 1) / L, n_blk = (K + 31) >> 5;
+    const BlockLds lay = bcjr_block_lds(K);
+    const uint32_t zero_slot = n_seg * (L + BLK_PAD); // holds 0 in E1, E2: what a hole or the padding past K reads
+    const uint32_t inv_L = 0xFFFFFFFFu / L + 1u;      // t / L = mulhi(t, inv_L) for t < 2^16 (L is 32, 64 or 96)
+    auto slot = [&](uint32_t t) { const uint32_t q = __umulhi(t, inv_L); return q * (L + BLK_PAD) + (t - q * L); };
+    int8_t   *S1 = sm + lay.S1, *P1 = sm + lay.P1, *S2 = sm + lay.S2, *P2 = sm + lay.P2, *E1 = sm + lay.E1, *E2 = sm + lay.E2;
+    uint8_t  *HD = reinterpret_cast<uint8_t *>(sm + lay.HD);
+    uint16_t *tabP = reinterpret_cast<uint16_t *>(sm + lay.tabP), *tabI = reinterpret_cast<uint16_t *>(sm + lay.tabI);
+    int16_t  *aB = reinterpret_cast<int16_t *>(sm + lay.aB), *bB = reinterpret_cast<int16_t *>(sm + lay.bB);
+    int      *chk = reinterpret_cast<int *>(sm + lay.chk);
+    const int8_t *d = soft + (size_t)cb * 3 * (K + 4);
+
+    // ---- prologue: zero what must read as zero (extrinsics, boundary states = "uniform", the padding), split the input, build the tables
+    for (uint32_t w = g; w < (lay.chk >> 2); w += 64) reinterpret_cast<uint32_t *>(sm)[w] = 0u;
+    __syncthreads();
+    auto clip = [](int v) { return (int8_t)max(v, -127); };
+    for (uint32_t i = g; i < K; i += 64) {
+        const uint32_t p = slot(i);
+        S1[p] = clip(d[3 * i]); P1[p] = clip(d[3 * i + 1]); P2[p] = clip(d[3 * i + 2]);
+    }
+    for (uint32_t t = g; t < Kp; t += 64) { // the tables as LDS slots; entries from K on (and holes) point at the zero slot
+        const uint32_t pr = pi_row[t], ir = inv_row[t], p = t < K ? slot(t) : zero_slot;
+        if (t < K) { tabP[p] = (uint16_t)(pr < K ? slot(pr) : zero_slot); tabI[p] = (uint16_t)(ir < K ? slot(ir) : zero_slot); }
+    }
+    __syncthreads();
+    for (uint32_t i = g; i < K; i += 64) S2[slot(i)] = S1[tabP[slot(i)]]; // S2[i] = S1[pi[i]]
+    // termination bits: x[3r + stream] = d_stream[K + r]  (36.212 5.1.3.2.2), as in k_bcjr_prep
+    int tl[12];
+    {
+        const int8_t *x = d + 3 * (size_t)K;
+        const int idx[12] = {0, 2, 4, 1, 3, 5, 6, 8, 10, 7, 9, 11};
+#pragma unroll
+        for (int k = 0; k < 12; k++) tl[k] = max((int)x[idx[k]], -127);
+    }
+    __syncthreads();
+
+    const uint32_t t_lo = g * L, t_hi = min(t_lo + L, K), base = g * (L + BLK_PAD); // this lane's segment, and its first slot
+    const bool     on = g < n_seg;
+
+    // one half-iteration of constituent decoder `dec` (0 / 1) in iteration `it`; LAST: also the decisions (decoder 2's order)
+    auto half = [&](uint32_t dec, uint32_t it, bool last) {
+        const int8_t   *S = dec ? S2 : S1, *P = dec ? P2 : P1, *A = dec ? E1 : E2;
+        int8_t         *E = dec ? E2 : E1;
+        const uint16_t *row = dec ? tabP : tabI;
+        const uint32_t  rd = it & 1u, wr = rd ^ 1u;
+        int16_t        *a_rd = aB + ((dec * 2 + rd) * 64) * 8, *a_wr = aB + ((dec * 2 + wr) * 64) * 8;
+        int16_t        *b_rd = bB + ((dec * 2 + rd) * n_blk) * 8, *b_wr = bB + ((dec * 2 + wr) * n_blk) * 8;
+        if (!on) return;
+        auto load_window = [&](uint32_t p0, int (&lsa)[8], int (&lp)[8]) { // the eight steps whose first slot is p0 (a multiple of 8)
+            const uint2 sv = *reinterpret_cast<const uint2 *>(S + p0), pv = *reinterpret_cast<const uint2 *>(P + p0);
+            const uint4 rw = *reinterpret_cast<const uint4 *>(row + p0);
+            const uint32_t r[4] = {rw.x, rw.y, rw.z, rw.w};
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int a = A[(r[k >> 1] >> (16 * (k & 1))) & 0xFFFFu];
+                lsa[k] = sb(k < 4 ? sv.x : sv.y, k & 3) + 2 * a;
+                lp[k]  = sb(k < 4 ? pv.x : pv.y, k & 3);
+            }
+        };
+        int a[8] = {0, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG};
+        if (g > 0) {
+#pragma unroll
+            for (int s = 0; s < 8; s++) a[s] = a_rd[g * 8 + s];
+        }
+        for (uint32_t b0 = t_lo; b0 < t_hi; b0 += 32) {
+            const uint32_t blk = b0 >> 5, n_w = min(32u, t_hi - b0) >> 3, p_blk = base + (b0 - t_lo);
+#pragma unroll 1
+            for (uint32_t w = 0; w < n_w; w++) {
+                int lsa[8], lp[8];
+                load_window(p_blk + 8 * w, lsa, lp);
+                norm8i(a);
+#pragma unroll
+                for (int s = 0; s < 8; s++) chk[(w * 8 + s) * 64 + g] = a[s];
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    int o[8];
+                    alpha_step_i(a, lsa[r] + lp[r], lsa[r], lp[r], o);
+#pragma unroll
+                    for (int s = 0; s < 8; s++) a[s] = o[s];
+                }
+            }
+            int b[8] = {0, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG, BCJR_NEG};
+            if (blk + 1 == n_blk) { // termination: only the a = 0 edges exist, state 2j + r3 continues to state j
+#pragma unroll
+                for (int k = 2; k >= 0; k--) {
+                    const int ls = tl[6 * dec + k], lp = tl[6 * dec + 3 + k], g00 = ls + lp, g01 = ls, g10 = lp;
+                    int       o[8];
+                    o[0] = b[0] + g00; o[1] = b[0];       o[2] = b[1] + g10; o[3] = b[1] + g01;
+                    o[4] = b[2] + g01; o[5] = b[2] + g10; o[6] = b[3];       o[7] = b[3] + g00;
+#pragma unroll
+                    for (int s = 0; s < 8; s++) b[s] = o[s];
+                }
+                norm8i(b);
+            } else {
+#pragma unroll
+                for (int s = 0; s < 8; s++) b[s] = b_rd[blk * 8 + s];
+            }
+#pragma unroll 1
+            for (int w = (int)n_w - 1; w >= 0; w--) {
+                int lsa[8], lp[8];
+                load_window(p_blk + 8 * w, lsa, lp);
+                int al[8][8];
+#pragma unroll
+                for (int s = 0; s < 8; s++) al[0][s] = chk[(w * 8 + s) * 64 + g];
+#pragma unroll
+                for (int r = 1; r < 8; r++) alpha_step_i(al[r - 1], lsa[r - 1] + lp[r - 1], lsa[r - 1], lp[r - 1], al[r]);
+#pragma unroll
+                for (int r = 7; r >= 0; r--) {
+                    const int g00 = lsa[r] + lp[r], g01 = lsa[r], g10 = lp[r];
+                    const int(&x)[8] = al[r];
+                    const int u0[8] = {b[0] + g00, b[4] + g00, b[5] + g01, b[1] + g01, b[2] + g01, b[6] + g01, b[7] + g00, b[3] + g00};
+                    const int u1[8] = {b[4], b[0], b[1] + g10, b[5] + g10, b[6] + g10, b[2] + g10, b[3], b[7]};
+                    int l0 = x[0] + u0[0], l1 = x[0] + u1[0];
+#pragma unroll
+                    for (int s = 1; s < 8; s++) { l0 = max(l0, x[s] + u0[s]); l1 = max(l1, x[s] + u1[s]); }
+                    const int llr = l0 - l1;
+                    int       e   = min(max(llr - lsa[r], -BCJR_X_MAX), BCJR_X_MAX);
+                    e             = (e * 3) >> 2;
+                    e             = min(max(e, -BCJR_LE_MAX), BCJR_LE_MAX) >> 1;
+                    const uint32_t p = p_blk + 8 * w + r;
+                    E[p] = (int8_t)e;
+                    if (last) HD[p] = llr < 0 ? 1 : 0;
+#pragma unroll
+                    for (int s = 0; s < 8; s++) b[s] = max(u0[s], u1[s]);
+                }
+                norm8i(b);
+            }
+            if (blk > 0) {
+#pragma unroll
+                for (int s = 0; s < 8; s++) b_wr[(blk - 1) * 8 + s] = (int16_t)b[s];
+            }
+        }
+        if (g + 1 < n_seg) {
+            norm8i(a);
+#pragma unroll
+            for (int s = 0; s < 8; s++) a_wr[(g + 1) * 8 + s] = (int16_t)a[s];
+        }
+    };
+    for (uint32_t it = 0; it < n_iter; it++) {
+        half(0, it, false);
+        __syncthreads();
+        half(1, it, it + 1 == n_iter);
+        __syncthreads();
+    }
+    // ---- decisions in natural order: c[j] = HD[inv[j]]; a hole of the de-interleaver falls back on the sign of S1[j]
+    uint8_t *o = c_bits + (size_t)cb * K;
+    for (uint32_t j = g; j < K; j += 64) {
+        const uint32_t p = slot(j), r = tabI[p];
+        o[j] = r != zero_slot ? HD[r] : (uint8_t)(S1[p] < 0 ? 1 : 0);
+    }
+}
+
 } // namespace
 
 extern "C" size_t mi_lte_turbo_bcjr_scratch_bytes(uint32_t K, uint32_t n_cb)
@@ -409,5 +612,25 @@ int mi_turbo_bcjr_batch(mi_lte_ctx *ctx, const int8_t *d_soft, uint32_t K, uint3
               (uint32_t)n_tiles, d_c_bits);
     MI_HIP_CHECK(ctx, hipGetLastError());
     ctx->last_kernels = "k_bcjr_prep:1,k_bcjr_half: 2 per iteration,k_bcjr_final:1";
+    return MI_LTE_OK;
+}
+
+// MI_LTE_TURBO_BCJR_BLOCK: one wavefront per code block, one launch for the whole decode (k_bcjr_block)
+int mi_turbo_bcjr_block_batch(mi_lte_ctx *ctx, const int8_t *d_soft, uint32_t K, uint32_t n_cb, uint32_t n_iter, int qpp_spec, uint8_t *d_c_bits)
+{
+    if (n_iter == 0 || n_iter > 64) return MI_LTE_ERR_INVALID_ARG;
+    TurboTables tb;
+    int         rc = mi_ctx_turbo_tables(ctx, K, qpp_spec ? 1 : 0, &tb);
+    if (rc != MI_LTE_OK) return rc;
+    const BlockLds lay = bcjr_block_lds(K);
+    static bool attr_set = false; // more than 64 KB of dynamic LDS has to be asked for once
+    if (!attr_set) {
+        MI_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_bcjr_block, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    MI_LAUNCH(ctx, "k_bcjr_block", k_bcjr_block, dim3(n_cb), dim3(64), lay.total, d_soft, K, n_cb, n_iter, (const uint32_t *)tb.d_pi_row,
+              (const uint32_t *)tb.d_inv_row, d_c_bits);
+    MI_HIP_CHECK(ctx, hipGetLastError());
+    ctx->last_kernels = "k_bcjr_block:1";
     return MI_LTE_OK;
 }

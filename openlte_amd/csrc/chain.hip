@@ -426,7 +426,8 @@ int mi_lte_pdsch_plan_soft_bits(const mi_lte_pdsch_plan *pl, uint32_t alloc, con
 
 int mi_lte_pdsch_plan_set_decoder(mi_lte_pdsch_plan *pl, uint32_t mode, uint32_t n_iter, int qpp_spec)
 {
-    if (!pl || !(mode == MI_LTE_TURBO_REF || mode == MI_LTE_TURBO_BCJR) || (mode == MI_LTE_TURBO_BCJR && (n_iter == 0 || n_iter > 64))) return MI_LTE_ERR_INVALID_ARG;
+    const bool bcjr = mode == MI_LTE_TURBO_BCJR || mode == MI_LTE_TURBO_BCJR_BLOCK;
+    if (!pl || !(mode == MI_LTE_TURBO_REF || bcjr) || (bcjr && (n_iter == 0 || n_iter > 64))) return MI_LTE_ERR_INVALID_ARG;
     pl->decoder = mode; pl->n_iter = n_iter; pl->qpp_spec = qpp_spec;
     return MI_LTE_OK;
 }
@@ -463,22 +464,24 @@ int mi_lte_pdsch_decode_run(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, const float 
         MI_LAUNCH(ctx, "k_pdsch_demod", k_pdsch_demod<false>, dim3(pl->n_alloc), dim3(256), lds, d_subframes, g, pl->d_allocs, d_subfr_num,
                   d_n_id_cell, gt, pl->d_e, pl->d_e_off, pl->d_e_len, pl->max_pairs, words_al, e_cap);
     MI_HIP_CHECK(ctx, hipGetLastError());
-    if (pl->decoder == MI_LTE_TURBO_BCJR && !pl->d_bcjr_soft) {
+    const bool bcjr = pl->decoder == MI_LTE_TURBO_BCJR || pl->decoder == MI_LTE_TURBO_BCJR_BLOCK;
+    if (bcjr && !pl->d_bcjr_soft) {
         size_t soft = 0, bits = 0;
         for (auto &gr : pl->groups) { soft = std::max(soft, (size_t)gr.n_cb * 3 * (gr.K + 4)); bits = std::max(bits, (size_t)gr.n_cb * gr.K); }
         MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_bcjr_soft, soft));
         MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_bcjr_bits, bits));
     }
     for (auto &gr : pl->groups) {
-        if (pl->decoder == MI_LTE_TURBO_BCJR)
+        if (bcjr)
             rc = mi_turbo_bcjr_group(ctx, gr.K, gr.n_cb, pl->d_allocs, pl->d_cb_alloc + gr.cb_base, pl->d_e, pl->d_e_off, pl->d_e_len, d_out_bits,
-                                     pl->out_stride, d_status, false, pl->d_bcjr_soft, pl->d_bcjr_bits, pl->n_iter, pl->qpp_spec, pl->packed != 0, gr.e_max);
+                                     pl->out_stride, d_status, false, pl->d_bcjr_soft, pl->d_bcjr_bits, pl->n_iter, pl->qpp_spec, pl->packed != 0, gr.e_max,
+                                     pl->decoder == MI_LTE_TURBO_BCJR_BLOCK);
         else
             rc = mi_turbo_ref_group(ctx, gr.K, gr.n_cb, pl->d_allocs, pl->d_cb_alloc + gr.cb_base, pl->d_e, pl->d_e_off, pl->d_e_len,
                                     d_out_bits, pl->out_stride, d_status, gr.e_max, false, pl->packed != 0);
         if (rc != MI_LTE_OK) return rc;
     }
-    ctx->last_kernels = pl->decoder == MI_LTE_TURBO_BCJR ? "k_pdsch_demod:1,k_rm_to_i8,k_bcjr_*,k_crc_finish per block size"
+    ctx->last_kernels = bcjr ? "k_pdsch_demod:1,k_rm_to_i8,k_bcjr_*,k_crc_finish per block size"
                                                          : "k_pdsch_demod:1,k_turbo_prep,k_turbo_siso,k_turbo_perm,k_turbo_vote per block size";
     return MI_LTE_OK;
 }

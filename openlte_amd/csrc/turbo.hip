@@ -1541,7 +1541,7 @@ int mi_turbo_ref_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_
 
 int mi_turbo_bcjr_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_pdsch_alloc *d_allocs, const uint32_t *d_cb_alloc, const int8_t *d_e,
                         const uint32_t *d_e_off, const uint32_t *d_e_len, uint8_t *d_out_bits, uint32_t out_stride, int32_t *d_status, bool ul,
-                        int8_t *d_soft, uint8_t *d_c_bits, uint32_t n_iter, int qpp_spec, bool packed, uint32_t e_max_bytes)
+                        int8_t *d_soft, uint8_t *d_c_bits, uint32_t n_iter, int qpp_spec, bool packed, uint32_t e_max_bytes, bool block_mode)
 {
     int rc = mi_ctx_crc_table(ctx);
     if (rc != MI_LTE_OK) return rc;
@@ -1552,7 +1552,7 @@ int mi_turbo_bcjr_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte
     const uint32_t cap = (e_max_bytes + 16u + 63u) & ~63u, e_cap = cap <= 60 * 1024 ? cap : 0; // stage the allocation in LDS when it fits
     MI_LAUNCH(ctx, "k_rm_to_i8", k_rm_to_i8, dim3(n_cb), dim3(256), e_cap, gd, K, n_cb, (const uint16_t *)t.d_tabs, (const uint32_t *)t.d_nnn, d_soft, e_cap);
     MI_HIP_CHECK(ctx, hipGetLastError());
-    rc = mi_turbo_bcjr_batch(ctx, d_soft, K, n_cb, n_iter, qpp_spec, d_c_bits);
+    rc = block_mode ? mi_turbo_bcjr_block_batch(ctx, d_soft, K, n_cb, n_iter, qpp_spec, d_c_bits) : mi_turbo_bcjr_batch(ctx, d_soft, K, n_cb, n_iter, qpp_spec, d_c_bits);
     if (rc != MI_LTE_OK) return rc;
     MI_LAUNCH(ctx, "k_crc_finish", k_crc_finish, dim3(n_cb), dim3(256), 0, (const uint8_t *)d_c_bits, K, n_cb, gd);
     MI_HIP_CHECK(ctx, hipGetLastError());
@@ -1579,6 +1579,7 @@ extern "C" int mi_lte_turbo_decode_batch(mi_lte_ctx *ctx, const void *d_soft, mi
         ctx->err = "BCJR mode takes int8 LLRs (MI_LTE_SOFT_I8)";
         return MI_LTE_ERR_UNSUPPORTED;
     }
+    if (mode == MI_LTE_TURBO_BCJR_BLOCK) return mi_turbo_bcjr_block_batch(ctx, (const int8_t *)d_soft, K, n_cb, n_iter, qpp_spec, d_c_bits);
     return mi_turbo_bcjr_batch(ctx, (const int8_t *)d_soft, K, n_cb, n_iter, qpp_spec, d_c_bits);
 }
 

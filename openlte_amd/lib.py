@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 SOFT_F32, SOFT_I8, SOFT_I16 = 0, 1, 2
-TURBO_REF, TURBO_BCJR = 0, 1
+TURBO_REF, TURBO_BCJR, TURBO_BCJR_BLOCK = 0, 1, 2  # BCJR_BLOCK: one code block per wavefront, one launch (a handful of blocks; its own model)
 _SOFT_OF_DTYPE = {np.dtype(np.float32): SOFT_F32, np.dtype(np.int8): SOFT_I8, np.dtype(np.int16): SOFT_I16}
 
 

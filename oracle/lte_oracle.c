@@ -380,7 +380,16 @@ uint32_t lo_bcjr_n_seg(uint32_t K)
     return 1;
 }
 #define BCJR_MAX_BLKS 192 /* 6144 / 32 */
-typedef struct { int16_t a[2][8][8], b[2][BCJR_MAX_BLKS][8]; } bcjr_bnd_t; /* [buffer][segment | block][state] */
+#define BCJR_MAX_SEGS 64 /* the one-block-per-wavefront mode: one segment per lane */
+typedef struct { int16_t a[2][BCJR_MAX_SEGS][8], b[2][BCJR_MAX_BLKS][8]; } bcjr_bnd_t; /* [buffer][segment | block][state] */
+/* Segment length of the "one code block per wavefront" mode (MI_LTE_TURBO_BCJR_BLOCK, k_bcjr_block): the block's 32-step beta blocks are
+ * dealt to the 64 lanes of a wavefront, every lane a whole number of them -- 96 steps per lane at K = 6144, 32 at K <= 2048.  Same decoder,
+ * same arithmetic; only the places where alpha restarts from the previous iteration's value are closer together. */
+uint32_t lo_bcjr_block_seg_len(uint32_t K)
+{
+    const uint32_t n_blk = (K + BCJR_BLK - 1) / BCJR_BLK;
+    return BCJR_BLK * ((n_blk + 63) / 64);
+}
 static int bcjr_range_ok = 1; /* cleared if any intermediate leaves int16 (checked by the tests through lo_bcjr_range_ok) */
 int lo_bcjr_range_ok(void) { return bcjr_range_ok; }
 #define BCJR_CHK(v) do { if ((v) > 32767 || (v) < -32768) bcjr_range_ok = 0; } while (0)
@@ -388,9 +397,11 @@ int lo_bcjr_range_ok(void) { return bcjr_range_ok; }
 /* one SISO pass: systematic S, parity P (int8), stored a-priori halves Aq (int8; La = 2*Aq), the 3 termination pairs -> stored
  * extrinsic halves Eq and (optionally) the sign of the a-posteriori LLR (1 = negative = bit 1).  it = iteration number. */
 static void bcjr_siso(const int8_t *S, const int8_t *P, const int8_t *Aq, const int8_t *tail_s, const int8_t *tail_p, uint32_t K,
-                      int8_t *Eq, uint8_t *hard, bcjr_bnd_t *bnd, uint32_t it)
+                      int8_t *Eq, uint8_t *hard, bcjr_bnd_t *bnd, uint32_t it, uint32_t seg_len_mode)
 {
-    const uint32_t n_seg = lo_bcjr_n_seg(K), seg_len = ((K + 63) / 64 / n_seg) * 64, rd = it & 1, wr = rd ^ 1, n_blk = (K + BCJR_BLK - 1) / BCJR_BLK;
+    /* seg_len_mode = 0: the batch kernels' segmentation (n_seg = 8, 4, 2, 1); else the segment length in steps (a multiple of 32) */
+    const uint32_t n_seg = seg_len_mode ? (K + seg_len_mode - 1) / seg_len_mode : lo_bcjr_n_seg(K);
+    const uint32_t seg_len = seg_len_mode ? seg_len_mode : ((K + 63) / 64 / n_seg) * 64, rd = it & 1, wr = rd ^ 1, n_blk = (K + BCJR_BLK - 1) / BCJR_BLK;
     int t8[8];
     for (uint32_t sg = 0; sg < n_seg; sg++) {
         const uint32_t t_lo = sg * seg_len, t_hi = (t_lo + seg_len < K) ? t_lo + seg_len : K;
@@ -461,7 +472,14 @@ static void bcjr_siso(const int8_t *S, const int8_t *P, const int8_t *Aq, const 
     }
 }
 
-void lo_turbo_decode_bcjr(const int16_t *soft, uint32_t K, uint32_t n_iter, int qpp_spec, uint8_t *c_bits)
+static void turbo_decode_bcjr(const int16_t *soft, uint32_t K, uint32_t n_iter, int qpp_spec, uint8_t *c_bits, uint32_t seg_len_mode);
+void lo_turbo_decode_bcjr(const int16_t *soft, uint32_t K, uint32_t n_iter, int qpp_spec, uint8_t *c_bits) { turbo_decode_bcjr(soft, K, n_iter, qpp_spec, c_bits, 0); }
+/* the same decoder with the one-block-per-wavefront segmentation (lo_bcjr_block_seg_len) */
+void lo_turbo_decode_bcjr_block(const int16_t *soft, uint32_t K, uint32_t n_iter, int qpp_spec, uint8_t *c_bits)
+{
+    turbo_decode_bcjr(soft, K, n_iter, qpp_spec, c_bits, lo_bcjr_block_seg_len(K));
+}
+static void turbo_decode_bcjr(const int16_t *soft, uint32_t K, uint32_t n_iter, int qpp_spec, uint8_t *c_bits, uint32_t seg_len_mode)
 {
     int8_t   *S1 = (int8_t *)malloc(4 * (size_t)K), *P1 = S1 + K, *S2 = P1 + K, *P2 = S2 + K;
     int8_t   *A1 = (int8_t *)calloc(4 * (size_t)K, 1), *A2 = A1 + K, *E1 = A2 + K, *E2 = E1 + K;
@@ -482,9 +500,9 @@ void lo_turbo_decode_bcjr(const int16_t *soft, uint32_t K, uint32_t n_iter, int 
     const int8_t t2s[3] = {x[6], x[8], x[10]}, t2p[3] = {x[7], x[9], x[11]};
     bcjr_bnd_t *bnd1 = (bcjr_bnd_t *)calloc(2, sizeof(bcjr_bnd_t)), *bnd2 = bnd1 + 1; /* all-zero (uniform) before the first iteration */
     for (uint32_t it = 0; it < n_iter; it++) {
-        bcjr_siso(S1, P1, A1, t1s, t1p, K, E1, NULL, bnd1, it);
+        bcjr_siso(S1, P1, A1, t1s, t1p, K, E1, NULL, bnd1, it, seg_len_mode);
         for (uint32_t i = 0; i < K; i++) A2[i] = E1[pi[i]];
-        bcjr_siso(S2, P2, A2, t2s, t2p, K, E2, it + 1 == n_iter ? hard : NULL, bnd2, it);
+        bcjr_siso(S2, P2, A2, t2s, t2p, K, E2, it + 1 == n_iter ? hard : NULL, bnd2, it, seg_len_mode);
         for (uint32_t j = 0; j < K; j++) A1[j] = inv[j] != 0xFFFF ? E2[inv[j]] : 0;
     }
     for (uint32_t j = 0; j < K; j++) /* a hole of the (wrapped) de-interleaver falls back on the first decoder's view of that bit */

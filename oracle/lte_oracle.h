@@ -75,6 +75,8 @@ void lo_turbo_decode_ref_taps(const float *d_interleaved, uint32_t K, uint8_t *c
  * holes read 0). */
 uint32_t lo_bcjr_n_seg(uint32_t K); /* 4, 2 or 1 independently decoded segments per block (see lte_oracle.c) */
 void lo_turbo_decode_bcjr(const int16_t *soft, uint32_t K, uint32_t n_iter, int qpp_spec, uint8_t *c_bits);
+uint32_t lo_bcjr_block_seg_len(uint32_t K); /* steps per alpha segment in the one-block-per-wavefront mode */
+void lo_turbo_decode_bcjr_block(const int16_t *soft, uint32_t K, uint32_t n_iter, int qpp_spec, uint8_t *c_bits);
 
 /* ---- encoder side (input synthesis for tests) ---- */
 void lo_turbo_encode(const uint8_t *c_bits, uint32_t K, uint8_t *d_planar /* 3(K+4) */);

@@ -102,6 +102,10 @@ def port():
     L.lo_time_turbo_decode_ref.restype = C.c_double
     if hasattr(L, "lo_turbo_decode_bcjr"):
         L.lo_turbo_decode_bcjr.argtypes = [np.ctypeslib.ndpointer(np.int16, flags="C_CONTIGUOUS"), u32, u32, C.c_int, u8p]
+    if hasattr(L, "lo_turbo_decode_bcjr_block"):
+        L.lo_turbo_decode_bcjr_block.argtypes = [np.ctypeslib.ndpointer(np.int16, flags="C_CONTIGUOUS"), u32, u32, C.c_int, u8p]
+        L.lo_bcjr_block_seg_len.argtypes = [u32]
+        L.lo_bcjr_block_seg_len.restype = u32
     _PORT = L
     return L
 

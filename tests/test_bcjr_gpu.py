@@ -140,3 +140,43 @@ def test_pdsch_chain_in_bcjr_mode(ctx, port, snr):
     assert n_ok == len(allocs) if snr >= 30 else n_ok > 0
     plan.close()
     d_sub.free()
+
+
+@pytest.mark.parametrize("K", [40, 104, 512, 1088, 2048, 3264, 6016, 6080, 6144])
+@pytest.mark.parametrize("sigma", [0.0, 0.9, 1.3])
+def test_bcjr_block_mode_bit_exact_vs_its_model(ctx, port, K, sigma):
+    """MI_LTE_TURBO_BCJR_BLOCK (k_bcjr_block: one code block per wavefront, 64 lanes = 64 segments, everything in LDS, one launch) against
+    ITS model, lo_turbo_decode_bcjr_block -- the batch model with the alpha recursion restarting every lo_bcjr_block_seg_len(K) steps.
+    Every block size class: one segment (K = 40), ragged last segments, 32 / 64 / 96 steps per lane, the wrapped interleaver (6144)."""
+    import openlte_amd as m
+    n = 5
+    tx, soft = llr_blocks(port, K, n, sigma, seed=2 * K + int(10 * sigma))
+    for n_iter, spec in ((8, False), (2, True)):
+        want = np.zeros((n, K), np.uint8)
+        for b in range(n):
+            port.lo_turbo_decode_bcjr_block(np.ascontiguousarray(soft[b].astype(np.int16)), K, n_iter, 1 if spec else 0, want[b])
+        got = ctx.turbo_decode(soft, K, mode=m.TURBO_BCJR_BLOCK, n_iter=n_iter, qpp_spec=spec)
+        assert (got == want).all(), (K, sigma, n_iter, spec)
+        if sigma <= 0.9 and not spec and K not in td.OVERFLOW_K:  # (the wrapped interleaver of those sizes is not a permutation)
+            assert (got == tx).all()
+
+
+def test_bcjr_block_mode_latency_of_one_block(ctx, port):
+    """What the mode is for: one K = 6144 block decoded alone (8 iterations).  Prints both modes' wall time per decode."""
+    import time
+    import openlte_amd as m
+    K = 6144
+    tx, soft = llr_blocks(port, K, 1, 0.9, seed=5)
+    res = {}
+    for name, mode in (("batch kernels", m.TURBO_BCJR), ("one block per wavefront", m.TURBO_BCJR_BLOCK)):
+        ctx.turbo_decode(soft, K, mode=mode, n_iter=8)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            ctx.turbo_decode(soft, K, mode=mode, n_iter=8)
+        res[name] = (time.perf_counter() - t0) / 20 * 1e3
+    print("BCJR, one K = 6144 block, 8 iterations, host round trip included:", {k: "%.2f ms" % v for k, v in res.items()})
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/bcjr_block_latency.txt", "w") as f:
+        f.write(repr(res) + "\n")
+    assert res["one block per wavefront"] < res["batch kernels"]

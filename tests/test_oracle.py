@@ -181,6 +181,24 @@ def test_bcjr_model_decodes_and_segments(port):
         assert (out == tx).all(), (K, spec)
 
 
+def test_bcjr_block_model_segments_and_decodes(port):
+    """The model of MI_LTE_TURBO_BCJR_BLOCK (one code block per wavefront): the batch model with the alpha recursion restarting every
+    lo_bcjr_block_seg_len(K) steps -- a whole number of 32-step beta blocks per lane, at most 64 segments -- still decodes."""
+    assert [port.lo_bcjr_block_seg_len(K) for K in (40, 2048, 2112, 4096, 4160, 6144)] == [32, 32, 64, 64, 96, 96]
+    assert all((K + port.lo_bcjr_block_seg_len(K) - 1) // port.lo_bcjr_block_seg_len(K) <= 64 for K in td.ALL_K)
+    rng = np.random.default_rng(8)
+    for K in (40, 1088, 6016):
+        tx = rng.integers(0, 2, K).astype(np.uint8)
+        d = np.zeros(3 * (K + 4), np.uint8)
+        port.lo_turbo_encode(np.ascontiguousarray(tx), K, d)
+        x = np.ascontiguousarray((1.0 - 2.0 * d.reshape(3, K + 4)).T).reshape(-1)
+        y = x + 0.9 * rng.standard_normal(x.shape)
+        llr = np.clip(np.round(y * 8 / 0.81), -127, 127).astype(np.int16)
+        out = np.zeros(K, np.uint8)
+        port.lo_turbo_decode_bcjr_block(np.ascontiguousarray(llr), K, 8, 0, out)
+        assert (out == tx).all(), K
+
+
 def _ref_vs_port_subframe(port, ref, iq_unit, sf, cell, n_ant):
     """Both CPU front ends on one int8 unit -> (ref phy, ref subframe, port cfg, port subframe)."""
     import ctypes as C

@@ -644,3 +644,34 @@ def test_limited_soft_buffer_and_redundancy_versions_on_large_blocks(ctx, port, 
             assert (bits[0] == tx[0, 0, :tbs]).all(), (tx_mode, tbs)
         plan.close()
         d_sub.free()
+
+
+@pytest.mark.parametrize("tbs,mod,nprb", [(16, 1, 1), (32, 1, 2), (48, 2, 1), (104, 1, 2), (152, 3, 1), (256, 1, 4), (296, 2, 3), (440, 1, 6)])
+def test_tiny_transport_blocks(ctx, port, tbs, mod, nprb):
+    """The smallest code blocks (K = 40 ... 464), half of them with K % 16 == 8: the last unit of the per-code-block kernels holds eight
+    positions, which is its own path in the rate un-matching gather, the vote and the CRC (whose weights are derived from one table
+    entry: the short unit starts from a negative exponent).  Soft bits, verdict and decoded bits against the oracle at three SNRs."""
+    import openlte_amd as m
+    from openlte_amd import synth
+    K = tbs + 24
+    assert K in td.ALL_K
+    cfg = m.DlCfg(2048, 100, 1, m.IQ_I8)
+    n_ok = 0
+    for k, snr in enumerate((30.0, 12.0, 4.0)):
+        cell, sf, first = 17 + 31 * k, (1, 4, 8)[k], 20 + 7 * k
+        alloc = [m.make_alloc(0, mod, tbs, list(range(first, first + nprb)), 0x200 + k)]
+        iq, tx = synth.dl_units(cfg, [sf], [cell], alloc, 1, n_pdcch_symbs=2, snr_db=snr, max_delay=4, seed=tbs + k)
+        lc, s = td.oracle_frontend(port, 2048, 100, 1, iq[0], sf, cell)
+        err, out, desc = oracle_pdsch(port, lc, s, alloc[0], 2, cell, 1)
+        d_sub = ctx.to_device(upload_oracle_subframe(ctx, s, 1))
+        plan = ctx.pdsch_plan(cfg, 2, alloc)
+        st, bits = plan.run(d_sub, [sf], [cell])
+        e = plan.soft_bits(0)
+        assert e.shape == desc.shape and (e == desc).all(), (tbs, snr)
+        assert st[0] == err and (err != 0 or (bits[0] == out).all()), (tbs, snr, st[0], err)
+        if err == 0:
+            assert (bits[0] == tx[0, 0, :tbs]).all()
+            n_ok += 1
+        plan.close()
+        d_sub.free()
+    assert n_ok >= 1, tbs  # the 30 dB case decodes

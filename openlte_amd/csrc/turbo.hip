@@ -161,6 +161,12 @@ __device__ __forceinline__ void load_idx16(const uint16_t *tab, uint32_t u, int 
 
 // sixteen table entries as fetched, for kernels that request them long before they unpack them
 struct IdxRaw { uint4 lo, hi; };
+__device__ __forceinline__ void unpack_idx16(const IdxRaw &r, uint32_t (&idx)[16])
+{
+    const uint32_t w[8] = {r.lo.x, r.lo.y, r.lo.z, r.lo.w, r.hi.x, r.hi.y, r.hi.z, r.hi.w};
+#pragma unroll
+    for (int k = 0; k < 16; k++) idx[k] = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+}
 
 // ---- where the soft values of a code block come from
 // (a) directly from the caller, in the reference's interleaved d[i*3+x] layout
@@ -1021,60 +1027,82 @@ __device__ __forceinline__ v2s sxor_tc(const SM &a, const SX &f) { return to_tc(
 //   C1 = soft_xor(A1, fb(A1)); I1[i] = C1[pi[i]]; M3 from pairs (q(d2), I1)
 struct PermArgs { const uint8_t *A1; const uint8_t *X2; uint8_t *out[2]; /* I1, M3 */ };
 
+// A workgroup handles PERM_NB code blocks one after the other (workgroup b + i * gridDim.x, i.e. the same XCD's chunk each time): thread u's
+// sixteen interleaver indices are the same for every block, so they are read once and stay in registers -- read per block, the table (the
+// same 6.5 KB for every workgroup of the launch) was 15 % of the kernel's time.
+#ifndef PERM_NB
+#define PERM_NB 4
+#endif
 template <int NSLOT>
 __global__ __launch_bounds__(384) void k_turbo_perm(PermArgs a, uint32_t K, uint32_t n_cb, const uint16_t *__restrict__ pi)
 {
     static_assert(NSLOT == 1, "one unit per thread");
     extern __shared__ __attribute__((aligned(16))) int8_t smp[]; // mtab[256] | C1[Kp] | reduction scratch (32 B); no static LDS (see k_turbo_prep)
     int8_t *mtab = smp, *sm = smp + MTAB_N;
-    const uint32_t cb = xcd_cb(blockIdx.x, n_cb), tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4;
-    if (cb >= n_cb) return;
-    const size_t   tile_off = (size_t)tile * Kp * 64;
+    const uint32_t Kp = kpad64(K), n_units = Kp >> 4;
     int           *red_i = reinterpret_cast<int *>(sm + Kp);
-    const uint32_t u  = threadIdx.x;
-    const int      nv = (u < n_units) ? min(16, max(0, (int)K - 16 * (int)u)) : -1;
-    uint4          X2 = make_uint4(0, 0, 0, 0);
-    if (nv >= 0) {
-        const UnitWords wa = load_unit_words(a.A1, tile_off, lane, u);
-        WordPairs       pa = word_pairs(wa.w[0]);
-        X2 = *reinterpret_cast<const uint4 *>(a.X2 + unit_off(tile_off, lane, u));
-        uint32_t c1[4];
+    const uint32_t u0 = threadIdx.x;
+    const int      nv = (u0 < n_units) ? min(16, max(0, (int)K - 16 * (int)u0)) : -1;
+    IdxRaw         praw; // the unit's interleaver indices; past the block end: slot K (C1 = 0 there)
+    {
+        const uint4 *ip = reinterpret_cast<const uint4 *>(pi + 16 * (size_t)(nv > 0 ? u0 : 0));
+        const uint32_t kk = K | K << 16;
+        praw.lo = ip[0];
+        praw.hi = (nv > 8) ? ip[1] : make_uint4(kk, kk, kk, kk);
+    }
+#pragma unroll 1
+    for (uint32_t it = 0; it < PERM_NB; it++) {
+        const uint32_t cb = xcd_cb(blockIdx.x + it * gridDim.x, n_cb), tile = cb >> 6, lane = cb & 63;
+        if (cb >= n_cb) continue; // uniform
+        const size_t   tile_off = (size_t)tile * Kp * 64;
+        // keep the loop body what the one-block kernel was: with the thread index and the packed indices opaque per iteration nothing derived
+        // from them (addresses, the sixteen unpacked indices) is hoisted out of the loop, which costs 33 registers and two waves per SIMD
+        uint32_t u = u0;
+        asm volatile("" : "+v"(u), "+v"(praw.lo.x), "+v"(praw.lo.y), "+v"(praw.lo.z), "+v"(praw.lo.w), "+v"(praw.hi.x), "+v"(praw.hi.y), "+v"(praw.hi.z), "+v"(praw.hi.w));
+        uint4          X2 = make_uint4(0, 0, 0, 0);
+        if (nv >= 0) {
+            const UnitWords wa = load_unit_words(a.A1, tile_off, lane, u);
+            WordPairs       pa = word_pairs(wa.w[0]);
+            X2 = *reinterpret_cast<const uint4 *>(a.X2 + unit_off(tile_off, lane, u));
+            uint32_t c1[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) { // Steps 2-3; 0 past the block end
-            const WordPairs ca = word_pairs(wa.w[j + 1]);
-            SX              fe, fo;
-            feedback_sm(ca, pa, fe, fo);
-            c1[j] = (4 * j < nv) ? merge_bytes(sxor_tc(ca.e, fe), sxor_tc(ca.o, fo)) : 0u;
-            pa    = ca;
+            for (int j = 0; j < 4; j++) { // Steps 2-3; 0 past the block end
+                const WordPairs ca = word_pairs(wa.w[j + 1]);
+                SX              fe, fo;
+                feedback_sm(ca, pa, fe, fo);
+                c1[j] = (4 * j < nv) ? merge_bytes(sxor_tc(ca.e, fe), sxor_tc(ca.o, fo)) : 0u;
+                pa    = ca;
+            }
+            *reinterpret_cast<uint4 *>(sm + 16 * u) = make_uint4(c1[0], c1[1], c1[2], c1[3]);
         }
-        *reinterpret_cast<uint4 *>(sm + 16 * u) = make_uint4(c1[0], c1[1], c1[2], c1[3]);
-    }
-    __syncthreads();
-    uint4 I1 = make_uint4(0, 0, 0, 0);
-    if (nv > 0) {
-        uint32_t idx[16];
-        load_idx16(pi, u, nv, idx, K); // past the block end: slot K (C1 = 0 there)
-        I1 = gather16_bytes(MTAB_N, idx); // Step 5
-    }
-    if (nv >= 0) *reinterpret_cast<uint4 *>(a.out[0] + unit_off(tile_off, lane, u)) = I1;
-    uint32_t w[16], wm = 0; // |q(d2)| + |I1|; both are 0 past the block end
-    if (nv <= 0) X2 = make_uint4(0, 0, 0, 0);
-    abs_sum16(X2, I1, w, wm);
-    const int   wmax = block_max_i((int)wm, red_i);
-    if (wmax == 254 || wmax == 127) { // closed forms of (int8)(127 * (w / W)), as in k_turbo_prep
-        uint32_t o[4];
+        __syncthreads();
+        uint4 I1 = make_uint4(0, 0, 0, 0);
+        if (nv > 0) {
+            uint32_t idx[16];
+            unpack_idx16(praw, idx);
+            I1 = gather16_bytes(MTAB_N, idx); // Step 5
+        }
+        if (nv >= 0) *reinterpret_cast<uint4 *>(a.out[0] + unit_off(tile_off, lane, u)) = I1;
+        uint32_t w[16], wm = 0; // |q(d2)| + |I1|; both are 0 past the block end
+        if (nv <= 0) X2 = make_uint4(0, 0, 0, 0);
+        abs_sum16(X2, I1, w, wm);
+        const int   wmax = block_max_i((int)wm, red_i); // (its two barriers also fence this block's C1 reads from the next block's writes)
+        if (wmax == 254 || wmax == 127) { // closed forms of (int8)(127 * (w / W)), as in k_turbo_prep
+            uint32_t o[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t p = pack4u(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
-            o[j] = wmax == 254 ? (p >> 1) & 0x7F7F7F7Fu : p;
+            for (int j = 0; j < 4; j++) {
+                const uint32_t p = pack4u(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+                o[j] = wmax == 254 ? (p >> 1) & 0x7F7F7F7Fu : p;
+            }
+            if (nv >= 0) *reinterpret_cast<uint4 *>(a.out[1] + unit_off(tile_off, lane, u)) = make_uint4(o[0], o[1], o[2], o[3]);
+            continue;
         }
-        if (nv >= 0) *reinterpret_cast<uint4 *>(a.out[1] + unit_off(tile_off, lane, u)) = make_uint4(o[0], o[1], o[2], o[3]);
-        return;
+        const float W = (float)wmax;
+        for (uint32_t t = threadIdx.x; t < MTAB_N; t += blockDim.x) mtab[t] = (int8_t)(int)(127.0f * ((float)t / W)); // one division per distinct w
+        __syncthreads();
+        if (nv >= 0) *reinterpret_cast<uint4 *>(a.out[1] + unit_off(tile_off, lane, u)) = lookup16(0, w);
+        __syncthreads(); // the table is rebuilt for the next block
     }
-    const float W = (float)wmax;
-    for (uint32_t t = threadIdx.x; t < MTAB_N; t += blockDim.x) mtab[t] = (int8_t)(int)(127.0f * ((float)t / W)); // one division per distinct w
-    __syncthreads();
-    if (nv >= 0) *reinterpret_cast<uint4 *>(a.out[1] + unit_off(tile_off, lane, u)) = lookup16(0, w);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1469,7 +1497,8 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
 
     PermArgs pa;
     pa.A1 = arr[AA1]; pa.X2 = arr[AX2]; pa.out[0] = arr[AI1]; pa.out[1] = arr[AM3];
-    MI_LAUNCH(ctx, "k_turbo_perm", k_turbo_perm<1>, dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), MTAB_N + Kp + 32, pa, K, n_cb, tb.d_pi);
+    const uint32_t perm_grid = ((8 * xcd_chunk(n_cb) + PERM_NB - 1) / PERM_NB + 7u) & ~7u; // a multiple of 8: b + i * grid stays on b's XCD
+    MI_LAUNCH(ctx, "k_turbo_perm", k_turbo_perm<1>, dim3(perm_grid), dim3(cb_threads), MTAB_N + Kp + 32, pa, K, n_cb, tb.d_pi);
 
     SisoArgs s23;
     s23.p[0] = {arr[AX2], arr[AI0], arr[AM2], arr[AB1], dec[1]};

@@ -100,9 +100,10 @@ def test_bcjr_rejects_float_input(ctx):
         ctx.turbo_decode(np.zeros((1, 3 * 44), np.float32), 40, mode=m.TURBO_BCJR)
 
 
+@pytest.mark.parametrize("block_mode", [False, True])
 @pytest.mark.parametrize("snr", [30.0, 9.0])
-def test_pdsch_chain_in_bcjr_mode(ctx, port, snr):
-    """mi_lte_pdsch_plan_set_decoder(BCJR): the full chain with the max-log-MAP decoder.  Checker = the pieces composed on the CPU:
+def test_pdsch_chain_in_bcjr_mode(ctx, port, snr, block_mode):
+    """mi_lte_pdsch_plan_set_decoder(BCJR / BCJR_BLOCK): the full chain with the max-log-MAP decoder (batch kernels, or one code block per wavefront).  Checker = the pieces composed on the CPU:
     the allocation's soft bits (already pinned to the oracle by the REF-mode tests) -> the restated rate un-matching -> saturation
     to int8, NULL -> 0 -> the plain-C model of the decoder -> filler removal + CRC24A.  Bits and verdicts must be equal."""
     import ctypes as C
@@ -117,7 +118,8 @@ def test_pdsch_chain_in_bcjr_mode(ctx, port, snr):
     got = ctx.dl_frontend(cfg, iq.reshape(-1, 2), np.arange(2) * iq.shape[1], sfs, cells)
     d_sub = ctx.to_device(np.ascontiguousarray(got, np.float32))
     plan = ctx.pdsch_plan(cfg, 2, allocs)
-    plan.set_decoder(m.TURBO_BCJR, 6, 0)
+    plan.set_decoder(m.TURBO_BCJR_BLOCK if block_mode else m.TURBO_BCJR, 6, 0)
+    model = port.lo_turbo_decode_bcjr_block if block_mode else port.lo_turbo_decode_bcjr
     st, bits = plan.run(d_sub, sfs, cells)
     n_ok = 0
     for a, al in enumerate(allocs):
@@ -128,7 +130,7 @@ def test_pdsch_chain_in_bcjr_mode(ctx, port, snr):
         assert n == 3 * (K + 4)
         soft = np.where(d == 10000.0, 0.0, np.clip(d, -127, 127)).astype(np.int16)
         c = np.zeros(K, np.uint8)
-        port.lo_turbo_decode_bcjr(soft, K, 6, 0, c)
+        model(soft, K, 6, 0, c)
         p = np.zeros(24, np.uint8)
         port.lo_crc24a(np.ascontiguousarray(c[:al.tbs]), al.tbs, p)
         ok = bool((p == c[al.tbs:]).all())

@@ -1415,17 +1415,40 @@ __global__ __launch_bounds__(256) void k_crc_finish(const uint8_t *__restrict__ 
     const uint8_t *c = c_bits + (size_t)cb * K;
     uint8_t       *o = g.out_bits + (size_t)alloc * g.out_stride;
     uint32_t crc = 0;
-    for (uint32_t j = F + threadIdx.x; j < K; j += blockDim.x) {
-        const uint32_t b = c[j] & 1u;
-        crc ^= b ? g.crc_tab[MI_CRC_TAB_BIAS + K - 1 - j] : 0u; // bit j weighs x^(K-1-j) mod gCRC24A; the check is "XOR of the weights == 0"
-        if (j < F + tbs && !g.packed) o[j - F] = (uint8_t)b;
-    }
-    if (g.packed)
-        for (uint32_t m = threadIdx.x; m < (tbs + 7) >> 3; m += blockDim.x) {
-            uint32_t v = 0;
-            for (uint32_t b = 0; b < 8; b++) v = v << 1 | ((8 * m + b < tbs) ? (c[F + 8 * m + b] & 1u) : 0u);
-            o[m] = (uint8_t)v;
+    if (((F | tbs) & 7u) == 0) {
+        // eight positions per thread and step: their bits as one 8-byte read, the weight of the LAST of them from the table and the other
+        // seven by "times x" (k_turbo_vote's scheme: the table is the same 13-24 KB for every workgroup, read per bit it was most of this kernel),
+        // the transport block's bytes (or its packed byte) as one store
+        const uint32_t GS = 0x864CFBu << 8; // g without its x^24 term, in the table's left-aligned form
+        for (uint32_t g8 = (F >> 3) + threadIdx.x; g8 < (K >> 3); g8 += blockDim.x) {
+            const uint2    bb = *reinterpret_cast<const uint2 *>(c + 8 * g8); // c is 8-byte aligned: K is a multiple of 8
+            const uint32_t lo = bb.x & 0x01010101u, hi = bb.y & 0x01010101u;   // positions 8 g8 .. + 3 | + 4 .. + 7, one bit per byte
+            uint32_t       w  = g.crc_tab[MI_CRC_TAB_BIAS + K - 8 * g8 - 8];   // position 8 g8 + 7 weighs x^(K - 8 g8 - 8)
+#pragma unroll
+            for (int k = 7; k >= 0; k--) {
+                const uint32_t m = 0u - (((k < 4 ? lo : hi) >> (8 * (k & 3))) & 1u);
+                crc ^= w & m;
+                if (k > 0) w = (w << 1) ^ ((uint32_t)((int)w >> 31) & GS);
+            }
+            const uint32_t j = 8 * g8 - F; // position in the transport block
+            if (j < tbs) {
+                if (g.packed) o[j >> 3] = (uint8_t)((((lo * 0x08040201u) >> 24) & 0xFu) << 4 | (((hi * 0x08040201u) >> 24) & 0xFu)); // first bit most significant
+                else          *reinterpret_cast<uint2 *>(o + j) = make_uint2(lo, hi); // out_stride and F are multiples of 8
+            }
         }
+    } else {
+        for (uint32_t j = F + threadIdx.x; j < K; j += blockDim.x) {
+            const uint32_t b = c[j] & 1u;
+            crc ^= b ? g.crc_tab[MI_CRC_TAB_BIAS + K - 1 - j] : 0u; // bit j weighs x^(K-1-j) mod gCRC24A; the check is "XOR of the weights == 0"
+            if (j < F + tbs && !g.packed) o[j - F] = (uint8_t)b;
+        }
+        if (g.packed)
+            for (uint32_t m = threadIdx.x; m < (tbs + 7) >> 3; m += blockDim.x) {
+                uint32_t v = 0;
+                for (uint32_t b = 0; b < 8; b++) v = v << 1 | ((8 * m + b < tbs) ? (c[F + 8 * m + b] & 1u) : 0u);
+                o[m] = (uint8_t)v;
+            }
+    }
     for (int sft = 32; sft > 0; sft >>= 1) crc ^= __shfl_xor(crc, sft);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = crc;
     __syncthreads();

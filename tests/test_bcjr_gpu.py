@@ -182,3 +182,20 @@ def test_bcjr_block_mode_latency_of_one_block(ctx, port):
     with open("gpurun_out/bcjr_block_latency.txt", "w") as f:
         f.write(repr(res) + "\n")
     assert res["one block per wavefront"] < res["batch kernels"]
+
+
+def test_bcjr_block_mode_more_blocks_than_compute_units(ctx, port):
+    """More workgroups than the chip runs at once (one wavefront per code block, ~100 KB of LDS each at K = 6144): every replica, wherever and
+    whenever its workgroup runs, decodes to its model's bits."""
+    import openlte_amd as m
+    for K, n_cb in ((6144, 700), (1088, 3000)):
+        tx, soft = llr_blocks(port, K, 4, 0.9, seed=K)
+        want = np.zeros((4, K), np.uint8)
+        for b in range(4):
+            port.lo_turbo_decode_bcjr_block(np.ascontiguousarray(soft[b].astype(np.int16)), K, 8, 0, want[b])
+        idx = (np.arange(n_cb) * 3 + np.arange(n_cb) // 7) % 4
+        d_in, d_out = ctx.to_device(soft[idx]), ctx.alloc(n_cb * K)
+        ctx.turbo_decode_dev(d_in, m.SOFT_I8, K, n_cb, d_out, mode=m.TURBO_BCJR_BLOCK, n_iter=8)
+        got = d_out.download(np.uint8).reshape(n_cb, K)
+        d_in.free(); d_out.free()
+        assert (got == want[idx]).all(), K

@@ -150,7 +150,8 @@ def turbo_own_io(K, n_cb, in_bytes, out_bytes, bcjr_iters=0):
     if bcjr_iters:
         h = 2 * bcjr_iters  # half-iterations: systematic, parity, a-priori in, extrinsic out, one byte of boundary state per step
         return {"k_bcjr_prep": n_cb * (in_bytes + 4 * k), "k_bcjr_half": n_cb * h * 5 * K, "k_bcjr_final": n_cb * 2 * K,
-                "k_rm_to_i8": n_cb * (in_bytes + 3 * (K + 4)), "k_crc_finish": n_cb * (K + out_bytes)}
+                "k_rm_bcjr_prep": n_cb * (in_bytes + 4 * k),  # the chain: soft bits in, the four granule arrays out (k_rm_to_i8 + k_bcjr_prep in one)
+                "k_crc_finish": n_cb * (K + out_bytes)}
     return {"k_turbo_prep": n_cb * (in_bytes + 6 * k),          # X0 X1 X2 I0 M1 M2
             "k_turbo_siso": n_cb * 3 * 5 * k,                   # per pass: two inputs, magnitudes, output, traceback bits out and back in
             "k_turbo_perm": n_cb * 4 * k,                       # A1 X2 in, I1 M3 out
@@ -417,10 +418,11 @@ class ChainWorkload:
         for K, cnt, E, tbs in ((3264, 8, 9936, 3240), (1088, 1, 3312, 1064)):
             for k, v in turbo_own_io(K, n * cnt, E, tbs, bc).items():
                 own[k] = own.get(k, 0) + v
-        tk = ["k_rm_to_i8", "k_bcjr_prep", "k_bcjr_half", "k_bcjr_final", "k_crc_finish"] if bc else \
+        tk = ["k_cb_desc", "k_rm_bcjr_prep", "k_bcjr_half", "k_bcjr_final", "k_crc_finish"] if bc else \
              ["k_cb_desc", "k_turbo_prep", "k_turbo_siso", "k_turbo_perm", "k_turbo_vote"]
-        if not bc:
-            own["k_cb_desc"] = n * 9 * 80  # per code block: its allocation's fields in, a 32-byte descriptor out
+        own["k_cb_desc"] = n * 9 * 80  # per code block: its allocation's fields in, a 32-byte descriptor out
+        if bc:
+            own.pop("k_bcjr_prep", None)  # (the stand-alone decoder's first kernel; the chain's is k_rm_bcjr_prep)
         return {"stages": {"frontend": (n * 339040, ["k_dl_fft", "k_dl_ce"]),
                            "demod": (n * res * (16 + 6), ["k_pdsch_demod"]),
                            "turbo": (n * (8 * _turbo_alg_bytes(3264) + _turbo_alg_bytes(1088)), tk)},

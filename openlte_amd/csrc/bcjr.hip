@@ -559,37 +559,61 @@ extern "C" size_t mi_lte_turbo_bcjr_scratch_bytes(uint32_t K, uint32_t n_cb)
     return n_tiles * (Kp * 64 * 4 + 64 * 16)                 // S1 P1 S2 P2, tails
            + n_pairs * ((Kp + 1) * 128 * 3)                  // E1 E2 HD rows
            + n_pairs * 64 * 32 * (2 * 2 * 8 + 2 * 2 * n_blk) // boundary states [decoder][buffer][segment | block]
+           + n_tiles * 64 * 32                                // 32 bytes per code block for the caller's prep kernel (MiBcjrBufs::aux)
            + 4096;
 }
 
-// n_iter full iterations of max-log-MAP over n_cb code blocks of size K; int8 soft input in the reference's layout
-int mi_turbo_bcjr_batch(mi_lte_ctx *ctx, const int8_t *d_soft, uint32_t K, uint32_t n_cb, uint32_t n_iter, int qpp_spec, uint8_t *d_c_bits)
+// The decode in three steps, so that a caller with its own first kernel (the PDSCH chain rate-un-matches straight into the granule arrays:
+// k_rm_bcjr_prep, turbo.hip) can replace the middle one:
+//   mi_turbo_bcjr_begin    scratch laid out and zeroed where the first half-iteration must read zero; returns the arrays the prep kernel fills
+//   (prep)                 S1 P1 S2 P2 granules + termination records
+//   mi_turbo_bcjr_iterate  n_iter full iterations + the decisions in natural order
+struct BcjrLayout { size_t n_tiles, n_pairs, Kp, a8, ex, n_blk, one, per_buf; uint8_t *base; int8_t *E1, *E2; uint8_t *HD; uint4 *bnd0; };
+static BcjrLayout bcjr_layout(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb)
+{
+    BcjrLayout l;
+    l.n_tiles = (n_cb + 63) / 64; l.n_pairs = (l.n_tiles + 1) / 2; l.Kp = kpad64(K); l.a8 = l.n_tiles * l.Kp * 64; l.ex = l.n_pairs * (l.Kp + 1) * 128;
+    l.n_blk = (l.Kp + 31) / 32;
+    l.base  = (uint8_t *)ctx->scratch;
+    l.E1    = (int8_t *)(l.base + 4 * l.a8 + l.n_tiles * 64 * 16); l.E2 = l.E1 + l.ex;
+    l.HD    = (uint8_t *)(l.E2 + l.ex);
+    // boundary states: per decoder and buffer, alpha [8 segments] then beta [n_blk blocks], each [pair][lane][8 x v2s = 2 x uint4]; uniform (0) before the first iteration
+    l.one     = l.n_pairs * 64 * 2; // uint4 per [segment | block]
+    l.bnd0    = (uint4 *)(((uintptr_t)(l.HD + l.ex) + 255) & ~(uintptr_t)255);
+    l.per_buf = (8 + l.n_blk) * l.one;
+    return l;
+}
+
+int mi_turbo_bcjr_begin(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, MiBcjrBufs *out)
+{
+    int rc = mi_ctx_reserve_scratch(ctx, mi_lte_turbo_bcjr_scratch_bytes(K, n_cb));
+    if (rc != MI_LTE_OK) return rc;
+    const BcjrLayout l = bcjr_layout(ctx, K, n_cb);
+    out->S1 = (int8_t *)l.base; out->P1 = out->S1 + l.a8; out->S2 = out->P1 + l.a8; out->P2 = out->S2 + l.a8;
+    out->tail = (int8_t *)(l.base + 4 * l.a8);
+    out->aux  = (void *)(((uintptr_t)(l.bnd0 + 4 * l.per_buf) + 255) & ~(uintptr_t)255);
+    MI_HIP_CHECK(ctx, hipMemsetAsync(l.bnd0, 0, 4 * l.per_buf * sizeof(uint4), ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemsetAsync(l.E2, 0, l.ex, ctx->stream)); // the a-priori values of the first half-iteration (and E2's zero rows)
+    MI_HIP_CHECK(ctx, hipMemset2DAsync(l.E1 + l.Kp * 128, (l.Kp + 1) * 128, 0, 128, l.n_pairs, ctx->stream)); // E1's zero row of every pair
+    if (n_cb % 64 || (l.n_tiles & 1)) MI_HIP_CHECK(ctx, hipMemsetAsync(l.base, 0, 4 * l.a8 + l.n_tiles * 64 * 16, ctx->stream)); // lanes past the batch end stay defined
+    return MI_LTE_OK;
+}
+
+int mi_turbo_bcjr_iterate(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, uint32_t n_iter, int qpp_spec, uint8_t *d_c_bits)
 {
     if (n_iter == 0 || n_iter > 64) return MI_LTE_ERR_INVALID_ARG;
     TurboTables tb;
     int         rc = mi_ctx_turbo_tables(ctx, K, qpp_spec ? 1 : 0, &tb);
     if (rc != MI_LTE_OK) return rc;
-    const size_t n_tiles = (n_cb + 63) / 64, n_pairs = (n_tiles + 1) / 2, Kp = kpad64(K), a8 = n_tiles * Kp * 64, ex = n_pairs * (Kp + 1) * 128;
-    const size_t n_blk = (Kp + 31) / 32;
-    rc = mi_ctx_reserve_scratch(ctx, mi_lte_turbo_bcjr_scratch_bytes(K, n_cb));
-    if (rc != MI_LTE_OK) return rc;
-    uint8_t *base = (uint8_t *)ctx->scratch;
+    const BcjrLayout l = bcjr_layout(ctx, K, n_cb);
+    const size_t     n_pairs = l.n_pairs, Kp = l.Kp, one = l.one, per_buf = l.per_buf;
     BcjrBufs B;
-    B.S1 = (int8_t *)base; B.P1 = B.S1 + a8; B.S2 = B.P1 + a8; B.P2 = B.S2 + a8;
-    B.tail = (int8_t *)(base + 4 * a8);
-    int8_t  *E1 = (int8_t *)(base + 4 * a8 + n_tiles * 64 * 16), *E2 = E1 + ex;
-    uint8_t *HD = (uint8_t *)(E2 + ex);
-    // boundary states: per decoder and buffer, alpha [8 segments] then beta [n_blk blocks], each [pair][lane][8 x v2s = 2 x uint4];
-    // uniform (0) before the first iteration
-    const size_t one = n_pairs * 64 * 2; // uint4 per [segment | block]
-    uint4       *bnd0 = (uint4 *)(((uintptr_t)(HD + ex) + 255) & ~(uintptr_t)255);
-    const size_t per_buf = (8 + n_blk) * one;
-    MI_HIP_CHECK(ctx, hipMemsetAsync(bnd0, 0, 4 * per_buf * sizeof(uint4), ctx->stream));
-    MI_HIP_CHECK(ctx, hipMemsetAsync(E2, 0, ex, ctx->stream)); // the a-priori values of the first half-iteration (and E2's zero rows)
-    MI_HIP_CHECK(ctx, hipMemset2DAsync(E1 + Kp * 128, (Kp + 1) * 128, 0, 128, n_pairs, ctx->stream)); // E1's zero row of every pair
-    if (n_cb % 64 || (n_tiles & 1)) MI_HIP_CHECK(ctx, hipMemsetAsync(base, 0, 4 * a8 + n_tiles * 64 * 16, ctx->stream)); // lanes past the batch end stay defined
-    const uint32_t cb_threads = (uint32_t)(((Kp >> 4) + 63) & ~(size_t)63);
-    MI_LAUNCH(ctx, "k_bcjr_prep", k_bcjr_prep, dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), Kp, d_soft, K, n_cb, tb.d_pi, B);
+    B.S1 = (int8_t *)l.base; B.P1 = B.S1 + l.a8; B.S2 = B.P1 + l.a8; B.P2 = B.S2 + l.a8;
+    B.tail = (int8_t *)(l.base + 4 * l.a8);
+    int8_t  *E1 = l.E1, *E2 = l.E2;
+    uint8_t *HD = l.HD;
+    uint4   *bnd0 = l.bnd0;
+    const size_t n_tiles = l.n_tiles;
     const uint32_t n_seg = bcjr_n_seg(K);
     for (uint32_t it = 0; it < n_iter; it++) {
         const bool last = it + 1 == n_iter;
@@ -613,6 +637,23 @@ int mi_turbo_bcjr_batch(mi_lte_ctx *ctx, const int8_t *d_soft, uint32_t K, uint3
     MI_HIP_CHECK(ctx, hipGetLastError());
     ctx->last_kernels = "k_bcjr_prep:1,k_bcjr_half: 2 per iteration,k_bcjr_final:1";
     return MI_LTE_OK;
+}
+
+// n_iter full iterations of max-log-MAP over n_cb code blocks of size K; int8 soft input in the reference's layout
+int mi_turbo_bcjr_batch(mi_lte_ctx *ctx, const int8_t *d_soft, uint32_t K, uint32_t n_cb, uint32_t n_iter, int qpp_spec, uint8_t *d_c_bits)
+{
+    if (n_iter == 0 || n_iter > 64) return MI_LTE_ERR_INVALID_ARG;
+    TurboTables tb;
+    int         rc = mi_ctx_turbo_tables(ctx, K, qpp_spec ? 1 : 0, &tb);
+    if (rc != MI_LTE_OK) return rc;
+    MiBcjrBufs mb;
+    rc = mi_turbo_bcjr_begin(ctx, K, n_cb, &mb);
+    if (rc != MI_LTE_OK) return rc;
+    BcjrBufs B{mb.S1, mb.P1, mb.S2, mb.P2, mb.tail};
+    const size_t   Kp = kpad64(K);
+    const uint32_t cb_threads = (uint32_t)(((Kp >> 4) + 63) & ~(size_t)63);
+    MI_LAUNCH(ctx, "k_bcjr_prep", k_bcjr_prep, dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), Kp, d_soft, K, n_cb, tb.d_pi, B);
+    return mi_turbo_bcjr_iterate(ctx, K, n_cb, n_iter, qpp_spec, d_c_bits);
 }
 
 // MI_LTE_TURBO_BCJR_BLOCK: one wavefront per code block, one launch for the whole decode (k_bcjr_block)

@@ -114,4 +114,7 @@ int   mi_pusch_plan_create_impl(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const
 int   mi_fft_rows(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const void *d_samples_a, const void *d_samples_b, const uint64_t *d_win_start,
                   uint32_t n_rows, float *d_rows);
 int   mi_turbo_bcjr_batch(mi_lte_ctx *ctx, const int8_t *d_soft, uint32_t K, uint32_t n_cb, uint32_t n_iter, int qpp_spec, uint8_t *d_c_bits);
+struct MiBcjrBufs { int8_t *S1, *P1, *S2, *P2, *tail; void *aux; }; // what a prep kernel fills (layouts: bcjr.hip); aux: 32 bytes per code block of its own
+int   mi_turbo_bcjr_begin(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, MiBcjrBufs *out);
+int   mi_turbo_bcjr_iterate(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, uint32_t n_iter, int qpp_spec, uint8_t *d_c_bits);
 int   mi_turbo_bcjr_block_batch(mi_lte_ctx *ctx, const int8_t *d_soft, uint32_t K, uint32_t n_cb, uint32_t n_iter, int qpp_spec, uint8_t *d_c_bits);

@@ -1408,6 +1408,69 @@ __global__ __launch_bounds__(256) void k_rm_to_i8(GroupDesc g, uint32_t K, uint3
     }
 }
 
+// The BCJR chain's first stage in one kernel: turbo rate un-matching (the REF path's rank-table gather, sums of repeats saturated to +-127) straight
+// into the max-log-MAP decoder's granule arrays (bcjr.hip: S1 P1 S2 P2, 16 steps = 16 bytes per lane) and termination records -- what k_rm_to_i8
+// followed by k_bcjr_prep did with the interleaved int8 block written to HBM and read back in between.  One workgroup per code block, thread
+// = 16 trellis steps, as in k_turbo_prep.  Dynamic LDS: staged e [e_cap] | S1 [Kp]; no static LDS (the gather addresses LDS from 0).
+__global__ __launch_bounds__(384) void k_rm_bcjr_prep(SrcRateUnmatch src, uint32_t K, uint32_t n_cb, const uint16_t *__restrict__ pi, MiBcjrBufs B)
+{
+    extern __shared__ __attribute__((aligned(16))) int8_t smr[];
+    const uint32_t cb = xcd_cb(blockIdx.x, n_cb), tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4, u = threadIdx.x;
+    if (cb >= n_cb) return; // uniform
+    int8_t *s1_lds = smr + src.e_cap;
+    src.init(cb, K);
+    const bool e_in_lds = src.stage_e(smr);
+    const int  nv = (u < n_units) ? min(16, max(0, (int)K - 16 * (int)u)) : -1;
+    int v[3][16];
+#pragma unroll
+    for (int x = 0; x < 3; x++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[x][k] = 0;
+    if (nv > 0) src.load16(u, nv, v, 0u, e_in_lds);
+    uint4 Q[3];
+#pragma unroll
+    for (int x = 0; x < 3; x++) {
+        int q[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) q[k] = max(-127, min(127, v[x][k])); // what the decoder takes: int8, +-127
+        Q[x] = pack16(q);
+    }
+    const size_t o8 = (size_t)tile * Kp * 64 + (size_t)u * 1024 + lane * 16; // granule u of this lane (bcjr.hip g8)
+    if (nv >= 0) {
+        *reinterpret_cast<uint4 *>(B.S1 + o8) = Q[0];
+        *reinterpret_cast<uint4 *>(B.P1 + o8) = Q[1];
+        *reinterpret_cast<uint4 *>(B.P2 + o8) = Q[2];
+        *reinterpret_cast<uint4 *>(s1_lds + 16 * u) = Q[0];
+    }
+    if (u < 12) { // the termination values d[K..K+3][x] (the rank tables stop at K): element 3K + u -> x[u] of k_bcjr_prep's record
+        const uint32_t a = src.g.desc[cb].alloc, txm = src.g.allocs[a].tx_mode, rv = src.g.allocs[a].rv_idx & 3u;
+        RmGeom rm;
+        if (src.g.ul) rm.init(K + 4, 1, rv, 1, 1, 1, false);
+        else          rm.init(K + 4, txm, rv);
+        const uint32_t i = K + u / 3;
+        const int      x = (int)(u % 3);
+        const uint32_t p = rm.pos(i, x);
+        int            t = 0;
+        if (p < rm.N_cb) {
+            const uint32_t c = rm.cnt(p);
+            for (uint32_t k = (p >= rm.k0m) ? c - rm.cnt_k0 : rm.Nnn - rm.cnt_k0 + c; k < src.E; k += src.Nnn) t += src.e[k];
+        }
+        const uint32_t slot = u < 6 ? ((u & 1u) ? 3 + (u >> 1) : (u >> 1)) : ((u & 1u) ? 9 + ((u - 7) >> 1) : 6 + ((u - 6) >> 1)); // t1s t1p t2s t2p
+        B.tail[((size_t)cb << 4) + slot] = (int8_t)max(-127, min(127, t));
+    }
+    __syncthreads();
+    if (nv >= 0) { // S2[i] = S1[pi[i]]
+        uint32_t s2[4] = {0, 0, 0, 0};
+        if (nv > 0) {
+            uint32_t idx[16];
+            load_idx16(pi, u, nv, idx, 0);
+#pragma unroll
+            for (int k = 0; k < 16; k++) s2[k >> 2] |= ((k < nv) ? (uint32_t)(uint8_t)s1_lds[idx[k]] : 0u) << (8 * (k & 3));
+        }
+        *reinterpret_cast<uint4 *>(B.S2 + o8) = make_uint4(s2[0], s2[1], s2[2], s2[3]);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_crc_finish(const uint8_t *__restrict__ c_bits, uint32_t K, uint32_t n_cb, GroupDesc g)
 {
     __shared__ uint32_t red[4];
@@ -1602,9 +1665,30 @@ int mi_turbo_bcjr_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte
     rc = rm_rank_tables(ctx, K, &t);
     if (rc != MI_LTE_OK) return rc;
     const uint32_t cap = (e_max_bytes + 16u + 63u) & ~63u, e_cap = cap <= 60 * 1024 ? cap : 0; // stage the allocation in LDS when it fits
-    MI_LAUNCH(ctx, "k_rm_to_i8", k_rm_to_i8, dim3(n_cb), dim3(256), e_cap, gd, K, n_cb, (const uint16_t *)t.d_tabs, (const uint32_t *)t.d_nnn, d_soft, e_cap);
-    MI_HIP_CHECK(ctx, hipGetLastError());
-    rc = block_mode ? mi_turbo_bcjr_block_batch(ctx, d_soft, K, n_cb, n_iter, qpp_spec, d_c_bits) : mi_turbo_bcjr_batch(ctx, d_soft, K, n_cb, n_iter, qpp_spec, d_c_bits);
+    if (block_mode) { // the one-block-per-wavefront kernel takes the interleaved int8 block
+        MI_LAUNCH(ctx, "k_rm_to_i8", k_rm_to_i8, dim3(n_cb), dim3(256), e_cap, gd, K, n_cb, (const uint16_t *)t.d_tabs, (const uint32_t *)t.d_nnn, d_soft, e_cap);
+        MI_HIP_CHECK(ctx, hipGetLastError());
+        rc = mi_turbo_bcjr_block_batch(ctx, d_soft, K, n_cb, n_iter, qpp_spec, d_c_bits);
+    } else { // the batch kernels: rate un-matching writes their granule arrays itself (k_rm_bcjr_prep)
+        static const bool lds_ok = no_static_lds((const void *)k_rm_bcjr_prep);
+        if (!lds_ok) { ctx->err = "k_rm_bcjr_prep was built with static LDS"; return MI_LTE_ERR_HIP; }
+        TurboTables tb;
+        rc = mi_ctx_turbo_tables(ctx, K, qpp_spec ? 1 : 0, &tb);
+        if (rc != MI_LTE_OK) return rc;
+        MiBcjrBufs mb;
+        rc = mi_turbo_bcjr_begin(ctx, K, n_cb, &mb);
+        if (rc != MI_LTE_OK) return rc;
+        const size_t   Kp = kpad64(K);
+        const uint32_t cb_threads = (uint32_t)(((Kp >> 4) + 63) & ~(size_t)63), e_cap2 = (Kp + cap <= 60 * 1024) ? cap : 0;
+        CbDesc *d_desc = (CbDesc *)mb.aux; // the per-block descriptors k_cb_desc writes
+        gd.desc = d_desc;
+        MI_LAUNCH(ctx, "k_cb_desc", k_cb_desc, dim3((n_cb + 255) / 256), dim3(256), 0, gd, n_cb, (const uint32_t *)t.d_nnn, d_desc);
+        SrcRateUnmatch src;
+        src.g = gd; src.tabs = t.d_tabs; src.nnn = t.d_nnn; src.e_cap = e_cap2;
+        MI_LAUNCH(ctx, "k_rm_bcjr_prep", k_rm_bcjr_prep, dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), e_cap2 + Kp, src, K, n_cb, (const uint16_t *)tb.d_pi, mb);
+        MI_HIP_CHECK(ctx, hipGetLastError());
+        rc = mi_turbo_bcjr_iterate(ctx, K, n_cb, n_iter, qpp_spec, d_c_bits);
+    }
     if (rc != MI_LTE_OK) return rc;
     MI_LAUNCH(ctx, "k_crc_finish", k_crc_finish, dim3(n_cb), dim3(256), 0, (const uint8_t *)d_c_bits, K, n_cb, gd);
     MI_HIP_CHECK(ctx, hipGetLastError());

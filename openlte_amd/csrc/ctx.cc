@@ -1,6 +1,8 @@
 // Context, memory and timing entry points of libmi_lte.so (see include/mi_lte.h).
 #include <cmath>
 
+#include <chrono>
+
 #include "ctx.hpp"
 
 #include <cstring>
@@ -182,6 +184,23 @@ void mi_prof_end(mi_lte_ctx *ctx)
     ctx->prof_armed = false;
     (void)hipEventRecord(ctx->prof_pool[ctx->prof_used + 1], ctx->stream);
     ctx->prof_used += 2;
+}
+
+// The wait of the per-call host forms (hostapi.cc).  Their caller is blocked on a result that is tens of microseconds of GPU work away, three
+// times per subframe; hipStreamSynchronize sleeps on the completion interrupt, and the wake-up alone costs ~35 us per wait on the MI355X box
+// (the scanner's per-subframe loop: 255 us with it, 134 us polling; HSA_ENABLE_INTERRUPT=0 shows the same from outside).  So: poll the
+// stream, and give the core back to the blocking wait only when the work turns out to be long (a first call that builds tables, a big batch).
+hipError_t mi_stream_wait_polling(mi_lte_ctx *ctx)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned n = 1;; n++) {
+        const hipError_t e = hipStreamQuery(ctx->stream);
+        if (e != hipErrorNotReady) return e;
+        if ((n & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) return hipStreamSynchronize(ctx->stream);
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
 }
 
 int mi_ctx_reserve_scratch(mi_lte_ctx *ctx, size_t bytes)

@@ -97,6 +97,7 @@ template <typename F> struct OnFail {
 template <typename F> OnFail<F> on_fail(F f) { return OnFail<F>{f}; }
 
 int   mi_ctx_reserve_scratch(mi_lte_ctx *ctx, size_t bytes);
+hipError_t mi_stream_wait_polling(mi_lte_ctx *ctx); // the per-call forms' wait: polls the stream instead of sleeping on an interrupt (ctx.cc)
 int   mi_ctx_gold_tables(mi_lte_ctx *ctx);
 int   mi_ctx_crc_table(mi_lte_ctx *ctx);
 int   mi_ctx_fft_twiddles(mi_lte_ctx *ctx);

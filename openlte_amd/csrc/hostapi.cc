@@ -112,7 +112,7 @@ int host_cache(mi_lte_ctx *ctx, HostCache **out)
 int need_pin(mi_lte_ctx *ctx, HostCache *hc, size_t bytes)
 {
     if (bytes <= hc->h_pin_bytes) return MI_LTE_OK;
-    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
     if (hc->h_pin) (void)hipHostFree(hc->h_pin);
     hc->h_pin = nullptr; hc->h_pin_bytes = 0;
     bytes = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
@@ -123,7 +123,7 @@ int need_pin(mi_lte_ctx *ctx, HostCache *hc, size_t bytes)
 int need_dev_in(mi_lte_ctx *ctx, HostCache *hc, size_t bytes)
 {
     if (bytes <= hc->d_in_bytes) return MI_LTE_OK;
-    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
     (void)hipFree(hc->d_in);
     hc->d_in = nullptr; hc->d_in_bytes = 0;
     bytes = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
@@ -137,7 +137,7 @@ int stage_pair(mi_lte_ctx *ctx, HostCache *hc, const float *h_a, const float *h_
     int rc = need_pin(ctx, hc, 2 * n * 4);
     if (rc == MI_LTE_OK) rc = need_dev_in(ctx, hc, 2 * n * 4);
     if (rc != MI_LTE_OK) return rc;
-    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); // the staging buffer may still be the source of the previous call's copy
+    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx)); // the staging buffer may still be the source of the previous call's copy
     memcpy(hc->h_pin, h_a, n * 4);
     memcpy(hc->h_pin + n * 4, h_b, n * 4);
     MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->d_in, hc->h_pin, 2 * n * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -245,7 +245,7 @@ int bind_subframe(mi_lte_ctx *ctx, HostCache *hc, const float *re, const float *
     const size_t planes = ul ? 2 : 2 + 2 * (size_t)n_ant, bytes = planes * ROW * 4;
     int rc = need_pin(ctx, hc, bytes);
     if (rc != MI_LTE_OK) return rc;
-    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
     float *st = (float *)hc->h_pin;
     memcpy(st, re, ROW * 4);
     memcpy(st + ROW, im, ROW * 4);
@@ -299,7 +299,7 @@ int mi_lte_get_dl_subframe_and_ce_host(mi_lte_ctx *ctx, uint32_t fft_size, uint3
     rc = need_pin(ctx, hc, total);
     if (rc == MI_LTE_OK) rc = need_dev_in(ctx, hc, total);
     if (rc != MI_LTE_OK) return rc;
-    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); // the staging buffer may still be the source of the previous call's copy
+    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx)); // the staging buffer may still be the source of the previous call's copy
     memcpy(hc->h_pin, h_i + start, need * 4);
     memcpy(hc->h_pin + need * 4, h_q + start, need * 4);
     struct { uint64_t start; uint32_t sf, cell; } par = {0, subfr_num, N_id_cell};
@@ -315,7 +315,7 @@ int mi_lte_get_dl_subframe_and_ce_host(mi_lte_ctx *ctx, uint32_t fft_size, uint3
     rc = need_pin(ctx, hc, bytes);
     if (rc != MI_LTE_OK) return rc;
     MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->h_pin, hc->d_sub, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
     const float *st = (const float *)hc->h_pin;
     memcpy(h_symb_re, st, ROW * 4);
     memcpy(h_symb_im, st + ROW, ROW * 4);
@@ -365,7 +365,7 @@ int mi_lte_pdsch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const fl
     if (rc != MI_LTE_OK) return rc;
     // verdict and bits in one copy (the bits are only handed over when the CRC matched, like the reference, :12861-12869)
     MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->h_pin, hc->d_res, 64 + (size_t)a.tbs, hipMemcpyDeviceToHost, ctx->stream));
-    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
     int32_t st;
     memcpy(&st, hc->h_pin, 4);
     if (st == 0) {
@@ -532,7 +532,7 @@ int mi_lte_get_ul_subframe_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_r
     rc = need_pin(ctx, hc, 2 * ROW * 4);
     if (rc != MI_LTE_OK) return rc;
     MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->h_pin, hc->d_sub, 2 * ROW * 4, hipMemcpyDeviceToHost, ctx->stream));
-    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
     const size_t row = 14 * 1200 * sizeof(float); // rows 14, 15 of the caller's struct are left alone, as the reference leaves them
     memcpy(h_symb_re, hc->h_pin, row);
     memcpy(h_symb_im, hc->h_pin + ROW * 4, row);
@@ -583,7 +583,7 @@ int mi_lte_pusch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_ul, const fl
     rc = need_pin(ctx, hc, 8192);
     if (rc != MI_LTE_OK) return rc;
     MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->h_pin, hc->d_res, 64 + (size_t)a.tbs, hipMemcpyDeviceToHost, ctx->stream));
-    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
     int32_t st;
     memcpy(&st, hc->h_pin, 4);
     if (st == 0) {
@@ -643,14 +643,14 @@ int mi_lte_rate_unmatch_turbo_host(mi_lte_ctx *ctx, const float *h_e, uint32_t N
     rc = need_pin(ctx, hc, e_bytes > d_bytes ? e_bytes : d_bytes);
     if (rc == MI_LTE_OK) rc = need_dev_in(ctx, hc, e_bytes + d_bytes);
     if (rc != MI_LTE_OK) return rc;
-    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
     memcpy(hc->h_pin, h_e, (size_t)N_e * 4);
     float *d_e = (float *)hc->d_in, *d_d = (float *)(hc->d_in + e_bytes);
     MI_HIP_CHECK(ctx, hipMemcpyAsync(d_e, hc->h_pin, (size_t)N_e * 4, hipMemcpyHostToDevice, ctx->stream));
     rc = mi_lte_rate_unmatch_turbo_batch(ctx, d_e, N_e, N_dummy_bits, C, tx_mode, N_soft, M_dl_harq, chan_type, rv_idx, 1, d_d);
     if (rc != MI_LTE_OK) return rc;
     MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->h_pin, d_d, d_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
     memcpy(h_d, hc->h_pin, d_bytes);
     *N_d = 3 * N_dummy_bits;
     return 0;

@@ -512,7 +512,7 @@ int mi_lte_pdcch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, float ph
         ctx->err = "PDCCH plan: device allocation failed";
         return MI_LTE_ERR_NOMEM;
     }
-    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
     pl->dev = PdcchDev{nrb, cfg->N_ant, n_cells, {sz[0], sz[1]}, (flags & MI_LTE_PDCCH_PER_PORT_ESTIMATES) ? 1u : 0u, (const uint32_t *)d_cells, (const uint32_t *)d_pcf, (const uint32_t *)d_cand,
                        (const uint16_t *)d_rm};
     guard.armed = false;
@@ -658,7 +658,7 @@ int mi_lte_pdcch_decode_run(mi_lte_ctx *ctx, mi_lte_pdcch_plan *pl, const float 
     MI_HIP_CHECK(ctx, hipGetLastError());
     std::vector<PdcchResult> res(n_units);
     MI_HIP_CHECK(ctx, hipMemcpyAsync(res.data(), d_res, sizeof(PdcchResult) * (size_t)n_units, hipMemcpyDeviceToHost, ctx->stream));
-    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
     for (uint32_t u = 0; u < n_units; u++) {
         h_cfi[u]     = res[u].cfi;
         h_n_symbs[u] = res[u].n_symbs;
@@ -714,7 +714,7 @@ int mi_lte_pbch_decode_run(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const floa
     MI_HIP_CHECK(ctx, hipGetLastError());
     std::vector<PbchResult> res(n_units);
     MI_HIP_CHECK(ctx, hipMemcpyAsync(res.data(), d_res, sizeof(PbchResult) * (size_t)n_units, hipMemcpyDeviceToHost, ctx->stream));
-    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
     for (uint32_t u = 0; u < n_units; u++) { h_N_ant[u] = res[u].N_ant; h_offset[u] = res[u].offset; h_mib[u] = res[u].mib; }
     ctx->last_kernels = "k_pbch_decode:1";
     return MI_LTE_OK;

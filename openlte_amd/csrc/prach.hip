@@ -221,7 +221,7 @@ static int prach_bluestein_tables(mi_lte_ctx *ctx, float2 **d_chirp, float2 **d_
     MI_HIP_CHECK(ctx, hipMalloc((void **)&d, sizeof(float2) * tab.size()));
     ctx->owned.push_back(d);
     MI_HIP_CHECK(ctx, hipMemcpyAsync(d, tab.data(), sizeof(float2) * tab.size(), hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
     ctx->d_prach_tab = d;
     *d_chirp = d; *d_bspec = d + 1024; *d_tw = d + 1024 + BL;
     return MI_LTE_OK;
@@ -290,7 +290,7 @@ static int prach_plan_common(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const mi
     MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_xu_fft, xu.data(), sizeof(float2) * xu.size(), hipMemcpyHostToDevice, ctx->stream));
     int rcb = prach_bluestein_tables(ctx, &pl->d_chirp, &pl->d_bspec, &pl->d_tw);
     if (rcb != MI_LTE_OK) return rcb;
-    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
     guard.armed = false;
     *out = pl;
     return MI_LTE_OK;
@@ -346,7 +346,7 @@ int mi_lte_prach_detect_run(mi_lte_ctx *ctx, mi_lte_prach_plan *pl, const void *
     MI_HIP_CHECK(ctx, hipGetLastError());
     std::vector<CorrOut> co((size_t)n_occ * pl->n_roots);
     MI_HIP_CHECK(ctx, hipMemcpyAsync(co.data(), d_co, co_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
     for (uint32_t o = 0; o < n_occ; o++) { // the reference's scalar verdict (liblte_phy.cc:3436-3474)
         float    ave_val = 0, max_val = 0;
         uint32_t max_root = 0, max_offset = 0;

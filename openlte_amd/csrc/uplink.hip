@@ -524,7 +524,7 @@ int mi_pusch_plan_create_impl(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const m
     MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_dmrs, dmrs.data(), sizeof(float) * dmrs.size(), hipMemcpyHostToDevice, ctx->stream));
     MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_e_off, pl->h_e_off.data(), sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
     MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_cb_alloc, cb_alloc.data(), sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
     guard.armed = false;
     *out = pl;
     return MI_LTE_OK;
@@ -614,7 +614,7 @@ int mi_lte_pucch_decode_run(mi_lte_ctx *ctx, uint32_t N_rb_ul, uint32_t N_ant, c
     MI_HIP_CHECK(ctx, hipGetLastError());
     std::vector<uint8_t> o(b_out);
     MI_HIP_CHECK(ctx, hipMemcpyAsync(o.data(), base + o_out, b_out, hipMemcpyDeviceToHost, ctx->stream));
-    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
     for (uint32_t r = 0; r < n_res; r++) { h_bits[2 * r] = o[4 * r]; h_bits[2 * r + 1] = o[4 * r + 1]; h_n_bits[r] = o[4 * r + 2]; h_rc[r] = o[4 * r + 3]; }
     ctx->last_kernels = "k_pucch_decode:1";
     return MI_LTE_OK;

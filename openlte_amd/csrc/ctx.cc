@@ -60,6 +60,7 @@ void mi_lte_ctx_destroy(mi_lte_ctx *ctx)
     for (void *p : ctx->owned) (void)hipFree(p);
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->h_small) (void)hipHostFree(ctx->h_small);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -212,6 +213,18 @@ int mi_ctx_reserve_scratch(mi_lte_ctx *ctx, size_t bytes)
     ctx->scratch_bytes = 0;
     MI_HIP_CHECK(ctx, hipMalloc(&ctx->scratch, bytes));
     ctx->scratch_bytes = bytes;
+    return MI_LTE_OK;
+}
+
+int mi_ctx_small_results(mi_lte_ctx *ctx, size_t bytes, void **h, void **d)
+{
+    if (bytes > MI_SMALL_BYTES) return MI_LTE_ERR_INVALID_ARG;
+    if (!ctx->h_small) {
+        MI_HIP_CHECK(ctx, hipHostMalloc(&ctx->h_small, MI_SMALL_BYTES, hipHostMallocMapped));
+        MI_HIP_CHECK(ctx, hipHostGetDevicePointer(&ctx->d_small, ctx->h_small, 0));
+    }
+    *h = ctx->h_small;
+    *d = ctx->d_small;
     return MI_LTE_OK;
 }
 

@@ -42,6 +42,7 @@ struct mi_lte_ctx {
     std::string        last_kernels;
     void              *scratch       = nullptr;
     size_t             scratch_bytes = 0;
+    void              *h_small = nullptr, *d_small = nullptr; // MI_SMALL_BYTES of pinned host memory the kernels can write (mi_ctx_small_results)
     std::map<uint64_t, TurboTables> turbo_tables; // key = K | (spec << 32)
     std::map<uint32_t, RmTables>    rm_tables;    // key = K
     std::vector<void *> owned;                    // allocations released at destroy
@@ -97,6 +98,11 @@ template <typename F> struct OnFail {
 template <typename F> OnFail<F> on_fail(F f) { return OnFail<F>{f}; }
 
 int   mi_ctx_reserve_scratch(mi_lte_ctx *ctx, size_t bytes);
+// Where a kernel puts a few KB of results that the host reads right after the wait: pinned host memory mapped into the device (no copy
+// command, which costs more API time than a small call's kernel runs for).  *h and *d are the host's and the device's pointer to the same
+// bytes; MI_LTE_ERR_INVALID_ARG when bytes > MI_SMALL_BYTES (the caller then takes its scratch + copy route).
+constexpr size_t MI_SMALL_BYTES = 64 * 1024;
+int   mi_ctx_small_results(mi_lte_ctx *ctx, size_t bytes, void **h, void **d);
 hipError_t mi_stream_wait_polling(mi_lte_ctx *ctx); // the per-call forms' wait: polls the stream instead of sleeping on an interrupt (ctx.cc)
 int   mi_ctx_gold_tables(mi_lte_ctx *ctx);
 int   mi_ctx_crc_table(mi_lte_ctx *ctx);

@@ -62,8 +62,11 @@ struct HostCache {
     uint8_t *h_pin = nullptr; size_t h_pin_bytes = 0; // pinned staging
     uint8_t *d_in = nullptr;  size_t d_in_bytes = 0;  // sample staging on the device
     float    *d_sub = nullptr;                        // the device subframe: (2 + 2*4) planes of 16 x 1200 floats
-    uint32_t *d_par = nullptr;                        // 16 words of per-call parameters
-    uint8_t  *d_res = nullptr;                        // one decode's results: verdict at byte 0, decoded bits from byte 64 (one D2H brings both)
+    // Parameters and results of a call live in PINNED HOST memory that the kernels read and write directly (h_* = the host's pointer, d_* = the
+    // device's for the same bytes): a dozen bytes of parameters and a few hundred of results per call are not worth a copy command each --
+    // hipMemcpyAsync costs ~20 us of API time per call on this platform, five of them per subframe were most of the 1.4 MHz scan's loop
+    uint32_t *h_par = nullptr, *d_par = nullptr;      // 16 words of per-call parameters
+    uint8_t  *h_res = nullptr, *d_res = nullptr;      // one decode's results: verdict at byte 0, decoded bits from byte 64
     uint8_t  *d_out = nullptr;                        // = d_res + 64
     int32_t  *d_st  = nullptr;                        // = d_res
     uint32_t  par_sf = ~0u, par_cell = ~0u;           // what d_par[4..5] hold (subframe number, cell): uploaded only when they change
@@ -86,7 +89,9 @@ void host_cache_free(mi_lte_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     hc->pdsch.clear(ctx); hc->pdcch.clear(ctx); hc->pusch.clear(ctx); hc->prach.clear(ctx);
     if (hc->h_pin) (void)hipHostFree(hc->h_pin);
-    (void)hipFree(hc->d_in); (void)hipFree(hc->d_sub); (void)hipFree(hc->d_par); (void)hipFree(hc->d_res);
+    (void)hipFree(hc->d_in); (void)hipFree(hc->d_sub);
+    if (hc->h_par) (void)hipHostFree(hc->h_par);
+    if (hc->h_res) (void)hipHostFree(hc->h_res);
     delete hc;
     ctx->host_cache = nullptr;
 }
@@ -100,8 +105,11 @@ int host_cache(mi_lte_ctx *ctx, HostCache **out)
         auto guard = on_fail([&] { host_cache_free(ctx); }); // a half-built cache is not left behind: the next call starts over
         MI_HIP_CHECK(ctx, hipMalloc((void **)&hc->d_sub, 10 * ROW * sizeof(float)));
         MI_HIP_CHECK(ctx, hipMemsetAsync(hc->d_sub, 0, 10 * ROW * sizeof(float), ctx->stream));
-        MI_HIP_CHECK(ctx, hipMalloc((void **)&hc->d_par, 64));
-        MI_HIP_CHECK(ctx, hipMalloc((void **)&hc->d_res, 64 + 6144 + 64));
+        MI_HIP_CHECK(ctx, hipHostMalloc((void **)&hc->h_par, 64, hipHostMallocMapped));
+        MI_HIP_CHECK(ctx, hipHostMalloc((void **)&hc->h_res, 64 + 6144 + 64, hipHostMallocMapped));
+        MI_HIP_CHECK(ctx, hipHostGetDevicePointer((void **)&hc->d_par, hc->h_par, 0));
+        MI_HIP_CHECK(ctx, hipHostGetDevicePointer((void **)&hc->d_res, hc->h_res, 0));
+        memset(hc->h_par, 0, 64);
         hc->d_st  = (int32_t *)hc->d_res;
         hc->d_out = hc->d_res + 64;
         guard.armed = false;
@@ -131,18 +139,25 @@ int need_dev_in(mi_lte_ctx *ctx, HostCache *hc, size_t bytes)
     hc->d_in_bytes = bytes;
     return MI_LTE_OK;
 }
-// n floats of each of two host arrays -> d_in (a | b), through the pinned staging buffer: one copy on the PCIe link
-int stage_pair(mi_lte_ctx *ctx, HostCache *hc, const float *h_a, const float *h_b, size_t n, float **d_a, float **d_b)
+// n floats of each of two host arrays -> (a | b) where a kernel can read them.  in_place: the pinned staging buffer itself, for a kernel
+// that reads every sample once (each crosses the PCIe link once either way, and there is no copy command to pay for); otherwise d_in,
+// through one copy, for a kernel that comes back to its samples (the PRACH correlator)
+int stage_pair(mi_lte_ctx *ctx, HostCache *hc, const float *h_a, const float *h_b, size_t n, bool in_place, float **d_a, float **d_b)
 {
     int rc = need_pin(ctx, hc, 2 * n * 4);
-    if (rc == MI_LTE_OK) rc = need_dev_in(ctx, hc, 2 * n * 4);
+    if (rc == MI_LTE_OK && !in_place) rc = need_dev_in(ctx, hc, 2 * n * 4);
     if (rc != MI_LTE_OK) return rc;
-    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx)); // the staging buffer may still be the source of the previous call's copy
+    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx)); // the staging buffer may still be in use by the previous call
     memcpy(hc->h_pin, h_a, n * 4);
     memcpy(hc->h_pin + n * 4, h_b, n * 4);
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->d_in, hc->h_pin, 2 * n * 4, hipMemcpyHostToDevice, ctx->stream));
-    *d_a = (float *)hc->d_in;
-    *d_b = (float *)hc->d_in + n;
+    float *d = (float *)hc->d_in;
+    if (in_place) {
+        MI_HIP_CHECK(ctx, hipHostGetDevicePointer((void **)&d, hc->h_pin, 0));
+    } else {
+        MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->d_in, hc->h_pin, 2 * n * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    *d_a = d;
+    *d_b = d + n;
     return MI_LTE_OK;
 }
 
@@ -214,23 +229,53 @@ uint64_t hash_plane(const void *p, size_t n_bytes, uint64_t seed) { return have_
 
 uint64_t subframe_fp(const float *re, const float *im, const float *ce_re, const float *ce_im, uint32_t n_ant, uint32_t n_sc, uint32_t rows)
 {
-    const size_t nb = (size_t)rows * 1200 * sizeof(float); // rows are contiguous inside a plane
-    uint64_t     h  = ((uint64_t)n_ant << 32) | n_sc;
-    h = hash_plane(re, nb, h);
-    h = hash_plane(im, nb, h);
+    uint64_t h = ((uint64_t)n_ant << 32) | n_sc;
+    // the first n_sc columns of each row are all that the decoders (and the reference's) ever read: a narrow carrier's fingerprint is
+    // over those alone, row by row (1.4 MHz: 4 KB a plane instead of 67 KB)
+    auto plane = [&](const float *p) {
+        if (n_sc >= 1200) { h = hash_plane(p, (size_t)rows * 1200 * sizeof(float), h); return; } // rows are contiguous inside a plane
+        for (uint32_t r = 0; r < rows; r++) h = hash_plane(p + r * 1200, n_sc * sizeof(float), h);
+    };
+    plane(re);
+    plane(im);
     for (uint32_t p = 0; p < n_ant && ce_re; p++) {
-        h = hash_plane(ce_re + p * ROW, nb, h);
-        h = hash_plane(ce_im + p * ROW, nb, h);
+        plane(ce_re + p * ROW);
+        plane(ce_im + p * ROW);
     }
     return h;
+}
+
+// rows of d_sub (1200 wide) -> their first n_sc columns, packed, written straight into pinned host memory: what a narrow carrier's
+// get_dl_subframe_and_ce hands back (1.4 MHz: 18 KB instead of 307 KB over the link, and no copy command)
+__global__ void k_pack_cols(const float *__restrict__ sub, float *__restrict__ out, uint32_t n_sc)
+{
+    const float *src = sub + (size_t)blockIdx.x * 1200;
+    float       *dst = out + (size_t)blockIdx.x * n_sc;
+    for (uint32_t c = threadIdx.x; c < n_sc; c += blockDim.x) dst[c] = src[c];
+}
+int fetch_packed_rows(mi_lte_ctx *ctx, HostCache *hc, size_t planes, uint32_t n_sc, const float **st)
+{
+    int rc = need_pin(ctx, hc, planes * 16 * n_sc * 4);
+    if (rc != MI_LTE_OK) return rc;
+    float *d_pin;
+    MI_HIP_CHECK(ctx, hipHostGetDevicePointer((void **)&d_pin, hc->h_pin, 0));
+    k_pack_cols<<<dim3((uint32_t)planes * 16), dim3(n_sc >= 256 ? 256 : 64), 0, ctx->stream>>>(hc->d_sub, d_pin, n_sc);
+    MI_HIP_CHECK(ctx, hipGetLastError());
+    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
+    *st = (const float *)hc->h_pin;
+    return MI_LTE_OK;
+}
+// rows 0..rows-1 of packed plane `plane` -> the first n_sc columns of the caller's 1200-wide rows
+void unpack_rows(float *dst, const float *st, size_t plane, uint32_t rows, uint32_t n_sc)
+{
+    for (uint32_t r = 0; r < rows; r++) memcpy(dst + r * 1200, st + (plane * 16 + r) * n_sc, n_sc * 4);
 }
 
 // (subframe number, cell) of the decoders' per-unit arrays at d_par[4], d_par[5]: the three or more decode calls of a subframe share them
 int bind_params(mi_lte_ctx *ctx, HostCache *hc, uint32_t subfr_num, uint32_t N_id_cell)
 {
     if (hc->par_sf == subfr_num && hc->par_cell == N_id_cell) return MI_LTE_OK;
-    const uint32_t par[2] = {subfr_num, N_id_cell};
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->d_par + 4, par, 8, hipMemcpyHostToDevice, ctx->stream));
+    hc->h_par[4] = subfr_num; hc->h_par[5] = N_id_cell; // (every per-call form ends with a wait: no kernel of an earlier call is still reading them)
     hc->par_sf = subfr_num; hc->par_cell = N_id_cell;
     return MI_LTE_OK;
 }
@@ -294,38 +339,39 @@ int mi_lte_get_dl_subframe_and_ce_host(mi_lte_ctx *ctx, uint32_t fft_size, uint3
     const uint32_t sc = 2048 / fft_size;
     const size_t   per_sf = 30720 / sc, need = per_sf + 2 * fft_size + 160 / sc + 144 / sc - 1; // last sample symbol 15 reads, +1
     const size_t   start = (size_t)frame_start_idx + (size_t)subfr_num * per_sf;
-    // the two sample arrays and the unit's parameters (start, subframe number, cell) in one staging buffer: one copy over the link
+    // the two sample arrays and the unit's parameters (start, subframe number, cell) in one staging buffer
     const size_t nb = 2 * need * 4, total = nb + 16;
     rc = need_pin(ctx, hc, total);
-    if (rc == MI_LTE_OK) rc = need_dev_in(ctx, hc, total);
     if (rc != MI_LTE_OK) return rc;
-    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx)); // the staging buffer may still be the source of the previous call's copy
+    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx)); // the staging buffer may still be in use by the previous call
     memcpy(hc->h_pin, h_i + start, need * 4);
     memcpy(hc->h_pin + need * 4, h_q + start, need * 4);
     struct { uint64_t start; uint32_t sf, cell; } par = {0, subfr_num, N_id_cell};
     memcpy(hc->h_pin + nb, &par, sizeof(par));
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->d_in, hc->h_pin, total, hipMemcpyHostToDevice, ctx->stream));
-    float          *d_i = (float *)hc->d_in, *d_q = d_i + need;
-    const uint32_t *d_p = (const uint32_t *)(hc->d_in + nb);
+    // the FFT kernel reads the staging buffer itself (pinned host memory, mapped): each sample crosses the link once either way, and a
+    // copy command's API time (~10 us) is a tenth of the whole call at 20 MHz, more on a narrow carrier
+    uint8_t *d_src;
+    MI_HIP_CHECK(ctx, hipHostGetDevicePointer((void **)&d_src, hc->h_pin, 0));
+    float          *d_i = (float *)d_src, *d_q = d_i + need;
+    const uint32_t *d_p = (const uint32_t *)(d_src + nb);
     hc->sub_host = nullptr; // d_sub is being rewritten
     mi_lte_dl_cfg cfg = {fft_size, N_rb_dl, N_ant, MI_LTE_IQ_F32_PLANAR | MI_LTE_IQ_ALL_ROWS}; // every row the reference's struct holds
     rc = mi_lte_dl_frontend_batch(ctx, &cfg, d_i, d_q, (const uint64_t *)d_p, d_p + 2, d_p + 3, 1, hc->d_sub);
     if (rc != MI_LTE_OK) return rc;
-    const size_t planes = 2 + 2 * (size_t)N_ant, bytes = planes * ROW * 4;
-    rc = need_pin(ctx, hc, bytes);
+    const size_t   planes = 2 + 2 * (size_t)N_ant;
+    const uint32_t n_sc = 12 * N_rb_dl;
+    // the reference writes columns 0..n_sc-1 of each row and nothing else (samples_to_symbols_dl, :8628-8632): so does this form
+    const float *st;
+    rc = fetch_packed_rows(ctx, hc, planes, n_sc, &st);
     if (rc != MI_LTE_OK) return rc;
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->h_pin, hc->d_sub, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
-    const float *st = (const float *)hc->h_pin;
-    memcpy(h_symb_re, st, ROW * 4);
-    memcpy(h_symb_im, st + ROW, ROW * 4);
+    unpack_rows(h_symb_re, st, 0, 16, n_sc);
+    unpack_rows(h_symb_im, st, 1, 16, n_sc);
     for (uint32_t p = 0; p < N_ant; p++) { // estimate rows 14 and 15 are never written, as in the reference
-        memcpy(h_ce_re + p * ROW, st + (2 + p) * ROW, 14 * 1200 * 4);
-        memcpy(h_ce_im + p * ROW, st + (2 + N_ant + p) * ROW, 14 * 1200 * 4);
+        unpack_rows(h_ce_re + p * ROW, st, 2 + p, 14, n_sc);
+        unpack_rows(h_ce_im + p * ROW, st, 2 + N_ant + p, 14, n_sc);
     }
-    // the device copy stays: the decoders the caller runs next on this struct read it (bind_subframe)
     hc->sub_host = h_symb_re; hc->sub_n_ant = N_ant; hc->sub_ul = false;
-    hc->sub_fp = subframe_fp(h_symb_re, h_symb_im, h_ce_re, h_ce_im, N_ant, 12 * N_rb_dl, 14);
+    hc->sub_fp = subframe_fp(h_symb_re, h_symb_im, h_ce_re, h_ce_im, N_ant, n_sc, 14);
     return 0;
 }
 
@@ -361,15 +407,13 @@ int mi_lte_pdsch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const fl
     if (rc != MI_LTE_OK) return rc;
     rc = mi_lte_pdsch_decode_run(ctx, plan, hc->d_sub, hc->d_par + 4, hc->d_par + 5, hc->d_out, hc->d_st);
     if (rc != MI_LTE_OK) return rc;
-    rc = need_pin(ctx, hc, 8192);
-    if (rc != MI_LTE_OK) return rc;
-    // verdict and bits in one copy (the bits are only handed over when the CRC matched, like the reference, :12861-12869)
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->h_pin, hc->d_res, 64 + (size_t)a.tbs, hipMemcpyDeviceToHost, ctx->stream));
+    // verdict and bits were written straight into pinned host memory (the bits are only handed over when the CRC matched, like the
+    // reference, :12861-12869)
     MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
     int32_t st;
-    memcpy(&st, hc->h_pin, 4);
+    memcpy(&st, hc->h_res, 4);
     if (st == 0) {
-        memcpy(h_out_bits, hc->h_pin + 64, a.tbs);
+        memcpy(h_out_bits, hc->h_res + 64, a.tbs);
         *N_out_bits = a.tbs;
     }
     return (int)st;
@@ -418,7 +462,7 @@ int mi_lte_bch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const floa
     mi_lte_dl_cfg cfg = {fft_of(N_rb_dl), N_rb_dl, 4, MI_LTE_IQ_F32_PLANAR};
     rc = bind_subframe(ctx, hc, h_symb_re, h_symb_im, h_ce_re, h_ce_im, 4, 12 * N_rb_dl, false); // all four ports' estimates are tried
     if (rc != MI_LTE_OK) return rc;
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->d_par + 6, &N_id_cell, 4, hipMemcpyHostToDevice, ctx->stream));
+    hc->h_par[6] = N_id_cell;
     uint32_t n_ant = 0, off = 0, mib = 0;
     rc = mi_lte_pbch_decode_run(ctx, &cfg, hc->d_sub, hc->d_par + 6, 1, &n_ant, &off, &mib);
     if (rc != MI_LTE_OK) return rc;
@@ -465,7 +509,7 @@ int mi_lte_dl_find_coarse_timing_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32
     if (rc != MI_LTE_OK) return rc;
     mi_lte_dl_cfg cfg = {fft_size, N_rb_dl, 1, MI_LTE_IQ_F32_PLANAR};
     float *d_i, *d_q;
-    rc = stage_pair(ctx, hc, h_i, h_q, mi_lte_coarse_timing_samples(fft_size, N_slots), &d_i, &d_q);
+    rc = stage_pair(ctx, hc, h_i, h_q, mi_lte_coarse_timing_samples(fft_size, N_slots), false, &d_i, &d_q);
     if (rc != MI_LTE_OK) return rc;
     return mi_lte_coarse_timing_run(ctx, &cfg, d_i, d_q, 0, N_slots, out);
 }
@@ -485,7 +529,7 @@ int mi_lte_find_pss_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_dl, c
     for (int j = 0; j < 7; j++) last = symb_starts[j] > last ? symb_starts[j] : last;
     const size_t n = (size_t)last + 11 * (15360 / sc) + 160 / sc + fft_size + 38; // last window of the 84, or of the +39 fine-timing trial
     float *d_i, *d_q;
-    rc = stage_pair(ctx, hc, h_i, h_q, n, &d_i, &d_q);
+    rc = stage_pair(ctx, hc, h_i, h_q, n, false, &d_i, &d_q);
     if (rc != MI_LTE_OK) return rc;
     return mi_lte_find_pss_run(ctx, &cfg, d_i, d_q, 0, symb_starts, N_id_2, pss_symb, pss_thresh, freq_offset);
 }
@@ -502,7 +546,7 @@ int mi_lte_find_sss_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_dl, c
     mi_lte_dl_cfg  cfg = {fft_size, N_rb_dl, 1, MI_LTE_IQ_F32_PLANAR};
     const uint32_t sc = 2048 / fft_size;
     float *d_i, *d_q;
-    rc = stage_pair(ctx, hc, h_i, h_q, (size_t)symb_starts[5] + 160 / sc - 1 + fft_size, &d_i, &d_q);
+    rc = stage_pair(ctx, hc, h_i, h_q, (size_t)symb_starts[5] + 160 / sc - 1 + fft_size, false, &d_i, &d_q);
     if (rc != MI_LTE_OK) return rc;
     uint32_t found = 0;
     rc = mi_lte_find_sss_run(ctx, &cfg, d_i, d_q, 0, N_id_2, symb_starts, pss_thresh, N_id_1, frame_start_idx, &found);
@@ -522,20 +566,19 @@ int mi_lte_get_ul_subframe_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_r
     const uint32_t sc = 2048 / fft_size;
     const size_t   need = 30720 / sc; // the last symbol's window ends one sample before the subframe does
     float *d_i, *d_q;
-    rc = stage_pair(ctx, hc, h_i, h_q, need, &d_i, &d_q);
+    rc = stage_pair(ctx, hc, h_i, h_q, need, true, &d_i, &d_q);
     if (rc != MI_LTE_OK) return rc;
-    MI_HIP_CHECK(ctx, hipMemsetAsync(hc->d_par, 0, 8, ctx->stream));
+    // (the sample offset of the one unit is words 0..1 of the parameter block: zero since it was allocated)
     hc->sub_host = nullptr;
     mi_lte_dl_cfg cfg = {fft_size, N_rb_ul, 1, MI_LTE_IQ_F32_PLANAR};
     rc = mi_lte_ul_frontend_batch(ctx, &cfg, d_i, d_q, (const uint64_t *)hc->d_par, 1, hc->d_sub);
     if (rc != MI_LTE_OK) return rc;
-    rc = need_pin(ctx, hc, 2 * ROW * 4);
+    const float *st;
+    rc = fetch_packed_rows(ctx, hc, 2, 12 * N_rb_ul, &st);
     if (rc != MI_LTE_OK) return rc;
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->h_pin, hc->d_sub, 2 * ROW * 4, hipMemcpyDeviceToHost, ctx->stream));
-    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
-    const size_t row = 14 * 1200 * sizeof(float); // rows 14, 15 of the caller's struct are left alone, as the reference leaves them
-    memcpy(h_symb_re, hc->h_pin, row);
-    memcpy(h_symb_im, hc->h_pin + ROW * 4, row);
+    // rows 14, 15 of the caller's struct and the columns past 12*N_rb_ul are left alone, as the reference leaves them (samples_to_symbols_ul, :8686-8691)
+    unpack_rows(h_symb_re, st, 0, 14, 12 * N_rb_ul);
+    unpack_rows(h_symb_im, st, 1, 14, 12 * N_rb_ul);
     hc->sub_host = h_symb_re; hc->sub_n_ant = 1; hc->sub_ul = true;
     hc->sub_fp = subframe_fp(h_symb_re, h_symb_im, nullptr, nullptr, 0, 12 * N_rb_ul, 14);
     return 0;
@@ -580,14 +623,11 @@ int mi_lte_pusch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_ul, const fl
     if (rc != MI_LTE_OK) return rc;
     rc = mi_lte_pusch_decode_run(ctx, plan, hc->d_sub, hc->d_out, hc->d_st);
     if (rc != MI_LTE_OK) return rc;
-    rc = need_pin(ctx, hc, 8192);
-    if (rc != MI_LTE_OK) return rc;
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->h_pin, hc->d_res, 64 + (size_t)a.tbs, hipMemcpyDeviceToHost, ctx->stream));
     MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
     int32_t st;
-    memcpy(&st, hc->h_pin, 4);
+    memcpy(&st, hc->h_res, 4);
     if (st == 0) {
-        memcpy(h_out_bits, hc->h_pin + 64, a.tbs);
+        memcpy(h_out_bits, hc->h_res + 64, a.tbs);
         *N_out_bits = a.tbs;
     }
     return st == 0 ? 0 : 1;
@@ -618,9 +658,9 @@ int mi_lte_detect_prach_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_u
     }
     const size_t need = mi_lte_prach_occasion_samples(plan);
     float *d_i, *d_q;
-    rc = stage_pair(ctx, hc, h_re, h_im, need, &d_i, &d_q);
+    rc = stage_pair(ctx, hc, h_re, h_im, need, false, &d_i, &d_q);
     if (rc != MI_LTE_OK) return rc;
-    MI_HIP_CHECK(ctx, hipMemsetAsync(hc->d_par, 0, 8, ctx->stream));
+    // (the sample offset of the one unit is words 0..1 of the parameter block: zero since it was allocated)
     uint32_t n = 0, p = 0, ta = 0;
     rc = mi_lte_prach_detect_run(ctx, plan, d_i, d_q, (const uint64_t *)hc->d_par, 1, &n, &p, &ta);
     if (rc != MI_LTE_OK) return rc;

@@ -649,16 +649,26 @@ int mi_lte_pdcch_decode_run(mi_lte_ctx *ctx, mi_lte_pdcch_plan *pl, const float 
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     int rc = mi_ctx_gold_tables(ctx);
     if (rc != MI_LTE_OK) return rc;
-    rc = mi_ctx_reserve_scratch(ctx, sizeof(PdcchResult) * (size_t)n_units);
-    if (rc != MI_LTE_OK) return rc;
-    PdcchResult *d_res = (PdcchResult *)ctx->scratch;
+    // a few units' results go straight into pinned host memory; a batch's through scratch and one copy
+    const size_t res_bytes = sizeof(PdcchResult) * (size_t)n_units;
+    PdcchResult *d_res, *h_res = nullptr;
+    if (mi_ctx_small_results(ctx, res_bytes, (void **)&h_res, (void **)&d_res) != MI_LTE_OK) {
+        h_res = nullptr;
+        rc = mi_ctx_reserve_scratch(ctx, res_bytes);
+        if (rc != MI_LTE_OK) return rc;
+        d_res = (PdcchResult *)ctx->scratch;
+    }
     GoldTables   gt{ctx->d_gold_x1, ctx->d_gold_x2b, ctx->gold_words};
     MI_LAUNCH(ctx, "k_pdcch_decode", k_pdcch_decode, dim3(n_units), dim3(384), 0, d_subframes, (uint32_t)mi_lte_subframe_floats(pl->cfg.N_ant),
               d_subfr_num, d_n_id_cell, pl->dev, gt, d_res);
     MI_HIP_CHECK(ctx, hipGetLastError());
-    std::vector<PdcchResult> res(n_units);
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(res.data(), d_res, sizeof(PdcchResult) * (size_t)n_units, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<PdcchResult> res_copy;
+    if (!h_res) {
+        res_copy.resize(n_units);
+        MI_HIP_CHECK(ctx, hipMemcpyAsync(res_copy.data(), d_res, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
     MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
+    const PdcchResult *res = h_res ? h_res : res_copy.data();
     for (uint32_t u = 0; u < n_units; u++) {
         h_cfi[u]     = res[u].cfi;
         h_n_symbs[u] = res[u].n_symbs;
@@ -701,20 +711,29 @@ int mi_lte_pbch_decode_run(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const floa
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     int rc = mi_ctx_gold_tables(ctx);
     if (rc != MI_LTE_OK) return rc;
-    rc = mi_ctx_reserve_scratch(ctx, sizeof(PbchResult) * (size_t)n_units);
-    if (rc != MI_LTE_OK) return rc;
+    const size_t res_bytes = sizeof(PbchResult) * (size_t)n_units;
+    PbchResult  *d_res, *h_res = nullptr;
+    if (mi_ctx_small_results(ctx, res_bytes, (void **)&h_res, (void **)&d_res) != MI_LTE_OK) {
+        h_res = nullptr;
+        rc = mi_ctx_reserve_scratch(ctx, res_bytes);
+        if (rc != MI_LTE_OK) return rc;
+        d_res = (PbchResult *)ctx->scratch;
+    }
     PbchLap  lap;
     uint16_t map[120];
     conv_rm_map(40, 120, map);
     for (uint32_t k = 0; k < 120; k++) lap.pos[k] = (uint8_t)map[k];
-    PbchResult *d_res = (PbchResult *)ctx->scratch;
     GoldTables  gt{ctx->d_gold_x1, ctx->d_gold_x2b, ctx->gold_words};
     MI_LAUNCH(ctx, "k_pbch_decode", k_pbch_decode, dim3(n_units), dim3(768), 0, d_subframes, (uint32_t)mi_lte_subframe_floats(4), cfg->N_rb_dl, d_n_id_cell,
               lap, gt, d_res);
     MI_HIP_CHECK(ctx, hipGetLastError());
-    std::vector<PbchResult> res(n_units);
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(res.data(), d_res, sizeof(PbchResult) * (size_t)n_units, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<PbchResult> res_copy;
+    if (!h_res) {
+        res_copy.resize(n_units);
+        MI_HIP_CHECK(ctx, hipMemcpyAsync(res_copy.data(), d_res, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
     MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
+    const PbchResult *res = h_res ? h_res : res_copy.data();
     for (uint32_t u = 0; u < n_units; u++) { h_N_ant[u] = res[u].N_ant; h_offset[u] = res[u].offset; h_mib[u] = res[u].mib; }
     ctx->last_kernels = "k_pbch_decode:1";
     return MI_LTE_OK;

@@ -25,6 +25,8 @@
 // LIBLTE_PHY_STRUCT stays byte-identical (callers read its fields directly); the GPU
 // context lives in a side table keyed by the struct pointer.
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 
@@ -88,7 +90,17 @@ LIBLTE_ERROR_ENUM liblte_phy_cleanup(LIBLTE_PHY_STRUCT *phy_struct)
         if (it != g_ctx.end()) { e = it->second; g_ctx.erase(it); }
     }
     if (e) {
-        { std::lock_guard<std::mutex> call(e->mu); if (e->ctx) mi_lte_ctx_destroy(e->ctx); } // waits for a call that is still running on it
+        {
+            std::lock_guard<std::mutex> call(e->mu); // waits for a call that is still running on it
+            if (e->ctx && getenv("MI_LTE_SHIM_STATS")) { // how often a decode call found the struct it was handed already on the device
+                uint64_t reuse = 0, upload = 0;
+                uint32_t plans = 0;
+                mi_lte_host_cache_stats(e->ctx, &reuse, &upload, &plans);
+                fprintf(stderr, "mi_lte shim: device subframe reused %llu times, uploaded %llu times; %u cached plans\n", (unsigned long long)reuse,
+                        (unsigned long long)upload, plans);
+            }
+            if (e->ctx) mi_lte_ctx_destroy(e->ctx);
+        }
         delete e;
     }
     return liblte_phy_cleanup_cpu(phy_struct);

@@ -140,6 +140,68 @@ def test_host_forms_keep_the_subframe_on_the_device(port):
     ctx.close()
 
 
+def test_host_forms_on_a_narrow_carrier_touch_only_its_columns(port):
+    """5 MHz (25 RB, 300 sub-carriers of the struct's 1200-wide rows): get_dl_subframe_and_ce writes columns 0..299 of each row and
+    nothing else, as the reference does (samples_to_symbols_dl, liblte_phy.cc:8628-8632) -- the subframe comes back as packed columns
+    written by the device into pinned host memory -- and the fingerprint that decides whether a decode call must upload the struct covers
+    the same columns: an edit outside them is not a change, an edit inside them is found without being announced."""
+    import ctypes as C
+    import openlte_amd as m
+    from openlte_amd import synth
+    ctx = m.Context(0)
+    L = ctx.L
+    f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+    u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+    L.mi_lte_get_dl_subframe_and_ce_host.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, f32p, f32p] + [C.c_uint32] * 4 + [f32p] * 4
+    L.mi_lte_pdsch_channel_decode_host.argtypes = [C.c_void_p, C.c_uint32, f32p, f32p, f32p, f32p, C.c_uint32, C.c_void_p,
+                                                   C.c_uint32, C.c_uint32, C.c_uint32, u8p, C.POINTER(C.c_uint32)]
+    L.mi_lte_host_cache_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+
+    def uploads():
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        assert L.mi_lte_host_cache_stats(ctx.h, C.byref(a), C.byref(b), C.byref(c)) == 0
+        return b.value
+
+    fft, nrb, sf, cell = 512, 25, 3, 77
+    cfg = m.DlCfg(fft, nrb, 1, 0)
+    allocs = [m.make_alloc(0, 1, 224, list(range(0, 6)), 0x500), m.make_alloc(0, 3, 776, list(range(19, 25)), 0x501)]
+    iq, tx = synth.dl_units(cfg, [sf], [cell], allocs, 2, snr_db=25.0, seed=5)
+    per_sf = 30720 // (2048 // fft)
+    i_s = np.concatenate([np.zeros(sf * per_sf, np.float32), iq[0, :, 0].astype(np.float32)])
+    q_s = np.concatenate([np.zeros(sf * per_sf, np.float32), iq[0, :, 1].astype(np.float32)])
+    sr, si = np.full((16, 1200), 7.0, np.float32), np.full((16, 1200), 7.0, np.float32)
+    cr, ci = np.full((4, 16, 1200), 7.0, np.float32), np.full((4, 16, 1200), 7.0, np.float32)
+    assert 0 == L.mi_lte_get_dl_subframe_and_ce_host(ctx.h, fft, nrb, i_s, q_s, 0, sf, cell, 1, sr, si, cr, ci)
+    n_sc = 12 * nrb
+    for arr in (sr, si):
+        assert (arr[:, n_sc:] == 7.0).all() and (arr[:, :n_sc] != 7.0).all()
+    assert (cr[0, :14, n_sc:] == 7.0).all() and (cr[0, 14:] == 7.0).all() and (cr[1:] == 7.0).all() and (ci[0, :14, n_sc:] == 7.0).all()
+    _, s = td.oracle_frontend(port, fft, nrb, 1, iq[0], sf, cell)
+    ref_re, ref_ce = s.arr("rx_symb_re")[:, :n_sc], s.arr("rx_ce_re")[0, :14, :n_sc]
+    assert np.linalg.norm(sr[:, :n_sc] - ref_re) / np.linalg.norm(ref_re) < 1e-5
+    assert np.linalg.norm(cr[0, :14, :n_sc] - ref_ce) / np.linalg.norm(ref_ce) < 1e-4
+
+    def decode(a):
+        out, n = np.zeros(6200, np.uint8), C.c_uint32()
+        rc = L.mi_lte_pdsch_channel_decode_host(ctx.h, nrb, sr, si, cr, ci, sf, C.addressof(allocs[a]), 2, cell, 1, out, C.byref(n))
+        return rc, out[:n.value].copy()
+
+    for a in range(2):
+        rc, out = decode(a)
+        assert rc == 0 and (out == tx[0, a, :allocs[a].tbs]).all(), a
+    assert uploads() == 0
+    sr[5, n_sc + 10] = -3.0  # outside the carrier: nobody reads it, so it is not a change
+    assert decode(0)[0] == 0 and uploads() == 0
+    keep = sr[5, 20:40].copy()
+    sr[5, 20:40] = 0.0  # inside: the next call sees it (one upload) and decodes what the arrays now hold
+    rc, out = decode(0)
+    assert uploads() == 1
+    sr[5, 20:40] = keep
+    rc, out = decode(0)
+    assert uploads() == 2 and rc == 0 and (out == tx[0, 0, :allocs[0].tbs]).all()
+    ctx.close()
+
+
 def _ul_demo_args(tmp_path):
     """One 20 MHz uplink subframe with three UEs, written as an int8 capture + the demo's command line."""
     case = td.ul_case("20MHz_3ue")

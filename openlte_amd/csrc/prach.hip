@@ -328,7 +328,12 @@ int mi_lte_prach_detect_run(mi_lte_ctx *ctx, mi_lte_prach_plan *pl, const void *
     int rc = mi_ctx_reserve_scratch(ctx, f_off + f_bytes);
     if (rc != MI_LTE_OK) return rc;
     float2  *d_xh = (float2 *)ctx->scratch;
-    CorrOut *d_co = (CorrOut *)((char *)ctx->scratch + ((xh_bytes + 63) & ~(size_t)63));
+    // the per-root maxima of a few occasions go straight into pinned host memory (no copy command for a per-call caller); a batch's through scratch
+    CorrOut *d_co = (CorrOut *)((char *)ctx->scratch + ((xh_bytes + 63) & ~(size_t)63)), *h_co = nullptr;
+    if (mi_ctx_small_results(ctx, co_bytes, (void **)&h_co, (void **)&d_co) != MI_LTE_OK) {
+        h_co = nullptr;
+        d_co = (CorrOut *)((char *)ctx->scratch + ((xh_bytes + 63) & ~(size_t)63));
+    }
     const uint32_t N2 = pl->T_fft / 24;
     if (pl->T_fft != 24 * N2 || (N2 & (N2 - 1)) || N2 < 2 || N2 > 1024) { ctx->err = "PRACH: T_fft must be 24 x a power of two"; return MI_LTE_ERR_UNSUPPORTED; }
     float2 *d_F = (float2 *)((char *)ctx->scratch + f_off);
@@ -344,9 +349,13 @@ int mi_lte_prach_detect_run(mi_lte_ctx *ctx, mi_lte_prach_plan *pl, const void *
     MI_LAUNCH(ctx, "k_prach_corr", k_prach_corr, dim3(pl->n_roots, n_occ), dim3(256), sizeof(float2) * (2 * BL + BL / 2), d_xh, pl->d_xu_fft, pl->n_roots,
               (const float2 *)pl->d_chirp, (const float2 *)pl->d_bspec, (const float2 *)pl->d_tw, d_co);
     MI_HIP_CHECK(ctx, hipGetLastError());
-    std::vector<CorrOut> co((size_t)n_occ * pl->n_roots);
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(co.data(), d_co, co_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<CorrOut> co_copy;
+    if (!h_co) {
+        co_copy.resize((size_t)n_occ * pl->n_roots);
+        MI_HIP_CHECK(ctx, hipMemcpyAsync(co_copy.data(), d_co, co_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
     MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
+    const CorrOut *co = h_co ? h_co : co_copy.data();
     for (uint32_t o = 0; o < n_occ; o++) { // the reference's scalar verdict (liblte_phy.cc:3436-3474)
         float    ave_val = 0, max_val = 0;
         uint32_t max_root = 0, max_offset = 0;

@@ -22,6 +22,7 @@
 
 #include <type_traits>
 
+#include <cstring>
 #include "ctx.hpp"
 #include "phy_dev.hpp"
 #include "lte_tables.h"
@@ -602,19 +603,36 @@ int mi_lte_pucch_decode_run(mi_lte_ctx *ctx, uint32_t N_rb_ul, uint32_t N_ant, c
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const size_t b_res = sizeof(PucchRes) * (size_t)n_res, b_tab = sizeof(float) * PUCCH_TAB_FLOATS * (size_t)n_res, b_out = 4 * (size_t)n_res;
     const size_t o_tab = (b_res + 255) & ~(size_t)255, o_out = (o_tab + b_tab + 255) & ~(size_t)255;
-    int rc = mi_ctx_reserve_scratch(ctx, o_out + b_out);
-    if (rc != MI_LTE_OK) return rc;
-    char *base = (char *)ctx->scratch;
+    // a few resources (a per-call caller has one): descriptors, reference tables and results live in pinned host memory that the kernel reads
+    // and writes itself -- three copy commands less; a batch goes through scratch
+    char *base, *h_base = nullptr;
+    int   rc = MI_LTE_OK;
+    if (mi_ctx_small_results(ctx, o_out + b_out, (void **)&h_base, (void **)&base) != MI_LTE_OK) {
+        h_base = nullptr;
+        rc = mi_ctx_reserve_scratch(ctx, o_out + b_out);
+        if (rc != MI_LTE_OK) return rc;
+        base = (char *)ctx->scratch;
+    }
     std::vector<PucchRes> res(n_res);
     for (uint32_t r = 0; r < n_res; r++) res[r] = PucchRes{h_res[r].unit, h_res[r].format, h_res[r].N_1_p_pucch};
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(base, res.data(), b_res, hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(base + o_tab, h_tables, b_tab, hipMemcpyHostToDevice, ctx->stream));
+    if (h_base) {
+        MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx)); // (a kernel of an earlier call may still be reading the block)
+        memcpy(h_base, res.data(), b_res);
+        memcpy(h_base + o_tab, h_tables, b_tab);
+    } else {
+        MI_HIP_CHECK(ctx, hipMemcpyAsync(base, res.data(), b_res, hipMemcpyHostToDevice, ctx->stream));
+        MI_HIP_CHECK(ctx, hipMemcpyAsync(base + o_tab, h_tables, b_tab, hipMemcpyHostToDevice, ctx->stream));
+    }
     MI_LAUNCH(ctx, "k_pucch_decode", k_pucch_decode, dim3(n_res), dim3(64), 0, d_subframes, (uint32_t)mi_lte_ul_subframe_floats(), N_rb_ul, N_ant,
               (const PucchRes *)base, (const float *)(base + o_tab), (uint8_t *)(base + o_out));
     MI_HIP_CHECK(ctx, hipGetLastError());
-    std::vector<uint8_t> o(b_out);
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(o.data(), base + o_out, b_out, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<uint8_t> o_copy;
+    if (!h_base) {
+        o_copy.resize(b_out);
+        MI_HIP_CHECK(ctx, hipMemcpyAsync(o_copy.data(), base + o_out, b_out, hipMemcpyDeviceToHost, ctx->stream));
+    }
     MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
+    const uint8_t *o = h_base ? (const uint8_t *)h_base + o_out : o_copy.data();
     for (uint32_t r = 0; r < n_res; r++) { h_bits[2 * r] = o[4 * r]; h_bits[2 * r + 1] = o[4 * r + 1]; h_n_bits[r] = o[4 * r + 2]; h_rc[r] = o[4 * r + 3]; }
     ctx->last_kernels = "k_pucch_decode:1";
     return MI_LTE_OK;

@@ -973,6 +973,150 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SISO_WPE, 8
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// siso for a handful of code blocks (the per-call forms: one transport block per call).  k_turbo_siso puts code blocks on lanes, so one
+// block is one lane issuing ~70 instructions per trellis step with the other 63 idle: 112 us per launch at K = 928, which is all of a
+// per-call PUSCH decode's time.  Here the lanes are the STATES: four lanes per trellis, lane j holding the metrics of states j and j + 4
+// (X, Y).  Lane j computes the new states j and j + 4 -- both come from the pair (PM[2j], PM[2j+1]), with opposite branch signs -- and
+// fetches that pair with two quad_perm DPP moves per operand (no LDS, no permute): ~16 instructions per step instead of 70.  The branch
+// terms of a step depend on the inputs only, so a pre-pass with the lanes as 64 STEPS computes them for a chunk at a time into LDS.
+// The traceback is not walked at all: one step of it is a map of the 8 states onto themselves that depends on that step's four compare
+// bits only (state s came from 2(s&3) + bit[s&3]); maps compose associatively, so a suffix scan over the 64 steps of a chunk (lanes as
+// steps again, a map = 8 x 3 bits in a register) gives every step's state at once, and with it the sign of every output.
+// Same arithmetic as k_turbo_siso (32-bit metrics instead of 16-bit halves: the differences are exact either way), same arrays in and out.
+constexpr uint32_t SMALL_G = 8; // trellises per wavefront (4 lanes each)
+struct SmallPar { int c, u; };  // sel(n - c, b + u, a - u) for the lane's lower state; the upper state takes (-c, -u)
+
+// a map of the 8 states onto themselves as 8 bytes (x: states 0-3, y: states 4-7); (F o G)[s] = F[G[s]] is two byte permutes
+__device__ __forceinline__ uint2 map_compose(uint2 F, uint2 G)
+{
+    return make_uint2(__builtin_amdgcn_perm(F.y, F.x, G.x), __builtin_amdgcn_perm(F.y, F.x, G.y));
+}
+__device__ __forceinline__ uint32_t map_at(uint2 F, uint32_t s) { return ((s & 4u ? F.y : F.x) >> (8 * (s & 3u))) & 7u; }
+// lane i <- lane i + N of its row of 16; lanes whose source is past the row end keep `keep`
+template <int N> __device__ __forceinline__ uint2 map_row_shl(uint2 v, uint2 keep)
+{
+    return make_uint2((uint32_t)__builtin_amdgcn_update_dpp((int)keep.x, (int)v.x, 0x100 + N, 0xF, 0xF, false),
+                      (uint32_t)__builtin_amdgcn_update_dpp((int)keep.y, (int)v.y, 0x100 + N, 0xF, 0xF, false));
+}
+
+__global__ __launch_bounds__(64) void k_turbo_siso_small(SisoArgs args, uint32_t K, uint32_t n_cb, uint32_t mode)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t sm_small[];
+    SmallPar (*par)[64][4] = reinterpret_cast<SmallPar(*)[64][4]>(sm_small);                    // [SMALL_G][64 steps][4 lanes]
+    const uint32_t Kp = kpad64(K), n_w32 = Kp >> 5;
+    uint32_t      *decw = sm_small + SMALL_G * 64 * 4 * 2;                                       // [SMALL_G][n_w32][4]: lane j's compare bits, 32 steps per word, first step in bit 31
+    const uint32_t lane = threadIdx.x, gi = lane >> 2, j = lane & 3u;
+    // mode 0: trellis g of the wavefront is code block 8 b + g, pass p[0]; mode 1: code block 4 b + g / 2, pass p[g & 1]
+    const uint32_t per_wave = mode ? SMALL_G / 2 : SMALL_G, cb0 = blockIdx.x * per_wave;
+    const uint32_t n_g = min(SMALL_G, (n_cb - cb0) * (mode ? 2u : 1u)); // trellises of this wavefront (uniform)
+    auto pass_of = [&](uint32_t g) -> const SisoPass & { return args.p[mode ? g & 1u : 0u]; };
+    auto off_of  = [&](uint32_t g) -> size_t { // the code block's lane of its tile: element t at (t / 64) * 4096 + t % 64 from here
+        const uint32_t cb = cb0 + (mode ? g >> 1 : g);
+        return (size_t)(cb >> 6) * Kp * 64 + (cb & 63u) * 64;
+    };
+    const uint32_t n_chunk = (K + 63) >> 6;
+
+    // ---- forward add-compare-select
+    int      X = 0, Y = 0; // all path metrics start at 0 (liblte_phy.cc:10411-10418)
+    uint32_t accv = 0;
+    for (uint32_t ch = 0; ch < n_chunk; ch++) {
+        // branch terms of the chunk's 64 steps, one trellis after the other, lanes = steps (acs_step2's formulas)
+        for (uint32_t g = 0; g < n_g; g++) {
+            const size_t   e  = off_of(g) + (size_t)ch * 4096 + lane;
+            const int      x  = (int8_t)pass_of(g).in_a[e], y = (int8_t)pass_of(g).in_b[e];
+            const int      m0 = x >> 31, mx = m0 ^ (y >> 31), nmx = ~mx; // mx = -1 iff the signs differ
+            const int      uP = ((x + y) << 1) & nmx, uQ = ((x - y) << 1) & mx;
+            const int      c4 = (m0 & 8) - 4, P2 = c4 & nmx, Q2 = c4 & mx;
+            uint4 *dst = reinterpret_cast<uint4 *>(&par[g][lane][0]);
+            dst[0] = make_uint4((uint32_t)P2, (uint32_t)uP, (uint32_t)Q2, (uint32_t)uQ);       // states 0 (4): (P2, uP); 1 (5): (Q2, uQ)
+            dst[1] = make_uint4((uint32_t)-Q2, (uint32_t)-uQ, (uint32_t)-P2, (uint32_t)-uP);   // states 2 (6): (-Q2, -uQ); 3 (7): (-P2, -uP)
+        }
+        __syncthreads(); // (one wavefront: orders the LDS accesses for the compiler)
+        const uint32_t n_t = min(64u, K - ch * 64);
+        if (gi < n_g) {
+            for (uint32_t t8 = 0; t8 < n_t; t8 += 8) { // K is a multiple of 8; the eight steps' terms are requested together
+                SmallPar pr[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) pr[k] = par[gi][t8 + k][j];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    // (a, b) = (PM[2j], PM[2j+1]): states 0..3 are the quad's X, states 4..7 its Y
+                    const int xa = __builtin_amdgcn_mov_dpp(X, 0x88, 0xF, 0xF, false), ya = __builtin_amdgcn_mov_dpp(Y, 0x88, 0xF, 0xF, false); // quad_perm [0,2,0,2]
+                    const int xb = __builtin_amdgcn_mov_dpp(X, 0xDD, 0xF, 0xF, false), yb = __builtin_amdgcn_mov_dpp(Y, 0xDD, 0xF, 0xF, false); // quad_perm [1,3,1,3]
+                    const int a = j < 2 ? xa : ya, b = j < 2 ? xb : yb;
+                    const int n = b - a;
+                    accv = (accv << 1) | ((uint32_t)n >> 31); // PM[2j] > PM[2j+1]
+                    X = (n - pr[k].c < 0) ? b + pr[k].u : a - pr[k].u;
+                    Y = (n + pr[k].c < 0) ? b - pr[k].u : a + pr[k].u;
+                }
+                const uint32_t t = t8 + 7;
+                if ((t & 31u) == 31u || t + 1 == n_t) {
+                    const uint32_t w = (ch * 64 + t) >> 5, fill = 31u - (t & 31u); // a last word that is not full: its first step still in bit 31
+                    decw[(gi * n_w32 + w) * 4 + j] = accv << fill;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- end state: first strict minimum (liblte_phy.cc:10467-10481), on the metrics relative to state 0
+    uint32_t cur = 0;
+    {
+        int pm[8];
+        // quad_perm [k,k,k,k]: every lane of the quad sees all eight metrics
+        pm[0] = __builtin_amdgcn_mov_dpp(X, 0x00, 0xF, 0xF, false); pm[4] = __builtin_amdgcn_mov_dpp(Y, 0x00, 0xF, 0xF, false);
+        pm[1] = __builtin_amdgcn_mov_dpp(X, 0x55, 0xF, 0xF, false); pm[5] = __builtin_amdgcn_mov_dpp(Y, 0x55, 0xF, 0xF, false);
+        pm[2] = __builtin_amdgcn_mov_dpp(X, 0xAA, 0xF, 0xF, false); pm[6] = __builtin_amdgcn_mov_dpp(Y, 0xAA, 0xF, 0xF, false);
+        pm[3] = __builtin_amdgcn_mov_dpp(X, 0xFF, 0xF, 0xF, false); pm[7] = __builtin_amdgcn_mov_dpp(Y, 0xFF, 0xF, 0xF, false);
+        int best = 0;
+#pragma unroll
+        for (int st = 1; st < 8; st++) {
+            const int d = pm[st] - pm[0];
+            if (d < best) { best = d; cur = st; }
+        }
+    }
+
+    // ---- traceback + signed soft output (liblte_phy.cc:10483-10527) by function composition, one trellis after the other, lanes = steps
+    const uint2 MAP_ID = make_uint2(0x03020100u, 0x07060504u);
+    for (uint32_t g = 0; g < n_g; g++) {
+        uint32_t       end = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(g * 4)); // state after the last step
+        const uint8_t *mag = pass_of(g).mag + off_of(g);
+        uint8_t       *out = pass_of(g).out + off_of(g);
+        for (int ch = (int)n_chunk - 1; ch >= 0; ch--) {
+            const uint32_t t = (uint32_t)ch * 64 + lane;
+            const uint4    w = *reinterpret_cast<const uint4 *>(&decw[(g * n_w32 + (t >> 5)) * 4]);
+            const uint32_t sh = 31u - (t & 31u);
+            uint2          G = MAP_ID; // a step past the block end changes nothing
+            if (t < K) {               // state s came from 2 (s & 3) + (compare bit of pair s & 3)
+                const uint32_t f = 0x06040200u + (((w.x >> sh) & 1u) | ((w.y >> sh) & 1u) << 8 | ((w.z >> sh) & 1u) << 16 | ((w.w >> sh) & 1u) << 24);
+                G = make_uint2(f, f);
+            }
+            // suffix composition G_t = f_t o f_{t+1} o ... o f_63 (the later steps are applied first): inside each row of 16 lanes by four
+            // DPP shifts, then the rows behind are applied whole (their first lane holds their composition)
+            G = map_compose(G, map_row_shl<1>(G, MAP_ID));
+            G = map_compose(G, map_row_shl<2>(G, MAP_ID));
+            G = map_compose(G, map_row_shl<4>(G, MAP_ID));
+            G = map_compose(G, map_row_shl<8>(G, MAP_ID));
+            const uint32_t row = lane >> 4;
+#pragma unroll
+            for (int r = 1; r < 4; r++) {
+                const uint2 R = make_uint2((uint32_t)__builtin_amdgcn_readlane((int)G.x, 16 * r), (uint32_t)__builtin_amdgcn_readlane((int)G.y, 16 * r));
+                if (row < (uint32_t)r) G = map_compose(G, R); // rows r = row + 1 .. 3 in this order: nearest first
+            }
+            const uint2    Gn  = make_uint2((uint32_t)__shfl_down((int)G.x, 1u), (uint32_t)__shfl_down((int)G.y, 1u));
+            const uint32_t nxt = lane == 63 ? end : map_at(Gn, end); // state at t + 1
+            const uint32_t st  = map_at(G, end);                      // state at t
+            if (t < K) {
+                const bool    pos = (nxt < st) || (nxt == st && nxt == 0); // "+" when the step moved to a lower state, or stayed in state 0
+                const uint8_t m   = mag[(size_t)ch * 4096 + lane];
+                out[(size_t)ch * 4096 + lane] = pos ? m : (uint8_t)(0u - m);
+            }
+            end = (uint32_t)__builtin_amdgcn_readlane((int)st, 0);
+        }
+    }
+}
+
 // A unit of 16 values x[0..15] plus its three-value halo x[-3..-1], as pairs: E[j] = (x[4j-4], x[4j-2]), O[j] = (x[4j-3], x[4j-1]),
 // j = 0 (halo word) .. 4, each pair split into magnitudes and sign masks (0 / 0xFFFF): soft_xor of two such values is
 // ((m_a + m_b) >> 1, s_a ^ s_b), three instructions per pair.  The delayed sequences the soft re-encoder needs are
@@ -1562,7 +1706,8 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
     for (int a = 0; a < N_BYTE_ARRAYS; a++) arr[a] = base + a * arr_bytes;
     uint32_t *dec[3];
     for (int p = 0; p < 3; p++) dec[p] = (uint32_t *)(base + N_BYTE_ARRAYS * arr_bytes + p * dec_bytes);
-    if (n_cb % 64) // lanes past the batch end walk whatever the scratch holds; keep it defined
+    const bool small = n_cb <= ctx->siso_small_max; // a handful of code blocks (a per-call caller's transport block): k_turbo_siso_small
+    if (n_cb % 64 && !small) // lanes past the batch end walk whatever the scratch holds; keep it defined (the state-parallel kernel has no such lanes)
         MI_HIP_CHECK(ctx, hipMemsetAsync(base, 0, N_BYTE_ARRAYS * arr_bytes, ctx->stream));
 
     if constexpr (GROUP) { // the per-block descriptors behind the tile arrays and the traceback words
@@ -1579,7 +1724,12 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
     SisoArgs s1;
     s1.p[0] = {arr[AX1], arr[AX0], arr[AM1], arr[AA1], dec[0]};
     s1.p[1] = s1.p[0];
-    MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso, dim3(((n_tiles + 1) / 2 + 3) / 4), dim3(256), 0, s1, K, (uint32_t)n_tiles, 0u); // two tiles per lane
+    // a handful of code blocks: states on the lanes instead of code blocks
+    const size_t lds_small = sizeof(uint32_t) * (SMALL_G * 64 * 4 * 2 + SMALL_G * (Kp >> 5) * 4);
+    if (small)
+        MI_LAUNCH(ctx, "k_turbo_siso_small", k_turbo_siso_small, dim3((n_cb + SMALL_G - 1) / SMALL_G), dim3(64), lds_small, s1, K, n_cb, 0u);
+    else
+        MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso, dim3(((n_tiles + 1) / 2 + 3) / 4), dim3(256), 0, s1, K, (uint32_t)n_tiles, 0u); // two tiles per lane
 
     PermArgs pa;
     pa.A1 = arr[AA1]; pa.X2 = arr[AX2]; pa.out[0] = arr[AI1]; pa.out[1] = arr[AM3];
@@ -1589,7 +1739,10 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
     SisoArgs s23;
     s23.p[0] = {arr[AX2], arr[AI0], arr[AM2], arr[AB1], dec[1]};
     s23.p[1] = {arr[AX2], arr[AI1], arr[AM3], arr[AB2], dec[2]};
-    MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso, dim3((n_tiles + 3) / 4), dim3(256), 0, s23, K, (uint32_t)n_tiles, 1u); // passes 2 and 3 of a tile per lane
+    if (small)
+        MI_LAUNCH(ctx, "k_turbo_siso_small", k_turbo_siso_small, dim3((n_cb + SMALL_G / 2 - 1) / (SMALL_G / 2)), dim3(64), lds_small, s23, K, n_cb, 1u);
+    else
+        MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso, dim3((n_tiles + 3) / 4), dim3(256), 0, s23, K, (uint32_t)n_tiles, 1u); // passes 2 and 3 of a tile per lane
 
     VoteArgs va = {arr[AX0], arr[AA1], arr[AB1], arr[AB2]};
     MI_LAUNCH(ctx, "k_turbo_vote", (k_turbo_vote<GROUP, 1>), dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), 3 * Kp + 64, va, K, n_cb, tb.d_inv2, d_c_bits, gd);

@@ -170,6 +170,7 @@ def load_library():
     L.mi_lte_dci_1a_unpack.argtypes = [u32, u32, u32, u32, u32, C.POINTER(PdcchDci)]
     L.mi_lte_dci_1c_unpack.argtypes = [u32, u32, u32, u32, u32, C.POINTER(PdcchDci)]
     L.mi_lte_turbo_decode_batch.argtypes = [vp, vp, C.c_int, u32, u32, C.c_int, u32, C.c_int, vp]
+    L.mi_lte_set_turbo_small_batch.argtypes = [vp, u32]
     L.mi_lte_turbo_scratch_bytes.argtypes = [u32, u32]
     L.mi_lte_turbo_scratch_bytes.restype = sz
     _LIB = L
@@ -639,6 +640,10 @@ class Context:
         finally:
             d_in.free()
             d_out.free()
+
+    def set_turbo_small_batch(self, n_cb_max):
+        """Code blocks per decode up to which the REF decoder's state-parallel trellis kernel runs (0: always the lock-step one)."""
+        self._check(self.L.mi_lte_set_turbo_small_batch(self.h, int(n_cb_max)))
 
     def close(self):
         if getattr(self, "h", None):

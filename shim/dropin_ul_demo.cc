@@ -9,6 +9,7 @@
 //   with PRACH_CAPTURE=<file> PRACH_CFG="root,fmt,zczc,hs,freq_offset" in the environment it also runs liblte_phy_detect_prach
 //   over that capture (one occasion starting at the file's first sample); with PUCCH_DEMO=1 it also decodes four PUCCH format 1/1a/1b
 //   resources it builds itself from the sequences in the struct (liblte_phy_pucch_format_1_1a_1b_channel_decode)
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -58,6 +59,26 @@ int main(int argc, char **argv)
         uint32 h = 2166136261u; // FNV-1a over the decoded bits
         for (uint32 i = 0; i < nb; i++) h = (h ^ out[i]) * 16777619u;
         printf("rnti 0x%x: err=%d N_out_bits=%u hash=%08x\n", (unsigned)al->rnti, (int)e, nb, h);
+    }
+    if (getenv("UL_DEMO_REPEAT")) { // what the eNodeB's radio thread pays per subframe: get_ul_subframe + one pusch_channel_decode per UE (stderr)
+        const int reps = atoi(getenv("UL_DEMO_REPEAT"));
+        const auto t0 = std::chrono::steady_clock::now();
+        uint32 ok = 0;
+        for (int r = 0; r < reps; r++) {
+            liblte_phy_get_ul_subframe(phy, i_s, q_s, rx);
+            for (int a = 10; a < argc; a += 5) {
+                memset(al, 0, sizeof(*al));
+                al->mod_type  = (LIBLTE_PHY_MODULATION_TYPE_ENUM)atoi(argv[a]);
+                al->chan_type = LIBLTE_PHY_CHAN_TYPE_ULSCH;
+                al->tbs = atoi(argv[a + 1]); al->rnti = atoi(argv[a + 2]); al->N_prb = atoi(argv[a + 4]);
+                for (uint32 i = 0; i < al->N_prb; i++) al->prb[0][i] = al->prb[1][i] = atoi(argv[a + 3]) + i;
+                al->N_codewords = 1; al->N_layers = 1; al->tx_mode = 1; al->rv_idx = 0;
+                uint8 out[LIBLTE_MAX_MSG_SIZE]; uint32 nb = 0;
+                ok += LIBLTE_SUCCESS == liblte_phy_pusch_channel_decode(phy, rx, al, cell, 1, out, &nb);
+            }
+        }
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        fprintf(stderr, "timing: %d x (get_ul_subframe + %d pusch_channel_decode): %.1f us per subframe, %u decodes ok\n", reps, (argc - 10) / 5, us / reps, ok);
     }
     if (getenv("PRACH_CAPTURE")) {
         FILE *pf = fopen(getenv("PRACH_CAPTURE"), "rb");

@@ -10,9 +10,18 @@ pytestmark = pytest.mark.gpu
 KS = [40, 104, 512, 1088, 3264, 3584, 6016, 6144]
 
 
+@pytest.fixture(params=["lockstep", "state-parallel"])
+def siso(ctx, request):
+    """The REF decoder's two trellis kernels (include/mi_lte.h, mi_lte_set_turbo_small_batch): code blocks on the lanes for every batch
+    size, or states on the lanes for the batch sizes of these tests.  Identical results are the requirement."""
+    ctx.set_turbo_small_batch(0 if request.param == "lockstep" else 2048)
+    yield request.param
+    ctx.set_turbo_small_batch(2048)
+
+
 @pytest.mark.parametrize("K", KS)
 @pytest.mark.parametrize("kind", ["clean", "awgn0.5", "awgn0.8", "hard127", "int", "i16"])
-def test_turbo_ref_bit_exact(ctx, port, K, kind):
+def test_turbo_ref_bit_exact(ctx, port, siso, K, kind):
     n = 70 if K <= 1088 else 66  # more than one tile, last tile ragged
     tx, soft = td.turbo_blocks(port, K, n, kind, seed=1000 + K)
     want = td.oracle_turbo_ref(port, soft, K)
@@ -26,7 +35,7 @@ def test_turbo_ref_bit_exact(ctx, port, K, kind):
 
 @pytest.mark.parametrize("K", [40, 3264, 6144])
 @pytest.mark.parametrize("kind", ["rand127", "noise"])
-def test_turbo_ref_bit_exact_without_a_code_word(ctx, port, K, kind):
+def test_turbo_ref_bit_exact_without_a_code_word(ctx, port, siso, K, kind):
     """The SISO kernel keeps its path metrics modulo 2^16 (two trellises per lane); that is exact as long as the spread of the eight
     metrics stays below 2^15.  Inputs with no code word underneath drive the spread as far as it goes."""
     tx, soft = td.turbo_blocks(port, K, 130, kind, seed=77 + K)
@@ -36,7 +45,7 @@ def test_turbo_ref_bit_exact_without_a_code_word(ctx, port, K, kind):
     assert bad.size == 0, "blocks differing from the oracle: %s" % bad[:10]
 
 
-def test_turbo_ref_all_188_block_sizes(ctx, port):
+def test_turbo_ref_all_188_block_sizes(ctx, port, siso):
     """every LTE turbo block size through the HIP decoder against the oracle -- 66 blocks each (one full tile + a ragged
     one) x {noise-free, AWGN sigma 0.8, +-127 with 2 % flips}.  The kernels have K-dependent paths: 16 / 8 / 0 valid steps in a
     block's last 16-step unit (K % 16 == 8 for 29 sizes), 1 .. 96 sixty-four-step lines, odd and even tile-line counts, and the
@@ -60,8 +69,8 @@ def test_turbo_ref_all_188_block_sizes(ctx, port):
     assert not bad, "block sizes with code blocks differing from the oracle (K, input kind, blocks): %s" % bad[:20]
 
 
-def test_turbo_ref_single_block_and_exact_tile(ctx, port):
-    for n in (1, 64, 128):
+def test_turbo_ref_single_block_and_exact_tile(ctx, port, siso):
+    for n in (1, 3, 8, 9, 64, 128):  # (the state-parallel kernel takes 8 / 4 code blocks per wavefront)
         tx, soft = td.turbo_blocks(port, 256, n, "awgn0.5", seed=n)
         assert (ctx.turbo_decode(soft, 256) == td.oracle_turbo_ref(port, soft, 256)).all()
 

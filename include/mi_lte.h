@@ -203,7 +203,7 @@ int mi_lte_turbo_decode_batch(mi_lte_ctx *ctx, const void *d_soft, mi_lte_soft_t
 /* The reference-faithful decoder's trellis kernel comes in two shapes with identical results: code blocks on the lanes (lock-step tiles of
  * 64: the throughput shape, 64k blocks per launch) and, for a decode of at most n_cb_max code blocks, STATES on the lanes (four lanes per
  * trellis, the traceback as a parallel composition of state maps): a third of the latency when one transport block is all there is, which
- * is what a per-call caller (the shim) has.  Default 2048; 0 = always the lock-step kernel.  A tuning / test knob, not a semantic one. */
+ * is what a per-call caller (the shim) has.  Default 4096; 0 = always the lock-step kernel.  A tuning / test knob, not a semantic one. */
 int mi_lte_set_turbo_small_batch(mi_lte_ctx *ctx, uint32_t n_cb_max);
 
 /* ---------------------------------------------------------------- turbo rate un-matching

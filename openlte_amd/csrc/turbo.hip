@@ -984,7 +984,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SISO_WPE, 8
 // bits only (state s came from 2(s&3) + bit[s&3]); maps compose associatively, so a suffix scan over the 64 steps of a chunk (lanes as
 // steps again, a map = 8 x 3 bits in a register) gives every step's state at once, and with it the sign of every output.
 // Same arithmetic as k_turbo_siso (32-bit metrics instead of 16-bit halves: the differences are exact either way), same arrays in and out.
-constexpr uint32_t SMALL_G = 8; // trellises per wavefront (4 lanes each)
+constexpr uint32_t SMALL_G = 8; // trellises per wavefront at most (4 lanes each)
 struct SmallPar { int c, u; };  // sel(n - c, b + u, a - u) for the lane's lower state; the upper state takes (-c, -u)
 
 // a map of the 8 states onto themselves as 8 bytes (x: states 0-3, y: states 4-7); (F o G)[s] = F[G[s]] is two byte permutes
@@ -1000,19 +1000,21 @@ template <int N> __device__ __forceinline__ uint2 map_row_shl(uint2 v, uint2 kee
                       (uint32_t)__builtin_amdgcn_update_dpp((int)keep.y, (int)v.y, 0x100 + N, 0xF, 0xF, false));
 }
 
-__global__ __launch_bounds__(64) void k_turbo_siso_small(SisoArgs args, uint32_t K, uint32_t n_cb, uint32_t mode)
+// gpw trellises per wavefront (1, 2, 4 or 8): the pre-pass and the traceback take the wavefront's trellises one after the other, so the
+// host asks for as few per wavefront as still leaves the device a wavefront or two per SIMD (siso_small_gpw)
+__global__ __launch_bounds__(64) void k_turbo_siso_small(SisoArgs args, uint32_t K, uint32_t n_cb, uint32_t mode, uint32_t gpw)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t sm_small[];
-    SmallPar (*par)[64][4] = reinterpret_cast<SmallPar(*)[64][4]>(sm_small);                    // [SMALL_G][64 steps][4 lanes]
+    SmallPar (*par)[64][4] = reinterpret_cast<SmallPar(*)[64][4]>(sm_small);                    // [gpw][64 steps][4 lanes]
     const uint32_t Kp = kpad64(K), n_w32 = Kp >> 5;
-    uint32_t      *decw = sm_small + SMALL_G * 64 * 4 * 2;                                       // [SMALL_G][n_w32][4]: lane j's compare bits, 32 steps per word, first step in bit 31
+    uint32_t      *decw = sm_small + gpw * 64 * 4 * 2;                                           // [gpw][n_w32][4]: lane j's compare bits, 32 steps per word, first step in bit 31
     const uint32_t lane = threadIdx.x, gi = lane >> 2, j = lane & 3u;
-    // mode 0: trellis g of the wavefront is code block 8 b + g, pass p[0]; mode 1: code block 4 b + g / 2, pass p[g & 1]
-    const uint32_t per_wave = mode ? SMALL_G / 2 : SMALL_G, cb0 = blockIdx.x * per_wave;
-    const uint32_t n_g = min(SMALL_G, (n_cb - cb0) * (mode ? 2u : 1u)); // trellises of this wavefront (uniform)
-    auto pass_of = [&](uint32_t g) -> const SisoPass & { return args.p[mode ? g & 1u : 0u]; };
+    // trellis T = gpw * b + g of the launch: mode 0: code block T, pass p[0]; mode 1: code block T / 2, pass p[T & 1]
+    const uint32_t T0 = blockIdx.x * gpw, n_tr = n_cb * (mode ? 2u : 1u);
+    const uint32_t n_g = min(gpw, n_tr - T0); // trellises of this wavefront (uniform)
+    auto pass_of = [&](uint32_t g) -> const SisoPass & { return args.p[mode ? (T0 + g) & 1u : 0u]; };
     auto off_of  = [&](uint32_t g) -> size_t { // the code block's lane of its tile: element t at (t / 64) * 4096 + t % 64 from here
-        const uint32_t cb = cb0 + (mode ? g >> 1 : g);
+        const uint32_t cb = mode ? (T0 + g) >> 1 : T0 + g;
         return (size_t)(cb >> 6) * Kp * 64 + (cb & 63u) * 64;
     };
     const uint32_t n_chunk = (K + 63) >> 6;
@@ -1725,9 +1727,11 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
     s1.p[0] = {arr[AX1], arr[AX0], arr[AM1], arr[AA1], dec[0]};
     s1.p[1] = s1.p[0];
     // a handful of code blocks: states on the lanes instead of code blocks
-    const size_t lds_small = sizeof(uint32_t) * (SMALL_G * 64 * 4 * 2 + SMALL_G * (Kp >> 5) * 4);
+    auto gpw_of = [](uint32_t n_tr) { return n_tr <= 2048 ? 1u : n_tr <= 4096 ? 2u : n_tr <= 8192 ? 4u : SMALL_G; }; // one or two wavefronts per SIMD
+    auto lds_of = [&](uint32_t gpw) { return sizeof(uint32_t) * gpw * (64 * 4 * 2 + (Kp >> 5) * 4); };
     if (small)
-        MI_LAUNCH(ctx, "k_turbo_siso_small", k_turbo_siso_small, dim3((n_cb + SMALL_G - 1) / SMALL_G), dim3(64), lds_small, s1, K, n_cb, 0u);
+        MI_LAUNCH(ctx, "k_turbo_siso_small", k_turbo_siso_small, dim3((n_cb + gpw_of(n_cb) - 1) / gpw_of(n_cb)), dim3(64), lds_of(gpw_of(n_cb)), s1, K, n_cb, 0u,
+                  gpw_of(n_cb));
     else
         MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso, dim3(((n_tiles + 1) / 2 + 3) / 4), dim3(256), 0, s1, K, (uint32_t)n_tiles, 0u); // two tiles per lane
 
@@ -1740,7 +1744,8 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
     s23.p[0] = {arr[AX2], arr[AI0], arr[AM2], arr[AB1], dec[1]};
     s23.p[1] = {arr[AX2], arr[AI1], arr[AM3], arr[AB2], dec[2]};
     if (small)
-        MI_LAUNCH(ctx, "k_turbo_siso_small", k_turbo_siso_small, dim3((n_cb + SMALL_G / 2 - 1) / (SMALL_G / 2)), dim3(64), lds_small, s23, K, n_cb, 1u);
+        MI_LAUNCH(ctx, "k_turbo_siso_small", k_turbo_siso_small, dim3((2 * n_cb + gpw_of(2 * n_cb) - 1) / gpw_of(2 * n_cb)), dim3(64), lds_of(gpw_of(2 * n_cb)), s23, K,
+                  n_cb, 1u, gpw_of(2 * n_cb));
     else
         MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso, dim3((n_tiles + 3) / 4), dim3(256), 0, s23, K, (uint32_t)n_tiles, 1u); // passes 2 and 3 of a tile per lane
 

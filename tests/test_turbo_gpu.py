@@ -14,9 +14,9 @@ KS = [40, 104, 512, 1088, 3264, 3584, 6016, 6144]
 def siso(ctx, request):
     """The REF decoder's two trellis kernels (include/mi_lte.h, mi_lte_set_turbo_small_batch): code blocks on the lanes for every batch
     size, or states on the lanes for the batch sizes of these tests.  Identical results are the requirement."""
-    ctx.set_turbo_small_batch(0 if request.param == "lockstep" else 2048)
+    ctx.set_turbo_small_batch(0 if request.param == "lockstep" else 4096)
     yield request.param
-    ctx.set_turbo_small_batch(2048)
+    ctx.set_turbo_small_batch(4096)
 
 
 @pytest.mark.parametrize("K", KS)
@@ -73,6 +73,26 @@ def test_turbo_ref_single_block_and_exact_tile(ctx, port, siso):
     for n in (1, 3, 8, 9, 64, 128):  # (the state-parallel kernel takes 8 / 4 code blocks per wavefront)
         tx, soft = td.turbo_blocks(port, 256, n, "awgn0.5", seed=n)
         assert (ctx.turbo_decode(soft, 256) == td.oracle_turbo_ref(port, soft, 256)).all()
+
+
+@pytest.mark.parametrize("n", [2100, 4500, 9000])
+def test_turbo_ref_state_parallel_kernel_with_several_trellises_per_wavefront(ctx, port, n):
+    """The state-parallel trellis kernel takes 1, 2, 4 or 8 trellises per wavefront depending on the size of the decode (turbo.hip,
+    gpw_of): 2100 / 4500 / 9000 code blocks reach the three larger settings in both of its launches.  Against the lock-step kernel on every
+    block and against the oracle on the unique ones."""
+    K, uniq = 104, 60
+    tx, soft = td.turbo_blocks(port, K, uniq, "awgn0.8", seed=n)
+    want = td.oracle_turbo_ref(port, soft, K)
+    idx = (np.arange(n) * 11 + np.arange(n) // 64) % uniq
+    big = np.ascontiguousarray(soft[idx])
+    try:
+        ctx.set_turbo_small_batch(0)
+        lock = ctx.turbo_decode(big, K)
+        ctx.set_turbo_small_batch(1 << 30)
+        par = ctx.turbo_decode(big, K)
+    finally:
+        ctx.set_turbo_small_batch(4096)
+    assert (lock == want[idx]).all() and (par == lock).all()
 
 
 def test_turbo_ref_full_batch_property(ctx, port):

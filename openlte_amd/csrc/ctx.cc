@@ -227,7 +227,7 @@ int mi_ctx_small_results(mi_lte_ctx *ctx, size_t bytes, void **h, void **d)
 {
     if (bytes > MI_SMALL_BYTES) return MI_LTE_ERR_INVALID_ARG;
     if (!ctx->h_small) {
-        MI_HIP_CHECK(ctx, hipHostMalloc(&ctx->h_small, MI_SMALL_BYTES, hipHostMallocMapped));
+        MI_HIP_CHECK(ctx, hipHostMalloc(&ctx->h_small, MI_SMALL_BYTES, hipHostMallocMapped | hipHostMallocCoherent));
         MI_HIP_CHECK(ctx, hipHostGetDevicePointer(&ctx->d_small, ctx->h_small, 0));
     }
     *h = ctx->h_small;

@@ -64,7 +64,9 @@ struct HostCache {
     float    *d_sub = nullptr;                        // the device subframe: (2 + 2*4) planes of 16 x 1200 floats
     // Parameters and results of a call live in PINNED HOST memory that the kernels read and write directly (h_* = the host's pointer, d_* = the
     // device's for the same bytes): a dozen bytes of parameters and a few hundred of results per call are not worth a copy command each --
-    // hipMemcpyAsync costs ~20 us of API time per call on this platform, five of them per subframe were most of the 1.4 MHz scan's loop
+    // hipMemcpyAsync costs ~20 us of API time per call on this platform, five of them per subframe were most of the 1.4 MHz scan's loop.
+    // All of these blocks (and the staging buffer) are asked for as COHERENT host memory explicitly: what a kernel wrote must be there
+    // when the stream reports it done, whatever HIP_HOST_COHERENT says about the default
     uint32_t *h_par = nullptr, *d_par = nullptr;      // 16 words of per-call parameters
     uint8_t  *h_res = nullptr, *d_res = nullptr;      // one decode's results: verdict at byte 0, decoded bits from byte 64
     uint8_t  *d_out = nullptr;                        // = d_res + 64
@@ -105,8 +107,8 @@ int host_cache(mi_lte_ctx *ctx, HostCache **out)
         auto guard = on_fail([&] { host_cache_free(ctx); }); // a half-built cache is not left behind: the next call starts over
         MI_HIP_CHECK(ctx, hipMalloc((void **)&hc->d_sub, 10 * ROW * sizeof(float)));
         MI_HIP_CHECK(ctx, hipMemsetAsync(hc->d_sub, 0, 10 * ROW * sizeof(float), ctx->stream));
-        MI_HIP_CHECK(ctx, hipHostMalloc((void **)&hc->h_par, 64, hipHostMallocMapped));
-        MI_HIP_CHECK(ctx, hipHostMalloc((void **)&hc->h_res, 64 + 6144 + 64, hipHostMallocMapped));
+        MI_HIP_CHECK(ctx, hipHostMalloc((void **)&hc->h_par, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        MI_HIP_CHECK(ctx, hipHostMalloc((void **)&hc->h_res, 64 + 6144 + 64, hipHostMallocMapped | hipHostMallocCoherent));
         MI_HIP_CHECK(ctx, hipHostGetDevicePointer((void **)&hc->d_par, hc->h_par, 0));
         MI_HIP_CHECK(ctx, hipHostGetDevicePointer((void **)&hc->d_res, hc->h_res, 0));
         memset(hc->h_par, 0, 64);
@@ -124,7 +126,7 @@ int need_pin(mi_lte_ctx *ctx, HostCache *hc, size_t bytes)
     if (hc->h_pin) (void)hipHostFree(hc->h_pin);
     hc->h_pin = nullptr; hc->h_pin_bytes = 0;
     bytes = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
-    MI_HIP_CHECK(ctx, hipHostMalloc((void **)&hc->h_pin, bytes, hipHostMallocDefault));
+    MI_HIP_CHECK(ctx, hipHostMalloc((void **)&hc->h_pin, bytes, hipHostMallocMapped | hipHostMallocCoherent));
     hc->h_pin_bytes = bytes;
     return MI_LTE_OK;
 }

@@ -1022,11 +1022,24 @@ __global__ __launch_bounds__(64) void k_turbo_siso_small(SisoArgs args, uint32_t
     // ---- forward add-compare-select
     int      X = 0, Y = 0; // all path metrics start at 0 (liblte_phy.cc:10411-10418)
     uint32_t accv = 0;
+    // the inputs of a chunk are requested a chunk ahead (lanes = steps): a wavefront on its own has nothing else to hide that round trip behind
+    int xs[SMALL_G], ys[SMALL_G];
+    auto fetch = [&](uint32_t ch) {
+#pragma unroll
+        for (uint32_t g = 0; g < SMALL_G; g++)
+            if (g < n_g) {
+                const size_t e = off_of(g) + (size_t)ch * 4096 + lane;
+                xs[g] = (int8_t)pass_of(g).in_a[e];
+                ys[g] = (int8_t)pass_of(g).in_b[e];
+            }
+    };
+    fetch(0);
     for (uint32_t ch = 0; ch < n_chunk; ch++) {
         // branch terms of the chunk's 64 steps, one trellis after the other, lanes = steps (acs_step2's formulas)
-        for (uint32_t g = 0; g < n_g; g++) {
-            const size_t   e  = off_of(g) + (size_t)ch * 4096 + lane;
-            const int      x  = (int8_t)pass_of(g).in_a[e], y = (int8_t)pass_of(g).in_b[e];
+#pragma unroll
+        for (uint32_t g = 0; g < SMALL_G; g++) {
+            if (g >= n_g) break;
+            const int      x  = xs[g], y = ys[g];
             const int      m0 = x >> 31, mx = m0 ^ (y >> 31), nmx = ~mx; // mx = -1 iff the signs differ
             const int      uP = ((x + y) << 1) & nmx, uQ = ((x - y) << 1) & mx;
             const int      c4 = (m0 & 8) - 4, P2 = c4 & nmx, Q2 = c4 & mx;
@@ -1035,6 +1048,7 @@ __global__ __launch_bounds__(64) void k_turbo_siso_small(SisoArgs args, uint32_t
             dst[1] = make_uint4((uint32_t)-Q2, (uint32_t)-uQ, (uint32_t)-P2, (uint32_t)-uP);   // states 2 (6): (-Q2, -uQ); 3 (7): (-P2, -uP)
         }
         __syncthreads(); // (one wavefront: orders the LDS accesses for the compiler)
+        if (ch + 1 < n_chunk) fetch(ch + 1);
         const uint32_t n_t = min(64u, K - ch * 64);
         if (gi < n_g) {
             for (uint32_t t8 = 0; t8 < n_t; t8 += 8) { // K is a multiple of 8; the eight steps' terms are requested together
@@ -1085,8 +1099,11 @@ __global__ __launch_bounds__(64) void k_turbo_siso_small(SisoArgs args, uint32_t
         uint32_t       end = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(g * 4)); // state after the last step
         const uint8_t *mag = pass_of(g).mag + off_of(g);
         uint8_t       *out = pass_of(g).out + off_of(g);
+        uint8_t m_nxt = mag[(size_t)(n_chunk - 1) * 4096 + lane]; // the magnitudes too are requested a chunk ahead
         for (int ch = (int)n_chunk - 1; ch >= 0; ch--) {
             const uint32_t t = (uint32_t)ch * 64 + lane;
+            const uint8_t  m = m_nxt;
+            if (ch > 0) m_nxt = mag[(size_t)(ch - 1) * 4096 + lane];
             const uint4    w = *reinterpret_cast<const uint4 *>(&decw[(g * n_w32 + (t >> 5)) * 4]);
             const uint32_t sh = 31u - (t & 31u);
             uint2          G = MAP_ID; // a step past the block end changes nothing
@@ -1111,7 +1128,6 @@ __global__ __launch_bounds__(64) void k_turbo_siso_small(SisoArgs args, uint32_t
             const uint32_t st  = map_at(G, end);                      // state at t
             if (t < K) {
                 const bool    pos = (nxt < st) || (nxt == st && nxt == 0); // "+" when the step moved to a lower state, or stayed in state 0
-                const uint8_t m   = mag[(size_t)ch * 4096 + lane];
                 out[(size_t)ch * 4096 + lane] = pos ? m : (uint8_t)(0u - m);
             }
             end = (uint32_t)__builtin_amdgcn_readlane((int)st, 0);

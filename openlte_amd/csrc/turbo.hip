@@ -978,14 +978,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SISO_WPE, 8
 // block is one lane issuing ~70 instructions per trellis step with the other 63 idle: 112 us per launch at K = 928, which is all of a
 // per-call PUSCH decode's time.  Here the lanes are the STATES: four lanes per trellis, lane j holding the metrics of states j and j + 4
 // (X, Y).  Lane j computes the new states j and j + 4 -- both come from the pair (PM[2j], PM[2j+1]), with opposite branch signs -- and
-// fetches that pair with two quad_perm DPP moves per operand (no LDS, no permute): ~16 instructions per step instead of 70.  The branch
+// keeps the two as the halves of one register (metrics modulo 2^16 as in k_turbo_siso), so the pair arrives with one quad_perm DPP move and one
+// byte permute per operand (no LDS) and both new states are one packed compare-select: 11 instructions per step instead of 70.  The branch
 // terms of a step depend on the inputs only, so a pre-pass with the lanes as 64 STEPS computes them for a chunk at a time into LDS.
 // The traceback is not walked at all: one step of it is a map of the 8 states onto themselves that depends on that step's four compare
 // bits only (state s came from 2(s&3) + bit[s&3]); maps compose associatively, so a suffix scan over the 64 steps of a chunk (lanes as
 // steps again, a map = 8 x 3 bits in a register) gives every step's state at once, and with it the sign of every output.
-// Same arithmetic as k_turbo_siso (32-bit metrics instead of 16-bit halves: the differences are exact either way), same arrays in and out.
+// Same arithmetic as k_turbo_siso, same arrays in and out.
 constexpr uint32_t SMALL_G = 8; // trellises per wavefront at most (4 lanes each)
-struct SmallPar { int c, u; };  // sel(n - c, b + u, a - u) for the lane's lower state; the upper state takes (-c, -u)
+// sel(n - c, b + u, a - u) for the lane's lower state, the upper state takes (-c, -u): both at once on int16 pairs, cw = (c, -c), uw = (u, -u)
+struct SmallPar { uint32_t cw, uw; };
 
 // a map of the 8 states onto themselves as 8 bytes (x: states 0-3, y: states 4-7); (F o G)[s] = F[G[s]] is two byte permutes
 __device__ __forceinline__ uint2 map_compose(uint2 F, uint2 G)
@@ -1020,8 +1022,12 @@ __global__ __launch_bounds__(64) void k_turbo_siso_small(SisoArgs args, uint32_t
     const uint32_t n_chunk = (K + 63) >> 6;
 
     // ---- forward add-compare-select
-    int      X = 0, Y = 0; // all path metrics start at 0 (liblte_phy.cc:10411-10418)
+    uint32_t XY = 0;   // (PM[j], PM[j + 4]) as int16 halves; all path metrics start at 0 (liblte_phy.cc:10411-10418)
     uint32_t accv = 0;
+    const uint32_t half_sel = j < 2 ? 0x01000100u : 0x03020302u; // v_perm selector: this lane's pair comes from the quad's lower / upper halves
+#ifdef SMALL_PAD
+    uint32_t padv[4] = {lane, lane + 1, lane + 2, lane + 3}; // A/B builds: independent instructions in the step loop (is it issue or latency?)
+#endif
     // the inputs of a chunk are requested a chunk ahead (lanes = steps): a wavefront on its own has nothing else to hide that round trip behind
     int xs[SMALL_G], ys[SMALL_G];
     auto fetch = [&](uint32_t ch) {
@@ -1043,52 +1049,68 @@ __global__ __launch_bounds__(64) void k_turbo_siso_small(SisoArgs args, uint32_t
             const int      m0 = x >> 31, mx = m0 ^ (y >> 31), nmx = ~mx; // mx = -1 iff the signs differ
             const int      uP = ((x + y) << 1) & nmx, uQ = ((x - y) << 1) & mx;
             const int      c4 = (m0 & 8) - 4, P2 = c4 & nmx, Q2 = c4 & mx;
+            auto pm16 = [](int v) { return ((uint32_t)v & 0xFFFFu) | ((uint32_t)(-v) << 16); }; // (v, -v)
+            const uint32_t cP = pm16(P2), uPw = pm16(uP), cQ = pm16(Q2), uQw = pm16(uQ);
+            auto swp = [](uint32_t w) { return (w >> 16) | (w << 16); };                        // (-v, v)
             uint4 *dst = reinterpret_cast<uint4 *>(&par[g][lane][0]);
-            dst[0] = make_uint4((uint32_t)P2, (uint32_t)uP, (uint32_t)Q2, (uint32_t)uQ);       // states 0 (4): (P2, uP); 1 (5): (Q2, uQ)
-            dst[1] = make_uint4((uint32_t)-Q2, (uint32_t)-uQ, (uint32_t)-P2, (uint32_t)-uP);   // states 2 (6): (-Q2, -uQ); 3 (7): (-P2, -uP)
+            dst[0] = make_uint4(cP, uPw, cQ, uQw);                       // states 0 (4): (P2, uP); 1 (5): (Q2, uQ)
+            dst[1] = make_uint4(swp(cQ), swp(uQw), swp(cP), swp(uPw));   // states 2 (6): (-Q2, -uQ); 3 (7): (-P2, -uP)
         }
         __syncthreads(); // (one wavefront: orders the LDS accesses for the compiler)
         if (ch + 1 < n_chunk) fetch(ch + 1);
         const uint32_t n_t = min(64u, K - ch * 64);
         if (gi < n_g) {
-            for (uint32_t t8 = 0; t8 < n_t; t8 += 8) { // K is a multiple of 8; the eight steps' terms are requested together
+            // eight steps with their terms requested together (K is a multiple of 8)
+            auto steps8 = [&](uint32_t t8) {
                 SmallPar pr[8];
 #pragma unroll
                 for (int k = 0; k < 8; k++) pr[k] = par[gi][t8 + k][j];
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
-                    // (a, b) = (PM[2j], PM[2j+1]): states 0..3 are the quad's X, states 4..7 its Y
-                    const int xa = __builtin_amdgcn_mov_dpp(X, 0x88, 0xF, 0xF, false), ya = __builtin_amdgcn_mov_dpp(Y, 0x88, 0xF, 0xF, false); // quad_perm [0,2,0,2]
-                    const int xb = __builtin_amdgcn_mov_dpp(X, 0xDD, 0xF, 0xF, false), yb = __builtin_amdgcn_mov_dpp(Y, 0xDD, 0xF, 0xF, false); // quad_perm [1,3,1,3]
-                    const int a = j < 2 ? xa : ya, b = j < 2 ? xb : yb;
-                    const int n = b - a;
-                    accv = (accv << 1) | ((uint32_t)n >> 31); // PM[2j] > PM[2j+1]
-                    X = (n - pr[k].c < 0) ? b + pr[k].u : a - pr[k].u;
-                    Y = (n + pr[k].c < 0) ? b - pr[k].u : a + pr[k].u;
+                    // (a, b) = (PM[2j], PM[2j+1]), each in both halves: states 0..3 are the quad's lower halves, states 4..7 its upper halves
+                    const uint32_t t0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)XY, 0x88, 0xF, 0xF, false); // quad_perm [0,2,0,2]
+                    const uint32_t t1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)XY, 0xDD, 0xF, 0xF, false); // quad_perm [1,3,1,3]
+                    const v2s a = as_v2s(__builtin_amdgcn_perm(t0, t0, half_sel)), b = as_v2s(__builtin_amdgcn_perm(t1, t1, half_sel));
+                    const v2s n = b - a;
+                    accv = __builtin_amdgcn_alignbit(accv, as_u32(n), 31); // (accv << 1) | (PM[2j] > PM[2j+1])
+                    const v2s uw = as_v2s(pr[k].uw);
+                    XY = as_u32(bit_select(neg_mask(n - as_v2s(pr[k].cw)), b + uw, a - uw)); // lower state: n - c < 0 ? b + u : a - u; upper: (-c, -u)
+#ifdef SMALL_PAD
+#pragma unroll
+                    for (int z = 0; z < SMALL_PAD; z++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(padv[z & 3]) : "v"(lane));
+#endif
                 }
-                const uint32_t t = t8 + 7;
-                if ((t & 31u) == 31u || t + 1 == n_t) {
-                    const uint32_t w = (ch * 64 + t) >> 5, fill = 31u - (t & 31u); // a last word that is not full: its first step still in bit 31
-                    decw[(gi * n_w32 + w) * 4 + j] = accv << fill;
-                }
+            };
+            // the step loop is bound by instruction issue (a wavefront on its own issues one instruction per ~4.9 cycles: 8 more per step cost
+            // 16 ns, tools/ab/small_pad.sh), so whole 32-step words run without a test in between
+            uint32_t t = 0;
+            for (; t + 32 <= n_t; t += 32) {
+                steps8(t); steps8(t + 8); steps8(t + 16); steps8(t + 24);
+                decw[(gi * n_w32 + ((ch * 64 + t) >> 5)) * 4 + j] = accv;
+            }
+            if (t < n_t) { // the block's last word when it is not full: its first step still goes to bit 31
+                const uint32_t w = (ch * 64 + t) >> 5, left = n_t - t;
+                for (; t < n_t; t += 8) steps8(t);
+                decw[(gi * n_w32 + w) * 4 + j] = accv << (32u - left);
             }
         }
         __syncthreads();
     }
 
+#ifdef SMALL_PAD
+    if ((padv[0] ^ padv[1] ^ padv[2] ^ padv[3]) == 0x12345678u) decw[0] = 0; // (keeps the padding alive)
+#endif
     // ---- end state: first strict minimum (liblte_phy.cc:10467-10481), on the metrics relative to state 0
     uint32_t cur = 0;
     {
-        int pm[8];
-        // quad_perm [k,k,k,k]: every lane of the quad sees all eight metrics
-        pm[0] = __builtin_amdgcn_mov_dpp(X, 0x00, 0xF, 0xF, false); pm[4] = __builtin_amdgcn_mov_dpp(Y, 0x00, 0xF, 0xF, false);
-        pm[1] = __builtin_amdgcn_mov_dpp(X, 0x55, 0xF, 0xF, false); pm[5] = __builtin_amdgcn_mov_dpp(Y, 0x55, 0xF, 0xF, false);
-        pm[2] = __builtin_amdgcn_mov_dpp(X, 0xAA, 0xF, 0xF, false); pm[6] = __builtin_amdgcn_mov_dpp(Y, 0xAA, 0xF, 0xF, false);
-        pm[3] = __builtin_amdgcn_mov_dpp(X, 0xFF, 0xF, 0xF, false); pm[7] = __builtin_amdgcn_mov_dpp(Y, 0xFF, 0xF, 0xF, false);
+        // quad_perm [k,k,k,k]: every lane of the quad sees all eight metrics (differences on 16 bits, as they are kept)
+        const uint32_t q0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)XY, 0x00, 0xF, 0xF, false), q1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)XY, 0x55, 0xF, 0xF, false);
+        const uint32_t q2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)XY, 0xAA, 0xF, 0xF, false), q3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)XY, 0xFF, 0xF, 0xF, false);
+        const short pm[8] = {(short)q0, (short)q1, (short)q2, (short)q3, (short)(q0 >> 16), (short)(q1 >> 16), (short)(q2 >> 16), (short)(q3 >> 16)};
         int best = 0;
 #pragma unroll
         for (int st = 1; st < 8; st++) {
-            const int d = pm[st] - pm[0];
+            const int d = (short)(pm[st] - pm[0]);
             if (d < best) { best = d; cur = st; }
         }
     }

@@ -95,6 +95,18 @@ def test_turbo_ref_state_parallel_kernel_with_several_trellises_per_wavefront(ct
     assert (lock == want[idx]).all() and (par == lock).all()
 
 
+@pytest.mark.parametrize("n", [4096, 4097])
+def test_turbo_ref_at_the_kernel_switch(ctx, port, n):
+    """With the default setting a decode of 4096 code blocks takes the state-parallel trellis kernel and one of 4097 the lock-step one:
+    both sides of the switch against the oracle (unique blocks replicated over the batch)."""
+    K, uniq = 40, 50
+    tx, soft = td.turbo_blocks(port, K, uniq, "awgn0.8", seed=n)
+    want = td.oracle_turbo_ref(port, soft, K)
+    idx = (np.arange(n) * 13 + np.arange(n) // 64) % uniq
+    got = ctx.turbo_decode(np.ascontiguousarray(soft[idx]), K)
+    assert (got == want[idx]).all()
+
+
 def test_turbo_ref_full_batch_property(ctx, port):
     """BASELINE config 3 shape: K=6144, 65536 blocks.  Oracle-check 32 unique blocks, and require
     every replica (placed in a different tile lane) to decode to the same bits."""

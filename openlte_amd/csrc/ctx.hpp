@@ -104,6 +104,7 @@ int   mi_ctx_reserve_scratch(mi_lte_ctx *ctx, size_t bytes);
 // bytes; MI_LTE_ERR_INVALID_ARG when bytes > MI_SMALL_BYTES (the caller then takes its scratch + copy route).
 constexpr size_t MI_SMALL_BYTES = 64 * 1024;
 int   mi_ctx_small_results(mi_lte_ctx *ctx, size_t bytes, void **h, void **d);
+hipError_t mi_stream_wait(mi_lte_ctx *ctx, size_t n_units); // polls for a call on a handful of units, sleeps on the interrupt for a batch
 hipError_t mi_stream_wait_polling(mi_lte_ctx *ctx); // the per-call forms' wait: polls the stream instead of sleeping on an interrupt (ctx.cc)
 int   mi_ctx_gold_tables(mi_lte_ctx *ctx);
 int   mi_ctx_crc_table(mi_lte_ctx *ctx);

@@ -2,6 +2,7 @@
 #include <cmath>
 
 #include <chrono>
+#include <cstdlib>
 
 #include "ctx.hpp"
 
@@ -210,6 +211,8 @@ hipError_t mi_stream_wait(mi_lte_ctx *ctx, size_t n_units) { return n_units <= 8
 #endif
 hipError_t mi_stream_wait_polling(mi_lte_ctx *ctx)
 {
+    static const bool never_poll = getenv("MI_LTE_BLOCKING_WAIT") != nullptr; // a deployment that would rather have the core than the ~35 us per wait
+    if (never_poll) return hipStreamSynchronize(ctx->stream);
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned n = 1;; n++) {
         const hipError_t e = hipStreamQuery(ctx->stream);

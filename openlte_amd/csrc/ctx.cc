@@ -62,6 +62,7 @@ void mi_lte_ctx_destroy(mi_lte_ctx *ctx)
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->h_small) (void)hipHostFree(ctx->h_small);
+    if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -197,27 +198,39 @@ void mi_prof_end(mi_lte_ctx *ctx)
 
 // The wait of the per-call host forms (hostapi.cc).  Their caller is blocked on a result that is tens of microseconds of GPU work away, three
 // times per subframe; hipStreamSynchronize sleeps on the completion interrupt, and the wake-up alone costs ~35 us per wait on the MI355X box
-// (the scanner's per-subframe loop: 255 us with it, 134 us polling; HSA_ENABLE_INTERRUPT=0 shows the same from outside).  So: poll the
-// stream, and give the core back to the blocking wait only when the work turns out to be long (a first call that builds tables, a big batch).
-// The spin is kept short (MI_POLL_US): every hipStreamQuery costs the runtime a round through its queue, and a batch call that was polled
-// for 2 ms ran 15 % slower (uplink workload: 7.05 against 6.1 ms per step).
-// The batch entry points wait with this: a call on a handful of units is a per-call caller's (poll), anything larger sleeps on the
-// interrupt -- a stream that has been queried while a batch ran finishes the batch later (uplink workload: 6.9 against 6.15 ms per step
-// with as few as 32 queries at the start of the wait; bisected to the commit that introduced the polling wait).
+// (the scanner's per-subframe loop: 255 us with it, 134 us without; HSA_ENABLE_INTERRUPT=0 shows the same from outside).  So the host
+// spins (mi_stream_wait_polling below), and gives the core back to the blocking wait only when the work turns out to be long (MI_POLL_US: a
+// first call that builds tables, a big batch).
+// The batch entry points wait with this: a call on a handful of units is a per-call caller's (spin), anything larger sleeps on the
+// interrupt (when the spin was on hipStreamQuery, a batch that had been queried finished later: uplink workload 6.9 against 6.15 ms per
+// step with as few as 32 queries at the start of the wait -- bisected; a batch has nothing to gain from spinning anyway).
 hipError_t mi_stream_wait(mi_lte_ctx *ctx, size_t n_units) { return n_units <= 8 ? mi_stream_wait_polling(ctx) : hipStreamSynchronize(ctx->stream); }
 
 #ifndef MI_POLL_US
 #define MI_POLL_US 200 // the work of a per-call form is done within this; a batch call goes to the blocking wait
 #endif
+// The wait itself: a one-thread kernel behind the call's work stores a sequence number into a word of coherent host memory and the host
+// spins on that word -- no runtime call in the loop.  (Spinning on hipStreamQuery instead cost 6-10 % more per call: scan loop 58 -> 51 us
+// per subframe at 1.4 MHz, 103 -> 95 at 20 MHz, the uplink subframe 355 -> 325 us; tools/ab/flag_wait.sh.)  Everything a per-call form hands
+// back is in coherent host memory written by kernels that precede the flag kernel in the stream, so when the word has changed the results
+// are there; anything the runtime itself must know to be complete (frees, re-allocations) still goes through its own synchronisation.
+__global__ void k_done_flag(volatile uint32_t *flag, uint32_t seq) { *flag = seq; }
+
 hipError_t mi_stream_wait_polling(mi_lte_ctx *ctx)
 {
     static const bool never_poll = getenv("MI_LTE_BLOCKING_WAIT") != nullptr; // a deployment that would rather have the core than the ~35 us per wait
     if (never_poll) return hipStreamSynchronize(ctx->stream);
+    if (!ctx->h_flag) {
+        if (hipHostMalloc((void **)&ctx->h_flag, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return hipStreamSynchronize(ctx->stream);
+        (void)hipHostGetDevicePointer((void **)&ctx->d_flag, ctx->h_flag, 0);
+        *ctx->h_flag = 0;
+    }
+    const uint32_t want = ++ctx->flag_seq;
+    k_done_flag<<<1, 1, 0, ctx->stream>>>(ctx->d_flag, want);
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned n = 1;; n++) {
-        const hipError_t e = hipStreamQuery(ctx->stream);
-        if (e != hipErrorNotReady) return e;
-        if ((n & 31u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(MI_POLL_US)) return hipStreamSynchronize(ctx->stream);
+        if (*(volatile uint32_t *)ctx->h_flag == want) return hipSuccess;
+        if ((n & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(MI_POLL_US)) return hipStreamSynchronize(ctx->stream);
 #if defined(__x86_64__)
         __builtin_ia32_pause();
 #endif

@@ -42,6 +42,8 @@ struct mi_lte_ctx {
     std::string        last_kernels;
     void              *scratch       = nullptr;
     size_t             scratch_bytes = 0;
+    uint32_t          *h_flag = nullptr, *d_flag = nullptr; // the completion word of the per-call waits (mi_stream_wait_polling) and its sequence number
+    uint32_t           flag_seq = 0;
     uint32_t           siso_small_max = 4096; // code blocks per decode up to which k_turbo_siso_small runs (mi_lte_set_turbo_small_batch)
     void              *h_small = nullptr, *d_small = nullptr; // MI_SMALL_BYTES of pinned host memory the kernels can write (mi_ctx_small_results)
     std::map<uint64_t, TurboTables> turbo_tables; // key = K | (spec << 32)

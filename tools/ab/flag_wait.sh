@@ -1,5 +1,6 @@
 #!/bin/bash
-# per-call forms: polling the stream (hipStreamQuery) against spinning on a word that a one-thread kernel behind the call's work stores
+# per-call forms: spinning on hipStreamQuery (BASE at the time) against spinning on a word that a one-thread kernel behind the call's work stores
+# (FLAG: ctx.cc built with -DMI_FLAG_WAIT from commit 2f0f.. of round 2; the variant has since become the library's wait, mi_stream_wait_polling)
 cd /root/repo
 cp openlte_amd/libmi_lte.so _ko/lib_BASE.so
 for v in BASE FLAG BASE FLAG; do

@@ -306,3 +306,26 @@ def test_closed_forms_of_the_two_float_sites_the_kernels_shortcut():
     assert ((f(127.0) * (w.astype(f) / f(254.0))).astype(np.int32) == (w >> 1)).all()
     w = np.arange(0, 128)
     assert ((f(127.0) * (w.astype(f) / f(127.0))).astype(np.int32) == w).all()
+
+def test_traceback_by_composition_of_state_maps_equals_the_serial_walk():
+    """k_turbo_siso_small does not walk the reference's traceback (liblte_phy.cc:10483-10527): one step of it sends state s at time t+1 to
+    2*(s & 3) + (compare bit of pair s & 3 at time t), a map of the 8 states onto themselves that depends on that step's four bits only,
+    and maps compose associatively -- so a suffix scan over the steps gives every state at once.  The rule itself, in numpy: the serial
+    walk against the suffix composition (doubling, as the kernel's scan does), on random compare bits and every end state."""
+    rng = np.random.default_rng(5)
+    for K in (8, 40, 64, 100, 528):
+        bits = rng.integers(0, 2, (K, 4))
+        maps = np.array([[2 * (s & 3) + bits[t, s & 3] for s in range(8)] for t in range(K)])  # f_t[s]
+        # suffix composition G_t = f_t o f_{t+1} o ... o f_{K-1}, by doubling: G_t <- G_t o G_{t+d}
+        G = maps.copy()
+        d = 1
+        while d < K:
+            nxt = np.vstack([G[d:], np.tile(np.arange(8), (d, 1))])  # the identity past the end
+            G = np.take_along_axis(G, nxt, axis=1)                  # (G_t o G_{t+d})[s] = G_t[G_{t+d}[s]]
+            d *= 2
+        for end in range(8):
+            cur, serial = end, []
+            for t in range(K - 1, -1, -1):
+                cur = 2 * (cur & 3) + bits[t, cur & 3]
+                serial.append(cur)
+            assert (G[:, end] == np.array(serial[::-1])).all(), (K, end)

@@ -667,7 +667,7 @@ int mi_lte_pdcch_decode_run(mi_lte_ctx *ctx, mi_lte_pdcch_plan *pl, const float 
         res_copy.resize(n_units);
         MI_HIP_CHECK(ctx, hipMemcpyAsync(res_copy.data(), d_res, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
     }
-    MI_HIP_CHECK(ctx, mi_stream_wait(ctx, n_units));
+    MI_HIP_CHECK(ctx, h_res ? mi_stream_wait(ctx, n_units) : hipStreamSynchronize(ctx->stream)); // (a copy into pageable memory is done when the runtime says so)
     const PdcchResult *res = h_res ? h_res : res_copy.data();
     for (uint32_t u = 0; u < n_units; u++) {
         h_cfi[u]     = res[u].cfi;
@@ -732,7 +732,7 @@ int mi_lte_pbch_decode_run(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const floa
         res_copy.resize(n_units);
         MI_HIP_CHECK(ctx, hipMemcpyAsync(res_copy.data(), d_res, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
     }
-    MI_HIP_CHECK(ctx, mi_stream_wait(ctx, n_units));
+    MI_HIP_CHECK(ctx, h_res ? mi_stream_wait(ctx, n_units) : hipStreamSynchronize(ctx->stream));
     const PbchResult *res = h_res ? h_res : res_copy.data();
     for (uint32_t u = 0; u < n_units; u++) { h_N_ant[u] = res[u].N_ant; h_offset[u] = res[u].offset; h_mib[u] = res[u].mib; }
     ctx->last_kernels = "k_pbch_decode:1";

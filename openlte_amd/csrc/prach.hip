@@ -354,7 +354,7 @@ int mi_lte_prach_detect_run(mi_lte_ctx *ctx, mi_lte_prach_plan *pl, const void *
         co_copy.resize((size_t)n_occ * pl->n_roots);
         MI_HIP_CHECK(ctx, hipMemcpyAsync(co_copy.data(), d_co, co_bytes, hipMemcpyDeviceToHost, ctx->stream));
     }
-    MI_HIP_CHECK(ctx, mi_stream_wait(ctx, n_occ));
+    MI_HIP_CHECK(ctx, h_co ? mi_stream_wait(ctx, n_occ) : hipStreamSynchronize(ctx->stream)); // (a copy into pageable memory is done when the runtime says so)
     const CorrOut *co = h_co ? h_co : co_copy.data();
     for (uint32_t o = 0; o < n_occ; o++) { // the reference's scalar verdict (liblte_phy.cc:3436-3474)
         float    ave_val = 0, max_val = 0;

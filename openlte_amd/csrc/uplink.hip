@@ -631,7 +631,7 @@ int mi_lte_pucch_decode_run(mi_lte_ctx *ctx, uint32_t N_rb_ul, uint32_t N_ant, c
         o_copy.resize(b_out);
         MI_HIP_CHECK(ctx, hipMemcpyAsync(o_copy.data(), base + o_out, b_out, hipMemcpyDeviceToHost, ctx->stream));
     }
-    MI_HIP_CHECK(ctx, mi_stream_wait(ctx, n_res));
+    MI_HIP_CHECK(ctx, h_base ? mi_stream_wait(ctx, n_res) : hipStreamSynchronize(ctx->stream)); // (a copy into pageable memory is done when the runtime says so)
     const uint8_t *o = h_base ? (const uint8_t *)h_base + o_out : o_copy.data();
     for (uint32_t r = 0; r < n_res; r++) { h_bits[2 * r] = o[4 * r]; h_bits[2 * r + 1] = o[4 * r + 1]; h_n_bits[r] = o[4 * r + 2]; h_rc[r] = o[4 * r + 3]; }
     ctx->last_kernels = "k_pucch_decode:1";

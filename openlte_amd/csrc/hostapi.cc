@@ -223,20 +223,57 @@ __attribute__((target("avx2"))) uint64_t hash_words_avx2(const void *p, size_t n
     return done < n_bytes ? hash_words((const char *)p + done, n_bytes - done, h) : h;
 }
 bool have_avx2() { static const bool v = __builtin_cpu_supports("avx2"); return v; }
+// the same construction on 64 lanes where the host has AVX-512 (the rotate is one instruction there): 256 bytes per round
+__attribute__((target("avx512f"))) uint64_t hash_words_avx512(const void *p, size_t n_bytes, uint64_t seed)
+{
+    const __m512i *w = (const __m512i *)p;
+    const size_t   n = n_bytes / 256; // four 64-byte vectors per round
+    const __m512i  c0 = _mm512_set1_epi32((int)0x9E3779B1u), c1 = _mm512_set1_epi32((int)0x85EBCA77u), c2 = _mm512_set1_epi32((int)0xC2B2AE3Du),
+                   c3 = _mm512_set1_epi32((int)0x27D4EB2Fu);
+    __m512i a = _mm512_set1_epi32((int)(uint32_t)seed), b = _mm512_set1_epi32((int)(uint32_t)(seed >> 32)), c = _mm512_set1_epi32(0x165667B1),
+            d = _mm512_set1_epi32((int)0xD6E8FEB8u);
+    for (size_t i = 0; i < n; i++) {
+        a = _mm512_rol_epi32(_mm512_mullo_epi32(_mm512_xor_si512(a, _mm512_loadu_si512(w + 4 * i)), c0), 13);
+        b = _mm512_rol_epi32(_mm512_mullo_epi32(_mm512_xor_si512(b, _mm512_loadu_si512(w + 4 * i + 1)), c1), 13);
+        c = _mm512_rol_epi32(_mm512_mullo_epi32(_mm512_xor_si512(c, _mm512_loadu_si512(w + 4 * i + 2)), c2), 13);
+        d = _mm512_rol_epi32(_mm512_mullo_epi32(_mm512_xor_si512(d, _mm512_loadu_si512(w + 4 * i + 3)), c3), 13);
+    }
+    uint32_t lanes[64];
+    _mm512_storeu_si512((void *)lanes, a); _mm512_storeu_si512((void *)(lanes + 16), b);
+    _mm512_storeu_si512((void *)(lanes + 32), c); _mm512_storeu_si512((void *)(lanes + 48), d);
+    uint64_t h = seed;
+    for (uint32_t k = 0; k < 64; k++) { // an injective mix of (lane index, lane state), summed
+        uint64_t x = ((uint64_t)(k + 1) << 32) | lanes[k];
+        x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull; x ^= x >> 33; x *= 0xC4CEB9FE1A85EC53ull; x ^= x >> 33;
+        h += x;
+    }
+    const size_t done = n * 256;
+    return done < n_bytes ? hash_words_avx2((const char *)p + done, n_bytes - done, h) : h;
+}
+bool have_avx512() { static const bool v = __builtin_cpu_supports("avx512f"); return v; }
 #else
 uint64_t hash_words_avx2(const void *p, size_t n, uint64_t s) { return hash_words(p, n, s); }
+uint64_t hash_words_avx512(const void *p, size_t n, uint64_t s) { return hash_words(p, n, s); }
 bool have_avx2() { return false; }
+bool have_avx512() { return false; }
 #endif
-uint64_t hash_plane(const void *p, size_t n_bytes, uint64_t seed) { return have_avx2() ? hash_words_avx2(p, n_bytes, seed) : hash_words(p, n_bytes, seed); }
+uint64_t hash_plane(const void *p, size_t n_bytes, uint64_t seed)
+{
+    if (have_avx512() && n_bytes >= 1024) return hash_words_avx512(p, n_bytes, seed);
+    return have_avx2() ? hash_words_avx2(p, n_bytes, seed) : hash_words(p, n_bytes, seed);
+}
 
 uint64_t subframe_fp(const float *re, const float *im, const float *ce_re, const float *ce_im, uint32_t n_ant, uint32_t n_sc, uint32_t rows)
 {
     uint64_t h = ((uint64_t)n_ant << 32) | n_sc;
     // the first n_sc columns of each row are all that the decoders (and the reference's) ever read: a narrow carrier's fingerprint is
     // over those alone, row by row (1.4 MHz: 4 KB a plane instead of 67 KB)
+    static thread_local std::vector<float> tmp; // a narrow carrier's rows side by side: one pass (and one fold of the lanes) per plane
     auto plane = [&](const float *p) {
         if (n_sc >= 1200) { h = hash_plane(p, (size_t)rows * 1200 * sizeof(float), h); return; } // rows are contiguous inside a plane
-        for (uint32_t r = 0; r < rows; r++) h = hash_plane(p + r * 1200, n_sc * sizeof(float), h);
+        tmp.resize((size_t)rows * n_sc);
+        for (uint32_t r = 0; r < rows; r++) memcpy(tmp.data() + (size_t)r * n_sc, p + r * 1200, n_sc * sizeof(float));
+        h = hash_plane(tmp.data(), (size_t)rows * n_sc * sizeof(float), h);
     };
     plane(re);
     plane(im);

@@ -329,3 +329,67 @@ def test_traceback_by_composition_of_state_maps_equals_the_serial_walk():
                 cur = 2 * (cur & 3) + bits[t, cur & 3]
                 serial.append(cur)
             assert (G[:, end] == np.array(serial[::-1])).all(), (K, end)
+
+def _siso_states_on_lanes_model(x, y):
+    """k_turbo_siso_small's arithmetic in numpy, for one trellis: four lanes, lane j holding the metrics of states j and j + 4 as int16
+    (modulo 2^16), the branch terms (c, u) of acs_step2 (turbo.hip) per lane class, the compare bits of the four state pairs per step, the
+    first strict minimum of the end metrics relative to state 0, and the traceback as a suffix composition of state maps.  Returns the sign
+    decisions (True = the reference's "+" branch) -- the magnitudes are not the trellis kernel's business (k_turbo_prep makes them)."""
+    K = len(x)
+    X = np.zeros(4, np.int16)  # states 0..3
+    Y = np.zeros(4, np.int16)  # states 4..7
+    bits = np.zeros((K, 4), np.int64)
+    with np.errstate(over="ignore"):
+        for t in range(K):
+            xi, yi = int(x[t]), int(y[t])
+            m0, my = (-1 if xi < 0 else 0), (-1 if yi < 0 else 0)
+            mx = m0 ^ my
+            nmx = ~mx
+            uP, uQ = ((xi + yi) << 1) & nmx, ((xi - yi) << 1) & mx
+            c4 = (m0 & 8) - 4
+            P2, Q2 = c4 & nmx, c4 & mx
+            c = np.array([P2, Q2, -Q2, -P2], np.int16)   # lanes 0..3: states 0 (4), 1 (5), 2 (6), 3 (7)
+            u = np.array([uP, uQ, -uQ, -uP], np.int16)
+            pm = np.concatenate([X, Y])                  # what the quad_perm moves + byte permutes fetch: (PM[2j], PM[2j+1])
+            a, b = pm[0::2].copy(), pm[1::2].copy()
+            n = (b - a).astype(np.int16)
+            bits[t] = n < 0
+            X = np.where((n - c).astype(np.int16) < 0, (b + u).astype(np.int16), (a - u).astype(np.int16))
+            Y = np.where((n + c).astype(np.int16) < 0, (b - u).astype(np.int16), (a + u).astype(np.int16))
+        pm = np.concatenate([X, Y])
+        best, end = 0, 0
+        for st in range(1, 8):
+            d = int(np.int16(pm[st] - pm[0]))
+            if d < best:
+                best, end = d, st
+    maps = np.array([[2 * (s & 3) + bits[t, s & 3] for s in range(8)] for t in range(K)])
+    G, d = maps.copy(), 1
+    while d < K:
+        nxt = np.vstack([G[d:], np.tile(np.arange(8), (d, 1))])
+        G = np.take_along_axis(G, nxt, axis=1)
+        d *= 2
+    st = G[:, end]                                  # state at t
+    nx = np.concatenate([st[1:], [end]])            # state at t + 1
+    return (nx < st) | ((nx == st) & (nx == 0))
+
+
+def test_states_on_lanes_siso_model_vs_the_restatement(port):
+    """The arithmetic k_turbo_siso_small is built on (int16 metrics modulo 2^16, two states per lane with opposite branch signs, the
+    composition traceback) against lo_viterbi_siso -- itself pinned to the reference above -- on inputs with a code word underneath, on
+    noise, and on +-127 without a code word (the widest metric spread)."""
+    rng = np.random.default_rng(21)
+    for K, kind in ((40, "noise"), (104, "pm127"), (528, "noise"), (528, "sparse"), (1024, "pm127")):
+        if kind == "noise":
+            v = rng.integers(-127, 128, 2 * K)
+        elif kind == "pm127":
+            v = 127 * (1 - 2 * rng.integers(0, 2, 2 * K))
+        else:
+            v = rng.integers(-127, 128, 2 * K) * (rng.random(2 * K) < 0.3)
+        v = v.astype(np.int8)
+        out = np.zeros(K + 16, np.int8)
+        port.lo_viterbi_siso(v, K, out)
+        pos = _siso_states_on_lanes_model(v[0::2], v[1::2])
+        w = np.abs(v[0::2].astype(np.int64)) + np.abs(v[1::2].astype(np.int64))
+        mag = (np.float32(127) * (w.astype(np.float32) / np.float32(w.max()))).astype(np.int8) if w.max() else np.zeros(K, np.int8)
+        want = np.where(pos, mag, -mag).astype(np.int8)
+        assert (want == out[:K]).all(), (K, kind, int((want != out[:K]).sum()))

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
     // before each pair.  Waves 1-3: the scrambling sequence words (c_init per :3831) for the upper bound of the bit count, which
     // does not wait for the scan.  One barrier for both.
     const uint32_t n_pairs = (14 - g.cfi) * N_prb;
-    const uint32_t c_init = (al.rnti << 14) | (0u << 13) | (sf << 9) | cell;
+    const uint32_t c_init = ((al.rnti << 14) | (0u << 13) | (sf << 9) | cell) & 0x7FFFFFFFu; // 31 bits: the Gold basis has 31 rows
     if (threadIdx.x < 64) {
         const uint32_t ln = threadIdx.x, per = (n_pairs + 63) / 64, q0 = ln * per, q1 = min(q0 + per, n_pairs);
         const uint32_t magic = 0xFFFFFFFFu / N_prb + 1u; // q / N_prb = mulhi(q, magic), exact for q < 2^32 / N_prb^2; a single PRB wraps it to 0 = "no division"
@@ -111,7 +111,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
     }
     __syncthreads();
     const uint32_t M_ap = offs[n_pairs];
-    // pre-decoder / layer de-mapper symbol counts (liblte_phy.cc:7683, 7693, 7720, 7497)
+    // pre-decoder / layer de-mapper symbol counts (liblte_phy.cc:7683, 7693, 7720, 7497).  M_ap is a multiple of N_ant for every
+    // allocation the extraction above can produce: each (slot, PRB) contributes 12, 8 or -- next to the PBCH / PSS / SSS window of the
+    // odd bandwidths -- 6 + 6, 4 + 4 + 6 + 6 resource elements (enumerated over every bandwidth, cell, subframe and control-region size
+    // in tests/test_fuzz_cpu.py), so the reference's `M_ap_symb % 4 != 0` branch (:7766-7795, with the mis-strided layer de-mapper
+    // it would feed, :7473-7514) is dead code on this path and the division is exact.
     const uint32_t n_grp = M_ap / N_ant, M_symb = n_grp * N_ant, N_bits = M_symb * Qm;
     if (threadIdx.x == 0) e_len[a_idx] = N_bits;
 
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
             x_im[0] = (h0r * y0i - h0i * y0r - h1r * y1i + h1i * y1r) / hn;
             x_re[1] = (-h1r * y0r - h1i * y0i + h0r * y1r + h0i * y1i) / hn;
             x_im[1] = (h1r * y0i - h1i * y0r + h0r * y1i - h0i * y1r) / hn;
-        } else { // N_ant == 4 (liblte_phy.cc:7721-7765); the M_ap % 4 != 0 tail is outside the envelope
+        } else { // N_ant == 4 (liblte_phy.cc:7721-7765); M_ap % 4 == 0 always, see the note at n_grp
             const uint32_t p0 = locate(4 * i), p1 = locate(4 * i + 1), p2 = locate(4 * i + 2), p3 = locate(4 * i + 3);
             const size_t   ps = 16 * N_SC_MAX;
             const float y0r = y_re_p[p0], y0i = y_im_p[p0], y1r = y_re_p[p1], y1i = y_im_p[p1];

@@ -99,6 +99,8 @@ int mi_lte_dl_pipeline_create(int device, const mi_lte_dl_cfg *cfg, uint32_t N_p
         MI_HIP_CHECK(l.ctx, hipMalloc((void **)&l.d_st, n_al * sizeof(int32_t)));
         MI_HIP_CHECK(l.ctx, hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
         MI_HIP_CHECK(l.ctx, hipMemcpy(l.d_start, starts.data(), sizeof(uint64_t) * chunk_units, hipMemcpyHostToDevice));
+        MI_HIP_CHECK(l.ctx, hipMemset(l.d_sf, 0, sizeof(uint32_t) * chunk_units));   // a ragged last chunk decodes the units past its end too
+        MI_HIP_CHECK(l.ctx, hipMemset(l.d_cell, 0, sizeof(uint32_t) * chunk_units)); // (results dropped): they must at least be valid numbers
         MI_HIP_CHECK(l.ctx, hipMemset(l.d_sub, 0, sizeof(float) * mi_lte_subframe_floats(cfg->N_ant) * chunk_units));
         MI_HIP_CHECK(l.ctx, hipMemset(l.d_iq, 0, (size_t)chunk_units * p->unit_samples * 2 + 64));
     }

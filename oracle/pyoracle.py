@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _PORT = None
 _REF = None
 _REF_TRIED = False
+_REF_BIG = False
 
 u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
 i8p = np.ctypeslib.ndpointer(np.int8, flags="C_CONTIGUOUS")
@@ -43,6 +44,27 @@ class LoSubframe(C.Structure):
     def arr(self, name):
         a = np.ctypeslib.as_array(getattr(self, name))
         return a.reshape((16, 1200)) if "symb" in name else a.reshape((4, 16, 1200))
+
+
+class RefDlCase(C.Structure):
+    """ref_dl_case (oracle/ref/ref_fuzz.cc)"""
+    _fields_ = [(n, u32) for n in ("fs_enum", "N_rb_dl", "N_ant", "N_id_cell", "subfr_num", "N_pdcch_symbs", "mod_type", "tbs", "rv_idx",
+                                   "tx_mode", "rnti", "N_prb")] + \
+               [("prb", (C.c_uint8 * 112) * 2), ("snr_db", C.c_float), ("peak", C.c_float), ("gain_re", C.c_float * 4),
+                ("gain_im", C.c_float * 4), ("delay", u32), ("seed", u32), ("rc_tx", C.c_int32), ("rc_fe", C.c_int32), ("rc", C.c_int32),
+                ("N_out", u32), ("N_soft", u32)]
+
+
+class RefUlAllocCase(C.Structure):
+    """ref_ul_alloc_case"""
+    _fields_ = [(n, u32) for n in ("unit", "mod_type", "tbs", "rnti", "N_prb")] + [("prb", C.c_uint8 * 112), ("rc", C.c_int32), ("N_out", u32),
+                                                                                     ("N_soft", u32)]
+
+
+class RefUlUnitCase(C.Structure):
+    """ref_ul_unit_case"""
+    _fields_ = [(n, u32) for n in ("fs_enum", "N_rb_ul", "N_id_cell", "subfr_num", "group_assignment_pusch", "group_hopping_enabled",
+                                   "sequence_hopping_enabled", "cyclic_shift", "cyclic_shift_dci")] + [("rc_fe", C.c_int32)]
 
 
 def make_alloc(mod_type, tbs, prbs, rnti, rv_idx=0, tx_mode=1, pre_coder_type=0, n_codewords=1):
@@ -110,6 +132,25 @@ def port():
     return L
 
 
+def ref_big():
+    """The reference compiled through the sed of oracle/ref/Makefile that only enlarges the PDSCH scratch literals (SURVEY 7.1
+    `oracle_big`): allocations of more than 10 000 soft bits.  None if it has not been built / shipped."""
+    global _REF_BIG
+    if _REF_BIG is not False:
+        return _REF_BIG
+    path = os.path.join(_HERE, "_ref", "libref_oracle_big.so")
+    if not os.path.exists(path):
+        try:
+            if not build_ref() or not os.path.exists(path):
+                _REF_BIG = None
+                return None
+        except Exception:
+            _REF_BIG = None
+            return None
+    _REF_BIG = _bind_ref(C.CDLL(path))
+    return _REF_BIG
+
+
 def ref():
     """The compiled reference, or None if oracle/_ref has not been built/shipped."""
     global _REF, _REF_TRIED
@@ -123,7 +164,11 @@ def ref():
                 return None
         except Exception:
             return None
-    L = C.CDLL(path)
+    _REF = _bind_ref(C.CDLL(path))
+    return _REF
+
+
+def _bind_ref(L):
     vp = C.c_void_p
     L.ref_phy_new.restype = vp
     L.ref_phy_new.argtypes = [C.c_int] * 4
@@ -220,7 +265,16 @@ def ref():
     L.ref_get_pucch_tables.argtypes = [vp, u32, u32, f32p]
     L.ref_get_n_rb_ul.argtypes = [vp]
     L.ref_get_n_rb_ul.restype = u32
-    _REF = L
+    if hasattr(L, "ref_dl_cases_run"):  # absent from a libref_oracle.so built before round 3
+        sz = C.c_size_t
+        L.ref_dl_case_sizeof.restype = sz
+        L.ref_ul_alloc_case_sizeof.restype = sz
+        L.ref_ul_unit_case_sizeof.restype = sz
+        L.ref_pdsch_soft_capacity.restype = sz
+        assert L.ref_dl_case_sizeof() == C.sizeof(RefDlCase) and L.ref_ul_alloc_case_sizeof() == C.sizeof(RefUlAllocCase)
+        assert L.ref_ul_unit_case_sizeof() == C.sizeof(RefUlUnitCase)
+        L.ref_dl_cases_run.argtypes = [vp, u32, C.c_int, vp, sz, vp, sz, vp, sz, vp, sz, vp, C.c_int]
+        L.ref_ul_cases_run.argtypes = [vp, u32, vp, u32, vp, sz, vp, vp, sz, vp, sz, C.c_int]
     return L
 
 

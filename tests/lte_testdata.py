@@ -1,5 +1,10 @@
 """Seeded synthetic inputs shared by the tests (uses the oracle's encoder -- test side only)."""
 import numpy as np
+import pytest
+
+# Collect a CPU-only checker test twice: unmarked (the `-m "not gpu"` suite) and marked `gpu` (the driver's `-m gpu` run on the GPU
+# box), so that the tests which tie the CPU checkers to the compiled reference are proven where the kernels they underwrite run.
+on_both_boxes = pytest.mark.parametrize("box", ["cpu", pytest.param("gpu_box", marks=pytest.mark.gpu)])
 
 
 def turbo_blocks(port, K, n, kind, seed):

@@ -106,27 +106,36 @@ def test_w4_full_chain_end_to_end(ctx, port):
 def test_big_allocation_soft_combining(ctx, port):
     """SURVEY 8d W4, "big" variant: one 100-PRB 64QAM allocation, E = 82 800 soft bits for K = 6016 -- 4.6 laps of the circular
     buffer, i.e. heavy soft combining.  The unmodified reference cannot run it (its scratch arrays hold 10 000 soft bits), so the
-    checker is the plain-C restatement with scratch sized from the allocation; the product has no such cap."""
+    checker is `oracle_big` -- the reference compiled through the sed of oracle/ref/Makefile that only enlarges those literals
+     -- on its own receive grid; the restatement with scratch sized from the allocation must agree with both."""
+    import fuzz_cases as fz
     import openlte_amd as m
     from openlte_amd import synth
+    from oracle import pyoracle
+    big = pyoracle.ref_big()
+    if big is None:
+        pytest.skip("oracle/_ref/libref_oracle_big.so not built (needs /root/reference)")
     cfg = m.DlCfg(2048, 100, 1, 0)
     sfs, cells = [1, 8], [17, 404]
     allocs = [m.make_alloc(u, 3, 5992, list(range(100)), 0x100 + u) for u in range(2)]
     for snr in (30, 14, 4):  # parity at every SNR (at 4 dB both sides fail the CRC); clean decode where the channel allows
         iq, tx = synth.dl_units(cfg, sfs, cells, allocs, 1, snr_db=snr, max_delay=4, seed=1234 + snr)
+        cases = [fz.make_case(2048, 100, 1, cells[u], sfs[u], 2, 3, 5992, list(range(100)), 0x100 + u) for u in range(2)]
+        r = fz.run_ref_dl(big, cases, iq=fz.pad_units(iq))
         for u in range(2):
-            lc, s = td.oracle_frontend(port, 2048, 100, 1, iq[u], sfs[u], cells[u])
-            sub = upload_oracle_subframe(ctx, s, 1)
             al = [m.make_alloc(0, 3, 5992, list(range(100)), 0x100 + u)]
             plan = ctx.pdsch_plan(cfg, 2, al)
-            d_sub = ctx.to_device(sub)
+            d_sub = ctx.to_device(np.ascontiguousarray(r["planes"][u, :4]).reshape(-1))
             st, bits = plan.run(d_sub, [sfs[u]], [cells[u]])
-            err, out, desc = oracle_pdsch(port, lc, s, al[0], 2, cells[u], 1)
-            assert len(desc) == 82800
-            assert (plan.soft_bits(0)[:len(desc)] == desc).all()
-            assert st[0] == err and (err != 0 or (bits[0] == out).all())
+            assert r["n_soft"][u] == 82800
+            assert (plan.soft_bits(0)[:82800] == r["soft"][u, :82800]).all()
+            assert (st[0] == 0) == (r["rc"][u] == 0) and (st[0] != 0 or (bits[0] == r["bits"][u, :5992]).all())
             if snr >= 14:
-                assert err == 0 and (bits[0] == tx[u, 0, :5992]).all(), (snr, u)
+                assert st[0] == 0 and (bits[0] == tx[u, 0, :5992]).all(), (snr, u)
+            # the restatement on its own grid: the same verdict and block (its front end differs from the reference's by float rounding)
+            lc, s = td.oracle_frontend(port, 2048, 100, 1, iq[u], sfs[u], cells[u])
+            err, out, desc = oracle_pdsch(port, lc, s, al[0], 2, cells[u], 1)
+            assert len(desc) == 82800 and (err == 0) == (st[0] == 0) and (err != 0 or (out == bits[0]).all())
             plan.close()
             d_sub.free()
 
@@ -632,7 +641,7 @@ def test_random_allocations_other_bandwidths_and_ports(ctx, port, fft, nrb, n_an
     done = 0
     for case in range(14):
         cell, cfi, mod = int(rng.integers(0, 504)), int(rng.integers(1, 4)), int(rng.integers(1, 4))
-        sf = int(rng.integers(0, 10)) if n_ant < 4 else int(rng.choice([1, 2, 3, 4, 6, 7, 8, 9]))  # 4 ports: the M_ap % 4 != 0 tail is outside the envelope
+        sf = int(rng.integers(0, 10)) if case % 3 else (0, 5)[case // 3 % 2]  # subframes 0 / 5 for every port count (M_ap % 4 == 0 always: test_fuzz_cpu.py)
         n_sym = cfi + (1 if nrb <= 10 else 0)
         n_prb = int(rng.integers(1, min(nrb, 16) + 1))
         first = int(rng.integers(0, nrb - n_prb + 1))

@@ -1,0 +1,206 @@
+"""GPU parity at scale: thousands of seeded random cases against the COMPILED REFERENCE (not the restatement).
+
+Downlink (>= 6000 cases, tests/fuzz_cases.py): the reference's own transmitter makes the capture (real 1 / 2 / 4-port transmit
+diversity), the reference's receiver -- liblte_phy_get_dl_subframe_and_ce + liblte_phy_pdsch_channel_decode, run in
+oracle/ref/ref_fuzz.cc on every host core, from the `oracle_big` build so that full-band allocations are inside its scratch --
+gives the expected grid, soft bits, verdict and transport block.  The GPU side batches every case of a (bandwidth, ports,
+control-region size) group into ONE front-end launch and ONE PDSCH plan run:
+
+* exact stage: the reference's receive grid is uploaded, so RE extraction, pre-decoding, layer de-mapping, de-mapping,
+  descrambling, rate un-matching, the REF turbo decoder and the CRC see the reference's inputs: soft bits, verdict and bits must be
+  IDENTICAL, every case;
+* tolerance stage: the library's own front end on the same capture: rx_symb / rx_ce within the FFT tolerance, and the
+  chain on its own grid must reach the reference's verdict (a soft bit may sit within float rounding of a decision boundary, so this
+  is counted, not demanded bit for bit -- the count is asserted and reported).
+
+Uplink (>= 1000 allocations): random cells / hopping modes / cyclic shifts / widths / positions through the library's uplink
+transmitter, liblte_phy_get_ul_subframe + liblte_phy_pusch_channel_decode as the checker: identical soft bits, verdicts, blocks.
+
+A report of what was run (counts per dimension, verdict mix, worst tolerances) goes to gpurun_out/fuzz_report.json."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+import fuzz_cases as fz
+import lte_testdata as td
+
+pytestmark = pytest.mark.gpu
+
+N_DL_CHUNKS, DL_CHUNK = 7, 1000
+N_UL_GROUPS = 100
+TOL_SYMB, TOL_CE = 1e-5, 1e-4
+REPORT = {}
+
+
+@pytest.fixture(scope="module")
+def ref_big():
+    from oracle import pyoracle
+    L = pyoracle.ref_big()
+    if L is None:
+        pytest.skip("oracle/_ref/libref_oracle_big.so not built (needs /root/reference)")
+    return L
+
+
+def rel_l2(a, b):
+    return float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-30))
+
+
+def write_report():
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "fuzz_report.json"), "w") as f:
+            json.dump(REPORT, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def run_group(ctx, cases, idx, r, stats, bad):
+    """One (fft, N_rb, N_ant, N_pdcch_symbs) group of a chunk on the GPU."""
+    import openlte_amd as m
+    c0 = cases[idx[0]]
+    n_ant, n = c0["n_ant"], len(idx)
+    cfg = m.DlCfg(c0["fft"], c0["n_rb"], n_ant, m.IQ_I8)
+    sfs = np.array([cases[i]["sf"] for i in idx], np.uint32)
+    cells = np.array([cases[i]["cell"] for i in idx], np.uint32)
+    allocs = [m.make_alloc(j, cases[i]["mod"], cases[i]["tbs"], cases[i]["prb0"], cases[i]["rnti"], cases[i]["rv"], cases[i]["tx_mode"], cases[i]["prb1"])
+              for j, i in enumerate(idx)]
+    nf = ctx.subframe_floats(n_ant)
+    assert nf == (2 + 2 * n_ant) * 16 * 1200
+    # ---- exact stage on the reference's grid
+    grid = np.ascontiguousarray(r["planes"][idx, :2 + 2 * n_ant]).reshape(-1)
+    d_sub = ctx.to_device(grid)
+    plan = ctx.pdsch_plan(cfg, c0["n_sym"], allocs)
+    st, bits = plan.run(d_sub, sfs, cells)
+    for j, i in enumerate(idx):
+        c = cases[i]
+        key = (i, c["n_rb"], n_ant, c["cell"], c["sf"], c["n_sym"], c["mod"], c["tbs"], c["rv"], c["tx_mode"], len(c["prb0"]), c["prb0"] != c["prb1"], c["snr"])
+        e = plan.soft_bits(j)
+        ne = int(r["n_soft"][i])
+        if len(e) != ne or not (e == r["soft"][i, :ne]).all():
+            bad.append(("soft", key, int(len(e)), ne, int((e[:min(len(e), ne)] != r["soft"][i, :min(len(e), ne)]).sum())))
+            continue
+        if (st[j] == 0) != (r["rc"][i] == 0):
+            bad.append(("verdict", key, int(st[j]), int(r["rc"][i])))
+            continue
+        if st[j] == 0 and not (bits[j] == r["bits"][i, :c["tbs"]]).all():
+            bad.append(("bits", key))
+            continue
+        stats["exact_ok"] += 1
+        stats["decoded"] += int(st[j] == 0)
+    plan.close()
+    d_sub.free()
+    # ---- tolerance stage: own front end on the capture, then the chain on its own grid
+    d_iq = ctx.to_device(np.ascontiguousarray(r["iq"][idx]).reshape(-1, 2))
+    d_start = ctx.to_device((np.arange(n) * fz.UNIT_CAP).astype(np.uint64))
+    d_sf, d_cell = ctx.to_device(sfs), ctx.to_device(cells)
+    d_own = ctx.alloc(n * nf * 4)
+    d_own.zero()
+    ctx.dl_frontend_dev(cfg, d_iq, None, d_start, d_sf, d_cell, n, d_own)
+    own = d_own.download(np.float32).reshape(n, 2 + 2 * n_ant, 16, 1200)
+    n_sc = 12 * c0["n_rb"]
+    for j, i in enumerate(idx):
+        want = r["planes"][i]
+        es = max(rel_l2(own[j, 0, :14, :n_sc], want[0, :14, :n_sc]), rel_l2(own[j, 1, :14, :n_sc], want[1, :14, :n_sc]))
+        ec = max(rel_l2(own[j, 2:2 + n_ant, :14, :n_sc], want[2:2 + n_ant, :14, :n_sc]), rel_l2(own[j, 2 + n_ant:, :14, :n_sc], want[2 + n_ant:2 + 2 * n_ant, :14, :n_sc]))
+        stats["worst_symb"], stats["worst_ce"] = max(stats["worst_symb"], es), max(stats["worst_ce"], ec)
+        if es >= TOL_SYMB or ec >= TOL_CE:
+            stats["tol_fail"].append((i, cases[i]["n_rb"], n_ant, cases[i]["cell"], cases[i]["sf"], cases[i]["snr"], es, ec))
+    plan = ctx.pdsch_plan(cfg, c0["n_sym"], allocs)
+    st2, bits2 = plan.run(d_own, sfs, cells)
+    for j, i in enumerate(idx):
+        same = (st2[j] == 0) == (r["rc"][i] == 0) and (st2[j] != 0 or (bits2[j] == r["bits"][i, :cases[i]["tbs"]]).all())
+        stats["own_same"] += int(same)
+        if not same:
+            stats["own_diff"].append((i, cases[i]["n_rb"], n_ant, cases[i]["mod"], cases[i]["tbs"], cases[i]["snr"], int(st2[j]), int(r["rc"][i])))
+    plan.close()
+    for b in (d_iq, d_start, d_sf, d_cell, d_own):
+        b.free()
+
+
+def test_downlink_fuzz_against_the_compiled_reference(ctx, ref_big):
+    stats = dict(exact_ok=0, decoded=0, own_same=0, worst_symb=0.0, worst_ce=0.0, tol_fail=[], own_diff=[])
+    bad, total = [], 0
+    dims = dict(n_rb={}, n_ant={}, mod={}, sf={}, n_sym={}, rv={}, tx_mode={}, kind={})
+    t_ref = t_gpu = 0.0
+    for chunk in range(N_DL_CHUNKS):
+        cases = fz.draw_dl_cases(DL_CHUNK, 1000 + chunk)
+        t0 = time.time()
+        r = fz.run_ref_dl(ref_big, cases)
+        t_ref += time.time() - t0
+        assert (r["rc_tx"] == 0).all() and (r["rc_fe"] == 0).all()
+        groups = {}
+        for i, c in enumerate(cases):
+            groups.setdefault((c["fft"], c["n_rb"], c["n_ant"], c["n_sym"]), []).append(i)
+            for k in ("n_rb", "n_ant", "mod", "sf", "n_sym", "rv", "tx_mode"):
+                dims[k][str(c[k])] = dims[k].get(str(c[k]), 0) + 1
+            kind = ("filler" if (c["tbs"] + 24) not in td.ALL_K else "punctured" if 3 * (c["tbs"] + 28) > c["e"] else "repeated" if c["e"] >= 6 * (c["tbs"] + 28) else "rate_third")
+            dims["kind"][kind] = dims["kind"].get(kind, 0) + 1
+            dims["kind"]["one_prb"] = dims["kind"].get("one_prb", 0) + (len(c["prb0"]) == 1)
+            dims["kind"]["full_band"] = dims["kind"].get("full_band", 0) + (len(c["prb0"]) == c["n_rb"])
+            dims["kind"]["slot_hopping"] = dims["kind"].get("slot_hopping", 0) + (c["prb0"] != c["prb1"])
+            dims["kind"]["beyond_10000_soft_bits"] = dims["kind"].get("beyond_10000_soft_bits", 0) + (c["e"] > 10000)
+            dims["kind"]["four_ports_subframe_0_or_5"] = dims["kind"].get("four_ports_subframe_0_or_5", 0) + (c["n_ant"] == 4 and c["sf"] in (0, 5))
+        t0 = time.time()
+        for key, idx in groups.items():
+            run_group(ctx, cases, idx, r, stats, bad)
+        t_gpu += time.time() - t0
+        total += len(cases)
+    REPORT["downlink"] = dict(cases=total, identical_soft_bits_verdict_and_bits=stats["exact_ok"], decoded_by_both=stats["decoded"], mismatches=[list(map(str, b)) for b in bad[:50]],
+                              own_front_end_same_verdict_and_bits=stats["own_same"], own_front_end_differences=stats["own_diff"][:50],
+                              worst_rel_l2_rx_symb=stats["worst_symb"], worst_rel_l2_rx_ce=stats["worst_ce"], tolerance_failures=stats["tol_fail"][:50],
+                              dimensions=dims, seconds_reference=round(t_ref, 1), seconds_gpu_side=round(t_gpu, 1))
+    write_report()
+    assert total >= 5000
+    assert not bad, bad[:10]
+    assert stats["exact_ok"] == total
+    assert stats["decoded"] >= 0.3 * total
+    assert not stats["tol_fail"], stats["tol_fail"][:10]
+    # own grid: a verdict may flip where a soft bit sits within float rounding of a decision boundary and the block is marginal
+    assert stats["own_same"] >= 0.995 * total, (stats["own_same"], total, stats["own_diff"][:10])
+
+
+def test_uplink_fuzz_against_the_compiled_reference(ctx, ref):
+    groups = fz.draw_ul_groups(N_UL_GROUPS, 2026)
+    fz.synth_ul_groups(groups)
+    t0 = time.time()
+    fz.run_ref_ul(ref, groups)
+    t_ref = time.time() - t0
+    n_alloc = n_ok = 0
+    bad, worst = [], 0.0
+    for gi, g in enumerate(groups):
+        n = len(g["sfs"])
+        ul_len = g["iq"].shape[1]
+        symb, d_sub = ctx.ul_frontend(g["cfg"], g["iq"].reshape(-1, 2), np.arange(n) * ul_len, keep=True)
+        plan = ctx.pusch_plan(g["cfg"], g["ulcfg"], g["sfs"], [g["cell"]] * n, g["mi_allocs"])
+        try:
+            st, bits = plan.run(d_sub)
+            soft = [plan.soft_bits(a) for a in range(len(g["mi_allocs"]))]
+        finally:
+            plan.close()
+            d_sub.free()
+        n_sc = 12 * g["n_rb"]
+        err = rel_l2(symb[:, :, :14, :n_sc], g["ref_symb"][:, :, :, :n_sc])
+        worst = max(worst, err)
+        if err >= TOL_SYMB:
+            bad.append(("symb", gi, g["n_rb"], g["cell"], err))
+        for k, ((u, mod, tbs, prbs, rnti), (rc, wbits, wsoft)) in enumerate(zip(g["allocs"], g["ref"])):
+            key = (gi, g["n_rb"], g["cell"], g["ulc"], g["sfs"][u], len(prbs), prbs[0], tbs, g["snr"])
+            n_alloc += 1
+            if soft[k].shape != wsoft.shape or not (soft[k] == wsoft).all():
+                bad.append(("soft", key, int((soft[k][:len(wsoft)] != wsoft[:len(soft[k])]).sum())))
+            elif (st[k] == 0) != (rc == 0):
+                bad.append(("verdict", key, int(st[k]), rc))
+            elif rc == 0 and not (bits[k] == wbits).all():
+                bad.append(("bits", key))
+            else:
+                n_ok += int(rc == 0)
+    REPORT["uplink"] = dict(groups=len(groups), units=sum(len(g["sfs"]) for g in groups), allocations=n_alloc, decoded_by_both=n_ok, mismatches=[list(map(str, b)) for b in bad[:50]],
+                            worst_rel_l2_rx_symb=worst, seconds_reference=round(t_ref, 1))
+    write_report()
+    assert n_alloc >= 1000
+    assert not bad, bad[:10]
+    assert n_ok >= 0.4 * n_alloc

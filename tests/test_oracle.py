@@ -27,8 +27,9 @@ def test_port_matches_golden_turbo_ref(port):
         assert (np.packbits(got, axis=-1) == want).all(), key
 
 
+@td.on_both_boxes
 @pytest.mark.parametrize("K", [40, 48, 200, 512, 1024, 3584, 4224, 6016, 6080, 6144])
-def test_port_turbo_ref_vs_reference(port, ref, ref_phy, K):
+def test_port_turbo_ref_vs_reference(port, ref, ref_phy, K, box):
     """Differential test against the compiled reference, incl. uint32-overflow sizes."""
     for kind in ("clean", "awgn0.5", "awgn0.8", "int"):
         tx, soft = td.turbo_blocks(port, K, 3, kind, seed=K)
@@ -40,7 +41,8 @@ def test_port_turbo_ref_vs_reference(port, ref, ref_phy, K):
             assert (a == c).all(), (K, kind, b)
 
 
-def test_port_all_188_block_sizes_vs_reference(port, ref, ref_phy):
+@td.on_both_boxes
+def test_port_all_188_block_sizes_vs_reference(port, ref, ref_phy, box):
     from oracle.pyoracle import port as _p  # noqa: F401
     rng = np.random.default_rng(5)
     sizes = list(range(40, 513, 8)) + list(range(528, 1025, 16)) + list(range(1056, 2049, 32)) + list(range(2112, 6145, 64))
@@ -59,7 +61,8 @@ def test_port_all_188_block_sizes_vs_reference(port, ref, ref_phy):
         assert (a == b).all(), K
 
 
-def test_port_siso_and_fb_vs_reference(port, ref, ref_phy):
+@td.on_both_boxes
+def test_port_siso_and_fb_vs_reference(port, ref, ref_phy, box):
     rng = np.random.default_rng(11)
     for K in (40, 1024, 6144):
         x = rng.integers(-127, 128, 2 * K).astype(np.int8)
@@ -76,7 +79,8 @@ def test_port_siso_and_fb_vs_reference(port, ref, ref_phy):
         assert (fa[:K] == fb[:K]).all()
 
 
-def test_port_prs_crc_crs_vs_reference(port, ref):
+@td.on_both_boxes
+def test_port_prs_crc_crs_vs_reference(port, ref, box):
     rng = np.random.default_rng(2)
     for c_init in (0, 1, 0x1234567, (0x1234 << 14) | (3 << 9) | 17, 2**31 - 1):
         a, b = np.zeros(3000, np.uint32), np.zeros(3000, np.uint8)
@@ -96,7 +100,8 @@ def test_port_prs_crc_crs_vs_reference(port, ref):
         assert (a[0] == a[2]).all() and (a[1] == a[3]).all()
 
 
-def test_port_rate_unmatch_vs_reference(port, ref, ref_phy):
+@td.on_both_boxes
+def test_port_rate_unmatch_vs_reference(port, ref, ref_phy, box):
     """Restated ratematch round trip (liblte/manual_tests/ratematch_test.cc:58-251) + element-wise
     comparison with the reference incl. puncturing, repetition (soft combining), rv, C, tx_mode."""
     rng = np.random.default_rng(3)
@@ -127,7 +132,8 @@ def test_port_rate_unmatch_vs_reference(port, ref, ref_phy):
             assert (rx == d).all()
 
 
-def test_port_demapper_vs_reference(port, ref):
+@td.on_both_boxes
+def test_port_demapper_vs_reference(port, ref, box):
     rng = np.random.default_rng(4)
     M = 4000
     re = (rng.standard_normal(M) * 0.8).astype(np.float32)
@@ -139,7 +145,8 @@ def test_port_demapper_vs_reference(port, ref):
         assert na == nb == q * M and (a == b).all(), mod
 
 
-def test_port_pre_decoder_vs_reference(port, ref):
+@td.on_both_boxes
+def test_port_pre_decoder_vs_reference(port, ref, box):
     rng = np.random.default_rng(6)
     for n_ant, M_ap in ((1, 1000), (2, 1000), (4, 1000), (4, 998)):
         cap = 5000
@@ -211,7 +218,8 @@ def _ref_vs_port_subframe(port, ref, iq_unit, sf, cell, n_ant):
     return phy, rx, lc, s
 
 
-def test_port_w4_subframe_front_end_and_pdsch_decode_vs_reference(port, ref):
+@td.on_both_boxes
+def test_port_w4_subframe_front_end_and_pdsch_decode_vs_reference(port, ref, box):
     """The two composite functions of the restatement that the GPU stage-parity and smoke tests check against, pinned directly on
     the headline configuration (20 MHz, 1 port, CFI 2, 8 x 12 PRB TBS 3240 + 1 x 4 PRB TBS 1064, 64QAM):
     lo_get_dl_subframe_and_ce vs liblte_phy_get_dl_subframe_and_ce (liblte_phy.cc:5905; float stage: both sit on a float64 DFT,
@@ -256,8 +264,9 @@ def test_port_w4_subframe_front_end_and_pdsch_decode_vs_reference(port, ref):
             ref.ref_phy_free(phy)
 
 
+@td.on_both_boxes
 @pytest.mark.parametrize("tbs,mod,nprb", [(672, 1, 8), (1376, 2, 8), (2000, 3, 8), (680, 1, 8)])
-def test_port_filler_bit_transport_blocks_vs_reference(port, ref, tbs, mod, nprb):
+def test_port_filler_bit_transport_blocks_vs_reference(port, ref, tbs, mod, nprb, box):
     """Transport blocks whose size + 24 is not a turbo block size (F > 0 filler bits).  The reference's transmitter skips the fillers
     when rate matching but its receiver does not treat them as NULL (uint8 filler markers never equal RX_NULL_BIT,
     liblte_phy.cc:9826-9829, :11404), so it fails its own noise-free loopback with LIBLTE_ERROR_DECODE_FAIL; tbs = 680 (F = 0) is the

@@ -1,6 +1,6 @@
 """GPU parity at scale: thousands of seeded random cases against the COMPILED REFERENCE (not the restatement).
 
-Downlink (>= 6000 cases, tests/fuzz_cases.py): the reference's own transmitter makes the capture (real 1 / 2 / 4-port transmit
+Downlink (~20 000 cases, tests/fuzz_cases.py): the reference's own transmitter makes the capture (real 1 / 2 / 4-port transmit
 diversity), the reference's receiver -- liblte_phy_get_dl_subframe_and_ce + liblte_phy_pdsch_channel_decode, run in
 oracle/ref/ref_fuzz.cc on every host core, from the `oracle_big` build so that full-band allocations are inside its scratch --
 gives the expected grid, soft bits, verdict and transport block.  The GPU side batches every case of a (bandwidth, ports,
@@ -13,8 +13,12 @@ control-region size) group into ONE front-end launch and ONE PDSCH plan run:
   chain on its own grid must reach the reference's verdict (a soft bit may sit within float rounding of a decision boundary, so this
   is counted, not demanded bit for bit -- the count is asserted and reported).
 
-Uplink (>= 1000 allocations): random cells / hopping modes / cyclic shifts / widths / positions through the library's uplink
-transmitter, liblte_phy_get_ul_subframe + liblte_phy_pusch_channel_decode as the checker: identical soft bits, verdicts, blocks.
+Uplink (>= 3000 allocations): random cells / hopping modes / cyclic shifts / widths / positions through the library's uplink
+transmitter, liblte_phy_get_ul_subframe + liblte_phy_pusch_channel_decode as the checker.  The uplink has no exact stage: the
+SC-FDMA demodulator AND the transform pre-decoding DFT in front of the de-mapper are floating point in an order FFTW does not
+specify, so a soft bit whose equalised value lies within float rounding of zero may come out with the other sign.  Measured: 2 of
+3.9 M soft bits in the first 1278 allocations.  The test therefore COUNTS differing soft bits (<= 1e-5 of all, reported), and
+demands identical verdicts and transport blocks for every allocation whose soft bits are identical.
 
 A report of what was run (counts per dimension, verdict mix, worst tolerances) goes to gpurun_out/fuzz_report.json."""
 import json
@@ -29,8 +33,8 @@ import lte_testdata as td
 
 pytestmark = pytest.mark.gpu
 
-N_DL_CHUNKS, DL_CHUNK = 7, 1000
-N_UL_GROUPS = 100
+N_DL_CHUNKS, DL_CHUNK = 20, 1000
+N_UL_GROUPS = 250
 TOL_SYMB, TOL_CE = 1e-5, 1e-4
 REPORT = {}
 
@@ -154,7 +158,7 @@ def test_downlink_fuzz_against_the_compiled_reference(ctx, ref_big):
                               worst_rel_l2_rx_symb=stats["worst_symb"], worst_rel_l2_rx_ce=stats["worst_ce"], tolerance_failures=stats["tol_fail"][:50],
                               dimensions=dims, seconds_reference=round(t_ref, 1), seconds_gpu_side=round(t_gpu, 1))
     write_report()
-    assert total >= 5000
+    assert total >= 19000
     assert not bad, bad[:10]
     assert stats["exact_ok"] == total
     assert stats["decoded"] >= 0.3 * total
@@ -169,8 +173,8 @@ def test_uplink_fuzz_against_the_compiled_reference(ctx, ref):
     t0 = time.time()
     fz.run_ref_ul(ref, groups)
     t_ref = time.time() - t0
-    n_alloc = n_ok = 0
-    bad, worst = [], 0.0
+    n_alloc = n_ok = n_soft = n_soft_diff = verdict_diff_after_soft_diff = 0
+    bad, soft_diff, worst = [], [], 0.0
     for gi, g in enumerate(groups):
         n = len(g["sfs"])
         ul_len = g["iq"].shape[1]
@@ -190,8 +194,15 @@ def test_uplink_fuzz_against_the_compiled_reference(ctx, ref):
         for k, ((u, mod, tbs, prbs, rnti), (rc, wbits, wsoft)) in enumerate(zip(g["allocs"], g["ref"])):
             key = (gi, g["n_rb"], g["cell"], g["ulc"], g["sfs"][u], len(prbs), prbs[0], tbs, g["snr"])
             n_alloc += 1
-            if soft[k].shape != wsoft.shape or not (soft[k] == wsoft).all():
-                bad.append(("soft", key, int((soft[k][:len(wsoft)] != wsoft[:len(soft[k])]).sum())))
+            n_soft += len(wsoft)
+            if soft[k].shape != wsoft.shape:
+                bad.append(("soft count", key, len(soft[k]), len(wsoft)))
+            elif not (soft[k] == wsoft).all():
+                nd = int((soft[k] != wsoft).sum())
+                n_soft_diff += nd
+                soft_diff.append((key, nd, int(st[k]), rc))
+                if (st[k] == 0) != (rc == 0):
+                    verdict_diff_after_soft_diff += 1
             elif (st[k] == 0) != (rc == 0):
                 bad.append(("verdict", key, int(st[k]), rc))
             elif rc == 0 and not (bits[k] == wbits).all():
@@ -199,8 +210,11 @@ def test_uplink_fuzz_against_the_compiled_reference(ctx, ref):
             else:
                 n_ok += int(rc == 0)
     REPORT["uplink"] = dict(groups=len(groups), units=sum(len(g["sfs"]) for g in groups), allocations=n_alloc, decoded_by_both=n_ok, mismatches=[list(map(str, b)) for b in bad[:50]],
-                            worst_rel_l2_rx_symb=worst, seconds_reference=round(t_ref, 1))
+                            worst_rel_l2_rx_symb=worst, seconds_reference=round(t_ref, 1), soft_bits=n_soft, soft_bits_differing=n_soft_diff,
+                            allocations_with_differing_soft_bits=[list(map(str, x)) for x in soft_diff[:50]],
+                            verdicts_differing_in_those=verdict_diff_after_soft_diff)
     write_report()
-    assert n_alloc >= 1000
+    assert n_alloc >= 3000
     assert not bad, bad[:10]
+    assert n_soft_diff <= 1e-5 * n_soft and len(soft_diff) <= 0.005 * n_alloc, (n_soft_diff, n_soft, soft_diff[:10])
     assert n_ok >= 0.4 * n_alloc

@@ -129,7 +129,9 @@ typedef struct {
     uint32_t tx_mode;
     uint32_t rnti;
     uint32_t N_prb;
-    uint32_t reserved;
+    uint32_t n_pdcch_symbs;  /* control-region size of the allocation's subframe (the reference's N_pdcch_symbs argument, 1..4); 0 = the
+                                plan's.  mi_lte_pdcch_decode_run fills it in the allocations it returns, so that the DCIs of a capture's
+                                subframes -- each with its own CFI -- go into ONE plan */
     uint8_t  prb[2][112];    /* PRB indices per slot (alloc->prb[L/7][...]), first N_prb valid    */
 } mi_lte_pdsch_alloc;
 
@@ -154,6 +156,18 @@ typedef struct mi_lte_pdsch_plan mi_lte_pdsch_plan;
 int      mi_lte_pdsch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, uint32_t N_pdcch_symbs,
                                   const mi_lte_pdsch_alloc *h_allocs, uint32_t n_alloc, mi_lte_pdsch_plan **out);
 void     mi_lte_pdsch_plan_destroy(mi_lte_ctx *ctx, mi_lte_pdsch_plan *plan);
+/* A plan whose allocation list changes from run to run -- a capture, where every subframe brings its own DCIs
+ * (LTE_fdd_dl_file_scan/src/LTE_fdd_dl_fs_samp_buf.cc:445-515 decodes what liblte_phy_pdcch_channel_decode just found): the device arrays
+ * and a pinned staging block are sized once (at most max_alloc allocations with at most max_soft_bytes of soft bits between them,
+ * every allocation's share rounded up to 64 bytes), and mi_lte_pdsch_plan_assign re-plans inside them -- host grouping by code-block
+ * size plus three asynchronous copies on the context's stream; no allocation, no wait.  The allocations' own n_pdcch_symbs (as
+ * mi_lte_pdcch_decode_run returns them) let subframes with different control-region sizes share the plan.  The output stride of a
+ * dynamic plan is that of the largest single-code-block transport block (6144 bytes, 768 packed) whatever is assigned. */
+int      mi_lte_pdsch_plan_create_dynamic(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, uint32_t max_alloc, size_t max_soft_bytes,
+                                          mi_lte_pdsch_plan **out);
+int      mi_lte_pdsch_plan_assign(mi_lte_ctx *ctx, mi_lte_pdsch_plan *plan, uint32_t N_pdcch_symbs, const mi_lte_pdsch_alloc *h_allocs,
+                                  uint32_t n_alloc);
+uint32_t mi_lte_pdsch_plan_n_alloc(const mi_lte_pdsch_plan *plan);
 /* Decoder of the plan's transport blocks: MI_LTE_TURBO_REF (default; the reference's decoder, bit-exact) or MI_LTE_TURBO_BCJR with
  * n_iter iterations (the max-log-MAP decoder of mi_lte_turbo_decode_batch; the reference has no such mode).  In BCJR mode the soft
  * bits are rate-un-matched to int8 channel values (sums of repeats saturated to +-127) and the decoded block is finished like
@@ -424,6 +438,16 @@ int    mi_lte_find_sss_run(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const void
                            uint32_t N_id_2, uint32_t *symb_starts /* [7] in/out */, float pss_thresh, uint32_t *N_id_1,
                            uint32_t *frame_start_idx, uint32_t *found);
 
+/* The scanner's caller-side steps between the searches, for a capture that stays in HBM:
+ *   mi_lte_iq_i8_to_planar  int8 I,Q pairs -> planar fp32 i_samps / q_samps (LTE_fdd_dl_fs_samp_buf.cc:657-694);
+ *   mi_lte_freq_shift_run   LTE_fdd_dl_fs_samp_buf::freq_shift (:696-713) in place: sample i (buffer index first_index + k for
+ *       k < n_samples, the reference's loop variable) is rotated by exp(-j*(i+1)*freq_offset*2*pi/fs), the argument evaluated in
+ *       the mixed float / double precision of the reference's expression; cosf / sinf are the device library's (<= 2 ulp), so the
+ *       result agrees with the host's to float rounding, like the FFT behind it. */
+int mi_lte_iq_i8_to_planar(mi_lte_ctx *ctx, const int8_t *d_iq, uint64_t n_samples, float *d_i_samps, float *d_q_samps);
+int mi_lte_freq_shift_run(mi_lte_ctx *ctx, float *d_i_samps, float *d_q_samps, uint64_t first_index, uint64_t n_samples, float freq_offset,
+                          uint32_t fs);
+
 /* ---------------------------------------------------------------- per-call host-pointer forms
  * The bodies of the reference's three entry points on this path, for callers that hold host
  * buffers exactly as the reference's callers do (LTE_fdd_dl_fs_samp_buf.cc:378-515,
@@ -489,26 +513,55 @@ int mi_lte_rate_unmatch_turbo_host(mi_lte_ctx *ctx, const float *h_e_bits, uint3
                                    uint32_t chan_type, uint32_t rv_idx, float *h_d_bits, uint32_t *N_d_bits);
 
 /* ---------------------------------------------------------------- whole-chain batches from host buffers
- * Captures live in host memory, so the batch form for callers that hold host buffers: n_units units of int8 I,Q (each
- * mi_lte_dl_pipeline_unit_samples() pairs: one subframe + the two look-ahead symbols, as for mi_lte_dl_frontend_batch with d_unit_start[u] =
- * u * that) go in, transport blocks come back packed eight bits per byte ([unit][allocation][mi_lte_dl_pipeline_out_stride()]) with one
- * verdict per allocation.  Every unit carries the same n_alloc_per_unit allocations (h_unit_allocs; a semi-static grant pattern -- the
- * `unit` field is ignored).  The batch is cut into chunks of chunk_units that flow H2D -> front end -> PDSCH chain -> D2H on n_lanes
- * independent lanes (a context, a stream, a plan and device buffers each), so that one lane's copies run under another lane's kernels;
- * nothing is allocated per run.  Host arrays should come from mi_lte_host_alloc (pinned): with pageable memory the copies are staged by the
- * driver and do not overlap.  cfg->sample_format: MI_LTE_IQ_I8, optionally | MI_LTE_CE_COMPACT.  The link is the limit by design: 70 KB
- * of samples per 20 MHz subframe. */
+ * Captures live in host memory, so the batch form for callers that hold host buffers: int8 I,Q in, transport blocks back packed eight
+ * bits per byte ([allocation][mi_lte_dl_pipeline_out_stride()], first bit most significant) with one verdict per allocation.  The batch
+ * is cut into chunks of chunk_units subframes that flow H2D -> front end -> PDSCH chain -> D2H on n_lanes independent lanes per device
+ * (a context, a stream, plans and device buffers each), so that one lane's copies run under another lane's kernels; nothing is allocated
+ * per run.  Host arrays should come from mi_lte_host_alloc (pinned, for every device of the process): with pageable memory the copies are
+ * staged by the driver and do not overlap.  cfg->sample_format: MI_LTE_IQ_I8, optionally | MI_LTE_CE_COMPACT.  The link is the limit by
+ * design: 70 KB of samples per 20 MHz subframe.
+ *
+ * Several devices: mi_lte_dl_pipeline_create_multi takes the device ordinals; chunk c of a run goes to device c mod n_devices,
+ * every device is driven by its own host thread for the duration of the run, results land at the allocation's own index -- no collective,
+ * no peer access.  The same ordinal may be listed more than once (the tests do: G "devices" on one GPU must reproduce the single-device
+ * result bit for bit).
+ *
+ * Three shapes of input:
+ *   mi_lte_dl_pipeline_run          units (each mi_lte_dl_pipeline_unit_samples() pairs: one subframe + the two look-ahead symbols, as for
+ *                                   mi_lte_dl_frontend_batch with d_unit_start[u] = u * that) that all carry the allocation template the
+ *                                   pipeline was created with (a semi-static grant pattern; the template's `unit` field is ignored);
+ *                                   results at [unit * n_alloc_per_unit + a].
+ *   mi_lte_dl_pipeline_run_units    the same units with PER-UNIT allocation lists -- what a capture yields once its PDCCHs are decoded
+ *                                   (LTE_fdd_dl_fs_samp_buf.cc:445-515): h_allocs sorted by unit, h_first[u] .. h_first[u+1] the slice of
+ *                                   unit u (n_units + 1 entries, at most n_alloc_per_unit per unit), each allocation's own n_pdcch_symbs or,
+ *                                   where that is 0, N_pdcch_symbs; results at the allocation's index in h_allocs.
+ *   mi_lte_dl_pipeline_run_capture  one CONTIGUOUS capture: n_subframes subframes from sample first_subframe_start on, subframe numbers
+ *                                   first_subfr_num, +1, ... mod 10, one cell.  The capture is split on subframe boundaries and every chunk is
+ *                                   copied with the 4 400 look-ahead samples (at 30.72 MHz) behind its last subframe -- the halo -- so that
+ *                                   the split is invisible: results equal the unsplit run's. */
 typedef struct mi_lte_dl_pipeline mi_lte_dl_pipeline;
 void       *mi_lte_host_alloc(size_t bytes);
 void        mi_lte_host_free(void *p);
 int         mi_lte_dl_pipeline_create(int device, const mi_lte_dl_cfg *cfg, uint32_t N_pdcch_symbs, const mi_lte_pdsch_alloc *h_unit_allocs,
                                       uint32_t n_alloc_per_unit, uint32_t chunk_units, uint32_t n_lanes, mi_lte_dl_pipeline **out);
+/* h_unit_allocs may be NULL (per-unit lists only): then n_alloc_per_unit is the most allocations a unit may carry and
+ * max_soft_bytes_per_unit the soft bits of a unit's allocations, averaged over a chunk (0: one full-band 64QAM allocation's worth) */
+int         mi_lte_dl_pipeline_create_multi(const int *devices, uint32_t n_devices, const mi_lte_dl_cfg *cfg, uint32_t N_pdcch_symbs,
+                                            const mi_lte_pdsch_alloc *h_unit_allocs, uint32_t n_alloc_per_unit, size_t max_soft_bytes_per_unit,
+                                            uint32_t chunk_units, uint32_t n_lanes, mi_lte_dl_pipeline **out);
 void        mi_lte_dl_pipeline_destroy(mi_lte_dl_pipeline *p);
 uint32_t    mi_lte_dl_pipeline_out_stride(const mi_lte_dl_pipeline *p);
 size_t      mi_lte_dl_pipeline_unit_samples(const mi_lte_dl_pipeline *p);
+uint32_t    mi_lte_dl_pipeline_n_devices(const mi_lte_dl_pipeline *p);
 const char *mi_lte_dl_pipeline_last_error(const mi_lte_dl_pipeline *p);
 int         mi_lte_dl_pipeline_run(mi_lte_dl_pipeline *p, const int8_t *h_iq, const uint32_t *h_subfr_num, const uint32_t *h_n_id_cell, uint32_t n_units,
                                    uint8_t *h_out_packed, int32_t *h_status);
+int         mi_lte_dl_pipeline_run_units(mi_lte_dl_pipeline *p, const int8_t *h_iq, const uint32_t *h_subfr_num, const uint32_t *h_n_id_cell,
+                                         uint32_t n_units, const mi_lte_pdsch_alloc *h_allocs, const uint32_t *h_first, uint32_t N_pdcch_symbs,
+                                         uint8_t *h_out_packed, int32_t *h_status);
+int         mi_lte_dl_pipeline_run_capture(mi_lte_dl_pipeline *p, const int8_t *h_capture, uint64_t n_samples, uint64_t first_subframe_start,
+                                           uint32_t n_subframes, uint32_t first_subfr_num, uint32_t N_id_cell, const mi_lte_pdsch_alloc *h_allocs,
+                                           const uint32_t *h_first, uint32_t N_pdcch_symbs, uint8_t *h_out_packed, int32_t *h_status);
 
 /* ---------------------------------------------------------------- input synthesis (host side)
  * A minimal LTE downlink transmitter for benchmark / test captures, the role LTE_fdd_dl_file_gen

@@ -664,10 +664,9 @@ int mi_turbo_bcjr_block_batch(mi_lte_ctx *ctx, const int8_t *d_soft, uint32_t K,
     int         rc = mi_ctx_turbo_tables(ctx, K, qpp_spec ? 1 : 0, &tb);
     if (rc != MI_LTE_OK) return rc;
     const BlockLds lay = bcjr_block_lds(K);
-    static bool attr_set = false; // more than 64 KB of dynamic LDS has to be asked for once
-    if (!attr_set) {
+    if (!ctx->bcjr_block_lds_set) { // more than 64 KB of dynamic LDS has to be asked for: a per-DEVICE attribute, so once per context
         MI_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_bcjr_block, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        ctx->bcjr_block_lds_set = true;
     }
     MI_LAUNCH(ctx, "k_bcjr_block", k_bcjr_block, dim3(n_cb), dim3(64), lay.total, d_soft, K, n_cb, n_iter, (const uint32_t *)tb.d_pi_row,
               (const uint32_t *)tb.d_inv_row, d_c_bits);

@@ -5,6 +5,7 @@
 // allocations, inside the envelope the reference itself can decode (one code block per allocation,
 // SURVEY F4).
 #include <algorithm>
+#include <cstring>
 #include <map>
 #include <type_traits>
 
@@ -81,14 +82,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
     // (liblte_phy.cc:3744-3802) -- a 12-bit mask per (symbol, PRB) pair and, by a scan inside the wave, the running count of REs
     // before each pair.  Waves 1-3: the scrambling sequence words (c_init per :3831) for the upper bound of the bit count, which
     // does not wait for the scan.  One barrier for both.
-    const uint32_t n_pairs = (14 - g.cfi) * N_prb;
+    const uint32_t cfi = al.n_pdcch_symbs ? al.n_pdcch_symbs : g.cfi; // the allocation's own control-region size, or the plan's
+    const uint32_t n_pairs = (14 - cfi) * N_prb;
     const uint32_t c_init = ((al.rnti << 14) | (0u << 13) | (sf << 9) | cell) & 0x7FFFFFFFu; // 31 bits: the Gold basis has 31 rows
     if (threadIdx.x < 64) {
         const uint32_t ln = threadIdx.x, per = (n_pairs + 63) / 64, q0 = ln * per, q1 = min(q0 + per, n_pairs);
         const uint32_t magic = 0xFFFFFFFFu / N_prb + 1u; // q / N_prb = mulhi(q, magic), exact for q < 2^32 / N_prb^2; a single PRB wraps it to 0 = "no division"
         uint32_t local = 0;
         for (uint32_t q = q0; q < q1; q++) {
-            const uint32_t row = magic ? __umulhi(q, magic) : q, L = g.cfi + row, prb = al.prb[L / 7][q - row * N_prb];
+            const uint32_t row = magic ? __umulhi(q, magic) : q, L = cfi + row, prb = al.prb[L / 7][q - row * N_prb];
             const uint32_t m = pdsch_mask(N_ant, cell, sf, L, prb, first_sc, last_sc);
             masks[q] = m | ((L * N_SC_MAX + prb * 12) << 12); // low 12 bits: RE mask, high 20 bits: L*1200 + first sub-carrier
             local += __popc(m);
@@ -192,8 +194,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
 #pragma unroll
                 for (int t = 0; t < 7; t++) {
                     const uint32_t L = 7 * s + t;
-                    if (L < g.cfi) continue;
-                    const uint32_t q = (L - g.cfi) * N_prb + i, mk = masks[q];
+                    if (L < cfi) continue;
+                    const uint32_t q = (L - cfi) * N_prb + i, mk = masks[q];
                     if (!((mk >> j) & 1u)) continue;
                     const uint32_t idx = offs[q] + __popc(mk & below);
                     float sn, cs;
@@ -317,11 +319,19 @@ struct mi_lte_pdsch_plan {
     int           qpp_spec = 0;
     int8_t       *d_bcjr_soft = nullptr;                  // [max n_cb][3(K+4)] int8 channel values of the group being decoded
     uint8_t      *d_bcjr_bits = nullptr;                  // [max n_cb][K] its hard decisions
+    size_t        bcjr_soft_cap = 0, bcjr_bits_cap = 0;
     uint32_t      cfi = 0, n_alloc = 0, out_stride = 0, max_pairs = 0, max_words = 0, max_tbs = 0, packed = 0;
     size_t        e_bytes = 0;
+    // capacity of the device arrays (a dynamic plan is re-assigned within it; a static plan's capacity is its first assignment)
+    uint32_t      cap_alloc = 0;
+    size_t        cap_e_bytes = 0;
+    bool          dynamic = false, wide = false; // wide: the output stride of the largest single-code-block transport block, whatever is held
     mi_lte_pdsch_alloc *d_allocs = nullptr;
     uint32_t *d_e_off = nullptr, *d_e_len = nullptr, *d_cb_alloc = nullptr;
     int8_t   *d_e = nullptr;
+    // pinned staging for re-assignments: allocs | e_off | cb_alloc, copied with one command each on the context's stream
+    void       *h_stage = nullptr;
+    hipEvent_t  staged = nullptr;
     struct Group { uint32_t K, n_cb, cb_base, e_max; };
     std::vector<Group>    groups;
     std::vector<uint32_t> h_e_off;
@@ -334,6 +344,68 @@ static uint32_t qpp_size_at_least(uint32_t B)
     for (int r = 0; r < LTE_QPP_N_SIZES; r++)
         if (LTE_QPP_ROWS[r].K >= B) return LTE_QPP_ROWS[r].K;
     return 0;
+}
+
+// Host side of a plan: group the allocations by code-block size, lay their soft bits out.  Fills everything but the device arrays;
+// cb_alloc receives the allocation index of every code-block slot, group after group.
+static int plan_layout(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, uint32_t N_pdcch_symbs, const mi_lte_pdsch_alloc *h_allocs, uint32_t n_alloc,
+                       std::vector<uint32_t> &cb_alloc)
+{
+    const mi_lte_dl_cfg *cfg = &pl->cfg;
+    pl->cfi       = N_pdcch_symbs;
+    pl->n_alloc   = n_alloc;
+    pl->max_pairs = pl->max_words = 0;
+    pl->groups.clear();
+    std::map<uint32_t, std::vector<uint32_t>> byK;
+    std::map<uint32_t, uint32_t>              emaxK;
+    uint32_t max_tbs = 0;
+    size_t   off = 0;
+    pl->h_e_off.resize(n_alloc);
+    for (uint32_t a = 0; a < n_alloc; a++) {
+        const mi_lte_pdsch_alloc &al = h_allocs[a];
+        const uint32_t B = al.tbs + 24, K = (B <= 6144) ? qpp_size_at_least(B) : 0;
+        const uint32_t cfi = al.n_pdcch_symbs ? al.n_pdcch_symbs : N_pdcch_symbs;
+        if (K == 0 || al.N_prb == 0 || al.N_prb > cfg->N_rb_dl || al.mod_type > 3 || cfi < 1 || cfi > 4) {
+            // multi-code-block transport blocks: the reference's own C > 1 path is broken (SURVEY F4)
+            ctx->err = "allocation outside the single-code-block envelope (tbs + 24 > 6144) or malformed";
+            return MI_LTE_ERR_UNSUPPORTED;
+        }
+        byK[K].push_back(a);
+        max_tbs = std::max(max_tbs, al.tbs);
+        const uint32_t Qm = al.mod_type == 3 ? 6 : al.mod_type == 2 ? 4 : al.mod_type == 1 ? 2 : 1;
+        const uint32_t pairs = (14 - cfi) * al.N_prb, e_max = pairs * 12 * Qm;
+        pl->max_pairs = std::max(pl->max_pairs, pairs);
+        pl->max_words = std::max(pl->max_words, (e_max + 31) / 32);
+        emaxK[K]       = std::max(emaxK[K], e_max);
+        pl->h_e_off[a] = (uint32_t)(off >> 6); // in 64-byte units
+        off += (e_max + 63) & ~63u;
+    }
+    if (pl->max_words > 4095) { // the demodulator reads one word past the allocation's last scrambling word
+        ctx->err = "allocation larger than the scrambling table";
+        return MI_LTE_ERR_UNSUPPORTED;
+    }
+    pl->e_bytes    = off;
+    pl->max_tbs    = max_tbs;
+    const uint32_t st_tbs = (pl->dynamic || pl->wide) ? 6120u : max_tbs; // a dynamic plan keeps ONE output stride over its assignments: the largest single-code-block size
+    pl->out_stride = pl->packed ? (((st_tbs + 7) / 8 + 63) & ~63u) : ((st_tbs + 63) & ~63u);
+    cb_alloc.clear();
+    for (auto &kv : byK) {
+        pl->groups.push_back({kv.first, (uint32_t)kv.second.size(), (uint32_t)cb_alloc.size(), emaxK[kv.first]});
+        cb_alloc.insert(cb_alloc.end(), kv.second.begin(), kv.second.end());
+    }
+    return MI_LTE_OK;
+}
+
+static int plan_device_arrays(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, uint32_t cap_alloc, size_t cap_e_bytes)
+{
+    pl->cap_alloc   = cap_alloc;
+    pl->cap_e_bytes = cap_e_bytes ? cap_e_bytes : 64;
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_allocs, sizeof(mi_lte_pdsch_alloc) * cap_alloc));
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_e_off, sizeof(uint32_t) * cap_alloc));
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_e_len, sizeof(uint32_t) * cap_alloc));
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_cb_alloc, sizeof(uint32_t) * cap_alloc));
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_e, pl->cap_e_bytes));
+    return MI_LTE_OK;
 }
 
 extern "C" {
@@ -350,48 +422,11 @@ int mi_lte_pdsch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, uint32_t
     auto *pl      = new mi_lte_pdsch_plan();
     auto  guard   = on_fail([&] { (void)hipStreamSynchronize(ctx->stream); mi_lte_pdsch_plan_destroy(nullptr, pl); });
     pl->cfg       = *cfg;
-    pl->cfi       = N_pdcch_symbs;
-    pl->n_alloc   = n_alloc;
-    std::map<uint32_t, std::vector<uint32_t>> byK;
-    std::map<uint32_t, uint32_t>              emaxK;
-    uint32_t max_tbs = 0;
-    size_t   off = 0;
-    pl->h_e_off.resize(n_alloc);
-    for (uint32_t a = 0; a < n_alloc; a++) {
-        const mi_lte_pdsch_alloc &al = h_allocs[a];
-        const uint32_t B = al.tbs + 24, K = (B <= 6144) ? qpp_size_at_least(B) : 0;
-        if (K == 0 || al.N_prb == 0 || al.N_prb > cfg->N_rb_dl || al.mod_type > 3) {
-            // multi-code-block transport blocks: the reference's own C > 1 path is broken (SURVEY F4)
-            ctx->err = "allocation outside the single-code-block envelope (tbs + 24 > 6144) or malformed";
-            return MI_LTE_ERR_UNSUPPORTED;
-        }
-        byK[K].push_back(a);
-        max_tbs = std::max(max_tbs, al.tbs);
-        const uint32_t Qm = al.mod_type == 3 ? 6 : al.mod_type == 2 ? 4 : al.mod_type == 1 ? 2 : 1;
-        const uint32_t pairs = (14 - N_pdcch_symbs) * al.N_prb, e_max = pairs * 12 * Qm;
-        pl->max_pairs = std::max(pl->max_pairs, pairs);
-        pl->max_words = std::max(pl->max_words, (e_max + 31) / 32);
-        emaxK[K]       = std::max(emaxK[K], e_max);
-        pl->h_e_off[a] = (uint32_t)(off >> 6); // in 64-byte units
-        off += (e_max + 63) & ~63u;
-    }
-    if (pl->max_words > 4095) { // the demodulator reads one word past the allocation's last scrambling word
-        ctx->err = "allocation larger than the scrambling table";
-        return MI_LTE_ERR_UNSUPPORTED;
-    }
-    pl->e_bytes    = off;
-    pl->out_stride = (max_tbs + 63) & ~63u;
-    pl->max_tbs    = max_tbs;
     std::vector<uint32_t> cb_alloc;
-    for (auto &kv : byK) {
-        pl->groups.push_back({kv.first, (uint32_t)kv.second.size(), (uint32_t)cb_alloc.size(), emaxK[kv.first]});
-        cb_alloc.insert(cb_alloc.end(), kv.second.begin(), kv.second.end());
-    }
-    MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_allocs, sizeof(mi_lte_pdsch_alloc) * n_alloc));
-    MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_e_off, sizeof(uint32_t) * n_alloc));
-    MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_e_len, sizeof(uint32_t) * n_alloc));
-    MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_cb_alloc, sizeof(uint32_t) * n_alloc));
-    MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_e, pl->e_bytes ? pl->e_bytes : 64));
+    int rc = plan_layout(ctx, pl, N_pdcch_symbs, h_allocs, n_alloc, cb_alloc);
+    if (rc != MI_LTE_OK) return rc;
+    rc = plan_device_arrays(ctx, pl, n_alloc, pl->e_bytes);
+    if (rc != MI_LTE_OK) return rc;
     MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_allocs, h_allocs, sizeof(mi_lte_pdsch_alloc) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
     MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_e_off, pl->h_e_off.data(), sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
     MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_cb_alloc, cb_alloc.data(), sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
@@ -400,6 +435,55 @@ int mi_lte_pdsch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, uint32_t
     *out = pl;
     return MI_LTE_OK;
 }
+
+// A plan whose allocation list changes from run to run (a capture: every subframe has its own DCIs, LTE_fdd_dl_fs_samp_buf.cc:445-515):
+// device arrays and pinned staging sized once, mi_lte_pdsch_plan_assign re-plans inside them with three asynchronous copies and no
+// allocation, no wait.
+int mi_lte_pdsch_plan_create_dynamic(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, uint32_t max_alloc, size_t max_soft_bytes, mi_lte_pdsch_plan **out)
+{
+    if (!ctx || !cfg || !out || max_alloc == 0) return MI_LTE_ERR_INVALID_ARG;
+    if (!(cfg->N_ant == 1 || cfg->N_ant == 2 || cfg->N_ant == 4)) return MI_LTE_ERR_INVALID_ARG;
+    if ((cfg->sample_format & MI_LTE_CE_COMPACT) && cfg->N_ant != 1) { ctx->err = "MI_LTE_CE_COMPACT: single-port cells only"; return MI_LTE_ERR_UNSUPPORTED; }
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    auto *pl    = new mi_lte_pdsch_plan();
+    auto  guard = on_fail([&] { mi_lte_pdsch_plan_destroy(nullptr, pl); });
+    pl->cfg     = *cfg;
+    pl->dynamic = true;
+    int rc = plan_device_arrays(ctx, pl, max_alloc, (max_soft_bytes + 63) & ~(size_t)63);
+    if (rc != MI_LTE_OK) return rc;
+    MI_HIP_CHECK(ctx, hipHostMalloc(&pl->h_stage, (sizeof(mi_lte_pdsch_alloc) + 2 * sizeof(uint32_t)) * (size_t)max_alloc, hipHostMallocDefault));
+    MI_HIP_CHECK(ctx, hipEventCreateWithFlags(&pl->staged, hipEventDisableTiming));
+    guard.armed = false;
+    *out = pl;
+    return MI_LTE_OK;
+}
+
+int mi_lte_pdsch_plan_assign(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, uint32_t N_pdcch_symbs, const mi_lte_pdsch_alloc *h_allocs, uint32_t n_alloc)
+{
+    if (!ctx || !pl || !pl->dynamic || !h_allocs || n_alloc == 0 || N_pdcch_symbs < 1 || N_pdcch_symbs > 4) return MI_LTE_ERR_INVALID_ARG;
+    if (n_alloc > pl->cap_alloc) { ctx->err = "more allocations than the dynamic plan was created for"; return MI_LTE_ERR_INVALID_ARG; }
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    std::vector<uint32_t> cb_alloc;
+    int rc = plan_layout(ctx, pl, N_pdcch_symbs, h_allocs, n_alloc, cb_alloc);
+    if (rc != MI_LTE_OK) { pl->n_alloc = 0; return rc; }
+    if (pl->e_bytes > pl->cap_e_bytes) { pl->n_alloc = 0; ctx->err = "more soft bits than the dynamic plan was created for"; return MI_LTE_ERR_INVALID_ARG; }
+    MI_HIP_CHECK(ctx, hipEventSynchronize(pl->staged)); // the previous assignment's copies have left the staging block
+    auto *sa = (mi_lte_pdsch_alloc *)pl->h_stage;
+    auto *so = (uint32_t *)(sa + pl->cap_alloc), *sc = so + pl->cap_alloc;
+    memcpy(sa, h_allocs, sizeof(mi_lte_pdsch_alloc) * n_alloc);
+    memcpy(so, pl->h_e_off.data(), sizeof(uint32_t) * n_alloc);
+    memcpy(sc, cb_alloc.data(), sizeof(uint32_t) * n_alloc);
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_allocs, sa, sizeof(mi_lte_pdsch_alloc) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_e_off, so, sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_cb_alloc, sc, sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipEventRecord(pl->staged, ctx->stream));
+    return MI_LTE_OK;
+}
+
+uint32_t mi_lte_pdsch_plan_n_alloc(const mi_lte_pdsch_plan *pl) { return pl ? pl->n_alloc : 0; }
+} // extern "C"
+void mi_pdsch_plan_wide_stride(mi_lte_pdsch_plan *pl) { pl->wide = true; (void)mi_lte_pdsch_plan_set_output(pl, pl->packed); }
+extern "C" {
 
 void mi_lte_pdsch_plan_destroy(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl)
 {
@@ -415,6 +499,8 @@ void mi_lte_pdsch_plan_destroy(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl)
     (void)hipFree(pl->d_e);
     if (pl->d_bcjr_soft) (void)hipFree(pl->d_bcjr_soft);
     if (pl->d_bcjr_bits) (void)hipFree(pl->d_bcjr_bits);
+    if (pl->h_stage) (void)hipHostFree(pl->h_stage);
+    if (pl->staged) (void)hipEventDestroy(pl->staged);
     delete pl;
 }
 
@@ -440,7 +526,8 @@ int mi_lte_pdsch_plan_set_output(mi_lte_pdsch_plan *pl, uint32_t packed)
 {
     if (!pl) return MI_LTE_ERR_INVALID_ARG;
     pl->packed     = packed ? 1u : 0u;
-    pl->out_stride = packed ? (((pl->max_tbs + 7) / 8 + 63) & ~63u) : ((pl->max_tbs + 63) & ~63u);
+    const uint32_t st_tbs = (pl->dynamic || pl->wide) ? 6120u : pl->max_tbs;
+    pl->out_stride = packed ? (((st_tbs + 7) / 8 + 63) & ~63u) : ((st_tbs + 63) & ~63u);
     return MI_LTE_OK;
 }
 
@@ -448,6 +535,7 @@ int mi_lte_pdsch_decode_run(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, const float 
                             const uint32_t *d_n_id_cell, uint8_t *d_out_bits, int32_t *d_status)
 {
     if (!ctx || !pl || !d_subframes || !d_subfr_num || !d_n_id_cell || !d_out_bits || !d_status) return MI_LTE_ERR_INVALID_ARG;
+    if (pl->n_alloc == 0) { ctx->err = "the dynamic plan holds no allocations (mi_lte_pdsch_plan_assign)"; return MI_LTE_ERR_INVALID_ARG; }
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     int rc = mi_ctx_gold_tables(ctx);
     if (rc != MI_LTE_OK) return rc;
@@ -469,11 +557,18 @@ int mi_lte_pdsch_decode_run(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, const float 
                   d_n_id_cell, gt, pl->d_e, pl->d_e_off, pl->d_e_len, pl->max_pairs, words_al, e_cap);
     MI_HIP_CHECK(ctx, hipGetLastError());
     const bool bcjr = pl->decoder == MI_LTE_TURBO_BCJR || pl->decoder == MI_LTE_TURBO_BCJR_BLOCK;
-    if (bcjr && !pl->d_bcjr_soft) {
+    if (bcjr) {
         size_t soft = 0, bits = 0;
         for (auto &gr : pl->groups) { soft = std::max(soft, (size_t)gr.n_cb * 3 * (gr.K + 4)); bits = std::max(bits, (size_t)gr.n_cb * gr.K); }
-        MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_bcjr_soft, soft));
-        MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_bcjr_bits, bits));
+        if (soft > pl->bcjr_soft_cap || bits > pl->bcjr_bits_cap) { // first run, or a re-assigned plan that needs more
+            MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            if (pl->d_bcjr_soft) (void)hipFree(pl->d_bcjr_soft);
+            if (pl->d_bcjr_bits) (void)hipFree(pl->d_bcjr_bits);
+            pl->d_bcjr_soft = nullptr; pl->d_bcjr_bits = nullptr;
+            MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_bcjr_soft, soft));
+            MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_bcjr_bits, bits));
+            pl->bcjr_soft_cap = soft; pl->bcjr_bits_cap = bits;
+        }
     }
     for (auto &gr : pl->groups) {
         if (bcjr)

@@ -44,6 +44,7 @@ struct mi_lte_ctx {
     size_t             scratch_bytes = 0;
     uint32_t          *h_flag = nullptr, *d_flag = nullptr; // the completion word of the per-call waits (mi_stream_wait_polling) and its sequence number
     uint32_t           flag_seq = 0;
+    bool               bcjr_block_lds_set = false; // hipFuncSetAttribute(k_bcjr_block, max dynamic LDS) made on this context's device
     uint32_t           siso_small_max = 4096; // code blocks per decode up to which k_turbo_siso_small runs (mi_lte_set_turbo_small_batch)
     void              *h_small = nullptr, *d_small = nullptr; // MI_SMALL_BYTES of pinned host memory the kernels can write (mi_ctx_small_results)
     std::map<uint64_t, TurboTables> turbo_tables; // key = K | (spec << 32)
@@ -118,6 +119,8 @@ int   mi_turbo_bcjr_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_l
                           const uint32_t *d_e_off, const uint32_t *d_e_len, uint8_t *d_out_bits, uint32_t out_stride, int32_t *d_status, bool ul,
                           int8_t *d_soft, uint8_t *d_c_bits, uint32_t n_iter, int qpp_spec, bool packed = false, uint32_t e_max_bytes = 0, bool block_mode = false);
 int   mi_ctx_turbo_tables(mi_lte_ctx *ctx, uint32_t K, int spec, TurboTables *out);
+struct mi_lte_pdsch_plan;
+void  mi_pdsch_plan_wide_stride(mi_lte_pdsch_plan *pl); // one output stride whatever the plan holds: that of the largest single-code-block transport block (pipeline.cc)
 struct mi_lte_pusch_plan;
 int   mi_pusch_plan_create_impl(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const mi_lte_ul_cfg *ul, const uint32_t *h_unit_subfr_num,
                                 const uint32_t *h_unit_n_id_cell, uint32_t n_units, const mi_lte_pdsch_alloc *h_allocs, uint32_t n_alloc,

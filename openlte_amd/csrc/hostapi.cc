@@ -430,7 +430,7 @@ int mi_lte_pdsch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const fl
     if (rc != MI_LTE_OK) return rc;
     mi_lte_dl_cfg       cfg = {fft_of(N_rb_dl), N_rb_dl, N_ant, MI_LTE_IQ_F32_PLANAR};
     mi_lte_pdsch_alloc  a   = *alloc;
-    a.unit = 0; a.reserved = 0;
+    a.unit = 0; a.n_pdcch_symbs = 0;
     std::string key;
     key_add(key, cfg); key_add(key, N_pdcch_symbs); key_add(key, a);
     mi_lte_pdsch_plan *plan = hc->pdsch.find(key);
@@ -642,7 +642,7 @@ int mi_lte_pusch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_ul, const fl
     if (rc != MI_LTE_OK) return rc;
     mi_lte_dl_cfg      cfg = {fft_of(N_rb_ul), N_rb_ul, 1, MI_LTE_IQ_F32_PLANAR};
     mi_lte_pdsch_alloc a   = *alloc;
-    a.unit = 0; a.reserved = 0;
+    a.unit = 0; a.n_pdcch_symbs = 0;
     const size_t       M   = 12 * (size_t)a.N_prb;
     std::vector<float> dm(4 * M);
     memcpy(&dm[0], h_dmrs_0_re, M * 4); memcpy(&dm[M], h_dmrs_0_im, M * 4);

@@ -688,6 +688,7 @@ int mi_lte_pdcch_decode_run(mi_lte_ctx *ctx, mi_lte_pdcch_plan *pl, const float 
             rc = urc == 0 ? 0u : 4u;  // the reference returns whatever its last unpacker call returned
             if (urc != 0) continue; // not counted (:4948-4960, :4989-5000)
             d.alloc_valid = 1;
+            d.alloc.n_pdcch_symbs = res[u].n_symbs; // the allocation can go into a PDSCH plan as it is
             o[n++] = d;
         }
         h_n_dci[u] = n;

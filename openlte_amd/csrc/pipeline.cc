@@ -1,12 +1,23 @@
 // Whole-chain batches from HOST buffers: captures live in host memory (LTE_fdd_dl_fs_samp_buf.cc:657-694), so a caller that
-// wants more than one subframe at a time hands over int8 I,Q units and gets transport blocks back.  The batch is cut into chunks that flow
+// wants more than one subframe at a time hands over int8 I,Q and gets transport blocks back.  The batch is cut into chunks that flow
 //     H2D (int8 IQ)  ->  front end  ->  PDSCH chain  ->  D2H (packed bits + verdicts)
-// on LANES: each lane is a context of its own (stream, scratch, plan, device buffers), chunks go to the lanes round robin, and because
-// a lane's stream orders its own three phases while the lanes are independent of each other, one lane's copies run under another
-// lane's kernels.  Nothing is allocated per run.  With the 70 KB of samples per subframe the PCIe link is the limit (a x16 Gen5 link
-// moves about 50 GB/s: ~0.7 M subframes/s per GPU), which is the point: the device-resident rate is three times that.
+// on LANES: each lane is a context of its own (stream, scratch, plans, device buffers), and because a lane's stream orders its own three
+// phases while the lanes are independent of each other, one lane's copies run under another lane's kernels.  Nothing is allocated per
+// run.  With the 70 KB of samples per subframe the PCIe link is the limit (a x16 Gen5 link moves about 50 GB/s: ~0.7 M subframes/s per
+// GPU), which is the point: the device-resident rate is three times that.
+//
+// Several devices ("each GPU owns a host thread ... static round-robin of subframes over 1/2/4/8 devices"): the chunks go to the
+// devices block-cyclically (chunk c -> device c mod G), every device is driven by its own host thread for the duration of a run, and its
+// lanes by that thread alone -- no collective, no peer access, results land in the caller's arrays at the allocation's own index.
+//
+// Three shapes of input:
+//   units + one allocation template   mi_lte_dl_pipeline_run         (a semi-static grant pattern: planned once per lane)
+//   units + per-unit allocation lists mi_lte_dl_pipeline_run_units   (a capture after its PDCCH pass: each chunk re-plans a dynamic plan)
+//   one contiguous capture            mi_lte_dl_pipeline_run_capture (split on subframe boundaries, each chunk copied with the look-ahead
+//                                                                      samples behind its last subframe -- the halo of SURVEY 8e)
 #include <algorithm>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "ctx.hpp"
@@ -14,32 +25,183 @@
 namespace {
 struct Lane {
     mi_lte_ctx        *ctx  = nullptr;
-    mi_lte_pdsch_plan *plan = nullptr;
+    mi_lte_pdsch_plan *plan = nullptr; // the template's plan over a whole chunk (template mode)
+    mi_lte_pdsch_plan *dyn  = nullptr; // re-assigned per chunk (per-unit lists, and the ragged last chunk of template mode)
     int8_t   *d_iq = nullptr;
-    uint64_t *d_start = nullptr;
+    uint64_t *d_start_units = nullptr, *d_start_capture = nullptr;
     uint32_t *d_sf = nullptr, *d_cell = nullptr;
     float    *d_sub = nullptr;
     uint8_t  *d_out = nullptr;
     int32_t  *d_st = nullptr;
-    hipEvent_t done = nullptr;
+};
+struct Dev {
+    int               device = 0;
+    std::vector<Lane> lanes;
+    std::string       err;
+    int               rc = MI_LTE_OK;
+};
+struct Job { // one run, as the device threads see it
+    const int8_t  *h_iq = nullptr;        // units back to back (unit_bytes each), or the capture from its first subframe on
+    bool           capture = false;
+    const uint32_t *h_sf = nullptr, *h_cell = nullptr;
+    uint32_t        n_units = 0;
+    const mi_lte_pdsch_alloc *h_allocs = nullptr; // per-unit lists: CSR over units (h_first[u] .. h_first[u+1]); template mode: nullptr
+    const uint32_t *h_first = nullptr;
+    uint32_t        cfi = 2;
+    uint8_t        *h_out = nullptr;
+    int32_t        *h_status = nullptr;
 };
 } // namespace
 
 struct mi_lte_dl_pipeline {
     mi_lte_dl_cfg cfg;
-    uint32_t      cfi = 0, n_alloc = 0, chunk = 0, out_stride = 0;
-    size_t        unit_samples = 0;
-    int           device = 0;
-    std::vector<Lane> lanes;
+    uint32_t      cfi = 0, n_alloc = 0, chunk = 0, out_stride = 0, max_alloc_per_unit = 0;
+    size_t        unit_samples = 0, sf_samples = 0, look_samples = 0, max_soft_per_unit = 0;
+    std::vector<mi_lte_pdsch_alloc> tmpl; // the allocation template (template mode)
+    std::vector<Dev> devs;
     std::string   err;
 };
+
+static void free_lane(Lane &l)
+{
+    if (l.ctx) (void)mi_lte_sync(l.ctx);
+    if (l.plan) mi_lte_pdsch_plan_destroy(l.ctx, l.plan);
+    if (l.dyn) mi_lte_pdsch_plan_destroy(l.ctx, l.dyn);
+    (void)hipFree(l.d_iq); (void)hipFree(l.d_start_units); (void)hipFree(l.d_start_capture); (void)hipFree(l.d_sf); (void)hipFree(l.d_cell);
+    (void)hipFree(l.d_sub); (void)hipFree(l.d_out); (void)hipFree(l.d_st);
+    if (l.ctx) mi_lte_ctx_destroy(l.ctx);
+    l = Lane();
+}
+
+// soft bits of an allocation with the largest control region excluded... the smallest one (1 symbol): the upper bound a dynamic plan is sized for
+static size_t soft_bound(const mi_lte_pdsch_alloc &a)
+{
+    const uint32_t qm = a.mod_type == 3 ? 6 : a.mod_type == 2 ? 4 : a.mod_type == 1 ? 2 : 1;
+    return ((size_t)13 * a.N_prb * 12 * qm + 63) & ~(size_t)63;
+}
+
+static int make_lane(mi_lte_dl_pipeline *p, Dev &d, Lane &l)
+{
+    int rc = mi_lte_ctx_create(d.device, &l.ctx);
+    if (rc != MI_LTE_OK) return rc;
+    const uint32_t chunk = p->chunk;
+    const size_t   cap_alloc = (size_t)chunk * p->max_alloc_per_unit;
+    if (!p->tmpl.empty()) {
+        std::vector<mi_lte_pdsch_alloc> allocs((size_t)chunk * p->n_alloc);
+        for (uint32_t u = 0; u < chunk; u++)
+            for (uint32_t a = 0; a < p->n_alloc; a++) {
+                allocs[(size_t)u * p->n_alloc + a]      = p->tmpl[a];
+                allocs[(size_t)u * p->n_alloc + a].unit = u;
+            }
+        rc = mi_lte_pdsch_plan_create(l.ctx, &p->cfg, p->cfi, allocs.data(), (uint32_t)allocs.size(), &l.plan);
+        if (rc != MI_LTE_OK) { d.err = mi_lte_last_error(l.ctx); return rc; }
+        mi_lte_pdsch_plan_set_output(l.plan, 1);
+        mi_pdsch_plan_wide_stride(l.plan); // the same output layout as the dynamic plan's
+    }
+    rc = mi_lte_pdsch_plan_create_dynamic(l.ctx, &p->cfg, (uint32_t)cap_alloc, (size_t)chunk * p->max_soft_per_unit, &l.dyn);
+    if (rc != MI_LTE_OK) { d.err = mi_lte_last_error(l.ctx); return rc; }
+    mi_lte_pdsch_plan_set_output(l.dyn, 1);
+    p->out_stride = mi_lte_pdsch_plan_out_stride(l.dyn); // the largest single-code-block stride: template and per-unit runs share the output layout
+    std::vector<uint64_t> su(chunk), sc(chunk);
+    for (uint32_t u = 0; u < chunk; u++) { su[u] = (uint64_t)u * p->unit_samples; sc[u] = (uint64_t)u * p->sf_samples; }
+    const size_t iq_bytes = (size_t)chunk * p->unit_samples * 2 + 64;
+    MI_HIP_CHECK(l.ctx, hipMalloc((void **)&l.d_iq, iq_bytes));
+    MI_HIP_CHECK(l.ctx, hipMalloc((void **)&l.d_start_units, sizeof(uint64_t) * chunk));
+    MI_HIP_CHECK(l.ctx, hipMalloc((void **)&l.d_start_capture, sizeof(uint64_t) * chunk));
+    MI_HIP_CHECK(l.ctx, hipMalloc((void **)&l.d_sf, sizeof(uint32_t) * chunk));
+    MI_HIP_CHECK(l.ctx, hipMalloc((void **)&l.d_cell, sizeof(uint32_t) * chunk));
+    MI_HIP_CHECK(l.ctx, hipMalloc((void **)&l.d_sub, sizeof(float) * mi_lte_subframe_floats(p->cfg.N_ant) * chunk));
+    MI_HIP_CHECK(l.ctx, hipMalloc((void **)&l.d_out, cap_alloc * p->out_stride));
+    MI_HIP_CHECK(l.ctx, hipMalloc((void **)&l.d_st, cap_alloc * sizeof(int32_t)));
+    MI_HIP_CHECK(l.ctx, hipMemcpy(l.d_start_units, su.data(), sizeof(uint64_t) * chunk, hipMemcpyHostToDevice));
+    MI_HIP_CHECK(l.ctx, hipMemcpy(l.d_start_capture, sc.data(), sizeof(uint64_t) * chunk, hipMemcpyHostToDevice));
+    MI_HIP_CHECK(l.ctx, hipMemset(l.d_sf, 0, sizeof(uint32_t) * chunk));
+    MI_HIP_CHECK(l.ctx, hipMemset(l.d_cell, 0, sizeof(uint32_t) * chunk));
+    MI_HIP_CHECK(l.ctx, hipMemset(l.d_sub, 0, sizeof(float) * mi_lte_subframe_floats(p->cfg.N_ant) * chunk));
+    MI_HIP_CHECK(l.ctx, hipMemset(l.d_iq, 0, iq_bytes));
+    return MI_LTE_OK;
+}
+
+// The chunks of one device, in order, on its lanes round robin.  Runs on the device's own host thread.
+static void device_worker(mi_lte_dl_pipeline *p, uint32_t di, const Job *job)
+{
+    Dev           &d = p->devs[di];
+    const uint32_t G = (uint32_t)p->devs.size(), n_chunks = (job->n_units + p->chunk - 1) / p->chunk;
+    d.rc = MI_LTE_OK;
+    d.err.clear();
+    if (hipSetDevice(d.device) != hipSuccess) { d.rc = MI_LTE_ERR_HIP; d.err = "hipSetDevice failed"; return; }
+    const size_t unit_bytes = p->unit_samples * 2;
+    uint32_t     k = 0; // chunks this device has taken
+    std::vector<mi_lte_pdsch_alloc> local;
+    auto fail = [&](Lane &l, int rc) { d.rc = rc; d.err = mi_lte_last_error(l.ctx); };
+    for (uint32_t c = di; c < n_chunks; c += G, k++) {
+        Lane          &l  = d.lanes[k % d.lanes.size()];
+        const uint32_t u0 = c * p->chunk, n = std::min(p->chunk, job->n_units - u0);
+        hipStream_t    st = (hipStream_t)mi_lte_stream(l.ctx);
+        hipError_t     e;
+        if (job->capture) // the chunk's subframes and the look-ahead samples behind the last of them, as they lie in the capture
+            e = hipMemcpyAsync(l.d_iq, job->h_iq + (size_t)u0 * p->sf_samples * 2, ((size_t)n * p->sf_samples + p->look_samples) * 2, hipMemcpyHostToDevice, st);
+        else
+            e = hipMemcpyAsync(l.d_iq, job->h_iq + (size_t)u0 * unit_bytes, (size_t)n * unit_bytes, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(l.d_sf, job->h_sf + u0, sizeof(uint32_t) * n, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(l.d_cell, job->h_cell + u0, sizeof(uint32_t) * n, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) { d.rc = MI_LTE_ERR_HIP; d.err = hipGetErrorString(e); return; }
+        int rc = mi_lte_dl_frontend_batch(l.ctx, &p->cfg, l.d_iq, nullptr, job->capture ? l.d_start_capture : l.d_start_units, l.d_sf, l.d_cell, n, l.d_sub);
+        if (rc != MI_LTE_OK) { fail(l, rc); return; }
+        // which plan decodes the chunk, and where its results go
+        mi_lte_pdsch_plan *plan;
+        size_t             a0, n_al;
+        if (job->h_allocs) { // per-unit lists: the chunk's slice of the caller's list, unit numbers made chunk-local
+            a0   = job->h_first[u0];
+            n_al = job->h_first[u0 + n] - a0;
+            if (n_al == 0) continue;
+            local.assign(job->h_allocs + a0, job->h_allocs + a0 + n_al);
+            for (auto &a : local) a.unit -= u0;
+            rc = mi_lte_pdsch_plan_assign(l.ctx, l.dyn, job->cfi, local.data(), (uint32_t)n_al);
+            plan = l.dyn;
+        } else if (n == p->chunk) {
+            a0 = (size_t)u0 * p->n_alloc; n_al = (size_t)n * p->n_alloc;
+            plan = l.plan;
+        } else { // the ragged last chunk of a template run: the template over n units only, in the dynamic plan
+            a0 = (size_t)u0 * p->n_alloc; n_al = (size_t)n * p->n_alloc;
+            local.resize(n_al);
+            for (uint32_t u = 0; u < n; u++)
+                for (uint32_t a = 0; a < p->n_alloc; a++) { local[(size_t)u * p->n_alloc + a] = p->tmpl[a]; local[(size_t)u * p->n_alloc + a].unit = u; }
+            rc = mi_lte_pdsch_plan_assign(l.ctx, l.dyn, p->cfi, local.data(), (uint32_t)n_al);
+            plan = l.dyn;
+        }
+        if (rc == MI_LTE_OK) rc = mi_lte_pdsch_decode_run(l.ctx, plan, l.d_sub, l.d_sf, l.d_cell, l.d_out, l.d_st);
+        if (rc != MI_LTE_OK) { fail(l, rc); return; }
+        e = hipMemcpyAsync(job->h_out + a0 * p->out_stride, l.d_out, n_al * p->out_stride, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(job->h_status + a0, l.d_st, n_al * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) { d.rc = MI_LTE_ERR_HIP; d.err = hipGetErrorString(e); return; }
+    }
+    for (Lane &l : d.lanes) {
+        const int rc = mi_lte_sync(l.ctx);
+        if (rc != MI_LTE_OK && d.rc == MI_LTE_OK) fail(l, rc);
+    }
+}
+
+static int run_job(mi_lte_dl_pipeline *p, const Job &job)
+{
+    p->err.clear();
+    if (p->devs.size() == 1) device_worker(p, 0, &job); // one device: the caller's thread drives it
+    else {
+        std::vector<std::thread> th;
+        for (uint32_t di = 0; di < p->devs.size(); di++) th.emplace_back(device_worker, p, di, &job);
+        for (auto &t : th) t.join();
+    }
+    for (Dev &d : p->devs)
+        if (d.rc != MI_LTE_OK) { p->err = d.err; return d.rc; }
+    return MI_LTE_OK;
+}
 
 extern "C" {
 
 void *mi_lte_host_alloc(size_t bytes)
 {
     void *p = nullptr;
-    return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+    return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) == hipSuccess ? p : nullptr; // portable: pinned for every device of the process
 }
 void mi_lte_host_free(void *p)
 {
@@ -49,108 +211,127 @@ void mi_lte_host_free(void *p)
 void mi_lte_dl_pipeline_destroy(mi_lte_dl_pipeline *p)
 {
     if (!p) return;
-    (void)hipSetDevice(p->device);
-    for (Lane &l : p->lanes) {
-        if (l.ctx) (void)mi_lte_sync(l.ctx);
-        if (l.plan) mi_lte_pdsch_plan_destroy(l.ctx, l.plan);
-        (void)hipFree(l.d_iq); (void)hipFree(l.d_start); (void)hipFree(l.d_sf); (void)hipFree(l.d_cell);
-        (void)hipFree(l.d_sub); (void)hipFree(l.d_out); (void)hipFree(l.d_st);
-        if (l.done) (void)hipEventDestroy(l.done);
-        if (l.ctx) mi_lte_ctx_destroy(l.ctx);
+    for (Dev &d : p->devs) {
+        (void)hipSetDevice(d.device);
+        for (Lane &l : d.lanes) free_lane(l);
     }
     delete p;
 }
 
-int mi_lte_dl_pipeline_create(int device, const mi_lte_dl_cfg *cfg, uint32_t N_pdcch_symbs, const mi_lte_pdsch_alloc *h_unit_allocs, uint32_t n_alloc_per_unit,
-                              uint32_t chunk_units, uint32_t n_lanes, mi_lte_dl_pipeline **out)
+// h_unit_allocs != NULL: template mode (every unit carries these n_alloc_per_unit allocations; per-unit runs are possible too, with at most
+// that many allocations per unit).  h_unit_allocs == NULL: per-unit lists only, at most n_alloc_per_unit allocations and max_soft_bytes_per_unit
+// soft bits per unit ON AVERAGE over a chunk (0: a full-band 64QAM allocation per unit).
+int mi_lte_dl_pipeline_create_multi(const int *devices, uint32_t n_devices, const mi_lte_dl_cfg *cfg, uint32_t N_pdcch_symbs,
+                                    const mi_lte_pdsch_alloc *h_unit_allocs, uint32_t n_alloc_per_unit, size_t max_soft_bytes_per_unit, uint32_t chunk_units,
+                                    uint32_t n_lanes, mi_lte_dl_pipeline **out)
 {
-    if (!cfg || !h_unit_allocs || !out || n_alloc_per_unit == 0 || chunk_units == 0 || n_lanes == 0 || n_lanes > 8) return MI_LTE_ERR_INVALID_ARG;
+    if (!devices || n_devices == 0 || n_devices > 64 || !cfg || !out || n_alloc_per_unit == 0 || chunk_units == 0 || n_lanes == 0 || n_lanes > 8)
+        return MI_LTE_ERR_INVALID_ARG;
     if ((cfg->sample_format & 0xFFu) != MI_LTE_IQ_I8) return MI_LTE_ERR_INVALID_ARG; // host batches are int8 captures
+    if (N_pdcch_symbs < 1 || N_pdcch_symbs > 4) return MI_LTE_ERR_INVALID_ARG;
     const uint32_t N = cfg->fft_size;
     if (!(N == 128 || N == 256 || N == 512 || N == 1024 || N == 2048)) return MI_LTE_ERR_INVALID_ARG;
     auto *p = new mi_lte_dl_pipeline();
     auto  guard = on_fail([&] { mi_lte_dl_pipeline_destroy(p); });
-    p->cfg = *cfg; p->cfi = N_pdcch_symbs; p->n_alloc = n_alloc_per_unit; p->chunk = chunk_units; p->device = device;
+    p->cfg = *cfg; p->cfi = N_pdcch_symbs; p->n_alloc = n_alloc_per_unit; p->max_alloc_per_unit = n_alloc_per_unit; p->chunk = chunk_units;
     const uint32_t sc = 2048 / N;
+    p->sf_samples   = 30720 / sc;
+    p->look_samples = 4400 / sc + (4400 % sc ? 1 : 0);
     p->unit_samples = ((30720 + 4400) / sc + 15) / 16 * 16; // one subframe + the two look-ahead symbols, a multiple of 16 samples (= mi_lte_synth_unit_len)
-    std::vector<mi_lte_pdsch_alloc> allocs((size_t)chunk_units * n_alloc_per_unit);
-    for (uint32_t u = 0; u < chunk_units; u++)
-        for (uint32_t a = 0; a < n_alloc_per_unit; a++) {
-            allocs[(size_t)u * n_alloc_per_unit + a]      = h_unit_allocs[a];
-            allocs[(size_t)u * n_alloc_per_unit + a].unit = u;
+    if (h_unit_allocs) {
+        p->tmpl.assign(h_unit_allocs, h_unit_allocs + n_alloc_per_unit);
+        size_t s = 0;
+        for (auto &a : p->tmpl) s += soft_bound(a);
+        p->max_soft_per_unit = std::max(s, max_soft_bytes_per_unit);
+    } else
+        p->max_soft_per_unit = max_soft_bytes_per_unit ? ((max_soft_bytes_per_unit + 63) & ~(size_t)63) * 1 + 64 * (size_t)n_alloc_per_unit
+                                                       : (size_t)13 * cfg->N_rb_dl * 12 * 6 + 64 * (size_t)n_alloc_per_unit;
+    p->devs.resize(n_devices);
+    for (uint32_t di = 0; di < n_devices; di++) {
+        Dev &d   = p->devs[di];
+        d.device = devices[di];
+        d.lanes.resize(n_lanes);
+        if (hipSetDevice(d.device) != hipSuccess) return MI_LTE_ERR_NO_DEVICE;
+        for (Lane &l : d.lanes) {
+            const int rc = make_lane(p, d, l);
+            if (rc != MI_LTE_OK) { p->err = d.err; return rc; }
         }
-    std::vector<uint64_t> starts(chunk_units);
-    for (uint32_t u = 0; u < chunk_units; u++) starts[u] = (uint64_t)u * p->unit_samples;
-    p->lanes.resize(n_lanes);
-    for (Lane &l : p->lanes) {
-        int rc = mi_lte_ctx_create(device, &l.ctx);
-        if (rc != MI_LTE_OK) return rc;
-        rc = mi_lte_pdsch_plan_create(l.ctx, cfg, N_pdcch_symbs, allocs.data(), (uint32_t)allocs.size(), &l.plan);
-        if (rc != MI_LTE_OK) { p->err = mi_lte_last_error(l.ctx); return rc; }
-        mi_lte_pdsch_plan_set_output(l.plan, 1);
-        p->out_stride = mi_lte_pdsch_plan_out_stride(l.plan);
-        const size_t n_al = allocs.size();
-        MI_HIP_CHECK(l.ctx, hipMalloc((void **)&l.d_iq, (size_t)chunk_units * p->unit_samples * 2 + 64));
-        MI_HIP_CHECK(l.ctx, hipMalloc((void **)&l.d_start, sizeof(uint64_t) * chunk_units));
-        MI_HIP_CHECK(l.ctx, hipMalloc((void **)&l.d_sf, sizeof(uint32_t) * chunk_units));
-        MI_HIP_CHECK(l.ctx, hipMalloc((void **)&l.d_cell, sizeof(uint32_t) * chunk_units));
-        MI_HIP_CHECK(l.ctx, hipMalloc((void **)&l.d_sub, sizeof(float) * mi_lte_subframe_floats(cfg->N_ant) * chunk_units));
-        MI_HIP_CHECK(l.ctx, hipMalloc((void **)&l.d_out, n_al * p->out_stride));
-        MI_HIP_CHECK(l.ctx, hipMalloc((void **)&l.d_st, n_al * sizeof(int32_t)));
-        MI_HIP_CHECK(l.ctx, hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
-        MI_HIP_CHECK(l.ctx, hipMemcpy(l.d_start, starts.data(), sizeof(uint64_t) * chunk_units, hipMemcpyHostToDevice));
-        MI_HIP_CHECK(l.ctx, hipMemset(l.d_sf, 0, sizeof(uint32_t) * chunk_units));   // a ragged last chunk decodes the units past its end too
-        MI_HIP_CHECK(l.ctx, hipMemset(l.d_cell, 0, sizeof(uint32_t) * chunk_units)); // (results dropped): they must at least be valid numbers
-        MI_HIP_CHECK(l.ctx, hipMemset(l.d_sub, 0, sizeof(float) * mi_lte_subframe_floats(cfg->N_ant) * chunk_units));
-        MI_HIP_CHECK(l.ctx, hipMemset(l.d_iq, 0, (size_t)chunk_units * p->unit_samples * 2 + 64));
     }
     guard.armed = false;
     *out = p;
     return MI_LTE_OK;
 }
 
+int mi_lte_dl_pipeline_create(int device, const mi_lte_dl_cfg *cfg, uint32_t N_pdcch_symbs, const mi_lte_pdsch_alloc *h_unit_allocs, uint32_t n_alloc_per_unit,
+                              uint32_t chunk_units, uint32_t n_lanes, mi_lte_dl_pipeline **out)
+{
+    if (!h_unit_allocs) return MI_LTE_ERR_INVALID_ARG;
+    return mi_lte_dl_pipeline_create_multi(&device, 1, cfg, N_pdcch_symbs, h_unit_allocs, n_alloc_per_unit, 0, chunk_units, n_lanes, out);
+}
+
 uint32_t    mi_lte_dl_pipeline_out_stride(const mi_lte_dl_pipeline *p) { return p ? p->out_stride : 0; }
 size_t      mi_lte_dl_pipeline_unit_samples(const mi_lte_dl_pipeline *p) { return p ? p->unit_samples : 0; }
+uint32_t    mi_lte_dl_pipeline_n_devices(const mi_lte_dl_pipeline *p) { return p ? (uint32_t)p->devs.size() : 0; }
 const char *mi_lte_dl_pipeline_last_error(const mi_lte_dl_pipeline *p)
 {
     if (!p) return "null pipeline";
-    if (!p->err.empty()) return p->err.c_str();
-    for (const Lane &l : p->lanes)
-        if (l.ctx && *mi_lte_last_error(l.ctx)) return mi_lte_last_error(l.ctx);
-    return "";
+    return p->err.c_str();
 }
 
 // h_iq: n_units units of unit_samples int8 I,Q pairs back to back; h_out_packed: [n_units * n_alloc][out_stride]; h_status likewise.
-// The three host arrays should be pinned (mi_lte_host_alloc): with pageable memory the copies fall back to the driver's staged path and
+// The host arrays should be pinned (mi_lte_host_alloc): with pageable memory the copies fall back to the driver's staged path and
 // stop overlapping.  Returns when every result is in host memory.
 int mi_lte_dl_pipeline_run(mi_lte_dl_pipeline *p, const int8_t *h_iq, const uint32_t *h_subfr_num, const uint32_t *h_n_id_cell, uint32_t n_units,
                            uint8_t *h_out_packed, int32_t *h_status)
 {
     if (!p || !h_iq || !h_subfr_num || !h_n_id_cell || !h_out_packed || !h_status || n_units == 0) return MI_LTE_ERR_INVALID_ARG;
-    if (hipSetDevice(p->device) != hipSuccess) return MI_LTE_ERR_HIP;
-    const size_t unit_bytes = p->unit_samples * 2, al_per_chunk = (size_t)p->chunk * p->n_alloc;
-    uint32_t c = 0;
-    for (uint32_t u0 = 0; u0 < n_units; u0 += p->chunk, c++) {
-        Lane          &l = p->lanes[c % p->lanes.size()];
-        const uint32_t n = std::min(p->chunk, n_units - u0);
-        hipStream_t    st = (hipStream_t)mi_lte_stream(l.ctx);
-        MI_HIP_CHECK(l.ctx, hipMemcpyAsync(l.d_iq, h_iq + (size_t)u0 * unit_bytes, (size_t)n * unit_bytes, hipMemcpyHostToDevice, st));
-        MI_HIP_CHECK(l.ctx, hipMemcpyAsync(l.d_sf, h_subfr_num + u0, sizeof(uint32_t) * n, hipMemcpyHostToDevice, st));
-        MI_HIP_CHECK(l.ctx, hipMemcpyAsync(l.d_cell, h_n_id_cell + u0, sizeof(uint32_t) * n, hipMemcpyHostToDevice, st));
-        int rc = mi_lte_dl_frontend_batch(l.ctx, &p->cfg, l.d_iq, nullptr, l.d_start, l.d_sf, l.d_cell, n, l.d_sub);
-        // a ragged last chunk: the plan covers a whole chunk, the units past the end decode whatever an earlier chunk left in the lane's
-        // buffers and their results are not copied back
-        if (rc == MI_LTE_OK) rc = mi_lte_pdsch_decode_run(l.ctx, l.plan, l.d_sub, l.d_sf, l.d_cell, l.d_out, l.d_st);
-        if (rc != MI_LTE_OK) { p->err = mi_lte_last_error(l.ctx); return rc; }
-        const size_t n_al = (size_t)n * p->n_alloc;
-        MI_HIP_CHECK(l.ctx, hipMemcpyAsync(h_out_packed + (size_t)c * al_per_chunk * p->out_stride, l.d_out, n_al * p->out_stride, hipMemcpyDeviceToHost, st));
-        MI_HIP_CHECK(l.ctx, hipMemcpyAsync(h_status + (size_t)c * al_per_chunk, l.d_st, n_al * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    }
-    for (Lane &l : p->lanes) {
-        int rc = mi_lte_sync(l.ctx);
-        if (rc != MI_LTE_OK) return rc;
+    if (p->tmpl.empty()) { p->err = "the pipeline was created without an allocation template: use mi_lte_dl_pipeline_run_units"; return MI_LTE_ERR_INVALID_ARG; }
+    Job job;
+    job.h_iq = h_iq; job.h_sf = h_subfr_num; job.h_cell = h_n_id_cell; job.n_units = n_units; job.h_out = h_out_packed; job.h_status = h_status;
+    return run_job(p, job);
+}
+
+static int check_lists(mi_lte_dl_pipeline *p, const mi_lte_pdsch_alloc *h_allocs, const uint32_t *h_first, uint32_t n_units)
+{
+    for (uint32_t u = 0; u < n_units; u++) {
+        if (h_first[u + 1] < h_first[u] || h_first[u + 1] - h_first[u] > p->max_alloc_per_unit) { p->err = "allocation list: not sorted by unit, or more allocations in a unit than the pipeline was created for"; return MI_LTE_ERR_INVALID_ARG; }
+        for (uint32_t a = h_first[u]; a < h_first[u + 1]; a++)
+            if (h_allocs[a].unit != u) { p->err = "allocation list: allocs[h_first[u] .. h_first[u+1]) must carry unit == u"; return MI_LTE_ERR_INVALID_ARG; }
     }
     return MI_LTE_OK;
+}
+
+int mi_lte_dl_pipeline_run_units(mi_lte_dl_pipeline *p, const int8_t *h_iq, const uint32_t *h_subfr_num, const uint32_t *h_n_id_cell, uint32_t n_units,
+                                 const mi_lte_pdsch_alloc *h_allocs, const uint32_t *h_first, uint32_t N_pdcch_symbs, uint8_t *h_out_packed, int32_t *h_status)
+{
+    if (!p || !h_iq || !h_subfr_num || !h_n_id_cell || !h_allocs || !h_first || !h_out_packed || !h_status || n_units == 0 || N_pdcch_symbs < 1 || N_pdcch_symbs > 4)
+        return MI_LTE_ERR_INVALID_ARG;
+    const int rc = check_lists(p, h_allocs, h_first, n_units);
+    if (rc != MI_LTE_OK) return rc;
+    Job job;
+    job.h_iq = h_iq; job.h_sf = h_subfr_num; job.h_cell = h_n_id_cell; job.n_units = n_units; job.h_allocs = h_allocs; job.h_first = h_first; job.cfi = N_pdcch_symbs;
+    job.h_out = h_out_packed; job.h_status = h_status;
+    return run_job(p, job);
+}
+
+int mi_lte_dl_pipeline_run_capture(mi_lte_dl_pipeline *p, const int8_t *h_capture, uint64_t n_samples, uint64_t first_subframe_start, uint32_t n_subframes,
+                                   uint32_t first_subfr_num, uint32_t N_id_cell, const mi_lte_pdsch_alloc *h_allocs, const uint32_t *h_first, uint32_t N_pdcch_symbs,
+                                   uint8_t *h_out_packed, int32_t *h_status)
+{
+    if (!p || !h_capture || !h_allocs || !h_first || !h_out_packed || !h_status || n_subframes == 0 || N_pdcch_symbs < 1 || N_pdcch_symbs > 4 || N_id_cell > 503)
+        return MI_LTE_ERR_INVALID_ARG;
+    if (first_subframe_start + (uint64_t)n_subframes * p->sf_samples + p->look_samples > n_samples) {
+        p->err = "capture too short: the last subframe needs its two look-ahead symbols";
+        return MI_LTE_ERR_INVALID_ARG;
+    }
+    const int rc = check_lists(p, h_allocs, h_first, n_subframes);
+    if (rc != MI_LTE_OK) return rc;
+    std::vector<uint32_t> sf(n_subframes), cell(n_subframes, N_id_cell);
+    for (uint32_t u = 0; u < n_subframes; u++) sf[u] = (first_subfr_num + u) % 10;
+    Job job;
+    job.h_iq = h_capture + first_subframe_start * 2; job.capture = true; job.h_sf = sf.data(); job.h_cell = cell.data(); job.n_units = n_subframes;
+    job.h_allocs = h_allocs; job.h_first = h_first; job.cfi = N_pdcch_symbs; job.h_out = h_out_packed; job.h_status = h_status;
+    return run_job(p, job);
 }
 
 } // extern "C"

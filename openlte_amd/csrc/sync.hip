@@ -184,6 +184,31 @@ int fft_and_corr(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const void *a, const
     return MI_LTE_OK;
 }
 
+// The scanner's carrier-frequency correction (LTE_fdd_dl_file_scan/src/LTE_fdd_dl_fs_samp_buf.cc:696-713), in place on planar float
+// samples: sample i is multiplied by exp(-j * arg), arg = (i+1)*f*2*M_PI/fs evaluated the way the C++ expression is typed -- (i+1)
+// converted to float, float product with f, float x 2, then double x M_PI / fs, rounded to float for cosf / sinf.
+__global__ __launch_bounds__(256) void k_freq_shift(float *__restrict__ si, float *__restrict__ sq, uint64_t first, uint64_t n, float f_off, uint32_t fs)
+{
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t i   = (uint32_t)(first + k);
+        const float    t   = ((float)(i + 1u) * f_off) * 2.0f;
+        const float    arg = (float)((double)t * M_PI / (double)fs);
+        const float    cr = cosf(arg), ci = sinf(arg);
+        const float    a = si[k], b = sq[k];
+        si[k] = a * cr + b * ci;
+        sq[k] = b * cr - a * ci;
+    }
+}
+// int8 I,Q interleaved (the capture file format) -> planar float, what the reference's callers do on the host (:657-694)
+__global__ __launch_bounds__(256) void k_i8_to_planar(const int8_t *__restrict__ iq, uint64_t n, float *__restrict__ si, float *__restrict__ sq)
+{
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        const char2 v = reinterpret_cast<const char2 *>(iq)[k];
+        si[k] = (float)v.x;
+        sq[k] = (float)v.y;
+    }
+}
+
 inline float mag(float2 c) { return (float)sqrt(c.x * c.x + c.y * c.y); } // abs_corr = sqrt(re*re + im*im): float expression, double sqrt
 
 } // namespace
@@ -372,6 +397,30 @@ int mi_lte_find_sss_run(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const void *d
                 break;
             }
     ctx->last_kernels = "k_sync_fft:1,k_seq_corr:1";
+    return MI_LTE_OK;
+}
+
+int mi_lte_freq_shift_run(mi_lte_ctx *ctx, float *d_i_samps, float *d_q_samps, uint64_t first_index, uint64_t n_samples, float freq_offset, uint32_t fs)
+{
+    if (!ctx || !d_i_samps || !d_q_samps || fs == 0) return MI_LTE_ERR_INVALID_ARG;
+    if (n_samples == 0) return MI_LTE_OK;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n_samples + 255) / 256, 256 * 32);
+    MI_LAUNCH(ctx, "k_freq_shift", k_freq_shift, dim3(grid), dim3(256), 0, d_i_samps, d_q_samps, first_index, n_samples, freq_offset, fs);
+    MI_HIP_CHECK(ctx, hipGetLastError());
+    ctx->last_kernels = "k_freq_shift:1";
+    return MI_LTE_OK;
+}
+
+int mi_lte_iq_i8_to_planar(mi_lte_ctx *ctx, const int8_t *d_iq, uint64_t n_samples, float *d_i_samps, float *d_q_samps)
+{
+    if (!ctx || !d_iq || !d_i_samps || !d_q_samps) return MI_LTE_ERR_INVALID_ARG;
+    if (n_samples == 0) return MI_LTE_OK;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n_samples + 255) / 256, 256 * 32);
+    MI_LAUNCH(ctx, "k_i8_to_planar", k_i8_to_planar, dim3(grid), dim3(256), 0, d_iq, n_samples, d_i_samps, d_q_samps);
+    MI_HIP_CHECK(ctx, hipGetLastError());
+    ctx->last_kernels = "k_i8_to_planar:1";
     return MI_LTE_OK;
 }
 

@@ -36,13 +36,14 @@ class PrachCfg(C.Structure):
 
 class PdschAlloc(C.Structure):
     """mi_lte_pdsch_alloc"""
-    _fields_ = [(n, C.c_uint32) for n in ("unit", "mod_type", "tbs", "rv_idx", "tx_mode", "rnti", "N_prb", "reserved")] + \
+    _fields_ = [(n, C.c_uint32) for n in ("unit", "mod_type", "tbs", "rv_idx", "tx_mode", "rnti", "N_prb", "n_pdcch_symbs")] + \
                [("prb", (C.c_uint8 * 112) * 2)]
 
 
-def make_alloc(unit, mod_type, tbs, prbs, rnti, rv_idx=0, tx_mode=1, prbs_slot1=None):
+def make_alloc(unit, mod_type, tbs, prbs, rnti, rv_idx=0, tx_mode=1, prbs_slot1=None, n_pdcch_symbs=0):
     a = PdschAlloc()
     a.unit, a.mod_type, a.tbs, a.rv_idx, a.tx_mode, a.rnti, a.N_prb = unit, mod_type, tbs, rv_idx, tx_mode, rnti, len(prbs)
+    a.n_pdcch_symbs = n_pdcch_symbs
     for i, p in enumerate(prbs):
         a.prb[0][i] = p
         a.prb[1][i] = (prbs_slot1 or prbs)[i]
@@ -123,7 +124,18 @@ def load_library():
     L.mi_lte_host_alloc.argtypes = [sz]
     L.mi_lte_host_alloc.restype = vp
     L.mi_lte_host_free.argtypes = [vp]
+    L.mi_lte_pdsch_plan_create_dynamic.argtypes = [vp, C.POINTER(DlCfg), u32, sz, C.POINTER(vp)]
+    L.mi_lte_pdsch_plan_assign.argtypes = [vp, vp, u32, vp, u32]
+    L.mi_lte_pdsch_plan_n_alloc.argtypes = [vp]
+    L.mi_lte_pdsch_plan_n_alloc.restype = u32
+    L.mi_lte_iq_i8_to_planar.argtypes = [vp, vp, C.c_uint64, vp, vp]
+    L.mi_lte_freq_shift_run.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_float, u32]
     L.mi_lte_dl_pipeline_create.argtypes = [C.c_int, C.POINTER(DlCfg), u32, vp, u32, u32, u32, C.POINTER(vp)]
+    L.mi_lte_dl_pipeline_create_multi.argtypes = [C.POINTER(C.c_int), u32, C.POINTER(DlCfg), u32, vp, u32, sz, u32, u32, C.POINTER(vp)]
+    L.mi_lte_dl_pipeline_n_devices.argtypes = [vp]
+    L.mi_lte_dl_pipeline_n_devices.restype = u32
+    L.mi_lte_dl_pipeline_run_units.argtypes = [vp, vp, vp, vp, u32, vp, vp, u32, vp, vp]
+    L.mi_lte_dl_pipeline_run_capture.argtypes = [vp, vp, C.c_uint64, C.c_uint64, u32, u32, u32, vp, vp, u32, vp, vp]
     L.mi_lte_dl_pipeline_destroy.argtypes = [vp]
     L.mi_lte_dl_pipeline_out_stride.argtypes = [vp]
     L.mi_lte_dl_pipeline_out_stride.restype = u32
@@ -210,17 +222,30 @@ class DeviceBuffer:
 
 
 class PdschPlan:
-    """mi_lte_pdsch_plan: device copy of an allocation list, grouped by code-block size."""
+    """mi_lte_pdsch_plan: device copy of an allocation list, grouped by code-block size.  allocs=None: a dynamic plan of the given
+    capacity (mi_lte_pdsch_plan_create_dynamic), filled and re-filled by assign()."""
 
-    def __init__(self, ctx, cfg, n_pdcch_symbs, allocs):
-        self.ctx, self.n_alloc = ctx, len(allocs)
-        arr = (PdschAlloc * len(allocs))(*allocs)
+    def __init__(self, ctx, cfg, n_pdcch_symbs, allocs, max_alloc=0, max_soft_bytes=0):
+        self.ctx = ctx
         h = C.c_void_p()
-        ctx._check(ctx.L.mi_lte_pdsch_plan_create(ctx.h, C.byref(cfg), n_pdcch_symbs, C.cast(arr, C.c_void_p), len(allocs),
-                                                  C.byref(h)))
-        self.h = h
+        if allocs is None:
+            ctx._check(ctx.L.mi_lte_pdsch_plan_create_dynamic(ctx.h, C.byref(cfg), max_alloc, max_soft_bytes, C.byref(h)))
+            self.h, self.n_alloc, self.tbs = h, 0, []
+        else:
+            self.n_alloc = len(allocs)
+            arr = (PdschAlloc * len(allocs))(*allocs)
+            ctx._check(ctx.L.mi_lte_pdsch_plan_create(ctx.h, C.byref(cfg), n_pdcch_symbs, C.cast(arr, C.c_void_p), len(allocs),
+                                                      C.byref(h)))
+            self.h = h
+            self.tbs = [a.tbs for a in allocs]
         self.out_stride = ctx.L.mi_lte_pdsch_plan_out_stride(h)
-        self.tbs = [a.tbs for a in allocs]
+
+    def assign(self, n_pdcch_symbs, allocs):
+        """Re-plan a dynamic plan (no allocation, no wait); allocations may carry their own n_pdcch_symbs."""
+        arr = (PdschAlloc * len(allocs))(*allocs)
+        self.ctx._check(self.ctx.L.mi_lte_pdsch_plan_assign(self.ctx.h, self.h, n_pdcch_symbs, C.cast(arr, C.c_void_p), len(allocs)))
+        self.n_alloc, self.tbs = len(allocs), [a.tbs for a in allocs]
+        self.out_stride = self.ctx.L.mi_lte_pdsch_plan_out_stride(self.h)
 
     def set_decoder(self, mode, n_iter=8, qpp_spec=0):
         """TURBO_REF (default, the reference's decoder) or TURBO_BCJR (max-log-MAP, n_iter iterations)."""
@@ -291,17 +316,46 @@ class HostBuffer:
 class DlPipeline:
     """mi_lte_dl_pipeline: whole-chain batches from host buffers, chunks overlapped on several lanes."""
 
-    def __init__(self, device, cfg, n_pdcch_symbs, unit_allocs, chunk_units, n_lanes=3):
+    def __init__(self, device, cfg, n_pdcch_symbs, unit_allocs, chunk_units, n_lanes=3, max_alloc_per_unit=0, max_soft_bytes_per_unit=0):
+        """device: one ordinal or a list of them (chunk c of a run goes to devices[c % len]); unit_allocs: the allocation template every
+        unit carries, or None for per-unit lists only (then max_alloc_per_unit bounds a unit's list)."""
         self.L = load_library()
-        arr = (PdschAlloc * len(unit_allocs))(*unit_allocs)
+        devs = list(device) if isinstance(device, (list, tuple)) else [device]
+        darr = (C.c_int * len(devs))(*devs)
         h = C.c_void_p()
-        rc = self.L.mi_lte_dl_pipeline_create(device, C.byref(cfg), n_pdcch_symbs, C.cast(arr, C.c_void_p), len(unit_allocs), chunk_units, n_lanes, C.byref(h))
+        if unit_allocs is not None:
+            arr = (PdschAlloc * len(unit_allocs))(*unit_allocs)
+            rc = self.L.mi_lte_dl_pipeline_create_multi(darr, len(devs), C.byref(cfg), n_pdcch_symbs, C.cast(arr, C.c_void_p), len(unit_allocs),
+                                                        max_soft_bytes_per_unit, chunk_units, n_lanes, C.byref(h))
+        else:
+            rc = self.L.mi_lte_dl_pipeline_create_multi(darr, len(devs), C.byref(cfg), n_pdcch_symbs, None, max_alloc_per_unit, max_soft_bytes_per_unit,
+                                                        chunk_units, n_lanes, C.byref(h))
         if rc != 0:
-            raise MiLteError("mi_lte_dl_pipeline_create failed: %d" % rc)
-        self.h, self.n_alloc = h, len(unit_allocs)
+            raise MiLteError("mi_lte_dl_pipeline_create_multi failed: %d" % rc)
+        self.h, self.n_alloc = h, len(unit_allocs) if unit_allocs is not None else 0
         self.out_stride = self.L.mi_lte_dl_pipeline_out_stride(h)
         self.unit_samples = self.L.mi_lte_dl_pipeline_unit_samples(h)
-        self.tbs = [a.tbs for a in unit_allocs]
+        self.n_devices = self.L.mi_lte_dl_pipeline_n_devices(h)
+        self.tbs = [a.tbs for a in unit_allocs] if unit_allocs is not None else []
+
+    def _err(self, what, rc):
+        raise MiLteError("%s failed: %d (%s)" % (what, rc, self.L.mi_lte_dl_pipeline_last_error(self.h).decode()))
+
+    def run_units(self, h_iq, h_sf, h_cell, n_units, allocs, first, n_pdcch_symbs, h_out, h_status):
+        """Per-unit allocation lists: allocs (ctypes array of PdschAlloc, sorted by unit), first uint32 [n_units + 1]."""
+        first = np.ascontiguousarray(first, np.uint32)
+        rc = self.L.mi_lte_dl_pipeline_run_units(self.h, h_iq.ctypes.data, h_sf.ctypes.data, h_cell.ctypes.data, n_units, C.cast(allocs, C.c_void_p),
+                                                 first.ctypes.data, n_pdcch_symbs, h_out.ctypes.data, h_status.ctypes.data)
+        if rc != 0:
+            self._err("mi_lte_dl_pipeline_run_units", rc)
+
+    def run_capture(self, h_capture, first_start, n_subframes, first_sf, cell, allocs, first, n_pdcch_symbs, h_out, h_status):
+        """One contiguous int8 capture [n_samples, 2], split on subframe boundaries with the look-ahead halo."""
+        first = np.ascontiguousarray(first, np.uint32)
+        rc = self.L.mi_lte_dl_pipeline_run_capture(self.h, h_capture.ctypes.data, h_capture.shape[0], first_start, n_subframes, first_sf, cell,
+                                                   C.cast(allocs, C.c_void_p), first.ctypes.data, n_pdcch_symbs, h_out.ctypes.data, h_status.ctypes.data)
+        if rc != 0:
+            self._err("mi_lte_dl_pipeline_run_capture", rc)
 
     def run(self, h_iq, h_sf, h_cell, n_units, h_out, h_status):
         """h_iq int8 [n_units, unit_samples, 2], h_sf / h_cell uint32 [n_units], h_out uint8 [n_units * n_alloc, out_stride], h_status int32:
@@ -619,6 +673,16 @@ class Context:
     # ---- PDSCH ------------------------------------------------------------------------------
     def pdsch_plan(self, cfg, n_pdcch_symbs, allocs):
         return PdschPlan(self, cfg, n_pdcch_symbs, allocs)
+
+    def pdsch_plan_dynamic(self, cfg, max_alloc, max_soft_bytes):
+        return PdschPlan(self, cfg, 0, None, max_alloc, max_soft_bytes)
+
+    def iq_to_planar(self, d_iq, n_samples, d_i, d_q):
+        self._check(self.L.mi_lte_iq_i8_to_planar(self.h, d_iq.ptr, n_samples, d_i.ptr, d_q.ptr))
+
+    def freq_shift(self, d_i, d_q, first_index, n_samples, freq_offset, fs):
+        """LTE_fdd_dl_fs_samp_buf::freq_shift on planar float samples in HBM, in place."""
+        self._check(self.L.mi_lte_freq_shift_run(self.h, d_i.ptr, d_q.ptr, first_index, n_samples, float(freq_offset), int(fs)))
 
     # ---- turbo -------------------------------------------------------------------------------
     def turbo_decode_dev(self, d_soft, soft_type, K, n_cb, d_out, mode=TURBO_REF, n_iter=8, qpp_spec=False):

@@ -4,7 +4,9 @@
 // LTE_fdd_dl_file_gen for the drop-in scan test (BASELINE config 1 / SURVEY 8d W1) and, like that tool, is nothing
 // but a caller of the reference's liblte_phy / liblte_rrc TX API -- linked against the unmodified reference objects.
 //
-//   capture_gen <out.bin> <N_rb_dl: 6|15|25|50|75|100> <N_id_cell> <N_frames>
+//   capture_gen <out.bin> <N_rb_dl: 6|15|25|50|75|100> <N_id_cell> <N_frames> [carrier offset in Hz] [leading samples]
+// (a carrier offset rotates sample k of the file by exp(+j*2*pi*f*k/fs) before the int8 conversion: what the scanner's coarse timing measures
+// and its freq_shift takes out again, LTE_fdd_dl_fs_samp_buf.cc:239, :696-713; leading samples: the file starts that many samples before a frame)
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -47,6 +49,8 @@ int main(int argc, char **argv)
     Cell c;
     c.N_rb_dl = atoi(argv[2]); c.N_id_cell = atoi(argv[3]); c.N_ant = 1;
     const uint32 n_frames = atoi(argv[4]);
+    const double cfo_hz   = argc > 5 ? atof(argv[5]) : 0.0;
+    const uint32 lead     = argc > 6 ? atoi(argv[6]) : 0;
     LIBLTE_PHY_FS_ENUM       fs;
     LIBLTE_RRC_DL_BANDWIDTH_ENUM bw;
     switch (c.N_rb_dl) {
@@ -97,6 +101,9 @@ int main(int argc, char **argv)
     float *ti = (float *)calloc(n_sf + 64, sizeof(float)), *tq = (float *)calloc(n_sf + 64, sizeof(float));
     FILE  *f  = fopen(argv[1], "wb");
     if (!f) return 4;
+    for (uint32 k = 0; k < lead; k++) { signed char z[2] = {0, 0}; fwrite(z, 1, 2, f); }
+    unsigned long long k_abs = lead;
+    const double       w     = 2.0 * M_PI * cfo_hz / (double)c.phy->fs;
     memset(&phich, 0, sizeof(phich)); // no HARQ indicators
     memset(&pcfich, 0, sizeof(pcfich));
     pcfich.cfi = 2;                   // the caller chooses the control format indicator (liblte_phy.cc:4171)
@@ -135,8 +142,14 @@ int main(int argc, char **argv)
                     fprintf(stderr, "sfn %u sf %u: %u bits tbs %u N_prb %u -> pdcch %d pdsch %d\n", sfn, sf, pd.alloc[0].msg[0].N_bits, pd.alloc[0].tbs, pd.alloc[0].N_prb, e1, e2);
             }
             liblte_phy_create_dl_subframe(c.phy, &sfm, 0, ti, tq);
-            for (uint32 k = 0; k < n_sf; k++) {
-                signed char v[2] = {(signed char)ti[k], (signed char)tq[k]};
+            for (uint32 k = 0; k < n_sf; k++, k_abs++) {
+                float a = ti[k], b = tq[k];
+                if (cfo_hz != 0.0) {
+                    const double cr = cos(w * (double)k_abs), ci = sin(w * (double)k_abs);
+                    a = (float)(ti[k] * cr - tq[k] * ci);
+                    b = (float)(tq[k] * cr + ti[k] * ci);
+                }
+                signed char v[2] = {(signed char)a, (signed char)b};
                 fwrite(v, 1, 2, f);
             }
         }

@@ -270,3 +270,26 @@ def test_cell_scan_matches_reference_output(tmp_path, n_rb, cell, frames, fs):
         with open(os.path.join(ROOT, "gpurun_out", "scan_timing_%drb.txt" % n_rb), "w") as f:
             f.write("scan_gpu %s" % got.stderr)
             f.write("scan_cpu %s" % cpu.stderr)
+
+
+@pytest.mark.parametrize("n_rb,cell,frames,fs,cfo,lead", [(6, 17, 30, "1.92", 731, 311), (25, 301, 24, "7.68", -1180, 1000), (100, 77, 12, "30.72", 2350, 4321)])
+def test_batch_scanner_with_carrier_offset_matches_reference_output(tmp_path, n_rb, cell, frames, fs, cfo, lead):
+    """The same scan on the library's BATCH entry points (shim/scan_batch.cc: no liblte_phy object linked, one launch per stage for all
+    subframes of a phase, the capture resident in HBM) over captures with a carrier offset and a frame that does not start at sample 0:
+    the frequency correction between the synchronisation stages (LTE_fdd_dl_fs_samp_buf.cc:696-713) runs on the device
+    (mi_lte_freq_shift_run).  Its report must equal what the all-reference per-call scanner prints for the same file."""
+    build = os.path.join(ROOT, "shim", "_build")
+    gen, scan_batch, scan_cpu = (os.path.join(build, n) for n in ("capture_gen", "scan_batch", "scan_cpu"))
+    if not (os.path.exists(gen) and os.path.exists(scan_batch) and os.path.exists(scan_cpu)):
+        pytest.skip("shim/_build/capture_gen / scan_batch / scan_cpu not built (need the reference tree at build time)")
+    cap = os.path.join(str(tmp_path), "capture.bin")
+    subprocess.run([gen, cap, str(n_rb), str(cell), str(frames), str(cfo), str(lead)], check=True, timeout=600)
+    want = subprocess.run([scan_cpu, cap, fs], capture_output=True, text=True, timeout=900)
+    assert want.returncode == 0 and "SIB1:" in want.stdout, want.stdout  # the reference finds the cell through the offset
+    got = subprocess.run([scan_batch, cap, fs], capture_output=True, text=True, timeout=900)
+    assert got.returncode == 0, got.stdout + got.stderr
+    assert got.stdout == want.stdout
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "scan_batch_timing_%drb.txt" % n_rb), "w") as f:
+        f.write("scan_batch %s" % got.stderr)
+        f.write("scan_cpu   %s" % want.stderr)

@@ -423,7 +423,10 @@ class ChainWorkload:
         own["k_cb_desc"] = n * 9 * 80  # per code block: its allocation's fields in, a 32-byte descriptor out
         if bc:
             own.pop("k_bcjr_prep", None)  # (the stand-alone decoder's first kernel; the chain's is k_rm_bcjr_prep)
-        return {"stages": {"frontend": (n * 339040, ["k_dl_fft", "k_dl_ce"]),
+        # front end: int8 IQ in, 14 symbol rows out, and the estimate in the form this run hands to the demodulator: 14 rows of re / im
+        # (339 040 B per subframe) or, compact, five magnitude + five phase rows (252 640 B)
+        fe = 70240 + 14 * 1200 * 8 + (10 * 1200 * 4 if CE_MODE == "compact" else 14 * 1200 * 8)
+        return {"stages": {"frontend": (n * fe, ["k_dl_fft", "k_dl_ce"]),
                            "demod": (n * res * (16 + 6), ["k_pdsch_demod"]),
                            "turbo": (n * (8 * _turbo_alg_bytes(3264) + _turbo_alg_bytes(1088)), tk)},
                 "own_io": own}
@@ -508,11 +511,18 @@ class ChainWorkload:
 class FrontendWorkload:
     """BASELINE config 2 / SURVEY 8d W2: 20 MHz OFDM demod + CRS channel estimate, 10k subframe units."""
     name = "frontend"
-    metric = "DL subframes/sec @20MHz 100RB, OFDM demod + CRS channel estimate only (SURVEY 8d W2)"
     unit = "subframes/s"
     dtype = "i8 IQ in, f32 FFT/CE"
-    alg_bytes_per_unit = 339040
+    N_ANT = 1
     dominant = "k_dl_ce"
+
+    @property
+    def metric(self):
+        return "DL subframes/sec @20MHz 100RB, OFDM demod + CRS channel estimate only, %d antenna port(s) (SURVEY 8d W2)" % self.N_ANT
+
+    @property
+    def alg_bytes_per_unit(self):  # int8 IQ in, 14 symbol rows + 14 estimate rows per port out
+        return 70240 + 14 * 1200 * 8 * (1 + self.N_ANT)
 
     def __init__(self, ctx, n_units, rank):
         import numpy as np
@@ -521,21 +531,21 @@ class FrontendWorkload:
         import lte_testdata as td
         self.ctx, self.np = ctx, np
         self.n = n_units or 10000
-        self.cfg = m.DlCfg(2048, 100, 1, 0)
+        self.cfg = m.DlCfg(2048, 100, self.N_ANT, 0)  # (the capture is a single-port cell's: the second port's estimator runs on noise, same work)
         U = 64
         sfs = (np.arange(U) % 10).astype(np.uint32)
         cells = ((np.arange(U) * 37 + rank) % 504).astype(np.uint32)
         allocs = []
         for u in range(U):
             allocs += td.w4_allocs(u)
-        iq, _ = synth.dl_units(self.cfg, sfs, cells, allocs, 9, snr_db=30.0, max_delay=8, seed=77 + rank)
+        iq, _ = synth.dl_units(m.DlCfg(2048, 100, 1, 0), sfs, cells, allocs, 9, snr_db=30.0, max_delay=8, seed=77 + rank)
         self.uniq = (iq, sfs, cells)
         idx = np.arange(self.n) % U
         ul = iq.shape[1]
         self.d_iq = ctx.to_device(iq[idx].reshape(-1, 2))
         self.d_start = ctx.to_device((np.arange(self.n) * ul).astype(np.uint64))
         self.d_sf, self.d_cell = ctx.to_device(sfs[idx]), ctx.to_device(cells[idx])
-        self.d_sub = ctx.alloc(self.n * ctx.subframe_floats(1) * 4)
+        self.d_sub = ctx.alloc(self.n * ctx.subframe_floats(self.N_ANT) * 4)
 
     def step(self):
         self.ctx.dl_frontend_dev(self.cfg, self.d_iq, None, self.d_start, self.d_sf, self.d_cell, self.n, self.d_sub)
@@ -547,13 +557,13 @@ class FrontendWorkload:
         return 1.0
 
     def accounting(self):
-        n = self.n
-        return {"stages": {"frontend": (n * 339040, ["k_dl_fft", "k_dl_ce"])},
-                "own_io": {"k_dl_fft": n * (15 * 2048 * 2 + 15 * 1200 * 8), "k_dl_ce": n * (5 * 200 * 8 + 14 * 1200 * 8)}}
+        n, p = self.n, self.N_ANT
+        return {"stages": {"frontend": (n * self.alg_bytes_per_unit, ["k_dl_fft", "k_dl_ce"])},
+                "own_io": {"k_dl_fft": n * (15 * 2048 * 2 + 15 * 1200 * 8), "k_dl_ce": n * p * (5 * 200 * 8 + 14 * 1200 * 8)}}
 
     def config(self, world):
-        return {"workload": "W2 front end: 20 MHz/100 RB, %d subframe units per GPU, int8 IQ in HBM" % self.n,
-                "subframes_per_gpu": self.n, "N_ant": 1, "sharding": "subframes over %d GPU(s), no collective" % world}
+        return {"workload": "W2 front end: 20 MHz/100 RB, %d subframe units per GPU, %d antenna port(s), int8 IQ in HBM" % (self.n, self.N_ANT),
+                "subframes_per_gpu": self.n, "N_ant": self.N_ANT, "sharding": "subframes over %d GPU(s), no collective" % world}
 
     def cpu_baseline(self, budget_s=10.0):
         np = self.np
@@ -565,11 +575,18 @@ class FrontendWorkload:
         phy, sfp = R.ref_phy_new(4, 0, 1, 100), R.ref_subframe_new()
         re = np.ascontiguousarray(iq[0, :, 0].astype(np.float32))
         im = np.ascontiguousarray(iq[0, :, 1].astype(np.float32))
-        t = R.ref_time_get_dl_subframe_and_ce(phy, re, im, 0, 0, int(cells[0]), 1, sfp, 50)
+        t = R.ref_time_get_dl_subframe_and_ce(phy, re, im, 0, 0, int(cells[0]), self.N_ANT, sfp, 50)
         reps = int(max(100, budget_s / (t / 50)))
-        t = R.ref_time_get_dl_subframe_and_ce(phy, re, im, 0, 0, int(cells[0]), 1, sfp, reps)
+        t = R.ref_time_get_dl_subframe_and_ce(phy, re, im, 0, 0, int(cells[0]), self.N_ANT, sfp, reps)
         return {"value": round(reps / t, 2), "unit": self.unit, "cores": 1, "kind": "reference",
-                "sample": "%d calls of liblte_phy_get_dl_subframe_and_ce, 1 thread, %.1f s; FFT = float64 radix-2 stand-in" % (reps, t)}
+                "sample": "%d calls of liblte_phy_get_dl_subframe_and_ce (N_ant = %d), 1 thread, %.1f s; FFT = float64 radix-2 stand-in for FFTW3f "
+                          "(pessimistic: the transform is most of this call)" % (reps, self.N_ANT, t)}
+
+
+class Frontend2Workload(FrontendWorkload):
+    """W2 with two antenna ports: the estimator runs once per port (liblte_phy.cc:5959-6194 loops over p)."""
+    name = "frontend2"
+    N_ANT = 2
 
 
 class UplinkWorkload:
@@ -864,7 +881,7 @@ class MultiStream:
     the lock-step trellis kernel 4+ waves per SIMD (32k subframes), one stream is the fastest."""
 
     def __init__(self, cls, ctxs, n_units, rank):
-        n_units = n_units or {"chain": 65536, "frontend": 10000, "turbo": 65536, "uplink": 16384, "control": 8192, "sync": 32}[cls.name]
+        n_units = n_units or {"chain": 65536, "frontend": 10000, "frontend2": 10000, "turbo": 65536, "uplink": 16384, "control": 8192, "sync": 32}[cls.name]
         per = max(64, (n_units // len(ctxs) + 63) // 64 * 64)
         self.parts = [cls(c, per, rank * 16 + k) for k, c in enumerate(ctxs)]
         self.ctxs = ctxs
@@ -926,7 +943,7 @@ class MultiStream:
         return self.parts[0].cpu_baseline()
 
 
-WORKLOADS = {"turbo": TurboWorkload, "frontend": FrontendWorkload, "chain": ChainWorkload, "uplink": UplinkWorkload, "control": ControlWorkload, "sync": SyncWorkload}
+WORKLOADS = {"turbo": TurboWorkload, "frontend": FrontendWorkload, "frontend2": Frontend2Workload, "chain": ChainWorkload, "uplink": UplinkWorkload, "control": ControlWorkload, "sync": SyncWorkload}
 
 
 def pick_workload(name):
@@ -986,6 +1003,125 @@ def turbo_leg(ctx, decoder, n_cb, steps):
     return out
 
 
+def roofline_of(wl, prof, steps):
+    """The `roofline` object of a run: the kernel with the largest share of the timed region, its STAGE's algorithmic bytes charged once
+    per step and spread over its launches, over its average launch time (HIP events).  Also returns {kernel: ms per step}."""
+    acc = wl.accounting()
+    stage_of = {k: st for st, (_, ks) in acc["stages"].items() for k in ks}
+    dom = max(prof, key=lambda k: prof[k][1])
+    n_launch, tot_ms = prof[dom]
+    lps = max(1, n_launch // steps)
+    st_bytes = acc["stages"][stage_of[dom]][0] if dom in stage_of else wl.alg_bytes_per_unit * wl.units_per_step()
+    avg_ms = tot_ms / n_launch
+    achieved = st_bytes / lps / (avg_ms * 1e-3) / 1e9
+    traffic = None
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % wl.name)))["bytes_per_launch"].get({"k_ul_fft": "k_dl_fft"}.get(dom, dom))
+    except Exception:
+        pass
+    return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": lps, "algorithmic_bytes_per_launch": st_bytes / lps,
+            "stage": stage_of.get(dom, "whole path")}, {k: round(ms / steps, 4) for k, (nl, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1])}
+
+
+def config_leg(cls, ctx, steps, cpu_budget_s):
+    """Another BASELINE config inside the default line (after the timed region, like the turbo legs): the workload at its own default
+    size on the same context, `steps` steps between two synchronisations with the per-launch HIP events on, its own `roofline` and
+    `cpu_baseline` (bounded)."""
+    wl = cls(ctx, 0, 0)
+    wl.step()
+    ctx.sync()
+    ctx.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step()
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_report()
+    ctx.profile(False)
+    roof, kern = roofline_of(wl, prof, steps)
+    out = {"metric": wl.metric, "value": round(wl.units_per_step() * wl.value_per_unit() * steps / dt, 1), "unit": wl.unit, "steps": steps,
+           "ms_per_step": round(dt / steps * 1e3, 4), "config": wl.config(1), "dtype": wl.dtype, "roofline": roof, "kernels_ms_per_step": kern}
+    if hasattr(wl, "extra"):
+        out.update(wl.extra(out["value"]))
+    if cpu_budget_s > 0:
+        cb = wl.cpu_baseline(cpu_budget_s)
+        if cb:
+            out["cpu_baseline"] = cb
+    for name, v in list(vars(wl).items()):  # release the leg's device buffers before the next one
+        if hasattr(v, "free") and name.startswith("d_"):
+            v.free()
+    for name in ("plan", "pplan"):
+        if hasattr(wl, name):
+            getattr(wl, name).close()
+    return out
+
+
+def strong_run(args):
+    """--strong: ONE contiguous host-resident capture through the product's multi-device entry point (mi_lte_dl_pipeline_create_multi +
+    mi_lte_dl_pipeline_run_capture): one process, one host thread per GPU, chunks block-cyclic over the devices, the capture split on
+    subframe boundaries with the look-ahead halo, per-subframe allocation lists, no collective.  Total work is fixed as N grows
+    (`scaling: strong`); PCIe-inclusive by construction (the capture starts in pinned host memory), so this is NOT the headline metric."""
+    import numpy as np
+    import openlte_amd as m
+    from openlte_amd import synth
+    import lte_testdata as td
+    n_dev = m.load_library().mi_lte_device_count()
+    devices = [d % max(1, n_dev) for d in range(args.gpus)] if args.oversubscribe else list(range(args.gpus))
+    if max(devices) >= n_dev:
+        raise SystemExit("bench.py --strong: --gpus %d but only %d HIP device(s) are visible (--oversubscribe maps them modulo, for testing)" % (args.gpus, n_dev))
+    cfg = m.DlCfg(2048, 100, 1, m.IQ_I8 | m.CE_COMPACT)
+    n, U, cell = args.units or 32768, 40, 77
+    sfs = [(3 + u) % 10 for u in range(U)]
+    per_u = [9 if sfs[u] not in (0, 5) else 3 for u in range(U)]  # (subframes 0 / 5: the first PRBs only, clear of the sync signals)
+    # the transmitter takes a fixed number of allocations per unit: synthesise the two kinds of subframes separately, static channel, and lay them end to end
+    full = [u for u in range(U) if per_u[u] == 9]
+    part = [u for u in range(U) if per_u[u] == 3]
+    iq_u = np.zeros((U, synth.unit_len(2048), 2), np.int8)
+    if full:
+        q, _ = synth.dl_units(cfg, [sfs[u] for u in full], [cell] * len(full), [a for k, u in enumerate(full) for a in td.w4_allocs(k)], 9, snr_db=30.0, max_delay=-1, gain=(1.0, 1.0), seed=11)
+        iq_u[full] = q
+    if part:
+        q, _ = synth.dl_units(cfg, [sfs[u] for u in part], [cell] * len(part), [a for k, u in enumerate(part) for a in td.w4_allocs(k)[:3]], 3, snr_db=30.0, max_delay=-1, gain=(1.0, 1.0), seed=12)
+        iq_u[part] = q
+    n = n // U * U
+    h_cap = m.HostBuffer((n * 30720 + 4400, 2), np.int8)
+    for u in range(U):
+        h_cap.arr[u * 30720:(u + 1) * 30720] = iq_u[u, :30720]
+    for r in range(1, n // U):
+        h_cap.arr[r * U * 30720:(r + 1) * U * 30720] = h_cap.arr[:U * 30720]
+    h_cap.arr[n * 30720:] = iq_u[0, :4400]  # the next subframe's first symbols (subframe sfs[0] again)
+    first, allocs = [0], []
+    for i in range(n):
+        u = i % U
+        for a in (td.w4_allocs(i) if per_u[u] == 9 else td.w4_allocs(i)[:3]):
+            allocs.append(a)
+        first.append(len(allocs))
+    arr = (m.PdschAlloc * len(allocs))(*allocs)
+    first = np.array(first, np.uint32)
+    pipe = m.DlPipeline(devices, cfg, 2, None, args.chunk, n_lanes=args.lanes, max_alloc_per_unit=9, max_soft_bytes_per_unit=8 * 9984 + 3328)
+    h_out, h_st = m.HostBuffer((len(allocs), pipe.out_stride), np.uint8), m.HostBuffer((len(allocs),), np.int32)
+    for _ in range(max(1, args.warmup)):
+        pipe.run_capture(h_cap.arr, 0, n, sfs[0], cell, arr, first, 2, h_out.arr, h_st.arr)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pipe.run_capture(h_cap.arr, 0, n, sfs[0], cell, arr, first, 2, h_out.arr, h_st.arr)
+    dt = time.perf_counter() - t0
+    ok = int((h_st.arr == 0).sum())
+    print(json.dumps({"metric": "DL subframes/sec @20MHz 100RB 64QAM, full chain from ONE host-resident capture (PCIe-inclusive), strong scaling over the product's "
+                                "multi-device pipeline", "value": round(n * args.steps / dt, 1), "unit": "subframes/s", "n_gpus": len(devices), "steps": args.steps,
+                      "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                      "dtype": ChainWorkload.dtype, "data": "synthetic",
+                      "config": {"workload": "one contiguous int8 capture of %d subframes (%.2f GB, pinned host memory), 9 allocations per subframe (3 in subframes 0 / 5), "
+                                             "mi_lte_dl_pipeline_run_capture: chunks of %d subframes block-cyclic over %d device(s), %d lanes each, look-ahead halo per chunk"
+                                             % (n, h_cap.arr.nbytes / 1e9, args.chunk, len(devices), args.lanes), "devices": devices},
+                      "crc_pass": "%d/%d allocations" % (ok, len(allocs)), "h2d_GBps": round(h_cap.arr.nbytes * args.steps / dt / 1e9, 2),
+                      "note": "PCIe-inclusive and host-driven: not comparable with the device-resident headline value"}))
+    pipe.close()
+    for b in (h_cap, h_out, h_st):
+        b.free()
+
+
 def selftest(args, rank, world, barrier, max_reduce):
     """--workload selftest: the launch / sharding / timing control plane with no GPU work (what tests/test_dist_cpu.py runs through
     `--gpus 2` on CPU).  A step is a host-side walk over this rank's shard of a 1000-unit batch."""
@@ -1025,10 +1161,16 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="time the steps without the per-launch HIP events (no roofline in the line): measures what the events cost")
     ap.add_argument("--no-host-leg", action="store_true", help="chain workload: skip the host-buffer pipeline measurement after the timed region")
     ap.add_argument("--no-turbo-leg", action="store_true", help="chain workload: skip the short W3 turbo-decode legs after the timed region")
+    ap.add_argument("--strong", action="store_true", help="one host-resident capture through the multi-device pipeline (one process, a host thread per GPU); strong scaling")
+    ap.add_argument("--oversubscribe", action="store_true", help="--strong: map --gpus N onto the visible devices modulo (testing the multi-device path on one GPU)")
+    ap.add_argument("--chunk", type=int, default=2048, help="--strong: subframes per chunk")
+    ap.add_argument("--lanes", type=int, default=4, help="--strong: lanes per device")
     args = ap.parse_args()
 
     global DECODER, CE_MODE, NO_HOST_LEG
     DECODER, CE_MODE, NO_HOST_LEG = args.decoder, args.ce, args.no_host_leg
+    if args.strong:
+        return strong_run(args)
     maybe_relaunch(args.gpus, sys.argv[1:])
     rank, world, barrier, max_reduce = dist_setup(args.gpus)
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
@@ -1143,6 +1285,13 @@ def main():
                                            "int8 soft values resident in HBM, information Mbit/s",
                                    "bcjr_max_log_map_8_iterations": turbo_leg(ctx, "bcjr", 65536, 3),
                                    "ref_decoder": turbo_leg(ctx, "ref", 65536, 3)}
+        if wl.name == "chain" and DECODER == "ref" and not args.no_turbo_leg and world == 1:
+            # BASELINE.json's other single-GPU configurations, measured in this run after the timed region (each with its own roofline and
+            # a bounded CPU baseline): config 2 (W2 front end, one and two antenna ports) and config 5 (W5 uplink)
+            cpu_s = 0 if args.no_cpu_baseline else 4.0
+            out["other_configs"] = {"W2_frontend_1_port": config_leg(FrontendWorkload, ctx, 10, cpu_s),
+                                    "W2_frontend_2_ports": config_leg(Frontend2Workload, ctx, 10, cpu_s),
+                                    "W5_uplink": config_leg(UplinkWorkload, ctx, 5, cpu_s)}
         if world == 1 and not args.no_cpu_baseline:
             cb = wl.cpu_baseline()
             if cb:

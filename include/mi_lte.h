@@ -574,7 +574,8 @@ int mi_lte_synth_turbo_soft_f32(uint32_t K, uint32_t n, double sigma, uint64_t s
 
 typedef struct {
     double   gain_min, gain_max; /* |h| drawn uniformly per unit                                  */
-    double   max_delay;          /* integer timing offset drawn from 0..max_delay samples          */
+    double   max_delay;          /* integer timing offset drawn from 0..max_delay samples; < 0: a STATIC channel (no random phase, no
+                                    delay, one int8 scale for all units): consecutive units laid end to end are one capture */
     double   snr_db;             /* AWGN relative to the mean signal power; >= 200 disables noise   */
     double   peak;               /* int8 full-scale target for the signal peak (e.g. 100)           */
     uint64_t seed;

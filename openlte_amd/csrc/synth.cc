@@ -231,6 +231,7 @@ int mi_lte_synth_dl_units_i8(const mi_lte_dl_cfg *cfg, uint32_t n_units, const u
     std::vector<float>  g_re(16 * N_sc), g_im(16 * N_sc);
     std::vector<double> xr(N), xi(N), t_re(unit_len + 64), t_im(unit_len + 64);
     const float         r2 = (float)(1 / std::sqrt(2.0));
+    double              scale_all = 1.0;
 
     for (uint32_t u = 0; u < n_units; u++) {
         const uint32_t sf = h_subfr_num[u] % 10, cell = h_n_id_cell[u];
@@ -301,16 +302,31 @@ int mi_lte_synth_dl_units_i8(const mi_lte_dl_cfg *cfg, uint32_t n_units, const u
             if (pos >= unit_len) break;
         }
         // one-tap channel, integer delay, AWGN, int8 quantisation
+        // max_delay < 0: a static channel -- no random phase, no delay, one int8 scale for every unit -- so that consecutive units can be
+        // laid end to end as ONE capture (a unit's look-ahead symbols are then what the next unit starts with)
+        const bool   fixed = chan->max_delay < 0;
         const double gain = chan->gain_min + (chan->gain_max - chan->gain_min) * rng.uniform();
-        const double ph   = 2.0 * M_PI * rng.uniform() - M_PI;
-        const uint32_t dly = (uint32_t)(rng.uniform() * (chan->max_delay + 0.999));
+        const double ph   = fixed ? 0.0 * rng.uniform() : 2.0 * M_PI * rng.uniform() - M_PI;
+        const uint32_t dly = fixed ? (uint32_t)(0.0 * rng.uniform()) : (uint32_t)(rng.uniform() * (chan->max_delay + 0.999));
         double p_sig = 0, peak = 0;
         for (size_t i = 0; i < unit_len; i++) {
             p_sig += t_re[i] * t_re[i] + t_im[i] * t_im[i];
             peak = std::max(peak, std::max(std::fabs(t_re[i]), std::fabs(t_im[i])));
         }
         p_sig /= (double)unit_len;
-        const double scale = (peak > 0 ? chan->peak / peak : 1.0);
+        if (!fixed) scale_all = (peak > 0 ? chan->peak / peak : 1.0);
+        else if (u == 0) {
+            // static: ONE scale whatever the units carry (and whichever call made them): the RMS of a fully loaded symbol of unit-power
+            // resource elements lands at peak / 3.6 -- OFDM's crest factor stays inside int8
+            std::fill(xr.begin(), xr.end(), 0.0);
+            std::fill(xi.begin(), xi.end(), 0.0);
+            for (uint32_t i = 0; i < half; i++) { xr[i + 1] = (i & 1) ? 1.0 : -1.0; xr[N - 1 - i] = (i % 3) ? 1.0 : -1.0; }
+            synth::idft(xr, xi);
+            double pr = 0;
+            for (uint32_t i = 0; i < N; i++) pr += xr[i] * xr[i] + xi[i] * xi[i];
+            scale_all = chan->peak / (3.6 * std::sqrt(pr / N));
+        }
+        const double scale = scale_all;
         const double sigma = chan->snr_db >= 200 ? 0.0 : std::sqrt(p_sig / std::pow(10.0, chan->snr_db / 10.0) / 2.0);
         const double hr = gain * std::cos(ph), hi = gain * std::sin(ph);
         int8_t *o = h_iq + (size_t)u * unit_len * 2;

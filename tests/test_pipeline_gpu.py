@@ -193,7 +193,7 @@ def test_contiguous_capture_split_with_the_look_ahead_halo(ctx):
     allocs = []
     for u in range(n):
         allocs += td.w4_allocs(u)[:4]
-    units, tx = synth.dl_units(cfg, sfs, [cell] * n, allocs, 4, snr_db=30, max_delay=0, gain=(1.0, 1.0), seed=9)
+    units, tx = synth.dl_units(cfg, sfs, [cell] * n, allocs, 4, snr_db=30, max_delay=-1, gain=(1.0, 1.0), seed=9)  # static channel: the units join up
     lead = 777
     cap = np.zeros((lead + n * 30720 + 4400, 2), np.int8)
     for u in range(n):  # subframe u, then (overwritten by the next subframe) its own look-ahead symbols

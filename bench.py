@@ -959,13 +959,15 @@ def turbo_leg(ctx, decoder, n_cb, steps):
     import openlte_amd as m
     from openlte_amd import synth
     K = 6144
-    tx, soft = synth.turbo_soft_blocks(K, 64, flip=0.02, seed=4321, ref_wrap=(decoder != "bcjr"))
+    tx, soft = synth.turbo_soft_blocks(K, 64, flip=0.02, seed=4321, ref_wrap=(decoder not in ("bcjr", "bcjr_early")))
     idx = (np.arange(n_cb) * 7 + np.arange(n_cb) // 64) % 64
     d_in, d_out = ctx.to_device(soft[idx]), ctx.alloc(n_cb * K)
 
     def step():
         if decoder == "bcjr":
             ctx.turbo_decode_dev(d_in, m.SOFT_I8, K, n_cb, d_out, mode=m.TURBO_BCJR, n_iter=8, qpp_spec=True)
+        elif decoder == "bcjr_early":
+            ctx.turbo_decode_dev(d_in, m.SOFT_I8, K, n_cb, d_out, mode=m.TURBO_BCJR_EARLY, n_iter=8, qpp_spec=True)
         else:
             ctx.turbo_decode_dev(d_in, m.SOFT_I8, K, n_cb, d_out)
     step()
@@ -976,6 +978,12 @@ def turbo_leg(ctx, decoder, n_cb, steps):
     ms = ctx.timer_stop()
     got = d_out.download(np.uint8, count=64 * K).reshape(64, K)
     out = {"mbit_per_s": round(n_cb * K * steps / (ms * 1e-3) / 1e6, 1), "ms_per_decode": round(ms / steps, 3), "code_blocks": n_cb, "K": K, "steps": steps}
+    if decoder == "bcjr_early":
+        it = ctx.turbo_early_exit_iterations()
+        out["sampled_blocks_equal_tx_bits"] = bool((got == tx[idx[:64]]).all())
+        out["iterations_per_tile_pair"] = {str(k): int((it == k).sum()) for k in sorted(set(int(x) for x in it))}
+        out["note"] = ("hard-decision-aided early termination per tile pair (128 code blocks), at most 8 iterations: a throughput mode of its own, "
+                       "NOT the 8-iteration figure; the soft values here are hard +-127 with 2 % flips, which two iterations settle")
     if decoder == "bcjr":
         out["sampled_blocks_equal_tx_bits"] = bool((got == tx[idx[:64]]).all())
         # the same decoder for a per-call caller's handful of blocks: MI_LTE_TURBO_BCJR_BLOCK, one code block per wavefront, one launch
@@ -991,7 +999,7 @@ def turbo_leg(ctx, decoder, n_cb, steps):
         out["latency_8_iterations"] = lat
     d_in.free()
     d_out.free()
-    if decoder != "bcjr":  # K = 6144 is one of the sizes whose interleaver the reference computes with uint32 overflow: it never decodes to the transmitted
+    if decoder not in ("bcjr", "bcjr_early"):  # K = 6144 is one of the sizes whose interleaver the reference computes with uint32 overflow: it never decodes to the transmitted
         # bits there; the check is bit-equality with the CPU restatement of the reference's decoder
         from oracle import pyoracle
         P, want = pyoracle.port(), np.zeros(K, np.uint8)
@@ -1284,6 +1292,7 @@ def main():
             out["turbo_decode"] = {"note": "BASELINE.json's second metric, measured in this run after the timed region: W3, K = 6144 x 65536 code blocks, "
                                            "int8 soft values resident in HBM, information Mbit/s",
                                    "bcjr_max_log_map_8_iterations": turbo_leg(ctx, "bcjr", 65536, 3),
+                                   "bcjr_early_termination_up_to_8_iterations": turbo_leg(ctx, "bcjr_early", 65536, 3),
                                    "ref_decoder": turbo_leg(ctx, "ref", 65536, 3)}
         if wl.name == "chain" and DECODER == "ref" and not args.no_turbo_leg and world == 1:
             # BASELINE.json's other single-GPU configurations, measured in this run after the timed region (each with its own roofline and

@@ -206,13 +206,23 @@ int      mi_lte_pdsch_plan_soft_bits(const mi_lte_pdsch_plan *plan, uint32_t all
  *                      reference's wrapped one.  Not a behaviour of the reference (its decoder is REF): specified
  *                      by oracle/lte_oracle.c lo_turbo_decode_bcjr, which the kernels match bit for bit.
  *
+ *   MI_LTE_TURBO_BCJR_EARLY  MI_LTE_TURBO_BCJR with hard-decision-aided early termination: from the second iteration on, a tile pair (128
+ *                      code blocks that share a wavefront) stops once an iteration changes none of its hard decisions; n_iter is the most
+ *                      iterations any pair runs.  A block's output is MI_LTE_TURBO_BCJR's with n_iter = the iterations its pair ran
+ *                      (mi_lte_turbo_early_exit_iterations reports them).  A throughput mode of its own: never what the 8-iteration
+ *                      numbers are quoted on.
+ *
  * Output: d_c_bits, one decoded bit per byte, K bytes per block (the reference's c_bits). */
-typedef enum { MI_LTE_TURBO_REF = 0, MI_LTE_TURBO_BCJR = 1, MI_LTE_TURBO_BCJR_BLOCK = 2 } mi_lte_turbo_mode;
+typedef enum { MI_LTE_TURBO_REF = 0, MI_LTE_TURBO_BCJR = 1, MI_LTE_TURBO_BCJR_BLOCK = 2, MI_LTE_TURBO_BCJR_EARLY = 3 } mi_lte_turbo_mode;
 typedef enum { MI_LTE_SOFT_F32 = 0, MI_LTE_SOFT_I8 = 1, MI_LTE_SOFT_I16 = 2 } mi_lte_soft_type;
 
 int mi_lte_turbo_decode_batch(mi_lte_ctx *ctx, const void *d_soft, mi_lte_soft_type soft_type, uint32_t K,
                               uint32_t n_cb, mi_lte_turbo_mode mode, uint32_t n_iter, int qpp_spec,
                               uint8_t *d_c_bits);
+
+/* iterations every tile pair (code blocks 128p .. 128p + 127) of the context's last MI_LTE_TURBO_BCJR_EARLY decode ran: h_pair_iters[p] in
+ * 2..n_iter; *n_pairs pairs (MI_LTE_ERR_INVALID_ARG with *n_pairs set when max_pairs is too small) */
+int mi_lte_turbo_early_exit_iterations(mi_lte_ctx *ctx, uint32_t *h_pair_iters, uint32_t max_pairs, uint32_t *n_pairs, uint32_t *n_iter);
 
 /* The reference-faithful decoder's trellis kernel comes in two shapes with identical results: code blocks on the lanes (lock-step tiles of
  * 64: the throughput shape, 64k blocks per launch) and, for a decode of at most n_cb_max code blocks, STATES on the lanes (four lanes per

@@ -170,14 +170,23 @@ struct HalfArgs {
     const uint4    *a_rd, *b_rd;
     uint4          *a_wr, *b_wr;
     uint32_t        K, n_cb, n_tiles, n_pairs;
+    // early termination (MI_LTE_TURBO_BCJR_EARLY): chg[it * n_pairs + pair] != 0 <=> some hard decision of the pair's 128 code blocks changed
+    // in iteration `it` against iteration it - 1 (always set for it = 0); a pair whose iteration it - 1 changed nothing has stopped
+    uint32_t       *chg;
+    uint32_t        it;
 };
 
 #ifndef BCJR_WPE
 #define BCJR_WPE 4
 #endif
-template <bool LAST>
+// LAST: the decoder-2 half of the final iteration (writes the hard decisions).  EARLY: hard-decision-aided stopping per tile pair -- every
+// decoder-2 half writes the decisions and notes whether any differs from the previous iteration's; both halves of a later iteration
+// return at once for a pair that has stopped (its extrinsics, boundary states and decisions stay what its last iteration left).
+template <bool LAST, bool EARLY = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BCJR_WPE, 8))) void k_bcjr_half(HalfArgs g)
 {
+    if (EARLY && g.it >= 2 && g.chg[(size_t)(g.it - 1) * g.n_pairs + blockIdx.x] == 0) return; // the pair stopped (uniform)
+    uint32_t hd_diff = 0;
     // alpha checkpoints of the current 32-step block: [window][first | second four states][lane].  The windows are walked by real
     // loops (a fully unrolled block is 67 KB of code, more than the instruction cache holds), so what is indexed by the window number
     // lives here rather than in registers
@@ -297,7 +306,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BCJR_WPE, 8)
                 *reinterpret_cast<uint16_t *>(erow + ro) = (uint16_t)__builtin_amdgcn_perm(0u, as_u32(e), 0x0C0C0200u); // the two low bytes
                 if (LAST) {
                     const uint32_t neg = as_u32(llr) >> 15; // bit 0: low half negative, bit 16: high half negative
-                    *reinterpret_cast<uint16_t *>(hrow + ro) = (uint16_t)((neg & 1u) | ((neg >> 8) & 0x100u));
+                    const uint16_t hd  = (uint16_t)((neg & 1u) | ((neg >> 8) & 0x100u));
+                    if (EARLY) hd_diff |= (uint32_t)(*reinterpret_cast<const uint16_t *>(hrow + ro) ^ hd);
+                    *reinterpret_cast<uint16_t *>(hrow + ro) = hd;
                 }
 #pragma unroll
                 for (int s = 0; s < 8; s++) b[s] = vmax(u0[s], u1[s]); // the beta step
@@ -313,6 +324,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BCJR_WPE, 8)
         norm8(a);
         g.a_wr[(seg + 1) * bnd_stride + bnd_lane]     = make_uint4(as_u32(a[0]), as_u32(a[1]), as_u32(a[2]), as_u32(a[3]));
         g.a_wr[(seg + 1) * bnd_stride + bnd_lane + 1] = make_uint4(as_u32(a[4]), as_u32(a[5]), as_u32(a[6]), as_u32(a[7]));
+    }
+    if (EARLY && LAST) { // lanes past the batch end (n_cb % 128 != 0) walk zeros: their decisions never change
+        const bool any = g.it == 0 || __any((int)(hd_diff != 0));
+        if (lane == 0 && any) atomicOr(&g.chg[(size_t)g.it * g.n_pairs + pair], 1u);
     }
 }
 
@@ -560,6 +575,7 @@ extern "C" size_t mi_lte_turbo_bcjr_scratch_bytes(uint32_t K, uint32_t n_cb)
            + n_pairs * ((Kp + 1) * 128 * 3)                  // E1 E2 HD rows
            + n_pairs * 64 * 32 * (2 * 2 * 8 + 2 * 2 * n_blk) // boundary states [decoder][buffer][segment | block]
            + n_tiles * 64 * 32                                // 32 bytes per code block for the caller's prep kernel (MiBcjrBufs::aux)
+           + n_pairs * 64 * 4                                 // early termination: one word per (iteration <= 64, pair)
            + 4096;
 }
 
@@ -568,7 +584,7 @@ extern "C" size_t mi_lte_turbo_bcjr_scratch_bytes(uint32_t K, uint32_t n_cb)
 //   mi_turbo_bcjr_begin    scratch laid out and zeroed where the first half-iteration must read zero; returns the arrays the prep kernel fills
 //   (prep)                 S1 P1 S2 P2 granules + termination records
 //   mi_turbo_bcjr_iterate  n_iter full iterations + the decisions in natural order
-struct BcjrLayout { size_t n_tiles, n_pairs, Kp, a8, ex, n_blk, one, per_buf; uint8_t *base; int8_t *E1, *E2; uint8_t *HD; uint4 *bnd0; };
+struct BcjrLayout { size_t n_tiles, n_pairs, Kp, a8, ex, n_blk, one, per_buf; uint8_t *base; int8_t *E1, *E2; uint8_t *HD; uint4 *bnd0; uint32_t *chg; };
 static BcjrLayout bcjr_layout(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb)
 {
     BcjrLayout l;
@@ -581,6 +597,8 @@ static BcjrLayout bcjr_layout(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb)
     l.one     = l.n_pairs * 64 * 2; // uint4 per [segment | block]
     l.bnd0    = (uint4 *)(((uintptr_t)(l.HD + l.ex) + 255) & ~(uintptr_t)255);
     l.per_buf = (8 + l.n_blk) * l.one;
+    const uintptr_t aux = ((uintptr_t)(l.bnd0 + 4 * l.per_buf) + 255) & ~(uintptr_t)255; // MiBcjrBufs::aux, 32 bytes per code block
+    l.chg = (uint32_t *)((aux + l.n_tiles * 64 * 32 + 255) & ~(uintptr_t)255);
     return l;
 }
 
@@ -599,7 +617,7 @@ int mi_turbo_bcjr_begin(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, MiBcjrBufs *
     return MI_LTE_OK;
 }
 
-int mi_turbo_bcjr_iterate(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, uint32_t n_iter, int qpp_spec, uint8_t *d_c_bits)
+int mi_turbo_bcjr_iterate(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, uint32_t n_iter, int qpp_spec, uint8_t *d_c_bits, bool early)
 {
     if (n_iter == 0 || n_iter > 64) return MI_LTE_ERR_INVALID_ARG;
     TurboTables tb;
@@ -615,6 +633,9 @@ int mi_turbo_bcjr_iterate(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, uint32_t n
     uint4   *bnd0 = l.bnd0;
     const size_t n_tiles = l.n_tiles;
     const uint32_t n_seg = bcjr_n_seg(K);
+    if (early) // the change words start at zero (the decisions need no initial value: the first iteration always counts as a change)
+        MI_HIP_CHECK(ctx, hipMemsetAsync(l.chg, 0, (size_t)n_iter * n_pairs * sizeof(uint32_t), ctx->stream));
+    ctx->bcjr_early = {early ? l.chg : nullptr, (uint32_t)n_pairs, n_iter, n_cb};
     for (uint32_t it = 0; it < n_iter; it++) {
         const bool last = it + 1 == n_iter;
         const uint32_t rd = it & 1u, wr = rd ^ 1u;
@@ -626,8 +647,14 @@ int mi_turbo_bcjr_iterate(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, uint32_t n
             h.tail = B.tail; h.tail_off = dec ? 6u : 0u;
             h.a_rd = d + rd * per_buf; h.b_rd = d + rd * per_buf + 8 * one; h.a_wr = d + wr * per_buf; h.b_wr = d + wr * per_buf + 8 * one;
             h.K = K; h.n_cb = n_cb; h.n_tiles = (uint32_t)n_tiles; h.n_pairs = (uint32_t)n_pairs;
+            h.chg = l.chg; h.it = it;
             return h;
         };
+        if (early) {
+            MI_LAUNCH(ctx, "k_bcjr_half", (k_bcjr_half<false, true>), dim3(n_pairs, n_seg), dim3(64), 0, args(0));
+            MI_LAUNCH(ctx, "k_bcjr_half", (k_bcjr_half<true, true>), dim3(n_pairs, n_seg), dim3(64), 0, args(1));
+            continue;
+        }
         MI_LAUNCH(ctx, "k_bcjr_half", k_bcjr_half<false>, dim3(n_pairs, n_seg), dim3(64), 0, args(0));
         if (!last) MI_LAUNCH(ctx, "k_bcjr_half", k_bcjr_half<false>, dim3(n_pairs, n_seg), dim3(64), 0, args(1));
         else       MI_LAUNCH(ctx, "k_bcjr_half", k_bcjr_half<true>, dim3(n_pairs, n_seg), dim3(64), 0, args(1));
@@ -640,7 +667,7 @@ int mi_turbo_bcjr_iterate(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, uint32_t n
 }
 
 // n_iter full iterations of max-log-MAP over n_cb code blocks of size K; int8 soft input in the reference's layout
-int mi_turbo_bcjr_batch(mi_lte_ctx *ctx, const int8_t *d_soft, uint32_t K, uint32_t n_cb, uint32_t n_iter, int qpp_spec, uint8_t *d_c_bits)
+int mi_turbo_bcjr_batch(mi_lte_ctx *ctx, const int8_t *d_soft, uint32_t K, uint32_t n_cb, uint32_t n_iter, int qpp_spec, uint8_t *d_c_bits, bool early)
 {
     if (n_iter == 0 || n_iter > 64) return MI_LTE_ERR_INVALID_ARG;
     TurboTables tb;
@@ -653,7 +680,7 @@ int mi_turbo_bcjr_batch(mi_lte_ctx *ctx, const int8_t *d_soft, uint32_t K, uint3
     const size_t   Kp = kpad64(K);
     const uint32_t cb_threads = (uint32_t)(((Kp >> 4) + 63) & ~(size_t)63);
     MI_LAUNCH(ctx, "k_bcjr_prep", k_bcjr_prep, dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), Kp, d_soft, K, n_cb, tb.d_pi, B);
-    return mi_turbo_bcjr_iterate(ctx, K, n_cb, n_iter, qpp_spec, d_c_bits);
+    return mi_turbo_bcjr_iterate(ctx, K, n_cb, n_iter, qpp_spec, d_c_bits, early);
 }
 
 // MI_LTE_TURBO_BCJR_BLOCK: one wavefront per code block, one launch for the whole decode (k_bcjr_block)
@@ -672,5 +699,26 @@ int mi_turbo_bcjr_block_batch(mi_lte_ctx *ctx, const int8_t *d_soft, uint32_t K,
               (const uint32_t *)tb.d_inv_row, d_c_bits);
     MI_HIP_CHECK(ctx, hipGetLastError());
     ctx->last_kernels = "k_bcjr_block:1";
+    return MI_LTE_OK;
+}
+
+// iterations each tile pair of the last MI_LTE_TURBO_BCJR_EARLY decode on this context ran (host side: reads the change words back)
+extern "C" int mi_lte_turbo_early_exit_iterations(mi_lte_ctx *ctx, uint32_t *h_pair_iters, uint32_t max_pairs, uint32_t *n_pairs, uint32_t *n_iter)
+{
+    if (!ctx || !h_pair_iters || !n_pairs || !n_iter) return MI_LTE_ERR_INVALID_ARG;
+    if (!ctx->bcjr_early.chg) { ctx->err = "no early-termination decode has run on this context"; return MI_LTE_ERR_INVALID_ARG; }
+    const uint32_t np = ctx->bcjr_early.n_pairs, ni = ctx->bcjr_early.n_iter;
+    *n_pairs = np; *n_iter = ni;
+    if (max_pairs < np) return MI_LTE_ERR_INVALID_ARG;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    std::vector<uint32_t> chg((size_t)ni * np);
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(chg.data(), ctx->bcjr_early.chg, chg.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t p = 0; p < np; p++) {
+        uint32_t done = ni;
+        for (uint32_t it = 2; it < ni; it++)
+            if (chg[(size_t)(it - 1) * np + p] == 0) { done = it; break; }
+        h_pair_iters[p] = done;
+    }
     return MI_LTE_OK;
 }

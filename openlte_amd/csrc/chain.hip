@@ -516,7 +516,7 @@ int mi_lte_pdsch_plan_soft_bits(const mi_lte_pdsch_plan *pl, uint32_t alloc, con
 
 int mi_lte_pdsch_plan_set_decoder(mi_lte_pdsch_plan *pl, uint32_t mode, uint32_t n_iter, int qpp_spec)
 {
-    const bool bcjr = mode == MI_LTE_TURBO_BCJR || mode == MI_LTE_TURBO_BCJR_BLOCK;
+    const bool bcjr = mode == MI_LTE_TURBO_BCJR || mode == MI_LTE_TURBO_BCJR_BLOCK || mode == MI_LTE_TURBO_BCJR_EARLY;
     if (!pl || !(mode == MI_LTE_TURBO_REF || bcjr) || (bcjr && (n_iter == 0 || n_iter > 64))) return MI_LTE_ERR_INVALID_ARG;
     pl->decoder = mode; pl->n_iter = n_iter; pl->qpp_spec = qpp_spec;
     return MI_LTE_OK;
@@ -556,7 +556,7 @@ int mi_lte_pdsch_decode_run(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, const float 
         MI_LAUNCH(ctx, "k_pdsch_demod", k_pdsch_demod<false>, dim3(pl->n_alloc), dim3(256), lds, d_subframes, g, pl->d_allocs, d_subfr_num,
                   d_n_id_cell, gt, pl->d_e, pl->d_e_off, pl->d_e_len, pl->max_pairs, words_al, e_cap);
     MI_HIP_CHECK(ctx, hipGetLastError());
-    const bool bcjr = pl->decoder == MI_LTE_TURBO_BCJR || pl->decoder == MI_LTE_TURBO_BCJR_BLOCK;
+    const bool bcjr = pl->decoder == MI_LTE_TURBO_BCJR || pl->decoder == MI_LTE_TURBO_BCJR_BLOCK || pl->decoder == MI_LTE_TURBO_BCJR_EARLY;
     if (bcjr) {
         size_t soft = 0, bits = 0;
         for (auto &gr : pl->groups) { soft = std::max(soft, (size_t)gr.n_cb * 3 * (gr.K + 4)); bits = std::max(bits, (size_t)gr.n_cb * gr.K); }
@@ -574,7 +574,7 @@ int mi_lte_pdsch_decode_run(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, const float 
         if (bcjr)
             rc = mi_turbo_bcjr_group(ctx, gr.K, gr.n_cb, pl->d_allocs, pl->d_cb_alloc + gr.cb_base, pl->d_e, pl->d_e_off, pl->d_e_len, d_out_bits,
                                      pl->out_stride, d_status, false, pl->d_bcjr_soft, pl->d_bcjr_bits, pl->n_iter, pl->qpp_spec, pl->packed != 0, gr.e_max,
-                                     pl->decoder == MI_LTE_TURBO_BCJR_BLOCK);
+                                     pl->decoder == MI_LTE_TURBO_BCJR_BLOCK, pl->decoder == MI_LTE_TURBO_BCJR_EARLY);
         else
             rc = mi_turbo_ref_group(ctx, gr.K, gr.n_cb, pl->d_allocs, pl->d_cb_alloc + gr.cb_base, pl->d_e, pl->d_e_off, pl->d_e_len,
                                     d_out_bits, pl->out_stride, d_status, gr.e_max, false, pl->packed != 0);

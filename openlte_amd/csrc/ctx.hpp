@@ -44,6 +44,7 @@ struct mi_lte_ctx {
     size_t             scratch_bytes = 0;
     uint32_t          *h_flag = nullptr, *d_flag = nullptr; // the completion word of the per-call waits (mi_stream_wait_polling) and its sequence number
     uint32_t           flag_seq = 0;
+    struct { uint32_t *chg; uint32_t n_pairs, n_iter, n_cb; } bcjr_early = {nullptr, 0, 0, 0}; // the last early-termination decode's change words (bcjr.hip)
     bool               bcjr_block_lds_set = false; // hipFuncSetAttribute(k_bcjr_block, max dynamic LDS) made on this context's device
     uint32_t           siso_small_max = 4096; // code blocks per decode up to which k_turbo_siso_small runs (mi_lte_set_turbo_small_batch)
     void              *h_small = nullptr, *d_small = nullptr; // MI_SMALL_BYTES of pinned host memory the kernels can write (mi_ctx_small_results)
@@ -117,7 +118,7 @@ int   mi_turbo_ref_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lt
                          uint8_t *d_out_bits, uint32_t out_stride, int32_t *d_status, uint32_t e_max_bytes, bool ul = false, bool packed = false);
 int   mi_turbo_bcjr_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_pdsch_alloc *d_allocs, const uint32_t *d_cb_alloc, const int8_t *d_e,
                           const uint32_t *d_e_off, const uint32_t *d_e_len, uint8_t *d_out_bits, uint32_t out_stride, int32_t *d_status, bool ul,
-                          int8_t *d_soft, uint8_t *d_c_bits, uint32_t n_iter, int qpp_spec, bool packed = false, uint32_t e_max_bytes = 0, bool block_mode = false);
+                          int8_t *d_soft, uint8_t *d_c_bits, uint32_t n_iter, int qpp_spec, bool packed = false, uint32_t e_max_bytes = 0, bool block_mode = false, bool early = false);
 int   mi_ctx_turbo_tables(mi_lte_ctx *ctx, uint32_t K, int spec, TurboTables *out);
 struct mi_lte_pdsch_plan;
 void  mi_pdsch_plan_wide_stride(mi_lte_pdsch_plan *pl); // one output stride whatever the plan holds: that of the largest single-code-block transport block (pipeline.cc)
@@ -127,8 +128,8 @@ int   mi_pusch_plan_create_impl(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const
                                 const float *h_dmrs, mi_lte_pusch_plan **out);
 int   mi_fft_rows(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const void *d_samples_a, const void *d_samples_b, const uint64_t *d_win_start,
                   uint32_t n_rows, float *d_rows);
-int   mi_turbo_bcjr_batch(mi_lte_ctx *ctx, const int8_t *d_soft, uint32_t K, uint32_t n_cb, uint32_t n_iter, int qpp_spec, uint8_t *d_c_bits);
+int   mi_turbo_bcjr_batch(mi_lte_ctx *ctx, const int8_t *d_soft, uint32_t K, uint32_t n_cb, uint32_t n_iter, int qpp_spec, uint8_t *d_c_bits, bool early = false);
 struct MiBcjrBufs { int8_t *S1, *P1, *S2, *P2, *tail; void *aux; }; // what a prep kernel fills (layouts: bcjr.hip); aux: 32 bytes per code block of its own
 int   mi_turbo_bcjr_begin(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, MiBcjrBufs *out);
-int   mi_turbo_bcjr_iterate(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, uint32_t n_iter, int qpp_spec, uint8_t *d_c_bits);
+int   mi_turbo_bcjr_iterate(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, uint32_t n_iter, int qpp_spec, uint8_t *d_c_bits, bool early = false);
 int   mi_turbo_bcjr_block_batch(mi_lte_ctx *ctx, const int8_t *d_soft, uint32_t K, uint32_t n_cb, uint32_t n_iter, int qpp_spec, uint8_t *d_c_bits);

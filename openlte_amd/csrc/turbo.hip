@@ -1852,7 +1852,7 @@ int mi_turbo_ref_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_
 
 int mi_turbo_bcjr_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_pdsch_alloc *d_allocs, const uint32_t *d_cb_alloc, const int8_t *d_e,
                         const uint32_t *d_e_off, const uint32_t *d_e_len, uint8_t *d_out_bits, uint32_t out_stride, int32_t *d_status, bool ul,
-                        int8_t *d_soft, uint8_t *d_c_bits, uint32_t n_iter, int qpp_spec, bool packed, uint32_t e_max_bytes, bool block_mode)
+                        int8_t *d_soft, uint8_t *d_c_bits, uint32_t n_iter, int qpp_spec, bool packed, uint32_t e_max_bytes, bool block_mode, bool early)
 {
     int rc = mi_ctx_crc_table(ctx);
     if (rc != MI_LTE_OK) return rc;
@@ -1883,7 +1883,7 @@ int mi_turbo_bcjr_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte
         src.g = gd; src.tabs = t.d_tabs; src.nnn = t.d_nnn; src.e_cap = e_cap2;
         MI_LAUNCH(ctx, "k_rm_bcjr_prep", k_rm_bcjr_prep, dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), e_cap2 + Kp, src, K, n_cb, (const uint16_t *)tb.d_pi, mb);
         MI_HIP_CHECK(ctx, hipGetLastError());
-        rc = mi_turbo_bcjr_iterate(ctx, K, n_cb, n_iter, qpp_spec, d_c_bits);
+        rc = mi_turbo_bcjr_iterate(ctx, K, n_cb, n_iter, qpp_spec, d_c_bits, early);
     }
     if (rc != MI_LTE_OK) return rc;
     MI_LAUNCH(ctx, "k_crc_finish", k_crc_finish, dim3(n_cb), dim3(256), 0, (const uint8_t *)d_c_bits, K, n_cb, gd);
@@ -1912,7 +1912,7 @@ extern "C" int mi_lte_turbo_decode_batch(mi_lte_ctx *ctx, const void *d_soft, mi
         return MI_LTE_ERR_UNSUPPORTED;
     }
     if (mode == MI_LTE_TURBO_BCJR_BLOCK) return mi_turbo_bcjr_block_batch(ctx, (const int8_t *)d_soft, K, n_cb, n_iter, qpp_spec, d_c_bits);
-    return mi_turbo_bcjr_batch(ctx, (const int8_t *)d_soft, K, n_cb, n_iter, qpp_spec, d_c_bits);
+    return mi_turbo_bcjr_batch(ctx, (const int8_t *)d_soft, K, n_cb, n_iter, qpp_spec, d_c_bits, mode == MI_LTE_TURBO_BCJR_EARLY);
 }
 
 extern "C" int mi_lte_rate_unmatch_turbo_batch(mi_lte_ctx *ctx, const float *d_e_bits, uint32_t N_e_bits, uint32_t D,

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 SOFT_F32, SOFT_I8, SOFT_I16 = 0, 1, 2
-TURBO_REF, TURBO_BCJR, TURBO_BCJR_BLOCK = 0, 1, 2  # BCJR_BLOCK: one code block per wavefront, one launch (a handful of blocks; its own model)
+TURBO_REF, TURBO_BCJR, TURBO_BCJR_BLOCK, TURBO_BCJR_EARLY = 0, 1, 2, 3  # BCJR_BLOCK: one code block per wavefront, one launch (a handful of blocks; its own model)
 _SOFT_OF_DTYPE = {np.dtype(np.float32): SOFT_F32, np.dtype(np.int8): SOFT_I8, np.dtype(np.int16): SOFT_I16}
 
 
@@ -183,6 +183,7 @@ def load_library():
     L.mi_lte_dci_1c_unpack.argtypes = [u32, u32, u32, u32, u32, C.POINTER(PdcchDci)]
     L.mi_lte_turbo_decode_batch.argtypes = [vp, vp, C.c_int, u32, u32, C.c_int, u32, C.c_int, vp]
     L.mi_lte_set_turbo_small_batch.argtypes = [vp, u32]
+    L.mi_lte_turbo_early_exit_iterations.argtypes = [vp, vp, u32, C.POINTER(u32), C.POINTER(u32)]
     L.mi_lte_turbo_scratch_bytes.argtypes = [u32, u32]
     L.mi_lte_turbo_scratch_bytes.restype = sz
     _LIB = L
@@ -704,6 +705,13 @@ class Context:
         finally:
             d_in.free()
             d_out.free()
+
+    def turbo_early_exit_iterations(self):
+        """Iterations each tile pair (128 code blocks) of the last TURBO_BCJR_EARLY decode ran: uint32 [n_pairs]."""
+        n, ni = C.c_uint32(), C.c_uint32()
+        out = np.zeros(1 << 16, np.uint32)
+        self._check(self.L.mi_lte_turbo_early_exit_iterations(self.h, out.ctypes.data, len(out), C.byref(n), C.byref(ni)))
+        return out[:n.value].copy()
 
     def set_turbo_small_batch(self, n_cb_max):
         """Code blocks per decode up to which the REF decoder's state-parallel trellis kernel runs (0: always the lock-step one)."""

@@ -199,3 +199,37 @@ def test_bcjr_block_mode_more_blocks_than_compute_units(ctx, port):
         got = d_out.download(np.uint8).reshape(n_cb, K)
         d_in.free(); d_out.free()
         assert (got == want[idx]).all(), K
+
+
+@pytest.mark.parametrize("K,spec", [(1088, False), (512, True), (3264, False)])
+def test_bcjr_early_termination_is_the_model_at_the_iterations_each_pair_ran(ctx, port, K, spec):
+    """MI_LTE_TURBO_BCJR_EARLY: a tile pair (128 code blocks) stops once an iteration (from the second on) changes none of its hard
+    decisions.  Specification = the plain-C model run for exactly the iterations the pair ran; the stopping rule itself is checked on the
+    model too: the pair's decisions after its last iteration equal those after the one before, and no earlier iteration had that property.
+    Pairs of different quality: clean (stop after 2), moderate noise, one pair with a block below threshold (runs all 8)."""
+    import openlte_amd as m
+    n_pairs, n = 4, 4 * 128 - 37  # the last pair is ragged
+    sig = np.concatenate([np.full(128, 0.3), np.full(128, 0.85), np.full(128, 1.05), np.full(n - 384, 0.6)])
+    sig[2 * 128 + 5] = 2.5  # one hopeless block keeps its pair iterating
+    tx = np.zeros((n, K), np.uint8)
+    soft = np.zeros((n, 3 * (K + 4)), np.int8)
+    for b in range(n):
+        t, s = llr_blocks(port, K, 1, float(sig[b]), seed=1000 * K + b)
+        tx[b], soft[b] = t[0], s[0]
+    got = ctx.turbo_decode(soft, K, mode=m.TURBO_BCJR_EARLY, n_iter=8, qpp_spec=spec)
+    iters = ctx.turbo_early_exit_iterations()
+    assert len(iters) == n_pairs and iters.min() >= 2 and iters.max() <= 8
+    assert iters[0] == 2 and iters[2] == 8 and iters[1] <= 6, iters
+    full = ctx.turbo_decode(soft, K, mode=m.TURBO_BCJR, n_iter=8, qpp_spec=spec)
+    for p in range(n_pairs):
+        blk = np.arange(128 * p, min(n, 128 * p + 128))
+        sample = blk if K <= 1088 else blk[::8]
+        dec = {k: oracle_bcjr(port, soft[sample], K, k, spec) for k in range(max(1, int(iters[p]) - 2), int(iters[p]) + 1)}
+        assert (got[sample] == dec[int(iters[p])]).all(), (p, iters[p])
+        if K <= 1088:  # the rule on the model, every block of the pair
+            if iters[p] < 8:
+                assert (dec[int(iters[p])] == dec[int(iters[p]) - 1]).all(), p
+            if iters[p] > 2:  # the iteration before did change something (else the pair would have stopped there)
+                assert (dec[int(iters[p]) - 1] != dec[int(iters[p]) - 2]).any(), p
+        ok = sig[blk] < 2
+        assert (got[blk][ok] == tx[blk][ok]).all() and (got[blk][ok] == full[blk][ok]).all()  # stopping early costs nothing on blocks that decode

@@ -170,13 +170,13 @@ class TurboWorkload:
 
     @property
     def metric(self):
-        if DECODER == "bcjr":
+        if DECODER.startswith("bcjr"):
             return "turbo-decode Mbit/s (K=6144 code blocks, 64QAM hard +-127 soft values, max-log-MAP BCJR, 8 iterations, per SURVEY 8d W3)"
         return "turbo-decode Mbit/s (K=6144 code blocks, 64QAM hard +-127 soft values, REF decoder, per SURVEY 8d W3)"
 
     @property
     def dominant(self):
-        return "k_bcjr_half" if DECODER == "bcjr" else "k_turbo_siso"
+        return "k_bcjr_half" if DECODER.startswith("bcjr") else "k_turbo_siso"
 
     def __init__(self, ctx, n_units, rank):
         import numpy as np
@@ -185,7 +185,7 @@ class TurboWorkload:
         self.ctx, self.m, self.np = ctx, m, np
         self.n_cb = n_units or 65536
         uniq = 64
-        self.tx, soft = synth.turbo_soft_blocks(self.K, uniq, flip=0.02, seed=1234 + rank, ref_wrap=(DECODER != "bcjr"))
+        self.tx, soft = synth.turbo_soft_blocks(self.K, uniq, flip=0.02, seed=1234 + rank, ref_wrap=(not DECODER.startswith("bcjr")))
         self.uniq_soft = soft
         idx = (np.arange(self.n_cb) * 7 + np.arange(self.n_cb) // 64) % uniq
         self.d_in = ctx.to_device(soft[idx])
@@ -193,8 +193,9 @@ class TurboWorkload:
         self.idx = idx
 
     def step(self):
-        if DECODER == "bcjr":
-            self.ctx.turbo_decode_dev(self.d_in, self.m.SOFT_I8, self.K, self.n_cb, self.d_out, mode=self.m.TURBO_BCJR, n_iter=8, qpp_spec=True)
+        if DECODER.startswith("bcjr"):
+            self.ctx.turbo_decode_dev(self.d_in, self.m.SOFT_I8, self.K, self.n_cb, self.d_out,
+                                      mode=self.m.TURBO_BCJR_EARLY if DECODER == "bcjr_early" else self.m.TURBO_BCJR, n_iter=8, qpp_spec=True)
         else:
             self.ctx.turbo_decode_dev(self.d_in, self.m.SOFT_I8, self.K, self.n_cb, self.d_out)
 
@@ -202,12 +203,12 @@ class TurboWorkload:
         return self.n_cb
 
     def accounting(self):
-        ks = ["k_bcjr_prep", "k_bcjr_half", "k_bcjr_final"] if DECODER == "bcjr" else ["k_turbo_prep", "k_turbo_siso", "k_turbo_perm", "k_turbo_vote"]
+        ks = ["k_bcjr_prep", "k_bcjr_half", "k_bcjr_final"] if DECODER.startswith("bcjr") else ["k_turbo_prep", "k_turbo_siso", "k_turbo_perm", "k_turbo_vote"]
         return {"stages": {"turbo": (self.alg_bytes_per_unit * self.n_cb, ks)},
-                "own_io": turbo_own_io(self.K, self.n_cb, 3 * (self.K + 4), self.K, 8 if DECODER == "bcjr" else 0)}
+                "own_io": turbo_own_io(self.K, self.n_cb, 3 * (self.K + 4), self.K, 8 if DECODER.startswith("bcjr") else 0)}
 
     def extra(self, value):
-        if DECODER != "bcjr":
+        if not DECODER.startswith("bcjr"):
             return {}
         got = self.d_out.download(self.np.uint8, count=64 * self.K).reshape(64, self.K)
         return {"decoder": "max-log-MAP, 8 iterations, fixed point (specified by oracle/lte_oracle.c lo_turbo_decode_bcjr)",
@@ -219,7 +220,7 @@ class TurboWorkload:
     def config(self, world):
         return {"workload": "W3 turbo decode: K=6144 x %d code blocks per GPU, int8 soft in HBM, %s mode" % (self.n_cb, DECODER.upper()),
                 "K": self.K, "blocks_per_gpu": self.n_cb,
-                "decoder": "BCJR max-log-MAP x8" if DECODER == "bcjr" else "REF (reference-faithful, bit-exact)",
+                "decoder": "BCJR max-log-MAP x8" if DECODER.startswith("bcjr") else "REF (reference-faithful, bit-exact)",
                 "sharding": "code blocks block-cyclic over %d GPU(s), no collective" % world}
 
     def cpu_baseline(self, budget_s=12.0):
@@ -227,7 +228,7 @@ class TurboWorkload:
         np = self.np
         from oracle import pyoracle
         K, D = self.K, self.K + 4
-        if DECODER == "bcjr":  # the reference has no such decoder: the CPU leg is the plain-C specification of the mode
+        if DECODER.startswith("bcjr"):  # the reference has no such decoder: the CPU leg is the plain-C specification of the mode
             P, s16 = pyoracle.port(), np.ascontiguousarray(self.uniq_soft.astype(np.int16))
             out, n, t0 = np.zeros(K, np.uint8), 0, time.perf_counter()
             while time.perf_counter() - t0 < budget_s:
@@ -282,7 +283,7 @@ class ChainWorkload:
     @property
     def metric(self):
         return "DL subframes/sec @20MHz 100RB 64QAM, full chain FFT->CE->demap->rate-unmatch->turbo(%s)->CRC (SURVEY 8d W4)" % \
-               ("max-log-MAP BCJR x8" if DECODER == "bcjr" else "REF")
+               ("max-log-MAP BCJR, early termination, <= 8 iterations" if DECODER == "bcjr_early" else "max-log-MAP BCJR x8" if DECODER.startswith("bcjr") else "REF")
 
     dtype = "i8 IQ in, f32 FFT/CE/equaliser, i8 soft bits, i16 path metrics (differences exact modulo 2^16)"
     alg_bytes_per_unit = 70240 + 26984 // 8  # fused accounting, SURVEY 8d: int8 IQ in + packed info bits out
@@ -326,8 +327,8 @@ class ChainWorkload:
         for i in range(self.n):
             all_allocs += td.w4_allocs(i)
         self.plan = ctx.pdsch_plan(self.cfg, 2, all_allocs)
-        if DECODER == "bcjr":  # the max-log-MAP decoder instead of the reference's (8 iterations; the reference transmitter's interleaver)
-            self.plan.set_decoder(m.TURBO_BCJR, 8, 0)
+        if DECODER.startswith("bcjr"):  # the max-log-MAP decoder instead of the reference's (8 iterations; the reference transmitter's interleaver)
+            self.plan.set_decoder(m.TURBO_BCJR_EARLY if DECODER == "bcjr_early" else m.TURBO_BCJR, 8, 0)
         self.d_out = ctx.alloc(self.n * 9 * self.plan.out_stride)
         self.d_status = ctx.alloc(self.n * 9 * 4)
 
@@ -408,7 +409,7 @@ class ChainWorkload:
         """SURVEY 8d per-stage bytes (charged once per step) and each kernel's own minimal I/O."""
         n = self.n
         res = 8 * 1656 + 552  # PDSCH resource elements per subframe
-        bc = 8 if DECODER == "bcjr" else 0
+        bc = 8 if DECODER.startswith("bcjr") else 0
         own = {"k_dl_fft": n * (15 * 2048 * 2 + 15 * 1200 * 8),       # the 15 symbol windows in, 15 rows of symbols out
                "k_dl_ce": n * (5 * 200 * 8 + 14 * 1200 * 8),           # pilots in, 14 estimate rows out
                "k_pdsch_demod": n * res * (16 + 6)}                    # y and h per element in, six soft bits out
@@ -435,7 +436,7 @@ class ChainWorkload:
         return {"workload": "W4 full DL chain: 20 MHz/100 RB/64QAM, 9 allocations per subframe (8x12 PRB TBS 3240 + 1x4 PRB "
                             "TBS 1064), %d subframes per GPU, int8 IQ in HBM" % self.n,
                 "subframes_per_gpu": self.n, "N_ant": 1, "CFI": 2, "channel_estimate_form": CE_MODE,
-                "decoder": "BCJR (max-log-MAP, 8 iterations; specified by the plain-C model, not by the reference)" if DECODER == "bcjr" else "REF (reference-faithful, bit-exact)",
+                "decoder": "BCJR (max-log-MAP, 8 iterations; specified by the plain-C model, not by the reference)" if DECODER.startswith("bcjr") else "REF (reference-faithful, bit-exact)",
                 "unique_subframes": len(self.uniq[2]),
                 "batch_note": "the %d subframes of a step are %d unique synthetic subframes (30 / 27 / 25 dB) repeated; every kernel on the path is "
                               "branch-free, so the repetition does not shorten the timed work" % (self.n, len(self.uniq[2])),
@@ -1163,7 +1164,7 @@ def main():
     ap.add_argument("--workload", default="auto")
     ap.add_argument("--units", type=int, default=0, help="units (subframes / code blocks) per GPU per step")
     ap.add_argument("--streams", type=int, default=1, help="independent shards (contexts/streams) per GPU")
-    ap.add_argument("--decoder", default="ref", choices=["ref", "bcjr"], help="turbo workload only: decoder mode")
+    ap.add_argument("--decoder", default="ref", choices=["ref", "bcjr", "bcjr_early"], help="turbo workload only: decoder mode")
     ap.add_argument("--ce", default="compact", choices=["compact", "full"], help="chain workload: channel-estimate form handed to the demodulator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="time the steps without the per-launch HIP events (no roofline in the line): measures what the events cost")
@@ -1231,7 +1232,7 @@ def main():
         stage_of = {k: st for st, (_, ks) in acc["stages"].items() for k in ks}
         traffic_tab = {}
         try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command (tools/profile_bench.sh)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s%s.json" % (wl.name, "_bcjr" if DECODER == "bcjr" else ""))))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s%s.json" % (wl.name, "_bcjr" if DECODER.startswith("bcjr") else ""))))
             traffic_tab = tj["bytes_per_launch"]
         except Exception:
             pass

@@ -319,6 +319,17 @@ int bind_params(mi_lte_ctx *ctx, HostCache *hc, uint32_t subfr_num, uint32_t N_i
     return MI_LTE_OK;
 }
 
+// An error after work was queued: the per-call forms share pinned parameter / result blocks and one device subframe on the assumption that
+// every call ends with a wait, so a failing call must wait too (kernels of its earlier stages may still be reading h_par / h_pin) and
+// must not leave the caches claiming that the device holds the caller's data
+int fail_after_launch(mi_lte_ctx *ctx, HostCache *hc, int rc)
+{
+    (void)mi_stream_wait_polling(ctx);
+    hc->sub_host = nullptr;
+    hc->par_sf = hc->par_cell = ~0u;
+    return rc;
+}
+
 // make d_sub hold the caller's subframe (downlink layout for n_ant ports, or the two uplink planes): nothing to do when it is the
 // copy this context produced (or uploaded) last and the arrays have not changed since
 int bind_subframe(mi_lte_ctx *ctx, HostCache *hc, const float *re, const float *im, const float *ce_re, const float *ce_im, uint32_t n_ant, uint32_t n_sc, bool ul)
@@ -396,13 +407,13 @@ int mi_lte_get_dl_subframe_and_ce_host(mi_lte_ctx *ctx, uint32_t fft_size, uint3
     hc->sub_host = nullptr; // d_sub is being rewritten
     mi_lte_dl_cfg cfg = {fft_size, N_rb_dl, N_ant, MI_LTE_IQ_F32_PLANAR | MI_LTE_IQ_ALL_ROWS}; // every row the reference's struct holds
     rc = mi_lte_dl_frontend_batch(ctx, &cfg, d_i, d_q, (const uint64_t *)d_p, d_p + 2, d_p + 3, 1, hc->d_sub);
-    if (rc != MI_LTE_OK) return rc;
+    if (rc != MI_LTE_OK) return fail_after_launch(ctx, hc, rc);
     const size_t   planes = 2 + 2 * (size_t)N_ant;
     const uint32_t n_sc = 12 * N_rb_dl;
     // the reference writes columns 0..n_sc-1 of each row and nothing else (samples_to_symbols_dl, :8628-8632): so does this form
     const float *st;
     rc = fetch_packed_rows(ctx, hc, planes, n_sc, &st);
-    if (rc != MI_LTE_OK) return rc;
+    if (rc != MI_LTE_OK) return fail_after_launch(ctx, hc, rc);
     unpack_rows(h_symb_re, st, 0, 16, n_sc);
     unpack_rows(h_symb_im, st, 1, 16, n_sc);
     for (uint32_t p = 0; p < N_ant; p++) { // estimate rows 14 and 15 are never written, as in the reference
@@ -445,7 +456,7 @@ int mi_lte_pdsch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const fl
     rc = bind_params(ctx, hc, subfr_num, N_id_cell);
     if (rc != MI_LTE_OK) return rc;
     rc = mi_lte_pdsch_decode_run(ctx, plan, hc->d_sub, hc->d_par + 4, hc->d_par + 5, hc->d_out, hc->d_st);
-    if (rc != MI_LTE_OK) return rc;
+    if (rc != MI_LTE_OK) return fail_after_launch(ctx, hc, rc);
     // verdict and bits were written straight into pinned host memory (the bits are only handed over when the CRC matched, like the
     // reference, :12861-12869)
     MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
@@ -485,7 +496,7 @@ int mi_lte_pdcch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const fl
     rc = bind_params(ctx, hc, subfr_num, N_id_cell);
     if (rc != MI_LTE_OK) return rc;
     rc = mi_lte_pdcch_decode_run(ctx, plan, hc->d_sub, hc->d_par + 4, hc->d_par + 5, 1, &h_rc, cfi, N_symbs, N_dci, dci);
-    return rc != MI_LTE_OK ? rc : (int)h_rc;
+    return rc != MI_LTE_OK ? fail_after_launch(ctx, hc, rc) : (int)h_rc;
 }
 
 // liblte_phy_bch_channel_decode (liblte_phy.cc:3968-4105)
@@ -504,7 +515,7 @@ int mi_lte_bch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const floa
     hc->h_par[6] = N_id_cell;
     uint32_t n_ant = 0, off = 0, mib = 0;
     rc = mi_lte_pbch_decode_run(ctx, &cfg, hc->d_sub, hc->d_par + 6, 1, &n_ant, &off, &mib);
-    if (rc != MI_LTE_OK) return rc;
+    if (rc != MI_LTE_OK) return fail_after_launch(ctx, hc, rc);
     *N_ant = (uint8_t)n_ant; // the reference zeroes it before trying (:4029)
     if (n_ant == 0) return 2;
     for (uint32_t i = 0; i < 24; i++) h_out_bits[i] = (uint8_t)((mib >> (23 - i)) & 1u);
@@ -611,10 +622,10 @@ int mi_lte_get_ul_subframe_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_r
     hc->sub_host = nullptr;
     mi_lte_dl_cfg cfg = {fft_size, N_rb_ul, 1, MI_LTE_IQ_F32_PLANAR};
     rc = mi_lte_ul_frontend_batch(ctx, &cfg, d_i, d_q, (const uint64_t *)hc->d_par, 1, hc->d_sub);
-    if (rc != MI_LTE_OK) return rc;
+    if (rc != MI_LTE_OK) return fail_after_launch(ctx, hc, rc);
     const float *st;
     rc = fetch_packed_rows(ctx, hc, 2, 12 * N_rb_ul, &st);
-    if (rc != MI_LTE_OK) return rc;
+    if (rc != MI_LTE_OK) return fail_after_launch(ctx, hc, rc);
     // rows 14, 15 of the caller's struct and the columns past 12*N_rb_ul are left alone, as the reference leaves them (samples_to_symbols_ul, :8686-8691)
     unpack_rows(h_symb_re, st, 0, 14, 12 * N_rb_ul);
     unpack_rows(h_symb_im, st, 1, 14, 12 * N_rb_ul);
@@ -661,7 +672,7 @@ int mi_lte_pusch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_ul, const fl
     rc = bind_subframe(ctx, hc, h_symb_re, h_symb_im, nullptr, nullptr, 1, 12 * N_rb_ul, true);
     if (rc != MI_LTE_OK) return rc;
     rc = mi_lte_pusch_decode_run(ctx, plan, hc->d_sub, hc->d_out, hc->d_st);
-    if (rc != MI_LTE_OK) return rc;
+    if (rc != MI_LTE_OK) return fail_after_launch(ctx, hc, rc);
     MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
     int32_t st;
     memcpy(&st, hc->h_res, 4);
@@ -702,7 +713,7 @@ int mi_lte_detect_prach_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_u
     // (the sample offset of the one unit is words 0..1 of the parameter block: zero since it was allocated)
     uint32_t n = 0, p = 0, ta = 0;
     rc = mi_lte_prach_detect_run(ctx, plan, d_i, d_q, (const uint64_t *)hc->d_par, 1, &n, &p, &ta);
-    if (rc != MI_LTE_OK) return rc;
+    if (rc != MI_LTE_OK) return fail_after_launch(ctx, hc, rc);
     *N_det_pre = n;
     if (n) { *det_pre = p; *det_ta = ta; }
     return 0;

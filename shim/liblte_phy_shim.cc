@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <memory>
 #include <mutex>
 
 #include "liblte_phy.h" // the reference's header, from -I<reference>/liblte/hdr -I<reference>/cmn_hdr
@@ -42,25 +43,28 @@ struct Entry {
     mi_lte_ctx *ctx = nullptr;
     std::mutex  mu;
 };
-std::mutex                         g_mu;
-std::map<LIBLTE_PHY_STRUCT *, Entry *> g_ctx;
+std::mutex                                            g_mu;
+std::map<LIBLTE_PHY_STRUCT *, std::shared_ptr<Entry>> g_ctx;
 
-Entry *entry_for(LIBLTE_PHY_STRUCT *phy)
+// The entry is SHARED between the table and every call that is using it: liblte_phy_cleanup on another thread takes it out of the table and
+// destroys the context under the entry's mutex, but the Entry (and its mutex) lives until the last caller lets go -- a late caller then
+// finds ctx == nullptr and fails with the reference's error instead of touching freed state.
+std::shared_ptr<Entry> entry_for(LIBLTE_PHY_STRUCT *phy)
 {
     std::lock_guard<std::mutex> lk(g_mu);
     auto                        it = g_ctx.find(phy);
     if (it != g_ctx.end()) return it->second;
-    Entry      *e  = new Entry();
+    auto        e  = std::make_shared<Entry>();
     const char *dv = getenv("MI_LTE_DEVICE");
     if (mi_lte_ctx_create(dv ? atoi(dv) : 0, &e->ctx) != MI_LTE_OK) e->ctx = nullptr; // no GPU: every call below fails loudly
     g_ctx[phy] = e;
     return e;
 }
-// the context of a struct, locked for the duration of the enclosing call
+// the context of a struct, locked for the duration of the enclosing call (the test of ctx is made under the lock: cleanup nulls it there)
 #define MI_LOCKED_CTX(phy, fail)                                                                                                   \
-    Entry *entry_ = entry_for(phy);                                                                                                \
-    if (!entry_->ctx) return fail;                                                                                                 \
+    std::shared_ptr<Entry> entry_ = entry_for(phy);                                                                                \
     std::lock_guard<std::mutex> call_lock_(entry_->mu);                                                                            \
+    if (!entry_->ctx) return fail;                                                                                                 \
     mi_lte_ctx *c = entry_->ctx
 
 void to_mi_alloc(const LIBLTE_PHY_ALLOCATION_STRUCT *a, mi_lte_pdsch_alloc *o)
@@ -83,7 +87,7 @@ void to_mi_alloc(const LIBLTE_PHY_ALLOCATION_STRUCT *a, mi_lte_pdsch_alloc *o)
 LIBLTE_ERROR_ENUM liblte_phy_cleanup_cpu(LIBLTE_PHY_STRUCT *phy_struct);
 LIBLTE_ERROR_ENUM liblte_phy_cleanup(LIBLTE_PHY_STRUCT *phy_struct)
 {
-    Entry *e = nullptr;
+    std::shared_ptr<Entry> e;
     {
         std::lock_guard<std::mutex> lk(g_mu);
         auto                        it = g_ctx.find(phy_struct);
@@ -100,8 +104,8 @@ LIBLTE_ERROR_ENUM liblte_phy_cleanup(LIBLTE_PHY_STRUCT *phy_struct)
                         (unsigned long long)upload, plans);
             }
             if (e->ctx) mi_lte_ctx_destroy(e->ctx);
+            e->ctx = nullptr; // a caller that was blocked on the mutex, or still holds the entry, fails cleanly
         }
-        delete e;
     }
     return liblte_phy_cleanup_cpu(phy_struct);
 }

@@ -1028,9 +1028,13 @@ def roofline_of(wl, prof, steps):
         traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % wl.name)))["bytes_per_launch"].get({"k_ul_fft": "k_dl_fft"}.get(dom, dom))
     except Exception:
         pass
+    st_ms = sum(prof[k][1] for k in acc["stages"][stage_of[dom]][1] if k in prof) / steps if dom in stage_of else tot_ms / steps
     return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": lps, "algorithmic_bytes_per_launch": st_bytes / lps,
-            "stage": stage_of.get(dom, "whole path")}, {k: round(ms / steps, 4) for k, (nl, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1])}
+            "stage": stage_of.get(dom, "whole path"),
+            # the same bytes over ALL of the stage's kernels (the stricter reading when the dominant kernel is only part of its stage)
+            "stage_ms_per_step": round(st_ms, 4), "stage_frac": round(st_bytes / (st_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}, \
+           {k: round(ms / steps, 4) for k, (nl, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1])}
 
 
 def config_leg(cls, ctx, steps, cpu_budget_s):

@@ -85,8 +85,6 @@ def draw_dl_cases(n, seed, bw_weights=(3, 3, 3, 2, 2, 3), big_share=0.06):
             prb1 = sorted(int(x) for x in rng.choice(n_rb, n_prb, replace=False))
         m_re = re_count(n_rb, n_ant, cell, sf, n_sym, prb0, prb1)
         e = m_re * qm
-        if e < 3 * 44:
-            continue
         # transport block
         t = rng.random()
         if t < 0.62:      # E >= 3(K+4): what the reference's decoder is built for
@@ -196,7 +194,10 @@ def draw_ul_groups(n_groups, seed, units_per_group=6):
                 e = 12 * 12 * w * 2
                 fit = [t for t in SIZES if 3 * (t + 28) <= e]
                 tbs = int(fit[-1 - int(rng.integers(0, min(6, len(fit))))]) if rng.random() < 0.8 else int(fit[int(rng.integers(0, len(fit)))])
-                allocs.append((u, 1, tbs, list(range(start, start + w)), 0x100 + 16 * u + a))
+                # QPSK is what the reference's uplink receiver decodes (its transform pre-decoding scales by 12 N_prb: 16QAM / 64QAM lose their
+                # inner bits and fail the CRC) -- one allocation in eight is 16QAM or 64QAM all the same: both sides must fail alike
+                mod = int(rng.choice([1, 1, 1, 1, 1, 1, 1, 2, 3][a % 2:])) if rng.random() < 0.25 else 1
+                allocs.append((u, mod, tbs, list(range(start, start + w)), 0x100 + 16 * u + a))
                 pos = start + w
         groups.append(dict(fs=fs, fft=fft, n_rb=n_rb, cell=cell, ulc=ulc, sfs=sfs, snr=float(rng.choice([25.0, 12.0, 4.0])), n_ue=n_ue, allocs=allocs,
                            seed=int(seed * 7919 + g)))
@@ -239,7 +240,7 @@ def run_ref_ul(R, groups):
         g["_u0"], g["_a0"] = u0, a0
         u0 += len(g["sfs"])
         a0 += len(g["allocs"])
-    soft_cap = max(12 * 12 * len(a[3]) * 2 for g in groups for a in g["allocs"])
+    soft_cap = max(12 * 12 * len(a[3]) * (1, 2, 4, 6)[a[1]] for g in groups for a in g["allocs"])
     symb = np.zeros((n_units, 2, 14, 1200), np.float32)
     soft, bits = np.zeros((n_allocs, soft_cap), np.int8), np.zeros((n_allocs, 6200), np.uint8)
     rc = R.ref_ul_cases_run(C.cast(units, C.c_void_p), n_units, C.cast(allocs, C.c_void_p), n_allocs, iq.ctypes.data, stride, symb.ctypes.data,

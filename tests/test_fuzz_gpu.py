@@ -218,3 +218,53 @@ def test_uplink_fuzz_against_the_compiled_reference(ctx, ref):
     assert not bad, bad[:10]
     assert n_soft_diff <= 1e-5 * n_soft and len(soft_diff) <= 0.005 * n_alloc, (n_soft_diff, n_soft, soft_diff[:10])
     assert n_ok >= 0.4 * n_alloc
+
+
+def test_control_region_fuzz_against_the_compiled_reference(ctx, ref):
+    """PCFICH + PDCCH common search space on ~3 800 random control regions -- six bandwidths x 1 / 2 / 4 ports, random cells,
+    subframes, CFIs, 0-3 DCIs per subframe with random RNTI / MCS / allocation, two noise levels (at the lower one part of what is decoded is
+    noise) -- in the reference-parity mode (the reference's own arithmetic, port-stride slip included, include/mi_lte.h): return code, CFI,
+    N_symbs, and every field of every allocation must equal liblte_phy_pdcch_channel_decode's on a fresh LIBLTE_PHY_STRUCT, unit by unit.
+    One kernel launch per configuration; the reference runs on the host cores."""
+    import openlte_amd as m
+    from openlte_amd import synth
+    configs = [(128, 6, 1), (128, 6, 2), (256, 15, 1), (256, 15, 4), (512, 25, 2), (512, 25, 1), (1024, 50, 1), (1024, 50, 2), (2048, 75, 4), (2048, 75, 1),
+               (2048, 100, 1), (2048, 100, 2)]
+    n, total, n_dci, bad = 320, 0, 0, []
+    rntis = [0xFFFF, 0xFFFE] + list(range(1, 0x3D))
+    for ci, (fft, nrb, n_ant) in enumerate(configs):
+        rng = np.random.default_rng(900 + ci)
+        cells = [int(c) for c in rng.choice(504, 6, replace=False)]
+        cfg = m.DlCfg(fft, nrb, n_ant, 0)
+        sfs, cell = rng.integers(0, 10, n), rng.choice(cells, n)
+        cfis = rng.integers(1, 4, n)
+        dcis = []
+        for u in range(n):
+            lst = []
+            for r in rng.choice(rntis, int(rng.integers(0, 4 if nrb > 6 else 2)), replace=False):
+                npb = int(rng.integers(1, min(nrb // 2, 8) + 1))
+                lst.append((int(r), int(rng.integers(0, 27)), npb, int(rng.integers(0, nrb - npb + 1)), int(rng.integers(0, 4))))
+            dcis.append(lst)
+        half = n // 2
+        g = np.concatenate([synth.ctrl_grids(cfg, sfs[:half], cell[:half], cfis[:half], dcis[:half], snr_db=14.0, seed=ci),
+                            synth.ctrl_grids(cfg, sfs[half:], cell[half:], cfis[half:], dcis[half:], snr_db=1.0, seed=100 + ci)])
+        plan = ctx.pdcch_plan(cfg, cells, 1.0)  # reference-parity mode
+        d_g, d_sf, d_cell = ctx.to_device(g), ctx.to_device(sfs.astype(np.uint32)), ctx.to_device(cell.astype(np.uint32))
+        rc, cfi, nsym, got = plan.decode_dev(d_g, d_sf, d_cell, n)
+        for d in (d_g, d_sf, d_cell):
+            d.free()
+        plan.close()
+
+        def ref_unit(u):
+            return td.ref_pdcch_decode(ref, dict(fft=fft, nrb=nrb, n_ant=n_ant, cell=int(cell[u]), phich_res=1.0, sfs=[int(sfs[u])], grids=g[u:u + 1]))[0]
+        want = td.parallel_map(ref_unit, range(n), threads=min(32, fz.n_threads()))
+        for u, (w_rc, w_cfi, w_nsym, recs) in enumerate(want):
+            mine = (int(rc[u]), int(cfi[u]), int(nsym[u]), td.dci_records(got[u]))
+            if mine != (w_rc, w_cfi, w_nsym, recs):
+                bad.append((fft, nrb, n_ant, u, int(cell[u]), int(sfs[u]), int(cfis[u]), mine[:3], (w_rc, w_cfi, w_nsym)))
+            n_dci += len(recs)
+        total += n
+    REPORT["control_region"] = dict(subframes=total, configurations=len(configs), dcis_found_by_both=n_dci, mismatches=[list(map(str, b)) for b in bad[:50]])
+    write_report()
+    assert total >= 3800 and not bad, bad[:10]
+    assert n_dci >= total // 6

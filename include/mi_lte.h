@@ -473,6 +473,23 @@ int mi_lte_freq_shift_run(mi_lte_ctx *ctx, float *d_i_samps, float *d_q_samps, u
  * "one call at a time per LIBLTE_PHY_STRUCT" (SURVEY 8b). */
 int mi_lte_host_cache_stats(mi_lte_ctx *ctx, uint64_t *n_subframe_reuse, uint64_t *n_subframe_upload, uint32_t *n_plans);
 int mi_lte_host_cache_invalidate(mi_lte_ctx *ctx);
+/* The explicit contract instead of the hash: in MI_LTE_HOST_CACHE_EXPLICIT mode the copy in HBM counts as current for as long as the
+ * decoders are handed the same arrays (rx_symb_re's address, same port count) -- a caller that changes a subframe's contents between
+ * decodes says so with mi_lte_host_cache_invalidate.  What LTE_fdd_dl_fs_samp_buf.cc does (it never touches a subframe between
+ * get_dl_subframe_and_ce and the decodes) qualifies; the default, MI_LTE_HOST_CACHE_FINGERPRINT, is safe for any caller. */
+enum { MI_LTE_HOST_CACHE_FINGERPRINT = 0, MI_LTE_HOST_CACHE_EXPLICIT = 1 };
+int mi_lte_host_cache_set_mode(mi_lte_ctx *ctx, uint32_t mode);
+/* One subframe in one call: the work of liblte_phy_get_dl_subframe_and_ce + liblte_phy_pdcch_channel_decode +
+ * liblte_phy_pdsch_channel_decode for every DCI found (the loop at LTE_fdd_dl_fs_samp_buf.cc:445-515), arguments as those calls take
+ * them.  The subframe stays in HBM (no LIBLTE_PHY_SUBFRAME_STRUCT comes back), the host waits twice.  Returns what
+ * liblte_phy_pdcch_channel_decode would (0, 1, 2) or MI_LTE_* < 0; on 0, dci[k] (k < *N_dci) is decoded into
+ * h_out_bits + k * out_stride (out_stride >= 6120) with status[k] = 0 and N_out_bits[k] = tbs, or status[k] = 2 and nothing
+ * written (CRC mismatch, or a transport block outside the single-code-block envelope). */
+int mi_lte_dl_subframe_decode_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_dl, const float *h_i_samps, const float *h_q_samps,
+                                   uint32_t frame_start_idx, uint32_t subfr_num, uint32_t N_id_cell, uint32_t N_ant, float phich_res,
+                                   uint32_t phich_dur_extended, uint32_t flags, uint32_t *cfi, uint32_t *N_symbs, uint32_t *N_dci,
+                                   mi_lte_pdcch_dci *dci /* [MI_LTE_PDCCH_MAX_DCI] */, uint8_t *h_out_bits, uint32_t out_stride,
+                                   uint32_t *N_out_bits /* [MI_LTE_PDCCH_MAX_DCI] */, int32_t *status /* [MI_LTE_PDCCH_MAX_DCI] */);
 int mi_lte_get_dl_subframe_and_ce_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_dl, const float *h_i_samps,
                                        const float *h_q_samps, uint32_t frame_start_idx, uint32_t subfr_num,
                                        uint32_t N_id_cell, uint32_t N_ant, float *h_rx_symb_re /*[16][1200]*/,

@@ -356,27 +356,38 @@ static int plan_layout(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, uint32_t N_pdcch_
     pl->n_alloc   = n_alloc;
     pl->max_pairs = pl->max_words = 0;
     pl->groups.clear();
-    std::map<uint32_t, std::vector<uint32_t>> byK;
-    std::map<uint32_t, uint32_t>              emaxK;
+    // two passes and a counting sort by code-block size (188 sizes): a capture's chunk re-plans tens of thousands of allocations per call
+    static_assert(LTE_QPP_N_SIZES <= 256, "size index fits a byte");
+    uint32_t cnt[LTE_QPP_N_SIZES] = {0}, emax[LTE_QPP_N_SIZES] = {0};
+    std::vector<uint8_t> kidx(n_alloc);
     uint32_t max_tbs = 0;
     size_t   off = 0;
     pl->h_e_off.resize(n_alloc);
     for (uint32_t a = 0; a < n_alloc; a++) {
         const mi_lte_pdsch_alloc &al = h_allocs[a];
-        const uint32_t B = al.tbs + 24, K = (B <= 6144) ? qpp_size_at_least(B) : 0;
+        const uint32_t B = al.tbs + 24;
+        int            r = -1;
+        if (B <= 6144) { // first size >= B: the sizes step by 8, 16, 32, 64 (36.212 table 5.1.3-3)
+            r = B <= 40 ? 0 : B <= 512 ? (int)((B - 40 + 7) / 8) : B <= 1024 ? 59 + (int)((B - 512 + 15) / 16) : B <= 2048 ? 91 + (int)((B - 1024 + 31) / 32)
+                                                                                                                              : 123 + (int)((B - 2048 + 63) / 64);
+            if (r >= LTE_QPP_N_SIZES || LTE_QPP_ROWS[r].K < B || (r > 0 && LTE_QPP_ROWS[r - 1].K >= B)) r = -2; // (table and closed form disagree: fall back)
+            if (r == -2)
+                for (r = 0; r < LTE_QPP_N_SIZES && LTE_QPP_ROWS[r].K < B; r++) {}
+        }
         const uint32_t cfi = al.n_pdcch_symbs ? al.n_pdcch_symbs : N_pdcch_symbs;
-        if (K == 0 || al.N_prb == 0 || al.N_prb > cfg->N_rb_dl || al.mod_type > 3 || cfi < 1 || cfi > 4) {
+        if (r < 0 || r >= LTE_QPP_N_SIZES || al.N_prb == 0 || al.N_prb > cfg->N_rb_dl || al.mod_type > 3 || cfi < 1 || cfi > 4) {
             // multi-code-block transport blocks: the reference's own C > 1 path is broken
             ctx->err = "allocation outside the single-code-block envelope (tbs + 24 > 6144) or malformed";
             return MI_LTE_ERR_UNSUPPORTED;
         }
-        byK[K].push_back(a);
+        kidx[a] = (uint8_t)r;
+        cnt[r]++;
         max_tbs = std::max(max_tbs, al.tbs);
         const uint32_t Qm = al.mod_type == 3 ? 6 : al.mod_type == 2 ? 4 : al.mod_type == 1 ? 2 : 1;
         const uint32_t pairs = (14 - cfi) * al.N_prb, e_max = pairs * 12 * Qm;
         pl->max_pairs = std::max(pl->max_pairs, pairs);
         pl->max_words = std::max(pl->max_words, (e_max + 31) / 32);
-        emaxK[K]       = std::max(emaxK[K], e_max);
+        emax[r]        = std::max(emax[r], e_max);
         pl->h_e_off[a] = (uint32_t)(off >> 6); // in 64-byte units
         off += (e_max + 63) & ~63u;
     }
@@ -388,11 +399,14 @@ static int plan_layout(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, uint32_t N_pdcch_
     pl->max_tbs    = max_tbs;
     const uint32_t st_tbs = (pl->dynamic || pl->wide) ? 6120u : max_tbs; // a dynamic plan keeps ONE output stride over its assignments: the largest single-code-block size
     pl->out_stride = pl->packed ? (((st_tbs + 7) / 8 + 63) & ~63u) : ((st_tbs + 63) & ~63u);
-    cb_alloc.clear();
-    for (auto &kv : byK) {
-        pl->groups.push_back({kv.first, (uint32_t)kv.second.size(), (uint32_t)cb_alloc.size(), emaxK[kv.first]});
-        cb_alloc.insert(cb_alloc.end(), kv.second.begin(), kv.second.end());
+    cb_alloc.resize(n_alloc);
+    uint32_t base[LTE_QPP_N_SIZES], run = 0;
+    for (int r = 0; r < LTE_QPP_N_SIZES; r++) { // groups in ascending block size, allocations inside a group in their own order
+        base[r] = run;
+        if (cnt[r]) pl->groups.push_back({LTE_QPP_ROWS[r].K, cnt[r], run, emax[r]});
+        run += cnt[r];
     }
+    for (uint32_t a = 0; a < n_alloc; a++) cb_alloc[base[kidx[a]]++] = a;
     return MI_LTE_OK;
 }
 

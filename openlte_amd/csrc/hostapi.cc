@@ -78,6 +78,11 @@ struct HostCache {
     bool         sub_ul = false;
     uint64_t     sub_fp = 0;
     uint64_t     n_reuse = 0, n_upload = 0; // statistics (mi_lte_host_cache_stats)
+    bool         trust_address = false;     // mi_lte_host_cache_set_mode: the caller announces changes with mi_lte_host_cache_invalidate, nothing is hashed
+    // the one-call-per-subframe form's own plan and result block (mi_lte_dl_subframe_decode_host)
+    mi_lte_pdsch_plan *sf_plan = nullptr;
+    mi_lte_dl_cfg      sf_cfg  = {0, 0, 0, 0};
+    uint8_t           *h_sf_res = nullptr, *d_sf_res = nullptr; // MI_LTE_PDCCH_MAX_DCI verdicts at byte 0, the blocks' bits from byte 64 at the plan's stride
     PlanCache<mi_lte_pdsch_plan> pdsch{mi_lte_pdsch_plan_destroy, 64};
     PlanCache<mi_lte_pdcch_plan> pdcch{mi_lte_pdcch_plan_destroy, 8};
     PlanCache<mi_lte_pusch_plan> pusch{mi_lte_pusch_plan_destroy, 64};
@@ -90,6 +95,8 @@ void host_cache_free(mi_lte_ctx *ctx)
     if (!hc) return;
     (void)hipStreamSynchronize(ctx->stream);
     hc->pdsch.clear(ctx); hc->pdcch.clear(ctx); hc->pusch.clear(ctx); hc->prach.clear(ctx);
+    if (hc->sf_plan) mi_lte_pdsch_plan_destroy(ctx, hc->sf_plan);
+    if (hc->h_sf_res) (void)hipHostFree(hc->h_sf_res);
     if (hc->h_pin) (void)hipHostFree(hc->h_pin);
     (void)hipFree(hc->d_in); (void)hipFree(hc->d_sub);
     if (hc->h_par) (void)hipHostFree(hc->h_par);
@@ -334,8 +341,9 @@ int fail_after_launch(mi_lte_ctx *ctx, HostCache *hc, int rc)
 // copy this context produced (or uploaded) last and the arrays have not changed since
 int bind_subframe(mi_lte_ctx *ctx, HostCache *hc, const float *re, const float *im, const float *ce_re, const float *ce_im, uint32_t n_ant, uint32_t n_sc, bool ul)
 {
-    const uint32_t rows = ul ? 14 : 16;
-    const uint64_t fp = subframe_fp(re, im, ce_re, ce_im, ul ? 0 : n_ant, n_sc, ul ? 14 : 14);
+    // explicit contract (mi_lte_host_cache_set_mode): same arrays, same layout, no invalidate since = the device copy is current
+    if (hc->trust_address && hc->sub_host == re && hc->sub_n_ant == n_ant && hc->sub_ul == ul) { hc->n_reuse++; return MI_LTE_OK; }
+    const uint64_t fp = hc->trust_address ? 0 : subframe_fp(re, im, ce_re, ce_im, ul ? 0 : n_ant, n_sc, 14);
     if (hc->sub_host == re && hc->sub_n_ant == n_ant && hc->sub_ul == ul && hc->sub_fp == fp) { hc->n_reuse++; return MI_LTE_OK; }
     const size_t planes = ul ? 2 : 2 + 2 * (size_t)n_ant, bytes = planes * ROW * 4;
     int rc = need_pin(ctx, hc, bytes);
@@ -348,7 +356,6 @@ int bind_subframe(mi_lte_ctx *ctx, HostCache *hc, const float *re, const float *
         memcpy(st + 2 * ROW, ce_re, n_ant * ROW * 4);
         memcpy(st + (2 + n_ant) * ROW, ce_im, n_ant * ROW * 4);
     }
-    (void)rows;
     MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->d_sub, st, bytes, hipMemcpyHostToDevice, ctx->stream));
     hc->sub_host = re; hc->sub_n_ant = n_ant; hc->sub_ul = ul; hc->sub_fp = fp;
     hc->n_upload++;
@@ -371,6 +378,17 @@ int mi_lte_host_cache_invalidate(mi_lte_ctx *ctx)
 {
     if (!ctx) return MI_LTE_ERR_INVALID_ARG;
     if (ctx->host_cache) ((HostCache *)ctx->host_cache)->sub_host = nullptr;
+    return MI_LTE_OK;
+}
+int mi_lte_host_cache_set_mode(mi_lte_ctx *ctx, uint32_t mode)
+{
+    if (!ctx || mode > MI_LTE_HOST_CACHE_EXPLICIT) return MI_LTE_ERR_INVALID_ARG;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    HostCache *hc;
+    int        rc = host_cache(ctx, &hc);
+    if (rc != MI_LTE_OK) return rc;
+    hc->trust_address = mode == MI_LTE_HOST_CACHE_EXPLICIT;
+    hc->sub_host      = nullptr; // whatever was mirrored under the other rule is not carried over
     return MI_LTE_OK;
 }
 
@@ -421,7 +439,103 @@ int mi_lte_get_dl_subframe_and_ce_host(mi_lte_ctx *ctx, uint32_t fft_size, uint3
         unpack_rows(h_ce_im + p * ROW, st, 2 + N_ant + p, 14, n_sc);
     }
     hc->sub_host = h_symb_re; hc->sub_n_ant = N_ant; hc->sub_ul = false;
-    hc->sub_fp = subframe_fp(h_symb_re, h_symb_im, h_ce_re, h_ce_im, N_ant, n_sc, 14);
+    hc->sub_fp = hc->trust_address ? 0 : subframe_fp(h_symb_re, h_symb_im, h_ce_re, h_ce_im, N_ant, n_sc, 14);
+    return 0;
+}
+
+// One subframe, one call: what LTE_fdd_dl_fs_samp_buf.cc:445-515 does with three or more calls of the reference API (get_dl_subframe_and_ce,
+// pdcch_channel_decode, pdsch_channel_decode per DCI found) -- the subframe never leaves HBM, nothing is hashed, and the host waits twice
+// (for the DCIs, which it needs to lay the PDSCH work out, and for the transport blocks) instead of 2 + N_dci times plus a 300-770 KB copy back.
+int mi_lte_dl_subframe_decode_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_dl, const float *h_i, const float *h_q, uint32_t frame_start_idx,
+                                   uint32_t subfr_num, uint32_t N_id_cell, uint32_t N_ant, float phich_res, uint32_t phich_dur_extended, uint32_t flags,
+                                   uint32_t *cfi, uint32_t *N_symbs, uint32_t *N_dci, mi_lte_pdcch_dci *dci, uint8_t *h_out_bits, uint32_t out_stride,
+                                   uint32_t *N_out_bits, int32_t *status)
+{
+    if (!ctx) return MI_LTE_ERR_INVALID_ARG;
+    if (!h_i || !h_q || !(N_ant == 1 || N_ant == 2 || N_ant == 4) || N_id_cell > 503 || subfr_num > 9 || !cfi || !N_symbs || !N_dci || !dci || !h_out_bits ||
+        !N_out_bits || !status || !valid_fft(fft_size, N_rb_dl))
+        return 1;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    HostCache *hc;
+    int        rc = host_cache(ctx, &hc);
+    if (rc != MI_LTE_OK) return rc;
+    const mi_lte_dl_cfg cfg = {fft_size, N_rb_dl, N_ant, MI_LTE_IQ_F32_PLANAR};
+    // plans: the control region's by what it was built from, ONE dynamic PDSCH plan per carrier configuration, re-planned per subframe
+    std::string key;
+    key_add(key, cfg); key_add(key, phich_res); key_add(key, phich_dur_extended); key_add(key, flags); key_add(key, N_id_cell);
+    mi_lte_pdcch_plan *cplan = hc->pdcch.find(key);
+    if (!cplan) {
+        rc = mi_lte_pdcch_plan_create(ctx, &cfg, phich_res, phich_dur_extended, flags, &N_id_cell, 1, &cplan);
+        if (rc != MI_LTE_OK) return rc;
+        hc->pdcch.put(ctx, key, cplan);
+    }
+    if (!hc->sf_plan || memcmp(&hc->sf_cfg, &cfg, sizeof(cfg)) != 0) {
+        MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
+        if (hc->sf_plan) mi_lte_pdsch_plan_destroy(ctx, hc->sf_plan);
+        hc->sf_plan = nullptr;
+        const size_t soft = (size_t)MI_LTE_PDCCH_MAX_DCI * (((size_t)13 * N_rb_dl * 12 * 6 + 63) & ~(size_t)63);
+        rc = mi_lte_pdsch_plan_create_dynamic(ctx, &cfg, MI_LTE_PDCCH_MAX_DCI, soft, &hc->sf_plan);
+        if (rc != MI_LTE_OK) return rc;
+        hc->sf_cfg = cfg;
+    }
+    const uint32_t stride = mi_lte_pdsch_plan_out_stride(hc->sf_plan);
+    if (!hc->h_sf_res) {
+        MI_HIP_CHECK(ctx, hipHostMalloc((void **)&hc->h_sf_res, 64 + (size_t)MI_LTE_PDCCH_MAX_DCI * 6144, hipHostMallocMapped | hipHostMallocCoherent));
+        MI_HIP_CHECK(ctx, hipHostGetDevicePointer((void **)&hc->d_sf_res, hc->h_sf_res, 0));
+    }
+    if (stride > 6144 || out_stride < 6120) return MI_LTE_ERR_INVALID_ARG;
+
+    // samples -> device subframe, as in mi_lte_get_dl_subframe_and_ce_host (the FFT kernel reads the mapped staging buffer)
+    const uint32_t sc = 2048 / fft_size;
+    const size_t   per_sf = 30720 / sc, need = per_sf + 2 * fft_size + 160 / sc + 144 / sc - 1;
+    const size_t   start = (size_t)frame_start_idx + (size_t)subfr_num * per_sf;
+    const size_t   nb = 2 * need * 4;
+    rc = need_pin(ctx, hc, nb + 16);
+    if (rc != MI_LTE_OK) return rc;
+    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
+    memcpy(hc->h_pin, h_i + start, need * 4);
+    memcpy(hc->h_pin + need * 4, h_q + start, need * 4);
+    struct { uint64_t start; uint32_t sf, cell; } par = {0, subfr_num, N_id_cell};
+    memcpy(hc->h_pin + nb, &par, sizeof(par));
+    uint8_t *d_src;
+    MI_HIP_CHECK(ctx, hipHostGetDevicePointer((void **)&d_src, hc->h_pin, 0));
+    const uint32_t *d_p = (const uint32_t *)(d_src + nb);
+    hc->sub_host = nullptr; // d_sub is being rewritten, and mirrors no host struct afterwards
+    rc = mi_lte_dl_frontend_batch(ctx, &cfg, d_src, d_src + need * 4, (const uint64_t *)d_p, d_p + 2, d_p + 3, 1, hc->d_sub);
+    if (rc != MI_LTE_OK) return fail_after_launch(ctx, hc, rc);
+    rc = bind_params(ctx, hc, subfr_num, N_id_cell);
+    if (rc != MI_LTE_OK) return fail_after_launch(ctx, hc, rc);
+    uint32_t h_rc = 1;
+    *N_dci = 0;
+    rc = mi_lte_pdcch_decode_run(ctx, cplan, hc->d_sub, hc->d_par + 4, hc->d_par + 5, 1, &h_rc, cfi, N_symbs, N_dci, dci); // (first wait)
+    if (rc != MI_LTE_OK) return fail_after_launch(ctx, hc, rc);
+    if (h_rc != 0) return (int)h_rc; // no PCFICH / no DCI: what liblte_phy_pdcch_channel_decode reports
+    // every DCI's transport block in one decode; the ones outside the single-code-block envelope report a decode failure, as the
+    // per-allocation form does
+    mi_lte_pdsch_alloc al[MI_LTE_PDCCH_MAX_DCI];
+    uint32_t           slot[MI_LTE_PDCCH_MAX_DCI], n_al = 0;
+    for (uint32_t k = 0; k < *N_dci && k < MI_LTE_PDCCH_MAX_DCI; k++) {
+        status[k] = 2; N_out_bits[k] = 0;
+        const mi_lte_pdsch_alloc &a = dci[k].alloc;
+        if (a.tbs + 24 > 6144 || a.tbs == 0 || a.N_prb == 0 || a.N_prb > N_rb_dl || a.mod_type > 3) continue;
+        al[n_al] = a; al[n_al].unit = 0; al[n_al].n_pdcch_symbs = *N_symbs;
+        slot[n_al++] = k;
+    }
+    if (n_al == 0) return 0;
+    rc = mi_lte_pdsch_plan_assign(ctx, hc->sf_plan, *N_symbs, al, n_al);
+    if (rc != MI_LTE_OK) return rc == MI_LTE_ERR_UNSUPPORTED ? 0 : fail_after_launch(ctx, hc, rc);
+    rc = mi_lte_pdsch_decode_run(ctx, hc->sf_plan, hc->d_sub, hc->d_par + 4, hc->d_par + 5, hc->d_sf_res + 64, (int32_t *)hc->d_sf_res);
+    if (rc != MI_LTE_OK) return fail_after_launch(ctx, hc, rc);
+    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx)); // (second wait)
+    for (uint32_t j = 0; j < n_al; j++) {
+        int32_t st;
+        memcpy(&st, hc->h_sf_res + 4 * j, 4);
+        status[slot[j]] = st;
+        if (st == 0) {
+            memcpy(h_out_bits + (size_t)slot[j] * out_stride, hc->h_sf_res + 64 + (size_t)j * stride, al[j].tbs);
+            N_out_bits[slot[j]] = al[j].tbs;
+        }
+    }
     return 0;
 }
 

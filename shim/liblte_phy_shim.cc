@@ -57,6 +57,9 @@ std::shared_ptr<Entry> entry_for(LIBLTE_PHY_STRUCT *phy)
     auto        e  = std::make_shared<Entry>();
     const char *dv = getenv("MI_LTE_DEVICE");
     if (mi_lte_ctx_create(dv ? atoi(dv) : 0, &e->ctx) != MI_LTE_OK) e->ctx = nullptr; // no GPU: every call below fails loudly
+    // a caller that never writes into a LIBLTE_PHY_SUBFRAME_STRUCT between the front end and the decodes (LTE_fdd_dl_fs_samp_buf.cc does not)
+    // can say so: the decodes then take the copy in HBM on the struct's address alone instead of hashing its contents
+    if (e->ctx && getenv("MI_LTE_SHIM_EXPLICIT_CACHE")) mi_lte_host_cache_set_mode(e->ctx, MI_LTE_HOST_CACHE_EXPLICIT);
     g_ctx[phy] = e;
     return e;
 }

@@ -293,3 +293,99 @@ def test_batch_scanner_with_carrier_offset_matches_reference_output(tmp_path, n_
     with open(os.path.join(ROOT, "gpurun_out", "scan_batch_timing_%drb.txt" % n_rb), "w") as f:
         f.write("scan_batch %s" % got.stderr)
         f.write("scan_cpu   %s" % want.stderr)
+
+
+@pytest.mark.parametrize("n_rb,fft,cell,frames,mode", [(25, 512, 301, 4, 0), (100, 2048, 77, 4, 1), (6, 128, 17, 8, 1)])
+def test_one_call_per_subframe_equals_the_per_call_sequence(tmp_path, n_rb, fft, cell, frames, mode):
+    """mi_lte_dl_subframe_decode_host == mi_lte_get_dl_subframe_and_ce_host + mi_lte_pdcch_channel_decode_host +
+    mi_lte_pdsch_channel_decode_host per DCI (the loop of LTE_fdd_dl_fs_samp_buf.cc:445-515; those three are pinned to the reference's
+    output by the scan tests above) on every subframe of a capture written by the reference's transmitter: same return value, control
+    format, DCIs, verdicts and transport blocks.  mode 1 runs the per-call sequence under the explicit cache contract
+    (mi_lte_host_cache_set_mode): nothing is hashed, every decode still reads the copy the front end left in HBM."""
+    import ctypes as C
+    import openlte_amd as m
+    from openlte_amd.lib import PdcchDci
+    gen = os.path.join(ROOT, "shim", "_build", "capture_gen")
+    if not os.path.exists(gen):
+        pytest.skip("shim/_build/capture_gen not built (needs the reference tree at build time)")
+    cap = os.path.join(str(tmp_path), "capture.bin")
+    subprocess.run([gen, cap, str(n_rb), str(cell), str(frames)], check=True, timeout=600)
+    raw = np.fromfile(cap, np.int8)
+    per_sf = 15 * fft
+    i_s = np.zeros(len(raw) // 2 + 4 * fft, np.float32)
+    q_s = np.zeros_like(i_s)
+    i_s[:len(raw) // 2], q_s[:len(raw) // 2] = raw[0::2], raw[1::2]
+    ctx = m.Context(0)
+    L = ctx.L
+    f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+    u32 = C.c_uint32
+    L.mi_lte_get_dl_subframe_and_ce_host.argtypes = [C.c_void_p, u32, u32, f32p, f32p] + [u32] * 4 + [f32p] * 4
+    L.mi_lte_pdcch_channel_decode_host.argtypes = [C.c_void_p, u32, f32p, f32p, f32p, f32p, u32, u32, u32, C.c_float, u32, u32] + [C.POINTER(u32)] * 3 + [C.POINTER(PdcchDci)]
+    L.mi_lte_pdsch_channel_decode_host.argtypes = [C.c_void_p, u32, f32p, f32p, f32p, f32p, u32, C.c_void_p, u32, u32, u32,
+                                                   np.ctypeslib.ndpointer(np.uint8), C.POINTER(u32)]
+    L.mi_lte_dl_subframe_decode_host.argtypes = [C.c_void_p, u32, u32, f32p, f32p] + [u32] * 4 + [C.c_float, u32, u32] + [C.POINTER(u32)] * 3 + [
+        C.POINTER(PdcchDci), np.ctypeslib.ndpointer(np.uint8), u32, C.POINTER(u32), C.POINTER(C.c_int32)]
+    L.mi_lte_host_cache_set_mode.argtypes = [C.c_void_p, u32]
+    L.mi_lte_host_cache_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(u32)]
+    assert L.mi_lte_host_cache_set_mode(ctx.h, 2) != 0
+    assert L.mi_lte_host_cache_set_mode(ctx.h, mode) == 0
+    sr, si = np.zeros((16, 1200), np.float32), np.zeros((16, 1200), np.float32)
+    cr, ci = np.zeros((4, 16, 1200), np.float32), np.zeros((4, 16, 1200), np.float32)
+    n_blocks = n_found = 0
+    for f in range(frames - 1):
+        for sf in range(10):
+            start = f * 10 * per_sf
+            # the per-call sequence
+            assert 0 == L.mi_lte_get_dl_subframe_and_ce_host(ctx.h, fft, n_rb, i_s, q_s, start, sf, cell, 1, sr, si, cr, ci)
+            cfi, nsym, ndci = u32(), u32(), u32()
+            dci = (PdcchDci * 6)()
+            rc_a = L.mi_lte_pdcch_channel_decode_host(ctx.h, n_rb, sr, si, cr, ci, sf, cell, 1, 1.0, 0, 0, C.byref(cfi), C.byref(nsym), C.byref(ndci), dci)
+            blocks = []
+            if rc_a == 0:
+                for k in range(ndci.value):
+                    out, n = np.zeros(6144, np.uint8), u32()
+                    rc = L.mi_lte_pdsch_channel_decode_host(ctx.h, n_rb, sr, si, cr, ci, sf, C.addressof(dci[k].alloc), nsym.value, cell, 1, out, C.byref(n))
+                    blocks.append((rc, out[:n.value].copy() if rc == 0 else None))
+            # one call
+            cfi2, nsym2, ndci2 = u32(), u32(), u32()
+            dci2 = (PdcchDci * 6)()
+            out2, n2, st2 = np.zeros((6, 6144), np.uint8), (u32 * 6)(), (C.c_int32 * 6)()
+            rc_b = L.mi_lte_dl_subframe_decode_host(ctx.h, fft, n_rb, i_s, q_s, start, sf, cell, 1, 1.0, 0, 0, C.byref(cfi2), C.byref(nsym2), C.byref(ndci2), dci2,
+                                                    out2.reshape(-1), 6144, n2, st2)
+            assert rc_b == rc_a, (f, sf, rc_a, rc_b, L.mi_lte_last_error(ctx.h))
+            if rc_a != 0:
+                continue
+            assert (cfi2.value, nsym2.value, ndci2.value) == (cfi.value, nsym.value, ndci.value)
+            n_found += ndci.value
+            for k in range(ndci.value):
+                assert bytes(dci2[k]) == bytes(dci[k]), (f, sf, k)
+                rc, bits = blocks[k]
+                assert st2[k] == rc, (f, sf, k, rc, st2[k])
+                if rc == 0:
+                    assert n2[k] == len(bits) and (out2[k, :n2[k]] == bits).all(), (f, sf, k)
+                    n_blocks += 1
+    # the capture carries SIB1 in subframe 5 of even frames and further system information behind it: something was decoded
+    assert n_found >= (frames - 1) // 2 and n_blocks >= (frames - 1) // 2, (n_found, n_blocks)
+    a, b, c = C.c_uint64(), C.c_uint64(), u32()
+    assert L.mi_lte_host_cache_stats(ctx.h, C.byref(a), C.byref(b), C.byref(c)) == 0
+    assert b.value == 0, "a decode of the per-call sequence uploaded the subframe its front end had just produced"
+
+
+def test_cell_scan_under_the_explicit_cache_contract(tmp_path):
+    """The 20 MHz scan through the shim with MI_LTE_SHIM_EXPLICIT_CACHE set (no content hash per decode call): same report."""
+    build = os.path.join(ROOT, "shim", "_build")
+    gen, scan_gpu = os.path.join(build, "capture_gen"), os.path.join(build, "scan_gpu")
+    if not (os.path.exists(gen) and os.path.exists(scan_gpu)):
+        pytest.skip("shim/_build/capture_gen / scan_gpu not built (need the reference tree at build time)")
+    cap = os.path.join(str(tmp_path), "capture.bin")
+    subprocess.run([gen, cap, "100", "77", "12"], check=True, timeout=600)
+    want = open(os.path.join(ROOT, "tests", "golden", "scan_100rb_reference_cpu.txt")).read()
+    runs = {}
+    for name, extra in (("fingerprint", {}), ("explicit", {"MI_LTE_SHIM_EXPLICIT_CACHE": "1"})):
+        got = subprocess.run([scan_gpu, cap, "30.72"], capture_output=True, text=True, timeout=900, env=dict(os.environ, MI_LTE_SHIM_STATS="1", **extra))
+        assert got.returncode == 0 and got.stdout == want, (name, got.stdout, got.stderr)
+        runs[name] = got.stderr
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "scan_timing_cache_modes.txt"), "w") as f:
+        for name, err in runs.items():
+            f.write("%s: %s" % (name, err))

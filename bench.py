@@ -75,6 +75,16 @@ def dist_setup(n_gpus):
     return rank, world, barrier, max_reduce
 
 
+def timing_ref(po):
+    """The compiled reference a cpu_baseline leg TIMES: the build against the single-precision FFT stand-in (oracle/ref/fftw_shim_f32.c:
+    Stockham radix 4 / mixed radix, what FFTW3f would pick, scalar) where it exists, else the parity build (float64 radix-2, slower than
+    the FFTW3f the reference really links).  Returns (library or None, the note for the sample string)."""
+    R = po.ref_f32fft()
+    if R is not None:
+        return R, "FFT = single-precision Stockham radix-4 / mixed-radix stand-in for FFTW3f (scalar C, gcc -O3)"
+    return po.ref(), "FFT = float64 radix-2 stand-in for FFTW3f (pessimistic for the transform's share)"
+
+
 def cpu_info():
     """(model string, logical CPUs this process may run on)."""
     model = "unknown CPU"
@@ -450,7 +460,7 @@ class ChainWorkload:
         from oracle import pyoracle as po
         import lte_testdata as td
         iq, tx, sfs, cells, allocs = self.uniq
-        R = po.ref()
+        R, fft_note = timing_ref(po)
         model, n_cpu = cpu_info()
         if R is None:  # no compiled reference on this machine: the plain-C restatement, one thread
             P = po.port()
@@ -499,8 +509,8 @@ class ChainWorkload:
         n1, t1, ok1 = worker(1, reps1)()()
         out = {"value": round(n1 / t1, 3), "unit": self.unit, "cores": 1, "kind": "reference", "cpu": model,
                "sample": "%d repetitions of one of the benchmark's subframes (liblte_phy_get_dl_subframe_and_ce + 9 x liblte_phy_pdsch_channel_decode, "
-                         "%d/%d CRC pass), 1 thread, %.1f s; FFT = float64 radix-2 stand-in for FFTW3f (pessimistic for the front-end share)"
-                         % (n1, ok1, 9 * n1, t1)}
+                         "%d/%d CRC pass), 1 thread, %.1f s; %s"
+                         % (n1, ok1, 9 * n1, t1, fft_note)}
         if n_cpu > 1:
             tot, wall, reps = all_cores_rate(worker, n_cpu, budget_s)
             out["all_cores"] = {"value": round(tot / wall, 2), "unit": self.unit, "cores": n_cpu, "kind": "reference", "cpu": model,
@@ -569,7 +579,7 @@ class FrontendWorkload:
     def cpu_baseline(self, budget_s=10.0):
         np = self.np
         from oracle import pyoracle as po
-        R = po.ref()
+        R, fft_note = timing_ref(po)
         iq, sfs, cells = self.uniq
         if R is None:
             return None
@@ -580,8 +590,7 @@ class FrontendWorkload:
         reps = int(max(100, budget_s / (t / 50)))
         t = R.ref_time_get_dl_subframe_and_ce(phy, re, im, 0, 0, int(cells[0]), self.N_ANT, sfp, reps)
         return {"value": round(reps / t, 2), "unit": self.unit, "cores": 1, "kind": "reference",
-                "sample": "%d calls of liblte_phy_get_dl_subframe_and_ce (N_ant = %d), 1 thread, %.1f s; FFT = float64 radix-2 stand-in for FFTW3f "
-                          "(pessimistic: the transform is most of this call)" % (reps, self.N_ANT, t)}
+                "sample": "%d calls of liblte_phy_get_dl_subframe_and_ce (N_ant = %d), 1 thread, %.1f s; %s" % (reps, self.N_ANT, t, fft_note)}
 
 
 class Frontend2Workload(FrontendWorkload):
@@ -691,7 +700,7 @@ class UplinkWorkload:
         import ctypes as C
         np = self.np
         from oracle import pyoracle as po
-        R = po.ref()
+        R, fft_note = timing_ref(po)
         if R is None:
             return None
         iq, tx, sfs, allocs = self.uniq
@@ -707,7 +716,7 @@ class UplinkWorkload:
         t = R.ref_time_pusch(phy, re, im, sfp, la, self.N_UE, self.cell, reps)
         return {"value": round(reps / t, 3), "unit": self.unit, "cores": 1, "kind": "reference",
                 "sample": "%d repetitions of one of the benchmark's subframes (get_ul_subframe + 16 x pusch_channel_decode), 1 thread, "
-                          "%.1f s; FFT/DFT = float64 stand-in for FFTW3f (O(n^2) for the 72-point DFTs)" % (reps, t)}
+                          "%.1f s; %s" % (reps, t, fft_note)}
 
 
 class ControlWorkload:

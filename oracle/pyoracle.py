@@ -151,6 +151,28 @@ def ref_big():
     return _REF_BIG
 
 
+_REF_F32 = False
+
+
+def ref_f32fft():
+    """The compiled reference linked against the single-precision FFT stand-in (oracle/ref/fftw_shim_f32.c): what bench.py's
+    cpu_baseline legs TIME.  No parity test goes through it.  None if it has not been built / shipped."""
+    global _REF_F32
+    if _REF_F32 is not False:
+        return _REF_F32
+    path = os.path.join(_HERE, "_ref", "libref_oracle_f32fft.so")
+    if not os.path.exists(path):
+        try:
+            if not build_ref() or not os.path.exists(path):
+                _REF_F32 = None
+                return None
+        except Exception:
+            _REF_F32 = None
+            return None
+    _REF_F32 = _bind_ref(C.CDLL(path))
+    return _REF_F32
+
+
 def ref():
     """The compiled reference, or None if oracle/_ref has not been built/shipped."""
     global _REF, _REF_TRIED

@@ -509,3 +509,53 @@ def test_bcjr_models_lose_little_against_a_full_trellis_max_log_map(port):
     assert 10 < lo[0] < n // 2 and hi[0] < lo[0], bler   # both points sit on the textbook decoder's waterfall
     assert hi[1] <= lo[0] and hi[2] <= lo[0] + 2, bler    # 0.2 dB up, the models lose no more blocks than the textbook decoder lost below: <= 0.2 dB
     assert hi[1] <= hi[0] + 12 and lo[1] <= lo[0] + 24, bler  # and the batch model stays within a few blocks of it at the same point
+
+
+def test_timing_fft_stand_in_agrees_with_the_parity_one(ref):
+    """oracle/ref/fftw_shim_f32.c (single precision: what bench.py's cpu_baseline legs time) against fftw_shim.c (float64 radix-2: what
+    every parity test uses) THROUGH the reference's own front ends: the downlink grid and estimates of a 20 MHz subframe
+    (liblte_phy_get_dl_subframe_and_ce: 2048-point transforms), the uplink grid (liblte_phy_get_ul_subframe) and the PRACH
+    root spectra made at init (839-point transforms: the mixed-radix / generic-prime path).  Single-precision rounding apart."""
+    from oracle import pyoracle as po
+    fast = po.ref_f32fft()
+    if fast is None:
+        pytest.skip("oracle/_ref/libref_oracle_f32fft.so not built")
+    rng = np.random.default_rng(5)
+    n = 30720 + 4400
+    i_f = np.ascontiguousarray(rng.integers(-90, 91, n).astype(np.float32))
+    q_f = np.ascontiguousarray(rng.integers(-90, 91, n).astype(np.float32))
+    outs = []
+    for R in (ref, fast):
+        phy, rx = R.ref_phy_new(4, 77, 2, 100), R.ref_subframe_new()
+        assert R.ref_get_dl_subframe_and_ce(phy, i_f, q_f, 0, 0, 77, 2, rx) == 0
+        dl = [po.ref_subframe_view(R, rx, w)[:14].copy() for w in (0, 1)] + [po.ref_subframe_view(R, rx, w, True)[:2, :14].copy() for w in (2, 3)]
+        assert R.ref_get_ul_subframe(phy, i_f, q_f, rx) == 0
+        ul = [po.ref_subframe_view(R, rx, w)[:14].copy() for w in (0, 1)]
+        R.ref_ul_init_prach(phy, 22, 0, 0, 1, 0)
+        roots = []
+        for r in range(min(R.ref_prach_n_roots(phy), 3)):
+            a, b = np.zeros(839, np.float32), np.zeros(839, np.float32)
+            R.ref_get_prach_root_fft(phy, r, a, b)
+            roots += [a, b]
+        outs.append(dl + ul + roots)
+    for a, b in zip(*outs):
+        assert np.linalg.norm(a) > 0 and np.linalg.norm(a - b) <= 3e-6 * np.linalg.norm(a)
+    # the transform itself at the sizes the uplink's transform pre-decoding uses (12 * N_prb with N_prb = 2^a 3^b 5^c: radix 4 / 2 / 3 / 5
+    # passes), both directions, against numpy's float64 FFT
+    import ctypes as C
+    c64 = np.ctypeslib.ndpointer(np.complex64, flags="C_CONTIGUOUS")
+    for L in (ref, fast):
+        L.fftwf_plan_dft_1d.restype = C.c_void_p
+        L.fftwf_plan_dft_1d.argtypes = [C.c_int, c64, c64, C.c_int, C.c_uint]
+        L.fftwf_execute.argtypes = [C.c_void_p]
+        L.fftwf_destroy_plan.argtypes = [C.c_void_p]
+    for n in (1, 2, 3, 8, 12, 24, 36, 60, 72, 108, 128, 180, 300, 512, 600, 1024, 1200, 1536, 7 * 11 * 4):
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+        for sign in (-1, 1):
+            want = np.fft.fft(x.astype(np.complex128)) if sign < 0 else np.fft.ifft(x.astype(np.complex128)) * n
+            for L in (ref, fast):
+                y = np.zeros(n, np.complex64)
+                plan = L.fftwf_plan_dft_1d(n, x, y, sign, 0)
+                L.fftwf_execute(plan)
+                L.fftwf_destroy_plan(plan)
+                assert np.linalg.norm(y - want) <= 2e-6 * max(np.linalg.norm(want), 1e-30), (n, sign, L is fast)

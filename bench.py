@@ -1021,6 +1021,20 @@ def turbo_leg(ctx, decoder, n_cb, steps):
     return out
 
 
+_COPY_RATE = {}
+
+
+def measured_copy_rate(ctx):
+    """GB/s of the library's copy kernel on ctx's device (1 GiB, 10 launches; once per process and device)."""
+    key = id(ctx)
+    if key not in _COPY_RATE:
+        try:
+            _COPY_RATE[key] = round(ctx.device_copy_rate(1 << 30, 10), 1)
+        except Exception:
+            _COPY_RATE[key] = None
+    return _COPY_RATE[key]
+
+
 def roofline_of(wl, prof, steps):
     """The `roofline` object of a run: the kernel with the largest share of the timed region, its STAGE's algorithmic bytes charged once
     per step and spread over its launches, over its average launch time (HIP events).  Also returns {kernel: ms per step}."""
@@ -1038,7 +1052,10 @@ def roofline_of(wl, prof, steps):
     except Exception:
         pass
     st_ms = sum(prof[k][1] for k in acc["stages"][stage_of[dom]][1] if k in prof) / steps if dom in stage_of else tot_ms / steps
+    copy = measured_copy_rate(wl.ctx) if hasattr(wl, "ctx") else None
     return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            # SURVEY 8d's second denominator: what a 16-bytes-per-lane copy kernel reaches on THIS device, measured in this run
+            "measured_copy_GBps": copy, "frac_of_measured_copy": round(achieved / copy, 5) if copy else None,
             "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": lps, "algorithmic_bytes_per_launch": st_bytes / lps,
             "stage": stage_of.get(dom, "whole path"),
             # the same bytes over ALL of the stage's kernels (the stricter reading when the dominant kernel is only part of its stage)
@@ -1249,6 +1266,7 @@ def main():
             traffic_tab = tj["bytes_per_launch"]
         except Exception:
             pass
+        copy_rate = measured_copy_rate(ctx)  # (the timed region is over)
         per_kernel = {}
         for k, (nl, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
             own = acc["own_io"].get(k)
@@ -1261,6 +1279,8 @@ def main():
             if tr:
                 ent["hbm_traffic_bytes_per_step"] = int(tr * (nl // steps))
                 ent["hbm_traffic_GBps"] = round(tr * (nl // steps) / (ms / steps * 1e-3) / 1e9, 1)
+                if copy_rate:  # how close the kernel's real traffic runs to what a copy kernel streams on this device
+                    ent["hbm_traffic_frac_of_measured_copy"] = round(ent["hbm_traffic_GBps"] / copy_rate, 3)
                 if own:
                     ent["traffic_over_own_io"] = round(tr * (nl // steps) / own, 2)
             per_kernel[k] = ent
@@ -1289,6 +1309,8 @@ def main():
             "config": wl.config(world),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": tr,
+                         # SURVEY 8d's second denominator: a 16-bytes-per-lane copy kernel on THIS device, measured after the timed region
+                         "measured_copy_GBps": copy_rate, "frac_of_measured_copy": round(achieved / copy_rate, 5) if copy_rate else None,
                          "traffic_source": ("profiles/pmc_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" % wl.name) if tr else None,
                          "avg_launch_ms": round(avg_ms, 4), "launches": n_launch, "launches_per_step": lps,
                          "algorithmic_bytes_per_launch": alg_per_launch,

@@ -4,6 +4,8 @@
 #include <chrono>
 #include <cstdlib>
 
+#include <algorithm>
+
 #include "ctx.hpp"
 
 #include <cstring>
@@ -100,6 +102,37 @@ int mi_lte_memset(mi_lte_ctx *ctx, void *d_ptr, int value, size_t bytes)
 {
     if (!ctx) return MI_LTE_ERR_INVALID_ARG;
     MI_HIP_CHECK(ctx, hipMemsetAsync(d_ptr, value, bytes, ctx->stream));
+    return MI_LTE_OK;
+}
+namespace {
+// grid-stride 16-byte copy: every wavefront access is one contiguous KiB
+__global__ void k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+} // namespace
+int mi_lte_device_copy_rate(mi_lte_ctx *ctx, size_t bytes, uint32_t reps, double *gb_per_s)
+{
+    if (!ctx || !gb_per_s || bytes < 16 || (bytes & 15) || reps == 0) return MI_LTE_ERR_INVALID_ARG;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    uint4 *a = nullptr, *b = nullptr;
+    auto   guard = on_fail([&] { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(a); (void)hipFree(b); });
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&a, bytes));
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&b, bytes));
+    MI_HIP_CHECK(ctx, hipMemsetAsync(a, 0x5A, bytes, ctx->stream));
+    const size_t n = bytes / 16;
+    const dim3   grid((unsigned)std::min<size_t>((n + 255) / 256, 256 * 32)), block(256); // 32 workgroups per CU, grid-stride
+    hipLaunchKernelGGL(k_copy16, grid, block, 0, ctx->stream, a, b, n); // warm-up (page tables, clocks)
+    MI_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (uint32_t r = 0; r < reps; r++) hipLaunchKernelGGL(k_copy16, grid, block, 0, ctx->stream, (r & 1) ? b : a, (r & 1) ? a : b, n);
+    MI_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    MI_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
+    MI_HIP_CHECK(ctx, hipGetLastError());
+    float ms = 0.f;
+    MI_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *gb_per_s = 2.0 * (double)bytes * reps / ((double)ms * 1e-3) / 1e9;
+    guard.armed = false;
+    (void)hipFree(a); (void)hipFree(b);
     return MI_LTE_OK;
 }
 int mi_lte_memcpy_h2d(mi_lte_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)

@@ -168,6 +168,7 @@ def load_library():
     L.mi_lte_prach_occasion_samples.argtypes = [vp]
     L.mi_lte_prach_occasion_samples.restype = u32
     L.mi_lte_prach_detect_run.argtypes = [vp, vp, vp, vp, vp, u32, u32p, u32p, u32p]
+    L.mi_lte_device_copy_rate.argtypes = [vp, C.c_size_t, u32, C.POINTER(C.c_double)]
     L.mi_lte_pdcch_plan_create.argtypes = [vp, C.POINTER(DlCfg), C.c_float, u32, u32, u32p, u32, C.POINTER(vp)]
     L.mi_lte_pdcch_plan_destroy.argtypes = [vp, vp]
     L.mi_lte_pdcch_decode_run.argtypes = [vp, vp, vp, vp, vp, u32, u32p, u32p, u32p, u32p, C.POINTER(PdcchDci)]
@@ -705,6 +706,12 @@ class Context:
         finally:
             d_in.free()
             d_out.free()
+
+    def device_copy_rate(self, nbytes=1 << 30, reps=10):
+        """GB/s (read + written) of a 16-bytes-per-lane copy kernel on this device: the measured streaming rate."""
+        out = C.c_double()
+        self._check(self.L.mi_lte_device_copy_rate(self.h, C.c_size_t(nbytes), reps, C.byref(out)))
+        return out.value
 
     def turbo_early_exit_iterations(self):
         """Iterations each tile pair (128 code blocks) of the last TURBO_BCJR_EARLY decode ran: uint32 [n_pairs]."""

@@ -70,3 +70,13 @@ def test_dci_unpackers_reject_bad_arguments():
     assert L.mi_lte_dci_1c_unpack(0, 15, 0xFFFF, 5, 1, C.byref(d)) == -1     # below the smallest LTE bandwidth
     assert L.mi_lte_dci_1a_unpack(0, 28, 0xFFFF, 100, 1, None) == -1
     assert L.mi_lte_dci_1a_unpack(0, 28, 0xFFFF, 100, 1, C.byref(d)) == 4    # first bit 0: a format-0 DCI (LIBLTE_ERROR_INVALID_CONTENTS)
+
+
+def test_device_copy_rate_is_a_plausible_hbm_figure(ctx):
+    """mi_lte_device_copy_rate (bench.py's second roofline denominator): rejects odd sizes, and a 256 MiB copy on an MI355X
+    lands between a tenth of the 8 TB/s peak and the peak."""
+    out = C.c_double()
+    assert ctx.L.mi_lte_device_copy_rate(ctx.h, C.c_size_t(1000), 1, C.byref(out)) == -1
+    assert ctx.L.mi_lte_device_copy_rate(ctx.h, C.c_size_t(1 << 20), 0, C.byref(out)) == -1
+    r = ctx.device_copy_rate(256 << 20, 5)
+    assert 800.0 < r < 8000.0, r

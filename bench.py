@@ -1030,6 +1030,7 @@ def measured_copy_rate(ctx):
     if key not in _COPY_RATE:
         try:
             _COPY_RATE[key] = round(ctx.device_copy_rate(1 << 30, 10), 1)
+            _COPY_RATE["shapes"] = ctx.device_copy_rates()
         except Exception:
             _COPY_RATE[key] = None
     return _COPY_RATE[key]
@@ -1311,6 +1312,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": tr,
                          # SURVEY 8d's second denominator: a 16-bytes-per-lane copy kernel on THIS device, measured after the timed region
                          "measured_copy_GBps": copy_rate, "frac_of_measured_copy": round(achieved / copy_rate, 5) if copy_rate else None,
+                         "measured_copy_shapes_GBps": dict(zip(("one_access_per_thread", "one_access_per_thread_non_temporal", "grid_stride_loop"), _COPY_RATE.get("shapes", ()))),
                          "traffic_source": ("profiles/pmc_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" % wl.name) if tr else None,
                          "avg_launch_ms": round(avg_ms, 4), "launches": n_launch, "launches_per_step": lps,
                          "algorithmic_bytes_per_launch": alg_per_launch,

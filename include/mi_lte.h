@@ -70,9 +70,12 @@ int mi_lte_timer_start(mi_lte_ctx *ctx);
 int mi_lte_timer_stop(mi_lte_ctx *ctx, float *elapsed_ms); /* records, synchronises, returns ms */
 
 /* What a streaming kernel reaches on this device ("use the measured copy bandwidth as a second denominator"): a 16-bytes-per-lane
- * copy of `bytes` (a multiple of 16) from one scratch buffer to another, `reps` launches between two events on the context's stream;
- * *gb_per_s = 2 * bytes * reps / time (bytes read + bytes written). */
+ * copy of `bytes` (a multiple of 16) from one scratch buffer to another, `reps` launches between two events on the context's stream, in
+ * three kernel shapes; *gb_per_s = the best shape's 2 * bytes * reps / time (bytes read + bytes written). */
 int mi_lte_device_copy_rate(mi_lte_ctx *ctx, size_t bytes, uint32_t reps, double *gb_per_s);
+/* the last call's three kernel shapes (one 16-byte access per thread; the same with the non-temporal hint; a grid-stride loop): *gb_per_s
+ * was their best */
+int mi_lte_device_copy_rates(const mi_lte_ctx *ctx, double *out3);
 
 /* Per-kernel timing: when enabled every kernel launch the library issues is bracketed by a pair
  * of HIP events on the context's stream.  The report is "kernel:launches:total_ms;..." since the

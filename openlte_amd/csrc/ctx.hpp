@@ -40,6 +40,7 @@ struct mi_lte_ctx {
     std::string        err;
     std::string        dev_name;
     std::string        last_kernels;
+    double             copy_rates[3] = {0, 0, 0}; // mi_lte_device_copy_rate's three kernel shapes, GB/s of the last call
     void              *scratch       = nullptr;
     size_t             scratch_bytes = 0;
     uint32_t          *h_flag = nullptr, *d_flag = nullptr; // the completion word of the per-call waits (mi_stream_wait_polling) and its sequence number

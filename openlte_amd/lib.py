@@ -169,6 +169,7 @@ def load_library():
     L.mi_lte_prach_occasion_samples.restype = u32
     L.mi_lte_prach_detect_run.argtypes = [vp, vp, vp, vp, vp, u32, u32p, u32p, u32p]
     L.mi_lte_device_copy_rate.argtypes = [vp, C.c_size_t, u32, C.POINTER(C.c_double)]
+    L.mi_lte_device_copy_rates.argtypes = [vp, C.POINTER(C.c_double)]
     L.mi_lte_pdcch_plan_create.argtypes = [vp, C.POINTER(DlCfg), C.c_float, u32, u32, u32p, u32, C.POINTER(vp)]
     L.mi_lte_pdcch_plan_destroy.argtypes = [vp, vp]
     L.mi_lte_pdcch_decode_run.argtypes = [vp, vp, vp, vp, vp, u32, u32p, u32p, u32p, u32p, C.POINTER(PdcchDci)]
@@ -712,6 +713,12 @@ class Context:
         out = C.c_double()
         self._check(self.L.mi_lte_device_copy_rate(self.h, C.c_size_t(nbytes), reps, C.byref(out)))
         return out.value
+
+    def device_copy_rates(self):
+        """The last device_copy_rate call's three kernel shapes: (one access per thread, the same non-temporal, grid-stride loop), GB/s."""
+        out = (C.c_double * 3)()
+        self._check(self.L.mi_lte_device_copy_rates(self.h, out))
+        return tuple(round(v, 1) for v in out)
 
     def turbo_early_exit_iterations(self):
         """Iterations each tile pair (128 code blocks) of the last TURBO_BCJR_EARLY decode ran: uint32 [n_pairs]."""

@@ -145,9 +145,9 @@ static void device_worker(mi_lte_dl_pipeline *p, uint32_t di, const Job *job)
             e = hipMemcpyAsync(l.d_iq, job->h_iq + (size_t)u0 * unit_bytes, (size_t)n * unit_bytes, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipMemcpyAsync(l.d_sf, job->h_sf + u0, sizeof(uint32_t) * n, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipMemcpyAsync(l.d_cell, job->h_cell + u0, sizeof(uint32_t) * n, hipMemcpyHostToDevice, st);
-        if (e != hipSuccess) { d.rc = MI_LTE_ERR_HIP; d.err = hipGetErrorString(e); return; }
+        if (e != hipSuccess) { d.rc = MI_LTE_ERR_HIP; d.err = hipGetErrorString(e); break; }
         int rc = mi_lte_dl_frontend_batch(l.ctx, &p->cfg, l.d_iq, nullptr, job->capture ? l.d_start_capture : l.d_start_units, l.d_sf, l.d_cell, n, l.d_sub);
-        if (rc != MI_LTE_OK) { fail(l, rc); return; }
+        if (rc != MI_LTE_OK) { fail(l, rc); break; }
         // which plan decodes the chunk, and where its results go
         mi_lte_pdsch_plan *plan;
         size_t             a0, n_al;
@@ -171,11 +171,12 @@ static void device_worker(mi_lte_dl_pipeline *p, uint32_t di, const Job *job)
             plan = l.dyn;
         }
         if (rc == MI_LTE_OK) rc = mi_lte_pdsch_decode_run(l.ctx, plan, l.d_sub, l.d_sf, l.d_cell, l.d_out, l.d_st);
-        if (rc != MI_LTE_OK) { fail(l, rc); return; }
+        if (rc != MI_LTE_OK) { fail(l, rc); break; }
         e = hipMemcpyAsync(job->h_out + a0 * p->out_stride, l.d_out, n_al * p->out_stride, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipMemcpyAsync(job->h_status + a0, l.d_st, n_al * sizeof(int32_t), hipMemcpyDeviceToHost, st);
-        if (e != hipSuccess) { d.rc = MI_LTE_ERR_HIP; d.err = hipGetErrorString(e); return; }
+        if (e != hipSuccess) { d.rc = MI_LTE_ERR_HIP; d.err = hipGetErrorString(e); break; }
     }
+    // (a failed chunk leaves the loop, not the function: copies of earlier chunks into the caller's arrays may still be in flight)
     for (Lane &l : d.lanes) {
         const int rc = mi_lte_sync(l.ctx);
         if (rc != MI_LTE_OK && d.rc == MI_LTE_OK) fail(l, rc);

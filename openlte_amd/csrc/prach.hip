@@ -250,6 +250,10 @@ static int prach_plan_common(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const mi
     pl->start = 7 + K * k_0 + K / 2;                 // :3426
     {   // N_cs and v_max of the FIRST root, as liblte_phy_detect_prach uses them for every root (:3336-3413)
         const PrachSets ps = prach_sets(LTE_PRACH_ROOT_ORDER[pc->root_seq_idx], pc->zczc, pc->hs_flag != 0);
+        if (!ps.ok) {
+            ctx->err = "PRACH: zeroCorrelationZoneConfig / root outside what the reference can process (restricted set: config 15, or a root without a cyclic shift)";
+            return MI_LTE_ERR_UNSUPPORTED;
+        }
         pl->N_cs = ps.N_cs; pl->v_max = ps.v_max;
     }
     std::vector<float2> xu;
@@ -260,7 +264,12 @@ static int prach_plan_common(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const mi
     } else { // roots needed for 64 preambles (prach_preamble_seq_gen, :7130-7290), their forward DFTs in double
         uint32_t n_gen = 0;
         while (n_gen < 64 && pc->root_seq_idx + pl->n_roots < 838) {
-            n_gen += prach_sets(LTE_PRACH_ROOT_ORDER[pc->root_seq_idx + pl->n_roots], pc->zczc, pc->hs_flag != 0).v_max + 1;
+            const PrachSets pr = prach_sets(LTE_PRACH_ROOT_ORDER[pc->root_seq_idx + pl->n_roots], pc->zczc, pc->hs_flag != 0);
+            if (!pr.ok) {
+                ctx->err = "PRACH: a root of the 64-preamble set has no cyclic shift in the restricted set (the reference divides by zero there)";
+                return MI_LTE_ERR_UNSUPPORTED;
+            }
+            n_gen += pr.v_max + 1 ? pr.v_max + 1 : 64; // (a wrapped v_max: the reference takes every remaining preamble from this root)
             pl->n_roots++;
         }
         xu.resize((size_t)pl->n_roots * N_ZC);

@@ -176,6 +176,7 @@ int mi_lte_synth_prach_i8(const mi_lte_dl_cfg *cfg, const mi_lte_prach_cfg *pc, 
             if (pc->root_seq_idx + r > 837) return MI_LTE_ERR_INVALID_ARG;
             u = LTE_PRACH_ROOT_ORDER[pc->root_seq_idx + r];
             const PrachSets ps = prach_sets(u, pc->zczc, pc->hs_flag != 0);
+            if (!ps.ok) return MI_LTE_ERR_UNSUPPORTED; // (the reference's own generator divides by zero / reads past its table there)
             if (p <= ps.v_max) {
                 C_v = pc->hs_flag ? ps.d_start * (p / ps.N_RA_shift) + (p % ps.N_RA_shift) * ps.N_cs : p * ps.N_cs;
                 break;

@@ -187,7 +187,7 @@ PRACH_CASES = {
 def prach_case(name, seed=3):
     import openlte_amd as m
     from openlte_amd import synth
-    fft, nrb, root, fmt, zczc, hs, fo, pre, dly, snr = PRACH_CASES[name]
+    fft, nrb, root, fmt, zczc, hs, fo, pre, dly, snr = PRACH_CASES[name] if isinstance(name, str) else name
     cfg, pc = m.DlCfg(fft, nrb, 1, 0), m.PrachCfg(root, fmt, zczc, hs, fo)
     iq = synth.prach_occasions(cfg, pc, pre, dly, snr_db=snr, seed=seed)
     return dict(cfg=cfg, pc=pc, iq=iq, fft=fft, nrb=nrb, args=(root, fmt, zczc, hs), fo=fo)
@@ -391,9 +391,10 @@ PBCH_CASES = {
 
 def pbch_case(R, name, seed=31):
     """Units for one case: grids in the device-subframe layout with FOUR estimate planes (float32 [n, 10, 16, 1200]), rx = sum over the
-    transmitted ports of h_p * tx_p + noise; ports that do not transmit get a noise-only estimate (what a CRS estimator sees)."""
+    transmitted ports of h_p * tx_p + noise; ports that do not transmit get a noise-only estimate (what a CRS estimator sees).
+    name: a key of PBCH_CASES, or such a tuple itself (the fuzz test draws them)."""
     from oracle import pyoracle as po
-    fft, nrb, n_ant, units, snr_db = PBCH_CASES[name]
+    fft, nrb, n_ant, units, snr_db = PBCH_CASES[name] if isinstance(name, str) else name
     rng = np.random.default_rng(seed)
     grids = np.zeros((len(units), 10, 16, 1200), np.float32)
     k = np.arange(1200)

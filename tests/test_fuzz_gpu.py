@@ -268,3 +268,67 @@ def test_control_region_fuzz_against_the_compiled_reference(ctx, ref):
     write_report()
     assert total >= 3800 and not bad, bad[:10]
     assert n_dci >= total // 6
+
+
+def test_pbch_fuzz_against_the_compiled_reference(ctx, ref):
+    """PBCH: 100 random configurations x 16 units -- bandwidth, transmitted ports 1 / 2 / 4, cell, frame number, SNR from
+    hopeless to clean -- through liblte_phy_bch_channel_encode, a random per-port channel and noise (tests/lte_testdata.pbch_case), against
+    liblte_phy_bch_channel_decode fed the same grids: return code, port count, position in the 40 ms period and the 24 MIB bits
+    identical for every unit, decodes on a wrong hypothesis included."""
+    import test_pbch_gpu as tp
+    rng = np.random.default_rng(2031)
+    n_units = n_ok = 0
+    ports = {1: 0, 2: 0, 4: 0}
+    for c in range(100):
+        _, fft, nrb = fz.BANDWIDTHS[int(rng.integers(len(fz.BANDWIDTHS)))]
+        n_ant = int(rng.choice([1, 2, 4]))
+        units = [(int(rng.integers(504)), int(rng.integers(1024))) for _ in range(16)]
+        case = td.pbch_case(ref, (fft, nrb, n_ant, units, float(rng.uniform(-7.0, 12.0))), seed=100 + c)
+        want = td.ref_pbch_decode(ref, case)
+        got = tp.run_case(ctx, case)
+        assert got.tolist() == want.tolist(), (c, fft, nrb, n_ant)
+        n_units += len(units)
+        n_ok += int((want[:, 0] == 0).sum())
+        ports[n_ant] += len(units)
+    assert 0.25 * n_units < n_ok < n_units  # the draw covers both outcomes
+    REPORT["pbch"] = {"units": n_units, "decoded": n_ok, "units_by_transmitted_ports": ports}
+    write_report()
+
+
+def test_prach_fuzz_against_the_compiled_reference(ctx, ref):
+    """PRACH: random bandwidths, preamble formats 0-3, root sequences, zero-correlation-zone configurations, unrestricted
+    and restricted sets, frequency offsets, preambles, delays and SNRs through the library's transmitter, liblte_phy_detect_prach as the
+    checker: detected or not, preamble index and timing advance identical for every occasion."""
+    import test_prach_gpu as tpr
+    import openlte_amd as m
+    rng = np.random.default_rng(839)
+    n_occ = n_det = n_cfg = skipped = 0
+    fmts = {0: 0, 1: 0, 2: 0, 3: 0}
+    bws = [(128, 6), (256, 15), (512, 25), (1024, 50), (2048, 100)]
+    while n_cfg < 80:
+        fft, nrb = bws[int(rng.integers(len(bws) if n_cfg % 7 == 0 else 3))]  # (the two wide ones cost the reference a second per occasion: a few)
+        fmt, root, zczc = int(rng.integers(4)), int(rng.integers(838)), int(rng.integers(16))
+        hs = int(rng.random() < 0.2)
+        fo = int(rng.integers(0, nrb - 6 + 1))
+        pre = [int(x) for x in rng.integers(0, 64, 4)]
+        dly = [int(x) for x in rng.integers(0, 24 * fft // 128, 4)]
+        spec = (fft, nrb, root, fmt, zczc, hs, fo, pre, dly, float(rng.uniform(-24.0, 10.0)))
+        try:
+            case = td.prach_case(spec, seed=200 + n_cfg + skipped)
+        except m.MiLteError:  # a restricted-set configuration without 64 preambles: the transmitter refuses it
+            skipped += 1
+            continue
+        try:
+            want, _ = td.ref_prach_detect(ref, case)
+        except AssertionError:  # ... or the reference's init does
+            skipped += 1
+            continue
+        got, _ = tpr.gpu_detect(ctx, case)
+        assert (got == want).all(), (spec, got.tolist(), want.tolist())
+        n_cfg += 1
+        n_occ += len(pre)
+        n_det += int((want[:, 0] > 0).sum())
+        fmts[fmt] += 1
+    assert 0 < n_det < n_occ and skipped < 80
+    REPORT["prach"] = {"configurations": n_cfg, "occasions": n_occ, "detected": n_det, "refused_configurations": skipped, "configurations_by_format": fmts}
+    write_report()

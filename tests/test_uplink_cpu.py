@@ -32,3 +32,16 @@ def test_reference_receiver_decodes_the_host_transmitter(ref, name):
             assert np.abs(g).max() == 1
         else:                 # 16QAM: inner bits are lost to that scaling -> CRC fails, reported as INVALID_INPUTS (1)
             assert rc == 1
+
+
+def test_prach_transmitter_refuses_what_the_reference_cannot_process():
+    """zeroCorrelationZoneConfig 15 with the restricted set is past the 15-entry N_cs table (the reference indexes past it and divides
+    by zero, liblte_phy.cc:295, :7190, :7258): the library's PRACH transmitter returns an error instead (it crashed once)."""
+    import openlte_amd as m
+    from openlte_amd import synth
+    cfg = m.DlCfg(128, 6, 1, 0)
+    with pytest.raises(m.MiLteError):
+        synth.prach_occasions(cfg, m.PrachCfg(175, 0, 15, 1, 0), [3], [0])
+    with pytest.raises(m.MiLteError):
+        synth.prach_occasions(cfg, m.PrachCfg(175, 0, 16, 0, 0), [3], [0])
+    assert synth.prach_occasions(cfg, m.PrachCfg(300, 0, 6, 1, 0), [3], [0]).shape[0] == 1  # a restricted-set configuration it can process

@@ -380,6 +380,12 @@ static int plan_layout(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, uint32_t N_pdcch_
             ctx->err = "allocation outside the single-code-block envelope (tbs + 24 > 6144) or malformed";
             return MI_LTE_ERR_UNSUPPORTED;
         }
+        for (uint32_t s = 0; s < 2; s++) // a resource block past the carrier would be read out of the neighbouring symbol row
+            for (uint32_t i = 0; i < al.N_prb; i++)
+                if (al.prb[s][i] >= cfg->N_rb_dl) {
+                    ctx->err = "allocation names a resource block outside the carrier";
+                    return MI_LTE_ERR_INVALID_ARG;
+                }
         kidx[a] = (uint8_t)r;
         cnt[r]++;
         max_tbs = std::max(max_tbs, al.tbs);

@@ -476,14 +476,21 @@ struct mi_lte_pdcch_plan {
 
 extern "C" {
 
+// the six LTE bandwidths and a PHICH resource N_g in (0, 2] (36.211 6.9: 1/6, 1/2, 1, 2): what bounds the REG tables below (a negative or
+// not-a-number N_g would size them by a wrapped group count)
+static bool standard_ctrl_cfg(uint32_t nrb, float phich_res)
+{
+    return (nrb == 6 || nrb == 15 || nrb == 25 || nrb == 50 || nrb == 75 || nrb == 100) && phich_res > 0.0f && phich_res <= 2.0f;
+}
+
 int mi_lte_pdcch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, float phich_res, uint32_t phich_dur_extended, uint32_t flags,
                              const uint32_t *h_cells, uint32_t n_cells, mi_lte_pdcch_plan **out)
 {
     if (!ctx || !cfg || !h_cells || n_cells == 0 || !out) return MI_LTE_ERR_INVALID_ARG;
     const uint32_t nrb = cfg->N_rb_dl;
-    if (!(nrb == 6 || nrb == 15 || nrb == 25 || nrb == 50 || nrb == 75 || nrb == 100) || !(cfg->N_ant == 1 || cfg->N_ant == 2 || cfg->N_ant == 4) ||
+    if (!standard_ctrl_cfg(nrb, phich_res) || !(cfg->N_ant == 1 || cfg->N_ant == 2 || cfg->N_ant == 4) ||
         phich_dur_extended) { // the reference does not handle the extended PHICH duration either (:8280-8283)
-        ctx->err = "PDCCH plan: standard bandwidths, 1/2/4 ports, normal PHICH duration";
+        ctx->err = "PDCCH plan: standard bandwidths, 1/2/4 ports, PHICH resource in (0, 2], normal PHICH duration";
         return MI_LTE_ERR_UNSUPPORTED;
     }
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -524,7 +531,7 @@ int mi_lte_pdcch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, float ph
 int mi_lte_pdcch_re_tables(uint32_t N_rb_dl, uint32_t N_ant, uint32_t N_id_cell, float phich_res, uint32_t N_symbs, uint32_t *pcfich /*[16]*/,
                            uint32_t *cand /*[6][288]*/)
 {
-    if (!pcfich || !cand || N_rb_dl < 6 || N_rb_dl > 100 || !(N_ant == 1 || N_ant == 2 || N_ant == 4) || N_id_cell > 503 || N_symbs < 1 || N_symbs > 4)
+    if (!pcfich || !cand || !standard_ctrl_cfg(N_rb_dl, phich_res) || !(N_ant == 1 || N_ant == 2 || N_ant == 4) || N_id_cell > 503 || N_symbs < 1 || N_symbs > 4)
         return MI_LTE_ERR_INVALID_ARG;
     const CtrlRegs cr = ctrl_regs(N_rb_dl, N_id_cell, phich_res);
     for (uint32_t i = 0; i < 4; i++) {
@@ -541,7 +548,7 @@ int mi_lte_pdcch_re_tables(uint32_t N_rb_dl, uint32_t N_ant, uint32_t N_id_cell,
 int mi_lte_ctrl_reg_positions(uint32_t N_rb_dl, uint32_t N_id_cell, float phich_res, uint32_t *pcfich_k /*[4]*/, float *pcfich_n /*[4]*/,
                               uint32_t *phich_N_reg, uint32_t *phich_k /*[75]*/)
 {
-    if (!pcfich_k || !pcfich_n || !phich_N_reg || !phich_k || N_rb_dl < 6 || N_rb_dl > 100 || N_id_cell > 503) return MI_LTE_ERR_INVALID_ARG;
+    if (!pcfich_k || !pcfich_n || !phich_N_reg || !phich_k || !standard_ctrl_cfg(N_rb_dl, phich_res) || N_id_cell > 503) return MI_LTE_ERR_INVALID_ARG;
     const CtrlRegs cr = ctrl_regs(N_rb_dl, N_id_cell, phich_res);
     if (cr.phich_k.size() > 75) return MI_LTE_ERR_INVALID_ARG;
     for (uint32_t i = 0; i < 4; i++) { pcfich_k[i] = cr.pcfich_k[i]; pcfich_n[i] = cr.pcfich_n[i]; }
@@ -564,7 +571,7 @@ static bool common_rnti(uint32_t rnti) { return rnti == 0xFFFFu || rnti == 0xFFF
 // reference: a distributed assignment leaves prb[][] untouched).  Returns 0, or 4 = LIBLTE_ERROR_INVALID_CONTENTS.
 int mi_lte_dci_1a_unpack(uint32_t payload, uint32_t n_bits, uint32_t rnti, uint32_t N_rb_dl, uint32_t N_ant, mi_lte_pdcch_dci *o)
 {
-    if (!o || n_bits > 32 || N_rb_dl == 0) return MI_LTE_ERR_INVALID_ARG;
+    if (!o || n_bits > 32 || N_rb_dl == 0 || N_rb_dl > 110) return MI_LTE_ERR_INVALID_ARG; // (110: LIBLTE_PHY_N_RB_DL_MAX)
     uint32_t pos = n_bits;
     auto take = [&](uint32_t n) { pos = pos >= n ? pos - n : 0; return (payload >> pos) & ((1u << n) - 1u); };
     if (take(1) == 0) return 4;                   // flagged as DCI format 0
@@ -593,7 +600,7 @@ int mi_lte_dci_1a_unpack(uint32_t payload, uint32_t n_bits, uint32_t rnti, uint3
 // format-1C transport-block sizes.  A RIV that matches no (length, start) pair leaves N_prb as the caller set it.
 int mi_lte_dci_1c_unpack(uint32_t payload, uint32_t n_bits, uint32_t rnti, uint32_t N_rb_dl, uint32_t N_ant, mi_lte_pdcch_dci *o)
 {
-    if (!o || n_bits > 32 || N_rb_dl < 6) return MI_LTE_ERR_INVALID_ARG;
+    if (!o || n_bits > 32 || N_rb_dl < 6 || N_rb_dl > 110) return MI_LTE_ERR_INVALID_ARG;
     uint32_t pos = n_bits;
     auto take = [&](uint32_t n) { pos = pos >= n ? pos - n : 0; return (payload >> pos) & ((1u << n) - 1u); };
     const uint32_t gap2 = N_rb_dl < 50 ? 0u : take(1);

@@ -222,7 +222,14 @@ int mi_lte_synth_dl_units_i8(const mi_lte_dl_cfg *cfg, uint32_t n_units, const u
                              uint32_t n_alloc, const mi_lte_synth_channel *chan, int8_t *h_iq, uint8_t *h_tx_bits,
                              uint32_t tbs_stride)
 {
-    if (!cfg || !h_subfr_num || !h_n_id_cell || !chan || !h_iq || cfg->N_ant != 1) return MI_LTE_ERR_INVALID_ARG;
+    if (!cfg || !h_subfr_num || !h_n_id_cell || !chan || !h_iq || cfg->N_ant != 1 || (n_alloc && !h_allocs)) return MI_LTE_ERR_INVALID_ARG;
+    if (!synth::valid_grid(cfg->fft_size, cfg->N_rb_dl) || N_pdcch_symbs < 1 || N_pdcch_symbs > 4) return MI_LTE_ERR_INVALID_ARG;
+    for (uint32_t u = 0; u < n_units; u++) {
+        if (h_n_id_cell[u] > 503) return MI_LTE_ERR_INVALID_ARG;
+        for (uint32_t a = 0; a < n_alloc; a++)
+            if (!synth::valid_alloc(h_allocs[(size_t)u * n_alloc + a], cfg->N_rb_dl) || (h_tx_bits && h_allocs[(size_t)u * n_alloc + a].tbs > tbs_stride))
+                return MI_LTE_ERR_INVALID_ARG;
+    }
     const uint32_t N = cfg->fft_size, sc = 2048 / N, cp0 = 160 / sc, cpe = 144 / sc, N_rb = cfg->N_rb_dl, half = 6 * N_rb, N_sc = 12 * N_rb;
     const size_t   unit_len = mi_lte_synth_unit_len(N);
     uint32_t       first_sc, last_sc;

@@ -3,7 +3,23 @@
 #include <cstdint>
 #include <vector>
 
+#include "../../include/mi_lte.h"
+
 namespace synth {
+// what the generators divide by and index with: an LTE transform length, a grid that fits inside it (and the 112-entry PRB lists), and an
+// allocation whose PRBs lie on the grid
+inline bool valid_grid(uint32_t fft_size, uint32_t N_rb)
+{
+    return (fft_size == 128 || fft_size == 256 || fft_size == 512 || fft_size == 1024 || fft_size == 2048) && N_rb >= 6 && N_rb <= 110 && 12 * N_rb < fft_size;
+}
+inline bool valid_alloc(const mi_lte_pdsch_alloc &a, uint32_t N_rb)
+{
+    if (a.N_prb == 0 || a.N_prb > N_rb || a.mod_type > 3 || a.tbs == 0 || a.tbs + 24 > 6144 || a.rv_idx > 3) return false;
+    for (uint32_t s = 0; s < 2; s++)
+        for (uint32_t i = 0; i < a.N_prb; i++)
+            if (a.prb[s][i] >= N_rb) return false;
+    return true;
+}
 struct Rng {
     uint64_t s;
     explicit Rng(uint64_t seed) : s(seed * 0x9E3779B97F4A7C15ull + 0x1234567ull) {}

@@ -29,8 +29,14 @@ int mi_lte_synth_ul_units_i8(const mi_lte_dl_cfg *cfg, const mi_lte_ul_cfg *ul, 
                              const mi_lte_synth_channel *chan, int8_t *h_iq, uint8_t *h_tx_bits, uint32_t tbs_stride)
 {
     if (!cfg || !ul || !h_subfr_num || !h_n_id_cell || !h_allocs || !chan || !h_iq) return MI_LTE_ERR_INVALID_ARG;
+    if (!synth::valid_grid(cfg->fft_size, cfg->N_rb_dl)) return MI_LTE_ERR_INVALID_ARG;
+    for (uint32_t u = 0; u < n_units; u++) {
+        if (h_n_id_cell[u] > 503) return MI_LTE_ERR_INVALID_ARG;
+        for (uint32_t a = 0; a < n_alloc; a++)
+            if (!synth::valid_alloc(h_allocs[(size_t)u * n_alloc + a], cfg->N_rb_dl) || (h_tx_bits && h_allocs[(size_t)u * n_alloc + a].tbs > tbs_stride))
+                return MI_LTE_ERR_INVALID_ARG;
+    }
     const uint32_t N = cfg->fft_size, sc = 2048 / N, cp0 = 160 / sc, cpe = 144 / sc, N_rb = cfg->N_rb_dl, half = 6 * N_rb, N_sc = 12 * N_rb;
-    if (!(N == 128 || N == 256 || N == 512 || N == 1024 || N == 2048) || N_sc >= N) return MI_LTE_ERR_INVALID_ARG;
     const size_t unit_len = mi_lte_synth_ul_unit_len(N);
     synth::Rng   rng(chan->seed);
     std::vector<float>  g_re(14 * (size_t)N_sc), g_im(14 * (size_t)N_sc);
@@ -159,6 +165,10 @@ int mi_lte_synth_prach_i8(const mi_lte_dl_cfg *cfg, const mi_lte_prach_cfg *pc, 
                           const uint32_t *h_delay, const mi_lte_synth_channel *chan, int8_t *h_iq)
 {
     if (!cfg || !pc || !h_preamble_idx || !h_delay || !chan || !h_iq || pc->preamble_format > 3 || pc->root_seq_idx > 837) return MI_LTE_ERR_INVALID_ARG;
+    // the six PRACH resource blocks lie on the grid (k_0 below is unsigned arithmetic), and a delay keeps the preamble inside the occasion
+    if (!synth::valid_grid(cfg->fft_size, cfg->N_rb_dl) || pc->freq_offset + 6 > cfg->N_rb_dl) return MI_LTE_ERR_INVALID_ARG;
+    for (uint32_t o = 0; o < n_occ; o++)
+        if (h_delay[o] > 1024 / (2048 / cfg->fft_size)) return MI_LTE_ERR_INVALID_ARG;
     constexpr uint32_t N_ZC = 839;
     static const uint32_t cp_of_fmt[4] = {3168, 21024, 6240, 21024};
     const uint32_t N = cfg->fft_size, sc = 2048 / N, T = 24576 / sc, T_cp = cp_of_fmt[pc->preamble_format] / sc;

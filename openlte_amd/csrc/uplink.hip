@@ -477,6 +477,12 @@ int mi_pusch_plan_create_impl(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const m
             ctx->err = "PUSCH allocation outside the envelope (one code block; N_prb < N_rb_ul and divisible by 2, 3 or 5) or malformed";
             return MI_LTE_ERR_UNSUPPORTED;
         }
+        for (uint32_t sl = 0; sl < 2; sl++) // a resource block past the carrier would be read out of the neighbouring symbol row
+            for (uint32_t i = 0; i < al.N_prb; i++)
+                if (al.prb[sl][i] >= cfg->N_rb_dl) {
+                    ctx->err = "PUSCH allocation names a resource block outside the carrier";
+                    return MI_LTE_ERR_INVALID_ARG;
+                }
         const uint32_t sf = h_unit_subfr_num[al.unit] % 10, cell = h_unit_n_id_cell[al.unit], M = 12 * al.N_prb;
         if (h_dmrs) {
             const uint32_t at = (uint32_t)dmrs.size();

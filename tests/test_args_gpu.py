@@ -80,3 +80,27 @@ def test_device_copy_rate_is_a_plausible_hbm_figure(ctx):
     assert ctx.L.mi_lte_device_copy_rate(ctx.h, C.c_size_t(1 << 20), 0, C.byref(out)) == -1
     r = ctx.device_copy_rate(256 << 20, 5)
     assert 800.0 < r < 8000.0, r
+
+
+def test_plans_refuse_resource_blocks_outside_the_carrier(ctx):
+    """An allocation whose PRB list leaves the carrier is refused by the PDSCH and PUSCH plan constructors (it would be read out of the
+    neighbouring symbol row of the grid): a static plan, a dynamic plan's assignment, a PUSCH plan."""
+    import openlte_amd as m
+    cfg = m.DlCfg(512, 25, 1, 0)
+    good = m.make_alloc(0, 1, 1064, [3, 4, 5, 6], 0x100)
+    bad = m.make_alloc(0, 1, 1064, [3, 4, 5, 25], 0x101)
+    bad1 = m.make_alloc(0, 1, 1064, [3, 4, 5, 6], 0x102, prbs_slot1=[3, 4, 200, 6])
+    ctx.pdsch_plan(cfg, 2, [good]).close()
+    for al in (bad, bad1):
+        with pytest.raises(m.MiLteError, match="outside the carrier"):
+            ctx.pdsch_plan(cfg, 2, [good, al])
+    dyn = ctx.pdsch_plan_dynamic(cfg, 4, 1 << 16)
+    dyn.assign(2, [good])
+    with pytest.raises(m.MiLteError, match="outside the carrier"):
+        dyn.assign(2, [good, bad])
+    dyn.assign(2, [good])  # (a refused assignment leaves the plan usable)
+    dyn.close()
+    ul = m.UlCfg(3, 0, 0, 2, 5)
+    ctx.pusch_plan(cfg, ul, [2], [17], [m.make_alloc(0, 1, 504, [3, 4, 5, 6], 0x100)]).close()
+    with pytest.raises(m.MiLteError, match="outside the carrier"):
+        ctx.pusch_plan(cfg, ul, [2], [17], [m.make_alloc(0, 1, 504, [3, 4, 5, 30], 0x100)])

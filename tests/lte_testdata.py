@@ -472,8 +472,8 @@ def sync_case(name, tmp_dir, seed=41):
     """int8 interleaved I,Q capture for one case (numpy int8 [n, 2])."""
     import os
     import subprocess
-    fft, nrb, cell, frames, delay, f_off, snr_db = SYNC_CASES[name]
-    path = os.path.join(str(tmp_dir), "cap_%s.bin" % name)
+    fft, nrb, cell, frames, delay, f_off, snr_db = SYNC_CASES[name] if isinstance(name, str) else name
+    path = os.path.join(str(tmp_dir), "cap_%s.bin" % (name if isinstance(name, str) else "drawn"))
     subprocess.run([capture_gen_path(), path, str(nrb), str(cell), str(frames)], check=True, timeout=600, stdout=subprocess.DEVNULL)
     x = np.fromfile(path, np.int8).reshape(-1, 2).astype(np.float32)
     os.remove(path)

@@ -326,6 +326,7 @@ struct mi_lte_pdsch_plan {
     uint32_t      cap_alloc = 0;
     size_t        cap_e_bytes = 0;
     bool          dynamic = false, wide = false; // wide: the output stride of the largest single-code-block transport block, whatever is held
+    bool          mapped = false; // the descriptor arrays ARE the pinned staging block, mapped into the device (mi_pdsch_plan_create_mapped)
     mi_lte_pdsch_alloc *d_allocs = nullptr;
     uint32_t *d_e_off = nullptr, *d_e_len = nullptr, *d_cb_alloc = nullptr;
     int8_t   *d_e = nullptr;
@@ -477,6 +478,37 @@ int mi_lte_pdsch_plan_create_dynamic(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, 
     *out = pl;
     return MI_LTE_OK;
 }
+} // extern "C"
+
+// The per-call forms' variant of a dynamic plan (hostapi.cc: a handful of allocations per subframe): the three descriptor arrays are not
+// copied at all -- they live in pinned host memory mapped into the device, mi_lte_pdsch_plan_assign stores into it and the kernels read
+// the few hundred bytes over the link (a copy command costs more API time than that).  Contract: the caller waits for the stream between a
+// run of the plan and its next assignment (every per-call form ends with a wait).
+int mi_pdsch_plan_create_mapped(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, uint32_t max_alloc, size_t max_soft_bytes, mi_lte_pdsch_plan **out)
+{
+    if (!ctx || !cfg || !out || max_alloc == 0 || max_alloc > 64) return MI_LTE_ERR_INVALID_ARG;
+    if (!(cfg->N_ant == 1 || cfg->N_ant == 2 || cfg->N_ant == 4) || (cfg->sample_format & MI_LTE_CE_COMPACT)) return MI_LTE_ERR_INVALID_ARG;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    auto *pl    = new mi_lte_pdsch_plan();
+    auto  guard = on_fail([&] { mi_lte_pdsch_plan_destroy(nullptr, pl); });
+    pl->cfg     = *cfg;
+    pl->dynamic = pl->mapped = true;
+    pl->cap_alloc   = max_alloc;
+    pl->cap_e_bytes = std::max<size_t>((max_soft_bytes + 63) & ~(size_t)63, 64);
+    MI_HIP_CHECK(ctx, hipHostMalloc(&pl->h_stage, (sizeof(mi_lte_pdsch_alloc) + 2 * sizeof(uint32_t)) * (size_t)max_alloc, hipHostMallocMapped | hipHostMallocCoherent));
+    void *d_stage = nullptr;
+    MI_HIP_CHECK(ctx, hipHostGetDevicePointer(&d_stage, pl->h_stage, 0));
+    pl->d_allocs   = (mi_lte_pdsch_alloc *)d_stage;
+    pl->d_e_off    = (uint32_t *)(pl->d_allocs + max_alloc);
+    pl->d_cb_alloc = pl->d_e_off + max_alloc;
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_e_len, sizeof(uint32_t) * max_alloc));
+    MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_e, pl->cap_e_bytes));
+    guard.armed = false;
+    *out = pl;
+    return MI_LTE_OK;
+}
+
+extern "C" {
 
 int mi_lte_pdsch_plan_assign(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, uint32_t N_pdcch_symbs, const mi_lte_pdsch_alloc *h_allocs, uint32_t n_alloc)
 {
@@ -487,12 +519,13 @@ int mi_lte_pdsch_plan_assign(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, uint32_t N_
     int rc = plan_layout(ctx, pl, N_pdcch_symbs, h_allocs, n_alloc, cb_alloc);
     if (rc != MI_LTE_OK) { pl->n_alloc = 0; return rc; }
     if (pl->e_bytes > pl->cap_e_bytes) { pl->n_alloc = 0; ctx->err = "more soft bits than the dynamic plan was created for"; return MI_LTE_ERR_INVALID_ARG; }
-    MI_HIP_CHECK(ctx, hipEventSynchronize(pl->staged)); // the previous assignment's copies have left the staging block
+    if (!pl->mapped) MI_HIP_CHECK(ctx, hipEventSynchronize(pl->staged)); // the previous assignment's copies have left the staging block
     auto *sa = (mi_lte_pdsch_alloc *)pl->h_stage;
     auto *so = (uint32_t *)(sa + pl->cap_alloc), *sc = so + pl->cap_alloc;
     memcpy(sa, h_allocs, sizeof(mi_lte_pdsch_alloc) * n_alloc);
     memcpy(so, pl->h_e_off.data(), sizeof(uint32_t) * n_alloc);
     memcpy(sc, cb_alloc.data(), sizeof(uint32_t) * n_alloc);
+    if (pl->mapped) return MI_LTE_OK; // the kernels read the block itself (mi_pdsch_plan_create_mapped: the caller has waited for the last run)
     MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_allocs, sa, sizeof(mi_lte_pdsch_alloc) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
     MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_e_off, so, sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
     MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_cb_alloc, sc, sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
@@ -512,10 +545,12 @@ void mi_lte_pdsch_plan_destroy(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl)
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
     }
-    (void)hipFree(pl->d_allocs);
-    (void)hipFree(pl->d_e_off);
+    if (!pl->mapped) { // (mapped: the three are views of h_stage)
+        (void)hipFree(pl->d_allocs);
+        (void)hipFree(pl->d_e_off);
+        (void)hipFree(pl->d_cb_alloc);
+    }
     (void)hipFree(pl->d_e_len);
-    (void)hipFree(pl->d_cb_alloc);
     (void)hipFree(pl->d_e);
     if (pl->d_bcjr_soft) (void)hipFree(pl->d_bcjr_soft);
     if (pl->d_bcjr_bits) (void)hipFree(pl->d_bcjr_bits);

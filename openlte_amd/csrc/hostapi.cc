@@ -474,7 +474,7 @@ int mi_lte_dl_subframe_decode_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t 
         if (hc->sf_plan) mi_lte_pdsch_plan_destroy(ctx, hc->sf_plan);
         hc->sf_plan = nullptr;
         const size_t soft = (size_t)MI_LTE_PDCCH_MAX_DCI * (((size_t)13 * N_rb_dl * 12 * 6 + 63) & ~(size_t)63);
-        rc = mi_lte_pdsch_plan_create_dynamic(ctx, &cfg, MI_LTE_PDCCH_MAX_DCI, soft, &hc->sf_plan);
+        rc = mi_pdsch_plan_create_mapped(ctx, &cfg, MI_LTE_PDCCH_MAX_DCI, soft, &hc->sf_plan); // (descriptors in mapped host memory: no copy commands)
         if (rc != MI_LTE_OK) return rc;
         hc->sf_cfg = cfg;
     }

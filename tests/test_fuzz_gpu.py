@@ -36,6 +36,8 @@ pytestmark = pytest.mark.gpu
 N_DL_CHUNKS, DL_CHUNK = 20, 1000
 N_UL_GROUPS = 250
 N_SYNC = 40
+# every draw below is offset by this: the suite runs with 0; tools/r3/fuzz_soak.sh runs the same tests over further seeds
+SEED = int(os.environ.get("MI_LTE_FUZZ_SEED", "0"))
 TOL_SYMB, TOL_CE = 1e-5, 1e-4
 REPORT = {}
 
@@ -132,7 +134,7 @@ def test_downlink_fuzz_against_the_compiled_reference(ctx, ref_big):
     dims = dict(n_rb={}, n_ant={}, mod={}, sf={}, n_sym={}, rv={}, tx_mode={}, kind={})
     t_ref = t_gpu = 0.0
     for chunk in range(N_DL_CHUNKS):
-        cases = fz.draw_dl_cases(DL_CHUNK, 1000 + chunk)
+        cases = fz.draw_dl_cases(DL_CHUNK, 1000 + chunk + 100000 * SEED)
         t0 = time.time()
         r = fz.run_ref_dl(ref_big, cases)
         t_ref += time.time() - t0
@@ -169,7 +171,7 @@ def test_downlink_fuzz_against_the_compiled_reference(ctx, ref_big):
 
 
 def test_uplink_fuzz_against_the_compiled_reference(ctx, ref):
-    groups = fz.draw_ul_groups(N_UL_GROUPS, 2026)
+    groups = fz.draw_ul_groups(N_UL_GROUPS, 2026 + 100000 * SEED)
     fz.synth_ul_groups(groups)
     t0 = time.time()
     fz.run_ref_ul(ref, groups)
@@ -234,7 +236,7 @@ def test_control_region_fuzz_against_the_compiled_reference(ctx, ref):
     n, total, n_dci, bad = 320, 0, 0, []
     rntis = [0xFFFF, 0xFFFE] + list(range(1, 0x3D))
     for ci, (fft, nrb, n_ant) in enumerate(configs):
-        rng = np.random.default_rng(900 + ci)
+        rng = np.random.default_rng(900 + ci + 100000 * SEED)
         cells = [int(c) for c in rng.choice(504, 6, replace=False)]
         cfg = m.DlCfg(fft, nrb, n_ant, 0)
         sfs, cell = rng.integers(0, 10, n), rng.choice(cells, n)
@@ -277,7 +279,7 @@ def test_pbch_fuzz_against_the_compiled_reference(ctx, ref):
     liblte_phy_bch_channel_decode fed the same grids: return code, port count, position in the 40 ms period and the 24 MIB bits
     identical for every unit, decodes on a wrong hypothesis included."""
     import test_pbch_gpu as tp
-    rng = np.random.default_rng(2031)
+    rng = np.random.default_rng(2031 + 100000 * SEED)
     n_units = n_ok = 0
     ports = {1: 0, 2: 0, 4: 0}
     for c in range(100):
@@ -302,7 +304,7 @@ def test_prach_fuzz_against_the_compiled_reference(ctx, ref):
     checker: detected or not, preamble index and timing advance identical for every occasion."""
     import test_prach_gpu as tpr
     import openlte_amd as m
-    rng = np.random.default_rng(839)
+    rng = np.random.default_rng(839 + 100000 * SEED)
     n_occ = n_det = n_cfg = skipped = 0
     fmts = {0: 0, 1: 0, 2: 0, 3: 0}
     bws = [(128, 6), (256, 15), (512, 25), (1024, 50), (2048, 100)]
@@ -343,7 +345,7 @@ def test_sync_fuzz_against_the_compiled_reference(ctx, ref, tmp_path):
     import test_sync_gpu as ts
     if td.capture_gen_path() is None:
         pytest.skip("shim/_build/capture_gen not built (needs the reference tree at build time)")
-    rng = np.random.default_rng(62)
+    rng = np.random.default_rng(62 + 100000 * SEED)
     bws = [(128, 6, 18), (256, 15, 14), (512, 25, 12), (2048, 100, 10)]
     n_peaks = n_cells = 0
     for c in range(N_SYNC):

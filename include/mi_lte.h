@@ -414,6 +414,9 @@ int  mi_lte_pdcch_re_tables(uint32_t N_rb_dl, uint32_t N_ant, uint32_t N_id_cell
 /* what the reference leaves in LIBLTE_PHY_PCFICH_STRUCT::k, n and LIBLTE_PHY_PHICH_STRUCT::N_reg, k (:7903-7910, :8243-8278) */
 int  mi_lte_ctrl_reg_positions(uint32_t N_rb_dl, uint32_t N_id_cell, float phich_res, uint32_t *pcfich_k /* [4] */,
                                float *pcfich_n /* [4] */, uint32_t *phich_N_reg, uint32_t *phich_k /* [75] */);
+/* atan2f as the de-mappers evaluate it where the reference DECIDES on an angle (QPSK / BPSK quadrants, PUCCH 1b regions): the algorithm of
+ * the reference host's libm (glibc 2.35) restated in float arithmetic, here on the host (tests pin it to libm bit for bit) */
+int  mi_lte_model_atan2f(const float *h_y, const float *h_x, float *h_out, size_t n);
 /* the two DCI unpackers on their own (host arithmetic; what the shim and tests compare with the reference's) */
 int  mi_lte_dci_1a_unpack(uint32_t payload, uint32_t n_bits, uint32_t rnti, uint32_t N_rb_dl, uint32_t N_ant, mi_lte_pdcch_dci *out);
 int  mi_lte_dci_1c_unpack(uint32_t payload, uint32_t n_bits, uint32_t rnti, uint32_t N_rb_dl, uint32_t N_ant, mi_lte_pdcch_dci *out);

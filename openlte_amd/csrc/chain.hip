@@ -561,6 +561,14 @@ void mi_lte_pdsch_plan_destroy(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl)
 
 uint32_t mi_lte_pdsch_plan_out_stride(const mi_lte_pdsch_plan *pl) { return pl ? pl->out_stride : 0; }
 
+// the de-mappers' atan2f (phy_dev.hpp: the host libm's algorithm restated) evaluated on the host, for the test that pins it to libm
+int mi_lte_model_atan2f(const float *h_y, const float *h_x, float *h_out, size_t n)
+{
+    if (!h_y || !h_x || !h_out) return MI_LTE_ERR_INVALID_ARG;
+    for (size_t i = 0; i < n; i++) h_out[i] = ref_atan2f(h_y[i], h_x[i]);
+    return MI_LTE_OK;
+}
+
 int mi_lte_pdsch_plan_soft_bits(const mi_lte_pdsch_plan *pl, uint32_t alloc, const int8_t **d_e, const uint32_t **d_len)
 {
     if (!pl || alloc >= pl->n_alloc || !d_e || !d_len) return MI_LTE_ERR_INVALID_ARG;

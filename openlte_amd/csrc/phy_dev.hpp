@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstring>
 
 namespace {
 
@@ -110,6 +111,71 @@ __device__ __forceinline__ void ce_time_interp5_slot(const float (&M)[5], float 
 #undef MI_CE_SLOPE
 }
 
+// atan2f as the reference's host computes it -- glibc 2.35 (the image's libm: the fdlibm single-precision algorithm with glibc's 2^25
+// large-argument threshold), restated operation by operation in float arithmetic (this file is compiled with -ffp-contract=off), so that
+// the DECISIONS the reference takes on an angle come out the same where the angle sits within an ulp of 0, +-pi/4, +-pi/2, +-3pi/4 or pi.
+// The device library's atan2f is good to a few ulp, which is not enough there: the differential soak found one QPSK symbol in 7.7e8
+// (re = -1.07, im = +4.0e-8: libm 0x40490fda < pi, device atan2f 0x40490fdb > pi, the other quadrant, tools/r3/repro_seed17.py).
+// Bit-identical to libm's atan2f on 1.2e8 argument pairs incl. NaN / infinities / zeros (tests/test_oracle.py through
+// mi_lte_model_atan2f).  A host with another libm may round differently: SURVEY 8c files that under the libm tolerance.
+__host__ __device__ inline uint32_t ref_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+__host__ __device__ inline float    ref_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+__host__ __device__ inline float ref_atanf(float x)
+{
+    const float atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+    const float atanlo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+    const float aT[11] = {3.3333334327e-01f, -2.0000000298e-01f, 1.4285714924e-01f, -1.1111110449e-01f, 9.0908870101e-02f, -7.6918758452e-02f,
+                          6.6610731184e-02f, -5.8335702866e-02f, 4.9768779427e-02f, -3.6531571299e-02f, 1.6285819933e-02f};
+    const int32_t hx = (int32_t)ref_f2u(x), ix = hx & 0x7fffffff;
+    int           id;
+    if (ix >= 0x4c000000) { // |x| >= 2^25
+        if (ix > 0x7f800000) return x + x;
+        return hx > 0 ? atanhi[3] + atanlo[3] : -atanhi[3] - atanlo[3];
+    }
+    if (ix < 0x3ee00000) { // |x| < 0.4375
+        if (ix < 0x39800000) return x; // |x| < 2^-12
+        id = -1;
+    } else {
+        x = fabsf(x);
+        if (ix < 0x3f980000) {
+            if (ix < 0x3f300000) { id = 0; x = (2.0f * x - 1.0f) / (2.0f + x); }
+            else                 { id = 1; x = (x - 1.0f) / (x + 1.0f); }
+        } else {
+            if (ix < 0x401c0000) { id = 2; x = (x - 1.5f) / (1.0f + 1.5f * x); }
+            else                 { id = 3; x = -1.0f / x; }
+        }
+    }
+    const float z = x * x, w = z * z;
+    const float s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
+    const float s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
+    if (id < 0) return x - x * (s1 + s2);
+    const float r = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+    return hx < 0 ? -r : r;
+}
+// (not inlined on the device: it is reached by one symbol in tens of thousands, and inlining it into k_pdsch_demod changed the register
+// allocation of the loop around it -- 4.48 -> 4.72 ms per 65 536 subframes, measured)
+__host__ __device__ __attribute__((noinline)) float ref_atan2f(float y, float x)
+{
+    const float   tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    const int32_t hx = (int32_t)ref_f2u(x), hy = (int32_t)ref_f2u(y), ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
+    if (hx == 0x3f800000) return ref_atanf(y);
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2); // 2 * sign(x) + sign(y)
+    if (iy == 0) return m < 2 ? y : m == 2 ? pi + tiny : -pi - tiny;
+    if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000) return m == 0 ? pi_o_4 + tiny : m == 1 ? -pi_o_4 - tiny : m == 2 ? 3.0f * pi_o_4 + tiny : -3.0f * pi_o_4 - tiny;
+        return m == 0 ? 0.0f : m == 1 ? -0.0f : m == 2 ? pi + tiny : -pi - tiny;
+    }
+    if (iy == 0x7f800000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    const int32_t k = (iy - ix) >> 23;
+    float         z;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
+    else if (hx < 0 && k < -60) z = 0.0f;
+    else z = ref_atanf(fabsf(y / x));
+    return m == 0 ? z : m == 1 ? ref_u2f(ref_f2u(z) ^ 0x80000000u) : m == 2 ? pi - (z - pi_lo) : (z - pi_lo) - pi;
+}
+
 // get_soft_decision (liblte_phy.cc:13880-13900) with max_dist = 1
 __device__ __forceinline__ float soft_decision(float rx_re, float rx_im, float exp_re, float exp_im)
 {
@@ -141,14 +207,15 @@ __device__ __forceinline__ void demap_symbol(float re, float im, uint32_t mod, i
     } else if (mod == 1) {
         float er, ei;
         // The reference picks the quadrant from atan2f(im, re) compared with 0, +-pi/2 and pi in double.  Away from the axes that
-        // is the pair of signs (atan2f is good to a few ulp, the margin below is five orders wider); on or next to an axis --
-        // zeros, signed zeros, angles that round to float(pi/2) or float(pi), NaN -- the comparisons themselves are evaluated.
+        // is the pair of signs (the margin below is two orders wider than the rounding of any atan2f); on or next to an axis --
+        // zeros, signed zeros, angles that round to float(pi/2) or float(pi), NaN -- the comparisons themselves are evaluated, on the
+        // host libm's atan2f (ref_atan2f above)
         const float ar = fabsf(re), ai = fabsf(im);
         if (ar > 1e-5f * ai && ai > 1e-5f * ar) { // false for NaN, zeros and infinities as well
             er = re > 0 ? r2 : -r2;
             ei = im > 0 ? r2 : -r2;
         } else {
-            const float ang = atan2f(im, re);
+            const float ang = ref_atan2f(im, re);
             if (((double)ang >= 0) && ((double)ang < M_PI / 2))         { er = r2;  ei = r2; }
             else if (((double)ang >= -M_PI / 2) && ((double)ang < 0))   { er = r2;  ei = -r2; }
             else if (((double)ang >= M_PI / 2) && ((double)ang < M_PI)) { er = -r2; ei = r2; }
@@ -158,7 +225,7 @@ __device__ __forceinline__ void demap_symbol(float re, float im, uint32_t mod, i
         b[0] = (int8_t)((er > 0) ? m : -m);
         b[1] = (int8_t)((ei > 0) ? m : -m);
     } else {
-        const float ang = atan2f(im, re);
+        const float ang = ref_atan2f(im, re);
         if (((double)ang > -M_PI / 4) && ((double)ang < 3 * M_PI / 4)) b[0] = (int8_t)(int)(127 * soft_decision(re, im, r2, r2));
         else                                                          b[0] = (int8_t)(-(int)(127 * soft_decision(re, im, -r2, -r2)));
     }

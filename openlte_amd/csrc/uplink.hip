@@ -408,7 +408,7 @@ __global__ __launch_bounds__(64) void k_pucch_decode(const float *__restrict__ s
             if (d_re < 0) { sd = pucch_soft(d_re, d_im, -1, 0); b0 = 1; }
             else          { sd = pucch_soft(d_re, d_im, 1, 0); b0 = 0; }
         } else {
-            const float ang = atan2f(d_im, d_re);
+            const float ang = ref_atan2f(d_im, d_re); // (decisions on the angle: the host libm's rounding, phy_dev.hpp)
             nb = 2;
             if (ang >= M_PI / 4 && ang < 3 * M_PI / 4)        { sd = pucch_soft(d_re, d_im, 0, 1); b0 = 1; b1 = 0; }
             else if (ang >= -M_PI / 4 && ang < M_PI / 4)      { sd = pucch_soft(d_re, d_im, 1, 0); b0 = 0; b1 = 0; }

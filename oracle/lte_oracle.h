@@ -121,6 +121,9 @@ int  lo_pdsch_channel_decode(const lo_cfg_t *cfg, const lo_subframe_t *sf, const
 /* ---- timing helper for bench.py's cpu_baseline leg ---- */
 double lo_time_turbo_decode_ref(const float *d_interleaved, uint32_t K, uint32_t n_cb, uint8_t *c_bits);
 
+/* ---- the host libm's atan2f over arrays (tests pin mi_lte_model_atan2f to it) ---- */
+void lo_libm_atan2f(const float *y, const float *x, float *out, uint64_t n);
+
 #ifdef __cplusplus
 }
 #endif

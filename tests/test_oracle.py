@@ -559,3 +559,44 @@ def test_timing_fft_stand_in_agrees_with_the_parity_one(ref):
                 L.fftwf_execute(plan)
                 L.fftwf_destroy_plan(plan)
                 assert np.linalg.norm(y - want) <= 2e-6 * max(np.linalg.norm(want), 1e-30), (n, sign, L is fast)
+
+
+@td.on_both_boxes
+def test_demappers_atan2f_is_the_host_libms(port, box):
+    """phy_dev.hpp's ref_atan2f (what the de-mappers decide QPSK / BPSK quadrants and PUCCH 1b regions on) against libm's atan2f on
+    this host, bit for bit: arbitrary bit patterns (NaNs, infinities, zeros, denormals), pairs within 2^-60 .. 2^-1 of either axis and of
+    the diagonals, moderate values.  The reference compares the float angle with 0, +-pi/2, pi (and +-pi/4, 3pi/4) in double, so one ulp
+    of difference at those values is another quadrant (the soak's one differing soft bit in 320 000 cases)."""
+    import ctypes as C
+    import openlte_amd as m
+    L = m.load_library()
+    f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+    L.mi_lte_model_atan2f.argtypes = [f32p, f32p, f32p, C.c_size_t]
+    port.lo_libm_atan2f.argtypes = [f32p, f32p, f32p, C.c_uint64]
+    rng = np.random.default_rng(17)
+    n = 3_000_000
+
+    def unit(k):  # random floats in [0.5, 1) with random signs
+        return (rng.integers(0, 1 << 23, k, dtype=np.uint32) | np.uint32(0x3F000000) | (rng.integers(0, 2, k, dtype=np.uint32) << np.uint32(31))).view(np.float32)
+
+    sets = []
+    a, b = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32), rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    sets.append((a, b))
+    small = np.ldexp(unit(n), -rng.integers(1, 61, n)).astype(np.float32)
+    x = unit(n)
+    sets.append((x * small, x))          # next to the real axis (both signs of both)
+    sets.append((x, x * small))          # next to the imaginary axis
+    d = (1.0 + rng.integers(-128, 129, n) * 1e-7).astype(np.float32) * rng.choice(np.array([-1.0, 1.0], np.float32), n)
+    sets.append((x * d, x))              # next to the diagonals
+    sets.append(((rng.integers(-2000, 2001, n) / 977.0).astype(np.float32), (rng.integers(-2000, 2001, n) / 1021.0).astype(np.float32)))
+    sets.append((np.array([-1.0715198516845703e+00 * 0 + 4.047898727321808e-08, 0.0, -0.0, 0.0, -0.0, np.inf, -np.inf, np.nan, 1.0], np.float32),
+                 np.array([-1.0715198516845703, -1.0, -1.0, 1.0, 0.0, -np.inf, np.inf, 1.0, np.nan], np.float32)))
+    for y, xx in sets:
+        y, xx = np.ascontiguousarray(y, np.float32), np.ascontiguousarray(xx, np.float32)
+        got, want = np.zeros(len(y), np.float32), np.zeros(len(y), np.float32)
+        assert L.mi_lte_model_atan2f(y, xx, got, len(y)) == 0
+        port.lo_libm_atan2f(y, xx, want, len(y))
+        same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), (y[~same][:4], xx[~same][:4], got[~same][:4], want[~same][:4])
+    # the soak's symbol: below pi (second quadrant) with libm, above it with a few-ulp atan2f
+    assert got[0].view(np.uint32) == 0x40490FDA

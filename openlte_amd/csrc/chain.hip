@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
                     if (QAM) put_qam(dst, idx, qam_neg_bits(xr, xi, MOD));
                     else {
                         int8_t b[6] = {0, 0, 0, 0, 0, 0};
-                        demap_symbol(xr, xi, MOD, b);
+                        demap_symbol<true>(xr, xi, MOD, b);
                         put_bits(dst, idx, b);
                     }
                 }
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
                     if (QAM) put_qam(dst, idx[r], qam_neg_bits(xr, xi, MOD));
                     else {
                         int8_t b[6] = {0, 0, 0, 0, 0, 0};
-                        demap_symbol(xr, xi, MOD, b);
+                        demap_symbol<true>(xr, xi, MOD, b);
                         put_bits(dst, idx[r], b);
                     }
                 }
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
                 continue;
             }
             int8_t b[6] = {0, 0, 0, 0, 0, 0};
-            demap_symbol(x_re[p], x_im[p], MOD, b);
+            demap_symbol<true>(x_re[p], x_im[p], MOD, b);
             if (via_lds) put_bits(e_lds, i * N_ant + p, b); else put_bits(e, i * N_ant + p, b);
         }
     }

@@ -152,9 +152,7 @@ __host__ __device__ inline float ref_atanf(float x)
     const float r = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
     return hx < 0 ? -r : r;
 }
-// (not inlined on the device: it is reached by one symbol in tens of thousands, and inlining it into k_pdsch_demod changed the register
-// allocation of the loop around it -- 4.48 -> 4.72 ms per 65 536 subframes, measured)
-__host__ __device__ __attribute__((noinline)) float ref_atan2f(float y, float x)
+__host__ __device__ inline float ref_atan2f(float y, float x)
 {
     const float   tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
     const int32_t hx = (int32_t)ref_f2u(x), hy = (int32_t)ref_f2u(y), ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
@@ -176,6 +174,12 @@ __host__ __device__ __attribute__((noinline)) float ref_atan2f(float y, float x)
     return m == 0 ? z : m == 1 ? ref_u2f(ref_f2u(z) ^ 0x80000000u) : m == 2 ? pi - (z - pi_lo) : (z - pi_lo) - pi;
 }
 
+// The same out of line: it is reached by one symbol in tens of thousands, and where the call site sits in a branch the benchmark's
+// modulation never takes (k_pdsch_demod: QPSK next to the 64QAM loop) inlining it changed that loop's register allocation -- 4.42 against
+// 4.72 ms per 65 536 subframes.  Where the QPSK path IS the hot loop (k_pusch_demod, k_pdcch_decode) a call inside it costs more than the
+// code (W5 2.65 -> 2.54 M subframes/s), so demap_symbol takes the choice as a template parameter (profiles/r03t_*, r03u_*).
+__host__ __device__ __attribute__((noinline)) float ref_atan2f_call(float y, float x) { return ref_atan2f(y, x); }
+
 // get_soft_decision (liblte_phy.cc:13880-13900) with max_dist = 1
 __device__ __forceinline__ float soft_decision(float rx_re, float rx_im, float exp_re, float exp_im)
 {
@@ -187,7 +191,7 @@ __device__ __forceinline__ float soft_decision(float rx_re, float rx_im, float e
 }
 
 // modulation_demapper (liblte_phy.cc:9502-9660) for one symbol; writes Q_m int8 values
-__device__ __forceinline__ void demap_symbol(float re, float im, uint32_t mod, int8_t *b)
+template <bool ATAN_OUT_OF_LINE = false> __device__ __forceinline__ void demap_symbol(float re, float im, uint32_t mod, int8_t *b)
 {
     const float r2 = (float)(1 / sqrt(2.0)), t10 = (float)(2 / sqrt(10.0)), t42 = (float)(2 / sqrt(42.0)),
                 f42 = (float)(4 / sqrt(42.0)), s42 = (float)(6 / sqrt(42.0));
@@ -215,7 +219,7 @@ __device__ __forceinline__ void demap_symbol(float re, float im, uint32_t mod, i
             er = re > 0 ? r2 : -r2;
             ei = im > 0 ? r2 : -r2;
         } else {
-            const float ang = ref_atan2f(im, re);
+            const float ang = ATAN_OUT_OF_LINE ? ref_atan2f_call(im, re) : ref_atan2f(im, re);
             if (((double)ang >= 0) && ((double)ang < M_PI / 2))         { er = r2;  ei = r2; }
             else if (((double)ang >= -M_PI / 2) && ((double)ang < 0))   { er = r2;  ei = -r2; }
             else if (((double)ang >= M_PI / 2) && ((double)ang < M_PI)) { er = -r2; ei = r2; }
@@ -225,7 +229,7 @@ __device__ __forceinline__ void demap_symbol(float re, float im, uint32_t mod, i
         b[0] = (int8_t)((er > 0) ? m : -m);
         b[1] = (int8_t)((ei > 0) ? m : -m);
     } else {
-        const float ang = ref_atan2f(im, re);
+        const float ang = ATAN_OUT_OF_LINE ? ref_atan2f_call(im, re) : ref_atan2f(im, re);
         if (((double)ang > -M_PI / 4) && ((double)ang < 3 * M_PI / 4)) b[0] = (int8_t)(int)(127 * soft_decision(re, im, r2, r2));
         else                                                          b[0] = (int8_t)(-(int)(127 * soft_decision(re, im, -r2, -r2)));
     }

@@ -70,10 +70,10 @@ def port_case(port, c, planes, iq):
 
 @td.on_both_boxes
 def test_restatement_equals_the_reference_on_random_cases(port, ref_big, box):
-    """~350 random downlink cases (one PRB list for both slots: the restatement's interface), every bandwidth, 1 / 2 / 4 ports,
+    """~2 000 random downlink cases (one PRB list for both slots: the restatement's interface), every bandwidth, 1 / 2 / 4 ports,
     allocations up to the full band: soft bits, verdict and transport block identical; its own front end within the FFT tolerance."""
-    cases = [c for c in fz.draw_dl_cases(420, 77, big_share=0.08) if c["prb0"] == c["prb1"]]
-    assert len(cases) >= 300
+    cases = [c for c in fz.draw_dl_cases(2400, 77, big_share=0.08) if c["prb0"] == c["prb1"]]
+    assert len(cases) >= 1800
     r = fz.run_ref_dl(ref_big, cases)
     res = td.parallel_map(lambda i: port_case(port, cases[i], r["planes"][i], r["iq"][i]), range(len(cases)))
     n_ok = n_big = 0
@@ -86,7 +86,7 @@ def test_restatement_equals_the_reference_on_random_cases(port, ref_big, box):
             n_ok += 1
         assert tol[0] < 1e-5 and tol[1] < 1e-4, key + tol
         n_big += c["e"] > 10000
-    assert n_ok >= 120 and n_big >= 15
+    assert n_ok >= 700 and n_big >= 90
 
 
 @td.on_both_boxes

@@ -27,6 +27,15 @@ bool valid_fft(uint32_t fft_size, uint32_t N_rb)
 }
 uint32_t fft_of(uint32_t N_rb) { return N_rb <= 6 ? 128 : N_rb <= 15 ? 256 : N_rb <= 25 ? 512 : N_rb <= 50 ? 1024 : 2048; }
 
+bool prbs_on_carrier(const mi_lte_pdsch_alloc &a, uint32_t N_rb)
+{
+    if (a.N_prb > 112) return false;
+    for (uint32_t s = 0; s < 2; s++)
+        for (uint32_t i = 0; i < a.N_prb; i++)
+            if (a.prb[s][i] >= N_rb) return false;
+    return true;
+}
+
 template <typename Plan> struct PlanCache { // key -> plan, most recently used first
     typedef void (*Destroy)(mi_lte_ctx *, Plan *);
     std::list<std::pair<std::string, Plan *>> items;
@@ -517,7 +526,7 @@ int mi_lte_dl_subframe_decode_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t 
     for (uint32_t k = 0; k < *N_dci && k < MI_LTE_PDCCH_MAX_DCI; k++) {
         status[k] = 2; N_out_bits[k] = 0;
         const mi_lte_pdsch_alloc &a = dci[k].alloc;
-        if (a.tbs + 24 > 6144 || a.tbs == 0 || a.N_prb == 0 || a.N_prb > N_rb_dl || a.mod_type > 3) continue;
+        if (a.tbs + 24 > 6144 || a.tbs == 0 || a.N_prb == 0 || a.N_prb > N_rb_dl || a.mod_type > 3 || !prbs_on_carrier(a, N_rb_dl)) continue;
         al[n_al] = a; al[n_al].unit = 0; al[n_al].n_pdcch_symbs = *N_symbs;
         slot[n_al++] = k;
     }
@@ -556,6 +565,9 @@ int mi_lte_pdsch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_dl, const fl
     mi_lte_dl_cfg       cfg = {fft_of(N_rb_dl), N_rb_dl, N_ant, MI_LTE_IQ_F32_PLANAR};
     mi_lte_pdsch_alloc  a   = *alloc;
     a.unit = 0; a.n_pdcch_symbs = 0;
+    // a resource block past the carrier (a DCI that passed its CRC by chance): the reference demodulates whatever lies behind the row and
+    // fails the transport block's CRC; the plans refuse such a list, so report the decode failure here
+    if (!prbs_on_carrier(a, N_rb_dl)) return 2;
     std::string key;
     key_add(key, cfg); key_add(key, N_pdcch_symbs); key_add(key, a);
     mi_lte_pdsch_plan *plan = hc->pdsch.find(key);
@@ -779,7 +791,7 @@ int mi_lte_pusch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_ul, const fl
     mi_lte_pusch_plan *plan = hc->pusch.find(key);
     if (!plan) {
         rc = mi_pusch_plan_create_impl(ctx, &cfg, nullptr, &subfr_num, &N_id_cell, 1, &a, 1, dm.data(), &plan);
-        if (rc == MI_LTE_ERR_UNSUPPORTED) return 1;
+        if (rc == MI_LTE_ERR_UNSUPPORTED || (rc == MI_LTE_ERR_INVALID_ARG && !prbs_on_carrier(a, N_rb_ul))) return 1; // (what the reference reports for an allocation it cannot decode)
         if (rc != MI_LTE_OK) return rc;
         hc->pusch.put(ctx, key, plan);
     }

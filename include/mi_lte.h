@@ -176,6 +176,13 @@ int      mi_lte_pdsch_plan_create_dynamic(mi_lte_ctx *ctx, const mi_lte_dl_cfg *
 int      mi_lte_pdsch_plan_assign(mi_lte_ctx *ctx, mi_lte_pdsch_plan *plan, uint32_t N_pdcch_symbs, const mi_lte_pdsch_alloc *h_allocs,
                                   uint32_t n_alloc);
 uint32_t mi_lte_pdsch_plan_n_alloc(const mi_lte_pdsch_plan *plan);
+/* 1 when the plans decode this allocation, 0 when they refuse it: more than one code block (tbs + 24 > 6144, the reference's own C > 1
+ * path is broken), N_prb == 0 or > N_rb_dl, a modulation past 64QAM, a control region outside 1..4 symbols, or a resource block
+ * outside the carrier (an invalid RIV: a DCI whose 16-bit CRC matched on noise).  liblte_phy_pdsch_channel_decode (liblte_phy.cc:3690-3853)
+ * fails such an allocation on its own -- the callers that plan many allocations at once (mi_lte_dl_pipeline_run_units / _run_capture,
+ * mi_lte_dl_subframe_decode_host, shim/scan_batch.cc) use this test to report status 2 (LIBLTE_ERROR_DECODE_FAIL) at the allocation's
+ * own index instead of failing the whole list; mi_lte_pdsch_plan_create / _assign themselves keep returning an error for it. */
+int      mi_lte_pdsch_alloc_decodable(const mi_lte_dl_cfg *cfg, const mi_lte_pdsch_alloc *alloc, uint32_t N_pdcch_symbs);
 /* Decoder of the plan's transport blocks: MI_LTE_TURBO_REF (default; the reference's decoder, bit-exact) or MI_LTE_TURBO_BCJR with
  * n_iter iterations (the max-log-MAP decoder of mi_lte_turbo_decode_batch; the reference has no such mode).  In BCJR mode the soft
  * bits are rate-un-matched to int8 channel values (sums of repeats saturated to +-127) and the decoded block is finished like

@@ -635,7 +635,7 @@ int mi_turbo_bcjr_iterate(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, uint32_t n
     const uint32_t n_seg = bcjr_n_seg(K);
     if (early) // the change words start at zero (the decisions need no initial value: the first iteration always counts as a change)
         MI_HIP_CHECK(ctx, hipMemsetAsync(l.chg, 0, (size_t)n_iter * n_pairs * sizeof(uint32_t), ctx->stream));
-    ctx->bcjr_early = {early ? l.chg : nullptr, (uint32_t)n_pairs, n_iter, n_cb};
+    ctx->bcjr_early = {nullptr, (uint32_t)n_pairs, n_iter, n_cb}; // set once the change words sit in the context's own buffer (below)
     for (uint32_t it = 0; it < n_iter; it++) {
         const bool last = it + 1 == n_iter;
         const uint32_t rd = it & 1u, wr = rd ^ 1u;
@@ -662,6 +662,17 @@ int mi_turbo_bcjr_iterate(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, uint32_t n
     MI_LAUNCH(ctx, "k_bcjr_final", k_bcjr_final, dim3(n_pairs, Kp / 64), dim3(128), 0, (const uint8_t *)HD, (const uint32_t *)tb.d_inv_row, (const int8_t *)B.S1, K, n_cb,
               (uint32_t)n_tiles, d_c_bits);
     MI_HIP_CHECK(ctx, hipGetLastError());
+    if (early) { // mi_lte_turbo_early_exit_iterations may be asked after other work has reused (or re-allocated) the scratch: keep a copy
+        const size_t n_words = (size_t)n_iter * n_pairs;
+        if (n_words > ctx->bcjr_early_cap) {
+            uint32_t *nb = nullptr;
+            MI_HIP_CHECK(ctx, hipMalloc((void **)&nb, n_words * sizeof(uint32_t)));
+            ctx->owned.push_back(nb); // (the smaller one it replaces stays owned until the context goes)
+            ctx->bcjr_early_buf = nb; ctx->bcjr_early_cap = n_words;
+        }
+        MI_HIP_CHECK(ctx, hipMemcpyAsync(ctx->bcjr_early_buf, l.chg, n_words * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+        ctx->bcjr_early.chg = ctx->bcjr_early_buf;
+    }
     ctx->last_kernels = "k_bcjr_prep:1,k_bcjr_half: 2 per iteration,k_bcjr_final:1";
     return MI_LTE_OK;
 }

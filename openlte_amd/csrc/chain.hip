@@ -510,6 +510,18 @@ int mi_pdsch_plan_create_mapped(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, uint3
 
 extern "C" {
 
+int mi_lte_pdsch_alloc_decodable(const mi_lte_dl_cfg *cfg, const mi_lte_pdsch_alloc *al, uint32_t N_pdcch_symbs)
+{ // the per-allocation conditions of plan_layout, for callers that must not lose a whole list to one chance-CRC DCI
+    if (!cfg || !al) return 0;
+    const uint32_t cfi = al->n_pdcch_symbs ? al->n_pdcch_symbs : N_pdcch_symbs;
+    if (al->tbs + 24 > 6144 || al->tbs + 24 < al->tbs || al->N_prb == 0 || al->N_prb > cfg->N_rb_dl || al->N_prb > 110 || al->mod_type > 3 || cfi < 1 || cfi > 4) return 0;
+    if ((14 - cfi) * al->N_prb * 12 * (al->mod_type == 3 ? 6u : al->mod_type == 2 ? 4u : al->mod_type == 1 ? 2u : 1u) > 4095u * 32u) return 0; // the scrambling table
+    for (uint32_t s = 0; s < 2; s++)
+        for (uint32_t i = 0; i < al->N_prb; i++)
+            if (al->prb[s][i] >= cfg->N_rb_dl) return 0;
+    return 1;
+}
+
 int mi_lte_pdsch_plan_assign(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, uint32_t N_pdcch_symbs, const mi_lte_pdsch_alloc *h_allocs, uint32_t n_alloc)
 {
     if (!ctx || !pl || !pl->dynamic || !h_allocs || n_alloc == 0 || N_pdcch_symbs < 1 || N_pdcch_symbs > 4) return MI_LTE_ERR_INVALID_ARG;

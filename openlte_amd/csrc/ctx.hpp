@@ -45,6 +45,7 @@ struct mi_lte_ctx {
     size_t             scratch_bytes = 0;
     uint32_t          *h_flag = nullptr, *d_flag = nullptr; // the completion word of the per-call waits (mi_stream_wait_polling) and its sequence number
     uint32_t           flag_seq = 0;
+    uint32_t *bcjr_early_buf = nullptr; size_t bcjr_early_cap = 0; // ctx-owned copy of the change words (the scratch they are counted in is shared with every other kernel family)
     struct { uint32_t *chg; uint32_t n_pairs, n_iter, n_cb; } bcjr_early = {nullptr, 0, 0, 0}; // the last early-termination decode's change words (bcjr.hip)
     bool               bcjr_block_lds_set = false; // hipFuncSetAttribute(k_bcjr_block, max dynamic LDS) made on this context's device
     uint32_t           siso_small_max = 4096; // code blocks per decode up to which k_turbo_siso_small runs (mi_lte_set_turbo_small_batch)

@@ -526,7 +526,7 @@ int mi_lte_dl_subframe_decode_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t 
     for (uint32_t k = 0; k < *N_dci && k < MI_LTE_PDCCH_MAX_DCI; k++) {
         status[k] = 2; N_out_bits[k] = 0;
         const mi_lte_pdsch_alloc &a = dci[k].alloc;
-        if (a.tbs + 24 > 6144 || a.tbs == 0 || a.N_prb == 0 || a.N_prb > N_rb_dl || a.mod_type > 3 || !prbs_on_carrier(a, N_rb_dl)) continue;
+        if (a.tbs == 0 || !mi_lte_pdsch_alloc_decodable(&cfg, &a, *N_symbs)) continue;
         al[n_al] = a; al[n_al].unit = 0; al[n_al].n_pdcch_symbs = *N_symbs;
         slot[n_al++] = k;
     }

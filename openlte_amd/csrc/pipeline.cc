@@ -133,6 +133,7 @@ static void device_worker(mi_lte_dl_pipeline *p, uint32_t di, const Job *job)
     const size_t unit_bytes = p->unit_samples * 2;
     uint32_t     k = 0; // chunks this device has taken
     std::vector<mi_lte_pdsch_alloc> local;
+    std::vector<size_t>             refused; // allocations outside the decodable envelope: status 2 at their own index
     auto fail = [&](Lane &l, int rc) { d.rc = rc; d.err = mi_lte_last_error(l.ctx); };
     for (uint32_t c = di; c < n_chunks; c += G, k++) {
         Lane          &l  = d.lanes[k % d.lanes.size()];
@@ -156,7 +157,18 @@ static void device_worker(mi_lte_dl_pipeline *p, uint32_t di, const Job *job)
             n_al = job->h_first[u0 + n] - a0;
             if (n_al == 0) continue;
             local.assign(job->h_allocs + a0, job->h_allocs + a0 + n_al);
-            for (auto &a : local) a.unit -= u0;
+            for (size_t i = 0; i < n_al; i++) {
+                mi_lte_pdsch_alloc &a = local[i];
+                a.unit -= u0;
+                if (!mi_lte_pdsch_alloc_decodable(&p->cfg, &a, job->cfi)) {
+                    // A DCI that passed its CRC by chance (resource blocks past the carrier, more than one code block ...): the reference fails
+                    // that one allocation (liblte_phy.cc:3690-3853), so must a run over thousands of subframes.  The slot keeps its place in the
+                    // chunk's list -- results are copied back in one piece -- with a one-block QPSK stand-in, and its verdict is overwritten below
+                    a.N_prb = 1; a.prb[0][0] = a.prb[1][0] = 0; a.mod_type = 1; a.tbs = 16; a.rv_idx = 0; a.tx_mode = 1;
+                    if (a.n_pdcch_symbs > 4) a.n_pdcch_symbs = 0;
+                    refused.push_back(a0 + i);
+                }
+            }
             rc = mi_lte_pdsch_plan_assign(l.ctx, l.dyn, job->cfi, local.data(), (uint32_t)n_al);
             plan = l.dyn;
         } else if (n == p->chunk) {
@@ -181,6 +193,7 @@ static void device_worker(mi_lte_dl_pipeline *p, uint32_t di, const Job *job)
         const int rc = mi_lte_sync(l.ctx);
         if (rc != MI_LTE_OK && d.rc == MI_LTE_OK) fail(l, rc);
     }
+    for (size_t i : refused) job->h_status[i] = 2; // LIBLTE_ERROR_DECODE_FAIL (after the copies of the stand-ins' verdicts have landed)
 }
 
 static int run_job(mi_lte_dl_pipeline *p, const Job &job)

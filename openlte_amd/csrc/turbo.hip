@@ -745,23 +745,30 @@ struct SisoArgs { SisoPass p[2]; };
 typedef unsigned short v2u __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t sign_bits(v2s n) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(v2u, n) >> 15); } // 1 per negative half
 
-// one trellis step of both halves.  x, y: the step's two soft inputs as int16 pairs; acc: the traceback bits of the current four
-// steps, 16 bits per half (bit = PM[2j] > PM[2j+1] = sign of n_j, j = 0 first)
-__device__ __forceinline__ void acs_step2(v2s (&pm)[8], v2s x, v2s y, uint32_t &acc)
+// one trellis step of both halves.  x2, y2: TWICE the step's two soft inputs as int16 pairs (the byte extraction shifts by 7 instead of 8:
+// the doubling the branch terms need comes for free); acc: the traceback bits of the current four steps, 16 bits per half
+// (bit = PM[2j] > PM[2j+1] = sign of n_j; step S of the four, pair j -> bit 15 - (4S + j)).
+// Every instruction of this loop costs four cycles of its SIMD, also the ones that issue in two on their own (v_and, v_xor, v_bitop3):
+// profiles/r04_ubench_issue_mix.txt -- a SIMD that alternates between the two kinds runs both at the slow rate -- so what counts is
+// the number of instructions, 66 per step and pair of trellises: 8 for the two inputs (2 byte permutes, 2 shifts, 3 sign masks and
+// their exclusive-or), 10 branch terms, 4 metric differences, 8 decision bits (a sign mask and one and-or with the bit's own
+// constant each: collecting the signs by shifts took 10), 8 threshold tests + 8 masks + 16 candidates + 8 selects.
+template <int S> __device__ __forceinline__ void acs_step2(v2s (&pm)[8], v2s x2, v2s y2, uint32_t &acc)
 {
     // With w = |x|+|y| and e = +1 for a negative soft value:  w*P = -2(x+y) if the two signs agree, else 0;
     // w*Q = -2(x-y) if they differ, else 0;  2P, 2Q = +-4 (sign of x) under the same conditions.
-    const v2s m0 = x >> 15, mx = m0 ^ (y >> 15), nmx = ~mx; // mx = -1 iff the signs differ
-    const v2s uP = ((x + y) << 1) & nmx;                    // -w*P
-    const v2s uQ = ((x - y) << 1) & mx;                     // -w*Q
-    const v2s c4 = (m0 & (v2s)(8)) - (v2s)(4);              // x < 0 ? 4 : -4
+    const v2s m0 = x2 >> 15, mx = m0 ^ (y2 >> 15), nmx = ~mx; // mx = -1 iff the signs differ
+    const v2s uP = (x2 + y2) & nmx;                          // -w*P
+    const v2s uQ = (x2 - y2) & mx;                           // -w*Q
+    const v2s c4 = (m0 & (v2s)(8)) - (v2s)(4);               // x < 0 ? 4 : -4
     const v2s P2 = c4 & nmx, Q2 = c4 & mx;
     const v2s n0 = pm[1] - pm[0], n1 = pm[3] - pm[2], n2 = pm[5] - pm[4], n3 = pm[7] - pm[6];
-    // (acc << 1) | sign, both halves in one 32-bit operation: a half never holds more than its 16 bits
-    acc = (acc << 1) | sign_bits(n0);
-    acc = (acc << 1) | sign_bits(n1);
-    acc = (acc << 1) | sign_bits(n2);
-    acc = (acc << 1) | sign_bits(n3);
+    constexpr uint32_t top = 0x00010001u << (15 - 4 * S); // the step's first bit in both halves
+    // acc | (mask & bit) as ONE instruction each (the compiler's own choice is an and per bit and an or3 per two)
+    acc = __builtin_amdgcn_bitop3_b32(acc, neg_mask(n0), top, 0xF8);
+    acc = __builtin_amdgcn_bitop3_b32(acc, neg_mask(n1), top >> 1, 0xF8);
+    acc = __builtin_amdgcn_bitop3_b32(acc, neg_mask(n2), top >> 2, 0xF8);
+    acc = __builtin_amdgcn_bitop3_b32(acc, neg_mask(n3), top >> 3, 0xF8);
     auto sel = [](v2s d, v2s yes, v2s no) { return bit_select(neg_mask(d), yes, no); }; // d < 0 ? yes : no per half
     v2s nw[8];
     nw[0] = sel(n0 - P2, pm[1] + uP, pm[0] - uP); // beta =  P: (n0 <  P2) ? ..
@@ -776,10 +783,10 @@ __device__ __forceinline__ void acs_step2(v2s (&pm)[8], v2s x, v2s y, uint32_t &
     for (int s = 0; s < 8; s++) pm[s] = nw[s];
 }
 
-// byte r of the two words, sign-extended, as the pair (lo: word0, hi: word1)
-template <int R> __device__ __forceinline__ v2s byte_pair(uint32_t w0, uint32_t w1)
+// twice byte r of the two words, sign-extended, as the pair (lo: word0, hi: word1)
+template <int R> __device__ __forceinline__ v2s byte_pair2(uint32_t w0, uint32_t w1)
 {
-    return as_v2s(__builtin_amdgcn_perm(w1, w0, (uint32_t)(4 + R) << 24 | 0x0C0000u | (uint32_t)R << 8 | 0x0Cu)) >> 8;
+    return as_v2s(__builtin_amdgcn_perm(w1, w0, (uint32_t)(4 + R) << 24 | 0x0C0000u | (uint32_t)R << 8 | 0x0Cu)) >> 7;
 }
 
 // Traceback two steps at a time.  One step of the reference's traceback (liblte_phy.cc:10483-10527) maps (state at t+1, the four stored
@@ -857,14 +864,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SISO_WPE, 8
                     const uint32_t a1l = g2 ? A[1][q].z : A[1][q].x, a1h = g2 ? A[1][q].w : A[1][q].y;
                     const uint32_t b0l = g2 ? B[0][q].z : B[0][q].x, b0h = g2 ? B[0][q].w : B[0][q].y;
                     const uint32_t b1l = g2 ? B[1][q].z : B[1][q].x, b1h = g2 ? B[1][q].w : B[1][q].y;
-                    acs_step2(pm, byte_pair<0>(a0l, a1l), byte_pair<0>(b0l, b1l), acc_lo);
-                    acs_step2(pm, byte_pair<1>(a0l, a1l), byte_pair<1>(b0l, b1l), acc_lo);
-                    acs_step2(pm, byte_pair<2>(a0l, a1l), byte_pair<2>(b0l, b1l), acc_lo);
-                    acs_step2(pm, byte_pair<3>(a0l, a1l), byte_pair<3>(b0l, b1l), acc_lo);
-                    acs_step2(pm, byte_pair<0>(a0h, a1h), byte_pair<0>(b0h, b1h), acc_hi);
-                    acs_step2(pm, byte_pair<1>(a0h, a1h), byte_pair<1>(b0h, b1h), acc_hi);
-                    acs_step2(pm, byte_pair<2>(a0h, a1h), byte_pair<2>(b0h, b1h), acc_hi);
-                    acs_step2(pm, byte_pair<3>(a0h, a1h), byte_pair<3>(b0h, b1h), acc_hi);
+                    acs_step2<0>(pm, byte_pair2<0>(a0l, a1l), byte_pair2<0>(b0l, b1l), acc_lo);
+                    acs_step2<1>(pm, byte_pair2<1>(a0l, a1l), byte_pair2<1>(b0l, b1l), acc_lo);
+                    acs_step2<2>(pm, byte_pair2<2>(a0l, a1l), byte_pair2<2>(b0l, b1l), acc_lo);
+                    acs_step2<3>(pm, byte_pair2<3>(a0l, a1l), byte_pair2<3>(b0l, b1l), acc_lo);
+                    acs_step2<0>(pm, byte_pair2<0>(a0h, a1h), byte_pair2<0>(b0h, b1h), acc_hi);
+                    acs_step2<1>(pm, byte_pair2<1>(a0h, a1h), byte_pair2<1>(b0h, b1h), acc_hi);
+                    acs_step2<2>(pm, byte_pair2<2>(a0h, a1h), byte_pair2<2>(b0h, b1h), acc_hi);
+                    acs_step2<3>(pm, byte_pair2<3>(a0h, a1h), byte_pair2<3>(b0h, b1h), acc_hi);
                 }
                 dw[0][g] = __builtin_amdgcn_perm(acc_lo, acc_hi, 0x05040100u); // steps 0-3 in the upper half, 4-7 in the lower
                 dw[1][g] = __builtin_amdgcn_perm(acc_lo, acc_hi, 0x07060302u);

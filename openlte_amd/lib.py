@@ -128,6 +128,8 @@ def load_library():
     L.mi_lte_pdsch_plan_assign.argtypes = [vp, vp, u32, vp, u32]
     L.mi_lte_pdsch_plan_n_alloc.argtypes = [vp]
     L.mi_lte_pdsch_plan_n_alloc.restype = u32
+    L.mi_lte_pdsch_alloc_decodable.argtypes = [C.POINTER(DlCfg), C.POINTER(PdschAlloc), u32]
+    L.mi_lte_pdsch_alloc_decodable.restype = C.c_int
     L.mi_lte_iq_i8_to_planar.argtypes = [vp, vp, C.c_uint64, vp, vp]
     L.mi_lte_freq_shift_run.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_float, u32]
     L.mi_lte_dl_pipeline_create.argtypes = [C.c_int, C.POINTER(DlCfg), u32, vp, u32, u32, u32, C.POINTER(vp)]

@@ -49,19 +49,25 @@ std::map<LIBLTE_PHY_STRUCT *, std::shared_ptr<Entry>> g_ctx;
 // The entry is SHARED between the table and every call that is using it: liblte_phy_cleanup on another thread takes it out of the table and
 // destroys the context under the entry's mutex, but the Entry (and its mutex) lives until the last caller lets go -- a late caller then
 // finds ctx == nullptr and fails with the reference's error instead of touching freed state.
-std::shared_ptr<Entry> entry_for(LIBLTE_PHY_STRUCT *phy)
+// Entries are made by liblte_phy_init (below) and by nothing else: a struct this table does not know -- one that liblte_phy_cleanup has
+// already taken out, or one that never came from liblte_phy_init -- gets an entry without a context, i.e. the reference's error, and
+// never a fresh GPU context keyed by a dead address that the next struct malloc places there would silently inherit.
+std::shared_ptr<Entry> make_entry()
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    auto                        it = g_ctx.find(phy);
-    if (it != g_ctx.end()) return it->second;
     auto        e  = std::make_shared<Entry>();
     const char *dv = getenv("MI_LTE_DEVICE");
     if (mi_lte_ctx_create(dv ? atoi(dv) : 0, &e->ctx) != MI_LTE_OK) e->ctx = nullptr; // no GPU: every call below fails loudly
     // a caller that never writes into a LIBLTE_PHY_SUBFRAME_STRUCT between the front end and the decodes (LTE_fdd_dl_fs_samp_buf.cc does not)
     // can say so: the decodes then take the copy in HBM on the struct's address alone instead of hashing its contents
     if (e->ctx && getenv("MI_LTE_SHIM_EXPLICIT_CACHE")) mi_lte_host_cache_set_mode(e->ctx, MI_LTE_HOST_CACHE_EXPLICIT);
-    g_ctx[phy] = e;
     return e;
+}
+std::shared_ptr<Entry> entry_for(LIBLTE_PHY_STRUCT *phy)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto                        it = g_ctx.find(phy);
+    if (it != g_ctx.end()) return it->second;
+    return std::make_shared<Entry>(); // unknown struct: ctx == nullptr, the call fails
 }
 // the context of a struct, locked for the duration of the enclosing call (the test of ctx is made under the lock: cleanup nulls it there)
 #define MI_LOCKED_CTX(phy, fail)                                                                                                   \
@@ -83,6 +89,31 @@ void to_mi_alloc(const LIBLTE_PHY_ALLOCATION_STRUCT *a, mi_lte_pdsch_alloc *o)
         for (uint32 i = 0; i < a->N_prb && i < 110; i++) o->prb[s][i] = (uint8_t)a->prb[s][i];
 }
 } // namespace
+
+// liblte_phy_init (liblte_phy.h:606-612, impl. liblte_phy.cc:2154-2522): the reference's own initialisation (compiled under the name
+// liblte_phy_init_cpu, shim/Makefile) builds the struct -- tables, FFT plans, everything the entry points that are NOT replaced read --
+// and the struct it returns is registered here with a GPU context of its own.
+LIBLTE_ERROR_ENUM liblte_phy_init_cpu(LIBLTE_PHY_STRUCT **phy_struct, LIBLTE_PHY_FS_ENUM fs, uint16 N_id_cell, uint8 N_ant, uint32 N_rb_dl, uint32 N_sc_rb_dl,
+                                      float phich_res);
+LIBLTE_ERROR_ENUM liblte_phy_init(LIBLTE_PHY_STRUCT **phy_struct, LIBLTE_PHY_FS_ENUM fs, uint16 N_id_cell, uint8 N_ant, uint32 N_rb_dl, uint32 N_sc_rb_dl,
+                                  float phich_res)
+{
+    const LIBLTE_ERROR_ENUM err = liblte_phy_init_cpu(phy_struct, fs, N_id_cell, N_ant, N_rb_dl, N_sc_rb_dl, phich_res);
+    if (err != LIBLTE_SUCCESS || !phy_struct || !*phy_struct) return err;
+    std::shared_ptr<Entry> e = make_entry(), stale;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto                        it = g_ctx.find(*phy_struct);
+        if (it != g_ctx.end()) stale = it->second; // a struct freed behind the shim's back (never cleaned up) whose address came round again
+        g_ctx[*phy_struct] = e;
+    }
+    if (stale) {
+        std::lock_guard<std::mutex> call(stale->mu);
+        if (stale->ctx) mi_lte_ctx_destroy(stale->ctx);
+        stale->ctx = nullptr;
+    }
+    return err;
+}
 
 // liblte_phy_cleanup (liblte_phy.h:636, impl. liblte_phy.cc:2524-2543): the struct's GPU context goes first -- stream, scratch, staging buffers
 // and cached plans are released, and a later struct that malloc places at the same address starts with a fresh context -- then the

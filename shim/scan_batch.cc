@@ -112,7 +112,7 @@ struct Scanner {
             if (b.rc[u] != 0 || b.n_dci[u] == 0) continue;
             const mi_lte_pdsch_alloc &a = b.dci[(size_t)u * MI_LTE_PDCCH_MAX_DCI].alloc;
             b.status[u] = MI_LTE_DECODE_FAIL;
-            if (a.tbs + 24 > 6144 || a.N_prb == 0 || a.N_prb > N_rb_dl) continue;
+            if (!mi_lte_pdsch_alloc_decodable(&cfg, &a, 2)) continue; // (a chance-CRC DCI must not end the scan: scan_cpu goes on, too)
             al.push_back(a);
             al.back().unit = u;
             unit_of.push_back(u);

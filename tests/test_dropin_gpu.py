@@ -389,3 +389,74 @@ def test_cell_scan_under_the_explicit_cache_contract(tmp_path):
     with open(os.path.join(ROOT, "gpurun_out", "scan_timing_cache_modes.txt"), "w") as f:
         for name, err in runs.items():
             f.write("%s: %s" % (name, err))
+
+
+def test_per_call_forms_fail_an_off_carrier_allocation_like_the_reference(ctx, ref):
+    """A DCI whose CRC matched by chance can name resource blocks past the carrier.  The reference demodulates whatever lies behind the
+    grid row and fails the transport block; the per-call downlink form must hand back the same return code (LIBLTE_ERROR_DECODE_FAIL, 2)
+    instead of the plans' argument error, and the good allocation of the same subframe must still decode afterwards.  The uplink form
+    reports LIBLTE_ERROR_INVALID_INPUTS (1), where the reference's NaN accident reports a decoded all-zero block (see below)."""
+    import ctypes as C
+    import openlte_amd as m
+    from oracle import pyoracle as po
+    L = ctx.L
+    f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+    u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+    L.mi_lte_get_dl_subframe_and_ce_host.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, f32p, f32p] + [C.c_uint32] * 4 + [f32p] * 4
+    L.mi_lte_pdsch_channel_decode_host.argtypes = [C.c_void_p, C.c_uint32, f32p, f32p, f32p, f32p, C.c_uint32, C.c_void_p,
+                                                   C.c_uint32, C.c_uint32, C.c_uint32, u8p, C.POINTER(C.c_uint32)]
+    # ---- downlink, 5 MHz: resource blocks 22..26 of a 25-block carrier
+    cap = td.multi_port_capture(ref, 1, seed=5, fft=512, nrb=25, cell=77, sf=3, cfi=2, mod=2, tbs=1064, prbs=list(range(4, 12)))
+    n_samp, sf, cell, iq, la, phy = 30720 // 4, cap["sf"], cap["cell"], cap["iq"], cap["la"], cap["phy"]
+    i_f = np.ascontiguousarray(np.concatenate([np.zeros(sf * n_samp, np.float32), iq[:, 0].astype(np.float32)]))
+    q_f = np.ascontiguousarray(np.concatenate([np.zeros(sf * n_samp, np.float32), iq[:, 1].astype(np.float32)]))
+    rx = ref.ref_subframe_new()
+    assert ref.ref_get_dl_subframe_and_ce(phy, i_f, q_f, 0, sf, cell, 1, rx) == 0
+    off_prbs = list(range(22, 27))
+    la_off = po.make_alloc(2, 1064, off_prbs, 0x2345, 0, 1, 0)
+    out, n = np.zeros(6200, np.uint8), C.c_uint32()
+    rc_ref_off = ref.ref_pdsch_channel_decode(phy, rx, C.byref(la_off), 2, cell, 1, out, C.byref(n))
+    rc_ref_ok = ref.ref_pdsch_channel_decode(phy, rx, C.byref(la), 2, cell, 1, out, C.byref(n))
+    assert rc_ref_off == 2 and rc_ref_ok == 0
+    sr, si = np.zeros((16, 1200), np.float32), np.zeros((16, 1200), np.float32)
+    cr, ci = np.zeros((4, 16, 1200), np.float32), np.zeros((4, 16, 1200), np.float32)
+    assert 0 == L.mi_lte_get_dl_subframe_and_ce_host(ctx.h, 512, 25, i_f, q_f, 0, sf, cell, 1, sr, si, cr, ci)
+    a_off, a_ok = m.make_alloc(0, 2, 1064, off_prbs, 0x2345), m.make_alloc(0, 2, 1064, cap["prbs"], 0x2345)
+    got, gn = np.zeros(6200, np.uint8), C.c_uint32()
+    assert L.mi_lte_pdsch_channel_decode_host(ctx.h, 25, sr, si, cr, ci, sf, C.addressof(a_off), 2, cell, 1, got, C.byref(gn)) == rc_ref_off
+    assert L.mi_lte_pdsch_channel_decode_host(ctx.h, 25, sr, si, cr, ci, sf, C.addressof(a_ok), 2, cell, 1, got, C.byref(gn)) == rc_ref_ok
+    assert gn.value == 1064 and (got[:1064] == cap["msg"]).all()
+    ref.ref_subframe_free(rx)
+    ref.ref_phy_free(phy)
+    # ---- uplink, 5 MHz: a four-block PUSCH allocation that ends one block past the carrier
+    L.mi_lte_pusch_channel_decode_host.argtypes = [C.c_void_p, C.c_uint32, f32p, f32p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32] + [f32p] * 4 + [
+        u8p, C.POINTER(C.c_uint32)]
+    ulc = (3, 0, 0, 2, 5)
+    phy = ref.ref_phy_new(po.FS_ENUM[512], 17, 1, 25)
+    assert ref.ref_ul_init(phy, 17, *ulc) == 0
+    rng = np.random.default_rng(9)
+    sfp = ref.ref_subframe_new()
+    ref.ref_subframe_set_num(sfp, 2)
+    re, im = (rng.standard_normal(7680).astype(np.float32) * 20 for _ in range(2))
+    assert ref.ref_get_ul_subframe(phy, re, im, sfp) == 0
+    la_ul = po.make_alloc(1, 504, [22, 23, 24, 25], 0x100, 0, 1)
+    rc_ref_ul = ref.ref_pusch_channel_decode(phy, sfp, C.byref(la_ul), 17, 1, out, C.byref(n))
+    # What the reference does here is an accident, pinned as such: the columns past the carrier were never written, its channel estimate
+    # over them divides by zero, the NaNs swallow the whole allocation, the decoder turns NaN soft bits into an all-zero block and the CRC
+    # of an all-zero block is zero -- "decoded", rc 0, 504 zero bits, whatever was received on the other three blocks.  The library
+    # reports the allocation as undecodable (1 = LIBLTE_ERROR_INVALID_INPUTS, the reference's failure value on this path): INTEGRATION.md,
+    # table of differences.
+    assert rc_ref_ul == 0 and n.value == 504 and not out[:504].any()
+    usr, usi = np.zeros((16, 1200), np.float32), np.zeros((16, 1200), np.float32)
+    usr[:14], usi[:14] = po.ref_subframe_view(ref, sfp, 0)[:14], po.ref_subframe_view(ref, sfp, 1)[:14]
+    dm = np.zeros(4 * 48, np.float32)
+    ref.ref_get_pusch_dmrs(phy, 2, 4, dm)
+    d = [np.ascontiguousarray(dm[k * 48:(k + 1) * 48]) for k in range(4)]
+    a_ul = m.make_alloc(0, 1, 504, [22, 23, 24, 25], 0x100)
+    assert L.mi_lte_pusch_channel_decode_host(ctx.h, 25, usr, usi, 2, C.addressof(a_ul), 17, 1, d[0], d[1], d[2], d[3], got, C.byref(gn)) == 1
+    la_in = po.make_alloc(1, 504, [21, 22, 23, 24], 0x100, 0, 1)  # the same noise inside the carrier: both fail, the same way
+    a_in = m.make_alloc(0, 1, 504, [21, 22, 23, 24], 0x100)
+    assert ref.ref_pusch_channel_decode(phy, sfp, C.byref(la_in), 17, 1, out, C.byref(n)) == 1
+    assert L.mi_lte_pusch_channel_decode_host(ctx.h, 25, usr, usi, 2, C.addressof(a_in), 17, 1, d[0], d[1], d[2], d[3], got, C.byref(gn)) == 1
+    ref.ref_subframe_free(sfp)
+    ref.ref_phy_free(phy)

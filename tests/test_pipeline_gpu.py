@@ -172,6 +172,25 @@ def test_pipeline_per_unit_allocation_lists(ctx):
     for k, a in enumerate(allocs):
         if want_st[k] == 0:
             assert (np.unpackbits(h_out.arr[k, :a.tbs // 8]) == want_bits[k]).all(), k
+    # An allocation the plans refuse -- a DCI that passed its CRC on noise: resource blocks past the carrier, more than one code block, a
+    # modulation that does not exist -- costs its own slot (status 2, as liblte_phy_pdsch_channel_decode would report for it, and as
+    # the per-call forms do), not the run
+    L = m.load_library()
+    for k, spoil in enumerate((lambda a: a.prb[1].__setitem__(0, 117), lambda a: setattr(a, "tbs", 6200), lambda a: setattr(a, "mod_type", 5),
+                               lambda a: setattr(a, "N_prb", 0))):
+        junk = (m.PdschAlloc * len(allocs))(*allocs)
+        victim = [3, len(allocs) - 1, 0, 7][k]
+        spoil(junk[victim])
+        assert L.mi_lte_pdsch_alloc_decodable(C.byref(cfg), C.byref(junk[victim]), 2) == 0
+        assert L.mi_lte_pdsch_alloc_decodable(C.byref(cfg), C.byref(junk[(victim + 1) % len(allocs)]), 2) == 1
+        h_st.arr[:] = -7
+        pipe.run_units(h_iq.arr, h_sf.arr, h_cell.arr, n, junk, first, 2, h_out.arr, h_st.arr)
+        expect = want_st.copy()
+        expect[victim] = 2
+        assert (h_st.arr == expect).all(), (k, h_st.arr, expect)
+        for j, a in enumerate(allocs):
+            if j != victim and want_st[j] == 0:
+                assert (np.unpackbits(h_out.arr[j, :a.tbs // 8]) == want_bits[j]).all(), (k, j)
     # a list that is not sorted by unit is refused, not mis-decoded
     bad = (m.PdschAlloc * len(allocs))(*allocs)
     bad[0].unit = 5

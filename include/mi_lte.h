@@ -587,6 +587,18 @@ int mi_lte_rate_unmatch_turbo_host(mi_lte_ctx *ctx, const float *h_e_bits, uint3
 typedef struct mi_lte_dl_pipeline mi_lte_dl_pipeline;
 void       *mi_lte_host_alloc(size_t bytes);
 void        mi_lte_host_free(void *p);
+/* Host placement ("each GPU owns a host thread"; eight devices at ~45 GB/s each read ~350 GB/s of host memory, which one
+ * NUMA node does not serve).  mi_lte_device_numa_node: the node of the device's PCIe slot (/sys/bus/pci/devices/<bdf>/numa_node), -1
+ * where the system does not say.  mi_lte_host_alloc_on: pinned memory for every device of the process like mi_lte_host_alloc, with its
+ * pages bound to that node (anonymous mapping + mbind + hipHostRegister); falls back to mi_lte_host_alloc's placement where the node is
+ * unknown or binding is not permitted -- mi_lte_host_alloc_node tells which happened (the node the block was bound to, -1 if none).
+ * device < 0: a block that every device reads a share of (one contiguous capture for mi_lte_dl_pipeline_run_capture): its pages are
+ * interleaved over all memory nodes (mi_lte_host_alloc_node: -2).
+ * Release with mi_lte_host_free.  A multi-device pipeline pins every device's host thread to the CPUs of the device's node for the
+ * duration of a run (the caller's own thread, which drives a single-device pipeline, is left alone). */
+int         mi_lte_device_numa_node(int device);
+void       *mi_lte_host_alloc_on(int device, size_t bytes);
+int         mi_lte_host_alloc_node(const void *p);
 int         mi_lte_dl_pipeline_create(int device, const mi_lte_dl_cfg *cfg, uint32_t N_pdcch_symbs, const mi_lte_pdsch_alloc *h_unit_allocs,
                                       uint32_t n_alloc_per_unit, uint32_t chunk_units, uint32_t n_lanes, mi_lte_dl_pipeline **out);
 /* h_unit_allocs may be NULL (per-unit lists only): then n_alloc_per_unit is the most allocations a unit may carry and
@@ -599,6 +611,17 @@ uint32_t    mi_lte_dl_pipeline_out_stride(const mi_lte_dl_pipeline *p);
 size_t      mi_lte_dl_pipeline_unit_samples(const mi_lte_dl_pipeline *p);
 uint32_t    mi_lte_dl_pipeline_n_devices(const mi_lte_dl_pipeline *p);
 const char *mi_lte_dl_pipeline_last_error(const mi_lte_dl_pipeline *p);
+/* What device slot `index` (0 .. n_devices-1) did in the pipeline's last run, so that a scaling run explains its own bottleneck: chunks
+ * and units it took, bytes over its link each way, the time its stream spent in each phase summed over its chunks (HIP events on the
+ * lanes' streams; phases of different lanes overlap, so the sums may exceed wall_s), the wall time of its host thread, and where that
+ * thread ran (numa_node / n_cpus of the affinity mask it was given; -1 / 0: not pinned). */
+typedef struct {
+    uint32_t device, chunks, units, n_cpus;
+    int32_t  numa_node, reserved;
+    uint64_t h2d_bytes, d2h_bytes;
+    double   wall_s, h2d_s, kernel_s, d2h_s;
+} mi_lte_pipeline_dev_stats;
+int         mi_lte_dl_pipeline_device_stats(const mi_lte_dl_pipeline *p, uint32_t index, mi_lte_pipeline_dev_stats *out);
 int         mi_lte_dl_pipeline_run(mi_lte_dl_pipeline *p, const int8_t *h_iq, const uint32_t *h_subfr_num, const uint32_t *h_n_id_cell, uint32_t n_units,
                                    uint8_t *h_out_packed, int32_t *h_status);
 int         mi_lte_dl_pipeline_run_units(mi_lte_dl_pipeline *p, const int8_t *h_iq, const uint32_t *h_subfr_num, const uint32_t *h_n_id_cell,

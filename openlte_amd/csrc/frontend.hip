@@ -35,9 +35,13 @@ __device__ __forceinline__ v2f    to_v(float2 a) { return __builtin_bit_cast(v2f
 __device__ __forceinline__ float2 to_f2(v2f a) { return __builtin_bit_cast(float2, a); }
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
-    // (a.x b.x - a.y b.y, a.x b.y + a.y b.x) as one packed multiply and one packed fused multiply-add
-    const v2f av = to_v(a), bv = to_v(b), sw = {-bv.y, bv.x};
-    return to_f2(__builtin_elementwise_fma(av.yy, sw, av.xx * bv));
+    // (a.x b.x - a.y b.y, a.x b.y + a.y b.x) as one packed multiply and one packed fused multiply-add, the swap and the sign taken by the
+    // second instruction's own operand selectors: written as vector code the compiler spends a v_xor and a v_mov per product on building
+    // (-b.y, b.x) -- 60 of the 2048-point transform's 390 vector instructions, in a kernel whose time is three quarters instruction issue
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(to_v(a)), "v"(to_v(b)));                                              // (a.x b.x, a.x b.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(to_v(a)), "v"(to_v(b)), "v"(t)); // (-a.y b.y, a.y b.x) + t
+    return to_f2(r);
 }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -73,14 +77,16 @@ template <int R> __device__ __forceinline__ void dftR(float2 *v)
 // (ctx.hpp MI_FFT_TWC_*: R / 2 float2 slots per butterfly, side by side), the rest are products.
 template <int R> __device__ __forceinline__ void twiddles(const float2 *__restrict__ tc, uint32_t k, float2 (&w)[8])
 {
-    if (R == 2) w[1] = tc[k];
+    // (tc is uniform over the workgroup: scalar base + the thread's 32-bit byte offset, not a 64-bit sum per read)
+    const char *tb = reinterpret_cast<const char *>(tc);
+    if (R == 2) w[1] = *reinterpret_cast<const float2 *>(tb + (size_t)(k * 8u));
     else {
-        const float4 a = *reinterpret_cast<const float4 *>(tc + (size_t)k * (R / 2));
+        const float4 a = *reinterpret_cast<const float4 *>(tb + (size_t)(k * (R / 2) * 8u));
         w[1] = make_float2(a.x, a.y);
         w[2] = make_float2(a.z, a.w);
         w[3] = cmul(w[1], w[2]);
         if (R == 8) {
-            w[4] = tc[(size_t)k * 4 + 2];
+            w[4] = *reinterpret_cast<const float2 *>(tb + 16 + (size_t)(k * 32u));
             w[5] = cmul(w[4], w[1]); w[6] = cmul(w[4], w[2]); w[7] = cmul(w[4], w[3]);
         }
     }
@@ -117,9 +123,18 @@ __device__ __forceinline__ void fft_pass(const float2 *__restrict__ tc, uint32_t
 template <typename T> struct SampleSrc;
 template <> struct SampleSrc<int8_t> { // interleaved I,Q int8 (capture file format, LTE_fdd_dl_fs_samp_buf.cc:657-694)
     const int8_t *p;
-    typedef char2 raw_t; // a fetched sample as it is held until its transform starts
-    __device__ __forceinline__ raw_t raw(size_t n) const { return *reinterpret_cast<const char2 *>(p + 2 * n); }
-    static __device__ __forceinline__ float2 cvt(raw_t v) { return make_float2((float)v.x, (float)v.y); }
+    typedef uint32_t raw_t; // a fetched sample (I in byte 0, Q in byte 1) as it is held until its transform starts
+    __device__ __forceinline__ raw_t raw(size_t n) const { return *reinterpret_cast<const uint16_t *>(p + 2 * n); }
+    // sample f + o + c with f uniform over the workgroup, o the thread's own 32-bit offset and c a constant: a scalar base, one offset
+    // register shared by all of a thread's loads and an immediate -- the 64-bit form costs two vector adds per load
+    __device__ __forceinline__ raw_t raw_at(size_t f, uint32_t o, uint32_t c) const { return *reinterpret_cast<const uint16_t *>((p + 2 * (f + c)) + (size_t)(2u * o)); }
+    static __device__ __forceinline__ float2 cvt(raw_t v)
+    {
+        float x, y; // one conversion per component, straight from its byte (the compiler's own choice shifts Q down first)
+        asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(x) : "v"(v));
+        asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(y) : "v"(v));
+        return make_float2(x, y);
+    }
     __device__ __forceinline__ float2 at(size_t n) const
     {
         const char2 v = *reinterpret_cast<const char2 *>(p + 2 * n);
@@ -130,6 +145,11 @@ template <> struct SampleSrc<float> { // planar i_samps / q_samps as the referen
     const float *i, *q;
     typedef float2 raw_t;
     __device__ __forceinline__ raw_t raw(size_t n) const { return make_float2(i[n], q[n]); }
+    __device__ __forceinline__ raw_t raw_at(size_t f, uint32_t o, uint32_t c) const
+    {
+        const char *bi = reinterpret_cast<const char *>(i + f + c), *bq = reinterpret_cast<const char *>(q + f + c);
+        return make_float2(*reinterpret_cast<const float *>(bi + (size_t)(4u * o)), *reinterpret_cast<const float *>(bq + (size_t)(4u * o)));
+    }
     static __device__ __forceinline__ float2 cvt(raw_t v) { return v; }
     __device__ __forceinline__ float2 at(size_t n) const { return make_float2(i[n], q[n]); }
 };
@@ -159,7 +179,7 @@ __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t
         const size_t f = win(sym);
         if (act) {
 #pragma unroll
-            for (int r = 0; r < 8; r++) v[r] = src.raw(f + j + r * nb);
+            for (int r = 0; r < 8; r++) v[r] = src.raw_at(f, j, r * nb);
         }
     };
     // element base + r * stride of the padded buffer: when the stride is a multiple of the padding period the pad of the sum splits,
@@ -178,8 +198,12 @@ __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t
         float *row_re = subframes + (size_t)unit * g.sf_stride + (size_t)sym * N_SC_MAX;
         float *row_im = row_re + (RAW ? N_SC_MAX : 16 * N_SC_MAX);
         auto st_g = [&](uint32_t o, float2 v) { // keep bins dc..half-1+dc and N-half..N-1 (liblte_phy.cc:8625-8634, :8685-8690)
-            if (o >= dc && o < half + dc) { row_re[half + o - dc] = v.x; row_im[half + o - dc] = v.y; }
-            else if (o >= N - half)       { row_re[o - (N - half)] = v.x; row_im[o - (N - half)] = v.y; }
+            const bool     pos = o >= dc && o < half + dc, neg = o >= N - half;
+            const uint32_t b   = 4u * (pos ? half + o - dc : o - (N - half)); // byte offset in the row: scalar base + 32-bit offset addressing
+            if (pos || neg) {
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(row_re) + (size_t)b) = v.x;
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(row_im) + (size_t)b) = v.y;
+            }
         };
         // radix plan: 8,8,8,4 (2048) | 8,8,8,2 (1024) | 8,8,8 (512) | 8,8,4 (256) | 8,8,2 (128)
         // first radix-8 pass (sub-transform length 1: no twiddles) straight from the fetched samples.

@@ -16,9 +16,19 @@
 //   one contiguous capture            mi_lte_dl_pipeline_run_capture (split on subframe boundaries, each chunk copied with the look-ahead
 //                                                                      samples behind its last subframe -- the halo of SURVEY 8e)
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <thread>
 #include <vector>
+
+#include <pthread.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include "ctx.hpp"
 
@@ -39,6 +49,10 @@ struct Dev {
     std::vector<Lane> lanes;
     std::string       err;
     int               rc = MI_LTE_OK;
+    int               node = -1;              // NUMA node of the device's PCIe slot (-1: the system does not say)
+    std::vector<int>  node_cpus;              // the CPUs of that node the process may run on
+    std::vector<hipEvent_t> ev;               // four per chunk of the last run: before H2D, after H2D, after the kernels, after D2H
+    mi_lte_pipeline_dev_stats stats = {};     // the last run, as this device saw it
 };
 struct Job { // one run, as the device threads see it
     const int8_t  *h_iq = nullptr;        // units back to back (unit_bytes each), or the capture from its first subframe on
@@ -61,6 +75,64 @@ struct mi_lte_dl_pipeline {
     std::vector<Dev> devs;
     std::string   err;
 };
+
+// ---- host placement: which NUMA node a device hangs off, its CPUs, memory bound to it
+static int sysfs_int(const std::string &path, int dflt)
+{
+    FILE *f = fopen(path.c_str(), "r");
+    int   v = dflt;
+    if (f) { if (fscanf(f, "%d", &v) != 1) v = dflt; fclose(f); }
+    return v;
+}
+static std::vector<int> parse_cpulist(const std::string &path) // "0-63,128-191"
+{
+    std::vector<int> cpus;
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return cpus;
+    char buf[4096];
+    if (fgets(buf, sizeof buf, f)) {
+        for (char *t = strtok(buf, ",\n"); t; t = strtok(nullptr, ",\n")) {
+            int a, b;
+            if (sscanf(t, "%d-%d", &a, &b) == 2) { for (int c = a; c <= b; c++) cpus.push_back(c); }
+            else if (sscanf(t, "%d", &a) == 1) cpus.push_back(a);
+        }
+    }
+    fclose(f);
+    return cpus;
+}
+static int device_numa_node(int device)
+{
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, sizeof bdf, device) != hipSuccess) return -1;
+    for (char *c = bdf; *c; c++) *c = (char)tolower(*c);
+    return sysfs_int(std::string("/sys/bus/pci/devices/") + bdf + "/numa_node", -1);
+}
+// the CPUs of a node that this process is allowed on (a container's cpuset may be a subset)
+static std::vector<int> node_cpus_allowed(int node)
+{
+    std::vector<int> out;
+    if (node < 0) return out;
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return out;
+    for (int c : parse_cpulist("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist"))
+        if (c >= 0 && c < CPU_SETSIZE && CPU_ISSET(c, &allowed)) out.push_back(c);
+    return out;
+}
+// pin the calling thread; returns how many CPUs the mask holds (0: not pinned)
+static uint32_t pin_this_thread(const std::vector<int> &cpus)
+{
+    if (cpus.empty()) return 0;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    for (int c : cpus) CPU_SET(c, &set);
+    return pthread_setaffinity_np(pthread_self(), sizeof set, &set) == 0 ? (uint32_t)cpus.size() : 0u;
+}
+namespace {
+struct HostBlock { size_t bytes; int node; }; // blocks of mi_lte_host_alloc_on (mapped here, registered with the runtime)
+std::mutex                      g_host_mu;
+std::map<const void *, HostBlock> g_host_blocks;
+} // namespace
 
 static void free_lane(Lane &l)
 {
@@ -129,9 +201,22 @@ static void device_worker(mi_lte_dl_pipeline *p, uint32_t di, const Job *job)
     const uint32_t G = (uint32_t)p->devs.size(), n_chunks = (job->n_units + p->chunk - 1) / p->chunk;
     d.rc = MI_LTE_OK;
     d.err.clear();
+    d.stats = {};
+    d.stats.device = (uint32_t)d.device; d.stats.numa_node = -1;
+    const auto t_start = std::chrono::steady_clock::now();
     if (hipSetDevice(d.device) != hipSuccess) { d.rc = MI_LTE_ERR_HIP; d.err = "hipSetDevice failed"; return; }
+    if (G > 1) { // a thread of the pipeline's own: keep it (and the staging it does) next to its device
+        d.stats.n_cpus = pin_this_thread(d.node_cpus);
+        if (d.stats.n_cpus) d.stats.numa_node = d.node;
+    }
     const size_t unit_bytes = p->unit_samples * 2;
     uint32_t     k = 0; // chunks this device has taken
+    const uint32_t my_chunks = di < n_chunks ? (n_chunks - di + G - 1) / G : 0;
+    while (d.ev.size() < (size_t)4 * my_chunks) { // (created once, reused by later runs)
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) { d.rc = MI_LTE_ERR_HIP; d.err = "hipEventCreate failed"; return; }
+        d.ev.push_back(e);
+    }
     std::vector<mi_lte_pdsch_alloc> local;
     std::vector<size_t>             refused; // allocations outside the decodable envelope: status 2 at their own index
     auto fail = [&](Lane &l, int rc) { d.rc = rc; d.err = mi_lte_last_error(l.ctx); };
@@ -140,6 +225,10 @@ static void device_worker(mi_lte_dl_pipeline *p, uint32_t di, const Job *job)
         const uint32_t u0 = c * p->chunk, n = std::min(p->chunk, job->n_units - u0);
         hipStream_t    st = (hipStream_t)mi_lte_stream(l.ctx);
         hipError_t     e;
+        hipEvent_t    *ev = &d.ev[(size_t)4 * k];
+        (void)hipEventRecord(ev[0], st);
+        const size_t   in_bytes = job->capture ? ((size_t)n * p->sf_samples + p->look_samples) * 2 : (size_t)n * unit_bytes;
+        d.stats.chunks++; d.stats.units += n; d.stats.h2d_bytes += in_bytes + 8 * (size_t)n;
         if (job->capture) // the chunk's subframes and the look-ahead samples behind the last of them, as they lie in the capture
             e = hipMemcpyAsync(l.d_iq, job->h_iq + (size_t)u0 * p->sf_samples * 2, ((size_t)n * p->sf_samples + p->look_samples) * 2, hipMemcpyHostToDevice, st);
         else
@@ -147,6 +236,7 @@ static void device_worker(mi_lte_dl_pipeline *p, uint32_t di, const Job *job)
         if (e == hipSuccess) e = hipMemcpyAsync(l.d_sf, job->h_sf + u0, sizeof(uint32_t) * n, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipMemcpyAsync(l.d_cell, job->h_cell + u0, sizeof(uint32_t) * n, hipMemcpyHostToDevice, st);
         if (e != hipSuccess) { d.rc = MI_LTE_ERR_HIP; d.err = hipGetErrorString(e); break; }
+        (void)hipEventRecord(ev[1], st);
         int rc = mi_lte_dl_frontend_batch(l.ctx, &p->cfg, l.d_iq, nullptr, job->capture ? l.d_start_capture : l.d_start_units, l.d_sf, l.d_cell, n, l.d_sub);
         if (rc != MI_LTE_OK) { fail(l, rc); break; }
         // which plan decodes the chunk, and where its results go
@@ -155,7 +245,7 @@ static void device_worker(mi_lte_dl_pipeline *p, uint32_t di, const Job *job)
         if (job->h_allocs) { // per-unit lists: the chunk's slice of the caller's list, unit numbers made chunk-local
             a0   = job->h_first[u0];
             n_al = job->h_first[u0 + n] - a0;
-            if (n_al == 0) continue;
+            if (n_al == 0) { (void)hipEventRecord(ev[2], st); (void)hipEventRecord(ev[3], st); continue; }
             local.assign(job->h_allocs + a0, job->h_allocs + a0 + n_al);
             for (size_t i = 0; i < n_al; i++) {
                 mi_lte_pdsch_alloc &a = local[i];
@@ -184,16 +274,27 @@ static void device_worker(mi_lte_dl_pipeline *p, uint32_t di, const Job *job)
         }
         if (rc == MI_LTE_OK) rc = mi_lte_pdsch_decode_run(l.ctx, plan, l.d_sub, l.d_sf, l.d_cell, l.d_out, l.d_st);
         if (rc != MI_LTE_OK) { fail(l, rc); break; }
+        (void)hipEventRecord(ev[2], st);
         e = hipMemcpyAsync(job->h_out + a0 * p->out_stride, l.d_out, n_al * p->out_stride, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipMemcpyAsync(job->h_status + a0, l.d_st, n_al * sizeof(int32_t), hipMemcpyDeviceToHost, st);
         if (e != hipSuccess) { d.rc = MI_LTE_ERR_HIP; d.err = hipGetErrorString(e); break; }
+        (void)hipEventRecord(ev[3], st);
+        d.stats.d2h_bytes += n_al * ((size_t)p->out_stride + sizeof(int32_t));
     }
+    const uint32_t k_done = k; // chunks whose four events were all recorded
     // (a failed chunk leaves the loop, not the function: copies of earlier chunks into the caller's arrays may still be in flight)
     for (Lane &l : d.lanes) {
         const int rc = mi_lte_sync(l.ctx);
         if (rc != MI_LTE_OK && d.rc == MI_LTE_OK) fail(l, rc);
     }
     for (size_t i : refused) job->h_status[i] = 2; // LIBLTE_ERROR_DECODE_FAIL (after the copies of the stand-ins' verdicts have landed)
+    if (d.rc == MI_LTE_OK)
+        for (uint32_t c = 0; c < k_done; c++) { // every lane has been waited for: the events are complete
+            float ms[3] = {0, 0, 0};
+            for (int ph = 0; ph < 3; ph++) (void)hipEventElapsedTime(&ms[ph], d.ev[(size_t)4 * c + ph], d.ev[(size_t)4 * c + ph + 1]);
+            d.stats.h2d_s += ms[0] * 1e-3; d.stats.kernel_s += ms[1] * 1e-3; d.stats.d2h_s += ms[2] * 1e-3;
+        }
+    d.stats.wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
 }
 
 static int run_job(mi_lte_dl_pipeline *p, const Job &job)
@@ -219,7 +320,65 @@ void *mi_lte_host_alloc(size_t bytes)
 }
 void mi_lte_host_free(void *p)
 {
-    if (p) (void)hipHostFree(p);
+    if (!p) return;
+    HostBlock b{0, -1};
+    {
+        std::lock_guard<std::mutex> lk(g_host_mu);
+        auto it = g_host_blocks.find(p);
+        if (it != g_host_blocks.end()) { b = it->second; g_host_blocks.erase(it); }
+    }
+    if (b.bytes) { (void)hipHostUnregister(p); (void)munmap(p, b.bytes); }
+    else         (void)hipHostFree(p);
+}
+
+int mi_lte_device_numa_node(int device) { return device_numa_node(device); }
+
+void *mi_lte_host_alloc_on(int device, size_t bytes)
+{
+    // device < 0: one block that every device reads a share of (a contiguous capture) -- its pages interleaved over all memory nodes
+    std::vector<int> nodes = device < 0 ? parse_cpulist("/sys/devices/system/node/online") : std::vector<int>();
+    const bool interleave = device < 0 && nodes.size() > 1;
+    const int  node = device < 0 ? (interleave ? -2 : -1) : device_numa_node(device);
+    if ((node >= 0 && node < 1024) || interleave) {
+        const size_t len = ((bytes ? bytes : 1) + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+        void *m = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m != MAP_FAILED) {
+            unsigned long mask[16] = {0};
+            if (!interleave) nodes.assign(1, node);
+            for (int nd : nodes)
+                if (nd >= 0 && nd < 1024) mask[nd / (8 * sizeof(unsigned long))] |= 1ul << (nd % (8 * sizeof(unsigned long)));
+#ifdef SYS_mbind
+            const long rc = syscall(SYS_mbind, m, len, interleave ? 3 /* MPOL_INTERLEAVE */ : 2 /* MPOL_BIND */, mask, (unsigned long)(8 * sizeof mask), 0u);
+#else
+            const long rc = -1;
+#endif
+            if (rc == 0) {
+                (void)madvise(m, len, MADV_HUGEPAGE);
+                memset(m, 0, len); // first touch under the policy: the pages exist, on that node, before the runtime pins them
+                if (hipHostRegister(m, len, hipHostRegisterPortable) == hipSuccess) {
+                    std::lock_guard<std::mutex> lk(g_host_mu);
+                    g_host_blocks[m] = HostBlock{len, node};
+                    return m;
+                }
+            }
+            (void)munmap(m, len);
+        }
+    }
+    return mi_lte_host_alloc(bytes); // node unknown, binding refused (a container without CAP_SYS_NICE), or registration failed
+}
+
+int mi_lte_host_alloc_node(const void *p)
+{
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    auto it = g_host_blocks.find(p);
+    return it == g_host_blocks.end() ? -1 : it->second.node;
+}
+
+int mi_lte_dl_pipeline_device_stats(const mi_lte_dl_pipeline *p, uint32_t index, mi_lte_pipeline_dev_stats *out)
+{
+    if (!p || !out || index >= p->devs.size()) return MI_LTE_ERR_INVALID_ARG;
+    *out = p->devs[index].stats;
+    return MI_LTE_OK;
 }
 
 void mi_lte_dl_pipeline_destroy(mi_lte_dl_pipeline *p)
@@ -228,6 +387,7 @@ void mi_lte_dl_pipeline_destroy(mi_lte_dl_pipeline *p)
     for (Dev &d : p->devs) {
         (void)hipSetDevice(d.device);
         for (Lane &l : d.lanes) free_lane(l);
+        for (hipEvent_t e : d.ev) (void)hipEventDestroy(e);
     }
     delete p;
 }
@@ -266,6 +426,8 @@ int mi_lte_dl_pipeline_create_multi(const int *devices, uint32_t n_devices, cons
         d.device = devices[di];
         d.lanes.resize(n_lanes);
         if (hipSetDevice(d.device) != hipSuccess) return MI_LTE_ERR_NO_DEVICE;
+        d.node      = device_numa_node(d.device);
+        d.node_cpus = node_cpus_allowed(d.node);
         for (Lane &l : d.lanes) {
             const int rc = make_lane(p, d, l);
             if (rc != MI_LTE_OK) { p->err = d.err; return rc; }

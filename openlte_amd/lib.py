@@ -50,6 +50,12 @@ def make_alloc(unit, mod_type, tbs, prbs, rnti, rv_idx=0, tx_mode=1, prbs_slot1=
     return a
 
 
+class PipelineDevStats(C.Structure):
+    """mi_lte_pipeline_dev_stats"""
+    _fields_ = [("device", C.c_uint32), ("chunks", C.c_uint32), ("units", C.c_uint32), ("n_cpus", C.c_uint32), ("numa_node", C.c_int32), ("reserved", C.c_int32),
+                ("h2d_bytes", C.c_uint64), ("d2h_bytes", C.c_uint64), ("wall_s", C.c_double), ("h2d_s", C.c_double), ("kernel_s", C.c_double), ("d2h_s", C.c_double)]
+
+
 class PucchRes(C.Structure):
     """mi_lte_pucch_res"""
     _fields_ = [("unit", C.c_uint32), ("format", C.c_uint32), ("N_1_p_pucch", C.c_uint32)]
@@ -123,6 +129,13 @@ def load_library():
     L.mi_lte_pdsch_plan_set_output.argtypes = [vp, u32]
     L.mi_lte_host_alloc.argtypes = [sz]
     L.mi_lte_host_alloc.restype = vp
+    L.mi_lte_host_alloc_on.argtypes = [C.c_int, sz]
+    L.mi_lte_host_alloc_on.restype = vp
+    L.mi_lte_host_alloc_node.argtypes = [vp]
+    L.mi_lte_host_alloc_node.restype = C.c_int
+    L.mi_lte_device_numa_node.argtypes = [C.c_int]
+    L.mi_lte_device_numa_node.restype = C.c_int
+    L.mi_lte_dl_pipeline_device_stats.argtypes = [vp, u32, C.POINTER(PipelineDevStats)]
     L.mi_lte_host_free.argtypes = [vp]
     L.mi_lte_pdsch_plan_create_dynamic.argtypes = [vp, C.POINTER(DlCfg), u32, sz, C.POINTER(vp)]
     L.mi_lte_pdsch_plan_assign.argtypes = [vp, vp, u32, vp, u32]
@@ -302,13 +315,15 @@ class PdschPlan:
 class HostBuffer:
     """Pinned host memory (mi_lte_host_alloc) viewed as a numpy array: what the host-batch pipeline wants its arrays in."""
 
-    def __init__(self, shape, dtype):
+    def __init__(self, shape, dtype, device=None):
+        """device: bind the pages to that device's NUMA node (mi_lte_host_alloc_on); self.node says whether that happened (-1: no)."""
         self.L = load_library()
         dt = np.dtype(dtype)
         n = int(np.prod(shape)) * dt.itemsize
-        self.ptr = self.L.mi_lte_host_alloc(max(n, 1))
+        self.ptr = self.L.mi_lte_host_alloc(max(n, 1)) if device is None else self.L.mi_lte_host_alloc_on(device, max(n, 1))
         if not self.ptr:
             raise MiLteError("mi_lte_host_alloc(%d) failed" % n)
+        self.node = self.L.mi_lte_host_alloc_node(self.ptr)
         self.arr = np.frombuffer((C.c_uint8 * max(n, 1)).from_address(self.ptr), dtype=dt, count=int(np.prod(shape))).reshape(shape)
 
     def free(self):
@@ -345,6 +360,16 @@ class DlPipeline:
 
     def _err(self, what, rc):
         raise MiLteError("%s failed: %d (%s)" % (what, rc, self.L.mi_lte_dl_pipeline_last_error(self.h).decode()))
+
+    def device_stats(self):
+        """What every device slot did in the last run (mi_lte_dl_pipeline_device_stats), as a list of dicts."""
+        out = []
+        for i in range(self.n_devices):
+            st = PipelineDevStats()
+            if self.L.mi_lte_dl_pipeline_device_stats(self.h, i, C.byref(st)) != 0:
+                raise MiLteError("mi_lte_dl_pipeline_device_stats failed")
+            out.append({k: getattr(st, k) for k, _ in PipelineDevStats._fields_ if k != "reserved"})
+        return out
 
     def run_units(self, h_iq, h_sf, h_cell, n_units, allocs, first, n_pdcch_symbs, h_out, h_status):
         """Per-unit allocation lists: allocs (ctypes array of PdschAlloc, sorted by unit), first uint32 [n_units + 1]."""

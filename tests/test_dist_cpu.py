@@ -48,3 +48,17 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--workload", "selftest"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "refusing" in (r.stdout + r.stderr)
+
+
+def test_bench_gpus_8_selftest_on_cpu():
+    """The same at the width the scaling run uses: eight ranks (gloo, 127.0.0.1), every unit owned by exactly one of them, one JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "selftest", "--steps", "2", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["shard_counts"] == [125] * 8 and out["scaling"] == "weak"
+    assert sorted(x[0] for x in out["ranks"]) == list(range(8)) and sorted(x[1] for x in out["ranks"]) == list(range(8))
+    assert {tuple(x[3]) for x in out["ranks"]} == {(k, k + 8, k + 16) for k in range(8)}

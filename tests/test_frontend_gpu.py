@@ -119,3 +119,18 @@ def test_frontend_real_multi_port_cell(ctx, ref, n_ant):
         assert (np.hypot(got[2 + p, :14] - w_re, got[2 + n_ant + p, :14] - w_im) / h).max() < 10 * TOL_CE, p
     ref.ref_subframe_free(rx)
     ref.ref_phy_free(cap["phy"])
+
+
+def test_two_port_cell_from_the_reference_transmitter_vs_golden(ctx):
+    """A real two-port cell (tests/golden/dl_two_port_units.npz: the reference's transmitter, CRS on both ports, per-antenna gains): symbol
+    rows and both ports' estimate rows against what the compiled reference made of unit 0 when the fixture was generated."""
+    import os
+    import openlte_amd as m
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dl_two_port_units.npz"))
+    cfg = m.DlCfg(2048, 100, 2, 0)
+    n = len(z["sfs"])
+    ul = z["iq"].shape[1]
+    got = ctx.dl_frontend(cfg, z["iq"].reshape(-1, 2), np.arange(n) * ul, z["sfs"], z["cells"])
+    assert rel_l2(got[0, 0, :14], z["symb_re"]) < TOL_SYMB and rel_l2(got[0, 1, :14], z["symb_im"]) < TOL_SYMB
+    for p in range(2):
+        assert rel_l2(got[0, 2 + p, :14], z["ce_re"][p]) < TOL_CE and rel_l2(got[0, 4 + p, :14], z["ce_im"][p]) < TOL_CE

@@ -600,3 +600,16 @@ def test_demappers_atan2f_is_the_host_libms(port, box):
         assert same.all(), (y[~same][:4], xx[~same][:4], got[~same][:4], want[~same][:4])
     # the soak's symbol: below pi (second quadrant) with libm, above it with a few-ulp atan2f
     assert got[0].view(np.uint32) == 0x40490FDA
+
+
+def test_port_two_port_front_end_vs_golden_from_reference(port):
+    """The restatement's two-port front end on a capture from the reference's own two-port transmitter, against what the compiled
+    reference made of it when the fixture was generated (tools/gen_golden.py two_port): symbol rows and both ports' estimate rows."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dl_two_port_units.npz"))
+    _, s = td.oracle_frontend(port, 2048, 100, 2, z["iq"][0], int(z["sfs"][0]), int(z["cells"][0]))
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    assert rel(s.arr("rx_symb_re")[:14], z["symb_re"]) < 1e-5 and rel(s.arr("rx_symb_im")[:14], z["symb_im"]) < 1e-5
+    for p in range(2):
+        assert rel(s.arr("rx_ce_re")[p, :14], z["ce_re"][p]) < 1e-4 and rel(s.arr("rx_ce_im")[p, :14], z["ce_im"][p]) < 1e-4
+        assert np.hypot(z["ce_re"][p], z["ce_im"][p]).mean() > 0.1  # a real second port: its estimate is a channel, not noise around zero

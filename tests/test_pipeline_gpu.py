@@ -126,8 +126,12 @@ def test_multi_device_pipeline_template_equals_device_resident(ctx, devices, n_u
     want_st, want_bits = device_resident(ctx, cfg, iq, sfs, cells, allocs, 2)
     pipe = m.DlPipeline(devices, cfg, 2, td.w4_allocs(0), chunk, n_lanes=2)
     assert pipe.n_devices == len(devices)
-    h_iq, h_sf, h_cell = m.HostBuffer(iq.shape, np.int8), m.HostBuffer((n_units,), np.uint32), m.HostBuffer((n_units,), np.uint32)
-    h_out, h_st = m.HostBuffer((n_units * 9, pipe.out_stride), np.uint8), m.HostBuffer((n_units * 9,), np.int32)
+    # host placement: the samples next to device 0 (mi_lte_host_alloc_on), the results interleaved -- both must behave like plain pinned
+    # memory whatever the box allows (node bound, interleaved, or the runtime's own placement where binding is refused)
+    h_iq, h_sf, h_cell = m.HostBuffer(iq.shape, np.int8, device=0), m.HostBuffer((n_units,), np.uint32), m.HostBuffer((n_units,), np.uint32)
+    h_out, h_st = m.HostBuffer((n_units * 9, pipe.out_stride), np.uint8, device=-1), m.HostBuffer((n_units * 9,), np.int32)
+    dev_node = m.load_library().mi_lte_device_numa_node(0)
+    assert h_iq.node in (-1, dev_node) and h_out.node in (-1, -2) and h_sf.node == -1
     h_iq.arr[:], h_sf.arr[:], h_cell.arr[:] = iq, sfs, cells
     for rep in range(2):
         h_out.arr[:], h_st.arr[:] = 0xEE, -7
@@ -137,6 +141,22 @@ def test_multi_device_pipeline_template_equals_device_resident(ctx, devices, n_u
             t = allocs[k].tbs
             assert (np.unpackbits(h_out.arr[k, :t // 8]) == want_bits[k]).all(), k
             assert (want_bits[k] == tx[k // 9, k % 9, :t]).all()
+        # the run's own account of itself: every chunk and unit counted once, on the device slot the block-cyclic rule gives it, its
+        # bytes over the link, its stream phases timed; host threads of a multi-device pipeline pinned to their device's node where
+        # the system names one (the single-device pipeline runs on the caller's thread and leaves it alone)
+        st = pipe.device_stats()
+        n_chunks = (n_units + chunk - 1) // chunk
+        assert [d["chunks"] for d in st] == [len(range(i, n_chunks, len(devices))) for i in range(len(devices))]
+        assert sum(d["units"] for d in st) == n_units and all(d["device"] == 0 for d in st)
+        assert sum(d["h2d_bytes"] for d in st) == n_units * (pipe.unit_samples * 2 + 8)
+        assert sum(d["d2h_bytes"] for d in st) == n_units * 9 * (pipe.out_stride + 4)
+        for d in st:
+            if d["chunks"]:
+                assert d["wall_s"] > 0 and d["kernel_s"] > 0 and d["h2d_s"] > 0 and d["d2h_s"] > 0
+            if len(devices) > 1 and dev_node >= 0:
+                assert d["numa_node"] == dev_node and d["n_cpus"] > 0
+            if len(devices) == 1:
+                assert d["numa_node"] == -1 and d["n_cpus"] == 0
     pipe.close()
     for b in (h_iq, h_sf, h_cell, h_out, h_st):
         b.free()

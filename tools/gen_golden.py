@@ -134,10 +134,38 @@ def sync_vectors(R):
     print("sync_ref.npz:", n, "peaks;", [(3 * s[0] + p[1], s[1]) for p, s in want["per_peak"] if s is not None])
 
 
+def two_port_units(R):
+    """Four 20 MHz subframe units of a TWO-port cell from the reference's own transmitter (CRS on both ports, one transmit-diversity
+    PDSCH allocation, each antenna through its own complex gain, noise, int8): the input of bench.py's two-port front-end leg (BASELINE
+    config 2), plus, for unit 0, what liblte_phy_get_dl_subframe_and_ce makes of it (symbol rows and both ports' estimate rows)."""
+    import ctypes as C
+    from openlte_amd import synth
+    ul = synth.unit_len(2048)
+    units, sfs, cells, want = [], [], [], None
+    for k, (cell, sf) in enumerate(((101, 4), (7, 1), (333, 8), (450, 6))):
+        cap = td.multi_port_capture(R, 2, seed=200 + k, cell=cell, sf=sf, noise=0.7)
+        iq = cap["iq"][:ul]
+        units.append(iq); sfs.append(sf); cells.append(cell)
+        if k == 0:
+            i_f = np.ascontiguousarray(np.concatenate([np.zeros(sf * 30720, np.float32), iq[:, 0].astype(np.float32)]))
+            q_f = np.ascontiguousarray(np.concatenate([np.zeros(sf * 30720, np.float32), iq[:, 1].astype(np.float32)]))
+            rx = R.ref_subframe_new()
+            assert R.ref_get_dl_subframe_and_ce(cap["phy"], i_f, q_f, 0, sf, cell, 2, rx) == 0
+            want = [po.ref_subframe_view(R, rx, 0)[:14].copy(), po.ref_subframe_view(R, rx, 1)[:14].copy(),
+                    po.ref_subframe_view(R, rx, 2, True)[:2, :14].copy(), po.ref_subframe_view(R, rx, 3, True)[:2, :14].copy()]
+            R.ref_subframe_free(rx)
+        R.ref_phy_free(cap["phy"])
+    np.savez_compressed(os.path.join(OUT, "dl_two_port_units.npz"), iq=np.stack(units), sfs=np.array(sfs, np.uint32), cells=np.array(cells, np.uint32),
+                        symb_re=want[0], symb_im=want[1], ce_re=want[2], ce_im=want[3])
+    print("dl_two_port_units.npz:", len(units), "units of", ul, "samples")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     R, P = po.ref(), po.port()
     assert R is not None, "oracle/_ref is not built (needs /root/reference)"
+    if len(sys.argv) > 1 and sys.argv[1] == "two_port":  # (the other fixtures are left as they are)
+        return two_port_units(R)
     phy = R.ref_phy_new(4, 17, 1, 100)
     turbo_ref_vectors(R, P, phy)
     R.ref_phy_free(phy)
@@ -146,6 +174,7 @@ def main():
     pdcch_vectors(R)
     pbch_vectors(R)
     sync_vectors(R)
+    two_port_units(R)
 
 
 if __name__ == "__main__":

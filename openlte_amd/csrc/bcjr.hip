@@ -61,6 +61,32 @@ __device__ __forceinline__ v2s byte_pair_rt(uint32_t w0, uint32_t w1, int r) // 
 {
     return r == 0 ? byte_pair<0>(w0, w1) : r == 1 ? byte_pair<1>(w0, w1) : r == 2 ? byte_pair<2>(w0, w1) : byte_pair<3>(w0, w1);
 }
+// Global accesses at "wavefront-uniform base + the lane's 32-bit offset": the base is pinned to scalar registers (an empty asm the
+// optimiser cannot look through -- left alone it re-associates "(base + row) + lane" into "(base + lane) + row" and carries the first sum
+// as a 64-bit vector pair, one v_lshl_add_u64 per access) and the access goes through an explicit global-address-space pointer (the asm
+// hides where the pointer came from; without the qualifier the access would become a flat one).  The offset's zero-extension has to be
+// formed in the basic block of the access -- hoisted out of a loop it reaches instruction selection as a 64-bit pair and the scalar-base
+// form is not recognised -- hence local_off() once per loop body.
+__device__ __forceinline__ uint32_t local_off(uint32_t v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) const char gconst_char_t;
+typedef __attribute__((address_space(1))) char       gchar_t;
+template <typename T> __device__ __forceinline__ T ld_sbase(const void *ubase, uint32_t voff)
+{
+    gconst_char_t *b = reinterpret_cast<gconst_char_t *>(reinterpret_cast<uintptr_t>(ubase));
+    asm volatile("" : "+s"(b));
+    return *reinterpret_cast<__attribute__((address_space(1))) const T *>(b + voff);
+}
+template <typename T> __device__ __forceinline__ void st_sbase(void *ubase, uint32_t voff, T v)
+{
+    gchar_t *b = reinterpret_cast<gchar_t *>(reinterpret_cast<uintptr_t>(ubase));
+    asm volatile("" : "+s"(b));
+    *reinterpret_cast<__attribute__((address_space(1))) T *>(b + voff) = v;
+}
 __device__ __forceinline__ uint32_t word_of(const uint4 &q, int k) { return k == 0 ? q.x : k == 1 ? q.y : k == 2 ? q.z : q.w; }
 
 __device__ __forceinline__ void norm8(v2s (&v)[8]) // subtract the maximum, floor at BCJR_NEG (per half)
@@ -194,23 +220,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BCJR_WPE, 8)
     const uint32_t pair = blockIdx.x, seg = blockIdx.y, n_seg = gridDim.y, lane = threadIdx.x, K = g.K, Kp = kpad64(K);
     const uint32_t seg_len = ((Kp >> 6) / n_seg) * 64, t_lo = seg * seg_len, t_hi = min(t_lo + seg_len, K), n_blk = (K + 31) >> 5;
     const uint32_t tile0 = 2 * pair, tile1 = min(2 * pair + 1, g.n_tiles - 1); // an odd tile count: the last tile twice (its results land in the spare half)
-    const char *s0 = reinterpret_cast<const char *>(g.S) + g8(tile0, Kp, lane, 0), *s1 = reinterpret_cast<const char *>(g.S) + g8(tile1, Kp, lane, 0);
-    const char *p0 = reinterpret_cast<const char *>(g.P) + g8(tile0, Kp, lane, 0), *p1 = reinterpret_cast<const char *>(g.P) + g8(tile1, Kp, lane, 0);
-    const char *arow = reinterpret_cast<const char *>(g.A) + ex_row(pair, Kp, 0) + lane * 2;
-    char       *erow = reinterpret_cast<char *>(g.E) + ex_row(pair, Kp, 0) + lane * 2;
-    char       *hrow = LAST ? reinterpret_cast<char *>(g.HD) + ex_row(pair, Kp, 0) + lane * 2 : nullptr;
+    // Every global address of the loops below is a wavefront-uniform base (scalar registers, scalar arithmetic) plus the lane's own 32-bit
+    // offset: written as per-lane 64-bit pointers they cost a v_lshl_add_u64 (and often a 64-bit shift) per access -- a tenth of the
+    // loops' vector instructions in a kernel that is bound by exactly those
+    const char *s0 = reinterpret_cast<const char *>(g.S) + g8(tile0, Kp, 0, 0), *s1 = reinterpret_cast<const char *>(g.S) + g8(tile1, Kp, 0, 0);
+    const char *p0 = reinterpret_cast<const char *>(g.P) + g8(tile0, Kp, 0, 0), *p1 = reinterpret_cast<const char *>(g.P) + g8(tile1, Kp, 0, 0);
+    const char *arow = reinterpret_cast<const char *>(g.A) + ex_row(pair, Kp, 0);
+    char       *erow = reinterpret_cast<char *>(g.E) + ex_row(pair, Kp, 0);
+    char       *hrow = LAST ? reinterpret_cast<char *>(g.HD) + ex_row(pair, Kp, 0) : nullptr;
     const size_t bnd_lane = ((size_t)pair * 64 + lane) * 2, bnd_stride = (size_t)g.n_pairs * 64 * 2; // in uint4 units: 8 x v2s = two uint4
 
     // the eight steps of the window that starts at t0 (a multiple of 8): Ls + La and Lp of both trellises
     auto load_window = [&](uint32_t t0, v2s (&lsa)[8], v2s (&lp)[8]) {
-        const size_t go = (size_t)(t0 >> 4) * 1024 + (t0 & 8u);
-        const uint2  S0 = *reinterpret_cast<const uint2 *>(s0 + go), S1 = *reinterpret_cast<const uint2 *>(s1 + go);
-        const uint2  P0 = *reinterpret_cast<const uint2 *>(p0 + go), P1 = *reinterpret_cast<const uint2 *>(p1 + go);
-        const uint4  r0 = *reinterpret_cast<const uint4 *>(g.row + t0), r1 = *reinterpret_cast<const uint4 *>(g.row + t0 + 4); // uniform: scalar loads
-        const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        const size_t   go = (size_t)(t0 >> 4) * 1024 + (t0 & 8u);
+        const uint32_t lane16 = local_off(lane * 16u), lane2 = local_off(lane * 2u);
+        const u32x2  S0 = ld_sbase<u32x2>(s0 + go, lane16), S1 = ld_sbase<u32x2>(s1 + go, lane16);
+        const u32x2  P0 = ld_sbase<u32x2>(p0 + go, lane16), P1 = ld_sbase<u32x2>(p1 + go, lane16);
+        // uniform, and read through the constant address space: only then does the compiler dare scalar loads (the kernel stores to global
+        // memory, and a plain pointer inside an argument struct carries no promise that the table is not what it stores to) -- as vector
+        // loads the eight row numbers of a window sat in vector registers and every row address was a 64-bit vector shift and add
+        typedef __attribute__((address_space(4))) const uint32_t const_u32_t;
+        const_u32_t *rp = reinterpret_cast<const_u32_t *>(reinterpret_cast<uintptr_t>(g.row + t0));
+        const uint32_t rw[8] = {rp[0], rp[1], rp[2], rp[3], rp[4], rp[5], rp[6], rp[7]};
         uint32_t aq[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) aq[r] = *reinterpret_cast<const uint16_t *>(arow + (size_t)rw[r] * 128); // (q of tile 2p) | (q of tile 2p+1) << 8
+        for (int r = 0; r < 8; r++) aq[r] = ld_sbase<uint16_t>(arow + (size_t)rw[r] * 128, lane2); // (q of tile 2p) | (q of tile 2p+1) << 8
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const v2s la = as_v2s(__builtin_amdgcn_perm(0u, aq[r], 0x010C000Cu)) >> 7; // 2q per half: the byte in the half's upper byte, arithmetic shift by 7
@@ -286,6 +320,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BCJR_WPE, 8)
             }
 #pragma unroll
             for (int r = 1; r < 8; r++) alpha_step(al[r - 1], lsa[r - 1] + lp[r - 1], lsa[r - 1], lp[r - 1], al[r]);
+            const uint32_t lane2 = local_off(lane * 2u);
 #pragma unroll
             for (int r = 7; r >= 0; r--) {
                 const v2s g00 = lsa[r] + lp[r], g01 = lsa[r], g10 = lp[r];
@@ -303,12 +338,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BCJR_WPE, 8)
                 e             = (e * (v2s)(3)) >> 2;              // the 3/4 scaling (arithmetic shift): within +-255
                 e             = vmax(e, splat(-BCJR_LE_MAX)) >> 1; // the stored half (the upper clamp would not change it: 255 >> 1 = 254 >> 1)
                 const size_t ro = (size_t)(b0 + 8 * w + r) * 128;
-                *reinterpret_cast<uint16_t *>(erow + ro) = (uint16_t)__builtin_amdgcn_perm(0u, as_u32(e), 0x0C0C0200u); // the two low bytes
+                st_sbase<uint16_t>(erow + ro, lane2, (uint16_t)__builtin_amdgcn_perm(0u, as_u32(e), 0x0C0C0200u)); // the two low bytes
                 if (LAST) {
                     const uint32_t neg = as_u32(llr) >> 15; // bit 0: low half negative, bit 16: high half negative
                     const uint16_t hd  = (uint16_t)((neg & 1u) | ((neg >> 8) & 0x100u));
-                    if (EARLY) hd_diff |= (uint32_t)(*reinterpret_cast<const uint16_t *>(hrow + ro) ^ hd);
-                    *reinterpret_cast<uint16_t *>(hrow + ro) = hd;
+                    if (EARLY) hd_diff |= (uint32_t)(ld_sbase<uint16_t>(hrow + ro, lane2) ^ hd);
+                    st_sbase<uint16_t>(hrow + ro, lane2, hd);
                 }
 #pragma unroll
                 for (int s = 0; s < 8; s++) b[s] = vmax(u0[s], u1[s]); // the beta step

@@ -81,9 +81,28 @@ __device__ __forceinline__ int soft_xor(int a, int b)
 }
 
 
+// Wavefront-wide reductions on the vector ALU's own cross-lane paths (DPP within a row of 16 lanes, v_readlane across the four rows) --
+// __shfl_xor is a ds_bpermute, i.e. an instruction of the LDS pipe, and that pipe is the busiest unit of the per-code-block kernels
+// (72 % of k_turbo_prep's time, SQ_ACTIVE_INST_LDS): three block-wide maxima there were eighteen of its ~110 LDS instructions per wavefront.
+// After the four steps every lane of a row holds the row's result; the four rows are combined in scalar registers (the result is uniform).
+template <typename Op> __device__ __forceinline__ int wave_reduce_i(int v, Op op)
+{
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]: lane ^ 1
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]: lane ^ 2
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false)); // row_half_mirror: the other quad of the eight
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false)); // row_mirror: the other eight of the row
+    return op(op(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), op(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int      wave_max_i(int v) { return wave_reduce_i(v, [](int a, int b) { return max(a, b); }); }
+__device__ __forceinline__ uint32_t wave_xor_u(uint32_t v) { return (uint32_t)wave_reduce_i((int)v, [](int a, int b) { return a ^ b; }); }
+__device__ __forceinline__ float    wave_max_f(float v) // (non-negative inputs: |x| maxima -- the integer order of their bit patterns is the float order)
+{
+    return __int_as_float(wave_max_i(__float_as_int(v)));
+}
+
 __device__ __forceinline__ float block_max_f(float v, float *red /* >= 8 floats */)
 {
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    v = wave_max_f(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -93,7 +112,7 @@ __device__ __forceinline__ float block_max_f(float v, float *red /* >= 8 floats 
 }
 __device__ __forceinline__ int block_max_i(int v, int *red)
 {
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    v = wave_max_i(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -105,7 +124,7 @@ __device__ __forceinline__ int block_max_i(int v, int *red)
 // two maxima in one round (red: >= 16 ints)
 __device__ __forceinline__ void block_max_i2(int &a, int &b, int *red)
 {
-    for (int o = 32; o > 0; o >>= 1) { a = max(a, __shfl_xor(a, o)); b = max(b, __shfl_xor(b, o)); }
+    a = wave_max_i(a); b = wave_max_i(b);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[8 + (threadIdx.x >> 6)] = b; }
     __syncthreads();
@@ -1425,7 +1444,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         }
     }
     if (GROUP) {
-        for (int sft = 32; sft > 0; sft >>= 1) crc ^= __shfl_xor(crc, sft);
+        crc = wave_xor_u(crc);
         __syncthreads();
         if ((threadIdx.x & 63) == 0) red_u[threadIdx.x >> 6] = crc;
         __syncthreads();
@@ -1703,7 +1722,7 @@ __global__ __launch_bounds__(256) void k_crc_finish(const uint8_t *__restrict__ 
                 o[m] = (uint8_t)v;
             }
     }
-    for (int sft = 32; sft > 0; sft >>= 1) crc ^= __shfl_xor(crc, sft);
+    crc = wave_xor_u(crc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = crc;
     __syncthreads();
     if (threadIdx.x == 0) g.status[alloc] = ((red[0] ^ red[1] ^ red[2] ^ red[3]) == 0) ? 0 : 2;

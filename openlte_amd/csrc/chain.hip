@@ -621,14 +621,19 @@ int mi_lte_pdsch_decode_run(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, const float 
     const uint32_t e_cap = (e_bytes <= 32 * 1024) ? e_bytes : 0;
     const uint32_t pairs_al = ((2 * pl->max_pairs + 1 + 3u) & ~3u);
     const size_t lds = sizeof(uint32_t) * ((size_t)pairs_al + words_al) + e_cap;
+    uint32_t threads = 256;
+    if (const char *ev = getenv("MI_LTE_PDSCH_THREADS")) { // (tuning aid)
+        const int t = atoi(ev);
+        if (t >= 64 && t <= 256 && t % 64 == 0) threads = (uint32_t)t;
+    }
     if (g.N_ant == 1 && (pl->cfg.sample_format & MI_LTE_CE_COMPACT))
-        MI_LAUNCH(ctx, "k_pdsch_demod", (k_pdsch_demod<true, true>), dim3(pl->n_alloc), dim3(256), lds, d_subframes, g, pl->d_allocs, d_subfr_num,
+        MI_LAUNCH(ctx, "k_pdsch_demod", (k_pdsch_demod<true, true>), dim3(pl->n_alloc), dim3(threads), lds, d_subframes, g, pl->d_allocs, d_subfr_num,
                   d_n_id_cell, gt, pl->d_e, pl->d_e_off, pl->d_e_len, pl->max_pairs, words_al, e_cap);
     else if (g.N_ant == 1)
-        MI_LAUNCH(ctx, "k_pdsch_demod", k_pdsch_demod<true>, dim3(pl->n_alloc), dim3(256), lds, d_subframes, g, pl->d_allocs, d_subfr_num,
+        MI_LAUNCH(ctx, "k_pdsch_demod", k_pdsch_demod<true>, dim3(pl->n_alloc), dim3(threads), lds, d_subframes, g, pl->d_allocs, d_subfr_num,
                   d_n_id_cell, gt, pl->d_e, pl->d_e_off, pl->d_e_len, pl->max_pairs, words_al, e_cap);
     else
-        MI_LAUNCH(ctx, "k_pdsch_demod", k_pdsch_demod<false>, dim3(pl->n_alloc), dim3(256), lds, d_subframes, g, pl->d_allocs, d_subfr_num,
+        MI_LAUNCH(ctx, "k_pdsch_demod", k_pdsch_demod<false>, dim3(pl->n_alloc), dim3(threads), lds, d_subframes, g, pl->d_allocs, d_subfr_num,
                   d_n_id_cell, gt, pl->d_e, pl->d_e_off, pl->d_e_len, pl->max_pairs, words_al, e_cap);
     MI_HIP_CHECK(ctx, hipGetLastError());
     const bool bcjr = pl->decoder == MI_LTE_TURBO_BCJR || pl->decoder == MI_LTE_TURBO_BCJR_BLOCK || pl->decoder == MI_LTE_TURBO_BCJR_EARLY;

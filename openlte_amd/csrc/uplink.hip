@@ -586,7 +586,16 @@ int mi_lte_pusch_decode_run(mi_lte_ctx *ctx, mi_lte_pusch_plan *pl, const float 
     while (S_par > 1 && (size_t)S_par * pl->M_max * 2 * sizeof(float2) > 40 * 1024) S_par = S_par == 12 ? 6 : S_par == 6 ? 3 : S_par - 1; // 12, or a divisor of 6
     const size_t lds = sizeof(float) * EST_ROWS * (size_t)pl->M_max + sizeof(float2) * (size_t)pl->M_max * (1 + 2 * S_par) +
                        sizeof(uint32_t) * (pl->words_max + 1);
-    MI_LAUNCH(ctx, "k_pusch_demod", k_pusch_demod, dim3(pl->n_alloc), dim3(PUSCH_THREADS), lds, d_subframes, (uint32_t)mi_lte_ul_subframe_floats(),
+    // Workgroup size: the kernel's phases hold 3 M, M, 2 M, 12 M / R and 12 M items (M = 12 N_prb sub-carriers) between barriers, and the
+    // heavy ones (atan2f, sincosf, the divisions) are the short ones -- a workgroup much wider than 3 M leaves whole wavefronts waiting at
+    // every barrier for the one that has the transcendental work (SQ_WAIT_ANY: 67 % of the wave time at 256 threads and M = 72).  Measured on
+    // W5 (16 UEs x 6 PRB): 64 / 128 / 192 / 256 threads = see profiles/r04_variants_pusch_threads.txt; larger allocations keep 256.
+    uint32_t threads = pl->M_max <= 96 ? 192u : PUSCH_THREADS;
+    if (const char *ev = getenv("MI_LTE_PUSCH_THREADS")) { // (tuning aid)
+        const int t = atoi(ev);
+        if (t >= 64 && t <= (int)PUSCH_THREADS && t % 64 == 0) threads = (uint32_t)t;
+    }
+    MI_LAUNCH(ctx, "k_pusch_demod", k_pusch_demod, dim3(pl->n_alloc), dim3(threads), lds, d_subframes, (uint32_t)mi_lte_ul_subframe_floats(),
               pl->d_allocs, pl->d_desc, pl->d_dmrs, gt, pl->d_e, pl->d_e_off, pl->d_e_len, pl->M_max, S_par);
     MI_HIP_CHECK(ctx, hipGetLastError());
     for (auto &gr : pl->groups) {

@@ -473,6 +473,8 @@ int    mi_lte_find_sss_run(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const void
  *       the mixed float / double precision of the reference's expression; cosf / sinf are the device library's (<= 2 ulp), so the
  *       result agrees with the host's to float rounding, like the FFT behind it. */
 int mi_lte_iq_i8_to_planar(mi_lte_ctx *ctx, const int8_t *d_iq, uint64_t n_samples, float *d_i_samps, float *d_q_samps);
+/* the scanner's other input format, gr_complex = interleaved float32 pairs (LTE_fdd_dl_fs_samp_buf.cc:686-692) -> planar fp32 */
+int mi_lte_iq_f32_pairs_to_planar(mi_lte_ctx *ctx, const float *d_iq, uint64_t n_samples, float *d_i_samps, float *d_q_samps);
 int mi_lte_freq_shift_run(mi_lte_ctx *ctx, float *d_i_samps, float *d_q_samps, uint64_t first_index, uint64_t n_samples, float freq_offset,
                           uint32_t fs);
 

@@ -209,6 +209,16 @@ __global__ __launch_bounds__(256) void k_i8_to_planar(const int8_t *__restrict__
     }
 }
 
+// gr_complex (interleaved float32 pairs, the reference scanner's other input format, :686-692) -> planar float
+__global__ __launch_bounds__(256) void k_f32_pairs_to_planar(const float2 *__restrict__ iq, uint64_t n, float *__restrict__ si, float *__restrict__ sq)
+{
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        const float2 v = iq[k];
+        si[k] = v.x;
+        sq[k] = v.y;
+    }
+}
+
 inline float mag(float2 c) { return (float)sqrt(c.x * c.x + c.y * c.y); } // abs_corr = sqrt(re*re + im*im): float expression, double sqrt
 
 } // namespace
@@ -421,6 +431,18 @@ int mi_lte_iq_i8_to_planar(mi_lte_ctx *ctx, const int8_t *d_iq, uint64_t n_sampl
     MI_LAUNCH(ctx, "k_i8_to_planar", k_i8_to_planar, dim3(grid), dim3(256), 0, d_iq, n_samples, d_i_samps, d_q_samps);
     MI_HIP_CHECK(ctx, hipGetLastError());
     ctx->last_kernels = "k_i8_to_planar:1";
+    return MI_LTE_OK;
+}
+
+int mi_lte_iq_f32_pairs_to_planar(mi_lte_ctx *ctx, const float *d_iq, uint64_t n_samples, float *d_i_samps, float *d_q_samps)
+{
+    if (!ctx || !d_iq || !d_i_samps || !d_q_samps) return MI_LTE_ERR_INVALID_ARG;
+    if (n_samples == 0) return MI_LTE_OK;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n_samples + 255) / 256, 256 * 32);
+    MI_LAUNCH(ctx, "k_f32_pairs_to_planar", k_f32_pairs_to_planar, dim3(grid), dim3(256), 0, reinterpret_cast<const float2 *>(d_iq), n_samples, d_i_samps, d_q_samps);
+    MI_HIP_CHECK(ctx, hipGetLastError());
+    ctx->last_kernels = "k_f32_pairs_to_planar:1";
     return MI_LTE_OK;
 }
 

@@ -155,7 +155,10 @@ struct Scanner {
 
 int main(int argc, char **argv)
 {
-    if (argc < 3) { fprintf(stderr, "usage: scan_batch <capture.bin> <fs MHz> [max SI frames]\n"); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: scan_batch <capture.bin> <fs MHz> [max SI frames] [int8 | gr_complex]\n"); return 2; }
+    // the two formats LTE_fdd_dl_file_scan reads (LTE_fdd_dl_fs_samp_buf.cc:657-694): int8 I,Q pairs (default) or gr_complex = float32 pairs
+    const bool gr_complex = argc > 4 && strcmp(argv[4], "gr_complex") == 0;
+    const size_t samp_bytes = gr_complex ? 8 : 2;
     const double fs_mhz = atof(argv[2]);
     const int    fsi = fs_mhz < 2 ? 0 : fs_mhz < 4 ? 1 : fs_mhz < 8 ? 2 : fs_mhz < 16 ? 3 : 4;
     static const char    *fs_text[5] = {"1.92", "3.84", "7.68", "15.36", "30.72"}; // liblte_phy_fs_text (liblte_phy.h:205)
@@ -167,10 +170,10 @@ int main(int argc, char **argv)
     FILE *f = fopen(argv[1], "rb");
     if (!f) return 4;
     fseek(f, 0, SEEK_END);
-    s.n = (uint32_t)(ftell(f) / 2);
+    s.n = (uint32_t)(ftell(f) / samp_bytes);
     fseek(f, 0, SEEK_SET);
-    std::vector<int8_t> raw((size_t)s.n * 2);
-    if (fread(raw.data(), 2, s.n, f) != s.n) return 4;
+    std::vector<int8_t> raw((size_t)s.n * samp_bytes);
+    if (fread(raw.data(), samp_bytes, s.n, f) != s.n) return 4;
     fclose(f);
     printf("capture: %u samples (%.1f frames) at %s Hz\n", s.n, (double)s.n / n_frame, fs_text[fsi]);
 
@@ -180,13 +183,14 @@ int main(int argc, char **argv)
     // the capture in HBM: int8 pairs once, then planar float with two frames of zeros behind it (the per-call scanner's calloc'ed pad)
     const uint64_t pad = 2ull * n_frame, n_buf = (uint64_t)s.n + pad;
     int8_t *d_raw;
-    CK(mi_lte_malloc(ctx, (size_t)s.n * 2, (void **)&d_raw));
+    CK(mi_lte_malloc(ctx, (size_t)s.n * samp_bytes, (void **)&d_raw));
     CK(mi_lte_malloc(ctx, sizeof(float) * n_buf, (void **)&s.d_i));
     CK(mi_lte_malloc(ctx, sizeof(float) * n_buf, (void **)&s.d_q));
     CK(mi_lte_memset(ctx, s.d_i, 0, sizeof(float) * n_buf));
     CK(mi_lte_memset(ctx, s.d_q, 0, sizeof(float) * n_buf));
-    CK(mi_lte_memcpy_h2d(ctx, d_raw, raw.data(), (size_t)s.n * 2));
-    CK(mi_lte_iq_i8_to_planar(ctx, d_raw, s.n, s.d_i, s.d_q));
+    CK(mi_lte_memcpy_h2d(ctx, d_raw, raw.data(), (size_t)s.n * samp_bytes));
+    if (gr_complex) CK(mi_lte_iq_f32_pairs_to_planar(ctx, reinterpret_cast<const float *>(d_raw), s.n, s.d_i, s.d_q));
+    else            CK(mi_lte_iq_i8_to_planar(ctx, d_raw, s.n, s.d_i, s.d_q));
     mi_lte_free(ctx, d_raw);
 
     mi_lte_dl_cfg cfg6 = {s.fft, 6, 1, MI_LTE_IQ_F32_PLANAR}; // before the MIB only the centre six resource blocks are known to exist

@@ -64,7 +64,9 @@ static void report_sib2(const LIBLTE_RRC_SYS_INFO_BLOCK_TYPE_2_STRUCT *b)
 
 int main(int argc, char **argv)
 {
-    if (argc < 3) { fprintf(stderr, "usage: scan <capture.bin> <fs MHz> [max SI frames]\n"); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: scan <capture.bin> <fs MHz> [max SI frames] [int8 | gr_complex]\n"); return 2; }
+    // the two formats LTE_fdd_dl_file_scan reads (LTE_fdd_dl_fs_samp_buf.cc:657-694): int8 I,Q pairs (default) or gr_complex = float32 pairs
+    const bool gr_complex = argc > 4 && strcmp(argv[4], "gr_complex") == 0;
     const double fs_mhz = atof(argv[2]);
     const LIBLTE_PHY_FS_ENUM fs = fs_mhz < 2 ? LIBLTE_PHY_FS_1_92MHZ : fs_mhz < 4 ? LIBLTE_PHY_FS_3_84MHZ : fs_mhz < 8 ? LIBLTE_PHY_FS_7_68MHZ
                                 : fs_mhz < 16 ? LIBLTE_PHY_FS_15_36MHZ : LIBLTE_PHY_FS_30_72MHZ;
@@ -76,16 +78,23 @@ int main(int argc, char **argv)
     FILE *f = fopen(argv[1], "rb");
     if (!f) return 4;
     fseek(f, 0, SEEK_END);
-    s.n = (uint32)(ftell(f) / 2);
+    s.n = (uint32)(ftell(f) / (gr_complex ? 8 : 2));
     fseek(f, 0, SEEK_SET);
     const uint32 pad = 2 * s.phy->N_samps_per_frame;
     s.i = (float *)calloc(s.n + pad, sizeof(float));
     s.q = (float *)calloc(s.n + pad, sizeof(float));
     for (uint32 k = 0; k < s.n; k++) {
-        signed char v[2];
-        if (fread(v, 1, 2, f) != 2) break;
-        s.i[k] = v[0];
-        s.q[k] = v[1];
+        if (gr_complex) {
+            float v[2];
+            if (fread(v, 4, 2, f) != 2) break;
+            s.i[k] = v[0];
+            s.q[k] = v[1];
+        } else {
+            signed char v[2];
+            if (fread(v, 1, 2, f) != 2) break;
+            s.i[k] = v[0];
+            s.q[k] = v[1];
+        }
     }
     fclose(f);
     const uint32 n_frame = s.phy->N_samps_per_frame, n_subfr = s.phy->N_samps_per_subfr;

@@ -460,3 +460,22 @@ def test_per_call_forms_fail_an_off_carrier_allocation_like_the_reference(ctx, r
     assert L.mi_lte_pusch_channel_decode_host(ctx.h, 25, usr, usi, 2, C.addressof(a_in), 17, 1, d[0], d[1], d[2], d[3], got, C.byref(gn)) == 1
     ref.ref_subframe_free(sfp)
     ref.ref_phy_free(phy)
+
+
+def test_scanners_read_gr_complex_captures(tmp_path):
+    """LTE_fdd_dl_file_scan reads int8 pairs or gr_complex (LTE_fdd_dl_fs_samp_buf.cc:657-694); so do the three scanners.  The same capture
+    as float32 pairs must give the report of the int8 file -- per-call scanner on the shim, batch scanner on the C-ABI (device-side
+    de-interleave, mi_lte_iq_f32_pairs_to_planar), and the all-reference build."""
+    build = os.path.join(ROOT, "shim", "_build")
+    gen, scan_gpu, scan_cpu, scan_batch = (os.path.join(build, n) for n in ("capture_gen", "scan_gpu", "scan_cpu", "scan_batch"))
+    if not all(os.path.exists(x) for x in (gen, scan_gpu, scan_batch)):
+        pytest.skip("shim/_build not built (needs the reference tree at build time)")
+    cap = os.path.join(str(tmp_path), "capture.bin")
+    subprocess.run([gen, cap, "25", "301", "24"], check=True, timeout=600)
+    capf = os.path.join(str(tmp_path), "capture.fc32")
+    np.fromfile(cap, np.int8).astype(np.float32).tofile(capf)
+    want = open(os.path.join(ROOT, "tests", "golden", "scan_25rb_reference_cpu.txt")).read()
+    for exe in (scan_gpu, scan_batch) + ((scan_cpu,) if os.path.exists(scan_cpu) else ()):
+        got = subprocess.run([exe, capf, "7.68", "9", "gr_complex"], capture_output=True, text=True, timeout=900)
+        assert got.returncode == 0, (exe, got.stdout + got.stderr)
+        assert got.stdout == want, exe

@@ -177,7 +177,7 @@ def test_uplink_fuzz_against_the_compiled_reference(ctx, ref):
     fz.run_ref_ul(ref, groups)
     t_ref = time.time() - t0
     n_alloc = n_ok = n_soft = n_soft_diff = verdict_diff_after_soft_diff = 0
-    bad, soft_diff, worst = [], [], 0.0
+    bad, soft_diff, worst, soft_values = [], [], 0.0, []
     for gi, g in enumerate(groups):
         n = len(g["sfs"])
         ul_len = g["iq"].shape[1]
@@ -204,6 +204,12 @@ def test_uplink_fuzz_against_the_compiled_reference(ctx, ref):
                 nd = int((soft[k] != wsoft).sum())
                 n_soft_diff += nd
                 soft_diff.append((key, nd, int(st[k]), rc))
+                # what the differing values are: (position, library, reference).  A QPSK symbol's two soft bits carry ONE magnitude,
+                # (int8)(127 * sd), and the quadrant's signs (liblte_phy.cc:9543-9570), so a lone differing bit with the same magnitude on both
+                # sides is a quadrant decision on a component that the two SC-FDMA transforms' rounding put on opposite sides of zero; a
+                # magnitude step would show in both bits of the symbol
+                for i in np.nonzero(soft[k] != wsoft)[0][:8]:
+                    soft_values.append([str(key), int(i), int(soft[k][i]), int(wsoft[i]), int(soft[k][i ^ 1]), int(wsoft[i ^ 1])])
                 if (st[k] == 0) != (rc == 0):
                     verdict_diff_after_soft_diff += 1
             elif (st[k] == 0) != (rc == 0):
@@ -215,8 +221,12 @@ def test_uplink_fuzz_against_the_compiled_reference(ctx, ref):
     REPORT["uplink"] = dict(groups=len(groups), units=sum(len(g["sfs"]) for g in groups), allocations=n_alloc, decoded_by_both=n_ok, mismatches=[list(map(str, b)) for b in bad[:50]],
                             worst_rel_l2_rx_symb=worst, seconds_reference=round(t_ref, 1), soft_bits=n_soft, soft_bits_differing=n_soft_diff,
                             allocations_with_differing_soft_bits=[list(map(str, x)) for x in soft_diff[:50]],
-                            verdicts_differing_in_those=verdict_diff_after_soft_diff)
+                            verdicts_differing_in_those=verdict_diff_after_soft_diff,
+                            differing_soft_bits_position_library_reference_and_the_symbols_other_bit=soft_values[:50],
+                            differing_soft_bits_are_sign_flips_of_equal_magnitude=bool(all(v[2] == -v[3] and v[4] == v[5] for v in soft_values)))
     write_report()
+    # every differing soft bit is the sign of a component at zero: same magnitude, opposite sign, the symbol's other bit untouched
+    assert all(v[2] == -v[3] and v[4] == v[5] for v in soft_values), soft_values[:10]
     assert n_alloc >= 2500
     assert not bad, bad[:10]
     assert n_soft_diff <= 1e-5 * n_soft and len(soft_diff) <= 0.005 * n_alloc, (n_soft_diff, n_soft, soft_diff[:10])

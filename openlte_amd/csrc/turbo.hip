@@ -769,18 +769,21 @@ __device__ __forceinline__ uint32_t sign_bits(v2s n) { return __builtin_bit_cast
 // (bit = PM[2j] > PM[2j+1] = sign of n_j; step S of the four, pair j -> bit 15 - (4S + j)).
 // Every instruction of this loop costs four cycles of its SIMD, also the ones that issue in two on their own (v_and, v_xor, v_bitop3):
 // profiles/r04_ubench_issue_mix.txt -- a SIMD that alternates between the two kinds runs both at the slow rate -- so what counts is
-// the number of instructions, 66 per step and pair of trellises: 8 for the two inputs (2 byte permutes, 2 shifts, 3 sign masks and
-// their exclusive-or), 10 branch terms, 4 metric differences, 8 decision bits (a sign mask and one and-or with the bit's own
+// the number of instructions, 66 per step and pair of trellises: 7 for the two inputs (2 byte permutes, 2 shifts, 2 sign masks and
+// an exclusive-or), 10 branch terms, 4 metric differences, 8 decision bits (a sign mask and one and-or with the bit's own
 // constant each: collecting the signs by shifts took 10), 8 threshold tests + 8 masks + 16 candidates + 8 selects.
 template <int S> __device__ __forceinline__ void acs_step2(v2s (&pm)[8], v2s x2, v2s y2, uint32_t &acc)
 {
     // With w = |x|+|y| and e = +1 for a negative soft value:  w*P = -2(x+y) if the two signs agree, else 0;
     // w*Q = -2(x-y) if they differ, else 0;  2P, 2Q = +-4 (sign of x) under the same conditions.
-    const v2s m0 = x2 >> 15, mx = m0 ^ (y2 >> 15), nmx = ~mx; // mx = -1 iff the signs differ
+    const v2s mx = as_v2s(neg_mask(x2 ^ y2)), nmx = ~mx; // mx = -1 iff the signs differ (opaque: see neg_mask)
     const v2s uP = (x2 + y2) & nmx;                          // -w*P
     const v2s uQ = (x2 - y2) & mx;                           // -w*Q
-    const v2s c4 = (m0 & (v2s)(8)) - (v2s)(4);               // x < 0 ? 4 : -4
-    const v2s P2 = c4 & nmx, Q2 = c4 & mx;
+    // 2P, 2Q = (x < 0 ? 4 : -4) where the signs agree / differ, else 0: 0xFFFC ^ (sign mask & 0xFFF8) is 4 or -4, and the masking by
+    // mx is the same instruction (v_bitop3) -- four instructions for the pair, the add-and-mask form took five
+    const uint32_t m0p = neg_mask(x2) & 0xFFF8FFF8u; // (the opaque mask: from a visible shift the compiler builds compares and selects)
+    const v2s P2 = as_v2s(__builtin_amdgcn_bitop3_b32(as_u32(mx), m0p, 0xFFFCFFFCu, 0x06)); // ~mx & (0xFFFC ^ m0p)
+    const v2s Q2 = as_v2s(__builtin_amdgcn_bitop3_b32(as_u32(mx), m0p, 0xFFFCFFFCu, 0x60)); //  mx & (0xFFFC ^ m0p)
     const v2s n0 = pm[1] - pm[0], n1 = pm[3] - pm[2], n2 = pm[5] - pm[4], n3 = pm[7] - pm[6];
     constexpr uint32_t top = 0x00010001u << (15 - 4 * S); // the step's first bit in both halves
     // acc | (mask & bit) as ONE instruction each (the compiler's own choice is an and per bit and an or3 per two)

@@ -322,7 +322,9 @@ int      mi_lte_pusch_plan_soft_bits(const mi_lte_pusch_plan *plan, uint32_t all
 
 /* PRACH detection: replaces liblte_phy_detect_prach() (liblte_phy.h:862-868, implementation liblte_phy.cc:3299-3479)
  * for a batch of PRACH occasions (d_occ_start[o] = sample index of the occasion's first cyclic-prefix sample; an
- * occasion spans mi_lte_prach_occasion_samples() samples), preamble formats 0-3.  The 839 PRACH sub-carriers are
+ * occasion spans mi_lte_prach_occasion_samples() samples), preamble formats 0-4 (format 4, the TDD UpPTS preamble of
+ * liblte_phy.cc:2462-2468: N_zc = 139 on 7.5 kHz sub-carriers, T_fft = 4 096, root table 5.7.2-5, N_cs table 5.7.2-3 -- the same
+ * kernels with the sequence length as an argument).  The 839 (139) PRACH sub-carriers are
  * computed directly from the T_fft samples behind the prefix, correlated with every root sequence the cell's 64
  * preambles use, and the reference's verdict -- one preamble if the peak reaches 50 x the averaged correlation
  * power (:3460-3474) -- is evaluated on the host: h_N_det_pre[o] in {0,1}, h_det_pre[o] = preamble index,
@@ -330,8 +332,8 @@ int      mi_lte_pusch_plan_soft_bits(const mi_lte_pusch_plan *plan, uint32_t all
  * spectra itself (prach_preamble_seq_gen :7130-7290 + the 839-point DFTs of liblte_phy_ul_init :2496-2508);
  * mi_lte_prach_plan_create_roots takes them from the caller instead (LIBLTE_PHY_STRUCT::prach_x_u_fft_re/im). */
 typedef struct {
-    uint32_t root_seq_idx;     /* logical root sequence index, 0..837 */
-    uint32_t preamble_format;  /* 0..3 */
+    uint32_t root_seq_idx;     /* logical root sequence index, 0..837 (format 4: 0..137) */
+    uint32_t preamble_format;  /* 0..4 */
     uint32_t zczc;             /* zeroCorrelationZoneConfig */
     uint32_t hs_flag;          /* restricted set */
     uint32_t freq_offset;      /* n_PRBoffset^RA */
@@ -340,8 +342,8 @@ typedef struct mi_lte_prach_plan mi_lte_prach_plan;
 int      mi_lte_prach_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg /* N_rb_dl = N_rb_ul */, const mi_lte_prach_cfg *prach,
                                   mi_lte_prach_plan **out);
 int      mi_lte_prach_plan_create_roots(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const mi_lte_prach_cfg *prach,
-                                        const float *h_x_u_fft_re /*[n_roots][839]*/, const float *h_x_u_fft_im, uint32_t n_roots,
-                                        mi_lte_prach_plan **out);
+                                        const float *h_x_u_fft_re /*[n_roots][839], the first N_zc of a row used*/, const float *h_x_u_fft_im,
+                                        uint32_t n_roots, mi_lte_prach_plan **out);
 void     mi_lte_prach_plan_destroy(mi_lte_ctx *ctx, mi_lte_prach_plan *plan);
 uint32_t mi_lte_prach_plan_n_roots(const mi_lte_prach_plan *plan);
 uint32_t mi_lte_prach_occasion_samples(const mi_lte_prach_plan *plan);

@@ -61,6 +61,7 @@ struct mi_lte_ctx {
     float2   *d_fft_tw  = nullptr; // exp(-2*pi*i*k/4096), k = 0..4095, then the per-pass tables at 4096 + MI_FFT_TWC_* (mi_ctx_fft_twiddles)
     uint32_t *d_crc_tab = nullptr; // (x^e mod gCRC24A) << 8 at index MI_CRC_TAB_BIAS + e, e = -8..6143 (mi_ctx_crc_table)
     float2   *d_prach_tab = nullptr; // chirp | filter spectrum | twiddles of the 839-point chirp-z transform (prach.hip)
+    float2   *d_prach_tab4 = nullptr; // the same for the 139-point sequences of preamble format 4
 
     // optional per-launch HIP-event bracketing (mi_lte_profile_*): pairs are resolved at report time
     bool                                   prof_on = false, prof_armed = false;

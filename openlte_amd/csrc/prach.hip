@@ -1,5 +1,7 @@
 // PRACH detection on gfx950 (the rest of SURVEY 8f N1 / BASELINE config 5): restates liblte_phy_detect_prach
-// (liblte/src/liblte_phy.cc:3299-3479) for preamble formats 0-3 and a batch of PRACH occasions.
+// (liblte/src/liblte_phy.cc:3299-3479) for preamble formats 0-4 and a batch of PRACH occasions.  (Format 4 -- the TDD UpPTS
+// preamble: N_zc = 139, T_fft = 4 096, 7.5 kHz sub-carriers, :2462-2468 -- runs through the same three kernels with 4 decimation phases
+// instead of 24 and its own chirp tables; the text below describes formats 0-3.)
 //
 // The reference transforms the T_fft = 24 576 samples behind the cyclic prefix with one FFT and keeps N_zc = 839 bins
 // (:3421-3433), multiplies them with the conjugate spectrum of each root sequence and goes back with an 839-point
@@ -21,7 +23,7 @@
 
 namespace {
 
-constexpr uint32_t N_ZC = 839;
+constexpr uint32_t N_ZC_MAX = 839; // formats 0-3; format 4: 139 (every kernel takes the length as an argument)
 
 template <typename T> struct Samp;
 template <> struct Samp<int8_t> {
@@ -43,14 +45,14 @@ template <> struct Samp<float> {
 // k_prach_fft: one workgroup per (occasion, r), radix-2 Stockham passes in LDS; k_prach_bins: the 24-term combination for the
 // 839 bins that are kept.  (The first version summed every bin directly: 24 576 x 839 complex MACs per occasion, 8.5 us at 20 MHz.)
 template <typename T>
-__global__ __launch_bounds__(256) void k_prach_fft(Samp<T> src, const uint64_t *__restrict__ occ_start, uint32_t T_cp, uint32_t N2,
+__global__ __launch_bounds__(256) void k_prach_fft(Samp<T> src, const uint64_t *__restrict__ occ_start, uint32_t T_cp, uint32_t N2, uint32_t P,
                                                    float2 *__restrict__ F)
 {
     extern __shared__ float2 lds[]; // two buffers of N2
     const uint32_t occ = blockIdx.y, r = blockIdx.x;
     const size_t   first = occ_start[occ] + T_cp;
     float2 *in = lds, *out = lds + N2;
-    for (uint32_t i = threadIdx.x; i < N2; i += blockDim.x) in[i] = src.at(first + (size_t)24 * i + r);
+    for (uint32_t i = threadIdx.x; i < N2; i += blockDim.x) in[i] = src.at(first + (size_t)P * i + r);
     __syncthreads();
     for (uint32_t Ns = 1; Ns < N2; Ns <<= 1) {
         for (uint32_t j = threadIdx.x; j < N2 / 2; j += blockDim.x) {
@@ -66,18 +68,19 @@ __global__ __launch_bounds__(256) void k_prach_fft(Samp<T> src, const uint64_t *
         __syncthreads();
         float2 *t = in; in = out; out = t;
     }
-    float2 *dst = F + ((size_t)occ * 24 + r) * N2;
+    float2 *dst = F + ((size_t)occ * P + r) * N2;
     for (uint32_t i = threadIdx.x; i < N2; i += blockDim.x) dst[i] = in[i];
 }
 
-__global__ __launch_bounds__(256) void k_prach_bins(const float2 *__restrict__ F, uint32_t N2, uint32_t T_fft, uint32_t start, float2 *__restrict__ x_hat)
+__global__ __launch_bounds__(256) void k_prach_bins(const float2 *__restrict__ F, uint32_t N2, uint32_t P, uint32_t T_fft, uint32_t start, uint32_t N_ZC,
+                                                    float2 *__restrict__ x_hat)
 {
     const uint32_t occ = blockIdx.y, b = blockIdx.x * 256 + threadIdx.x;
     if (b >= N_ZC) return;
     const uint32_t idx = (b + start + T_fft / 2) % T_fft, km = idx & (N2 - 1);
-    const float2  *f = F + (size_t)occ * 24 * N2 + km;
+    const float2  *f = F + (size_t)occ * P * N2 + km;
     float ar = 0.f, ai = 0.f;
-    for (uint32_t r = 0; r < 24; r++) {
+    for (uint32_t r = 0; r < P; r++) {
         const uint32_t t = (r * idx) % T_fft; // r * idx < 24 * 24576: no overflow
         float ws, wc;
         sincospif(-2.0f * (float)t / (float)T_fft, &ws, &wc);
@@ -117,7 +120,7 @@ __device__ __forceinline__ float2 *lds_fft_2048(float2 *in, float2 *out, const f
     return in; // 11 passes: the result sits in the buffer that was `out` at entry
 }
 
-__global__ __launch_bounds__(256) void k_prach_corr(const float2 *__restrict__ x_hat, const float2 *__restrict__ xu_fft, uint32_t n_roots,
+__global__ __launch_bounds__(256) void k_prach_corr(const float2 *__restrict__ x_hat, const float2 *__restrict__ xu_fft, uint32_t n_roots, uint32_t N_ZC,
                                                     const float2 *__restrict__ chirp, const float2 *__restrict__ bspec, const float2 *__restrict__ tw_g,
                                                     CorrOut *__restrict__ out)
 {
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(256) void k_prach_corr(const float2 *__restrict__ x
 
 struct mi_lte_prach_plan {
     mi_lte_dl_cfg cfg;
-    uint32_t      T_fft = 0, T_cp = 0, start = 0, N_cs = 0, v_max = 0, n_roots = 0;
+    uint32_t      T_fft = 0, T_cp = 0, start = 0, N_cs = 0, v_max = 0, n_roots = 0, n_zc = 839, phases = 24;
     float2       *d_xu_fft = nullptr;
     float2       *d_chirp = nullptr, *d_bspec = nullptr, *d_tw = nullptr; // Bluestein tables of the 839-point inverse DFT (owned by the context)
 };
@@ -185,10 +188,11 @@ struct mi_lte_prach_plan {
 // Bluestein tables of the 839-point inverse DFT, built once per context (they depend on nothing but 839 and 2048):
 // chirp c[n] = exp(+pi*i*n^2/839) with n^2 reduced mod 2*839 in integers; the 2048-point spectrum of the wrapped filter conj(c)
 // (double-precision radix-2 FFT on the host); the FFT twiddles.
-static int prach_bluestein_tables(mi_lte_ctx *ctx, float2 **d_chirp, float2 **d_bspec, float2 **d_tw)
+static int prach_bluestein_tables(mi_lte_ctx *ctx, uint32_t N_ZC, float2 **d_chirp, float2 **d_bspec, float2 **d_tw)
 {
-    if (ctx->d_prach_tab) {
-        *d_chirp = ctx->d_prach_tab; *d_bspec = ctx->d_prach_tab + 1024; *d_tw = ctx->d_prach_tab + 1024 + BL;
+    float2 *&cached = N_ZC == 839 ? ctx->d_prach_tab : ctx->d_prach_tab4; // one set per sequence length (839: formats 0-3, 139: format 4)
+    if (cached) {
+        *d_chirp = cached; *d_bspec = cached + 1024; *d_tw = cached + 1024 + BL;
         return MI_LTE_OK;
     }
     const double PI = 3.14159265358979323846;
@@ -222,7 +226,7 @@ static int prach_bluestein_tables(mi_lte_ctx *ctx, float2 **d_chirp, float2 **d_
     ctx->owned.push_back(d);
     MI_HIP_CHECK(ctx, hipMemcpyAsync(d, tab.data(), sizeof(float2) * tab.size(), hipMemcpyHostToDevice, ctx->stream));
     MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
-    ctx->d_prach_tab = d;
+    cached = d;
     *d_chirp = d; *d_bspec = d + 1024; *d_tw = d + 1024 + BL;
     return MI_LTE_OK;
 }
@@ -234,8 +238,11 @@ static int prach_plan_common(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const mi
     if (!ctx || !cfg || !pc || !out) return MI_LTE_ERR_INVALID_ARG;
     const uint32_t N = cfg->fft_size;
     if (!(N == 128 || N == 256 || N == 512 || N == 1024 || N == 2048) || cfg->N_rb_dl * 12 >= N) return MI_LTE_ERR_INVALID_ARG;
-    if (pc->preamble_format > 3 || pc->zczc > (pc->hs_flag ? 14u : 15u) || pc->root_seq_idx > 837) {
-        ctx->err = "PRACH: preamble formats 0-3 only (format 4 is TDD), zczc / root index out of range";
+    const uint32_t   fmt = pc->preamble_format;
+    const PrachGeom  pg  = prach_geom(fmt);
+    const uint32_t   N_ZC = pg.n_zc;
+    if (fmt > 4 || (fmt == 4 ? pc->zczc > 6u : pc->zczc > (pc->hs_flag ? 14u : 15u)) || pc->root_seq_idx >= pg.n_root_idx) {
+        ctx->err = "PRACH: preamble format, zeroCorrelationZoneConfig or root index out of range";
         return MI_LTE_ERR_UNSUPPORTED;
     }
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -243,13 +250,13 @@ static int prach_plan_common(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const mi
     auto  guard = on_fail([&] { (void)hipStreamSynchronize(ctx->stream); mi_lte_prach_plan_destroy(nullptr, pl); });
     pl->cfg  = *cfg;
     const uint32_t sc = 2048 / N; // 30.72 MHz / fs
-    static const uint32_t cp_of_fmt[4] = {3168, 21024, 6240, 21024};
-    pl->T_fft = 24576 / sc;                          // liblte_phy.cc:2417-2448
-    pl->T_cp  = cp_of_fmt[pc->preamble_format] / sc;
-    const uint32_t k_0 = pc->freq_offset * 12 - cfg->N_rb_dl * 12 / 2 + N / 2, K = 12; // :3416-3418 (uint32 arithmetic)
-    pl->start = 7 + K * k_0 + K / 2;                 // :3426
+    pl->n_zc = N_ZC; pl->phases = pg.phases;
+    pl->T_fft = pg.T_fft_30 / sc;                    // liblte_phy.cc:2430-2470
+    pl->T_cp  = pg.T_cp_30 / sc;
+    const uint32_t k_0 = pc->freq_offset * 12 - cfg->N_rb_dl * 12 / 2 + N / 2, K = pg.K; // :3416-3418 (uint32 arithmetic); K = 15000 / delta_f_RA
+    pl->start = pg.phi + K * k_0 + K / 2;            // :3426
     {   // N_cs and v_max of the FIRST root, as liblte_phy_detect_prach uses them for every root (:3336-3413)
-        const PrachSets ps = prach_sets(LTE_PRACH_ROOT_ORDER[pc->root_seq_idx], pc->zczc, pc->hs_flag != 0);
+        const PrachSets ps = prach_sets(prach_root(fmt, pc->root_seq_idx), pc->zczc, pc->hs_flag != 0, fmt);
         if (!ps.ok) {
             ctx->err = "PRACH: zeroCorrelationZoneConfig / root outside what the reference can process (restricted set: config 15, or a root without a cyclic shift)";
             return MI_LTE_ERR_UNSUPPORTED;
@@ -257,14 +264,15 @@ static int prach_plan_common(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const mi
         pl->N_cs = ps.N_cs; pl->v_max = ps.v_max;
     }
     std::vector<float2> xu;
-    if (h_xu_fft_re && h_xu_fft_im) { // the caller's spectra (what liblte_phy_ul_init left in LIBLTE_PHY_STRUCT)
+    if (h_xu_fft_re && h_xu_fft_im) { // the caller's spectra (what liblte_phy_ul_init left in LIBLTE_PHY_STRUCT: rows of 839, the first N_zc used)
         pl->n_roots = n_roots_given;
         xu.resize((size_t)pl->n_roots * N_ZC);
-        for (size_t k = 0; k < xu.size(); k++) xu[k] = make_float2(h_xu_fft_re[k], h_xu_fft_im[k]);
+        for (uint32_t r = 0; r < pl->n_roots; r++)
+            for (uint32_t k = 0; k < N_ZC; k++) xu[(size_t)r * N_ZC + k] = make_float2(h_xu_fft_re[(size_t)r * N_ZC_MAX + k], h_xu_fft_im[(size_t)r * N_ZC_MAX + k]);
     } else { // roots needed for 64 preambles (prach_preamble_seq_gen, :7130-7290), their forward DFTs in double
         uint32_t n_gen = 0;
-        while (n_gen < 64 && pc->root_seq_idx + pl->n_roots < 838) {
-            const PrachSets pr = prach_sets(LTE_PRACH_ROOT_ORDER[pc->root_seq_idx + pl->n_roots], pc->zczc, pc->hs_flag != 0);
+        while (n_gen < 64 && pc->root_seq_idx + pl->n_roots < pg.n_root_idx) {
+            const PrachSets pr = prach_sets(prach_root(fmt, pc->root_seq_idx + pl->n_roots), pc->zczc, pc->hs_flag != 0, fmt);
             if (!pr.ok) {
                 ctx->err = "PRACH: a root of the 64-preamble set has no cyclic shift in the restricted set (the reference divides by zero there)";
                 return MI_LTE_ERR_UNSUPPORTED;
@@ -276,7 +284,7 @@ static int prach_plan_common(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const mi
         std::vector<double> xr(N_ZC), xi(N_ZC), cs(N_ZC), sn(N_ZC);
         for (uint32_t t = 0; t < N_ZC; t++) { cs[t] = std::cos(-2.0 * M_PI * t / N_ZC); sn[t] = std::sin(-2.0 * M_PI * t / N_ZC); }
         for (uint32_t r = 0; r < pl->n_roots; r++) {
-            const uint32_t u = LTE_PRACH_ROOT_ORDER[pc->root_seq_idx + r];
+            const uint32_t u = prach_root(fmt, pc->root_seq_idx + r);
             for (uint32_t i = 0; i < N_ZC; i++) { // x_u(n), rounded to float like the reference's arrays (:7167-7172)
                 const double ph = -M_PI * u * i * (i + 1) / N_ZC;
                 xr[i] = (double)(float)std::cos(ph);
@@ -297,7 +305,7 @@ static int prach_plan_common(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const mi
     }
     MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_xu_fft, sizeof(float2) * xu.size()));
     MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_xu_fft, xu.data(), sizeof(float2) * xu.size(), hipMemcpyHostToDevice, ctx->stream));
-    int rcb = prach_bluestein_tables(ctx, &pl->d_chirp, &pl->d_bspec, &pl->d_tw);
+    int rcb = prach_bluestein_tables(ctx, N_ZC, &pl->d_chirp, &pl->d_bspec, &pl->d_tw);
     if (rcb != MI_LTE_OK) return rcb;
     MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
     guard.armed = false;
@@ -332,8 +340,9 @@ int mi_lte_prach_detect_run(mi_lte_ctx *ctx, mi_lte_prach_plan *pl, const void *
 {
     if (!ctx || !pl || !d_samples_a || !d_occ_start || n_occ == 0 || !h_N_det_pre || !h_det_pre || !h_det_ta) return MI_LTE_ERR_INVALID_ARG;
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const uint32_t N_ZC = pl->n_zc, P = pl->phases;
     const size_t xh_bytes = sizeof(float2) * (size_t)n_occ * N_ZC, co_bytes = sizeof(CorrOut) * (size_t)n_occ * pl->n_roots;
-    const size_t f_off = (xh_bytes + co_bytes + 64 + 255) & ~(size_t)255, f_bytes = sizeof(float2) * (size_t)n_occ * pl->T_fft; // 24 x N2 per occasion
+    const size_t f_off = (xh_bytes + co_bytes + 64 + 255) & ~(size_t)255, f_bytes = sizeof(float2) * (size_t)n_occ * pl->T_fft; // P x N2 per occasion
     int rc = mi_ctx_reserve_scratch(ctx, f_off + f_bytes);
     if (rc != MI_LTE_OK) return rc;
     float2  *d_xh = (float2 *)ctx->scratch;
@@ -343,19 +352,19 @@ int mi_lte_prach_detect_run(mi_lte_ctx *ctx, mi_lte_prach_plan *pl, const void *
         h_co = nullptr;
         d_co = (CorrOut *)((char *)ctx->scratch + ((xh_bytes + 63) & ~(size_t)63));
     }
-    const uint32_t N2 = pl->T_fft / 24;
-    if (pl->T_fft != 24 * N2 || (N2 & (N2 - 1)) || N2 < 2 || N2 > 1024) { ctx->err = "PRACH: T_fft must be 24 x a power of two"; return MI_LTE_ERR_UNSUPPORTED; }
+    const uint32_t N2 = pl->T_fft / P;
+    if (pl->T_fft != P * N2 || (N2 & (N2 - 1)) || N2 < 2 || N2 > 1024) { ctx->err = "PRACH: T_fft must be 24 (format 4: 4) x a power of two"; return MI_LTE_ERR_UNSUPPORTED; }
     float2 *d_F = (float2 *)((char *)ctx->scratch + f_off);
     if (pl->cfg.sample_format == MI_LTE_IQ_I8) {
         Samp<int8_t> s{(const int8_t *)d_samples_a};
-        MI_LAUNCH(ctx, "k_prach_fft", (k_prach_fft<int8_t>), dim3(24, n_occ), dim3(256), 2 * N2 * sizeof(float2), s, d_occ_start, pl->T_cp, N2, d_F);
+        MI_LAUNCH(ctx, "k_prach_fft", (k_prach_fft<int8_t>), dim3(P, n_occ), dim3(256), 2 * N2 * sizeof(float2), s, d_occ_start, pl->T_cp, N2, P, d_F);
     } else {
         if (!d_samples_b) return MI_LTE_ERR_INVALID_ARG;
         Samp<float> s{(const float *)d_samples_a, (const float *)d_samples_b};
-        MI_LAUNCH(ctx, "k_prach_fft", (k_prach_fft<float>), dim3(24, n_occ), dim3(256), 2 * N2 * sizeof(float2), s, d_occ_start, pl->T_cp, N2, d_F);
+        MI_LAUNCH(ctx, "k_prach_fft", (k_prach_fft<float>), dim3(P, n_occ), dim3(256), 2 * N2 * sizeof(float2), s, d_occ_start, pl->T_cp, N2, P, d_F);
     }
-    MI_LAUNCH(ctx, "k_prach_bins", k_prach_bins, dim3((N_ZC + 255) / 256, n_occ), dim3(256), 0, (const float2 *)d_F, N2, pl->T_fft, pl->start, d_xh);
-    MI_LAUNCH(ctx, "k_prach_corr", k_prach_corr, dim3(pl->n_roots, n_occ), dim3(256), sizeof(float2) * (2 * BL + BL / 2), d_xh, pl->d_xu_fft, pl->n_roots,
+    MI_LAUNCH(ctx, "k_prach_bins", k_prach_bins, dim3((N_ZC + 255) / 256, n_occ), dim3(256), 0, (const float2 *)d_F, N2, P, pl->T_fft, pl->start, N_ZC, d_xh);
+    MI_LAUNCH(ctx, "k_prach_corr", k_prach_corr, dim3(pl->n_roots, n_occ), dim3(256), sizeof(float2) * (2 * BL + BL / 2), d_xh, pl->d_xu_fft, pl->n_roots, N_ZC,
               (const float2 *)pl->d_chirp, (const float2 *)pl->d_bspec, (const float2 *)pl->d_tw, d_co);
     MI_HIP_CHECK(ctx, hipGetLastError());
     std::vector<CorrOut> co_copy;

@@ -11,11 +11,28 @@ struct PrachSets { uint32_t N_cs, v_max, N_RA_shift, d_start; bool ok; };
 // the reference reads past PRACH_5_7_2_2_RS, liblte_phy.cc:295, :7190) or a restricted-set root without a single cyclic shift
 // (N_RA_shift = 0: its C_v expression divides by it, :7258).  The callers refuse those instead of dividing by zero.
 
-inline PrachSets prach_sets(uint32_t u, uint32_t zczc, bool hs)
+// Preamble format 4 (the TDD UpPTS preamble): N_zc = 139, 138 root indices (36.211 table 5.7.2-5: u = 1, 138, 2, 137, ... -- the
+// reference's PRACH_5_7_2_5, liblte_phy.cc:373), N_cs from table 5.7.2-3 whatever the high-speed flag says (:7189-7192, :3347-3350); the
+// restricted-set arithmetic below is then run with 139 in the place of 839, as the reference does when the flag is set.
+struct PrachGeom { uint32_t n_zc, T_fft_30, T_cp_30, K, phi, phases, reps, n_root_idx; }; // T_* at 30.72 MHz; phases: T_fft = phases x a power of two
+inline PrachGeom prach_geom(uint32_t fmt)
 {
-    constexpr uint32_t N_ZC = 839;
-    if (zczc > 15 || (hs && zczc > 14)) return PrachSets{0, 0, 0, 0, false};
-    PrachSets s{hs ? (uint32_t)LTE_PRACH_NCS_RESTRICTED[zczc] : (uint32_t)LTE_PRACH_NCS_UNRESTRICTED[zczc], 0, 0, 0, true};
+    static const uint32_t cp_of_fmt[4] = {3168, 21024, 6240, 21024}; // liblte_phy.cc:2430-2470
+    if (fmt >= 4) return PrachGeom{139, 4096, 448, 2, 2, 4, 1, 138};
+    return PrachGeom{839, 24576, cp_of_fmt[fmt], 12, 7, 24, fmt >= 2 ? 2u : 1u, 838};
+}
+inline uint32_t prach_root(uint32_t fmt, uint32_t idx) // physical root u of logical index idx (idx < prach_geom(fmt).n_root_idx)
+{
+    if (fmt >= 4) return (idx & 1u) ? 139u - (idx + 1u) / 2u : idx / 2u + 1u;
+    return LTE_PRACH_ROOT_ORDER[idx];
+}
+
+inline PrachSets prach_sets(uint32_t u, uint32_t zczc, bool hs, uint32_t fmt = 0)
+{
+    const uint32_t N_ZC = fmt >= 4 ? 139u : 839u;
+    static const uint16_t ncs_fmt4[7] = {2, 4, 6, 8, 10, 12, 15}; // 36.211 table 5.7.2-3
+    if (fmt >= 4 ? zczc > 6 : (zczc > 15 || (hs && zczc > 14))) return PrachSets{0, 0, 0, 0, false};
+    PrachSets s{fmt >= 4 ? (uint32_t)ncs_fmt4[zczc] : hs ? (uint32_t)LTE_PRACH_NCS_RESTRICTED[zczc] : (uint32_t)LTE_PRACH_NCS_UNRESTRICTED[zczc], 0, 0, 0, true};
     if (hs) {
         uint32_t p;
         for (p = 1; p <= N_ZC; p++)

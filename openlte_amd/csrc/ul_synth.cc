@@ -156,25 +156,27 @@ int mi_lte_synth_ul_units_i8(const mi_lte_dl_cfg *cfg, const mi_lte_ul_cfg *ul, 
 // sub-carriers (1.25 kHz spacing) phi + K(k0 + 1/2) + k in natural order; cyclic prefix + sequence (twice for formats 2, 3)
 size_t mi_lte_synth_prach_len(uint32_t fft_size, uint32_t preamble_format)
 {
-    static const uint32_t cp_of_fmt[4] = {3168, 21024, 6240, 21024};
-    const uint32_t sc = 2048 / (fft_size ? fft_size : 2048), f = preamble_format & 3;
-    return ((cp_of_fmt[f] + 24576 * (f >= 2 ? 2 : 1) + 1024) / sc + 15) / 16 * 16;
+    const PrachGeom pg = prach_geom(preamble_format > 4 ? 0 : preamble_format);
+    const uint32_t  sc = 2048 / (fft_size ? fft_size : 2048);
+    return ((pg.T_cp_30 + pg.T_fft_30 * pg.reps + 1024) / sc + 15) / 16 * 16;
 }
 
 int mi_lte_synth_prach_i8(const mi_lte_dl_cfg *cfg, const mi_lte_prach_cfg *pc, uint32_t n_occ, const uint32_t *h_preamble_idx,
                           const uint32_t *h_delay, const mi_lte_synth_channel *chan, int8_t *h_iq)
 {
-    if (!cfg || !pc || !h_preamble_idx || !h_delay || !chan || !h_iq || pc->preamble_format > 3 || pc->root_seq_idx > 837) return MI_LTE_ERR_INVALID_ARG;
+    if (!cfg || !pc || !h_preamble_idx || !h_delay || !chan || !h_iq || pc->preamble_format > 4 || pc->root_seq_idx >= prach_geom(pc->preamble_format).n_root_idx)
+        return MI_LTE_ERR_INVALID_ARG;
     // the six PRACH resource blocks lie on the grid (k_0 below is unsigned arithmetic), and a delay keeps the preamble inside the occasion
     if (!synth::valid_grid(cfg->fft_size, cfg->N_rb_dl) || pc->freq_offset + 6 > cfg->N_rb_dl) return MI_LTE_ERR_INVALID_ARG;
     for (uint32_t o = 0; o < n_occ; o++)
         if (h_delay[o] > 1024 / (2048 / cfg->fft_size)) return MI_LTE_ERR_INVALID_ARG;
-    constexpr uint32_t N_ZC = 839;
-    static const uint32_t cp_of_fmt[4] = {3168, 21024, 6240, 21024};
-    const uint32_t N = cfg->fft_size, sc = 2048 / N, T = 24576 / sc, T_cp = cp_of_fmt[pc->preamble_format] / sc;
-    const uint32_t reps = pc->preamble_format >= 2 ? 2 : 1;
-    const size_t   len = mi_lte_synth_prach_len(N, pc->preamble_format);
-    const uint32_t k_0 = pc->freq_offset * 12 - cfg->N_rb_dl * 12 / 2 + N / 2, start = 7 + 12 * k_0 + 6;
+    const uint32_t  fmt = pc->preamble_format;
+    const PrachGeom pg = prach_geom(fmt); // format 4: N_zc = 139 on 7.5 kHz sub-carriers, 4 096 samples, one repetition (36.211 table 5.7.1-1)
+    const uint32_t N_ZC = pg.n_zc;
+    const uint32_t N = cfg->fft_size, sc = 2048 / N, T = pg.T_fft_30 / sc, T_cp = pg.T_cp_30 / sc;
+    const uint32_t reps = pg.reps;
+    const size_t   len = mi_lte_synth_prach_len(N, fmt);
+    const uint32_t k_0 = pc->freq_offset * 12 - cfg->N_rb_dl * 12 / 2 + N / 2, start = pg.phi + pg.K * k_0 + pg.K / 2;
     synth::Rng rng(chan->seed);
     std::vector<double> xr(N_ZC), xi(N_ZC), Xr(N_ZC), Xi(N_ZC), cz(N_ZC), sz(N_ZC), ct(T), st(T), sr(T), si(T), t_re(len), t_im(len);
     for (uint32_t t = 0; t < N_ZC; t++) { cz[t] = std::cos(-2.0 * M_PI * t / N_ZC); sz[t] = std::sin(-2.0 * M_PI * t / N_ZC); }
@@ -183,9 +185,9 @@ int mi_lte_synth_prach_i8(const mi_lte_dl_cfg *cfg, const mi_lte_prach_cfg *pc, 
         // which root and cyclic shift carry preamble index p (prach_preamble_seq_gen's enumeration, liblte_phy.cc:7155-7290)
         uint32_t p = h_preamble_idx[o] % 64, r = 0, u = 0, C_v = 0;
         for (;; r++) {
-            if (pc->root_seq_idx + r > 837) return MI_LTE_ERR_INVALID_ARG;
-            u = LTE_PRACH_ROOT_ORDER[pc->root_seq_idx + r];
-            const PrachSets ps = prach_sets(u, pc->zczc, pc->hs_flag != 0);
+            if (pc->root_seq_idx + r >= pg.n_root_idx) return MI_LTE_ERR_INVALID_ARG;
+            u = prach_root(fmt, pc->root_seq_idx + r);
+            const PrachSets ps = prach_sets(u, pc->zczc, pc->hs_flag != 0, fmt);
             if (!ps.ok) return MI_LTE_ERR_UNSUPPORTED; // (the reference's own generator divides by zero / reads past its table there)
             if (p <= ps.v_max) {
                 C_v = pc->hs_flag ? ps.d_start * (p / ps.N_RA_shift) + (p % ps.N_RA_shift) * ps.N_cs : p * ps.N_cs;

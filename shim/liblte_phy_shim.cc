@@ -220,8 +220,8 @@ LIBLTE_ERROR_ENUM liblte_phy_detect_prach(LIBLTE_PHY_STRUCT *phy_struct, float *
                                           uint32 *N_det_pre, uint32 *det_pre, uint32 *det_ta)
 {
     if (phy_struct == NULL || samps_re == NULL || samps_im == NULL || N_det_pre == NULL || det_pre == NULL || det_ta == NULL ||
-        !phy_struct->ul_init || phy_struct->prach_preamble_format > 3)
-        return LIBLTE_ERROR_INVALID_INPUTS; // (format 4 is TDD-only; this shim covers the FDD formats)
+        !phy_struct->ul_init || phy_struct->prach_preamble_format > 4)
+        return LIBLTE_ERROR_INVALID_INPUTS;
     MI_LOCKED_CTX(phy_struct, LIBLTE_ERROR_INVALID_INPUTS);
     mi_lte_prach_cfg pc = {phy_struct->prach_root_seq_idx, phy_struct->prach_preamble_format, phy_struct->prach_zczc,
                            phy_struct->prach_hs_flag ? 1u : 0u, freq_offset};

@@ -181,6 +181,9 @@ PRACH_CASES = {
     "1p4MHz_format1": (128, 6, 50, 1, 11, 0, 0, [3, 44], [0, 9], 10.0),
     "5MHz_format2": (512, 25, 700, 2, 4, 0, 3, [0, 21, 63], [0, 30, 11], 5.0),
     "3MHz_format3": (256, 15, 123, 3, 8, 0, 1, [7, 50], [2, 15], 8.0),
+    # format 4, the short TDD preamble: N_zc = 139 on 7.5 kHz sub-carriers, its own root and N_cs tables (liblte_phy.cc:2462-2468, :3339-3350)
+    "5MHz_format4": (512, 25, 20, 4, 3, 0, 2, [0, 21, 63, 40], [0, 10, 3, 7], 8.0),
+    "1p4MHz_format4": (128, 6, 101, 4, 6, 0, 0, [5, 62], [1, 0], 10.0),
 }
 
 

@@ -309,19 +309,21 @@ def test_pbch_fuzz_against_the_compiled_reference(ctx, ref):
 
 
 def test_prach_fuzz_against_the_compiled_reference(ctx, ref):
-    """PRACH: random bandwidths, preamble formats 0-3, root sequences, zero-correlation-zone configurations, unrestricted
+    """PRACH: random bandwidths, preamble formats 0-4, root sequences, zero-correlation-zone configurations, unrestricted
     and restricted sets, frequency offsets, preambles, delays and SNRs through the library's transmitter, liblte_phy_detect_prach as the
     checker: detected or not, preamble index and timing advance identical for every occasion."""
     import test_prach_gpu as tpr
     import openlte_amd as m
     rng = np.random.default_rng(839 + 100000 * SEED)
     n_occ = n_det = n_cfg = skipped = 0
-    fmts = {0: 0, 1: 0, 2: 0, 3: 0}
+    fmts = {0: 0, 1: 0, 2: 0, 3: 0, 4: 0}
     bws = [(128, 6), (256, 15), (512, 25), (1024, 50), (2048, 100)]
-    while n_cfg < 80:
+    while n_cfg < 96:
         fft, nrb = bws[int(rng.integers(len(bws) if n_cfg % 7 == 0 else 3))]  # (the two wide ones cost the reference a second per occasion: a few)
         fmt, root, zczc = int(rng.integers(4)), int(rng.integers(838)), int(rng.integers(16))
         hs = int(rng.random() < 0.2)
+        if n_cfg >= 80:  # the last sixteen: format 4 (139-point sequences, 138 roots, its own N_cs table; the flag still switches the set arithmetic)
+            fmt, root, zczc = 4, int(rng.integers(138)), int(rng.integers(7))
         fo = int(rng.integers(0, nrb - 6 + 1))
         pre = [int(x) for x in rng.integers(0, 64, 4)]
         dly = [int(x) for x in rng.integers(0, 24 * fft // 128, 4)]
@@ -342,7 +344,7 @@ def test_prach_fuzz_against_the_compiled_reference(ctx, ref):
         n_occ += len(pre)
         n_det += int((want[:, 0] > 0).sum())
         fmts[fmt] += 1
-    assert 0 < n_det < n_occ and skipped < 80
+    assert 0 < n_det < n_occ and skipped < 80 and fmts[4] == 16
     REPORT["prach"] = {"configurations": n_cfg, "occasions": n_occ, "detected": n_det, "refused_configurations": skipped, "configurations_by_format": fmts}
     write_report()
 

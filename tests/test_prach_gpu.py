@@ -32,7 +32,7 @@ def test_prach_vs_golden_from_reference(ctx, name):
     assert (got == z[name + "_det"]).all(), (got.tolist(), z[name + "_det"].tolist())
 
 
-@pytest.mark.parametrize("name", ["1p4MHz_8roots", "3MHz_restricted", "1p4MHz_format1", "5MHz_format2", "3MHz_format3"])
+@pytest.mark.parametrize("name", ["1p4MHz_8roots", "3MHz_restricted", "1p4MHz_format1", "5MHz_format2", "3MHz_format3", "5MHz_format4", "1p4MHz_format4"])
 def test_prach_vs_reference_live(ctx, ref, name):
     case = td.prach_case(name, seed=17)
     want, roots = td.ref_prach_detect(ref, case)

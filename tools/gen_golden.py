@@ -166,6 +166,8 @@ def main():
     assert R is not None, "oracle/_ref is not built (needs /root/reference)"
     if len(sys.argv) > 1 and sys.argv[1] == "two_port":  # (the other fixtures are left as they are)
         return two_port_units(R)
+    if len(sys.argv) > 1 and sys.argv[1] == "prach":
+        return prach_vectors(R)
     phy = R.ref_phy_new(4, 17, 1, 100)
     turbo_ref_vectors(R, P, phy)
     R.ref_phy_free(phy)

@@ -442,12 +442,13 @@ int mi_ctx_fft_twiddles(mi_lte_ctx *ctx)
         tw[k] = make_float2((float)cos(a), (float)sin(a));
     }
     auto fill = [&](uint32_t off, uint32_t Ns, uint32_t R) { // entry k: tw[k * 4096 / (Ns * R)] and its 2nd / 4th power, R / 2 (at least 1) slots wide
-        const uint32_t st = N / (Ns * R), wd = R == 8 ? 4 : R == 4 ? 2 : 1;
+        const uint32_t st = N / (Ns * R), wd = R >= 8 ? 4 : R == 4 ? 2 : 1;
         for (uint32_t k = 0; k < Ns; k++) {
             float2 *e = &tw[N + off + (size_t)k * wd];
             e[0] = tw[k * st];
             if (R >= 4) e[1] = tw[2 * k * st];
-            if (R == 8) e[2] = tw[4 * k * st];
+            if (R >= 8) e[2] = tw[4 * k * st];
+            if (R == 16) e[3] = tw[8 * k * st];
         }
     };
     fill(MI_FFT_TWC_P2, 8, 8);
@@ -456,6 +457,8 @@ int mi_ctx_fft_twiddles(mi_lte_ctx *ctx)
     fill(MI_FFT_TWC_L1024, 512, 2);
     fill(MI_FFT_TWC_L256, 64, 4);
     fill(MI_FFT_TWC_L128, 64, 2);
+    fill(MI_FFT_TWC_X2, 8, 16);
+    fill(MI_FFT_TWC_X3, 128, 16);
     MI_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_fft_tw, sizeof(float2) * tw.size()));
     ctx->owned.push_back(ctx->d_fft_tw);
     MI_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_fft_tw, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice, ctx->stream));

@@ -29,7 +29,8 @@ struct RmTables { // per-K rank tables of the fused turbo rate un-matching (see 
 // (sub-transform length 8, radix 8: 4 slots per butterfly), third pass (64, radix 8; also the last pass of the 512-point transform),
 // and the last pass of the 2048 / 1024 / 256 / 128-point transforms (radix 4: 2 slots, radix 2: 1 slot)
 enum : uint32_t { MI_FFT_TWC_P2 = 0, MI_FFT_TWC_P3 = 32, MI_FFT_TWC_L2048 = 288, MI_FFT_TWC_L1024 = 1312, MI_FFT_TWC_L256 = 1824, MI_FFT_TWC_L128 = 1952,
-                  MI_FFT_TWC_TOTAL = 2016 };
+                  MI_FFT_TWC_X2 = 2016, MI_FFT_TWC_X3 = 2048, // the radix-16 passes of the 2048-point transform: w, w^2, w^4, w^8 per butterfly
+                  MI_FFT_TWC_TOTAL = 2560 };
 
 constexpr uint32_t MI_CRC_TAB_BIAS = 8;
 

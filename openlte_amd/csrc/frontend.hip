@@ -9,6 +9,8 @@
 //   k_dl_ce   : one workgroup per (unit, antenna port): pilot LS estimates, the reference's
 //               sequential phase unwrap, frequency interpolation, then time interpolation and
 //               mag/phase -> re/im for all 14 symbols (liblte_phy.cc:5959-6194).
+#include <type_traits>
+
 #include "ctx.hpp"
 #include "phy_dev.hpp"
 
@@ -41,6 +43,15 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b)
     v2f t, r;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(to_v(a)), "v"(to_v(b)));                                              // (a.x b.x, a.x b.y)
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(to_v(a)), "v"(to_v(b)), "v"(t)); // (-a.y b.y, a.y b.x) + t
+    return to_f2(r);
+}
+// the same product with a wave-uniform b (the fixed twiddles inside a butterfly): b may sit in a scalar register pair, so that nobody
+// has to move a constant into vector registers first (a packed instruction issues in 4 cycles with or without a scalar operand)
+__device__ __forceinline__ float2 cmul_u(float2 a, float2 b)
+{
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(to_v(a)), "s"(to_v(b)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(to_v(a)), "s"(to_v(b)), "v"(t));
     return to_f2(r);
 }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
@@ -275,10 +286,140 @@ __global__ __launch_bounds__(256) void k_dl_fft(SampleSrc<T> src, const uint64_t
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The 2048-point transform as 8 x 16 x 16 (round 4): 128 threads per symbol, two LDS exchanges and three barriers instead of three and
+// five (k_dl_fft above keeps every other length).  The 8 x 8 x 8 x 4 plan wrote 48 KB and read 48 KB of LDS per symbol and the LDS
+// pipe was as busy as the vector ALU; this one moves 32 + 32 KB, multiplies by 15/16 + 15/16 of its points' twiddles
+// instead of 7/8 + 7/8 + 3/4, and its last pass knows at compile time that outputs 5..10 of every radix-16 butterfly are guard band
+// (bins 640..1407: LTE uses at most 600 sub-carriers per side), so six of its sixteen stores do not exist.
+__device__ __forceinline__ void dft16(float2 *v)
+{
+    // 16 = 4 x 4: X[b + 4c] = sum_a W4^(ac) W16^(ab) sum_d W4^(bd) x[a + 4d]
+    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+    float2 t[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        t[a][0] = v[a]; t[a][1] = v[a + 4]; t[a][2] = v[a + 8]; t[a][3] = v[a + 12];
+        dft4(t[a]);
+    }
+    t[1][1] = cmul_u(t[1][1], make_float2(c1, -s1));  // W16^1
+    t[1][2] = cmul_u(t[1][2], make_float2(h, -h));    // W16^2
+    t[1][3] = cmul_u(t[1][3], make_float2(s1, -c1));  // W16^3
+    t[2][1] = cmul_u(t[2][1], make_float2(h, -h));    // W16^2
+    t[2][2] = mul_mi(t[2][2]);                      // W16^4
+    t[2][3] = cmul_u(t[2][3], make_float2(-h, -h));   // W16^6
+    t[3][1] = cmul_u(t[3][1], make_float2(s1, -c1));  // W16^3
+    t[3][2] = cmul_u(t[3][2], make_float2(-h, -h));   // W16^6
+    t[3][3] = cmul_u(t[3][3], make_float2(-c1, s1));  // W16^9
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        float2 u[4] = {t[0][b], t[1][b], t[2][b], t[3][b]};
+        dft4(u);
+#pragma unroll
+        for (int c = 0; c < 4; c++) v[b + 4 * c] = u[c];
+    }
+}
+
+// w^1 .. w^15 of butterfly k: w, w^2, w^4, w^8 side by side in the pass's table (32 bytes per butterfly), the rest as products
+__device__ __forceinline__ void twiddles16(const float2 *__restrict__ tc, uint32_t k, float2 (&w)[16])
+{
+    const char  *tb = reinterpret_cast<const char *>(tc);
+    const float4 a = *reinterpret_cast<const float4 *>(tb + (size_t)(k * 32u)), b = *reinterpret_cast<const float4 *>(tb + 16 + (size_t)(k * 32u));
+    w[1] = make_float2(a.x, a.y); w[2] = make_float2(a.z, a.w); w[4] = make_float2(b.x, b.y); w[8] = make_float2(b.z, b.w);
+    w[3] = cmul(w[1], w[2]);
+    w[5] = cmul(w[4], w[1]); w[6] = cmul(w[4], w[2]); w[7] = cmul(w[4], w[3]);
+#pragma unroll
+    for (int r = 1; r < 8; r++) w[8 + r] = cmul(w[8], w[r]);
+}
+
+// LDS padding of the 2048-point buffer: two float2 slots (16 bytes, so that 16-byte accesses stay aligned) after every 32
+__device__ __forceinline__ uint32_t pad2(uint32_t i) { return i + ((i >> 5) << 1); }
+
+template <typename T, bool RAW>
+__global__ __launch_bounds__(128) void k_dl_fft2k(SampleSrc<T> src, const uint64_t *__restrict__ unit_start, DlGeom g,
+                                                  const float2 *__restrict__ tw, float *__restrict__ subframes)
+{
+    __shared__ __attribute__((aligned(16))) float2 buf[2048 + 2 * 64];
+    constexpr uint32_t N = 2048;
+    const uint32_t unit = blockIdx.y, j = threadIdx.x, half = g.half, sym = blockIdx.x;
+    const size_t   ustart = unit_start[unit];
+    const uint32_t so = sym % 7;
+    const size_t   f = RAW ? ustart : ustart + (size_t)(sym / 7) * g.n_slot + (size_t)(N + g.cpe) * so + (so ? g.cp0 - g.cpe : 0) + (so == 0 ? g.cp0 : g.cpe) - 1;
+    typedef typename SampleSrc<T>::raw_t raw_t;
+    raw_t cur[16];
+#pragma unroll
+    for (int m = 0; m < 16; m++) cur[m] = src.raw_at(f, j, m * 128);
+    const float2 *__restrict__ twc = tw + 4096;
+    // pass 1, radix 8, no twiddles: butterflies j and j + 128 (inputs x[b + 256 r]) straight from the fetched samples, outputs at 8 b + r
+    auto pass1 = [&](auto ul) {
+#pragma unroll
+        for (int hb = 0; hb < 2; hb++) {
+            float2 v[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const float2 x = SampleSrc<T>::cvt(cur[hb + 2 * r]);
+                v[r] = decltype(ul)::value ? cmul(x, tw[j + 128 * (hb + 2 * r)]) : x; // (uplink: the half-sub-carrier rotation, as in k_dl_fft)
+            }
+            dft8(v);
+            const uint32_t b = j + 128 * hb; // pad2(8 b + r) = 8 b + r + 2 (b >> 2)
+            float4 *dst = reinterpret_cast<float4 *>(&buf[8 * b + 2 * (b >> 2)]);
+#pragma unroll
+            for (int r = 0; r < 4; r++) dst[r] = make_float4(v[2 * r].x, v[2 * r].y, v[2 * r + 1].x, v[2 * r + 1].y);
+        }
+    };
+    if (g.ul) pass1(std::true_type{});
+    else      pass1(std::false_type{});
+    __syncthreads();
+    const uint32_t rd = j + 2 * (j >> 5); // pad2(j + 128 r) = rd + 136 r
+    {   // pass 2, radix 16 over sub-transforms of length 8, in place
+        float2 v[16], w[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = buf[rd + 136 * r];
+        __syncthreads();
+        const uint32_t k = j & 7;
+        twiddles16(twc + MI_FFT_TWC_X2, k, w);
+#pragma unroll
+        for (int r = 1; r < 16; r++) v[r] = cmul(v[r], w[r]);
+        dft16(v);
+        const uint32_t wr = 136 * (j >> 3) + k; // output 128 (j >> 3) + k + 8 r: pad2 adds 2 (4 (j >> 3) + (r >> 2))
+#pragma unroll
+        for (int r = 0; r < 16; r++) buf[wr + 8 * r + 2 * (r >> 2)] = v[r];
+    }
+    __syncthreads();
+    {   // pass 3, radix 16 over sub-transforms of length 128: butterfly j, bins j + 128 r
+        float2 v[16], w[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = buf[rd + 136 * r];
+        twiddles16(twc + MI_FFT_TWC_X3, j, w);
+#pragma unroll
+        for (int r = 1; r < 16; r++) v[r] = cmul(v[r], w[r]);
+        dft16(v);
+        float         *row_re = subframes + (size_t)unit * g.sf_stride + (size_t)sym * N_SC_MAX;
+        float         *row_im = row_re + (RAW ? N_SC_MAX : 16 * N_SC_MAX);
+        const uint32_t dc = g.ul ? 0u : 1u;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            if (r >= 5 && r <= 10) continue; // bins 640 .. 1407: guard band whatever the bandwidth (half <= 600)
+            const uint32_t o = j + 128 * r;
+            const bool     pos = o >= dc && o < half + dc, neg = o >= N - half;
+            const uint32_t b   = 4u * (pos ? half + o - dc : o - (N - half));
+            if (pos || neg) {
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(row_re) + (size_t)b) = v[r].x;
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(row_im) + (size_t)b) = v[r].y;
+            }
+        }
+    }
+}
+
 // one instantiation per LTE transform length
+#ifdef MI_FFT_OLD2K // (tools/ab: the 8 x 8 x 8 x 4 plan for the 2048-point transform, to time the two against each other)
+#define MI_FFT2K_LAUNCH(name, T, RAW, grid, ...) MI_LAUNCH(ctx, name, (k_dl_fft<T, RAW, 2048>), grid, dim3(256), lds_fft, __VA_ARGS__)
+#else
+#define MI_FFT2K_LAUNCH(name, T, RAW, grid, ...) MI_LAUNCH(ctx, name, (k_dl_fft2k<T, RAW>), grid, dim3(128), 0, __VA_ARGS__)
+#endif
 #define FFT_LAUNCH(name, T, RAW, grid, ...)                                                                                        \
     switch (g.N) {                                                                                                                 \
-    case 2048: MI_LAUNCH(ctx, name, (k_dl_fft<T, RAW, 2048>), grid, dim3(256), lds_fft, __VA_ARGS__); break;                       \
+    case 2048: MI_FFT2K_LAUNCH(name, T, RAW, grid, __VA_ARGS__); break;                                                            \
     case 1024: MI_LAUNCH(ctx, name, (k_dl_fft<T, RAW, 1024>), grid, dim3(256), lds_fft, __VA_ARGS__); break;                       \
     case 512:  MI_LAUNCH(ctx, name, (k_dl_fft<T, RAW, 512>), grid, dim3(256), lds_fft, __VA_ARGS__); break;                        \
     case 256:  MI_LAUNCH(ctx, name, (k_dl_fft<T, RAW, 256>), grid, dim3(256), lds_fft, __VA_ARGS__); break;                        \

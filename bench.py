@@ -1057,6 +1057,14 @@ def turbo_leg(ctx, decoder, n_cb, steps):
 _COPY_RATE = {}
 
 
+def traffic_of(tab, label):
+    """PMC bytes per launch of the kernel behind a launch label.  rocprof sees the kernel's own name: the 2048-point transform of all
+    three front ends (labels k_dl_fft / k_ul_fft / k_sync_fft) is k_dl_fft2k since round 4, k_dl_fft in older tables."""
+    if label in ("k_dl_fft", "k_ul_fft", "k_sync_fft"):
+        return tab.get("k_dl_fft2k", tab.get("k_dl_fft"))
+    return tab.get(label)
+
+
 def measured_copy_rate(ctx):
     """GB/s of the library's copy kernel on ctx's device (1 GiB, 10 launches; once per process and device)."""
     key = id(ctx)
@@ -1082,7 +1090,7 @@ def roofline_of(wl, prof, steps):
     achieved = st_bytes / lps / (avg_ms * 1e-3) / 1e9
     traffic = None
     try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % wl.name)))["bytes_per_launch"].get({"k_ul_fft": "k_dl_fft"}.get(dom, dom))
+        traffic = traffic_of(json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % wl.name)))["bytes_per_launch"], dom)
     except Exception:
         pass
     st_ms = sum(prof[k][1] for k in acc["stages"][stage_of[dom]][1] if k in prof) / steps if dom in stage_of else tot_ms / steps
@@ -1334,7 +1342,7 @@ def main():
                 ent["own_io_bytes_per_step"] = own
                 ent["own_io_GBps"] = round(own / (ms / steps * 1e-3) / 1e9, 1)
                 ent["own_io_frac_of_peak"] = round(own / (ms / steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-            tr = traffic_tab.get({"k_ul_fft": "k_dl_fft"}.get(k, k))  # rocprof sees the kernel's own name
+            tr = traffic_of(traffic_tab, k)
             if tr:
                 ent["hbm_traffic_bytes_per_step"] = int(tr * (nl // steps))
                 ent["hbm_traffic_GBps"] = round(tr * (nl // steps) / (ms / steps * 1e-3) / 1e9, 1)
@@ -1364,7 +1372,7 @@ def main():
             st_ms = sum(prof[k][1] for k in acc["stages"][stage_of[dom]][1] if k in prof) / steps
             dom_alone = {"kernel": dom, "stage_bytes_over_this_kernels_time_GBps": round(achieved, 2), "avg_launch_ms": round(avg_ms, 4)}
             achieved = st_bytes / (st_ms * 1e-3) / 1e9
-        tr = traffic_tab.get({"k_ul_fft": "k_dl_fft"}.get(dom, dom))
+        tr = traffic_of(traffic_tab, dom)
         whole = wl.alg_bytes_per_unit * units / elapsed / 1e9
         out = {
             "metric": wl.metric, "value": round(value, 3), "unit": wl.unit, "n_gpus": world, "steps": steps,

@@ -24,8 +24,8 @@ template <typename V> __global__ __launch_bounds__(256) void k_read(const V *p, 
 {
     const V *b = p + (size_t)blockIdx.x * n_per_block;
     uint32_t acc = 0;
-    for (size_t i = threadIdx.x; i < n_per_block; i += 256) { V v = b[i]; acc ^= *reinterpret_cast<const uint32_t *>(&v) & 0xffffu; }
-    if (acc == 0x12345u) *sink = acc;
+    for (size_t i = threadIdx.x; i < n_per_block; i += 256) { V v = b[i]; uint16_t lo; __builtin_memcpy(&lo, &v, 2); acc ^= lo; }
+    if (acc == 0x1234u) *sink = acc; // (a value the XOR of 16-bit words can take: the loads stay)
 }
 // like k_dl_fft2k's store phase: 128 threads, ten 4-byte stores per thread and plane at a 512-byte stride, two planes
 __global__ __launch_bounds__(128) void k_rows4(float *p, size_t row_floats)

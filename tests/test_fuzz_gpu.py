@@ -16,8 +16,9 @@ control-region size) group into ONE front-end launch and ONE PDSCH plan run:
 Uplink (>= 3000 allocations): random cells / hopping modes / cyclic shifts / widths / positions through the library's uplink
 transmitter, liblte_phy_get_ul_subframe + liblte_phy_pusch_channel_decode as the checker.  The uplink has no exact stage: the
 SC-FDMA demodulator AND the transform pre-decoding DFT in front of the de-mapper are floating point in an order FFTW does not
-specify, so a soft bit whose equalised value lies within float rounding of zero may come out with the other sign.  Measured: 2 of
-3.9 M soft bits in the first 1278 allocations.  The test therefore COUNTS differing soft bits (<= 1e-5 of all, reported), and
+specify, so a soft bit whose equalised value lies within float rounding of zero may come out with the other sign, and a QPSK symbol whose
+127 * sd lies within that rounding of an integer with a magnitude one unit off (both of its bits).  Measured: 2 of 3.9 M soft bits in the
+first 1278 allocations; round 4's soaks: 14 of 158 M, ten sign flips and two magnitude steps (four bits).  The test therefore COUNTS differing soft bits (<= 1e-5 of all, reported), and
 demands identical verdicts and transport blocks for every allocation whose soft bits are identical.
 
 A report of what was run (counts per dimension, verdict mix, worst tolerances) goes to gpurun_out/fuzz_report.json."""
@@ -207,7 +208,8 @@ def test_uplink_fuzz_against_the_compiled_reference(ctx, ref):
                 # what the differing values are: (position, library, reference).  A QPSK symbol's two soft bits carry ONE magnitude,
                 # (int8)(127 * sd), and the quadrant's signs (liblte_phy.cc:9543-9570), so a lone differing bit with the same magnitude on both
                 # sides is a quadrant decision on a component that the two SC-FDMA transforms' rounding put on opposite sides of zero; a
-                # magnitude step would show in both bits of the symbol
+                # magnitude step -- 127 * sd within the transforms' rounding of an integer -- shows in both bits of the symbol, one unit, signs kept
+                # (two symbols in 63 M soft bits over eight seeds of round 4's soak, profiles/r04_fuzz_soak/)
                 for i in np.nonzero(soft[k] != wsoft)[0][:8]:
                     soft_values.append([str(key), int(i), int(soft[k][i]), int(wsoft[i]), int(soft[k][i ^ 1]), int(wsoft[i ^ 1])])
                 if (st[k] == 0) != (rc == 0):
@@ -223,14 +225,24 @@ def test_uplink_fuzz_against_the_compiled_reference(ctx, ref):
                             allocations_with_differing_soft_bits=[list(map(str, x)) for x in soft_diff[:50]],
                             verdicts_differing_in_those=verdict_diff_after_soft_diff,
                             differing_soft_bits_position_library_reference_and_the_symbols_other_bit=soft_values[:50],
-                            differing_soft_bits_are_sign_flips_of_equal_magnitude=bool(all(v[2] == -v[3] and v[4] == v[5] for v in soft_values)))
+                            differing_soft_bits_that_are_sign_flips_of_equal_magnitude=sum(sign_flip(v) for v in soft_values),
+                            differing_soft_bits_that_are_one_step_of_the_symbols_magnitude=sum(magnitude_step(v) for v in soft_values))
     write_report()
-    # every differing soft bit is the sign of a component at zero: same magnitude, opposite sign, the symbol's other bit untouched
-    assert all(v[2] == -v[3] and v[4] == v[5] for v in soft_values), soft_values[:10]
+    # every differing soft bit is either the sign of a component at zero (same magnitude, opposite sign, the symbol's other bit untouched)
+    # or one quantisation step of its symbol's magnitude (both bits of the symbol move by one unit, signs kept)
+    assert all(sign_flip(v) or magnitude_step(v) for v in soft_values), soft_values[:10]
     assert n_alloc >= 2500
     assert not bad, bad[:10]
     assert n_soft_diff <= 1e-5 * n_soft and len(soft_diff) <= 0.005 * n_alloc, (n_soft_diff, n_soft, soft_diff[:10])
     assert n_ok >= 0.4 * n_alloc
+
+
+def sign_flip(v):  # v = [allocation, position, library, reference, library's other bit of the symbol, reference's]
+    return v[2] == -v[3] and v[4] == v[5]
+
+
+def magnitude_step(v):
+    return abs(v[2] - v[3]) == 1 and abs(v[4] - v[5]) == 1 and abs(v[2]) == abs(v[4]) and abs(v[3]) == abs(v[5]) and v[2] * v[3] > 0 and v[4] * v[5] > 0
 
 
 def test_control_region_fuzz_against_the_compiled_reference(ctx, ref):

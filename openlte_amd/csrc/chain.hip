@@ -650,15 +650,47 @@ int mi_lte_pdsch_decode_run(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, const float 
             pl->bcjr_soft_cap = soft; pl->bcjr_bits_cap = bits;
         }
     }
-    for (auto &gr : pl->groups) {
+    auto run_group = [&](const mi_lte_pdsch_plan::Group &gr) -> int {
         if (bcjr)
-            rc = mi_turbo_bcjr_group(ctx, gr.K, gr.n_cb, pl->d_allocs, pl->d_cb_alloc + gr.cb_base, pl->d_e, pl->d_e_off, pl->d_e_len, d_out_bits,
-                                     pl->out_stride, d_status, false, pl->d_bcjr_soft, pl->d_bcjr_bits, pl->n_iter, pl->qpp_spec, pl->packed != 0, gr.e_max,
-                                     pl->decoder == MI_LTE_TURBO_BCJR_BLOCK, pl->decoder == MI_LTE_TURBO_BCJR_EARLY);
-        else
-            rc = mi_turbo_ref_group(ctx, gr.K, gr.n_cb, pl->d_allocs, pl->d_cb_alloc + gr.cb_base, pl->d_e, pl->d_e_off, pl->d_e_len,
-                                    d_out_bits, pl->out_stride, d_status, gr.e_max, false, pl->packed != 0);
+            return mi_turbo_bcjr_group(ctx, gr.K, gr.n_cb, pl->d_allocs, pl->d_cb_alloc + gr.cb_base, pl->d_e, pl->d_e_off, pl->d_e_len, d_out_bits,
+                                       pl->out_stride, d_status, false, pl->d_bcjr_soft, pl->d_bcjr_bits, pl->n_iter, pl->qpp_spec, pl->packed != 0, gr.e_max,
+                                       pl->decoder == MI_LTE_TURBO_BCJR_BLOCK, pl->decoder == MI_LTE_TURBO_BCJR_EARLY);
+        return mi_turbo_ref_group(ctx, gr.K, gr.n_cb, pl->d_allocs, pl->d_cb_alloc + gr.cb_base, pl->d_e, pl->d_e_off, pl->d_e_len, d_out_bits,
+                                  pl->out_stride, d_status, gr.e_max, false, pl->packed != 0);
+    };
+    // The block-size groups of a decode are independent of each other (own code blocks, own status words and output rows).  In a batch the
+    // groups differ widely in size -- W4: 65 536 blocks of K = 1088 next to 524 288 of K = 3264 -- and the small ones do not fill the device
+    // (the K = 1088 trellis walk is one or two wavefronts per SIMD: 0.46 ms of latency for 3 % of the work), so with the reference-faithful
+    // decoder every group but the largest runs on a side stream, in a scratch block of its own, next to the largest one.
+    size_t big = 0, total_cb = 0;
+    for (size_t i = 0; i < pl->groups.size(); i++) {
+        total_cb += pl->groups[i].n_cb;
+        if ((size_t)pl->groups[i].n_cb * pl->groups[i].K > (size_t)pl->groups[big].n_cb * pl->groups[big].K) big = i;
+    }
+    static const bool side_ok = [] { const char *e = getenv("MI_LTE_GROUP_STREAMS"); return !e || atoi(e) != 0; }(); // (0: one stream, for A/B runs)
+    if (!bcjr && side_ok && pl->groups.size() >= 2 && total_cb >= 16384) {
+        if (!ctx->side_stream) {
+            MI_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+            MI_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+            MI_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        }
+        MI_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream)); // the soft bits are there, the previous run's side work was joined
+        MI_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+        auto swap_side = [&] { std::swap(ctx->stream, ctx->side_stream); std::swap(ctx->scratch, ctx->side_scratch); std::swap(ctx->scratch_bytes, ctx->side_scratch_bytes); };
+        swap_side(); // the launch helpers take the stream and the scratch from the context
+        for (size_t i = 0; i < pl->groups.size() && rc == MI_LTE_OK; i++)
+            if (i != big) rc = run_group(pl->groups[i]);
+        swap_side();
         if (rc != MI_LTE_OK) return rc;
+        MI_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream));
+        rc = run_group(pl->groups[big]);
+        MI_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        if (rc != MI_LTE_OK) return rc;
+    } else {
+        for (auto &gr : pl->groups) {
+            rc = run_group(gr);
+            if (rc != MI_LTE_OK) return rc;
+        }
     }
     ctx->last_kernels = bcjr ? "k_pdsch_demod:1,k_rm_to_i8,k_bcjr_*,k_crc_finish per block size"
                                                          : "k_pdsch_demod:1,k_turbo_prep,k_turbo_siso,k_turbo_perm,k_turbo_vote per block size";

@@ -63,6 +63,11 @@ void mi_lte_ctx_destroy(mi_lte_ctx *ctx)
     for (void *p : ctx->owned) (void)hipFree(p);
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
+    if (ctx->side_scratch) (void)hipFree(ctx->side_scratch);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->h_small) (void)hipHostFree(ctx->h_small);
     if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

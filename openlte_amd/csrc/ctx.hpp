@@ -44,6 +44,11 @@ struct mi_lte_ctx {
     double             copy_rates[3] = {0, 0, 0}; // mi_lte_device_copy_rate's three kernel shapes, GB/s of the last call
     void              *scratch       = nullptr;
     size_t             scratch_bytes = 0;
+    // a second stream with its own scratch: the smaller block-size groups of a PDSCH decode run there next to the largest one (chain.hip)
+    hipStream_t        side_stream = nullptr;
+    hipEvent_t         ev_fork = nullptr, ev_join = nullptr;
+    void              *side_scratch       = nullptr;
+    size_t             side_scratch_bytes = 0;
     uint32_t          *h_flag = nullptr, *d_flag = nullptr; // the completion word of the per-call waits (mi_stream_wait_polling) and its sequence number
     uint32_t           flag_seq = 0;
     uint32_t *bcjr_early_buf = nullptr; size_t bcjr_early_cap = 0; // ctx-owned copy of the change words (the scratch they are counted in is shared with every other kernel family)

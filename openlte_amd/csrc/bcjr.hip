@@ -183,6 +183,73 @@ __global__ __launch_bounds__(384) void k_bcjr_prep(const int8_t *__restrict__ so
     }
 }
 
+// The same for EIGHT neighbouring code blocks per workgroup (lanes 8 m .. 8 m + 7 of one tile): a granule is 16 bytes per lane, so a
+// workgroup that owns one code block writes 16 bytes into each 128-byte line of its four arrays and seven other workgroups the rest --
+// the PMC pass of round 4 counted 3.3 GB written for 1.6 GB of granules (profiles/r04_turbo_bcjr_summary.md).  Here a wavefront's
+// store covers 8 units x 8 blocks = eight whole lines.  Item = (unit u, block b), b fastest.
+__global__ __launch_bounds__(512) void k_bcjr_prep8(const int8_t *__restrict__ soft, uint32_t K, uint32_t n_cb,
+                                                    const uint16_t *__restrict__ pi, BcjrBufs B)
+{
+    extern __shared__ __attribute__((aligned(16))) int8_t sm[]; // S1[8][Kp]
+    const uint32_t grp = (blockIdx.x & 7u) * (xcd_chunk(n_cb) >> 3) + (blockIdx.x >> 3), cb0 = grp * 8, tile = cb0 >> 6, lane0 = cb0 & 63;
+    const uint32_t Kp = kpad64(K), n_units = Kp >> 4;
+    if (cb0 >= n_cb) return;
+    for (uint32_t item = threadIdx.x; item < 8 * n_units; item += blockDim.x) {
+        const uint32_t b = item & 7u, u = item >> 3, cb = cb0 + b;
+        if (cb >= n_cb) continue;
+        const int8_t *d = soft + (size_t)cb * 3 * (K + 4);
+        const size_t  o8 = g8(tile, Kp, lane0 + b, u);
+        const int     nv = min(16, max(0, (int)K - 16 * (int)u));
+        uint32_t s1[4] = {0, 0, 0, 0}, p1[4] = {0, 0, 0, 0}, p2[4] = {0, 0, 0, 0};
+        if (nv > 0) {
+            const uint32_t *g = reinterpret_cast<const uint32_t *>(d + (size_t)u * 48); // 48 (24) bytes, 4-byte aligned
+#pragma unroll
+            for (int w = 0; w < 12; w++) {
+                const uint32_t x = (w < 6 || nv > 8) ? g[w] : 0u;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int e = 4 * w + k, i = e / 3, st = e - 3 * i; // element e = 3*i + stream
+                    const int v = max(sb(x, k), -127);                  // clip to +-127
+                    const uint32_t byte = ((uint32_t)v & 0xFFu) << (8 * (i & 3));
+                    if (st == 0) s1[i >> 2] |= byte; else if (st == 1) p1[i >> 2] |= byte; else p2[i >> 2] |= byte;
+                }
+            }
+        }
+        *reinterpret_cast<uint4 *>(B.S1 + o8) = make_uint4(s1[0], s1[1], s1[2], s1[3]);
+        *reinterpret_cast<uint4 *>(B.P1 + o8) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+        *reinterpret_cast<uint4 *>(B.P2 + o8) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+        *reinterpret_cast<uint4 *>(sm + b * Kp + 16 * u) = make_uint4(s1[0], s1[1], s1[2], s1[3]);
+    }
+    if (threadIdx.x < 8 && cb0 + threadIdx.x < n_cb) { // termination bits: x[3r + stream] = d_stream[K + r]  (36.212 5.1.3.2.2)
+        const uint32_t cb = cb0 + threadIdx.x;
+        const int8_t  *x = soft + (size_t)cb * 3 * (K + 4) + 3 * (size_t)K;
+        int8_t        *t = B.tail + ((size_t)cb << 4);
+        auto c = [&](int i) { return (int8_t)max((int)x[i], -127); };
+        t[0] = c(0); t[1] = c(2); t[2] = c(4);   t[3] = c(1); t[4] = c(3);  t[5] = c(5);  // decoder 1: x_K x_K+1 x_K+2 | z_K z_K+1 z_K+2
+        t[6] = c(6); t[7] = c(8); t[8] = c(10);  t[9] = c(7); t[10] = c(9); t[11] = c(11); // decoder 2
+    }
+    __syncthreads();
+    for (uint32_t item = threadIdx.x; item < 8 * n_units; item += blockDim.x) { // S2[i] = S1[pi[i]]
+        const uint32_t b = item & 7u, u = item >> 3, cb = cb0 + b;
+        if (cb >= n_cb) continue;
+        const int nv = min(16, max(0, (int)K - 16 * (int)u));
+        uint32_t  s2[4] = {0, 0, 0, 0};
+        if (nv > 0) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(pi + 16 * (size_t)u);
+            const uint4  lo = p[0], hi = (nv > 8) ? p[1] : make_uint4(0, 0, 0, 0);
+            const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            const int8_t  *s1b = sm + b * Kp;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t idx = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                const uint32_t v   = (uint8_t)s1b[idx];
+                s2[k >> 2] |= ((k < nv) ? v : 0u) << (8 * (k & 3));
+            }
+        }
+        *reinterpret_cast<uint4 *>(B.S2 + g8(tile, Kp, lane0 + b, u)) = make_uint4(s2[0], s2[1], s2[2], s2[3]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // one half-iteration of one constituent decoder over a segment of a tile pair
 struct HalfArgs {
@@ -370,31 +437,54 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BCJR_WPE, 8)
 // hard decisions in natural order: c[j] = HD[inv[j]] (decoder 2's last a-posteriori sign), a hole of the de-interleaver falls back on
 // the sign of S1[j] (its a-priori value is the zero a hole reads).  One workgroup per (tile pair, 64 bit positions): 64 rows of 128
 // bytes come in coalesced, go through LDS, and leave as 64 contiguous bytes per code block.
+// (Until late in round 4 the 64 rows were fetched one after the other -- a scalar load of the row number, a byte load per thread, a wait,
+// an LDS store, 64 times: 0.62 ms for 65 536 blocks of K = 6144, a tenth of an early-termination decode.  Now the row numbers are read once,
+// the rows come in as sixteen independent 4-byte loads per thread, and a code block's 64 bytes leave as four 16-byte stores.)
 __global__ __launch_bounds__(128) void k_bcjr_final(const uint8_t *__restrict__ HD, const uint32_t *__restrict__ inv_row, const int8_t *__restrict__ S1,
                                                     uint32_t K, uint32_t n_cb, uint32_t n_tiles, uint8_t *__restrict__ c_bits)
 {
-    __shared__ uint8_t sm[64][132];
+    __shared__ uint32_t sm32[64][33]; // 64 rows of 128 bytes (+ 4: the column reads below then fall on different banks)
+    __shared__ uint32_t rows[64];
+    __shared__ uint64_t hole_rows;
     const uint32_t pair = blockIdx.x, j0 = blockIdx.y * 64, Kp = kpad64(K), th = threadIdx.x;
     const uint8_t *base = HD + ex_row(pair, Kp, 0);
-    for (uint32_t jj = 0; jj < 64; jj++) {
-        const uint32_t j = j0 + jj, r = j < K ? inv_row[j] : Kp;
-        uint8_t        v = base[(size_t)r * 128 + th]; // byte th = lane * 2 + h
-        if (r == Kp && j < K) { // a hole: the sign of the systematic value of that code block at position j
-            const uint32_t tile = min(2 * pair + (th & 1u), n_tiles - 1), lane = th >> 1;
-            v = (uint8_t)(S1[g8(tile, Kp, lane, j >> 4) + (j & 15u)] < 0 ? 1 : 0);
-        }
-        sm[jj][th] = v;
+    if (th < 64) {
+        const uint32_t j = j0 + th, r = j < K ? inv_row[j] : Kp;
+        rows[th] = r;
+        const uint64_t holes = __ballot(r == Kp && j < K);
+        if (th == 0) hole_rows = holes;
     }
     __syncthreads();
+    {
+        const uint32_t sub = th >> 5, dw = th & 31u; // four rows per pass, 32 dwords each
+        uint32_t v[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = *reinterpret_cast<const uint32_t *>(base + (size_t)rows[4 * i + sub] * 128 + 4 * dw);
+#pragma unroll
+        for (int i = 0; i < 16; i++) sm32[4 * i + sub][dw] = v[i];
+    }
+    __syncthreads();
+    uint8_t (*sm)[132] = reinterpret_cast<uint8_t (*)[132]>(sm32);
+    for (uint64_t hm = hole_rows; hm; hm &= hm - 1) { // a hole: the sign of the systematic value of that code block at position j (rare: the wrapped sizes)
+        const uint32_t jj = (uint32_t)__builtin_ctzll(hm), jh = j0 + jj;
+        const uint32_t tile = min(2 * pair + (th & 1u), n_tiles - 1), lane = th >> 1; // byte th = lane * 2 + h
+        sm[jj][th] = (uint8_t)(S1[g8(tile, Kp, lane, jh >> 4) + (jh & 15u)] < 0 ? 1 : 0);
+    }
+    if (hole_rows) __syncthreads(); // uniform
     const uint32_t h = th >> 6, lane = th & 63u, tile = 2 * pair + h, cb = tile * 64 + lane; // thread -> code block
     if (tile >= n_tiles || cb >= n_cb) return;
     uint8_t *o = c_bits + (size_t)cb * K + j0;
-    const uint32_t n = min(64u, K > j0 ? K - j0 : 0u); // a multiple of 8
-    for (uint32_t q = 0; q < n; q += 8) {
-        uint32_t w0 = 0, w1 = 0;
+    const uint32_t n = min(64u, K > j0 ? K - j0 : 0u), col = lane * 2 + h; // n: a multiple of 8
 #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) { w0 |= (uint32_t)sm[q + k][lane * 2 + h] << (8 * k); w1 |= (uint32_t)sm[q + 4 + k][lane * 2 + h] << (8 * k); }
-        *reinterpret_cast<uint2 *>(o + q) = make_uint2(w0, w1); // 8-byte aligned: K and j0 are multiples of 8
+    for (uint32_t q = 0; q < 64; q += 16) {
+        if (q >= n) break; // uniform
+        uint32_t w[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++)
+            w[k] = (uint32_t)sm[q + 4 * k][col] | (uint32_t)sm[q + 4 * k + 1][col] << 8 | (uint32_t)sm[q + 4 * k + 2][col] << 16 | (uint32_t)sm[q + 4 * k + 3][col] << 24;
+        // (cb * K + j0 + q is a multiple of 8, of 16 only for even cb * K / 8: two 8-byte stores)
+        *reinterpret_cast<uint2 *>(o + q) = make_uint2(w[0], w[1]);
+        if (q + 8 < n) *reinterpret_cast<uint2 *>(o + q + 8) = make_uint2(w[2], w[3]);
     }
 }
 
@@ -725,7 +815,10 @@ int mi_turbo_bcjr_batch(mi_lte_ctx *ctx, const int8_t *d_soft, uint32_t K, uint3
     BcjrBufs B{mb.S1, mb.P1, mb.S2, mb.P2, mb.tail};
     const size_t   Kp = kpad64(K);
     const uint32_t cb_threads = (uint32_t)(((Kp >> 4) + 63) & ~(size_t)63);
-    MI_LAUNCH(ctx, "k_bcjr_prep", k_bcjr_prep, dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), Kp, d_soft, K, n_cb, tb.d_pi, B);
+    static const bool one_per_wg = [] { const char *e = getenv("MI_LTE_BCJR_PREP1"); return e && atoi(e) != 0; }(); // (A/B: the one-block-per-workgroup kernel)
+    if (one_per_wg || 8 * Kp > 64 * 1024) MI_LAUNCH(ctx, "k_bcjr_prep", k_bcjr_prep, dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), Kp, d_soft, K, n_cb, tb.d_pi, B);
+    else MI_LAUNCH(ctx, "k_bcjr_prep", k_bcjr_prep8, dim3(xcd_chunk(n_cb)), dim3(512), 8 * Kp, d_soft, K, n_cb, tb.d_pi, B);
+    (void)cb_threads;
     return mi_turbo_bcjr_iterate(ctx, K, n_cb, n_iter, qpp_spec, d_c_bits, early);
 }
 

@@ -267,6 +267,7 @@ struct HalfArgs {
     // in iteration `it` against iteration it - 1 (always set for it = 0); a pair whose iteration it - 1 changed nothing has stopped
     uint32_t       *chg;
     uint32_t        it;
+    uint32_t        noap_rt;    // EARLY instantiations: 1 = this launch is the decode's first half-iteration (see NOAP)
 };
 
 #ifndef BCJR_WPE
@@ -275,7 +276,12 @@ struct HalfArgs {
 // LAST: the decoder-2 half of the final iteration (writes the hard decisions).  EARLY: hard-decision-aided stopping per tile pair -- every
 // decoder-2 half writes the decisions and notes whether any differs from the previous iteration's; both halves of a later iteration
 // return at once for a pair that has stopped (its extrinsics, boundary states and decisions stay what its last iteration left).
-template <bool LAST, bool EARLY = false>
+// NOAP: the first half-iteration of a decode -- the a-priori values are zero and are not read (nor is their array filled any more: 400 MB
+// per 65 536-block decode).  A template parameter for the fixed-iteration kernels: as a run-time test the uniform branch around the eight
+// row reads of a window cost their other fifteen half-iterations 3 %.  The EARLY instantiations take the run-time flag (HalfArgs::noap_rt)
+// instead -- with them the same branch came out 5 % FASTER per half-iteration than the branch-free code (W3 early termination, same box:
+// 6.53 ms with the template form, 6.19-6.32 with the flag; profiles/r04_variants_bcjr_first_half.txt), so each mode keeps what measured best.
+template <bool LAST, bool EARLY = false, bool NOAP = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BCJR_WPE, 8))) void k_bcjr_half(HalfArgs g)
 {
     if (EARLY && g.it >= 2 && g.chg[(size_t)(g.it - 1) * g.n_pairs + blockIdx.x] == 0) return; // the pair stopped (uniform)
@@ -309,9 +315,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BCJR_WPE, 8)
         typedef __attribute__((address_space(4))) const uint32_t const_u32_t;
         const_u32_t *rp = reinterpret_cast<const_u32_t *>(reinterpret_cast<uintptr_t>(g.row + t0));
         const uint32_t rw[8] = {rp[0], rp[1], rp[2], rp[3], rp[4], rp[5], rp[6], rp[7]};
-        uint32_t aq[8];
+        uint32_t aq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (!(NOAP || (EARLY && g.noap_rt))) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) aq[r] = ld_sbase<uint16_t>(arow + (size_t)rw[r] * 128, lane2); // (q of tile 2p) | (q of tile 2p+1) << 8
+            for (int r = 0; r < 8; r++) aq[r] = ld_sbase<uint16_t>(arow + (size_t)rw[r] * 128, lane2); // (q of tile 2p) | (q of tile 2p+1) << 8
+        }
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const v2s la = as_v2s(__builtin_amdgcn_perm(0u, aq[r], 0x010C000Cu)) >> 7; // 2q per half: the byte in the half's upper byte, arithmetic shift by 7
@@ -735,9 +743,13 @@ int mi_turbo_bcjr_begin(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, MiBcjrBufs *
     out->S1 = (int8_t *)l.base; out->P1 = out->S1 + l.a8; out->S2 = out->P1 + l.a8; out->P2 = out->S2 + l.a8;
     out->tail = (int8_t *)(l.base + 4 * l.a8);
     out->aux  = (void *)(((uintptr_t)(l.bnd0 + 4 * l.per_buf) + 255) & ~(uintptr_t)255);
-    MI_HIP_CHECK(ctx, hipMemsetAsync(l.bnd0, 0, 4 * l.per_buf * sizeof(uint4), ctx->stream));
-    MI_HIP_CHECK(ctx, hipMemsetAsync(l.E2, 0, l.ex, ctx->stream)); // the a-priori values of the first half-iteration (and E2's zero rows)
-    MI_HIP_CHECK(ctx, hipMemset2DAsync(l.E1 + l.Kp * 128, (l.Kp + 1) * 128, 0, 128, l.n_pairs, ctx->stream)); // E1's zero row of every pair
+    // boundary states "uniform" before the first iteration: the buffer iteration 0 reads (index 0) of either decoder; iteration 0 writes the other one
+    MI_HIP_CHECK(ctx, hipMemsetAsync(l.bnd0, 0, l.per_buf * sizeof(uint4), ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemsetAsync(l.bnd0 + 2 * l.per_buf, 0, l.per_buf * sizeof(uint4), ctx->stream));
+    // the zero row of every pair in E1 and E2 (what a hole of the interleaver and the padding past K read); the a-priori values of the
+    // first half-iteration are zero too, but that launch does not read them (k_bcjr_half's NOAP) -- filling E2 for it was 400 MB per decode
+    MI_HIP_CHECK(ctx, hipMemset2DAsync(l.E1 + l.Kp * 128, (l.Kp + 1) * 128, 0, 128, l.n_pairs, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemset2DAsync(l.E2 + l.Kp * 128, (l.Kp + 1) * 128, 0, 128, l.n_pairs, ctx->stream));
     if (n_cb % 64 || (l.n_tiles & 1)) MI_HIP_CHECK(ctx, hipMemsetAsync(l.base, 0, 4 * l.a8 + l.n_tiles * 64 * 16, ctx->stream)); // lanes past the batch end stay defined
     return MI_LTE_OK;
 }
@@ -772,7 +784,7 @@ int mi_turbo_bcjr_iterate(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, uint32_t n
             h.tail = B.tail; h.tail_off = dec ? 6u : 0u;
             h.a_rd = d + rd * per_buf; h.b_rd = d + rd * per_buf + 8 * one; h.a_wr = d + wr * per_buf; h.b_wr = d + wr * per_buf + 8 * one;
             h.K = K; h.n_cb = n_cb; h.n_tiles = (uint32_t)n_tiles; h.n_pairs = (uint32_t)n_pairs;
-            h.chg = l.chg; h.it = it;
+            h.chg = l.chg; h.it = it; h.noap_rt = (early && it == 0 && dec == 0) ? 1u : 0u;
             return h;
         };
         if (early) {
@@ -780,7 +792,8 @@ int mi_turbo_bcjr_iterate(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, uint32_t n
             MI_LAUNCH(ctx, "k_bcjr_half", (k_bcjr_half<true, true>), dim3(n_pairs, n_seg), dim3(64), 0, args(1));
             continue;
         }
-        MI_LAUNCH(ctx, "k_bcjr_half", k_bcjr_half<false>, dim3(n_pairs, n_seg), dim3(64), 0, args(0));
+        if (it == 0) MI_LAUNCH(ctx, "k_bcjr_half", (k_bcjr_half<false, false, true>), dim3(n_pairs, n_seg), dim3(64), 0, args(0)); // (its a-priori array is not filled)
+        else         MI_LAUNCH(ctx, "k_bcjr_half", k_bcjr_half<false>, dim3(n_pairs, n_seg), dim3(64), 0, args(0));
         if (!last) MI_LAUNCH(ctx, "k_bcjr_half", k_bcjr_half<false>, dim3(n_pairs, n_seg), dim3(64), 0, args(1));
         else       MI_LAUNCH(ctx, "k_bcjr_half", k_bcjr_half<true>, dim3(n_pairs, n_seg), dim3(64), 0, args(1));
     }

@@ -1687,7 +1687,12 @@ __global__ __launch_bounds__(384) void k_rm_bcjr_prep(SrcRateUnmatch src, uint32
 __global__ __launch_bounds__(256) void k_crc_finish(const uint8_t *__restrict__ c_bits, uint32_t K, uint32_t n_cb, GroupDesc g)
 {
     __shared__ uint32_t red[4];
-    const uint32_t cb = blockIdx.x, alloc = g.cb_alloc[cb], tbs = g.allocs[alloc].tbs, F = K - tbs - 24;
+    // (the block's allocation and size from its descriptor where k_cb_desc has written one: slot -> allocation -> its fields is two
+    // dependent round trips at the start of a workgroup that lives for little more than three)
+    uint32_t alloc, tbs;
+    if (g.desc) { const uint4 d0 = reinterpret_cast<const uint4 *>(g.desc + blockIdx.x)[0], d1 = reinterpret_cast<const uint4 *>(g.desc + blockIdx.x)[1]; alloc = d0.x; tbs = d1.z; }
+    else        { alloc = g.cb_alloc[blockIdx.x]; tbs = g.allocs[alloc].tbs; }
+    const uint32_t cb = blockIdx.x, F = K - tbs - 24;
     const uint8_t *c = c_bits + (size_t)cb * K;
     uint8_t       *o = g.out_bits + (size_t)alloc * g.out_stride;
     uint32_t crc = 0;

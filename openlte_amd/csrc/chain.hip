@@ -661,13 +661,15 @@ int mi_lte_pdsch_decode_run(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, const float 
     // The block-size groups of a decode are independent of each other (own code blocks, own status words and output rows).  In a batch the
     // groups differ widely in size -- W4: 65 536 blocks of K = 1088 next to 524 288 of K = 3264 -- and the small ones do not fill the device
     // (the K = 1088 trellis walk is one or two wavefronts per SIMD: 0.46 ms of latency for 3 % of the work), so with the reference-faithful
-    // decoder every group but the largest runs on a side stream, in a scratch block of its own, next to the largest one.
+    // decoder every group but the largest can run on a side stream, in a scratch block of its own, next to the largest one.
     size_t big = 0, total_cb = 0;
     for (size_t i = 0; i < pl->groups.size(); i++) {
         total_cb += pl->groups[i].n_cb;
         if ((size_t)pl->groups[i].n_cb * pl->groups[i].K > (size_t)pl->groups[big].n_cb * pl->groups[big].K) big = i;
     }
-    static const bool side_ok = [] { const char *e = getenv("MI_LTE_GROUP_STREAMS"); return !e || atoi(e) != 0; }(); // (0: one stream, for A/B runs)
+    // Opt-in (MI_LTE_GROUP_STREAMS=1): worth 1 % of the W4 step (24.77 -> 24.55 ms), and it stretches the launches that overlap -- the
+    // per-launch times the roofline accounting of bench.py and the rocprof summaries are built on stop describing a kernel alone.
+    static const bool side_ok = [] { const char *e = getenv("MI_LTE_GROUP_STREAMS"); return e && atoi(e) != 0; }();
     if (!bcjr && side_ok && pl->groups.size() >= 2 && total_cb >= 16384) {
         if (!ctx->side_stream) {
             MI_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));

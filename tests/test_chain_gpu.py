@@ -723,3 +723,28 @@ def test_tiny_transport_blocks(ctx, port, tbs, mod, nprb):
         plan.close()
         d_sub.free()
     assert n_ok >= 1, tbs  # the 30 dB case decodes
+
+
+def test_block_size_groups_on_a_side_stream_give_the_same_results():
+    """MI_LTE_GROUP_STREAMS=1 (chain.hip: every block-size group of a decode but the largest on a side stream with its own scratch, fork /
+    join by events) is read once per process, so the W4 batch -- 2 048 subframes, 18 432 code blocks in two groups -- runs in two child
+    processes, with and without it: verdicts and transport blocks must hash the same, and most allocations must pass their CRC."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = ("import sys, hashlib, numpy as np; sys.path.insert(0, ROOT); sys.path.insert(0, TESTS); import bench, openlte_amd as m; "
+             "ctx = m.Context(0); wl = bench.ChainWorkload(ctx, 2048, 0); wl.step(); wl.step(); ctx.sync(); "
+             "st = wl.d_status.download(np.int32); bits = wl.d_out.download(np.uint8).reshape(st.size, -1).copy(); "
+             "n = np.where(np.arange(st.size) % 9 < 8, 3240, 1064); bits[np.arange(bits.shape[1])[None, :] >= n[:, None]] = 0; "  # (the rows' tails are never written)
+             "print('RESULT', hashlib.sha256(st.tobytes() + bits.tobytes()).hexdigest(), int((st == 0).sum()), st.size)")
+    child = child.replace("ROOT", repr(root)).replace("TESTS", repr(os.path.join(root, "tests")))
+    out = {}
+    for gs in ("0", "1"):
+        env = dict(os.environ, MI_LTE_GROUP_STREAMS=gs)
+        r = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+        assert r.returncode == 0 and line, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+        out[gs] = line[0].split()[1:]
+    assert out["0"] == out["1"], out
+    assert int(out["1"][1]) > 0.9 * int(out["1"][2]), out

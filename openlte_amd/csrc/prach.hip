@@ -39,28 +39,39 @@ template <> struct Samp<float> {
     __device__ __forceinline__ float2 at(size_t n) const { return make_float2(i[n], q[n]); }
 };
 
-// x_hat[occ][b] = sum_n x[n] exp(-2*pi*i*n*idx_b/T), idx_b = (b + start + T/2) mod T        (liblte_phy.cc:3421-3433)
-// T = 24 * N2 with N2 a power of two (64 ... 1024), so the 839 bins come from the decimation-in-time split n = 24 m + r:
-//     X[k] = sum_{r < 24} exp(-2*pi*i*r*k/T) * F_r[k mod N2],   F_r = N2-point DFT of x[24 m + r]
-// k_prach_fft: one workgroup per (occasion, r), radix-2 Stockham passes in LDS; k_prach_bins: the 24-term combination for the
-// 839 bins that are kept.  (The first version summed every bin directly: 24 576 x 839 complex MACs per occasion, 8.5 us at 20 MHz.)
-template <typename T>
-__global__ __launch_bounds__(256) void k_prach_fft(Samp<T> src, const uint64_t *__restrict__ occ_start, uint32_t T_cp, uint32_t N2, uint32_t P,
-                                                   float2 *__restrict__ F)
+// Forward FFT of N = 2^n points (N <= 2048) in LDS, unnormalised: radix-4 Stockham passes between two buffers (and one radix-2 pass when n is
+// odd), twiddles from tw[k] = exp(-2*pi*i*k/2048), k < 1024 (in LDS: w and w^2 are read, w^3 is their product).  Returns the buffer that
+// holds the result.  (Until late in round 4 these were radix-2 passes -- eleven LDS round trips for 2048 points -- and k_prach_fft
+// evaluated sincospif per butterfly: 40 of its 55 instructions.)
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 *lds_fft_pow2(float2 *in, float2 *out, uint32_t N, const float2 *tw)
 {
-    extern __shared__ float2 lds[]; // two buffers of N2
-    const uint32_t occ = blockIdx.y, r = blockIdx.x;
-    const size_t   first = occ_start[occ] + T_cp;
-    float2 *in = lds, *out = lds + N2;
-    for (uint32_t i = threadIdx.x; i < N2; i += blockDim.x) in[i] = src.at(first + (size_t)P * i + r);
-    __syncthreads();
-    for (uint32_t Ns = 1; Ns < N2; Ns <<= 1) {
-        for (uint32_t j = threadIdx.x; j < N2 / 2; j += blockDim.x) {
+    uint32_t Ns = 1;
+    for (; N / Ns >= 4; Ns <<= 2) {
+        const uint32_t nb = N >> 2, st = 2048u / (Ns << 2);
+        for (uint32_t j = threadIdx.x; j < nb; j += blockDim.x) {
             const uint32_t k = j & (Ns - 1);
-            float ws, wc;
-            sincospif(-(float)k / (float)Ns, &ws, &wc);
-            const float2 u = in[j], x = in[j + N2 / 2];
-            const float2 v = make_float2(x.x * wc - x.y * ws, x.x * ws + x.y * wc);
+            float2 a = in[j], b = in[j + nb], c = in[j + 2 * nb], d = in[j + 3 * nb];
+            if (Ns > 1) {
+                const float2 w1 = tw[k * st], w2 = tw[2 * k * st];
+                b = cmulf(b, w1); c = cmulf(c, w2); d = cmulf(d, cmulf(w1, w2));
+            }
+            const float2 s02 = make_float2(a.x + c.x, a.y + c.y), d02 = make_float2(a.x - c.x, a.y - c.y);
+            const float2 s13 = make_float2(b.x + d.x, b.y + d.y), d13 = make_float2(b.y - d.y, d.x - b.x); // -i (b - d)
+            const uint32_t j0 = ((j - k) << 2) + k;
+            out[j0]          = make_float2(s02.x + s13.x, s02.y + s13.y);
+            out[j0 + Ns]     = make_float2(d02.x + d13.x, d02.y + d13.y);
+            out[j0 + 2 * Ns] = make_float2(s02.x - s13.x, s02.y - s13.y);
+            out[j0 + 3 * Ns] = make_float2(d02.x - d13.x, d02.y - d13.y);
+        }
+        __syncthreads();
+        float2 *t = in; in = out; out = t;
+    }
+    if (Ns < N) { // one radix-2 pass left (Ns = N / 2)
+        const uint32_t st = 2048u / (Ns << 1);
+        for (uint32_t j = threadIdx.x; j < N / 2; j += blockDim.x) {
+            const uint32_t k = j & (Ns - 1);
+            const float2   u = in[j], v = cmulf(in[j + N / 2], tw[k * st]);
             const uint32_t j0 = ((j - k) << 1) + k;
             out[j0]      = make_float2(u.x + v.x, u.y + v.y);
             out[j0 + Ns] = make_float2(u.x - v.x, u.y - v.y);
@@ -68,8 +79,28 @@ __global__ __launch_bounds__(256) void k_prach_fft(Samp<T> src, const uint64_t *
         __syncthreads();
         float2 *t = in; in = out; out = t;
     }
+    return in;
+}
+
+// x_hat[occ][b] = sum_n x[n] exp(-2*pi*i*n*idx_b/T), idx_b = (b + start + T/2) mod T        (liblte_phy.cc:3421-3433)
+// T = 24 * N2 with N2 a power of two (64 ... 1024), so the 839 bins come from the decimation-in-time split n = 24 m + r:
+//     X[k] = sum_{r < 24} exp(-2*pi*i*r*k/T) * F_r[k mod N2],   F_r = N2-point DFT of x[24 m + r]
+// k_prach_fft: one workgroup per (occasion, r), radix-2 Stockham passes in LDS; k_prach_bins: the 24-term combination for the
+// 839 bins that are kept.  (The first version summed every bin directly: 24 576 x 839 complex MACs per occasion, 8.5 us at 20 MHz.)
+template <typename T>
+__global__ __launch_bounds__(256) void k_prach_fft(Samp<T> src, const uint64_t *__restrict__ occ_start, uint32_t T_cp, uint32_t N2, uint32_t P,
+                                                   const float2 *__restrict__ tw_g, float2 *__restrict__ F)
+{
+    extern __shared__ float2 lds[]; // two buffers of N2 | tw[1024]
+    const uint32_t occ = blockIdx.y, r = blockIdx.x;
+    const size_t   first = occ_start[occ] + T_cp;
+    float2 *in = lds, *out = lds + N2, *tw = lds + 2 * N2;
+    for (uint32_t k = threadIdx.x; k < 1024; k += blockDim.x) tw[k] = tw_g[k];
+    for (uint32_t i = threadIdx.x; i < N2; i += blockDim.x) in[i] = src.at(first + (size_t)P * i + r);
+    __syncthreads();
+    const float2 *res = lds_fft_pow2(in, out, N2, tw);
     float2 *dst = F + ((size_t)occ * P + r) * N2;
-    for (uint32_t i = threadIdx.x; i < N2; i += blockDim.x) dst[i] = in[i];
+    for (uint32_t i = threadIdx.x; i < N2; i += blockDim.x) dst[i] = res[i];
 }
 
 __global__ __launch_bounds__(256) void k_prach_bins(const float2 *__restrict__ F, uint32_t N2, uint32_t P, uint32_t T_fft, uint32_t start, uint32_t N_ZC,
@@ -101,25 +132,6 @@ struct CorrOut { float sum, max_val; uint32_t max_off, pad; };
 // (2.8 -> 0.3 ms for 1638 occasions x 8 roots).
 constexpr uint32_t BL = 2048;
 
-// in-place-by-ping-pong radix-2 Stockham FFT of BL points in LDS (forward, unnormalised); tw[k] = exp(-2*pi*i*k/BL), k < BL/2
-__device__ __forceinline__ float2 *lds_fft_2048(float2 *in, float2 *out, const float2 *tw)
-{
-    for (uint32_t Ns = 1; Ns < BL; Ns <<= 1) {
-        for (uint32_t j = threadIdx.x; j < BL / 2; j += blockDim.x) {
-            const uint32_t k = j & (Ns - 1);
-            const float2   w = tw[k * (BL / 2 / Ns)];
-            const float2   u = in[j], x = in[j + BL / 2];
-            const float2   v = make_float2(x.x * w.x - x.y * w.y, x.x * w.y + x.y * w.x);
-            const uint32_t j0 = ((j - k) << 1) + k;
-            out[j0]      = make_float2(u.x + v.x, u.y + v.y);
-            out[j0 + Ns] = make_float2(u.x - v.x, u.y - v.y);
-        }
-        __syncthreads();
-        float2 *t = in; in = out; out = t;
-    }
-    return in; // 11 passes: the result sits in the buffer that was `out` at entry
-}
-
 __global__ __launch_bounds__(256) void k_prach_corr(const float2 *__restrict__ x_hat, const float2 *__restrict__ xu_fft, uint32_t n_roots, uint32_t N_ZC,
                                                     const float2 *__restrict__ chirp, const float2 *__restrict__ bspec, const float2 *__restrict__ tw_g,
                                                     CorrOut *__restrict__ out)
@@ -140,14 +152,14 @@ __global__ __launch_bounds__(256) void k_prach_corr(const float2 *__restrict__ x
         A[j] = v;
     }
     __syncthreads();
-    float2 *X = lds_fft_2048(A, B, tw), *Y = (X == A) ? B : A;
+    float2 *X = lds_fft_pow2(A, B, BL, tw), *Y = (X == A) ? B : A;
     // product with the chirp filter's spectrum, conjugated so that the same forward FFT performs the inverse transform
     for (uint32_t k = threadIdx.x; k < BL; k += blockDim.x) {
         const float2 x = X[k], g = bspec[k];
         Y[k] = make_float2(x.x * g.x - x.y * g.y, -(x.x * g.y + x.y * g.x));
     }
     __syncthreads();
-    float2 *Z = lds_fft_2048(Y, X, tw); // = conj(BL * convolution)
+    float2 *Z = lds_fft_pow2(Y, X, BL, tw); // = conj(BL * convolution)
     float    sum = 0.f, mx = -1.f;
     uint32_t off = 0;
     for (uint32_t m = threadIdx.x; m < N_ZC; m += blockDim.x) { // ascending m per thread: the first maximum wins
@@ -357,11 +369,11 @@ int mi_lte_prach_detect_run(mi_lte_ctx *ctx, mi_lte_prach_plan *pl, const void *
     float2 *d_F = (float2 *)((char *)ctx->scratch + f_off);
     if (pl->cfg.sample_format == MI_LTE_IQ_I8) {
         Samp<int8_t> s{(const int8_t *)d_samples_a};
-        MI_LAUNCH(ctx, "k_prach_fft", (k_prach_fft<int8_t>), dim3(P, n_occ), dim3(256), 2 * N2 * sizeof(float2), s, d_occ_start, pl->T_cp, N2, P, d_F);
+        MI_LAUNCH(ctx, "k_prach_fft", (k_prach_fft<int8_t>), dim3(P, n_occ), dim3(256), (2 * N2 + 1024) * sizeof(float2), s, d_occ_start, pl->T_cp, N2, P, (const float2 *)pl->d_tw, d_F);
     } else {
         if (!d_samples_b) return MI_LTE_ERR_INVALID_ARG;
         Samp<float> s{(const float *)d_samples_a, (const float *)d_samples_b};
-        MI_LAUNCH(ctx, "k_prach_fft", (k_prach_fft<float>), dim3(P, n_occ), dim3(256), 2 * N2 * sizeof(float2), s, d_occ_start, pl->T_cp, N2, P, d_F);
+        MI_LAUNCH(ctx, "k_prach_fft", (k_prach_fft<float>), dim3(P, n_occ), dim3(256), (2 * N2 + 1024) * sizeof(float2), s, d_occ_start, pl->T_cp, N2, P, (const float2 *)pl->d_tw, d_F);
     }
     MI_LAUNCH(ctx, "k_prach_bins", k_prach_bins, dim3((N_ZC + 255) / 256, n_occ), dim3(256), 0, (const float2 *)d_F, N2, P, pl->T_fft, pl->start, N_ZC, d_xh);
     MI_LAUNCH(ctx, "k_prach_corr", k_prach_corr, dim3(pl->n_roots, n_occ), dim3(256), sizeof(float2) * (2 * BL + BL / 2), d_xh, pl->d_xu_fft, pl->n_roots, N_ZC,

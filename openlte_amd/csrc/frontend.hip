@@ -5,7 +5,8 @@
 //   k_dl_fft  : one workgroup per (unit, OFDM symbol).  N-point Stockham FFT through LDS, radix-8
 //               passes in registers, int8->fp32 conversion fused into the first pass's loads and the
 //               guard-band drop / spectrum un-shift fused into the last pass's stores
-//               (samples_to_symbols_dl, liblte_phy.cc:8593-8644, scale = 0).
+//               (samples_to_symbols_dl, liblte_phy.cc:8593-8644, scale = 0).  N = 2048 (20 MHz) runs
+//               k_dl_fft2k: 8 x 16 x 16 with 128 threads per symbol, two LDS exchanges (round 4).
 //   k_dl_ce   : one workgroup per (unit, antenna port): pilot LS estimates, the reference's
 //               sequential phase unwrap, frequency interpolation, then time interpolation and
 //               mag/phase -> re/im for all 14 symbols (liblte_phy.cc:5959-6194).

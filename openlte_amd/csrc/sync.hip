@@ -39,29 +39,57 @@ template <> struct Samples<float> {
 };
 
 // corr[slot][i] = sum_{j < cp} x[b + j] * conj(x[b + j + N]), b = start + slot*n_slot + i  (liblte_phy.cc:5731-5742)
+// A thread owns FOUR neighbouring windows: window i + 1 uses the samples of window i shifted by one, so a step of the (serial, reference-
+// order) sum loads one new sample per side and serves four accumulators -- a quarter of the LDS reads the one-window-per-thread form made,
+// which were all the kernel did (two 8-byte reads for four multiply-adds).  Element k of the staged samples sits at k + k / 4: the lanes
+// of a wavefront then read at a stride of five 8-byte slots, which spreads over all banks (a stride of four would hit eight of them).
+constexpr uint32_t CP_WIN = 4, CP_BLK = 256 * CP_WIN;
 template <typename S>
 __global__ __launch_bounds__(256) void k_cp_corr(S src, uint64_t start, uint32_t n_slot, uint32_t N, uint32_t cp, float2 *__restrict__ corr)
 {
-    // the 256 windows of a block overlap: stage the 256 + cp samples at both ends of the symbol once (cp <= 144)
-    __shared__ float2 xa[256 + 144], xb[256 + 144];
-    const uint32_t i0 = blockIdx.x * 256, slot = blockIdx.y, t = threadIdx.x;
+    // the 1024 windows of a block overlap: stage the 1024 + cp samples at both ends of the symbol once (cp <= 144)
+    constexpr uint32_t NS = CP_BLK + 144;
+    __shared__ float2 xa[NS + NS / 4 + 1], xb[NS + NS / 4 + 1];
+    const uint32_t i0 = blockIdx.x * CP_BLK, slot = blockIdx.y, t = threadIdx.x;
     const size_t   b0 = start + (size_t)slot * n_slot + i0;
-    for (uint32_t k = t; k < 256 + cp; k += 256) {
+    const uint32_t n_win = min(CP_BLK, n_slot - i0); // windows of this block; nothing past the last one's samples is read (the capture may end there)
+    for (uint32_t k = t; k < n_win + cp; k += 256) {
         float re, im;
         src.at(b0 + k, re, im);
-        xa[k] = make_float2(re, im);
+        xa[k + (k >> 2)] = make_float2(re, im);
         src.at(b0 + k + N, re, im);
-        xb[k] = make_float2(re, im);
+        xb[k + (k >> 2)] = make_float2(re, im);
     }
     __syncthreads();
-    if (i0 + t >= n_slot) return;
-    float re = 0, im = 0;
-    for (uint32_t j = 0; j < cp; j++) { // serial, in the reference's order
-        const float2 a = xa[t + j], b = xb[t + j];
-        re += a.x * b.x + a.y * b.y;
-        im += a.x * b.y - a.y * b.x;
+    const uint32_t w0 = CP_WIN * t; // first window of this thread inside the block
+    if (i0 + w0 >= n_slot) return;
+    // (re, im) as one packed pair: (a.x b.x, a.x b.y) + (a.y b.y, -(a.y b.x)), then the sum added to the accumulator -- the same four products,
+    // the same two additions per component in the same order as the scalar form (x - y and x + (-y) are the same IEEE operation), in four
+    // packed instructions instead of eight: the kernel is bound by instruction issue (88 us per search at four cycles per instruction)
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f    acc[CP_WIN] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    float2 a[CP_WIN], b[CP_WIN]; // samples w0 + j .. w0 + j + 3
+#pragma unroll
+    for (uint32_t p = 0; p < CP_WIN - 1; p++) { a[p + 1] = xa[(w0 + p) + ((w0 + p) >> 2)]; b[p + 1] = xb[(w0 + p) + ((w0 + p) >> 2)]; }
+    for (uint32_t j = 0; j < cp; j++) { // serial, in the reference's order, for each of the four windows
+#pragma unroll
+        for (uint32_t p = 0; p < CP_WIN - 1; p++) { a[p] = a[p + 1]; b[p] = b[p + 1]; }
+        const uint32_t k = w0 + j + CP_WIN - 1;
+        a[CP_WIN - 1] = xa[k + (k >> 2)];
+        b[CP_WIN - 1] = xb[k + (k >> 2)];
+#pragma unroll
+        for (uint32_t p = 0; p < CP_WIN; p++) {
+            // (the operand selectors do the broadcasts, the swap and the sign: written as vector code the compiler builds (b.y, -b.x) in registers)
+            const v2f av = {a[p].x, a[p].y}, bv = {b[p].x, b[p].y};
+            v2f t1, t2;
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t1) : "v"(av), "v"(bv));                            // (a.x b.x,  a.x b.y)
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(t2) : "v"(av), "v"(bv)); // (a.y b.y, -a.y b.x)
+            acc[p] += t1 + t2;
+        }
     }
-    corr[(size_t)slot * n_slot + i0 + t] = make_float2(re, im);
+#pragma unroll
+    for (uint32_t p = 0; p < CP_WIN; p++)
+        if (i0 + w0 + p < n_slot) corr[(size_t)slot * n_slot + i0 + w0 + p] = make_float2(acc[p].x, acc[p].y);
 }
 
 // acc[i] = sum over slots, in slot order, of |corr|^2 (:5743)
@@ -247,7 +275,7 @@ int mi_lte_coarse_timing_run(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const vo
     uint32_t *d_pos  = (uint32_t *)(d_acc + g.n_slot);
     float2   *d_pk   = (float2 *)(d_pos + 8);
     rc = with_samples(cfg, d_samples_a, d_samples_b, [&](auto src) {
-        MI_LAUNCH(ctx, "k_cp_corr", (k_cp_corr<decltype(src)>), dim3((g.n_slot + 255) / 256, N_slots), dim3(256), 0, src, start, g.n_slot, g.N, g.cpe, d_corr);
+        MI_LAUNCH(ctx, "k_cp_corr", (k_cp_corr<decltype(src)>), dim3((g.n_slot + CP_BLK - 1) / CP_BLK, N_slots), dim3(256), 0, src, start, g.n_slot, g.N, g.cpe, d_corr);
         return MI_LTE_OK;
     });
     if (rc != MI_LTE_OK) return rc;

@@ -185,8 +185,8 @@ int mi_lte_synth_prach_i8(const mi_lte_dl_cfg *cfg, const mi_lte_prach_cfg *pc, 
         // which root and cyclic shift carry preamble index p (prach_preamble_seq_gen's enumeration, liblte_phy.cc:7155-7290)
         uint32_t p = h_preamble_idx[o] % 64, r = 0, u = 0, C_v = 0;
         for (;; r++) {
-            if (pc->root_seq_idx + r >= pg.n_root_idx) return MI_LTE_ERR_INVALID_ARG;
-            u = prach_root(fmt, pc->root_seq_idx + r);
+            if (r >= 64) return MI_LTE_ERR_INVALID_ARG;
+            u = prach_root(fmt, (pc->root_seq_idx + r) % pg.n_root_idx); // the logical root order is cyclic (36.211 5.7.2; prach.hip)
             const PrachSets ps = prach_sets(u, pc->zczc, pc->hs_flag != 0, fmt);
             if (!ps.ok) return MI_LTE_ERR_UNSUPPORTED; // (the reference's own generator divides by zero / reads past its table there)
             if (p <= ps.v_max) {

@@ -327,7 +327,7 @@ def test_prach_fuzz_against_the_compiled_reference(ctx, ref):
     import test_prach_gpu as tpr
     import openlte_amd as m
     rng = np.random.default_rng(839 + 100000 * SEED)
-    n_occ = n_det = n_cfg = skipped = 0
+    n_occ = n_det = n_cfg = skipped = past_table = 0
     fmts = {0: 0, 1: 0, 2: 0, 3: 0, 4: 0}
     bws = [(128, 6), (256, 15), (512, 25), (1024, 50), (2048, 100)]
     while n_cfg < 96:
@@ -350,14 +350,22 @@ def test_prach_fuzz_against_the_compiled_reference(ctx, ref):
         except AssertionError:  # ... or the reference's init does
             skipped += 1
             continue
-        got, _ = tpr.gpu_detect(ctx, case)
+        got, n_roots = tpr.gpu_detect(ctx, case)
+        if root + n_roots > (138 if fmt == 4 else 838):
+            # the 64-preamble set runs past the end of the root table: the library wraps to index 0 (36.211 5.7.2), the reference reads whatever
+            # follows its table (liblte_phy.cc:7168-7171) and, through the recursively averaged threshold of liblte_phy_detect_prach, lets that
+            # decide -- found by seed 91 of the soak (format 4, root 134, six roots).  Nothing to compare (the shim, which hands the reference's own
+            # root spectra to the detector, stays identical there: tests/test_prach_gpu.py, the caller's-roots form)
+            past_table += 1
+            continue
         assert (got == want).all(), (spec, got.tolist(), want.tolist())
         n_cfg += 1
         n_occ += len(pre)
         n_det += int((want[:, 0] > 0).sum())
         fmts[fmt] += 1
     assert 0 < n_det < n_occ and skipped < 80 and fmts[4] == 16
-    REPORT["prach"] = {"configurations": n_cfg, "occasions": n_occ, "detected": n_det, "refused_configurations": skipped, "configurations_by_format": fmts}
+    REPORT["prach"] = {"configurations": n_cfg, "occasions": n_occ, "detected": n_det, "refused_configurations": skipped, "configurations_by_format": fmts,
+                       "configurations_whose_root_set_wraps_past_the_table_not_compared": past_table}
     write_report()
 
 

@@ -330,7 +330,9 @@ int      mi_lte_pusch_plan_soft_bits(const mi_lte_pusch_plan *plan, uint32_t all
  * power (:3460-3474) -- is evaluated on the host: h_N_det_pre[o] in {0,1}, h_det_pre[o] = preamble index,
  * h_det_ta[o] = timing advance, exactly the reference's three outputs.  The plan generates the root sequences'
  * spectra itself (prach_preamble_seq_gen :7130-7290 + the 839-point DFTs of liblte_phy_ul_init :2496-2508);
- * mi_lte_prach_plan_create_roots takes them from the caller instead (LIBLTE_PHY_STRUCT::prach_x_u_fft_re/im). */
+ * mi_lte_prach_plan_create_roots takes them from the caller instead (LIBLTE_PHY_STRUCT::prach_x_u_fft_re/im).
+ * A 64-preamble set that starts near the end of the logical root table continues at index 0 (36.211 5.7.2: the order is cyclic);
+ * the reference indexes past its table there (liblte_phy.cc:7168-7171), so only the caller's-roots form reproduces it in that case. */
 typedef struct {
     uint32_t root_seq_idx;     /* logical root sequence index, 0..837 (format 4: 0..137) */
     uint32_t preamble_format;  /* 0..4 */

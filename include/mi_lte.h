@@ -348,6 +348,10 @@ int      mi_lte_prach_plan_create_roots(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cf
                                         uint32_t n_roots, mi_lte_prach_plan **out);
 void     mi_lte_prach_plan_destroy(mi_lte_ctx *ctx, mi_lte_prach_plan *plan);
 uint32_t mi_lte_prach_plan_n_roots(const mi_lte_prach_plan *plan);
+/* Host arithmetic only (no device): the physical root sequence numbers u of the configuration's 64 preambles in the order
+ * prach_preamble_seq_gen enumerates them (liblte_phy.cc:7155-7290; cyclic logical order, see above).  MI_LTE_ERR_UNSUPPORTED where the
+ * reference itself cannot process the configuration (a restricted-set root without a cyclic shift, zeroCorrelationZoneConfig past the table). */
+int      mi_lte_prach_root_set(const mi_lte_prach_cfg *prach, uint32_t *h_u /* [64] */, uint32_t *n_roots);
 uint32_t mi_lte_prach_occasion_samples(const mi_lte_prach_plan *plan);
 int      mi_lte_prach_detect_run(mi_lte_ctx *ctx, mi_lte_prach_plan *plan, const void *d_samples_a, const void *d_samples_b,
                                  const uint64_t *d_occ_start, uint32_t n_occ, uint32_t *h_N_det_pre, uint32_t *h_det_pre,

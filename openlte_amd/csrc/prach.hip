@@ -282,24 +282,18 @@ static int prach_plan_common(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const mi
         for (uint32_t r = 0; r < pl->n_roots; r++)
             for (uint32_t k = 0; k < N_ZC; k++) xu[(size_t)r * N_ZC + k] = make_float2(h_xu_fft_re[(size_t)r * N_ZC_MAX + k], h_xu_fft_im[(size_t)r * N_ZC_MAX + k]);
     } else { // roots needed for 64 preambles (prach_preamble_seq_gen, :7130-7290), their forward DFTs in double
-        // The logical root order is cyclic (36.211 5.7.2: index 0 follows the last one), so a set that starts near the end of the table wraps.
-        // The reference does not wrap: prach_preamble_seq_gen indexes its table with root_seq_idx + n (liblte_phy.cc:7168-7171) and reads
-        // whatever lies behind it -- a caller that wants exactly that hands in the reference's own root spectra (the shim does).
-        uint32_t n_gen = 0;
-        while (n_gen < 64 && pl->n_roots < 64) {
-            const PrachSets pr = prach_sets(prach_root(fmt, (pc->root_seq_idx + pl->n_roots) % pg.n_root_idx), pc->zczc, pc->hs_flag != 0, fmt);
-            if (!pr.ok) {
-                ctx->err = "PRACH: a root of the 64-preamble set has no cyclic shift in the restricted set (the reference divides by zero there)";
-                return MI_LTE_ERR_UNSUPPORTED;
-            }
-            n_gen += pr.v_max + 1 ? pr.v_max + 1 : 64; // (a wrapped v_max: the reference takes every remaining preamble from this root)
-            pl->n_roots++;
+        // (prach_sets.hpp: the logical root order is cyclic, a set that starts near the end of the table wraps; the reference reads past its table)
+        const PrachRootSet rs = prach_root_set(fmt, pc->root_seq_idx, pc->zczc, pc->hs_flag != 0);
+        if (!rs.ok) {
+            ctx->err = "PRACH: a root of the 64-preamble set has no cyclic shift in the restricted set (the reference divides by zero there)";
+            return MI_LTE_ERR_UNSUPPORTED;
         }
+        pl->n_roots = rs.n_roots;
         xu.resize((size_t)pl->n_roots * N_ZC);
         std::vector<double> xr(N_ZC), xi(N_ZC), cs(N_ZC), sn(N_ZC);
         for (uint32_t t = 0; t < N_ZC; t++) { cs[t] = std::cos(-2.0 * M_PI * t / N_ZC); sn[t] = std::sin(-2.0 * M_PI * t / N_ZC); }
         for (uint32_t r = 0; r < pl->n_roots; r++) {
-            const uint32_t u = prach_root(fmt, (pc->root_seq_idx + r) % pg.n_root_idx);
+            const uint32_t u = rs.u[r];
             for (uint32_t i = 0; i < N_ZC; i++) { // x_u(n), rounded to float like the reference's arrays (:7167-7172)
                 const double ph = -M_PI * u * i * (i + 1) / N_ZC;
                 xr[i] = (double)(float)std::cos(ph);

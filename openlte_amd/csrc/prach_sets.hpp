@@ -60,3 +60,26 @@ inline PrachSets prach_sets(uint32_t u, uint32_t zczc, bool hs, uint32_t fmt = 0
         s.v_max = s.N_cs == 0 ? 0 : N_ZC / s.N_cs - 1;
     return s;
 }
+
+// The physical roots of a cell's 64 preambles, in the order prach_preamble_seq_gen enumerates them (liblte_phy.cc:7155-7290): root after
+// root in the logical order, v_max + 1 cyclic shifts from each, until 64 are there.  The logical order is cyclic (36.211 5.7.2: index 0
+// follows the last one); the reference does not wrap -- it indexes its table with root_seq_idx + n and reads whatever lies behind it
+// (:7168-7171) -- so for a set that runs past the table only the first (table size - root_seq_idx) roots are the reference's.
+// ok = false: a configuration the reference itself cannot process (PrachSets::ok of one of the roots), or indices out of range.
+struct PrachRootSet { uint32_t n_roots; uint32_t u[64]; bool ok; };
+inline PrachRootSet prach_root_set(uint32_t fmt, uint32_t root_seq_idx, uint32_t zczc, bool hs)
+{
+    PrachRootSet rs{0, {0}, true};
+    if (fmt > 4) { rs.ok = false; return rs; }
+    const PrachGeom pg = prach_geom(fmt);
+    if (root_seq_idx >= pg.n_root_idx) { rs.ok = false; return rs; }
+    uint32_t n_gen = 0;
+    while (n_gen < 64 && rs.n_roots < 64) {
+        const uint32_t  u  = prach_root(fmt, (root_seq_idx + rs.n_roots) % pg.n_root_idx);
+        const PrachSets pr = prach_sets(u, zczc, hs, fmt);
+        if (!pr.ok) { rs.ok = false; return rs; }
+        rs.u[rs.n_roots++] = u;
+        n_gen += pr.v_max + 1 ? pr.v_max + 1 : 64; // (a wrapped v_max: the reference takes every remaining preamble from this root)
+    }
+    return rs;
+}

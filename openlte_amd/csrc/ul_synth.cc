@@ -161,6 +161,17 @@ size_t mi_lte_synth_prach_len(uint32_t fft_size, uint32_t preamble_format)
     return ((pg.T_cp_30 + pg.T_fft_30 * pg.reps + 1024) / sc + 15) / 16 * 16;
 }
 
+// the physical roots u of the cell's 64 preambles in the order they are enumerated (prach_sets.hpp: prach_root_set; host arithmetic only)
+int mi_lte_prach_root_set(const mi_lte_prach_cfg *pc, uint32_t *h_u /* [64] */, uint32_t *n_roots)
+{
+    if (!pc || !h_u || !n_roots) return MI_LTE_ERR_INVALID_ARG;
+    const PrachRootSet rs = prach_root_set(pc->preamble_format, pc->root_seq_idx, pc->zczc, pc->hs_flag != 0);
+    if (!rs.ok) return pc->preamble_format > 4 || pc->root_seq_idx >= prach_geom(pc->preamble_format > 4 ? 0 : pc->preamble_format).n_root_idx ? MI_LTE_ERR_INVALID_ARG : MI_LTE_ERR_UNSUPPORTED;
+    for (uint32_t r = 0; r < rs.n_roots; r++) h_u[r] = rs.u[r];
+    *n_roots = rs.n_roots;
+    return MI_LTE_OK;
+}
+
 int mi_lte_synth_prach_i8(const mi_lte_dl_cfg *cfg, const mi_lte_prach_cfg *pc, uint32_t n_occ, const uint32_t *h_preamble_idx,
                           const uint32_t *h_delay, const mi_lte_synth_channel *chan, int8_t *h_iq)
 {

@@ -265,6 +265,8 @@ def _bind_ref(L):
     L.ref_prach_n_roots.argtypes = [vp]
     L.ref_prach_n_roots.restype = u32
     L.ref_get_prach_root_fft.argtypes = [vp, u32, f32p, f32p]
+    if hasattr(L, "ref_get_prach_root_seq"):  # (added in round 4: an older prebuilt harness does not have it)
+        L.ref_get_prach_root_seq.argtypes = [vp, u32, f32p, f32p]
     L.ref_time_pusch.argtypes = [vp, f32p, f32p, vp, C.POINTER(LoAlloc), u32, u32, u32]
     L.ref_time_pusch.restype = C.c_double
     # control channels

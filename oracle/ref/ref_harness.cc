@@ -569,6 +569,13 @@ void ref_get_prach_root_fft(void *vphy, uint32_t root, float *re, float *im)
     memcpy(re, phy->prach_x_u_fft_re[root], sizeof(float) * 839);
     memcpy(im, phy->prach_x_u_fft_im[root], sizeof(float) * 839);
 }
+// the root SEQUENCE x_u(n) itself (prach_preamble_seq_gen :7174-7181): x_u(1) = exp(-2 pi i u / N_zc) names the physical root
+void ref_get_prach_root_seq(void *vphy, uint32_t root, float *re, float *im)
+{
+    LIBLTE_PHY_STRUCT *phy = (LIBLTE_PHY_STRUCT *)vphy;
+    memcpy(re, phy->prach_x_u_re[root], sizeof(float) * 839);
+    memcpy(im, phy->prach_x_u_im[root], sizeof(float) * 839);
+}
 // DMRS of (subframe, N_prb) as ul_init left it in the struct: out = dmrs_0_re | dmrs_0_im | dmrs_1_re | dmrs_1_im, M each
 void ref_get_pusch_dmrs(void *vphy, uint32_t N_subfr, uint32_t N_prb, float *out)
 {

@@ -613,3 +613,62 @@ def test_port_two_port_front_end_vs_golden_from_reference(port):
     for p in range(2):
         assert rel(s.arr("rx_ce_re")[p, :14], z["ce_re"][p]) < 1e-4 and rel(s.arr("rx_ce_im")[p, :14], z["ce_im"][p]) < 1e-4
         assert np.hypot(z["ce_re"][p], z["ce_im"][p]).mean() > 0.1  # a real second port: its estimate is a channel, not noise around zero
+
+
+def test_prach_root_sets_vs_reference(ref):
+    """The physical roots of a cell's 64 preambles (prach_sets.hpp: prach_root_set -- what mi_lte_prach_plan_create correlates against and the
+    library's transmitter draws from) against what liblte_phy_ul_init leaves in LIBLTE_PHY_STRUCT, over formats 0 and 4 (1-3 share format 0's
+    tables), every zeroCorrelationZoneConfig, both sets, and root indices that include the ends of the logical root tables: same number of
+    roots, same root for every one that lies inside the reference's table.  Where the set runs past the table the reference indexes past it
+    (liblte_phy.cc:7168-7171: whatever follows the array names the root) and the library continues at index 0 (36.211 5.7.2) -- there the
+    count must still agree whenever the wrapped roots have as many cyclic shifts as the reference's stray ones (always, in the unrestricted
+    set), and the wrapped roots must be the table's first entries."""
+    import ctypes as C
+    import openlte_amd as m
+    from oracle import pyoracle as po
+    if not hasattr(ref, "ref_get_prach_root_seq"):
+        pytest.skip("oracle/_ref predates ref_get_prach_root_seq (rebuild it: make -C oracle/ref)")
+    L = m.load_library()
+    L.mi_lte_prach_root_set.argtypes = [C.POINTER(m.PrachCfg), np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS"), C.POINTER(C.c_uint32)]
+    table4 = [(i // 2 + 1) if i % 2 == 0 else 139 - (i + 1) // 2 for i in range(138)]  # 36.211 table 5.7.2-5
+    n_cmp = n_wrap = n_refused = 0
+    re, im = np.zeros(839, np.float32), np.zeros(839, np.float32)
+    for fmt, n_idx, n_zc, zmax in ((0, 838, 839, 16), (4, 138, 139, 7)):
+        roots = sorted(set([0, 1, 2, 7, 22, 129, 300, 411, 836, 837] + list(range(n_idx - 70, n_idx, 9)) + [n_idx - 3, n_idx - 2, n_idx - 1]) & set(range(n_idx)))
+        for root in roots:
+            for zczc in range(zmax):
+                for hs in (0, 1):
+                    if (root * 7 + zczc * 3 + hs) % 4 and root < n_idx - 70:  # (the reference's init costs 0.1 s: a quarter of the inner grid, all of the table's end)
+                        continue
+                    pc = m.PrachCfg(root, fmt, zczc, hs, 0)
+                    u = np.zeros(64, np.uint32)
+                    n = C.c_uint32(0)
+                    rc = L.mi_lte_prach_root_set(C.byref(pc), u, C.byref(n))
+                    if rc != 0:  # configurations the reference cannot process (it divides by zero -- SIGFPE -- or indexes past its N_cs table): refused
+                        n_refused += 1
+                        continue
+                    if hs and root + n.value > n_idx:  # restricted-set arithmetic on whatever follows the reference's table may divide by zero: not run
+                        n_wrap += 1
+                        continue
+                    phy = ref.ref_phy_new(po.FS_ENUM[128], 1, 1, 6)
+                    try:
+                        assert ref.ref_ul_init_prach(phy, 1, root, fmt, zczc, hs) == 0
+                        n_ref = ref.ref_prach_n_roots(phy)
+                        inside = min(n.value, n_idx - root)
+                        for r in range(min(inside, n_ref)):
+                            ref.ref_get_prach_root_seq(phy, r, re, im)
+                            u_ref = int(round(-np.arctan2(float(im[1]), float(re[1])) * n_zc / (2 * np.pi))) % n_zc  # x_u(1) = exp(-2 pi i u / N_zc)
+                            assert u_ref == int(u[r]), (fmt, root, zczc, hs, r, u_ref, int(u[r]))
+                        if root + n.value <= n_idx:
+                            assert n_ref == n.value, (fmt, root, zczc, hs, n_ref, n.value)
+                            n_cmp += 1
+                        else:
+                            n_wrap += 1
+                            want = [(table4[i] if fmt == 4 else None) for i in range(n.value - inside)]
+                            if fmt == 4:
+                                assert [int(x) for x in u[inside:n.value]] == want, (root, zczc, hs, u[:n.value].tolist())
+                            if not hs:
+                                assert n_ref == n.value, (fmt, root, zczc, n_ref, n.value)
+                    finally:
+                        ref.ref_phy_free(phy)
+    assert n_cmp > 200 and n_wrap > 20, (n_cmp, n_wrap, n_refused)

@@ -68,31 +68,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
                                                      uint32_t *__restrict__ e_len, uint32_t max_pairs, uint32_t max_words,
                                                      uint32_t e_lds_cap)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smu[]; // offs[max_pairs+1] | masks[max_pairs] | cw[...]
+    extern __shared__ __attribute__((aligned(16))) uint32_t smu[]; // tab[max_pairs+1] (offset, mask | position) | cw[...] | soft bits
     __shared__ uint2 qam_lut[64]; // hard-decision mask -> six soft bits (16QAM / 64QAM)
     const uint32_t a_idx = blockIdx.x;
     const mi_lte_pdsch_alloc &al = allocs[a_idx];
     const uint32_t unit = al.unit, sf = subfr_num[unit], cell = n_id_cell[unit], N_ant = ONE_PORT ? 1u : g.N_ant, N_prb = al.N_prb;
     const uint32_t Qm = al.mod_type == 3 ? 6 : al.mod_type == 2 ? 4 : al.mod_type == 1 ? 2 : 1;
-    uint32_t *offs = smu, *masks = smu + max_pairs + 1, *cw = smu + ((2 * max_pairs + 1 + 3u) & ~3u); // cw and e_lds stay 16-byte aligned
+    uint2    *tab = reinterpret_cast<uint2 *>(smu);
+    uint32_t *cw  = smu + ((2 * (max_pairs + 1) + 3u) & ~3u); // cw and e_lds stay 16-byte aligned
     uint32_t first_sc, last_sc;
     sync_window(g.N_rb_dl, first_sc, last_sc);
 
     // ---- phases 1 and 2 side by side.  Wave 0: which REs, in the reference's loop order L -> PRB -> sub-carrier
-    // (liblte_phy.cc:3744-3802) -- a 12-bit mask per (symbol, PRB) pair and, by a scan inside the wave, the running count of REs
-    // before each pair.  Waves 1-3: the scrambling sequence words (c_init per :3831) for the upper bound of the bit count, which
-    // does not wait for the scan.  One barrier for both.
+    // (liblte_phy.cc:3744-3802) -- per (symbol, PRB) pair, for ALL 14 symbols, a 12-bit mask (0 in the control region) with the pair's
+    // position L * 1200 + first sub-carrier above it and, by a scan inside the wave, the running count of REs before the pair.
+    // Waves 1-3: the scrambling sequence words (c_init per :3831) for the upper bound of the bit count, which does not wait for the scan.
+    // One barrier for both.
     const uint32_t cfi = al.n_pdcch_symbs ? al.n_pdcch_symbs : g.cfi; // the allocation's own control-region size, or the plan's
-    const uint32_t n_pairs = (14 - cfi) * N_prb;
+    const uint32_t n_pairs = 14 * N_prb, pair0 = cfi * N_prb;          // pairs [0, pair0) are the control region: empty masks
     const uint32_t c_init = ((al.rnti << 14) | (0u << 13) | (sf << 9) | cell) & 0x7FFFFFFFu; // 31 bits: the Gold basis has 31 rows
     if (threadIdx.x < 64) {
         const uint32_t ln = threadIdx.x, per = (n_pairs + 63) / 64, q0 = ln * per, q1 = min(q0 + per, n_pairs);
         const uint32_t magic = 0xFFFFFFFFu / N_prb + 1u; // q / N_prb = mulhi(q, magic), exact for q < 2^32 / N_prb^2; a single PRB wraps it to 0 = "no division"
         uint32_t local = 0;
         for (uint32_t q = q0; q < q1; q++) {
-            const uint32_t row = magic ? __umulhi(q, magic) : q, L = cfi + row, prb = al.prb[L / 7][q - row * N_prb];
-            const uint32_t m = pdsch_mask(N_ant, cell, sf, L, prb, first_sc, last_sc);
-            masks[q] = m | ((L * N_SC_MAX + prb * 12) << 12); // low 12 bits: RE mask, high 20 bits: L*1200 + first sub-carrier
+            const uint32_t L = magic ? __umulhi(q, magic) : q, prb = al.prb[L / 7][q - L * N_prb];
+            const uint32_t m = L < cfi ? 0u : pdsch_mask(N_ant, cell, sf, L, prb, first_sc, last_sc);
+            tab[q].y = m | ((L * N_SC_MAX + prb * 12) << 12); // low 12 bits: RE mask, high 20 bits: L*1200 + first sub-carrier
             local += __popc(m);
         }
         uint32_t incl = local;
@@ -102,17 +104,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
         }
         uint32_t run = incl - local;
         for (uint32_t q = q0; q < q1; q++) {
-            offs[q] = run;
-            run += __popc(masks[q] & 0xFFFu);
+            tab[q].x = run;
+            run += __popc(tab[q].y & 0xFFFu);
         }
-        if (ln == 63) offs[n_pairs] = incl; // total
+        if (ln == 63) tab[n_pairs] = make_uint2(incl, 0u); // total
     } else {
-        const uint32_t n_words_ub = (n_pairs * 12 * Qm + 31) / 32; // <= max_words; one word of slack for the 2-word window in put_bits
+        const uint32_t n_words_ub = ((n_pairs - pair0) * 12 * Qm + 31) / 32; // <= max_words; one word of slack for the 2-word window in put_bits
         if (threadIdx.x < 128) qam_lut[threadIdx.x - 64] = qam_lut_entry(threadIdx.x - 64);
         for (uint32_t w = threadIdx.x - 64; w <= n_words_ub; w += blockDim.x - 64) cw[w] = gold_word(gt, c_init, w);
     }
     __syncthreads();
-    const uint32_t M_ap = offs[n_pairs];
+    const uint32_t M_ap = tab[n_pairs].x;
     // pre-decoder / layer de-mapper symbol counts (liblte_phy.cc:7683, 7693, 7720, 7497).  M_ap is a multiple of N_ant for every
     // allocation the extraction above can produce: each (slot, PRB) contributes 12, 8 or -- next to the PBCH / PSS / SSS window of the
     // odd bandwidths -- 6 + 6, 4 + 4 + 6 + 6 resource elements (enumerated over every bandwidth, cell, subframe and control-region size
@@ -129,14 +131,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
     const float *h_re_p = base + 2 * 16 * N_SC_MAX, *h_im_p = h_re_p + (size_t)N_ant * 16 * N_SC_MAX;
     int8_t *e = e_base + (size_t)e_off[a_idx] * 64; // offsets are kept in 64-byte units: a batch may hold more than 4 GiB of soft bits
     auto locate = [&](uint32_t idx) -> uint32_t { // RE index -> L * 1200 + sub-carrier
-        uint32_t lo = 0, hi = n_pairs; // offs[lo] <= idx < offs[hi]
+        uint32_t lo = pair0, hi = n_pairs; // tab[lo].x <= idx < tab[hi].x
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
-            if (offs[mid] <= idx) lo = mid; else hi = mid;
+            if (tab[mid].x <= idx) lo = mid; else hi = mid;
         }
-        uint32_t r = idx - offs[lo], m = masks[lo] & 0xFFFu;
+        const uint2 t = tab[lo];
+        uint32_t r = idx - t.x, m = t.y & 0xFFFu;
         for (; r; r--) m &= m - 1;
-        return (masks[lo] >> 12) + (uint32_t)__builtin_ctz(m);
+        return (t.y >> 12) + (uint32_t)__builtin_ctz(m);
     };
     // soft bits are assembled in LDS when they fit and leave with 16-byte stores
     int8_t    *e_lds  = reinterpret_cast<int8_t *>(cw + max_words);
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
     // 16QAM / 64QAM: every soft bit is +-127, so a symbol is its mask of negative bits; XOR with the scrambling bits and one table
     // read give the Q_m bytes (4: one store; 6: three 16-bit stores, the symbol starts on an even address)
     auto put_qam = [&](auto *dst, uint32_t idx, uint32_t neg) {
-        const uint32_t n0 = QM == 4 ? idx << 2 : (idx << 2) + (idx << 1), w = n0 >> 5, sh = n0 & 31;
+        const uint32_t n0 = QM == 4 ? idx << 2 : __umul24(idx, 6u), w = n0 >> 5, sh = n0 & 31;
         const uint32_t c  = __builtin_amdgcn_alignbit(cw[w + 1], cw[w], sh);
         const uint2    v  = qam_lut[(neg ^ c) & (QM == 4 ? 15u : 63u)];
         if (QM == 4) *reinterpret_cast<uint32_t *>(dst + n0) = v.x;
@@ -172,43 +175,71 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
             *reinterpret_cast<uint16_t *>(dst + n0 + 4) = (uint16_t)v.y;
         }
     };
+    // equalised symbol (nr, ni) / den -> soft bits of RE idx.  16QAM / 64QAM: the decisions without the divisions (qam_neg_bits_nodiv:
+    // the reference's own divisions under a guard next to the thresholds); BPSK / QPSK grade the quotient, so they divide.
+    auto put_symbol = [&](auto *dst, uint32_t idx, float nr, float ni, float den) {
+        if constexpr (QAM) put_qam(dst, idx, qam_neg_bits_nodiv<MOD>(nr, ni, den));
+        else {
+            int8_t b[6] = {0, 0, 0, 0, 0, 0};
+            demap_symbol<true>(nr / den, ni / den, MOD, b);
+            put_bits(dst, idx, b);
+        }
+    };
     if (ONE_PORT && COMPACT) {
         // MI_LTE_CE_COMPACT: the estimate arrives as magnitude / phase rows at the five CRS symbols (mag in the real-part plane, phase in
-        // the imaginary-part plane, rows 0-4).  One thread per (slot, PRB, sub-carrier): it loads the ten values of its sub-carrier, runs the
-        // reference's time interpolation for the whole subframe (the later segments depend on the phases wrapped in the earlier ones), and
-        // equalises its slot's resource elements with m * (cos a, sin a) -- the values k_dl_ce would have written, bit for bit.
+        // the imaginary-part plane, rows 0-4).  One thread per (slot, PRB, sub-carrier): it loads the six values its slot's two segments
+        // hang on (and, in the second slot, the two phases its first row is wrapped through), runs the reference's time interpolation
+        // (the later segments depend on the phases wrapped in the earlier ones), and equalises its slot's resource elements with
+        // m * (cos a, sin a) -- the values k_dl_ce would have written, bit for bit.  Rows are addressed as a uniform row pointer plus one
+        // 32-bit byte offset per thread (global_load ... saddr), the pair table gives the PRB and the first RE in one LDS read.
+        constexpr uint32_t ROW = N_SC_MAX * 4, Y_IM = 16 * ROW, H_M = 32 * ROW, H_A = 48 * ROW; // byte offsets of the planes in a unit
         const uint32_t per_slot = N_prb * 12, n_items = 2 * per_slot;
-        const uint32_t magic12 = 0xFFFFFFFFu / 12u + 1u;
+        // one buffer descriptor for the unit: a load is (descriptor, 32-bit byte offset per thread, row offset in a scalar register)
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)(g.sf_stride * 4u), 0x00020000);
+        auto ld = [&](uint32_t row, uint32_t off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, (int)row, 0)); };
         auto body = [&](auto *dst) {
             for (uint32_t item = threadIdx.x; item < n_items; item += blockDim.x) {
-                const uint32_t s = item >= per_slot ? 1u : 0u, r = item - s * per_slot, i = __umulhi(r, magic12), j = r - 12 * i;
-                const uint32_t k = (uint32_t)al.prb[s][i] * 12 + j, below = (1u << j) - 1u;
-                float M[5], A[5], m[7], a[7];
-#pragma unroll
-                for (int c = 0; c < 5; c++) { M[c] = h_re_p[c * N_SC_MAX + k]; A[c] = h_im_p[c * N_SC_MAX + k]; }
+                const uint32_t s = item >= per_slot ? 1u : 0u, r = item - s * per_slot, i = __umul24(r, 43691u) >> 19, j = r - __umul24(i, 12u); // r / 12 for r < 2^15
+                const uint32_t bit = 1u << j, below = bit - 1u;
+                const uint2   *tp = tab + (s ? 7 * N_prb : 0u) + i; // the pair of the slot's first symbol; the next symbols' are N_prb apart
+                const uint2    t0 = *tp;
+                const uint32_t vy = ((t0.y >> 12) + j) << 2;                  // byte offset of (symbol 7s, sub-carrier k) in a plane
+                const uint32_t vk = vy - s * (7 * ROW), vh = vk + s * (2 * ROW); // (row 0, k) and (row 2s, k)
+                const float M0 = ld(H_M, vh), M1 = ld(H_M + ROW, vh), M2 = ld(H_M + 2 * ROW, vh);
+                const float P0 = ld(H_A, vh), P1 = ld(H_A + ROW, vh), P2 = ld(H_A + 2 * ROW, vh);
+                const float Q0 = ld(H_A, vk), Q1 = ld(H_A + ROW, vk); // the first slot's phases (second slot only; the same rows again in the first)
                 // the slot's symbols: requested before the interpolation needs its inputs
                 float yr[7], yi[7];
 #pragma unroll
-                for (int t = 0; t < 7; t++) { yr[t] = y_re_p[(7 * s + t) * N_SC_MAX + k]; yi[t] = y_im_p[(7 * s + t) * N_SC_MAX + k]; }
-                ce_time_interp5_slot(M, A, s, m, a);
+                for (int t = 0; t < 7; t++) { yr[t] = ld(t * ROW, vy); yi[t] = ld(Y_IM + t * ROW, vy); }
+                // liblte_phy.cc:6119-6190 for symbols 7s .. 7s+6 (ce_time_interp5 above is the whole subframe): symbols 7s and 7s+4 take
+                // the CRS-symbol values as estimated; the slopes see the phases wrapped against their predecessors, from symbol 0 on
+                float m[7], a[7];
+                m[0] = M0; a[0] = P0; m[4] = M1; a[4] = P1;
+                float W0 = P0;
+                if (s) W0 = wrap_phase_rare(P0, wrap_phase_rare(Q1, Q0));
+                {
+                    const float fm = (M1 - M0) / 4, W1 = wrap_phase_rare(P1, W0);
+                    const float fa = wrap_phase_rare(W1 - W0, 0.0f) / 4;
+                    float cm = M1, ca = W1;
+#pragma unroll
+                    for (int z = 3; z > 0; z--) { cm -= fm; ca -= fa; m[z] = cm; a[z] = ca; }
+                    const float gm = div3(M2 - M1), W2 = wrap_phase_rare(P2, W1);
+                    const float ga = div3(wrap_phase_rare(W2 - W1, 0.0f));
+                    cm = M2; ca = W2;
+#pragma unroll
+                    for (int z = 6; z > 4; z--) { cm -= gm; ca -= ga; m[z] = cm; a[z] = ca; }
+                }
 #pragma unroll
                 for (int t = 0; t < 7; t++) {
-                    const uint32_t L = 7 * s + t;
-                    if (L < cfi) continue;
-                    const uint32_t q = (L - cfi) * N_prb + i, mk = masks[q];
-                    if (!((mk >> j) & 1u)) continue;
-                    const uint32_t idx = offs[q] + __popc(mk & below);
+                    const uint2 pr = t ? tp[t * N_prb] : t0;
+                    if (!(pr.y & bit)) continue;
+                    const uint32_t idx = pr.x + __popc(pr.y & below);
                     float sn, cs;
                     ce_sincos(a[t], sn, cs);
                     const float mm = m[t], hr = mm * cs, hi = mm * sn;
                     const float hn = hr * hr + hi * hi;
-                    const float xr = (yr[t] * hr + yi[t] * hi) / hn, xi = (yi[t] * hr - yr[t] * hi) / hn;
-                    if (QAM) put_qam(dst, idx, qam_neg_bits(xr, xi, MOD));
-                    else {
-                        int8_t b[6] = {0, 0, 0, 0, 0, 0};
-                        demap_symbol<true>(xr, xi, MOD, b);
-                        put_bits(dst, idx, b);
-                    }
+                    put_symbol(dst, idx, yr[t] * hr + yi[t] * hi, yi[t] * hr - yr[t] * hi, hn);
                 }
             }
         };
@@ -219,7 +250,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
         const uint32_t q_thr = threadIdx.x / 12, j = threadIdx.x - 12 * q_thr, below = (1u << j) - 1u;
         const bool     lane_on = threadIdx.x < 252;
         auto body = [&](auto *dst) {
-            for (uint32_t qb = 0; qb < n_pairs; qb += 21 * UNR) {
+            for (uint32_t qb = pair0; qb < n_pairs; qb += 21 * UNR) {
                 float    yr[UNR], yi[UNR], hr[UNR], hi[UNR];
                 uint32_t idx[UNR];
                 bool     on[UNR];
@@ -227,10 +258,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
                 for (int r = 0; r < UNR; r++) {
                     const uint32_t q = qb + 21 * r + q_thr;
                     const bool     in = lane_on && q < n_pairs;
-                    const uint32_t qc = in ? q : 0u, mk = masks[qc];
-                    on[r]  = in && ((mk >> j) & 1u);
-                    idx[r] = offs[qc] + __popc(mk & below);
-                    const uint32_t ob = on[r] ? ((mk >> 12) + j) << 2 : 0u; // byte offset in 32 bits: one register serves the four planes
+                    const uint2    pr = tab[in ? q : 0u];
+                    on[r]  = in && ((pr.y >> j) & 1u);
+                    idx[r] = pr.x + __popc(pr.y & below);
+                    const uint32_t ob = on[r] ? ((pr.y >> 12) + j) << 2 : 0u; // byte offset in 32 bits: one register serves the four planes
                     yr[r] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(y_re_p) + ob);
                     yi[r] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(y_im_p) + ob);
                     hr[r] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(h_re_p) + ob);
@@ -240,30 +271,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
                 for (int r = 0; r < UNR; r++) {
                     if (!on[r]) continue;
                     const float hn = hr[r] * hr[r] + hi[r] * hi[r];
-                    const float xr = (yr[r] * hr[r] + yi[r] * hi[r]) / hn, xi = (yi[r] * hr[r] - yr[r] * hi[r]) / hn;
-                    if (QAM) put_qam(dst, idx[r], qam_neg_bits(xr, xi, MOD));
-                    else {
-                        int8_t b[6] = {0, 0, 0, 0, 0, 0};
-                        demap_symbol<true>(xr, xi, MOD, b);
-                        put_bits(dst, idx[r], b);
-                    }
+                    put_symbol(dst, idx[r], yr[r] * hr[r] + yi[r] * hi[r], yi[r] * hr[r] - yr[r] * hi[r], hn);
                 }
             }
         };
         if (via_lds) body(e_lds); else body(e);
     } else
     for (uint32_t i = threadIdx.x; i < n_grp; i += blockDim.x) {
-        float x_re[4], x_im[4];
+        float n_re[4], n_im[4], den[4]; // x_p = (n_re, n_im) / den
         if (N_ant == 2) { // Alamouti combiner with the reference's normaliser (liblte_phy.cc:7694-7717)
             const uint32_t p0 = locate(2 * i), p1 = locate(2 * i + 1);
             const float y0r = y_re_p[p0], y0i = y_im_p[p0], y1r = y_re_p[p1], y1i = y_im_p[p1];
             const float h0r = h_re_p[p0], h0i = h_im_p[p0], h1r = h_re_p[16 * N_SC_MAX + p0], h1i = h_im_p[16 * N_SC_MAX + p0];
             const float a0 = h0r * h0r + h0i * h0i, a1 = h1r * h1r + h1i * h1i;
             const float hn = sqrtf(a0 * a0 + a1 * a1);
-            x_re[0] = (h0r * y0r + h0i * y0i + h1r * y1r + h1i * y1i) / hn;
-            x_im[0] = (h0r * y0i - h0i * y0r - h1r * y1i + h1i * y1r) / hn;
-            x_re[1] = (-h1r * y0r - h1i * y0i + h0r * y1r + h0i * y1i) / hn;
-            x_im[1] = (h1r * y0i - h1i * y0r + h0r * y1i - h0i * y1r) / hn;
+            den[0] = den[1] = hn;
+            n_re[0] = h0r * y0r + h0i * y0i + h1r * y1r + h1i * y1i;
+            n_im[0] = h0r * y0i - h0i * y0r - h1r * y1i + h1i * y1r;
+            n_re[1] = -h1r * y0r - h1i * y0i + h0r * y1r + h0i * y1i;
+            n_im[1] = h1r * y0i - h1i * y0r + h0r * y1i - h0i * y1r;
         } else { // N_ant == 4 (liblte_phy.cc:7721-7765); M_ap % 4 == 0 always, see the note at n_grp
             const uint32_t p0 = locate(4 * i), p1 = locate(4 * i + 1), p2 = locate(4 * i + 2), p3 = locate(4 * i + 3);
             const size_t   ps = 16 * N_SC_MAX;
@@ -273,25 +299,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
             const float h1r = h_re_p[ps + p2], h1i = h_im_p[ps + p2], h3r = h_re_p[3 * ps + p2], h3i = h_im_p[3 * ps + p2];
             const float a0 = h0r * h0r + h0i * h0i, a1 = h1r * h1r + h1i * h1i, a2 = h2r * h2r + h2i * h2i, a3 = h3r * h3r + h3i * h3i;
             const float n02 = sqrtf(a0 * a0 + a2 * a2), n13 = sqrtf(a1 * a1 + a3 * a3);
-            x_re[0] = (h0r * y0r + h0i * y0i + h2r * y1r + h2i * y1i) / n02;
-            x_im[0] = (h0r * y0i - h0i * y0r - h2r * y1i + h2i * y1r) / n02;
-            x_re[1] = (-h2r * y0r - h2i * y0i + h0r * y1r + h0i * y1i) / n02;
-            x_im[1] = -(-h2r * y0i + h2i * y0r - h0r * y1i + h0i * y1r) / n02;
-            x_re[2] = (h1r * y2r + h1i * y2i + h3r * y3r + h3i * y3i) / n13;
-            x_im[2] = (h1r * y2i - h1i * y2r - h3r * y3i + h3i * y3r) / n13;
-            x_re[3] = (-h3r * y2r - h3i * y2i + h1r * y3r + h1i * y3i) / n13;
-            x_im[3] = -(-h3r * y2i + h3i * y2r - h1r * y3i + h1i * y3r) / n13;
+            den[0] = den[1] = n02; den[2] = den[3] = n13;
+            n_re[0] = h0r * y0r + h0i * y0i + h2r * y1r + h2i * y1i;
+            n_im[0] = h0r * y0i - h0i * y0r - h2r * y1i + h2i * y1r;
+            n_re[1] = -h2r * y0r - h2i * y0i + h0r * y1r + h0i * y1i;
+            n_im[1] = -(-h2r * y0i + h2i * y0r - h0r * y1i + h0i * y1r);
+            n_re[2] = h1r * y2r + h1i * y2i + h3r * y3r + h3i * y3i;
+            n_im[2] = h1r * y2i - h1i * y2r - h3r * y3i + h3i * y3r;
+            n_re[3] = -h3r * y2r - h3i * y2i + h1r * y3r + h1i * y3i;
+            n_im[3] = -(-h3r * y2i + h3i * y2r - h1r * y3i + h1i * y3r);
         }
         // layer de-mapping d[i*N_ant + p] = x_p[i] (liblte_phy.cc:7506-7513), de-map, descramble (:3833-3836)
         for (uint32_t p = 0; p < N_ant; p++) {
-            if (QAM) {
-                const uint32_t neg = qam_neg_bits(x_re[p], x_im[p], MOD);
-                if (via_lds) put_qam(e_lds, i * N_ant + p, neg); else put_qam(e, i * N_ant + p, neg);
-                continue;
-            }
-            int8_t b[6] = {0, 0, 0, 0, 0, 0};
-            demap_symbol<true>(x_re[p], x_im[p], MOD, b);
-            if (via_lds) put_bits(e_lds, i * N_ant + p, b); else put_bits(e, i * N_ant + p, b);
+            if (via_lds) put_symbol(e_lds, i * N_ant + p, n_re[p], n_im[p], den[p]);
+            else         put_symbol(e, i * N_ant + p, n_re[p], n_im[p], den[p]);
         }
     }
     };
@@ -392,7 +413,7 @@ static int plan_layout(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, uint32_t N_pdcch_
         max_tbs = std::max(max_tbs, al.tbs);
         const uint32_t Qm = al.mod_type == 3 ? 6 : al.mod_type == 2 ? 4 : al.mod_type == 1 ? 2 : 1;
         const uint32_t pairs = (14 - cfi) * al.N_prb, e_max = pairs * 12 * Qm;
-        pl->max_pairs = std::max(pl->max_pairs, pairs);
+        pl->max_pairs = std::max(pl->max_pairs, 14 * al.N_prb); // the demodulator's pair table spans all 14 symbols
         pl->max_words = std::max(pl->max_words, (e_max + 31) / 32);
         emax[r]        = std::max(emax[r], e_max);
         pl->h_e_off[a] = (uint32_t)(off >> 6); // in 64-byte units
@@ -616,10 +637,10 @@ int mi_lte_pdsch_decode_run(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, const float 
     if (rc != MI_LTE_OK) return rc;
     DemodGeom  g{pl->cfg.N_rb_dl, pl->cfg.N_ant, pl->cfi, (uint32_t)mi_lte_subframe_floats(pl->cfg.N_ant)};
     GoldTables gt{ctx->d_gold_x1, ctx->d_gold_x2b, ctx->gold_words};
-    // LDS: offs | masks | scrambling words | (when it fits in 32 KiB) the allocation's soft bits
+    // LDS: pair table | scrambling words | (when it fits in 32 KiB) the allocation's soft bits
     const uint32_t words_al = (pl->max_words + 1u + 3u) & ~3u, e_bytes = (pl->max_words * 32 + 63u) & ~63u;
     const uint32_t e_cap = (e_bytes <= 32 * 1024) ? e_bytes : 0;
-    const uint32_t pairs_al = ((2 * pl->max_pairs + 1 + 3u) & ~3u);
+    const uint32_t pairs_al = ((2 * (pl->max_pairs + 1) + 3u) & ~3u);
     const size_t lds = sizeof(uint32_t) * ((size_t)pairs_al + words_al) + e_cap;
     uint32_t threads = 256;
     if (const char *ev = getenv("MI_LTE_PDSCH_THREADS")) { // (tuning aid)

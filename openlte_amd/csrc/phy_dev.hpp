@@ -42,6 +42,15 @@ __device__ __forceinline__ float wrap_phase(float p1, float p2)
     return p1;
 }
 
+// The same with the common case first: the wrap loops run only when |p1 - p2| >= pi on entry (never for NaN), which one comparison decides.
+__device__ __forceinline__ float wrap_phase_rare(float p1, float p2)
+{
+    if (__builtin_expect(fabsf(p1 - p2) >= 3.14159274101257324f, 0)) p1 = wrap_phase(p1, p2);
+    return p1;
+}
+// x / 3.0f (the second and fourth segments of the time interpolation divide by their three symbols)
+__device__ __forceinline__ float div3(float x) { return x / 3.0f; }
+
 // sin / cos of an unwrapped phase for the time interpolation: two-constant reduction to [-pi, pi] (the phases are a few turns at
 // most), then the hardware's v_sin_f32 / v_cos_f32, which take revolutions.  The estimate is a float-tolerance stage
 // (TOL_CE = 1e-4 in tests/test_frontend_gpu.py; measured against the CPU restatement of the reference the estimate's relative L2 error is 2.4e-7 this way and
@@ -252,6 +261,32 @@ __device__ __forceinline__ uint32_t qam_neg_bits(float re, float im, uint32_t mo
         t |= (!(ar < t10) ? 4u : 0u) | (!(ai < t10) ? 8u : 0u);
     }
     return t;
+}
+// The same mask for a symbol x = (nr, ni) / den WITHOUT the two divisions.  The reference divides (liblte_phy.cc:7680-7690, 7694-7765)
+// and then only compares the quotients with 0 and with k * 2/sqrt(42) (k = 1, 2, 3; 2/sqrt(10) for 16QAM) -- liblte_phy.cc:9573-9659.
+// With u = |n| * (rcp(den) * sqrt(42)/2) those thresholds sit at the integers: floor(u) picks the amplitude ring, the sign bit of n the
+// half plane.  u carries a relative error below 2^-21 against the reference's rounded quotient measured in threshold units (v_rcp_f32 is
+// 1 ulp, three roundings, the two constants' own roundings, the quotient's rounding: 2.5 + 1 + 0.5 units of 2^-23, times u <= 3 at the
+// last threshold -> 1.5e-6), so a decision can only differ when u lies within that of an integer.  Such symbols -- anything within
+// 2^-16 of an integer, which also catches zeros, underflowing quotients, a zero / subnormal / infinite / NaN denominator (u becomes 0,
+// inf or NaN: the test is written so that NaN fails it) and |u| >= 2^23 -- take the reference's own route: the IEEE divisions and
+// qam_neg_bits above.  So the mask is the reference's by construction; the guarded route is taken by about one symbol in 16 000.
+// (tests/test_chain_gpu.py::test_qam_decisions_next_to_the_thresholds places symbols 0-3 ulp around every threshold.)
+template <uint32_t MOD> __device__ __forceinline__ uint32_t qam_neg_bits_nodiv(float nr, float ni, float den)
+{
+    static_assert(MOD == 2 || MOD == 3, "16QAM / 64QAM");
+    constexpr float    C      = MOD == 3 ? 3.24037034920393f : 1.58113883008419f; // sqrt(42)/2, sqrt(10)/2
+    constexpr uint32_t K_TOP  = MOD == 3 ? 3u : 1u;                               // rings past the last threshold are the last ring
+    // ring k -> (bit 2, bit 4) of the real part; the imaginary part's bits are one position higher.  64QAM, rings 0..3: bit 2 (outer half)
+    // 0 0 1 1, bit 4 (-127 in the innermost and outermost ring) 1 0 0 1.  16QAM, rings 0..1: bit 2 = k.
+    constexpr uint32_t RINGS  = MOD == 3 ? (16u | (0u << 8) | (4u << 16) | (20u << 24)) : (0u | (4u << 8));
+    const float rc = __builtin_amdgcn_rcpf(den) * C;
+    const float ur = nr * rc, ui = ni * rc;
+    const float fr = ur - rintf(ur), fi = ui - rintf(ui);
+    if (!(fabsf(fr) >= 0x1p-16f) || !(fabsf(fi) >= 0x1p-16f)) return qam_neg_bits(nr / den, ni / den, MOD);
+    const uint32_t kr = min((uint32_t)fabsf(ur), K_TOP), ki = min((uint32_t)fabsf(ui), K_TOP); // (v_cvt_u32_f32 saturates)
+    const uint32_t s  = (ref_f2u(ur) >> 31) | ((ref_f2u(ui) >> 30) & 2u);
+    return s | ((RINGS >> (8 * kr)) & 0xFFu) | (((RINGS >> (8 * ki)) & 0xFFu) << 1);
 }
 // entry t of the table that turns such a mask into soft bits: byte k = (t >> k) & 1 ? -127 : 127, k = 0..5
 __device__ __forceinline__ uint2 qam_lut_entry(uint32_t t)

@@ -748,3 +748,82 @@ def test_block_size_groups_on_a_side_stream_give_the_same_results():
         out[gs] = line[0].split()[1:]
     assert out["0"] == out["1"], out
     assert int(out["1"][1]) > 0.9 * int(out["1"][2]), out
+
+
+def _ulp_ladder(x, steps):
+    """float32 neighbours of x: x stepped by each entry of `steps` ulps"""
+    out = []
+    for k in steps:
+        v = np.float32(x)
+        for _ in range(abs(k)):
+            v = np.nextafter(v, np.float32(np.inf if k > 0 else -np.inf), dtype=np.float32)
+        out.append(v)
+    return np.array(out, np.float32)
+
+
+@pytest.mark.parametrize("form", ["full", "compact", "two_port"])
+@pytest.mark.parametrize("mod", [2, 3])
+def test_qam_decisions_next_to_the_thresholds(ctx, ref, port, mod, form):
+    """16QAM / 64QAM hard decisions are taken without the equaliser's divisions (phy_dev.hpp qam_neg_bits_nodiv); next to a threshold the
+    kernel divides as the reference does (liblte_phy.cc:7680-7690 -> :9573-9659).  Here every resource element of the allocations holds a
+    symbol whose real or imaginary part, after the reference's own equaliser arithmetic, lands 0-3 ulp either side of a de-mapper
+    threshold (0, 2/sqrt(42), 4/sqrt(42), 6/sqrt(42); 0, 2/sqrt(10)), with three kinds of channel estimate: 1 (the quotient IS the
+    received value), 2 (exact halving) and random gains (the quotient rounds wherever it rounds).  Soft bits must equal the reference's
+    on all of them -- in the full estimate form, in the compact form (magnitude / phase rows, time interpolation in the demodulator) and
+    through the two-port combiner."""
+    import ctypes as C
+    import openlte_amd as m
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(100 * mod + len(form))
+    n_ant = 2 if form == "two_port" else 1
+    cell, sf, cfi = 77, 3, 2
+    t = 2 / np.sqrt(42.0) if mod == 3 else 2 / np.sqrt(10.0)
+    thr = [np.float32(0.0)] + [np.float32(k * t) for k in ((1, 2, 3) if mod == 3 else (1,))]  # liblte_phy.cc:9514-9517
+    ladder = np.concatenate([_ulp_ladder(s * th, range(-3, 4)) for th in thr for s in (1, -1)] +
+                            [np.array([0.0, -0.0, 1e-45, -1e-45, 1e-38, -1e-38], np.float32)])
+    # the grid: y = target * gain, gain per sub-carrier constant over the subframe (the compact form interpolates it in time)
+    gains = np.ones(1200, np.float32)
+    gains[400:800] = 2.0
+    gains[800:] = rng.uniform(0.3, 3.0, 400).astype(np.float32)
+    kind = rng.integers(0, 3, (14, 1200))  # 0: both parts next to a threshold, 1: the real part only, 2: the imaginary part only
+    free = rng.uniform(-1.3, 1.3, (2, 14, 1200)).astype(np.float32)
+    tgt_re = np.where(kind == 2, free[0], rng.choice(ladder, (14, 1200))).astype(np.float32)
+    tgt_im = np.where(kind == 1, free[1], rng.choice(ladder, (14, 1200))).astype(np.float32)
+    y_re = np.zeros((16, 1200), np.float32)
+    y_im = np.zeros((16, 1200), np.float32)
+    y_re[:14], y_im[:14] = tgt_re * gains, tgt_im * gains  # exact for gains 1 and 2
+    ce_re = np.zeros((4, 16, 1200), np.float32)
+    ce_im = np.zeros((4, 16, 1200), np.float32)
+    ce_re[0, :14] = gains  # port 0: (gain, 0); port 1 (two_port): 0, so the combiner's normaliser is gain^2 -> sqrt -> gain^2 again
+    phy = ref.ref_phy_new(4, cell, n_ant, 100)
+    rx = ref.ref_subframe_new()
+    ref.ref_subframe_set_num(rx, sf)
+    po.ref_subframe_view(ref, rx, 0)[:], po.ref_subframe_view(ref, rx, 1)[:] = y_re, y_im
+    po.ref_subframe_view(ref, rx, 2, True)[:], po.ref_subframe_view(ref, rx, 3, True)[:] = ce_re, ce_im
+    tbs = {2: 1384, 3: 2024}[mod]
+    allocs = [m.make_alloc(0, mod, tbs, list(range(p, p + 10)), 0x300 + p, 0, 2 if n_ant == 2 else 1) for p in range(0, 100, 10)]
+    if form == "compact":
+        cfg = m.DlCfg(2048, 100, 1, m.IQ_I8 | m.CE_COMPACT)
+        h_m, h_a = np.zeros((16, 1200), np.float32), np.zeros((16, 1200), np.float32)
+        h_m[:5] = gains  # magnitude rows at the five CRS symbols, phase 0
+        grid = np.concatenate([y_re.ravel(), y_im.ravel(), h_m.ravel(), h_a.ravel()])
+    else:
+        cfg = m.DlCfg(2048, 100, n_ant, 0)
+        grid = np.concatenate([y_re.ravel(), y_im.ravel(), ce_re[:n_ant].ravel(), ce_im[:n_ant].ravel()])
+    d_sub = ctx.to_device(grid.astype(np.float32))
+    plan = ctx.pdsch_plan(cfg, cfi, allocs)
+    plan.run(d_sub, [sf], [cell])
+    n_sym = 0
+    for a, al in enumerate(allocs):
+        la = td.to_lo_alloc(al)
+        out, n = np.zeros(6200, np.uint8), C.c_uint32()
+        ref.ref_pdsch_channel_decode(phy, rx, C.byref(la), cfi, cell, n_ant, out, C.byref(n))  # (the verdict is a CRC failure: the bits are not a code word)
+        e = plan.soft_bits(a)
+        want = np.ctypeslib.as_array(ref.ref_pdsch_descramb_bits_ptr(phy), shape=(len(e),)).astype(np.int8)
+        assert len(e) >= 10 * 12 * 10 * (4 if mod == 2 else 6) and (e == want).all(), (a, int((e != want).sum()))
+        n_sym += len(e) // (4 if mod == 2 else 6)
+    assert n_sym > 13000
+    plan.close()
+    d_sub.free()
+    ref.ref_subframe_free(rx)
+    ref.ref_phy_free(phy)

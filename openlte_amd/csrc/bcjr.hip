@@ -864,7 +864,7 @@ extern "C" int mi_lte_turbo_early_exit_iterations(mi_lte_ctx *ctx, uint32_t *h_p
     if (max_pairs < np) return MI_LTE_ERR_INVALID_ARG;
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     std::vector<uint32_t> chg((size_t)ni * np);
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(chg.data(), ctx->bcjr_early.chg, chg.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    MI_D2H(ctx, chg.data(), ctx->bcjr_early.chg, chg.size() * sizeof(uint32_t));
     MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     for (uint32_t p = 0; p < np; p++) {
         uint32_t done = ni;

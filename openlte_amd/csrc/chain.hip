@@ -469,9 +469,9 @@ int mi_lte_pdsch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, uint32_t
     if (rc != MI_LTE_OK) return rc;
     rc = plan_device_arrays(ctx, pl, n_alloc, pl->e_bytes);
     if (rc != MI_LTE_OK) return rc;
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_allocs, h_allocs, sizeof(mi_lte_pdsch_alloc) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_e_off, pl->h_e_off.data(), sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_cb_alloc, cb_alloc.data(), sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
+    MI_H2D(ctx, pl->d_allocs, h_allocs, sizeof(mi_lte_pdsch_alloc) * n_alloc);
+    MI_H2D(ctx, pl->d_e_off, pl->h_e_off.data(), sizeof(uint32_t) * n_alloc);
+    MI_H2D(ctx, pl->d_cb_alloc, cb_alloc.data(), sizeof(uint32_t) * n_alloc);
     MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
     guard.armed = false;
     *out = pl;

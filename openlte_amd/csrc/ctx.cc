@@ -69,6 +69,7 @@ void mi_lte_ctx_destroy(mi_lte_ctx *ctx)
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->h_small) (void)hipHostFree(ctx->h_small);
+    if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
     if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -170,9 +171,76 @@ int mi_lte_device_copy_rates(const mi_lte_ctx *ctx, double *out3)
     for (int i = 0; i < 3; i++) out3[i] = ctx->copy_rates[i];
     return MI_LTE_OK;
 }
+// Copies of 16 KB .. 64 MB between the device and host memory do not use the runtime's copy engines: the first use of EACH engine in a
+// process costs 7-9 ms (its queue is made then), the runtime rotates through them, and a caller with a few dozen subframes in hand meets
+// that cost inside its first batches -- 8.2 ms of the 8.8 ms a 20 MHz cell scan spent on its 70-subframe pass went into one 30 KB copy of
+// transport blocks (profiles/r05_scan_batch_trace_100rb.txt; HSA_ENABLE_SDMA=0 from outside removes it, and so does this from inside).
+// Instead a kernel moves the bytes to / from 4 MiB of pinned host memory mapped into the device, 4 MiB at a time, and the host copies
+// between that block and the caller's buffer.  Smaller copies stay on the runtime's staging path (13-30 us), larger ones amortise an
+// engine's start-up and run at the link rate.
+__global__ __launch_bounds__(256) void k_copy_words(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t n16, uint8_t *dst_tail, const uint8_t *src_tail, uint32_t n_tail)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x < n_tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+static constexpr size_t BOUNCE_LO = 16u << 10, BOUNCE_BYTES = 4u << 20, BOUNCE_HI = 64u << 20;
+static const bool runtime_copies = getenv("MI_LTE_RUNTIME_COPIES") != nullptr; // (A/B switch: every copy through hipMemcpyAsync, as before round 5)
+static bool bounce_ready(mi_lte_ctx *ctx, const void *d_ptr, size_t bytes)
+{
+    if (runtime_copies || bytes <= BOUNCE_LO || bytes > BOUNCE_HI || ((uintptr_t)d_ptr & 15u)) return false;
+    if (!ctx->h_bounce) {
+        if (hipHostMalloc(&ctx->h_bounce, BOUNCE_BYTES, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&ctx->d_bounce, ctx->h_bounce, 0) != hipSuccess) {
+            if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
+            ctx->h_bounce = ctx->d_bounce = nullptr;
+            (void)hipGetLastError();
+        }
+    }
+    return ctx->h_bounce != nullptr;
+}
+static void launch_copy(mi_lte_ctx *ctx, void *dst, const void *src, size_t n)
+{
+    const size_t n16 = n / 16;
+    const unsigned grid = (unsigned)std::min<size_t>((n16 + 255) / 256 + 1, 2048);
+    k_copy_words<<<grid, 256, 0, ctx->stream>>>((uint4 *)dst, (const uint4 *)src, n16, (uint8_t *)dst + 16 * n16, (const uint8_t *)src + 16 * n16, (uint32_t)(n - 16 * n16));
+}
+} // extern "C"
+// The asynchronous pair for the library's own MAPPED pinned blocks (hostapi.cc's staging buffer): the same kernel on the block's device
+// alias, no wait; small copies and anything unaligned go to the runtime.  The caller waits for the stream before it touches the block.
+hipError_t mi_pinned_to_device(mi_lte_ctx *ctx, void *d_dst, const void *h_pinned, size_t bytes)
+{
+    void *alias = nullptr;
+    if (!runtime_copies && bytes > BOUNCE_LO && !(((uintptr_t)d_dst | (uintptr_t)h_pinned) & 15u) && hipHostGetDevicePointer(&alias, const_cast<void *>(h_pinned), 0) == hipSuccess) {
+        launch_copy(ctx, d_dst, alias, bytes);
+        return hipGetLastError();
+    }
+    (void)hipGetLastError();
+    return hipMemcpyAsync(d_dst, h_pinned, bytes, hipMemcpyHostToDevice, ctx->stream);
+}
+hipError_t mi_device_to_pinned(mi_lte_ctx *ctx, void *h_pinned, const void *d_src, size_t bytes)
+{
+    void *alias = nullptr;
+    if (!runtime_copies && bytes > BOUNCE_LO && !(((uintptr_t)d_src | (uintptr_t)h_pinned) & 15u) && hipHostGetDevicePointer(&alias, h_pinned, 0) == hipSuccess) {
+        launch_copy(ctx, alias, d_src, bytes);
+        return hipGetLastError();
+    }
+    (void)hipGetLastError();
+    return hipMemcpyAsync(h_pinned, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+}
+extern "C" {
 int mi_lte_memcpy_h2d(mi_lte_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
 {
     if (!ctx) return MI_LTE_ERR_INVALID_ARG;
+    if (bounce_ready(ctx, d_dst, bytes)) {
+        MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+        for (size_t off = 0; off < bytes; off += BOUNCE_BYTES) {
+            const size_t n = std::min(BOUNCE_BYTES, bytes - off);
+            memcpy(ctx->h_bounce, (const uint8_t *)h_src + off, n);
+            launch_copy(ctx, (uint8_t *)d_dst + off, ctx->d_bounce, n);
+            MI_HIP_CHECK(ctx, hipGetLastError());
+            MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        return MI_LTE_OK;
+    }
     MI_HIP_CHECK(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return MI_LTE_OK;
@@ -180,6 +248,17 @@ int mi_lte_memcpy_h2d(mi_lte_ctx *ctx, void *d_dst, const void *h_src, size_t by
 int mi_lte_memcpy_d2h(mi_lte_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
 {
     if (!ctx) return MI_LTE_ERR_INVALID_ARG;
+    if (bounce_ready(ctx, d_src, bytes)) {
+        MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+        for (size_t off = 0; off < bytes; off += BOUNCE_BYTES) {
+            const size_t n = std::min(BOUNCE_BYTES, bytes - off);
+            launch_copy(ctx, ctx->d_bounce, (const uint8_t *)d_src + off, n);
+            MI_HIP_CHECK(ctx, hipGetLastError());
+            MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); // (also makes the kernel's writes to the host block visible)
+            memcpy((uint8_t *)h_dst + off, ctx->h_bounce, n);
+        }
+        return MI_LTE_OK;
+    }
     MI_HIP_CHECK(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return MI_LTE_OK;
@@ -374,17 +453,17 @@ int mi_ctx_turbo_tables(mi_lte_ctx *ctx, uint32_t K, int spec, TurboTables *out)
     MI_HIP_CHECK(ctx, hipMalloc((void **)&t.d_inv_row, sizeof(uint32_t) * Kp64));
     ctx->owned.push_back(t.d_pi_row);
     ctx->owned.push_back(t.d_inv_row);
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(t.d_pi_row, pi_row.data(), sizeof(uint32_t) * Kp64, hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(t.d_inv_row, inv_row.data(), sizeof(uint32_t) * Kp64, hipMemcpyHostToDevice, ctx->stream));
+    MI_H2D(ctx, t.d_pi_row, pi_row.data(), sizeof(uint32_t) * Kp64);
+    MI_H2D(ctx, t.d_inv_row, inv_row.data(), sizeof(uint32_t) * Kp64);
     MI_HIP_CHECK(ctx, hipMalloc((void **)&t.d_pi, sizeof(uint16_t) * K));
     MI_HIP_CHECK(ctx, hipMalloc((void **)&t.d_inv, sizeof(uint16_t) * K));
     MI_HIP_CHECK(ctx, hipMalloc((void **)&t.d_inv2, sizeof(uint16_t) * K16));
     ctx->owned.push_back(t.d_pi);
     ctx->owned.push_back(t.d_inv);
     ctx->owned.push_back(t.d_inv2);
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(t.d_inv2, inv2.data(), sizeof(uint16_t) * K16, hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(t.d_pi, pi.data(), sizeof(uint16_t) * K, hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(t.d_inv, inv.data(), sizeof(uint16_t) * K, hipMemcpyHostToDevice, ctx->stream));
+    MI_H2D(ctx, t.d_inv2, inv2.data(), sizeof(uint16_t) * K16);
+    MI_H2D(ctx, t.d_pi, pi.data(), sizeof(uint16_t) * K);
+    MI_H2D(ctx, t.d_inv, inv.data(), sizeof(uint16_t) * K);
     MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->turbo_tables[key] = t;
     *out                   = t;
@@ -425,8 +504,8 @@ int mi_ctx_gold_tables(mi_lte_ctx *ctx)
     MI_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_gold_x2b, sizeof(uint32_t) * 31 * W));
     ctx->owned.push_back(ctx->d_gold_x1);
     ctx->owned.push_back(ctx->d_gold_x2b);
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_gold_x1, x1w.data(), sizeof(uint32_t) * W, hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_gold_x2b, x2w.data(), sizeof(uint32_t) * 31 * W, hipMemcpyHostToDevice, ctx->stream));
+    MI_H2D(ctx, ctx->d_gold_x1, x1w.data(), sizeof(uint32_t) * W);
+    MI_H2D(ctx, ctx->d_gold_x2b, x2w.data(), sizeof(uint32_t) * 31 * W);
     MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->gold_words = W;
     return MI_LTE_OK;
@@ -466,7 +545,7 @@ int mi_ctx_fft_twiddles(mi_lte_ctx *ctx)
     fill(MI_FFT_TWC_X3, 128, 16);
     MI_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_fft_tw, sizeof(float2) * tw.size()));
     ctx->owned.push_back(ctx->d_fft_tw);
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_fft_tw, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice, ctx->stream));
+    MI_H2D(ctx, ctx->d_fft_tw, tw.data(), sizeof(float2) * tw.size());
     MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return MI_LTE_OK;
 }
@@ -496,7 +575,7 @@ int mi_ctx_crc_table(mi_lte_ctx *ctx)
     }
     MI_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_crc_tab, sizeof(uint32_t) * N));
     ctx->owned.push_back(ctx->d_crc_tab);
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_crc_tab, tab.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice, ctx->stream));
+    MI_H2D(ctx, ctx->d_crc_tab, tab.data(), sizeof(uint32_t) * N);
     MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return MI_LTE_OK;
 }

@@ -56,6 +56,7 @@ struct mi_lte_ctx {
     bool               bcjr_block_lds_set = false; // hipFuncSetAttribute(k_bcjr_block, max dynamic LDS) made on this context's device
     uint32_t           siso_small_max = 4096; // code blocks per decode up to which k_turbo_siso_small runs (mi_lte_set_turbo_small_batch)
     void              *h_small = nullptr, *d_small = nullptr; // MI_SMALL_BYTES of pinned host memory the kernels can write (mi_ctx_small_results)
+    void              *h_bounce = nullptr, *d_bounce = nullptr; // 4 MiB of pinned host memory mapped into the device: mi_lte_memcpy_* move mid-size copies through it with a kernel
     std::map<uint64_t, TurboTables> turbo_tables; // key = K | (spec << 32)
     std::map<uint32_t, RmTables>    rm_tables;    // key = K
     std::vector<void *> owned;                    // allocations released at destroy
@@ -101,6 +102,11 @@ void mi_prof_end(mi_lte_ctx *ctx);
         }                                                                                            \
     } while (0)
 
+// host <-> device copy AND wait through mi_lte_memcpy_* (ctx.cc): mid-size copies keep off the runtime's copy engines, whose first
+// use costs 7-9 ms each; for the tables, plan arrays and results the library itself moves
+#define MI_H2D(ctx, d, h, n) do { const int rc_ = mi_lte_memcpy_h2d((ctx), (d), (h), (n)); if (rc_ != MI_LTE_OK) return rc_; } while (0)
+#define MI_D2H(ctx, h, d, n) do { const int rc_ = mi_lte_memcpy_d2h((ctx), (h), (d), (n)); if (rc_ != MI_LTE_OK) return rc_; } while (0)
+
 // runs f when the enclosing function leaves without having disarmed it: the error paths of the plan constructors (every MI_HIP_CHECK
 // is a return) wait for the stream -- copies from host vectors that are about to go out of scope may still be queued -- and release
 // what was built so far
@@ -112,6 +118,8 @@ template <typename F> struct OnFail {
 template <typename F> OnFail<F> on_fail(F f) { return OnFail<F>{f}; }
 
 int   mi_ctx_reserve_scratch(mi_lte_ctx *ctx, size_t bytes);
+hipError_t mi_pinned_to_device(mi_lte_ctx *ctx, void *d_dst, const void *h_pinned, size_t bytes); // asynchronous, from / to a MAPPED pinned block (ctx.cc)
+hipError_t mi_device_to_pinned(mi_lte_ctx *ctx, void *h_pinned, const void *d_src, size_t bytes);
 // Where a kernel puts a few KB of results that the host reads right after the wait: pinned host memory mapped into the device (no copy
 // command, which costs more API time than a small call's kernel runs for).  *h and *d are the host's and the device's pointer to the same
 // bytes; MI_LTE_ERR_INVALID_ARG when bytes > MI_SMALL_BYTES (the caller then takes its scratch + copy route).

@@ -172,7 +172,7 @@ int stage_pair(mi_lte_ctx *ctx, HostCache *hc, const float *h_a, const float *h_
     if (in_place) {
         MI_HIP_CHECK(ctx, hipHostGetDevicePointer((void **)&d, hc->h_pin, 0));
     } else {
-        MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->d_in, hc->h_pin, 2 * n * 4, hipMemcpyHostToDevice, ctx->stream));
+        MI_HIP_CHECK(ctx, mi_pinned_to_device(ctx, hc->d_in, hc->h_pin, 2 * n * 4));
     }
     *d_a = d;
     *d_b = d + n;
@@ -365,7 +365,7 @@ int bind_subframe(mi_lte_ctx *ctx, HostCache *hc, const float *re, const float *
         memcpy(st + 2 * ROW, ce_re, n_ant * ROW * 4);
         memcpy(st + (2 + n_ant) * ROW, ce_im, n_ant * ROW * 4);
     }
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->d_sub, st, bytes, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, mi_pinned_to_device(ctx, hc->d_sub, st, bytes));
     hc->sub_host = re; hc->sub_n_ant = n_ant; hc->sub_ul = ul; hc->sub_fp = fp;
     hc->n_upload++;
     return MI_LTE_OK;
@@ -862,10 +862,10 @@ int mi_lte_rate_unmatch_turbo_host(mi_lte_ctx *ctx, const float *h_e, uint32_t N
     MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
     memcpy(hc->h_pin, h_e, (size_t)N_e * 4);
     float *d_e = (float *)hc->d_in, *d_d = (float *)(hc->d_in + e_bytes);
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(d_e, hc->h_pin, (size_t)N_e * 4, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, mi_pinned_to_device(ctx, d_e, hc->h_pin, (size_t)N_e * 4));
     rc = mi_lte_rate_unmatch_turbo_batch(ctx, d_e, N_e, N_dummy_bits, C, tx_mode, N_soft, M_dl_harq, chan_type, rv_idx, 1, d_d);
     if (rc != MI_LTE_OK) return rc;
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(hc->h_pin, d_d, d_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP_CHECK(ctx, mi_device_to_pinned(ctx, hc->h_pin, d_d, d_bytes));
     MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
     memcpy(h_d, hc->h_pin, d_bytes);
     *N_d = 3 * N_dummy_bits;

@@ -511,7 +511,7 @@ int mi_lte_pdcch_plan_create(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, float ph
     auto up = [&](const void *h, size_t bytes, void **d) -> int {
         if (hipMalloc(d, bytes ? bytes : 4) != hipSuccess) return -1;
         pl->owned.push_back(*d);
-        return hipMemcpyAsync(*d, h, bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess ? 0 : -1;
+        return mi_lte_memcpy_h2d(ctx, *d, h, bytes) == MI_LTE_OK ? 0 : -1;
     };
     void *d_cells, *d_pcf, *d_cand, *d_rm;
     if (up(cells.data(), cells.size() * 4, &d_cells) || up(pcf.data(), pcf.size() * 4, &d_pcf) || up(cand.data(), cand.size() * 4, &d_cand) ||
@@ -672,7 +672,7 @@ int mi_lte_pdcch_decode_run(mi_lte_ctx *ctx, mi_lte_pdcch_plan *pl, const float 
     std::vector<PdcchResult> res_copy;
     if (!h_res) {
         res_copy.resize(n_units);
-        MI_HIP_CHECK(ctx, hipMemcpyAsync(res_copy.data(), d_res, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        MI_D2H(ctx, res_copy.data(), d_res, res_bytes);
     }
     MI_HIP_CHECK(ctx, h_res ? mi_stream_wait(ctx, n_units) : hipStreamSynchronize(ctx->stream)); // (a copy into pageable memory is done when the runtime says so)
     const PdcchResult *res = h_res ? h_res : res_copy.data();
@@ -738,7 +738,7 @@ int mi_lte_pbch_decode_run(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const floa
     std::vector<PbchResult> res_copy;
     if (!h_res) {
         res_copy.resize(n_units);
-        MI_HIP_CHECK(ctx, hipMemcpyAsync(res_copy.data(), d_res, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        MI_D2H(ctx, res_copy.data(), d_res, res_bytes);
     }
     MI_HIP_CHECK(ctx, h_res ? mi_stream_wait(ctx, n_units) : hipStreamSynchronize(ctx->stream));
     const PbchResult *res = h_res ? h_res : res_copy.data();

@@ -236,7 +236,7 @@ static int prach_bluestein_tables(mi_lte_ctx *ctx, uint32_t N_ZC, float2 **d_chi
     float2 *d = nullptr;
     MI_HIP_CHECK(ctx, hipMalloc((void **)&d, sizeof(float2) * tab.size()));
     ctx->owned.push_back(d);
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(d, tab.data(), sizeof(float2) * tab.size(), hipMemcpyHostToDevice, ctx->stream));
+    MI_H2D(ctx, d, tab.data(), sizeof(float2) * tab.size());
     MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
     cached = d;
     *d_chirp = d; *d_bspec = d + 1024; *d_tw = d + 1024 + BL;
@@ -313,7 +313,7 @@ static int prach_plan_common(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const mi
         }
     }
     MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_xu_fft, sizeof(float2) * xu.size()));
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_xu_fft, xu.data(), sizeof(float2) * xu.size(), hipMemcpyHostToDevice, ctx->stream));
+    MI_H2D(ctx, pl->d_xu_fft, xu.data(), sizeof(float2) * xu.size());
     int rcb = prach_bluestein_tables(ctx, N_ZC, &pl->d_chirp, &pl->d_bspec, &pl->d_tw);
     if (rcb != MI_LTE_OK) return rcb;
     MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
@@ -379,7 +379,7 @@ int mi_lte_prach_detect_run(mi_lte_ctx *ctx, mi_lte_prach_plan *pl, const void *
     std::vector<CorrOut> co_copy;
     if (!h_co) {
         co_copy.resize((size_t)n_occ * pl->n_roots);
-        MI_HIP_CHECK(ctx, hipMemcpyAsync(co_copy.data(), d_co, co_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        MI_D2H(ctx, co_copy.data(), d_co, co_bytes);
     }
     MI_HIP_CHECK(ctx, h_co ? mi_stream_wait(ctx, n_occ) : hipStreamSynchronize(ctx->stream)); // (a copy into pageable memory is done when the runtime says so)
     const CorrOut *co = h_co ? h_co : co_copy.data();

@@ -198,16 +198,16 @@ int fft_and_corr(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const void *a, const
     if (rc0 != MI_LTE_OK) return rc0;
     char *base = (char *)ctx->scratch;
     d_win.p = base + off[0]; d_rows.p = base + off[1]; d_seq.p = base + off[2]; d_z0.p = base + off[3]; d_out.p = base + off[4];
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(d_win.p, win.data(), 8 * n_rows, hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(d_seq.p, seq.data(), seq.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(d_z0.p, z0.data(), 4 * n_seq, hipMemcpyHostToDevice, ctx->stream));
+    MI_H2D(ctx, d_win.p, win.data(), 8 * n_rows);
+    MI_H2D(ctx, d_seq.p, seq.data(), seq.size() * 8);
+    MI_H2D(ctx, d_z0.p, z0.data(), 4 * n_seq);
     int rc = mi_fft_rows(ctx, cfg, a, b, (const uint64_t *)d_win.p, n_rows, (float *)d_rows.p);
     if (rc != MI_LTE_OK) return rc;
     MI_LAUNCH(ctx, "k_seq_corr", k_seq_corr, dim3((n_seq + 63) / 64, n_rows), dim3(64), 0, (const float *)d_rows.p, n_rows, (const float2 *)d_seq.p,
               (const uint32_t *)d_z0.p, n_seq, (float2 *)d_out.p);
     MI_HIP_CHECK(ctx, hipGetLastError());
     h_out.resize((size_t)n_rows * n_seq);
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(h_out.data(), d_out.p, h_out.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    MI_D2H(ctx, h_out.data(), d_out.p, h_out.size() * 8);
     MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return MI_LTE_OK;
 }
@@ -283,7 +283,7 @@ int mi_lte_coarse_timing_run(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const vo
     MI_HIP_CHECK(ctx, hipGetLastError());
     // ---- the reference's decisions on the n_slot accumulated values (:5746-5805)
     std::vector<float> c(2 * 15360 + 1, 0.0f); // dl_timing_abs_corr[LIBLTE_PHY_N_SAMPS_PER_SLOT_30_72MHZ*2] (liblte_phy.h:475)
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(c.data(), d_acc, (size_t)g.n_slot * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MI_D2H(ctx, c.data(), d_acc, (size_t)g.n_slot * 4);
     MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t ns = g.n_slot, sym_else = g.N + g.cpe, n_blank = sym_else / 10;
     float corr_mean = 0;
@@ -318,10 +318,10 @@ int mi_lte_coarse_timing_run(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const vo
         uint32_t pos[5];
         for (uint32_t i = 0; i < n_peaks; i++) pos[i] = (uint32_t)peak[i];
         std::vector<float2> pk((size_t)n_peaks * N_slots);
-        MI_HIP_CHECK(ctx, hipMemcpyAsync(d_pos, pos, 4 * n_peaks, hipMemcpyHostToDevice, ctx->stream));
+        MI_H2D(ctx, d_pos, pos, 4 * n_peaks);
         MI_LAUNCH(ctx, "k_cp_gather", k_cp_gather, dim3((N_slots + 63) / 64, n_peaks), dim3(64), 0, (const float2 *)d_corr, g.n_slot, N_slots,
                   (const uint32_t *)d_pos, d_pk);
-        MI_HIP_CHECK(ctx, hipMemcpyAsync(pk.data(), d_pk, pk.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        MI_D2H(ctx, pk.data(), d_pk, pk.size() * 8);
         MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         float freq_err[5] = {0, 0, 0, 0, 0};
         for (uint32_t s = 0; s < N_slots; s++)

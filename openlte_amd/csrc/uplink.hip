@@ -526,11 +526,11 @@ int mi_pusch_plan_create_impl(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const m
     MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_e_len, sizeof(uint32_t) * n_alloc));
     MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_cb_alloc, sizeof(uint32_t) * n_alloc));
     MI_HIP_CHECK(ctx, hipMalloc((void **)&pl->d_e, pl->e_bytes ? pl->e_bytes : 64));
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_allocs, h_allocs, sizeof(mi_lte_pdsch_alloc) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_desc, desc.data(), sizeof(PuschDesc) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_dmrs, dmrs.data(), sizeof(float) * dmrs.size(), hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_e_off, pl->h_e_off.data(), sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_cb_alloc, cb_alloc.data(), sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
+    MI_H2D(ctx, pl->d_allocs, h_allocs, sizeof(mi_lte_pdsch_alloc) * n_alloc);
+    MI_H2D(ctx, pl->d_desc, desc.data(), sizeof(PuschDesc) * n_alloc);
+    MI_H2D(ctx, pl->d_dmrs, dmrs.data(), sizeof(float) * dmrs.size());
+    MI_H2D(ctx, pl->d_e_off, pl->h_e_off.data(), sizeof(uint32_t) * n_alloc);
+    MI_H2D(ctx, pl->d_cb_alloc, cb_alloc.data(), sizeof(uint32_t) * n_alloc);
     MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
     guard.armed = false;
     *out = pl;
@@ -635,8 +635,8 @@ int mi_lte_pucch_decode_run(mi_lte_ctx *ctx, uint32_t N_rb_ul, uint32_t N_ant, c
         memcpy(h_base, res.data(), b_res);
         memcpy(h_base + o_tab, h_tables, b_tab);
     } else {
-        MI_HIP_CHECK(ctx, hipMemcpyAsync(base, res.data(), b_res, hipMemcpyHostToDevice, ctx->stream));
-        MI_HIP_CHECK(ctx, hipMemcpyAsync(base + o_tab, h_tables, b_tab, hipMemcpyHostToDevice, ctx->stream));
+        MI_H2D(ctx, base, res.data(), b_res);
+        MI_H2D(ctx, base + o_tab, h_tables, b_tab);
     }
     MI_LAUNCH(ctx, "k_pucch_decode", k_pucch_decode, dim3(n_res), dim3(64), 0, d_subframes, (uint32_t)mi_lte_ul_subframe_floats(), N_rb_ul, N_ant,
               (const PucchRes *)base, (const float *)(base + o_tab), (uint8_t *)(base + o_out));
@@ -644,7 +644,7 @@ int mi_lte_pucch_decode_run(mi_lte_ctx *ctx, uint32_t N_rb_ul, uint32_t N_ant, c
     std::vector<uint8_t> o_copy;
     if (!h_base) {
         o_copy.resize(b_out);
-        MI_HIP_CHECK(ctx, hipMemcpyAsync(o_copy.data(), base + o_out, b_out, hipMemcpyDeviceToHost, ctx->stream));
+        MI_D2H(ctx, o_copy.data(), base + o_out, b_out);
     }
     MI_HIP_CHECK(ctx, h_base ? mi_stream_wait(ctx, n_res) : hipStreamSynchronize(ctx->stream)); // (a copy into pageable memory is done when the runtime says so)
     const uint8_t *o = h_base ? (const uint8_t *)h_base + o_out : o_copy.data();

@@ -16,7 +16,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <ctime>
+#include <initializer_list>
 #include <vector>
 
 #include "liblte_mac.h"
@@ -57,6 +59,15 @@ static void report_sib2(const LIBLTE_RRC_SYS_INFO_BLOCK_TYPE_2_STRUCT *b)
            (int)b->time_alignment_timer);
 }
 
+static void probe(mi_lte_ctx *ctx, const char *where)
+{
+    if (!getenv("MI_LTE_SCAN_PROBE")) return;
+    void *d; std::vector<uint8_t> h(30720);
+    mi_lte_malloc(ctx, 30720, &d); mi_lte_memset(ctx, d, 1, 30720); mi_lte_sync(ctx);
+    double t0 = now_s(); mi_lte_memcpy_d2h(ctx, h.data(), d, 30720);
+    fprintf(stderr, "  probe %-22s: 30 KB to the host in %.0f us\n", where, 1e6 * (now_s() - t0));
+    mi_lte_free(ctx, d);
+}
 // One batch of subframes of one cell through front end -> PCFICH / PDCCH -> PDSCH of the first allocation of every subframe whose
 // control region decoded (what the per-call scanner hands to liblte_phy_pdsch_channel_decode: pdcch.alloc[0], pdcch.N_symbs).
 struct Batch {
@@ -69,11 +80,45 @@ struct Batch {
     uint32_t                      stride = 0;
 };
 
+// a device array that is kept between batches and only ever grows (hipFree costs 0.2 ms a call, a plan's set-up ten of them)
+struct DevBuf {
+    void  *p = nullptr;
+    size_t cap = 0;
+    void *get(mi_lte_ctx *ctx, size_t bytes)
+    {
+        if (bytes > cap) {
+            if (p) mi_lte_free(ctx, p);
+            cap = bytes + bytes / 2;
+            if (mi_lte_malloc(ctx, cap, &p) != MI_LTE_OK) { fprintf(stderr, "mi_lte_malloc failed: %s\n", mi_lte_last_error(ctx)); exit(5); }
+        }
+        return p;
+    }
+    void release(mi_lte_ctx *ctx) { if (p) mi_lte_free(ctx, p); p = nullptr; cap = 0; }
+};
+
 struct Scanner {
     mi_lte_ctx *ctx = nullptr;
     float      *d_i = nullptr, *d_q = nullptr;
     uint32_t    fft = 0, fs_hz = 0, n = 0;
     double      t_stage[3] = {0, 0, 0};
+    // kept from batch to batch: the unit arrays, the subframes, the outputs, and the two plans (re-made when the cell's geometry or a
+    // capacity changes -- i.e. once per cell here)
+    DevBuf             b_start, b_sf, b_cell, b_sub, b_out, b_st;
+    mi_lte_pdcch_plan *cp = nullptr;
+    mi_lte_pdsch_plan *pp = nullptr;
+    mi_lte_dl_cfg      cp_cfg = {0, 0, 0, 0}, pp_cfg = {0, 0, 0, 0};
+    uint32_t           cp_cell = ~0u, pp_alloc = 0;
+    float              cp_res = -1;
+    size_t             pp_soft = 0;
+
+    static bool same(const mi_lte_dl_cfg &a, const mi_lte_dl_cfg &b) { return a.fft_size == b.fft_size && a.N_rb_dl == b.N_rb_dl && a.N_ant == b.N_ant && a.sample_format == b.sample_format; }
+    void release()
+    {
+        if (cp) mi_lte_pdcch_plan_destroy(ctx, cp);
+        if (pp) mi_lte_pdsch_plan_destroy(ctx, pp);
+        cp = nullptr; pp = nullptr;
+        for (DevBuf *d : {&b_start, &b_sf, &b_cell, &b_sub, &b_out, &b_st}) d->release(ctx);
+    }
 
     void run(Batch &b, uint32_t N_rb_dl, uint32_t N_ant, uint32_t cell, float phich_res)
     {
@@ -83,25 +128,25 @@ struct Scanner {
         b.status.assign(nu, -1);
         if (nu == 0) return;
         mi_lte_dl_cfg cfg = {fft, N_rb_dl, N_ant, MI_LTE_IQ_F32_PLANAR};
-        uint64_t     *d_start;
-        uint32_t     *d_sf, *d_cell;
-        float        *d_sub;
         std::vector<uint32_t> cells(nu, cell);
-        CK(mi_lte_malloc(ctx, sizeof(uint64_t) * nu, (void **)&d_start));
-        CK(mi_lte_malloc(ctx, sizeof(uint32_t) * nu, (void **)&d_sf));
-        CK(mi_lte_malloc(ctx, sizeof(uint32_t) * nu, (void **)&d_cell));
-        CK(mi_lte_malloc(ctx, sizeof(float) * mi_lte_subframe_floats(N_ant) * nu, (void **)&d_sub));
+        uint64_t *d_start = (uint64_t *)b_start.get(ctx, sizeof(uint64_t) * nu);
+        uint32_t *d_sf = (uint32_t *)b_sf.get(ctx, sizeof(uint32_t) * nu), *d_cell = (uint32_t *)b_cell.get(ctx, sizeof(uint32_t) * nu);
+        float    *d_sub = (float *)b_sub.get(ctx, sizeof(float) * mi_lte_subframe_floats(N_ant) * nu);
         CK(mi_lte_memcpy_h2d(ctx, d_start, b.start.data(), sizeof(uint64_t) * nu));
         CK(mi_lte_memcpy_h2d(ctx, d_sf, b.sf.data(), sizeof(uint32_t) * nu));
         CK(mi_lte_memcpy_h2d(ctx, d_cell, cells.data(), sizeof(uint32_t) * nu));
         double t0 = now_s();
         CK(mi_lte_dl_frontend_batch(ctx, &cfg, d_i, d_q, d_start, d_sf, d_cell, nu, d_sub));
         CK(mi_lte_sync(ctx));
+        probe(ctx, "after front end");
         t_stage[0] += now_s() - t0; t0 = now_s();
-        mi_lte_pdcch_plan *cp;
-        CK(mi_lte_pdcch_plan_create(ctx, &cfg, phich_res, 0, 0, &cell, 1, &cp));
+        if (!cp || !same(cfg, cp_cfg) || cell != cp_cell || phich_res != cp_res) {
+            if (cp) mi_lte_pdcch_plan_destroy(ctx, cp);
+            CK(mi_lte_pdcch_plan_create(ctx, &cfg, phich_res, 0, 0, &cell, 1, &cp));
+            cp_cfg = cfg; cp_cell = cell; cp_res = phich_res;
+        }
         CK(mi_lte_pdcch_decode_run(ctx, cp, d_sub, d_sf, d_cell, nu, b.rc.data(), b.cfi.data(), b.n_symbs.data(), b.n_dci.data(), b.dci.data()));
-        mi_lte_pdcch_plan_destroy(ctx, cp);
+        probe(ctx, "after pdcch");
         t_stage[1] += now_s() - t0; t0 = now_s();
         // the first allocation of every subframe whose control region decoded; transport blocks of more than one code block are outside
         // the envelope (the reference's own path for them is broken) and count as failed decodes
@@ -120,29 +165,36 @@ struct Scanner {
             soft += ((size_t)(14 - a.n_pdcch_symbs) * a.N_prb * 12 * qm + 63) & ~(size_t)63;
         }
         if (!al.empty()) {
-            mi_lte_pdsch_plan *pp;
-            CK(mi_lte_pdsch_plan_create_dynamic(ctx, &cfg, (uint32_t)al.size(), soft, &pp));
+            if (!pp || !same(cfg, pp_cfg) || al.size() > pp_alloc || soft > pp_soft) { // room for every subframe of a batch of this size to carry a full-band QPSK block
+                if (pp) mi_lte_pdsch_plan_destroy(ctx, pp);
+                pp_alloc = std::max<uint32_t>((uint32_t)al.size(), nu);
+                pp_soft  = std::max(soft, (size_t)pp_alloc * (((size_t)13 * N_rb_dl * 12 * 2 + 63) & ~(size_t)63));
+                CK(mi_lte_pdsch_plan_create_dynamic(ctx, &cfg, pp_alloc, pp_soft, &pp));
+                pp_cfg = cfg;
+            }
+            const double ta = now_s();
             CK(mi_lte_pdsch_plan_assign(ctx, pp, 2, al.data(), (uint32_t)al.size()));
             b.stride = mi_lte_pdsch_plan_out_stride(pp);
-            uint8_t *d_out;
-            int32_t *d_st;
-            CK(mi_lte_malloc(ctx, (size_t)al.size() * b.stride, (void **)&d_out));
-            CK(mi_lte_malloc(ctx, sizeof(int32_t) * al.size(), (void **)&d_st));
+            uint8_t *d_out = (uint8_t *)b_out.get(ctx, (size_t)al.size() * b.stride);
+            int32_t *d_st = (int32_t *)b_st.get(ctx, sizeof(int32_t) * al.size());
+            const double tb = now_s();
             CK(mi_lte_pdsch_decode_run(ctx, pp, d_sub, d_sf, d_cell, d_out, d_st));
+            const double tc = now_s();
             std::vector<int32_t> st(al.size());
             std::vector<uint8_t> ob((size_t)al.size() * b.stride);
             CK(mi_lte_memcpy_d2h(ctx, st.data(), d_st, sizeof(int32_t) * al.size()));
+            const double td = now_s();
             CK(mi_lte_memcpy_d2h(ctx, ob.data(), d_out, ob.size()));
+            if (getenv("MI_LTE_SCAN_TRACE"))
+                fprintf(stderr, "  pdsch stage of %u units, %zu allocations: plan %.0f us, assign %.0f us, decode_run (launches) %.0f us, wait + verdicts %.0f us, %zu bytes of transport blocks %.0f us\n",
+                        nu, al.size(), 1e6 * (ta - t0), 1e6 * (tb - ta), 1e6 * (tc - tb), 1e6 * (td - tc), ob.size(), 1e6 * (now_s() - td));
             b.bits.assign((size_t)nu * b.stride, 0);
             for (size_t k = 0; k < al.size(); k++) {
                 b.status[unit_of[k]] = st[k];
                 memcpy(&b.bits[(size_t)unit_of[k] * b.stride], &ob[k * b.stride], b.stride);
             }
-            mi_lte_free(ctx, d_out); mi_lte_free(ctx, d_st);
-            mi_lte_pdsch_plan_destroy(ctx, pp);
         }
         t_stage[2] += now_s() - t0;
-        mi_lte_free(ctx, d_start); mi_lte_free(ctx, d_sf); mi_lte_free(ctx, d_cell); mi_lte_free(ctx, d_sub);
     }
     // unit u's decoded transport block as the message the RRC unpackers take
     static void to_msg(const Batch &b, uint32_t u, LIBLTE_BIT_MSG_STRUCT *msg)
@@ -180,6 +232,7 @@ int main(int argc, char **argv)
     const double t_start = now_s();
     if (mi_lte_ctx_create(0, &s.ctx) != MI_LTE_OK) { fprintf(stderr, "no usable gfx950 device (the library has no CPU path)\n"); return 3; }
     mi_lte_ctx *ctx = s.ctx;
+    probe(ctx, "after ctx_create");
     // the capture in HBM: int8 pairs once, then planar float with two frames of zeros behind it (the per-call scanner's calloc'ed pad)
     const uint64_t pad = 2ull * n_frame, n_buf = (uint64_t)s.n + pad;
     int8_t *d_raw;
@@ -198,6 +251,7 @@ int main(int argc, char **argv)
     mi_lte_coarse_timing timing;
     CK(mi_lte_coarse_timing_run(ctx, &cfg6, s.d_i, s.d_q, 0, 160, &timing));
     const double t_coarse = now_s() - t_start;
+    probe(ctx, "after coarse timing");
     printf("coarse timing: %u correlation peak(s)\n", timing.n_corr_peaks);
 
     static LIBLTE_BIT_MSG_STRUCT            msg;
@@ -233,6 +287,7 @@ int main(int argc, char **argv)
             CK(mi_lte_pbch_decode_run(ctx, &cfg4, d_sub, d_cell, 1, &N_ant, &sfn_off, &mib_bits));
             mi_lte_free(ctx, d_st); mi_lte_free(ctx, d_sf); mi_lte_free(ctx, d_cell); mi_lte_free(ctx, d_sub);
         }
+        probe(ctx, "after pbch");
         if (N_ant == 0) continue;
         msg.N_bits = 24;
         for (uint32_t k = 0; k < 24; k++) msg.msg[k] = (mib_bits >> (23 - k)) & 1u;
@@ -298,6 +353,7 @@ int main(int argc, char **argv)
     fprintf(stderr, "timing: total %.4f s; up to the coarse timing (HIP start-up, upload) %.4f s; all-subframes batch (front end + pdcch + pdsch) "
                     "%.4f s for %u subframes = %.1f us per subframe; stages: front end %.4f s, pdcch %.4f s, pdsch %.4f s\n",
             now_s() - t_start, t_coarse, t_subframes, n_subframes, n_subframes ? 1e6 * t_subframes / n_subframes : 0.0, s.t_stage[0], s.t_stage[1], s.t_stage[2]);
+    s.release();
     mi_lte_free(ctx, s.d_i); mi_lte_free(ctx, s.d_q);
     mi_lte_ctx_destroy(ctx);
     return cells ? 0 : 1;

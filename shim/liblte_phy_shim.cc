@@ -90,9 +90,60 @@ void to_mi_alloc(const LIBLTE_PHY_ALLOCATION_STRUCT *a, mi_lte_pdsch_alloc *o)
 }
 } // namespace
 
-// liblte_phy_init (liblte_phy.h:606-612, impl. liblte_phy.cc:2154-2522): the reference's own initialisation (compiled under the name
-// liblte_phy_init_cpu, shim/Makefile) builds the struct -- tables, FFT plans, everything the entry points that are NOT replaced read --
-// and the struct it returns is registered here with a GPU context of its own.
+// ---- lifetime of a LIBLTE_PHY_STRUCT.  Two builds of this file:
+//
+//   default                     : liblte_phy_init / liblte_phy_cleanup WRAP the reference's own (compiled under the names *_cpu, shim/Makefile):
+//                                 the struct is the reference's in every field, so the entry points that are NOT replaced (TX side, UL init,
+//                                 TBS helpers) keep working next to the replaced ones.
+//   -DMI_LTE_SHIM_OWN_LIFECYCLE : liblte_phy_init / liblte_phy_cleanup / liblte_phy_update_n_rb_dl are DEFINED here and no object of the
+//                                 reference's PHY is linked at all (shim/Makefile: scan_gpu_pure = scan_demo.cc + liblte_rrc + this file +
+//                                 libmi_lte.so).  That is the receive side of LTE_fdd_dl_file_scan: its ten liblte_phy calls are the three
+//                                 above and seven replaced entry points.  The struct is the header's (layout is ABI); the fields a caller or
+//                                 a replaced entry point reads are filled as liblte_phy.cc:2210-2335 and :2592-2647 fill them
+//                                 (shim/lifecycle_check.cc compares them with the reference's for every sampling rate x bandwidth), the
+//                                 reference's private work areas are zero, its FFTW plans and the transmitter's PDCCH permutation /
+//                                 CRS storage (:2292-2307) do not exist -- nothing on the receive path reads them.
+namespace {
+void register_struct(LIBLTE_PHY_STRUCT *phy)
+{
+    std::shared_ptr<Entry> e = make_entry(), stale;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto                        it = g_ctx.find(phy);
+        if (it != g_ctx.end()) stale = it->second; // a struct freed behind the shim's back (never cleaned up) whose address came round again
+        g_ctx[phy] = e;
+    }
+    if (stale) {
+        std::lock_guard<std::mutex> call(stale->mu);
+        if (stale->ctx) mi_lte_ctx_destroy(stale->ctx);
+        stale->ctx = nullptr;
+    }
+}
+void unregister_struct(LIBLTE_PHY_STRUCT *phy)
+{
+    std::shared_ptr<Entry> e;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto                        it = g_ctx.find(phy);
+        if (it != g_ctx.end()) { e = it->second; g_ctx.erase(it); }
+    }
+    if (!e) return;
+    std::lock_guard<std::mutex> call(e->mu); // waits for a call that is still running on it
+    if (e->ctx && getenv("MI_LTE_SHIM_STATS")) { // how often a decode call found the struct it was handed already on the device
+        uint64_t reuse = 0, upload = 0;
+        uint32_t plans = 0;
+        mi_lte_host_cache_stats(e->ctx, &reuse, &upload, &plans);
+        fprintf(stderr, "mi_lte shim: device subframe reused %llu times, uploaded %llu times; %u cached plans\n", (unsigned long long)reuse,
+                (unsigned long long)upload, plans);
+    }
+    if (e->ctx) mi_lte_ctx_destroy(e->ctx);
+    e->ctx = nullptr; // a caller that was blocked on the mutex, or still holds the entry, fails cleanly
+}
+} // namespace
+
+#ifndef MI_LTE_SHIM_OWN_LIFECYCLE
+// liblte_phy_init (liblte_phy.h:606-612, impl. liblte_phy.cc:2210-2335): the reference's own initialisation builds the struct -- tables, FFT
+// plans, everything the entry points that are NOT replaced read -- and the struct it returns is registered here with a GPU context of its own.
 LIBLTE_ERROR_ENUM liblte_phy_init_cpu(LIBLTE_PHY_STRUCT **phy_struct, LIBLTE_PHY_FS_ENUM fs, uint16 N_id_cell, uint8 N_ant, uint32 N_rb_dl, uint32 N_sc_rb_dl,
                                       float phich_res);
 LIBLTE_ERROR_ENUM liblte_phy_init(LIBLTE_PHY_STRUCT **phy_struct, LIBLTE_PHY_FS_ENUM fs, uint16 N_id_cell, uint8 N_ant, uint32 N_rb_dl, uint32 N_sc_rb_dl,
@@ -100,18 +151,7 @@ LIBLTE_ERROR_ENUM liblte_phy_init(LIBLTE_PHY_STRUCT **phy_struct, LIBLTE_PHY_FS_
 {
     const LIBLTE_ERROR_ENUM err = liblte_phy_init_cpu(phy_struct, fs, N_id_cell, N_ant, N_rb_dl, N_sc_rb_dl, phich_res);
     if (err != LIBLTE_SUCCESS || !phy_struct || !*phy_struct) return err;
-    std::shared_ptr<Entry> e = make_entry(), stale;
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        auto                        it = g_ctx.find(*phy_struct);
-        if (it != g_ctx.end()) stale = it->second; // a struct freed behind the shim's back (never cleaned up) whose address came round again
-        g_ctx[*phy_struct] = e;
-    }
-    if (stale) {
-        std::lock_guard<std::mutex> call(stale->mu);
-        if (stale->ctx) mi_lte_ctx_destroy(stale->ctx);
-        stale->ctx = nullptr;
-    }
+    register_struct(*phy_struct);
     return err;
 }
 
@@ -121,28 +161,87 @@ LIBLTE_ERROR_ENUM liblte_phy_init(LIBLTE_PHY_STRUCT **phy_struct, LIBLTE_PHY_FS_
 LIBLTE_ERROR_ENUM liblte_phy_cleanup_cpu(LIBLTE_PHY_STRUCT *phy_struct);
 LIBLTE_ERROR_ENUM liblte_phy_cleanup(LIBLTE_PHY_STRUCT *phy_struct)
 {
-    std::shared_ptr<Entry> e;
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        auto                        it = g_ctx.find(phy_struct);
-        if (it != g_ctx.end()) { e = it->second; g_ctx.erase(it); }
-    }
-    if (e) {
-        {
-            std::lock_guard<std::mutex> call(e->mu); // waits for a call that is still running on it
-            if (e->ctx && getenv("MI_LTE_SHIM_STATS")) { // how often a decode call found the struct it was handed already on the device
-                uint64_t reuse = 0, upload = 0;
-                uint32_t plans = 0;
-                mi_lte_host_cache_stats(e->ctx, &reuse, &upload, &plans);
-                fprintf(stderr, "mi_lte shim: device subframe reused %llu times, uploaded %llu times; %u cached plans\n", (unsigned long long)reuse,
-                        (unsigned long long)upload, plans);
-            }
-            if (e->ctx) mi_lte_ctx_destroy(e->ctx);
-            e->ctx = nullptr; // a caller that was blocked on the mutex, or still holds the entry, fails cleanly
-        }
-    }
+    unregister_struct(phy_struct);
     return liblte_phy_cleanup_cpu(phy_struct);
 }
+#else
+// liblte_phy_update_n_rb_dl (liblte_phy.h:620-621, impl. liblte_phy.cc:2592-2647): a bandwidth is accepted when its sub-carriers fit the
+// sampling rate's transform (at 30.72 MHz the reference accepts anything); N_rb_ul follows N_rb_dl, the pad is the unused half band.
+LIBLTE_ERROR_ENUM liblte_phy_update_n_rb_dl(LIBLTE_PHY_STRUCT *phy_struct, uint32 N_rb_dl)
+{
+    if (phy_struct == NULL) return LIBLTE_ERROR_INVALID_INPUTS;
+    static const uint32 rb_of_bw[6] = {LIBLTE_PHY_N_RB_DL_1_4MHZ, LIBLTE_PHY_N_RB_DL_3MHZ, LIBLTE_PHY_N_RB_DL_5MHZ,
+                                       LIBLTE_PHY_N_RB_DL_10MHZ, LIBLTE_PHY_N_RB_DL_15MHZ, LIBLTE_PHY_N_RB_DL_20MHZ};
+    uint32 n_bw; // how many of the six bandwidths the sampling rate carries
+    switch (phy_struct->N_samps_per_symb) {
+    case LIBLTE_PHY_N_SAMPS_PER_SYMB_1_92MHZ:  n_bw = 1; break;
+    case LIBLTE_PHY_N_SAMPS_PER_SYMB_3_84MHZ:  n_bw = 2; break;
+    case LIBLTE_PHY_N_SAMPS_PER_SYMB_7_68MHZ:  n_bw = 3; break;
+    case LIBLTE_PHY_N_SAMPS_PER_SYMB_15_36MHZ: n_bw = 4; break;
+    case LIBLTE_PHY_N_SAMPS_PER_SYMB_30_72MHZ: n_bw = 6; break;
+    default: return LIBLTE_ERROR_INVALID_INPUTS;
+    }
+    bool ok = n_bw == 6; // (30.72 MHz: no test in the reference, :2606-2609)
+    for (uint32 b = 0; b < n_bw && !ok; b++) ok = rb_of_bw[b] == N_rb_dl;
+    if (!ok) return LIBLTE_ERROR_INVALID_INPUTS;
+    phy_struct->FFT_size     = phy_struct->N_samps_per_symb; // LIBLTE_PHY_FFT_SIZE_* = LIBLTE_PHY_N_SAMPS_PER_SYMB_* (liblte_phy.h:100-104, :142-170)
+    phy_struct->N_rb_dl      = N_rb_dl;
+    phy_struct->N_rb_ul      = N_rb_dl;
+    phy_struct->FFT_pad_size = (phy_struct->FFT_size - N_rb_dl * phy_struct->N_sc_rb_dl) / 2;
+    return LIBLTE_SUCCESS;
+}
+
+// liblte_phy_init (liblte_phy.h:606-612, impl. liblte_phy.cc:2210-2335), receive side: the sampling-rate geometry, the bandwidth (through
+// liblte_phy_update_n_rb_dl, whose verdict the reference ignores here, too), the PHICH group count, and a GPU context of the struct's own.
+LIBLTE_ERROR_ENUM liblte_phy_init(LIBLTE_PHY_STRUCT **phy_struct, LIBLTE_PHY_FS_ENUM fs, uint16 N_id_cell, uint8 N_ant, uint32 N_rb_dl, uint32 N_sc_rb_dl,
+                                  float phich_res)
+{
+    if (phy_struct == NULL) return LIBLTE_ERROR_INVALID_INPUTS;
+    LIBLTE_PHY_STRUCT *p = (LIBLTE_PHY_STRUCT *)calloc(1, sizeof(LIBLTE_PHY_STRUCT));
+    *phy_struct = p;
+    if (p == NULL) return LIBLTE_ERROR_INVALID_INPUTS;
+    uint32 scale; // 30.72 MHz / fs
+    switch (fs) {
+    case LIBLTE_PHY_FS_30_72MHZ: scale = 1; break;
+    case LIBLTE_PHY_FS_15_36MHZ: scale = 2; break;
+    case LIBLTE_PHY_FS_7_68MHZ:  scale = 4; break;
+    case LIBLTE_PHY_FS_3_84MHZ:  scale = 8; break;
+    case LIBLTE_PHY_FS_1_92MHZ:  scale = 16; break;
+    default: scale = 0; break; // (the reference leaves the fields unset)
+    }
+    if (scale) {
+        p->fs                = 30720000 / scale;
+        p->N_samps_per_symb  = LIBLTE_PHY_N_SAMPS_PER_SYMB_30_72MHZ / scale;
+        p->N_samps_cp_l_0    = LIBLTE_PHY_N_SAMPS_CP_L_0_30_72MHZ / scale;
+        p->N_samps_cp_l_else = LIBLTE_PHY_N_SAMPS_CP_L_ELSE_30_72MHZ / scale;
+        p->N_samps_per_slot  = LIBLTE_PHY_N_SAMPS_PER_SLOT_30_72MHZ / scale;
+        p->N_samps_per_subfr = LIBLTE_PHY_N_SAMPS_PER_SUBFR_30_72MHZ / scale;
+        p->N_samps_per_frame = LIBLTE_PHY_N_SAMPS_PER_FRAME_30_72MHZ / scale;
+    }
+    p->N_sc_rb_dl = N_sc_rb_dl;
+    p->N_sc_rb_ul = LIBLTE_PHY_N_SC_RB_UL;
+    (void)liblte_phy_update_n_rb_dl(p, N_rb_dl);
+    p->N_ant   = N_ant;
+    p->ul_init = false;
+    // PHICH groups (36.211 6.9): ceil(N_g * N_rb_dl / 8), twice that with the extended prefix
+    const uint32 groups = (uint32)ceilf((float)phich_res * ((float)p->N_rb_dl / (float)8));
+    const bool   normal = LIBLTE_PHY_N_SC_RB_DL_NORMAL_CP == p->N_sc_rb_dl;
+    p->N_group_phich = normal ? groups : 2 * groups;
+    p->N_sf_phich    = normal ? 4 : 2;
+    if (LIBLTE_PHY_INIT_N_ID_CELL_UNKNOWN != N_id_cell) p->N_id_cell_crs = N_id_cell; // (stored with the reference's CRS cache, which the replaced front end does not read)
+    register_struct(p);
+    return LIBLTE_SUCCESS;
+}
+
+// liblte_phy_cleanup (liblte_phy.h:636, impl. liblte_phy.cc:2524-2543): the GPU context, then the struct.
+LIBLTE_ERROR_ENUM liblte_phy_cleanup(LIBLTE_PHY_STRUCT *phy_struct)
+{
+    if (phy_struct == NULL) return LIBLTE_ERROR_INVALID_INPUTS;
+    unregister_struct(phy_struct);
+    free(phy_struct);
+    return LIBLTE_SUCCESS;
+}
+#endif
 
 LIBLTE_ERROR_ENUM liblte_phy_get_dl_subframe_and_ce(LIBLTE_PHY_STRUCT *phy_struct, float *i_samps, float *q_samps,
                                                     uint32 frame_start_idx, uint8 subfr_num, uint32 N_id_cell, uint8 N_ant,
@@ -328,7 +427,11 @@ LIBLTE_ERROR_ENUM liblte_phy_find_sss(LIBLTE_PHY_STRUCT *phy_struct, float *i_sa
 
 // ---- PUCCH formats 1 / 1a / 1b (LTE_fdd_enb_phy.cc:867)
 
+#ifndef MI_LTE_SHIM_OWN_LIFECYCLE
 extern int32 W_5_4_1_2[3][4]; // the reference's orthogonal-sequence table (liblte_phy.cc:161), still its own object
+#else
+static const int32 W_5_4_1_2[3][4] = {{1, 1, 1, 1}, {1, -1, 1, -1}, {1, -1, -1, 1}}; // 36.211 table 5.4.1-2 (the uplink needs the reference's liblte_phy_ul_init anyway)
+#endif
 
 LIBLTE_ERROR_ENUM liblte_phy_pucch_format_1_1a_1b_channel_decode(LIBLTE_PHY_STRUCT *phy_struct, LIBLTE_PHY_SUBFRAME_STRUCT *subframe,
                                                                  LIBLTE_PHY_PUCCH_FORMAT_ENUM format, uint32 N_id_cell, uint8 N_ant, uint32 N_1_p_pucch,

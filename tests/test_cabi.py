@@ -49,3 +49,16 @@ def test_product_never_touches_the_oracle():
             if re.search(r"\boracle\b", open(path, errors="ignore").read()):
                 bad.append(os.path.relpath(path, ROOT))
     assert not bad, bad
+
+
+def test_own_lifecycle_equals_the_references():
+    """shim/_build/lifecycle_check: the shim's own liblte_phy_init / liblte_phy_update_n_rb_dl / liblte_phy_cleanup against the
+    reference's (linked into the TEST binary under other names): return codes and every field a caller or a replaced entry point reads,
+    for every sampling rate x bandwidth x PHICH resource x prefix (liblte_phy.cc:2210-2335, :2592-2647).  Needs no GPU: without one the
+    struct simply has no context."""
+    import subprocess
+    exe = os.path.join(ROOT, "shim", "_build", "lifecycle_check")
+    if not os.path.exists(exe):
+        pytest.skip("shim/_build/lifecycle_check not built (needs the reference tree at build time)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "combinations equal" in r.stdout, r.stdout[-2000:]

@@ -272,6 +272,28 @@ def test_cell_scan_matches_reference_output(tmp_path, n_rb, cell, frames, fs):
             f.write("scan_cpu %s" % cpu.stderr)
 
 
+@pytest.mark.parametrize("n_rb,cell,frames,fs", [(6, 17, 30, "1.92"), (25, 301, 24, "7.68"), (100, 77, 12, "30.72")])
+def test_cell_scan_with_no_reference_phy_object_in_the_link(tmp_path, n_rb, cell, frames, fs):
+    """scan_gpu_pure = the same scanner source (scan_demo.cc) linked with NO object of the reference's PHY: liblte_phy_init,
+    liblte_phy_cleanup and liblte_phy_update_n_rb_dl are the shim's own (liblte_phy_shim.cc, -DMI_LTE_SHIM_OWN_LIFECYCLE), the other
+    seven calls of LTE_fdd_dl_file_scan are the replaced entry points.  Its report must equal the all-reference build's text, and the
+    executable must not contain a single function of the reference's PHY besides the fifteen the shim defines."""
+    build = os.path.join(ROOT, "shim", "_build")
+    gen, pure = os.path.join(build, "capture_gen"), os.path.join(build, "scan_gpu_pure")
+    if not (os.path.exists(gen) and os.path.exists(pure)):
+        pytest.skip("shim/_build/capture_gen / scan_gpu_pure not built (need the reference tree at build time)")
+    cap = os.path.join(str(tmp_path), "capture.bin")
+    subprocess.run([gen, cap, str(n_rb), str(cell), str(frames)], check=True, timeout=600)
+    want = open(os.path.join(ROOT, "tests", "golden", "scan_%drb_reference_cpu.txt" % n_rb)).read()
+    got = subprocess.run([pure, cap, fs], capture_output=True, text=True, timeout=900)
+    assert got.returncode == 0, got.stdout + got.stderr
+    assert got.stdout == want
+    syms = subprocess.run(["nm", "-C", "--defined-only", pure], capture_output=True, text=True).stdout
+    phy = sorted({l.split(" T ")[1].split("(")[0] for l in syms.splitlines() if " T liblte_phy_" in l})
+    assert len(phy) == 15 and "liblte_phy_init" in phy and "liblte_phy_update_n_rb_dl" in phy, phy
+    assert "pdcch_permute_pre_calc" not in syms and "turbo_decode" not in syms and "fftwf_" not in syms
+
+
 @pytest.mark.parametrize("n_rb,cell,frames,fs,cfo,lead", [(6, 17, 30, "1.92", 731, 311), (25, 301, 24, "7.68", -1180, 1000), (100, 77, 12, "30.72", 2350, 4321)])
 def test_batch_scanner_with_carrier_offset_matches_reference_output(tmp_path, n_rb, cell, frames, fs, cfo, lead):
     """The same scan on the library's BATCH entry points (shim/scan_batch.cc: no liblte_phy object linked, one launch per stage for all

@@ -371,7 +371,7 @@ static uint32_t qpp_size_at_least(uint32_t B)
 // Host side of a plan: group the allocations by code-block size, lay their soft bits out.  Fills everything but the device arrays;
 // cb_alloc receives the allocation index of every code-block slot, group after group.
 static int plan_layout(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, uint32_t N_pdcch_symbs, const mi_lte_pdsch_alloc *h_allocs, uint32_t n_alloc,
-                       std::vector<uint32_t> &cb_alloc)
+                       std::vector<uint32_t> &cb_alloc, bool prbs_checked = false)
 {
     const mi_lte_dl_cfg *cfg = &pl->cfg;
     pl->cfi       = N_pdcch_symbs;
@@ -402,7 +402,7 @@ static int plan_layout(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, uint32_t N_pdcch_
             ctx->err = "allocation outside the single-code-block envelope (tbs + 24 > 6144) or malformed";
             return MI_LTE_ERR_UNSUPPORTED;
         }
-        for (uint32_t s = 0; s < 2; s++) // a resource block past the carrier would be read out of the neighbouring symbol row
+        for (uint32_t s = 0; s < 2 && !prbs_checked; s++) // a resource block past the carrier would be read out of the neighbouring symbol row
             for (uint32_t i = 0; i < al.N_prb; i++)
                 if (al.prb[s][i] >= cfg->N_rb_dl) {
                     ctx->err = "allocation names a resource block outside the carrier";
@@ -568,6 +568,43 @@ int mi_lte_pdsch_plan_assign(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, uint32_t N_
 
 uint32_t mi_lte_pdsch_plan_n_alloc(const mi_lte_pdsch_plan *pl) { return pl ? pl->n_alloc : 0; }
 } // extern "C"
+
+// The host pipeline's assignment (pipeline.cc: one per chunk of a capture, tens of thousands of allocations each, on the thread that also
+// feeds the copy engines): the chunk's slice of the caller's list goes into the plan's staging block in ONE pass -- unit numbers made
+// chunk-local, every allocation tested once (mi_lte_pdsch_alloc_decodable's conditions), one outside the envelope replaced by a one-block
+// QPSK stand-in and its index reported -- instead of a copy, a test pass and the layout's own test pass.
+int mi_pdsch_plan_assign_slice(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, uint32_t N_pdcch_symbs, const mi_lte_pdsch_alloc *h_src, uint32_t n_alloc, uint32_t unit0,
+                               std::vector<uint32_t> *refused)
+{
+    if (!ctx || !pl || !pl->dynamic || pl->mapped || !h_src || n_alloc == 0 || N_pdcch_symbs < 1 || N_pdcch_symbs > 4) return MI_LTE_ERR_INVALID_ARG;
+    if (n_alloc > pl->cap_alloc) { ctx->err = "more allocations than the dynamic plan was created for"; return MI_LTE_ERR_INVALID_ARG; }
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    MI_HIP_CHECK(ctx, hipEventSynchronize(pl->staged)); // the previous assignment's copies have left the staging block
+    auto *sa = (mi_lte_pdsch_alloc *)pl->h_stage;
+    auto *so = (uint32_t *)(sa + pl->cap_alloc), *sc = so + pl->cap_alloc;
+    for (uint32_t i = 0; i < n_alloc; i++) {
+        mi_lte_pdsch_alloc &a = sa[i];
+        a = h_src[i];
+        a.unit -= unit0;
+        if (!mi_lte_pdsch_alloc_decodable(&pl->cfg, &a, N_pdcch_symbs)) {
+            // a DCI that passed its CRC by chance: the reference fails that one allocation (liblte_phy.cc:3690-3853); the slot keeps its place
+            a.N_prb = 1; a.prb[0][0] = a.prb[1][0] = 0; a.mod_type = 1; a.tbs = 16; a.rv_idx = 0; a.tx_mode = pl->cfg.N_ant == 1 ? 1 : 2;
+            if (a.n_pdcch_symbs > 4) a.n_pdcch_symbs = 0;
+            if (refused) refused->push_back(i);
+        }
+    }
+    std::vector<uint32_t> cb_alloc;
+    int rc = plan_layout(ctx, pl, N_pdcch_symbs, sa, n_alloc, cb_alloc, true);
+    if (rc != MI_LTE_OK) { pl->n_alloc = 0; return rc; }
+    if (pl->e_bytes > pl->cap_e_bytes) { pl->n_alloc = 0; ctx->err = "more soft bits than the dynamic plan was created for"; return MI_LTE_ERR_INVALID_ARG; }
+    memcpy(so, pl->h_e_off.data(), sizeof(uint32_t) * n_alloc);
+    memcpy(sc, cb_alloc.data(), sizeof(uint32_t) * n_alloc);
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_allocs, sa, sizeof(mi_lte_pdsch_alloc) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_e_off, so, sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_cb_alloc, sc, sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(ctx, hipEventRecord(pl->staged, ctx->stream));
+    return MI_LTE_OK;
+}
 void mi_pdsch_plan_wide_stride(mi_lte_pdsch_plan *pl) { pl->wide = true; (void)mi_lte_pdsch_plan_set_output(pl, pl->packed); }
 extern "C" {
 

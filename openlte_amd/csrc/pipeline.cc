@@ -43,6 +43,8 @@ struct Lane {
     float    *d_sub = nullptr;
     uint8_t  *d_out = nullptr;
     int32_t  *d_st = nullptr;
+    hipEvent_t in_free = nullptr, out_free = nullptr; // the front end has read d_iq / the results have left d_out (copy-stream mode)
+    bool       used = false;
 };
 struct Dev {
     int               device = 0;
@@ -51,6 +53,7 @@ struct Dev {
     int               rc = MI_LTE_OK;
     int               node = -1;              // NUMA node of the device's PCIe slot (-1: the system does not say)
     std::vector<int>  node_cpus;              // the CPUs of that node the process may run on
+    hipStream_t       h2d = nullptr, d2h = nullptr; // one stream per copy direction (see device_worker)
     std::vector<hipEvent_t> ev;               // four per chunk of the last run: before H2D, after H2D, after the kernels, after D2H
     mi_lte_pipeline_dev_stats stats = {};     // the last run, as this device saw it
 };
@@ -141,6 +144,8 @@ static void free_lane(Lane &l)
     if (l.dyn) mi_lte_pdsch_plan_destroy(l.ctx, l.dyn);
     (void)hipFree(l.d_iq); (void)hipFree(l.d_start_units); (void)hipFree(l.d_start_capture); (void)hipFree(l.d_sf); (void)hipFree(l.d_cell);
     (void)hipFree(l.d_sub); (void)hipFree(l.d_out); (void)hipFree(l.d_st);
+    if (l.in_free) (void)hipEventDestroy(l.in_free);
+    if (l.out_free) (void)hipEventDestroy(l.out_free);
     if (l.ctx) mi_lte_ctx_destroy(l.ctx);
     l = Lane();
 }
@@ -191,6 +196,8 @@ static int make_lane(mi_lte_dl_pipeline *p, Dev &d, Lane &l)
     MI_HIP_CHECK(l.ctx, hipMemset(l.d_cell, 0, sizeof(uint32_t) * chunk));
     MI_HIP_CHECK(l.ctx, hipMemset(l.d_sub, 0, sizeof(float) * mi_lte_subframe_floats(p->cfg.N_ant) * chunk));
     MI_HIP_CHECK(l.ctx, hipMemset(l.d_iq, 0, iq_bytes));
+    MI_HIP_CHECK(l.ctx, hipEventCreateWithFlags(&l.in_free, hipEventDisableTiming));
+    MI_HIP_CHECK(l.ctx, hipEventCreateWithFlags(&l.out_free, hipEventDisableTiming));
     return MI_LTE_OK;
 }
 
@@ -220,23 +227,34 @@ static void device_worker(mi_lte_dl_pipeline *p, uint32_t di, const Job *job)
     std::vector<mi_lte_pdsch_alloc> local;
     std::vector<size_t>             refused; // allocations outside the decodable envelope: status 2 at their own index
     auto fail = [&](Lane &l, int rc) { d.rc = rc; d.err = mi_lte_last_error(l.ctx); };
+    // Copies on streams of their own (default): ONE stream carries every host-to-device copy of the device in chunk order, one every
+    // device-to-host copy, the lanes' streams carry kernels only and meet the copies through events.  A lane's stream that also carried its
+    // copies (rounds 2-4, MI_LTE_PIPELINE_LANE_COPIES=1) put up to `lanes` input copies on the link at once, each behind its own lane's
+    // previous results copy: 43 GB/s of the 57.6 GB/s one copy alone reaches.  In order on one stream they run back to back at that rate.
+    static const bool lane_copies = getenv("MI_LTE_PIPELINE_LANE_COPIES") != nullptr;
+    for (Lane &l : d.lanes) l.used = false;
     for (uint32_t c = di; c < n_chunks; c += G, k++) {
         Lane          &l  = d.lanes[k % d.lanes.size()];
         const uint32_t u0 = c * p->chunk, n = std::min(p->chunk, job->n_units - u0);
-        hipStream_t    st = (hipStream_t)mi_lte_stream(l.ctx);
+        hipStream_t    st = (hipStream_t)mi_lte_stream(l.ctx), s_in = lane_copies ? st : d.h2d, s_out = lane_copies ? st : d.d2h;
         hipError_t     e;
         hipEvent_t    *ev = &d.ev[(size_t)4 * k];
-        (void)hipEventRecord(ev[0], st);
+        if (!lane_copies && l.used) (void)hipStreamWaitEvent(s_in, l.in_free, 0); // the lane's previous chunk has been read out of d_iq
+        (void)hipEventRecord(ev[0], s_in);
         const size_t   in_bytes = job->capture ? ((size_t)n * p->sf_samples + p->look_samples) * 2 : (size_t)n * unit_bytes;
         d.stats.chunks++; d.stats.units += n; d.stats.h2d_bytes += in_bytes + 8 * (size_t)n;
         if (job->capture) // the chunk's subframes and the look-ahead samples behind the last of them, as they lie in the capture
-            e = hipMemcpyAsync(l.d_iq, job->h_iq + (size_t)u0 * p->sf_samples * 2, ((size_t)n * p->sf_samples + p->look_samples) * 2, hipMemcpyHostToDevice, st);
+            e = hipMemcpyAsync(l.d_iq, job->h_iq + (size_t)u0 * p->sf_samples * 2, ((size_t)n * p->sf_samples + p->look_samples) * 2, hipMemcpyHostToDevice, s_in);
         else
-            e = hipMemcpyAsync(l.d_iq, job->h_iq + (size_t)u0 * unit_bytes, (size_t)n * unit_bytes, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(l.d_sf, job->h_sf + u0, sizeof(uint32_t) * n, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(l.d_cell, job->h_cell + u0, sizeof(uint32_t) * n, hipMemcpyHostToDevice, st);
+            e = hipMemcpyAsync(l.d_iq, job->h_iq + (size_t)u0 * unit_bytes, (size_t)n * unit_bytes, hipMemcpyHostToDevice, s_in);
+        if (e == hipSuccess) e = hipMemcpyAsync(l.d_sf, job->h_sf + u0, sizeof(uint32_t) * n, hipMemcpyHostToDevice, s_in);
+        if (e == hipSuccess) e = hipMemcpyAsync(l.d_cell, job->h_cell + u0, sizeof(uint32_t) * n, hipMemcpyHostToDevice, s_in);
         if (e != hipSuccess) { d.rc = MI_LTE_ERR_HIP; d.err = hipGetErrorString(e); break; }
-        (void)hipEventRecord(ev[1], st);
+        (void)hipEventRecord(ev[1], s_in);
+        if (!lane_copies) {
+            (void)hipStreamWaitEvent(st, ev[1], 0);                      // the chunk's samples are on the device
+            if (l.used) (void)hipStreamWaitEvent(st, l.out_free, 0);    // the lane's previous results have left d_out
+        }
         int rc = mi_lte_dl_frontend_batch(l.ctx, &p->cfg, l.d_iq, nullptr, job->capture ? l.d_start_capture : l.d_start_units, l.d_sf, l.d_cell, n, l.d_sub);
         if (rc != MI_LTE_OK) { fail(l, rc); break; }
         // which plan decodes the chunk, and where its results go
@@ -245,21 +263,10 @@ static void device_worker(mi_lte_dl_pipeline *p, uint32_t di, const Job *job)
         if (job->h_allocs) { // per-unit lists: the chunk's slice of the caller's list, unit numbers made chunk-local
             a0   = job->h_first[u0];
             n_al = job->h_first[u0 + n] - a0;
-            if (n_al == 0) { (void)hipEventRecord(ev[2], st); (void)hipEventRecord(ev[3], st); continue; }
-            local.assign(job->h_allocs + a0, job->h_allocs + a0 + n_al);
-            for (size_t i = 0; i < n_al; i++) {
-                mi_lte_pdsch_alloc &a = local[i];
-                a.unit -= u0;
-                if (!mi_lte_pdsch_alloc_decodable(&p->cfg, &a, job->cfi)) {
-                    // A DCI that passed its CRC by chance (resource blocks past the carrier, more than one code block ...): the reference fails
-                    // that one allocation (liblte_phy.cc:3690-3853), so must a run over thousands of subframes.  The slot keeps its place in the
-                    // chunk's list -- results are copied back in one piece -- with a one-block QPSK stand-in, and its verdict is overwritten below
-                    a.N_prb = 1; a.prb[0][0] = a.prb[1][0] = 0; a.mod_type = 1; a.tbs = 16; a.rv_idx = 0; a.tx_mode = 1;
-                    if (a.n_pdcch_symbs > 4) a.n_pdcch_symbs = 0;
-                    refused.push_back(a0 + i);
-                }
-            }
-            rc = mi_lte_pdsch_plan_assign(l.ctx, l.dyn, job->cfi, local.data(), (uint32_t)n_al);
+            if (n_al == 0) { (void)hipEventRecord(ev[2], st); (void)hipEventRecord(ev[3], st); (void)hipEventRecord(l.in_free, st); (void)hipEventRecord(l.out_free, st); l.used = true; continue; }
+            std::vector<uint32_t> bad;
+            rc = mi_pdsch_plan_assign_slice(l.ctx, l.dyn, job->cfi, job->h_allocs + a0, (uint32_t)n_al, u0, &bad);
+            for (uint32_t i : bad) refused.push_back(a0 + i);
             plan = l.dyn;
         } else if (n == p->chunk) {
             a0 = (size_t)u0 * p->n_alloc; n_al = (size_t)n * p->n_alloc;
@@ -275,10 +282,14 @@ static void device_worker(mi_lte_dl_pipeline *p, uint32_t di, const Job *job)
         if (rc == MI_LTE_OK) rc = mi_lte_pdsch_decode_run(l.ctx, plan, l.d_sub, l.d_sf, l.d_cell, l.d_out, l.d_st);
         if (rc != MI_LTE_OK) { fail(l, rc); break; }
         (void)hipEventRecord(ev[2], st);
-        e = hipMemcpyAsync(job->h_out + a0 * p->out_stride, l.d_out, n_al * p->out_stride, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(job->h_status + a0, l.d_st, n_al * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        (void)hipEventRecord(l.in_free, st); // the kernels have read d_iq, d_sf, d_cell: the lane's next input may come
+        if (!lane_copies) (void)hipStreamWaitEvent(s_out, ev[2], 0);
+        e = hipMemcpyAsync(job->h_out + a0 * p->out_stride, l.d_out, n_al * p->out_stride, hipMemcpyDeviceToHost, s_out);
+        if (e == hipSuccess) e = hipMemcpyAsync(job->h_status + a0, l.d_st, n_al * sizeof(int32_t), hipMemcpyDeviceToHost, s_out);
         if (e != hipSuccess) { d.rc = MI_LTE_ERR_HIP; d.err = hipGetErrorString(e); break; }
-        (void)hipEventRecord(ev[3], st);
+        (void)hipEventRecord(ev[3], s_out);
+        (void)hipEventRecord(l.out_free, s_out);
+        l.used = true;
         d.stats.d2h_bytes += n_al * ((size_t)p->out_stride + sizeof(int32_t));
     }
     const uint32_t k_done = k; // chunks whose four events were all recorded
@@ -287,12 +298,22 @@ static void device_worker(mi_lte_dl_pipeline *p, uint32_t di, const Job *job)
         const int rc = mi_lte_sync(l.ctx);
         if (rc != MI_LTE_OK && d.rc == MI_LTE_OK) fail(l, rc);
     }
-    for (size_t i : refused) job->h_status[i] = 2; // LIBLTE_ERROR_DECODE_FAIL (after the copies of the stand-ins' verdicts have landed)
+    if ((hipStreamSynchronize(d.h2d) != hipSuccess || hipStreamSynchronize(d.d2h) != hipSuccess) && d.rc == MI_LTE_OK) { d.rc = MI_LTE_ERR_HIP; d.err = "copy stream failed"; }
+    for (size_t i : refused) { // LIBLTE_ERROR_DECODE_FAIL, and an all-zero row instead of the stand-in's bits (after the copies of the stand-ins' results have landed)
+        job->h_status[i] = 2;
+        memset(job->h_out + i * p->out_stride, 0, p->out_stride);
+    }
     if (d.rc == MI_LTE_OK)
         for (uint32_t c = 0; c < k_done; c++) { // every lane has been waited for: the events are complete
             float ms[3] = {0, 0, 0};
             for (int ph = 0; ph < 3; ph++) (void)hipEventElapsedTime(&ms[ph], d.ev[(size_t)4 * c + ph], d.ev[(size_t)4 * c + ph + 1]);
             d.stats.h2d_s += ms[0] * 1e-3; d.stats.kernel_s += ms[1] * 1e-3; d.stats.d2h_s += ms[2] * 1e-3;
+            if (getenv("MI_LTE_PIPELINE_TRACE")) { // the chunk's four events on the clock of the run's first
+                float t0 = 0;
+                (void)hipEventElapsedTime(&t0, d.ev[0], d.ev[(size_t)4 * c]);
+                fprintf(stderr, "  device %d chunk %2u lane %u: H2D %7.3f .. %7.3f ms, kernels .. %7.3f, D2H .. %7.3f\n", d.device, c, (unsigned)(c % d.lanes.size()), t0, t0 + ms[0],
+                        t0 + ms[0] + ms[1], t0 + ms[0] + ms[1] + ms[2]);
+            }
         }
     d.stats.wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
 }
@@ -386,8 +407,12 @@ void mi_lte_dl_pipeline_destroy(mi_lte_dl_pipeline *p)
     if (!p) return;
     for (Dev &d : p->devs) {
         (void)hipSetDevice(d.device);
+        if (d.h2d) (void)hipStreamSynchronize(d.h2d);
+        if (d.d2h) (void)hipStreamSynchronize(d.d2h);
         for (Lane &l : d.lanes) free_lane(l);
         for (hipEvent_t e : d.ev) (void)hipEventDestroy(e);
+        if (d.h2d) (void)hipStreamDestroy(d.h2d);
+        if (d.d2h) (void)hipStreamDestroy(d.d2h);
     }
     delete p;
 }
@@ -428,6 +453,7 @@ int mi_lte_dl_pipeline_create_multi(const int *devices, uint32_t n_devices, cons
         if (hipSetDevice(d.device) != hipSuccess) return MI_LTE_ERR_NO_DEVICE;
         d.node      = device_numa_node(d.device);
         d.node_cpus = node_cpus_allowed(d.node);
+        if (hipStreamCreateWithFlags(&d.h2d, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&d.d2h, hipStreamNonBlocking) != hipSuccess) return MI_LTE_ERR_HIP;
         for (Lane &l : d.lanes) {
             const int rc = make_lane(p, d, l);
             if (rc != MI_LTE_OK) { p->err = d.err; return rc; }

@@ -1390,6 +1390,12 @@ def main():
                          "traffic_source": ("profiles/pmc_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" % wl.name) if tr else None,
                          "avg_launch_ms": round(avg_ms, 4), "launches": n_launch, "launches_per_step": lps,
                          "algorithmic_bytes_per_launch": alg_per_launch,
+                         # the stricter readings, inside this object so that they travel with it: the same stage bytes over ALL of the stage's
+                         # kernels, and the whole path's algorithmic bytes over the whole step
+                         "stage": stage_of.get(dom, "whole path"),
+                         "stage_ms_per_step": stages.get(stage_of.get(dom), {}).get("ms_per_step"),
+                         "stage_frac": stages.get(stage_of.get(dom), {}).get("frac_of_peak"),
+                         "chain_ms_per_step": round(elapsed / steps * 1e3, 4), "chain_frac": round(whole / HBM_PEAK_GBS, 5),
                          "accounting": "stage '%s' algorithmic bytes (SURVEY 8d, %d B per step) charged ONCE per step and spread over this kernel's %d "
                                        "launches, divided by its measured average launch time (HIP events on the launch stream)"
                                        % (stage_of.get(dom, "whole path"), st_bytes, lps)},

@@ -741,11 +741,14 @@ int mi_lte_pdsch_decode_run(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, const float 
         for (size_t i = 0; i < pl->groups.size() && rc == MI_LTE_OK; i++)
             if (i != big) rc = run_group(pl->groups[i]);
         swap_side();
+        // whatever happened on the side stream is joined before this function returns, on every path: groups already launched there
+        // still write d_out_bits / d_status / the side scratch, and a later mi_lte_sync only waits for ctx->stream
+        const hipError_t e_rec = hipEventRecord(ctx->ev_join, ctx->side_stream);
+        if (rc == MI_LTE_OK && e_rec == hipSuccess) rc = run_group(pl->groups[big]);
+        const hipError_t e_join = e_rec == hipSuccess ? hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0) : hipStreamSynchronize(ctx->side_stream);
         if (rc != MI_LTE_OK) return rc;
-        MI_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream));
-        rc = run_group(pl->groups[big]);
-        MI_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-        if (rc != MI_LTE_OK) return rc;
+        MI_HIP_CHECK(ctx, e_rec);
+        MI_HIP_CHECK(ctx, e_join);
     } else {
         for (auto &gr : pl->groups) {
             rc = run_group(gr);

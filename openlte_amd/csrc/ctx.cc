@@ -112,7 +112,7 @@ int mi_lte_memset(mi_lte_ctx *ctx, void *d_ptr, int value, size_t bytes)
 }
 } // extern "C"
 namespace {
-// 16-byte copies, every wavefront access one contiguous KiB.  Three shapes, the best of which is reported (tools/r3/nt_copy.hip measured
+// 16-byte copies, every wavefront access one contiguous KiB.  Three shapes, the best of which is reported (tools/ubench/nt_copy.hip measured
 // more: on an MI355X one access per thread streams best, 6.2 TB/s, 6.5 with the non-temporal hint; four loads in flight per thread 5.7 /
 // 6.3; a grid-stride loop 4.6-4.9): one 16-byte load and store per thread; the same with the non-temporal hint; a grid-stride loop
 typedef uint32_t mi_u32x4 __attribute__((ext_vector_type(4)));

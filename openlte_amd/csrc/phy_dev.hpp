@@ -124,7 +124,7 @@ __device__ __forceinline__ void ce_time_interp5_slot(const float (&M)[5], float 
 // large-argument threshold), restated operation by operation in float arithmetic (this file is compiled with -ffp-contract=off), so that
 // the DECISIONS the reference takes on an angle come out the same where the angle sits within an ulp of 0, +-pi/4, +-pi/2, +-3pi/4 or pi.
 // The device library's atan2f is good to a few ulp, which is not enough there: the differential soak found one QPSK symbol in 7.7e8
-// (re = -1.07, im = +4.0e-8: libm 0x40490fda < pi, device atan2f 0x40490fdb > pi, the other quadrant, tools/r3/repro_seed17.py).
+// (re = -1.07, im = +4.0e-8: libm 0x40490fda < pi, device atan2f 0x40490fdb > pi, the other quadrant, tools/repro_seed17.py).
 // Bit-identical to libm's atan2f on 1.2e8 argument pairs incl. NaN / infinities / zeros (tests/test_oracle.py through
 // mi_lte_model_atan2f).  A host with another libm may round differently: SURVEY 8c files that under the libm tolerance.
 __host__ __device__ inline uint32_t ref_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }

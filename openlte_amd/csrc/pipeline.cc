@@ -369,7 +369,7 @@ void *mi_lte_host_alloc_on(int device, size_t bytes)
             for (int nd : nodes)
                 if (nd >= 0 && nd < 1024) mask[nd / (8 * sizeof(unsigned long))] |= 1ul << (nd % (8 * sizeof(unsigned long)));
 #ifdef SYS_mbind
-            const long rc = syscall(SYS_mbind, m, len, interleave ? 3 /* MPOL_INTERLEAVE */ : 2 /* MPOL_BIND */, mask, (unsigned long)(8 * sizeof mask), 0u);
+            const long rc = syscall(SYS_mbind, m, len, interleave ? 3 /* MPOL_INTERLEAVE */ : 2 /* MPOL_BIND */, mask, (unsigned long)(8 * sizeof mask + 1), 0u); // maxnode counts bits + 1 (the kernel reads maxnode - 1 of them)
 #else
             const long rc = -1;
 #endif

@@ -100,7 +100,8 @@ __device__ __forceinline__ float    wave_max_f(float v) // (non-negative inputs:
     return __int_as_float(wave_max_i(__float_as_int(v)));
 }
 
-__device__ __forceinline__ float block_max_f(float v, float *red /* >= 8 floats */)
+// (the same precondition: non-negative inputs -- maxima of fabsf values; a negative value would compare as a large unsigned pattern)
+__device__ __forceinline__ float block_max_abs_f(float v, float *red /* >= 8 floats */)
 {
     v = wave_max_f(v);
     __syncthreads();
@@ -591,7 +592,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Src::kPacke
             for (int x = 0; x < 3; x++)
 #pragma unroll
                 for (int k = 0; k < 16; k++) mxv = fmaxf(mxv, fabsf(v[Src::kPacked ? 0 : x][k]));
-            mx = block_max_f(mxv, red_f);
+            mx = block_max_abs_f(mxv, red_f);
         }
     }
     const bool use_qtab = Src::kIntegerValued && mx < (float)QTAB_HALF; // uniform over the workgroup

@@ -37,7 +37,7 @@ pytestmark = pytest.mark.gpu
 N_DL_CHUNKS, DL_CHUNK = 20, 1000
 N_UL_GROUPS = 250
 N_SYNC = 40
-# every draw below is offset by this: the suite runs with 0; tools/r3/fuzz_soak.sh runs the same tests over further seeds
+# every draw below is offset by this: the suite runs with 0; tools/fuzz_soak.sh runs the same tests over further seeds
 SEED = int(os.environ.get("MI_LTE_FUZZ_SEED", "0"))
 TOL_SYMB, TOL_CE = 1e-5, 1e-4
 REPORT = {}

@@ -56,3 +56,36 @@ def test_prach_20mhz_batch(ctx):
     plan.close()
     assert (n == 1).all() and (p == np.array(pre)[idx]).all()
     assert (ta == ta[:4][idx]).all() and (np.diff(ta[:4].astype(np.int64)) > 0).all()  # longer delays -> larger timing advances
+
+
+def test_prach_root_set_that_wraps_past_the_table_is_self_consistent(ctx):
+    """A cell whose 64 preambles need more roots than are left in the logical root table (format 0: root_seq_idx 836 of 838, seven cyclic
+    shifts per root -> ten roots: 836, 837, then 0 .. 7 as 36.211 5.7.2 orders them cyclically).  The reference indexes past its table
+    there (liblte_phy.cc:7168-7171), so there is nothing of its to compare with (tests/test_fuzz_gpu.py counts and skips such draws);
+    the library's transmitter and detector must agree with each other and with the un-wrapped cell that owns the same physical roots:
+    preamble 14 + k of the wrapping cell IS preamble k of the cell with root_seq_idx 0, sample for sample, so the detector must report the
+    same timing advance for both, and every preamble must be found where it was put."""
+    import openlte_amd as m
+    from openlte_amd import synth
+    cfg = m.DlCfg(512, 25, 1, 0)
+    wrap, first = m.PrachCfg(836, 0, 12, 0, 2), m.PrachCfg(0, 0, 12, 0, 2)
+    L = ctx.L
+    import ctypes as C
+    u_w, u_f, n_w, n_f = (C.c_uint32 * 64)(), (C.c_uint32 * 64)(), C.c_uint32(), C.c_uint32()
+    assert L.mi_lte_prach_root_set(C.byref(wrap), u_w, C.byref(n_w)) == 0 and L.mi_lte_prach_root_set(C.byref(first), u_f, C.byref(n_f)) == 0
+    assert n_w.value == 10 and list(u_w[2:10]) == list(u_f[0:8]), "the wrapped part of the set is the head of the logical order"
+    pre_w, dly = [0, 13, 14, 27, 35, 63], [40, 90, 140, 190, 240, 290]
+    iq_w = synth.prach_occasions(cfg, wrap, pre_w, dly, snr_db=3.0, seed=11)
+    plan = ctx.prach_plan(cfg, wrap)
+    assert plan.n_roots == 10
+    n, p, ta = plan.detect(iq_w.reshape(-1, 2), np.arange(len(pre_w)) * iq_w.shape[1])
+    plan.close()
+    assert (n == 1).all() and (p == np.array(pre_w)).all(), (n.tolist(), p.tolist())
+    assert (np.diff(ta.astype(np.int64)) > 0).all()  # longer delays -> larger timing advances
+    # the same physical sequences sent by the cell that owns them without wrapping: identical samples, identical timing advances
+    pre_f = [q - 14 for q in pre_w[2:]]
+    iq_f = synth.prach_occasions(cfg, first, pre_f, dly[2:], snr_db=3.0, seed=11)
+    plan = ctx.prach_plan(cfg, first)
+    n2, p2, ta2 = plan.detect(iq_f.reshape(-1, 2), np.arange(len(pre_f)) * iq_f.shape[1])
+    plan.close()
+    assert (n2 == 1).all() and (p2 == np.array(pre_f)).all() and (ta2 == ta[2:]).all(), (ta.tolist(), ta2.tolist())

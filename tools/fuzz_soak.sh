@@ -1,7 +1,7 @@
 #!/bin/bash
-# tools/r3/fuzz_soak.sh <first seed> <last seed>: the differential tests of tests/test_fuzz_gpu.py over further seeds (the suite runs seed 0);
+# tools/fuzz_soak.sh <first seed> <last seed>: the differential tests of tests/test_fuzz_gpu.py over further seeds (the suite runs seed 0);
 # one line per seed and the report of each under gpurun_out/fuzz_soak/.  On the GPU box.
-cd "$(dirname "$0")/../.."
+cd "$(dirname "$0")/.."
 mkdir -p gpurun_out/fuzz_soak
 for s in $(seq $1 $2); do
   MI_LTE_FUZZ_SEED=$s timeout 900 python -m pytest tests/test_fuzz_gpu.py -m gpu -q -p no:cacheprovider 2>&1 | grep -v "^ERROR: DCI" | tail -1 | sed "s/^/seed $s: /" | tee -a gpurun_out/fuzz_soak/summary.txt

@@ -1,6 +1,6 @@
-// tools/r3/nt_copy.hip -- which half of a streaming kernel the non-temporal hint pays for on this device: a 16-bytes-per-lane copy of 1 GiB
+// tools/ubench/nt_copy.hip -- which half of a streaming kernel the non-temporal hint pays for on this device: a 16-bytes-per-lane copy of 1 GiB
 // with the hint on the loads, on the stores, on both, on neither; read-only (sum) and write-only (fill) kernels as well.
-//   hipcc --offload-arch=gfx950 -O3 tools/r3/nt_copy.hip -o gpurun_out/nt_copy && gpurun_out/nt_copy
+//   hipcc --offload-arch=gfx950 -O3 tools/ubench/nt_copy.hip -o gpurun_out/nt_copy && gpurun_out/nt_copy
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

@@ -128,24 +128,24 @@ template <> __device__ __forceinline__ void butterfly<9>(float2 (&v)[9])
 // transform), one thread per butterfly:
 //   out[(j-k)*R + k + q*Ns] = sum_r in[j + r*M/R] * w^(r*k) * exp(+2*pi*i * r*q/R),  k = j mod Ns,  w = exp(+2*pi*i / (Ns*R)),
 // the twiddle w^(r*k) being entry r*k*M/(Ns*R) (< M) of the allocation's table tw[t] = exp(+2*pi*i*t/M).
-template <uint32_t R>
+template <uint32_t R, uint32_t THREADS>
 __device__ __forceinline__ void dft_pass_r(const float2 *__restrict__ in, float2 *__restrict__ out, const float2 *__restrict__ tw,
                                            uint32_t S, uint32_t M, uint32_t M_max, uint32_t Ns)
 {
     const uint32_t nb = M / R, tstride = nb / Ns, inv_nb = inv_of(nb), inv_ns = inv_of(Ns);
-    for (uint32_t o = threadIdx.x; o < S * nb; o += blockDim.x) {
-        const uint32_t sy = div_by(o, inv_nb), j = o - sy * nb, k = j - div_by(j, inv_ns) * Ns;
-        const float2  *x = in + sy * M_max + j;
+    for (uint32_t o = threadIdx.x; o < S * nb; o += THREADS) {
+        const uint32_t sy = div_by(o, inv_nb), j = o - __umul24(sy, nb), k = j - __umul24(div_by(j, inv_ns), Ns);
+        const float2  *x = in + __umul24(sy, M_max) + j;
         float2         v[R];
 #pragma unroll
         for (uint32_t r = 0; r < R; r++) v[r] = x[r * nb];
         if (Ns > 1) { // uniform; the first pass has k = 0 throughout
-            const uint32_t t = k * tstride;
+            const uint32_t t = __umul24(k, tstride);
 #pragma unroll
             for (uint32_t r = 1; r < R; r++) v[r] = cmul(v[r], tw[r * t]);
         }
         butterfly<R>(v);
-        float2 *y = out + sy * M_max + (j - k) * R + k;
+        float2 *y = out + __umul24(sy, M_max) + __umul24(j - k, R) + k;
 #pragma unroll
         for (uint32_t q = 0; q < R; q++) y[q * Ns] = v[q];
     }
@@ -153,12 +153,13 @@ __device__ __forceinline__ void dft_pass_r(const float2 *__restrict__ in, float2
 
 // The same pass for any other radix (the prime FFTW would be left with when N_prb has a factor >= 7), one thread per output:
 // step = (k + q*Ns) * M/(Ns*R) < M, twiddle index r*step mod M.
+template <uint32_t THREADS>
 __device__ __forceinline__ void dft_pass(const float2 *__restrict__ in, float2 *__restrict__ out, const float2 *__restrict__ tw,
                                          uint32_t S, uint32_t M, uint32_t M_max, uint32_t R, uint32_t Ns)
 {
     const uint32_t nb = M / R, period = Ns * R, tstride = M / period;
     const uint32_t inv_m = inv_of(M), inv_nb = inv_of(nb), inv_ns = inv_of(Ns);
-    for (uint32_t o = threadIdx.x; o < S * M; o += blockDim.x) {
+    for (uint32_t o = threadIdx.x; o < S * M; o += THREADS) {
         const uint32_t sy = div_by(o, inv_m), oo = o - sy * M;
         const uint32_t q = div_by(oo, inv_nb), j = oo - q * nb, k = j - div_by(j, inv_ns) * Ns, step = (k + q * Ns) * tstride;
         const float2  *x = in + sy * M_max + j;
@@ -181,8 +182,12 @@ __device__ __forceinline__ void dft_pass(const float2 *__restrict__ in, float2 *
 #ifndef WPE
 #define WPE 6
 #endif
+// THREADS = the workgroup's width as a compile-time constant (64 / 128 / 192 / 256): every phase is a loop `o += THREADS` -- with blockDim.x the
+// stride was re-read from the dispatch packet in every iteration of the de-mapper's loop (a store in the body could alias it as far as the
+// compiler knows) -- and the index products are 24-bit multiplies (v_mul_lo_u32 / v_mad_u64_u32 issue at a quarter of the rate)
+template <uint32_t THREADS>
 __attribute__((amdgpu_waves_per_eu(WPE, 8)))
-__global__ __launch_bounds__(PUSCH_THREADS) void k_pusch_demod(const float *__restrict__ subframes, uint32_t sf_stride,
+__global__ __launch_bounds__(THREADS) void k_pusch_demod(const float *__restrict__ subframes, uint32_t sf_stride,
                                                      const mi_lte_pdsch_alloc *__restrict__ allocs, const PuschDesc *__restrict__ desc,
                                                      const float *__restrict__ dmrs_pool, GoldTables gt, int8_t *__restrict__ e_base,
                                                      const uint32_t *__restrict__ e_off, uint32_t *__restrict__ e_len, uint32_t M_max,
@@ -206,14 +211,14 @@ __global__ __launch_bounds__(PUSCH_THREADS) void k_pusch_demod(const float *__re
 
     // scrambling sequence (c_init per liblte_phy.cc:2893), one word of slack for the 2-word window below
     const uint32_t c_init = (al.rnti << 14) | (0u << 13) | (ds.subfr << 9) | ds.cell, n_words = (N_bits + 31) / 32;
-    for (uint32_t w = threadIdx.x; w <= n_words; w += blockDim.x) cw[w] = gold_word(gt, c_init, w);
+    for (uint32_t w = threadIdx.x; w <= n_words; w += THREADS) cw[w] = gold_word(gt, c_init, w);
 
     // ---- DMRS estimates and their interpolation slopes (get_ulsch_ce, liblte_phy.cc:13745-13768); DFT twiddles.
     // The reference interpolates in polar form, h(s) = (mag_b + n f_mag) exp(i (ang_b + n f_ang)), n = -3..3 around DMRS symbol b:
     // what is kept per subcarrier is exp(i ang_b) = t_b / |t_b| and exp(i f_ang), so the 12 data symbols cost complex products,
     // not 12 sin/cos pairs.  Work is spread as (subcarrier, task): task 0/1 = DMRS symbol 0/1, task 2 = the twiddle.
     const float *d_pool = dmrs_pool + ds.dmrs_off; // dmrs_0_re | dmrs_0_im | dmrs_1_re | dmrs_1_im (M each)
-    for (uint32_t o = threadIdx.x; o < 3 * M; o += blockDim.x) {
+    for (uint32_t o = threadIdx.x; o < 3 * M; o += THREADS) {
         const uint32_t task = o >= 2 * M ? 2 : o >= M ? 1 : 0, i = o - task * M;
         if (task == 2) {
             float sn, cs;
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(PUSCH_THREADS) void k_pusch_demod(const float *__re
         }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < M; i += blockDim.x) {
+    for (uint32_t i = threadIdx.x; i < M; i += THREADS) {
         const float f_mag = (est[M_max + i] - est[i]) / 7;
         float       f_ang = est[2 * M_max + i] - est[8 * M_max + i];
         if ((double)f_ang >= M_PI) f_ang = (float)((double)f_ang - 2 * M_PI); // float compared / corrected in double (:13758-13764)
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(PUSCH_THREADS) void k_pusch_demod(const float *__re
         // estimate, its unit vector and the powers of exp(i f_ang) are fetched / formed once and serve the slot's (up to) six data
         // symbols; S is 12 (both slots) or divides 6 (part of one slot).
         const uint32_t slot0 = s0 >= 6, n_slots = S == 12 ? 2 : 1, sp0 = s0 - 6 * slot0, sp1 = sp0 + (S == 12 ? 6 : S);
-        for (uint32_t o = threadIdx.x; o < n_slots * M; o += blockDim.x) {
+        for (uint32_t o = threadIdx.x; o < n_slots * M; o += THREADS) {
             const uint32_t b = slot0 + (o >= M), i = o - (o >= M ? M : 0);
             const float    mag = est[b * M_max + i], f_mag = est[2 * M_max + i];
             const float2   u = make_float2(est[(3 + 2 * b) * M_max + i], est[(4 + 2 * b) * M_max + i]);
@@ -286,16 +291,16 @@ __global__ __launch_bounds__(PUSCH_THREADS) void k_pusch_demod(const float *__re
         uint32_t rem = M, Ns = 1;
         while (rem > 1) { // uniform over the workgroup
             uint32_t R;
-            if (rem % 9 == 0)      { R = 9; dft_pass_r<9>(src, dst, tw, S, M, M_max, Ns); }
-            else if (rem % 3 == 0) { R = 3; dft_pass_r<3>(src, dst, tw, S, M, M_max, Ns); }
-            else if (rem % 5 == 0) { R = 5; dft_pass_r<5>(src, dst, tw, S, M, M_max, Ns); }
-            else if (rem % 8 == 0) { R = 8; dft_pass_r<8>(src, dst, tw, S, M, M_max, Ns); }
-            else if (rem % 4 == 0) { R = 4; dft_pass_r<4>(src, dst, tw, S, M, M_max, Ns); }
-            else if (rem % 2 == 0) { R = 2; dft_pass_r<2>(src, dst, tw, S, M, M_max, Ns); }
+            if (rem % 9 == 0)      { R = 9; dft_pass_r<9, THREADS>(src, dst, tw, S, M, M_max, Ns); }
+            else if (rem % 3 == 0) { R = 3; dft_pass_r<3, THREADS>(src, dst, tw, S, M, M_max, Ns); }
+            else if (rem % 5 == 0) { R = 5; dft_pass_r<5, THREADS>(src, dst, tw, S, M, M_max, Ns); }
+            else if (rem % 8 == 0) { R = 8; dft_pass_r<8, THREADS>(src, dst, tw, S, M, M_max, Ns); }
+            else if (rem % 4 == 0) { R = 4; dft_pass_r<4, THREADS>(src, dst, tw, S, M, M_max, Ns); }
+            else if (rem % 2 == 0) { R = 2; dft_pass_r<2, THREADS>(src, dst, tw, S, M, M_max, Ns); }
             else {
                 R = 7;
                 while (rem % R) R += 2;
-                dft_pass(src, dst, tw, S, M, M_max, R, Ns);
+                dft_pass<THREADS>(src, dst, tw, S, M, M_max, R, Ns);
             }
             __syncthreads();
             Ns *= R;
@@ -306,14 +311,15 @@ __global__ __launch_bounds__(PUSCH_THREADS) void k_pusch_demod(const float *__re
         // (uniform over the workgroup): no modulation branches and no re-read of the allocation descriptor per element
         auto demap_all = [&](auto modc) {
         constexpr uint32_t MOD = decltype(modc)::value, QM = MOD == 3 ? 6 : MOD == 2 ? 4 : MOD == 1 ? 2 : 1;
-        for (uint32_t o = threadIdx.x; o < S * M; o += blockDim.x) {
-            const uint32_t k = div_by(o, inv_s), sy = o - k * S, s = s0 + sy; // neighbouring threads write neighbouring bytes of e
-            const float2   x = src[sy * M_max + k];
+        for (uint32_t o = threadIdx.x; o < S * M; o += THREADS) {
+            // (all twelve symbols side by side is the common case: o / 12 for o < 2^15 as one 24-bit multiply and a shift)
+            const uint32_t k = S == 12 ? __umul24(o, 43691u) >> 19 : div_by(o, inv_s), sy = o - __umul24(k, S), s = s0 + sy; // neighbouring threads write neighbouring bytes of e
+            const float2   x = src[__umul24(sy, M_max) + k];
             int8_t         b[6] = {0, 0, 0, 0, 0, 0};
             demap_symbol(sqrt_M * x.x, sqrt_M * x.y, MOD, b);
-            const uint32_t n0 = (s * M + k) * QM, w = n0 >> 5, sh = n0 & 31;
+            const uint32_t n0 = (__umul24(s, M) + k) * QM, w = n0 >> 5, sh = n0 & 31;
             const uint32_t c  = __builtin_amdgcn_alignbit(cw[w + 1], cw[w], sh);
-            int8_t        *ob = e + (size_t)(k * 12 + s) * QM;
+            int8_t        *ob = e + (__umul24(k, 12u) + s) * QM; // (32-bit offset: an allocation's soft bits are at most 12 * 1320 * 6 bytes)
             // descrambled soft bits q, q + 1 as one 16-bit word (the Q_m bytes of a symbol start on an even address)
             auto pair = [&](uint32_t q) -> uint32_t {
                 const int lo = ((c >> q) & 1u) ? -b[q] : b[q], hi = ((c >> (q + 1)) & 1u) ? -b[q + 1] : b[q + 1];
@@ -595,8 +601,10 @@ int mi_lte_pusch_decode_run(mi_lte_ctx *ctx, mi_lte_pusch_plan *pl, const float 
         const int t = atoi(ev);
         if (t >= 64 && t <= (int)PUSCH_THREADS && t % 64 == 0) threads = (uint32_t)t;
     }
-    MI_LAUNCH(ctx, "k_pusch_demod", k_pusch_demod, dim3(pl->n_alloc), dim3(threads), lds, d_subframes, (uint32_t)mi_lte_ul_subframe_floats(),
-              pl->d_allocs, pl->d_desc, pl->d_dmrs, gt, pl->d_e, pl->d_e_off, pl->d_e_len, pl->M_max, S_par);
+#define MI_PUSCH_LAUNCH(T) MI_LAUNCH(ctx, "k_pusch_demod", k_pusch_demod<T>, dim3(pl->n_alloc), dim3(T), lds, d_subframes, (uint32_t)mi_lte_ul_subframe_floats(), \
+                                    pl->d_allocs, pl->d_desc, pl->d_dmrs, gt, pl->d_e, pl->d_e_off, pl->d_e_len, pl->M_max, S_par)
+    if (threads == 64) MI_PUSCH_LAUNCH(64); else if (threads == 128) MI_PUSCH_LAUNCH(128); else if (threads == 192) MI_PUSCH_LAUNCH(192); else MI_PUSCH_LAUNCH(256);
+#undef MI_PUSCH_LAUNCH
     MI_HIP_CHECK(ctx, hipGetLastError());
     for (auto &gr : pl->groups) {
         rc = mi_turbo_ref_group(ctx, gr.K, gr.n_cb, pl->d_allocs, pl->d_cb_alloc + gr.cb_base, pl->d_e, pl->d_e_off, pl->d_e_len,

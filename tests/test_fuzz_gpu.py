@@ -379,7 +379,7 @@ def test_sync_fuzz_against_the_compiled_reference(ctx, ref, tmp_path):
         pytest.skip("shim/_build/capture_gen not built (needs the reference tree at build time)")
     rng = np.random.default_rng(62 + 100000 * SEED)
     bws = [(128, 6, 18), (256, 15, 14), (512, 25, 12), (2048, 100, 10)]
-    n_peaks = n_cells = 0
+    n_peaks = n_cells = near_ties = 0
     for c in range(N_SYNC):
         fft, nrb, frames = bws[int(rng.integers(3)) if c % 7 else 3]
         n_frame = 307200 * fft // 2048
@@ -387,9 +387,10 @@ def test_sync_fuzz_against_the_compiled_reference(ctx, ref, tmp_path):
         case = td.sync_case(spec, tmp_path, seed=300 + c)
         want = td.ref_sync(ref, case)
         got = ts.gpu_sync(ctx, case)
-        ts.compare(got, want)
+        near_ties += ts.compare(got, want)
         n_peaks += want["coarse"][0]
         n_cells += sum(1 for p, s in want["per_peak"] if s is not None and 3 * s[0] + p[1] == case["cell"])
     assert n_cells >= N_SYNC // 3  # (a carrier offset beyond ~1 kHz hides the cell from the uncorrected searches: the scanner's loop corrects it first)
-    REPORT["sync"] = {"captures": N_SYNC, "coarse_peaks": n_peaks, "captures_whose_cell_was_found": n_cells}
+    assert near_ties <= 1 + n_peaks // 100  # (see tests/test_sync_gpu.compare: seed 107 has one)
+    REPORT["sync"] = {"captures": N_SYNC, "coarse_peaks": n_peaks, "captures_whose_cell_was_found": n_cells, "pss_fine_timing_near_ties": near_ties}
     write_report()

@@ -32,16 +32,29 @@ def gpu_sync(ctx, case, n_slots=160):
 
 
 def compare(got, want):
+    """Returns the number of coarse peaks whose fine timing is a NEAR TIE (0 in every fixed case of this file; the seeded fuzz has met
+    one in ~2 000 peaks, seed 107): the reference's fine-timing search takes the arg-max of |correlation| over 80 sample offsets, each
+    behind its own FFT (liblte_phy.cc:5444-5510); when two neighbouring offsets correlate equally to 1e-6 the rounding of the transform
+    picks between them, and the library's transform is not FFTW's (nor is the float64 stand-in the compiled reference runs on here).
+    Such a peak must differ in nothing else: every symbol start and the frame start shifted by the same one sample, N_id_2, the PSS
+    symbol, the frequency-offset verdict, N_id_1 equal, and the two maxima within 1e-6 relative."""
     n = want["coarse"][0]
     assert got["coarse"][0] == n
     assert got["coarse"][2][:n].tolist() == want["coarse"][2][:n].tolist()
     assert got["coarse"][1][:n].tobytes() == want["coarse"][1][:n].tobytes(), (got["coarse"][1], want["coarse"][1])
+    near_ties = 0
     for (gp, gs), (wp, ws) in zip(got["per_peak"], want["per_peak"]):
-        assert gp[0].tolist() == wp[0].tolist() and gp[1:3] == wp[1:3] and gp[4] == wp[4], (gp, wp)
+        shift = 0
+        if gp[0].tolist() != wp[0].tolist():
+            d = gp[0].astype(np.int64) - wp[0].astype(np.int64)
+            assert abs(int(d[0])) == 1 and (d == d[0]).all() and abs(gp[3] - wp[3]) <= 1e-6 * abs(wp[3]), (gp, wp)
+            shift, near_ties = int(d[0]), near_ties + 1
+        assert gp[1:3] == wp[1:3] and gp[4] == wp[4], (gp, wp)
         assert abs(gp[3] - wp[3]) <= 1e-4 * abs(wp[3])
         assert (gs is None) == (ws is None)
         if ws is not None:
-            assert gs[:2] == ws[:2] and gs[2].tolist() == ws[2].tolist()
+            assert gs[0] == ws[0] and int(gs[1]) - int(ws[1]) == shift and (gs[2].astype(np.int64) - ws[2].astype(np.int64) == shift).all(), (gs, ws, shift)
+    return near_ties
 
 
 @pytest.mark.parametrize("name", list(td.SYNC_CASES))
@@ -51,7 +64,7 @@ def test_sync_matches_reference(ctx, ref, tmp_path, name):
     case = td.sync_case(name, tmp_path)
     want = td.ref_sync(ref, case)
     got = gpu_sync(ctx, case)
-    compare(got, want)
+    assert compare(got, want) == 0
     # and the cell comes out where it was put (the fine timing lands a few samples inside the cyclic prefix at the wider bandwidths)
     hits = [(3 * s[0] + p[1], s[1]) for p, s in got["per_peak"] if s is not None]
     n_frame, slack = 307200 * case["fft"] // 2048, 20 * case["fft"] // 2048 + 1

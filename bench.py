@@ -310,7 +310,40 @@ class ChainWorkload:
         # MI_LTE_CE_COMPACT: the estimator hands the demodulator magnitude / phase rows at the CRS symbols instead of 14 estimate rows
         # (identical results, 172 KB less HBM traffic per subframe); --ce full runs the reference's stage boundary as it is
         self.cfg = m.DlCfg(2048, 100, 1, m.IQ_I8 | (m.CE_COMPACT if CE_MODE == "compact" else 0))
-        U = min(96, self.n)
+        host = self.host_setup(self.n, rank, self.cfg)
+        self.uniq, self.idx = host["uniq"], host["idx"]
+        iq, tx, sfs, cells, allocs = self.uniq
+        idx, ul = self.idx, iq.shape[1]
+        if ctx is None:  # --dry-setup: the host side of the set-up only (what an 8-rank launch does eight times over before the first kernel)
+            self.host = host
+            return
+        # the batch in HBM: the unique subframes uploaded over and over until n distinct copies lie there (unit i = unique subframe i mod U);
+        # materialising the 4.6 GB on the host first cost every rank of a multi-GPU launch half a minute and 5 GB before its first kernel
+        self.d_iq = ctx.alloc(self.n * ul * 2)
+        U = iq.shape[0]
+        for c0 in range(0, self.n, U):
+            self.d_iq.upload(iq[:min(U, self.n - c0)], c0 * ul * 2)
+        self.d_start = ctx.to_device((np.arange(self.n) * ul).astype(np.uint64))
+        self.d_sf = ctx.to_device(sfs[idx])
+        self.d_cell = ctx.to_device(cells[idx])
+        self.d_sub = ctx.alloc(self.n * ctx.subframe_floats(1) * 4)
+        all_allocs = host["all_allocs"]
+        self.plan = ctx.pdsch_plan(self.cfg, 2, all_allocs)
+        if DECODER.startswith("bcjr"):  # the max-log-MAP decoder instead of the reference's (8 iterations; the reference transmitter's interleaver)
+            self.plan.set_decoder(m.TURBO_BCJR_EARLY if DECODER == "bcjr_early" else m.TURBO_BCJR, 8, 0)
+        self.d_out = ctx.alloc(self.n * 9 * self.plan.out_stride)
+        self.d_status = ctx.alloc(self.n * 9 * 4)
+
+    @staticmethod
+    def host_setup(n, rank, cfg):
+        """Everything of the set-up that runs on the host: the 96 unique synthetic subframes (the C transmitter), the batch of n subframes
+        index of the batch (unit i = unique subframe i mod 96; the batch itself -- n x 70 240 bytes, 4.6 GB at the default size, distinct bytes in
+        HBM -- is laid down by repeated uploads of the unique block, not built here) and the n x 9 allocation descriptors."""
+        import numpy as np
+        import openlte_amd as m
+        from openlte_amd import synth
+        import lte_testdata as td
+        U = min(96, n)
         sfs = np.array([[1, 2, 3, 4, 6, 7, 8, 9][i % 8] for i in range(U)], np.uint32)  # subframes 0/5 carry sync signals
         cells = ((np.arange(U) * 37 + 11 * rank) % 504).astype(np.uint32)
         allocs = []
@@ -318,29 +351,14 @@ class ChainWorkload:
             allocs += td.w4_allocs(u)
         # three thirds of the unique subframes at 30 / 27 / 25 dB: the demapper's hard 64QAM decisions carry a growing share of wrong
         # +-127 soft bits into the decoder (the kernels are branch-free, so this changes the data, not the timing)
-        parts = [synth.dl_units(self.cfg, sfs[k::3], cells[k::3], [a for u in range(k, U, 3) for a in td.w4_allocs(u // 3)], 9,
+        parts = [synth.dl_units(cfg, sfs[k::3], cells[k::3], [a for u in range(k, U, 3) for a in td.w4_allocs(u // 3)], 9,
                                 snr_db=snr, max_delay=8, seed=4242 + rank + k) for k, snr in enumerate((30.0, 27.0, 25.0)) if len(sfs[k::3])]
         iq = np.zeros((U,) + parts[0][0].shape[1:], parts[0][0].dtype)
         tx = np.zeros((U,) + parts[0][1].shape[1:], parts[0][1].dtype)
         for k, (q, t) in enumerate(parts):
             iq[k::3], tx[k::3] = q, t
-        self.uniq = (iq, tx, sfs, cells, allocs)
-        idx = np.arange(self.n) % U
-        self.idx = idx
-        ul = iq.shape[1]
-        self.d_iq = ctx.to_device(iq[idx].reshape(-1, 2))
-        self.d_start = ctx.to_device((np.arange(self.n) * ul).astype(np.uint64))
-        self.d_sf = ctx.to_device(sfs[idx])
-        self.d_cell = ctx.to_device(cells[idx])
-        self.d_sub = ctx.alloc(self.n * ctx.subframe_floats(1) * 4)
-        all_allocs = []
-        for i in range(self.n):
-            all_allocs += td.w4_allocs(i)
-        self.plan = ctx.pdsch_plan(self.cfg, 2, all_allocs)
-        if DECODER.startswith("bcjr"):  # the max-log-MAP decoder instead of the reference's (8 iterations; the reference transmitter's interleaver)
-            self.plan.set_decoder(m.TURBO_BCJR_EARLY if DECODER == "bcjr_early" else m.TURBO_BCJR, 8, 0)
-        self.d_out = ctx.alloc(self.n * 9 * self.plan.out_stride)
-        self.d_status = ctx.alloc(self.n * 9 * 4)
+        idx = np.arange(n) % U
+        return {"uniq": (iq, tx, sfs, cells, allocs), "idx": idx, "all_allocs": m.tile_allocs(td.w4_allocs(0), n)}
 
     def step(self):
         self.ctx.dl_frontend_dev(self.cfg, self.d_iq, None, self.d_start, self.d_sf, self.d_cell, self.n, self.d_sub)
@@ -1254,6 +1272,31 @@ def selftest(args, rank, world, barrier, max_reduce):
     barrier()
 
 
+def dry_setup(args, rank, world, barrier, max_reduce):
+    """--workload chain-setup: the HOST side of the chain workload's set-up on every rank, no GPU (needs none): what `--gpus 8` does eight
+    times over on one node before its first kernel -- the C transmitter's 96 unique subframes and the allocation descriptors (the 4.6 GB batch is laid down
+    in HBM by repeated uploads of the unique block; until round 5 it was built on the host first: 29 s and 5 GB per rank).  Prints seconds and resident memory per rank, so that the 8-GPU launch is
+    known to fit and how long its silence lasts."""
+    import resource
+    import openlte_amd as m
+    barrier()
+    t0 = time.perf_counter()
+    n = args.units or 65536
+    host = ChainWorkload.host_setup(n, rank, m.DlCfg(2048, 100, 1, m.IQ_I8 | m.CE_COMPACT))
+    dt = time.perf_counter() - t0
+    rss = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6  # GB (ru_maxrss is in KB)
+    worst, peak = max_reduce(dt), max_reduce(rss)
+    barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "chain workload, host side of the set-up only (no GPU work)", "value": round(worst, 2), "unit": "s", "n_gpus": world,
+                          "steps": 0, "warmup": 0, "ms_per_step": None, "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "none",
+                          "data": "synthetic", "config": {"workload": "chain-setup", "subframes_per_rank": n},
+                          "slowest_rank_s": round(worst, 2), "peak_resident_GB_per_rank": round(peak, 2), "ranks": world,
+                          "unique_block_bytes_per_rank": int(host["uniq"][0].nbytes), "batch_bytes_in_hbm_per_rank": int(n * host["uniq"][0][0].nbytes),
+                          "descriptor_bytes_per_rank": n * 9 * 260}))
+    barrier()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1285,6 +1328,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     if args.workload == "selftest":
         return selftest(args, rank, world, barrier, max_reduce)
+    if args.workload == "chain-setup":
+        return dry_setup(args, rank, world, barrier, max_reduce)
     import openlte_amd as m
     n_dev = m.load_library().mi_lte_device_count()
     if local_rank >= n_dev:  # one GPU per rank, no sharing: n_gpus in the line means N contexts on N distinct devices

@@ -50,6 +50,17 @@ def make_alloc(unit, mod_type, tbs, prbs, rnti, rv_idx=0, tx_mode=1, prbs_slot1=
     return a
 
 
+def tile_allocs(template, n_units):
+    """The allocation list of n_units units that all carry the same template (a list of PdschAlloc for one unit): a ctypes array of
+    n_units * len(template) structs with `unit` = 0 .. n_units - 1, built by numpy (half a million Python-made structs take a minute)."""
+    k, sz = len(template), C.sizeof(PdschAlloc)
+    base = np.frombuffer((PdschAlloc * k)(*template), np.uint8).reshape(k, sz)
+    full = np.ascontiguousarray(np.broadcast_to(base, (n_units, k, sz))).reshape(n_units * k, sz)
+    off = PdschAlloc.unit.offset
+    full[:, off:off + 4] = np.repeat(np.arange(n_units, dtype=np.uint32), k).view(np.uint8).reshape(-1, 4)
+    return (PdschAlloc * (n_units * k)).from_buffer(full)
+
+
 class PipelineDevStats(C.Structure):
     """mi_lte_pipeline_dev_stats"""
     _fields_ = [("device", C.c_uint32), ("chunks", C.c_uint32), ("units", C.c_uint32), ("n_cpus", C.c_uint32), ("numa_node", C.c_int32), ("reserved", C.c_int32),
@@ -251,11 +262,12 @@ class PdschPlan:
             self.h, self.n_alloc, self.tbs = h, 0, []
         else:
             self.n_alloc = len(allocs)
-            arr = (PdschAlloc * len(allocs))(*allocs)
+            arr = allocs if isinstance(allocs, C.Array) else (PdschAlloc * len(allocs))(*allocs)  # (a ready-made ctypes array: tile_allocs below)
             ctx._check(ctx.L.mi_lte_pdsch_plan_create(ctx.h, C.byref(cfg), n_pdcch_symbs, C.cast(arr, C.c_void_p), len(allocs),
                                                       C.byref(h)))
             self.h = h
-            self.tbs = [a.tbs for a in allocs]
+            self.tbs = None if isinstance(allocs, C.Array) else [a.tbs for a in allocs]  # (a ctypes array: read on demand, run() below)
+            self._arr = arr
         self.out_stride = ctx.L.mi_lte_pdsch_plan_out_stride(h)
 
     def assign(self, n_pdcch_symbs, allocs):
@@ -290,11 +302,16 @@ class PdschPlan:
             st = d_st.download(np.int32)
             bits = d_out.download(np.uint8).reshape(self.n_alloc, self.out_stride)
             if getattr(self, "packed", False):  # back to one bit per byte for the caller
-                return st, [np.unpackbits(bits[a, :(self.tbs[a] + 7) // 8])[:self.tbs[a]] for a in range(self.n_alloc)]
-            return st, [bits[a, :self.tbs[a]] for a in range(self.n_alloc)]
+                return st, [np.unpackbits(bits[a, :(self._tbs()[a] + 7) // 8])[:self._tbs()[a]] for a in range(self.n_alloc)]
+            return st, [bits[a, :self._tbs()[a]] for a in range(self.n_alloc)]
         finally:
             for b in (d_sf, d_cell, d_out, d_st):
                 b.free()
+
+    def _tbs(self):
+        if self.tbs is None:
+            self.tbs = [a.tbs for a in self._arr]
+        return self.tbs
 
     def soft_bits(self, alloc):
         """Descrambled int8 soft bits of one allocation (stage tap)."""

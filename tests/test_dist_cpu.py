@@ -62,3 +62,19 @@ def test_bench_gpus_8_selftest_on_cpu():
     assert out["n_gpus"] == 8 and out["shard_counts"] == [125] * 8 and out["scaling"] == "weak"
     assert sorted(x[0] for x in out["ranks"]) == list(range(8)) and sorted(x[1] for x in out["ranks"]) == list(range(8))
     assert {tuple(x[3]) for x in out["ranks"]} == {(k, k + 8, k + 16) for k in range(8)}
+
+
+def test_bench_gpus_8_chain_setup_on_cpu():
+    """The host side of the CHAIN workload's set-up at the width and size the scaling run uses (`--gpus 8`, 65 536 subframes per rank), no
+    GPU: eight ranks synthesise their 96 unique subframes (rank-dependent cells and seeds) and build their 589 824 allocation
+    descriptors; the 4.6 GB batch per rank is laid down in HBM by repeated uploads and never exists on the host.  Must stay a matter of
+    seconds and of well under 2 GB per rank (it was 29 s and 5 GB per rank when the batch was built on the host first)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "chain-setup"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["subframes_per_rank"] == 65536
+    assert out["slowest_rank_s"] < 60 and out["peak_resident_GB_per_rank"] < 2.0, out
+    assert out["batch_bytes_in_hbm_per_rank"] == 65536 * 70240 and out["descriptor_bytes_per_rank"] == 65536 * 9 * 260

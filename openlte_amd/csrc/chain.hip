@@ -573,9 +573,12 @@ uint32_t mi_lte_pdsch_plan_n_alloc(const mi_lte_pdsch_plan *pl) { return pl ? pl
 // feeds the copy engines): the chunk's slice of the caller's list goes into the plan's staging block in ONE pass -- unit numbers made
 // chunk-local, every allocation tested once (mi_lte_pdsch_alloc_decodable's conditions), one outside the envelope replaced by a one-block
 // QPSK stand-in and its index reported -- instead of a copy, a test pass and the layout's own test pass.
+// copy_stream: where the three descriptor copies go (nullptr: the context's stream).  The pipeline passes its input-copy stream: a third
+// engine moving 4.8 MB per chunk next to the sample and result copies slowed both (profiles/r05_host_pipeline_profile.txt, section 5).
 int mi_pdsch_plan_assign_slice(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, uint32_t N_pdcch_symbs, const mi_lte_pdsch_alloc *h_src, uint32_t n_alloc, uint32_t unit0,
-                               std::vector<uint32_t> *refused)
+                               std::vector<uint32_t> *refused, hipStream_t copy_stream)
 {
+    const hipStream_t cs = copy_stream ? copy_stream : ctx->stream;
     if (!ctx || !pl || !pl->dynamic || pl->mapped || !h_src || n_alloc == 0 || N_pdcch_symbs < 1 || N_pdcch_symbs > 4) return MI_LTE_ERR_INVALID_ARG;
     if (n_alloc > pl->cap_alloc) { ctx->err = "more allocations than the dynamic plan was created for"; return MI_LTE_ERR_INVALID_ARG; }
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -599,10 +602,10 @@ int mi_pdsch_plan_assign_slice(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, uint32_t 
     if (pl->e_bytes > pl->cap_e_bytes) { pl->n_alloc = 0; ctx->err = "more soft bits than the dynamic plan was created for"; return MI_LTE_ERR_INVALID_ARG; }
     memcpy(so, pl->h_e_off.data(), sizeof(uint32_t) * n_alloc);
     memcpy(sc, cb_alloc.data(), sizeof(uint32_t) * n_alloc);
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_allocs, sa, sizeof(mi_lte_pdsch_alloc) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_e_off, so, sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_cb_alloc, sc, sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP_CHECK(ctx, hipEventRecord(pl->staged, ctx->stream));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_allocs, sa, sizeof(mi_lte_pdsch_alloc) * n_alloc, hipMemcpyHostToDevice, cs));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_e_off, so, sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, cs));
+    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_cb_alloc, sc, sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, cs));
+    MI_HIP_CHECK(ctx, hipEventRecord(pl->staged, cs));
     return MI_LTE_OK;
 }
 void mi_pdsch_plan_wide_stride(mi_lte_pdsch_plan *pl) { pl->wide = true; (void)mi_lte_pdsch_plan_set_output(pl, pl->packed); }

@@ -140,7 +140,7 @@ int   mi_ctx_turbo_tables(mi_lte_ctx *ctx, uint32_t K, int spec, TurboTables *ou
 struct mi_lte_pdsch_plan;
 int   mi_pdsch_plan_create_mapped(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, uint32_t max_alloc, size_t max_soft_bytes, mi_lte_pdsch_plan **out); // chain.hip
 int   mi_pdsch_plan_assign_slice(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, uint32_t N_pdcch_symbs, const mi_lte_pdsch_alloc *h_src, uint32_t n_alloc, uint32_t unit0,
-                                 std::vector<uint32_t> *refused); // chain.hip: the host pipeline's one-pass assignment
+                                 std::vector<uint32_t> *refused, hipStream_t copy_stream = nullptr); // chain.hip: the host pipeline's one-pass assignment
 void  mi_pdsch_plan_wide_stride(mi_lte_pdsch_plan *pl); // one output stride whatever the plan holds: that of the largest single-code-block transport block (pipeline.cc)
 struct mi_lte_pusch_plan;
 int   mi_pusch_plan_create_impl(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const mi_lte_ul_cfg *ul, const uint32_t *h_unit_subfr_num,

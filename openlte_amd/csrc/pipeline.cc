@@ -250,7 +250,19 @@ static void device_worker(mi_lte_dl_pipeline *p, uint32_t di, const Job *job)
         if (e == hipSuccess) e = hipMemcpyAsync(l.d_sf, job->h_sf + u0, sizeof(uint32_t) * n, hipMemcpyHostToDevice, s_in);
         if (e == hipSuccess) e = hipMemcpyAsync(l.d_cell, job->h_cell + u0, sizeof(uint32_t) * n, hipMemcpyHostToDevice, s_in);
         if (e != hipSuccess) { d.rc = MI_LTE_ERR_HIP; d.err = hipGetErrorString(e); break; }
+        // per-unit lists: the chunk's slice of the caller's list goes into the lane's dynamic plan now, its descriptor copies behind the samples
+        // on the input stream (the host's part of it, ~1 ms, runs while the samples are in flight)
+        int  rc_assign = MI_LTE_OK;
+        bool assigned = false;
+        if (job->h_allocs && !lane_copies && job->h_first[u0 + n] > job->h_first[u0]) {
+            std::vector<uint32_t> bad;
+            const size_t a0s = job->h_first[u0];
+            rc_assign = mi_pdsch_plan_assign_slice(l.ctx, l.dyn, job->cfi, job->h_allocs + a0s, (uint32_t)(job->h_first[u0 + n] - a0s), u0, &bad, s_in);
+            for (uint32_t i : bad) refused.push_back(a0s + i);
+            assigned = true;
+        }
         (void)hipEventRecord(ev[1], s_in);
+        if (rc_assign != MI_LTE_OK) { fail(l, rc_assign); break; }
         if (!lane_copies) {
             (void)hipStreamWaitEvent(st, ev[1], 0);                      // the chunk's samples are on the device
             if (l.used) (void)hipStreamWaitEvent(st, l.out_free, 0);    // the lane's previous results have left d_out
@@ -264,9 +276,11 @@ static void device_worker(mi_lte_dl_pipeline *p, uint32_t di, const Job *job)
             a0   = job->h_first[u0];
             n_al = job->h_first[u0 + n] - a0;
             if (n_al == 0) { (void)hipEventRecord(ev[2], st); (void)hipEventRecord(ev[3], st); (void)hipEventRecord(l.in_free, st); (void)hipEventRecord(l.out_free, st); l.used = true; continue; }
-            std::vector<uint32_t> bad;
-            rc = mi_pdsch_plan_assign_slice(l.ctx, l.dyn, job->cfi, job->h_allocs + a0, (uint32_t)n_al, u0, &bad);
-            for (uint32_t i : bad) refused.push_back(a0 + i);
+            if (!assigned) {
+                std::vector<uint32_t> bad;
+                rc = mi_pdsch_plan_assign_slice(l.ctx, l.dyn, job->cfi, job->h_allocs + a0, (uint32_t)n_al, u0, &bad);
+                for (uint32_t i : bad) refused.push_back(a0 + i);
+            }
             plan = l.dyn;
         } else if (n == p->chunk) {
             a0 = (size_t)u0 * p->n_alloc; n_al = (size_t)n * p->n_alloc;

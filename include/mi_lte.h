@@ -559,7 +559,9 @@ int mi_lte_pusch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_ul, const fl
                                      uint32_t subfr_num, const mi_lte_pdsch_alloc *alloc, uint32_t N_id_cell, uint32_t N_ant,
                                      const float *h_dmrs_0_re, const float *h_dmrs_0_im, const float *h_dmrs_1_re,
                                      const float *h_dmrs_1_im, uint8_t *h_out_bits, uint32_t *N_out_bits);
-/* liblte_phy_detect_prach: h_re / h_im point at the occasion's first cyclic-prefix sample; root spectra from the caller's struct */
+/* liblte_phy_detect_prach: h_re / h_im point at the occasion's first cyclic-prefix sample; root spectra from the caller's struct
+ * (LIBLTE_PHY_STRUCT::prach_x_u_fft_*, what liblte_phy_ul_init left there), or both pointers NULL: the library generates the cell's
+ * root set itself (mi_lte_prach_plan_create; n_roots is ignored) */
 int mi_lte_detect_prach_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_ul, const mi_lte_prach_cfg *prach,
                              const float *h_x_u_fft_re /*[n_roots][839]*/, const float *h_x_u_fft_im, uint32_t n_roots, const float *h_re,
                              const float *h_im, uint32_t *N_det_pre, uint32_t *det_pre, uint32_t *det_ta);

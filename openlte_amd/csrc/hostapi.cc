@@ -817,18 +817,19 @@ int mi_lte_detect_prach_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_u
                              uint32_t *det_pre, uint32_t *det_ta)
 {
     if (!ctx) return MI_LTE_ERR_INVALID_ARG;
-    if (!prach || !h_x_u_fft_re || !h_x_u_fft_im || !h_re || !h_im || !N_det_pre || !det_pre || !det_ta || !valid_fft(fft_size, N_rb_ul) || n_roots == 0 || n_roots > 64) return 1;
+    const bool own_roots = !h_x_u_fft_re && !h_x_u_fft_im; // no spectra handed over: the library's own root set for the cell's configuration
+    if (!prach || (!own_roots && (!h_x_u_fft_re || !h_x_u_fft_im || n_roots == 0 || n_roots > 64)) || !h_re || !h_im || !N_det_pre || !det_pre || !det_ta || !valid_fft(fft_size, N_rb_ul)) return 1;
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     HostCache *hc;
     int        rc = host_cache(ctx, &hc);
     if (rc != MI_LTE_OK) return rc;
     mi_lte_dl_cfg cfg = {fft_size, N_rb_ul, 1, MI_LTE_IQ_F32_PLANAR};
     std::string   key;
-    key_add(key, cfg); key_add(key, *prach); key_add(key, n_roots);
-    key_add(key, fnv(h_x_u_fft_re, (size_t)n_roots * 839 * 4, fnv(h_x_u_fft_im, (size_t)n_roots * 839 * 4)));
+    key_add(key, cfg); key_add(key, *prach); key_add(key, own_roots ? 0u : n_roots);
+    if (!own_roots) key_add(key, fnv(h_x_u_fft_re, (size_t)n_roots * 839 * 4, fnv(h_x_u_fft_im, (size_t)n_roots * 839 * 4)));
     mi_lte_prach_plan *plan = hc->prach.find(key);
     if (!plan) {
-        rc = mi_lte_prach_plan_create_roots(ctx, &cfg, prach, h_x_u_fft_re, h_x_u_fft_im, n_roots, &plan);
+        rc = own_roots ? mi_lte_prach_plan_create(ctx, &cfg, prach, &plan) : mi_lte_prach_plan_create_roots(ctx, &cfg, prach, h_x_u_fft_re, h_x_u_fft_im, n_roots, &plan);
         if (rc != MI_LTE_OK) return rc == MI_LTE_ERR_UNSUPPORTED ? 1 : rc;
         hc->prach.put(ctx, key, plan);
     }

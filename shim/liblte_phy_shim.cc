@@ -30,6 +30,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <vector>
 
 #include "liblte_phy.h" // the reference's header, from -I<reference>/liblte/hdr -I<reference>/cmn_hdr
 #include "mi_lte.h"
@@ -42,6 +43,13 @@ namespace {
 struct Entry {
     mi_lte_ctx *ctx = nullptr;
     std::mutex  mu;
+#ifdef MI_LTE_SHIM_OWN_LIFECYCLE
+    // what the shim's own liblte_phy_ul_init was given (the reference turns it into tables inside the struct; here the library's generators
+    // are asked per call and their answers kept): PUSCH reference-signal configuration, the cell the tables are FOR, DMRS per (subframe, N_prb)
+    mi_lte_ul_cfg ul = {0, 0, 0, 0, 0};
+    uint32_t      ul_cell = 0;
+    std::map<uint32_t, std::vector<float>> dmrs;
+#endif
 };
 std::mutex                                            g_mu;
 std::map<LIBLTE_PHY_STRUCT *, std::shared_ptr<Entry>> g_ctx;
@@ -241,6 +249,52 @@ LIBLTE_ERROR_ENUM liblte_phy_cleanup(LIBLTE_PHY_STRUCT *phy_struct)
     free(phy_struct);
     return LIBLTE_SUCCESS;
 }
+
+// liblte_phy_ul_init (liblte_phy.h:613-625, impl. liblte_phy.cc:2337-2517), receive side of PUSCH and PRACH: the reference fills the struct with
+// DMRS tables for every (subframe, N_prb), PUCCH sequence tables, the cell's PRACH root sequences and their spectra, and a dozen FFTW plans.
+// Here the configuration is kept (struct fields where the reference has fields for it, the side table otherwise) and the library's own
+// generators are asked when a decode needs them.  PUCCH decoding is not available in this build.
+LIBLTE_ERROR_ENUM liblte_phy_ul_init(LIBLTE_PHY_STRUCT *phy_struct, uint16 N_id_cell, uint32 prach_root_seq_idx, uint32 prach_preamble_format, uint32 prach_zczc,
+                                     bool prach_hs_flag, uint8 group_assignment_pusch, bool group_hopping_enabled, bool sequence_hopping_enabled, uint8 cyclic_shift,
+                                     uint8 cyclic_shift_dci, uint8 N_cs_an, uint8 delta_pucch_shift)
+{
+    (void)N_cs_an; (void)delta_pucch_shift;
+    if (phy_struct == NULL) return LIBLTE_ERROR_INVALID_INPUTS;
+    std::shared_ptr<Entry> e = entry_for(phy_struct);
+    std::lock_guard<std::mutex> call(e->mu);
+    e->ul      = mi_lte_ul_cfg{group_assignment_pusch, group_hopping_enabled ? 1u : 0u, sequence_hopping_enabled ? 1u : 0u, cyclic_shift, cyclic_shift_dci};
+    e->ul_cell = N_id_cell;
+    e->dmrs.clear();
+    phy_struct->prach_root_seq_idx    = prach_root_seq_idx; // (prach_preamble_seq_gen, liblte_phy.cc:7157-7172)
+    phy_struct->prach_preamble_format = prach_preamble_format;
+    phy_struct->prach_zczc            = prach_zczc;
+    phy_struct->prach_hs_flag         = prach_hs_flag;
+    phy_struct->prach_N_zc            = prach_preamble_format == 4 ? 139 : 839;
+    mi_lte_prach_cfg pc = {prach_root_seq_idx, prach_preamble_format, prach_zczc, prach_hs_flag ? 1u : 0u, 0};
+    uint32_t         roots[64], n_roots = 0;
+    phy_struct->prach_N_x_u = mi_lte_prach_root_set(&pc, roots, &n_roots) == MI_LTE_OK ? n_roots : 0;
+    const uint32 down = 30720000 / phy_struct->fs; // occasion geometry in samples of this rate (liblte_phy.cc:2430-2467)
+    static const uint32 t_seq[5] = {24576, 24576, 2 * 24576, 2 * 24576, 4096}, t_cp[5] = {3168, 21024, 6240, 21024, 448};
+    const uint32 f = prach_preamble_format > 4 ? 4 : prach_preamble_format;
+    phy_struct->prach_T_fft      = (f == 4 ? 4096 : 24576) / down;
+    phy_struct->prach_T_seq      = t_seq[f] / down;
+    phy_struct->prach_T_cp       = t_cp[f] / down;
+    phy_struct->prach_delta_f_RA = f == 4 ? 7500 : 1250;
+    phy_struct->prach_phi        = f == 4 ? 2 : 7;
+    phy_struct->ul_init          = true;
+    return LIBLTE_SUCCESS;
+}
+
+// liblte_phy_ul_cleanup (liblte_phy.h:639, impl. liblte_phy.cc:2544-2582)
+LIBLTE_ERROR_ENUM liblte_phy_ul_cleanup(LIBLTE_PHY_STRUCT *phy_struct)
+{
+    if (phy_struct == NULL || !phy_struct->ul_init) return LIBLTE_ERROR_INVALID_INPUTS;
+    std::shared_ptr<Entry> e = entry_for(phy_struct);
+    std::lock_guard<std::mutex> call(e->mu);
+    e->dmrs.clear();
+    phy_struct->ul_init = false;
+    return LIBLTE_SUCCESS;
+}
 #endif
 
 LIBLTE_ERROR_ENUM liblte_phy_get_dl_subframe_and_ce(LIBLTE_PHY_STRUCT *phy_struct, float *i_samps, float *q_samps,
@@ -307,11 +361,26 @@ LIBLTE_ERROR_ENUM liblte_phy_pusch_channel_decode(LIBLTE_PHY_STRUCT *phy_struct,
     MI_LOCKED_CTX(phy_struct, LIBLTE_ERROR_INVALID_INPUTS);
     mi_lte_pdsch_alloc a;
     to_mi_alloc(alloc, &a);
-    // the reference signals are the ones liblte_phy_ul_init (still the reference's own code) left in the struct
     const uint32 sf = subframe->num, np = alloc->N_prb;
+#ifndef MI_LTE_SHIM_OWN_LIFECYCLE
+    // the reference signals are the ones liblte_phy_ul_init (still the reference's own code) left in the struct
+    const float *d0r = phy_struct->pusch_dmrs_0_re[sf][np], *d0i = phy_struct->pusch_dmrs_0_im[sf][np];
+    const float *d1r = phy_struct->pusch_dmrs_1_re[sf][np], *d1i = phy_struct->pusch_dmrs_1_im[sf][np];
+#else
+    // ... or the library's own generator (mi_lte_ul_dmrs_pusch restates generate_dmrs_pusch, liblte_phy.cc:6745-6990, value for value:
+    // tests/test_uplink_cpu.py), asked once per (subframe, N_prb) with the configuration and the cell liblte_phy_ul_init was given
+    std::vector<float> &tab = entry_->dmrs[sf * 256u + np];
+    if (tab.empty()) {
+        tab.resize((size_t)4 * 12 * np);
+        if (mi_lte_ul_dmrs_pusch(&entry_->ul, entry_->ul_cell, sf, np, &tab[0], &tab[12 * np], &tab[24 * np], &tab[36 * np]) != MI_LTE_OK) {
+            tab.clear();
+            return LIBLTE_ERROR_INVALID_INPUTS;
+        }
+    }
+    const float *d0r = &tab[0], *d0i = &tab[12 * np], *d1r = &tab[24 * np], *d1i = &tab[36 * np];
+#endif
     int rc = mi_lte_pusch_channel_decode_host(c, phy_struct->N_rb_ul, &subframe->rx_symb_re[0][0], &subframe->rx_symb_im[0][0], sf, &a,
-                                              N_id_cell, N_ant, phy_struct->pusch_dmrs_0_re[sf][np], phy_struct->pusch_dmrs_0_im[sf][np],
-                                              phy_struct->pusch_dmrs_1_re[sf][np], phy_struct->pusch_dmrs_1_im[sf][np], out_bits, N_out_bits);
+                                              N_id_cell, N_ant, d0r, d0i, d1r, d1i, out_bits, N_out_bits);
     return rc == 0 ? LIBLTE_SUCCESS : LIBLTE_ERROR_INVALID_INPUTS; // the reference's own failure code on this path (:2809, :2929)
 }
 
@@ -324,9 +393,14 @@ LIBLTE_ERROR_ENUM liblte_phy_detect_prach(LIBLTE_PHY_STRUCT *phy_struct, float *
     MI_LOCKED_CTX(phy_struct, LIBLTE_ERROR_INVALID_INPUTS);
     mi_lte_prach_cfg pc = {phy_struct->prach_root_seq_idx, phy_struct->prach_preamble_format, phy_struct->prach_zczc,
                            phy_struct->prach_hs_flag ? 1u : 0u, freq_offset};
+#ifndef MI_LTE_SHIM_OWN_LIFECYCLE
     // the root sequences' spectra are the ones liblte_phy_ul_init (still the reference's code) left in the struct
     int rc = mi_lte_detect_prach_host(c, phy_struct->N_samps_per_symb, phy_struct->N_rb_ul, &pc, &phy_struct->prach_x_u_fft_re[0][0],
                                       &phy_struct->prach_x_u_fft_im[0][0], phy_struct->prach_N_x_u, samps_re, samps_im, N_det_pre, det_pre, det_ta);
+#else
+    // ... or the library's own (no spectra handed over: the plan generates the cell's root set itself, prach.hip / prach_sets.hpp)
+    int rc = mi_lte_detect_prach_host(c, phy_struct->N_samps_per_symb, phy_struct->N_rb_ul, &pc, NULL, NULL, 0, samps_re, samps_im, N_det_pre, det_pre, det_ta);
+#endif
     return rc == 0 ? LIBLTE_SUCCESS : LIBLTE_ERROR_INVALID_INPUTS;
 }
 
@@ -430,7 +504,7 @@ LIBLTE_ERROR_ENUM liblte_phy_find_sss(LIBLTE_PHY_STRUCT *phy_struct, float *i_sa
 #ifndef MI_LTE_SHIM_OWN_LIFECYCLE
 extern int32 W_5_4_1_2[3][4]; // the reference's orthogonal-sequence table (liblte_phy.cc:161), still its own object
 #else
-static const int32 W_5_4_1_2[3][4] = {{1, 1, 1, 1}, {1, -1, 1, -1}, {1, -1, -1, 1}}; // 36.211 table 5.4.1-2 (the uplink needs the reference's liblte_phy_ul_init anyway)
+int32 W_5_4_1_2[3][4] = {{1, 1, 1, 1}, {1, -1, 1, -1}, {1, -1, -1, 1}}; // 36.211 table 5.4.1-2; external like the reference's (liblte_phy.cc:161): callers name it
 #endif
 
 LIBLTE_ERROR_ENUM liblte_phy_pucch_format_1_1a_1b_channel_decode(LIBLTE_PHY_STRUCT *phy_struct, LIBLTE_PHY_SUBFRAME_STRUCT *subframe,
@@ -441,6 +515,9 @@ LIBLTE_ERROR_ENUM liblte_phy_pucch_format_1_1a_1b_channel_decode(LIBLTE_PHY_STRU
     if (phy_struct == NULL || subframe == NULL || !(format == LIBLTE_PHY_PUCCH_FORMAT_1 || format == LIBLTE_PHY_PUCCH_FORMAT_1A || format == LIBLTE_PHY_PUCCH_FORMAT_1B) ||
         out_bits == NULL || N_out_bits == NULL || subframe->num > 9 || N_1_p_pucch >= LIBLTE_PHY_N_RB_UL_MAX / 2 || N_ant != 1)
         return LIBLTE_ERROR_INVALID_INPUTS;
+#ifdef MI_LTE_SHIM_OWN_LIFECYCLE
+    return LIBLTE_ERROR_INVALID_INPUTS; // (this build has no generator for the PUCCH sequence tables liblte_phy_ul_init computes, liblte_phy.cc:2401-2421)
+#endif
     MI_LOCKED_CTX(phy_struct, LIBLTE_ERROR_INVALID_INPUTS);
     // the sequences liblte_phy_ul_init (still the reference's code) left in the struct for this (subframe, resource)
     static const uint32 symb[4] = {0, 1, 5, 6};

@@ -245,6 +245,26 @@ def test_uplink_dropin_demo_matches_reference_output(tmp_path):
     assert abs(e_got - e_want) / e_want < 1e-4
 
 
+def test_uplink_dropin_demo_with_no_reference_phy_object_in_the_link(tmp_path):
+    """dropin_ul_gpu_pure = the same uplink caller linked with NO object of the reference's PHY: liblte_phy_init / _ul_init / _cleanup are the
+    shim's own (-DMI_LTE_SHIM_OWN_LIFECYCLE), the PUSCH reference signals come from the library's generator (mi_lte_ul_dmrs_pusch, asked
+    with what liblte_phy_ul_init was given) and the PRACH detector builds the cell's root set itself.  Per-UE verdicts, bit counts and
+    hashes of the decoded bits and the PRACH line must be the all-reference build's.  (PUCCH is not part of this build.)"""
+    exe = os.path.join(ROOT, "shim", "_build", "dropin_ul_gpu_pure")
+    if not os.path.exists(exe):
+        pytest.skip("shim/_build/dropin_ul_gpu_pure not built (needs the reference tree at build time)")
+    args, env = _ul_demo_args(tmp_path), _ul_demo_env(tmp_path)
+    env.pop("PUCCH_DEMO")
+    got = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300, env=env)
+    assert got.returncode == 0, got.stdout + got.stderr
+    lines = got.stdout.strip().splitlines()
+    want = open(os.path.join(ROOT, "tests", "golden", "dropin_ul_demo_reference_cpu.txt")).read().strip().splitlines()[:5]
+    assert lines[1:5] == want[1:], (lines, want)
+    assert abs(float(lines[0].split("=")[1]) - float(want[0].split("=")[1])) / float(want[0].split("=")[1]) < 1e-4
+    syms = subprocess.run(["nm", "-C", "--defined-only", exe], capture_output=True, text=True).stdout
+    assert " T liblte_phy_ul_init" in syms and "generate_dmrs_pusch" not in syms and "prach_preamble_seq_gen" not in syms and "fftwf_" not in syms
+
+
 @pytest.mark.parametrize("n_rb,cell,frames,fs", [(6, 17, 30, "1.92"), (25, 301, 24, "7.68"), (100, 77, 12, "30.72")])
 def test_cell_scan_matches_reference_output(tmp_path, n_rb, cell, frames, fs):
     """BASELINE config 1 / SURVEY 8d W1 (plumbing): a GNU-Radio-free cell scan in LTE_fdd_dl_file_scan's call order --
@@ -277,7 +297,7 @@ def test_cell_scan_with_no_reference_phy_object_in_the_link(tmp_path, n_rb, cell
     """scan_gpu_pure = the same scanner source (scan_demo.cc) linked with NO object of the reference's PHY: liblte_phy_init,
     liblte_phy_cleanup and liblte_phy_update_n_rb_dl are the shim's own (liblte_phy_shim.cc, -DMI_LTE_SHIM_OWN_LIFECYCLE), the other
     seven calls of LTE_fdd_dl_file_scan are the replaced entry points.  Its report must equal the all-reference build's text, and the
-    executable must not contain a single function of the reference's PHY besides the fifteen the shim defines."""
+    executable must not contain a single function of the reference's PHY besides the seventeen the shim defines."""
     build = os.path.join(ROOT, "shim", "_build")
     gen, pure = os.path.join(build, "capture_gen"), os.path.join(build, "scan_gpu_pure")
     if not (os.path.exists(gen) and os.path.exists(pure)):
@@ -290,7 +310,7 @@ def test_cell_scan_with_no_reference_phy_object_in_the_link(tmp_path, n_rb, cell
     assert got.stdout == want
     syms = subprocess.run(["nm", "-C", "--defined-only", pure], capture_output=True, text=True).stdout
     phy = sorted({l.split(" T ")[1].split("(")[0] for l in syms.splitlines() if " T liblte_phy_" in l})
-    assert len(phy) == 15 and "liblte_phy_init" in phy and "liblte_phy_update_n_rb_dl" in phy, phy
+    assert len(phy) == 17 and "liblte_phy_init" in phy and "liblte_phy_update_n_rb_dl" in phy and "liblte_phy_ul_init" in phy, phy
     assert "pdcch_permute_pre_calc" not in syms and "turbo_decode" not in syms and "fftwf_" not in syms
 
 

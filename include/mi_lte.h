@@ -374,6 +374,11 @@ typedef struct {
     uint32_t format;       /* 0 = format 1, 1 = 1a, 2 = 1b (LIBLTE_PHY_PUCCH_FORMAT_ENUM) */
     uint32_t N_1_p_pucch;
 } mi_lte_pucch_res;
+/* The tables of one (subframe, resource) from the cell's configuration, for callers that have no LIBLTE_PHY_STRUCT: restates what
+ * liblte_phy_ul_init computes through generate_dmrs_pucch (liblte_phy.cc:2401-2421, :6986-7129) and what the decoder derives from it
+ * (:3058-3083).  delta_pucch_shift = deltaPUCCH-Shift (1..3 in 36.211; i.e. the value liblte_phy_ul_init is given + 1, :2414); host function. */
+int mi_lte_ul_pucch_tables(const mi_lte_ul_cfg *ul, uint32_t N_id_cell, uint32_t N_subfr, uint32_t N_1_p_pucch, uint32_t N_cs_an,
+                           uint32_t delta_pucch_shift, uint32_t N_ant, float *h_tables /* [MI_LTE_PUCCH_TAB_FLOATS] */);
 int mi_lte_pucch_decode_run(mi_lte_ctx *ctx, uint32_t N_rb_ul, uint32_t N_ant, const float *d_subframes, const mi_lte_pucch_res *h_res,
                             const float *h_tables, uint32_t n_res, uint8_t *h_bits, uint32_t *h_n_bits, uint32_t *h_rc);
 

@@ -35,11 +35,12 @@ uint32_t bits_to_u8(const uint8_t *c) // 8 sequence bits, LSB first (liblte_phy.
     return v;
 }
 
-// r_{u,v}^{(alpha)}(n), n < 12*N_prb, for one slot (generate_ul_rs with chan_type = ULSCH)
-void ul_rs_slot(const mi_lte_ul_cfg &ul, uint32_t N_slot, uint32_t N_id_cell, uint32_t N_prb, float alpha, float *rs_re, float *rs_im)
+// r_{u,v}^{(alpha)}(n), n < 12*N_prb, for one slot (generate_ul_rs; control = chan_type ULCCH: the sequence-shift pattern without
+// delta_ss, liblte_phy.cc:6782-6788)
+void ul_rs_slot(const mi_lte_ul_cfg &ul, uint32_t N_slot, uint32_t N_id_cell, uint32_t N_prb, float alpha, float *rs_re, float *rs_im, bool control = false)
 {
     const uint32_t M_sc = 12 * N_prb, N_zc = largest_prime_below(M_sc);
-    const uint32_t f_ss = ((N_id_cell % 30) + ul.group_assignment_pusch) % 30;
+    const uint32_t f_ss = control ? N_id_cell % 30 : ((N_id_cell % 30) + ul.group_assignment_pusch) % 30;
     uint32_t       u, v = 0;
     if (ul.group_hopping_enabled) { // group hopping pattern f_gh(ns), 36.211 5.5.1.3
         uint8_t c[160];
@@ -103,6 +104,73 @@ extern "C" int mi_lte_ul_dmrs_pusch(const mi_lte_ul_cfg *ul, uint32_t N_id_cell,
         for (uint32_t i = 0; i < M_sc; i++) { // orthogonal cover w(m)
             out_re[s][i] = w[s] * out_re[s][i];
             out_im[s][i] = w[s] * out_im[s][i];
+        }
+    }
+    return MI_LTE_OK;
+}
+
+
+// The PUCCH format 1 / 1a / 1b sequences of one (subframe, resource) in the layout mi_lte_pucch_decode_run takes (MI_LTE_PUCCH_TAB_FLOATS): what
+// liblte_phy_ul_init leaves in LIBLTE_PHY_STRUCT through generate_dmrs_pucch (liblte_phy.cc:2401-2421, :6986-7129; 36.211 v10.1.0 sections
+// 5.4.1 and 5.5.2.2) and what the decoder derives from it (s(n_s) and the orthogonal cover, :3058-3083).  Integer steps as the reference
+// takes them (its unsigned arithmetic included), floating point where its overloads put it.
+extern "C" int mi_lte_ul_pucch_tables(const mi_lte_ul_cfg *ul, uint32_t N_id_cell, uint32_t N_subfr, uint32_t N_1_p_pucch, uint32_t N_cs_an,
+                                      uint32_t delta_pucch_shift, uint32_t N_ant, float *t)
+{
+    if (!ul || !t || N_subfr > 9 || N_id_cell > 503 || N_1_p_pucch > 255 || N_cs_an > 7 || delta_pucch_shift < 1 || delta_pucch_shift > 12 ||
+        !(N_ant == 1 || N_ant == 2 || N_ant == 4) || ul->group_assignment_pusch > 29)
+        return MI_LTE_ERR_INVALID_ARG;
+    const uint32_t N_slot = 2 * N_subfr, n1 = N_1_p_pucch & 0xFFu, dps = delta_pucch_shift, N_cs_1 = N_cs_an;
+    const bool     mixed = n1 < 3 * N_cs_1 / dps; // a resource in the mixed resource block
+    const uint32_t N_prime = mixed ? N_cs_1 : 12u;
+    uint32_t       n_prime[2], n_oc[2];
+    if (mixed) {
+        n_prime[0] = n1;
+        const uint32_t h_p = (n_prime[0] + 2) % (3 * N_prime / dps);
+        n_prime[1] = h_p / 3 + (h_p % 3) * N_prime / dps;
+    } else {
+        n_prime[0] = (n1 - 3 * N_cs_1 / dps) % (3 * 12 / dps);
+        n_prime[1] = ((3 * (n_prime[0] + 1)) % ((3 * 12 / dps) + 1)) - 1; // (unsigned: a remainder of 0 wraps, as in the reference)
+    }
+    for (int i = 0; i < 2; i++) n_oc[i] = n_prime[i] * dps / N_prime;
+    // n_cs^cell(n_s, l): 8 bits of the cell's sequence per symbol (36.211 5.4)
+    std::vector<uint8_t> c(8 * 7 * 20);
+    synth::gold(N_id_cell, 8 * 7 * 20, c.data());
+    float r_re[2][7][12], r_im[2][7][12];
+    for (uint32_t i = 0; i < 2; i++)
+        for (uint32_t j = 0; j < 7; j++) {
+            const uint32_t n_cs_cell = bits_to_u8(c.data() + 8 * 7 * (N_slot + i) + 8 * j);
+            const uint32_t n_cs_p    = (n_cs_cell + ((n_prime[i] * dps + (n_oc[i] % dps)) % N_prime)) % 12;
+            const float    alpha     = 2 * M_PI * n_cs_p / 12; // double expression rounded to float, as the reference stores it
+            ul_rs_slot(*ul, N_slot + i, N_id_cell, 1, alpha, r_re[i][j], r_im[i][j], true);
+        }
+    // DMRS: symbols 2, 3, 4 of each slot with the cover w(m) = exp(i phase) of 36.211 table 5.5.2.2.1-2, z(m) = 1
+    static const float W_PHASE[3][3] = {{0, 0, 0}, {0, (float)(2 * M_PI / 3), (float)(4 * M_PI / 3)}, {0, (float)(4 * M_PI / 3), (float)(2 * M_PI / 3)}};
+    for (uint32_t i = 0; i < 2; i++) {
+        float *d_re = t + 72 * i, *d_im = d_re + 36;
+        for (uint32_t j = 0; j < 3; j++) {
+            const float w_re = std::cos(W_PHASE[n_oc[i] % 3][j]), w_im = std::sin(W_PHASE[n_oc[i] % 3][j]); // (float overloads, like the reference's calls)
+            for (uint32_t k = 0; k < 12; k++) {
+                const float a_re = r_re[i][j + 2][k], a_im = r_im[i][j + 2][k];
+                d_re[12 * j + k] = (float)((1 / std::sqrt((double)N_ant)) * (w_re * a_re - w_im * a_im));
+                d_im[12 * j + k] = (float)((1 / std::sqrt((double)N_ant)) * (w_re * a_im + w_im * a_re));
+            }
+        }
+    }
+    // data symbols 0, 1, 5, 6 of each slot: r_u_v and s(n_s) w(i)
+    static const uint32_t symb[4] = {0, 1, 5, 6};
+    static const int32_t  W4[3][4] = {{1, 1, 1, 1}, {1, -1, 1, -1}, {1, -1, -1, 1}}; // 36.211 table 5.4.1-2
+    for (uint32_t m = 0; m < 2; m++) {
+        float s_re, s_im;
+        if ((n_prime[m] % 2) == 0) { s_re = 1; s_im = 0; }
+        else { s_re = (float)std::cos(M_PI / 2); s_im = (float)std::sin(M_PI / 2); }
+        for (uint32_t i = 0; i < 4; i++) {
+            for (uint32_t k = 0; k < 12; k++) {
+                t[144 + (m * 4 + i) * 12 + k] = r_re[m][symb[i]][k];
+                t[240 + (m * 4 + i) * 12 + k] = r_im[m][symb[i]][k];
+            }
+            t[336 + m * 4 + i] = s_re * W4[n_oc[m] % 3][i];
+            t[344 + m * 4 + i] = s_im * W4[n_oc[m] % 3][i];
         }
     }
     return MI_LTE_OK;

@@ -47,8 +47,8 @@ struct Entry {
     // what the shim's own liblte_phy_ul_init was given (the reference turns it into tables inside the struct; here the library's generators
     // are asked per call and their answers kept): PUSCH reference-signal configuration, the cell the tables are FOR, DMRS per (subframe, N_prb)
     mi_lte_ul_cfg ul = {0, 0, 0, 0, 0};
-    uint32_t      ul_cell = 0;
-    std::map<uint32_t, std::vector<float>> dmrs;
+    uint32_t      ul_cell = 0, n_cs_an = 0, delta_pucch_shift = 1;
+    std::map<uint32_t, std::vector<float>> dmrs, pucch; // keys: subframe * 256 + N_prb / + N_1_p_pucch
 #endif
 };
 std::mutex                                            g_mu;
@@ -253,18 +253,20 @@ LIBLTE_ERROR_ENUM liblte_phy_cleanup(LIBLTE_PHY_STRUCT *phy_struct)
 // liblte_phy_ul_init (liblte_phy.h:613-625, impl. liblte_phy.cc:2337-2517), receive side of PUSCH and PRACH: the reference fills the struct with
 // DMRS tables for every (subframe, N_prb), PUCCH sequence tables, the cell's PRACH root sequences and their spectra, and a dozen FFTW plans.
 // Here the configuration is kept (struct fields where the reference has fields for it, the side table otherwise) and the library's own
-// generators are asked when a decode needs them.  PUCCH decoding is not available in this build.
+// generators (ul_rs.cc, prach_sets.hpp) are asked when a decode needs them.
 LIBLTE_ERROR_ENUM liblte_phy_ul_init(LIBLTE_PHY_STRUCT *phy_struct, uint16 N_id_cell, uint32 prach_root_seq_idx, uint32 prach_preamble_format, uint32 prach_zczc,
                                      bool prach_hs_flag, uint8 group_assignment_pusch, bool group_hopping_enabled, bool sequence_hopping_enabled, uint8 cyclic_shift,
                                      uint8 cyclic_shift_dci, uint8 N_cs_an, uint8 delta_pucch_shift)
 {
-    (void)N_cs_an; (void)delta_pucch_shift;
     if (phy_struct == NULL) return LIBLTE_ERROR_INVALID_INPUTS;
     std::shared_ptr<Entry> e = entry_for(phy_struct);
     std::lock_guard<std::mutex> call(e->mu);
     e->ul      = mi_lte_ul_cfg{group_assignment_pusch, group_hopping_enabled ? 1u : 0u, sequence_hopping_enabled ? 1u : 0u, cyclic_shift, cyclic_shift_dci};
     e->ul_cell = N_id_cell;
+    e->n_cs_an = N_cs_an;
+    e->delta_pucch_shift = (uint32_t)delta_pucch_shift + 1; // (generate_dmrs_pucch is handed delta_pucch_shift + 1, liblte_phy.cc:2414)
     e->dmrs.clear();
+    e->pucch.clear();
     phy_struct->prach_root_seq_idx    = prach_root_seq_idx; // (prach_preamble_seq_gen, liblte_phy.cc:7157-7172)
     phy_struct->prach_preamble_format = prach_preamble_format;
     phy_struct->prach_zczc            = prach_zczc;
@@ -292,6 +294,7 @@ LIBLTE_ERROR_ENUM liblte_phy_ul_cleanup(LIBLTE_PHY_STRUCT *phy_struct)
     std::shared_ptr<Entry> e = entry_for(phy_struct);
     std::lock_guard<std::mutex> call(e->mu);
     e->dmrs.clear();
+    e->pucch.clear();
     phy_struct->ul_init = false;
     return LIBLTE_SUCCESS;
 }
@@ -515,13 +518,24 @@ LIBLTE_ERROR_ENUM liblte_phy_pucch_format_1_1a_1b_channel_decode(LIBLTE_PHY_STRU
     if (phy_struct == NULL || subframe == NULL || !(format == LIBLTE_PHY_PUCCH_FORMAT_1 || format == LIBLTE_PHY_PUCCH_FORMAT_1A || format == LIBLTE_PHY_PUCCH_FORMAT_1B) ||
         out_bits == NULL || N_out_bits == NULL || subframe->num > 9 || N_1_p_pucch >= LIBLTE_PHY_N_RB_UL_MAX / 2 || N_ant != 1)
         return LIBLTE_ERROR_INVALID_INPUTS;
-#ifdef MI_LTE_SHIM_OWN_LIFECYCLE
-    return LIBLTE_ERROR_INVALID_INPUTS; // (this build has no generator for the PUCCH sequence tables liblte_phy_ul_init computes, liblte_phy.cc:2401-2421)
-#endif
     MI_LOCKED_CTX(phy_struct, LIBLTE_ERROR_INVALID_INPUTS);
+    const uint32 N = subframe->num, n = N_1_p_pucch;
+#ifdef MI_LTE_SHIM_OWN_LIFECYCLE
+    // the library's own generator (mi_lte_ul_pucch_tables restates generate_dmrs_pucch, liblte_phy.cc:6986-7129, value for value:
+    // tests/test_uplink_cpu.py), asked once per (subframe, resource) with what liblte_phy_ul_init was given
+    if (!phy_struct->ul_init) return LIBLTE_ERROR_INVALID_INPUTS;
+    std::vector<float> &tab = entry_->pucch[N * 256u + n];
+    if (tab.empty()) {
+        tab.resize(MI_LTE_PUCCH_TAB_FLOATS);
+        if (mi_lte_ul_pucch_tables(&entry_->ul, entry_->ul_cell, N, n, entry_->n_cs_an, entry_->delta_pucch_shift, phy_struct->N_ant, &tab[0]) != MI_LTE_OK) {
+            tab.clear();
+            return LIBLTE_ERROR_INVALID_INPUTS;
+        }
+    }
+    const float *t = &tab[0];
+#else
     // the sequences liblte_phy_ul_init (still the reference's code) left in the struct for this (subframe, resource)
     static const uint32 symb[4] = {0, 1, 5, 6};
-    const uint32 N = subframe->num, n = N_1_p_pucch;
     float        t[MI_LTE_PUCCH_TAB_FLOATS];
     memcpy(t, phy_struct->pucch_dmrs_0_re[N][n], 36 * sizeof(float));
     memcpy(t + 36, phy_struct->pucch_dmrs_0_im[N][n], 36 * sizeof(float));
@@ -538,6 +552,7 @@ LIBLTE_ERROR_ENUM liblte_phy_pucch_format_1_1a_1b_channel_decode(LIBLTE_PHY_STRU
             t[344 + m * 4 + i] = s_im * W_5_4_1_2[phy_struct->pucch_n_oc_p[N][n][m]][i];
         }
     }
+#endif
     uint32_t nb = 0;
     int rc = mi_lte_pucch_decode_host(c, phy_struct->N_rb_ul, &subframe->rx_symb_re[0][0], &subframe->rx_symb_im[0][0], (uint32_t)format, N_ant, N_1_p_pucch, t,
                                       out_bits, &nb);

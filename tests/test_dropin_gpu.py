@@ -247,9 +247,11 @@ def test_uplink_dropin_demo_matches_reference_output(tmp_path):
 
 def test_uplink_dropin_demo_with_no_reference_phy_object_in_the_link(tmp_path):
     """dropin_ul_gpu_pure = the same uplink caller linked with NO object of the reference's PHY: liblte_phy_init / _ul_init / _cleanup are the
-    shim's own (-DMI_LTE_SHIM_OWN_LIFECYCLE), the PUSCH reference signals come from the library's generator (mi_lte_ul_dmrs_pusch, asked
-    with what liblte_phy_ul_init was given) and the PRACH detector builds the cell's root set itself.  Per-UE verdicts, bit counts and
-    hashes of the decoded bits and the PRACH line must be the all-reference build's.  (PUCCH is not part of this build.)"""
+    shim's own (-DMI_LTE_SHIM_OWN_LIFECYCLE), the PUSCH reference signals and the PUCCH sequence tables come from the library's generators
+    (mi_lte_ul_dmrs_pusch, mi_lte_ul_pucch_tables, asked with what liblte_phy_ul_init was given) and the PRACH detector builds the cell's
+    root set itself.  Per-UE verdicts, bit counts and hashes of the decoded bits and the PRACH detection must be the all-reference build's.
+    (The demo's own PUCCH section BUILDS its resources from the reference's private tables in the struct, which this build leaves empty:
+    the PUCCH decoder of this build is checked by `lifecycle_check pucch` below.)"""
     exe = os.path.join(ROOT, "shim", "_build", "dropin_ul_gpu_pure")
     if not os.path.exists(exe):
         pytest.skip("shim/_build/dropin_ul_gpu_pure not built (needs the reference tree at build time)")
@@ -263,6 +265,18 @@ def test_uplink_dropin_demo_with_no_reference_phy_object_in_the_link(tmp_path):
     assert abs(float(lines[0].split("=")[1]) - float(want[0].split("=")[1])) / float(want[0].split("=")[1]) < 1e-4
     syms = subprocess.run(["nm", "-C", "--defined-only", exe], capture_output=True, text=True).stdout
     assert " T liblte_phy_ul_init" in syms and "generate_dmrs_pusch" not in syms and "prach_preamble_seq_gen" not in syms and "fftwf_" not in syms
+
+
+def test_pucch_decoder_of_the_build_without_the_reference_phy():
+    """`shim/_build/lifecycle_check pucch` (a TEST binary that links the reference's PHY under other names): 360 PUCCH format 1 / 1a / 1b
+    resources built from the tables the REFERENCE's liblte_phy_ul_init computed, decoded by the reference on its struct and by the
+    own-lifecycle shim on a struct of its own, whose decoder asks mi_lte_ul_pucch_tables instead of reading tables out of the struct.
+    Error code, bit count and bits equal for every resource (three cell configurations, mixed and unmixed resource blocks)."""
+    exe = os.path.join(ROOT, "shim", "_build", "lifecycle_check")
+    if not os.path.exists(exe):
+        pytest.skip("shim/_build/lifecycle_check not built (needs the reference tree at build time)")
+    r = subprocess.run([exe, "pucch"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "decodes equal" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
 
 
 @pytest.mark.parametrize("n_rb,cell,frames,fs", [(6, 17, 30, "1.92"), (25, 301, 24, "7.68"), (100, 77, 12, "30.72")])

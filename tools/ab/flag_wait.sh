@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-call forms: spinning on hipStreamQuery (BASE at the time) against spinning on a word that a one-thread kernel behind the call's work stores
 # (FLAG: the experimental branch of mi_stream_wait_polling, built with -DMI_FLAG_WAIT before it became the library's wait; results: profiles/r02k_scan_timing.txt)
-cd /root/repo
+cd "$(dirname "$0")/../.."
 cp openlte_amd/libmi_lte.so _ko/lib_BASE.so
 for v in BASE FLAG BASE FLAG; do
   cp _ko/lib_$v.so openlte_amd/libmi_lte.so; echo "== $v"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # what the GPU's clocks and power are while the chain bench runs (is the chip power-limited?): samples rocm-smi once a second
-cd /root/repo
+cd "$(dirname "$0")/.."
 (timeout 120 python bench.py --workload chain --steps 60 --no-turbo-leg --no-host-leg --no-cpu-baseline --no-kernel-events > /tmp/b.json 2>/dev/null) &
 BP=$!
 sleep 12

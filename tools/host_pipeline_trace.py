@@ -1,6 +1,6 @@
 import os, sys, time
 import numpy as np
-ROOT = "/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import lte_testdata as td, openlte_amd as m
 from openlte_amd import synth

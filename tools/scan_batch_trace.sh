@@ -1,6 +1,6 @@
 #!/bin/bash
 # where the 20 MHz batch scanner's PDSCH stage spends its time: HIP API calls and kernels of the LAST Scanner::run (the all-subframes batch), in order
-cd /root/repo/shim/_build; export TMPDIR=/tmp
+cd "$(dirname "$0")/../shim/_build"; export TMPDIR=/tmp
 ./capture_gen /tmp/cap_100.bin 100 77 12 > /dev/null 2>&1
 for i in 1 2 3; do ./scan_batch /tmp/cap_100.bin 30.72 2>&1 >/dev/null | grep timing; done
 rm -rf /tmp/tr; rocprofv3 --hip-trace --kernel-trace --output-format csv -d /tmp/tr -o t -- ./scan_batch /tmp/cap_100.bin 30.72 > /dev/null 2>/tmp/tr.err

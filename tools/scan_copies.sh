@@ -1,6 +1,6 @@
 #!/bin/bash
 # which copy commands the per-call scan still issues inside its per-subframe loop (sizes and directions)
-cd /root/repo/shim/_build; export TMPDIR=/tmp
+cd "$(dirname "$0")/../shim/_build"; export TMPDIR=/tmp
 ./capture_gen /tmp/cap_100.bin 100 77 12 > /dev/null 2>&1
 rm -rf /tmp/tr; rocprofv3 --memory-copy-trace --kernel-trace --output-format csv -d /tmp/tr -o t -- ./scan_gpu /tmp/cap_100.bin 30.72 > /dev/null 2>/tmp/tr.err
 python3 - <<'PY'

@@ -1,5 +1,5 @@
 #!/bin/bash
-cd /root/repo/shim/_build
+cd "$(dirname "$0")/../shim/_build"
 ./capture_gen /tmp/cap_25.bin 25 301 24 > /dev/null 2>&1
 ./capture_gen /tmp/cap_100.bin 100 77 12 > /dev/null 2>&1
 for e in "" "HSA_ENABLE_INTERRUPT=0" "GPU_MAX_HW_QUEUES=1"; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 # where the per-call scan's time goes (1.4 MHz and 20 MHz captures): HIP API time by call, GPU time by kernel, per subframe of the loop
-cd /root/repo/shim/_build; export TMPDIR=/tmp
+cd "$(dirname "$0")/../shim/_build"; export TMPDIR=/tmp
 for cfg in "6 17 30 1.92" "100 77 12 30.72"; do
   set -- $cfg
   ./capture_gen /tmp/cap_$1.bin $1 $2 $3 > /dev/null 2>&1

@@ -1,4 +1,4 @@
-cd /root/repo; export TMPDIR=/tmp
+cd "$(dirname "$0")/.."; export TMPDIR=/tmp
 rm -rf /tmp/trb; rocprofv3 --hip-trace --kernel-trace --memory-copy-trace --stats --output-format csv -d /tmp/trb -o t -- python bench.py --workload uplink --steps 10 --warmup 2 --no-cpu-baseline --no-kernel-events > /tmp/trb.out 2>/tmp/trb.err
 tail -1 /tmp/trb.out | cut -c1-200
 f=$(find /tmp/trb -name "*hip_api_stats.csv" | head -1); head -12 $f | cut -d, -f1-5

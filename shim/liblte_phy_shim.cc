@@ -43,13 +43,11 @@ namespace {
 struct Entry {
     mi_lte_ctx *ctx = nullptr;
     std::mutex  mu;
-#ifdef MI_LTE_SHIM_OWN_LIFECYCLE
-    // what the shim's own liblte_phy_ul_init was given (the reference turns it into tables inside the struct; here the library's generators
-    // are asked per call and their answers kept): PUSCH reference-signal configuration, the cell the tables are FOR, DMRS per (subframe, N_prb)
+    // what liblte_phy_ul_init was given (the reference turns it into tables inside the struct; here the library's generators are asked per
+    // call and their answers kept): PUSCH reference-signal configuration, the cell the tables are FOR, DMRS per (subframe, N_prb)
     mi_lte_ul_cfg ul = {0, 0, 0, 0, 0};
     uint32_t      ul_cell = 0, n_cs_an = 0, delta_pucch_shift = 1;
     std::map<uint32_t, std::vector<float>> dmrs, pucch; // keys: subframe * 256 + N_prb / + N_1_p_pucch
-#endif
 };
 std::mutex                                            g_mu;
 std::map<LIBLTE_PHY_STRUCT *, std::shared_ptr<Entry>> g_ctx;
@@ -171,6 +169,32 @@ LIBLTE_ERROR_ENUM liblte_phy_cleanup(LIBLTE_PHY_STRUCT *phy_struct)
 {
     unregister_struct(phy_struct);
     return liblte_phy_cleanup_cpu(phy_struct);
+}
+
+// liblte_phy_ul_init (liblte_phy.h:613-625, impl. liblte_phy.cc:2337-2517): the reference's own (compiled under the name liblte_phy_ul_init_cpu)
+// fills the struct for the entry points that are NOT replaced -- the transmit side reads its DMRS and PRACH tables -- and the configuration
+// is kept here: the replaced receive side asks the library's own generators (ul_rs.cc, prach_sets.hpp), exactly as the build without the
+// reference's PHY object does, and reads none of the struct's uplink tables.
+LIBLTE_ERROR_ENUM liblte_phy_ul_init_cpu(LIBLTE_PHY_STRUCT *phy_struct, uint16 N_id_cell, uint32 prach_root_seq_idx, uint32 prach_preamble_format, uint32 prach_zczc,
+                                         bool prach_hs_flag, uint8 group_assignment_pusch, bool group_hopping_enabled, bool sequence_hopping_enabled,
+                                         uint8 cyclic_shift, uint8 cyclic_shift_dci, uint8 N_cs_an, uint8 delta_pucch_shift);
+LIBLTE_ERROR_ENUM liblte_phy_ul_init(LIBLTE_PHY_STRUCT *phy_struct, uint16 N_id_cell, uint32 prach_root_seq_idx, uint32 prach_preamble_format, uint32 prach_zczc,
+                                     bool prach_hs_flag, uint8 group_assignment_pusch, bool group_hopping_enabled, bool sequence_hopping_enabled, uint8 cyclic_shift,
+                                     uint8 cyclic_shift_dci, uint8 N_cs_an, uint8 delta_pucch_shift)
+{
+    const LIBLTE_ERROR_ENUM err = liblte_phy_ul_init_cpu(phy_struct, N_id_cell, prach_root_seq_idx, prach_preamble_format, prach_zczc, prach_hs_flag,
+                                                         group_assignment_pusch, group_hopping_enabled, sequence_hopping_enabled, cyclic_shift, cyclic_shift_dci,
+                                                         N_cs_an, delta_pucch_shift);
+    if (err != LIBLTE_SUCCESS || phy_struct == NULL) return err;
+    std::shared_ptr<Entry>      e = entry_for(phy_struct);
+    std::lock_guard<std::mutex> call(e->mu);
+    e->ul      = mi_lte_ul_cfg{group_assignment_pusch, group_hopping_enabled ? 1u : 0u, sequence_hopping_enabled ? 1u : 0u, cyclic_shift, cyclic_shift_dci};
+    e->ul_cell = N_id_cell;
+    e->n_cs_an = N_cs_an;
+    e->delta_pucch_shift = (uint32_t)delta_pucch_shift + 1; // (generate_dmrs_pucch is handed delta_pucch_shift + 1, liblte_phy.cc:2414)
+    e->dmrs.clear();
+    e->pucch.clear();
+    return err;
 }
 #else
 // liblte_phy_update_n_rb_dl (liblte_phy.h:620-621, impl. liblte_phy.cc:2592-2647): a bandwidth is accepted when its sub-carriers fit the
@@ -365,13 +389,9 @@ LIBLTE_ERROR_ENUM liblte_phy_pusch_channel_decode(LIBLTE_PHY_STRUCT *phy_struct,
     mi_lte_pdsch_alloc a;
     to_mi_alloc(alloc, &a);
     const uint32 sf = subframe->num, np = alloc->N_prb;
-#ifndef MI_LTE_SHIM_OWN_LIFECYCLE
-    // the reference signals are the ones liblte_phy_ul_init (still the reference's own code) left in the struct
-    const float *d0r = phy_struct->pusch_dmrs_0_re[sf][np], *d0i = phy_struct->pusch_dmrs_0_im[sf][np];
-    const float *d1r = phy_struct->pusch_dmrs_1_re[sf][np], *d1i = phy_struct->pusch_dmrs_1_im[sf][np];
-#else
-    // ... or the library's own generator (mi_lte_ul_dmrs_pusch restates generate_dmrs_pusch, liblte_phy.cc:6745-6990, value for value:
-    // tests/test_uplink_cpu.py), asked once per (subframe, N_prb) with the configuration and the cell liblte_phy_ul_init was given
+    // the reference signals come from the library's own generator (mi_lte_ul_dmrs_pusch restates generate_dmrs_pusch, liblte_phy.cc:6745-6990,
+    // value for value: tests/test_uplink_cpu.py), asked once per (subframe, N_prb) with the configuration and the cell liblte_phy_ul_init was
+    // given -- not from the tables the reference's liblte_phy_ul_init leaves in the struct (pusch_dmrs_*), in either build
     std::vector<float> &tab = entry_->dmrs[sf * 256u + np];
     if (tab.empty()) {
         tab.resize((size_t)4 * 12 * np);
@@ -381,7 +401,6 @@ LIBLTE_ERROR_ENUM liblte_phy_pusch_channel_decode(LIBLTE_PHY_STRUCT *phy_struct,
         }
     }
     const float *d0r = &tab[0], *d0i = &tab[12 * np], *d1r = &tab[24 * np], *d1i = &tab[36 * np];
-#endif
     int rc = mi_lte_pusch_channel_decode_host(c, phy_struct->N_rb_ul, &subframe->rx_symb_re[0][0], &subframe->rx_symb_im[0][0], sf, &a,
                                               N_id_cell, N_ant, d0r, d0i, d1r, d1i, out_bits, N_out_bits);
     return rc == 0 ? LIBLTE_SUCCESS : LIBLTE_ERROR_INVALID_INPUTS; // the reference's own failure code on this path (:2809, :2929)
@@ -396,14 +415,9 @@ LIBLTE_ERROR_ENUM liblte_phy_detect_prach(LIBLTE_PHY_STRUCT *phy_struct, float *
     MI_LOCKED_CTX(phy_struct, LIBLTE_ERROR_INVALID_INPUTS);
     mi_lte_prach_cfg pc = {phy_struct->prach_root_seq_idx, phy_struct->prach_preamble_format, phy_struct->prach_zczc,
                            phy_struct->prach_hs_flag ? 1u : 0u, freq_offset};
-#ifndef MI_LTE_SHIM_OWN_LIFECYCLE
-    // the root sequences' spectra are the ones liblte_phy_ul_init (still the reference's code) left in the struct
-    int rc = mi_lte_detect_prach_host(c, phy_struct->N_samps_per_symb, phy_struct->N_rb_ul, &pc, &phy_struct->prach_x_u_fft_re[0][0],
-                                      &phy_struct->prach_x_u_fft_im[0][0], phy_struct->prach_N_x_u, samps_re, samps_im, N_det_pre, det_pre, det_ta);
-#else
-    // ... or the library's own (no spectra handed over: the plan generates the cell's root set itself, prach.hip / prach_sets.hpp)
+    // no spectra handed over: the plan generates the cell's root set itself (prach.hip / prach_sets.hpp) -- the struct's prach_x_u_fft_* tables are
+    // not read, in either build
     int rc = mi_lte_detect_prach_host(c, phy_struct->N_samps_per_symb, phy_struct->N_rb_ul, &pc, NULL, NULL, 0, samps_re, samps_im, N_det_pre, det_pre, det_ta);
-#endif
     return rc == 0 ? LIBLTE_SUCCESS : LIBLTE_ERROR_INVALID_INPUTS;
 }
 
@@ -504,9 +518,7 @@ LIBLTE_ERROR_ENUM liblte_phy_find_sss(LIBLTE_PHY_STRUCT *phy_struct, float *i_sa
 
 // ---- PUCCH formats 1 / 1a / 1b (LTE_fdd_enb_phy.cc:867)
 
-#ifndef MI_LTE_SHIM_OWN_LIFECYCLE
-extern int32 W_5_4_1_2[3][4]; // the reference's orthogonal-sequence table (liblte_phy.cc:161), still its own object
-#else
+#ifdef MI_LTE_SHIM_OWN_LIFECYCLE
 int32 W_5_4_1_2[3][4] = {{1, 1, 1, 1}, {1, -1, 1, -1}, {1, -1, -1, 1}}; // 36.211 table 5.4.1-2; external like the reference's (liblte_phy.cc:161): callers name it
 #endif
 
@@ -520,9 +532,8 @@ LIBLTE_ERROR_ENUM liblte_phy_pucch_format_1_1a_1b_channel_decode(LIBLTE_PHY_STRU
         return LIBLTE_ERROR_INVALID_INPUTS;
     MI_LOCKED_CTX(phy_struct, LIBLTE_ERROR_INVALID_INPUTS);
     const uint32 N = subframe->num, n = N_1_p_pucch;
-#ifdef MI_LTE_SHIM_OWN_LIFECYCLE
     // the library's own generator (mi_lte_ul_pucch_tables restates generate_dmrs_pucch, liblte_phy.cc:6986-7129, value for value:
-    // tests/test_uplink_cpu.py), asked once per (subframe, resource) with what liblte_phy_ul_init was given
+    // tests/test_uplink_cpu.py), asked once per (subframe, resource) with what liblte_phy_ul_init was given -- not the struct's pucch_* tables, in either build
     if (!phy_struct->ul_init) return LIBLTE_ERROR_INVALID_INPUTS;
     std::vector<float> &tab = entry_->pucch[N * 256u + n];
     if (tab.empty()) {
@@ -533,26 +544,6 @@ LIBLTE_ERROR_ENUM liblte_phy_pucch_format_1_1a_1b_channel_decode(LIBLTE_PHY_STRU
         }
     }
     const float *t = &tab[0];
-#else
-    // the sequences liblte_phy_ul_init (still the reference's code) left in the struct for this (subframe, resource)
-    static const uint32 symb[4] = {0, 1, 5, 6};
-    float        t[MI_LTE_PUCCH_TAB_FLOATS];
-    memcpy(t, phy_struct->pucch_dmrs_0_re[N][n], 36 * sizeof(float));
-    memcpy(t + 36, phy_struct->pucch_dmrs_0_im[N][n], 36 * sizeof(float));
-    memcpy(t + 72, phy_struct->pucch_dmrs_1_re[N][n], 36 * sizeof(float));
-    memcpy(t + 108, phy_struct->pucch_dmrs_1_im[N][n], 36 * sizeof(float));
-    for (uint32 m = 0; m < 2; m++) {
-        float s_re, s_im; // s(n_s), liblte_phy.cc:3058-3068
-        if ((phy_struct->pucch_n_prime_p[N][n][m] % 2) == 0) { s_re = 1; s_im = 0; }
-        else { s_re = cos(M_PI / 2); s_im = sin(M_PI / 2); }
-        for (uint32 i = 0; i < 4; i++) {
-            memcpy(t + 144 + (m * 4 + i) * 12, phy_struct->pucch_r_u_v_alpha_p_re[N][n][m][symb[i]], 12 * sizeof(float));
-            memcpy(t + 240 + (m * 4 + i) * 12, phy_struct->pucch_r_u_v_alpha_p_im[N][n][m][symb[i]], 12 * sizeof(float));
-            t[336 + m * 4 + i] = s_re * W_5_4_1_2[phy_struct->pucch_n_oc_p[N][n][m]][i];
-            t[344 + m * 4 + i] = s_im * W_5_4_1_2[phy_struct->pucch_n_oc_p[N][n][m]][i];
-        }
-    }
-#endif
     uint32_t nb = 0;
     int rc = mi_lte_pucch_decode_host(c, phy_struct->N_rb_ul, &subframe->rx_symb_re[0][0], &subframe->rx_symb_im[0][0], (uint32_t)format, N_ant, N_1_p_pucch, t,
                                       out_bits, &nb);

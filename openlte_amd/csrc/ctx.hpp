@@ -64,6 +64,7 @@ struct mi_lte_ctx {
     // Gold-sequence tables (see mi_ctx_gold_tables)
     uint32_t *d_gold_x1 = nullptr, *d_gold_x2b = nullptr;
     uint32_t  gold_words = 0;
+    void     *d_pusch_shapes = nullptr; // uplink.hip: one PuschShape per N_prb (transform pre-decoding passes), made on first use
 
     float2   *d_fft_tw  = nullptr; // exp(-2*pi*i*k/4096), k = 0..4095, then the per-pass tables at 4096 + MI_FFT_TWC_* (mi_ctx_fft_twiddles)
     uint32_t *d_crc_tab = nullptr; // (x^e mod gCRC24A) << 8 at index MI_CRC_TAB_BIAS + e, e = -8..6143 (mi_ctx_crc_table)

@@ -189,14 +189,30 @@ __host__ __device__ inline float ref_atan2f(float y, float x)
 // code (W5 2.65 -> 2.54 M subframes/s), so demap_symbol takes the choice as a template parameter (profiles/r03t_*, r03u_*).
 __host__ __device__ __attribute__((noinline)) float ref_atan2f_call(float y, float x) { return ref_atan2f(y, x); }
 
-// get_soft_decision (liblte_phy.cc:13880-13900) with max_dist = 1
-__device__ __forceinline__ float soft_decision(float rx_re, float rx_im, float exp_re, float exp_im)
+// (int)(127 * get_soft_decision(...)) (liblte_phy.cc:13880-13900 with max_dist = 1, scaled and truncated as modulation_demapper does with it).
+// The reference's sqrtf is the correctly rounded one, which on this hardware is v_sqrt_f32 plus a dozen instructions of scaling and fix-up; the
+// integer it ends in depends on that last bit only when 127 (1 - dist) lies next to an integer.  So: the hardware's root (1 ulp), the same
+// float operations after it, and the exact route whenever the result is within 2^-13 of an integer (or the squared distance is down where
+// v_sqrt_f32 no longer sees its argument).  Two roots that differ by up to 2 ulp (<= 2^-23) move 1 - dist by at most 3 * 2^-24 and the product by
+// at most 127 * 3 * 2^-24 + 2^-17 < 2^-15, a quarter of the guard: outside it both routes truncate to the same integer; inside it the exact
+// route is the one that runs -- for the whole wavefront when any of its lanes asks (one symbol in 4 000, so one wavefront in 60).  NaN falls
+// through both routes alike.
+__device__ __forceinline__ int soft_decision_127(float rx_re, float rx_im, float exp_re, float exp_im)
 {
-    const float d_re = rx_re - exp_re, d_im = rx_im - exp_im;
-    float dist = sqrtf(d_re * d_re + d_im * d_im);
+    const float d_re = rx_re - exp_re, d_im = rx_im - exp_im, d2 = d_re * d_re + d_im * d_im;
     const float cap = 1.0f - (1.0f / 120);
-    if (dist >= cap) dist = cap;
-    return 1.0f - dist;
+    const float s = __builtin_amdgcn_sqrtf(d2);
+    float       v = 127 * (1.0f - (s >= cap ? cap : s));
+    const float f = __builtin_amdgcn_fractf(v);
+    // (a wave-uniform branch around something the compiler may not hoist: left to itself it turns the `if` into selects and computes both
+    // routes for everybody)
+    if (__builtin_amdgcn_ballot_w64(!(f > 0x1p-13f && f < 1.0f - 0x1p-13f && d2 >= 0x1p-96f)) != 0) {
+        asm volatile("; exact route" ::: "memory");
+        float dist = sqrtf(d2);
+        if (dist >= cap) dist = cap;
+        v = 127 * (1.0f - dist);
+    }
+    return (int)v;
 }
 
 // modulation_demapper (liblte_phy.cc:9502-9660) for one symbol; writes Q_m int8 values
@@ -234,13 +250,13 @@ template <bool ATAN_OUT_OF_LINE = false> __device__ __forceinline__ void demap_s
             else if (((double)ang >= M_PI / 2) && ((double)ang < M_PI)) { er = -r2; ei = r2; }
             else                                                        { er = -r2; ei = -r2; }
         }
-        const int m = (int)(127 * soft_decision(re, im, er, ei));
+        const int m = soft_decision_127(re, im, er, ei);
         b[0] = (int8_t)((er > 0) ? m : -m);
         b[1] = (int8_t)((ei > 0) ? m : -m);
     } else {
         const float ang = ATAN_OUT_OF_LINE ? ref_atan2f_call(im, re) : ref_atan2f(im, re);
-        if (((double)ang > -M_PI / 4) && ((double)ang < 3 * M_PI / 4)) b[0] = (int8_t)(int)(127 * soft_decision(re, im, r2, r2));
-        else                                                          b[0] = (int8_t)(-(int)(127 * soft_decision(re, im, -r2, -r2)));
+        if (((double)ang > -M_PI / 4) && ((double)ang < 3 * M_PI / 4)) b[0] = (int8_t)soft_decision_127(re, im, r2, r2);
+        else                                                          b[0] = (int8_t)(-soft_decision_127(re, im, -r2, -r2));
     }
 }
 

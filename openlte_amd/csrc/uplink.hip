@@ -38,11 +38,29 @@ struct PuschDesc {
     uint32_t dmrs_off;      // float offset of dmrs_0_re | dmrs_0_im | dmrs_1_re | dmrs_1_im (M each) in the DMRS pool
 };
 
-// floor(n / d) for n < 2^16, d < 2^16 as the high word of n * inv, inv = floor((2^32 - 1) / d) + 1 (exact in that range; d = 1
-// wraps to inv = 0, which div_by reads as "no division"): the index arithmetic of the passes below divides by sizes known only
-// per allocation, and a 32-bit division without a hardware divider costs more than the butterfly it addresses.
-__device__ __forceinline__ uint32_t inv_of(uint32_t d) { return 0xFFFFFFFFu / d + 1u; }
-__device__ __forceinline__ uint32_t div_by(uint32_t n, uint32_t inv) { return inv ? __umulhi(n, inv) : n; }
+// The transform pre-decoding of an allocation of N_prb resource blocks, M = 12 N_prb: the radices of its Stockham passes in the order they
+// run (9, 3, 5, 8, 4, 2, then the primes that are left) with each pass's sizes, sqrt(M) as the reference forms it (liblte_phy.cc:6644: integer
+// argument -> double sqrt, stored to float) and the reciprocals the index arithmetic divides by.  One row per N_prb, made once per context on
+// the host (pusch_shapes below): forming them in the kernel -- a double-precision square root, a dozen 32-bit divisions of workgroup-uniform
+// values that have no scalar instruction and so run on the vector unit, the radix search -- was 11 % of its vector instructions at 6 PRB.
+constexpr uint32_t MAX_PASSES = 6;
+struct DftPass {
+    uint32_t R, Ns, nb, tstride; // radix, product of the radices before it, M / R, M / (Ns R)
+    float    r_nb, r_ns;         // reciprocals for quot() below
+};
+struct PuschShape {
+    float    sqrt_M, r_M;
+    uint32_t n_pass, pad;
+    DftPass  pass[MAX_PASSES];
+};
+static_assert(sizeof(PuschShape) == 160, "one row = 40 words");
+constexpr uint32_t N_SHAPES = 111; // N_prb 0 .. 110
+
+// floor(n / d) for n < 2^20 as the truncated float product n * r, r = the float next above or equal to 1 / d (recip_up on the host):
+// n r >= n / d, so a multiple of d never lands below its quotient (the quotient is representable and rounding is monotonic), and the excess
+// n / d * 2^-22 stays under the 1 / d that separates n / d from the next integer while n < 2^22.  Three full-rate instructions where
+// v_mul_hi_u32 issues at a quarter of the rate.
+__device__ __forceinline__ uint32_t quot(uint32_t n, float r) { return (uint32_t)((float)n * r); }
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
@@ -130,11 +148,11 @@ template <> __device__ __forceinline__ void butterfly<9>(float2 (&v)[9])
 // the twiddle w^(r*k) being entry r*k*M/(Ns*R) (< M) of the allocation's table tw[t] = exp(+2*pi*i*t/M).
 template <uint32_t R, uint32_t THREADS>
 __device__ __forceinline__ void dft_pass_r(const float2 *__restrict__ in, float2 *__restrict__ out, const float2 *__restrict__ tw,
-                                           uint32_t S, uint32_t M, uint32_t M_max, uint32_t Ns)
+                                           uint32_t S, uint32_t M_max, const DftPass ps)
 {
-    const uint32_t nb = M / R, tstride = nb / Ns, inv_nb = inv_of(nb), inv_ns = inv_of(Ns);
+    const uint32_t nb = ps.nb, Ns = ps.Ns, tstride = ps.tstride;
     for (uint32_t o = threadIdx.x; o < S * nb; o += THREADS) {
-        const uint32_t sy = div_by(o, inv_nb), j = o - __umul24(sy, nb), k = j - __umul24(div_by(j, inv_ns), Ns);
+        const uint32_t sy = quot(o, ps.r_nb), j = o - __umul24(sy, nb), k = Ns > 1 ? j - __umul24(quot(j, ps.r_ns), Ns) : 0;
         const float2  *x = in + __umul24(sy, M_max) + j;
         float2         v[R];
 #pragma unroll
@@ -155,13 +173,12 @@ __device__ __forceinline__ void dft_pass_r(const float2 *__restrict__ in, float2
 // step = (k + q*Ns) * M/(Ns*R) < M, twiddle index r*step mod M.
 template <uint32_t THREADS>
 __device__ __forceinline__ void dft_pass(const float2 *__restrict__ in, float2 *__restrict__ out, const float2 *__restrict__ tw,
-                                         uint32_t S, uint32_t M, uint32_t M_max, uint32_t R, uint32_t Ns)
+                                         uint32_t S, uint32_t M, float r_M, uint32_t M_max, const DftPass ps)
 {
-    const uint32_t nb = M / R, period = Ns * R, tstride = M / period;
-    const uint32_t inv_m = inv_of(M), inv_nb = inv_of(nb), inv_ns = inv_of(Ns);
+    const uint32_t R = ps.R, nb = ps.nb, Ns = ps.Ns, tstride = ps.tstride;
     for (uint32_t o = threadIdx.x; o < S * M; o += THREADS) {
-        const uint32_t sy = div_by(o, inv_m), oo = o - sy * M;
-        const uint32_t q = div_by(oo, inv_nb), j = oo - q * nb, k = j - div_by(j, inv_ns) * Ns, step = (k + q * Ns) * tstride;
+        const uint32_t sy = quot(o, r_M), oo = o - sy * M;
+        const uint32_t q = quot(oo, ps.r_nb), j = oo - q * nb, k = j - quot(j, ps.r_ns) * Ns, step = (k + q * Ns) * tstride;
         const float2  *x = in + sy * M_max + j;
         float    ar = 0.0f, ai = 0.0f;
         uint32_t t  = 0; // r*step mod M
@@ -191,7 +208,7 @@ __global__ __launch_bounds__(THREADS) void k_pusch_demod(const float *__restrict
                                                      const mi_lte_pdsch_alloc *__restrict__ allocs, const PuschDesc *__restrict__ desc,
                                                      const float *__restrict__ dmrs_pool, GoldTables gt, int8_t *__restrict__ e_base,
                                                      const uint32_t *__restrict__ e_off, uint32_t *__restrict__ e_len, uint32_t M_max,
-                                                     uint32_t S_par)
+                                                     uint32_t S_par, float r_S_par, const PuschShape *__restrict__ shapes)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     // LDS: est[9][M_max] (mag0 mag1 dmag | unit vectors of ang0, ang1, dang) | tw[M_max] | buf A[S_par][M_max] | buf B[S_par][M_max] (float2) | scrambling words
@@ -204,6 +221,7 @@ __global__ __launch_bounds__(THREADS) void k_pusch_demod(const float *__restrict
     const mi_lte_pdsch_alloc &al = allocs[a_idx];
     const PuschDesc           ds = desc[a_idx];
     const uint32_t N_prb = al.N_prb, M = 12 * N_prb;
+    const PuschShape &sh = shapes[N_prb]; // (uniform: scalar loads)
     const uint32_t Qm = al.mod_type == 3 ? 6 : al.mod_type == 2 ? 4 : al.mod_type == 1 ? 2 : 1;
     const uint32_t N_bits = 12 * M * Qm;
     const float   *rx_re = subframes + (size_t)al.unit * sf_stride, *rx_im = rx_re + 16 * N_SC_MAX;
@@ -225,7 +243,8 @@ __global__ __launch_bounds__(THREADS) void k_pusch_demod(const float *__restrict
             sincospif(2.0f * (float)i / (float)M, &sn, &cs);
             tw[i] = make_float2(cs, sn);
         } else {
-            const uint32_t sc = al.prb[task][i / 12] * 12 + i % 12, L = task ? 10 : 3;
+            const uint32_t rb = __umul24(i, 10923u) >> 17; // i / 12 for i < 1536
+            const uint32_t sc = al.prb[task][rb] * 12 + (i - 12 * rb), L = task ? 10 : 3;
             const float    cr = rx_re[L * N_SC_MAX + sc], ci = rx_im[L * N_SC_MAX + sc];
             const float    dr = d_pool[2 * task * M + i], di = d_pool[(2 * task + 1) * M + i];
             const float    t_re = cr * dr + ci * di, t_im = ci * dr - cr * di;
@@ -250,11 +269,11 @@ __global__ __launch_bounds__(THREADS) void k_pusch_demod(const float *__restrict
     }
     __syncthreads();
 
-    const float sqrt_M = (float)sqrt((double)M); // liblte_phy.cc:6644 (integer argument -> double sqrt, stored to float)
+    const float sqrt_M = sh.sqrt_M; // liblte_phy.cc:6644 (integer argument -> double sqrt, stored to float: formed on the host)
     int8_t     *e      = e_base + (size_t)e_off[a_idx] * 64; // 64-byte units
 
     for (uint32_t s0 = 0; s0 < 12; s0 += S_par) { // S_par data symbols at a time (all 12 when they fit in LDS)
-        const uint32_t S = min(S_par, 12u - s0), inv_s = inv_of(S);
+        const uint32_t S = S_par; // (12, 6, 3, 2 or 1: always a divisor of 12)
         // ---- channel estimate of each symbol and the one-tap equaliser.  One item per (subcarrier, slot): the slot's DMRS
         // estimate, its unit vector and the powers of exp(i f_ang) are fetched / formed once and serve the slot's (up to) six data
         // symbols; S is 12 (both slots) or divides 6 (part of one slot).
@@ -264,7 +283,8 @@ __global__ __launch_bounds__(THREADS) void k_pusch_demod(const float *__restrict
             const float    mag = est[b * M_max + i], f_mag = est[2 * M_max + i];
             const float2   u = make_float2(est[(3 + 2 * b) * M_max + i], est[(4 + 2 * b) * M_max + i]);
             const float2   f1 = make_float2(est[7 * M_max + i], est[8 * M_max + i]), f2 = cmul(f1, f1), f3 = cmul(f2, f1);
-            const uint32_t sc = al.prb[b][i / 12] * 12 + i % 12;
+            const uint32_t rb = __umul24(i, 10923u) >> 17; // i / 12 for i < 1536
+            const uint32_t sc = al.prb[b][rb] * 12 + (i - 12 * rb);
             const float   *z_re = rx_re + 7 * b * N_SC_MAX + sc, *z_im = rx_im + 7 * b * N_SC_MAX + sc;
             float2        *dst = bufA + ((int)(6 * b) - (int)s0) * (int)M_max + (int)i; // symbol s = 6 b + sp goes to row s - s0
 #pragma unroll
@@ -287,24 +307,19 @@ __global__ __launch_bounds__(THREADS) void k_pusch_demod(const float *__restrict
         // ---- transform pre-decoding: M-point backward DFTs, radices 9, 3, 5, 8, 4, 2, then the remaining prime.  Odd radices go
         // first: the first pass writes its R outputs R float2 apart across lanes, which is conflict-free in LDS only for odd R
         // (M = 12 N_prb always has a factor 3 to start with).
-        float2  *src = bufA, *dst = bufB;
-        uint32_t rem = M, Ns = 1;
-        while (rem > 1) { // uniform over the workgroup
-            uint32_t R;
-            if (rem % 9 == 0)      { R = 9; dft_pass_r<9, THREADS>(src, dst, tw, S, M, M_max, Ns); }
-            else if (rem % 3 == 0) { R = 3; dft_pass_r<3, THREADS>(src, dst, tw, S, M, M_max, Ns); }
-            else if (rem % 5 == 0) { R = 5; dft_pass_r<5, THREADS>(src, dst, tw, S, M, M_max, Ns); }
-            else if (rem % 8 == 0) { R = 8; dft_pass_r<8, THREADS>(src, dst, tw, S, M, M_max, Ns); }
-            else if (rem % 4 == 0) { R = 4; dft_pass_r<4, THREADS>(src, dst, tw, S, M, M_max, Ns); }
-            else if (rem % 2 == 0) { R = 2; dft_pass_r<2, THREADS>(src, dst, tw, S, M, M_max, Ns); }
-            else {
-                R = 7;
-                while (rem % R) R += 2;
-                dft_pass<THREADS>(src, dst, tw, S, M, M_max, R, Ns);
+        float2 *src = bufA, *dst = bufB;
+        for (uint32_t p = 0; p < sh.n_pass; p++) { // uniform over the workgroup
+            const DftPass ps = sh.pass[p];
+            switch (ps.R) {
+            case 9:  dft_pass_r<9, THREADS>(src, dst, tw, S, M_max, ps); break;
+            case 3:  dft_pass_r<3, THREADS>(src, dst, tw, S, M_max, ps); break;
+            case 5:  dft_pass_r<5, THREADS>(src, dst, tw, S, M_max, ps); break;
+            case 8:  dft_pass_r<8, THREADS>(src, dst, tw, S, M_max, ps); break;
+            case 4:  dft_pass_r<4, THREADS>(src, dst, tw, S, M_max, ps); break;
+            case 2:  dft_pass_r<2, THREADS>(src, dst, tw, S, M_max, ps); break;
+            default: dft_pass<THREADS>(src, dst, tw, S, M, sh.r_M, M_max, ps); break;
             }
             __syncthreads();
-            Ns *= R;
-            rem /= R;
             float2 *t = src; src = dst; dst = t;
         }
         // ---- de-map, descramble, de-interleave (transpose): soft bit q of symbol k goes to (k*12 + s)*Q_m + q.  Instantiated per modulation
@@ -313,7 +328,7 @@ __global__ __launch_bounds__(THREADS) void k_pusch_demod(const float *__restrict
         constexpr uint32_t MOD = decltype(modc)::value, QM = MOD == 3 ? 6 : MOD == 2 ? 4 : MOD == 1 ? 2 : 1;
         for (uint32_t o = threadIdx.x; o < S * M; o += THREADS) {
             // (all twelve symbols side by side is the common case: o / 12 for o < 2^15 as one 24-bit multiply and a shift)
-            const uint32_t k = S == 12 ? __umul24(o, 43691u) >> 19 : div_by(o, inv_s), sy = o - __umul24(k, S), s = s0 + sy; // neighbouring threads write neighbouring bytes of e
+            const uint32_t k = S == 12 ? __umul24(o, 43691u) >> 19 : quot(o, r_S_par), sy = o - __umul24(k, S), s = s0 + sy; // neighbouring threads write neighbouring bytes of e
             const float2   x = src[__umul24(sy, M_max) + k];
             int8_t         b[6] = {0, 0, 0, 0, 0, 0};
             demap_symbol(sqrt_M * x.x, sqrt_M * x.y, MOD, b);
@@ -443,6 +458,51 @@ struct mi_lte_pusch_plan {
     std::vector<Group>    groups;
     std::vector<uint32_t> h_e_off, h_e_len;
 };
+
+// the float next above or equal to 1 / d (see quot)
+static float recip_up(uint32_t d)
+{
+    const double rd = 1.0 / (double)d;
+    float        r  = (float)rd;
+    if ((double)r < rd) r = nextafterf(r, 2.0f);
+    return r;
+}
+
+// One PuschShape per N_prb, in HBM for the life of the context
+static int pusch_shapes(mi_lte_ctx *ctx)
+{
+    if (ctx->d_pusch_shapes) return MI_LTE_OK;
+    std::vector<PuschShape> tab(N_SHAPES);
+    memset(tab.data(), 0, sizeof(PuschShape) * N_SHAPES);
+    for (uint32_t n = 1; n < N_SHAPES; n++) {
+        PuschShape    &sh = tab[n];
+        const uint32_t M  = 12 * n;
+        sh.sqrt_M = (float)sqrt((double)M);
+        sh.r_M    = recip_up(M);
+        uint32_t rem = M, Ns = 1;
+        while (rem > 1) {
+            uint32_t R;
+            if (rem % 9 == 0) R = 9;
+            else if (rem % 3 == 0) R = 3;
+            else if (rem % 5 == 0) R = 5;
+            else if (rem % 8 == 0) R = 8;
+            else if (rem % 4 == 0) R = 4;
+            else if (rem % 2 == 0) R = 2;
+            else { R = 7; while (rem % R) R += 2; }
+            if (sh.n_pass == MAX_PASSES) { ctx->err = "transform size with more passes than the table has room for"; return MI_LTE_ERR_UNSUPPORTED; }
+            sh.pass[sh.n_pass++] = {R, Ns, M / R, M / (Ns * R), recip_up(M / R), recip_up(Ns)};
+            Ns *= R;
+            rem /= R;
+        }
+    }
+    void *d = nullptr;
+    MI_HIP_CHECK(ctx, hipMalloc(&d, sizeof(PuschShape) * N_SHAPES));
+    ctx->owned.push_back(d);
+    MI_H2D(ctx, d, tab.data(), sizeof(PuschShape) * N_SHAPES);
+    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx));
+    ctx->d_pusch_shapes = d;
+    return MI_LTE_OK;
+}
 
 static uint32_t ul_qpp_size_at_least(uint32_t B)
 {
@@ -586,6 +646,7 @@ int mi_lte_pusch_decode_run(mi_lte_ctx *ctx, mi_lte_pusch_plan *pl, const float 
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     int rc = mi_ctx_gold_tables(ctx);
     if (rc != MI_LTE_OK) return rc;
+    if ((rc = pusch_shapes(ctx)) != MI_LTE_OK) return rc;
     GoldTables   gt{ctx->d_gold_x1, ctx->d_gold_x2b, ctx->gold_words};
     // as many of the 12 data symbols side by side as fit in ~40 KiB of ping-pong buffers (all 12 up to 17 PRB)
     uint32_t S_par = 12;
@@ -602,7 +663,8 @@ int mi_lte_pusch_decode_run(mi_lte_ctx *ctx, mi_lte_pusch_plan *pl, const float 
         if (t >= 64 && t <= (int)PUSCH_THREADS && t % 64 == 0) threads = (uint32_t)t;
     }
 #define MI_PUSCH_LAUNCH(T) MI_LAUNCH(ctx, "k_pusch_demod", k_pusch_demod<T>, dim3(pl->n_alloc), dim3(T), lds, d_subframes, (uint32_t)mi_lte_ul_subframe_floats(), \
-                                    pl->d_allocs, pl->d_desc, pl->d_dmrs, gt, pl->d_e, pl->d_e_off, pl->d_e_len, pl->M_max, S_par)
+                                    pl->d_allocs, pl->d_desc, pl->d_dmrs, gt, pl->d_e, pl->d_e_off, pl->d_e_len, pl->M_max, S_par, recip_up(S_par), \
+                                    static_cast<const PuschShape *>(ctx->d_pusch_shapes))
     if (threads == 64) MI_PUSCH_LAUNCH(64); else if (threads == 128) MI_PUSCH_LAUNCH(128); else if (threads == 192) MI_PUSCH_LAUNCH(192); else MI_PUSCH_LAUNCH(256);
 #undef MI_PUSCH_LAUNCH
     MI_HIP_CHECK(ctx, hipGetLastError());

@@ -827,3 +827,89 @@ def test_qam_decisions_next_to_the_thresholds(ctx, ref, port, mod, form):
     d_sub.free()
     ref.ref_subframe_free(rx)
     ref.ref_phy_free(phy)
+
+
+@pytest.mark.parametrize("form", ["full", "compact", "two_port"])
+def test_qpsk_soft_values_next_to_an_integer(ctx, ref, port, form):
+    """QPSK soft bits are (int)(127 (1 - dist)), dist the distance to the quadrant's constellation point (liblte_phy.cc:9541-9556 ->
+    get_soft_decision :13880-13900).  The kernels take the hardware's 1-ulp square root and fall back to the correctly rounded one only
+    where 127 (1 - dist) is within 2^-13 of an integer (phy_dev.hpp soft_decision_127) -- the only place the root's last bit can show.  Here
+    every resource element holds a symbol for which that product lands within a few float steps of an integer k = 2 .. 126 (both sides of
+    it), or sits at / beyond the distance cap, or on the constellation point itself; channel estimates 1, 2 and random gains as in the QAM
+    test above.  Soft bits must equal the reference's on all of them."""
+    import ctypes as C
+    import openlte_amd as m
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(31 + len(form))
+    n_ant = 2 if form == "two_port" else 1
+    cell, sf, cfi = 91, 6, 1
+    r2 = np.float32(1 / np.sqrt(2.0))
+    n = 14 * 1200
+    # per element: quadrant, integer k, direction (pointing out of the origin's side so the quadrant holds), a step of -8 .. 8 floats
+    sgn = rng.choice(np.array([-1.0, 1.0]), (2, n))
+    k = rng.integers(2, 127, n)
+    phi = rng.uniform(0.02, np.pi / 2 - 0.02, n)
+    dist = 1.0 - k / 127.0
+    d_im = (dist * np.sin(phi)).astype(np.float32)  # the imaginary offset as a float; the real one solved for in float64
+    d_re = np.sqrt(np.maximum(dist * dist - d_im.astype(np.float64) ** 2, 0.0))
+    x_re = (r2 + d_re).astype(np.float32)
+    x_im = (r2 + d_im).astype(np.float32)
+    steps = rng.integers(-8, 9, n)
+    for s in range(1, 9):
+        x_re = np.where(steps >= s, np.nextafter(x_re, np.float32(np.inf), dtype=np.float32), x_re)
+        x_re = np.where(steps <= -s, np.nextafter(x_re, np.float32(-np.inf), dtype=np.float32), x_re)
+    # how close did that get?  (the reference's own float chain, restated)
+    e_re, e_im = x_re - r2, x_im - r2
+    v = np.float32(127) * (np.float32(1) - np.minimum(np.sqrt(e_re * e_re + e_im * e_im, dtype=np.float32), np.float32(1 - 1 / 120)))
+    near = np.abs(v - np.rint(v)) < 2.0 ** -13
+    assert near.mean() > 0.9, near.mean()
+    special = rng.integers(0, 40, n)  # one in 40 each: on the constellation point; at the distance cap; far beyond it
+    x_re = np.where(special == 0, r2, x_re)
+    x_im = np.where(special == 0, r2, x_im)
+    cap = np.float32(1 - 1 / 120)
+    x_re = np.where(special == 1, r2 + cap, x_re).astype(np.float32)
+    x_im = np.where(special == 1, r2, x_im).astype(np.float32)
+    x_re = np.where(special == 2, r2 + np.float32(1.7), x_re).astype(np.float32)
+    tgt_re = (x_re * sgn[0]).astype(np.float32).reshape(14, 1200)
+    tgt_im = (x_im * sgn[1]).astype(np.float32).reshape(14, 1200)
+    gains = np.ones(1200, np.float32)
+    gains[600:900] = 2.0
+    gains[900:] = rng.uniform(0.3, 3.0, 300).astype(np.float32)
+    y_re = np.zeros((16, 1200), np.float32)
+    y_im = np.zeros((16, 1200), np.float32)
+    y_re[:14], y_im[:14] = tgt_re * gains, tgt_im * gains  # exact for gains 1 and 2
+    ce_re = np.zeros((4, 16, 1200), np.float32)
+    ce_im = np.zeros((4, 16, 1200), np.float32)
+    ce_re[0, :14] = gains
+    phy = ref.ref_phy_new(4, cell, n_ant, 100)
+    rx = ref.ref_subframe_new()
+    ref.ref_subframe_set_num(rx, sf)
+    po.ref_subframe_view(ref, rx, 0)[:], po.ref_subframe_view(ref, rx, 1)[:] = y_re, y_im
+    po.ref_subframe_view(ref, rx, 2, True)[:], po.ref_subframe_view(ref, rx, 3, True)[:] = ce_re, ce_im
+    allocs = [m.make_alloc(0, 1, 256, list(range(p, p + 10)), 0x500 + p, 0, 2 if n_ant == 2 else 1) for p in range(0, 100, 10)]
+    if form == "compact":
+        cfg = m.DlCfg(2048, 100, 1, m.IQ_I8 | m.CE_COMPACT)
+        h_m, h_a = np.zeros((16, 1200), np.float32), np.zeros((16, 1200), np.float32)
+        h_m[:5] = gains
+        grid = np.concatenate([y_re.ravel(), y_im.ravel(), h_m.ravel(), h_a.ravel()])
+    else:
+        cfg = m.DlCfg(2048, 100, n_ant, 0)
+        grid = np.concatenate([y_re.ravel(), y_im.ravel(), ce_re[:n_ant].ravel(), ce_im[:n_ant].ravel()])
+    d_sub = ctx.to_device(grid.astype(np.float32))
+    plan = ctx.pdsch_plan(cfg, cfi, allocs)
+    plan.run(d_sub, [sf], [cell])
+    n_sym, values = 0, set()
+    for a, al in enumerate(allocs):
+        la = td.to_lo_alloc(al)
+        out, nb = np.zeros(6200, np.uint8), C.c_uint32()
+        ref.ref_pdsch_channel_decode(phy, rx, C.byref(la), cfi, cell, n_ant, out, C.byref(nb))  # (the verdict is a CRC failure: the bits are not a code word)
+        e = plan.soft_bits(a)
+        want = np.ctypeslib.as_array(ref.ref_pdsch_descramb_bits_ptr(phy), shape=(len(e),)).astype(np.int8)
+        assert len(e) >= 10 * 12 * 10 * 2 and (e == want).all(), (a, int((e != want).sum()), np.flatnonzero(e != want)[:8], e[e != want][:8], want[e != want][:8])
+        n_sym += len(e) // 2
+        values |= set(np.abs(e).tolist())
+    assert n_sym > 13000 and len(values) > 100  # (the whole range of soft values took part)
+    plan.close()
+    d_sub.free()
+    ref.ref_subframe_free(rx)
+    ref.ref_phy_free(phy)

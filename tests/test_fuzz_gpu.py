@@ -210,8 +210,10 @@ def test_uplink_fuzz_against_the_compiled_reference(ctx, ref):
                 # sides is a quadrant decision on a component that the two SC-FDMA transforms' rounding put on opposite sides of zero; a
                 # magnitude step -- 127 * sd within the transforms' rounding of an integer -- shows in both bits of the symbol, one unit, signs kept
                 # (two symbols in 63 M soft bits over eight seeds of round 4's soak, profiles/r04_fuzz_soak/)
+                q_m = {0: 1, 1: 2, 2: 4, 3: 6}[mod]
                 for i in np.nonzero(soft[k] != wsoft)[0][:8]:
-                    soft_values.append([str(key), int(i), int(soft[k][i]), int(wsoft[i]), int(soft[k][i ^ 1]), int(wsoft[i ^ 1])])
+                    room = steps_behind_an_extrapolated_estimate(g, u, prbs, (int(i) // q_m) % 12)  # (soft bit (k 12 + s) Q_m + q belongs to symbol s)
+                    soft_values.append([str(key), int(i), int(soft[k][i]), int(wsoft[i]), int(soft[k][i ^ 1]), int(wsoft[i ^ 1]), room])
                 if (st[k] == 0) != (rc == 0):
                     verdict_diff_after_soft_diff += 1
             elif (st[k] == 0) != (rc == 0):
@@ -226,19 +228,54 @@ def test_uplink_fuzz_against_the_compiled_reference(ctx, ref):
                             verdicts_differing_in_those=verdict_diff_after_soft_diff,
                             differing_soft_bits_position_library_reference_and_the_symbols_other_bit=soft_values[:50],
                             differing_soft_bits_that_are_sign_flips_of_equal_magnitude=sum(sign_flip(v) for v in soft_values),
-                            differing_soft_bits_that_are_one_step_of_the_symbols_magnitude=sum(magnitude_step(v) for v in soft_values))
+                            differing_soft_bits_that_are_one_step_of_the_symbols_magnitude=sum(magnitude_step(v) for v in soft_values),
+                            differing_soft_bits_behind_an_equalised_outlier=sum(outlier(v) and not sign_flip(v) and not magnitude_step(v) for v in soft_values))
     write_report()
-    # every differing soft bit is either the sign of a component at zero (same magnitude, opposite sign, the symbol's other bit untouched)
-    # or one quantisation step of its symbol's magnitude (both bits of the symbol move by one unit, signs kept)
-    assert all(sign_flip(v) or magnitude_step(v) for v in soft_values), soft_values[:10]
+    # every differing soft bit is either the sign of a component at zero (same magnitude, opposite sign, the symbol's other bit untouched),
+    # or one quantisation step of its symbol's magnitude (both bits of the symbol move by one unit, signs kept), or lies in an allocation
+    # whose extrapolated channel magnitude passes next to zero on some resource element of the bit's symbol (steps_behind_an_extrapolated_estimate)
+    assert all(sign_flip(v) or magnitude_step(v) or outlier(v) for v in soft_values), soft_values[:10]
     assert n_alloc >= 2500
     assert not bad, bad[:10]
     assert n_soft_diff <= 1e-5 * n_soft and len(soft_diff) <= 0.005 * n_alloc, (n_soft_diff, n_soft, soft_diff[:10])
     assert n_ok >= 0.4 * n_alloc
 
 
-def sign_flip(v):  # v = [allocation, position, library, reference, library's other bit of the symbol, reference's]
+def sign_flip(v):  # v = [allocation, position, library, reference, library's other bit of the symbol, reference's, the allocation's weakest estimate]
     return v[2] == -v[3] and v[4] == v[5]
+
+
+def steps_behind_an_extrapolated_estimate(g, u, prbs, s):
+    """The reference's uplink channel estimate is polar and LINEAR in time: magnitude mag_b + n f_mag, n = -3 .. 3 steps from the slot's DMRS
+    symbol, f_mag = (mag_1 - mag_0) / 7 (get_ulsch_ce, liblte_phy.cc:13745-13780).  Over the outer symbols that is an extrapolation, and where
+    one DMRS magnitude is more than 10/3 of the other it passes through zero.  On a resource element next to the crossing the estimate is
+    what two nearly equal numbers leave, w = |mag_b + n f_mag| / mean(mag) << 1: the 1e-7 by which the two front ends' received symbols (and
+    so the magnitudes) differ becomes 1e-7 / w of the estimate, the element's equalised value (:6708-6736) is 1 / w of a normal one, and the
+    transform pre-decoding hands sqrt(M) times its error to EVERY output of that SC-FDMA symbol (:6627-6660; the reference's scaling leaves
+    the outputs M times the constellation, so all but the few that land next to a constellation point sit at the de-mapper's cap and show
+    nothing).  Returns how many quantisation steps 1 / 127 of the de-mapper that is for data symbol s of the allocation,
+    127 sqrt(M) 2e-7 / w^2, from the reference's own received symbols in float64 (contiguous allocations, the same resource blocks in both
+    slots: what draw_ul_groups makes).  Seed 123 of round 5's soak: w = 0.0055 on one element, one unsaturated output in that symbol, three
+    steps between the library and the reference (13 allowed) -- profiles/r05_fuzz_soak/."""
+    import openlte_amd as m
+    M = 12 * len(prbs)
+    sc = 12 * prbs[0] + np.arange(M)
+    z = g["ref_symb"][u].astype(np.float64)
+    d = m.ul_dmrs_pusch(g["ulcfg"], g["cell"], g["sfs"][u], len(prbs)).astype(np.float64)
+    mags = []
+    for b, L in ((0, 3), (1, 10)):
+        t = (z[0, L, sc] + 1j * z[1, L, sc]) * np.conj(d[2 * b] + 1j * d[2 * b + 1])
+        mags.append(np.abs(t))
+    b, sp = s // 6, s % 6
+    n = sp - 3 if sp < 3 else sp - 2
+    w = float(np.abs(mags[b] + n * (mags[1] - mags[0]) / 7).min()) / float(np.mean(mags))
+    return 127 * np.sqrt(M) * 2e-7 / max(w * w, 1e-30)
+
+
+def outlier(v):
+    """a differing soft bit within the steps its symbol's weakest extrapolated estimate accounts for (at least two: below that it is one of
+    the two ordinary kinds or nothing)"""
+    return v[6] >= 2 and abs(v[2] - v[3]) <= 1 + v[6] and abs(v[4] - v[5]) <= 1 + v[6]
 
 
 def magnitude_step(v):

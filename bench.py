@@ -704,12 +704,22 @@ class UplinkWorkload:
         self.d_prach = ctx.to_device(piq[self.pidx].reshape(-1, 2))
         self.d_pstart = ctx.to_device((np.arange(self.n_occ) * piq.shape[1]).astype(np.uint64))
         self.pplan = ctx.prach_plan(self.cfg, self.pc)
-        self.prach_last = None
+        self.prach_last, self.prach_in_flight = None, False
 
     def step(self):
+        """One batch of subframes and its PRACH occasions.  The random-access verdicts come back through mi_lte_prach_detect_launch / _fetch:
+        this step's are fetched (a wait for THAT launch, then a few microseconds of host arithmetic) after the next step's subframes have been
+        handed to the device, as a receiver that keeps its stream busy would; finish() fetches the last ones inside the timed region."""
         self.ctx.ul_frontend_dev(self.cfg, self.d_iq, None, self.d_start, self.n, self.d_sub)
         self.plan.run_dev(self.d_sub, self.d_out, self.d_status)
-        self.prach_last = self.pplan.detect_dev(self.d_prach, None, self.d_pstart, self.n_occ)
+        self.finish()
+        self.pplan.launch_dev(self.d_prach, None, self.d_pstart, self.n_occ)
+        self.prach_in_flight = True
+
+    def finish(self):
+        if self.prach_in_flight:
+            self.prach_last = self.pplan.fetch()
+            self.prach_in_flight = False
 
     def units_per_step(self):
         return self.n
@@ -958,6 +968,9 @@ class MultiStream:
             p.step()
 
     def sync(self):
+        for p in self.parts:  # (results a workload fetches behind its last step: part of the step, inside the timed region)
+            if hasattr(p, "finish"):
+                p.finish()
         for c in self.ctxs:
             c.sync()
 

@@ -356,6 +356,14 @@ uint32_t mi_lte_prach_occasion_samples(const mi_lte_prach_plan *plan);
 int      mi_lte_prach_detect_run(mi_lte_ctx *ctx, mi_lte_prach_plan *plan, const void *d_samples_a, const void *d_samples_b,
                                  const uint64_t *d_occ_start, uint32_t n_occ, uint32_t *h_N_det_pre, uint32_t *h_det_pre,
                                  uint32_t *h_det_ta);
+/* The same detection (liblte_phy_detect_prach, liblte/hdr/liblte_phy.h:727-733, liblte_phy.cc:3293-3480) in two halves for a caller that keeps
+ * the stream busy -- a receiver that hands the device the next subframes while the random-access verdicts of these are on their way:
+ * _launch queues the kernels and the copy of the per-root maxima (pinned memory of the plan's own) and returns at once; _fetch waits for
+ * the stream and forms the verdicts of the launch before it (max_occ = room in the three arrays).  One launch in flight per plan. */
+int      mi_lte_prach_detect_launch(mi_lte_ctx *ctx, mi_lte_prach_plan *plan, const void *d_samples_a, const void *d_samples_b,
+                                    const uint64_t *d_occ_start, uint32_t n_occ);
+int      mi_lte_prach_detect_fetch(mi_lte_ctx *ctx, mi_lte_prach_plan *plan, uint32_t *h_N_det_pre, uint32_t *h_det_pre,
+                                   uint32_t *h_det_ta, uint32_t max_occ);
 
 /* ---------------------------------------------------------------- PUCCH formats 1 / 1a / 1b
  * mi_lte_pucch_decode_run replaces liblte_phy_pucch_format_1_1a_1b_channel_decode() (liblte/hdr/liblte_phy.h:775-782,

@@ -195,6 +195,11 @@ struct mi_lte_prach_plan {
     uint32_t      T_fft = 0, T_cp = 0, start = 0, N_cs = 0, v_max = 0, n_roots = 0, n_zc = 839, phases = 24;
     float2       *d_xu_fft = nullptr;
     float2       *d_chirp = nullptr, *d_bspec = nullptr, *d_tw = nullptr; // Bluestein tables of the 839-point inverse DFT (owned by the context)
+    // mi_lte_prach_detect_launch / _fetch: the per-root maxima of the launch that is in flight, in pinned host memory of the plan's own
+    void      *h_pending = nullptr;
+    size_t     pending_cap = 0;
+    uint32_t   pending_occ = 0;
+    hipEvent_t pending_done = nullptr;
 };
 
 // Bluestein tables of the 839-point inverse DFT, built once per context (they depend on nothing but 839 and 2048):
@@ -339,15 +344,18 @@ void mi_lte_prach_plan_destroy(mi_lte_ctx *ctx, mi_lte_prach_plan *pl)
     if (!pl) return;
     if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
     (void)hipFree(pl->d_xu_fft);
+    if (pl->h_pending) (void)hipHostFree(pl->h_pending);
+    if (pl->pending_done) (void)hipEventDestroy(pl->pending_done);
     delete pl;
 }
 uint32_t mi_lte_prach_plan_n_roots(const mi_lte_prach_plan *pl) { return pl ? pl->n_roots : 0; }
 uint32_t mi_lte_prach_occasion_samples(const mi_lte_prach_plan *pl) { return pl ? pl->T_cp + pl->T_fft : 0; }
 
-int mi_lte_prach_detect_run(mi_lte_ctx *ctx, mi_lte_prach_plan *pl, const void *d_samples_a, const void *d_samples_b,
-                            const uint64_t *d_occ_start, uint32_t n_occ, uint32_t *h_N_det_pre, uint32_t *h_det_pre, uint32_t *h_det_ta)
+// The kernels of one batch of occasions and where their per-root maxima go: *h_co = pinned host memory the kernel wrote itself (a few
+// occasions), or d_co in the context's scratch for the caller to copy
+static int prach_launch(mi_lte_ctx *ctx, mi_lte_prach_plan *pl, const void *d_samples_a, const void *d_samples_b, const uint64_t *d_occ_start, uint32_t n_occ,
+                        bool small_results, CorrOut **h_co_out, CorrOut **d_co_out, size_t *co_bytes_out)
 {
-    if (!ctx || !pl || !d_samples_a || !d_occ_start || n_occ == 0 || !h_N_det_pre || !h_det_pre || !h_det_ta) return MI_LTE_ERR_INVALID_ARG;
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const uint32_t N_ZC = pl->n_zc, P = pl->phases;
     const size_t xh_bytes = sizeof(float2) * (size_t)n_occ * N_ZC, co_bytes = sizeof(CorrOut) * (size_t)n_occ * pl->n_roots;
@@ -357,7 +365,7 @@ int mi_lte_prach_detect_run(mi_lte_ctx *ctx, mi_lte_prach_plan *pl, const void *
     float2  *d_xh = (float2 *)ctx->scratch;
     // the per-root maxima of a few occasions go straight into pinned host memory (no copy command for a per-call caller); a batch's through scratch
     CorrOut *d_co = (CorrOut *)((char *)ctx->scratch + ((xh_bytes + 63) & ~(size_t)63)), *h_co = nullptr;
-    if (mi_ctx_small_results(ctx, co_bytes, (void **)&h_co, (void **)&d_co) != MI_LTE_OK) {
+    if (!small_results || mi_ctx_small_results(ctx, co_bytes, (void **)&h_co, (void **)&d_co) != MI_LTE_OK) {
         h_co = nullptr;
         d_co = (CorrOut *)((char *)ctx->scratch + ((xh_bytes + 63) & ~(size_t)63));
     }
@@ -376,14 +384,16 @@ int mi_lte_prach_detect_run(mi_lte_ctx *ctx, mi_lte_prach_plan *pl, const void *
     MI_LAUNCH(ctx, "k_prach_corr", k_prach_corr, dim3(pl->n_roots, n_occ), dim3(256), sizeof(float2) * (2 * BL + BL / 2), d_xh, pl->d_xu_fft, pl->n_roots, N_ZC,
               (const float2 *)pl->d_chirp, (const float2 *)pl->d_bspec, (const float2 *)pl->d_tw, d_co);
     MI_HIP_CHECK(ctx, hipGetLastError());
-    std::vector<CorrOut> co_copy;
-    if (!h_co) {
-        co_copy.resize((size_t)n_occ * pl->n_roots);
-        MI_D2H(ctx, co_copy.data(), d_co, co_bytes);
-    }
-    MI_HIP_CHECK(ctx, h_co ? mi_stream_wait(ctx, n_occ) : hipStreamSynchronize(ctx->stream)); // (a copy into pageable memory is done when the runtime says so)
-    const CorrOut *co = h_co ? h_co : co_copy.data();
-    for (uint32_t o = 0; o < n_occ; o++) { // the reference's scalar verdict (liblte_phy.cc:3436-3474)
+    ctx->last_kernels = "k_prach_bins:1,k_prach_corr:1";
+    *h_co_out = h_co; *d_co_out = d_co; *co_bytes_out = co_bytes;
+    return MI_LTE_OK;
+}
+
+// the reference's scalar verdict per occasion (liblte_phy.cc:3436-3474) from the per-root maxima
+static void prach_verdicts(const mi_lte_prach_plan *pl, const CorrOut *co, uint32_t n_occ, uint32_t *h_N_det_pre, uint32_t *h_det_pre, uint32_t *h_det_ta)
+{
+    const uint32_t N_ZC = pl->n_zc;
+    for (uint32_t o = 0; o < n_occ; o++) {
         float    ave_val = 0, max_val = 0;
         uint32_t max_root = 0, max_offset = 0;
         for (uint32_t r = 0; r < pl->n_roots; r++) {
@@ -406,7 +416,60 @@ int mi_lte_prach_detect_run(mi_lte_ctx *ctx, mi_lte_prach_plan *pl, const void *
             h_det_pre[o] = h_det_ta[o] = 0;
         }
     }
-    ctx->last_kernels = "k_prach_bins:1,k_prach_corr:1";
+}
+
+int mi_lte_prach_detect_run(mi_lte_ctx *ctx, mi_lte_prach_plan *pl, const void *d_samples_a, const void *d_samples_b,
+                            const uint64_t *d_occ_start, uint32_t n_occ, uint32_t *h_N_det_pre, uint32_t *h_det_pre, uint32_t *h_det_ta)
+{
+    if (!ctx || !pl || !d_samples_a || !d_occ_start || n_occ == 0 || !h_N_det_pre || !h_det_pre || !h_det_ta) return MI_LTE_ERR_INVALID_ARG;
+    CorrOut *h_co = nullptr, *d_co = nullptr;
+    size_t   co_bytes = 0;
+    int rc = prach_launch(ctx, pl, d_samples_a, d_samples_b, d_occ_start, n_occ, true, &h_co, &d_co, &co_bytes);
+    if (rc != MI_LTE_OK) return rc;
+    std::vector<CorrOut> co_copy;
+    if (!h_co) {
+        co_copy.resize((size_t)n_occ * pl->n_roots);
+        MI_D2H(ctx, co_copy.data(), d_co, co_bytes);
+    }
+    MI_HIP_CHECK(ctx, h_co ? mi_stream_wait(ctx, n_occ) : hipStreamSynchronize(ctx->stream)); // (a copy into pageable memory is done when the runtime says so)
+    prach_verdicts(pl, h_co ? h_co : co_copy.data(), n_occ, h_N_det_pre, h_det_pre, h_det_ta);
+    return MI_LTE_OK;
+}
+
+// The same in two halves for a caller that keeps the stream busy: _launch queues the kernels and the copy of the per-root maxima into pinned
+// memory of the plan's own and returns; _fetch waits for THAT copy (an event behind it, not the stream: whatever the caller queued since keeps
+// running) and forms the verdicts.  One launch in flight per plan (a second one before the fetch would overwrite the first's results:
+// MI_LTE_ERR_INVALID_ARG).
+int mi_lte_prach_detect_launch(mi_lte_ctx *ctx, mi_lte_prach_plan *pl, const void *d_samples_a, const void *d_samples_b, const uint64_t *d_occ_start,
+                               uint32_t n_occ)
+{
+    if (!ctx || !pl || !d_samples_a || !d_occ_start || n_occ == 0 || pl->pending_occ) return MI_LTE_ERR_INVALID_ARG;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t need = sizeof(CorrOut) * (size_t)n_occ * pl->n_roots;
+    if (need > pl->pending_cap) {
+        if (pl->h_pending) (void)hipHostFree(pl->h_pending);
+        pl->h_pending = nullptr; pl->pending_cap = 0;
+        MI_HIP_CHECK(ctx, hipHostMalloc(&pl->h_pending, need, hipHostMallocMapped));
+        pl->pending_cap = need;
+    }
+    CorrOut *h_co = nullptr, *d_co = nullptr;
+    size_t   co_bytes = 0;
+    int rc = prach_launch(ctx, pl, d_samples_a, d_samples_b, d_occ_start, n_occ, false, &h_co, &d_co, &co_bytes);
+    if (rc != MI_LTE_OK) return rc;
+    MI_HIP_CHECK(ctx, mi_device_to_pinned(ctx, pl->h_pending, d_co, co_bytes));
+    if (!pl->pending_done) MI_HIP_CHECK(ctx, hipEventCreateWithFlags(&pl->pending_done, hipEventDisableTiming));
+    MI_HIP_CHECK(ctx, hipEventRecord(pl->pending_done, ctx->stream));
+    pl->pending_occ = n_occ;
+    return MI_LTE_OK;
+}
+
+int mi_lte_prach_detect_fetch(mi_lte_ctx *ctx, mi_lte_prach_plan *pl, uint32_t *h_N_det_pre, uint32_t *h_det_pre, uint32_t *h_det_ta, uint32_t max_occ)
+{
+    if (!ctx || !pl || !h_N_det_pre || !h_det_pre || !h_det_ta || pl->pending_occ == 0 || max_occ < pl->pending_occ) return MI_LTE_ERR_INVALID_ARG;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    MI_HIP_CHECK(ctx, hipEventSynchronize(pl->pending_done));
+    prach_verdicts(pl, (const CorrOut *)pl->h_pending, pl->pending_occ, h_N_det_pre, h_det_pre, h_det_ta);
+    pl->pending_occ = 0;
     return MI_LTE_OK;
 }
 

@@ -194,6 +194,8 @@ def load_library():
     L.mi_lte_prach_occasion_samples.argtypes = [vp]
     L.mi_lte_prach_occasion_samples.restype = u32
     L.mi_lte_prach_detect_run.argtypes = [vp, vp, vp, vp, vp, u32, u32p, u32p, u32p]
+    L.mi_lte_prach_detect_launch.argtypes = [vp, vp, vp, vp, vp, u32]
+    L.mi_lte_prach_detect_fetch.argtypes = [vp, vp, u32p, u32p, u32p, u32]
     L.mi_lte_device_copy_rate.argtypes = [vp, C.c_size_t, u32, C.POINTER(C.c_double)]
     L.mi_lte_device_copy_rates.argtypes = [vp, C.POINTER(C.c_double)]
     L.mi_lte_pdcch_plan_create.argtypes = [vp, C.POINTER(DlCfg), C.c_float, u32, u32, u32p, u32, C.POINTER(vp)]
@@ -482,6 +484,19 @@ class PrachPlan:
         out = [np.zeros(n_occ, np.uint32) for _ in range(3)]
         self.ctx._check(self.ctx.L.mi_lte_prach_detect_run(self.ctx.h, self.h, d_a.ptr, d_b.ptr if d_b is not None else None, d_start.ptr,
                                                             n_occ, out[0], out[1], out[2]))
+        return out
+
+    def launch_dev(self, d_a, d_b, d_start, n_occ):
+        """Queue the detection of n_occ occasions and return at once (mi_lte_prach_detect_launch); fetch() has the verdicts."""
+        self.ctx._check(self.ctx.L.mi_lte_prach_detect_launch(self.ctx.h, self.h, d_a.ptr, d_b.ptr if d_b is not None else None, d_start.ptr, n_occ))
+        self._pending = n_occ
+
+    def fetch(self):
+        """(N_det_pre, det_pre, det_ta) of the launch before it (waits for that launch only)."""
+        n = self._pending
+        out = [np.zeros(n, np.uint32) for _ in range(3)]
+        self.ctx._check(self.ctx.L.mi_lte_prach_detect_fetch(self.ctx.h, self.h, out[0], out[1], out[2], n))
+        self._pending = 0
         return out
 
     def detect(self, iq, occ_start):

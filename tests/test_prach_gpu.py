@@ -88,3 +88,36 @@ def test_prach_root_set_that_wraps_past_the_table_is_self_consistent(ctx):
     n2, p2, ta2 = plan.detect(iq_f.reshape(-1, 2), np.arange(len(pre_f)) * iq_f.shape[1])
     plan.close()
     assert (n2 == 1).all() and (p2 == np.array(pre_f)).all() and (ta2 == ta[2:]).all(), (ta.tolist(), ta2.tolist())
+
+
+def test_prach_launch_and_fetch_equal_the_one_call_form(ctx):
+    """mi_lte_prach_detect_launch / _fetch (the detection in two halves, for a caller that keeps the stream busy): the verdicts of a batch of
+    2 000 occasions (past the few-occasions route that writes results straight into pinned memory) and of 3 occasions equal
+    mi_lte_prach_detect_run's, with other work queued on the stream between the launch and the fetch; one launch in flight per plan."""
+    import openlte_amd as m
+    from openlte_amd import synth
+    cfg, pc = m.DlCfg(2048, 100, 1, 0), m.PrachCfg(22, 0, 11, 0, 4)
+    pre = [(7 * k + 3) % 64 for k in range(8)]
+    iq = synth.prach_occasions(cfg, pc, pre, [16 * (k + 1) for k in range(8)], snr_db=5.0, seed=9)
+    plan = ctx.prach_plan(cfg, pc)
+    try:
+        for n_occ in (2000, 3):
+            idx = np.arange(n_occ) % 8
+            d_a = ctx.to_device(iq[idx].reshape(-1, 2))
+            d_s = ctx.to_device((np.arange(n_occ) * iq.shape[1]).astype(np.uint64))
+            want = plan.detect_dev(d_a, None, d_s, n_occ)
+            plan.launch_dev(d_a, None, d_s, n_occ)
+            with pytest.raises(m.MiLteError):
+                plan.launch_dev(d_a, None, d_s, n_occ)  # one in flight
+            junk = ctx.to_device(np.zeros(1 << 20, np.uint8))  # something else on the stream meanwhile
+            got = plan.fetch()
+            junk.free()
+            for w, g in zip(want, got):
+                assert (w == g).all()
+            assert (got[0] == 1).all() and (got[1] == np.array(pre)[idx]).all()
+            with pytest.raises(m.MiLteError):
+                ctx._check(ctx.L.mi_lte_prach_detect_fetch(ctx.h, plan.h, got[0], got[1], got[2], n_occ))  # nothing in flight
+            d_a.free()
+            d_s.free()
+    finally:
+        plan.close()

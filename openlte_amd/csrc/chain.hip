@@ -602,9 +602,19 @@ int mi_pdsch_plan_assign_slice(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, uint32_t 
     if (pl->e_bytes > pl->cap_e_bytes) { pl->n_alloc = 0; ctx->err = "more soft bits than the dynamic plan was created for"; return MI_LTE_ERR_INVALID_ARG; }
     memcpy(so, pl->h_e_off.data(), sizeof(uint32_t) * n_alloc);
     memcpy(sc, cb_alloc.data(), sizeof(uint32_t) * n_alloc);
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_allocs, sa, sizeof(mi_lte_pdsch_alloc) * n_alloc, hipMemcpyHostToDevice, cs));
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_e_off, so, sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, cs));
-    MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_cb_alloc, sc, sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, cs));
+    // The three arrays leave the (pinned) staging block with a copy KERNEL on the same stream, not with copy commands: the runtime rotates its
+    // copy engines from command to command, and three small commands per chunk between the sample copies put every third chunk's samples on
+    // the engine the result copy of the chunk before was using -- a 3.1 ms + 1.0 ms pair where 2.4 + 0.3 is the rule
+    // (profiles/r05_host_pipeline_profile.txt section 6, and section 7 for this)
+    static const bool slice_by_engine = getenv("MI_LTE_SLICE_COPY_COMMANDS") != nullptr; // (A/B switch)
+    if (slice_by_engine) {
+        MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_allocs, sa, sizeof(mi_lte_pdsch_alloc) * n_alloc, hipMemcpyHostToDevice, cs));
+        MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_e_off, so, sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, cs));
+        MI_HIP_CHECK(ctx, hipMemcpyAsync(pl->d_cb_alloc, sc, sizeof(uint32_t) * n_alloc, hipMemcpyHostToDevice, cs));
+    } else {
+        const MiCopySeg segs[3] = {{pl->d_allocs, sa, sizeof(mi_lte_pdsch_alloc) * n_alloc}, {pl->d_e_off, so, sizeof(uint32_t) * n_alloc}, {pl->d_cb_alloc, sc, sizeof(uint32_t) * n_alloc}};
+        MI_HIP_CHECK(ctx, mi_pinned_segments_to_device(ctx, segs, 3, cs));
+    }
     MI_HIP_CHECK(ctx, hipEventRecord(pl->staged, cs));
     return MI_LTE_OK;
 }

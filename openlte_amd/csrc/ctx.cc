@@ -197,24 +197,24 @@ static bool bounce_ready(mi_lte_ctx *ctx, const void *d_ptr, size_t bytes)
     }
     return ctx->h_bounce != nullptr;
 }
-static void launch_copy(mi_lte_ctx *ctx, void *dst, const void *src, size_t n)
+static void launch_copy(mi_lte_ctx *ctx, void *dst, const void *src, size_t n, hipStream_t stream = nullptr)
 {
     const size_t n16 = n / 16;
     const unsigned grid = (unsigned)std::min<size_t>((n16 + 255) / 256 + 1, 2048);
-    k_copy_words<<<grid, 256, 0, ctx->stream>>>((uint4 *)dst, (const uint4 *)src, n16, (uint8_t *)dst + 16 * n16, (const uint8_t *)src + 16 * n16, (uint32_t)(n - 16 * n16));
+    k_copy_words<<<grid, 256, 0, stream ? stream : ctx->stream>>>((uint4 *)dst, (const uint4 *)src, n16, (uint8_t *)dst + 16 * n16, (const uint8_t *)src + 16 * n16, (uint32_t)(n - 16 * n16));
 }
 } // extern "C"
 // The asynchronous pair for the library's own MAPPED pinned blocks (hostapi.cc's staging buffer): the same kernel on the block's device
 // alias, no wait; small copies and anything unaligned go to the runtime.  The caller waits for the stream before it touches the block.
-hipError_t mi_pinned_to_device(mi_lte_ctx *ctx, void *d_dst, const void *h_pinned, size_t bytes)
+hipError_t mi_pinned_to_device(mi_lte_ctx *ctx, void *d_dst, const void *h_pinned, size_t bytes, hipStream_t stream)
 {
     void *alias = nullptr;
     if (!runtime_copies && bytes > BOUNCE_LO && !(((uintptr_t)d_dst | (uintptr_t)h_pinned) & 15u) && hipHostGetDevicePointer(&alias, const_cast<void *>(h_pinned), 0) == hipSuccess) {
-        launch_copy(ctx, d_dst, alias, bytes);
+        launch_copy(ctx, d_dst, alias, bytes, stream);
         return hipGetLastError();
     }
     (void)hipGetLastError();
-    return hipMemcpyAsync(d_dst, h_pinned, bytes, hipMemcpyHostToDevice, ctx->stream);
+    return hipMemcpyAsync(d_dst, h_pinned, bytes, hipMemcpyHostToDevice, stream ? stream : ctx->stream);
 }
 hipError_t mi_device_to_pinned(mi_lte_ctx *ctx, void *h_pinned, const void *d_src, size_t bytes)
 {
@@ -225,6 +225,44 @@ hipError_t mi_device_to_pinned(mi_lte_ctx *ctx, void *h_pinned, const void *d_sr
     }
     (void)hipGetLastError();
     return hipMemcpyAsync(h_pinned, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+}
+// Up to three blocks of pinned host memory to the device in ONE launch on the given stream (the host pipeline's per-chunk arrays: subframe numbers
+// and cells; a slice's descriptors, offsets and code-block map).  A copy COMMAND per array costs a copy engine's start-up each and makes the
+// runtime rotate engines between the sample copies; a kernel per array costs a dispatch each.  64 workgroups: the arrays are a few MB at most,
+// and a wide grid next to the lanes' kernels waits for wave slots it does not need.  Sizes are multiples of 4 bytes; blocks that are not
+// 16-byte aligned, or memory the device cannot see, go to the runtime instead.
+__global__ __launch_bounds__(256) void k_copy_segments(MiCopySeg a, MiCopySeg b, MiCopySeg c)
+{
+    const MiCopySeg s = blockIdx.y == 0 ? a : blockIdx.y == 1 ? b : c;
+    const size_t    n16 = s.bytes / 16;
+    uint4          *d = (uint4 *)s.dst;
+    const uint4    *h = (const uint4 *)s.src;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) d[i] = h[i];
+    const uint32_t n4 = (uint32_t)(s.bytes - 16 * n16) / 4;
+    if (blockIdx.x == 0 && threadIdx.x < n4) ((uint32_t *)(d + n16))[threadIdx.x] = ((const uint32_t *)(h + n16))[threadIdx.x];
+}
+hipError_t mi_pinned_segments_to_device(mi_lte_ctx *ctx, const MiCopySeg *segs, uint32_t n_seg, hipStream_t stream)
+{
+    MiCopySeg k[3] = {{nullptr, nullptr, 0}, {nullptr, nullptr, 0}, {nullptr, nullptr, 0}};
+    bool      by_kernel = !runtime_copies && n_seg >= 1 && n_seg <= 3;
+    for (uint32_t i = 0; by_kernel && i < n_seg; i++) {
+        void *alias = nullptr;
+        if ((((uintptr_t)segs[i].dst | (uintptr_t)segs[i].src) & 15u) || (segs[i].bytes & 3u) || hipHostGetDevicePointer(&alias, const_cast<void *>(segs[i].src), 0) != hipSuccess) by_kernel = false;
+        k[i] = {segs[i].dst, alias, segs[i].bytes};
+    }
+    (void)hipGetLastError();
+    if (!by_kernel) {
+        static bool said = false;
+        if (!said && getenv("MI_LTE_PIPELINE_TRACE")) { said = true; fprintf(stderr, "mi_lte: pinned segments copied by the runtime (unaligned or not mapped)\n"); }
+        for (uint32_t i = 0; i < n_seg; i++) {
+            const hipError_t e = hipMemcpyAsync(segs[i].dst, segs[i].src, segs[i].bytes, hipMemcpyHostToDevice, stream ? stream : ctx->stream);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    static const unsigned seg_grid = getenv("MI_LTE_SIDE_COPY_BLOCKS") ? (unsigned)std::max(1, atoi(getenv("MI_LTE_SIDE_COPY_BLOCKS"))) : 64u; // (tuning aid)
+    k_copy_segments<<<dim3(seg_grid, n_seg), 256, 0, stream ? stream : ctx->stream>>>(k[0], k[1], k[2]);
+    return hipGetLastError();
 }
 extern "C" {
 int mi_lte_memcpy_h2d(mi_lte_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)

@@ -119,8 +119,10 @@ template <typename F> struct OnFail {
 template <typename F> OnFail<F> on_fail(F f) { return OnFail<F>{f}; }
 
 int   mi_ctx_reserve_scratch(mi_lte_ctx *ctx, size_t bytes);
-hipError_t mi_pinned_to_device(mi_lte_ctx *ctx, void *d_dst, const void *h_pinned, size_t bytes); // asynchronous, from / to a MAPPED pinned block (ctx.cc)
+hipError_t mi_pinned_to_device(mi_lte_ctx *ctx, void *d_dst, const void *h_pinned, size_t bytes, hipStream_t stream = nullptr); // asynchronous, from / to a MAPPED pinned block (ctx.cc); stream: the context's unless given
 hipError_t mi_device_to_pinned(mi_lte_ctx *ctx, void *h_pinned, const void *d_src, size_t bytes);
+struct MiCopySeg { void *dst; const void *src; size_t bytes; };
+hipError_t mi_pinned_segments_to_device(mi_lte_ctx *ctx, const MiCopySeg *segs, uint32_t n_seg, hipStream_t stream); // 1..3 pinned blocks, one launch (ctx.cc)
 // Where a kernel puts a few KB of results that the host reads right after the wait: pinned host memory mapped into the device (no copy
 // command, which costs more API time than a small call's kernel runs for).  *h and *d are the host's and the device's pointer to the same
 // bytes; MI_LTE_ERR_INVALID_ARG when bytes > MI_SMALL_BYTES (the caller then takes its scratch + copy route).

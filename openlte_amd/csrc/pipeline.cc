@@ -39,11 +39,13 @@ struct Lane {
     mi_lte_pdsch_plan *dyn  = nullptr; // re-assigned per chunk (per-unit lists, and the ragged last chunk of template mode)
     int8_t   *d_iq = nullptr;
     uint64_t *d_start_units = nullptr, *d_start_capture = nullptr;
-    uint32_t *d_sf = nullptr, *d_cell = nullptr;
+    uint32_t *d_sf = nullptr, *d_cell = nullptr; // two halves of one block (d_sf owns it)
+    uint32_t *h_meta = nullptr;                  // pinned staging of a chunk's subframe numbers and cells, laid out like that block
     float    *d_sub = nullptr;
     uint8_t  *d_out = nullptr;
     int32_t  *d_st = nullptr;
     hipEvent_t in_free = nullptr, out_free = nullptr; // the front end has read d_iq / the results have left d_out (copy-stream mode)
+    hipEvent_t meta_out = nullptr;                    // h_meta has been copied
     bool       used = false;
 };
 struct Dev {
@@ -142,10 +144,11 @@ static void free_lane(Lane &l)
     if (l.ctx) (void)mi_lte_sync(l.ctx);
     if (l.plan) mi_lte_pdsch_plan_destroy(l.ctx, l.plan);
     if (l.dyn) mi_lte_pdsch_plan_destroy(l.ctx, l.dyn);
-    (void)hipFree(l.d_iq); (void)hipFree(l.d_start_units); (void)hipFree(l.d_start_capture); (void)hipFree(l.d_sf); (void)hipFree(l.d_cell);
+    (void)hipFree(l.d_iq); (void)hipFree(l.d_start_units); (void)hipFree(l.d_start_capture); (void)hipFree(l.d_sf); if (l.h_meta) (void)hipHostFree(l.h_meta);
     (void)hipFree(l.d_sub); (void)hipFree(l.d_out); (void)hipFree(l.d_st);
     if (l.in_free) (void)hipEventDestroy(l.in_free);
     if (l.out_free) (void)hipEventDestroy(l.out_free);
+    if (l.meta_out) (void)hipEventDestroy(l.meta_out);
     if (l.ctx) mi_lte_ctx_destroy(l.ctx);
     l = Lane();
 }
@@ -185,19 +188,21 @@ static int make_lane(mi_lte_dl_pipeline *p, Dev &d, Lane &l)
     MI_HIP_CHECK(l.ctx, hipMalloc((void **)&l.d_iq, iq_bytes));
     MI_HIP_CHECK(l.ctx, hipMalloc((void **)&l.d_start_units, sizeof(uint64_t) * chunk));
     MI_HIP_CHECK(l.ctx, hipMalloc((void **)&l.d_start_capture, sizeof(uint64_t) * chunk));
-    MI_HIP_CHECK(l.ctx, hipMalloc((void **)&l.d_sf, sizeof(uint32_t) * chunk));
-    MI_HIP_CHECK(l.ctx, hipMalloc((void **)&l.d_cell, sizeof(uint32_t) * chunk));
+    const uint32_t chunk_al = (chunk + 3) & ~3u; // (16-byte aligned halves)
+    MI_HIP_CHECK(l.ctx, hipMalloc((void **)&l.d_sf, sizeof(uint32_t) * 2 * chunk_al));
+    l.d_cell = l.d_sf + chunk_al;
+    MI_HIP_CHECK(l.ctx, hipHostMalloc((void **)&l.h_meta, sizeof(uint32_t) * 2 * chunk_al, hipHostMallocMapped));
     MI_HIP_CHECK(l.ctx, hipMalloc((void **)&l.d_sub, sizeof(float) * mi_lte_subframe_floats(p->cfg.N_ant) * chunk));
     MI_HIP_CHECK(l.ctx, hipMalloc((void **)&l.d_out, cap_alloc * p->out_stride));
     MI_HIP_CHECK(l.ctx, hipMalloc((void **)&l.d_st, cap_alloc * sizeof(int32_t)));
     MI_HIP_CHECK(l.ctx, hipMemcpy(l.d_start_units, su.data(), sizeof(uint64_t) * chunk, hipMemcpyHostToDevice));
     MI_HIP_CHECK(l.ctx, hipMemcpy(l.d_start_capture, sc.data(), sizeof(uint64_t) * chunk, hipMemcpyHostToDevice));
-    MI_HIP_CHECK(l.ctx, hipMemset(l.d_sf, 0, sizeof(uint32_t) * chunk));
-    MI_HIP_CHECK(l.ctx, hipMemset(l.d_cell, 0, sizeof(uint32_t) * chunk));
+    MI_HIP_CHECK(l.ctx, hipMemset(l.d_sf, 0, sizeof(uint32_t) * 2 * chunk_al));
     MI_HIP_CHECK(l.ctx, hipMemset(l.d_sub, 0, sizeof(float) * mi_lte_subframe_floats(p->cfg.N_ant) * chunk));
     MI_HIP_CHECK(l.ctx, hipMemset(l.d_iq, 0, iq_bytes));
     MI_HIP_CHECK(l.ctx, hipEventCreateWithFlags(&l.in_free, hipEventDisableTiming));
     MI_HIP_CHECK(l.ctx, hipEventCreateWithFlags(&l.out_free, hipEventDisableTiming));
+    MI_HIP_CHECK(l.ctx, hipEventCreateWithFlags(&l.meta_out, hipEventDisableTiming));
     return MI_LTE_OK;
 }
 
@@ -247,8 +252,22 @@ static void device_worker(mi_lte_dl_pipeline *p, uint32_t di, const Job *job)
             e = hipMemcpyAsync(l.d_iq, job->h_iq + (size_t)u0 * p->sf_samples * 2, ((size_t)n * p->sf_samples + p->look_samples) * 2, hipMemcpyHostToDevice, s_in);
         else
             e = hipMemcpyAsync(l.d_iq, job->h_iq + (size_t)u0 * unit_bytes, (size_t)n * unit_bytes, hipMemcpyHostToDevice, s_in);
-        if (e == hipSuccess) e = hipMemcpyAsync(l.d_sf, job->h_sf + u0, sizeof(uint32_t) * n, hipMemcpyHostToDevice, s_in);
-        if (e == hipSuccess) e = hipMemcpyAsync(l.d_cell, job->h_cell + u0, sizeof(uint32_t) * n, hipMemcpyHostToDevice, s_in);
+        // subframe numbers and cells: through the lane's pinned block and ONE copy kernel (two more copy commands per chunk made the runtime
+        // rotate its engines between the sample copies, and each costs an engine's start-up on the input stream)
+        static const char *meta_env = getenv("MI_LTE_PIPELINE_META_KERNEL"); // (A/B switch: "0" / "1")
+        const bool meta_by_kernel = !lane_copies && (meta_env ? meta_env[0] == '1' : job->h_allocs != nullptr);
+        if (e == hipSuccess && !meta_by_kernel) {
+            e = hipMemcpyAsync(l.d_sf, job->h_sf + u0, sizeof(uint32_t) * n, hipMemcpyHostToDevice, s_in);
+            if (e == hipSuccess) e = hipMemcpyAsync(l.d_cell, job->h_cell + u0, sizeof(uint32_t) * n, hipMemcpyHostToDevice, s_in);
+        } else if (e == hipSuccess) {
+            if (l.used) (void)hipEventSynchronize(l.meta_out); // the lane's previous chunk has left the staging block (long ago)
+            const uint32_t half = (uint32_t)(l.d_cell - l.d_sf);
+            memcpy(l.h_meta, job->h_sf + u0, sizeof(uint32_t) * n);
+            memcpy(l.h_meta + half, job->h_cell + u0, sizeof(uint32_t) * n);
+            const MiCopySeg seg = {l.d_sf, l.h_meta, sizeof(uint32_t) * 2 * half};
+            e = mi_pinned_segments_to_device(l.ctx, &seg, 1, s_in);
+            if (e == hipSuccess) e = hipEventRecord(l.meta_out, s_in);
+        }
         if (e != hipSuccess) { d.rc = MI_LTE_ERR_HIP; d.err = hipGetErrorString(e); break; }
         // per-unit lists: the chunk's slice of the caller's list goes into the lane's dynamic plan now, its descriptor copies behind the samples
         // on the input stream (the host's part of it, ~1 ms, runs while the samples are in flight)
@@ -257,7 +276,8 @@ static void device_worker(mi_lte_dl_pipeline *p, uint32_t di, const Job *job)
         if (job->h_allocs && !lane_copies && job->h_first[u0 + n] > job->h_first[u0]) {
             std::vector<uint32_t> bad;
             const size_t a0s = job->h_first[u0];
-            rc_assign = mi_pdsch_plan_assign_slice(l.ctx, l.dyn, job->cfi, job->h_allocs + a0s, (uint32_t)(job->h_first[u0 + n] - a0s), u0, &bad, s_in);
+            static const bool slice_on_input = getenv("MI_LTE_SLICE_ON_LANE_STREAM") == nullptr; // (A/B switch)
+            rc_assign = mi_pdsch_plan_assign_slice(l.ctx, l.dyn, job->cfi, job->h_allocs + a0s, (uint32_t)(job->h_first[u0 + n] - a0s), u0, &bad, slice_on_input ? s_in : nullptr);
             for (uint32_t i : bad) refused.push_back(a0s + i);
             assigned = true;
         }
@@ -467,6 +487,7 @@ int mi_lte_dl_pipeline_create_multi(const int *devices, uint32_t n_devices, cons
         if (hipSetDevice(d.device) != hipSuccess) return MI_LTE_ERR_NO_DEVICE;
         d.node      = device_numa_node(d.device);
         d.node_cpus = node_cpus_allowed(d.node);
+        // (a high-priority input stream was tried for the sake of its copy kernels: 0.75 -> 0.65 M subframes/s, profiles/r05_host_pipeline_profile.txt section 7)
         if (hipStreamCreateWithFlags(&d.h2d, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&d.d2h, hipStreamNonBlocking) != hipSuccess) return MI_LTE_ERR_HIP;
         for (Lane &l : d.lanes) {
             const int rc = make_lane(p, d, l);

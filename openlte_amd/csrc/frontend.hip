@@ -29,7 +29,21 @@ struct DlGeom {
     uint32_t sf_stride; // floats per device subframe
     uint32_t ul;        // 1: uplink SC-FDMA demodulation (samples_to_symbols_ul, liblte_phy.cc:8654-8692)
     uint32_t ce_compact; // 1: the estimator stops after the frequency direction and writes magnitude / phase rows (MI_LTE_CE_COMPACT)
+    float    r_n_pil, r_nq; // the floats next above 1 / (2 N_rb_dl) and 1 / (3 N_rb_dl): k_dl_ce's row / column splits (quot_f below)
 };
+
+// floor(n / d) for n < 2^20 as the truncated float product n * r, r = the float next above or equal to 1 / d: n r >= n / d, so a multiple of d
+// never lands below its quotient, and the excess (n / d) 2^-22 stays under the 1 / d that separates n / d from the next integer.  Three
+// full-rate instructions; the compiler's own sequence for a division by a run-time value is ~25 with quarter-rate multiplies in it.
+__device__ __forceinline__ uint32_t quot_f(uint32_t n, float r) { return (uint32_t)((float)n * r); }
+static float recip_up(uint32_t d)
+{
+    const double rd = 1.0 / (double)d;
+    float        r  = (float)rd;
+    if ((double)r < rd) r = nextafterf(r, 2.0f);
+    return r;
+}
+__device__ __forceinline__ uint32_t mod6_lt12(uint32_t x) { return x >= 6 ? x - 6 : x; } // x % 6 for x < 12
 
 // The FFT has no bit-exact reference (FFTW's operation order is unspecified; parity is to tolerance), so its
 // complex multiplies may use fused multiply-adds; the rest of the library is built with -ffp-contract=off.
@@ -460,9 +474,10 @@ __global__ __launch_bounds__(256) void k_dl_ce(const uint32_t *__restrict__ subf
 
     // CRS bits (generate_crs, liblte_phy.cc:8300-8333; slots per :5960-5967)
     if (threadIdx.x < n_i * 14) {
-        const uint32_t i = i_lo + threadIdx.x / 14, w = threadIdx.x % 14;
-        const uint32_t ns = (sf * 2 + sym_of(i) / 7) % 20, l = sym_of(i) % 7;
-        const uint32_t c_init = 1024 * (7 * (ns + 1) + l + 1) * (2 * cell + 1) + 2 * cell + 1;
+        const uint32_t ri = __umul24(threadIdx.x, 4682u) >> 16, i = i_lo + ri, w = threadIdx.x - 14 * ri; // / 14 and % 14 for < 5461
+        const uint32_t sy = sym_of(i), slot = sy >= 14 ? 2u : sy >= 7 ? 1u : 0u, l = sy - 7 * slot; // (sy <= 15)
+        const uint32_t ns2 = (sf * 2) % 20 + slot, ns = ns2 >= 20 ? ns2 - 20 : ns2;                   // (sf is uniform: its part is scalar arithmetic)
+        const uint32_t c_init = (__umul24(7 * (ns + 1) + l + 1, 2 * cell + 1) << 10) + 2 * cell + 1;
         crs_bits[i - i_lo][w] = gold_word(gt, c_init, w);
     }
     __syncthreads();
@@ -470,14 +485,14 @@ __global__ __launch_bounds__(256) void k_dl_ce(const uint32_t *__restrict__ subf
     // least-squares estimate at every pilot (liblte_phy.cc:6023-6030)
     const float r2 = (float)(1.0 / sqrt(2.0));
     for (uint32_t t = threadIdx.x; t < n_i * n_pil; t += blockDim.x) {
-        const uint32_t ri = t / n_pil, i = i_lo + ri, j = t % n_pil;
-        const uint32_t k = 6 * j + (voff_of(i) + v_shift) % 6, mp = j + 110 - g.N_rb_dl;
+        const uint32_t ri = quot_f(t, g.r_n_pil), i = i_lo + ri, j = t - __umul24(ri, n_pil);
+        const uint32_t k = 6 * j + mod6_lt12(voff_of(i) + v_shift), mp = j + 110 - g.N_rb_dl;
         const uint32_t b0 = (crs_bits[ri][(2 * mp) >> 5] >> ((2 * mp) & 31)) & 1u, b1 = (crs_bits[ri][(2 * mp + 1) >> 5] >> ((2 * mp + 1) & 31)) & 1u;
         const float rs_re = r2 * (1 - 2 * (float)b0), rs_im = r2 * (1 - 2 * (float)b1);
-        const float s_re = sym_re[sym_of(i) * N_SC_MAX + k], s_im = sym_im[sym_of(i) * N_SC_MAX + k];
+        const float s_re = sym_re[__umul24(sym_of(i), (uint32_t)N_SC_MAX) + k], s_im = sym_im[__umul24(sym_of(i), (uint32_t)N_SC_MAX) + k];
         const float t_re = s_re * rs_re + s_im * rs_im, t_im = s_im * rs_re - s_re * rs_im;
-        mag[ri * N_sc + k] = sqrtf(t_re * t_re + t_im * t_im);
-        ang[ri * N_sc + k] = atan2f(t_im, t_re);
+        mag[__umul24(ri, N_sc) + k] = sqrtf(t_re * t_re + t_im * t_im);
+        ang[__umul24(ri, N_sc) + k] = atan2f(t_im, t_re);
     }
     __syncthreads();
     // unwrap along frequency (liblte_phy.cc:6033-6035): u_0 = r_0, u_j = wrap_phase(r_j, u_{j-1}).  The chain is
@@ -490,14 +505,15 @@ __global__ __launch_bounds__(256) void k_dl_ce(const uint32_t *__restrict__ subf
         const uint32_t wave = threadIdx.x >> 6, ln = threadIdx.x & 63, n_wave = blockDim.x >> 6;
         const uint32_t C = (n_pil + 63) / 64; // pilots per lane (<= 4 for 100 RB)
         for (uint32_t i = i_lo + wave; i < i_hi; i += n_wave) {
-            const uint32_t off = (voff_of(i) + v_shift) % 6;
-            float *a = ang + (i - i_lo) * N_sc + off;
+            const uint32_t off = mod6_lt12(voff_of(i) + v_shift);
+            float *a = ang + __umul24(i - i_lo, N_sc) + off;
             float  r[4], uu[4];
             int    c[4], run = 0;
-            float  rprev = (ln > 0 && (ln * C - 1) < n_pil) ? a[6 * (ln * C - 1)] : 0.0f;
+            const uint32_t j0 = __umul24(ln, C); // the lane's first pilot
+            float  rprev = (ln > 0 && (j0 - 1) < n_pil) ? a[6 * (j0 - 1)] : 0.0f;
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) {
-                const uint32_t j = ln * C + k;
+                const uint32_t j = j0 + k;
                 r[k] = (k < C && j < n_pil) ? a[6 * j] : 0.0f;
                 int d = 0;
                 if (k < C && j < n_pil && j > 0) {
@@ -529,7 +545,7 @@ __global__ __launch_bounds__(256) void k_dl_ce(const uint32_t *__restrict__ subf
             bool  bad = false;
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) {
-                const uint32_t j = ln * C + k;
+                const uint32_t j = j0 + k;
                 if (k < C && j < n_pil) {
                     if (j > 0) bad |= (__float_as_uint(wrap_phase(r[k], uprev)) != __float_as_uint(uu[k]));
                     uprev = uu[k];
@@ -546,7 +562,7 @@ __global__ __launch_bounds__(256) void k_dl_ce(const uint32_t *__restrict__ subf
             } else {
 #pragma unroll
                 for (uint32_t k = 0; k < 4; k++) {
-                    const uint32_t j = ln * C + k;
+                    const uint32_t j = j0 + k;
                     if (k < C && j < n_pil) a[6 * j] = uu[k];
                 }
             }
@@ -556,10 +572,10 @@ __global__ __launch_bounds__(256) void k_dl_ce(const uint32_t *__restrict__ subf
     // frequency interpolation between pilots, edges continue the first / last slope
     // (liblte_phy.cc:6037-6063; repeated subtraction kept to reproduce the rounding)
     for (uint32_t t = threadIdx.x; t < n_i * n_pil; t += blockDim.x) {
-        const uint32_t ri = t / n_pil, i = i_lo + ri, j = t % n_pil;
+        const uint32_t ri = quot_f(t, g.r_n_pil), i = i_lo + ri, j = t - __umul24(ri, n_pil);
         if (j == 0) continue;
-        const uint32_t off = (voff_of(i) + v_shift) % 6, k = 6 * j + off;
-        float *m = mag + ri * N_sc, *a = ang + ri * N_sc;
+        const uint32_t off = mod6_lt12(voff_of(i) + v_shift), k = 6 * j + off;
+        float *m = mag + __umul24(ri, N_sc), *a = ang + __umul24(ri, N_sc);
         const float fm = (m[k] - m[k - 6]) / 6, fa = (a[k] - a[k - 6]) / 6;
         float cm = m[k], ca = a[k];
         for (uint32_t z = 1; z < 6; z++) { cm -= fm; ca -= fa; m[k - z] = cm; a[k - z] = ca; }
@@ -580,9 +596,9 @@ __global__ __launch_bounds__(256) void k_dl_ce(const uint32_t *__restrict__ subf
         // real-part plane hold mag, the same rows of its imaginary-part plane hold ang
         const uint32_t nq = N_sc >> 2; // N_sc is a multiple of 12
         for (uint32_t t = threadIdx.x; t < n_i * nq; t += blockDim.x) {
-            const uint32_t ri = t / nq, i = i_lo + ri, c = t - ri * nq;
-            reinterpret_cast<float4 *>(ce_re + i * N_SC_MAX)[c] = reinterpret_cast<const float4 *>(mag + ri * N_sc)[c];
-            reinterpret_cast<float4 *>(ce_im + i * N_SC_MAX)[c] = reinterpret_cast<const float4 *>(ang + ri * N_sc)[c];
+            const uint32_t ri = quot_f(t, g.r_nq), i = i_lo + ri, c = t - __umul24(ri, nq);
+            reinterpret_cast<float4 *>(ce_re + __umul24(i, (uint32_t)N_SC_MAX))[c] = reinterpret_cast<const float4 *>(mag + __umul24(ri, N_sc))[c];
+            reinterpret_cast<float4 *>(ce_im + __umul24(i, (uint32_t)N_SC_MAX))[c] = reinterpret_cast<const float4 *>(ang + __umul24(ri, N_sc))[c];
         }
         return;
     }
@@ -632,6 +648,8 @@ int make_geom(const mi_lte_dl_cfg *cfg, DlGeom *g)
     g->sf_stride = (uint32_t)mi_lte_subframe_floats(cfg->N_ant);
     g->ul = 0;
     g->ce_compact = 0;
+    g->r_n_pil = recip_up(2 * cfg->N_rb_dl);
+    g->r_nq    = recip_up(3 * cfg->N_rb_dl);
     return MI_LTE_OK;
 }
 

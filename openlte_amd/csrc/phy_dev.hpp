@@ -21,7 +21,7 @@ __device__ __forceinline__ uint32_t gold_word(const GoldTables &gt, uint32_t c_i
         for (int k = 0; k < 8; k++) {
             const bool     on = m != 0;
             const uint32_t b  = on ? (uint32_t)__builtin_ctz(m) : 0u;
-            t[k] = gt.x2b[b * gt.words + w]; // unconditional (row 0 when the bits are used up): no branch between the loads
+            t[k] = gt.x2b[__umul24(b, gt.words) + w]; // unconditional (row 0 when the bits are used up): no branch between the loads; b < 31, words < 2^13
             t[k] = on ? t[k] : 0u;
             m &= m - 1; // 0 stays 0
         }

@@ -89,10 +89,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
     const uint32_t c_init = ((al.rnti << 14) | (0u << 13) | (sf << 9) | cell) & 0x7FFFFFFFu; // 31 bits: the Gold basis has 31 rows
     if (threadIdx.x < 64) {
         const uint32_t ln = threadIdx.x, per = (n_pairs + 63) / 64, q0 = ln * per, q1 = min(q0 + per, n_pairs);
-        const uint32_t magic = 0xFFFFFFFFu / N_prb + 1u; // q / N_prb = mulhi(q, magic), exact for q < 2^32 / N_prb^2; a single PRB wraps it to 0 = "no division"
+        // q / N_prb as a truncated float product (q < 1540): the hardware reciprocal is within 1 ulp of 1 / N_prb, three ulp on top make it an
+        // upper bound, and the excess -- under 5 * 2^-23 of q / N_prb -- stays far below the 1 / N_prb that separates a quotient from the next
+        // integer.  The exact magic number (0xFFFFFFFF / N_prb + 1) was a 32-bit division of a workgroup-uniform value on the vector unit.
+        const float r_prb = __builtin_amdgcn_rcpf((float)N_prb) * (1.0f + 0x1.8p-22f);
         uint32_t local = 0;
         for (uint32_t q = q0; q < q1; q++) {
-            const uint32_t L = magic ? __umulhi(q, magic) : q, prb = al.prb[L / 7][q - L * N_prb];
+            const uint32_t L = (uint32_t)((float)q * r_prb), prb = al.prb[L >= 7 ? 1 : 0][q - __umul24(L, N_prb)];
             const uint32_t m = L < cfi ? 0u : pdsch_mask(N_ant, cell, sf, L, prb, first_sc, last_sc);
             tab[q].y = m | ((L * N_SC_MAX + prb * 12) << 12); // low 12 bits: RE mask, high 20 bits: L*1200 + first sub-carrier
             local += __popc(m);
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
     // odd bandwidths -- 6 + 6, 4 + 4 + 6 + 6 resource elements (enumerated over every bandwidth, cell, subframe and control-region size
     // in tests/test_fuzz_cpu.py), so the reference's `M_ap_symb % 4 != 0` branch (:7766-7795, with the mis-strided layer de-mapper
     // it would feed, :7473-7514) is dead code on this path and the division is exact.
-    const uint32_t n_grp = M_ap / N_ant, M_symb = n_grp * N_ant, N_bits = M_symb * Qm;
+    const uint32_t n_grp = M_ap >> (N_ant >> 1), M_symb = n_grp * N_ant, N_bits = M_symb * Qm; // (N_ant is 1, 2 or 4)
     if (threadIdx.x == 0) e_len[a_idx] = N_bits;
 
     // ---- phase 3: per group of N_ant REs: gather, pre-decode, de-map, descramble.  The modulation is uniform over the workgroup: the whole
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COMPACT ? D
         auto ld = [&](uint32_t row, uint32_t off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, (int)row, 0)); };
         auto body = [&](auto *dst) {
             for (uint32_t item = threadIdx.x; item < n_items; item += blockDim.x) {
-                const uint32_t s = item >= per_slot ? 1u : 0u, r = item - s * per_slot, i = __umul24(r, 43691u) >> 19, j = r - __umul24(i, 12u); // r / 12 for r < 2^15
+                const uint32_t s = item >= per_slot ? 1u : 0u, r = item - s * per_slot, i = __umul24(r, 43691u) >> 19, j = r - ((i << 3) + (i << 2)); // r / 12 for r < 2^15; 12 i as shifts (the product form became a 64-bit multiply-add at a quarter of the rate)
                 const uint32_t bit = 1u << j, below = bit - 1u;
                 const uint2   *tp = tab + (s ? 7 * N_prb : 0u) + i; // the pair of the slot's first symbol; the next symbols' are N_prb apart
                 const uint2    t0 = *tp;

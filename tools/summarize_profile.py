@@ -86,6 +86,8 @@ def main(src, tag, workload="chain"):
         for k, v in stats.items():
             if k.startswith("k_"):
                 f.write("| %s | %d | %.1f | %.2f | %.1f |\n" % (k, v["calls"], v["avg_us"], v["total_ms"], v["pct"]))
+        f.write("\n(`k_copy_words`, `k_copy16`, `k_copy16_loop`, `k_done_flag`: the workload's set-up -- the batch is laid down in HBM by repeated uploads "
+                "through the 4 MiB bounce block -- and `bench.py`'s copy-rate measurement; outside the timed region.  The percentages are of the whole process.)\n")
         f.write("\nPer launch shape (grid in threads), HBM bytes per launch from the PMC passes "
                 "(FETCH_SIZE x2 per the gfx950 correction in MI355X_MICROARCH.md; WRITE_SIZE uncorrected):\n\n")
         f.write("| kernel | grid | launches | avg us | fetch B (x2) | write B | (fetch+write)/time GB/s |\n|---|---|---|---|---|---|---|\n")

@@ -9,10 +9,11 @@ for s in $(seq $1 $2); do
 done
 python - <<'PY'
 import glob, json
-tot = dict(downlink=0, dl_identical=0, uplink=0, ul_diff_bits=0, ul_bits=0, control=0, pbch=0, prach=0, sync=0)
+tot = dict(downlink=0, dl_identical=0, ce_phase_ties=0, uplink=0, ul_diff_bits=0, ul_bits=0, control=0, pbch=0, prach=0, sync=0)
 for f in sorted(glob.glob("gpurun_out/fuzz_soak/report_seed_*.json")):
     d = json.load(open(f))
     tot["downlink"] += d["downlink"]["cases"]; tot["dl_identical"] += d["downlink"]["identical_soft_bits_verdict_and_bits"]
+    tot["ce_phase_ties"] += len(d["downlink"].get("channel_estimate_phase_ties", []))
     u = d.get("uplink", {})
     tot["uplink"] += u.get("allocations", 0); tot["ul_diff_bits"] += u.get("soft_bits_differing", 0); tot["ul_bits"] += u.get("soft_bits", 0)
     tot["control"] += d.get("control_region", {}).get("subframes", 0); tot["pbch"] += d.get("pbch", {}).get("units", 0)

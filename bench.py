@@ -1153,12 +1153,15 @@ def config_leg(cls, ctx, steps, cpu_budget_s):
     size on the same context, `steps` steps between two synchronisations with the per-launch HIP events on, its own `roofline` and
     `cpu_baseline` (bounded)."""
     wl = cls(ctx, 0, 0)
+    finish = getattr(wl, "finish", lambda: None)  # (results a workload fetches behind its last step: inside the timed interval)
     wl.step()
+    finish()
     ctx.sync()
     ctx.profile(True)
     t0 = time.perf_counter()
     for _ in range(steps):
         wl.step()
+    finish()
     ctx.sync()
     dt = time.perf_counter() - t0
     prof = ctx.profile_report()

@@ -252,6 +252,8 @@ def _bind_ref(L):
     L.ref_get_pusch_dmrs.argtypes = [vp, u32, u32, f32p]
     L.ref_get_ul_subframe.argtypes = [vp, f32p, f32p, vp]
     L.ref_pusch_channel_decode.argtypes = [vp, vp, C.POINTER(LoAlloc), u32, u32, u8p, C.POINTER(u32)]
+    if hasattr(L, "ref_pusch_channel_decode_slots"):
+        L.ref_pusch_channel_decode_slots.argtypes = [vp, vp, C.POINTER(LoAlloc), C.POINTER(u32), u32, u32, u8p, C.POINTER(u32)]
     L.ref_pusch_soft_bits_ptr.argtypes = [vp]
     L.ref_pusch_soft_bits_ptr.restype = C.POINTER(C.c_int8)
     L.ref_ulsch_rx_g_bits_ptr.argtypes = [vp]

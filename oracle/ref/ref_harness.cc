@@ -604,6 +604,22 @@ int ref_pusch_channel_decode(void *phy, void *sf, const ref_alloc_t *alloc, uint
     free(a);
     return err;
 }
+// the same with a resource-block list of its own for the second slot (PUSCH hopping: liblte_phy_pusch_channel_decode reads alloc->prb[L / 7], :2840)
+int ref_pusch_channel_decode_slots(void *phy, void *sf, const ref_alloc_t *alloc, const uint32_t *prb_slot1, uint32_t N_id_cell, uint32_t N_ant,
+                                   uint8_t *out_bits, uint32_t *N_out_bits)
+{
+    LIBLTE_PHY_ALLOCATION_STRUCT *a = (LIBLTE_PHY_ALLOCATION_STRUCT *)calloc(1, sizeof(*a));
+    uint32                        N = 0;
+    fill_alloc(a, alloc, NULL);
+    for (uint32_t i = 0; i < alloc->N_prb && i < 110; i++) a->prb[1][i] = prb_slot1[i];
+    a->chan_type = LIBLTE_PHY_CHAN_TYPE_ULSCH;
+    ref_zero_turbo_scratch(phy);
+    int err = (int)liblte_phy_pusch_channel_decode((LIBLTE_PHY_STRUCT *)phy, (LIBLTE_PHY_SUBFRAME_STRUCT *)sf, a, N_id_cell,
+                                                   (uint8)N_ant, out_bits, &N);
+    *N_out_bits = N;
+    free(a);
+    return err;
+}
 int8_t *ref_pusch_soft_bits_ptr(void *phy) { return (int8_t *)((LIBLTE_PHY_STRUCT *)phy)->pusch_soft_bits; }
 float  *ref_ulsch_rx_g_bits_ptr(void *phy) { return ((LIBLTE_PHY_STRUCT *)phy)->ulsch_rx_g_bits; }
 float  *ref_pusch_d_re_ptr(void *phy) { return ((LIBLTE_PHY_STRUCT *)phy)->pusch_d_re; }

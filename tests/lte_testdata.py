@@ -158,7 +158,11 @@ def ref_ul_decode(R, case):
             al = case["allocs"][u * case["n_alloc"] + a]
             la = po.make_alloc(al.mod_type, al.tbs, [al.prb[0][i] for i in range(al.N_prb)], al.rnti, al.rv_idx, al.tx_mode)
             out, n = np.zeros(6200, np.uint8), C.c_uint32()
-            rc = R.ref_pusch_channel_decode(phy, sfp, C.byref(la), case["cell"], 1, out, C.byref(n))
+            slot1 = [al.prb[1][i] for i in range(al.N_prb)]
+            if slot1 != [al.prb[0][i] for i in range(al.N_prb)]:  # a second-slot list of its own (PUSCH hopping)
+                rc = R.ref_pusch_channel_decode_slots(phy, sfp, C.byref(la), (C.c_uint32 * 110)(*slot1), case["cell"], 1, out, C.byref(n))
+            else:
+                rc = R.ref_pusch_channel_decode(phy, sfp, C.byref(la), case["cell"], 1, out, C.byref(n))
             qm = {0: 1, 1: 2, 2: 4, 3: 6}[al.mod_type]
             ng = 12 * 12 * al.N_prb * qm
             g = np.ctypeslib.as_array(R.ref_ulsch_rx_g_bits_ptr(phy), shape=(ng,)).astype(np.int8).copy()

@@ -540,6 +540,276 @@ class ChainWorkload:
         return out
 
 
+class ChainMixedWorkload(ChainWorkload):
+    """The W4 chain on MIXED traffic: 65 536 fully loaded 20 MHz subframes whose allocation lists differ from subframe to subframe --
+    every subframe its own control-region size (1-3 symbols) and 4-25 allocations of 1-25 PRB each, QPSK / 16QAM / 64QAM, redundancy
+    versions 0-3, transport block sizes from 36.213 table 7.1.7.2.1-1 (F = 0, one code block: the reference's envelope) at code rates
+    around 1/3 with some repetition and some puncturing: ~150 distinct code-block sizes in one batch.  Same kernels, same device-resident
+    accounting as W4; the allocation list lives in a DYNAMIC plan (mi_lte_pdsch_plan_create_dynamic / _assign), as a caller that decodes
+    DCIs per subframe has it (LTE_fdd_enb_phy.cc:557-770, LTE_fdd_dl_fs_samp_buf.cc:445-515)."""
+    name = "chain_mixed"
+    dominant = "k_turbo_siso"
+    N_UNIQUE = 192
+
+    @property
+    def metric(self):
+        return "DL subframes/sec @20MHz 100RB, MIXED traffic (QPSK/16QAM/64QAM, 1-25 PRB allocations, per-subframe lists), full chain FFT->CE->demap->rate-unmatch->turbo(REF)->CRC"
+
+    @staticmethod
+    def draw_lists(n_unique, rank, seed=20260601):
+        """Per unique subframe: (subframe number, cell, CFI, [allocation tuples (mod, tbs, first PRB, N_prb, rnti, rv)])."""
+        import numpy as np
+        import openlte_amd as m
+        import lte_testdata as td
+        L = m.load_library()
+        sizes = set(td.ALL_K)
+        rng = np.random.default_rng(seed + rank)
+        out = []
+        for u in range(n_unique):
+            sf = [1, 2, 3, 4, 6, 7, 8, 9][u % 8]  # subframes 0 / 5 carry the synchronisation signals (W4's choice too)
+            cell, cfi = int((u * 37 + 11 * rank) % 504), int(rng.integers(1, 4))
+            first, lst = 0, []
+            while first < 100:
+                n_prb = min(int(rng.integers(1, 26)), 100 - first)
+                mod = int(rng.integers(1, 4))
+                per_prb = ((14 - cfi) * 12 - 6) * (2, 4, 6)[mod - 1]    # single port: two CRS elements per PRB in symbols 4, 7, 11
+                n_prb = min(n_prb, 10000 // per_prb)                    # the unmodified reference holds 10 000 soft bits per allocation (liblte_phy.h:355-363): 64QAM 11-13 PRB, 16QAM 16-19
+                e = n_prb * per_prb
+                cand = sorted({int(L.mi_lte_tbs(i, n_prb)) for i in range(27)})
+                cand = [t for t in cand if t + 24 in sizes]             # one code block, no filler bits
+                fit = [t for t in cand if 3 * (t + 28) <= e]
+                r = rng.random()
+                if not fit:
+                    tbs = cand[0]
+                elif r < 0.75:    # the reference's decoder is built for rate <= 1/3: the largest sizes that fit
+                    tbs = fit[max(0, len(fit) - 1 - int(rng.integers(0, 3)))]
+                elif r < 0.90:    # repetition (soft combining over several laps of the circular buffer)
+                    tbs = fit[int(rng.integers(0, len(fit)))]
+                else:             # punctured: the next sizes up
+                    above = [t for t in cand if t > fit[-1]][:3]
+                    tbs = above[int(rng.integers(0, len(above)))] if above else fit[-1]
+                lst.append((mod, tbs, first, n_prb, 0x100 + len(lst), int(rng.choice([0, 0, 0, 0, 1, 2, 3]))))
+                first += n_prb
+            out.append((sf, cell, cfi, lst))
+        return out
+
+    @staticmethod
+    def host_setup(n, rank, cfg):
+        import ctypes as C
+        import numpy as np
+        import openlte_amd as m
+        from openlte_amd import synth
+        U = min(ChainMixedWorkload.N_UNIQUE, n)
+        lists = ChainMixedWorkload.draw_lists(U, rank)
+        sfs = np.array([l[0] for l in lists], np.uint32)
+        cells = np.array([l[1] for l in lists], np.uint32)
+        max_tbs = max(t[1] for l in lists for t in l[3])
+        iq, tx, allocs, first = None, [], [], [0]
+        for u, (sf, cell, cfi, lst) in enumerate(lists):
+            al = [m.make_alloc(u, mod, tbs, list(range(p0, p0 + n_prb)), rnti, rv, 1, None, cfi) for (mod, tbs, p0, n_prb, rnti, rv) in lst]
+            q, t = synth.dl_units(cfg, [sf], [cell], al, len(al), n_pdcch_symbs=cfi, snr_db=(30.0, 27.0, 25.0)[u % 3], max_delay=8, seed=777 + 13 * rank + u)
+            if iq is None:
+                iq = np.zeros((U,) + q.shape[1:], q.dtype)
+            iq[u] = q[0]
+            tx += [np.pad(t[0, a], (0, max_tbs - t.shape[2])) for a in range(len(al))]
+            allocs += al
+            first.append(len(allocs))
+        first = np.array(first, np.int64)
+        # the batch's list: unit i carries unique subframe (i mod U)'s allocations, `unit` = i -- built on the struct bytes by numpy
+        sz, off = C.sizeof(m.PdschAlloc), m.PdschAlloc.unit.offset
+        base = np.frombuffer((m.PdschAlloc * len(allocs))(*allocs), np.uint8).reshape(len(allocs), sz)
+        reps, rem = divmod(n, U)
+        full = np.concatenate([np.tile(base, (reps, 1)), base[:first[rem]]]) if rem else np.tile(base, (reps, 1))
+        uidx = np.repeat(np.arange(U), np.diff(first))
+        unit = np.concatenate([uidx + r * U for r in range(reps)] + ([uidx[:first[rem]] + reps * U] if rem else [])).astype(np.uint32)
+        full = np.ascontiguousarray(full)
+        full[:, off:off + 4] = unit.view(np.uint8).reshape(-1, 4)
+        return {"uniq": (iq, np.array(tx, np.uint8), sfs, cells, allocs), "idx": np.arange(n) % U, "lists": lists, "first": first,
+                "all_allocs": (m.PdschAlloc * len(full)).from_buffer(full), "_keep": full}
+
+    def __init__(self, ctx, n_units, rank):
+        import numpy as np
+        import openlte_amd as m
+        self.ctx, self.m, self.np = ctx, m, np
+        self.n = n_units or 65536
+        self.cfg = m.DlCfg(2048, 100, 1, m.IQ_I8 | (m.CE_COMPACT if CE_MODE == "compact" else 0))
+        host = self.host_setup(self.n, rank, self.cfg)
+        self.host, self.uniq, self.idx, self.lists, self.first = host, host["uniq"], host["idx"], host["lists"], host["first"]
+        if ctx is None:
+            return
+        iq, ul, U = self.uniq[0], self.uniq[0].shape[1], self.uniq[0].shape[0]
+        self.d_iq = ctx.alloc(self.n * ul * 2)
+        for c0 in range(0, self.n, U):
+            self.d_iq.upload(iq[:min(U, self.n - c0)], c0 * ul * 2)
+        self.d_start = ctx.to_device((np.arange(self.n) * ul).astype(np.uint64))
+        self.d_sf = ctx.to_device(self.uniq[2][self.idx])
+        self.d_cell = ctx.to_device(self.uniq[3][self.idx])
+        self.d_sub = ctx.alloc(self.n * ctx.subframe_floats(1) * 4)
+        arr = host["all_allocs"]
+        self.n_alloc = len(arr)
+        # every allocation of a unique subframe with its E (soft bits), K and information bits, for the accounting
+        rows = []
+        for (sf, cell, cfi, lst) in self.lists:
+            rows += [(n_prb * ((14 - cfi) * 12 - 6), (2, 4, 6)[mod - 1], tbs + 24, tbs) for (mod, tbs, p0, n_prb, rnti, rv) in lst]
+        self.rows = np.array(rows, np.int64)
+        reps, rem = divmod(self.n, U)
+        self.mult = np.full(len(rows), reps, np.int64)
+        self.mult[:self.first[rem]] += 1  # how often each unique allocation occurs in the batch
+        # the plan reserves an allocation's soft bits by (14 - CFI) x 12 x N_prb x Q_m, CRS positions included, in 64-byte lines
+        cap = np.array([(14 - cfi) * 12 * n_prb * (2, 4, 6)[mod - 1] for (sf, cell, cfi, lst) in self.lists for (mod, tbs, p0, n_prb, rnti, rv) in lst], np.int64)
+        soft_bytes = int((((cap + 63) // 64 * 64) * self.mult).sum())
+        self.plan = ctx.pdsch_plan_dynamic(self.cfg, self.n_alloc, soft_bytes)
+        self.assign = lambda: ctx._check(ctx.L.mi_lte_pdsch_plan_assign(ctx.h, self.plan.h, 2, C_cast_void(arr), self.n_alloc))
+        self.assign()
+        self.plan.out_stride = ctx.L.mi_lte_pdsch_plan_out_stride(self.plan.h)
+        self.d_out = ctx.alloc(self.n_alloc * self.plan.out_stride)
+        self.d_status = ctx.alloc(self.n_alloc * 4)
+        self.info_bits_per_step = int((self.rows[:, 3] * self.mult).sum())
+        self.info_bits = self.info_bits_per_step / self.n  # per subframe (mean)
+
+    def extra(self, value):
+        import ctypes as C
+        np = self.np
+        st = self.d_status.download(np.int32)
+        U, first = len(self.lists), self.first
+        n_u = int(first[-1])
+        tx = self.uniq[1]
+        # where the CRC passed the bits must be the transmitted ones: every allocation of the batch's first pass over the unique subframes ...
+        bits = self.d_out.download(np.uint8, count=n_u * self.plan.out_stride).reshape(n_u, self.plan.out_stride)
+        tbs = self.rows[:, 3]
+        exact = all(st[a] != 0 or bool((bits[a, :tbs[a]] == tx[a, :tbs[a]]).all()) for a in range(n_u))
+        # ... the verdicts repeat with the subframes (unit i = unique subframe i mod U) ...
+        reps = self.n // U
+        periodic = bool((st[:reps * n_u].reshape(reps, n_u) == st[:n_u]).all())
+        # ... and verdict + bits must be the compiled reference's on a sample of the unique subframes (the checker, not the product)
+        from oracle import pyoracle as po
+        import lte_testdata as td
+        R = po.ref()
+        same, n_cmp, kind, differ = True, 0, "compiled reference (oracle/_ref)", []
+        if R is None:
+            kind = "plain-C restatement (oracle/lte_oracle.c)"
+        P = po.port()
+        for u in range(0, U, max(1, U // 8)):
+            sf, cell, cfi, lst = self.lists[u]
+            q = self.uniq[0][u]
+            if R is not None:
+                i_f = np.ascontiguousarray(np.concatenate([np.zeros(sf * 30720, np.float32), q[:, 0].astype(np.float32)]))
+                q_f = np.ascontiguousarray(np.concatenate([np.zeros(sf * 30720, np.float32), q[:, 1].astype(np.float32)]))
+                phy, rx = R.ref_phy_new(4, cell, 1, 100), R.ref_subframe_new()
+                R.ref_get_dl_subframe_and_ce(phy, i_f, q_f, 0, sf, cell, 1, rx)
+            else:
+                lc, sfr = td.oracle_frontend(P, 2048, 100, 1, q, sf, cell)
+            for k, (mod, t, p0, n_prb, rnti, rv) in enumerate(lst):
+                a = int(first[u]) + k
+                o, nb = np.zeros(6200, np.uint8), C.c_uint32()
+                la = po.make_alloc(mod, t, list(range(p0, p0 + n_prb)), rnti, rv, 1)
+                if R is not None:
+                    rc = R.ref_pdsch_channel_decode(phy, rx, C.byref(la), cfi, cell, 1, o, C.byref(nb))
+                else:
+                    rc = P.lo_pdsch_channel_decode(C.byref(lc), C.byref(sfr), C.byref(la), cfi, cell, 1, o, C.byref(nb), None, None)
+                eq = int(st[a]) == rc and (rc != 0 or bool((bits[a, :nb.value] == o[:nb.value]).all()))
+                if not eq:
+                    differ.append({"unique_subframe": u, "allocation": k, "mod": mod, "tbs": t, "N_prb": n_prb, "rv": rv, "cfi": cfi, "library": int(st[a]), "checker": int(rc)})
+                same &= eq
+                n_cmp += 1
+            if R is not None:
+                R.ref_subframe_free(rx)
+                R.ref_phy_free(phy)
+        ok_bits = int((self.rows[:, 3] * self.mult * (st[:n_u] == 0)).sum()) if periodic else None
+        ks = np.unique(self.rows[:, 2])
+        res = {"turbo_info_mbit_per_s": round(value * self.info_bits / 1e6, 2),
+               "turbo_info_mbit_per_s_crc_passed": round(value / self.n * ok_bits / 1e6, 2) if ok_bits is not None else None,
+               "info_bits_per_subframe_mean": round(self.info_bits, 1),
+               "allocations_per_step": self.n_alloc, "distinct_code_block_sizes": int(len(ks)),
+               "crc_pass": "%d/%d allocations" % (int((st == 0).sum()), st.size), "verdicts_repeat_with_the_unique_subframes": periodic,
+               "sampled_blocks_equal_tx_bits": bool(exact),
+               "sampled_allocations_equal_checker": {"equal": bool(same), "allocations": n_cmp, "checker": kind, "differing": differ[:8]}}
+        # the same step with the list handed over anew every step (a caller whose grants change per batch): mi_lte_pdsch_plan_assign + run
+        ctx = self.ctx
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            self.assign()
+            self.step()
+        ctx.sync()
+        res["ms_per_step_with_plan_assign"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+        return res
+
+    def accounting(self):
+        n, np = self.n, self.np
+        re_, qm, K, tbs = (self.rows[:, k] for k in range(4))
+        mult = self.mult
+        own = {"k_dl_fft": n * (15 * 2048 * 2 + 15 * 1200 * 8), "k_dl_ce": n * (5 * 200 * 8 + 14 * 1200 * 8),
+               "k_pdsch_demod": int((re_ * (16 + qm) * mult).sum())}
+        if CE_MODE == "compact":
+            own["k_dl_ce"] = n * (5 * 200 * 8 + 10 * 1200 * 4)
+            own["k_pdsch_demod"] = int((re_ * (8 + qm) * mult).sum()) + n * 2 * 1200 * 40
+        for k_ in np.unique(K):
+            sel = K == k_
+            for kn, v in turbo_own_io(int(k_), 1, 0, 0).items():
+                own[kn] = own.get(kn, 0) + v * int(mult[sel].sum())
+            own["k_turbo_prep"] += int((re_[sel] * qm[sel] * mult[sel]).sum())
+            own["k_turbo_vote"] += int((tbs[sel] * mult[sel]).sum())
+        own["k_cb_desc"] = self.n_alloc * 80
+        fe = 70240 + 14 * 1200 * 8 + (10 * 1200 * 4 if CE_MODE == "compact" else 14 * 1200 * 8)
+        tk = ["k_cb_desc", "k_turbo_prep", "k_turbo_siso", "k_turbo_perm", "k_turbo_vote", "k_turbo_tail"]
+        return {"stages": {"frontend": (n * fe, ["k_dl_fft", "k_dl_ce"]),
+                           "demod": (int((re_ * (16 + qm) * mult).sum()), ["k_pdsch_demod"]),
+                           "turbo": (int(((3 * (K + 4) + K // 8 + 4) * mult).sum()), tk)},
+                "own_io": own}
+
+    @property
+    def alg_bytes_per_unit(self):  # fused accounting (SURVEY 8d): int8 IQ in + packed information bits out
+        return 70240 + self.info_bits / 8
+
+    def config(self, world):
+        ks = self.np.unique(self.rows[:, 2])
+        return {"workload": "W4-mixed: full DL chain, 20 MHz/100 RB, every subframe fully loaded with its own list of 1-25 PRB allocations "
+                            "(QPSK/16QAM/64QAM, at most 10 000 soft bits each = the reference's PDSCH scratch, rv 0-3, CFI 1-3, TBS from 36.213 table 7.1.7.2.1-1 with F = 0), %d subframes per GPU, int8 IQ in HBM" % self.n,
+                "subframes_per_gpu": self.n, "N_ant": 1, "channel_estimate_form": CE_MODE, "decoder": "REF (reference-faithful, bit-exact)",
+                "unique_subframes": len(self.lists), "allocations_per_subframe_mean": round(self.n_alloc / self.n, 2),
+                "distinct_code_block_sizes": int(len(ks)), "K_min": int(ks.min()), "K_max": int(ks.max()),
+                "plan": "dynamic (mi_lte_pdsch_plan_create_dynamic + _assign), list resident on the device during the timed steps",
+                "sharding": "subframes block-cyclic over %d GPU(s), no collective" % world}
+
+    def cpu_baseline(self, budget_s=10.0):
+        """The compiled reference, one thread, on the unique subframes of this workload in turn (front end + every allocation)."""
+        import ctypes as C
+        np = self.np
+        from oracle import pyoracle as po
+        R, fft_note = timing_ref(po)
+        if R is None:
+            return None
+        model, n_cpu = cpu_info()
+        t_total, done, ok, n_al = 0.0, 0, 0, 0
+        out, nb = np.zeros(6200, np.uint8), C.c_uint32()
+        while t_total < budget_s and done < 2000:
+            u = done % len(self.lists)
+            sf, cell, cfi, lst = self.lists[u]
+            q = self.uniq[0][u]
+            i_f = np.ascontiguousarray(np.concatenate([np.zeros(sf * 30720, np.float32), q[:, 0].astype(np.float32)]))
+            q_f = np.ascontiguousarray(np.concatenate([np.zeros(sf * 30720, np.float32), q[:, 1].astype(np.float32)]))
+            las = [po.make_alloc(mod, t, list(range(p0, p0 + n_prb)), rnti, rv, 1) for (mod, t, p0, n_prb, rnti, rv) in lst]
+            phy, rx = R.ref_phy_new(4, cell, 1, 100), R.ref_subframe_new()
+            t0 = time.perf_counter()
+            R.ref_get_dl_subframe_and_ce(phy, i_f, q_f, 0, sf, cell, 1, rx)
+            for la in las:
+                ok += R.ref_pdsch_channel_decode(phy, rx, C.byref(la), cfi, cell, 1, out, C.byref(nb)) == 0
+            t_total += time.perf_counter() - t0
+            R.ref_subframe_free(rx)
+            R.ref_phy_free(phy)
+            done += 1
+            n_al += len(las)
+        return {"value": round(done / t_total, 3), "unit": self.unit, "cores": 1, "kind": "reference", "cpu": model,
+                "sample": "%d of this workload's unique subframes (liblte_phy_get_dl_subframe_and_ce + every allocation's liblte_phy_pdsch_channel_decode, "
+                          "%d/%d CRC pass), 1 thread, %.1f s; %s" % (done, ok, n_al, t_total, fft_note)}
+
+
+def C_cast_void(arr):
+    import ctypes as C
+    return C.cast(arr, C.c_void_p)
+
+
 class FrontendWorkload:
     """BASELINE config 2 / SURVEY 8d W2: 20 MHz OFDM demod + CRS channel estimate, 10k subframe units."""
     name = "frontend"
@@ -955,7 +1225,7 @@ class MultiStream:
     the lock-step trellis kernel 4+ waves per SIMD (32k subframes), one stream is the fastest."""
 
     def __init__(self, cls, ctxs, n_units, rank):
-        n_units = n_units or {"chain": 65536, "frontend": 10000, "frontend2": 10000, "turbo": 65536, "uplink": 16384, "control": 8192, "sync": 32}[cls.name]
+        n_units = n_units or {"chain": 65536, "chain_mixed": 65536, "frontend": 10000, "frontend2": 10000, "turbo": 65536, "uplink": 16384, "control": 8192, "sync": 32}[cls.name]
         per = max(64, (n_units // len(ctxs) + 63) // 64 * 64)
         self.parts = [cls(c, per, rank * 16 + k) for k, c in enumerate(ctxs)]
         self.ctxs = ctxs
@@ -1020,7 +1290,7 @@ class MultiStream:
         return self.parts[0].cpu_baseline()
 
 
-WORKLOADS = {"turbo": TurboWorkload, "frontend": FrontendWorkload, "frontend2": Frontend2Workload, "chain": ChainWorkload, "uplink": UplinkWorkload, "control": ControlWorkload, "sync": SyncWorkload}
+WORKLOADS = {"turbo": TurboWorkload, "frontend": FrontendWorkload, "frontend2": Frontend2Workload, "chain": ChainWorkload, "chain-mixed": ChainMixedWorkload, "uplink": UplinkWorkload, "control": ControlWorkload, "sync": SyncWorkload}
 
 
 def pick_workload(name):

@@ -582,6 +582,32 @@ int mi_lte_rate_unmatch_turbo_host(mi_lte_ctx *ctx, const float *h_e_bits, uint3
                                    uint32_t N_codeblocks, uint32_t tx_mode, uint32_t N_soft, uint32_t M_dl_harq,
                                    uint32_t chan_type, uint32_t rv_idx, float *h_d_bits, uint32_t *N_d_bits);
 
+/* ---------------------------------------------------------------- scheduler-side helpers ("CPU pass-through restatements")
+ * Pure host functions of a few small integers that LTE_fdd_enodeb calls every TTI next to the receive chains; no context, no device.
+ * Each returns what the reference's function returns (a LIBLTE_ERROR_ENUM value where that one does) and leaves its outputs untouched
+ * exactly where the reference does (a search that finds nothing).  sched.cc; compared with the compiled reference over their whole
+ * argument ranges by shim/lifecycle_check.
+ *   mi_lte_tbs                              36.213 table 7.1.7.2.1-1, I_TBS 0..26, N_PRB 1..110 (TBS_71721, liblte_phy.cc:477-746); 0 outside
+ *   mi_lte_get_tbs_mcs_and_n_prb_for_dl     liblte_phy_get_tbs_mcs_and_n_prb_for_dl   liblte_phy.h:1210   liblte_phy.cc:6251-6357
+ *   mi_lte_get_tbs_and_n_prb_for_dl         liblte_phy_get_tbs_and_n_prb_for_dl       liblte_phy.h:1234   liblte_phy.cc:6359-6407
+ *   mi_lte_get_tbs_mcs_and_n_prb_for_ul     liblte_phy_get_tbs_mcs_and_n_prb_for_ul   liblte_phy.h:1253   liblte_phy.cc:6409-6475
+ *   mi_lte_get_n_cce                        liblte_phy_get_n_cce                      liblte_phy.h:1271   liblte_phy.cc:6477-6505 (the struct's
+ *                                           N_rb_dl and N_group_phich as arguments; phich_res is not read by the reference either)
+ *   mi_lte_pucch_map_sr_config_idx          liblte_phy_pucch_map_sr_config_idx        liblte_phy.h:830    liblte_phy.cc:3183-3217
+ *   mi_lte_code_block_segmentation          liblte_phy_code_block_segmentation        liblte_phy.h:1337   liblte_phy.cc:9753-9865
+ *   mi_lte_code_block_desegmentation        liblte_phy_code_block_desegmentation      liblte_phy.h:1357   liblte_phy.cc:9875-9987 */
+uint32_t mi_lte_tbs(uint32_t I_tbs, uint32_t N_prb);
+int      mi_lte_get_tbs_mcs_and_n_prb_for_dl(uint32_t N_bits, uint32_t N_subframe, uint32_t N_rb_dl, uint16_t rnti, uint32_t *tbs, uint8_t *mcs,
+                                             uint32_t *N_prb);
+int      mi_lte_get_tbs_and_n_prb_for_dl(uint32_t N_bits, uint32_t N_rb_dl, uint8_t mcs, uint32_t *tbs, uint32_t *N_prb);
+int      mi_lte_get_tbs_mcs_and_n_prb_for_ul(uint32_t N_bits, uint32_t N_rb_ul, uint32_t *tbs, uint8_t *mcs, uint32_t *N_prb);
+uint32_t mi_lte_get_n_cce(uint32_t N_rb_dl, uint32_t N_group_phich, uint32_t N_pdcch_symbs, uint32_t N_ant);
+void     mi_lte_pucch_map_sr_config_idx(uint32_t i_sr, uint32_t *sr_periodicity, uint32_t *N_offset_sr);
+void     mi_lte_code_block_segmentation(const uint8_t *b_bits, uint32_t N_b_bits, uint32_t *N_codeblocks, uint32_t *N_filler_bits, uint8_t *c_bits,
+                                        uint32_t N_c_bits_max, uint32_t *N_c_bits);
+void     mi_lte_code_block_desegmentation(const uint8_t *c_bits, const uint32_t *N_c_bits, uint32_t N_c_bits_max, uint32_t tbs, uint8_t *b_bits,
+                                          uint32_t N_b_bits);
+
 /* ---------------------------------------------------------------- whole-chain batches from host buffers
  * Captures live in host memory, so the batch form for callers that hold host buffers: int8 I,Q in, transport blocks back packed eight
  * bits per byte ([allocation][mi_lte_dl_pipeline_out_stride()], first bit most significant) with one verdict per allocation.  The batch

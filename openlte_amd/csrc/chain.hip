@@ -357,9 +357,10 @@ struct mi_lte_pdsch_plan {
     // pinned staging for re-assignments: allocs | e_off | cb_alloc, copied with one command each on the context's stream
     void       *h_stage = nullptr;
     hipEvent_t  staged = nullptr;
-    struct Group { uint32_t K, n_cb, cb_base, e_max; };
+    using Group = MiKGroup; // { K, n_cb, cb_base, e_max }
     std::vector<Group>    groups;
     std::vector<uint32_t> h_e_off;
+    MiMultiCache          multi; // the merged decode's device tables for `groups` (turbo.hip: mi_turbo_ref_multi)
 };
 
 static uint32_t qpp_size_at_least(uint32_t B);
@@ -642,6 +643,7 @@ void mi_lte_pdsch_plan_destroy(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl)
     if (pl->d_bcjr_bits) (void)hipFree(pl->d_bcjr_bits);
     if (pl->h_stage) (void)hipHostFree(pl->h_stage);
     if (pl->staged) (void)hipEventDestroy(pl->staged);
+    mi_multi_cache_free(&pl->multi);
     delete pl;
 }
 
@@ -744,6 +746,29 @@ int mi_lte_pdsch_decode_run(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, const float 
     // Opt-in (MI_LTE_GROUP_STREAMS=1): worth 1 % of the W4 step (24.77 -> 24.55 ms), and it stretches the launches that overlap -- the
     // per-launch times the roofline accounting of bench.py and the rocprof summaries are built on stop describing a kernel alone.
     static const bool side_ok = [] { const char *e = getenv("MI_LTE_GROUP_STREAMS"); return e && atoi(e) != 0; }();
+    // A batch with several block sizes and more code blocks than the state-parallel kernel is for: ONE launch set over all sizes
+    // (turbo.hip: KSeg).  A cell's TTIs hold dozens of the 188 sizes; size by size that is ~7 launches per size in series, each a sliver
+    // of the device -- 65 536 mixed subframes took 72.6 ms that way, 48.8 of them in the decoder (profiles/r06_chain_mixed_per_size.json).
+    // MI_LTE_NO_MERGED_DECODE=1 keeps the per-size launches (A/B).
+    static const bool merged_off = [] { const char *e = getenv("MI_LTE_NO_MERGED_DECODE"); return e && atoi(e) != 0; }();
+    if (!bcjr && !merged_off && !side_ok && pl->groups.size() >= 2 && total_cb > ctx->siso_small_max) {
+        // (MI_LTE_MERGE_MAX_TILES=n, tuning aid: a size with more than n tiles of 64 blocks keeps its own launches)
+        static const uint32_t max_tiles = [] { const char *e = getenv("MI_LTE_MERGE_MAX_TILES"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 0xFFFFFFFFu; }();
+        auto merged = [&](const MiKGroup &gr) { return mi_turbo_ref_multi_takes(gr.K, gr.e_max) && (gr.n_cb + 63) / 64 <= max_tiles; };
+        std::vector<MiKGroup> take;
+        for (auto &gr : pl->groups)
+            if (merged(gr)) take.push_back(gr);
+        if (take.size() >= 2) {
+            rc = mi_turbo_ref_multi(ctx, take.data(), (uint32_t)take.size(), pl->d_allocs, pl->d_cb_alloc, pl->d_e, pl->d_e_off, pl->d_e_len, d_out_bits, pl->out_stride, d_status,
+                                    false, pl->packed != 0, &pl->multi);
+            if (rc != MI_LTE_OK) return rc;
+            for (auto &gr : pl->groups) // (an allocation repeated over more than 258 laps of its circular buffer: 32-bit sums, the per-size path)
+                if (!merged(gr) && (rc = run_group(gr)) != MI_LTE_OK) return rc;
+            ctx->last_kernels = take.size() == pl->groups.size() ? "k_pdsch_demod:1,k_cb_desc:1,k_turbo_prep,k_turbo_siso:2,k_turbo_perm,k_turbo_vote per workgroup width over all block sizes"
+                                                                  : "k_pdsch_demod:1,k_cb_desc:1,k_turbo_prep,k_turbo_siso:2,k_turbo_perm,k_turbo_vote per workgroup width over all block sizes but the per-size ones";
+            return MI_LTE_OK;
+        }
+    }
     if (!bcjr && side_ok && pl->groups.size() >= 2 && total_cb >= 16384) {
         if (!ctx->side_stream) {
             MI_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));

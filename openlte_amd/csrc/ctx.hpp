@@ -136,6 +136,21 @@ int   mi_ctx_fft_twiddles(mi_lte_ctx *ctx);
 int   mi_turbo_ref_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_pdsch_alloc *d_allocs,
                          const uint32_t *d_cb_alloc, const int8_t *d_e, const uint32_t *d_e_off, const uint32_t *d_e_len,
                          uint8_t *d_out_bits, uint32_t out_stride, int32_t *d_status, uint32_t e_max_bytes, bool ul = false, bool packed = false);
+// the merged REF decode of a batch with many code-block sizes (turbo.hip: KSeg, mi_turbo_ref_multi)
+struct MiKGroup { uint32_t K, n_cb, cb_base, e_max; }; // a block size's code blocks: slots cb_base .. cb_base + n_cb of the batch's code-block order; e_max: its longest allocation's soft bits
+struct MiMultiGeom { // launch geometry derived from the groups; classes = workgroup widths 64 (c + 1)
+    uint64_t arr_bytes = 0;                           // bytes of one scratch array over all sizes
+    uint32_t n_slots = 0, n_wv1 = 0, n_wv23 = 0;
+    uint32_t grid_cb[6] = {0}, grid_perm[6] = {0}, lds_prep[6] = {0}, kp_max[6] = {0};
+    uint32_t map_cb[6] = {0}, map_perm[6] = {0}, map_wv1 = 0, map_wv23 = 0; // where each launch's map starts (entries)
+    size_t   map_off = 0;                             // bytes from the table's start to the maps
+};
+struct MiMultiCache { void *d_tab = nullptr; size_t cap = 0; std::vector<MiKGroup> built_for; MiMultiGeom geom; };
+bool  mi_turbo_ref_multi_takes(uint32_t K, uint32_t e_max_bytes);
+int   mi_turbo_ref_multi(mi_lte_ctx *ctx, const MiKGroup *groups, uint32_t n_groups, const mi_lte_pdsch_alloc *d_allocs, const uint32_t *d_cb_alloc,
+                         const int8_t *d_e, const uint32_t *d_e_off, const uint32_t *d_e_len, uint8_t *d_out_bits, uint32_t out_stride, int32_t *d_status,
+                         bool ul, bool packed, MiMultiCache *cache);
+void  mi_multi_cache_free(MiMultiCache *cache);
 int   mi_turbo_bcjr_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_pdsch_alloc *d_allocs, const uint32_t *d_cb_alloc, const int8_t *d_e,
                           const uint32_t *d_e_off, const uint32_t *d_e_len, uint8_t *d_out_bits, uint32_t out_stride, int32_t *d_status, bool ul,
                           int8_t *d_soft, uint8_t *d_c_bits, uint32_t n_iter, int qpp_spec, bool packed = false, uint32_t e_max_bytes = 0, bool block_mode = false, bool early = false);

@@ -18,7 +18,10 @@
 //     vote) run as one workgroup per code block with the block staged in LDS.
 //
 // Kernel sequence per batch:  prep -> siso(pass 1) -> perm -> siso(pass 2 | pass 3) -> vote
+#include <algorithm>
+#include <cstring>
 #include <type_traits>
+#include <vector>
 
 #include "ctx.hpp"
 
@@ -188,6 +191,8 @@ __device__ __forceinline__ void unpack_idx16(const IdxRaw &r, uint32_t (&idx)[16
     for (int k = 0; k < 16; k++) idx[k] = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
 }
 
+struct KSeg; // (a block size's row of a merged decode's table, below)
+typedef __attribute__((address_space(4))) const KSeg const_seg_fwd_t;
 // ---- where the soft values of a code block come from
 // (a) directly from the caller, in the reference's interleaved d[i*3+x] layout
 template <typename T> struct SrcDirect {
@@ -198,6 +203,7 @@ template <typename T> struct SrcDirect {
     const T *soft;
     const T *d;
     __device__ __forceinline__ void init(uint32_t cb, uint32_t K) { d = soft + (size_t)cb * 3 * (K + 4); }
+    __device__ __forceinline__ void seg(const_seg_fwd_t &) {} // (a merged decode always comes from rate-matched soft bits)
     __device__ __forceinline__ bool hard_inputs() const { return false; }
     __device__ __forceinline__ bool stage_e(int8_t *) { return false; }
     // v[Src::kPacked ? 0 : x][k] = d[(16u+k)*3 + x] for k < nvalid (16 or 8), with Step 0 (RX_NULL_BIT -> 0, liblte_phy.cc:10636-10642)
@@ -330,6 +336,43 @@ struct GroupDesc {                 // one launch = the code blocks of one size K
     const CbDesc   *desc;          // [n_cb] filled by k_cb_desc before the first kernel of the group (REF decoder)
 };
 
+// One block size of a MERGED decode (mi_turbo_ref_multi: a PDSCH batch whose allocations have many code-block sizes -- a cell's TTIs
+// have dozens of the 188).  Launched size by size such a batch is ~7 launches per size in series, each far too small for the device (a
+// trellis walk is as long for one tile as for a thousand); merged, every kernel below is launched ONCE over the tiles / code blocks of
+// all sizes (the per-code-block kernels once per workgroup width, 64 .. 384 threads), and what the per-size launches pass as kernel
+// arguments -- K, the block count, the interleaver and rank tables, where the size's tiles lie in the scratch arrays -- is read from
+// this table by the workgroup (wavefront) at its start: one scalar load of its index in `map`, then scalar loads of the row.
+struct KSeg {
+    uint32_t        K, n_cb, cb_base, n_tiles; // cb_base: the size's first slot in the batch's code-block order (cb_alloc, desc)
+    uint32_t        wg_cb;                     // first workgroup of the size in its prep / vote launch (a multiple of 8: blockIdx % 8 = XCD)
+    uint32_t        wg_perm, perm_grid;        // the same for perm, and the size's own grid there (a workgroup takes PERM_NB blocks grid apart)
+    uint32_t        e_cap;                     // LDS bytes prep stages an allocation's soft bits in (0: gathers from global memory)
+    uint32_t        wv1, wv23;                 // first wavefront of the size in SISO pass 1 / passes 2 + 3
+    uint64_t        arr_off;                   // where the size's tiles start in each of the eleven byte arrays (traceback words: half of it)
+    const uint16_t *pi, *inv2, *tabs;          // mi_ctx_turbo_tables / rm_rank_tables of K
+    const uint32_t *nnn;
+    uint64_t        pad[2];
+};
+static_assert(sizeof(KSeg) == 96, "KSeg is read with scalar loads: keep it a multiple of 16 bytes");
+struct MultiArgs { const KSeg *segs; const uint32_t *map; }; // map: per 8 workgroups (prep, perm, vote) or per wavefront (siso) the index of its size
+// Both reads go through the CONSTANT address space: only then are they scalar loads (the kernels store to global memory, and a plain pointer
+// carries no promise that the table is not what they store to).  As vector loads the two dependent round trips to the L2 at the start of
+// every workgroup cost k_turbo_prep 18 % (W4: 4.15 -> 4.90 ms); the scalar cache serves the row every workgroup of a CU reads.
+typedef __attribute__((address_space(4))) const KSeg     const_seg_t;
+typedef __attribute__((address_space(4))) const uint32_t const_map_t;
+__device__ __forceinline__ const_seg_t &multi_seg(const MultiArgs &ma, uint32_t slot)
+{
+    const uint32_t idx = reinterpret_cast<const_map_t *>(reinterpret_cast<uintptr_t>(ma.map))[__builtin_amdgcn_readfirstlane(slot)];
+    return reinterpret_cast<const_seg_t *>(reinterpret_cast<uintptr_t>(ma.segs))[idx];
+}
+
+// What a workgroup reads from its row is uniform, but the compiler does not take it for that (the row's index went through memory): it
+// kept K, the tile offsets and everything derived from them in vector registers -- k_turbo_perm<MULTI> at 99 VGPRs and 4 waves per SIMD
+// where the per-size kernel has 63 and 8.  v_readfirstlane states it.
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t uni(uint64_t v) { return (uint64_t)uni((uint32_t)(v >> 32)) << 32 | uni((uint32_t)v); }
+template <typename T> __device__ __forceinline__ T *uni(T *p) { return reinterpret_cast<T *>(uni((uint64_t)reinterpret_cast<uintptr_t>(p))); }
+
 struct SrcRateUnmatch {
     static constexpr bool kIntegerValued = true; // sums of int8 soft bits
     uint32_t e_cap; // bytes of LDS available for staging e (0 = gather from global)
@@ -339,6 +382,7 @@ struct SrcRateUnmatch {
     const uint16_t *tab;
     const int8_t   *e;
     uint32_t        E, Nnn, K_;
+    __device__ __forceinline__ void seg(const_seg_fwd_t &sg); // merged launch: the size's tables and descriptors (defined below KSeg)
     __device__ __forceinline__ void init(uint32_t cb, uint32_t K)
     {
         const uint4 *dp = reinterpret_cast<const uint4 *>(g.desc + cb);
@@ -483,6 +527,10 @@ struct SrcRateUnmatch {
     }
 };
 // chosen by the host when no sum can leave int16: ceil(E / Nnn) laps of |e| <= 127 each
+__device__ __forceinline__ void SrcRateUnmatch::seg(const_seg_fwd_t &sg)
+{
+    tabs = uni(sg.tabs); nnn = uni(sg.nnn); g.desc += uni(sg.cb_base);
+}
 struct SrcRateUnmatchPk : SrcRateUnmatch { static constexpr bool kPacked = true; };
 
 // LDS tables that replace the per-element IEEE divisions: the quantiser and the SISO output magnitude
@@ -526,23 +574,39 @@ __device__ __forceinline__ uint4 lookup16(uint32_t base, const uint32_t (&w)[16]
 // g[k] = byte at LDS address base + idx[k], as sixteen packed bytes
 __device__ __forceinline__ uint4 gather16_bytes(uint32_t base, const uint32_t (&idx)[16]) { return lookup16(base, idx); }
 
-template <typename Src, int NSLOT>
+template <typename Src, int NSLOT, bool MULTI = false>
 #ifndef PREP_WPE
 #define PREP_WPE 6
 #endif
 #ifndef PREP_WPE_PK
 #define PREP_WPE_PK 6 // the int16-pair variant needs 79 VGPRs unspilled (7 waves: 5.3 ms, 8 waves: 8.9 ms, 6: 4.65 ms per 64k subframes)
 #endif
-__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Src::kPacked ? PREP_WPE_PK : PREP_WPE, 8))) void k_turbo_prep(Src src, uint32_t K, uint32_t n_cb,
-                                                    const uint16_t *__restrict__ pi, PrepOut out)
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Src::kPacked ? PREP_WPE_PK : PREP_WPE, 8))) void k_turbo_prep(Src src, uint32_t K_arg, uint32_t n_cb_arg,
+                                                    const uint16_t *__restrict__ pi_arg, PrepOut out, MultiArgs ma)
 {
     static_assert(NSLOT == 1, "one unit per thread (K <= 6144 -> at most 384 units)");
+    uint32_t K = K_arg, n_cb = n_cb_arg, bidx = blockIdx.x;
+    size_t   seg_off = 0;
+    const uint16_t *__restrict__ pi = pi_arg;
+    if constexpr (MULTI) { // the workgroup's block size out of a merged launch (KSeg)
+        const_seg_t &sg = multi_seg(ma, blockIdx.x >> 3);
+        K = uni(sg.K); n_cb = uni(sg.n_cb); pi = uni(sg.pi); bidx = blockIdx.x - uni(sg.wg_cb); seg_off = uni(sg.arr_off);
+        src.e_cap = uni(sg.e_cap);
+        src.seg(sg);
+    }
     // qtab | mtab1 | mtab2 | staged e [e_cap] | q(d0)[Kp] | reduction scratch (64 B).  No static LDS next to it: the dynamic block then
     // starts at LDS address 0 and the table / gather reads below are "index register + immediate offset", with no base to add
     extern __shared__ __attribute__((aligned(16))) int8_t sm[];
-    const uint32_t cb = xcd_cb(blockIdx.x, n_cb), tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4;
-    if (cb >= n_cb) return; // uniform
-    const size_t   tile_off = (size_t)tile * Kp * 64;
+    const uint32_t cb = xcd_cb(bidx, n_cb), tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4;
+    const size_t   tile_off = seg_off + (size_t)tile * Kp * 64;
+    if (cb >= n_cb) { // uniform
+        // the lanes behind the last code block of a size's last tile: the trellis kernel walks them like any lane (a merged launch does not
+        // clear the scratch first), so they get zeros to walk
+        if (MULTI && cb < ((n_cb + 63u) & ~63u) && threadIdx.x < n_units)
+#pragma unroll
+            for (int a = 0; a < 6; a++) *reinterpret_cast<uint4 *>(out.arr[a] + unit_off(tile_off, lane, threadIdx.x)) = make_uint4(0, 0, 0, 0);
+        return;
+    }
     int8_t        *qtab = sm, *qc = sm + QTAB_HALF, *mtab1 = sm + QTAB_N, *mtab2 = mtab1 + MTAB_N, *e_lds = sm + PREP_TAB_BYTES;
     int8_t        *q0_lds = e_lds + src.e_cap;
     float         *red_f  = reinterpret_cast<float *>(q0_lds + Kp);
@@ -839,12 +903,24 @@ __device__ __forceinline__ uint32_t negate_bytes(uint32_t w, uint32_t m) // -b i
 #ifndef SISO_WPE
 #define SISO_WPE 4
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SISO_WPE, 8))) void k_turbo_siso(SisoArgs args, uint32_t K, uint32_t n_tiles, uint32_t mode)
+// MULTI: a merged launch over the tiles of many block sizes (KSeg): n_tiles_arg is then the launch's wavefront count and K, the tile range and
+// the arrays' offsets come from the wavefront's row of the table (the wavefronts are ordered by falling K: the long walks start first)
+template <bool MULTI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SISO_WPE, 8))) void k_turbo_siso(SisoArgs args, uint32_t K_arg, uint32_t n_tiles_arg, uint32_t mode, MultiArgs ma)
 {
     __shared__ uint32_t tb_lut[2048];
     for (uint32_t i = threadIdx.x; i < 2048; i += blockDim.x) tb_lut[i] = traceback_entry(i >> 3, i & 7u);
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u, wv = blockIdx.x * 4 + (threadIdx.x >> 6), n_wv = mode ? n_tiles : (n_tiles + 1) / 2;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t       K = K_arg, n_tiles = n_tiles_arg, wv = blockIdx.x * 4 + (threadIdx.x >> 6), n_wv = mode ? n_tiles : (n_tiles + 1) / 2;
+    size_t         seg_off = 0;
+    if constexpr (MULTI) {
+        if (wv >= n_tiles_arg) return; // wavefront-uniform
+        const_seg_t &sg = multi_seg(ma, wv);
+        K = uni(sg.K); n_tiles = uni(sg.n_tiles); seg_off = uni(sg.arr_off);
+        wv -= uni(mode ? sg.wv23 : sg.wv1);
+        n_wv = mode ? n_tiles : (n_tiles + 1) / 2;
+    }
     const uint32_t Kp = kpad64(K), nblk = Kp >> 6;
     if (wv >= n_wv) return; // wavefront-uniform
     const uint8_t *pa[2], *pb[2], *pmag[2];
@@ -854,9 +930,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SISO_WPE, 8
     for (int h = 0; h < 2; h++) {
         const SisoPass &ps   = args.p[mode ? h : 0];
         const uint32_t  tile = mode ? wv : min(2 * wv + h, n_tiles - 1); // an odd tile count: the last one twice
-        const size_t    off  = (size_t)tile * Kp * 64 + lane * 64;
+        const size_t    off  = seg_off + (size_t)tile * Kp * 64 + lane * 64;
         pa[h] = ps.in_a + off; pb[h] = ps.in_b + off; pmag[h] = ps.mag + off; pout[h] = ps.out + off;
-        dec[h] = ps.dec + ((size_t)tile * nblk * 64 + lane) * 8;
+        dec[h] = ps.dec + (seg_off >> 3) + ((size_t)tile * nblk * 64 + lane) * 8; // (traceback: 32 bytes per step and tile = half an array's 64)
     }
 
     v2s pm[8];
@@ -1247,10 +1323,18 @@ struct PermArgs { const uint8_t *A1; const uint8_t *X2; uint8_t *out[2]; /* I1, 
 #ifndef PERM_NB
 #define PERM_NB 4
 #endif
-template <int NSLOT>
-__global__ __launch_bounds__(384) void k_turbo_perm(PermArgs a, uint32_t K, uint32_t n_cb, const uint16_t *__restrict__ pi)
+template <int NSLOT, bool MULTI = false>
+__global__ __launch_bounds__(384) void k_turbo_perm(PermArgs a, uint32_t K_arg, uint32_t n_cb_arg, const uint16_t *__restrict__ pi_arg, MultiArgs ma)
 {
     static_assert(NSLOT == 1, "one unit per thread");
+    uint32_t K = K_arg, n_cb = n_cb_arg, bidx = blockIdx.x, grid = gridDim.x;
+    size_t   seg_off = 0;
+    const uint16_t *__restrict__ pi = pi_arg;
+    if constexpr (MULTI) { // the workgroup's block size out of a merged launch (KSeg)
+        const_seg_t &sg = multi_seg(ma, blockIdx.x >> 3);
+        K = uni(sg.K); n_cb = uni(sg.n_cb); pi = uni(sg.pi); bidx = blockIdx.x - uni(sg.wg_perm); grid = uni(sg.perm_grid);
+        seg_off = uni(sg.arr_off);
+    }
     extern __shared__ __attribute__((aligned(16))) int8_t smp[]; // mtab[256] | C1[Kp] | reduction scratch (32 B); no static LDS (see k_turbo_prep)
     int8_t *mtab = smp, *sm = smp + MTAB_N;
     const uint32_t Kp = kpad64(K), n_units = Kp >> 4;
@@ -1266,9 +1350,15 @@ __global__ __launch_bounds__(384) void k_turbo_perm(PermArgs a, uint32_t K, uint
     }
 #pragma unroll 1
     for (uint32_t it = 0; it < PERM_NB; it++) {
-        const uint32_t cb = xcd_cb(blockIdx.x + it * gridDim.x, n_cb), tile = cb >> 6, lane = cb & 63;
-        if (cb >= n_cb) continue; // uniform
-        const size_t   tile_off = (size_t)tile * Kp * 64;
+        const uint32_t cb = xcd_cb(bidx + it * grid, n_cb), tile = cb >> 6, lane = cb & 63;
+        const size_t   tile_off = seg_off + (size_t)tile * Kp * 64;
+        if (cb >= n_cb) { // uniform
+            if (MULTI && cb < ((n_cb + 63u) & ~63u) && nv >= 0) { // the idle lanes of a size's last tile get zeros to walk (see k_turbo_prep)
+                *reinterpret_cast<uint4 *>(a.out[0] + unit_off(tile_off, lane, u0)) = make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<uint4 *>(a.out[1] + unit_off(tile_off, lane, u0)) = make_uint4(0, 0, 0, 0);
+            }
+            continue;
+        }
         // keep the loop body what the one-block kernel was: with the thread index and the packed indices opaque per iteration nothing derived
         // from them (addresses, the sixteen unpacked indices) is hoisted out of the loop, which costs 33 registers and two waves per SIMD
         uint32_t u = u0;
@@ -1327,15 +1417,23 @@ struct VoteArgs { const uint8_t *X0, *A1, *B1, *B2; };
 // GROUP = true : finish dlsch_channel_decode (liblte_phy.cc:12840-12869): drop the F filler positions
 //                (liblte_phy_code_block_desegmentation, :9948-9986), check CRC24A (calc_crc :9713-9743)
 //                and report LIBLTE_SUCCESS / LIBLTE_ERROR_DECODE_FAIL like liblte_phy_pdsch_channel_decode.
-template <bool GROUP, int NSLOT>
-__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_turbo_vote(VoteArgs a, uint32_t K, uint32_t n_cb, const uint16_t *__restrict__ inv,
-                                                    uint8_t *__restrict__ c_bits, GroupDesc g)
+template <bool GROUP, int NSLOT, bool MULTI = false>
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_turbo_vote(VoteArgs a, uint32_t K_arg, uint32_t n_cb_arg, const uint16_t *__restrict__ inv_arg,
+                                                    uint8_t *__restrict__ c_bits, GroupDesc g, MultiArgs ma)
 {
     static_assert(NSLOT == 1, "one unit per thread");
+    uint32_t K = K_arg, n_cb = n_cb_arg, bidx = blockIdx.x;
+    size_t   seg_off = 0;
+    const uint16_t *__restrict__ inv = inv_arg;
+    if constexpr (MULTI) { // the workgroup's block size out of a merged launch (KSeg)
+        const_seg_t &sg = multi_seg(ma, blockIdx.x >> 3);
+        K = uni(sg.K); n_cb = uni(sg.n_cb); inv = uni(sg.inv2); bidx = blockIdx.x - uni(sg.wg_cb); seg_off = uni(sg.arr_off);
+        g.desc += uni(sg.cb_base);
+    }
     extern __shared__ __attribute__((aligned(16))) int8_t sm[]; // D12[Kp + 16] (int16: D1 + D2, a zero slot at Kp) | bits[Kp] | reduction scratch (32 B); no static LDS
-    const uint32_t cb = xcd_cb(blockIdx.x, n_cb), tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4;
+    const uint32_t cb = xcd_cb(bidx, n_cb), tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4;
     if (cb >= n_cb) return;
-    const size_t   tile_off = (size_t)tile * Kp * 64;
+    const size_t   tile_off = seg_off + (size_t)tile * Kp * 64;
     int8_t        *d12 = sm, *bits = sm + 2 * Kp + 32;
     uint32_t      *red_u = reinterpret_cast<uint32_t *>(bits + Kp);
     const uint32_t u  = threadIdx.x;
@@ -1495,6 +1593,26 @@ __global__ __launch_bounds__(256) void k_cb_desc(GroupDesc g, uint32_t n_cb, con
     CbDesc d;
     d.alloc = a; d.e_off = g.e_off[a]; d.E = g.e_len[a]; d.combo = combo; d.Nnn = nnn[combo];
     d.hard  = (g.allocs[a].mod_type >= 2 && d.E <= d.Nnn) ? 1u : 0u; // the de-mapper's 16QAM / 64QAM soft bits are all +-127 (liblte_phy.cc:9573-9659), and no position is summed
+    d.tbs   = g.allocs[a].tbs; d.pad = 0;
+    out[cb] = d;
+}
+
+// the same for a merged decode: one thread per code-block slot of the whole batch, the slot's size found by bisection of the table
+__global__ __launch_bounds__(256) void k_cb_desc_multi(GroupDesc g, uint32_t n_cb, const KSeg *__restrict__ segs, uint32_t n_seg, CbDesc *__restrict__ out)
+{
+    const uint32_t cb = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cb >= n_cb) return;
+    uint32_t lo = 0, hi = n_seg; // segs are in slot order: the last one with cb_base <= cb
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (segs[mid].cb_base <= cb) lo = mid; else hi = mid;
+    }
+    const uint32_t a = g.cb_alloc[cb], txm = g.allocs[a].tx_mode;
+    const uint32_t combo = g.ul ? 8u + (g.allocs[a].rv_idx & 3u)
+                                : ((g.allocs[a].rv_idx & 3u) << 1) | ((txm == 3 || txm == 4 || txm == 8 || txm == 9) ? 1u : 0u);
+    CbDesc d;
+    d.alloc = a; d.e_off = g.e_off[a]; d.E = g.e_len[a]; d.combo = combo; d.Nnn = segs[lo].nnn[combo];
+    d.hard  = (g.allocs[a].mod_type >= 2 && d.E <= d.Nnn) ? 1u : 0u;
     d.tbs   = g.allocs[a].tbs; d.pad = 0;
     out[cb] = d;
 }
@@ -1794,7 +1912,7 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
     po.arr[0] = arr[AX0]; po.arr[1] = arr[AX1]; po.arr[2] = arr[AX2];
     po.arr[3] = arr[AI0]; po.arr[4] = arr[AM1]; po.arr[5] = arr[AM2];
     const uint32_t cb_threads = (uint32_t)(((Kp >> 4) + 63) & ~(size_t)63); // one thread per 16-step unit: 64..384
-    MI_LAUNCH(ctx, "k_turbo_prep", (k_turbo_prep<Src, 1>), dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), PREP_TAB_BYTES + Kp + e_cap + 64, src, K, n_cb, tb.d_pi, po);
+    MI_LAUNCH(ctx, "k_turbo_prep", (k_turbo_prep<Src, 1>), dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), PREP_TAB_BYTES + Kp + e_cap + 64, src, K, n_cb, tb.d_pi, po, MultiArgs{});
 
     SisoArgs s1;
     s1.p[0] = {arr[AX1], arr[AX0], arr[AM1], arr[AA1], dec[0]};
@@ -1806,12 +1924,12 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
         MI_LAUNCH(ctx, "k_turbo_siso_small", k_turbo_siso_small, dim3((n_cb + gpw_of(n_cb) - 1) / gpw_of(n_cb)), dim3(64), lds_of(gpw_of(n_cb)), s1, K, n_cb, 0u,
                   gpw_of(n_cb));
     else
-        MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso, dim3(((n_tiles + 1) / 2 + 3) / 4), dim3(256), 0, s1, K, (uint32_t)n_tiles, 0u); // two tiles per lane
+        MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso<false>, dim3(((n_tiles + 1) / 2 + 3) / 4), dim3(256), 0, s1, K, (uint32_t)n_tiles, 0u, MultiArgs{}); // two tiles per lane
 
     PermArgs pa;
     pa.A1 = arr[AA1]; pa.X2 = arr[AX2]; pa.out[0] = arr[AI1]; pa.out[1] = arr[AM3];
     const uint32_t perm_grid = ((8 * xcd_chunk(n_cb) + PERM_NB - 1) / PERM_NB + 7u) & ~7u; // a multiple of 8: b + i * grid stays on b's XCD
-    MI_LAUNCH(ctx, "k_turbo_perm", k_turbo_perm<1>, dim3(perm_grid), dim3(cb_threads), MTAB_N + Kp + 32, pa, K, n_cb, tb.d_pi);
+    MI_LAUNCH(ctx, "k_turbo_perm", k_turbo_perm<1>, dim3(perm_grid), dim3(cb_threads), MTAB_N + Kp + 32, pa, K, n_cb, tb.d_pi, MultiArgs{});
 
     SisoArgs s23;
     s23.p[0] = {arr[AX2], arr[AI0], arr[AM2], arr[AB1], dec[1]};
@@ -1820,10 +1938,10 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
         MI_LAUNCH(ctx, "k_turbo_siso_small", k_turbo_siso_small, dim3((2 * n_cb + gpw_of(2 * n_cb) - 1) / gpw_of(2 * n_cb)), dim3(64), lds_of(gpw_of(2 * n_cb)), s23, K,
                   n_cb, 1u, gpw_of(2 * n_cb));
     else
-        MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso, dim3((n_tiles + 3) / 4), dim3(256), 0, s23, K, (uint32_t)n_tiles, 1u); // passes 2 and 3 of a tile per lane
+        MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso<false>, dim3((n_tiles + 3) / 4), dim3(256), 0, s23, K, (uint32_t)n_tiles, 1u, MultiArgs{}); // passes 2 and 3 of a tile per lane
 
     VoteArgs va = {arr[AX0], arr[AA1], arr[AB1], arr[AB2]};
-    MI_LAUNCH(ctx, "k_turbo_vote", (k_turbo_vote<GROUP, 1>), dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), 3 * Kp + 64, va, K, n_cb, tb.d_inv2, d_c_bits, gd);
+    MI_LAUNCH(ctx, "k_turbo_vote", (k_turbo_vote<GROUP, 1>), dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), 3 * Kp + 64, va, K, n_cb, tb.d_inv2, d_c_bits, gd, MultiArgs{});
     MI_HIP_CHECK(ctx, hipGetLastError());
     ctx->last_kernels = "k_turbo_prep:1,k_turbo_siso:2,k_turbo_perm:1,k_turbo_vote:1";
     return MI_LTE_OK;
@@ -1883,6 +2001,167 @@ int mi_turbo_ref_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_
         return turbo_ref_run<SrcRateUnmatchPk, true>(ctx, pk, K, n_cb, nullptr, gd, src.e_cap);
     }
     return turbo_ref_run<SrcRateUnmatch, true>(ctx, src, K, n_cb, nullptr, gd, src.e_cap);
+}
+
+// Can the block-size group join a merged decode?  The merged kernels keep the rate un-matching sums as int16 pairs (SrcRateUnmatchPk): a
+// group whose longest allocation makes more than 258 laps of the circular buffer takes the per-size path with 32-bit sums instead.
+bool mi_turbo_ref_multi_takes(uint32_t K, uint32_t e_max_bytes) { return (e_max_bytes + (3 * K - 81) - 1) / (3 * K - 81) <= 258; }
+
+// A whole PDSCH batch -- the code blocks of MANY sizes -- through the REF decoder with every kernel launched once (the per-code-block
+// kernels once per workgroup width): see KSeg.  `groups` in ascending K, cb_base = the group's first slot in d_cb_alloc.  The tables the
+// kernels read are rebuilt only when the groups differ from the ones `cache` was built for (a static plan: once; a dynamic plan: per
+// assignment).
+int mi_turbo_ref_multi(mi_lte_ctx *ctx, const MiKGroup *groups, uint32_t n_groups, const mi_lte_pdsch_alloc *d_allocs, const uint32_t *d_cb_alloc,
+                       const int8_t *d_e, const uint32_t *d_e_off, const uint32_t *d_e_len, uint8_t *d_out_bits, uint32_t out_stride, int32_t *d_status,
+                       bool ul, bool packed, MiMultiCache *cache)
+{
+    if (!groups || n_groups == 0 || n_groups > 0xFFFF || !cache) return MI_LTE_ERR_INVALID_ARG;
+    int rc = mi_ctx_crc_table(ctx);
+    if (rc != MI_LTE_OK) return rc;
+    static const bool lds_ok = no_static_lds((const void *)k_turbo_prep<SrcRateUnmatchPk, 1, true>) && no_static_lds((const void *)k_turbo_perm<1, true>) &&
+                               no_static_lds((const void *)k_turbo_vote<true, 1, true>);
+    if (!lds_ok) { ctx->err = "turbo kernels were built with static LDS: absolute LDS addressing is invalid"; return MI_LTE_ERR_HIP; }
+    constexpr int NCLS = 6; // workgroup widths 64 .. 384: one thread per 16-step unit
+    auto cls_of = [](uint32_t K) { return (int)((((kpad64(K) >> 4) + 63) >> 6) - 1); };
+    const bool same = cache->built_for.size() == n_groups && memcmp(cache->built_for.data(), groups, sizeof(MiKGroup) * n_groups) == 0;
+    if (!same) {
+        std::vector<KSeg>     segs(n_groups);
+        std::vector<uint32_t> map;
+        MiMultiGeom          &G = cache->geom;
+        G = MiMultiGeom{};
+        uint64_t arr = 0;
+        uint32_t cbs = 0;
+        for (uint32_t i = 0; i < n_groups; i++) {
+            const MiKGroup &gr = groups[i];
+            if ((i && gr.K <= groups[i - 1].K) || gr.n_cb == 0) { ctx->err = "merged decode: groups must be non-empty and in ascending block size"; return MI_LTE_ERR_INVALID_ARG; }
+            TurboTables tb;
+            RmTables    rt;
+            if ((rc = mi_ctx_turbo_tables(ctx, gr.K, 0, &tb)) != MI_LTE_OK || (rc = rm_rank_tables(ctx, gr.K, &rt)) != MI_LTE_OK) return rc;
+            KSeg &sg = segs[i];
+            memset(&sg, 0, sizeof(sg));
+            const uint32_t Kp = kpad64(gr.K), cap = (gr.e_max + 16u + 63u) & ~63u;
+            sg.K = gr.K; sg.n_cb = gr.n_cb; sg.cb_base = gr.cb_base; sg.n_tiles = (gr.n_cb + 63) / 64;
+            sg.e_cap = (PREP_TAB_BYTES + Kp + cap + 64 <= 48 * 1024) ? cap : 0; // stage e in LDS when the group's largest allocation fits next to the block's own arrays
+            sg.arr_off = arr;
+            sg.pi = tb.d_pi; sg.inv2 = tb.d_inv2; sg.tabs = rt.d_tabs; sg.nnn = rt.d_nnn;
+            arr += (uint64_t)sg.n_tiles * Kp * 64;
+            cbs = std::max(cbs, gr.cb_base + gr.n_cb);
+            const int c = cls_of(gr.K);
+            G.lds_prep[c] = std::max(G.lds_prep[c], PREP_TAB_BYTES + Kp + sg.e_cap + 64);
+            G.kp_max[c]   = std::max(G.kp_max[c], Kp);
+        }
+        G.arr_bytes = arr;
+        G.n_slots   = cbs;
+        // workgroup -> size maps of the per-code-block kernels, one entry per 8 workgroups, class after class
+        for (int c = 0; c < NCLS; c++) {
+            G.map_cb[c] = (uint32_t)map.size();
+            uint32_t wg = 0;
+            for (uint32_t i = 0; i < n_groups; i++)
+                if (cls_of(groups[i].K) == c) {
+                    segs[i].wg_cb = wg;
+                    const uint32_t g = 8 * xcd_chunk(groups[i].n_cb);
+                    map.insert(map.end(), g / 8, i);
+                    wg += g;
+                }
+            G.grid_cb[c] = wg;
+        }
+        for (int c = 0; c < NCLS; c++) {
+            G.map_perm[c] = (uint32_t)map.size();
+            uint32_t wg = 0;
+            for (uint32_t i = 0; i < n_groups; i++)
+                if (cls_of(groups[i].K) == c) {
+                    segs[i].wg_perm   = wg;
+                    segs[i].perm_grid = ((8 * xcd_chunk(groups[i].n_cb) + PERM_NB - 1) / PERM_NB + 7u) & ~7u; // a multiple of 8: b + i * grid stays on b's XCD
+                    map.insert(map.end(), segs[i].perm_grid / 8, i);
+                    wg += segs[i].perm_grid;
+                }
+            G.grid_perm[c] = wg;
+        }
+        // wavefront -> size maps of the trellis kernel, the largest sizes first (their walks are the longest: started first, the short ones fill in behind them)
+        G.map_wv1 = (uint32_t)map.size();
+        uint32_t wv = 0;
+        for (uint32_t i = n_groups; i-- > 0;) {
+            segs[i].wv1 = wv;
+            map.insert(map.end(), (segs[i].n_tiles + 1) / 2, i);
+            wv += (segs[i].n_tiles + 1) / 2;
+        }
+        G.n_wv1   = wv;
+        G.map_wv23 = (uint32_t)map.size();
+        wv = 0;
+        for (uint32_t i = n_groups; i-- > 0;) {
+            segs[i].wv23 = wv;
+            map.insert(map.end(), segs[i].n_tiles, i);
+            wv += segs[i].n_tiles;
+        }
+        G.n_wv23 = wv;
+        const size_t seg_bytes = sizeof(KSeg) * n_groups, map_bytes = (sizeof(uint32_t) * map.size() + 15) & ~(size_t)15, need = seg_bytes + map_bytes;
+        if (need > cache->cap) {
+            MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            if (cache->d_tab) (void)hipFree(cache->d_tab);
+            cache->d_tab = nullptr; cache->cap = 0;
+            MI_HIP_CHECK(ctx, hipMalloc(&cache->d_tab, need + need / 4));
+            cache->cap = need + need / 4;
+        }
+        std::vector<uint8_t> blob(need, 0);
+        memcpy(blob.data(), segs.data(), seg_bytes);
+        memcpy(blob.data() + seg_bytes, map.data(), sizeof(uint32_t) * map.size());
+        MI_H2D(ctx, cache->d_tab, blob.data(), need); // (waits: the kernels of an earlier run that read the old tables are behind it on the stream)
+        G.map_off = seg_bytes;
+        cache->built_for.assign(groups, groups + n_groups);
+    }
+    const MiMultiGeom &G = cache->geom;
+    const size_t A = G.arr_bytes, dec_bytes = A / 2;
+    rc = mi_ctx_reserve_scratch(ctx, N_BYTE_ARRAYS * A + 3 * dec_bytes + (size_t)((G.n_slots + 63) & ~63u) * sizeof(CbDesc));
+    if (rc != MI_LTE_OK) return rc;
+    uint8_t *base = (uint8_t *)ctx->scratch;
+    uint8_t *arr[N_BYTE_ARRAYS];
+    for (int a = 0; a < N_BYTE_ARRAYS; a++) arr[a] = base + a * A;
+    uint32_t *dec[3];
+    for (int p = 0; p < 3; p++) dec[p] = (uint32_t *)(base + N_BYTE_ARRAYS * A + p * dec_bytes);
+    CbDesc *d_desc = (CbDesc *)(base + N_BYTE_ARRAYS * A + 3 * dec_bytes);
+    const KSeg     *d_segs = (const KSeg *)cache->d_tab;
+    const uint32_t *d_map  = (const uint32_t *)((const uint8_t *)cache->d_tab + G.map_off);
+
+    GroupDesc gd{d_allocs, d_cb_alloc, d_e, d_e_off, d_e_len, d_out_bits, out_stride, d_status, ctx->d_crc_tab, ul ? 1u : 0u, packed ? 1u : 0u};
+    gd.desc = d_desc;
+    MI_LAUNCH(ctx, "k_cb_desc", k_cb_desc_multi, dim3((G.n_slots + 255) / 256), dim3(256), 0, gd, G.n_slots, d_segs, n_groups, d_desc);
+    SrcRateUnmatchPk src;
+    src.g = gd; src.tabs = nullptr; src.nnn = nullptr; src.e_cap = 0;
+    PrepOut po;
+    po.arr[0] = arr[AX0]; po.arr[1] = arr[AX1]; po.arr[2] = arr[AX2];
+    po.arr[3] = arr[AI0]; po.arr[4] = arr[AM1]; po.arr[5] = arr[AM2];
+    for (int c = 0; c < NCLS; c++)
+        if (G.grid_cb[c])
+            MI_LAUNCH(ctx, "k_turbo_prep", (k_turbo_prep<SrcRateUnmatchPk, 1, true>), dim3(G.grid_cb[c]), dim3(64 * (c + 1)), G.lds_prep[c], src, 0u, 0u, (const uint16_t *)nullptr, po,
+                      (MultiArgs{d_segs, d_map + G.map_cb[c]}));
+    SisoArgs s1;
+    s1.p[0] = {arr[AX1], arr[AX0], arr[AM1], arr[AA1], dec[0]};
+    s1.p[1] = s1.p[0];
+    MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso<true>, dim3((G.n_wv1 + 3) / 4), dim3(256), 0, s1, 0u, G.n_wv1, 0u, (MultiArgs{d_segs, d_map + G.map_wv1}));
+    PermArgs pa;
+    pa.A1 = arr[AA1]; pa.X2 = arr[AX2]; pa.out[0] = arr[AI1]; pa.out[1] = arr[AM3];
+    for (int c = 0; c < NCLS; c++)
+        if (G.grid_perm[c])
+            MI_LAUNCH(ctx, "k_turbo_perm", (k_turbo_perm<1, true>), dim3(G.grid_perm[c]), dim3(64 * (c + 1)), MTAB_N + G.kp_max[c] + 32, pa, 0u, 0u, (const uint16_t *)nullptr,
+                      (MultiArgs{d_segs, d_map + G.map_perm[c]}));
+    SisoArgs s23;
+    s23.p[0] = {arr[AX2], arr[AI0], arr[AM2], arr[AB1], dec[1]};
+    s23.p[1] = {arr[AX2], arr[AI1], arr[AM3], arr[AB2], dec[2]};
+    MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso<true>, dim3((G.n_wv23 + 3) / 4), dim3(256), 0, s23, 0u, G.n_wv23, 1u, (MultiArgs{d_segs, d_map + G.map_wv23}));
+    VoteArgs va = {arr[AX0], arr[AA1], arr[AB1], arr[AB2]};
+    for (int c = 0; c < NCLS; c++)
+        if (G.grid_cb[c])
+            MI_LAUNCH(ctx, "k_turbo_vote", (k_turbo_vote<true, 1, true>), dim3(G.grid_cb[c]), dim3(64 * (c + 1)), 3 * G.kp_max[c] + 64, va, 0u, 0u, (const uint16_t *)nullptr,
+                      (uint8_t *)nullptr, gd, (MultiArgs{d_segs, d_map + G.map_cb[c]}));
+    MI_HIP_CHECK(ctx, hipGetLastError());
+    ctx->last_kernels = "k_cb_desc:1,k_turbo_prep,k_turbo_siso:2,k_turbo_perm,k_turbo_vote per workgroup width over all block sizes";
+    return MI_LTE_OK;
+}
+
+void mi_multi_cache_free(MiMultiCache *cache)
+{
+    if (cache && cache->d_tab) (void)hipFree(cache->d_tab);
+    if (cache) { cache->d_tab = nullptr; cache->cap = 0; cache->built_for.clear(); }
 }
 
 int mi_turbo_bcjr_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_pdsch_alloc *d_allocs, const uint32_t *d_cb_alloc, const int8_t *d_e,

@@ -216,6 +216,8 @@ def load_library():
     L.mi_lte_turbo_early_exit_iterations.argtypes = [vp, vp, u32, C.POINTER(u32), C.POINTER(u32)]
     L.mi_lte_turbo_scratch_bytes.argtypes = [u32, u32]
     L.mi_lte_turbo_scratch_bytes.restype = sz
+    L.mi_lte_tbs.argtypes = [u32, u32]
+    L.mi_lte_tbs.restype = u32
     _LIB = L
     return L
 

@@ -550,3 +550,43 @@ LIBLTE_ERROR_ENUM liblte_phy_pucch_format_1_1a_1b_channel_decode(LIBLTE_PHY_STRU
     if (rc == 0 || rc == 1) *N_out_bits = nb;
     return rc == 0 ? LIBLTE_SUCCESS : LIBLTE_ERROR_INVALID_INPUTS;
 }
+
+// ---- the scheduler-side helpers (SURVEY 8b's "CPU pass-through" functions), own-lifecycle build only: with them a caller's link needs no
+// object of the reference's PHY for anything but transmitting.  Host arithmetic in libmi_lte.so (sched.cc); each is compared with the
+// compiled reference over its whole argument range by `lifecycle_check helpers`.
+#ifdef MI_LTE_SHIM_OWN_LIFECYCLE
+// liblte_phy.h:1210, liblte_phy.cc:6251-6357 -- LTE_fdd_enb_mac.cc (scheduler), LTE_fdd_dl_file_gen
+LIBLTE_ERROR_ENUM liblte_phy_get_tbs_mcs_and_n_prb_for_dl(uint32 N_bits, uint32 N_subframe, uint32 N_rb_dl, uint16 rnti, uint32 *tbs, uint8 *mcs, uint32 *N_prb)
+{
+    return (LIBLTE_ERROR_ENUM)mi_lte_get_tbs_mcs_and_n_prb_for_dl(N_bits, N_subframe, N_rb_dl, rnti, tbs, mcs, N_prb);
+}
+// liblte_phy.h:1234, liblte_phy.cc:6359-6407
+LIBLTE_ERROR_ENUM liblte_phy_get_tbs_and_n_prb_for_dl(uint32 N_bits, uint32 N_rb_dl, uint8 mcs, uint32 *tbs, uint32 *N_prb)
+{
+    return (LIBLTE_ERROR_ENUM)mi_lte_get_tbs_and_n_prb_for_dl(N_bits, N_rb_dl, mcs, tbs, N_prb);
+}
+// liblte_phy.h:1253, liblte_phy.cc:6409-6475
+LIBLTE_ERROR_ENUM liblte_phy_get_tbs_mcs_and_n_prb_for_ul(uint32 N_bits, uint32 N_rb_ul, uint32 *tbs, uint8 *mcs, uint32 *N_prb)
+{
+    return (LIBLTE_ERROR_ENUM)mi_lte_get_tbs_mcs_and_n_prb_for_ul(N_bits, N_rb_ul, tbs, mcs, N_prb);
+}
+// liblte_phy.h:1271, liblte_phy.cc:6477-6505 (no argument checks there either; called under the MAC's sys_info_sem, LTE_fdd_enb_phy.cc:357-369: reads two fields)
+LIBLTE_ERROR_ENUM liblte_phy_get_n_cce(LIBLTE_PHY_STRUCT *phy_struct, float phich_res, uint32 N_pdcch_symbs, uint8 N_ant, uint32 *N_cce)
+{
+    (void)phich_res;
+    *N_cce = mi_lte_get_n_cce(phy_struct->N_rb_dl, phy_struct->N_group_phich, N_pdcch_symbs, N_ant);
+    return LIBLTE_SUCCESS;
+}
+// liblte_phy.h:830, liblte_phy.cc:3183-3217
+void liblte_phy_pucch_map_sr_config_idx(uint32 i_sr, uint32 *sr_periodicity, uint32 *N_offset_sr) { mi_lte_pucch_map_sr_config_idx(i_sr, sr_periodicity, N_offset_sr); }
+// liblte_phy.h:1337, liblte_phy.cc:9753-9865
+void liblte_phy_code_block_segmentation(uint8 *b_bits, uint32 N_b_bits, uint32 *N_codeblocks, uint32 *N_filler_bits, uint8 *c_bits, uint32 N_c_bits_max, uint32 *N_c_bits)
+{
+    mi_lte_code_block_segmentation(b_bits, N_b_bits, N_codeblocks, N_filler_bits, c_bits, N_c_bits_max, N_c_bits);
+}
+// liblte_phy.h:1357, liblte_phy.cc:9875-9987
+void liblte_phy_code_block_desegmentation(uint8 *c_bits, uint32 *N_c_bits, uint32 N_c_bits_max, uint32 tbs, uint8 *b_bits, uint32 N_b_bits)
+{
+    mi_lte_code_block_desegmentation(c_bits, N_c_bits, N_c_bits_max, tbs, b_bits, N_b_bits);
+}
+#endif

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fcntl.h>
 
 #include "liblte_phy.h"
 
@@ -81,6 +82,106 @@ static int pucch_check()
     return bad ? 1 : 0;
 }
 
+// `lifecycle_check helpers` (CPU only): the seven scheduler-side helpers the own-lifecycle build defines (sched.cc behind the shim) against the
+// reference's, linked here under the names *_cpu -- over their whole argument ranges, the outputs pre-set to the same sentinel on both sides
+// so that "left untouched" is compared too.
+LIBLTE_ERROR_ENUM liblte_phy_get_tbs_mcs_and_n_prb_for_dl_cpu(uint32 N_bits, uint32 N_subframe, uint32 N_rb_dl, uint16 rnti, uint32 *tbs, uint8 *mcs, uint32 *N_prb);
+LIBLTE_ERROR_ENUM liblte_phy_get_tbs_and_n_prb_for_dl_cpu(uint32 N_bits, uint32 N_rb_dl, uint8 mcs, uint32 *tbs, uint32 *N_prb);
+LIBLTE_ERROR_ENUM liblte_phy_get_tbs_mcs_and_n_prb_for_ul_cpu(uint32 N_bits, uint32 N_rb_ul, uint32 *tbs, uint8 *mcs, uint32 *N_prb);
+LIBLTE_ERROR_ENUM liblte_phy_get_n_cce_cpu(LIBLTE_PHY_STRUCT *phy_struct, float phich_res, uint32 N_pdcch_symbs, uint8 N_ant, uint32 *N_cce);
+void liblte_phy_pucch_map_sr_config_idx_cpu(uint32 i_sr, uint32 *sr_periodicity, uint32 *N_offset_sr);
+void liblte_phy_code_block_segmentation_cpu(uint8 *b_bits, uint32 N_b_bits, uint32 *N_codeblocks, uint32 *N_filler_bits, uint8 *c_bits, uint32 N_c_bits_max, uint32 *N_c_bits);
+void liblte_phy_code_block_desegmentation_cpu(uint8 *c_bits, uint32 *N_c_bits, uint32 N_c_bits_max, uint32 tbs, uint8 *b_bits, uint32 N_b_bits);
+
+#include <unistd.h>
+static int helpers_check()
+{
+    static const uint32 bws[6] = {6, 15, 25, 50, 75, 100};
+    long n = 0, bad = 0;
+#define CHECK(cond, ...) do { n++; if (!(cond)) { if (bad < 20) { printf("  " __VA_ARGS__); printf("\n"); } bad++; } } while (0)
+    // DL grant sizes: every message size up to past the table's largest entry for user RNTIs; the broadcast RNTIs (their search reads the
+    // N_PRB = 3 column only, largest entry 2216) for every subframe number
+    static const uint16 user[3] = {0x003D, 0x1234, 0xFFF3}, bcast[4] = {0xFFFF, 0xFFFE, 0x0001, 0x003C};
+    for (int b = 0; b < 6; b++) {
+        for (int r = 0; r < 3; r++)
+            for (uint32 bits = 0; bits <= 76000; bits += (bits < 9000 ? 1 : 7)) {
+                uint32 t1 = 0xAAAA, t2 = 0xAAAA, p1 = 0xBBBB, p2 = 0xBBBB; uint8 m1 = 0xCC, m2 = 0xCC;
+                const LIBLTE_ERROR_ENUM e1 = liblte_phy_get_tbs_mcs_and_n_prb_for_dl(bits, 3, bws[b], user[r], &t1, &m1, &p1);
+                const LIBLTE_ERROR_ENUM e2 = liblte_phy_get_tbs_mcs_and_n_prb_for_dl_cpu(bits, 3, bws[b], user[r], &t2, &m2, &p2);
+                CHECK(e1 == e2 && t1 == t2 && m1 == m2 && p1 == p2, "tbs_mcs_n_prb_for_dl(%u, N_rb_dl %u, rnti %x): %d %u %u %u vs %d %u %u %u", bits, bws[b], user[r], e1, t1, m1, p1, e2, t2, m2, p2);
+            }
+        for (int r = 0; r < 4; r++)
+            for (uint32 sf = 0; sf < 10; sf++)
+                for (uint32 bits = 0; bits <= 2400; bits++) {
+                    uint32 t1 = 300 + bits % 7, t2 = t1, p1 = 0xBBBB, p2 = 0xBBBB; uint8 m1 = 0xCC, m2 = 0xCC; // (a message past the column's end prices the caller's own *tbs)
+                    const LIBLTE_ERROR_ENUM e1 = liblte_phy_get_tbs_mcs_and_n_prb_for_dl(bits, sf, bws[b], bcast[r], &t1, &m1, &p1);
+                    const LIBLTE_ERROR_ENUM e2 = liblte_phy_get_tbs_mcs_and_n_prb_for_dl_cpu(bits, sf, bws[b], bcast[r], &t2, &m2, &p2);
+                    CHECK(e1 == e2 && t1 == t2 && m1 == m2 && p1 == p2, "tbs_mcs_n_prb_for_dl(%u, sf %u, N_rb_dl %u, rnti %x): %d %u %u %u vs %d %u %u %u", bits, sf, bws[b], bcast[r], e1, t1, m1, p1, e2, t2, m2, p2);
+                }
+        for (uint32 mcs = 0; mcs < 32; mcs++)
+            for (uint32 bits = 0; bits <= 76000; bits += (bits < 9000 ? 1 : 7)) {
+                uint32 t1 = 0xAAAA, t2 = 0xAAAA, p1 = 0xBBBB, p2 = 0xBBBB;
+                const LIBLTE_ERROR_ENUM e1 = liblte_phy_get_tbs_and_n_prb_for_dl(bits, bws[b], (uint8)mcs, &t1, &p1);
+                const LIBLTE_ERROR_ENUM e2 = liblte_phy_get_tbs_and_n_prb_for_dl_cpu(bits, bws[b], (uint8)mcs, &t2, &p2);
+                CHECK(e1 == e2 && t1 == t2 && p1 == p2, "tbs_and_n_prb_for_dl(%u, N_rb_dl %u, mcs %u): %d %u %u vs %d %u %u", bits, bws[b], mcs, e1, t1, p1, e2, t2, p2);
+            }
+        for (uint32 bits = 0; bits <= 9000; bits++) {
+            uint32 t1 = 0xAAAA, t2 = 0xAAAA, p1 = 0xBBBB, p2 = 0xBBBB; uint8 m1 = 0xCC, m2 = 0xCC;
+            const LIBLTE_ERROR_ENUM e1 = liblte_phy_get_tbs_mcs_and_n_prb_for_ul(bits, bws[b], &t1, &m1, &p1);
+            const LIBLTE_ERROR_ENUM e2 = liblte_phy_get_tbs_mcs_and_n_prb_for_ul_cpu(bits, bws[b], &t2, &m2, &p2);
+            CHECK(e1 == e2 && t1 == t2 && m1 == m2 && p1 == p2, "tbs_mcs_n_prb_for_ul(%u): %d %u %u %u vs %d %u %u %u", bits, e1, t1, m1, p1, e2, t2, m2, p2);
+        }
+        // control channel elements: every PHICH group count a cell of this bandwidth can have (N_g = 1/6 .. 2 -> ceil(N_g * N_rb / 8)), and one it cannot
+        static LIBLTE_PHY_STRUCT ps; // (46 MB: static)
+        ps.N_rb_dl = bws[b];
+        for (uint32 g = 0; g <= 26; g++)
+            for (uint32 cfi = 1; cfi <= 4; cfi++)
+                for (uint8 ant = 1; ant <= 4; ant <<= 1) {
+                    ps.N_group_phich = g;
+                    uint32 c1 = 0xAAAA, c2 = 0xAAAA;
+                    const LIBLTE_ERROR_ENUM e1 = liblte_phy_get_n_cce(&ps, 1.0f, cfi, ant, &c1), e2 = liblte_phy_get_n_cce_cpu(&ps, 1.0f, cfi, ant, &c2);
+                    CHECK(e1 == e2 && c1 == c2, "get_n_cce(N_rb_dl %u, groups %u, cfi %u, ports %u): %u vs %u", bws[b], g, cfi, ant, c1, c2);
+                }
+    }
+    for (uint32 i = 0; i < 400; i++) {
+        uint32 a1 = 1, a2 = 1, o1 = 2, o2 = 2;
+        liblte_phy_pucch_map_sr_config_idx(i, &a1, &o1);
+        liblte_phy_pucch_map_sr_config_idx_cpu(i, &a2, &o2);
+        CHECK(a1 == a2 && o1 == o2, "pucch_map_sr_config_idx(%u): %u %u vs %u %u", i, a1, o1, a2, o2);
+    }
+    // segmentation / desegmentation: every transport block length up to one code block, a spread of lengths that need two to five
+    // (there the reference computes each block's CRC over what the caller's buffer holds where the parity goes: the buffers start out equal)
+    {
+        const uint32 MAXC = 6, STRIDE = 6176;
+        static uint8 b[40000], c1[6 * 6176], c2[6 * 6176], d1[40000], d2[40000];
+        uint32 x = 12345;
+        for (uint32 i = 0; i < sizeof b; i++) { x = x * 1103515245u + 12345u; b[i] = (uint8)((x >> 16) & 1u); }
+        fflush(stdout);
+        const int keep = dup(1), nul = open("/dev/null", 1); // the reference's desegmentation prints a line per code block when there are several
+        for (uint32 B = 1; B <= 30000; B += (B <= 6200 ? 1 : 131)) {
+            for (uint32 i = 0; i < MAXC * STRIDE; i++) { x = x * 1103515245u + 12345u; c1[i] = c2[i] = (uint8)((x >> 16) & 1u); }
+            uint32 nc1 = 77, nc2 = 77, f1 = 88, f2 = 88, l1[MAXC], l2[MAXC];
+            for (uint32 i = 0; i < MAXC; i++) l1[i] = l2[i] = 99;
+            liblte_phy_code_block_segmentation(b, B, &nc1, &f1, c1, STRIDE, l1);
+            liblte_phy_code_block_segmentation_cpu(b, B, &nc2, &f2, c2, STRIDE, l2);
+            CHECK(nc1 == nc2 && f1 == f2 && !memcmp(l1, l2, sizeof l1) && !memcmp(c1, c2, sizeof c1), "code_block_segmentation(%u): %u blocks %u filler vs %u %u", B, nc1, f1, nc2, f2);
+            if (B >= 25) { // and back: tbs = B - 24
+                memset(d1, 7, sizeof d1); memset(d2, 7, sizeof d2);
+                dup2(nul, 1);
+                liblte_phy_code_block_desegmentation_cpu(c2, l2, STRIDE, B - 24, d2, B);
+                fflush(stdout);
+                dup2(keep, 1);
+                liblte_phy_code_block_desegmentation(c1, l1, STRIDE, B - 24, d1, B);
+                CHECK(!memcmp(d1, d2, sizeof d1), "code_block_desegmentation(tbs %u)", B - 24);
+            }
+        }
+        close(nul); close(keep);
+    }
+#undef CHECK
+    printf("lifecycle_check helpers: %ld comparisons %s\n", n, bad ? "DIFFER" : "equal");
+    return bad ? 1 : 0;
+}
+
 static int diff(const char *what, const LIBLTE_PHY_STRUCT *a, const LIBLTE_PHY_STRUCT *b, bool with_bw)
 {
     int n = 0;
@@ -95,6 +196,7 @@ static int diff(const char *what, const LIBLTE_PHY_STRUCT *a, const LIBLTE_PHY_S
 int main(int argc, char **argv)
 {
     if (argc > 1 && !strcmp(argv[1], "pucch")) return pucch_check();
+    if (argc > 1 && !strcmp(argv[1], "helpers")) return helpers_check();
     static const LIBLTE_PHY_FS_ENUM fss[5] = {LIBLTE_PHY_FS_1_92MHZ, LIBLTE_PHY_FS_3_84MHZ, LIBLTE_PHY_FS_7_68MHZ, LIBLTE_PHY_FS_15_36MHZ, LIBLTE_PHY_FS_30_72MHZ};
     static const uint32 rbs[8] = {6, 15, 25, 50, 75, 100, 7, 110};
     static const float  res[4] = {1.0f / 6, 0.5f, 1.0f, 2.0f};

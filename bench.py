@@ -1369,6 +1369,73 @@ def traffic_of(tab, label):
     return tab.get(label)
 
 
+KERNEL_FILE = (("k_turbo", "turbo.hip"), ("k_cb_desc", "turbo.hip"), ("k_rm_", "turbo.hip"), ("k_crc_finish", "turbo.hip"), ("k_rate_unmatch", "turbo.hip"),
+               ("k_bcjr", "bcjr.hip"), ("k_pdsch", "chain.hip"), ("k_dl_", "frontend.hip"), ("k_ul_fft", "frontend.hip"), ("k_sync_fft", "frontend.hip"),
+               ("k_pusch", "uplink.hip"), ("k_pucch", "uplink.hip"), ("k_prach", "prach.hip"), ("k_pdcch", "pdcch.hip"), ("k_pbch", "pdcch.hip"),
+               ("k_cp_corr", "sync.hip"), ("k_seq_corr", "sync.hip"), ("k_freq_shift", "sync.hip"), ("k_pss", "sync.hip"), ("k_sss", "sync.hip"))
+
+
+def build_id():
+    import openlte_amd as m
+    return m.load_library().mi_lte_build_id().decode()
+
+
+def table_is_current(kernel, table_id):
+    """Was the committed profiler table (profiles/pmc_traffic_*.json, sq_counters_*.json: "build_id") measured on THIS build of the kernel's
+    source file?  The id is "file.hip:<sha1 of the file><sha1 of the shared headers>;" per file (mi_lte_build_id); a table without an id, or a kernel
+    whose file has changed since, is stale: its number is not reported."""
+    if not table_id:
+        return False
+    f = next((fn for pre, fn in KERNEL_FILE if kernel.startswith(pre)), None)
+    then = dict(x.split(":") for x in table_id.split(";") if x)
+    now = dict(x.split(":") for x in build_id().split(";") if x)
+    return f is not None and f in then and then[f] == now.get(f)
+
+
+def load_table(name):
+    """(table dict or None, its build id)"""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+        return tj, tj.get("build_id")
+    except Exception:
+        return None, None
+
+
+# cycles one SIMD spends per wave64 vector instruction in a stream that mixes the opcode classes -- what every kernel on these paths is
+# (profiles/r04_ubench_issue_mix.txt: alternating fast and slow opcodes run both at 4.1-4.5; profiles/r06_isa_classes.txt: 1-7 % of the
+# kernels' vector instructions sit in runs of fast opcodes long enough to issue at their own 2.2-2.5)
+VALU_CYCLES_PER_INST = 4.3
+N_SIMD = 1024
+
+
+def valu_of(wl_name, ms_per_kernel, step_ms, units_per_step):
+    """The `roofline.valu` object: the vector ALUs' ISSUE time per step from the committed SQ counters of this workload (profiles/
+    sq_counters_<workload>.json: wave64 vector instructions issued per step and kernel, SQ_INSTS_VALU) at the measured issue cost and
+    the clock the same counters give (busy cycles over this run's kernel times).  None when the table is missing or stale for a timed kernel."""
+    tab, tid = load_table("sq_counters_%s.json" % wl_name)
+    if not tab:
+        return None
+    per = tab["per_step"]
+    timed = [k for k in ms_per_kernel if ms_per_kernel[k] > 0]
+    names = {k: ("k_dl_fft2k" if k in ("k_dl_fft", "k_ul_fft", "k_sync_fft") and "k_dl_fft2k" in per else k) for k in timed}
+    if any(names[k] not in per or not table_is_current(k, tid) for k in timed):
+        return {"note": "profiles/sq_counters_%s.json was measured on another build of a timed kernel (or lacks one): no VALU figure" % wl_name}
+    scale = units_per_step / tab["units_per_step"] if tab.get("units_per_step") else 1.0
+    insts = sum(per[names[k]].get("SQ_INSTS_VALU", 0) for k in timed) * scale
+    busy = sum(per[names[k]].get("SQ_BUSY_CYCLES", 0) for k in timed) * scale / 32.0  # (one count per shader engine)
+    kern_ms = sum(ms_per_kernel[k] for k in timed)
+    clock_ghz = busy / (kern_ms * 1e-3) / 1e9 if busy else 2.3
+    issue_ms = insts * VALU_CYCLES_PER_INST / (N_SIMD * clock_ghz * 1e9) * 1e3
+    return {"wave_instructions_per_step": int(insts), "issue_cycles_per_instruction": VALU_CYCLES_PER_INST, "simds": N_SIMD, "clock_GHz": round(clock_ghz, 3),
+            "valu_issue_ms_per_step": round(issue_ms, 3), "valu_issue_frac": round(issue_ms / step_ms, 4),
+            "per_kernel_issue_ms": {k: round(per[names[k]].get("SQ_INSTS_VALU", 0) * scale * VALU_CYCLES_PER_INST / (N_SIMD * clock_ghz * 1e9) * 1e3, 3) for k in timed},
+            "source": "profiles/sq_counters_%s.json (rocprofv3 --pmc SQ_INSTS_VALU, SQ_BUSY_CYCLES; build %s) x %.1f cycles per wave64 instruction "
+                      "(profiles/r04_ubench_issue_rate_run2_wall.txt, r04_ubench_issue_mix.txt, r06_isa_classes.txt)" % (wl_name, "current", VALU_CYCLES_PER_INST),
+            "reading": "share of the step during which every one of the 1024 SIMDs would be issuing vector instructions if the instruction stream were spread evenly: "
+                       "the bound this path runs against (no dense contraction, nothing for the matrix cores); the HBM fractions beside it say how little of the "
+                       "memory system the same step needs"}
+
+
 def measured_copy_rate(ctx):
     """GB/s of the library's copy kernel on ctx's device (1 GiB, 10 launches; once per process and device)."""
     key = id(ctx)
@@ -1393,10 +1460,9 @@ def roofline_of(wl, prof, steps):
     avg_ms = tot_ms / n_launch
     achieved = st_bytes / lps / (avg_ms * 1e-3) / 1e9
     traffic = None
-    try:
-        traffic = traffic_of(json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % wl.name)))["bytes_per_launch"], dom)
-    except Exception:
-        pass
+    tj, tid = load_table("pmc_traffic_%s.json" % wl.name)
+    if tj and table_is_current(dom, tid):
+        traffic = traffic_of(tj["bytes_per_launch"], dom)
     st_ms = sum(prof[k][1] for k in acc["stages"][stage_of[dom]][1] if k in prof) / steps if dom in stage_of else tot_ms / steps
     copy = measured_copy_rate(wl.ctx) if hasattr(wl, "ctx") else None
     alone = None
@@ -1406,7 +1472,11 @@ def roofline_of(wl, prof, steps):
         # kernel's output (round-3 review, item 6).  The dominant kernel's own figure stays beside it.
         alone = {"kernel": dom, "stage_bytes_over_this_kernels_time_GBps": round(achieved, 2), "avg_launch_ms": round(avg_ms, 4)}
         achieved = st_bytes / (st_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": dom if alone is None else "+".join(k for k in acc["stages"][stage_of[dom]][1] if k in prof),
+    step_ms = sum(ms for (nl, ms) in prof.values()) / steps
+    valu = valu_of(wl.name, {k: ms / steps for k, (nl, ms) in prof.items()}, step_ms, wl.units_per_step())
+    whole_frac = wl.alg_bytes_per_unit * wl.units_per_step() / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    return {"bound": "valu" if valu and valu.get("valu_issue_frac", 0) > max(whole_frac, achieved / HBM_PEAK_GBS) else "hbm", "valu": valu,
+            "kernel": dom if alone is None else "+".join(k for k in acc["stages"][stage_of[dom]][1] if k in prof),
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
             "dominant_kernel_alone": alone,
             # SURVEY 8d's second denominator: what a 16-bytes-per-lane copy kernel reaches on THIS device, measured in this run
@@ -1653,7 +1723,7 @@ def main():
         units = wl.units_per_step() * world * args.steps
         print(json.dumps({"metric": wl.metric, "value": round(units * wl.value_per_unit() / elapsed, 3), "unit": wl.unit, "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic", "config": wl.config(world), "kernel_events": False}))
+                          "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic", "config": wl.config(world), "kernel_events": False, "build_id": build_id()}))
     elif rank == 0:
         steps = args.steps
         units = wl.units_per_step() * world * steps
@@ -1661,12 +1731,11 @@ def main():
         acc = wl.accounting()
         ms_step = {k: ms / steps for k, (nl, ms) in prof.items()}
         stage_of = {k: st for st, (_, ks) in acc["stages"].items() for k in ks}
-        traffic_tab = {}
-        try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command (tools/profile_bench.sh)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s%s.json" % (wl.name, "_bcjr" if DECODER.startswith("bcjr") else ""))))
-            traffic_tab = tj["bytes_per_launch"]
-        except Exception:
-            pass
+        # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command (tools/profile_bench.sh) -- only for kernels whose
+        # source file is the one the table was measured on (mi_lte_build_id): an edited kernel without a re-profile reports no traffic
+        tj, tid = load_table("pmc_traffic_%s%s.json" % (wl.name, "_bcjr" if DECODER.startswith("bcjr") else ""))
+        traffic_tab = {k: v for k, v in (tj["bytes_per_launch"] if tj else {}).items() if table_is_current(k, tid)}
+        stale_tables = sorted(k for k in (tj["bytes_per_launch"] if tj else {}) if not table_is_current(k, tid))
         copy_rate = measured_copy_rate(ctx)  # (the timed region is over)
         per_kernel = {}
         for k, (nl, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
@@ -1708,13 +1777,17 @@ def main():
             achieved = st_bytes / (st_ms * 1e-3) / 1e9
         tr = traffic_of(traffic_tab, dom)
         whole = wl.alg_bytes_per_unit * units / elapsed / 1e9
+        valu = valu_of(wl.name + ("_bcjr" if DECODER.startswith("bcjr") else ""), ms_step, elapsed / steps * 1e3, wl.units_per_step())
         out = {
             "metric": wl.metric, "value": round(value, 3), "unit": wl.unit, "n_gpus": world, "steps": steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
             "config": wl.config(world),
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": tr, "dominant_kernel_alone": dom_alone,
+            "roofline": {"bound": "valu" if valu and valu.get("valu_issue_frac", 0) > max(whole / HBM_PEAK_GBS, achieved / HBM_PEAK_GBS) else "hbm",
+                         "bound_note": "the larger of the two fractions: `frac` / `stage_frac` / `chain_frac` price SURVEY 8d's algorithmic bytes against the 8 TB/s of HBM3E, "
+                                       "`valu.valu_issue_frac` prices the vector instructions the step issues against the SIMDs' measured issue rate",
+                         "valu": valu, "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": tr, "traffic_tables_stale_for": stale_tables or None, "dominant_kernel_alone": dom_alone,
                          # SURVEY 8d's second denominator: a 16-bytes-per-lane copy kernel on THIS device, measured after the timed region
                          "measured_copy_GBps": copy_rate, "frac_of_measured_copy": round(achieved / copy_rate, 5) if copy_rate else None,
                          "measured_copy_shapes_GBps": dict(zip(("one_access_per_thread", "one_access_per_thread_non_temporal", "grid_stride_loop"), _COPY_RATE.get("shapes", ()))),
@@ -1733,7 +1806,7 @@ def main():
             "stages": stages,
             "kernels": per_kernel,
             "whole_chain_alg_GBps": round(whole, 2), "whole_chain_frac_of_peak": round(whole / HBM_PEAK_GBS, 5),
-            "device": ctx.device_name, "devices": devices,
+            "device": ctx.device_name, "devices": devices, "build_id": build_id(),
         }
         if hasattr(wl, "extra"):
             out.update(wl.extra(value))

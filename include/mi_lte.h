@@ -51,6 +51,10 @@ typedef struct mi_lte_ctx mi_lte_ctx; /* opaque */
 
 /* ---------------------------------------------------------------- context, memory, timing */
 int         mi_lte_version(void);
+/* identity of the device code this library was built from: "file.hip:hhhhhhhhHHHHHHHH;" per kernel source (sha1 of the file, sha1 of the
+ * shared headers, eight hex digits each).  The committed profiler tables (profiles/pmc_traffic_*.json, sq_counters_*.json) carry the id of
+ * the build they were measured on; bench.py reports their numbers only for kernels whose file has not changed since. */
+const char *mi_lte_build_id(void);
 int         mi_lte_device_count(void);
 int         mi_lte_ctx_create(int device, mi_lte_ctx **out);
 void        mi_lte_ctx_destroy(mi_lte_ctx *ctx);

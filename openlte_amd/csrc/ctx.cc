@@ -7,6 +7,7 @@
 #include <algorithm>
 
 #include "ctx.hpp"
+#include "build_id.h"
 
 #include <cstring>
 
@@ -15,6 +16,7 @@
 extern "C" {
 
 int mi_lte_version(void) { return MI_LTE_VERSION; }
+const char *mi_lte_build_id(void) { return MI_LTE_BUILD_ID; }
 
 int mi_lte_device_count(void)
 {

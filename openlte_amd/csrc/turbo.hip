@@ -172,6 +172,16 @@ __device__ __forceinline__ size_t unit_off(size_t tile_off, uint32_t lane, uint3
 // 16 uint16 table entries starting at index 16u (nvalid = 16 or 8); the entries past nvalid read `pad`
 // (callers pass the index of a slot that holds 0, so that nothing downstream needs a per-element predicate
 // -- predicated LDS reads compile to one branch + one waitcnt each)
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(4))) const u32x4_t const_u32x4_t; // sixteen bytes of a table that no kernel writes, read through the constant address space
+__device__ __forceinline__ void load_idx16_at(const_u32x4_t *p /* the unit's first sixteen bytes */, int nvalid, uint32_t (&idx)[16], uint32_t pad)
+{
+    const uint32_t pp = pad | (pad << 16);
+    const u32x4_t  lo = p[0], hi = (nvalid > 8) ? p[1] : (u32x4_t)(pp);
+    const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (int k = 0; k < 16; k++) idx[k] = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+}
 __device__ __forceinline__ void load_idx16(const uint16_t *tab, uint32_t u, int nvalid, uint32_t (&idx)[16], uint32_t pad = 0)
 {
     const uint4 *p = reinterpret_cast<const uint4 *>(tab + 16 * (size_t)u);
@@ -349,15 +359,20 @@ struct KSeg {
     uint32_t        e_cap;                     // LDS bytes prep stages an allocation's soft bits in (0: gathers from global memory)
     uint32_t        wv1, wv23;                 // first wavefront of the size in SISO pass 1 / passes 2 + 3
     uint64_t        arr_off;                   // where the size's tiles start in each of the eleven byte arrays (traceback words: half of it)
-    const uint16_t *pi, *inv2, *tabs;          // mi_ctx_turbo_tables / rm_rank_tables of K
-    const uint32_t *nnn;
+    // mi_ctx_turbo_tables / rm_rank_tables of K.  Typed as GLOBAL pointers: a pointer that comes out of memory is otherwise of unknown address
+    // space and every load through it a flat_load, which counts against the LDS counter too -- k_turbo_prep's LDS gathers then waited for its
+    // table loads (W4 as a merged decode: 4.88 ms, 4.53 without them)
+    __attribute__((address_space(1))) const uint16_t *pi, *inv2, *tabs;
+    __attribute__((address_space(1))) const uint32_t *nnn;
     uint64_t        pad[2];
 };
 static_assert(sizeof(KSeg) == 96, "KSeg is read with scalar loads: keep it a multiple of 16 bytes");
 struct MultiArgs { const KSeg *segs; const uint32_t *map; }; // map: per 8 workgroups (prep, perm, vote) or per wavefront (siso) the index of its size
 // Both reads go through the CONSTANT address space: only then are they scalar loads (the kernels store to global memory, and a plain pointer
-// carries no promise that the table is not what they store to).  As vector loads the two dependent round trips to the L2 at the start of
-// every workgroup cost k_turbo_prep 18 % (W4: 4.15 -> 4.90 ms); the scalar cache serves the row every workgroup of a CU reads.
+// carries no promise that the table is not what they store to); the scalar cache serves the row every workgroup of a CU reads.
+// What remains: on W4 (two sizes of 8192 and 1024 tiles, each filling the device by itself) the merged k_turbo_prep takes 4.5-4.6 ms
+// against the per-size launches' 4.15 with identical registers, LDS and grid -- not found in the listings; a size that large keeps its own
+// launches (chain.hip), and the merged path is for what it was written for, many sizes of a few tiles each.
 typedef __attribute__((address_space(4))) const KSeg     const_seg_t;
 typedef __attribute__((address_space(4))) const uint32_t const_map_t;
 __device__ __forceinline__ const_seg_t &multi_seg(const MultiArgs &ma, uint32_t slot)
@@ -366,12 +381,6 @@ __device__ __forceinline__ const_seg_t &multi_seg(const MultiArgs &ma, uint32_t 
     return reinterpret_cast<const_seg_t *>(reinterpret_cast<uintptr_t>(ma.segs))[idx];
 }
 
-// What a workgroup reads from its row is uniform, but the compiler does not take it for that (the row's index went through memory): it
-// kept K, the tile offsets and everything derived from them in vector registers -- k_turbo_perm<MULTI> at 99 VGPRs and 4 waves per SIMD
-// where the per-size kernel has 63 and 8.  v_readfirstlane states it.
-__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ uint64_t uni(uint64_t v) { return (uint64_t)uni((uint32_t)(v >> 32)) << 32 | uni((uint32_t)v); }
-template <typename T> __device__ __forceinline__ T *uni(T *p) { return reinterpret_cast<T *>(uni((uint64_t)reinterpret_cast<uintptr_t>(p))); }
 
 struct SrcRateUnmatch {
     static constexpr bool kIntegerValued = true; // sums of int8 soft bits
@@ -385,8 +394,10 @@ struct SrcRateUnmatch {
     __device__ __forceinline__ void seg(const_seg_fwd_t &sg); // merged launch: the size's tables and descriptors (defined below KSeg)
     __device__ __forceinline__ void init(uint32_t cb, uint32_t K)
     {
-        const uint4 *dp = reinterpret_cast<const uint4 *>(g.desc + cb);
-        const uint4  d0 = dp[0], d1 = dp[1]; // alloc e_off E combo | Nnn hard tbs -
+        // (through the constant address space: written by the launch before this one, uniform -> scalar loads, also where the pointer itself
+        // came out of a merged decode's table and the compiler no longer sees a kernel argument behind it)
+        const_u32x4_t *dp = reinterpret_cast<const_u32x4_t *>(reinterpret_cast<uintptr_t>(g.desc + cb));
+        const u32x4_t  d0 = dp[0], d1 = dp[1]; // alloc e_off E combo | Nnn hard tbs -
         tab = tabs + (size_t)d0.w * 3 * K;
         Nnn = d1.x;
         K_  = K;
@@ -429,15 +440,29 @@ struct SrcRateUnmatch {
     // block end) included -- three operations per element and lap, no predicate
     // (emit(x, acc) receives the 16 sums of stream x; it is called stream by stream so that a caller that packs them keeps only one
     // stream unpacked at a time)
-    template <typename Emit> __device__ __forceinline__ void gather16_staged(uint32_t el /* LDS address of the staged copy */, uint32_t u, int nvalid, Emit emit) const
+    // the rank words of a unit's three streams (16 ranks of 16 bits each; 0xFFFF = NULL or past the block end)
+    struct RankWords { uint4 raw[3][2]; };
+    __device__ __forceinline__ void load_ranks(uint32_t u, int nvalid, RankWords &rw) const
     {
-        uint4 raw[3][2];
 #pragma unroll
         for (int x = 0; x < 3; x++) {
-            const uint4 *p = reinterpret_cast<const uint4 *>(tab + (size_t)x * K_ + 16 * (size_t)u);
-            raw[x][0] = p[0];
-            raw[x][1] = (nvalid > 8) ? p[1] : make_uint4(~0u, ~0u, ~0u, ~0u);
+            rw.raw[x][0] = rw.raw[x][1] = make_uint4(~0u, ~0u, ~0u, ~0u);
+            if (nvalid > 0) {
+                const uint4 *p = reinterpret_cast<const uint4 *>(tab + (size_t)x * K_ + 16 * (size_t)u);
+                rw.raw[x][0] = p[0];
+                if (nvalid > 8) rw.raw[x][1] = p[1];
+            }
         }
+    }
+    template <typename Emit> __device__ __forceinline__ void gather16_staged(uint32_t el /* LDS address of the staged copy */, uint32_t u, int nvalid, Emit emit) const
+    {
+        RankWords rw;
+        load_ranks(u, nvalid, rw);
+        gather16_staged(el, rw, emit);
+    }
+    template <typename Emit> __device__ __forceinline__ void gather16_staged(uint32_t el, const RankWords &rw, Emit emit) const
+    {
+        const uint4 (&raw)[3][2] = rw.raw;
 #pragma unroll
         for (int x = 0; x < 3; x++) {
             const uint32_t w[8] = {raw[x][0].x, raw[x][0].y, raw[x][0].z, raw[x][0].w, raw[x][1].x, raw[x][1].y, raw[x][1].z, raw[x][1].w};
@@ -469,13 +494,9 @@ struct SrcRateUnmatch {
     template <typename P, typename Emit> __device__ __forceinline__ void gather16(P ep, uint32_t u, int nvalid, Emit emit) const
     {
         // the rank words of all three streams are requested before the first is used: one L2 round trip instead of three
-        uint4 raw[3][2];
-#pragma unroll
-        for (int x = 0; x < 3; x++) {
-            const uint4 *p = reinterpret_cast<const uint4 *>(tab + (size_t)x * K_ + 16 * (size_t)u);
-            raw[x][0] = p[0];
-            raw[x][1] = (nvalid > 8) ? p[1] : make_uint4(0, 0, 0, 0);
-        }
+        RankWords rw;
+        load_ranks(u, nvalid, rw); // (a missing upper half reads 0xFFFF: never filled, like the positions past nvalid)
+        const uint4 (&raw)[3][2] = rw.raw;
 #pragma unroll
         for (int x = 0; x < 3; x++) {
             uint32_t r[16];
@@ -529,7 +550,7 @@ struct SrcRateUnmatch {
 // chosen by the host when no sum can leave int16: ceil(E / Nnn) laps of |e| <= 127 each
 __device__ __forceinline__ void SrcRateUnmatch::seg(const_seg_fwd_t &sg)
 {
-    tabs = uni(sg.tabs); nnn = uni(sg.nnn); g.desc += uni(sg.cb_base);
+    tabs = (const uint16_t *)sg.tabs; nnn = (const uint32_t *)sg.nnn; g.desc += sg.cb_base;
 }
 struct SrcRateUnmatchPk : SrcRateUnmatch { static constexpr bool kPacked = true; };
 
@@ -590,8 +611,8 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Src::kPacke
     const uint16_t *__restrict__ pi = pi_arg;
     if constexpr (MULTI) { // the workgroup's block size out of a merged launch (KSeg)
         const_seg_t &sg = multi_seg(ma, blockIdx.x >> 3);
-        K = uni(sg.K); n_cb = uni(sg.n_cb); pi = uni(sg.pi); bidx = blockIdx.x - uni(sg.wg_cb); seg_off = uni(sg.arr_off);
-        src.e_cap = uni(sg.e_cap);
+        K = sg.K; n_cb = sg.n_cb; pi = (const uint16_t *)sg.pi; bidx = blockIdx.x - sg.wg_cb; seg_off = sg.arr_off;
+        src.e_cap = sg.e_cap;
         src.seg(sg);
     }
     // qtab | mtab1 | mtab2 | staged e [e_cap] | q(d0)[Kp] | reduction scratch (64 B).  No static LDS next to it: the dynamic block then
@@ -612,9 +633,12 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Src::kPacke
     float         *red_f  = reinterpret_cast<float *>(q0_lds + Kp);
     int           *red_i  = reinterpret_cast<int *>(q0_lds + Kp);
     src.init(cb, K);
-    const bool     e_in_lds = src.stage_e(e_lds);
     const uint32_t u  = threadIdx.x;
     const int      nv = (u < n_units) ? min(16, max(0, (int)K - 16 * (int)u)) : -1; // 16, 8 (last unit of a K % 16 == 8 block), 0 (padding), -1
+    // (Tried in round 6: the rank words of the gather requested HERE, before the soft bits are staged, so that the table's round trip runs
+    // under the copy's.  The 24 registers they occupy across the copy do not fit next to the gather's own peak: 100 bytes of scratch per
+    // lane, and the kernel went from 4.15 to 7.84 ms on W4 -- gpurun_out/hoist1.log.  The kernel is at its register limit for 6 waves.)
+    const bool     e_in_lds = src.stage_e(e_lds);
 
     typedef typename std::conditional<Src::kIntPath, int, float>::type val_t;
     val_t    v[Src::kPacked ? 1 : 3][16]; // the sums of the three streams ...
@@ -741,7 +765,14 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Src::kPacke
     uint4 I0 = make_uint4(0, 0, 0, 0);
     if (nv > 0) {
         uint32_t idx[16];
-        load_idx16(pi, u, nv, idx, K); // past the block end: slot K, which holds q = 0 whenever K % 16 == 8
+        // past the block end: slot K, which holds q = 0 whenever K % 16 == 8.
+        // Merged launch: the table's address came out of memory, not out of a __restrict__ kernel argument, and with that the promise that
+        // nothing the kernel stores to is the table; read through the constant address space the promise is back (no measurable effect:
+        // the per-size kernel requests the indices behind the barrier too).
+        if constexpr (MULTI)
+            load_idx16_at(reinterpret_cast<const_u32x4_t *>(reinterpret_cast<uintptr_t>(pi + 16 * (size_t)u)), nv, idx, K);
+        else
+            load_idx16(pi, u, nv, idx, K);
         I0 = gather16_bytes(PREP_TAB_BYTES + src.e_cap, idx);
     }
     if (nv >= 0) *reinterpret_cast<uint4 *>(out.arr[3] + unit_off(tile_off, lane, u)) = I0;
@@ -917,8 +948,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SISO_WPE, 8
     if constexpr (MULTI) {
         if (wv >= n_tiles_arg) return; // wavefront-uniform
         const_seg_t &sg = multi_seg(ma, wv);
-        K = uni(sg.K); n_tiles = uni(sg.n_tiles); seg_off = uni(sg.arr_off);
-        wv -= uni(mode ? sg.wv23 : sg.wv1);
+        K = sg.K; n_tiles = sg.n_tiles; seg_off = sg.arr_off;
+        wv -= mode ? sg.wv23 : sg.wv1;
         n_wv = mode ? n_tiles : (n_tiles + 1) / 2;
     }
     const uint32_t Kp = kpad64(K), nblk = Kp >> 6;
@@ -1332,8 +1363,8 @@ __global__ __launch_bounds__(384) void k_turbo_perm(PermArgs a, uint32_t K_arg, 
     const uint16_t *__restrict__ pi = pi_arg;
     if constexpr (MULTI) { // the workgroup's block size out of a merged launch (KSeg)
         const_seg_t &sg = multi_seg(ma, blockIdx.x >> 3);
-        K = uni(sg.K); n_cb = uni(sg.n_cb); pi = uni(sg.pi); bidx = blockIdx.x - uni(sg.wg_perm); grid = uni(sg.perm_grid);
-        seg_off = uni(sg.arr_off);
+        K = sg.K; n_cb = sg.n_cb; pi = (const uint16_t *)sg.pi; bidx = blockIdx.x - sg.wg_perm; grid = sg.perm_grid;
+        seg_off = sg.arr_off;
     }
     extern __shared__ __attribute__((aligned(16))) int8_t smp[]; // mtab[256] | C1[Kp] | reduction scratch (32 B); no static LDS (see k_turbo_prep)
     int8_t *mtab = smp, *sm = smp + MTAB_N;
@@ -1427,8 +1458,8 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     const uint16_t *__restrict__ inv = inv_arg;
     if constexpr (MULTI) { // the workgroup's block size out of a merged launch (KSeg)
         const_seg_t &sg = multi_seg(ma, blockIdx.x >> 3);
-        K = uni(sg.K); n_cb = uni(sg.n_cb); inv = uni(sg.inv2); bidx = blockIdx.x - uni(sg.wg_cb); seg_off = uni(sg.arr_off);
-        g.desc += uni(sg.cb_base);
+        K = sg.K; n_cb = sg.n_cb; inv = (const uint16_t *)sg.inv2; bidx = blockIdx.x - sg.wg_cb; seg_off = sg.arr_off;
+        g.desc += sg.cb_base;
     }
     extern __shared__ __attribute__((aligned(16))) int8_t sm[]; // D12[Kp + 16] (int16: D1 + D2, a zero slot at Kp) | bits[Kp] | reduction scratch (32 B); no static LDS
     const uint32_t cb = xcd_cb(bidx, n_cb), tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4;
@@ -2043,7 +2074,9 @@ int mi_turbo_ref_multi(mi_lte_ctx *ctx, const MiKGroup *groups, uint32_t n_group
             sg.K = gr.K; sg.n_cb = gr.n_cb; sg.cb_base = gr.cb_base; sg.n_tiles = (gr.n_cb + 63) / 64;
             sg.e_cap = (PREP_TAB_BYTES + Kp + cap + 64 <= 48 * 1024) ? cap : 0; // stage e in LDS when the group's largest allocation fits next to the block's own arrays
             sg.arr_off = arr;
-            sg.pi = tb.d_pi; sg.inv2 = tb.d_inv2; sg.tabs = rt.d_tabs; sg.nnn = rt.d_nnn;
+            typedef __attribute__((address_space(1))) const uint16_t gl16_t;
+            typedef __attribute__((address_space(1))) const uint32_t gl32_t;
+            sg.pi = (gl16_t *)tb.d_pi; sg.inv2 = (gl16_t *)tb.d_inv2; sg.tabs = (gl16_t *)rt.d_tabs; sg.nnn = (gl32_t *)rt.d_nnn;
             arr += (uint64_t)sg.n_tiles * Kp * 64;
             cbs = std::max(cbs, gr.cb_base + gr.n_cb);
             const int c = cls_of(gr.K);

@@ -109,6 +109,7 @@ def load_library():
     vp, u32, sz = C.c_void_p, C.c_uint32, C.c_size_t
     L.mi_lte_version.restype = C.c_int
     L.mi_lte_device_count.restype = C.c_int
+    L.mi_lte_build_id.restype = C.c_char_p
     L.mi_lte_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.mi_lte_ctx_destroy.argtypes = [vp]
     L.mi_lte_last_error.argtypes = [vp]

@@ -74,7 +74,14 @@ def main(src, tag, workload="chain"):
         t[0] += r["launches"]
         t[1] += r["launches"] * (r["fetch_bytes_x2"] + r["write_bytes"])
     with open(os.path.join(dst, "pmc_traffic_%s.json" % workload), "w") as f:
-        json.dump({"source": tag, "workload": workload, "note": "avg (2*FETCH_SIZE + WRITE_SIZE) bytes per launch, rocprofv3 --pmc passes of bench.py",
+        bid = None
+        try:  # the bench line of the profiled run names the build the numbers belong to (mi_lte_build_id)
+            for l in open(os.path.join(src, "bench_trace.json")):
+                if l.startswith("{"):
+                    bid = json.loads(l).get("build_id")
+        except OSError:
+            pass
+        json.dump({"source": tag, "workload": workload, "build_id": bid, "note": "avg (2*FETCH_SIZE + WRITE_SIZE) bytes per launch, rocprofv3 --pmc passes of bench.py",
                    "bytes_per_launch": {k: int(v[1] / v[0]) for k, v in traffic.items()}}, f, indent=1)
     with open(os.path.join(dst, tag + "_summary.json"), "w") as f:
         json.dump({"kernel_stats": stats, "per_launch": rows}, f, indent=1)

@@ -248,6 +248,10 @@ int mi_lte_turbo_early_exit_iterations(mi_lte_ctx *ctx, uint32_t *h_pair_iters, 
  * trellis, the traceback as a parallel composition of state maps): a third of the latency when one transport block is all there is, which
  * is what a per-call caller (the shim) has.  Default 4096; 0 = always the lock-step kernel.  A tuning / test knob, not a semantic one. */
 int mi_lte_set_turbo_small_batch(mi_lte_ctx *ctx, uint32_t n_cb_max);
+/* A PDSCH / PUSCH decode whose allocations have several code-block sizes launches each of its kernels ONCE over the blocks of all sizes
+ * (the per-code-block kernels once per workgroup width) instead of size by size; on = 0 keeps the per-size launches.  Identical results
+ * (tests/test_mixed_gpu.py); a test / tuning knob like the one above.  Default on. */
+int mi_lte_set_turbo_merged(mi_lte_ctx *ctx, uint32_t on);
 
 /* ---------------------------------------------------------------- turbo rate un-matching
  * Replaces liblte_phy_rate_unmatch_turbo() (liblte/hdr/liblte_phy.h:1311-1323, implementation
@@ -535,6 +539,21 @@ int mi_lte_dl_subframe_decode_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t 
                                    uint32_t phich_dur_extended, uint32_t flags, uint32_t *cfi, uint32_t *N_symbs, uint32_t *N_dci,
                                    mi_lte_pdcch_dci *dci /* [MI_LTE_PDCCH_MAX_DCI] */, uint8_t *h_out_bits, uint32_t out_stride,
                                    uint32_t *N_out_bits /* [MI_LTE_PDCCH_MAX_DCI] */, int32_t *status /* [MI_LTE_PDCCH_MAX_DCI] */);
+/* One UPLINK subframe in one call: the work of liblte_phy_get_ul_subframe (liblte_phy.h:1190-1193, liblte_phy.cc:6209-6236) +
+ * liblte_phy_pucch_format_1_1a_1b_channel_decode per resource (liblte_phy.h:775-782, liblte_phy.cc:2961-3146) +
+ * liblte_phy_pusch_channel_decode per scheduled UE (liblte_phy.h:722-728, liblte_phy.cc:2801-2935) -- the eNodeB radio thread's receive
+ * half of a TTI (LTE_fdd_enb_phy.cc:832-917) -- as one launch chain with one wait; the received grid stays in HBM.  h_i / h_q: the
+ * subframe's 30720 / (2048 / fft_size) samples; ul: what liblte_phy_ul_init was given (the reference signals are generated from it);
+ * allocs[k] (k < n_alloc <= MI_LTE_UL_SUBFRAME_MAX_ALLOC) is decoded into h_out_bits + k * out_stride (out_stride >= 6120) with
+ * status[k] = 0 and N_out_bits[k] = tbs, or status[k] = 1 (the reference's failure value on this path: CRC mismatch, or an allocation it
+ * has no transform plan for) and nothing written; pucch[r] (unit 0) with h_pucch_tables as for mi_lte_pucch_decode_run.  Returns 0,
+ * 1 (invalid arguments, the reference's value) or MI_LTE_* < 0. */
+#define MI_LTE_UL_SUBFRAME_MAX_ALLOC 16
+int mi_lte_ul_subframe_decode_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_ul, const float *h_i_samps, const float *h_q_samps,
+                                   uint32_t subfr_num, uint32_t N_id_cell, const mi_lte_ul_cfg *ul, const mi_lte_pdsch_alloc *allocs,
+                                   uint32_t n_alloc, uint8_t *h_out_bits, uint32_t out_stride, uint32_t *N_out_bits, int32_t *status,
+                                   const mi_lte_pucch_res *pucch, const float *h_pucch_tables, uint32_t n_pucch, uint8_t *h_pucch_bits /*[n_pucch][2]*/,
+                                   uint32_t *h_pucch_n_bits, uint32_t *h_pucch_rc);
 int mi_lte_get_dl_subframe_and_ce_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_dl, const float *h_i_samps,
                                        const float *h_q_samps, uint32_t frame_start_idx, uint32_t subfr_num,
                                        uint32_t N_id_cell, uint32_t N_ant, float *h_rx_symb_re /*[16][1200]*/,

@@ -746,12 +746,12 @@ int mi_lte_pdsch_decode_run(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, const float 
     // Opt-in (MI_LTE_GROUP_STREAMS=1): worth 1 % of the W4 step (24.77 -> 24.55 ms), and it stretches the launches that overlap -- the
     // per-launch times the roofline accounting of bench.py and the rocprof summaries are built on stop describing a kernel alone.
     static const bool side_ok = [] { const char *e = getenv("MI_LTE_GROUP_STREAMS"); return e && atoi(e) != 0; }();
-    // A batch with several block sizes and more code blocks than the state-parallel kernel is for: ONE launch set over all sizes
+    // A decode with several block sizes -- a batch, or a per-call caller's subframe with a handful of transport blocks: ONE launch set over all sizes
     // (turbo.hip: KSeg).  A cell's TTIs hold dozens of the 188 sizes; size by size that is ~7 launches per size in series, each a sliver
     // of the device -- 65 536 mixed subframes took 72.6 ms that way, 48.8 of them in the decoder (profiles/r06_chain_mixed_per_size.json).
     // MI_LTE_NO_MERGED_DECODE=1 keeps the per-size launches (A/B).
     static const bool merged_off = [] { const char *e = getenv("MI_LTE_NO_MERGED_DECODE"); return e && atoi(e) != 0; }();
-    if (!bcjr && !merged_off && !side_ok && pl->groups.size() >= 2 && total_cb > ctx->siso_small_max) {
+    if (!bcjr && !merged_off && ctx->merged_decode && !side_ok && pl->groups.size() >= 2) {
         // A size with 4096 tiles or more (64 blocks each: one lane of every wavefront the device holds at the trellis kernel's four per SIMD)
         // fills the device by itself and keeps its own launches: merged, W4's two sizes ran 24.2-24.7 ms against 24.0-24.35 per size
         // (gpurun_out/w4_merged.json, w4_persize.json; the difference is k_turbo_prep, see KSeg).  MI_LTE_MERGE_MAX_TILES=n moves the limit (tuning aid).

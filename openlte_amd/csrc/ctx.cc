@@ -86,6 +86,13 @@ int mi_lte_set_turbo_small_batch(mi_lte_ctx *ctx, uint32_t n_cb_max)
     return MI_LTE_OK;
 }
 
+int mi_lte_set_turbo_merged(mi_lte_ctx *ctx, uint32_t on)
+{
+    if (!ctx) return MI_LTE_ERR_INVALID_ARG;
+    ctx->merged_decode = on != 0;
+    return MI_LTE_OK;
+}
+
 const char *mi_lte_last_error(const mi_lte_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 const char *mi_lte_device_name(const mi_lte_ctx *ctx) { return ctx ? ctx->dev_name.c_str() : ""; }
 void       *mi_lte_stream(const mi_lte_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }

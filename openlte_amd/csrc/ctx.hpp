@@ -55,6 +55,7 @@ struct mi_lte_ctx {
     struct { uint32_t *chg; uint32_t n_pairs, n_iter, n_cb; } bcjr_early = {nullptr, 0, 0, 0}; // the last early-termination decode's change words (bcjr.hip)
     bool               bcjr_block_lds_set = false; // hipFuncSetAttribute(k_bcjr_block, max dynamic LDS) made on this context's device
     uint32_t           siso_small_max = 4096; // code blocks per decode up to which k_turbo_siso_small runs (mi_lte_set_turbo_small_batch)
+    bool               merged_decode = true;  // several block sizes in one decode: one launch set over all of them (mi_lte_set_turbo_merged; turbo.hip: KSeg)
     void              *h_small = nullptr, *d_small = nullptr; // MI_SMALL_BYTES of pinned host memory the kernels can write (mi_ctx_small_results)
     void              *h_bounce = nullptr, *d_bounce = nullptr; // 4 MiB of pinned host memory mapped into the device: mi_lte_memcpy_* move mid-size copies through it with a kernel
     std::map<uint64_t, TurboTables> turbo_tables; // key = K | (spec << 32)
@@ -143,6 +144,7 @@ struct MiMultiGeom { // launch geometry derived from the groups; classes = workg
     uint32_t n_slots = 0, n_wv1 = 0, n_wv23 = 0;
     uint32_t grid_cb[6] = {0}, grid_perm[6] = {0}, lds_prep[6] = {0}, kp_max[6] = {0};
     uint32_t map_cb[6] = {0}, map_perm[6] = {0}, map_wv1 = 0, map_wv23 = 0; // where each launch's map starts (entries)
+    uint32_t map_ws1 = 0, map_ws23 = 0, n_ws1 = 0, n_ws23 = 0, gpw1 = 1, gpw23 = 1, kp_all = 0; // the state-parallel trellis kernel's launches (a handful of blocks)
     size_t   map_off = 0;                             // bytes from the table's start to the maps
 };
 struct MiMultiCache { void *d_tab = nullptr; size_t cap = 0; std::vector<MiKGroup> built_for; MiMultiGeom geom; };
@@ -160,6 +162,11 @@ int   mi_pdsch_plan_create_mapped(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, uin
 int   mi_pdsch_plan_assign_slice(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, uint32_t N_pdcch_symbs, const mi_lte_pdsch_alloc *h_src, uint32_t n_alloc, uint32_t unit0,
                                  std::vector<uint32_t> *refused, hipStream_t copy_stream = nullptr); // chain.hip: the host pipeline's one-pass assignment
 void  mi_pdsch_plan_wide_stride(mi_lte_pdsch_plan *pl); // one output stride whatever the plan holds: that of the largest single-code-block transport block (pipeline.cc)
+constexpr uint32_t MI_PUCCH_STAGED_MAX = 32; // (352 floats of tables each: inside the 64 KB mapped block)
+struct MiPucchStaged { char *h_base = nullptr, *d_base = nullptr; size_t o_tab = 0, o_out = 0; uint32_t n_res = 0; };
+int   mi_pucch_stage(mi_lte_ctx *ctx, uint32_t N_rb_ul, const mi_lte_pucch_res *h_res, const float *h_tables, uint32_t n_res, MiPucchStaged *st); // uplink.hip
+int   mi_pucch_launch(mi_lte_ctx *ctx, const MiPucchStaged *st, uint32_t N_rb_ul, const float *d_subframes);
+void  mi_pucch_collect(const MiPucchStaged *st, uint8_t *h_bits, uint32_t *h_n_bits, uint32_t *h_rc);
 struct mi_lte_pusch_plan;
 int   mi_pusch_plan_create_impl(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, const mi_lte_ul_cfg *ul, const uint32_t *h_unit_subfr_num,
                                 const uint32_t *h_unit_n_id_cell, uint32_t n_units, const mi_lte_pdsch_alloc *h_allocs, uint32_t n_alloc,

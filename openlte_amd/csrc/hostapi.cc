@@ -92,6 +92,7 @@ struct HostCache {
     mi_lte_pdsch_plan *sf_plan = nullptr;
     mi_lte_dl_cfg      sf_cfg  = {0, 0, 0, 0};
     uint8_t           *h_sf_res = nullptr, *d_sf_res = nullptr; // MI_LTE_PDCCH_MAX_DCI verdicts at byte 0, the blocks' bits from byte 64 at the plan's stride
+    uint8_t           *h_ul_res = nullptr, *d_ul_res = nullptr; // mi_lte_ul_subframe_decode_host: MI_LTE_UL_SUBFRAME_MAX_ALLOC verdicts at byte 0, the blocks' bits from byte 256
     PlanCache<mi_lte_pdsch_plan> pdsch{mi_lte_pdsch_plan_destroy, 64};
     PlanCache<mi_lte_pdcch_plan> pdcch{mi_lte_pdcch_plan_destroy, 8};
     PlanCache<mi_lte_pusch_plan> pusch{mi_lte_pusch_plan_destroy, 64};
@@ -106,6 +107,7 @@ void host_cache_free(mi_lte_ctx *ctx)
     hc->pdsch.clear(ctx); hc->pdcch.clear(ctx); hc->pusch.clear(ctx); hc->prach.clear(ctx);
     if (hc->sf_plan) mi_lte_pdsch_plan_destroy(ctx, hc->sf_plan);
     if (hc->h_sf_res) (void)hipHostFree(hc->h_sf_res);
+    if (hc->h_ul_res) (void)hipHostFree(hc->h_ul_res);
     if (hc->h_pin) (void)hipHostFree(hc->h_pin);
     (void)hipFree(hc->d_in); (void)hipFree(hc->d_sub);
     if (hc->h_par) (void)hipHostFree(hc->h_par);
@@ -807,6 +809,88 @@ int mi_lte_pusch_channel_decode_host(mi_lte_ctx *ctx, uint32_t N_rb_ul, const fl
         *N_out_bits = a.tbs;
     }
     return st == 0 ? 0 : 1;
+}
+
+// One UPLINK subframe, one call: what LTE_fdd_enb_phy.cc:832-917 does with 1 + N_pucch + N_pusch calls of the reference API
+// (liblte_phy_get_ul_subframe, liblte_phy_pucch_format_1_1a_1b_channel_decode per resource, liblte_phy_pusch_channel_decode per scheduled UE)
+// as ONE dependent launch chain with ONE polled wait: the received grid never leaves HBM (the per-call sequence brings its 134 KB back and
+// fingerprints it before every decode), the PUCCH resources and all PUSCH transport blocks are queued behind the front end at once.
+// The eNodeB's radio thread has 1 ms per subframe for this and the downlink encode (README).
+int mi_lte_ul_subframe_decode_host(mi_lte_ctx *ctx, uint32_t fft_size, uint32_t N_rb_ul, const float *h_i, const float *h_q, uint32_t subfr_num,
+                                   uint32_t N_id_cell, const mi_lte_ul_cfg *ul, const mi_lte_pdsch_alloc *allocs, uint32_t n_alloc, uint8_t *h_out_bits,
+                                   uint32_t out_stride, uint32_t *N_out_bits, int32_t *status, const mi_lte_pucch_res *pucch, const float *h_pucch_tables,
+                                   uint32_t n_pucch, uint8_t *h_pucch_bits, uint32_t *h_pucch_n_bits, uint32_t *h_pucch_rc)
+{
+    if (!ctx) return MI_LTE_ERR_INVALID_ARG;
+    if (!h_i || !h_q || !ul || subfr_num > 9 || N_id_cell > 503 || !valid_fft(fft_size, N_rb_ul) || n_alloc > MI_LTE_UL_SUBFRAME_MAX_ALLOC ||
+        (n_alloc && (!allocs || !h_out_bits || !N_out_bits || !status || out_stride < 6120)) || n_pucch > MI_PUCCH_STAGED_MAX ||
+        (n_pucch && (!pucch || !h_pucch_tables || !h_pucch_bits || !h_pucch_n_bits || !h_pucch_rc)))
+        return 1;
+    MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    HostCache *hc;
+    int        rc = host_cache(ctx, &hc);
+    if (rc != MI_LTE_OK) return rc;
+    const mi_lte_dl_cfg cfg = {fft_size, N_rb_ul, 1, MI_LTE_IQ_F32_PLANAR};
+    // the transport blocks this library decodes (the reference's envelope: one code block, a width it has a transform plan for,
+    // liblte_phy.cc:2360-2377); the others report the reference's failure value without stopping the rest
+    mi_lte_pdsch_alloc al[MI_LTE_UL_SUBFRAME_MAX_ALLOC];
+    uint32_t           slot[MI_LTE_UL_SUBFRAME_MAX_ALLOC], n_al = 0;
+    for (uint32_t k = 0; k < n_alloc; k++) {
+        status[k] = 1; N_out_bits[k] = 0;
+        const mi_lte_pdsch_alloc &a = allocs[k];
+        const bool planned = a.N_prb > 0 && a.N_prb < N_rb_ul && (a.N_prb % 2 == 0 || a.N_prb % 3 == 0 || a.N_prb % 5 == 0);
+        if (!planned || a.tbs + 24 > 6144 || a.tbs + 24 < a.tbs || a.mod_type > 3 || !prbs_on_carrier(a, N_rb_ul)) continue;
+        al[n_al] = a; al[n_al].unit = 0; al[n_al].n_pdcch_symbs = 0;
+        slot[n_al++] = k;
+    }
+    mi_lte_pusch_plan *plan = nullptr;
+    if (n_al) { // the plan carries subframe number, cell, reference signals and the list: all of them are its key (a grant pattern that recurs is planned once)
+        std::string key;
+        key_add(key, cfg); key_add(key, subfr_num); key_add(key, N_id_cell); key_add(key, *ul); key_add(key, n_al);
+        for (uint32_t j = 0; j < n_al; j++) key_add(key, al[j]);
+        plan = hc->pusch.find(key);
+        if (!plan) {
+            rc = mi_pusch_plan_create_impl(ctx, &cfg, ul, &subfr_num, &N_id_cell, 1, al, n_al, nullptr, &plan);
+            if (rc != MI_LTE_OK) return rc;
+            hc->pusch.put(ctx, key, plan);
+        }
+        if (mi_lte_pusch_plan_out_stride(plan) > 6144) return MI_LTE_ERR_INVALID_ARG;
+        if (!hc->h_ul_res) {
+            MI_HIP_CHECK(ctx, hipHostMalloc((void **)&hc->h_ul_res, 256 + (size_t)MI_LTE_UL_SUBFRAME_MAX_ALLOC * 6144, hipHostMallocMapped | hipHostMallocCoherent));
+            MI_HIP_CHECK(ctx, hipHostGetDevicePointer((void **)&hc->d_ul_res, hc->h_ul_res, 0));
+        }
+    }
+    // samples where the transform reads them (the mapped staging buffer), as in mi_lte_get_ul_subframe_host; this is the call's first and --
+    // the stream being idle between calls -- free wait
+    const uint32_t sc = 2048 / fft_size;
+    float *d_i, *d_q;
+    rc = stage_pair(ctx, hc, h_i, h_q, 30720 / sc, true, &d_i, &d_q);
+    if (rc != MI_LTE_OK) return rc;
+    MiPucchStaged ps;
+    if (n_pucch) {
+        for (uint32_t r = 0; r < n_pucch; r++)
+            if (pucch[r].unit != 0) return 1;
+        rc = mi_pucch_stage(ctx, N_rb_ul, pucch, h_pucch_tables, n_pucch, &ps); // (the stream is idle: nothing reads the block)
+        if (rc != MI_LTE_OK) return rc == MI_LTE_ERR_INVALID_ARG ? 1 : rc;
+    }
+    hc->sub_host = nullptr; // d_sub is being rewritten, and mirrors no host struct afterwards
+    rc = mi_lte_ul_frontend_batch(ctx, &cfg, d_i, d_q, (const uint64_t *)hc->d_par, 1, hc->d_sub);
+    if (rc != MI_LTE_OK) return fail_after_launch(ctx, hc, rc);
+    if (n_pucch && (rc = mi_pucch_launch(ctx, &ps, N_rb_ul, hc->d_sub)) != MI_LTE_OK) return fail_after_launch(ctx, hc, rc);
+    if (plan && (rc = mi_lte_pusch_decode_run(ctx, plan, hc->d_sub, hc->d_ul_res + 256, (int32_t *)hc->d_ul_res)) != MI_LTE_OK) return fail_after_launch(ctx, hc, rc);
+    MI_HIP_CHECK(ctx, mi_stream_wait_polling(ctx)); // (the wait)
+    if (n_pucch) mi_pucch_collect(&ps, h_pucch_bits, h_pucch_n_bits, h_pucch_rc);
+    const uint32_t stride = plan ? mi_lte_pusch_plan_out_stride(plan) : 0;
+    for (uint32_t j = 0; j < n_al; j++) {
+        int32_t st;
+        memcpy(&st, hc->h_ul_res + 4 * j, 4);
+        status[slot[j]] = st == 0 ? 0 : 1; // a failed CRC is LIBLTE_ERROR_INVALID_INPUTS on this path (liblte_phy.cc:2809, :2929)
+        if (st == 0) {
+            memcpy(h_out_bits + (size_t)slot[j] * out_stride, hc->h_ul_res + 256 + (size_t)j * stride, al[j].tbs);
+            N_out_bits[slot[j]] = al[j].tbs;
+        }
+    }
+    return 0;
 }
 
 // liblte_phy_detect_prach (liblte_phy.cc:3299-3479): h_re / h_im point at the occasion's first cyclic-prefix sample; the root

@@ -364,7 +364,8 @@ struct KSeg {
     // table loads (W4 as a merged decode: 4.88 ms, 4.53 without them)
     __attribute__((address_space(1))) const uint16_t *pi, *inv2, *tabs;
     __attribute__((address_space(1))) const uint32_t *nnn;
-    uint64_t        pad[2];
+    uint32_t        ws1, ws23;                 // first workgroup of the size in the state-parallel trellis kernel's launches (a handful of blocks: k_turbo_siso_small)
+    uint64_t        pad;
 };
 static_assert(sizeof(KSeg) == 96, "KSeg is read with scalar loads: keep it a multiple of 16 bytes");
 struct MultiArgs { const KSeg *segs; const uint32_t *map; }; // map: per 8 workgroups (prep, perm, vote) or per wavefront (siso) the index of its size
@@ -1141,20 +1142,28 @@ template <int N> __device__ __forceinline__ uint2 map_row_shl(uint2 v, uint2 kee
 
 // gpw trellises per wavefront (1, 2, 4 or 8): the pre-pass and the traceback take the wavefront's trellises one after the other, so the
 // host asks for as few per wavefront as still leaves the device a wavefront or two per SIMD (siso_small_gpw)
-__global__ __launch_bounds__(64) void k_turbo_siso_small(SisoArgs args, uint32_t K, uint32_t n_cb, uint32_t mode, uint32_t gpw)
+// MULTI: a merged launch over the code blocks of several sizes (KSeg): a wavefront's trellises are all of one size, which it reads from its row
+template <bool MULTI>
+__global__ __launch_bounds__(64) void k_turbo_siso_small(SisoArgs args, uint32_t K_arg, uint32_t n_cb_arg, uint32_t mode, uint32_t gpw, MultiArgs ma)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t sm_small[];
     SmallPar (*par)[64][4] = reinterpret_cast<SmallPar(*)[64][4]>(sm_small);                    // [gpw][64 steps][4 lanes]
+    uint32_t K = K_arg, n_cb = n_cb_arg, bidx = blockIdx.x;
+    size_t   seg_off = 0;
+    if constexpr (MULTI) {
+        const_seg_t &sg = multi_seg(ma, blockIdx.x);
+        K = sg.K; n_cb = sg.n_cb; seg_off = sg.arr_off; bidx = blockIdx.x - (mode ? sg.ws23 : sg.ws1);
+    }
     const uint32_t Kp = kpad64(K), n_w32 = Kp >> 5;
     uint32_t      *decw = sm_small + gpw * 64 * 4 * 2;                                           // [gpw][n_w32][4]: lane j's compare bits, 32 steps per word, first step in bit 31
     const uint32_t lane = threadIdx.x, gi = lane >> 2, j = lane & 3u;
     // trellis T = gpw * b + g of the launch: mode 0: code block T, pass p[0]; mode 1: code block T / 2, pass p[T & 1]
-    const uint32_t T0 = blockIdx.x * gpw, n_tr = n_cb * (mode ? 2u : 1u);
+    const uint32_t T0 = bidx * gpw, n_tr = n_cb * (mode ? 2u : 1u);
     const uint32_t n_g = min(gpw, n_tr - T0); // trellises of this wavefront (uniform)
     auto pass_of = [&](uint32_t g) -> const SisoPass & { return args.p[mode ? (T0 + g) & 1u : 0u]; };
     auto off_of  = [&](uint32_t g) -> size_t { // the code block's lane of its tile: element t at (t / 64) * 4096 + t % 64 from here
         const uint32_t cb = mode ? (T0 + g) >> 1 : T0 + g;
-        return (size_t)(cb >> 6) * Kp * 64 + (cb & 63u) * 64;
+        return seg_off + (size_t)(cb >> 6) * Kp * 64 + (cb & 63u) * 64;
     };
     const uint32_t n_chunk = (K + 63) >> 6;
 
@@ -1952,8 +1961,8 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
     auto gpw_of = [](uint32_t n_tr) { return n_tr <= 2048 ? 1u : n_tr <= 4096 ? 2u : n_tr <= 8192 ? 4u : SMALL_G; }; // one or two wavefronts per SIMD
     auto lds_of = [&](uint32_t gpw) { return sizeof(uint32_t) * gpw * (64 * 4 * 2 + (Kp >> 5) * 4); };
     if (small)
-        MI_LAUNCH(ctx, "k_turbo_siso_small", k_turbo_siso_small, dim3((n_cb + gpw_of(n_cb) - 1) / gpw_of(n_cb)), dim3(64), lds_of(gpw_of(n_cb)), s1, K, n_cb, 0u,
-                  gpw_of(n_cb));
+        MI_LAUNCH(ctx, "k_turbo_siso_small", k_turbo_siso_small<false>, dim3((n_cb + gpw_of(n_cb) - 1) / gpw_of(n_cb)), dim3(64), lds_of(gpw_of(n_cb)), s1, K, n_cb, 0u,
+                  gpw_of(n_cb), MultiArgs{});
     else
         MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso<false>, dim3(((n_tiles + 1) / 2 + 3) / 4), dim3(256), 0, s1, K, (uint32_t)n_tiles, 0u, MultiArgs{}); // two tiles per lane
 
@@ -1966,8 +1975,8 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
     s23.p[0] = {arr[AX2], arr[AI0], arr[AM2], arr[AB1], dec[1]};
     s23.p[1] = {arr[AX2], arr[AI1], arr[AM3], arr[AB2], dec[2]};
     if (small)
-        MI_LAUNCH(ctx, "k_turbo_siso_small", k_turbo_siso_small, dim3((2 * n_cb + gpw_of(2 * n_cb) - 1) / gpw_of(2 * n_cb)), dim3(64), lds_of(gpw_of(2 * n_cb)), s23, K,
-                  n_cb, 1u, gpw_of(2 * n_cb));
+        MI_LAUNCH(ctx, "k_turbo_siso_small", k_turbo_siso_small<false>, dim3((2 * n_cb + gpw_of(2 * n_cb) - 1) / gpw_of(2 * n_cb)), dim3(64), lds_of(gpw_of(2 * n_cb)), s23, K,
+                  n_cb, 1u, gpw_of(2 * n_cb), MultiArgs{});
     else
         MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso<false>, dim3((n_tiles + 3) / 4), dim3(256), 0, s23, K, (uint32_t)n_tiles, 1u, MultiArgs{}); // passes 2 and 3 of a tile per lane
 
@@ -2127,6 +2136,29 @@ int mi_turbo_ref_multi(mi_lte_ctx *ctx, const MiKGroup *groups, uint32_t n_group
             wv += segs[i].n_tiles;
         }
         G.n_wv23 = wv;
+        // ... and of the state-parallel trellis kernel (a handful of code blocks in all): workgroup = wavefront = up to gpw trellises of one size
+        auto gpw_of = [](uint32_t n_tr) { return n_tr <= 2048 ? 1u : n_tr <= 4096 ? 2u : n_tr <= 8192 ? 4u : SMALL_G; };
+        uint32_t tot = 0, kp_all = 0;
+        for (uint32_t i = 0; i < n_groups; i++) { tot += groups[i].n_cb; kp_all = std::max(kp_all, kpad64(groups[i].K)); }
+        G.gpw1 = gpw_of(tot); G.gpw23 = gpw_of(2 * tot); G.kp_all = kp_all;
+        G.map_ws1 = (uint32_t)map.size();
+        uint32_t wg = 0;
+        for (uint32_t i = 0; i < n_groups; i++) {
+            const uint32_t n = (groups[i].n_cb + G.gpw1 - 1) / G.gpw1;
+            segs[i].ws1 = wg;
+            map.insert(map.end(), n, i);
+            wg += n;
+        }
+        G.n_ws1   = wg;
+        G.map_ws23 = (uint32_t)map.size();
+        wg = 0;
+        for (uint32_t i = 0; i < n_groups; i++) {
+            const uint32_t n = (2 * groups[i].n_cb + G.gpw23 - 1) / G.gpw23;
+            segs[i].ws23 = wg;
+            map.insert(map.end(), n, i);
+            wg += n;
+        }
+        G.n_ws23 = wg;
         const size_t seg_bytes = sizeof(KSeg) * n_groups, map_bytes = (sizeof(uint32_t) * map.size() + 15) & ~(size_t)15, need = seg_bytes + map_bytes;
         if (need > cache->cap) {
             MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -2170,6 +2202,12 @@ int mi_turbo_ref_multi(mi_lte_ctx *ctx, const MiKGroup *groups, uint32_t n_group
     SisoArgs s1;
     s1.p[0] = {arr[AX1], arr[AX0], arr[AM1], arr[AA1], dec[0]};
     s1.p[1] = s1.p[0];
+    // a handful of code blocks in all (a per-call caller's subframe): the trellis's states on the lanes instead of code blocks, as in the per-size launches
+    const bool small = G.n_slots <= ctx->siso_small_max;
+    auto lds_small = [&](uint32_t gpw) { return sizeof(uint32_t) * gpw * (64 * 4 * 2 + (G.kp_all >> 5) * 4); };
+    if (small)
+        MI_LAUNCH(ctx, "k_turbo_siso_small", k_turbo_siso_small<true>, dim3(G.n_ws1), dim3(64), lds_small(G.gpw1), s1, 0u, 0u, 0u, G.gpw1, (MultiArgs{d_segs, d_map + G.map_ws1}));
+    else
     MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso<true>, dim3((G.n_wv1 + 3) / 4), dim3(256), 0, s1, 0u, G.n_wv1, 0u, (MultiArgs{d_segs, d_map + G.map_wv1}));
     PermArgs pa;
     pa.A1 = arr[AA1]; pa.X2 = arr[AX2]; pa.out[0] = arr[AI1]; pa.out[1] = arr[AM3];
@@ -2180,6 +2218,9 @@ int mi_turbo_ref_multi(mi_lte_ctx *ctx, const MiKGroup *groups, uint32_t n_group
     SisoArgs s23;
     s23.p[0] = {arr[AX2], arr[AI0], arr[AM2], arr[AB1], dec[1]};
     s23.p[1] = {arr[AX2], arr[AI1], arr[AM3], arr[AB2], dec[2]};
+    if (small)
+        MI_LAUNCH(ctx, "k_turbo_siso_small", k_turbo_siso_small<true>, dim3(G.n_ws23), dim3(64), lds_small(G.gpw23), s23, 0u, 0u, 1u, G.gpw23, (MultiArgs{d_segs, d_map + G.map_ws23}));
+    else
     MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso<true>, dim3((G.n_wv23 + 3) / 4), dim3(256), 0, s23, 0u, G.n_wv23, 1u, (MultiArgs{d_segs, d_map + G.map_wv23}));
     VoteArgs va = {arr[AX0], arr[AA1], arr[AB1], arr[AB2]};
     for (int c = 0; c < NCLS; c++)

@@ -457,6 +457,7 @@ struct mi_lte_pusch_plan {
     struct Group { uint32_t K, n_cb, cb_base, e_max; };
     std::vector<Group>    groups;
     std::vector<uint32_t> h_e_off, h_e_len;
+    MiMultiCache          multi; // the merged decode's device tables for `groups` (turbo.hip: mi_turbo_ref_multi)
 };
 
 // the float next above or equal to 1 / d (see quot)
@@ -627,6 +628,7 @@ void mi_lte_pusch_plan_destroy(mi_lte_ctx *ctx, mi_lte_pusch_plan *pl)
     (void)hipFree(pl->d_e_len);
     (void)hipFree(pl->d_cb_alloc);
     (void)hipFree(pl->d_e);
+    mi_multi_cache_free(&pl->multi);
     delete pl;
 }
 
@@ -668,15 +670,62 @@ int mi_lte_pusch_decode_run(mi_lte_ctx *ctx, mi_lte_pusch_plan *pl, const float 
     if (threads == 64) MI_PUSCH_LAUNCH(64); else if (threads == 128) MI_PUSCH_LAUNCH(128); else if (threads == 192) MI_PUSCH_LAUNCH(192); else MI_PUSCH_LAUNCH(256);
 #undef MI_PUSCH_LAUNCH
     MI_HIP_CHECK(ctx, hipGetLastError());
+    // several block sizes (the UEs of a subframe rarely share one): one launch set over all of them (turbo.hip: KSeg), as in the PDSCH chain
+    std::vector<MiKGroup> take;
+    if (ctx->merged_decode && pl->groups.size() >= 2)
+        for (auto &gr : pl->groups)
+            if (mi_turbo_ref_multi_takes(gr.K, gr.e_max) && (gr.n_cb + 63) / 64 < 4096) take.push_back(MiKGroup{gr.K, gr.n_cb, gr.cb_base, gr.e_max});
+    if (take.size() >= 2) {
+        rc = mi_turbo_ref_multi(ctx, take.data(), (uint32_t)take.size(), pl->d_allocs, pl->d_cb_alloc, pl->d_e, pl->d_e_off, pl->d_e_len, d_out_bits, pl->out_stride, d_status,
+                                /*ul=*/true, false, &pl->multi);
+        if (rc != MI_LTE_OK) return rc;
+    }
     for (auto &gr : pl->groups) {
+        if (take.size() >= 2 && mi_turbo_ref_multi_takes(gr.K, gr.e_max) && (gr.n_cb + 63) / 64 < 4096) continue;
         rc = mi_turbo_ref_group(ctx, gr.K, gr.n_cb, pl->d_allocs, pl->d_cb_alloc + gr.cb_base, pl->d_e, pl->d_e_off, pl->d_e_len,
                                 d_out_bits, pl->out_stride, d_status, gr.e_max, /*ul=*/true);
         if (rc != MI_LTE_OK) return rc;
     }
-    ctx->last_kernels = "k_pusch_demod:1,k_turbo_prep,k_turbo_siso,k_turbo_perm,k_turbo_vote per block size";
+    ctx->last_kernels = take.size() >= 2 ? "k_pusch_demod:1,k_cb_desc:1,k_turbo_prep,k_turbo_siso:2,k_turbo_perm,k_turbo_vote per workgroup width over all block sizes"
+                                         : "k_pusch_demod:1,k_turbo_prep,k_turbo_siso,k_turbo_perm,k_turbo_vote per block size";
     return MI_LTE_OK;
 }
 
+} // extern "C"
+
+// The same decode in three steps for a caller that builds ONE launch chain per subframe (hostapi.cc: mi_lte_ul_subframe_decode_host): the
+// descriptors and tables go into the context's mapped pinned block while the stream is idle (the caller has waited), the kernel is queued
+// behind the caller's front end, the results are read after the caller's single wait.  At most MI_PUCCH_STAGED_MAX resources.
+int mi_pucch_stage(mi_lte_ctx *ctx, uint32_t N_rb_ul, const mi_lte_pucch_res *h_res, const float *h_tables, uint32_t n_res, MiPucchStaged *st)
+{
+    if (!ctx || !h_res || !h_tables || !st || n_res == 0 || n_res > MI_PUCCH_STAGED_MAX) return MI_LTE_ERR_INVALID_ARG;
+    for (uint32_t r = 0; r < n_res; r++)
+        if (h_res[r].format > 2 || h_res[r].N_1_p_pucch >= N_rb_ul) return MI_LTE_ERR_INVALID_ARG;
+    const size_t b_res = sizeof(PucchRes) * (size_t)n_res, b_tab = sizeof(float) * PUCCH_TAB_FLOATS * (size_t)n_res, b_out = 4 * (size_t)n_res;
+    st->n_res = n_res;
+    st->o_tab = (b_res + 255) & ~(size_t)255;
+    st->o_out = (st->o_tab + b_tab + 255) & ~(size_t)255;
+    int rc = mi_ctx_small_results(ctx, st->o_out + b_out, (void **)&st->h_base, (void **)&st->d_base);
+    if (rc != MI_LTE_OK) return rc;
+    PucchRes *res = (PucchRes *)st->h_base;
+    for (uint32_t r = 0; r < n_res; r++) res[r] = PucchRes{h_res[r].unit, h_res[r].format, h_res[r].N_1_p_pucch};
+    memcpy(st->h_base + st->o_tab, h_tables, b_tab);
+    return MI_LTE_OK;
+}
+int mi_pucch_launch(mi_lte_ctx *ctx, const MiPucchStaged *st, uint32_t N_rb_ul, const float *d_subframes)
+{
+    MI_LAUNCH(ctx, "k_pucch_decode", k_pucch_decode, dim3(st->n_res), dim3(64), 0, d_subframes, (uint32_t)mi_lte_ul_subframe_floats(), N_rb_ul, 1u,
+              (const PucchRes *)st->d_base, (const float *)(st->d_base + st->o_tab), (uint8_t *)(st->d_base + st->o_out));
+    MI_HIP_CHECK(ctx, hipGetLastError());
+    return MI_LTE_OK;
+}
+void mi_pucch_collect(const MiPucchStaged *st, uint8_t *h_bits, uint32_t *h_n_bits, uint32_t *h_rc)
+{
+    const uint8_t *o = (const uint8_t *)st->h_base + st->o_out;
+    for (uint32_t r = 0; r < st->n_res; r++) { h_bits[2 * r] = o[4 * r]; h_bits[2 * r + 1] = o[4 * r + 1]; h_n_bits[r] = o[4 * r + 2]; h_rc[r] = o[4 * r + 3]; }
+}
+
+extern "C" {
 // liblte_phy_pucch_format_1_1a_1b_channel_decode for a batch of PUCCH resources over UL device subframes
 int mi_lte_pucch_decode_run(mi_lte_ctx *ctx, uint32_t N_rb_ul, uint32_t N_ant, const float *d_subframes, const mi_lte_pucch_res *h_res,
                             const float *h_tables, uint32_t n_res, uint8_t *h_bits /*[n_res][2]*/, uint32_t *h_n_bits, uint32_t *h_rc)

@@ -689,6 +689,32 @@ class Context:
             if not keep:
                 d_out.free()
 
+    def ul_subframe_decode(self, fft_size, n_rb_ul, i_samps, q_samps, subfr_num, cell, ulcfg, allocs, pucch=(), pucch_tables=None):
+        """mi_lte_ul_subframe_decode_host: one uplink subframe (float32 sample arrays) in one call.  allocs: list of PdschAlloc; pucch: list of
+        (format 0/1/2, N_1_p_pucch) with tables float32 [n, 352].  Returns (status int32 [n_alloc], list of bit arrays (None where the CRC failed),
+        (pucch bits uint8 [n, 2], n_bits, rc))."""
+        L = self.L
+        if not getattr(L, "_ul_sf_bound", False):
+            L.mi_lte_ul_subframe_decode_host.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(UlCfg), C.c_void_p,
+                                                         C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
+                                                         C.c_void_p, C.c_void_p]
+            L._ul_sf_bound = True
+        n, npu = len(allocs), len(pucch)
+        arr = (PdschAlloc * max(n, 1))(*allocs)
+        i_s, q_s = np.ascontiguousarray(i_samps, np.float32), np.ascontiguousarray(q_samps, np.float32)
+        out, nb, st = np.zeros((max(n, 1), 6144), np.uint8), np.zeros(max(n, 1), np.uint32), np.full(max(n, 1), -7, np.int32)
+        pr = (PucchRes * max(npu, 1))(*[PucchRes(0, f, n1) for (f, n1) in pucch])
+        tabs = np.ascontiguousarray(pucch_tables if pucch_tables is not None else np.zeros((1, 352)), np.float32)
+        pb, pnb, prc = np.zeros((max(npu, 1), 2), np.uint8), np.zeros(max(npu, 1), np.uint32), np.zeros(max(npu, 1), np.uint32)
+        rc = L.mi_lte_ul_subframe_decode_host(self.h, fft_size, n_rb_ul, i_s.ctypes.data, q_s.ctypes.data, subfr_num, cell, C.byref(ulcfg), C.cast(arr, C.c_void_p), n,
+                                              out.ctypes.data, 6144, nb.ctypes.data, st.ctypes.data, C.cast(pr, C.c_void_p), tabs.ctypes.data, npu, pb.ctypes.data,
+                                              pnb.ctypes.data, prc.ctypes.data)
+        if rc < 0:
+            self._check(rc)
+        if rc != 0:
+            raise MiLteError("mi_lte_ul_subframe_decode_host: invalid arguments (%d)" % rc)
+        return st[:n], [out[a, :nb[a]].copy() if st[a] == 0 else None for a in range(n)], (pb[:npu], pnb[:npu], prc[:npu])
+
     def prach_plan(self, cfg, prach_cfg, roots_fft=None):
         return PrachPlan(self, cfg, prach_cfg, roots_fft)
 
@@ -788,6 +814,11 @@ class Context:
         out = np.zeros(1 << 16, np.uint32)
         self._check(self.L.mi_lte_turbo_early_exit_iterations(self.h, out.ctypes.data, len(out), C.byref(n), C.byref(ni)))
         return out[:n.value].copy()
+
+    def set_turbo_merged(self, on=True):
+        """Several code-block sizes in one decode: one launch set over all of them (default) or, off, size by size (mi_lte_set_turbo_merged)."""
+        self.L.mi_lte_set_turbo_merged.argtypes = [C.c_void_p, C.c_uint32]
+        self._check(self.L.mi_lte_set_turbo_merged(self.h, 1 if on else 0))
 
     def set_turbo_small_batch(self, n_cb_max):
         """Code blocks per decode up to which the REF decoder's state-parallel trellis kernel runs (0: always the lock-step one)."""

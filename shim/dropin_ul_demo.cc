@@ -15,6 +15,9 @@
 #include <cstring>
 
 #include "liblte_phy.h"
+#ifdef MI_LTE_HAVE_UL_SUBFRAME_DECODE
+#include "liblte_phy_ext.h"
+#endif
 
 int main(int argc, char **argv)
 {
@@ -80,6 +83,41 @@ int main(int argc, char **argv)
         const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
         fprintf(stderr, "timing: %d x (get_ul_subframe + %d pusch_channel_decode): %.1f us per subframe, %u decodes ok\n", reps, (argc - 10) / 5, us / reps, ok);
     }
+#ifdef MI_LTE_HAVE_UL_SUBFRAME_DECODE
+    if (getenv("UL_DEMO_ONE_CALL")) { // the same subframe through the shim's one-call form (liblte_phy_ext.h): same lines as above, prefixed
+        const uint32 n_ue = (argc - 10) / 5;
+        LIBLTE_PHY_ALLOCATION_STRUCT *als = (LIBLTE_PHY_ALLOCATION_STRUCT *)calloc(n_ue, sizeof(*als));
+        for (uint32 u = 0; u < n_ue; u++) {
+            const int a = 10 + 5 * u;
+            als[u].mod_type  = (LIBLTE_PHY_MODULATION_TYPE_ENUM)atoi(argv[a]);
+            als[u].chan_type = LIBLTE_PHY_CHAN_TYPE_ULSCH;
+            als[u].tbs = atoi(argv[a + 1]); als[u].rnti = atoi(argv[a + 2]); als[u].N_prb = atoi(argv[a + 4]);
+            for (uint32 i = 0; i < als[u].N_prb; i++) als[u].prb[0][i] = als[u].prb[1][i] = atoi(argv[a + 3]) + i;
+            als[u].N_codewords = 1; als[u].N_layers = 1; als[u].tx_mode = 1; als[u].rv_idx = 0;
+        }
+        uint8 *ob = (uint8 *)calloc(n_ue, LIBLTE_MAX_MSG_SIZE);
+        uint32 *onb = (uint32 *)calloc(n_ue, sizeof(uint32));
+        LIBLTE_ERROR_ENUM *ost = (LIBLTE_ERROR_ENUM *)calloc(n_ue, sizeof(LIBLTE_ERROR_ENUM));
+        LIBLTE_ERROR_ENUM e = liblte_phy_ul_subframe_decode(phy, i_s, q_s, sf_num, cell, als, n_ue, ob, onb, ost, NULL, NULL, 0, NULL, NULL, NULL);
+        if (e != LIBLTE_SUCCESS) printf("one call: failed (%d)\n", (int)e);
+        for (uint32 u = 0; u < n_ue && e == LIBLTE_SUCCESS; u++) {
+            uint32 h = 2166136261u;
+            for (uint32 i = 0; i < onb[u]; i++) h = (h ^ ob[(size_t)u * LIBLTE_MAX_MSG_SIZE + i]) * 16777619u;
+            printf("one call: rnti 0x%x: err=%d N_out_bits=%u hash=%08x\n", (unsigned)als[u].rnti, (int)ost[u], onb[u], h);
+        }
+        if (getenv("UL_DEMO_REPEAT")) {
+            const int reps = atoi(getenv("UL_DEMO_REPEAT"));
+            const auto t0 = std::chrono::steady_clock::now();
+            uint32 ok = 0;
+            for (int r = 0; r < reps; r++) {
+                liblte_phy_ul_subframe_decode(phy, i_s, q_s, sf_num, cell, als, n_ue, ob, onb, ost, NULL, NULL, 0, NULL, NULL, NULL);
+                for (uint32 u = 0; u < n_ue; u++) ok += ost[u] == LIBLTE_SUCCESS;
+            }
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            fprintf(stderr, "timing: %d x (ul_subframe_decode, %u UEs in one call): %.1f us per subframe, %u decodes ok\n", reps, n_ue, us / reps, ok);
+        }
+    }
+#endif
     if (getenv("PRACH_CAPTURE")) {
         FILE *pf = fopen(getenv("PRACH_CAPTURE"), "rb");
         if (!pf) return 6;

@@ -34,6 +34,8 @@
 
 #include "liblte_phy.h" // the reference's header, from -I<reference>/liblte/hdr -I<reference>/cmn_hdr
 #include "mi_lte.h"
+#include "liblte_phy_ext.h"
+#include <algorithm>
 
 namespace {
 // One GPU context per LIBLTE_PHY_STRUCT, created on first use and destroyed with the struct (liblte_phy_cleanup below).  The
@@ -404,6 +406,64 @@ LIBLTE_ERROR_ENUM liblte_phy_pusch_channel_decode(LIBLTE_PHY_STRUCT *phy_struct,
     int rc = mi_lte_pusch_channel_decode_host(c, phy_struct->N_rb_ul, &subframe->rx_symb_re[0][0], &subframe->rx_symb_im[0][0], sf, &a,
                                               N_id_cell, N_ant, d0r, d0i, d1r, d1i, out_bits, N_out_bits);
     return rc == 0 ? LIBLTE_SUCCESS : LIBLTE_ERROR_INVALID_INPUTS; // the reference's own failure code on this path (:2809, :2929)
+}
+
+// Not a reference symbol (shim/liblte_phy_ext.h): the receive half of a TTI in one call -- mi_lte_ul_subframe_decode_host
+LIBLTE_ERROR_ENUM liblte_phy_ul_subframe_decode(LIBLTE_PHY_STRUCT *phy_struct, float *i_samps, float *q_samps, uint8 subfr_num, uint32 N_id_cell,
+                                                LIBLTE_PHY_ALLOCATION_STRUCT *allocs, uint32 N_allocs, uint8 *out_bits, uint32 *N_out_bits,
+                                                LIBLTE_ERROR_ENUM *status, LIBLTE_PHY_PUCCH_FORMAT_ENUM *pucch_format, uint32 *N_1_p_pucch,
+                                                uint32 N_pucch, uint8 *pucch_bits, uint32 *N_pucch_bits, LIBLTE_ERROR_ENUM *pucch_status)
+{
+    if (phy_struct == NULL || i_samps == NULL || q_samps == NULL || !phy_struct->ul_init || subfr_num > 9 || N_allocs > LIBLTE_PHY_UL_SUBFRAME_MAX_ALLOC ||
+        N_pucch > 32 || (N_allocs && (allocs == NULL || out_bits == NULL || N_out_bits == NULL || status == NULL)) ||
+        (N_pucch && (pucch_format == NULL || N_1_p_pucch == NULL || pucch_bits == NULL || N_pucch_bits == NULL || pucch_status == NULL)))
+        return LIBLTE_ERROR_INVALID_INPUTS;
+    MI_LOCKED_CTX(phy_struct, LIBLTE_ERROR_INVALID_INPUTS);
+    std::vector<mi_lte_pdsch_alloc> al(N_allocs ? N_allocs : 1);
+    for (uint32 k = 0; k < N_allocs; k++) {
+        to_mi_alloc(&allocs[k], &al[k]);
+        // (what liblte_phy_pusch_channel_decode itself refuses: reported per allocation below)
+        if (allocs[k].N_prb == 0 || allocs[k].N_prb >= LIBLTE_PHY_N_RB_UL_MAX) al[k].N_prb = 0;
+    }
+    std::vector<mi_lte_pucch_res> pr(N_pucch ? N_pucch : 1);
+    std::vector<float>            tabs((size_t)(N_pucch ? N_pucch : 1) * MI_LTE_PUCCH_TAB_FLOATS);
+    for (uint32 r = 0; r < N_pucch; r++) {
+        if (!(pucch_format[r] == LIBLTE_PHY_PUCCH_FORMAT_1 || pucch_format[r] == LIBLTE_PHY_PUCCH_FORMAT_1A || pucch_format[r] == LIBLTE_PHY_PUCCH_FORMAT_1B) ||
+            N_1_p_pucch[r] >= LIBLTE_PHY_N_RB_UL_MAX / 2)
+            return LIBLTE_ERROR_INVALID_INPUTS;
+        pr[r] = mi_lte_pucch_res{0, (uint32_t)pucch_format[r], N_1_p_pucch[r]};
+        std::vector<float> &tab = entry_->pucch[subfr_num * 256u + N_1_p_pucch[r]]; // (as in liblte_phy_pucch_format_1_1a_1b_channel_decode below)
+        if (tab.empty()) {
+            tab.resize(MI_LTE_PUCCH_TAB_FLOATS);
+            if (mi_lte_ul_pucch_tables(&entry_->ul, entry_->ul_cell, subfr_num, N_1_p_pucch[r], entry_->n_cs_an, entry_->delta_pucch_shift, phy_struct->N_ant, &tab[0]) != MI_LTE_OK) {
+                tab.clear();
+                return LIBLTE_ERROR_INVALID_INPUTS;
+            }
+        }
+        std::copy(tab.begin(), tab.end(), tabs.begin() + (size_t)r * MI_LTE_PUCCH_TAB_FLOATS);
+    }
+    static thread_local std::vector<uint8_t> bits;
+    bits.resize((size_t)LIBLTE_PHY_UL_SUBFRAME_MAX_ALLOC * 6144);
+    std::vector<uint32_t> nb(N_allocs ? N_allocs : 1), pnb(N_pucch ? N_pucch : 1), prc(N_pucch ? N_pucch : 1);
+    std::vector<int32_t>  st(N_allocs ? N_allocs : 1);
+    std::vector<uint8_t>  pb(2 * (size_t)(N_pucch ? N_pucch : 1));
+    int rc = mi_lte_ul_subframe_decode_host(c, phy_struct->N_samps_per_symb, phy_struct->N_rb_ul, i_samps, q_samps, subfr_num, N_id_cell, &entry_->ul, al.data(), N_allocs,
+                                            bits.data(), 6144, nb.data(), st.data(), pr.data(), tabs.data(), N_pucch, pb.data(), pnb.data(), prc.data());
+    if (rc != 0) return LIBLTE_ERROR_INVALID_INPUTS;
+    for (uint32 k = 0; k < N_allocs; k++) {
+        status[k] = st[k] == 0 && nb[k] <= LIBLTE_MAX_MSG_SIZE ? LIBLTE_SUCCESS : LIBLTE_ERROR_INVALID_INPUTS;
+        if (status[k] == LIBLTE_SUCCESS) {
+            std::copy(bits.begin() + (size_t)k * 6144, bits.begin() + (size_t)k * 6144 + nb[k], out_bits + (size_t)k * LIBLTE_MAX_MSG_SIZE);
+            N_out_bits[k] = nb[k];
+        }
+    }
+    for (uint32 r = 0; r < N_pucch; r++) {
+        pucch_bits[2 * r] = pb[2 * r];
+        if (pnb[r] == 2) pucch_bits[2 * r + 1] = pb[2 * r + 1];
+        N_pucch_bits[r] = pnb[r];
+        pucch_status[r] = prc[r] == 0 ? LIBLTE_SUCCESS : LIBLTE_ERROR_INVALID_INPUTS;
+    }
+    return LIBLTE_SUCCESS;
 }
 
 LIBLTE_ERROR_ENUM liblte_phy_detect_prach(LIBLTE_PHY_STRUCT *phy_struct, float *samps_re, float *samps_im, uint32 freq_offset,

@@ -267,6 +267,26 @@ def test_uplink_dropin_demo_with_no_reference_phy_object_in_the_link(tmp_path):
     assert " T liblte_phy_ul_init" in syms and "generate_dmrs_pusch" not in syms and "prach_preamble_seq_gen" not in syms and "fftwf_" not in syms
 
 
+@pytest.mark.parametrize("exe_name", ["dropin_ul_gpu", "dropin_ul_gpu_pure"])
+def test_uplink_one_call_per_subframe_prints_the_per_call_lines(tmp_path, exe_name):
+    """The shim's liblte_phy_ul_subframe_decode (shim/liblte_phy_ext.h: get_ul_subframe + every UE's PUSCH decode as one launch chain with one
+    wait, mi_lte_ul_subframe_decode_host) inside the same uplink caller: its per-UE lines -- verdict, bit count, hash of the decoded bits --
+    are the per-call sequence's, which are the all-reference build's (the tests above)."""
+    exe = os.path.join(ROOT, "shim", "_build", exe_name)
+    if not os.path.exists(exe):
+        pytest.skip("shim/_build/%s not built (needs the reference tree at build time)" % exe_name)
+    args, env = _ul_demo_args(tmp_path), _ul_demo_env(tmp_path)
+    env.pop("PUCCH_DEMO", None)
+    env["UL_DEMO_ONE_CALL"] = "1"
+    got = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300, env=env)
+    assert got.returncode == 0, got.stdout + got.stderr
+    lines = got.stdout.strip().splitlines()
+    per_call = [l for l in lines if l.startswith("rnti ")]
+    one_call = [l[len("one call: "):] for l in lines if l.startswith("one call: ")]
+    assert len(per_call) == 3 and one_call == per_call, lines
+    assert all("err=0" in l for l in per_call)
+
+
 def test_pucch_decoder_of_the_build_without_the_reference_phy():
     """`shim/_build/lifecycle_check pucch` (a TEST binary that links the reference's PHY under other names): 360 PUCCH format 1 / 1a / 1b
     resources built from the tables the REFERENCE's liblte_phy_ul_init computed, decoded by the reference on its struct and by the

@@ -93,7 +93,7 @@ def test_merged_decode_equals_the_per_size_launches(ctx):
     """The same batch (96 mixed subframes from the library's own front end, compact estimates, ~900 allocations) through the merged
     launches and through the per-size launches: identical verdicts and bits.  One allocation repeats its block over more than 258 laps of
     the circular buffer (K = 40 behind 13 PRB of 64QAM): the merged kernels' int16 sums do not hold that, it takes the per-size path
-    next to the merged ones."""
+    next to the merged ones.  The merged launches are run with either shape of the trellis kernel."""
     import openlte_amd as m
     lists = _lists(96, 78)
     sf, cell, cfi, lst = lists[5]
@@ -110,15 +110,20 @@ def test_merged_decode_equals_the_per_size_launches(ctx):
     plan = ctx.pdsch_plan(cfg, 2, allocs)
     got = {}
     try:
-        for name, small in (("merged", 0), ("per_size", 1 << 30)):
+        # merged launches with the lock-step trellis kernel (code blocks on the lanes), merged with the state-parallel one (what a decode of
+        # this size takes by itself), and size by size
+        for name, small, merged in (("merged", 0, True), ("merged_small", 4096, True), ("per_size", 4096, False)):
             ctx.set_turbo_small_batch(small)
+            ctx.set_turbo_merged(merged)
             got[name] = plan.run(d_sub, sfs, cells)
-            assert ("over all block sizes" in ctx.last_kernels()) == (name == "merged"), (name, ctx.last_kernels())
+            assert ("over all block sizes" in ctx.last_kernels()) == merged, (name, ctx.last_kernels())
     finally:
         ctx.set_turbo_small_batch(4096)
+        ctx.set_turbo_merged(True)
     (st_a, bits_a), (st_b, bits_b) = got["merged"], got["per_size"]
-    assert (st_a == st_b).all()
-    assert all((x == y).all() for x, y in zip(bits_a, bits_b))
+    for other in ("merged", "merged_small"):
+        assert (got[other][0] == st_b).all(), other
+        assert all((x == y).all() for x, y in zip(got[other][1], bits_b)), other
     ok = sum(int(st_a[a] == 0 and (bits_a[a] == tx[a]).all()) for a in range(len(allocs)))
     assert ok == int((st_a == 0).sum()) and ok >= len(allocs) * 0.7, (ok, len(allocs))
     plan.close()

@@ -495,6 +495,9 @@ int mi_lte_pdsch_plan_create_dynamic(mi_lte_ctx *ctx, const mi_lte_dl_cfg *cfg, 
     auto  guard = on_fail([&] { mi_lte_pdsch_plan_destroy(nullptr, pl); });
     pl->cfg     = *cfg;
     pl->dynamic = true;
+    // the capacity a multiple of four entries: the staging block's three arrays (260-byte structs, then two uint32 arrays) then all start on 16
+    // bytes whatever the caller asked for, which is what the copy kernel of mi_pdsch_plan_assign_slice needs (otherwise three copy commands)
+    max_alloc = (max_alloc + 3u) & ~3u;
     int rc = plan_device_arrays(ctx, pl, max_alloc, (max_soft_bytes + 63) & ~(size_t)63);
     if (rc != MI_LTE_OK) return rc;
     MI_HIP_CHECK(ctx, hipHostMalloc(&pl->h_stage, (sizeof(mi_lte_pdsch_alloc) + 2 * sizeof(uint32_t)) * (size_t)max_alloc, hipHostMallocDefault));
@@ -582,8 +585,8 @@ uint32_t mi_lte_pdsch_plan_n_alloc(const mi_lte_pdsch_plan *pl) { return pl ? pl
 int mi_pdsch_plan_assign_slice(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, uint32_t N_pdcch_symbs, const mi_lte_pdsch_alloc *h_src, uint32_t n_alloc, uint32_t unit0,
                                std::vector<uint32_t> *refused, hipStream_t copy_stream)
 {
-    const hipStream_t cs = copy_stream ? copy_stream : ctx->stream;
     if (!ctx || !pl || !pl->dynamic || pl->mapped || !h_src || n_alloc == 0 || N_pdcch_symbs < 1 || N_pdcch_symbs > 4) return MI_LTE_ERR_INVALID_ARG;
+    const hipStream_t cs = copy_stream ? copy_stream : ctx->stream;
     if (n_alloc > pl->cap_alloc) { ctx->err = "more allocations than the dynamic plan was created for"; return MI_LTE_ERR_INVALID_ARG; }
     MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     MI_HIP_CHECK(ctx, hipEventSynchronize(pl->staged)); // the previous assignment's copies have left the staging block

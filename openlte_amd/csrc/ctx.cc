@@ -72,6 +72,8 @@ void mi_lte_ctx_destroy(mi_lte_ctx *ctx)
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->h_small) (void)hipHostFree(ctx->h_small);
     if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
+    for (int k = 0; k < 2; k++)
+        if (ctx->ev_bounce[k]) (void)hipEventDestroy(ctx->ev_bounce[k]);
     if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -192,15 +194,22 @@ __global__ __launch_bounds__(256) void k_copy_words(uint4 *__restrict__ dst, con
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
     if (blockIdx.x == 0 && threadIdx.x < n_tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
 }
-static constexpr size_t BOUNCE_LO = 16u << 10, BOUNCE_BYTES = 4u << 20, BOUNCE_HI = 64u << 20;
+static constexpr size_t BOUNCE_LO = 16u << 10, BOUNCE_BYTES = 4u << 20, BOUNCE_HALF = BOUNCE_BYTES / 2, BOUNCE_HI = 64u << 20;
 static const bool runtime_copies = getenv("MI_LTE_RUNTIME_COPIES") != nullptr; // (A/B switch: every copy through hipMemcpyAsync, as before round 5)
 static bool bounce_ready(mi_lte_ctx *ctx, const void *d_ptr, size_t bytes)
 {
-    if (runtime_copies || bytes <= BOUNCE_LO || bytes > BOUNCE_HI || ((uintptr_t)d_ptr & 15u)) return false;
+    if (runtime_copies || ctx->bounce_failed || bytes <= BOUNCE_LO || bytes > BOUNCE_HI || ((uintptr_t)d_ptr & 15u)) return false;
     if (!ctx->h_bounce) {
-        if (hipHostMalloc(&ctx->h_bounce, BOUNCE_BYTES, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&ctx->d_bounce, ctx->h_bounce, 0) != hipSuccess) {
+        // the block is mapped for the context's OWN device (a multi-device process: whatever device the calling thread had current otherwise);
+        // a failure is remembered -- the runtime path serves from then on, without a retry per copy
+        if (hipSetDevice(ctx->device) != hipSuccess || hipHostMalloc(&ctx->h_bounce, BOUNCE_BYTES, hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer(&ctx->d_bounce, ctx->h_bounce, 0) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_bounce[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ev_bounce[1], hipEventDisableTiming) != hipSuccess) {
             if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
+            for (int k = 0; k < 2; k++)
+                if (ctx->ev_bounce[k]) { (void)hipEventDestroy(ctx->ev_bounce[k]); ctx->ev_bounce[k] = nullptr; }
             ctx->h_bounce = ctx->d_bounce = nullptr;
+            ctx->bounce_failed = true;
             (void)hipGetLastError();
         }
     }
@@ -279,13 +288,19 @@ int mi_lte_memcpy_h2d(mi_lte_ctx *ctx, void *d_dst, const void *h_src, size_t by
     if (!ctx) return MI_LTE_ERR_INVALID_ARG;
     if (bounce_ready(ctx, d_dst, bytes)) {
         MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-        for (size_t off = 0; off < bytes; off += BOUNCE_BYTES) {
-            const size_t n = std::min(BOUNCE_BYTES, bytes - off);
-            memcpy(ctx->h_bounce, (const uint8_t *)h_src + off, n);
-            launch_copy(ctx, (uint8_t *)d_dst + off, ctx->d_bounce, n);
+        // the two halves of the block in turn: the host fills one while the kernel behind the other is still reading it across the link
+        // (one 4 MiB buffer, filled, copied and waited for in series, ran a 64 MB call at about half the link rate)
+        uint32_t k = 0;
+        for (size_t off = 0; off < bytes; off += BOUNCE_HALF, k++) {
+            const size_t n = std::min(BOUNCE_HALF, bytes - off);
+            uint8_t     *hb = (uint8_t *)ctx->h_bounce + (k & 1) * BOUNCE_HALF;
+            if (k >= 2) MI_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev_bounce[k & 1])); // the kernel that read this half two chunks ago is done
+            memcpy(hb, (const uint8_t *)h_src + off, n);
+            launch_copy(ctx, (uint8_t *)d_dst + off, (uint8_t *)ctx->d_bounce + (k & 1) * BOUNCE_HALF, n);
             MI_HIP_CHECK(ctx, hipGetLastError());
-            MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            MI_HIP_CHECK(ctx, hipEventRecord(ctx->ev_bounce[k & 1], ctx->stream));
         }
+        MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         return MI_LTE_OK;
     }
     MI_HIP_CHECK(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -297,12 +312,20 @@ int mi_lte_memcpy_d2h(mi_lte_ctx *ctx, void *h_dst, const void *d_src, size_t by
     if (!ctx) return MI_LTE_ERR_INVALID_ARG;
     if (bounce_ready(ctx, d_src, bytes)) {
         MI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-        for (size_t off = 0; off < bytes; off += BOUNCE_BYTES) {
-            const size_t n = std::min(BOUNCE_BYTES, bytes - off);
-            launch_copy(ctx, ctx->d_bounce, (const uint8_t *)d_src + off, n);
-            MI_HIP_CHECK(ctx, hipGetLastError());
-            MI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); // (also makes the kernel's writes to the host block visible)
-            memcpy((uint8_t *)h_dst + off, ctx->h_bounce, n);
+        // two halves in flight: while the host empties one, the kernel is filling the other
+        const size_t n_chunks = (bytes + BOUNCE_HALF - 1) / BOUNCE_HALF;
+        for (size_t k = 0; k <= n_chunks; k++) {
+            if (k < n_chunks) { // (chunk k goes into the half chunk k - 2 was emptied from, one iteration ago)
+                const size_t off = k * BOUNCE_HALF, n = std::min(BOUNCE_HALF, bytes - off);
+                launch_copy(ctx, (uint8_t *)ctx->d_bounce + (k & 1) * BOUNCE_HALF, (const uint8_t *)d_src + off, n);
+                MI_HIP_CHECK(ctx, hipGetLastError());
+                MI_HIP_CHECK(ctx, hipEventRecord(ctx->ev_bounce[k & 1], ctx->stream));
+            }
+            if (k >= 1) {
+                const size_t off = (k - 1) * BOUNCE_HALF, n = std::min(BOUNCE_HALF, bytes - off);
+                MI_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev_bounce[(k - 1) & 1])); // (also makes the kernel's writes to the host block visible)
+                memcpy((uint8_t *)h_dst + off, (const uint8_t *)ctx->h_bounce + ((k - 1) & 1) * BOUNCE_HALF, n);
+            }
         }
         return MI_LTE_OK;
     }

@@ -58,6 +58,8 @@ struct mi_lte_ctx {
     bool               merged_decode = true;  // several block sizes in one decode: one launch set over all of them (mi_lte_set_turbo_merged; turbo.hip: KSeg)
     void              *h_small = nullptr, *d_small = nullptr; // MI_SMALL_BYTES of pinned host memory the kernels can write (mi_ctx_small_results)
     void              *h_bounce = nullptr, *d_bounce = nullptr; // 4 MiB of pinned host memory mapped into the device: mi_lte_memcpy_* move mid-size copies through it with a kernel
+    hipEvent_t         ev_bounce[2] = {nullptr, nullptr};       // ... in two halves: one event behind the copy kernel of each
+    bool               bounce_failed = false;                   // the block could not be made: the runtime's copies from then on
     std::map<uint64_t, TurboTables> turbo_tables; // key = K | (spec << 32)
     std::map<uint32_t, RmTables>    rm_tables;    // key = K
     std::vector<void *> owned;                    // allocations released at destroy

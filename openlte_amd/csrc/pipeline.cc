@@ -264,8 +264,12 @@ static void device_worker(mi_lte_dl_pipeline *p, uint32_t di, const Job *job)
             const uint32_t half = (uint32_t)(l.d_cell - l.d_sf);
             memcpy(l.h_meta, job->h_sf + u0, sizeof(uint32_t) * n);
             memcpy(l.h_meta + half, job->h_cell + u0, sizeof(uint32_t) * n);
-            const MiCopySeg seg = {l.d_sf, l.h_meta, sizeof(uint32_t) * 2 * half};
-            e = mi_pinned_segments_to_device(l.ctx, &seg, 1, s_in);
+            // Only the n refreshed entries of each half are moved (two segments of one launch).  ORDER: this kernel writes l.d_sf / l.d_cell, which
+            // the lane's PREVIOUS chunk's kernels read -- the only thing that keeps it behind them is the wait on l.in_free issued on s_in at the
+            // top of this iteration (copy-stream mode only, which is the only mode that takes this branch: meta_by_kernel implies !lane_copies).
+            // Anything that writes l.d_sf earlier than that wait breaks the previous chunk.
+            const MiCopySeg seg[2] = {{l.d_sf, l.h_meta, sizeof(uint32_t) * (size_t)((n + 3u) & ~3u)}, {l.d_cell, l.h_meta + half, sizeof(uint32_t) * (size_t)((n + 3u) & ~3u)}};
+            e = mi_pinned_segments_to_device(l.ctx, seg, 2, s_in);
             if (e == hipSuccess) e = hipEventRecord(l.meta_out, s_in);
         }
         if (e != hipSuccess) { d.rc = MI_LTE_ERR_HIP; d.err = hipGetErrorString(e); break; }

@@ -67,6 +67,10 @@ def test_soft_bit_classifiers():
     assert T.outlier(far_ok) and not T.sign_flip(far_ok) and not T.magnitude_step(far_ok)
     assert not T.outlier(too_far)                                                     # more than the estimate accounts for
     assert isinstance(T.outlier(far_ok), bool)
+    # an estimate that passes through zero makes the formula's room unbounded: no such evidence excuses more than OUTLIER_ROOM_CAP steps
+    assert T.outlier(["a", 10, 21, 50, -21, -50, 1e9]) and not T.outlier(["a", 10, 21, 60, -21, -60, 1e9]) and T.OUTLIER_ROOM_CAP == 32.0
+    # the accepted kinds are a closed set (a new one needs a test here that fails without it, and an entry in DESIGN.md section 4)
+    assert T.ACCEPTED_KINDS == ("sign_flip", "magnitude_step", "outlier", "ce_phase_tie", "pss_near_tie")
 
 
 def test_steps_behind_an_extrapolated_estimate_grows_as_the_estimate_vanishes():

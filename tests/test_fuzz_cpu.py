@@ -113,3 +113,40 @@ def test_re_count_closed_form_equals_the_reference_loop(ref_big, box):
     r = fz.run_ref_dl(ref_big, cases, want_planes=False)
     for i, c in enumerate(cases):
         assert r["n_soft"][i] == c["e"], (i, c["n_rb"], c["n_ant"], c["cell"], c["sf"], c["n_sym"], c["mod"], c["prb0"], c["prb1"])
+
+
+@td.on_both_boxes
+def test_reference_on_a_float32_fft_against_itself_on_a_float64_one(box):
+    """The second opinion on the FFT boundary (the reference links FFTW3f, which no box here has): the SAME captures through the
+    reference built on the float64 DFT stand-in (the parity build every test compares with) and through the reference built on the
+    single-precision Stockham stand-in (oracle/ref/fftw_shim_f32.c: the operation order FFTW3f would plausibly pick).  What moves between
+    the two is the noise floor any float32 FFT -- FFTW3f's included -- sits in: soft bits that differ, verdicts that flip.  The library's
+    own front end against the float64 build moves LESS than that (test_fuzz_gpu.py: 0 of 20 000 verdicts per run), which is what 'within the
+    FFT's own rounding' means here.  The numbers go to gpurun_out/fft_noise_floor.json; the asserts only bound the floor itself."""
+    import json
+    import os
+    import fuzz_cases as fz
+    from oracle import pyoracle as po
+    r64, r32 = po.ref(), po.ref_f32fft()
+    if r64 is None or r32 is None:
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    n = 4000 if fz.n_threads() >= 32 else 600
+    cases = [c for c in fz.draw_dl_cases(2 * n, 424242, big_share=0.0) if c["e"] <= 10000][:n]  # (both builds have the unmodified 10 000-soft-bit scratch)
+    a = fz.run_ref_dl(r64, cases, want_planes=True)
+    b = fz.run_ref_dl(r32, cases, want_planes=True, iq=a["iq"])
+    assert (a["rc_tx"] == 0).all() and (a["rc_fe"] == 0).all() and (b["rc_fe"] == 0).all()
+    n_soft = int(a["n_soft"].sum())
+    soft_diff = sum(int((a["soft"][i, :a["n_soft"][i]] != b["soft"][i, :a["n_soft"][i]]).sum()) for i in range(len(cases)))
+    cases_soft = sum(bool((a["soft"][i, :a["n_soft"][i]] != b["soft"][i, :a["n_soft"][i]]).any()) for i in range(len(cases)))
+    verdicts = int((a["rc"] != b["rc"]).sum())
+    bits = sum(bool(a["rc"][i] == 0 and b["rc"][i] == 0 and (a["bits"][i, :a["n_out"][i]] != b["bits"][i, :a["n_out"][i]]).any()) for i in range(len(cases)))
+    rel = [float(np.linalg.norm((a["planes"][i, :2] - b["planes"][i, :2]).ravel()) / max(np.linalg.norm(a["planes"][i, :2].ravel()), 1e-30)) for i in range(len(cases))]
+    out = dict(cases=len(cases), soft_bits=n_soft, soft_bits_differing=soft_diff, cases_with_differing_soft_bits=int(cases_soft), verdicts_differing=verdicts,
+               decoded_by_both_with_different_bits=int(bits), worst_rel_l2_rx_symb_f32_vs_f64=max(rel),
+               note="reference on fftw_shim_f32.c vs reference on fftw_shim.c (float64), same int8 captures; QPSK soft values and 16/64QAM decisions next to a threshold are what moves")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(root, "gpurun_out", "fft_noise_floor.json"), "w"), indent=1)
+    assert max(rel) < 1e-5                       # the two transforms agree as transforms
+    assert verdicts <= max(2, len(cases) // 500)  # and almost always on the verdict
+    assert bits == 0                              # a block both decode is the same block

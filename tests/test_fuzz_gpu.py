@@ -174,7 +174,8 @@ def test_downlink_fuzz_against_the_compiled_reference(ctx, ref_big):
     assert stats["decoded"] >= 0.3 * total
     assert not stats["tol_fail"], stats["tol_fail"][:10]
     # own grid: a verdict may flip where a soft bit sits within float rounding of a decision boundary and the block is marginal
-    assert stats["own_same"] >= 0.995 * total, (stats["own_same"], total, stats["own_diff"][:10])
+    # (observed: 20 000 of 20 000 per run, 840 000 of 840 000 over round 5's soak; the gate was 0.5 % until round 6)
+    assert stats["own_same"] >= total - 2, (stats["own_same"], total, stats["own_diff"][:10])
 
 
 def test_uplink_fuzz_against_the_compiled_reference(ctx, ref):
@@ -243,7 +244,9 @@ def test_uplink_fuzz_against_the_compiled_reference(ctx, ref):
     assert all(sign_flip(v) or magnitude_step(v) or outlier(v) for v in soft_values), soft_values[:10]
     assert n_alloc >= 2500
     assert not bad, bad[:10]
-    assert n_soft_diff <= 1e-5 * n_soft and len(soft_diff) <= 0.005 * n_alloc, (n_soft_diff, n_soft, soft_diff[:10])
+    # (observed: ~1 of 7 million soft bits, in one of ~3 000 allocations; the gates were 1e-5 of the bits and 0.5 % of the allocations until round 6)
+    assert n_soft_diff <= 5e-7 * n_soft and len(soft_diff) <= 3, (n_soft_diff, n_soft, soft_diff[:10])
+    assert sum(bool(outlier(v) and not sign_flip(v) and not magnitude_step(v)) for v in soft_values) <= 2
     assert n_ok >= 0.4 * n_alloc
 
 
@@ -313,10 +316,19 @@ def steps_behind_an_extrapolated_estimate(g, u, prbs, s):
     return float(127 * np.sqrt(M) * 2e-7 / max(w * w, 1e-30))
 
 
+# (where the extrapolated magnitude passes through zero inside a symbol the formula's room is unbounded; no evidence of that kind excuses more than
+# a quarter of the de-mapper's range -- a de-mapper or transform regression confined to such allocations must still fail)
+OUTLIER_ROOM_CAP = 32.0
+# The set of accepted kinds of difference is FROZEN (sign_flip, magnitude_step, outlier, ce_phase_tie here; the PSS near tie in test_sync_gpu.py):
+# a new kind needs a CPU test in test_fuzz_classifiers_cpu.py that fails without it and an entry in DESIGN.md section 4 before it may be added.
+ACCEPTED_KINDS = ("sign_flip", "magnitude_step", "outlier", "ce_phase_tie", "pss_near_tie")
+
+
 def outlier(v):
     """a differing soft bit within the steps its symbol's weakest extrapolated estimate accounts for (at least two: below that it is one of
-    the two ordinary kinds or nothing)"""
-    return bool(v[6] >= 2 and abs(v[2] - v[3]) <= 1 + v[6] and abs(v[4] - v[5]) <= 1 + v[6])
+    the two ordinary kinds or nothing; at most OUTLIER_ROOM_CAP)"""
+    room = min(v[6], OUTLIER_ROOM_CAP)
+    return bool(v[6] >= 2 and abs(v[2] - v[3]) <= 1 + room and abs(v[4] - v[5]) <= 1 + room)
 
 
 def magnitude_step(v):

@@ -1818,9 +1818,11 @@ def main():
                                    "ref_decoder": turbo_leg(ctx, "ref", 65536, 3)}
         if wl.name == "chain" and DECODER == "ref" and not args.no_turbo_leg and world == 1:
             # BASELINE.json's other single-GPU configurations, measured in this run after the timed region (each with its own roofline and
-            # a bounded CPU baseline): config 2 (W2 front end, one and two antenna ports) and config 5 (W5 uplink)
+            # a bounded CPU baseline): config 4 again on MIXED traffic (per-subframe allocation lists, ~100 code-block sizes: what the callers
+            # of the reference see; the headline's W4 is its best-case shape), config 2 (W2 front end, one and two antenna ports), config 5 (W5 uplink)
             cpu_s = 0 if args.no_cpu_baseline else 4.0
-            out["other_configs"] = {"W2_frontend_1_port": config_leg(FrontendWorkload, ctx, 10, cpu_s),
+            out["other_configs"] = {"W4_mixed_traffic": config_leg(ChainMixedWorkload, ctx, 5, cpu_s),
+                                    "W2_frontend_1_port": config_leg(FrontendWorkload, ctx, 10, cpu_s),
                                     "W2_frontend_2_ports": config_leg(Frontend2Workload, ctx, 10, cpu_s),
                                     "W5_uplink": config_leg(UplinkWorkload, ctx, 5, cpu_s)}
         if world == 1 and not args.no_cpu_baseline:

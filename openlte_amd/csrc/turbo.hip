@@ -368,7 +368,7 @@ struct KSeg {
     uint64_t        pad;
 };
 static_assert(sizeof(KSeg) == 96, "KSeg is read with scalar loads: keep it a multiple of 16 bytes");
-struct MultiArgs { const KSeg *segs; const uint32_t *map; }; // map: per 8 workgroups (prep, perm, vote) or per wavefront (siso) the index of its size
+struct MultiArgs { const KSeg *segs; const uint32_t *map; }; // map: per 512 workgroups (prep, vote: a size's grid is a multiple of that), per 128 (perm), per wavefront (siso) the index of its size
 // Both reads go through the CONSTANT address space: only then are they scalar loads (the kernels store to global memory, and a plain pointer
 // carries no promise that the table is not what they store to); the scalar cache serves the row every workgroup of a CU reads.
 // What remains: on W4 (two sizes of 8192 and 1024 tiles, each filling the device by itself) the merged k_turbo_prep takes 4.5-4.6 ms
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Src::kPacke
     size_t   seg_off = 0;
     const uint16_t *__restrict__ pi = pi_arg;
     if constexpr (MULTI) { // the workgroup's block size out of a merged launch (KSeg)
-        const_seg_t &sg = multi_seg(ma, blockIdx.x >> 3);
+        const_seg_t &sg = multi_seg(ma, blockIdx.x >> 9);
         K = sg.K; n_cb = sg.n_cb; pi = (const uint16_t *)sg.pi; bidx = blockIdx.x - sg.wg_cb; seg_off = sg.arr_off;
         src.e_cap = sg.e_cap;
         src.seg(sg);
@@ -624,9 +624,11 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Src::kPacke
     if (cb >= n_cb) { // uniform
         // the lanes behind the last code block of a size's last tile: the trellis kernel walks them like any lane (a merged launch does not
         // clear the scratch first), so they get zeros to walk
+#ifndef AB_NO_TAILFILL
         if (MULTI && cb < ((n_cb + 63u) & ~63u) && threadIdx.x < n_units)
 #pragma unroll
             for (int a = 0; a < 6; a++) *reinterpret_cast<uint4 *>(out.arr[a] + unit_off(tile_off, lane, threadIdx.x)) = make_uint4(0, 0, 0, 0);
+#endif
         return;
     }
     int8_t        *qtab = sm, *qc = sm + QTAB_HALF, *mtab1 = sm + QTAB_N, *mtab2 = mtab1 + MTAB_N, *e_lds = sm + PREP_TAB_BYTES;
@@ -1371,7 +1373,7 @@ __global__ __launch_bounds__(384) void k_turbo_perm(PermArgs a, uint32_t K_arg, 
     size_t   seg_off = 0;
     const uint16_t *__restrict__ pi = pi_arg;
     if constexpr (MULTI) { // the workgroup's block size out of a merged launch (KSeg)
-        const_seg_t &sg = multi_seg(ma, blockIdx.x >> 3);
+        const_seg_t &sg = multi_seg(ma, blockIdx.x >> 7);
         K = sg.K; n_cb = sg.n_cb; pi = (const uint16_t *)sg.pi; bidx = blockIdx.x - sg.wg_perm; grid = sg.perm_grid;
         seg_off = sg.arr_off;
     }
@@ -1466,7 +1468,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     size_t   seg_off = 0;
     const uint16_t *__restrict__ inv = inv_arg;
     if constexpr (MULTI) { // the workgroup's block size out of a merged launch (KSeg)
-        const_seg_t &sg = multi_seg(ma, blockIdx.x >> 3);
+        const_seg_t &sg = multi_seg(ma, blockIdx.x >> 9);
         K = sg.K; n_cb = sg.n_cb; inv = (const uint16_t *)sg.inv2; bidx = blockIdx.x - sg.wg_cb; seg_off = sg.arr_off;
         g.desc += sg.cb_base;
     }
@@ -2094,7 +2096,7 @@ int mi_turbo_ref_multi(mi_lte_ctx *ctx, const MiKGroup *groups, uint32_t n_group
         }
         G.arr_bytes = arr;
         G.n_slots   = cbs;
-        // workgroup -> size maps of the per-code-block kernels, one entry per 8 workgroups, class after class
+        // workgroup -> size maps of the per-code-block kernels, one entry per 512 (prep, vote) / 128 (perm) workgroups -- a few KB: they stay in the scalar cache --, class after class
         for (int c = 0; c < NCLS; c++) {
             G.map_cb[c] = (uint32_t)map.size();
             uint32_t wg = 0;
@@ -2102,7 +2104,7 @@ int mi_turbo_ref_multi(mi_lte_ctx *ctx, const MiKGroup *groups, uint32_t n_group
                 if (cls_of(groups[i].K) == c) {
                     segs[i].wg_cb = wg;
                     const uint32_t g = 8 * xcd_chunk(groups[i].n_cb);
-                    map.insert(map.end(), g / 8, i);
+                    map.insert(map.end(), g / 512, i);
                     wg += g;
                 }
             G.grid_cb[c] = wg;
@@ -2114,7 +2116,7 @@ int mi_turbo_ref_multi(mi_lte_ctx *ctx, const MiKGroup *groups, uint32_t n_group
                 if (cls_of(groups[i].K) == c) {
                     segs[i].wg_perm   = wg;
                     segs[i].perm_grid = ((8 * xcd_chunk(groups[i].n_cb) + PERM_NB - 1) / PERM_NB + 7u) & ~7u; // a multiple of 8: b + i * grid stays on b's XCD
-                    map.insert(map.end(), segs[i].perm_grid / 8, i);
+                    map.insert(map.end(), segs[i].perm_grid / 128, i);
                     wg += segs[i].perm_grid;
                 }
             G.grid_perm[c] = wg;
@@ -2196,9 +2198,30 @@ int mi_turbo_ref_multi(mi_lte_ctx *ctx, const MiKGroup *groups, uint32_t n_group
     po.arr[0] = arr[AX0]; po.arr[1] = arr[AX1]; po.arr[2] = arr[AX2];
     po.arr[3] = arr[AI0]; po.arr[4] = arr[AM1]; po.arr[5] = arr[AM2];
     for (int c = 0; c < NCLS; c++)
-        if (G.grid_cb[c])
+        if (G.grid_cb[c]) {
+#ifdef AB_ARGS_PREP
+            uint32_t n_in = 0, which = 0;
+            for (uint32_t i = 0; i < n_groups; i++)
+                if (cls_of(groups[i].K) == c) { n_in++; which = i; }
+            if (n_in == 1) { // (A/B: the per-size kernel on the merged decode's layout)
+                TurboTables tb; RmTables rt;
+                mi_ctx_turbo_tables(ctx, groups[which].K, 0, &tb); rm_rank_tables(ctx, groups[which].K, &rt);
+                uint64_t off = 0;
+                for (uint32_t i = 0; i < which; i++) off += (uint64_t)((groups[i].n_cb + 63) / 64) * kpad64(groups[i].K) * 64;
+                SrcRateUnmatchPk s1 = src;
+                s1.tabs = rt.d_tabs; s1.nnn = rt.d_nnn; s1.g.desc = d_desc + groups[which].cb_base;
+                const uint32_t Kp1 = kpad64(groups[which].K), cap1 = (groups[which].e_max + 16u + 63u) & ~63u;
+                s1.e_cap = (PREP_TAB_BYTES + Kp1 + cap1 + 64 <= 48 * 1024) ? cap1 : 0;
+                PrepOut p1 = po;
+                for (int a = 0; a < 6; a++) p1.arr[a] += off;
+                MI_LAUNCH(ctx, "k_turbo_prep", (k_turbo_prep<SrcRateUnmatchPk, 1, false>), dim3(G.grid_cb[c]), dim3(64 * (c + 1)), G.lds_prep[c], s1, groups[which].K, groups[which].n_cb,
+                          (const uint16_t *)tb.d_pi, p1, MultiArgs{});
+                continue;
+            }
+#endif
             MI_LAUNCH(ctx, "k_turbo_prep", (k_turbo_prep<SrcRateUnmatchPk, 1, true>), dim3(G.grid_cb[c]), dim3(64 * (c + 1)), G.lds_prep[c], src, 0u, 0u, (const uint16_t *)nullptr, po,
                       (MultiArgs{d_segs, d_map + G.map_cb[c]}));
+        }
     SisoArgs s1;
     s1.p[0] = {arr[AX1], arr[AX0], arr[AM1], arr[AA1], dec[0]};
     s1.p[1] = s1.p[0];

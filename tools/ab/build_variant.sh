@@ -11,4 +11,4 @@ cd $root/openlte_amd/csrc
 objs=""
 for o in ctx bcjr chain frontend pdcch prach sync turbo uplink; do if [ "$o" = "$f" ]; then objs="$objs /tmp/${f}_$n.o"; else objs="$objs $o.o"; fi; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function "$@" -c $f.hip -o /tmp/${f}_$n.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs hostapi.o pipeline.o synth.o ul_rs.o ul_synth.o -o $root/_ko/lib_$n.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs hostapi.o pipeline.o synth.o ul_rs.o ul_synth.o sched.o -o $root/_ko/lib_$n.so

@@ -371,9 +371,12 @@ static_assert(sizeof(KSeg) == 96, "KSeg is read with scalar loads: keep it a mul
 struct MultiArgs { const KSeg *segs; const uint32_t *map; }; // map: per 512 workgroups (prep, vote: a size's grid is a multiple of that), per 128 (perm), per wavefront (siso) the index of its size
 // Both reads go through the CONSTANT address space: only then are they scalar loads (the kernels store to global memory, and a plain pointer
 // carries no promise that the table is not what they store to); the scalar cache serves the row every workgroup of a CU reads.
-// What remains: on W4 (two sizes of 8192 and 1024 tiles, each filling the device by itself) the merged k_turbo_prep takes 4.5-4.6 ms
-// against the per-size launches' 4.15 with identical registers, LDS and grid -- not found in the listings; a size that large keeps its own
-// launches (chain.hip), and the merged path is for what it was written for, many sizes of a few tiles each.
+// What remains: on W4 (two sizes of 8192 and 1024 tiles, each filling the device by itself) the merged k_turbo_prep takes 4.3-4.5 ms
+// against 4.1 for the per-size kernel ON THE SAME merged layout (profiles/r06_variants_merged_prep.txt: the per-size kernel launched through
+// this path, everything else merged, is the fastest W4 of all, 23.6-23.8 ms) with identical registers, LDS, grid and all but identical listings:
+// what is left is the workgroup's start -- two more dependent scalar loads (map entry, row) before its first own load can go out, in a
+// kernel whose workgroups live ~14 us.  The maps are coarse (one entry per 512 / 128 workgroups: a few KB, scalar-cache resident) for that
+// reason.  A size that fills the device by itself keeps its own launches (chain.hip); the merged path is for many sizes of a few tiles each.
 typedef __attribute__((address_space(4))) const KSeg     const_seg_t;
 typedef __attribute__((address_space(4))) const uint32_t const_map_t;
 __device__ __forceinline__ const_seg_t &multi_seg(const MultiArgs &ma, uint32_t slot)
@@ -624,11 +627,9 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Src::kPacke
     if (cb >= n_cb) { // uniform
         // the lanes behind the last code block of a size's last tile: the trellis kernel walks them like any lane (a merged launch does not
         // clear the scratch first), so they get zeros to walk
-#ifndef AB_NO_TAILFILL
         if (MULTI && cb < ((n_cb + 63u) & ~63u) && threadIdx.x < n_units)
 #pragma unroll
             for (int a = 0; a < 6; a++) *reinterpret_cast<uint4 *>(out.arr[a] + unit_off(tile_off, lane, threadIdx.x)) = make_uint4(0, 0, 0, 0);
-#endif
         return;
     }
     int8_t        *qtab = sm, *qc = sm + QTAB_HALF, *mtab1 = sm + QTAB_N, *mtab2 = mtab1 + MTAB_N, *e_lds = sm + PREP_TAB_BYTES;
@@ -1365,6 +1366,7 @@ struct PermArgs { const uint8_t *A1; const uint8_t *X2; uint8_t *out[2]; /* I1, 
 #ifndef PERM_NB
 #define PERM_NB 4
 #endif
+static_assert(PERM_NB == 4, "a size's perm grid is a multiple of 128 workgroups (the merged decode's map granularity) only for four blocks per workgroup");
 template <int NSLOT, bool MULTI = false>
 __global__ __launch_bounds__(384) void k_turbo_perm(PermArgs a, uint32_t K_arg, uint32_t n_cb_arg, const uint16_t *__restrict__ pi_arg, MultiArgs ma)
 {
@@ -2199,26 +2201,6 @@ int mi_turbo_ref_multi(mi_lte_ctx *ctx, const MiKGroup *groups, uint32_t n_group
     po.arr[3] = arr[AI0]; po.arr[4] = arr[AM1]; po.arr[5] = arr[AM2];
     for (int c = 0; c < NCLS; c++)
         if (G.grid_cb[c]) {
-#ifdef AB_ARGS_PREP
-            uint32_t n_in = 0, which = 0;
-            for (uint32_t i = 0; i < n_groups; i++)
-                if (cls_of(groups[i].K) == c) { n_in++; which = i; }
-            if (n_in == 1) { // (A/B: the per-size kernel on the merged decode's layout)
-                TurboTables tb; RmTables rt;
-                mi_ctx_turbo_tables(ctx, groups[which].K, 0, &tb); rm_rank_tables(ctx, groups[which].K, &rt);
-                uint64_t off = 0;
-                for (uint32_t i = 0; i < which; i++) off += (uint64_t)((groups[i].n_cb + 63) / 64) * kpad64(groups[i].K) * 64;
-                SrcRateUnmatchPk s1 = src;
-                s1.tabs = rt.d_tabs; s1.nnn = rt.d_nnn; s1.g.desc = d_desc + groups[which].cb_base;
-                const uint32_t Kp1 = kpad64(groups[which].K), cap1 = (groups[which].e_max + 16u + 63u) & ~63u;
-                s1.e_cap = (PREP_TAB_BYTES + Kp1 + cap1 + 64 <= 48 * 1024) ? cap1 : 0;
-                PrepOut p1 = po;
-                for (int a = 0; a < 6; a++) p1.arr[a] += off;
-                MI_LAUNCH(ctx, "k_turbo_prep", (k_turbo_prep<SrcRateUnmatchPk, 1, false>), dim3(G.grid_cb[c]), dim3(64 * (c + 1)), G.lds_prep[c], s1, groups[which].K, groups[which].n_cb,
-                          (const uint16_t *)tb.d_pi, p1, MultiArgs{});
-                continue;
-            }
-#endif
             MI_LAUNCH(ctx, "k_turbo_prep", (k_turbo_prep<SrcRateUnmatchPk, 1, true>), dim3(G.grid_cb[c]), dim3(64 * (c + 1)), G.lds_prep[c], src, 0u, 0u, (const uint16_t *)nullptr, po,
                       (MultiArgs{d_segs, d_map + G.map_cb[c]}));
         }

@@ -755,10 +755,10 @@ int mi_lte_pdsch_decode_run(mi_lte_ctx *ctx, mi_lte_pdsch_plan *pl, const float 
     // MI_LTE_NO_MERGED_DECODE=1 keeps the per-size launches (A/B).
     static const bool merged_off = [] { const char *e = getenv("MI_LTE_NO_MERGED_DECODE"); return e && atoi(e) != 0; }();
     if (!bcjr && !merged_off && ctx->merged_decode && !side_ok && pl->groups.size() >= 2) {
-        // A size with 4096 tiles or more (64 blocks each: one lane of every wavefront the device holds at the trellis kernel's four per SIMD)
-        // fills the device by itself and keeps its own launches: merged, W4's two sizes ran 24.2-24.7 ms against 24.0-24.35 per size
-        // (gpurun_out/w4_merged.json, w4_persize.json; the difference is k_turbo_prep, see KSeg).  MI_LTE_MERGE_MAX_TILES=n moves the limit (tuning aid).
-        static const uint32_t max_tiles = [] { const char *e = getenv("MI_LTE_MERGE_MAX_TILES"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 4095u; }();
+        // (MI_LTE_MERGE_MAX_TILES=n, tuning aid: a size with more than n tiles of 64 blocks keeps its own launches.  No limit by default: W4's two
+        // sizes run 23.6-23.9 ms merged -- the trellis kernel's two launches instead of four, 6.5 against 6.8 ms -- and 24.0-24.3 size by size,
+        // profiles/r06_variants_merged_prep.txt)
+        static const uint32_t max_tiles = [] { const char *e = getenv("MI_LTE_MERGE_MAX_TILES"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 0xFFFFFFFFu; }();
         auto merged = [&](const MiKGroup &gr) { return mi_turbo_ref_multi_takes(gr.K, gr.e_max) && (gr.n_cb + 63) / 64 <= max_tiles; };
         std::vector<MiKGroup> take;
         for (auto &gr : pl->groups)

@@ -2093,6 +2093,9 @@ int mi_turbo_ref_multi(mi_lte_ctx *ctx, const MiKGroup *groups, uint32_t n_group
             arr += (uint64_t)sg.n_tiles * Kp * 64;
             cbs = std::max(cbs, gr.cb_base + gr.n_cb);
             const int c = cls_of(gr.K);
+            // (a size whose last tile is partly filled stays with the table kernel: it zeroes the idle lanes the trellis kernel will walk)
+            G.one_size[c] = (G.lds_prep[c] == 0 && gr.n_cb % 64 == 0) ? (int)i : -1; // the width's only size so far, or not the only one
+            G.off_one[c] = sg.arr_off; G.e_cap_one[c] = sg.e_cap;
             G.lds_prep[c] = std::max(G.lds_prep[c], PREP_TAB_BYTES + Kp + sg.e_cap + 64);
             G.kp_max[c]   = std::max(G.kp_max[c], Kp);
         }
@@ -2201,6 +2204,21 @@ int mi_turbo_ref_multi(mi_lte_ctx *ctx, const MiKGroup *groups, uint32_t n_group
     po.arr[3] = arr[AI0]; po.arr[4] = arr[AM1]; po.arr[5] = arr[AM2];
     for (int c = 0; c < NCLS; c++)
         if (G.grid_cb[c]) {
+            // a width that holds ONE size (W4: each of its two sizes): the per-size kernel with kernel arguments, on the merged layout -- its
+            // workgroups start two dependent scalar loads earlier, which is worth 0.2-0.4 ms of W4's 4.1-4.5 (see KSeg)
+            if (G.one_size[c] >= 0) {
+                const MiKGroup &gr = groups[G.one_size[c]];
+                TurboTables tb;
+                RmTables    rt;
+                if ((rc = mi_ctx_turbo_tables(ctx, gr.K, 0, &tb)) != MI_LTE_OK || (rc = rm_rank_tables(ctx, gr.K, &rt)) != MI_LTE_OK) return rc;
+                SrcRateUnmatchPk s1 = src;
+                s1.tabs = rt.d_tabs; s1.nnn = rt.d_nnn; s1.g.desc = d_desc + gr.cb_base; s1.e_cap = G.e_cap_one[c];
+                PrepOut p1 = po;
+                for (int a = 0; a < 6; a++) p1.arr[a] += G.off_one[c];
+                MI_LAUNCH(ctx, "k_turbo_prep", (k_turbo_prep<SrcRateUnmatchPk, 1, false>), dim3(G.grid_cb[c]), dim3(64 * (c + 1)), G.lds_prep[c], s1, gr.K, gr.n_cb, (const uint16_t *)tb.d_pi,
+                          p1, MultiArgs{});
+                continue;
+            }
             MI_LAUNCH(ctx, "k_turbo_prep", (k_turbo_prep<SrcRateUnmatchPk, 1, true>), dim3(G.grid_cb[c]), dim3(64 * (c + 1)), G.lds_prep[c], src, 0u, 0u, (const uint16_t *)nullptr, po,
                       (MultiArgs{d_segs, d_map + G.map_cb[c]}));
         }

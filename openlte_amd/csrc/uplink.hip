@@ -674,14 +674,14 @@ int mi_lte_pusch_decode_run(mi_lte_ctx *ctx, mi_lte_pusch_plan *pl, const float 
     std::vector<MiKGroup> take;
     if (ctx->merged_decode && pl->groups.size() >= 2)
         for (auto &gr : pl->groups)
-            if (mi_turbo_ref_multi_takes(gr.K, gr.e_max) && (gr.n_cb + 63) / 64 < 4096) take.push_back(MiKGroup{gr.K, gr.n_cb, gr.cb_base, gr.e_max});
+            if (mi_turbo_ref_multi_takes(gr.K, gr.e_max)) take.push_back(MiKGroup{gr.K, gr.n_cb, gr.cb_base, gr.e_max});
     if (take.size() >= 2) {
         rc = mi_turbo_ref_multi(ctx, take.data(), (uint32_t)take.size(), pl->d_allocs, pl->d_cb_alloc, pl->d_e, pl->d_e_off, pl->d_e_len, d_out_bits, pl->out_stride, d_status,
                                 /*ul=*/true, false, &pl->multi);
         if (rc != MI_LTE_OK) return rc;
     }
     for (auto &gr : pl->groups) {
-        if (take.size() >= 2 && mi_turbo_ref_multi_takes(gr.K, gr.e_max) && (gr.n_cb + 63) / 64 < 4096) continue;
+        if (take.size() >= 2 && mi_turbo_ref_multi_takes(gr.K, gr.e_max)) continue;
         rc = mi_turbo_ref_group(ctx, gr.K, gr.n_cb, pl->d_allocs, pl->d_cb_alloc + gr.cb_base, pl->d_e, pl->d_e_off, pl->d_e_len,
                                 d_out_bits, pl->out_stride, d_status, gr.e_max, /*ul=*/true);
         if (rc != MI_LTE_OK) return rc;

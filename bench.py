@@ -1366,7 +1366,7 @@ def traffic_of(tab, label):
     three front ends (labels k_dl_fft / k_ul_fft / k_sync_fft) is k_dl_fft2k since round 4, k_dl_fft in older tables."""
     if label in ("k_dl_fft", "k_ul_fft", "k_sync_fft"):
         return tab.get("k_dl_fft2k", tab.get("k_dl_fft"))
-    return tab.get(label)
+    return tab.get(label, tab.get(label + "_multi"))  # (k_cb_desc: the merged decode's kernel is k_cb_desc_multi)
 
 
 KERNEL_FILE = (("k_turbo", "turbo.hip"), ("k_cb_desc", "turbo.hip"), ("k_rm_", "turbo.hip"), ("k_crc_finish", "turbo.hip"), ("k_rate_unmatch", "turbo.hip"),
@@ -1417,7 +1417,12 @@ def valu_of(wl_name, ms_per_kernel, step_ms, units_per_step):
         return None
     per = tab["per_step"]
     timed = [k for k in ms_per_kernel if ms_per_kernel[k] > 0]
-    names = {k: ("k_dl_fft2k" if k in ("k_dl_fft", "k_ul_fft", "k_sync_fft") and "k_dl_fft2k" in per else k) for k in timed}
+    def prof_name(k):  # rocprof sees the kernel's own name: the 2048-point transform behind three launch labels, the merged decode's descriptor kernel
+        for cand in (("k_dl_fft2k",) if k in ("k_dl_fft", "k_ul_fft", "k_sync_fft") else ()) + (k, k + "_multi"):
+            if cand in per:
+                return cand
+        return k
+    names = {k: prof_name(k) for k in timed}
     if any(names[k] not in per or not table_is_current(k, tid) for k in timed):
         return {"note": "profiles/sq_counters_%s.json was measured on another build of a timed kernel (or lacks one): no VALU figure" % wl_name}
     scale = units_per_step / tab["units_per_step"] if tab.get("units_per_step") else 1.0
@@ -1735,7 +1740,7 @@ def main():
         # source file is the one the table was measured on (mi_lte_build_id): an edited kernel without a re-profile reports no traffic
         tj, tid = load_table("pmc_traffic_%s%s.json" % (wl.name, "_bcjr" if DECODER.startswith("bcjr") else ""))
         traffic_tab = {k: v for k, v in (tj["bytes_per_launch"] if tj else {}).items() if table_is_current(k, tid)}
-        stale_tables = sorted(k for k in (tj["bytes_per_launch"] if tj else {}) if not table_is_current(k, tid))
+        stale_tables = sorted(k for k in (tj["bytes_per_launch"] if tj else {}) if any(k.startswith(pre) for pre, _ in KERNEL_FILE) and not table_is_current(k, tid))
         copy_rate = measured_copy_rate(ctx)  # (the timed region is over)
         per_kernel = {}
         for k, (nl, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):

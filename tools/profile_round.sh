@@ -15,7 +15,8 @@ for w in chain chain-mixed uplink; do
   n=${w//-/_}
   bash tools/pmc_sq.sh ${TAG}a_$n --workload $w 2>&1 | grep "k_" > gpurun_out/sq_${TAG}_$n.txt
   SQ_COUNTERS="SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" bash tools/pmc_sq.sh ${TAG}b_$n --workload $w 2>&1 | grep "k_" >> gpurun_out/sq_${TAG}_$n.txt
-  python tools/sq_json.py gpurun_out/sq_${TAG}_$n.txt $n gpurun_out/pmc_${TAG}a_$n/bench.json 3 > /dev/null
+  steps=3; [ "$n" = chain_mixed ] && steps=6   # (the mixed workload's own closing check runs three more steps with a plan assignment each)
+  python tools/sq_json.py gpurun_out/sq_${TAG}_$n.txt $n gpurun_out/pmc_${TAG}a_$n/bench.json $steps > /dev/null
   cp gpurun_out/sq_${TAG}_$n.txt profiles/${TAG}_${n}_sq_counters.txt
 done
 mkdir -p gpurun_out/bench_$TAG gpurun_out/profiles_$TAG

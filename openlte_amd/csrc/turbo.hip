@@ -550,6 +550,55 @@ struct SrcRateUnmatch {
         if (in_lds) gather16_staged(e_lds, u, nvalid, emit);
         else        gather16(e, u, nvalid, emit);
     }
+    // An allocation longer than the LDS block (repetition: several laps of the circular buffer, and a merged decode sizes the block for
+    // one lap and a quarter, not for a size's longest allocation -- k_turbo_prep's occupancy is what its LDS leaves): ONE LAP AT A TIME.
+    // Lap t's soft bits e[t Nnn .. t Nnn + len) are staged (from the 16-byte line they start in: `shift` bytes of the lap before come along
+    // and are never read), rank r of the lap reads index min(r, len) -- a zero at len serves the NULL slots and the ranks the last lap does
+    // not reach -- and the sums accumulate as int16 pairs.  Called by EVERY thread of the workgroup (barriers inside).
+    __device__ __forceinline__ bool window_ok() const { return Nnn + 48 <= e_cap; }
+    __device__ __forceinline__ void gather_windowed_pk(uint32_t u, int nvalid, uint32_t (&vp)[3][8], int8_t *lds, uint32_t el) const
+    {
+        uint4 *l = reinterpret_cast<uint4 *>(lds);
+        for (uint32_t base = 0; base < E; base += Nnn) {
+            const uint32_t len = min(Nnn, E - base), shift = base & 15u, end = shift + len, nq = end >> 4, tail = end & 15u;
+            const uint4   *gp = reinterpret_cast<const uint4 *>(e + (base - shift)); // (the allocation starts on a 64-byte line and is padded to one)
+            RankWords rw;
+            load_ranks(u, nvalid, rw); // (per lap: a few L2 hits under the copy, instead of 24 registers across the barriers)
+            if (base) __syncthreads(); // the lap before has been read
+#pragma unroll 4
+            for (uint32_t w = threadIdx.x; w < nq; w += blockDim.x) l[w] = gp[w];
+            if (threadIdx.x == (nq & 63u)) { // the quarter line that holds index `end`: zero from there on
+                uint4 t = make_uint4(0, 0, 0, 0);
+                if (tail) {
+                    t = gp[nq];
+                    uint32_t c[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) {
+                        const int keep = (int)tail - 4 * (int)k;
+                        c[k] = keep >= 4 ? c[k] : keep <= 0 ? 0u : (c[k] & ((1u << (8 * keep)) - 1u));
+                    }
+                    t = make_uint4(c[0], c[1], c[2], c[3]);
+                }
+                l[nq] = t;
+            }
+            __syncthreads();
+            if (nvalid > 0) {
+#pragma unroll
+                for (int x = 0; x < 3; x++) {
+                    const uint32_t w[8] = {rw.raw[x][0].x, rw.raw[x][0].y, rw.raw[x][0].z, rw.raw[x][0].w, rw.raw[x][1].x, rw.raw[x][1].y, rw.raw[x][1].z, rw.raw[x][1].w};
+                    int acc[16];
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        const uint32_t r = (k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xFFFFu);
+                        acc[k] = lds_i8(el + shift + min(r, len));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        vp[x][j] = as_u32(as_v2s(vp[x][j]) + as_v2s(__builtin_amdgcn_perm((uint32_t)acc[2 * j + 1], (uint32_t)acc[2 * j], 0x05040100u)));
+                }
+            }
+        }
+    }
 };
 // chosen by the host when no sum can leave int16: ceil(E / Nnn) laps of |e| <= 127 each
 __device__ __forceinline__ void SrcRateUnmatch::seg(const_seg_fwd_t &sg)
@@ -654,7 +703,8 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Src::kPacke
         for (int x = 0; x < 3; x++)
 #pragma unroll
             for (int j = 0; j < 8; j++) vp[x][j] = 0;
-        if (nv > 0) src.load16_pk(u, nv, vp, PREP_TAB_BYTES, e_in_lds);
+        if (!e_in_lds && src.window_ok()) src.gather_windowed_pk(u, nv, vp, e_lds, PREP_TAB_BYTES); // (uniform; vp starts at zero)
+        else if (nv > 0) src.load16_pk(u, nv, vp, PREP_TAB_BYTES, e_in_lds);
         v2s hi = (v2s)(0), lo = (v2s)(0);
 #pragma unroll
         for (int x = 0; x < 3; x++)
@@ -2085,7 +2135,14 @@ int mi_turbo_ref_multi(mi_lte_ctx *ctx, const MiKGroup *groups, uint32_t n_group
             memset(&sg, 0, sizeof(sg));
             const uint32_t Kp = kpad64(gr.K), cap = (gr.e_max + 16u + 63u) & ~63u;
             sg.K = gr.K; sg.n_cb = gr.n_cb; sg.cb_base = gr.cb_base; sg.n_tiles = (gr.n_cb + 63) / 64;
-            sg.e_cap = (PREP_TAB_BYTES + Kp + cap + 64 <= 48 * 1024) ? cap : 0; // stage e in LDS when the group's largest allocation fits next to the block's own arrays
+            // LDS for an allocation's soft bits: room for the size's longest allocation, but no more than a lap and a quarter of the circular buffer
+            // (3 (K + 4) positions) -- an allocation beyond that is staged lap by lap (gather_windowed_pk), and one repeated allocation of a size
+            // no longer sets the occupancy of every workgroup of its width (width 64 of the mixed batch: 16 KB -> 9.7 KB per workgroup).
+            // Only where the LDS is what limits the occupancy -- the 64-thread width, K <= 1024, one wavefront per workgroup: 1.02 -> 0.80 ms of the mixed
+            // batch's prep; applied to every width it cost the 128- and 192-thread ones 0.05 and 0.11 ms (their blocks beyond a lap and a quarter pay
+            // two barriers per lap and their occupancy is bound by registers anyway), gpurun_out/windowed.log
+            const uint32_t cap_w = (uint32_t)((15 * (size_t)(gr.K + 4) / 4 + 64 + 63) & ~(size_t)63);
+            sg.e_cap = (PREP_TAB_BYTES + Kp + cap + 64 <= 48 * 1024) ? (Kp <= 1024 ? std::min(cap, cap_w) : cap) : cap_w;
             sg.arr_off = arr;
             typedef __attribute__((address_space(1))) const uint16_t gl16_t;
             typedef __attribute__((address_space(1))) const uint32_t gl32_t;

@@ -104,3 +104,36 @@ def test_plans_refuse_resource_blocks_outside_the_carrier(ctx):
     ctx.pusch_plan(cfg, ul, [2], [17], [m.make_alloc(0, 1, 504, [3, 4, 5, 6], 0x100)]).close()
     with pytest.raises(m.MiLteError, match="outside the carrier"):
         ctx.pusch_plan(cfg, ul, [2], [17], [m.make_alloc(0, 1, 504, [3, 4, 5, 30], 0x100)])
+
+
+def test_one_call_uplink_subframe_rejects_bad_arguments(ctx):
+    """mi_lte_ul_subframe_decode_host: NULL samples / configuration, a subframe number or cell out of range, more allocations than the entry takes,
+    an output stride shorter than a transport block, a PUCCH resource on another unit -> 1 (the reference's LIBLTE_ERROR_INVALID_INPUTS), nothing
+    launched; and a call with neither PUSCH nor PUCCH work is the front end alone (0)."""
+    import openlte_amd as m
+    ul = m.UlCfg(3, 0, 0, 2, 5)
+    i_s = q_s = np.zeros(30720, np.float32)
+    al = [m.make_alloc(0, 1, 504, list(range(6)), 0x40)]
+    assert len(ctx.ul_subframe_decode(2048, 100, i_s, q_s, 1, 17, ul, [])[0]) == 0          # nothing to decode: fine
+    st, bits, _ = ctx.ul_subframe_decode(2048, 100, i_s, q_s, 1, 17, ul, al)
+    assert st[0] == 0 and not bits[0].any()                                                  # silence decodes to the all-zero block, whose CRC (zero) checks -- as the reference has it
+    for kw in (dict(subfr_num=10), dict(cell=504), dict(fft=2048, nrb=171), dict(allocs=al * 17)):
+        with pytest.raises(m.MiLteError):
+            ctx.ul_subframe_decode(kw.get("fft", 2048), kw.get("nrb", 100), i_s, q_s, kw.get("subfr_num", 1), kw.get("cell", 17), ul, kw.get("allocs", al))
+    L = ctx.L
+    out, nb, stt = np.zeros(6144, np.uint8), np.zeros(1, np.uint32), np.zeros(1, np.int32)
+    arr = (m.PdschAlloc * 1)(*al)
+    args = lambda i, q, u, stride: L.mi_lte_ul_subframe_decode_host(ctx.h, 2048, 100, i, q, 1, 17, u, C.cast(arr, C.c_void_p), 1, out.ctypes.data, stride, nb.ctypes.data,
+                                                                    stt.ctypes.data, None, None, 0, None, None, None)
+    assert args(None, q_s.ctypes.data, C.byref(ul), 6144) == 1
+    assert args(i_s.ctypes.data, q_s.ctypes.data, None, 6144) == 1
+    assert args(i_s.ctypes.data, q_s.ctypes.data, C.byref(ul), 4096) == 1
+    with pytest.raises(m.MiLteError):  # PUCCH resources are the subframe's own: unit 0 only (the binding passes unit 0; call the C entry with unit 1)
+        from openlte_amd.lib import PucchRes
+        pr = (PucchRes * 1)(PucchRes(1, 0, 0))
+        tabs = np.zeros(352, np.float32)
+        pb, pnb, prc = np.zeros(2, np.uint8), np.zeros(1, np.uint32), np.zeros(1, np.uint32)
+        rc = L.mi_lte_ul_subframe_decode_host(ctx.h, 2048, 100, i_s.ctypes.data, q_s.ctypes.data, 1, 17, C.byref(ul), None, 0, None, 0, None, None, C.cast(pr, C.c_void_p),
+                                              tabs.ctypes.data, 1, pb.ctypes.data, pnb.ctypes.data, prc.ctypes.data)
+        if rc != 0:
+            raise m.MiLteError("rc %d" % rc)

@@ -244,8 +244,12 @@ def test_uplink_fuzz_against_the_compiled_reference(ctx, ref):
     assert all(sign_flip(v) or magnitude_step(v) or outlier(v) for v in soft_values), soft_values[:10]
     assert n_alloc >= 2500
     assert not bad, bad[:10]
-    # (observed: ~1 of 7 million soft bits, in one of ~3 000 allocations; the gates were 1e-5 of the bits and 0.5 % of the allocations until round 6)
-    assert n_soft_diff <= 5e-7 * n_soft and len(soft_diff) <= 3, (n_soft_diff, n_soft, soft_diff[:10])
+    # Observed per run of ~8 million soft bits / ~3 200 allocations: 0 to 6 differing bits in 0 to 4 allocations (54 seeds: profiles/r05_fuzz_soak,
+    # profiles/r06_fuzz_soak -- a magnitude step moves both bits of its symbol, so the counts come in pairs), every one of an accepted kind and none
+    # with a verdict behind it.  The gates are twice the worst run seen; until round 6 they were 1e-5 of the bits (80) and 0.5 % of the allocations (15).
+    # (Round 6 first set them at 5e-7 / 3 allocations from the one run the review quoted: seeds 149, 153 and 155 of the next soak had 5, 5 and 6 bits.)
+    assert n_soft_diff <= 12 and len(soft_diff) <= 8, (n_soft_diff, n_soft, soft_diff[:10])
+    assert verdict_diff_after_soft_diff == 0
     assert sum(bool(outlier(v) and not sign_flip(v) and not magnitude_step(v)) for v in soft_values) <= 2
     assert n_ok >= 0.4 * n_alloc
 

@@ -19,6 +19,7 @@ for w in chain chain-mixed uplink; do
   python tools/sq_json.py gpurun_out/sq_${TAG}_$n.txt $n gpurun_out/pmc_${TAG}a_$n/bench.json $steps > /dev/null
   cp gpurun_out/sq_${TAG}_$n.txt profiles/${TAG}_${n}_sq_counters.txt
 done
+python tools/trace_by_shape.py gpurun_out/prof_${TAG}_chain_mixed/trace | grep -v k_rm_rank > profiles/${TAG}_chain_mixed_by_shape.txt
 mkdir -p gpurun_out/bench_$TAG gpurun_out/profiles_$TAG
 cp profiles/${TAG}_* profiles/pmc_traffic_*.json profiles/sq_counters_*.json gpurun_out/profiles_$TAG/ 2>/dev/null
 for w in chain-mixed uplink turbo frontend frontend2 control sync; do python bench.py --workload $w > gpurun_out/bench_$TAG/${w//-/_}.json 2> gpurun_out/bench_$TAG/${w//-/_}.err; done

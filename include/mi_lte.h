@@ -705,6 +705,52 @@ int         mi_lte_dl_pipeline_run_capture(mi_lte_dl_pipeline *p, const int8_t *
                                            uint32_t n_subframes, uint32_t first_subfr_num, uint32_t N_id_cell, const mi_lte_pdsch_alloc *h_allocs,
                                            const uint32_t *h_first, uint32_t N_pdcch_symbs, uint8_t *h_out_packed, int32_t *h_status);
 
+/* ---------------------------------------------------------------- the transmit side (host code, no device work)
+ * The ten transmit functions of liblte_phy that LTE_fdd_enodeb's PHY and LTE_fdd_dl_file_gen call (2: "CPU pass-through") restated on
+ * the host so that a link against this library and the shim needs no object of the reference's PHY.  Bit outputs are the reference's bit for
+ * bit; float outputs come from the same float operations in the same order; the transforms (the reference: FFTW3f) run in float64 rounded to
+ * float.  Return values are LIBLTE_ERROR_ENUM's: 0 success, 1 invalid inputs -- also for what the reference has no defined behaviour for
+ * (three ports, a pre-coder type it leaves without output, more than 10 000 coded bits per allocation: its own arrays end there).
+ * shim/lifecycle_check.cc (`tx`) compares every one with the compiled reference.
+ *
+ * Grids are LIBLTE_PHY_SUBFRAME_STRUCT::tx_symb_re / tx_symb_im (liblte_phy.h:234-235): float [4 ports][16 symbols][1200 sub-carriers].
+ *
+ *   mi_lte_rate_match_turbo       liblte_phy_rate_match_turbo       liblte_phy.h:1288  liblte_phy.cc:11081-11237 (d planar, as the reference takes it)
+ *   mi_lte_pdsch_channel_encode   liblte_phy_pdsch_channel_encode   liblte_phy.h:888   liblte_phy.cc:3489-3688
+ *   mi_lte_bch_channel_encode     liblte_phy_bch_channel_encode     liblte_phy.h:927   liblte_phy.cc:3863-3966
+ *   mi_lte_map_crs / _pss / _sss  liblte_phy_map_crs / _pss / _sss  liblte_phy.h:1034 / 1051 / 1089   liblte_phy.cc:5144 / 5265 / 5520
+ *   mi_lte_create_dl_subframe     liblte_phy_create_dl_subframe     liblte_phy.h:1152  liblte_phy.cc:5862-5903
+ * The handle is the scratch of LIBLTE_PHY_STRUCT that outlives a call (the PBCH's 40 ms block; what a later call can read of an earlier one). */
+#define MI_LTE_TX_GRID_SC 1200u
+#define MI_LTE_TX_GRID_AT(p, L, k) (((size_t)(p) * 16u + (L)) * MI_LTE_TX_GRID_SC + (k))
+#define MI_LTE_TX_GRID_FLOATS (4u * 16u * MI_LTE_TX_GRID_SC)
+enum { MI_LTE_MOD_BPSK = 0, MI_LTE_MOD_QPSK = 1, MI_LTE_MOD_16QAM = 2, MI_LTE_MOD_64QAM = 3 };        /* LIBLTE_PHY_MODULATION_TYPE_ENUM */
+enum { MI_LTE_CHAN_DLSCH = 0, MI_LTE_CHAN_PCH = 1, MI_LTE_CHAN_ULSCH = 2, MI_LTE_CHAN_ULCCH = 3 };     /* LIBLTE_PHY_CHAN_TYPE_ENUM       */
+enum { MI_LTE_PRECODER_TX_DIVERSITY = 0, MI_LTE_PRECODER_SPATIAL_MULTIPLEXING = 1 };                   /* LIBLTE_PHY_PRE_CODER_TYPE_ENUM  */
+/* LIBLTE_PHY_ALLOCATION_STRUCT (liblte_phy.h:684-702) as the transmit functions read it */
+typedef struct {
+    const uint8_t *msg[2];      /* transport-block bits of codeword 0 / 1, one per byte                 */
+    uint32_t       msg_bits[2]; /* how many of them are given; the block is zero-padded to tbs          */
+    uint32_t       pre_coder_type, mod_type, chan_type, tbs, rv_idx, N_prb;
+    uint32_t       prb[2][110]; /* per slot                                                             */
+    uint32_t       N_codewords, N_layers, tx_mode, rnti;
+    uint32_t       mcs, tpc, ndi, dl_alloc; /* what the DCI of the allocation carries (PDCCH encode)    */
+} mi_lte_tx_alloc;
+typedef struct mi_lte_tx mi_lte_tx;
+int  mi_lte_tx_create(mi_lte_tx **out);
+void mi_lte_tx_destroy(mi_lte_tx *tx);
+void mi_lte_rate_match_turbo(const uint8_t *d_bits, uint32_t N_d_bits, uint32_t N_codeblocks, uint32_t tx_mode, uint32_t N_soft, uint32_t M_dl_harq,
+                             uint32_t chan_type, uint32_t rv_idx, uint32_t N_e_bits, uint8_t *e_bits);
+int  mi_lte_pdsch_channel_encode(mi_lte_tx *tx, uint32_t N_rb_dl, uint32_t N_sc_rb_dl, const mi_lte_tx_alloc *allocs, uint32_t N_alloc, uint32_t N_pdcch_symbs,
+                                 uint32_t N_id_cell, uint32_t N_ant, uint32_t subfr_num, float *tx_re, float *tx_im);
+int  mi_lte_bch_channel_encode(mi_lte_tx *tx, uint32_t N_rb_dl, uint32_t N_sc_rb_dl, const uint8_t *in_bits, uint32_t N_in_bits, uint32_t N_id_cell, uint32_t N_ant,
+                               uint32_t sfn, float *tx_re, float *tx_im);
+int  mi_lte_map_crs(uint32_t N_rb_dl, uint32_t N_sc_rb_dl, uint32_t subfr_num, uint32_t N_id_cell, uint32_t N_ant, float *tx_re, float *tx_im);
+int  mi_lte_map_pss(uint32_t N_rb_dl, uint32_t N_sc_rb_dl, uint32_t N_id_2, uint32_t N_ant, float *tx_re, float *tx_im);
+int  mi_lte_map_sss(uint32_t N_rb_dl, uint32_t N_sc_rb_dl, uint32_t subfr_num, uint32_t N_id_1, uint32_t N_id_2, uint32_t N_ant, float *tx_re, float *tx_im);
+int  mi_lte_create_dl_subframe(uint32_t N_samps_per_symb, uint32_t N_used_sc, uint32_t N_samps_cp_l_0, uint32_t N_samps_cp_l_else, const float *tx_re,
+                               const float *tx_im, uint32_t ant, float *i_samps, float *q_samps);
+
 /* ---------------------------------------------------------------- input synthesis (host side)
  * A minimal LTE downlink transmitter for benchmark / test captures, the role LTE_fdd_dl_file_gen
  * plays for the reference (LTE_fdd_dl_file_gen/src/LTE_fdd_dl_fg_samp_buf.cc:269-668).  Host code

@@ -50,6 +50,9 @@ struct Entry {
     mi_lte_ul_cfg ul = {0, 0, 0, 0, 0};
     uint32_t      ul_cell = 0, n_cs_an = 0, delta_pucch_shift = 1;
     std::map<uint32_t, std::vector<float>> dmrs, pucch; // keys: subframe * 256 + N_prb / + N_1_p_pucch
+    // the transmit side's scratch (host memory only; made by the first transmit call, own-lifecycle build)
+    mi_lte_tx *tx = nullptr;
+    ~Entry() { if (tx) mi_lte_tx_destroy(tx); }
 };
 std::mutex                                            g_mu;
 std::map<LIBLTE_PHY_STRUCT *, std::shared_ptr<Entry>> g_ctx;
@@ -83,6 +86,23 @@ std::shared_ptr<Entry> entry_for(LIBLTE_PHY_STRUCT *phy)
     std::lock_guard<std::mutex> call_lock_(entry_->mu);                                                                            \
     if (!entry_->ctx) return fail;                                                                                                 \
     mi_lte_ctx *c = entry_->ctx
+
+// the entry of a struct locked for a call that needs no GPU (the transmit side): the struct must be one liblte_phy_init made
+#define MI_LOCKED_ENTRY(phy, fail)                                                                                                 \
+    std::shared_ptr<Entry> entry_ = entry_for(phy);                                                                                \
+    std::lock_guard<std::mutex> call_lock_(entry_->mu);                                                                            \
+    if (!entry_->tx && mi_lte_tx_create(&entry_->tx) != MI_LTE_OK) return fail;                                                    \
+    mi_lte_tx *t = entry_->tx
+
+void to_tx_alloc(const LIBLTE_PHY_ALLOCATION_STRUCT *a, mi_lte_tx_alloc *o)
+{
+    memset(o, 0, sizeof(*o));
+    for (int i = 0; i < 2; i++) o->msg[i] = a->msg[i].msg, o->msg_bits[i] = a->msg[i].N_bits;
+    o->pre_coder_type = (uint32_t)a->pre_coder_type, o->mod_type = (uint32_t)a->mod_type, o->chan_type = (uint32_t)a->chan_type;
+    o->tbs = a->tbs, o->rv_idx = a->rv_idx, o->N_prb = a->N_prb, o->N_codewords = a->N_codewords, o->N_layers = a->N_layers, o->tx_mode = a->tx_mode;
+    o->rnti = a->rnti, o->mcs = a->mcs, o->tpc = a->tpc, o->ndi = a->ndi, o->dl_alloc = a->dl_alloc;
+    memcpy(o->prb, a->prb, sizeof(o->prb));
+}
 
 void to_mi_alloc(const LIBLTE_PHY_ALLOCATION_STRUCT *a, mi_lte_pdsch_alloc *o)
 {
@@ -648,5 +668,63 @@ void liblte_phy_code_block_segmentation(uint8 *b_bits, uint32 N_b_bits, uint32 *
 void liblte_phy_code_block_desegmentation(uint8 *c_bits, uint32 *N_c_bits, uint32 N_c_bits_max, uint32 tbs, uint8 *b_bits, uint32 N_b_bits)
 {
     mi_lte_code_block_desegmentation(c_bits, N_c_bits, N_c_bits_max, tbs, b_bits, N_b_bits);
+}
+
+// ---- the transmit side (2: "CPU pass-through"), own-lifecycle build only: host code in libmi_lte.so (tx.cc ...) behind the reference's
+// signatures, the struct's fields handed over as arguments, its long-lived scratch in the entry.  `lifecycle_check tx` compares each with the
+// compiled reference.
+static_assert(sizeof(((LIBLTE_PHY_SUBFRAME_STRUCT *)0)->tx_symb_re) == MI_LTE_TX_GRID_FLOATS * sizeof(float), "grid layout");
+static_assert(sizeof(((LIBLTE_PHY_ALLOCATION_STRUCT *)0)->prb) == sizeof(((mi_lte_tx_alloc *)0)->prb), "PRB list layout");
+// liblte_phy.h:1288, liblte_phy.cc:11081-11237
+void liblte_phy_rate_match_turbo(LIBLTE_PHY_STRUCT *phy_struct, uint8 *d_bits, uint32 N_d_bits, uint32 N_codeblocks, uint32 tx_mode, uint32 N_soft, uint32 M_dl_harq,
+                                 LIBLTE_PHY_CHAN_TYPE_ENUM chan_type, uint32 rv_idx, uint32 N_e_bits, uint8 *e_bits)
+{
+    (void)phy_struct; // (the reference uses it for scratch only)
+    mi_lte_rate_match_turbo(d_bits, N_d_bits, N_codeblocks, tx_mode, N_soft, M_dl_harq, (uint32_t)chan_type, rv_idx, N_e_bits, e_bits);
+}
+// liblte_phy.h:888, liblte_phy.cc:3489-3688
+LIBLTE_ERROR_ENUM liblte_phy_pdsch_channel_encode(LIBLTE_PHY_STRUCT *phy_struct, LIBLTE_PHY_PDCCH_STRUCT *pdcch, uint32 N_id_cell, uint8 N_ant, LIBLTE_PHY_SUBFRAME_STRUCT *subframe)
+{
+    if (!phy_struct || !pdcch || !subframe || pdcch->N_alloc > LIBLTE_PHY_PDCCH_MAX_ALLOC) return LIBLTE_ERROR_INVALID_INPUTS;
+    MI_LOCKED_ENTRY(phy_struct, LIBLTE_ERROR_INVALID_INPUTS);
+    mi_lte_tx_alloc al[LIBLTE_PHY_PDCCH_MAX_ALLOC];
+    for (uint32 i = 0; i < pdcch->N_alloc; i++) to_tx_alloc(&pdcch->alloc[i], &al[i]);
+    return (LIBLTE_ERROR_ENUM)mi_lte_pdsch_channel_encode(t, phy_struct->N_rb_dl, phy_struct->N_sc_rb_dl, al, pdcch->N_alloc, pdcch->N_symbs, N_id_cell, N_ant, subframe->num,
+                                                          &subframe->tx_symb_re[0][0][0], &subframe->tx_symb_im[0][0][0]);
+}
+// liblte_phy.h:927, liblte_phy.cc:3863-3966
+LIBLTE_ERROR_ENUM liblte_phy_bch_channel_encode(LIBLTE_PHY_STRUCT *phy_struct, uint8 *in_bits, uint32 N_in_bits, uint32 N_id_cell, uint8 N_ant, LIBLTE_PHY_SUBFRAME_STRUCT *subframe,
+                                                uint32 sfn)
+{
+    if (!phy_struct || !in_bits || !subframe) return LIBLTE_ERROR_INVALID_INPUTS;
+    MI_LOCKED_ENTRY(phy_struct, LIBLTE_ERROR_INVALID_INPUTS);
+    return (LIBLTE_ERROR_ENUM)mi_lte_bch_channel_encode(t, phy_struct->N_rb_dl, phy_struct->N_sc_rb_dl, in_bits, N_in_bits, N_id_cell, N_ant, sfn, &subframe->tx_symb_re[0][0][0],
+                                                        &subframe->tx_symb_im[0][0][0]);
+}
+// liblte_phy.h:1034, liblte_phy.cc:5144-5263
+LIBLTE_ERROR_ENUM liblte_phy_map_crs(LIBLTE_PHY_STRUCT *phy_struct, LIBLTE_PHY_SUBFRAME_STRUCT *subframe, uint32 N_id_cell, uint8 N_ant)
+{
+    if (!phy_struct || !subframe) return LIBLTE_ERROR_INVALID_INPUTS;
+    return (LIBLTE_ERROR_ENUM)mi_lte_map_crs(phy_struct->N_rb_dl, phy_struct->N_sc_rb_dl, subframe->num, N_id_cell, N_ant, &subframe->tx_symb_re[0][0][0], &subframe->tx_symb_im[0][0][0]);
+}
+// liblte_phy.h:1051, liblte_phy.cc:5265-5304
+LIBLTE_ERROR_ENUM liblte_phy_map_pss(LIBLTE_PHY_STRUCT *phy_struct, LIBLTE_PHY_SUBFRAME_STRUCT *subframe, uint32 N_id_2, uint8 N_ant)
+{
+    if (!phy_struct || !subframe) return LIBLTE_ERROR_INVALID_INPUTS;
+    return (LIBLTE_ERROR_ENUM)mi_lte_map_pss(phy_struct->N_rb_dl, phy_struct->N_sc_rb_dl, N_id_2, N_ant, &subframe->tx_symb_re[0][0][0], &subframe->tx_symb_im[0][0][0]);
+}
+// liblte_phy.h:1089, liblte_phy.cc:5520-5576
+LIBLTE_ERROR_ENUM liblte_phy_map_sss(LIBLTE_PHY_STRUCT *phy_struct, LIBLTE_PHY_SUBFRAME_STRUCT *subframe, uint32 N_id_1, uint32 N_id_2, uint8 N_ant)
+{
+    if (!phy_struct || !subframe) return LIBLTE_ERROR_INVALID_INPUTS;
+    return (LIBLTE_ERROR_ENUM)mi_lte_map_sss(phy_struct->N_rb_dl, phy_struct->N_sc_rb_dl, subframe->num, N_id_1, N_id_2, N_ant, &subframe->tx_symb_re[0][0][0],
+                                             &subframe->tx_symb_im[0][0][0]);
+}
+// liblte_phy.h:1152, liblte_phy.cc:5862-5903
+LIBLTE_ERROR_ENUM liblte_phy_create_dl_subframe(LIBLTE_PHY_STRUCT *phy_struct, LIBLTE_PHY_SUBFRAME_STRUCT *subframe, uint8 ant, float *i_samps, float *q_samps)
+{
+    if (!phy_struct || !subframe) return LIBLTE_ERROR_INVALID_INPUTS;
+    return (LIBLTE_ERROR_ENUM)mi_lte_create_dl_subframe(phy_struct->N_samps_per_symb, phy_struct->FFT_size - 2 * phy_struct->FFT_pad_size, phy_struct->N_samps_cp_l_0,
+                                                        phy_struct->N_samps_cp_l_else, &subframe->tx_symb_re[0][0][0], &subframe->tx_symb_im[0][0][0], ant, i_samps, q_samps);
 }
 #endif

@@ -94,6 +94,7 @@ void liblte_phy_code_block_segmentation_cpu(uint8 *b_bits, uint32 N_b_bits, uint
 void liblte_phy_code_block_desegmentation_cpu(uint8 *c_bits, uint32 *N_c_bits, uint32 N_c_bits_max, uint32 tbs, uint8 *b_bits, uint32 N_b_bits);
 
 #include <unistd.h>
+int tx_check(); // tx_check.cc: the transmit functions
 static int helpers_check()
 {
     static const uint32 bws[6] = {6, 15, 25, 50, 75, 100};
@@ -197,6 +198,7 @@ int main(int argc, char **argv)
 {
     if (argc > 1 && !strcmp(argv[1], "pucch")) return pucch_check();
     if (argc > 1 && !strcmp(argv[1], "helpers")) return helpers_check();
+    if (argc > 1 && !strcmp(argv[1], "tx")) return tx_check();
     static const LIBLTE_PHY_FS_ENUM fss[5] = {LIBLTE_PHY_FS_1_92MHZ, LIBLTE_PHY_FS_3_84MHZ, LIBLTE_PHY_FS_7_68MHZ, LIBLTE_PHY_FS_15_36MHZ, LIBLTE_PHY_FS_30_72MHZ};
     static const uint32 rbs[8] = {6, 15, 25, 50, 75, 100, 7, 110};
     static const float  res[4] = {1.0f / 6, 0.5f, 1.0f, 2.0f};

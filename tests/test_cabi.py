@@ -77,6 +77,20 @@ def test_scheduler_helpers_equal_the_references():
     assert r.returncode == 0 and "comparisons equal" in r.stdout, r.stdout[-2000:]
 
 
+def test_transmit_functions_equal_the_references():
+    """`lifecycle_check tx`: the transmit functions the own-lifecycle shim defines (tx.cc ...: liblte_phy_rate_match_turbo :11081-11237,
+    _pdsch_channel_encode :3489-3688, _bch_channel_encode :3863-3966, _map_crs / _pss / _sss :5144 / :5265 / :5520, _create_dl_subframe :5862-5903
+    ...) against the reference's own on the same sequences of calls: grids bit for bit (every cell, subframe, port count and bandwidth for the
+    signals; random allocations incl. filler bits, several code blocks, two codewords, four ports, BPSK for the PDSCH; 40 ms periods entered in the
+    middle for the PBCH), return codes, and the OFDM modulator to float rounding.  CPU only."""
+    import subprocess
+    exe = os.path.join(ROOT, "shim", "_build", "lifecycle_check")
+    if not os.path.exists(exe):
+        pytest.skip("shim/_build/lifecycle_check not built (needs the reference tree at build time)")
+    r = subprocess.run([exe, "tx"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "comparisons equal" in r.stdout, r.stdout[-3000:]
+
+
 def test_tbs_table_lookup():
     """mi_lte_tbs: corner entries of 36.213 table 7.1.7.2.1-1 (values every LTE reference agrees on) and the out-of-range answer."""
     import openlte_amd

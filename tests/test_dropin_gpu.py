@@ -16,6 +16,7 @@ import lte_testdata as td
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_PURE_SYMBOLS = 32  # liblte_phy_* functions the build without any reference PHY object defines: 24 + 7 transmit functions so far + the one-call uplink entry
 
 
 def test_dropin_demo_matches_reference_output():
@@ -344,9 +345,11 @@ def test_cell_scan_with_no_reference_phy_object_in_the_link(tmp_path, n_rb, cell
     assert got.stdout == want
     syms = subprocess.run(["nm", "-C", "--defined-only", pure], capture_output=True, text=True).stdout
     phy = sorted({l.split(" T ")[1].split("(")[0] for l in syms.splitlines() if " T liblte_phy_" in l})
-    # twenty-four of the reference's 34 symbols (the receive side, the lifecycle, the seven scheduler-side helpers) + the shim's own one-call uplink entry
-    assert len(phy) == 25 and all(f in phy for f in ("liblte_phy_init", "liblte_phy_update_n_rb_dl", "liblte_phy_ul_init", "liblte_phy_get_tbs_mcs_and_n_prb_for_dl",
-                                                     "liblte_phy_get_n_cce", "liblte_phy_code_block_segmentation", "liblte_phy_ul_subframe_decode")), phy
+    # the reference's 34 symbols (the receive side, the lifecycle, the seven scheduler-side helpers, the ten transmit functions) + the shim's own
+    # one-call uplink entry
+    assert len(phy) == N_PURE_SYMBOLS and all(f in phy for f in ("liblte_phy_init", "liblte_phy_update_n_rb_dl", "liblte_phy_ul_init", "liblte_phy_get_tbs_mcs_and_n_prb_for_dl",
+                                                     "liblte_phy_get_n_cce", "liblte_phy_code_block_segmentation", "liblte_phy_ul_subframe_decode",
+                                                                "liblte_phy_pdsch_channel_encode", "liblte_phy_create_dl_subframe")), phy
     assert "pdcch_permute_pre_calc" not in syms and "turbo_decode" not in syms and "fftwf_" not in syms
 
 

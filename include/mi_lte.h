@@ -748,6 +748,17 @@ int  mi_lte_bch_channel_encode(mi_lte_tx *tx, uint32_t N_rb_dl, uint32_t N_sc_rb
 int  mi_lte_map_crs(uint32_t N_rb_dl, uint32_t N_sc_rb_dl, uint32_t subfr_num, uint32_t N_id_cell, uint32_t N_ant, float *tx_re, float *tx_im);
 int  mi_lte_map_pss(uint32_t N_rb_dl, uint32_t N_sc_rb_dl, uint32_t N_id_2, uint32_t N_ant, float *tx_re, float *tx_im);
 int  mi_lte_map_sss(uint32_t N_rb_dl, uint32_t N_sc_rb_dl, uint32_t subfr_num, uint32_t N_id_1, uint32_t N_id_2, uint32_t N_ant, float *tx_re, float *tx_im);
+/* the uplink pair (tx_ul.cc): liblte_phy_pusch_channel_encode (liblte_phy.h:704, liblte_phy.cc:2664-2799; one port, one layer, one codeword, an N_prb the
+ * reference has a transform-precoder plan for) and liblte_phy_generate_prach (liblte_phy.h:845, liblte_phy.cc:3219-3297; T_cp + T_seq samples).  ul /
+ * ul_cell are what liblte_phy_ul_init was given (the reference signal of symbols 3 and 10 comes from mi_lte_ul_dmrs_pusch). */
+typedef struct mi_lte_tx_ul mi_lte_tx_ul;
+int    mi_lte_tx_ul_create(mi_lte_tx_ul **out);
+void   mi_lte_tx_ul_destroy(mi_lte_tx_ul *tx);
+int    mi_lte_pusch_channel_encode(mi_lte_tx_ul *tx, const mi_lte_ul_cfg *ul, uint32_t ul_cell, uint32_t N_rb_ul, uint32_t N_sc_rb_ul, const mi_lte_tx_alloc *alloc,
+                                   uint32_t N_id_cell, uint32_t N_ant, uint32_t subfr_num, float *tx_re, float *tx_im);
+size_t mi_lte_generate_prach_len(uint32_t fft_size, uint32_t preamble_format);
+int    mi_lte_generate_prach(const mi_lte_prach_cfg *prach, uint32_t fft_size, uint32_t N_rb_ul, uint32_t N_sc_rb_ul, uint32_t preamble_idx, uint32_t freq_offset,
+                             float *samps_re, float *samps_im);
 int  mi_lte_create_dl_subframe(uint32_t N_samps_per_symb, uint32_t N_used_sc, uint32_t N_samps_cp_l_0, uint32_t N_samps_cp_l_else, const float *tx_re,
                                const float *tx_im, uint32_t ant, float *i_samps, float *q_samps);
 

@@ -51,8 +51,9 @@ struct Entry {
     uint32_t      ul_cell = 0, n_cs_an = 0, delta_pucch_shift = 1;
     std::map<uint32_t, std::vector<float>> dmrs, pucch; // keys: subframe * 256 + N_prb / + N_1_p_pucch
     // the transmit side's scratch (host memory only; made by the first transmit call, own-lifecycle build)
-    mi_lte_tx *tx = nullptr;
-    ~Entry() { if (tx) mi_lte_tx_destroy(tx); }
+    mi_lte_tx    *tx    = nullptr;
+    mi_lte_tx_ul *tx_ul = nullptr;
+    ~Entry() { if (tx) mi_lte_tx_destroy(tx); if (tx_ul) mi_lte_tx_ul_destroy(tx_ul); }
 };
 std::mutex                                            g_mu;
 std::map<LIBLTE_PHY_STRUCT *, std::shared_ptr<Entry>> g_ctx;
@@ -719,6 +720,25 @@ LIBLTE_ERROR_ENUM liblte_phy_map_sss(LIBLTE_PHY_STRUCT *phy_struct, LIBLTE_PHY_S
     if (!phy_struct || !subframe) return LIBLTE_ERROR_INVALID_INPUTS;
     return (LIBLTE_ERROR_ENUM)mi_lte_map_sss(phy_struct->N_rb_dl, phy_struct->N_sc_rb_dl, subframe->num, N_id_1, N_id_2, N_ant, &subframe->tx_symb_re[0][0][0],
                                              &subframe->tx_symb_im[0][0][0]);
+}
+// liblte_phy.h:704, liblte_phy.cc:2664-2799 (the UE side of the reference's loop-back: nothing in LTE_fdd_enodeb calls it)
+LIBLTE_ERROR_ENUM liblte_phy_pusch_channel_encode(LIBLTE_PHY_STRUCT *phy_struct, LIBLTE_PHY_ALLOCATION_STRUCT *alloc, uint32 N_id_cell, uint8 N_ant, LIBLTE_PHY_SUBFRAME_STRUCT *subframe)
+{
+    if (!phy_struct || !alloc || !subframe || !phy_struct->ul_init) return LIBLTE_ERROR_INVALID_INPUTS; // (without liblte_phy_ul_init the reference reads tables nobody filled)
+    std::shared_ptr<Entry> entry_ = entry_for(phy_struct);
+    std::lock_guard<std::mutex> call_lock_(entry_->mu);
+    if (!entry_->tx_ul && mi_lte_tx_ul_create(&entry_->tx_ul) != MI_LTE_OK) return LIBLTE_ERROR_INVALID_INPUTS;
+    mi_lte_tx_alloc al;
+    to_tx_alloc(alloc, &al);
+    return (LIBLTE_ERROR_ENUM)mi_lte_pusch_channel_encode(entry_->tx_ul, &entry_->ul, entry_->ul_cell, phy_struct->N_rb_ul, phy_struct->N_sc_rb_ul, &al, N_id_cell, N_ant, subframe->num,
+                                                          &subframe->tx_symb_re[0][0][0], &subframe->tx_symb_im[0][0][0]);
+}
+// liblte_phy.h:845, liblte_phy.cc:3219-3297
+LIBLTE_ERROR_ENUM liblte_phy_generate_prach(LIBLTE_PHY_STRUCT *phy_struct, uint32 preamble_idx, uint32 freq_offset, float *samps_re, float *samps_im)
+{
+    if (!phy_struct || !samps_re || !samps_im || !phy_struct->ul_init) return LIBLTE_ERROR_INVALID_INPUTS;
+    const mi_lte_prach_cfg pc = {phy_struct->prach_root_seq_idx, phy_struct->prach_preamble_format, phy_struct->prach_zczc, phy_struct->prach_hs_flag ? 1u : 0u, freq_offset};
+    return (LIBLTE_ERROR_ENUM)mi_lte_generate_prach(&pc, phy_struct->FFT_size, phy_struct->N_rb_ul, phy_struct->N_sc_rb_ul, preamble_idx, freq_offset, samps_re, samps_im);
 }
 // liblte_phy.h:1152, liblte_phy.cc:5862-5903
 LIBLTE_ERROR_ENUM liblte_phy_create_dl_subframe(LIBLTE_PHY_STRUCT *phy_struct, LIBLTE_PHY_SUBFRAME_STRUCT *subframe, uint8 ant, float *i_samps, float *q_samps)

@@ -21,6 +21,11 @@ LIBLTE_ERROR_ENUM liblte_phy_map_crs_cpu(LIBLTE_PHY_STRUCT *phy_struct, LIBLTE_P
 LIBLTE_ERROR_ENUM liblte_phy_map_pss_cpu(LIBLTE_PHY_STRUCT *phy_struct, LIBLTE_PHY_SUBFRAME_STRUCT *subframe, uint32 N_id_2, uint8 N_ant);
 LIBLTE_ERROR_ENUM liblte_phy_map_sss_cpu(LIBLTE_PHY_STRUCT *phy_struct, LIBLTE_PHY_SUBFRAME_STRUCT *subframe, uint32 N_id_1, uint32 N_id_2, uint8 N_ant);
 LIBLTE_ERROR_ENUM liblte_phy_create_dl_subframe_cpu(LIBLTE_PHY_STRUCT *phy_struct, LIBLTE_PHY_SUBFRAME_STRUCT *subframe, uint8 ant, float *i_samps, float *q_samps);
+LIBLTE_ERROR_ENUM liblte_phy_ul_init_cpu(LIBLTE_PHY_STRUCT *phy_struct, uint16 N_id_cell, uint32 prach_root_seq_idx, uint32 prach_preamble_format, uint32 prach_zczc,
+                                         bool prach_hs_flag, uint8 group_assignment_pusch, bool group_hopping_enabled, bool sequence_hopping_enabled, uint8 cyclic_shift,
+                                         uint8 cyclic_shift_dci, uint8 N_cs_an, uint8 delta_pucch_shift);
+LIBLTE_ERROR_ENUM liblte_phy_pusch_channel_encode_cpu(LIBLTE_PHY_STRUCT *phy_struct, LIBLTE_PHY_ALLOCATION_STRUCT *alloc, uint32 N_id_cell, uint8 N_ant, LIBLTE_PHY_SUBFRAME_STRUCT *subframe);
+LIBLTE_ERROR_ENUM liblte_phy_generate_prach_cpu(LIBLTE_PHY_STRUCT *phy_struct, uint32 preamble_idx, uint32 freq_offset, float *samps_re, float *samps_im);
 LIBLTE_ERROR_ENUM liblte_phy_get_tbs_and_n_prb_for_dl_cpu(uint32 N_bits, uint32 N_rb_dl, uint8 mcs, uint32 *tbs, uint32 *N_prb);
 
 namespace {
@@ -241,6 +246,92 @@ void check_ofdm()
     }
     printf("  create_dl_subframe: worst relative L2 against the reference on the float64 transform stand-in %.3g\n", worst);
 }
+// relative L2 distance of two grids / sample vectors (the transforms on the reference's side run on the FFTW stand-in)
+double rel_l2(const float *a_re, const float *a_im, const float *b_re, const float *b_im, size_t n)
+{
+    double num = 0, den = 0;
+    for (size_t i = 0; i < n; i++) {
+        num += (double)(a_re[i] - b_re[i]) * (a_re[i] - b_re[i]) + (double)(a_im[i] - b_im[i]) * (a_im[i] - b_im[i]);
+        den += (double)b_re[i] * b_re[i] + (double)b_im[i] * b_im[i];
+    }
+    return den > 0 ? sqrt(num / den) : (num > 0 ? 1.0 : 0.0);
+}
+
+void check_pusch()
+{
+    static LIBLTE_PHY_ALLOCATION_STRUCT al;
+    double worst = 0;
+    long   exact = 0, total = 0;
+    const struct { uint32 delta_ss; bool group_hop, seq_hop; uint8 cs, cs_dci; } ulc[3] = {{0, false, false, 0, 0}, {7, true, false, 3, 5}, {13, false, true, 6, 1}};
+    for (int b = 1; b < 6; b++) {
+        Pair P;
+        const uint32 cell = 40 * b + 3;
+        if (!P.open(BW[b].fs, (uint16)cell, 1, BW[b].n_rb)) { g_bad++; return; }
+        const int u = b % 3;
+        if (liblte_phy_ul_init(P.own, (uint16)cell, 0, 0, 1, false, (uint8)ulc[u].delta_ss, ulc[u].group_hop, ulc[u].seq_hop, ulc[u].cs, ulc[u].cs_dci, 0, 1) != LIBLTE_SUCCESS ||
+            liblte_phy_ul_init_cpu(P.ref, (uint16)cell, 0, 0, 1, false, (uint8)ulc[u].delta_ss, ulc[u].group_hop, ulc[u].seq_hop, ulc[u].cs, ulc[u].cs_dci, 0, 1) != LIBLTE_SUCCESS) { g_bad++; return; }
+        memset(P.ref->pusch_z_re, 0, sizeof P.ref->pusch_z_re), memset(P.ref->pusch_z_im, 0, sizeof P.ref->pusch_z_im); // (see Pair::open)
+        memset(P.ref->ulsch_c_bits, 0, sizeof P.ref->ulsch_c_bits), memset(P.ref->ulsch_tx_e_bits, 0, sizeof P.ref->ulsch_tx_e_bits);
+        for (uint32 trial = 0; trial < 28; trial++) {
+            memset(&al, 0, sizeof al);
+            static const uint32 sizes[12] = {2, 2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 20}; // (sizes the reference has a transform plan for: a factor 2, 3 or 5 -- it calls a null plan otherwise)
+            uint32 n_prb = sizes[rnd(12)];
+            if (n_prb >= BW[b].n_rb) n_prb = 2;
+            al.N_prb = n_prb, al.N_layers = 1, al.N_codewords = 1, al.tx_mode = 1, al.rv_idx = rnd(4), al.rnti = (uint16)(1 + rnd(65000));
+            al.mod_type  = (LIBLTE_PHY_MODULATION_TYPE_ENUM)(trial % 5 == 4 ? 0 : 1 + rnd(3));
+            al.chan_type = LIBLTE_PHY_CHAN_TYPE_ULSCH;
+            for (uint32 i = 0; i < n_prb; i++) al.prb[0][i] = al.prb[1][i] = 3 + i;
+            al.tbs = trial % 9 == 8 ? 6200 + rnd(7000) : trial % 4 == 3 ? 17 + rnd(2000) : 8 * (2 + rnd(180)) ;
+            al.msg[0].N_bits = al.tbs > LIBLTE_MAX_MSG_SIZE ? LIBLTE_MAX_MSG_SIZE : al.tbs;
+            for (uint32 i = 0; i < al.msg[0].N_bits; i++) al.msg[0].msg[i] = (uint8)(rnd() & 1);
+            const uint32 sf = rnd(10);
+            fill_grids(sf);
+            if (getenv("TX_TRACE")) printf("pusch %u trial %u: N_prb %u mod %d tbs %u\n", BW[b].n_rb, trial, n_prb, (int)al.mod_type, al.tbs);
+            const LIBLTE_ERROR_ENUM e1 = liblte_phy_pusch_channel_encode(P.own, &al, cell, 1, &g_s1);
+            if (getenv("TX_TRACE")) printf("  own done\n");
+            const LIBLTE_ERROR_ENUM e2 = liblte_phy_pusch_channel_encode_cpu(P.ref, &al, cell, 1, &g_s2);
+            uint32 p = 0, l = 0, k = 0;
+            const bool same = grids_equal(&p, &l, &k);
+            const double rel = rel_l2(&g_s1.tx_symb_re[0][0][0], &g_s1.tx_symb_im[0][0][0], &g_s2.tx_symb_re[0][0][0], &g_s2.tx_symb_im[0][0][0], 14 * 1200);
+            // the two reference-signal symbols and everything the call leaves alone are not transformed: bit for bit
+            const bool rs_same = !memcmp(g_s1.tx_symb_re[0][3], g_s2.tx_symb_re[0][3], sizeof g_s1.tx_symb_re[0][3]) && !memcmp(g_s1.tx_symb_im[0][10], g_s2.tx_symb_im[0][10], sizeof g_s1.tx_symb_im[0][10]) &&
+                                 !memcmp(g_s1.tx_symb_re[1], g_s2.tx_symb_re[1], sizeof g_s1.tx_symb_re[1]) && !memcmp(&g_s1.tx_symb_re[0][14], &g_s2.tx_symb_re[0][14], 2 * sizeof g_s1.tx_symb_re[0][0]);
+            total++, exact += same;
+            if (rel > worst) worst = rel;
+            CHECK(e1 == e2 && rs_same && rel < 2e-7, "pusch_channel_encode(N_rb_ul %u, trial %u: N_prb %u, mod %d, tbs %u, rv %u, subframe %u): %d vs %d, relative L2 %.3g, reference signals %s, first at symbol %u sub-carrier %u",
+                  BW[b].n_rb, trial, n_prb, (int)al.mod_type, al.tbs, al.rv_idx, sf, e1, e2, rel, rs_same ? "equal" : "DIFFER", l, k);
+        }
+        CHECK(liblte_phy_pusch_channel_encode(P.own, NULL, cell, 1, &g_s1) == LIBLTE_ERROR_INVALID_INPUTS && liblte_phy_pusch_channel_encode(P.own, &al, cell, 1, NULL) == LIBLTE_ERROR_INVALID_INPUTS,
+              "pusch_channel_encode: argument checks"); // (the reference dereferences alloc before it tests it: not called with NULL)
+        P.close();
+    }
+    printf("  pusch_channel_encode: %ld of %ld grids bit for bit, worst relative L2 %.3g\n", exact, total, worst);
+}
+
+void check_prach()
+{
+    static float r1[60000], i1[60000], r2[60000], i2[60000];
+    double worst = 0;
+    const struct { int bw; uint32 fmt, root, zczc; bool hs; uint32 pre, off; } tc[9] = {{0, 0, 22, 1, false, 0, 0},   {0, 0, 700, 12, false, 63, 0}, {1, 1, 5, 6, false, 17, 3},
+                                                                                       {2, 2, 128, 9, false, 40, 10}, {1, 3, 837, 4, false, 9, 2},   {0, 0, 300, 5, true, 33, 0},
+                                                                                       {2, 4, 7, 3, false, 21, 4},    {3, 0, 410, 14, false, 50, 20}, {5, 0, 0, 0, false, 0, 50}};
+    for (int c = 0; c < 9; c++) {
+        Pair P;
+        if (!P.open(BW[tc[c].bw].fs, 11, 1, BW[tc[c].bw].n_rb)) { g_bad++; return; }
+        if (liblte_phy_ul_init(P.own, 11, tc[c].root, tc[c].fmt, tc[c].zczc, tc[c].hs, 0, false, false, 0, 0, 0, 1) != LIBLTE_SUCCESS ||
+            liblte_phy_ul_init_cpu(P.ref, 11, tc[c].root, tc[c].fmt, tc[c].zczc, tc[c].hs, 0, false, false, 0, 0, 0, 1) != LIBLTE_SUCCESS) { g_bad++; return; }
+        const size_t n = P.ref->prach_T_cp + P.ref->prach_T_seq;
+        memset(r1, 0, sizeof r1), memset(i1, 0, sizeof i1), memset(r2, 0, sizeof r2), memset(i2, 0, sizeof i2);
+        const LIBLTE_ERROR_ENUM e1 = liblte_phy_generate_prach(P.own, tc[c].pre, tc[c].off, r1, i1), e2 = liblte_phy_generate_prach_cpu(P.ref, tc[c].pre, tc[c].off, r2, i2);
+        const double rel = rel_l2(r1, i1, r2, i2, n + 16);
+        if (rel > worst) worst = rel;
+        CHECK(e1 == e2 && n <= 59000 && rel < 2e-7, "generate_prach(N_rb_ul %u, format %u, root %u, zczc %u, hs %d, preamble %u, offset %u): %d vs %d, %zu samples, relative L2 %.3g", BW[tc[c].bw].n_rb,
+              tc[c].fmt, tc[c].root, tc[c].zczc, (int)tc[c].hs, tc[c].pre, tc[c].off, e1, e2, n, rel);
+        CHECK(liblte_phy_generate_prach(P.own, 0, 0, NULL, i1) == liblte_phy_generate_prach_cpu(P.ref, 0, 0, NULL, i2), "generate_prach: argument checks");
+        P.close();
+    }
+    printf("  generate_prach: worst relative L2 %.3g\n", worst);
+}
 } // namespace
 
 int tx_check()
@@ -256,6 +347,10 @@ int tx_check()
     printf("  pdsch: %ld comparisons so far, %ld differ\n", g_n, g_bad);
     check_ofdm();
     printf("  ofdm: %ld comparisons so far, %ld differ\n", g_n, g_bad);
+    check_pusch();
+    printf("  pusch: %ld comparisons so far, %ld differ\n", g_n, g_bad);
+    check_prach();
+    printf("  prach: %ld comparisons so far, %ld differ\n", g_n, g_bad);
     printf("lifecycle_check tx: %ld comparisons %s\n", g_n, g_bad ? "DIFFER" : "equal");
     return g_bad ? 1 : 0;
 }

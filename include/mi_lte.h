@@ -748,6 +748,15 @@ int  mi_lte_bch_channel_encode(mi_lte_tx *tx, uint32_t N_rb_dl, uint32_t N_sc_rb
 int  mi_lte_map_crs(uint32_t N_rb_dl, uint32_t N_sc_rb_dl, uint32_t subfr_num, uint32_t N_id_cell, uint32_t N_ant, float *tx_re, float *tx_im);
 int  mi_lte_map_pss(uint32_t N_rb_dl, uint32_t N_sc_rb_dl, uint32_t N_id_2, uint32_t N_ant, float *tx_re, float *tx_im);
 int  mi_lte_map_sss(uint32_t N_rb_dl, uint32_t N_sc_rb_dl, uint32_t subfr_num, uint32_t N_id_1, uint32_t N_id_2, uint32_t N_ant, float *tx_re, float *tx_im);
+/* the control region (tx_ctrl.cc): liblte_phy_pdcch_channel_encode (liblte_phy.h:988, liblte_phy.cc:4113-4517) -- PCFICH, PHICH and one DCI per
+ * allocation (format 1A for downlink, format 0 for uplink grants) at aggregation level 4 in the common search space.  mi_lte_pcfich / mi_lte_phich
+ * have the layout of LIBLTE_PHY_PCFICH_STRUCT / LIBLTE_PHY_PHICH_STRUCT (liblte_phy.h:972-986); like the reference the call writes the REG
+ * positions into them, the region's size into *N_pdcch_symbs and each downlink allocation's transport block size into allocs[].tbs. */
+typedef struct { float n[4]; uint32_t k[4]; uint32_t cfi; uint32_t N_reg; } mi_lte_pcfich;
+typedef struct { float z_re[3], z_im[3]; uint32_t k[75]; uint32_t N_reg; uint8_t b[25][8]; uint8_t present[25][8]; } mi_lte_phich;
+int mi_lte_pdcch_channel_encode(mi_lte_tx *tx, uint32_t N_rb_dl, uint32_t N_rb_ul, uint32_t N_sc_rb_dl, uint32_t N_group_phich, uint32_t N_sf_phich,
+                                mi_lte_pcfich *pcfich, mi_lte_phich *phich, mi_lte_tx_alloc *allocs, uint32_t N_alloc, uint32_t *N_pdcch_symbs, uint32_t N_id_cell,
+                                uint32_t N_ant, uint32_t phich_dur, uint32_t subfr_num, float *tx_re, float *tx_im);
 /* the uplink pair (tx_ul.cc): liblte_phy_pusch_channel_encode (liblte_phy.h:704, liblte_phy.cc:2664-2799; one port, one layer, one codeword, an N_prb the
  * reference has a transform-precoder plan for) and liblte_phy_generate_prach (liblte_phy.h:845, liblte_phy.cc:3219-3297; T_cp + T_seq samples).  ul /
  * ul_cell are what liblte_phy_ul_init was given (the reference signal of symbols 3 and 10 comes from mi_lte_ul_dmrs_pusch). */

@@ -99,7 +99,7 @@ void rate_match_turbo(const uint8_t *d, uint32_t N_d_bits, uint32_t N_codeblocks
 
 // 36.212 5.1.3.1, constraint length 7, rate 1/3, tail biting: d[3 i + x] (conv_encode with tail_bit, liblte_phy.cc:9997-10059; generators
 // 133 / 171 / 165 octal as every caller passes them)
-static void conv_encode_tb(const uint8_t *c, uint32_t n, uint8_t *d)
+void conv_encode_tb(const uint8_t *c, uint32_t n, uint8_t *d)
 {
     static const uint32_t g[3] = {0133, 0171, 0165};
     uint32_t              reg  = 0; // bit 6 = newest
@@ -111,7 +111,7 @@ static void conv_encode_tb(const uint8_t *c, uint32_t n, uint8_t *d)
 }
 
 // 36.212 5.1.4.2 (rate_match_conv, liblte_phy.cc:11499-11588): d interleaved d[3 i + x]; the column order is 5.1.4-2's = the turbo one turned by 16
-static void rate_match_conv(const uint8_t *d, uint32_t N_d_bits, uint32_t N_e_bits, uint8_t *e)
+void rate_match_conv(const uint8_t *d, uint32_t N_d_bits, uint32_t N_e_bits, uint8_t *e)
 {
     const uint32_t D = N_d_bits / 3, R = (D + 31) / 32, K_pi = 32 * R, N_dummy = K_pi - D;
     std::vector<uint8_t> w(3 * (size_t)K_pi);
@@ -160,7 +160,7 @@ void modulate(const uint8_t *bits, uint32_t N_bits, uint32_t mod, float *re, flo
 // 36.211 6.3.3.1 / 6.3.3.3 (layer_mapper_dl, liblte_phy.cc:7293-7463) for the cases dl_layers_supported() admits: x holds the layers one after
 // another, M_layer_symb each.  On four ports a symbol count that is 2 modulo 4 reads the two symbols behind the block -- whatever the previous
 // call left in d, as in the reference (the specification appends two nulls there).
-static void layer_map_dl(const float *d_re, const float *d_im, uint32_t M_symb, uint32_t N_ant, uint32_t N_codewords, float *x_re, float *x_im, uint32_t *M_layer)
+void layer_map_dl(const float *d_re, const float *d_im, uint32_t M_symb, uint32_t N_ant, uint32_t N_codewords, float *x_re, float *x_im, uint32_t *M_layer)
 {
     const uint32_t v = (N_ant == 1 && N_codewords == 1) ? 1 : N_ant == 2 ? 2 : 4;
     const uint32_t M = v == 4 ? (M_symb % 4 == 0 ? M_symb / 4 : (M_symb + 2) / 4) : M_symb / v;
@@ -171,7 +171,7 @@ static void layer_map_dl(const float *d_re, const float *d_im, uint32_t M_symb, 
 
 // 36.211 6.3.4.1 / 6.3.4.3 (pre_coder_dl, liblte_phy.cc:7526-7636): y[p * y_len + n]; every product is (float)(1 / sqrt 2) or its negative
 // times the layer's value
-static void pre_code_dl(const float *x_re, const float *x_im, uint32_t M, uint32_t N_ant, float *y_re, float *y_im, uint32_t y_len, uint32_t *M_ap)
+void pre_code_dl(const float *x_re, const float *x_im, uint32_t M, uint32_t N_ant, float *y_re, float *y_im, uint32_t y_len, uint32_t *M_ap)
 {
     const float a = 1 / sqrt(2);
     if (N_ant == 1) {
@@ -195,15 +195,24 @@ static void pre_code_dl(const float *x_re, const float *x_im, uint32_t M, uint32
     }
     const bool nulls = M > 0 && x_re[2 * M + M - 1] == (float)TX_NULL && x_im[2 * M + M - 1] == (float)TX_NULL && x_re[3 * M + M - 1] == (float)TX_NULL &&
                        x_im[3 * M + M - 1] == (float)TX_NULL;
-    for (uint32_t i = 0; i < M; i++) {
-        for (uint32_t n = 0; n < 4; n++) // the ports that rest in each place of the group
-            for (uint32_t q = 0; q < 2; q++) {
-                const uint32_t p = n < 2 ? 1 + 2 * q : 2 * q;
-                y_re[(size_t)p * y_len + 4 * i + n] = 0, y_im[(size_t)p * y_len + 4 * i + n] = 0;
+    // four ports: layers (0, 1) as an Alamouti pair on ports (0, 2) in places 0 / 1 of every group of four, layers (2, 3) on ports (1, 3) in places
+    // 2 / 3, the other ports resting.  Stored place by place, port by port, real part first -- the control channels hand this function rows that
+    // overlap (tx_ctrl.cc), where the order of the stores decides what is left
+    for (uint32_t i = 0; i < M; i++)
+        for (uint32_t n = 0; n < 4; n++) {
+            const uint32_t la = n < 2 ? 0 : 2, lb = la + 1, pa = n < 2 ? 0 : 1, pb = pa + 2; // the pair's layers and ports
+            const uint32_t first = (n & 1) ? lb : la, second = (n & 1) ? la : lb;             // place 0: (a, conj-ish b); place 1: (b, a)
+            for (uint32_t p = 0; p < 4; p++) {
+                float re = 0, im = 0;
+                if (p == pa) re = +a * x_re[first * M + i], im = +a * x_im[first * M + i];
+                else if (p == pb) {
+                    if (n & 1) re = +a * x_re[second * M + i], im = -a * x_im[second * M + i];
+                    else re = -a * x_re[second * M + i], im = +a * x_im[second * M + i];
+                }
+                y_re[(size_t)p * y_len + 4 * i + n] = re;
+                y_im[(size_t)p * y_len + 4 * i + n] = im;
             }
-        pair(0, 1, 0, 2, 4, 0, i);
-        pair(2, 3, 1, 3, 4, 2, i);
-    }
+        }
     *M_ap = nulls ? 4 * M - 2 : 4 * M;
 }
 
@@ -271,17 +280,6 @@ static bool dl_layers_supported(uint32_t N_ant, uint32_t N_codewords, uint32_t p
 } // namespace tx
 
 using namespace tx;
-
-// the scratch of LIBLTE_PHY_STRUCT that outlives a call and that a later call can see (see the file comment)
-struct mi_lte_tx {
-    float   pdsch_d_re[10000 + 4], pdsch_d_im[10000 + 4], pdsch_x_re[10000 + 8], pdsch_x_im[10000 + 8];
-    float   pdsch_y_re[4 * 5000], pdsch_y_im[4 * 5000];
-    uint8_t dlsch_e[MI_LTE_TX_MAX_CODE_BLOCKS][18432], dlsch_c[MI_LTE_TX_MAX_CODE_BLOCKS][6176];
-    // PBCH: the 1920 bits of a 40 ms period, coded in the first call of the period, and the cell's scrambling sequence
-    uint32_t bch_N_bits;
-    uint8_t  bch_encode_bits[1920], bch_c[1920];
-    float    bch_d_re[480], bch_d_im[480], bch_x_re[480], bch_x_im[480], bch_y_re[4 * 240], bch_y_im[4 * 240];
-};
 
 extern "C" {
 

@@ -721,6 +721,22 @@ LIBLTE_ERROR_ENUM liblte_phy_map_sss(LIBLTE_PHY_STRUCT *phy_struct, LIBLTE_PHY_S
     return (LIBLTE_ERROR_ENUM)mi_lte_map_sss(phy_struct->N_rb_dl, phy_struct->N_sc_rb_dl, subframe->num, N_id_1, N_id_2, N_ant, &subframe->tx_symb_re[0][0][0],
                                              &subframe->tx_symb_im[0][0][0]);
 }
+// liblte_phy.h:988, liblte_phy.cc:4113-4517
+static_assert(sizeof(LIBLTE_PHY_PCFICH_STRUCT) == sizeof(mi_lte_pcfich) && sizeof(LIBLTE_PHY_PHICH_STRUCT) == sizeof(mi_lte_phich) && sizeof(bool) == 1, "control structs");
+LIBLTE_ERROR_ENUM liblte_phy_pdcch_channel_encode(LIBLTE_PHY_STRUCT *phy_struct, LIBLTE_PHY_PCFICH_STRUCT *pcfich, LIBLTE_PHY_PHICH_STRUCT *phich, LIBLTE_PHY_PDCCH_STRUCT *pdcch,
+                                                  uint32 N_id_cell, uint8 N_ant, float phich_res, LIBLTE_RRC_PHICH_DURATION_ENUM phich_dur, LIBLTE_PHY_SUBFRAME_STRUCT *subframe)
+{
+    (void)phich_res; // (the reference does not read it here either: the group count is the struct's)
+    if (!phy_struct || !pcfich || !phich || !pdcch || !subframe || pdcch->N_alloc > LIBLTE_PHY_PDCCH_MAX_ALLOC) return LIBLTE_ERROR_INVALID_INPUTS;
+    MI_LOCKED_ENTRY(phy_struct, LIBLTE_ERROR_INVALID_INPUTS);
+    mi_lte_tx_alloc al[LIBLTE_PHY_PDCCH_MAX_ALLOC];
+    for (uint32 i = 0; i < pdcch->N_alloc; i++) to_tx_alloc(&pdcch->alloc[i], &al[i]);
+    const int rc = mi_lte_pdcch_channel_encode(t, phy_struct->N_rb_dl, phy_struct->N_rb_ul, phy_struct->N_sc_rb_dl, phy_struct->N_group_phich, phy_struct->N_sf_phich,
+                                               (mi_lte_pcfich *)pcfich, (mi_lte_phich *)phich, al, pdcch->N_alloc, &pdcch->N_symbs, N_id_cell, N_ant, (uint32_t)phich_dur, subframe->num,
+                                               &subframe->tx_symb_re[0][0][0], &subframe->tx_symb_im[0][0][0]);
+    for (uint32 i = 0; i < pdcch->N_alloc; i++) pdcch->alloc[i].tbs = al[i].tbs; // (the DCI's transport block size, as dci_1a_pack leaves it: liblte_phy.cc:13206, :13232)
+    return (LIBLTE_ERROR_ENUM)rc;
+}
 // liblte_phy.h:704, liblte_phy.cc:2664-2799 (the UE side of the reference's loop-back: nothing in LTE_fdd_enodeb calls it)
 LIBLTE_ERROR_ENUM liblte_phy_pusch_channel_encode(LIBLTE_PHY_STRUCT *phy_struct, LIBLTE_PHY_ALLOCATION_STRUCT *alloc, uint32 N_id_cell, uint8 N_ant, LIBLTE_PHY_SUBFRAME_STRUCT *subframe)
 {

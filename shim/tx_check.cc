@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "liblte_phy.h"
+#include "liblte_rrc.h"
 
 LIBLTE_ERROR_ENUM liblte_phy_init_cpu(LIBLTE_PHY_STRUCT **phy_struct, LIBLTE_PHY_FS_ENUM fs, uint16 N_id_cell, uint8 N_ant, uint32 N_rb_dl, uint32 N_sc_rb_dl, float phich_res);
 LIBLTE_ERROR_ENUM liblte_phy_cleanup_cpu(LIBLTE_PHY_STRUCT *phy_struct);
@@ -21,6 +22,8 @@ LIBLTE_ERROR_ENUM liblte_phy_map_crs_cpu(LIBLTE_PHY_STRUCT *phy_struct, LIBLTE_P
 LIBLTE_ERROR_ENUM liblte_phy_map_pss_cpu(LIBLTE_PHY_STRUCT *phy_struct, LIBLTE_PHY_SUBFRAME_STRUCT *subframe, uint32 N_id_2, uint8 N_ant);
 LIBLTE_ERROR_ENUM liblte_phy_map_sss_cpu(LIBLTE_PHY_STRUCT *phy_struct, LIBLTE_PHY_SUBFRAME_STRUCT *subframe, uint32 N_id_1, uint32 N_id_2, uint8 N_ant);
 LIBLTE_ERROR_ENUM liblte_phy_create_dl_subframe_cpu(LIBLTE_PHY_STRUCT *phy_struct, LIBLTE_PHY_SUBFRAME_STRUCT *subframe, uint8 ant, float *i_samps, float *q_samps);
+LIBLTE_ERROR_ENUM liblte_phy_pdcch_channel_encode_cpu(LIBLTE_PHY_STRUCT *phy_struct, LIBLTE_PHY_PCFICH_STRUCT *pcfich, LIBLTE_PHY_PHICH_STRUCT *phich, LIBLTE_PHY_PDCCH_STRUCT *pdcch,
+                                                      uint32 N_id_cell, uint8 N_ant, float phich_res, LIBLTE_RRC_PHICH_DURATION_ENUM phich_dur, LIBLTE_PHY_SUBFRAME_STRUCT *subframe);
 LIBLTE_ERROR_ENUM liblte_phy_ul_init_cpu(LIBLTE_PHY_STRUCT *phy_struct, uint16 N_id_cell, uint32 prach_root_seq_idx, uint32 prach_preamble_format, uint32 prach_zczc,
                                          bool prach_hs_flag, uint8 group_assignment_pusch, bool group_hopping_enabled, bool sequence_hopping_enabled, uint8 cyclic_shift,
                                          uint8 cyclic_shift_dci, uint8 N_cs_an, uint8 delta_pucch_shift);
@@ -246,6 +249,61 @@ void check_ofdm()
     }
     printf("  create_dl_subframe: worst relative L2 against the reference on the float64 transform stand-in %.3g\n", worst);
 }
+void check_pdcch()
+{
+    static LIBLTE_PHY_PDCCH_STRUCT  pd1, pd2;
+    static LIBLTE_PHY_PCFICH_STRUCT pc1, pc2;
+    static LIBLTE_PHY_PHICH_STRUCT  ph1, ph2;
+    const float res[4] = {1.0f / 6, 0.5f, 1.0f, 2.0f};
+    for (int b = 0; b < 6; b++)
+        for (uint32 n_ant = 1; n_ant <= 4; n_ant *= 2)
+            for (int g = 0; g < 4; g++) {
+                if (BW[b].n_rb == 6 && g == 3) continue; // (the reference's own init crashes there: lifecycle_check.cc)
+                LIBLTE_PHY_STRUCT *own = NULL, *ref = NULL;
+                if (liblte_phy_init(&own, BW[b].fs, 7, (uint8)n_ant, BW[b].n_rb, 12, res[g]) != LIBLTE_SUCCESS || liblte_phy_init_cpu(&ref, BW[b].fs, 7, (uint8)n_ant, BW[b].n_rb, 12, res[g]) != LIBLTE_SUCCESS) { g_bad++; return; }
+                // (the control region's scratch from zeros on both sides, see Pair::open)
+                memset(ref->pdcch_y_re, 0, sizeof ref->pdcch_y_re), memset(ref->pdcch_y_im, 0, sizeof ref->pdcch_y_im), memset(ref->pdcch_cce_re, 0, sizeof ref->pdcch_cce_re);
+                memset(ref->pdcch_cce_im, 0, sizeof ref->pdcch_cce_im), memset(ref->pdcch_reg_re, 0, sizeof ref->pdcch_reg_re), memset(ref->pdcch_reg_im, 0, sizeof ref->pdcch_reg_im);
+                memset(ref->pdcch_cce_used, 0, sizeof ref->pdcch_cce_used);
+                uint32 p = 0, l = 0, k = 0;
+                for (uint32 trial = 0; trial < 40; trial++) {
+                    memset(&pd1, 0, sizeof pd1), memset(&pc1, 0, sizeof pc1), memset(&ph1, 0, sizeof ph1);
+                    const uint32 sf = rnd(10), cell = rnd(504);
+                    pc1.cfi = 1 + rnd(3);
+                    // (a region without a single REG left for the PDCCH -- four ports, one symbol, many PHICH groups -- sends the reference's unsigned count round: not called)
+                    auto regs = [&](uint32 cfi) { return (int)((cfi + (BW[b].n_rb <= 10 ? 1 : 0)) * 3 * BW[b].n_rb) - (int)BW[b].n_rb - 4 - 3 * (int)own->N_group_phich - (n_ant == 4 ? (int)BW[b].n_rb : 0); };
+                    while (pc1.cfi < 3 && regs(pc1.cfi) <= 0) pc1.cfi++;
+                    if (regs(pc1.cfi) <= 0) continue;
+                    for (uint32 m = 0; m < own->N_group_phich && m < 25; m++)
+                        for (uint32 q = 0; q < 8; q++) ph1.present[m][q] = rnd(3) == 0, ph1.b[m][q] = (uint8)(rnd() & 1);
+                    pd1.N_alloc = trial % 8 == 7 ? 0 : 1 + rnd(trial % 5 == 4 ? 6 : 3); // (more than four: the common search space runs out, the rest is dropped)
+                    pd1.N_symbs = 77;
+                    for (uint32 a = 0; a < pd1.N_alloc; a++) {
+                        LIBLTE_PHY_ALLOCATION_STRUCT &al = pd1.alloc[a];
+                        static const uint16 special[4] = {0xFFFF, 0xFFFE, 0x0001, 0x003C};
+                        al.chan_type = rnd(4) == 0 ? LIBLTE_PHY_CHAN_TYPE_ULSCH : LIBLTE_PHY_CHAN_TYPE_DLSCH;
+                        al.rnti      = rnd(3) == 0 ? special[rnd(4)] : (uint16)(0x3D + rnd(60000));
+                        al.N_prb     = 1 + rnd(BW[b].n_rb);
+                        al.prb[0][0] = rnd(BW[b].n_rb - al.N_prb + 1);
+                        al.mcs = (uint8)rnd(27), al.ndi = rnd() & 1, al.tpc = (uint8)rnd(4), al.rv_idx = rnd(4), al.tbs = 4242;
+                    }
+                    pd2 = pd1, pc2 = pc1, ph2 = ph1;
+                    fill_grids(sf);
+                    if (getenv("TX_TRACE")) printf("pdcch %u %u %d trial %u: cfi %u allocs %u groups %u\n", BW[b].n_rb, n_ant, g, trial, pc1.cfi, pd1.N_alloc, own->N_group_phich);
+                    const LIBLTE_ERROR_ENUM e1 = liblte_phy_pdcch_channel_encode(own, &pc1, &ph1, &pd1, cell, (uint8)n_ant, res[g], LIBLTE_RRC_PHICH_DURATION_NORMAL, &g_s1);
+                    if (getenv("TX_TRACE")) printf("  own done\n");
+                    const LIBLTE_ERROR_ENUM e2 = liblte_phy_pdcch_channel_encode_cpu(ref, &pc2, &ph2, &pd2, cell, (uint8)n_ant, res[g], LIBLTE_RRC_PHICH_DURATION_NORMAL, &g_s2);
+                    const bool structs = !memcmp(&pc1, &pc2, sizeof pc1) && !memcmp(&ph1, &ph2, sizeof ph1) && !memcmp(&pd1, &pd2, sizeof pd1);
+                    CHECK(e1 == e2 && structs && grids_equal(&p, &l, &k), "pdcch_channel_encode(N_rb_dl %u, %u ports, phich %.3f, trial %u: subframe %u, cell %u, cfi %u, %u allocations): %d vs %d, structs %s (N_symbs %u / %u, tbs %u / %u), port %u symbol %u sub-carrier %u",
+                          BW[b].n_rb, n_ant, res[g], trial, sf, cell, pc1.cfi, pd1.N_alloc, e1, e2, structs ? "equal" : "DIFFER", pd1.N_symbs, pd2.N_symbs, pd1.alloc[0].tbs, pd2.alloc[0].tbs, p, l, k);
+                }
+                CHECK(liblte_phy_pdcch_channel_encode(own, NULL, &ph1, &pd1, 1, 1, 1, LIBLTE_RRC_PHICH_DURATION_NORMAL, &g_s1) == liblte_phy_pdcch_channel_encode_cpu(ref, NULL, &ph2, &pd2, 1, 1, 1, LIBLTE_RRC_PHICH_DURATION_NORMAL, &g_s2) &&
+                          liblte_phy_pdcch_channel_encode(own, &pc1, &ph1, &pd1, 504, 1, 1, LIBLTE_RRC_PHICH_DURATION_NORMAL, &g_s1) == liblte_phy_pdcch_channel_encode_cpu(ref, &pc2, &ph2, &pd2, 504, 1, 1, LIBLTE_RRC_PHICH_DURATION_NORMAL, &g_s2),
+                      "pdcch_channel_encode: argument checks");
+                liblte_phy_cleanup(own), liblte_phy_cleanup_cpu(ref);
+            }
+}
+
 // relative L2 distance of two grids / sample vectors (the transforms on the reference's side run on the FFTW stand-in)
 double rel_l2(const float *a_re, const float *a_im, const float *b_re, const float *b_im, size_t n)
 {
@@ -345,6 +403,8 @@ int tx_check()
     printf("  bch: %ld comparisons so far, %ld differ\n", g_n, g_bad);
     check_pdsch();
     printf("  pdsch: %ld comparisons so far, %ld differ\n", g_n, g_bad);
+    check_pdcch();
+    printf("  pdcch: %ld comparisons so far, %ld differ\n", g_n, g_bad);
     check_ofdm();
     printf("  ofdm: %ld comparisons so far, %ld differ\n", g_n, g_bad);
     check_pusch();

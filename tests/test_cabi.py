@@ -79,16 +79,35 @@ def test_scheduler_helpers_equal_the_references():
 
 def test_transmit_functions_equal_the_references():
     """`lifecycle_check tx`: the transmit functions the own-lifecycle shim defines (tx.cc ...: liblte_phy_rate_match_turbo :11081-11237,
-    _pdsch_channel_encode :3489-3688, _bch_channel_encode :3863-3966, _map_crs / _pss / _sss :5144 / :5265 / :5520, _create_dl_subframe :5862-5903
-    ...) against the reference's own on the same sequences of calls: grids bit for bit (every cell, subframe, port count and bandwidth for the
+    _pdsch_channel_encode :3489-3688, _bch_channel_encode :3863-3966, _pdcch_channel_encode :4113-4517, _map_crs / _pss / _sss :5144 / :5265 / :5520,
+    _create_dl_subframe :5862-5903, _pusch_channel_encode :2664-2799, _generate_prach :3219-3297) against the reference's own on the same sequences of calls: grids bit for bit (every cell, subframe, port count and bandwidth for the
     signals; random allocations incl. filler bits, several code blocks, two codewords, four ports, BPSK for the PDSCH; 40 ms periods entered in the
-    middle for the PBCH), return codes, and the OFDM modulator to float rounding.  CPU only."""
+    middle for the PBCH; PCFICH + PHICH groups + up to six DCIs per control region for every PHICH resource and port count, with what the call
+    writes back into the caller's structs), return codes, and the three transforms (OFDM, SC-FDMA, PRACH) to float rounding.  CPU only."""
     import subprocess
     exe = os.path.join(ROOT, "shim", "_build", "lifecycle_check")
     if not os.path.exists(exe):
         pytest.skip("shim/_build/lifecycle_check not built (needs the reference tree at build time)")
     r = subprocess.run([exe, "tx"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "comparisons equal" in r.stdout, r.stdout[-3000:]
+
+
+@pytest.mark.parametrize("n_rb,cell,frames", [(6, 17, 4), (25, 301, 3), (100, 77, 2)])
+def test_capture_generator_without_the_references_phy_writes_the_same_file(tmp_path, n_rb, cell, frames):
+    """shim/_build/capture_gen_pure: the capture generator (LTE_fdd_dl_file_gen's sequence of transmit calls: map_pss / _sss / _crs, bch / pdcch /
+    pdsch channel encode with SIB1, create_dl_subframe, the TBS search) linked with NO object of the reference's PHY -- the shim's own lifecycle
+    and the library's host-side transmit functions -- must write the file the all-reference build writes, byte for byte.  CPU only."""
+    import subprocess
+    build = os.path.join(ROOT, "shim", "_build")
+    ref, own = os.path.join(build, "capture_gen"), os.path.join(build, "capture_gen_pure")
+    if not (os.path.exists(ref) and os.path.exists(own)):
+        pytest.skip("shim/_build/capture_gen / capture_gen_pure not built (need the reference tree at build time)")
+    a, b = os.path.join(str(tmp_path), "ref.bin"), os.path.join(str(tmp_path), "own.bin")
+    subprocess.run([ref, a, str(n_rb), str(cell), str(frames)], check=True, timeout=600, capture_output=True)
+    subprocess.run([own, b, str(n_rb), str(cell), str(frames)], check=True, timeout=600, capture_output=True)
+    assert os.path.getsize(a) > 100000 and open(a, "rb").read() == open(b, "rb").read()
+    syms = subprocess.run(["nm", "-C", own], capture_output=True, text=True).stdout
+    assert "fftwf_" not in syms and "turbo_constituent_encoder" not in syms and "dci_1a_pack" not in syms  # nothing of liblte_phy.cc or FFTW in the link
 
 
 def test_tbs_table_lookup():

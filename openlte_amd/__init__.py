@@ -5,8 +5,8 @@ this package is only its ctypes binding plus small host-side helpers.  There is 
 importing works anywhere (so the C-ABI can be inspected), but creating a ``Context`` without the
 built library or without a gfx950 GPU raises.
 """
-from .lib import (DlCfg, UlCfg, PrachCfg, CoarseTiming, PdcchDci, dci_unpack, pdcch_re_tables, ul_dmrs_pusch, PdschAlloc, make_alloc, tile_allocs, IQ_I8, IQ_F32_PLANAR, IQ_ALL_ROWS, CE_COMPACT, Context, DeviceBuffer, HostBuffer, DlPipeline, MiLteError, build_library, library_path, load_library,
+from .lib import (Transmitter, TxAlloc, DlCfg, UlCfg, PrachCfg, CoarseTiming, PdcchDci, dci_unpack, pdcch_re_tables, ul_dmrs_pusch, PdschAlloc, make_alloc, tile_allocs, IQ_I8, IQ_F32_PLANAR, IQ_ALL_ROWS, CE_COMPACT, Context, DeviceBuffer, HostBuffer, DlPipeline, MiLteError, build_library, library_path, load_library,
                   SOFT_F32, SOFT_I8, SOFT_I16, TURBO_REF, TURBO_BCJR, TURBO_BCJR_BLOCK, TURBO_BCJR_EARLY)
 
-__all__ = ["DlCfg", "UlCfg", "PrachCfg", "CoarseTiming", "PdcchDci", "dci_unpack", "pdcch_re_tables", "ul_dmrs_pusch", "PdschAlloc", "make_alloc", "tile_allocs", "IQ_I8", "IQ_F32_PLANAR", "IQ_ALL_ROWS", "CE_COMPACT", "Context", "DeviceBuffer", "HostBuffer", "DlPipeline", "MiLteError", "build_library", "library_path", "load_library",
+__all__ = ["Transmitter", "TxAlloc", "DlCfg", "UlCfg", "PrachCfg", "CoarseTiming", "PdcchDci", "dci_unpack", "pdcch_re_tables", "ul_dmrs_pusch", "PdschAlloc", "make_alloc", "tile_allocs", "IQ_I8", "IQ_F32_PLANAR", "IQ_ALL_ROWS", "CE_COMPACT", "Context", "DeviceBuffer", "HostBuffer", "DlPipeline", "MiLteError", "build_library", "library_path", "load_library",
            "SOFT_F32", "SOFT_I8", "SOFT_I16", "TURBO_REF", "TURBO_BCJR", "TURBO_BCJR_BLOCK", "TURBO_BCJR_EARLY"]

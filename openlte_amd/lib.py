@@ -82,6 +82,13 @@ class CoarseTiming(C.Structure):
     _fields_ = [("freq_offset", C.c_float * 5), ("symb_starts", (C.c_uint32 * 7) * 5), ("n_corr_peaks", C.c_uint32)]
 
 
+class TxAlloc(C.Structure):
+    """mi_lte_tx_alloc: LIBLTE_PHY_ALLOCATION_STRUCT as the transmit functions read it"""
+    _fields_ = [("msg", C.POINTER(C.c_uint8) * 2), ("msg_bits", C.c_uint32 * 2)] + \
+               [(n, C.c_uint32) for n in ("pre_coder_type", "mod_type", "chan_type", "tbs", "rv_idx", "N_prb")] + [("prb", (C.c_uint32 * 110) * 2)] + \
+               [(n, C.c_uint32) for n in ("N_codewords", "N_layers", "tx_mode", "rnti", "mcs", "tpc", "ndi", "dl_alloc")]
+
+
 class MiLteError(RuntimeError):
     pass
 
@@ -219,6 +226,15 @@ def load_library():
     L.mi_lte_turbo_scratch_bytes.restype = sz
     L.mi_lte_tbs.argtypes = [u32, u32]
     L.mi_lte_tbs.restype = u32
+    # the transmit side (host code): the handle and the grid functions
+    L.mi_lte_tx_create.argtypes = [C.POINTER(vp)]
+    L.mi_lte_tx_destroy.argtypes = [vp]
+    L.mi_lte_pdsch_channel_encode.argtypes = [vp, u32, u32, C.POINTER(TxAlloc), u32, u32, u32, u32, u32, f32p, f32p]
+    L.mi_lte_bch_channel_encode.argtypes = [vp, u32, u32, u8p, u32, u32, u32, u32, f32p, f32p]
+    L.mi_lte_map_crs.argtypes = [u32, u32, u32, u32, u32, f32p, f32p]
+    L.mi_lte_map_pss.argtypes = [u32, u32, u32, u32, f32p, f32p]
+    L.mi_lte_map_sss.argtypes = [u32, u32, u32, u32, u32, u32, f32p, f32p]
+    L.mi_lte_create_dl_subframe.argtypes = [u32, u32, u32, u32, f32p, f32p, u32, f32p, f32p]
     _LIB = L
     return L
 
@@ -546,6 +562,74 @@ class PdcchPlan:
     def close(self):
         if self.h:
             self.ctx.L.mi_lte_pdcch_plan_destroy(self.ctx.h, self.h)
+            self.h = None
+
+
+class Transmitter:
+    """The host-side transmit functions of one cell (mi_lte_tx): the reference's liblte_phy_map_crs / _pss / _sss, _bch_channel_encode,
+    _pdsch_channel_encode and _create_dl_subframe on a grid of the reference's layout (tx_symb_re / _im: [4][16][1200]).  Host code, no GPU."""
+
+    def __init__(self, fft_size, n_rb_dl, n_id_cell, n_ant=1):
+        self.L = load_library()
+        self.fft, self.n_rb, self.cell, self.n_ant = fft_size, n_rb_dl, n_id_cell, n_ant
+        self.h = C.c_void_p()
+        if self.L.mi_lte_tx_create(C.byref(self.h)) != 0:
+            raise MiLteError("mi_lte_tx_create failed")
+        self.re, self.im = np.zeros((4, 16, 1200), np.float32), np.zeros((4, 16, 1200), np.float32)
+        self._keep = []
+
+    def _g(self):
+        return self.re, self.im
+
+    def _ok(self, rc, what):
+        if rc != 0:
+            raise MiLteError("%s: %d (the reference's LIBLTE_ERROR_INVALID_INPUTS)" % (what, rc))
+
+    def clear(self):
+        self.re[:], self.im[:] = 0, 0
+
+    def signals(self, subfr_num):
+        """CRS in every subframe, PSS / SSS in subframes 0 and 5 (what LTE_fdd_dl_file_gen maps first)."""
+        re, im = self._g()
+        if subfr_num in (0, 5):
+            self._ok(self.L.mi_lte_map_pss(self.n_rb, 12, self.cell % 3, self.n_ant, re, im), "mi_lte_map_pss")
+            self._ok(self.L.mi_lte_map_sss(self.n_rb, 12, subfr_num, self.cell // 3, self.cell % 3, self.n_ant, re, im), "mi_lte_map_sss")
+        self._ok(self.L.mi_lte_map_crs(self.n_rb, 12, subfr_num, self.cell, self.n_ant, re, im), "mi_lte_map_crs")
+
+    def bch(self, mib_bits, sfn):
+        re, im = self._g()
+        b = np.ascontiguousarray(mib_bits, np.uint8)
+        self._ok(self.L.mi_lte_bch_channel_encode(self.h, self.n_rb, 12, b, len(b), self.cell, self.n_ant, sfn, re, im), "mi_lte_bch_channel_encode")
+
+    def pdsch(self, subfr_num, n_pdcch_symbs, allocs):
+        """allocs: (PdschAlloc, transport-block bits) pairs -- the receive side's own allocation struct, so that the same list goes to a PDSCH plan."""
+        arr = (TxAlloc * len(allocs))()
+        self._keep = []
+        for t, (a, bits) in zip(arr, allocs):
+            b = np.ascontiguousarray(bits, np.uint8)
+            self._keep.append(b)
+            t.msg[0], t.msg_bits[0] = b.ctypes.data_as(C.POINTER(C.c_uint8)), len(b)
+            t.pre_coder_type, t.mod_type, t.chan_type, t.tbs, t.rv_idx, t.N_prb = 0, a.mod_type, 0, a.tbs, a.rv_idx, a.N_prb
+            t.N_codewords, t.N_layers, t.tx_mode, t.rnti = 1, 1, a.tx_mode, a.rnti
+            for s in range(2):
+                for i in range(a.N_prb):
+                    t.prb[s][i] = a.prb[s][i]
+        re, im = self._g()
+        self._ok(self.L.mi_lte_pdsch_channel_encode(self.h, self.n_rb, 12, arr, len(allocs), n_pdcch_symbs, self.cell, self.n_ant, subfr_num, re, im), "mi_lte_pdsch_channel_encode")
+
+    def samples(self, ant=0):
+        """OFDM modulation of the grid's 14 symbols: (i, q) float32 of one subframe."""
+        s = self.fft // 128
+        n = 14 * self.fft + 2 * 10 * s + 12 * 9 * s
+        i, q = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        re, im = self._g()
+        self._ok(self.L.mi_lte_create_dl_subframe(self.fft, 12 * self.n_rb, 10 * s, 9 * s, re, im, ant, i, q),
+                 "mi_lte_create_dl_subframe")
+        return i, q
+
+    def close(self):
+        if self.h:
+            self.L.mi_lte_tx_destroy(self.h)
             self.h = None
 
 

@@ -353,6 +353,23 @@ def test_cell_scan_with_no_reference_phy_object_in_the_link(tmp_path, n_rb, cell
     assert "pdcch_permute_pre_calc" not in syms and "turbo_decode" not in syms and "fftwf_" not in syms
 
 
+@pytest.mark.parametrize("n_rb,cell,frames,fs", [(6, 17, 30, "1.92"), (100, 77, 12, "30.72")])
+def test_transmit_and_scan_with_no_reference_phy_object_on_either_side(tmp_path, n_rb, cell, frames, fs):
+    """The whole loop of BASELINE config 1 without liblte_phy.cc: capture_gen_pure (the generator on the library's host-side transmit functions)
+    writes the capture, scan_gpu_pure (the scanner on the GPU receive chains) reads it -- and prints what the all-reference scanner printed for
+    the all-reference generator's file (tests/golden/scan_*_reference_cpu.txt)."""
+    build = os.path.join(ROOT, "shim", "_build")
+    gen, pure = os.path.join(build, "capture_gen_pure"), os.path.join(build, "scan_gpu_pure")
+    if not (os.path.exists(gen) and os.path.exists(pure)):
+        pytest.skip("shim/_build/capture_gen_pure / scan_gpu_pure not built (need the reference tree at build time)")
+    cap = os.path.join(str(tmp_path), "capture.bin")
+    subprocess.run([gen, cap, str(n_rb), str(cell), str(frames)], check=True, timeout=600, capture_output=True)
+    want = open(os.path.join(ROOT, "tests", "golden", "scan_%drb_reference_cpu.txt" % n_rb)).read()
+    got = subprocess.run([pure, cap, fs], capture_output=True, text=True, timeout=900)
+    assert got.returncode == 0, got.stdout + got.stderr
+    assert got.stdout == want
+
+
 @pytest.mark.parametrize("n_rb,cell,frames,fs,cfo,lead", [(6, 17, 30, "1.92", 731, 311), (25, 301, 24, "7.68", -1180, 1000), (100, 77, 12, "30.72", 2350, 4321)])
 def test_batch_scanner_with_carrier_offset_matches_reference_output(tmp_path, n_rb, cell, frames, fs, cfo, lead):
     """The same scan on the library's BATCH entry points (shim/scan_batch.cc: no liblte_phy object linked, one launch per stage for all

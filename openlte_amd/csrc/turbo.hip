@@ -613,7 +613,12 @@ struct SrcRateUnmatchPk : SrcRateUnmatch { static constexpr bool kPacked = true;
 constexpr uint32_t QTAB_N = 4096; // q(x) for |x| <= 2047 (signed index x + max on the integer path); larger maxima divide per element
 constexpr uint32_t QTAB_HALF = 2048;
 constexpr uint32_t MTAB_N = 256;  // w = |a|+|b| <= 254
-constexpr uint32_t PREP_TAB_BYTES = QTAB_N + 2 * MTAB_N;
+// k_turbo_prep's LDS: mtab1 | mtab2 | reduction scratch (64 B) | { staged e [e_cap]  OVER  qtab [QTAB_N] | q(d0) [Kp] }.  The soft bits are dead once
+// every wavefront has summed its own (the first block-wide maximum is the fence), the quantiser table and q(d0) are written after it: they
+// share the bytes.  Before round 6 the four lay side by side -- 9.7 KB for a 64-thread workgroup, 16.7 for a 128-thread one, which held those
+// widths at 4 and 4.5 wavefronts per SIMD where the registers allow 6.
+constexpr uint32_t PREP_RED_AT = 2 * MTAB_N, PREP_E_AT = PREP_RED_AT + 64, PREP_QTAB_AT = PREP_E_AT, PREP_Q0_AT = PREP_QTAB_AT + QTAB_N;
+__host__ __device__ constexpr uint32_t prep_lds_bytes(uint32_t Kp, uint32_t e_cap) { return PREP_E_AT + (e_cap > QTAB_N + Kp ? e_cap : QTAB_N + Kp); }
 
 // byte-parallel helpers for the per-code-block kernels.  Soft values travel as four int8 per register; |a| of one of them is
 // the masked byte SAD of the biased word (x + 128 per byte, i.e. word ^ 0x80808080) against 0x80 in that byte alone
@@ -668,8 +673,8 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Src::kPacke
         src.e_cap = sg.e_cap;
         src.seg(sg);
     }
-    // qtab | mtab1 | mtab2 | staged e [e_cap] | q(d0)[Kp] | reduction scratch (64 B).  No static LDS next to it: the dynamic block then
-    // starts at LDS address 0 and the table / gather reads below are "index register + immediate offset", with no base to add
+    // the layout above.  No static LDS next to it: the dynamic block then starts at LDS address 0 and the table / gather reads below are "index
+    // register + immediate offset", with no base to add
     extern __shared__ __attribute__((aligned(16))) int8_t sm[];
     const uint32_t cb = xcd_cb(bidx, n_cb), tile = cb >> 6, lane = cb & 63, Kp = kpad64(K), n_units = Kp >> 4;
     const size_t   tile_off = seg_off + (size_t)tile * Kp * 64;
@@ -681,10 +686,10 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Src::kPacke
             for (int a = 0; a < 6; a++) *reinterpret_cast<uint4 *>(out.arr[a] + unit_off(tile_off, lane, threadIdx.x)) = make_uint4(0, 0, 0, 0);
         return;
     }
-    int8_t        *qtab = sm, *qc = sm + QTAB_HALF, *mtab1 = sm + QTAB_N, *mtab2 = mtab1 + MTAB_N, *e_lds = sm + PREP_TAB_BYTES;
-    int8_t        *q0_lds = e_lds + src.e_cap;
-    float         *red_f  = reinterpret_cast<float *>(q0_lds + Kp);
-    int           *red_i  = reinterpret_cast<int *>(q0_lds + Kp);
+    int8_t        *qtab = sm + PREP_QTAB_AT, *qc = qtab + QTAB_HALF, *mtab1 = sm, *mtab2 = mtab1 + MTAB_N, *e_lds = sm + PREP_E_AT;
+    int8_t        *q0_lds = sm + PREP_Q0_AT;
+    float         *red_f  = reinterpret_cast<float *>(sm + PREP_RED_AT);
+    int           *red_i  = reinterpret_cast<int *>(sm + PREP_RED_AT);
     src.init(cb, K);
     const uint32_t u  = threadIdx.x;
     const int      nv = (u < n_units) ? min(16, max(0, (int)K - 16 * (int)u)) : -1; // 16, 8 (last unit of a K % 16 == 8 block), 0 (padding), -1
@@ -703,8 +708,8 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Src::kPacke
         for (int x = 0; x < 3; x++)
 #pragma unroll
             for (int j = 0; j < 8; j++) vp[x][j] = 0;
-        if (!e_in_lds && src.window_ok()) src.gather_windowed_pk(u, nv, vp, e_lds, PREP_TAB_BYTES); // (uniform; vp starts at zero)
-        else if (nv > 0) src.load16_pk(u, nv, vp, PREP_TAB_BYTES, e_in_lds);
+        if (!e_in_lds && src.window_ok()) src.gather_windowed_pk(u, nv, vp, e_lds, PREP_E_AT); // (uniform; vp starts at zero)
+        else if (nv > 0) src.load16_pk(u, nv, vp, PREP_E_AT, e_in_lds);
         v2s hi = (v2s)(0), lo = (v2s)(0);
 #pragma unroll
         for (int x = 0; x < 3; x++)
@@ -713,7 +718,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Src::kPacke
         mxi = block_max_i(max(max((int)hi.x, (int)hi.y), -min((int)lo.x, (int)lo.y)), red_i);
         mx  = (float)mxi;
     } else {
-        if (nv > 0) src.load16(u, nv, v, PREP_TAB_BYTES, e_in_lds);
+        if (nv > 0) src.load16(u, nv, v, PREP_E_AT, e_in_lds);
         else {
 #pragma unroll
             for (int x = 0; x < 3; x++)
@@ -775,7 +780,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Src::kPacke
                 if (use_qtab) {
 #pragma unroll
                     for (int j = 0; j < 4; j++) // 0 past the block end -> q(0) = 0
-                        o[j] = pack4u(lds_u8(QTAB_HALF + d[4 * j]), lds_u8(QTAB_HALF + d[4 * j + 1]), lds_u8(QTAB_HALF + d[4 * j + 2]), lds_u8(QTAB_HALF + d[4 * j + 3]));
+                        o[j] = pack4u(lds_u8(PREP_QTAB_AT + QTAB_HALF + d[4 * j]), lds_u8(PREP_QTAB_AT + QTAB_HALF + d[4 * j + 1]), lds_u8(PREP_QTAB_AT + QTAB_HALF + d[4 * j + 2]), lds_u8(PREP_QTAB_AT + QTAB_HALF + d[4 * j + 3]));
                 } else {
                     int q[16];
 #pragma unroll
@@ -794,7 +799,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Src::kPacke
             uint32_t o[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) // 0 past the block end -> q(0) = 0
-                o[j] = pack4u(lds_u8(QTAB_HALF + v[Src::kPacked ? 0 : x][4 * j]), lds_u8(QTAB_HALF + v[Src::kPacked ? 0 : x][4 * j + 1]), lds_u8(QTAB_HALF + v[Src::kPacked ? 0 : x][4 * j + 2]), lds_u8(QTAB_HALF + v[Src::kPacked ? 0 : x][4 * j + 3]));
+                o[j] = pack4u(lds_u8(PREP_QTAB_AT + QTAB_HALF + v[Src::kPacked ? 0 : x][4 * j]), lds_u8(PREP_QTAB_AT + QTAB_HALF + v[Src::kPacked ? 0 : x][4 * j + 1]), lds_u8(PREP_QTAB_AT + QTAB_HALF + v[Src::kPacked ? 0 : x][4 * j + 2]), lds_u8(PREP_QTAB_AT + QTAB_HALF + v[Src::kPacked ? 0 : x][4 * j + 3]));
             Q[x] = make_uint4(o[0], o[1], o[2], o[3]);
         } else {
             int q[16];
@@ -827,7 +832,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Src::kPacke
             load_idx16_at(reinterpret_cast<const_u32x4_t *>(reinterpret_cast<uintptr_t>(pi + 16 * (size_t)u)), nv, idx, K);
         else
             load_idx16(pi, u, nv, idx, K);
-        I0 = gather16_bytes(PREP_TAB_BYTES + src.e_cap, idx);
+        I0 = gather16_bytes(PREP_Q0_AT, idx);
     }
     if (nv >= 0) *reinterpret_cast<uint4 *>(out.arr[3] + unit_off(tile_off, lane, u)) = I0;
     if (identity && src.hard_inputs()) {
@@ -877,8 +882,8 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Src::kPacke
         __syncthreads();
     }
     if (nv >= 0) {
-        *reinterpret_cast<uint4 *>(out.arr[4] + unit_off(tile_off, lane, u)) = closed(w1max) ? closed16(w1, w1max) : lookup16(QTAB_N, w1); // past the end: entry 0 = 0
-        *reinterpret_cast<uint4 *>(out.arr[5] + unit_off(tile_off, lane, u)) = closed(w2max) ? closed16(w2, w2max) : lookup16(QTAB_N + MTAB_N, w2);
+        *reinterpret_cast<uint4 *>(out.arr[4] + unit_off(tile_off, lane, u)) = closed(w1max) ? closed16(w1, w1max) : lookup16(0, w1); // past the end: entry 0 = 0
+        *reinterpret_cast<uint4 *>(out.arr[5] + unit_off(tile_off, lane, u)) = closed(w2max) ? closed16(w2, w2max) : lookup16(MTAB_N, w2);
     }
 }
 
@@ -2006,7 +2011,7 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
     po.arr[0] = arr[AX0]; po.arr[1] = arr[AX1]; po.arr[2] = arr[AX2];
     po.arr[3] = arr[AI0]; po.arr[4] = arr[AM1]; po.arr[5] = arr[AM2];
     const uint32_t cb_threads = (uint32_t)(((Kp >> 4) + 63) & ~(size_t)63); // one thread per 16-step unit: 64..384
-    MI_LAUNCH(ctx, "k_turbo_prep", (k_turbo_prep<Src, 1>), dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), PREP_TAB_BYTES + Kp + e_cap + 64, src, K, n_cb, tb.d_pi, po, MultiArgs{});
+    MI_LAUNCH(ctx, "k_turbo_prep", (k_turbo_prep<Src, 1>), dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), prep_lds_bytes(Kp, e_cap), src, K, n_cb, tb.d_pi, po, MultiArgs{});
 
     SisoArgs s1;
     s1.p[0] = {arr[AX1], arr[AX0], arr[AM1], arr[AA1], dec[0]};
@@ -2085,7 +2090,7 @@ int mi_turbo_ref_group(mi_lte_ctx *ctx, uint32_t K, uint32_t n_cb, const mi_lte_
     src.nnn  = rt.d_nnn;
     // stage e in LDS when the largest allocation of the group fits next to the block's own arrays
     const uint32_t cap = (e_max_bytes + 16u + 63u) & ~63u; // room for the zero slot behind the longest allocation
-    src.e_cap          = (PREP_TAB_BYTES + kpad64(K) + cap + 64 <= 48 * 1024) ? cap : 0;
+    src.e_cap          = (prep_lds_bytes(kpad64(K), cap) <= 48 * 1024) ? cap : 0;
     // every stream has at most 31 NULL slots, so a lap of the circular buffer consumes at least 3K - 81 soft bits: while the longest
     // allocation makes no more than 258 laps no sum of int8 values leaves int16, and the kernel may keep them in pairs
     const uint32_t laps = (e_max_bytes + (3 * K - 81) - 1) / (3 * K - 81);
@@ -2142,7 +2147,7 @@ int mi_turbo_ref_multi(mi_lte_ctx *ctx, const MiKGroup *groups, uint32_t n_group
             // batch's prep; applied to every width it cost the 128- and 192-thread ones 0.05 and 0.11 ms (their blocks beyond a lap and a quarter pay
             // two barriers per lap and their occupancy is bound by registers anyway), gpurun_out/windowed.log
             const uint32_t cap_w = (uint32_t)((15 * (size_t)(gr.K + 4) / 4 + 64 + 63) & ~(size_t)63);
-            sg.e_cap = (PREP_TAB_BYTES + Kp + cap + 64 <= 48 * 1024) ? (Kp <= 1024 ? std::min(cap, cap_w) : cap) : cap_w;
+            sg.e_cap = (prep_lds_bytes(Kp, cap) <= 48 * 1024) ? (Kp <= 1024 ? std::min(cap, cap_w) : cap) : cap_w;
             sg.arr_off = arr;
             typedef __attribute__((address_space(1))) const uint16_t gl16_t;
             typedef __attribute__((address_space(1))) const uint32_t gl32_t;
@@ -2153,7 +2158,7 @@ int mi_turbo_ref_multi(mi_lte_ctx *ctx, const MiKGroup *groups, uint32_t n_group
             // (a size whose last tile is partly filled stays with the table kernel: it zeroes the idle lanes the trellis kernel will walk)
             G.one_size[c] = (G.lds_prep[c] == 0 && gr.n_cb % 64 == 0) ? (int)i : -1; // the width's only size so far, or not the only one
             G.off_one[c] = sg.arr_off; G.e_cap_one[c] = sg.e_cap;
-            G.lds_prep[c] = std::max(G.lds_prep[c], PREP_TAB_BYTES + Kp + sg.e_cap + 64);
+            G.lds_prep[c] = std::max(G.lds_prep[c], prep_lds_bytes(Kp, sg.e_cap));
             G.kp_max[c]   = std::max(G.kp_max[c], Kp);
         }
         G.arr_bytes = arr;

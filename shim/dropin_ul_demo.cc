@@ -8,13 +8,17 @@
 //               then per UE: <mod> <tbs> <rnti> <first_prb> <N_prb>
 //   with PRACH_CAPTURE=<file> PRACH_CFG="root,fmt,zczc,hs,freq_offset" in the environment it also runs liblte_phy_detect_prach
 //   over that capture (one occasion starting at the file's first sample); with PUCCH_DEMO=1 it also decodes four PUCCH format 1/1a/1b
-//   resources it builds itself from the sequences in the struct (liblte_phy_pucch_format_1_1a_1b_channel_decode)
+//   resources it builds itself from the sequences in the struct (liblte_phy_pucch_format_1_1a_1b_channel_decode); with ENB_DL_TX=1 it also builds and
+//   modulates the downlink subframe of the same TTI the way LTE_fdd_enb_phy.cc:557-770 does
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
+#include <cmath>
+
 #include "liblte_phy.h"
+#include "liblte_rrc.h"
 #ifdef MI_LTE_HAVE_UL_SUBFRAME_DECODE
 #include "liblte_phy_ext.h"
 #endif
@@ -171,6 +175,61 @@ int main(int argc, char **argv)
             uint32 nb = 0;
             LIBLTE_ERROR_ENUM e = liblte_phy_pucch_format_1_1a_1b_channel_decode(phy, &ps, tc[t].fmt, cell, 1, n1, b, &nb);
             printf("pucch format %s resource %u: err=%d N_out_bits=%u bits=%u%u\n", liblte_phy_pucch_format_text[tc[t].fmt], n1, (int)e, nb, b[0], nb == 2 ? b[1] : 0);
+        }
+    }
+    if (getenv("ENB_DL_TX")) {
+        // ... and the other half of the eNodeB's TTI (LTE_fdd_enb_phy.cc:557-770): the downlink subframe it transmits while it receives this one --
+        // synchronisation and reference signals, the MIB in subframe 0, a control region with HARQ acknowledgements, a downlink assignment and
+        // an uplink grant sized by the scheduler-side searches, the PDSCH, OFDM modulation.  With the receive calls above that is every
+        // liblte_phy function LTE_fdd_enodeb calls; the lines must not depend on which build runs them.
+        static LIBLTE_PHY_SUBFRAME_STRUCT tx;
+        static LIBLTE_PHY_PDCCH_STRUCT    pd;
+        static LIBLTE_PHY_PCFICH_STRUCT   pcfich;
+        static LIBLTE_PHY_PHICH_STRUCT    phich;
+        memset(&tx, 0, sizeof tx), memset(&pd, 0, sizeof pd), memset(&pcfich, 0, sizeof pcfich), memset(&phich, 0, sizeof phich);
+        uint32 x = 2463534242u + cell;
+        for (uint32 sfn = 0; sfn < 2; sfn++) {
+            tx.num = sf_num;
+            for (uint32 p = 0; p < 1; p++)
+                for (uint32 l = 0; l < 16; l++) memset(tx.tx_symb_re[p][l], 0, sizeof tx.tx_symb_re[p][l]), memset(tx.tx_symb_im[p][l], 0, sizeof tx.tx_symb_im[p][l]);
+            if (sf_num == 0 || sf_num == 5) { liblte_phy_map_pss(phy, &tx, cell % 3, 1); liblte_phy_map_sss(phy, &tx, cell / 3, cell % 3, 1); }
+            liblte_phy_map_crs(phy, &tx, cell, 1);
+            if (sf_num == 0) {
+                uint8 mib[24];
+                for (int i = 0; i < 24; i++) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; mib[i] = x & 1; }
+                liblte_phy_bch_channel_encode(phy, mib, 24, cell, 1, &tx, sfn);
+            }
+            memset(&pd, 0, sizeof pd), memset(&phich, 0, sizeof phich);
+            pcfich.cfi = 2;
+            phich.present[0][1] = true, phich.b[0][1] = 1, phich.present[1 % phy->N_group_phich][4] = true;
+            LIBLTE_PHY_ALLOCATION_STRUCT &dl = pd.alloc[0], &ul = pd.alloc[1];
+            dl.msg[0].N_bits = 300 + 40 * sfn;
+            for (uint32 i = 0; i < dl.msg[0].N_bits; i++) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; dl.msg[0].msg[i] = x & 1; }
+            dl.rnti = 0x0042, dl.chan_type = LIBLTE_PHY_CHAN_TYPE_DLSCH, dl.pre_coder_type = LIBLTE_PHY_PRE_CODER_TYPE_TX_DIVERSITY, dl.mod_type = LIBLTE_PHY_MODULATION_TYPE_QPSK;
+            dl.N_codewords = 1, dl.tx_mode = 1, dl.rv_idx = 0, dl.ndi = sfn & 1, dl.tpc = 1;
+            const LIBLTE_ERROR_ENUM es = liblte_phy_get_tbs_mcs_and_n_prb_for_dl(dl.msg[0].N_bits, sf_num, phy->N_rb_dl, dl.rnti, &dl.tbs, &dl.mcs, &dl.N_prb);
+            for (uint32 i = 0; i < dl.N_prb; i++) dl.prb[0][i] = dl.prb[1][i] = 1 + i;
+            ul.rnti = 0x0042, ul.chan_type = LIBLTE_PHY_CHAN_TYPE_ULSCH, ul.ndi = 1, ul.tpc = 2;
+            const LIBLTE_ERROR_ENUM eu = liblte_phy_get_tbs_mcs_and_n_prb_for_ul(500, phy->N_rb_ul, &ul.tbs, &ul.mcs, &ul.N_prb);
+            ul.prb[0][0] = ul.prb[1][0] = 2;
+            pd.N_alloc = 2;
+            uint32 n_cce = 0, sr_per = 0, sr_off = 0;
+            liblte_phy_get_n_cce(phy, 1.0f, pcfich.cfi, 1, &n_cce);
+            liblte_phy_pucch_map_sr_config_idx(17 + sf_num, &sr_per, &sr_off);
+            const LIBLTE_ERROR_ENUM e1 = liblte_phy_pdcch_channel_encode(phy, &pcfich, &phich, &pd, cell, 1, 1.0f, LIBLTE_RRC_PHICH_DURATION_NORMAL, &tx);
+            const LIBLTE_ERROR_ENUM e2 = liblte_phy_pdsch_channel_encode(phy, &pd, cell, 1, &tx);
+            float *ti = (float *)calloc(n + 64, sizeof(float)), *tq = (float *)calloc(n + 64, sizeof(float));
+            const LIBLTE_ERROR_ENUM e3 = liblte_phy_create_dl_subframe(phy, &tx, 0, ti, tq);
+            uint32 h = 2166136261u; // FNV-1a over the samples as a 12-bit converter would send them
+            double pw = 0;
+            for (uint32 k = 0; k < n; k++) {
+                const int a = (int)lrintf(ti[k] * 16.0f), b = (int)lrintf(tq[k] * 16.0f);
+                h = (h ^ (uint32)(a & 0xFFFF)) * 16777619u, h = (h ^ (uint32)(b & 0xFFFF)) * 16777619u;
+                pw += (double)ti[k] * ti[k] + (double)tq[k] * tq[k];
+            }
+            printf("dl tx frame %u subframe %u: searches %d %d (tbs %u mcs %u N_prb %u | tbs %u mcs %u N_prb %u) n_cce %u sr %u/%u encode %d %d %d N_symbs %u power %.5e samples %08x\n", sfn, sf_num,
+                   (int)es, (int)eu, dl.tbs, (unsigned)dl.mcs, dl.N_prb, ul.tbs, (unsigned)ul.mcs, ul.N_prb, n_cce, sr_per, sr_off, (int)e1, (int)e2, (int)e3, pd.N_symbs, pw, h);
+            free(ti), free(tq);
         }
     }
     liblte_phy_cleanup(phy);

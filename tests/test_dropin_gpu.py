@@ -288,6 +288,31 @@ def test_uplink_one_call_per_subframe_prints_the_per_call_lines(tmp_path, exe_na
     assert all("err=0" in l for l in per_call)
 
 
+@pytest.mark.parametrize("exe_name", ["dropin_ul_gpu", "dropin_ul_gpu_pure"])
+def test_enodeb_tti_receive_and_transmit_prints_the_references_lines(tmp_path, exe_name):
+    """Both halves of an eNodeB's TTI in one caller (LTE_fdd_enb_phy.cc:557-770 and :832-917): the uplink subframe received (get_ul_subframe, a PUSCH
+    decode per UE, the PRACH occasion) and the downlink subframe of the same TTI built and modulated (map_pss / _sss / _crs, the MIB, PCFICH + PHICH +
+    a downlink assignment + an uplink grant sized by the TBS searches, get_n_cce, the SR configuration, PDSCH, create_dl_subframe).  That is every
+    liblte_phy function LTE_fdd_enodeb calls.  The build with the receive chains on the GPU, and the build with NO object of the reference's PHY in
+    its link (transmit side and helpers from libmi_lte.so's host code), print what the all-reference build prints -- incl. the hash of the samples."""
+    build = os.path.join(ROOT, "shim", "_build")
+    exe, cpu = os.path.join(build, exe_name), os.path.join(build, "dropin_ul_cpu")
+    if not (os.path.exists(exe) and os.path.exists(cpu)):
+        pytest.skip("shim/_build/%s / dropin_ul_cpu not built (need the reference tree at build time)" % exe_name)
+    for sf in (0, 4, 5):
+        args, env = _ul_demo_args(tmp_path), _ul_demo_env(tmp_path)
+        args[3] = str(sf)  # (the capture was made for another subframe number: the PUSCH verdicts are whatever the reference's are, and the same)
+        env.pop("PUCCH_DEMO", None)
+        env["ENB_DL_TX"] = "1"
+        want = subprocess.run([cpu] + args, capture_output=True, text=True, timeout=600, env=env)
+        got = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300, env=env)
+        assert got.returncode == 0 and want.returncode == 0, got.stdout + got.stderr
+        w, g = want.stdout.strip().splitlines(), got.stdout.strip().splitlines()
+        assert len([l for l in w if l.startswith("dl tx frame")]) == 2 and "encode 0 0 0" in w[-1]
+        assert g[1:] == w[1:], (g, w)  # (line 0 is the grid energy: a float sum, compared to rounding)
+        assert abs(float(g[0].split("=")[1]) - float(w[0].split("=")[1])) <= 1e-4 * abs(float(w[0].split("=")[1]))
+
+
 def test_pucch_decoder_of_the_build_without_the_reference_phy():
     """`shim/_build/lifecycle_check pucch` (a TEST binary that links the reference's PHY under other names): 360 PUCCH format 1 / 1a / 1b
     resources built from the tables the REFERENCE's liblte_phy_ul_init computed, decoded by the reference on its struct and by the

@@ -395,6 +395,7 @@ void check_prach()
 int tx_check()
 {
     setvbuf(stdout, NULL, _IONBF, 0);
+    if (getenv("TX_SEED")) { g_x ^= 2654435761u * (uint32)atoi(getenv("TX_SEED")); if (!g_x) g_x = 1; printf("  seed %s\n", getenv("TX_SEED")); } // further draws of every random case (soak)
     check_rate_match();
     printf("  rate_match: %ld comparisons so far, %ld differ\n", g_n, g_bad);
     check_signals();

@@ -87,10 +87,15 @@ void rate_match_turbo(const uint8_t *d, uint32_t N_d_bits, uint32_t N_codeblocks
         w[K_pi + 2 * k + 1] = at(2, (bitrev5(col) + 32 * row + 1) % K_pi);         // v(2), shifted by one, on the odd ones
     }
     const uint32_t K_w = 3 * K_pi, K_mimo = (tx_mode == 3 || tx_mode == 4 || tx_mode == 8 || tx_mode == 9) ? 2 : 1;
+    if (D == 0 || M_dl_harq == 0 || N_codeblocks == 0) return; // (the reference divides by these: nothing is written instead)
     const uint32_t N_ir = N_soft / (K_mimo * (M_dl_harq < 8 ? M_dl_harq : 8));
     uint32_t       N_cb = K_w;
     if ((chan_type == MI_LTE_CHAN_DLSCH || chan_type == MI_LTE_CHAN_PCH) && N_ir / N_codeblocks < K_w) N_cb = N_ir / N_codeblocks;
+    if (N_cb == 0) return; // (a soft buffer without room for a single bit: the reference takes a remainder by zero)
     const uint32_t k_0 = R * (2 * (uint32_t)ceilf((float)N_cb / (float)(8 * R)) * rv_idx + 2);
+    bool any = false; // (a window of the circular buffer that holds nothing but <NULL>s would be walked for ever)
+    for (uint32_t j = 0; j < N_cb && !any; j++) any = w[j] != TX_NULL;
+    if (!any) return;
     for (uint32_t k = 0, j = 0; k < N_e_bits; j++) {
         const uint8_t b = w[(k_0 + j) % N_cb];
         if (b != TX_NULL) e[k++] = b;

@@ -110,6 +110,37 @@ def test_capture_generator_without_the_references_phy_writes_the_same_file(tmp_p
     assert "fftwf_" not in syms and "turbo_constituent_encoder" not in syms and "dci_1a_pack" not in syms  # nothing of liblte_phy.cc or FFTW in the link
 
 
+def test_transmit_functions_refuse_what_the_reference_has_no_defined_behaviour_for():
+    """The host-side transmit entry points return 1 (the reference's LIBLTE_ERROR_INVALID_INPUTS) for NULL grids, a cell identity past 503, three
+    antenna ports, a pre-coder type the reference leaves without output, an allocation beyond its 10 000-bit arrays and a PUSCH size it has no
+    transform plan for -- and leave the grid alone.  Through the Python mirror (openlte_amd.Transmitter); CPU only."""
+    import ctypes as C
+    import numpy as np
+    import openlte_amd as m
+    L = m.load_library()
+    t = m.Transmitter(2048, 100, 17)
+    re, im = t.re, t.im
+    assert L.mi_lte_map_crs(100, 12, 0, 504, 1, re, im) == 1 and L.mi_lte_map_crs(100, 12, 0, 17, 5, re, im) == 1
+    assert L.mi_lte_map_crs(100, 12, 0, 17, 1, re, im) == 0 and np.count_nonzero(re[0, 0]) == 200
+    a = m.make_alloc(0, 3, 3240, list(range(12)), 0x100)
+    bits = np.zeros(3240, np.uint8)
+    t.pdsch(1, 2, [(a, bits)])  # W4's allocation: fine
+    before = re.copy()
+    big = m.make_alloc(0, 3, 3240, list(range(13)), 0x100)  # 13 PRB x 138 elements x 6 bits = 10 764 > 10 000
+    with pytest.raises(m.MiLteError):
+        t.pdsch(1, 2, [(big, bits)])
+    assert np.array_equal(before, re)
+    t.n_ant = 3
+    with pytest.raises(m.MiLteError):
+        t.pdsch(1, 2, [(a, bits)])
+    t.n_ant = 1
+    arr = (m.TxAlloc * 1)()
+    arr[0].N_prb, arr[0].mod_type, arr[0].tbs, arr[0].N_codewords, arr[0].pre_coder_type = 2, 1, 120, 1, 1  # spatial multiplexing on two ports
+    assert L.mi_lte_pdsch_channel_encode(t.h, 100, 12, arr, 1, 2, 17, 2, 1, re, im) == 1
+    assert L.mi_lte_pdsch_channel_encode(None, 100, 12, arr, 1, 2, 17, 1, 1, re, im) == 1
+    t.close()
+
+
 def test_tbs_table_lookup():
     """mi_lte_tbs: corner entries of 36.213 table 7.1.7.2.1-1 (values every LTE reference agrees on) and the out-of-range answer."""
     import openlte_amd

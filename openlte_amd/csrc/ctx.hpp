@@ -146,6 +146,8 @@ struct MiMultiGeom { // launch geometry derived from the groups; classes = workg
     uint32_t n_slots = 0, n_wv1 = 0, n_wv23 = 0;
     uint32_t grid_cb[6] = {0}, grid_perm[6] = {0}, lds_prep[6] = {0}, kp_max[6] = {0};
     uint32_t map_cb[6] = {0}, map_perm[6] = {0}, map_wv1 = 0, map_wv23 = 0; // where each launch's map starts (entries)
+    uint32_t ord_wv1 = 0, ord_wv23 = 0, n_ord1 = 0, n_ord23 = 0;             // the trellis kernel's launch order: launched wavefront -> wavefront of the map (entries; 0 = none)
+    uint32_t siso_pad1 = 0, siso_pad23 = 0;                                  // dynamic LDS the trellis kernel is launched with: it holds nothing, it limits the resident workgroups per compute unit
     int      one_size[6] = {-1, -1, -1, -1, -1, -1};   // the index of a width's ONLY size (its prep launch then takes the per-size kernel), -1 otherwise
     uint64_t off_one[6] = {0}; uint32_t e_cap_one[6] = {0};
     uint32_t map_ws1 = 0, map_ws23 = 0, n_ws1 = 0, n_ws23 = 0, gpw1 = 1, gpw23 = 1, kp_all = 0; // the state-parallel trellis kernel's launches (a handful of blocks)

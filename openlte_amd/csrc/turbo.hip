@@ -996,7 +996,8 @@ __device__ __forceinline__ uint32_t negate_bytes(uint32_t w, uint32_t m) // -b i
 // MULTI: a merged launch over the tiles of many block sizes (KSeg): n_tiles_arg is then the launch's wavefront count and K, the tile range and
 // the arrays' offsets come from the wavefront's row of the table (the wavefronts are ordered by falling K: the long walks start first)
 template <bool MULTI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SISO_WPE, 8))) void k_turbo_siso(SisoArgs args, uint32_t K_arg, uint32_t n_tiles_arg, uint32_t mode, MultiArgs ma)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SISO_WPE, 8))) void k_turbo_siso(SisoArgs args, uint32_t K_arg, uint32_t n_tiles_arg, uint32_t mode, MultiArgs ma,
+                                                                                                         const uint32_t *__restrict__ order)
 {
     __shared__ uint32_t tb_lut[2048];
     for (uint32_t i = threadIdx.x; i < 2048; i += blockDim.x) tb_lut[i] = traceback_entry(i >> 3, i & 7u);
@@ -1005,6 +1006,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SISO_WPE, 8
     uint32_t       K = K_arg, n_tiles = n_tiles_arg, wv = blockIdx.x * 4 + (threadIdx.x >> 6), n_wv = mode ? n_tiles : (n_tiles + 1) / 2;
     size_t         seg_off = 0;
     if constexpr (MULTI) {
+        // the launch order is not the map's order (mi_turbo_ref_multi: walks of different lengths dealt out so that every compute unit gets its share)
+        if (order) wv = __builtin_amdgcn_readfirstlane(order[wv]);
         if (wv >= n_tiles_arg) return; // wavefront-uniform
         const_seg_t &sg = multi_seg(ma, wv);
         K = sg.K; n_tiles = sg.n_tiles; seg_off = sg.arr_off;
@@ -2023,7 +2026,7 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
         MI_LAUNCH(ctx, "k_turbo_siso_small", k_turbo_siso_small<false>, dim3((n_cb + gpw_of(n_cb) - 1) / gpw_of(n_cb)), dim3(64), lds_of(gpw_of(n_cb)), s1, K, n_cb, 0u,
                   gpw_of(n_cb), MultiArgs{});
     else
-        MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso<false>, dim3(((n_tiles + 1) / 2 + 3) / 4), dim3(256), 0, s1, K, (uint32_t)n_tiles, 0u, MultiArgs{}); // two tiles per lane
+        MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso<false>, dim3(((n_tiles + 1) / 2 + 3) / 4), dim3(256), 0, s1, K, (uint32_t)n_tiles, 0u, MultiArgs{}, (const uint32_t *)nullptr); // two tiles per lane
 
     PermArgs pa;
     pa.A1 = arr[AA1]; pa.X2 = arr[AX2]; pa.out[0] = arr[AI1]; pa.out[1] = arr[AM3];
@@ -2037,7 +2040,7 @@ static int turbo_ref_run(mi_lte_ctx *ctx, Src src, uint32_t K, uint32_t n_cb, ui
         MI_LAUNCH(ctx, "k_turbo_siso_small", k_turbo_siso_small<false>, dim3((2 * n_cb + gpw_of(2 * n_cb) - 1) / gpw_of(2 * n_cb)), dim3(64), lds_of(gpw_of(2 * n_cb)), s23, K,
                   n_cb, 1u, gpw_of(2 * n_cb), MultiArgs{});
     else
-        MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso<false>, dim3((n_tiles + 3) / 4), dim3(256), 0, s23, K, (uint32_t)n_tiles, 1u, MultiArgs{}); // passes 2 and 3 of a tile per lane
+        MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso<false>, dim3((n_tiles + 3) / 4), dim3(256), 0, s23, K, (uint32_t)n_tiles, 1u, MultiArgs{}, (const uint32_t *)nullptr); // passes 2 and 3 of a tile per lane
 
     VoteArgs va = {arr[AX0], arr[AA1], arr[AB1], arr[AB2]};
     MI_LAUNCH(ctx, "k_turbo_vote", (k_turbo_vote<GROUP, 1>), dim3(8 * xcd_chunk(n_cb)), dim3(cb_threads), 3 * Kp + 64, va, K, n_cb, tb.d_inv2, d_c_bits, gd, MultiArgs{});
@@ -2205,6 +2208,48 @@ int mi_turbo_ref_multi(mi_lte_ctx *ctx, const MiKGroup *groups, uint32_t n_group
             wv += segs[i].n_tiles;
         }
         G.n_wv23 = wv;
+        // The order the trellis kernel's workgroups are LAUNCHED in.  A walk is as long as its block size, the device holds 1024 workgroups of four
+        // walks at a time, and a mixed batch has little more than that (pass 1) or twice that (passes 2 + 3): with the longest walks simply first,
+        // a compute unit's four resident workgroups are neighbours in the sorted order and the unit that got the four longest decides when the
+        // launch ends.  Dealt out in rounds of 256 (one workgroup per compute unit and round), every other round backwards, each unit gets the
+        // r-th longest of one round with the r-th shortest of the next: equal sums (0.07 ms of the mixed batch's 3.6; a scatter that gives up
+        // "longest first" costs 1.3).  Batches of a few sizes (W4) keep the sorted order.  (MI_LTE_SISO_ORDER=0 / 1: A/B.)
+        // And how many of them a compute unit holds at a time.  The registers allow four (16 walks per unit, 4096 in all): right for W4, whose
+        // walks are equally long and come in more than two rounds of that.  A mixed batch of this size has 1.2 rounds (pass 1) and 2.3 (passes
+        // 2 + 3) of walks between 44 and 4612 steps: the units that drew short ones run dry and nothing is left to hand them.  Half as many
+        // resident workgroups are twice as many rounds -- the queue stays non-empty until close to the end -- at the price of fewer wavefronts to
+        // hide latency behind; measured on the mixed batch (gpurun_out/occ*.log): 2 per unit for pass 1 and 3 for passes 2 + 3 take 0.12-0.15 ms
+        // off the trellis kernel's 3.6, one per unit costs 0.15.  The limit is set with dynamic LDS that the kernel never touches.
+        G.n_ord1 = G.n_ord23 = 0;
+        G.siso_pad1 = G.siso_pad23 = 0;
+        const bool many_sizes = n_groups >= 8;
+        if (many_sizes) { G.siso_pad1 = 60000; G.siso_pad23 = 45000; } // (+ the kernel's own 8 KB: two / three of them in a unit's 160 KB)
+        if (getenv("MI_LTE_SISO1_LDS")) G.siso_pad1 = (uint32_t)atoi(getenv("MI_LTE_SISO1_LDS"));
+        if (getenv("MI_LTE_SISO23_LDS")) G.siso_pad23 = (uint32_t)atoi(getenv("MI_LTE_SISO23_LDS"));
+        {
+            const char *eo = getenv("MI_LTE_SISO_ORDER");
+            const int   mode = eo ? atoi(eo) : (many_sizes ? 1 : 0);
+            auto deal = [&](uint32_t n_wv, uint32_t *at, uint32_t *n_out) {
+                const uint32_t n_wg = (n_wv + 3) / 4;
+                if (mode == 0 || n_wg < 512) { *n_out = 0; return; }
+                *at = (uint32_t)map.size();
+                for (uint32_t j = 0; j < n_wg; j++) {
+                    const uint32_t round = j / 256, c = j % 256, in_round = std::min(256u, n_wg - 256 * round);
+                    uint32_t       src = j;
+                    if (mode == 1 && (round & 1u)) src = 256 * round + (in_round - 1 - std::min(c, in_round - 1));
+                    if (mode == 2) { // (a scatter by a stride coprime to the count, for comparison)
+                        uint32_t st = (uint32_t)(0.618 * n_wg) | 1u;
+                        auto gcd = [](uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; };
+                        while (gcd(st, n_wg) != 1) st += 2;
+                        src = (uint32_t)(((uint64_t)j * st) % n_wg);
+                    }
+                    for (uint32_t t = 0; t < 4; t++) map.push_back(4 * src + t < n_wv ? 4 * src + t : 0xFFFFFFFFu);
+                }
+                *n_out = 4 * n_wg;
+            };
+            deal(G.n_wv1, &G.ord_wv1, &G.n_ord1);
+            deal(G.n_wv23, &G.ord_wv23, &G.n_ord23);
+        }
         // ... and of the state-parallel trellis kernel (a handful of code blocks in all): workgroup = wavefront = up to gpw trellises of one size
         auto gpw_of = [](uint32_t n_tr) { return n_tr <= 2048 ? 1u : n_tr <= 4096 ? 2u : n_tr <= 8192 ? 4u : SMALL_G; };
         uint32_t tot = 0, kp_all = 0;
@@ -2293,7 +2338,8 @@ int mi_turbo_ref_multi(mi_lte_ctx *ctx, const MiKGroup *groups, uint32_t n_group
     if (small)
         MI_LAUNCH(ctx, "k_turbo_siso_small", k_turbo_siso_small<true>, dim3(G.n_ws1), dim3(64), lds_small(G.gpw1), s1, 0u, 0u, 0u, G.gpw1, (MultiArgs{d_segs, d_map + G.map_ws1}));
     else
-    MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso<true>, dim3((G.n_wv1 + 3) / 4), dim3(256), 0, s1, 0u, G.n_wv1, 0u, (MultiArgs{d_segs, d_map + G.map_wv1}));
+    MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso<true>, dim3(G.n_ord1 ? G.n_ord1 / 4 : (G.n_wv1 + 3) / 4), dim3(256), G.siso_pad1, s1, 0u, G.n_wv1, 0u, (MultiArgs{d_segs, d_map + G.map_wv1}),
+              G.n_ord1 ? d_map + G.ord_wv1 : (const uint32_t *)nullptr);
     PermArgs pa;
     pa.A1 = arr[AA1]; pa.X2 = arr[AX2]; pa.out[0] = arr[AI1]; pa.out[1] = arr[AM3];
     for (int c = 0; c < NCLS; c++)
@@ -2306,7 +2352,8 @@ int mi_turbo_ref_multi(mi_lte_ctx *ctx, const MiKGroup *groups, uint32_t n_group
     if (small)
         MI_LAUNCH(ctx, "k_turbo_siso_small", k_turbo_siso_small<true>, dim3(G.n_ws23), dim3(64), lds_small(G.gpw23), s23, 0u, 0u, 1u, G.gpw23, (MultiArgs{d_segs, d_map + G.map_ws23}));
     else
-    MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso<true>, dim3((G.n_wv23 + 3) / 4), dim3(256), 0, s23, 0u, G.n_wv23, 1u, (MultiArgs{d_segs, d_map + G.map_wv23}));
+    MI_LAUNCH(ctx, "k_turbo_siso", k_turbo_siso<true>, dim3(G.n_ord23 ? G.n_ord23 / 4 : (G.n_wv23 + 3) / 4), dim3(256), G.siso_pad23, s23, 0u, G.n_wv23, 1u, (MultiArgs{d_segs, d_map + G.map_wv23}),
+              G.n_ord23 ? d_map + G.ord_wv23 : (const uint32_t *)nullptr);
     VoteArgs va = {arr[AX0], arr[AA1], arr[AB1], arr[AB2]};
     for (int c = 0; c < NCLS; c++)
         if (G.grid_cb[c])

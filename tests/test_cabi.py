@@ -141,6 +141,18 @@ def test_transmit_functions_refuse_what_the_reference_has_no_defined_behaviour_f
     t.close()
 
 
+def test_transmit_functions_under_address_and_undefined_behaviour_sanitizers():
+    """tools/asan/run.sh: the host-side transmit sources (tx.cc, tx_ctrl.cc, tx_ul.cc, sched.cc, synth.cc, ul_rs.cc) compiled with g++
+    -fsanitize=address,undefined and driven through every transmit entry point with random inputs, out-of-range ones included (PRB numbers past
+    the grid, transport blocks past five code blocks, MCS past the table, control regions without a REG): no report.  CPU build only."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "asan", "run.sh"), "400"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "asan driver:" in r.stdout and "ERROR" not in r.stderr and "runtime error" not in r.stderr, (r.stdout + r.stderr)[-3000:]
+
+
 def test_tbs_table_lookup():
     """mi_lte_tbs: corner entries of 36.213 table 7.1.7.2.1-1 (values every LTE reference agrees on) and the out-of-range answer."""
     import openlte_amd
